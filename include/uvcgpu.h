@@ -1,0 +1,276 @@
+/* uvcgpu.h -- C ABI of the MI355X-native UVC hot path (libuvcgpu.so).
+ *
+ * The reference (genetronhealth/uvc v0.15.1) has no FFI/plugin layer; the seam this library
+ * replaces is the pair of C++ call groups inside `process_batch` (main.cpp:458-1193):
+ *
+ *   accumulate:  Symbol2CountCoverageSet S(tid, beg, end+1)                 main.cpp:569
+ *                S.updateByRegion3Aln(fq3, hap_bq, hap_fq, hap_f2q, alns3,
+ *                    refstring, region_repeatvec, baq, baq2, prev, cur, params)
+ *                                                   main.cpp:575-591 -> main.hpp:3665-3742
+ *   score:       BcfFormat_symboltype_init   main.cpp:648 -> main.hpp:3889
+ *                BcfFormat_symbol_init       main.cpp:911 -> main.hpp:4094
+ *                BcfFormat_symbol_calc_DPv   main.cpp:931 -> main.hpp:4274
+ *                BcfFormat_symbol_sum_DPv    main.cpp:957 -> main.hpp:4888
+ *                BcfFormat_symbol_calc_qual  main.cpp:967 -> main.hpp:4908
+ *
+ * Everything crosses the boundary as plain pointers + sizes (no C++/torch types).  All entry
+ * points return 0 on success and a negative UVCGPU_E* code on failure; uvcgpu_last_error()
+ * gives the text.  Library code never aborts (the reference abort()s / exit()s instead,
+ * e.g. grouping.cpp:59-87).  A handle is confined to one host thread at a time, which is how
+ * the reference calls process_batch from its OpenMP loop (main.cpp:1478-1520).
+ *
+ * Coordinates are 0-based reference positions, as in the reference (uvc1_refgpos_t).
+ */
+#ifndef UVCGPU_H_INCLUDED
+#define UVCGPU_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- alphabet (a1) ------------ */
+/* AlignmentSymbol, main_conversion.hpp:316-334.  Numeric values are part of the ABI. */
+enum {
+    UVC_BASE_A = 0, UVC_BASE_C = 1, UVC_BASE_G = 2, UVC_BASE_T = 3, UVC_BASE_N = 4, UVC_BASE_NN = 5,
+    UVC_LINK_M = 6, UVC_LINK_D3P = 7, UVC_LINK_D2 = 8, UVC_LINK_D1 = 9,
+    UVC_LINK_I3P = 10, UVC_LINK_I2 = 11, UVC_LINK_I1 = 12, UVC_LINK_NN = 13,
+    UVC_NUM_SYMBOLS = 14
+};
+enum { UVC_BASE_SYMBOL = 0, UVC_LINK_SYMBOL = 1 };       /* SymbolType, main_conversion.hpp:375-379 */
+enum { UVC_PLATFORM_AUTO = 0, UVC_PLATFORM_ILLUMINA = 1, UVC_PLATFORM_IONTORRENT = 2, UVC_PLATFORM_OTHER = 3 };
+
+/* ---------------------------------------------------------------- errors ------------------- */
+enum {
+    UVCGPU_OK = 0,
+    UVCGPU_ENOREADS = -1,      /* region has no reads: process_batch returns -1 (main.cpp:520-523) */
+    UVCGPU_EINVAL = -2,        /* malformed argument (bad offsets, read outside region, ...) */
+    UVCGPU_EUNSUPPORTED = -3,  /* CIGAR op the reference itself throws on (process_cigar, main_conversion.hpp:902-916) or a shape beyond the documented limits */
+    UVCGPU_EDEVICE = -4,       /* HIP runtime failure / no gfx950 device */
+    UVCGPU_ESTATE = -5,        /* call order violated (e.g. score before accumulate) */
+    UVCGPU_ENOMEM = -6
+};
+
+/* ---------------------------------------------------------------- parameters (C15) --------- */
+/* POD mirror of the hot-path fields of `struct CommandLineArgs` (CmdLineArgs.hpp:20-438).
+ * `struct_size` versions the struct (set by uvcgpu_params_default). */
+typedef struct UvcParams {
+    int32_t struct_size;
+    int32_t reserved_;
+#define UVC_PI(name, dflt) int32_t name;
+#define UVC_PD(name, dflt)
+#include "uvc_params.def"
+#undef UVC_PI
+#undef UVC_PD
+    int32_t pad_to_8_;
+#define UVC_PI(name, dflt)
+#define UVC_PD(name, dflt) double name;
+#include "uvc_params.def"
+#undef UVC_PI
+#undef UVC_PD
+} UvcParams;
+
+/* Fills *p with the reference defaults (CmdLineArgs.hpp:43-417). */
+void uvcgpu_params_default(UvcParams *p);
+/* Applies the platform deltas of CommandLineArgs::selfUpdateByPlatform (CmdLineArgs.cpp:113-134)
+ * and sets inferred_sequencing_platform / central_readlen / inferred_maxMQ, which the reference
+ * infers from the first 5000 BAM records (CmdLineArgs.cpp:50-92). */
+void uvcgpu_params_apply_platform(UvcParams *p, int32_t platform, int32_t central_readlen, int32_t max_mapq);
+
+/* ---------------------------------------------------------------- reads (alns3) ------------ */
+/* SoA image of `alns3` = vector<pair<array<vector<vector<bam1_t*>>,2>, MolecularBarcode>>
+ * (main.hpp:3672): family -> strand(2) -> fragment (qname) -> alignment (R1, R2).
+ * Reads must be grouped: all reads of one (fam_id, fam_strand, frag_id) contiguous, fragments
+ * of one (fam_id, fam_strand) contiguous, both strands of one family contiguous.
+ * Per read (htslib bam1_core_t fields, BAM spec):                                              */
+typedef struct UvcReadSoA {
+    int64_t n_reads;
+    const int32_t  *pos;        /* core.pos  (0-based leftmost)                                  */
+    const int32_t  *mpos;       /* core.mpos                                                    */
+    const int32_t  *isize;      /* core.isize, already NORM_INSERT_SIZE'd (common.hpp:73)       */
+    const uint16_t *flag;       /* core.flag                                                    */
+    const uint8_t  *mapq;       /* core.qual                                                    */
+    const int32_t  *nm;         /* NM aux tag, -1 when absent (main.hpp:980-981)                */
+    const int32_t  *l_qseq;     /* core.l_qseq                                                  */
+    const int64_t  *seq_off;    /* offset of the read's first base in bases[] / quals[]         */
+    const int64_t  *cigar_off;  /* offset of the read's first op in cigars[]                    */
+    const int32_t  *n_cigar;    /* core.n_cigar                                                 */
+    const int32_t  *frag_id;    /* fragment (qname group) id, unique within (fam_id, strand)    */
+    const int32_t  *fam_id;     /* family index, 0..n_fams-1                                    */
+    const uint8_t  *fam_strand; /* 0/1 = bam_get_strand(aln) slot of alns3 (grouping.cpp:926)   */
+    int64_t n_bases;
+    const uint8_t  *bases;      /* 1 B/base = seq_nt16_int[bam_seqi()]: 0..3 = ACGT, 4 = other  */
+    const uint8_t  *quals;      /* 1 B/base phred (bam_get_qual), after apply_bq_err_correction3 unless uvcgpu_region_correct_bq() is used */
+    int64_t n_cigar_ops;
+    const uint32_t *cigars;     /* BAM-packed ops: len<<4 | op                                  */
+    int32_t n_fams;
+    const uint8_t  *fam_dflag;  /* MolecularBarcode::duplexflag per family (grouping.cpp:931):
+                                   0x1 UMI found, 0x2 duplex found, 0x4 amplicon, 0x8 borders preserved */
+} UvcReadSoA;
+
+/* ---------------------------------------------------------------- per-position state (a2) -- */
+/* Plane groups readable with uvcgpu_region_fetch().  Every group is a dense array
+ * [n_planes][n_positions] (position fastest), position index = refpos - region begin.
+ * "per symbol" groups are [field][symbol][pos]. */
+enum UvcField {
+    UVC_F_PREP32 = 0,   /* int32 [UVC_NPREP32][npos]          SegFormatPrepSet i32 fields, main_conversion.hpp:541-605 */
+    UVC_F_PREP64 = 1,   /* int64 [UVC_NPREP64][npos]          SegFormatPrepSet i64 fields                             */
+    UVC_F_THRES  = 2,   /* int32 [UVC_NTHRES][npos]           SegFormatThresSet, main_conversion.hpp:614-643          */
+    UVC_F_SEG32  = 3,   /* int32 [UVC_NSEG32][14][npos]       SegFormatInfoSet i32 fields, main_conversion.hpp:645-691 */
+    UVC_F_SEG64  = 4,   /* int64 [UVC_NSEG64][14][npos]       SegFormatInfoSet i64 fields                             */
+    UVC_F_VQ     = 5,   /* int32 [UVC_NVQ][14][npos]          VQFormatTagSet stored slots, main_conversion.hpp:743-763 */
+    UVC_F_BQSUM  = 6,   /* int32 [14][npos]                   bg_seg_bqsum_conslogo, main.hpp:2566                    */
+    UVC_F_FRAG   = 7,   /* int32 [2][UVC_NFRAG][14][npos]     FragFormatDepthSet x strand, main_conversion.hpp:693-699 */
+    UVC_F_FAM    = 8,   /* int32 [2][UVC_NFAM][14][npos]      FamFormatDepthSet x strand, main_conversion.hpp:722-734 */
+    UVC_F_FAMINFO32 = 9,/* int32 [UVC_NFAMINFO32][14][npos]   FamFormatInfoSet i32 fields, main_conversion.hpp:701-720 */
+    UVC_F_FAMINFO64 = 10,/* int64 [UVC_NFAMINFO64][14][npos]  FamFormatInfoSet i64 fields                             */
+    UVC_F_DUPLEX = 11,  /* int32 [UVC_NDUPLEX][14][npos]      DuplexFormatDepthSet, main_conversion.hpp:736-741       */
+    UVC_F_RTR    = 12,  /* int32 [UVC_NRTR][npos+1]           RegionalTandemRepeat AFTER P1b edits indelphred, common.hpp:150-160 */
+    UVC_F_BAQ    = 13,  /* int64 [2][npos]                    baq_offsetarr, baq_offsetarr2, main.cpp:400-429         */
+    UVC_NUM_FIELD_GROUPS = 14
+};
+
+/* plane indices inside the groups (order = declaration order in the reference structs) */
+enum { /* UVC_F_PREP32 */
+    UVC_P_a_dp = 0, UVC_P_a_near_ins_dp, UVC_P_a_near_del_dp, UVC_P_a_near_RTR_ins_dp, UVC_P_a_near_RTR_del_dp,
+    UVC_P_a_pcr_dp, UVC_P_a_umi_dp, UVC_P_a_snv_dp, UVC_P_a_dnv_dp, UVC_P_a_highBQ_dp,
+    UVC_P_a_near_pcr_clip_dp, UVC_P_a_near_long_clip_dp, UVC_P_a_at_ins_dp, UVC_P_a_at_del_dp,
+    UVC_P_a_XM1500, UVC_P_a_GO1500, UVC_P_a_GAPLEN, UVC_P_a_qlen,
+    UVC_P_a_near_ins_inv100len, UVC_P_a_near_del_inv100len,
+    UVC_P_a_LIDP, UVC_P_a_RIDP,
+    UVC_P_a_l_dist_sum, UVC_P_a_r_dist_sum, UVC_P_a_inslen_sum, UVC_P_a_dellen_sum,
+    UVC_NPREP32
+};
+enum { /* UVC_F_PREP64 */
+    UVC_P_a_near_ins_pow2len = 0, UVC_P_a_near_del_pow2len,
+    UVC_P_a_near_ins_l_pow2len, UVC_P_a_near_ins_r_pow2len, UVC_P_a_near_del_l_pow2len, UVC_P_a_near_del_r_pow2len,
+    UVC_P_a_LI, UVC_P_a_RI,
+    UVC_P_a_l_BAQ_sum, UVC_P_a_r_BAQ_sum, UVC_P_a_insBAQ_sum, UVC_P_a_delBAQ_sum,
+    UVC_NPREP64
+};
+enum { /* UVC_F_THRES */
+    UVC_T_aLPxT = 0, UVC_T_aRPxT,
+    UVC_T_aLI1T, UVC_T_aLI2T, UVC_T_aRI1T, UVC_T_aRI2T, UVC_T_aLI1t, UVC_T_aLI2t, UVC_T_aRI1t, UVC_T_aRI2t,
+    UVC_T_aLP1t, UVC_T_aLP2t, UVC_T_aRP1t, UVC_T_aRP2t,
+    UVC_T_aLB1t, UVC_T_aLB2t, UVC_T_aRB1t, UVC_T_aRB2t,
+    UVC_NTHRES
+};
+enum { /* UVC_F_SEG32 */
+    UVC_S_a2XM2 = 0, UVC_S_a2BM2, UVC_S_aPF1, UVC_S_aPF2, UVC_S_aBQ2, UVC_S_aMQs,
+    UVC_S_aP1, UVC_S_aP2, UVC_S_aP3, UVC_S_aNC,
+    UVC_S_aDPff, UVC_S_aDPfr, UVC_S_aDPrf, UVC_S_aDPrr,
+    UVC_S_aLP1, UVC_S_aLP2, UVC_S_aLPL, UVC_S_aRP1, UVC_S_aRP2, UVC_S_aRPL,
+    UVC_S_aLB1, UVC_S_aLB2, UVC_S_aRB1, UVC_S_aRB2,
+    UVC_S_aLI1, UVC_S_aLI2, UVC_S_aRI1, UVC_S_aRI2, UVC_S_aRIf, UVC_S_aLIr,
+    UVC_NSEG32
+};
+enum { UVC_S64_aLBL = 0, UVC_S64_aRBL, UVC_S64_aLIT, UVC_S64_aRIT, UVC_NSEG64 };   /* UVC_F_SEG64 */
+enum { /* UVC_F_VQ: the 14 stored VQFormatTagSet slots */
+    UVC_VQ_a1BQf = 0, UVC_VQ_a1BQr, UVC_VQ_a2BQf, UVC_VQ_a2BQr, UVC_VQ_bMQ,
+    UVC_VQ_bIAQb, UVC_VQ_bIADb, UVC_VQ_bIDQb,
+    UVC_VQ_cIAQf, UVC_VQ_cIADf, UVC_VQ_cIDQf, UVC_VQ_cIAQr, UVC_VQ_cIADr, UVC_VQ_cIDQr,
+    UVC_NVQ
+};
+enum { UVC_FRAG_bDP = 0, UVC_FRAG_bTA, UVC_FRAG_bTB, UVC_NFRAG };                  /* UVC_F_FRAG */
+enum { UVC_FAM_cDP1 = 0, UVC_FAM_cDP12, UVC_FAM_cDP2, UVC_FAM_cDP3, UVC_FAM_cDPM, UVC_FAM_cDPm, UVC_FAM_cDP21, UVC_FAM_cDPD, UVC_NFAM };
+enum { /* UVC_F_FAMINFO32 */
+    UVC_FI_c2LP1 = 0, UVC_FI_c2LP2, UVC_FI_c2LPL, UVC_FI_c2RP1, UVC_FI_c2RP2, UVC_FI_c2RPL, UVC_FI_c2LP0, UVC_FI_c2RP0,
+    UVC_FI_c2LB1, UVC_FI_c2LB2, UVC_FI_c2RB1, UVC_FI_c2RB2, UVC_FI_c2BQ2,
+    UVC_NFAMINFO32
+};
+enum { UVC_FI64_c2LBL = 0, UVC_FI64_c2RBL, UVC_NFAMINFO64 };
+enum { UVC_DUPLEX_dDP1 = 0, UVC_DUPLEX_dDP2, UVC_NDUPLEX };
+enum { UVC_RTR_begpos = 0, UVC_RTR_tracklen, UVC_RTR_unitlen, UVC_RTR_indelphred, UVC_RTR_anyTR_begpos, UVC_RTR_anyTR_tracklen, UVC_RTR_anyTR_unitlen, UVC_NRTR };
+
+/* ---------------------------------------------------------------- scoring (a13-a17) -------- */
+/* One scored allele = one (refpos, symbol[, indel string]) the reference would carry as a
+ * bcfrec::BcfFormat through symbol_init -> calc_DPv -> sum_DPv -> calc_qual.  Integer FORMAT
+ * fields only (bcf_formats_generator1.cpp:135-527); string fields stay host side. */
+enum UvcScoreField {
+    /* identity + depths (bit-exact class) */
+    UVC_O_refpos = 0, UVC_O_symbol, UVC_O_refsymbol,
+    UVC_O_DP, UVC_O_AD, UVC_O_bDP, UVC_O_bAD, UVC_O_c2DP, UVC_O_c2AD, UVC_O_bDPa, UVC_O_cDP0a,
+    /* fill_symbol_VQ_fmts, main.hpp:3820-3887 */
+    UVC_O_a2BQf, UVC_O_a2BQr, UVC_O_aBQ, UVC_O_aBQQ, UVC_O_bMQ,
+    /* calc_DPv, main.hpp:4274-4844 */
+    UVC_O_nPF0, UVC_O_nPF1, UVC_O_bNMa, UVC_O_bNMb, UVC_O_bNMQ,
+    UVC_O_nNFA0, UVC_O_nNFA1, UVC_O_nNFA2, UVC_O_nNFA3, UVC_O_nNFA4, UVC_O_nNFA5,
+    UVC_O_nAFA0, UVC_O_nAFA1, UVC_O_nAFA2, UVC_O_nAFA3, UVC_O_nAFA4, UVC_O_nAFA5, UVC_O_nAFA6, UVC_O_nAFA7, UVC_O_nAFA8,
+    UVC_O_nBCFA0, UVC_O_nBCFA1, UVC_O_nBCFA2, UVC_O_nBCFA3, UVC_O_nBCFA4, UVC_O_nBCFA5, UVC_O_nBCFA6, UVC_O_nBCFA7, UVC_O_nBCFA8, UVC_O_nBCFA9,
+    UVC_O_FTS,          /* bit i set <=> i-th fmt_bias_push (main.hpp:4745-4769) fired; 0 <=> "PASS" */
+    UVC_O_tier2,        /* enable_tier2_consensus_format_tags */
+    UVC_O_cDP1v, UVC_O_cDP1w, UVC_O_cDP1x, UVC_O_cDP2v, UVC_O_cDP2w, UVC_O_cDP2x,
+    /* sum_DPv, main.hpp:4888-4906: [0] = sum over alleles, [1] = the NN allele */
+    UVC_O_CDP1v0, UVC_O_CDP1v1, UVC_O_CDP1w0, UVC_O_CDP1w1, UVC_O_CDP1x0, UVC_O_CDP1x1,
+    UVC_O_CDP2v0, UVC_O_CDP2v1, UVC_O_CDP2w0, UVC_O_CDP2w1, UVC_O_CDP2x0, UVC_O_CDP2x1,
+    /* calc_qual, main.hpp:4908-5343 */
+    UVC_O_cMmQ, UVC_O_aAaMQ, UVC_O_bMQQ, UVC_O_bIAQ, UVC_O_cIAQ,
+    UVC_O_cPCQ1, UVC_O_cPLQ1, UVC_O_cPCQ2, UVC_O_cPLQ2, UVC_O_bTINQ, UVC_O_cTINQ,
+    UVC_O_gVQ1, UVC_O_cVQ1, UVC_O_dVQinc, UVC_O_cVQ2, UVC_O_CONTQ,
+    UVC_NUM_SCORE_FIELDS
+};
+
+/* Host-supplied allele refinement for InDel symbols.  In the reference these come from the
+ * string-keyed maps walked by fill_by_indel_info / indel_get_majority (main.hpp:5350-5455,
+ * instcode.hpp), which stay on the host.  Alleles not listed here are scored with
+ * bDPa = bdepth, cDP0a = cdepth (main.cpp:809-816, 903) and indel_len = |units| of the symbol. */
+typedef struct UvcIndelAllele {
+    int32_t refpos;
+    int32_t symbol;
+    int32_t bDPa;       /* std::get<0>(bcad0a_indelstring_tki), main.cpp:923 */
+    int32_t cDP0a;      /* std::get<1>(...),                    main.cpp:924 */
+    int32_t indel_len;  /* indelstring.size(),                  main.cpp:907 */
+} UvcIndelAllele;
+
+typedef struct UvcScoreRequest {
+    int32_t pos_beg;            /* first zerobased_pos scored (rpos_inclu_beg, main.cpp:527); -1 = whole region core */
+    int32_t pos_end;            /* exclusive */
+    int32_t all_out;            /* paramset.should_output_all (-A), main.cpp:835 */
+    int32_t is_amplicon;        /* ASSAY_TYPE_AMPLICON == inferred_assay_type, main.cpp:510-525 */
+    int64_t n_indel_alleles;
+    const UvcIndelAllele *indel_alleles;
+} UvcScoreRequest;
+
+typedef struct UvcScoreOut {
+    int64_t capacity;           /* in: records the planes can hold */
+    int64_t n_records;          /* out: records produced (may exceed capacity => UVCGPU_ENOMEM, nothing written) */
+    int32_t *fields;            /* [UVC_NUM_SCORE_FIELDS][capacity], record index fastest */
+} UvcScoreOut;
+
+/* ---------------------------------------------------------------- entry points ------------- */
+typedef struct uvcgpu_region uvcgpu_region_t;
+
+/* Once per host thread / process.  Fails with UVCGPU_EDEVICE when there is no gfx950 device:
+ * there is no CPU fallback inside this library. */
+int uvcgpu_init(int device_id);
+const char *uvcgpu_last_error(void);
+const char *uvcgpu_version(void);
+
+/* Replaces `Symbol2CountCoverageSet(tid, ext_beg, ext_end+1)` (main.cpp:569) together with the
+ * region side arrays built just before it (main.cpp:553-563): refstring -> refstring2repeatvec
+ * (main.hpp:803-874) -> the two BAQ prefix-sum arrays (main.cpp:400-429).
+ * refseq = ASCII reference of [beg, end) (the caller's load_refstring result, +-MAX_STR_N_BASES halo). */
+int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params,
+                         int32_t tid, int32_t beg, int32_t end, const char *refseq);
+/* Copies the reads to the device (the caller keeps ownership of its buffers). */
+int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *reads);
+/* Optional: apply_bq_err_correction3 (grouping.cpp:459-543) on the device copy of quals. */
+int uvcgpu_region_correct_bq(uvcgpu_region_t *r);
+/* Replaces updateByRegion3Aln (main.hpp:3665-3742): passes P1..P5b. Asynchronous on the handle's stream. */
+int uvcgpu_region_accumulate(uvcgpu_region_t *r);
+/* Upper bound of records a request can produce (2 symbol types x <= 8 symbols x positions). */
+int64_t uvcgpu_region_score_size(const uvcgpu_region_t *r, const UvcScoreRequest *req);
+/* Replaces the BcfFormat_symbol* call group.  Synchronous: returns after D2H of the records. */
+int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScoreOut *out);
+/* Raw state access (the reference reads members directly, main.cpp:682-688, 759-760, 801-816). */
+int64_t uvcgpu_region_field_bytes(const uvcgpu_region_t *r, int32_t field_group);
+int uvcgpu_region_fetch(uvcgpu_region_t *r, int32_t field_group, void *dst, int64_t dst_bytes);
+int uvcgpu_region_sync(uvcgpu_region_t *r);
+void uvcgpu_region_destroy(uvcgpu_region_t *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UVCGPU_H_INCLUDED */

@@ -1,0 +1,154 @@
+// TEST INFRASTRUCTURE -- NOT PART OF THE PRODUCT (see oracle_common.hpp header).
+// C ABI of the oracle (liboracle.so), shaped exactly like include/uvcgpu.h so that the same test
+// harness drives the oracle and the HIP library.  Symbols are prefixed uvc_oracle_.
+#include "oracle_common.hpp"
+
+using namespace uvco;
+
+namespace uvco { i32 oracle_sscs_phred(const UvcParams &P, int con_symbol, int alt_symbol); }
+
+static thread_local std::string g_err;
+
+extern "C" {
+
+const char *uvc_oracle_last_error(void) { return g_err.c_str(); }
+
+void uvc_oracle_params_default(UvcParams *p) {
+    memset(p, 0, sizeof(*p));
+    p->struct_size = (int32_t)sizeof(UvcParams);
+#define UVC_PI(name, dflt) p->name = (int32_t)(dflt);
+#define UVC_PD(name, dflt) p->name = (double)(dflt);
+#include "uvc_params.def"
+#undef UVC_PI
+#undef UVC_PD
+}
+
+int uvc_oracle_create(void **out, const UvcParams *params, int32_t tid, int32_t beg, int32_t end, const char *refseq) {
+    if (!out || !params || !refseq || end <= beg || params->struct_size != (int32_t)sizeof(UvcParams)) { g_err = "bad argument"; return UVCGPU_EINVAL; }
+    State *S = new State();
+    S->tid = tid; S->beg = beg; S->end = end + 1; S->npos = (i64)end - beg + 1;   // Symbol2CountCoverageSet(tid, beg, end + 1), main.cpp:569
+    S->refstring.assign(refseq, (size_t)(end - beg));
+    S->P = *params;
+    build_side_arrays(*S);
+    *out = S;
+    return 0;
+}
+
+int uvc_oracle_set_reads(void *h, const UvcReadSoA *r) {
+    State &S = *(State *)h;
+    if (!r || r->n_reads < 0) { g_err = "bad reads"; return UVCGPU_EINVAL; }
+    S.bases.assign(r->bases, r->bases + r->n_bases);
+    S.quals.assign(r->quals, r->quals + r->n_bases);
+    S.cigars.assign(r->cigars, r->cigars + r->n_cigar_ops);
+    S.alns.clear(); S.frags.clear(); S.fams.clear();
+    S.fams.resize(r->n_fams);
+    for (auto &f : S.fams) { f.fs[0].frag_beg = f.fs[0].frag_end = f.fs[1].frag_beg = f.fs[1].frag_end = 0; f.dflag = 0; }
+    for (int i = 0; i < r->n_fams; i++) S.fams[i].dflag = r->fam_dflag[i];
+    int prev_fam = -1, prev_strand = -1, prev_frag = -1;
+    std::vector<char> seen((size_t)r->n_fams * 2, 0);
+    for (i64 i = 0; i < r->n_reads; i++) {
+        Aln a;
+        a.pos = r->pos[i]; a.mpos = r->mpos[i]; a.isize = r->isize[i]; a.flag = r->flag[i]; a.mapq = r->mapq[i]; a.nm = r->nm[i];
+        a.l_qseq = r->l_qseq[i]; a.n_cigar = r->n_cigar[i];
+        if (r->seq_off[i] < 0 || r->seq_off[i] + a.l_qseq > r->n_bases || r->cigar_off[i] < 0 || r->cigar_off[i] + a.n_cigar > r->n_cigar_ops) { g_err = "read offsets out of range"; return UVCGPU_EINVAL; }
+        a.bases = S.bases.data() + r->seq_off[i]; a.quals = S.quals.data() + r->seq_off[i]; a.cigar = S.cigars.data() + r->cigar_off[i];
+        a.frag = r->frag_id[i]; a.fam = r->fam_id[i]; a.strand = r->fam_strand[i];
+        i32 e = a.pos; i64 q = 0;   // bam_endpos: pos + sum of reference-consuming op lengths (htslib 1.11 sam.c; SAM spec)
+        for (int k = 0; k < a.n_cigar; k++) { int op = cig_op(a.cigar[k]); i32 len = (i32)cig_len(a.cigar[k]);
+            if (op == C_MATCH || op == C_DEL || op == C_REF_SKIP || op == C_EQUAL || op == C_DIFF) e += len;
+            if (op == C_MATCH || op == C_INS || op == C_SOFT_CLIP || op == C_EQUAL || op == C_DIFF) q += len; }
+        if (e == a.pos) e = a.pos + 1;   // bam_endpos returns pos + 1 for reads without reference-consuming ops
+        a.endpos = e;
+        if (q != a.l_qseq) { g_err = "CIGAR query length != l_qseq"; return UVCGPU_EINVAL; }
+        if (a.fam < 0 || a.fam >= r->n_fams || a.strand > 1) { g_err = "fam_id / fam_strand out of range"; return UVCGPU_EINVAL; }
+        if (a.pos < S.beg || a.endpos > S.end - 1) { g_err = "read outside region"; return UVCGPU_EINVAL; }
+        const bool new_fs = (a.fam != prev_fam || a.strand != prev_strand);
+        if (new_fs) {
+            if (seen[(size_t)a.fam * 2 + a.strand]) { g_err = "reads of one (fam_id, fam_strand) are not contiguous"; return UVCGPU_EINVAL; }
+            seen[(size_t)a.fam * 2 + a.strand] = 1;
+            S.fams[a.fam].fs[a.strand].frag_beg = (int)S.frags.size();
+        }
+        if (new_fs || a.frag != prev_frag) { Frag f; f.aln_beg = (int)S.alns.size(); f.aln_end = f.aln_beg; S.frags.push_back(f); }
+        S.alns.push_back(a);
+        S.frags.back().aln_end = (int)S.alns.size();
+        S.fams[a.fam].fs[a.strand].frag_end = (int)S.frags.size();
+        prev_fam = a.fam; prev_strand = a.strand; prev_frag = a.frag;
+    }
+    S.accumulated = false;
+    return 0;
+}
+
+int uvc_oracle_accumulate(void *h) { State &S = *(State *)h; return accumulate(S, g_err); }
+
+static const void *group_ptr(State &S, int g, i64 &bytes, std::vector<i32> &tmp32, std::vector<i64> &tmp64) {
+    switch (g) {
+        case UVC_F_PREP32: bytes = S.prep32.size() * 4; return S.prep32.data();
+        case UVC_F_PREP64: bytes = S.prep64.size() * 8; return S.prep64.data();
+        case UVC_F_THRES: bytes = S.thres.size() * 4; return S.thres.data();
+        case UVC_F_SEG32: bytes = S.seg32.size() * 4; return S.seg32.data();
+        case UVC_F_SEG64: bytes = S.seg64.size() * 8; return S.seg64.data();
+        case UVC_F_VQ: bytes = S.vq.size() * 4; return S.vq.data();
+        case UVC_F_BQSUM: bytes = S.bqsum.size() * 4; return S.bqsum.data();
+        case UVC_F_FRAG: bytes = S.frag.size() * 4; return S.frag.data();
+        case UVC_F_FAM: bytes = S.fam.size() * 4; return S.fam.data();
+        case UVC_F_FAMINFO32: bytes = S.faminfo32.size() * 4; return S.faminfo32.data();
+        case UVC_F_FAMINFO64: bytes = S.faminfo64.size() * 8; return S.faminfo64.data();
+        case UVC_F_DUPLEX: bytes = S.duplex.size() * 4; return S.duplex.data();
+        case UVC_F_RTR: {
+            tmp32.assign((size_t)UVC_NRTR * S.npos, 0);
+            for (i64 i = 0; i < S.npos; i++) { const Rtr &r = S.rtr[i];
+                const i32 v[UVC_NRTR] = { r.begpos, r.tracklen, r.unitlen, r.indelphred, r.anyTR_begpos, r.anyTR_tracklen, r.anyTR_unitlen };
+                for (int f = 0; f < UVC_NRTR; f++) tmp32[(size_t)f * S.npos + i] = v[f]; }
+            bytes = tmp32.size() * 4; return tmp32.data(); }
+        case UVC_F_BAQ: {
+            tmp64.assign((size_t)2 * S.npos, 0);
+            for (i64 i = 0; i < S.npos; i++) { tmp64[i] = S.baq[i]; tmp64[S.npos + i] = S.baq2[i]; }
+            bytes = tmp64.size() * 8; return tmp64.data(); }
+    }
+    bytes = -1; return NULL;
+}
+
+int64_t uvc_oracle_field_bytes(void *h, int32_t g) {
+    State &S = *(State *)h; i64 b; std::vector<i32> t32; std::vector<i64> t64;
+    if (g != UVC_F_RTR && g != UVC_F_BAQ && !S.accumulated) return -1;
+    group_ptr(S, g, b, t32, t64); return b;
+}
+int uvc_oracle_fetch(void *h, int32_t g, void *dst, int64_t dst_bytes) {
+    State &S = *(State *)h; i64 b; std::vector<i32> t32; std::vector<i64> t64;
+    if (g != UVC_F_RTR && g != UVC_F_BAQ && !S.accumulated) { g_err = "fetch before accumulate"; return UVCGPU_ESTATE; }
+    const void *p = group_ptr(S, g, b, t32, t64);
+    if (!p || b != dst_bytes) { g_err = "bad field group or size"; return UVCGPU_EINVAL; }
+    memcpy(dst, p, (size_t)b); return 0;
+}
+
+int uvc_oracle_score(void *h, const UvcScoreRequest *req, UvcScoreOut *out) {
+    State &S = *(State *)h;
+    std::vector<std::vector<i32>> recs;
+    int rc = score(S, req, recs, g_err);
+    if (rc) return rc;
+    out->n_records = (i64)recs.size();
+    if (out->n_records > out->capacity) { g_err = "score output capacity too small"; return UVCGPU_ENOMEM; }
+    for (i64 i = 0; i < out->n_records; i++) for (int f = 0; f < UVC_NUM_SCORE_FIELDS; f++) out->fields[(size_t)f * out->capacity + i] = recs[i][f];
+    return 0;
+}
+
+void uvc_oracle_destroy(void *h) { delete (State *)h; }
+
+// ---- unit-test hooks for the math primitives (tests/test_oracle_math.py) ----
+double uvc_oracle_calc_binom_10log10_likeratio(double prob, double a, double b, int bidirectional, int set_max_prob_to_one) {
+    return calc_binom_10log10_likeratio(prob, a, b, bidirectional != 0, set_max_prob_to_one != 0);
+}
+double uvc_oracle_prob2odds(double p) { return p / (1.0 - p); }          // main_conversion.hpp:191-196
+double uvc_oracle_odds2prob(double odds) { return odds / (odds + 1.0); } // main_conversion.hpp:198-203
+void uvc_oracle_dp4_to_pcFA(double *out2, int bidir, int overseq_disabled, double overseq_frac, double aADpass, double aADfail, double aDPpass, double aDPfail,
+                            double pl_exponent, double n_nats, double aADavgKeyVal, double aDPavgKeyVal, double priorAD, double priorDP) {
+    dp4_to_pcFA(out2, bidir != 0, overseq_disabled != 0, overseq_frac, aADpass, aADfail, aDPpass, aDPfail, pl_exponent, n_nats, aADavgKeyVal, aDPavgKeyVal, priorAD, priorDP);
+}
+void uvc_oracle_infer_max_qual(int32_t *out3, int32_t max_qual, int32_t dec_qual, const int32_t *distr16, int32_t totDP) {
+    infer_max_qual_assuming_independence(out3[0], out3[1], out3[2], max_qual, dec_qual, distr16, totDP);
+}
+int32_t uvc_oracle_indel_phred(double ampfact, int32_t rs, int32_t rn) { return indel_phred(ampfact, rs, rn); }
+int32_t uvc_oracle_indel_len_rusize_phred(int32_t len, int32_t rs) { return indel_len_rusize_phred(len, rs); }
+int32_t uvc_oracle_sscs_phred(const UvcParams *p, int32_t con, int32_t alt) { return oracle_sscs_phred(*p, con, alt); }
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+"""Host-side mirror of the reference's per-region processing surface (process_batch, main.cpp:458-1193).
+
+    region = Region(lib, params, tid, beg, end, refseq)   # Symbol2CountCoverageSet(tid, beg, end+1), main.cpp:569
+    region.set_reads(reads)                               # the alns3 equivalent (UvcReadSoA)
+    region.accumulate()                                   # updateByRegion3Aln, main.hpp:3665
+    records = region.score(all_out=False)                 # BcfFormat_symbol* call group, main.cpp:648-967
+    planes  = region.fetch("SEG32")                       # raw per-position state
+
+`lib` is a `_ffi.Lib`.  The product path binds uvc_amd/csrc/libuvcgpu.so (hand-written HIP for
+gfx950); there is NO CPU fallback here -- `gpu_lib()` raises when the extension is missing.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+
+
+class UvcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("uvc error %d: %s" % (code, msg))
+        self.code = code
+
+
+_gpu_lib = None
+
+
+def gpu_lib():
+    """Loads libuvcgpu.so and initialises device 0.  Fails loudly when the extension or the GPU is missing."""
+    global _gpu_lib
+    if _gpu_lib is None:
+        import os
+        path = _ffi.gpu_library_path()
+        if not os.path.exists(path):
+            raise ImportError("HIP extension %s is not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+        lib = _ffi.Lib(path, "uvcgpu_")
+        lib.dll.uvcgpu_init.restype, lib.dll.uvcgpu_init.argtypes = C.c_int, [C.c_int]
+        _gpu_lib = lib
+    return _gpu_lib
+
+
+def default_params(lib, platform=1, central_readlen=150, max_mapq=60):
+    """Reference defaults + the platform deltas of CommandLineArgs::selfUpdateByPlatform (CmdLineArgs.cpp:113-134)."""
+    p = _ffi.UvcParams()
+    lib.call("params_default", C.byref(p))
+    apply_platform(p, platform, central_readlen, max_mapq)
+    return p
+
+
+def apply_platform(p, platform, central_readlen, max_mapq):
+    # CmdLineArgs.cpp:13-15, 113-134
+    p.inferred_sequencing_platform = platform
+    if p.central_readlen == 0:
+        p.central_readlen = central_readlen
+    p.inferred_maxMQ = max(p.inferred_maxMQ, max_mapq)
+    if platform == 2:    # IonTorrent
+        p.bq_phred_added_misma += 8
+        for name, dec in (("fam_thres_highBQ_snv", 30), ("fam_thres_highBQ_indel", 30), ("bias_thres_PFBQ1", 30), ("bias_thres_PFBQ2", 30), ("bias_thres_highBQ", 13)):
+            v = getattr(p, name)
+            setattr(p, name, v - min(v, dec))
+    elif platform == 1:  # Illumina
+        p.syserr_minABQ_pcr_snv += 200
+        p.syserr_minABQ_pcr_indel += 100
+        p.syserr_minABQ_cap_snv += 200
+        p.syserr_minABQ_cap_indel += 100
+
+
+_READ_FIELDS = [("pos", np.int32), ("mpos", np.int32), ("isize", np.int32), ("flag", np.uint16), ("mapq", np.uint8), ("nm", np.int32),
+                ("l_qseq", np.int32), ("seq_off", np.int64), ("cigar_off", np.int64), ("n_cigar", np.int32),
+                ("frag_id", np.int32), ("fam_id", np.int32), ("fam_strand", np.uint8)]
+
+
+def pack_reads(reads):
+    """dict of numpy arrays -> (UvcReadSoA, keepalive list)."""
+    keep = []
+    soa = _ffi.UvcReadSoA()
+    soa.n_reads = int(reads["n_reads"])
+    for name, dt in _READ_FIELDS:
+        a = np.ascontiguousarray(reads[name], dtype=dt)
+        assert a.shape == (soa.n_reads,), name
+        keep.append(a)
+        setattr(soa, name, a.ctypes.data)
+    for name, dt, cnt in (("bases", np.uint8, "n_bases"), ("quals", np.uint8, "n_bases"), ("cigars", np.uint32, "n_cigar_ops")):
+        a = np.ascontiguousarray(reads[name], dtype=dt)
+        keep.append(a)
+        setattr(soa, name, a.ctypes.data)
+        setattr(soa, cnt, a.size)
+    d = np.ascontiguousarray(reads["fam_dflag"], dtype=np.uint8)
+    keep.append(d)
+    soa.n_fams = int(reads["n_fams"])
+    soa.fam_dflag = d.ctypes.data
+    return soa, keep
+
+
+class Region:
+    def __init__(self, lib, params, tid, beg, end, refseq):
+        self.lib, self.tid, self.beg, self.end = lib, tid, beg, end
+        self.npos = end - beg + 1
+        self.h = C.c_void_p()
+        self._params = params
+        ref = refseq.encode() if isinstance(refseq, str) else bytes(refseq)
+        if len(ref) != end - beg:
+            raise ValueError("refseq must cover [beg, end)")
+        self._check(lib.call("create", C.byref(self.h), C.byref(params), tid, beg, end, ref))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise UvcError(rc, self.lib.last_error())
+
+    def set_reads(self, reads):
+        soa, keep = pack_reads(reads)
+        self._check(self.lib.call("set_reads", self.h, C.byref(soa)))
+
+    def accumulate(self):
+        self._check(self.lib.call("accumulate", self.h))
+
+    def fetch(self, group):
+        gid, dt, shape = _ffi.FIELD_GROUPS[group]
+        nbytes = self.lib.call("field_bytes", self.h, gid)
+        if nbytes < 0:
+            raise UvcError(-5, "field group %s not available" % group)
+        out = np.empty(shape + (self.npos,), dtype=dt)
+        assert out.nbytes == nbytes, (group, out.nbytes, nbytes)
+        self._check(self.lib.call("fetch", self.h, gid, out.ctypes.data, out.nbytes))
+        return out
+
+    def score(self, all_out=False, pos_beg=-1, pos_end=-1, is_amplicon=False, indel_alleles=None, capacity=None):
+        req = _ffi.UvcScoreRequest()
+        req.pos_beg, req.pos_end, req.all_out, req.is_amplicon = pos_beg, pos_end, int(all_out), int(is_amplicon)
+        arr = None
+        if indel_alleles:
+            arr = (_ffi.UvcIndelAllele * len(indel_alleles))(*[_ffi.UvcIndelAllele(*a) for a in indel_alleles])
+            req.n_indel_alleles, req.indel_alleles = len(indel_alleles), C.cast(arr, C.c_void_p)
+        if capacity is None:
+            npos = (pos_end - pos_beg) if pos_beg >= 0 else self.npos
+            capacity = 14 * (npos + 1) if all_out else max(4096, 4 * (npos + 1))
+        while True:
+            buf = np.zeros((_ffi.NUM_SCORE_FIELDS, capacity), dtype=np.int32)
+            out = _ffi.UvcScoreOut(capacity, 0, buf.ctypes.data)
+            rc = self.lib.call("score", self.h, C.byref(req), C.byref(out))
+            if rc == -6 and out.n_records > capacity:
+                capacity = int(out.n_records)
+                continue
+            self._check(rc)
+            return {name: buf[i, :out.n_records].copy() for i, name in enumerate(_ffi.SCORE_FIELDS)}
+
+    def close(self):
+        if self.h:
+            self.lib.call("destroy", self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
