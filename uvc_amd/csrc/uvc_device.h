@@ -1,0 +1,179 @@
+// uvc_device.h -- device-side data layout of the MI355X UVC hot path (gfx950 only).
+//
+// HBM layout: every per-position quantity is a plane [field][symbol][pos]
+// with the position fastest, so that a wavefront whose 64 lanes own 64 consecutive positions
+// reads and writes 256 contiguous bytes per plane.  Reads are kept as 1 B/base + 1 B/qual SoA;
+// a lane that owns position p reads byte (qbase + p) of every alignment that covers p, so the
+// 64 lanes of a wave read 64 consecutive bytes of the same read (coalesced), and everything else
+// about the read is wave-uniform and comes through scalar loads.
+#ifndef UVC_DEVICE_H
+#define UVC_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "uvcgpu.h"
+
+#define NSYM UVC_NUM_SYMBOLS
+#define NBUCKETS 16          // NUM_BUCKETS, main_conversion.hpp:920
+#define SQR_QUAL_DIV 32      // main_conversion.hpp:20
+#define MAX_INSERT_SIZE 2000 // common.hpp:64
+#define MAX_STR_N_BASES 100  // common.hpp:63
+
+enum { C_MATCH = 0, C_INS = 1, C_DEL = 2, C_REF_SKIP = 3, C_SOFT_CLIP = 4, C_HARD_CLIP = 5, C_PAD = 6, C_EQUAL = 7, C_DIFF = 8 };
+
+// One alignment.  "simple" = [one clip op] one M/=/X op [one clip op]; everything else is "complex"
+// and goes through the sequential per-read kernels + the contribution table.
+struct AlnRec {
+    int32_t pos, rend, mpos, isize;
+    int32_t flag, mapq, dflag, l_qseq;
+    int64_t seq_off;            // first query base in bases[] / quals[]
+    int64_t qbase;              // simple: seq_off + lclip_q - pos, so that query byte of ref position p is qbase + p
+    int64_t cigar_off;
+    int64_t table_off;          // complex: first row of the contribution table (row = p - pos), else -1
+    int32_t n_cigar, kind;      // kind: 0 simple, 1 complex
+    int32_t xm1500, go1500;
+    int32_t bm1500[5];          // per base symbol (main.hpp:1860-1863); LINK/NN symbols are always 0
+    int32_t clip_cnt;
+    int32_t nogap_penal, indel_penal;   // micro_nogap_penal / micro_indel_penal, main.hpp:1882-1885
+    int32_t lclip_len, rclip_len;       // soft-clip lengths at either end (0 if none), main.hpp:1880-1881
+    int32_t lclip_oplen, rclip_oplen;   // S or H clip op adjacent to the M op (0 if none)
+    int32_t lclip_q;                    // query offset of the first aligned base
+    int32_t m_index;                    // cigar index of the M op (simple)
+    int32_t frag, fs;                   // owning fragment / family-strand unit
+    int32_t pad_;
+};
+
+struct FragRec {
+    int32_t aln_beg, aln_end;   // alignments are stored fragment-major
+    int32_t beg, end;           // span with the reference's cumulative "+1 per alignment" (fillTidBegEndFromAlns1, main.hpp:658-673), clamped to the region
+    int32_t fs, strand, dflag, normMQ;
+    int32_t n_cov, n_near;      // b10xSeqTlen / b10xSeqTNevents, main.hpp:2747-2756 (filled by k_fragstat)
+    int32_t singleton;          // 1: the only fragment of its family-strand unit and the fast P4/P5 identities apply
+    int32_t pad_;
+};
+
+struct FsRec {                  // family x strand unit (alns2 of main.hpp:2869)
+    int32_t frag_beg, frag_end;
+    int32_t beg, end;           // fillTidBegEndFromAlns2 span, clamped
+    int32_t strand, dflag, fam, generic;   // generic: handled by the per-(unit, position) family kernels
+    int64_t work_off;           // prefix offset of this unit's positions in the generic work list
+    int32_t l2r_end_median, r2l_end_median, nsb_min, nsb_max;   // main.hpp:2939-2940, 2959-2998
+    int32_t other_fs;           // the opposite-strand unit of the same family, or -1
+    int32_t pad_;
+};
+
+// contribution of one alignment at one reference position under BASE_QUALITY_MAX (main.hpp:1980, 1924, 2077, 2192, 2223)
+struct Contrib { uint8_t bsym, bval, l1sym, l1val, l2sym, l2val, l3sym, l3val; };   // sym == 0xFF: empty slot
+
+struct DevParams { UvcParams P; };
+
+struct RegionDev {
+    int32_t beg, end; int64_t npos;
+    const uint8_t *refsym;          // [npos + 1]
+    int32_t *rtr;                   // [UVC_NRTR][npos]
+    const int64_t *baq;             // [2][npos]
+    int32_t *prep32; int64_t *prep64; int32_t *thres;
+    int32_t *seg32; int64_t *seg64; int32_t *vq; int32_t *bqsum;
+    int32_t *frag; int32_t *fam; int32_t *faminfo32; int64_t *faminfo64; int32_t *duplex;
+    int32_t *bucket;                // [2][NSYM][NBUCKETS][npos] dedup_ampDistr, main.hpp:2377
+    const uint8_t *bases; const uint8_t *quals; const uint32_t *cigars;
+    AlnRec *alns; int32_t n_alns;
+    AlnRec *fast; int32_t n_fast;   // simple alignments, sorted by pos
+    const int32_t *complex_ids; int32_t n_complex;
+    FragRec *frags; int32_t n_frags;
+    const int32_t *frag_sorted;     // fragment ids sorted by FragRec::beg
+    FsRec *fss; int32_t n_fs;
+    const int32_t *generic_fs; int32_t n_generic_fs; int64_t n_generic_work;
+    Contrib *table;
+    int32_t max_aln_span, max_frag_span;
+    int32_t *err;                   // device error flag (unsupported CIGAR shapes etc.)
+};
+
+#define DEV __device__ __forceinline__
+
+DEV int imin(int a, int b) { return a < b ? a : b; }
+DEV int imax(int a, int b) { return a > b ? a : b; }
+DEV int64_t lmin(int64_t a, int64_t b) { return a < b ? a : b; }
+DEV int64_t lmax(int64_t a, int64_t b) { return a > b ? a : b; }
+DEV int64_t nnminus(int64_t a, int64_t b) { return a > b ? a - b : 0; }     // non_neg_minus, common.hpp:195-200
+DEV int ibetween(int v, int a, int b) { return imin(imax(a, v), b); }       // BETWEEN, main_conversion.hpp:124-128
+DEV bool is_ins(int s) { return s == UVC_LINK_I3P || s == UVC_LINK_I2 || s == UVC_LINK_I1; }
+DEV bool is_del(int s) { return s == UVC_LINK_D3P || s == UVC_LINK_D2 || s == UVC_LINK_D1; }
+DEV bool is_subst(int s) { return s <= UVC_BASE_NN; }
+DEV bool symbols_mutated(int ref, int alt) {      // areSymbolsMutated, main_conversion.hpp:364-371
+    if (alt <= UVC_BASE_NN) return ref != alt && ref < UVC_BASE_N && alt < UVC_BASE_N;
+    return alt != UVC_LINK_M && alt != UVC_LINK_NN;
+}
+DEV int cig_op(uint32_t c) { return (int)(c & 0xF); }
+DEV int cig_len(uint32_t c) { return (int)(c >> 4); }
+
+// plane addressing
+#define P32(R, f, x) ((R).prep32[(size_t)(f) * (R).npos + (x)])
+#define P64(R, f, x) ((R).prep64[(size_t)(f) * (R).npos + (x)])
+#define TH(R, f, x) ((R).thres[(size_t)(f) * (R).npos + (x)])
+#define S32(R, f, s, x) ((R).seg32[((size_t)(f) * NSYM + (s)) * (R).npos + (x)])
+#define S64(R, f, s, x) ((R).seg64[((size_t)(f) * NSYM + (s)) * (R).npos + (x)])
+#define VQP(R, f, s, x) ((R).vq[((size_t)(f) * NSYM + (s)) * (R).npos + (x)])
+#define BQS(R, s, x) ((R).bqsum[(size_t)(s) * (R).npos + (x)])
+#define FRP(R, st, f, s, x) ((R).frag[(((size_t)(st) * UVC_NFRAG + (f)) * NSYM + (s)) * (R).npos + (x)])
+#define FAP(R, st, f, s, x) ((R).fam[(((size_t)(st) * UVC_NFAM + (f)) * NSYM + (s)) * (R).npos + (x)])
+#define FIP(R, f, s, x) ((R).faminfo32[((size_t)(f) * NSYM + (s)) * (R).npos + (x)])
+#define FI64P(R, f, s, x) ((R).faminfo64[((size_t)(f) * NSYM + (s)) * (R).npos + (x)])
+#define DUP(R, f, s, x) ((R).duplex[((size_t)(f) * NSYM + (s)) * (R).npos + (x)])
+#define BKP(R, st, s, b, x) ((R).bucket[((((size_t)(st) * NSYM + (s)) * NBUCKETS) + (b)) * (R).npos + (x)])
+#define RTRP(R, f, x) ((R).rtr[(size_t)(f) * (R).npos + (x)])
+#define BAQ1(R, p) ((R).baq[(p) - (R).beg])
+#define BAQ2(R, p) ((R).baq[(R).npos + (p) - (R).beg])
+
+DEV void add64(int64_t *p, int64_t v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
+
+// GenericSymbol2Count::_fillConsensusCounts<TIsRefCountedOnlyOnce>, main.hpp:374-402
+DEV void fill_consensus(const int *c, int &argmax, int &cmax, int &csum, int st, bool ref_once_in_link, bool ignore_padded_del) {
+    const int b = (st == UVC_BASE_SYMBOL ? UVC_BASE_A : UVC_LINK_M);
+    const int e = (st == UVC_BASE_SYMBOL ? (ignore_padded_del ? UVC_BASE_T : UVC_BASE_NN) : UVC_LINK_NN);
+    const bool once = (st == UVC_LINK_SYMBOL && ref_once_in_link);
+    argmax = e; cmax = 0; csum = 0;
+    for (int s = b; s <= e; s++) {
+        const int v = c[s];
+        if (once) {
+            if (cmax < v || (UVC_LINK_M == argmax && (0 < v))) { argmax = s; cmax = v; csum = cmax; }
+        } else {
+            if (cmax < v) { argmax = s; cmax = v; }
+            csum += v;
+        }
+    }
+}
+
+// PhredMutationTable::toPhredErrRate, main.hpp:213-262
+DEV int sscs_phred(const UvcParams &P, int con_symbol, int alt_symbol) {
+    int raw;
+    if (is_ins(con_symbol) || is_del(con_symbol)) raw = P.fam_phred_sscs_indel_open;
+    else if (con_symbol == UVC_LINK_M) {
+        if (UVC_LINK_D1 == alt_symbol || UVC_LINK_I1 == alt_symbol) raw = P.fam_phred_sscs_indel_open;
+        else if (UVC_LINK_D2 == alt_symbol || UVC_LINK_I2 == alt_symbol) raw = P.fam_phred_sscs_indel_open + P.fam_phred_sscs_indel_ext;
+        else raw = P.fam_phred_sscs_indel_open + P.fam_phred_sscs_indel_ext * 2;
+    } else if ((con_symbol == UVC_BASE_C && alt_symbol == UVC_BASE_T) || (con_symbol == UVC_BASE_G && alt_symbol == UVC_BASE_A)) raw = P.fam_phred_sscs_transition_CG_TA;
+    else if ((con_symbol == UVC_BASE_A && alt_symbol == UVC_BASE_G) || (con_symbol == UVC_BASE_T && alt_symbol == UVC_BASE_C)) raw = P.fam_phred_sscs_transition_AT_GC;
+    else if ((con_symbol == UVC_BASE_C && alt_symbol == UVC_BASE_A) || (con_symbol == UVC_BASE_G && alt_symbol == UVC_BASE_T)) raw = P.fam_phred_sscs_transversion_CG_AT;
+    else raw = P.fam_phred_sscs_transversion_other;
+    return raw + (P.tumor_vcf_fname_nonempty ? 3 : 0);
+}
+
+// infer_max_qual_assuming_independence, main_conversion.hpp:943-974.  fp64 log, result truncated to int.
+template <class GetBucket>
+DEV void infer_max_qual(int &maxvqual, int &argmaxAD, int &argmaxBQ, int max_qual, int dec_qual, int totDP, GetBucket get) {
+    int currAD = 0;
+    maxvqual = 0; argmaxAD = 0; argmaxBQ = 0;
+    const int n = imin(NBUCKETS, max_qual / dec_qual);
+    for (int idx = 0; idx < n; idx++) {
+        const int currQD = get(idx);
+        if (0 == currQD) continue;
+        currAD += currQD;
+        const int currBQ = max_qual - (dec_qual * idx);
+        const double expBQ = 10.0 / log(10.0) * log(((double)totDP / (double)currAD) + 2.220446049250313e-16);
+        const int currvqual = (int)(currAD * (currBQ - expBQ));
+        if (currvqual > maxvqual) { argmaxAD = currAD; argmaxBQ = currBQ; maxvqual = currvqual; }
+    }
+}
+
+#endif

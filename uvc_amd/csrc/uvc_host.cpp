@@ -1,0 +1,439 @@
+// uvc_host.cpp -- C ABI of libuvcgpu.so (include/uvcgpu.h): region handles, host-side packing of the
+// alns3-equivalent SoA into device records, kernel sequencing on the handle's HIP stream.
+// There is no CPU compute fallback in this library: every entry point that computes launches HIP kernels.
+#include "uvc_device.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+struct RawReads {
+    const int32_t *pos, *endpos, *mpos, *isize, *flag, *mapq, *nm, *l_qseq, *n_cigar, *frag, *fs, *dflag, *kind, *fast_rank;
+    const int64_t *seq_off, *cigar_off, *table_off;
+};
+extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const UvcParams *P, hipStream_t s);
+extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, int half_ratio_phred,
+                                      const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s);
+extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles,
+                                int32_t *d_fields, int64_t capacity, int64_t *d_count, hipStream_t s);
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(UVCGPU_EDEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct uvcgpu_region {
+    UvcParams P;
+    int32_t tid, beg, end;     // state covers [beg, end): end = caller's end + 1 (main.cpp:569)
+    int64_t npos;
+    std::string refstring;
+    hipStream_t stream = nullptr;
+    // device buffers
+    uint8_t *d_refsym = nullptr; int32_t *d_rtr = nullptr, *d_rtr0 = nullptr; int64_t *d_baq = nullptr;
+    char *d_state = nullptr; size_t state_bytes = 0;
+    std::vector<void *> owned;   // read-dependent device allocations
+    RegionDev R;
+    int32_t *d_dup_units = nullptr; int64_t *d_dup_off = nullptr; int n_dup = 0; int64_t n_dup_work = 0;
+    size_t off[UVC_NUM_FIELD_GROUPS + 1];
+    bool has_reads = false, accumulated = false;
+};
+
+static size_t group_bytes(const uvcgpu_region *r, int g) {
+    const size_t n = (size_t)r->npos;
+    switch (g) {
+        case UVC_F_PREP32: return 4 * n * UVC_NPREP32;
+        case UVC_F_PREP64: return 8 * n * UVC_NPREP64;
+        case UVC_F_THRES: return 4 * n * UVC_NTHRES;
+        case UVC_F_SEG32: return 4 * n * UVC_NSEG32 * NSYM;
+        case UVC_F_SEG64: return 8 * n * UVC_NSEG64 * NSYM;
+        case UVC_F_VQ: return 4 * n * UVC_NVQ * NSYM;
+        case UVC_F_BQSUM: return 4 * n * NSYM;
+        case UVC_F_FRAG: return 4 * n * 2 * UVC_NFRAG * NSYM;
+        case UVC_F_FAM: return 4 * n * 2 * UVC_NFAM * NSYM;
+        case UVC_F_FAMINFO32: return 4 * n * UVC_NFAMINFO32 * NSYM;
+        case UVC_F_FAMINFO64: return 8 * n * UVC_NFAMINFO64 * NSYM;
+        case UVC_F_DUPLEX: return 4 * n * UVC_NDUPLEX * NSYM;
+        case UVC_F_RTR: return 4 * n * UVC_NRTR;
+        case UVC_F_BAQ: return 8 * n * 2;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- region side arrays (a3) ---
+// refstring2repeatvec (main.hpp:803-874) + region_repeatvec_to_baq_offsetarr (main.cpp:400-429), host side
+// (O(region x 35); SURVEY C10: "cheap; do on host first").
+namespace {
+struct Track { int32_t begpos = 0, tracklen = 0, unitlen = 0, indelphred = 0, a_begpos = 0, a_tracklen = 0, a_unitlen = 0; };
+
+bool str_better(int32_t ulen1, int32_t cnt1, int32_t ulen2, int32_t cnt2, int32_t umax) {   // is_indel_context_more_STR, main.hpp:699-721
+    if (ulen2 * cnt2 == 0) return true;
+    if (ulen1 > umax || ulen2 > umax) return (ulen1 < ulen2 || (ulen1 == ulen2 && cnt1 > cnt2));
+    int r1 = (cnt1 <= 1 ? (-(int)cnt1 * ulen1) : ((int)(cnt1 - 1) * ulen1));
+    int r2 = (cnt2 <= 1 ? (-(int)cnt2 * ulen1) : ((int)(cnt2 - 1) * ulen2));
+    if (0 == cnt1 || 0 == ulen1) r1 = -100;
+    if (0 == cnt2 || 0 == ulen2) r2 = -100;
+    return r1 > r2;
+}
+int32_t slip_phred(double ampfact, int32_t ulen, int32_t cnt) {   // indel_phred, main.hpp:794-801
+    const int32_t span = ulen * cnt;
+    const double slips = (span > 64 ? (double)(span - 8) : std::log1p(std::exp((double)span - 8.0))) * ampfact / ((double)(ulen * ulen));
+    return (int32_t)std::floor(-10 * std::log((1.0 - 2.220446049250313e-16) / (slips + 1.0)) / std::log(10.0));
+}
+void build_tracks(const std::string &ref, const UvcParams &P, std::vector<Track> &tr, std::vector<int64_t> &baq /*[2][npos]*/) {
+    const int32_t n = (int32_t)ref.size();
+    tr.assign(n, Track());
+    for (auto &t : tr) t.indelphred = P.indel_BQ_max;
+    const int32_t smax = P.indel_str_repeatsize_max, vmax = P.indel_vntr_repeatsize_max;
+    int32_t at = 0;
+    while (at < n) {
+        int32_t best_u = 0, best_c = 0, best_end = at, any_u = 0, any_c = 0, any_end = at;
+        for (int32_t u = 1; u <= vmax; u++) {
+            int32_t q = at;
+            while (q + u < n && ref[q] == ref[q + u]) q++;
+            const int32_t c = (q - at) / u + 1;
+            if (u <= smax && str_better(u, c, best_u, best_c, smax)) { best_u = u; best_c = c; best_end = q + u; }
+            if (str_better(u, c, any_u, any_c, vmax)) { any_u = u; any_c = c; any_end = q + u; }
+        }
+        const int32_t stop = std::min(best_end, n), len = stop - at;
+        const int32_t dec = slip_phred(P.indel_polymerase_slip_rate * P.indel_del_to_ins_err_ratio, best_u, len / best_u);
+        for (int32_t i = at; i != stop; i++) if (len > tr[i].tracklen) {
+            tr[i].begpos = at; tr[i].tracklen = len; tr[i].unitlen = best_u; tr[i].indelphred = P.indel_BQ_max - std::min(P.indel_BQ_max - 1, dec);
+        }
+        const int32_t astop = std::min(any_end, n), alen = astop - at;
+        for (int32_t i = at; i != astop; i++) if (alen > tr[i].a_tracklen) { tr[i].a_begpos = at; tr[i].a_tracklen = alen; tr[i].a_unitlen = any_u; }
+        const int32_t skip = smax + best_u;
+        at += std::max(best_u * best_c, skip + 1) - skip;
+    }
+    tr.push_back(tr.back());
+    const size_t npos = tr.size();
+    baq.assign(2 * npos, 0);
+    for (int any = 0; any < 2; any++) {
+        int64_t run = 0;
+        for (size_t i = 0; i < npos; i++) {
+            const int32_t tl = any ? tr[i].a_tracklen : tr[i].tracklen;
+            const int32_t reps = tl / tr[i].unitlen;
+            if (reps >= 3 || (reps >= 2 && tl >= (int32_t)std::round(P.indel_polymerase_size))) run += (P.indel_str_phred_per_region * 10) / tl + 1;
+            else run += P.indel_nonSTR_phred_per_base * 10;
+            baq[any * npos + i] = run;
+        }
+        for (size_t i = 0; i < npos; i++) baq[any * npos + i] /= 10;
+    }
+}
+uint8_t base_code(char c) {   // CHAR_TO_SYMBOL, main_conversion.hpp:473-488
+    switch (c) { case 'A': case 'a': return UVC_BASE_A; case 'C': case 'c': return UVC_BASE_C; case 'G': case 'g': return UVC_BASE_G; case 'T': case 't': return UVC_BASE_T;
+                 case 'I': case 'i': return UVC_LINK_M; case '-': case '_': return UVC_LINK_D1; default: return UVC_BASE_N; }
+}
+template <class T> int upload(uvcgpu_region *r, const std::vector<T> &v, T **out, bool owned = true) {
+    *out = nullptr;
+    const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    hipError_t e = hipMalloc((void **)out, bytes);
+    if (e != hipSuccess) return fail(UVCGPU_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (owned) r->owned.push_back(*out);
+    if (!v.empty()) { e = hipMemcpyAsync(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, r->stream); if (e != hipSuccess) return fail(UVCGPU_EDEVICE, hipGetErrorString(e)); }
+    return 0;
+}
+void free_reads(uvcgpu_region *r) { for (void *p : r->owned) hipFree(p); r->owned.clear(); r->has_reads = false; r->accumulated = false; }
+}  // namespace
+
+extern "C" {
+
+const char *uvcgpu_last_error(void) { return g_err.c_str(); }
+const char *uvcgpu_version(void) { return "uvcgpu 0.1 (gfx950)"; }
+
+int uvcgpu_init(int device_id) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(UVCGPU_EDEVICE, "no HIP device: libuvcgpu has no CPU fallback");
+    HIP_OK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, device_id));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) return fail(UVCGPU_EDEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    return 0;
+}
+
+void uvcgpu_params_default(UvcParams *p) {
+    memset(p, 0, sizeof(*p));
+    p->struct_size = (int32_t)sizeof(UvcParams);
+#define UVC_PI(name, dflt) p->name = (int32_t)(dflt);
+#define UVC_PD(name, dflt) p->name = (double)(dflt);
+#include "uvc_params.def"
+#undef UVC_PI
+#undef UVC_PD
+}
+
+void uvcgpu_params_apply_platform(UvcParams *p, int32_t platform, int32_t central_readlen, int32_t max_mapq) {   // CmdLineArgs.cpp:13-15, 50-134
+    p->inferred_sequencing_platform = platform;
+    if (0 == p->central_readlen) p->central_readlen = central_readlen;
+    p->inferred_maxMQ = std::max(p->inferred_maxMQ, max_mapq);
+    auto dec = [](int32_t &a, int32_t b) { a = a - std::min(a, b); };
+    if (platform == UVC_PLATFORM_IONTORRENT) {
+        p->bq_phred_added_misma += 8;
+        dec(p->fam_thres_highBQ_snv, 30); dec(p->fam_thres_highBQ_indel, 30); dec(p->bias_thres_PFBQ1, 30); dec(p->bias_thres_PFBQ2, 30); dec(p->bias_thres_highBQ, 13);
+    } else if (platform == UVC_PLATFORM_ILLUMINA) {
+        p->syserr_minABQ_pcr_snv += 200; p->syserr_minABQ_pcr_indel += 100; p->syserr_minABQ_cap_snv += 200; p->syserr_minABQ_cap_indel += 100;
+    }
+}
+
+int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params, int32_t tid, int32_t beg, int32_t end, const char *refseq) {
+    if (!out || !params || !refseq || end <= beg) return fail(UVCGPU_EINVAL, "bad argument");
+    if (params->struct_size != (int32_t)sizeof(UvcParams)) return fail(UVCGPU_EINVAL, "UvcParams::struct_size mismatch");
+    if (params->indel_str_repeatsize_max < 1 || params->indel_vntr_repeatsize_max < params->indel_str_repeatsize_max) return fail(UVCGPU_EINVAL, "bad repeat-size parameters");
+    uvcgpu_region *r = new uvcgpu_region();
+    r->P = *params; r->tid = tid; r->beg = beg; r->end = end + 1; r->npos = (int64_t)end - beg + 1;
+    r->refstring.assign(refseq, (size_t)(end - beg));
+    if (hipStreamCreate(&r->stream) != hipSuccess) { delete r; return fail(UVCGPU_EDEVICE, "hipStreamCreate failed (no GPU?)"); }
+    std::vector<Track> tr; std::vector<int64_t> baq;
+    build_tracks(r->refstring, r->P, tr, baq);
+    std::vector<uint8_t> refsym((size_t)r->npos + 1, 0);
+    for (size_t i = 0; i < r->refstring.size(); i++) refsym[i] = base_code(r->refstring[i]);
+    std::vector<int32_t> rtr((size_t)UVC_NRTR * r->npos);
+    for (int64_t i = 0; i < r->npos; i++) {
+        const Track &t = tr[i];
+        const int32_t v[UVC_NRTR] = { t.begpos, t.tracklen, t.unitlen, t.indelphred, t.a_begpos, t.a_tracklen, t.a_unitlen };
+        for (int f = 0; f < UVC_NRTR; f++) rtr[(size_t)f * r->npos + i] = v[f];
+    }
+    int rc;
+    if ((rc = upload(r, refsym, &r->d_refsym, false)) || (rc = upload(r, rtr, &r->d_rtr0, false)) || (rc = upload(r, rtr, &r->d_rtr, false)) || (rc = upload(r, baq, &r->d_baq, false))) { uvcgpu_region_destroy(r); return rc; }
+    // one slab for all per-position planes (+ the transient bucket planes), 8-byte groups first
+    const int order[] = { UVC_F_PREP64, UVC_F_SEG64, UVC_F_FAMINFO64, UVC_F_PREP32, UVC_F_THRES, UVC_F_SEG32, UVC_F_VQ, UVC_F_BQSUM, UVC_F_FRAG, UVC_F_FAM, UVC_F_FAMINFO32, UVC_F_DUPLEX };
+    size_t o = 0;
+    for (int g : order) { r->off[g] = o; o += group_bytes(r, g); }
+    const size_t bucket_off = o; o += (size_t)4 * r->npos * 2 * NSYM * NBUCKETS;
+    r->state_bytes = o;
+    if (hipMalloc((void **)&r->d_state, r->state_bytes) != hipSuccess) { uvcgpu_region_destroy(r); return fail(UVCGPU_ENOMEM, "hipMalloc(state planes) failed"); }
+    int32_t *d_err = nullptr;
+    if (hipMalloc((void **)&d_err, 4) != hipSuccess) { uvcgpu_region_destroy(r); return fail(UVCGPU_ENOMEM, "hipMalloc failed"); }
+    hipMemsetAsync(d_err, 0, 4, r->stream);
+    RegionDev &R = r->R;
+    memset(&R, 0, sizeof(R));
+    R.beg = r->beg; R.end = r->end; R.npos = r->npos; R.refsym = r->d_refsym; R.rtr = r->d_rtr; R.baq = r->d_baq;
+    char *b = r->d_state;
+    R.prep64 = (int64_t *)(b + r->off[UVC_F_PREP64]); R.seg64 = (int64_t *)(b + r->off[UVC_F_SEG64]); R.faminfo64 = (int64_t *)(b + r->off[UVC_F_FAMINFO64]);
+    R.prep32 = (int32_t *)(b + r->off[UVC_F_PREP32]); R.thres = (int32_t *)(b + r->off[UVC_F_THRES]); R.seg32 = (int32_t *)(b + r->off[UVC_F_SEG32]);
+    R.vq = (int32_t *)(b + r->off[UVC_F_VQ]); R.bqsum = (int32_t *)(b + r->off[UVC_F_BQSUM]); R.frag = (int32_t *)(b + r->off[UVC_F_FRAG]);
+    R.fam = (int32_t *)(b + r->off[UVC_F_FAM]); R.faminfo32 = (int32_t *)(b + r->off[UVC_F_FAMINFO32]); R.duplex = (int32_t *)(b + r->off[UVC_F_DUPLEX]);
+    R.bucket = (int32_t *)(b + bucket_off);
+    R.err = d_err;
+    HIP_OK(hipStreamSynchronize(r->stream));
+    *out = r;
+    return 0;
+}
+
+int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
+    if (!r || !in || in->n_reads < 0 || in->n_fams < 0) return fail(UVCGPU_EINVAL, "bad reads");
+    free_reads(r);
+    const int64_t n = in->n_reads;
+    if (n == 0) return 0;
+    if (n > INT32_MAX / 2) return fail(UVCGPU_EUNSUPPORTED, "more than 2^30 reads in one region");
+    std::vector<int32_t> endpos(n), frag_of(n), fs_of(n), dflag_of(n), kind(n), fast_rank(n, -1);
+    std::vector<int64_t> table_off(n, -1);
+    std::vector<FragRec> frags; std::vector<FsRec> fss;
+    std::vector<int32_t> fam_fs((size_t)in->n_fams * 2, -1);
+    int prev_fam = -1, prev_strand = -1, prev_frag = -1;
+    int64_t table_rows = 0;
+    int32_t max_aln_span = 1, max_frag_span = 1;
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t nc = in->n_cigar[i], lq = in->l_qseq[i];
+        if (in->seq_off[i] < 0 || in->seq_off[i] + lq > in->n_bases || in->cigar_off[i] < 0 || in->cigar_off[i] + nc > in->n_cigar_ops || nc < 1) return fail(UVCGPU_EINVAL, "read offsets out of range");
+        const uint32_t *cg = in->cigars + in->cigar_off[i];
+        int32_t e = in->pos[i]; int64_t q = 0; int n_m = 0; bool simple = true;
+        for (int k = 0; k < nc; k++) {
+            const int op = (int)(cg[k] & 0xF); const int32_t len = (int32_t)(cg[k] >> 4);
+            if (op > C_DIFF) return fail(UVCGPU_EUNSUPPORTED, "unsupported CIGAR op (process_cigar throws, main_conversion.hpp:902-916)");
+            if (op == C_MATCH || op == C_DEL || op == C_REF_SKIP || op == C_EQUAL || op == C_DIFF) e += len;
+            if (op == C_MATCH || op == C_INS || op == C_SOFT_CLIP || op == C_EQUAL || op == C_DIFF) q += len;
+            if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) n_m++;
+            else if (!(op == C_SOFT_CLIP || op == C_HARD_CLIP)) simple = false;
+        }
+        if (e == in->pos[i]) e = in->pos[i] + 1;   // bam_endpos of a read without reference-consuming ops
+        if (q != lq) return fail(UVCGPU_EINVAL, "CIGAR query length != l_qseq");
+        if (n_m != 1 || nc > 3) simple = false;
+        if (simple && nc == 3) { const int o0 = cg[0] & 0xF, o2 = cg[2] & 0xF; if ((o0 == C_MATCH || o0 == C_EQUAL || o0 == C_DIFF) || (o2 == C_MATCH || o2 == C_EQUAL || o2 == C_DIFF)) simple = false; }
+        endpos[i] = e;
+        if (in->pos[i] < r->beg || e > r->end - 1) return fail(UVCGPU_EINVAL, "read outside region");
+        const int fam = in->fam_id[i], strand = in->fam_strand[i];
+        if (fam < 0 || fam >= in->n_fams || strand > 1) return fail(UVCGPU_EINVAL, "fam_id / fam_strand out of range");
+        const bool new_fs = (fam != prev_fam || strand != prev_strand);
+        if (new_fs) {
+            if (fam_fs[(size_t)fam * 2 + strand] >= 0) return fail(UVCGPU_EINVAL, "reads of one (fam_id, fam_strand) are not contiguous");
+            fam_fs[(size_t)fam * 2 + strand] = (int32_t)fss.size();
+            FsRec u; memset(&u, 0, sizeof(u));
+            u.frag_beg = u.frag_end = (int32_t)frags.size(); u.beg = INT32_MAX; u.end = 0; u.strand = strand; u.dflag = in->fam_dflag[fam]; u.fam = fam; u.other_fs = -1;
+            fss.push_back(u);
+        }
+        if (new_fs || in->frag_id[i] != prev_frag) {
+            FragRec f; memset(&f, 0, sizeof(f));
+            f.aln_beg = f.aln_end = (int32_t)i; f.beg = INT32_MAX; f.end = 0; f.fs = (int32_t)fss.size() - 1; f.strand = strand; f.dflag = in->fam_dflag[fam];
+            frags.push_back(f);
+        }
+        FragRec &f = frags.back(); FsRec &u = fss.back();
+        f.aln_end = (int32_t)i + 1; f.beg = std::min(f.beg, in->pos[i]); f.end = std::max(f.end, e) + 1;   // fillTidBegEndFromAlns1, main.hpp:658-673
+        f.normMQ = std::max(f.normMQ, (int32_t)in->mapq[i]);
+        u.frag_end = (int32_t)frags.size(); u.beg = std::min(u.beg, in->pos[i]); u.end = std::max(u.end, e) + 1;
+        frag_of[i] = (int32_t)frags.size() - 1; fs_of[i] = (int32_t)fss.size() - 1; dflag_of[i] = in->fam_dflag[fam];
+        kind[i] = simple ? 0 : 1;
+        if (!simple) { table_off[i] = table_rows; table_rows += (e - in->pos[i]); }
+        else max_aln_span = std::max(max_aln_span, e - in->pos[i]);
+        prev_fam = fam; prev_strand = strand; prev_frag = in->frag_id[i];
+    }
+    const UvcParams &P = r->P;
+    const bool singleton_ok = (P.fam_thres_dup1add >= 2 && P.fam_thres_dup2add >= 2 && P.fam_thres_emperr_all_flat_snv >= 2 && P.fam_thres_emperr_all_flat_indel >= 2);
+    std::vector<int32_t> generic_fs, dup_units; std::vector<int64_t> dup_off;
+    int64_t work = 0, dup_work = 0;
+    for (size_t ui = 0; ui < fss.size(); ui++) {
+        FsRec &u = fss[ui];
+        u.end = std::min(u.end, r->end);
+        u.other_fs = fam_fs[(size_t)u.fam * 2 + (1 - u.strand)];
+        const bool duplex = ((u.dflag & 0x2) && u.other_fs >= 0);
+        u.generic = ((u.frag_end - u.frag_beg) >= 2 || duplex || !singleton_ok) ? 1 : 0;
+        if (u.generic) { u.work_off = work; work += (u.end - u.beg); generic_fs.push_back((int32_t)ui); }
+        if (duplex && u.strand == 0) {
+            const FsRec &o = fss[u.other_fs];
+            dup_units.push_back((int32_t)ui); dup_off.push_back(dup_work);
+            dup_work += std::max(u.end, std::min(o.end, r->end)) - std::min(u.beg, o.beg);
+        }
+    }
+    for (auto &f : frags) { f.end = std::min(f.end, r->end); f.singleton = fss[f.fs].generic ? 0 : 1; max_frag_span = std::max(max_frag_span, f.end - f.beg); }
+    // pos-sorted order of the simple alignments, beg-sorted order of the fragments
+    std::vector<int32_t> simple_ids, complex_ids, frag_sorted(frags.size());
+    for (int64_t i = 0; i < n; i++) (kind[i] == 0 ? simple_ids : complex_ids).push_back((int32_t)i);
+    std::stable_sort(simple_ids.begin(), simple_ids.end(), [&](int32_t a, int32_t b) { return in->pos[a] < in->pos[b]; });
+    for (size_t k = 0; k < simple_ids.size(); k++) fast_rank[simple_ids[k]] = (int32_t)k;
+    std::iota(frag_sorted.begin(), frag_sorted.end(), 0);
+    std::stable_sort(frag_sorted.begin(), frag_sorted.end(), [&](int32_t a, int32_t b) { return frags[a].beg < frags[b].beg; });
+
+    // uploads
+    RegionDev &R = r->R;
+    RawReads W;
+    int rc;
+    auto up32 = [&](const int32_t *src, const int32_t **dst) { std::vector<int32_t> v(src, src + n); int32_t *d; int c = upload(r, v, &d); *dst = d; return c; };
+    auto up64 = [&](const int64_t *src, const int64_t **dst) { std::vector<int64_t> v(src, src + n); int64_t *d; int c = upload(r, v, &d); *dst = d; return c; };
+    std::vector<int32_t> flag32(n), mapq32(n);
+    for (int64_t i = 0; i < n; i++) { flag32[i] = in->flag[i]; mapq32[i] = in->mapq[i]; }
+    if ((rc = up32(in->pos, &W.pos)) || (rc = up32(endpos.data(), &W.endpos)) || (rc = up32(in->mpos, &W.mpos)) || (rc = up32(in->isize, &W.isize))
+        || (rc = up32(flag32.data(), &W.flag)) || (rc = up32(mapq32.data(), &W.mapq)) || (rc = up32(in->nm, &W.nm)) || (rc = up32(in->l_qseq, &W.l_qseq))
+        || (rc = up32(in->n_cigar, &W.n_cigar)) || (rc = up32(frag_of.data(), &W.frag)) || (rc = up32(fs_of.data(), &W.fs)) || (rc = up32(dflag_of.data(), &W.dflag))
+        || (rc = up32(kind.data(), &W.kind)) || (rc = up32(fast_rank.data(), &W.fast_rank))
+        || (rc = up64(in->seq_off, &W.seq_off)) || (rc = up64(in->cigar_off, &W.cigar_off)) || (rc = up64(table_off.data(), &W.table_off))) return rc;
+    { std::vector<uint8_t> v(in->bases, in->bases + in->n_bases); uint8_t *d; if ((rc = upload(r, v, &d))) return rc; R.bases = d; }
+    { std::vector<uint8_t> v(in->quals, in->quals + in->n_bases); uint8_t *d; if ((rc = upload(r, v, &d))) return rc; R.quals = d; }
+    { std::vector<uint32_t> v(in->cigars, in->cigars + in->n_cigar_ops); uint32_t *d; if ((rc = upload(r, v, &d))) return rc; R.cigars = d; }
+    { std::vector<AlnRec> v((size_t)n); AlnRec *d; if ((rc = upload(r, v, &d))) return rc; R.alns = d; R.n_alns = (int32_t)n; }
+    { std::vector<AlnRec> v(simple_ids.size()); AlnRec *d; if ((rc = upload(r, v, &d))) return rc; R.fast = d; R.n_fast = (int32_t)simple_ids.size(); }
+    { int32_t *d; if ((rc = upload(r, complex_ids, &d))) return rc; R.complex_ids = d; R.n_complex = (int32_t)complex_ids.size(); }
+    { FragRec *d; if ((rc = upload(r, frags, &d))) return rc; R.frags = d; R.n_frags = (int32_t)frags.size(); }
+    { int32_t *d; if ((rc = upload(r, frag_sorted, &d))) return rc; R.frag_sorted = d; }
+    { FsRec *d; if ((rc = upload(r, fss, &d))) return rc; R.fss = d; R.n_fs = (int32_t)fss.size(); }
+    { int32_t *d; if ((rc = upload(r, generic_fs, &d))) return rc; R.generic_fs = d; R.n_generic_fs = (int32_t)generic_fs.size(); R.n_generic_work = work; }
+    { std::vector<Contrib> v; Contrib *d = nullptr; const size_t bytes = std::max<int64_t>(table_rows, 1) * sizeof(Contrib);
+      if (hipMalloc((void **)&d, bytes) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(table)"); r->owned.push_back(d); R.table = d; r->state_bytes += 0; (void)v; }
+    { if ((rc = upload(r, dup_units, &r->d_dup_units)) || (rc = upload(r, dup_off, &r->d_dup_off))) return rc; r->n_dup = (int)dup_units.size(); r->n_dup_work = dup_work; }
+    R.max_aln_span = max_aln_span; R.max_frag_span = max_frag_span;
+    r->R.n_complex = (int32_t)complex_ids.size();
+    // table rows are written by k_p2_slow<false>; mark all slots empty (0xFF)
+    HIP_OK(hipMemsetAsync(R.table, 0xFF, std::max<int64_t>(table_rows, 1) * sizeof(Contrib), r->stream));
+    uvc_launch_prelude(&R, &W, &r->P, r->stream);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(r->stream));   // the staging vectors above die here
+    r->has_reads = true;
+    return 0;
+}
+
+int uvcgpu_region_correct_bq(uvcgpu_region_t *) { return fail(UVCGPU_EUNSUPPORTED, "apply_bq_err_correction3 on device: not built yet (SURVEY row a11)"); }
+
+int uvcgpu_region_accumulate(uvcgpu_region_t *r) {
+    if (!r) return fail(UVCGPU_EINVAL, "null region");
+    if (!r->has_reads) return fail(UVCGPU_ENOREADS, "no reads");   // process_batch returns -1, main.cpp:520-523
+    HIP_OK(hipMemsetAsync(r->d_state, 0, r->state_bytes, r->stream));
+    HIP_OK(hipMemcpyAsync(r->d_rtr, r->d_rtr0, (size_t)4 * UVC_NRTR * r->npos, hipMemcpyDeviceToDevice, r->stream));   // P1b edits indelphred in place
+    // the table is rebuilt by k_p2_slow<false>: MAX-merge needs empty slots
+    if (r->R.n_complex) {
+        // rows were set to 0xFF in set_reads and k_p2_slow<false> is idempotent under MAX, so no reset is needed
+    }
+    const int half = (int)std::round((10.0 / std::log(10.0)) * std::log(r->P.indel_del_to_ins_err_ratio)) / 2;   // main.hpp:1244
+    uvc_launch_accumulate(&r->R, &r->P, half, r->d_dup_units, r->n_dup, r->d_dup_off, r->n_dup_work, r->stream);
+    HIP_OK(hipGetLastError());
+    r->accumulated = true;
+    return 0;
+}
+
+int uvcgpu_region_sync(uvcgpu_region_t *r) {
+    if (!r) return fail(UVCGPU_EINVAL, "null region");
+    HIP_OK(hipStreamSynchronize(r->stream));
+    int32_t e = 0;
+    HIP_OK(hipMemcpy(&e, r->R.err, 4, hipMemcpyDeviceToHost));
+    if (e) return fail(e, "a kernel flagged an unsupported read shape (CIGAR with >3 LINK symbols at one position, >16 low-quality InDels, or an op the reference throws on)");
+    return 0;
+}
+
+int64_t uvcgpu_region_field_bytes(const uvcgpu_region_t *r, int32_t g) {
+    if (!r || g < 0 || g >= UVC_NUM_FIELD_GROUPS) return -1;
+    if (g != UVC_F_RTR && g != UVC_F_BAQ && !r->accumulated) return -1;
+    return (int64_t)group_bytes(r, g);
+}
+
+int uvcgpu_region_fetch(uvcgpu_region_t *r, int32_t g, void *dst, int64_t dst_bytes) {
+    if (!r || !dst || g < 0 || g >= UVC_NUM_FIELD_GROUPS) return fail(UVCGPU_EINVAL, "bad argument");
+    if (g != UVC_F_RTR && g != UVC_F_BAQ && !r->accumulated) return fail(UVCGPU_ESTATE, "fetch before accumulate");
+    if ((int64_t)group_bytes(r, g) != dst_bytes) return fail(UVCGPU_EINVAL, "bad destination size");
+    int rc = uvcgpu_region_sync(r);
+    if (rc) return rc;
+    const void *src = (g == UVC_F_RTR) ? (const void *)r->d_rtr : (g == UVC_F_BAQ) ? (const void *)r->d_baq : (const void *)(r->d_state + r->off[g]);
+    HIP_OK(hipMemcpy(dst, src, (size_t)dst_bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int64_t uvcgpu_region_score_size(const uvcgpu_region_t *r, const UvcScoreRequest *req) {
+    if (!r) return -1;
+    const int64_t np = (req && req->pos_beg >= 0) ? (req->pos_end - req->pos_beg) : r->npos;
+    return NSYM * (np + 1) + (req ? req->n_indel_alleles : 0);
+}
+
+int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScoreOut *out) {
+    if (!r || !out || !out->fields) return fail(UVCGPU_EINVAL, "bad argument");
+    if (!r->accumulated) return fail(UVCGPU_ESTATE, "score before accumulate");
+    if (r->P.tumor_vcf_is_provided) return fail(UVCGPU_EUNSUPPORTED, "T/N rescue scoring is SURVEY next-row N2");
+    UvcScoreRequest rq; memset(&rq, 0, sizeof(rq)); rq.pos_beg = -1;
+    if (req) rq = *req;
+    if (rq.pos_beg < 0) { rq.pos_beg = r->beg + 1; rq.pos_end = r->end - 1; }
+    if (rq.pos_beg <= r->beg || rq.pos_end > r->end - 1 || rq.pos_end < rq.pos_beg) return fail(UVCGPU_EINVAL, "score range outside the region core");
+    UvcIndelAllele *d_al = nullptr;
+    if (rq.n_indel_alleles > 0) {
+        HIP_OK(hipMalloc((void **)&d_al, sizeof(UvcIndelAllele) * rq.n_indel_alleles));
+        HIP_OK(hipMemcpyAsync(d_al, rq.indel_alleles, sizeof(UvcIndelAllele) * rq.n_indel_alleles, hipMemcpyHostToDevice, r->stream));
+    }
+    int32_t *d_fields = nullptr; int64_t *d_count = nullptr;
+    const int64_t cap = std::max<int64_t>(out->capacity, 1);
+    HIP_OK(hipMalloc((void **)&d_fields, sizeof(int32_t) * UVC_NUM_SCORE_FIELDS * cap));
+    HIP_OK(hipMalloc((void **)&d_count, 8));
+    HIP_OK(hipMemsetAsync(d_count, 0, 8, r->stream));
+    int rc = uvc_launch_score(&r->R, &r->P, &rq, d_al, d_fields, out->capacity, d_count, r->stream);
+    if (!rc) rc = uvcgpu_region_sync(r);
+    int64_t cnt = 0;
+    if (!rc && hipMemcpy(&cnt, d_count, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(UVCGPU_EDEVICE, "hipMemcpy(count)");
+    if (!rc) {
+        out->n_records = cnt;
+        if (cnt > out->capacity) rc = fail(UVCGPU_ENOMEM, "score output capacity too small");
+        else if (cnt > 0 && hipMemcpy2D(out->fields, sizeof(int32_t) * out->capacity, d_fields, sizeof(int32_t) * cap, sizeof(int32_t) * cnt, UVC_NUM_SCORE_FIELDS, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(UVCGPU_EDEVICE, "hipMemcpy2D(records)");
+    }
+    hipFree(d_fields); hipFree(d_count); if (d_al) hipFree(d_al);
+    return rc;
+}
+
+void uvcgpu_region_destroy(uvcgpu_region_t *r) {
+    if (!r) return;
+    if (r->stream) hipStreamSynchronize(r->stream);
+    free_reads(r);
+    if (r->d_refsym) hipFree(r->d_refsym);
+    if (r->d_rtr) hipFree(r->d_rtr);
+    if (r->d_rtr0) hipFree(r->d_rtr0);
+    if (r->d_baq) hipFree(r->d_baq);
+    if (r->d_state) hipFree(r->d_state);
+    if (r->R.err) hipFree(r->R.err);
+    if (r->stream) hipStreamDestroy(r->stream);
+    delete r;
+}
+
+}  // extern "C"

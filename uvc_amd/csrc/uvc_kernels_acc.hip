@@ -1,0 +1,1332 @@
+// uvc_kernels_acc.hip -- hand-written gfx950 kernels for the accumulate half of the UVC hot path.
+//
+// Decomposition.  The reference walks every read 5 times and scatters `+=`
+// into ~5.5 KB of per-position state (main.hpp:2543-3594).  Here the loops are turned inside out:
+// a wavefront owns 64 consecutive reference positions (one lane = one position), loops over the
+// alignments / fragments that overlap its window (wave-uniform control flow, read scalars through
+// scalar loads, base/qual bytes coalesced across lanes) and keeps the accumulators of the two
+// symbols that matter at a position -- the reference base and LINK_M -- in registers.  Everything
+// that is rare (mismatching bases, N, clips, reads with InDels) takes a sparse path: global integer
+// atomics for rare symbols, and one-thread-per-read sequential kernels for reads whose CIGAR has
+// InDels.  All updates are integer adds or maxima, so any order gives bit-identical results
+// (SURVEY Appendix B).
+//
+//   k_aln_prelude   per read      nge/ngo/clips, xm1500, bm1500s, penalties      main.hpp:1795-1885
+//   k_prep_fast     per position  P1 for simple reads                            main.hpp:924-1204
+//   k_prep_slow     per read      P1 for reads with InDels (atomics)
+//   k_thres         per position  P1b, also edits rtr.indelphred                 main.hpp:1206-1299
+//   k_p2_fast       per position  P2 + dealwith_segbias for simple reads         main.hpp:1360-1595, 1762-2296
+//   k_p2_slow       per read      P2 for reads with InDels (atomics) and, in TABLE mode, the
+//                                 BASE_QUALITY_MAX contribution table used by P3/P4/P5
+//   k_fragstat      per fragment  covered / near-mutation position counts        main.hpp:2738-2756
+//   k_frag          per position  P3 + P3b, and P4/P5 of singleton families      main.hpp:2620-2830, 2832-3594
+//   k_fam_stat/p4/p5 per (family-strand unit, position): multi-fragment families main.hpp:2883-3522
+//   k_duplex        per (duplex family, position)                                main.hpp:3523-3550
+//   k_p5b           per position  bucket -> quality for family consensus         main.hpp:3552-3591
+#include "uvc_device.h"
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+DEV int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+DEV int lower_bound_pos(const AlnRec *a, int n, int key) {   // first index with a[i].pos >= key
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid].pos < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+struct SegAcc {   // SegFormatInfoSet (main_conversion.hpp:645-691) + the VQ a1/a2 sums + bqsum of ONE symbol at ONE position
+    int s[UVC_NSEG32];
+    long long l[UVC_NSEG64];
+    int a1BQf, a1BQr, a2BQf, a2BQr, bq;
+    DEV void zero() { for (int i = 0; i < UVC_NSEG32; i++) s[i] = 0; for (int i = 0; i < UVC_NSEG64; i++) l[i] = 0; a1BQf = a1BQr = a2BQf = a2BQr = bq = 0; }
+};
+
+DEV void seg_flush(const RegionDev &R, const SegAcc &A, int sym, int64_t x) {
+#pragma unroll
+    for (int f = 0; f < UVC_NSEG32; f++) if (A.s[f]) atomicAdd(&S32(R, f, sym, x), A.s[f]);
+#pragma unroll
+    for (int f = 0; f < UVC_NSEG64; f++) if (A.l[f]) add64(&S64(R, f, sym, x), A.l[f]);
+    if (A.a1BQf) atomicAdd(&VQP(R, UVC_VQ_a1BQf, sym, x), A.a1BQf);
+    if (A.a1BQr) atomicAdd(&VQP(R, UVC_VQ_a1BQr, sym, x), A.a1BQr);
+    if (A.a2BQf) atomicAdd(&VQP(R, UVC_VQ_a2BQf, sym, x), A.a2BQf);
+    if (A.a2BQr) atomicAdd(&VQP(R, UVC_VQ_a2BQr, sym, x), A.a2BQr);
+    if (A.bq) atomicAdd(&BQS(R, sym, x), A.bq);
+}
+
+struct PosThres { int t[UVC_NTHRES]; };
+
+// per-read quantities that dealwith_segbias needs; all wave-uniform in the fast kernels
+struct SegRead {
+    int pos, rend, flag, mapq, isize, frag_pos_L, frag_pos_R, xm1500, clip_cnt, dflag;
+    long long baq_pos, baq_last, baq2_last;
+};
+
+DEV SegRead make_segread(const RegionDev &R, const AlnRec &a) {
+    SegRead r;
+    r.pos = a.pos; r.rend = a.rend; r.flag = a.flag; r.mapq = a.mapq; r.isize = a.isize;
+    r.frag_pos_L = imin(a.pos, a.mpos); r.frag_pos_R = r.frag_pos_L + abs(a.isize);
+    r.xm1500 = a.xm1500; r.clip_cnt = a.clip_cnt; r.dflag = a.dflag;
+    r.baq_pos = BAQ1(R, a.pos); r.baq_last = BAQ1(R, a.rend - 1); r.baq2_last = BAQ2(R, a.rend - 1);
+    return r;
+}
+
+// update_bidirectional_bias, main.hpp:1318-1358
+DEV void bidir(int &LP1, int &LP2, int &RP1, int &RP2, long long &LPL, long long &RPL, int L1, int L2, int R1, int R2, long long nl, long long nr, bool tier2, int n_indel) {
+    if (nl + n_indel >= L1) LP1 += 1;
+    if ((nl + n_indel >= L2) && tier2) LP2 += 1;
+    if (nr >= R1) RP1 += 1;
+    if ((nr >= R2) && tier2) RP2 += 1;
+    LPL += nl; RPL += nr;
+}
+
+// dealwith_segbias<isGap>, main.hpp:1360-1595 (COMPILATION_ENABLE_XMGOT == 0)
+template <bool isGap>
+DEV void segbias(SegAcc &A, const UvcParams &P, const SegRead &r, const PosThres &T, int rpos, long long baq_p, long long baq2_p,
+                 int bq, int bm1500, int cigar_op, int indel_len, int dist_to_interfering_indel) {
+    const bool is_assay_amplicon = ((r.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag)));
+    const bool normal_filter_primers = (P.tn_is_paired && (0x1 & P.primer_flag));
+    const bool is_assay_UMI = (r.dflag & 0x1);
+    const int seg_l_baq1 = (int)(baq_p - r.baq_pos + 1);
+    const int _seg_r_baq = (int)(r.baq_last - baq_p + 1);
+    const int seg_r_baq1 = (isGap ? (int)lmin((long long)_seg_r_baq, r.baq2_last - baq2_p + 7) : _seg_r_baq);
+    const int seg_l_nbases = rpos - r.pos + 1;
+    const int seg_r_nbases = r.rend - rpos;
+    const bool is_high_readlen = (P.central_readlen >= P.microadjust_median_readlen_thres);
+    const int seg_l_baq = (is_high_readlen ? seg_l_baq1 : imax(seg_l_baq1, seg_l_nbases * P.microadjust_BAQ_per_base_x1024 / 1024));
+    const int seg_r_baq = (is_high_readlen ? seg_r_baq1 : imax(seg_r_baq1, seg_r_nbases * P.microadjust_BAQ_per_base_x1024 / 1024));
+    const int frag_l_nbases2 = ((r.isize != 0) ? imin(rpos - r.frag_pos_L + 1, MAX_INSERT_SIZE) : MAX_INSERT_SIZE);
+    const int frag_r_nbases2 = ((r.isize != 0) ? imin(r.frag_pos_R - rpos, MAX_INSERT_SIZE) : MAX_INSERT_SIZE);
+    const bool is_normal = ((r.isize != 0) || (0 == (r.flag & 0x1)));
+    const bool isrc = (r.flag & 0x10) != 0;
+    const bool strand = ((r.flag & 0x81) == 0x81) ? ((r.flag & 0x20) != 0) : ((r.flag & 0x10) != 0);   // bam_get_strand, common.hpp:89
+
+    if (isrc) { A.a1BQr += bq; A.a2BQr += bq * bq / SQR_QUAL_DIV; } else { A.a1BQf += bq; A.a2BQf += bq * bq / SQR_QUAL_DIV; }
+    A.s[UVC_S_aMQs] += r.mapq;
+    A.s[UVC_S_aDPff] += (!strand && !isrc); A.s[UVC_S_aDPfr] += (!strand && isrc);
+    A.s[UVC_S_aDPrf] += (strand && !isrc);  A.s[UVC_S_aDPrr] += (strand && isrc);
+    if (imin(dist_to_interfering_indel, imin(seg_l_nbases, seg_r_nbases)) >= P.bias_thres_interfering_indel) A.s[UVC_S_aP3] += 1;
+    if (0 == r.clip_cnt) A.s[UVC_S_aNC] += 1;
+    if (isrc) A.l[UVC_S64_aLIT] += ((r.isize != 0) ? frag_l_nbases2 : 0);
+    else      A.l[UVC_S64_aRIT] += ((r.isize != 0) ? frag_r_nbases2 : 0);
+
+    const int _LPxT = T.t[UVC_T_aLPxT], RPxT = T.t[UVC_T_aRPxT];
+    const int LPxT = (isGap ? _LPxT : imin(_LPxT, RPxT));
+    const bool is_far_from_edge = (seg_l_nbases + ((C_INS == cigar_op) ? (int)nnminus(indel_len, P.microadjust_nobias_pos_indel_maxlen) : 0) >= LPxT) && (seg_r_nbases >= RPxT);
+    const int thres_highBAQ = P.bias_thres_highBAQ + (isGap ? 0 : 3);
+    const bool is_unaffected_by_edge = (seg_l_baq >= thres_highBAQ && seg_r_baq >= thres_highBAQ);
+    const int min_dist2iend = ((r.flag & 0x1) ? imin(frag_l_nbases2, frag_r_nbases2) : (isrc ? seg_r_nbases : seg_l_nbases));
+    if (is_far_from_edge && is_unaffected_by_edge && (min_dist2iend > P.primerlen2 || !is_assay_amplicon)) A.s[UVC_S_aP1] += 1;
+    if (is_assay_UMI || !is_assay_amplicon) A.s[UVC_S_aP2] += 1;
+
+    int ampfact2 = 100;
+    if (bq < P.bias_thres_PFBQ1) ampfact2 = 100 * (bq * bq) / (P.bias_thres_PFBQ1 * P.bias_thres_PFBQ1);
+    A.s[UVC_S_aPF1] += (isGap ? imin(100, ampfact2) : (100 * ampfact2 / 100));
+    ampfact2 = 100;
+    if (bq < P.bias_thres_PFBQ2) ampfact2 = 100 * (bq * bq) / (P.bias_thres_PFBQ2 * P.bias_thres_PFBQ2);
+    A.s[UVC_S_aPF2] += (isGap ? imin(100, ampfact2) : (100 * ampfact2 / 100));
+    if (!isGap) {
+        A.s[UVC_S_a2XM2] += (r.xm1500 > 20 ? (100 * (20 * 20) / (r.xm1500 * r.xm1500)) : 100);
+        A.s[UVC_S_a2BM2] += (bm1500 > 20 ? (100 * (20 * 20) / (bm1500 * bm1500)) : 100);
+    }
+    if (((!isGap) && bq >= P.bias_thres_highBQ) || (isGap && dist_to_interfering_indel >= P.bias_thres_interfering_indel)) {
+        const bool tier2 = (isGap || bq >= P.bias_thres_highBQ);
+        if (is_far_from_edge) {
+            long long LPL = 0, RPL = 0;
+            bidir(A.s[UVC_S_aLP1], A.s[UVC_S_aLP2], A.s[UVC_S_aRP1], A.s[UVC_S_aRP2], LPL, RPL,
+                  T.t[UVC_T_aLP1t], T.t[UVC_T_aLP2t], T.t[UVC_T_aRP1t], T.t[UVC_T_aRP2t], seg_l_nbases, seg_r_nbases, tier2, indel_len);
+            A.s[UVC_S_aLPL] += (int)LPL; A.s[UVC_S_aRPL] += (int)RPL;
+        }
+        if (is_unaffected_by_edge) {
+            bidir(A.s[UVC_S_aLB1], A.s[UVC_S_aLB2], A.s[UVC_S_aRB1], A.s[UVC_S_aRB2], A.l[UVC_S64_aLBL], A.l[UVC_S64_aRBL],
+                  P.bias_thres_BAQ1, P.bias_thres_BAQ2, P.bias_thres_BAQ1, P.bias_thres_BAQ2, seg_l_baq, seg_r_baq, tier2, 0);
+        }
+        A.s[UVC_S_aBQ2] += 1;
+    }
+    const bool mate_ok = ((0 == (r.flag & 0x8)) || (0 == (r.flag & 0x1)));
+    const bool is_l_nonbiased = (mate_ok && seg_l_nbases > seg_r_nbases);
+    const bool is_r_nonbiased = (mate_ok && seg_l_nbases < seg_r_nbases);
+    const bool pos_good = ((!is_assay_amplicon) || (!normal_filter_primers) || (is_far_from_edge && is_unaffected_by_edge));
+    if (isrc) {
+        const int d = frag_l_nbases2;
+        if ((d >= T.t[UVC_T_aLI1t]) && (d <= T.t[UVC_T_aLI1T] || isGap) && (is_normal || (isGap && is_l_nonbiased))) A.s[UVC_S_aLI1] += 1;
+        if ((d >= T.t[UVC_T_aLI2t]) && (d <= T.t[UVC_T_aLI2T] || isGap) && (is_normal || (isGap && is_l_nonbiased))) { if (pos_good) A.s[UVC_S_aLI2] += 1; }
+        if (pos_good) A.s[UVC_S_aLIr] += 1;
+    } else {
+        const int d = frag_r_nbases2;
+        if ((d >= T.t[UVC_T_aRI1t]) && (d <= T.t[UVC_T_aRI1T] || isGap) && (is_normal || (isGap && is_r_nonbiased))) A.s[UVC_S_aRI1] += 1;
+        if ((d >= T.t[UVC_T_aRI2t]) && (d <= T.t[UVC_T_aRI2T] || isGap) && (is_normal || (isGap && is_r_nonbiased))) { if (pos_good) A.s[UVC_S_aRI2] += 1; }
+        if (pos_good) A.s[UVC_S_aRIf] += 1;
+    }
+}
+
+DEV void load_thres(const RegionDev &R, PosThres &T, int64_t x) {
+#pragma unroll
+    for (int f = 0; f < UVC_NTHRES; f++) T.t[f] = TH(R, f, x);
+}
+
+// primer gating of updateByAln, main.hpp:1872-1875, 1895
+DEV void primer_window(const UvcParams &P, const AlnRec &a, int &ibeg, int &iend) {
+    const bool isrc = (a.flag & 0x10) != 0;
+    ibeg = ((a.isize != 0) ? (imin(a.pos, a.mpos) + P.primerlen) : ((isrc && (0x0 == (0x1 & a.flag))) ? 0 : (a.pos + P.primerlen)));
+    iend = ((a.isize != 0) ? (int)nnminus(imin(a.pos, a.mpos) + abs(a.isize), P.primerlen) : ((isrc && (0x0 == (0x1 & a.flag))) ? (int)nnminus(a.rend, P.primerlen) : INT32_MAX));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_aln_prelude: one thread per alignment (main.hpp:1795-1885 prelude of updateByAln)
+// ------------------------------------------------------------------------------------------------
+struct RawReads {
+    const int32_t *pos, *endpos, *mpos, *isize, *flag, *mapq, *nm, *l_qseq, *n_cigar, *frag, *fs, *dflag, *kind, *fast_rank;
+    const int64_t *seq_off, *cigar_off, *table_off;
+};
+
+__global__ void __launch_bounds__(256) k_aln_prelude(RegionDev R, RawReads W, UvcParams P) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= R.n_alns) return;
+    AlnRec a;
+    a.pos = W.pos[id]; a.rend = W.endpos[id]; a.mpos = W.mpos[id]; a.isize = W.isize[id]; a.flag = W.flag[id]; a.mapq = W.mapq[id];
+    a.dflag = W.dflag[id]; a.l_qseq = W.l_qseq[id]; a.seq_off = W.seq_off[id]; a.cigar_off = W.cigar_off[id]; a.table_off = W.table_off[id];
+    a.n_cigar = W.n_cigar[id]; a.kind = W.kind[id]; a.frag = W.frag[id]; a.fs = W.fs[id]; a.pad_ = 0;
+    const uint32_t *cigar = R.cigars + a.cigar_off;
+    const uint8_t *bases = R.bases + a.seq_off;
+    int nge = 0, ngo = 0, clip_cnt = 0;
+    for (int i = 0; i < a.n_cigar; i++) {
+        const int op = cig_op(cigar[i]);
+        if (C_INS == op || C_DEL == op) { nge += cig_len(cigar[i]); ngo++; }
+        if (C_SOFT_CLIP == op || C_HARD_CLIP == op) clip_cnt++;
+        if (op > C_DIFF) atomicExch(R.err, UVCGPU_EUNSUPPORTED);   // BAM_CBACK etc.: process_cigar throws, main_conversion.hpp:911-915
+    }
+    const int nm_cnt = (W.nm[id] >= 0 ? W.nm[id] : nge);
+    const int qlen = a.rend - a.pos;
+    a.xm1500 = (nm_cnt - nge) * 1500 / qlen;
+    a.go1500 = ngo * 1500 / qlen;
+    a.clip_cnt = clip_cnt;
+    int bm[5] = { 0, 0, 0, 0, 0 };
+    int qpos = 0, rpos = a.pos, lclip_q = 0, m_index = -1;
+    for (int i = 0; i < a.n_cigar; i++) {
+        const int op = cig_op(cigar[i]), len = cig_len(cigar[i]);
+        if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) {
+            if (m_index < 0) { m_index = i; lclip_q = qpos; }
+            for (int k = 0; k < len; k++) { const int b = bases[qpos]; if (R.refsym[rpos - R.beg] != b) bm[b] += 1; qpos++; rpos++; }
+        } else if (op == C_INS || op == C_SOFT_CLIP) qpos += len;
+        else if (op == C_DEL || op == C_REF_SKIP) rpos += len;
+    }
+    for (int s = 0; s < 5; s++) a.bm1500[s] = bm[s] * 1500 / qlen;
+    a.lclip_len = ((a.n_cigar > 0 && cig_op(cigar[0]) == C_SOFT_CLIP) ? cig_len(cigar[0]) : 0);
+    a.rclip_len = ((a.n_cigar > 0 && cig_op(cigar[a.n_cigar - 1]) == C_SOFT_CLIP) ? cig_len(cigar[a.n_cigar - 1]) : 0);
+    const int by_clip = imax(a.lclip_len, a.rclip_len) / 6;
+    const int by_nm = (a.xm1500 + a.go1500) / 30;
+    a.indel_penal = imin(1, by_nm + by_clip);
+    a.nogap_penal = imin(4, by_nm + by_clip) + 1;
+    a.lclip_q = lclip_q; a.m_index = m_index;
+    a.lclip_oplen = 0; a.rclip_oplen = 0;
+    if (a.kind == 0) {
+        if (m_index > 0) a.lclip_oplen = cig_len(cigar[m_index - 1]);
+        if (m_index + 1 < a.n_cigar) a.rclip_oplen = cig_len(cigar[m_index + 1]);
+    }
+    a.qbase = a.seq_off + lclip_q - a.pos;
+    R.alns[id] = a;
+    const int rk = W.fast_rank[id];
+    if (rk >= 0) R.fast[rk] = a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// P1 (update_seg_format_prep_sets_by_aln, main.hpp:924-1204)
+// ------------------------------------------------------------------------------------------------
+// SNV / DNV run detection started at ref position s of alignment a (main.hpp:1025-1046).
+// `q_of_r` maps the walk to the query: the reference advances query and reference together
+// regardless of the CIGAR, so q = q_s + (r - s).
+DEV void snv_dnv_scatter(const RegionDev &R, const uint8_t *qbases, int q_s, int l_qseq, int apos, int rend, int s) {
+    int nq = q_s, nr = s;
+    int refsymbol = UVC_BASE_NN, readsymbol = UVC_NUM_SYMBOLS;
+    while (refsymbol != readsymbol && nq < l_qseq && nr < rend) {
+        refsymbol = R.refsym[nr - R.beg];
+        readsymbol = qbases[nq];
+        nq++; nr++;
+    }
+    if (nr == s + 2) for (int r = imax(apos, s - 1); r < imin(nr, rend); r++) atomicAdd(&P32(R, UVC_P_a_snv_dp, r - R.beg), 1);
+    if (nr > s + 2)  for (int r = imax(apos, s - 1); r < imin(nr, rend); r++) atomicAdd(&P32(R, UVC_P_a_dnv_dp, r - R.beg), 1);
+}
+
+DEV void clip_event(const RegionDev &R, const UvcParams &P, int rpos, int i, int len, int pcr_dp_inc) {   // main.hpp:1183-1199
+    const int delta = ((0 == i) ? 0 : -1);
+    if (pcr_dp_inc) {
+        for (int r2 = rpos + delta - P.microadjust_near_clip_dist; r2 <= rpos + delta + P.microadjust_near_clip_dist; r2++)
+            if (R.beg <= r2 && r2 < R.end) atomicAdd(&P32(R, UVC_P_a_near_pcr_clip_dp, r2 - R.beg), pcr_dp_inc);
+    }
+    if ((0 == pcr_dp_inc) && (len >= P.microadjust_alignment_clip_min_len)) {
+        const int r2 = rpos + delta;
+        if (R.beg <= r2 && r2 < R.end) atomicAdd(&P32(R, UVC_P_a_near_long_clip_dp, r2 - R.beg), 1);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_uniform((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int64_t x0 = (int64_t)wave * 64;
+    if (x0 >= R.npos) return;
+    const int w0 = R.beg + (int)x0;
+    const int p = w0 + lane;
+    const int64_t x = x0 + lane;
+    const bool valid = x < R.npos;
+    const int my_ref = valid ? R.refsym[x] : 0;
+    const long long my_baq = valid ? R.baq[x] : 0;
+    int dp = 0, pcr = 0, umi = 0, qlen_s = 0, xm_s = 0, lidp = 0, ridp = 0, ldist = 0, rdist = 0, hbq = 0;
+    long long li = 0, ri = 0, lbaq = 0, rbaq = 0;
+    const int lo = wave_uniform(lower_bound_pos(R.fast, R.n_fast, w0 - R.max_aln_span + 1));
+    const int hi = wave_uniform(lower_bound_pos(R.fast, R.n_fast, w0 + 64));
+    for (int k = lo; k < hi; k++) {
+        const AlnRec &a = R.fast[k];
+        const int apos = a.pos, rend = a.rend;
+        if (rend <= w0) continue;
+        if (valid && p >= apos && p < rend) {
+            const uint8_t b = R.bases[a.qbase + p];
+            const uint8_t q = R.quals[a.qbase + p];
+            const int pcr_inc = ((a.dflag & 0x4) ? 1 : 0);
+            dp += 1; pcr += pcr_inc; umi += ((a.dflag & 0x1) ? 1 : 0);
+            qlen_s += rend - apos; xm_s += a.xm1500;
+            if (a.isize != 0) {
+                const int fl = imin(apos, a.mpos);
+                if (a.flag & 0x10) { li += imin(p - fl + 1, MAX_INSERT_SIZE); lidp += 1; }
+                else { ri += imin(fl + abs(a.isize) - p, MAX_INSERT_SIZE); ridp += 1; }
+            }
+            if (b != my_ref) snv_dnv_scatter(R, R.bases + a.seq_off, (int)(a.qbase + p - a.seq_off), a.l_qseq, apos, rend, p);
+            if (q >= P.bias_thres_highBQ) {
+                ldist += p - apos + 1; rdist += rend - p;
+                lbaq += (int)(my_baq - BAQ1(R, apos) + 1);
+                rbaq += (int)(BAQ1(R, rend - 1) - my_baq + 1);
+                hbq += 1;
+            }
+            if (p == apos && a.lclip_oplen > 0) clip_event(R, P, apos, a.m_index - 1, a.lclip_oplen, pcr_inc);
+            if (p == rend - 1 && a.rclip_oplen > 0) clip_event(R, P, rend, a.m_index + 1, a.rclip_oplen, pcr_inc);
+        }
+    }
+    if (!valid) return;
+    if (dp) atomicAdd(&P32(R, UVC_P_a_dp, x), dp);
+    if (pcr) atomicAdd(&P32(R, UVC_P_a_pcr_dp, x), pcr);
+    if (umi) atomicAdd(&P32(R, UVC_P_a_umi_dp, x), umi);
+    if (qlen_s) atomicAdd(&P32(R, UVC_P_a_qlen, x), qlen_s);
+    if (xm_s) atomicAdd(&P32(R, UVC_P_a_XM1500, x), xm_s);
+    if (lidp) { atomicAdd(&P32(R, UVC_P_a_LIDP, x), lidp); add64(&P64(R, UVC_P_a_LI, x), li); }
+    if (ridp) { atomicAdd(&P32(R, UVC_P_a_RIDP, x), ridp); add64(&P64(R, UVC_P_a_RI, x), ri); }
+    if (hbq) {
+        atomicAdd(&P32(R, UVC_P_a_highBQ_dp, x), hbq);
+        atomicAdd(&P32(R, UVC_P_a_l_dist_sum, x), ldist); atomicAdd(&P32(R, UVC_P_a_r_dist_sum, x), rdist);
+        add64(&P64(R, UVC_P_a_l_BAQ_sum, x), lbaq); add64(&P64(R, UVC_P_a_r_BAQ_sum, x), rbaq);
+    }
+}
+
+// sequential P1 for one alignment whose CIGAR has InDels / unusual clip layouts
+__global__ void __launch_bounds__(64) k_prep_slow(RegionDev R, UvcParams P) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= R.n_complex) return;
+    const AlnRec a = R.alns[R.complex_ids[t]];
+    const uint32_t *cigar = R.cigars + a.cigar_off;
+    const uint8_t *bases = R.bases + a.seq_off, *quals = R.quals + a.seq_off;
+    const int off = R.beg, rend = a.rend;
+    const long long baq_last = R.end - 1;
+    int nge = 0, ngo = 0, insbaq_sum = 0, delbaq_sum = 0, inslen_sum = 0, dellen_sum = 0;
+    int qpos = 0, rpos = a.pos;
+    for (int i = 0; i < a.n_cigar; i++) {
+        const int op = cig_op(cigar[i]), len = cig_len(cigar[i]);
+        if (C_INS == op) { nge += len; ngo++; insbaq_sum += (int)(BAQ1(R, lmin((long long)rpos + len, baq_last)) - BAQ1(R, rpos)); inslen_sum += len; qpos += len; }
+        else if (C_DEL == op) { nge += len; ngo++; delbaq_sum += (int)(BAQ1(R, lmin((long long)rpos + len, baq_last)) - BAQ1(R, rpos)); dellen_sum += len; rpos += len; }
+        else if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) { qpos += len; rpos += len; }
+        else if (op == C_REF_SKIP) rpos += len;
+        else if (op == C_SOFT_CLIP) qpos += len;
+    }
+    const int qlen = rend - a.pos;
+    const int xm1500 = a.xm1500, go1500 = a.go1500;
+    const int avg_gaplen = nge / imax(1, ngo);
+    const int frag_pos_L = imin(a.pos, a.mpos), frag_pos_R = frag_pos_L + abs(a.isize);
+    const bool isrc = (a.flag & 0x10) != 0;
+    const int pcr_dp_inc = ((a.dflag & 0x4) ? 1 : 0), umi_dp_inc = ((a.dflag & 0x1) ? 1 : 0);
+    const int atd = P.indel_adj_tracklen_dist;
+    const int nrtr = (int)R.npos;
+    qpos = 0; rpos = a.pos;
+    for (int i = 0; i < a.n_cigar; i++) {
+        const int op = cig_op(cigar[i]), len = cig_len(cigar[i]);
+        if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) {
+            for (int j = 0; j < len; j++) {
+                const int64_t x = rpos - off;
+                if (pcr_dp_inc) atomicAdd(&P32(R, UVC_P_a_pcr_dp, x), pcr_dp_inc);
+                if (umi_dp_inc) atomicAdd(&P32(R, UVC_P_a_umi_dp, x), umi_dp_inc);
+                atomicAdd(&P32(R, UVC_P_a_dp, x), 1);
+                atomicAdd(&P32(R, UVC_P_a_qlen, x), qlen);
+                atomicAdd(&P32(R, UVC_P_a_XM1500, x), xm1500);
+                atomicAdd(&P32(R, UVC_P_a_GO1500, x), go1500);
+                atomicAdd(&P32(R, UVC_P_a_GAPLEN, x), avg_gaplen);
+                if (a.isize != 0) {
+                    if (isrc) { add64(&P64(R, UVC_P_a_LI, x), imin(rpos - frag_pos_L + 1, MAX_INSERT_SIZE)); atomicAdd(&P32(R, UVC_P_a_LIDP, x), 1); }
+                    else      { add64(&P64(R, UVC_P_a_RI, x), imin(frag_pos_R - rpos, MAX_INSERT_SIZE));     atomicAdd(&P32(R, UVC_P_a_RIDP, x), 1); }
+                }
+                snv_dnv_scatter(R, bases, qpos, a.l_qseq, a.pos, rend, rpos);
+                if (quals[qpos] >= P.bias_thres_highBQ) {
+                    atomicAdd(&P32(R, UVC_P_a_l_dist_sum, x), rpos - a.pos + 1);
+                    atomicAdd(&P32(R, UVC_P_a_r_dist_sum, x), rend - rpos);
+                    atomicAdd(&P32(R, UVC_P_a_inslen_sum, x), inslen_sum);
+                    atomicAdd(&P32(R, UVC_P_a_dellen_sum, x), dellen_sum);
+                    add64(&P64(R, UVC_P_a_l_BAQ_sum, x), (int)(BAQ1(R, rpos) - BAQ1(R, a.pos) + 1));
+                    add64(&P64(R, UVC_P_a_r_BAQ_sum, x), (int)(BAQ1(R, rend - 1) - BAQ1(R, rpos) + 1));
+                    add64(&P64(R, UVC_P_a_insBAQ_sum, x), insbaq_sum);
+                    add64(&P64(R, UVC_P_a_delBAQ_sum, x), delbaq_sum);
+                    atomicAdd(&P32(R, UVC_P_a_highBQ_dp, x), 1);
+                }
+                qpos++; rpos++;
+            }
+        } else if (op == C_INS || op == C_DEL) {
+            const int i1 = imax(atd, rpos - off) - atd, i2 = imin(rpos - off + atd, nrtr - 1);
+            const int t1 = RTRP(R, UVC_RTR_tracklen, i1), t2 = RTRP(R, UVC_RTR_tracklen, i2);
+            const int unitlen2 = imax(1, (t1 > t2) ? RTRP(R, UVC_RTR_unitlen, i1) : RTRP(R, UVC_RTR_unitlen, i2));
+            const int rtr_lo = imax((off + RTRP(R, UVC_RTR_begpos, i1)) - atd, a.pos);
+            const int rtr_hi = imin((off + RTRP(R, UVC_RTR_begpos, i2) + t2) + atd, rend);
+            const int inv100 = (int)(100u / ((0 == (unsigned)len % (unsigned)unitlen2) ? ((unsigned)len / (unsigned)unitlen2) : 4u));
+            if (op == C_INS) {
+                const int nbases = (int)((unsigned)len * (unsigned)P.indel_adj_indellen_perc / 100u);
+                for (int r2 = imax(rpos - nbases, a.pos); r2 < imin(rpos + nbases, rend); r2++) {
+                    const int64_t x = r2 - off;
+                    atomicAdd(&P32(R, UVC_P_a_near_ins_dp, x), 1);
+                    add64(&P64(R, UVC_P_a_near_ins_pow2len, x), (long long)((unsigned)len * (unsigned)len));
+                    add64(&P64(R, UVC_P_a_near_ins_l_pow2len, x), (long long)(r2 + 1 - (rpos - nbases)) * (r2 + 1 - (rpos - nbases)));
+                    add64(&P64(R, UVC_P_a_near_ins_r_pow2len, x), (long long)((rpos + nbases) - r2) * ((rpos + nbases) - r2));
+                    atomicAdd(&P32(R, UVC_P_a_near_ins_inv100len, x), inv100);
+                }
+                for (int r2 = rtr_lo; r2 < rtr_hi; r2++) atomicAdd(&P32(R, UVC_P_a_near_RTR_ins_dp, r2 - off), 1);
+                atomicAdd(&P32(R, UVC_P_a_at_ins_dp, rpos - off), 1);
+                qpos += len;
+            } else {
+                for (int r2 = rpos; r2 < rpos + len; r2++) {
+                    const int64_t x = r2 - off;
+                    if (pcr_dp_inc) atomicAdd(&P32(R, UVC_P_a_pcr_dp, x), pcr_dp_inc);
+                    if (umi_dp_inc) atomicAdd(&P32(R, UVC_P_a_umi_dp, x), umi_dp_inc);
+                    atomicAdd(&P32(R, UVC_P_a_dp, x), 1);
+                    atomicAdd(&P32(R, UVC_P_a_qlen, x), qlen);
+                    atomicAdd(&P32(R, UVC_P_a_highBQ_dp, x), 1);
+                    atomicAdd(&P32(R, UVC_P_a_XM1500, x), xm1500);
+                    atomicAdd(&P32(R, UVC_P_a_GO1500, x), go1500);
+                    atomicAdd(&P32(R, UVC_P_a_GAPLEN, x), avg_gaplen);
+                    if (a.isize != 0) {   // sic: the deletion start rpos, not r2 (main.hpp:1137-1145)
+                        if (isrc) { add64(&P64(R, UVC_P_a_LI, x), imin(rpos - frag_pos_L + 1, MAX_INSERT_SIZE)); atomicAdd(&P32(R, UVC_P_a_LIDP, x), 1); }
+                        else      { add64(&P64(R, UVC_P_a_RI, x), imin(frag_pos_R - rpos, MAX_INSERT_SIZE));     atomicAdd(&P32(R, UVC_P_a_RIDP, x), 1); }
+                    }
+                    atomicAdd(&P32(R, UVC_P_a_l_dist_sum, x), rpos - a.pos + 1);
+                    atomicAdd(&P32(R, UVC_P_a_r_dist_sum, x), rend - rpos);
+                    atomicAdd(&P32(R, UVC_P_a_inslen_sum, x), inslen_sum);
+                    atomicAdd(&P32(R, UVC_P_a_dellen_sum, x), dellen_sum);
+                    add64(&P64(R, UVC_P_a_l_BAQ_sum, rpos - off), (int)(BAQ1(R, rpos) - BAQ1(R, a.pos) + 1));   // sic: at rpos (main.hpp:1156-1157)
+                    add64(&P64(R, UVC_P_a_r_BAQ_sum, rpos - off), (int)(BAQ1(R, rend - 1) - BAQ1(R, rpos) + 1));
+                    add64(&P64(R, UVC_P_a_insBAQ_sum, x), insbaq_sum);
+                    add64(&P64(R, UVC_P_a_delBAQ_sum, x), delbaq_sum);
+                }
+                const int nbases_l = (int)((unsigned)len * (unsigned)(P.indel_adj_indellen_perc - 100) / 100u);
+                const int nbases_r = (int)((unsigned)len * (unsigned)P.indel_adj_indellen_perc / 100u);
+                const int lpos = imax(rpos - nbases_l, a.pos), rpos_r = imin(rpos + nbases_r, rend) - 1;
+                for (int r2 = lpos; r2 <= rpos_r; r2++) {
+                    const int64_t x = r2 - off;
+                    atomicAdd(&P32(R, UVC_P_a_near_del_dp, x), 1);
+                    add64(&P64(R, UVC_P_a_near_del_pow2len, x), (long long)((unsigned)len * (unsigned)len));
+                    add64(&P64(R, UVC_P_a_near_del_l_pow2len, x), (long long)(r2 - lpos + 1) * (r2 - lpos + 1));
+                    add64(&P64(R, UVC_P_a_near_del_r_pow2len, x), (long long)(rpos_r - r2 + 1) * (rpos_r - r2 + 1));
+                    atomicAdd(&P32(R, UVC_P_a_near_del_inv100len, x), inv100);
+                }
+                for (int r2 = rtr_lo; r2 < rtr_hi; r2++) atomicAdd(&P32(R, UVC_P_a_near_RTR_del_dp, r2 - off), 1);
+                atomicAdd(&P32(R, UVC_P_a_at_del_dp, rpos - off), 1);
+                rpos += len;
+            }
+        } else {
+            if (C_SOFT_CLIP == op || C_HARD_CLIP == op) clip_event(R, P, rpos, i, len, pcr_dp_inc);
+            if (op == C_REF_SKIP) rpos += len; else if (op == C_SOFT_CLIP) qpos += len;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// P1b (update_seg_format_thres_from_prep_sets, main.hpp:1206-1299)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_thres(RegionDev R, UvcParams P, int half_ratio_phred) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= R.npos) return;
+    const bool is_normal = P.tumor_vcf_is_provided;
+    const int segLIDP = imax(P32(R, UVC_P_a_LIDP, x), 1), segRIDP = imax(P32(R, UVC_P_a_RIDP, x), 1);
+    const int ins_dp = P32(R, UVC_P_a_near_ins_dp, x), del_dp = P32(R, UVC_P_a_near_del_dp, x);
+    const double ins_l = ceil(sqrt((double)(P64(R, UVC_P_a_near_ins_l_pow2len, x) / imax(ins_dp, 1))));
+    const double del_l = ceil(sqrt((double)(P64(R, UVC_P_a_near_del_l_pow2len, x) / imax(del_dp, 1))));
+    const double ins_r = ceil(sqrt((double)(P64(R, UVC_P_a_near_ins_r_pow2len, x) / imax(ins_dp, 1))));
+    const double del_r = ceil(sqrt((double)(P64(R, UVC_P_a_near_del_r_pow2len, x) / imax(del_dp, 1))));
+    const int dnv_border = ((UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform && (P32(R, UVC_P_a_dnv_dp, x) * 2 > P32(R, UVC_P_a_snv_dp, x))) ? 10 : 0);
+    TH(R, UVC_T_aLPxT, x) = (int)(fmax(ins_l, fmax(del_l, (double)dnv_border)) + P.bias_thres_aLPxT_add);
+    TH(R, UVC_T_aRPxT, x) = (int)(fmax(ins_r, fmax(del_r, (double)dnv_border)) + P.bias_thres_aLPxT_add);
+    int ip = RTRP(R, UVC_RTR_indelphred, x);
+    if (ins_dp * P.indel_del_to_ins_err_ratio < del_dp) ip += half_ratio_phred;
+    if (del_dp * P.indel_del_to_ins_err_ratio < ins_dp) ip -= half_ratio_phred;
+    const int pc_inc1 = (int)(3 * 100 * imax(1, ins_dp + del_dp) / (imax(1, P32(R, UVC_P_a_near_ins_inv100len, x) + P32(R, UVC_P_a_near_del_inv100len, x)))) - 3;
+    ip += ibetween(pc_inc1, 0, 6);
+    RTRP(R, UVC_RTR_indelphred, x) = imax(ip, 0);
+    const int p1T = (is_normal ? P.bias_thres_aLRI1NT_perc : P.bias_thres_aLRI1T_perc), p1t = (is_normal ? P.bias_thres_aLRI1Nt_perc : P.bias_thres_aLRI1t_perc);
+    const long long LI = P64(R, UVC_P_a_LI, x), RI = P64(R, UVC_P_a_RI, x);
+    TH(R, UVC_T_aLI1T, x) = (int)(LI * p1T / (segLIDP * 100) + P.bias_thres_aLRI1T_add);
+    TH(R, UVC_T_aLI2T, x) = (int)(LI * P.bias_thres_aLRI2T_perc / (segLIDP * 100) + P.bias_thres_aLRI2T_add);
+    TH(R, UVC_T_aLI1t, x) = (int)(LI * p1t / (segLIDP * 100));
+    TH(R, UVC_T_aLI2t, x) = (int)(LI * P.bias_thres_aLRI2t_perc / (segLIDP * 100));
+    TH(R, UVC_T_aRI1T, x) = (int)(RI * p1T / (segRIDP * 100) + P.bias_thres_aLRI1T_add);
+    TH(R, UVC_T_aRI2T, x) = (int)(RI * P.bias_thres_aLRI2T_perc / (segRIDP * 100) + P.bias_thres_aLRI2T_add);
+    TH(R, UVC_T_aRI1t, x) = (int)(RI * p1t / (segRIDP * 100));
+    TH(R, UVC_T_aRI2t, x) = (int)(RI * P.bias_thres_aLRI2t_perc / (segRIDP * 100));
+    const int pP1 = (is_normal ? P.bias_thres_aLRP1Nt_avgmul_perc : P.bias_thres_aLRP1t_avgmul_perc), pP2 = P.bias_thres_aLRP2t_avgmul_perc;
+    const int pB1 = (is_normal ? P.bias_thres_aLRB1Nt_avgmul_perc : P.bias_thres_aLRB1t_avgmul_perc), pB2 = P.bias_thres_aLRB2t_avgmul_perc;
+    const int hb = P32(R, UVC_P_a_highBQ_dp, x);
+    const long long den = imax(1, hb * 100);
+    const long long lds = P32(R, UVC_P_a_l_dist_sum, x), rds = P32(R, UVC_P_a_r_dist_sum, x);
+    TH(R, UVC_T_aLP1t, x) = (int)nnminus(lds * pP1 / den, P.bias_thres_aLRP1t_minus);
+    TH(R, UVC_T_aLP2t, x) = (int)nnminus(lds * pP2 / den, P.bias_thres_aLRP2t_minus);
+    TH(R, UVC_T_aRP1t, x) = (int)nnminus(rds * pP1 / den, P.bias_thres_aLRP1t_minus);
+    TH(R, UVC_T_aRP2t, x) = (int)nnminus(rds * pP2 / den, P.bias_thres_aLRP2t_minus);
+    const long long pdel = P64(R, UVC_P_a_delBAQ_sum, x) / imax(1, hb);
+    const long long lb = P64(R, UVC_P_a_l_BAQ_sum, x), rb = P64(R, UVC_P_a_r_BAQ_sum, x);
+    TH(R, UVC_T_aLB1t, x) = (int)nnminus(lb * pB1 / den, P.bias_thres_aLRB1t_minus + pdel);
+    TH(R, UVC_T_aLB2t, x) = (int)nnminus(lb * pB2 / den, P.bias_thres_aLRB2t_minus);
+    TH(R, UVC_T_aRB1t, x) = (int)nnminus(rb * pB1 / den, P.bias_thres_aLRB1t_minus + pdel);
+    TH(R, UVC_T_aRB2t, x) = (int)nnminus(rb * pB2 / den, P.bias_thres_aLRB2t_minus);
+}
+
+// ------------------------------------------------------------------------------------------------
+// contribution of a SIMPLE alignment at reference position p (BASE_QUALITY_MAX values, no bias)
+// main.hpp:1918-1924 (LINK_M), 1949-1980 (base)
+// ------------------------------------------------------------------------------------------------
+DEV int simple_link_value(const RegionDev &R, const UvcParams &P, const AlnRec &a, int p, const uint8_t *quals_qbase, bool proton) {
+    const int64_t x = p - R.beg;
+    const int noindel = imin(RTRP(R, UVC_RTR_indelphred, x - 1), RTRP(R, UVC_RTR_indelphred, x));
+    const int qfromBQ2 = (proton ? imin((int)quals_qbase[p - 1], (int)quals_qbase[p]) : 80);
+    return (int)nnminus(imin(qfromBQ2, noindel), a.nogap_penal) + 1;
+}
+DEV int simple_base_value(const UvcParams &P, const AlnRec &a, int p, const uint8_t *quals_qbase, bool proton) {
+    const int q = quals_qbase[p];
+    if (proton) {
+        const int i2 = p - a.pos, len = a.rend - a.pos;
+        if ((0 == i2) || (len - 1 == i2)) {
+            // packed neighbouring cigar words never equal the bare op codes (main.hpp:1953-1956), so both flags hold at the op ends
+            const bool next_gap = (len - 1 == i2), prev_gap = (0 == i2);
+            const bool isrc2 = (0 != i2);
+            const int qpos = (int)(p - a.pos) + a.lclip_q;
+            int prev_base_phred = 1;
+            if (isrc2 && (qpos + 1 < a.l_qseq)) prev_base_phred = quals_qbase[p + 1];
+            if ((!isrc2) && (qpos > 0)) prev_base_phred = quals_qbase[p - 1];
+            int adj = 100;
+            if (next_gap) adj = imin(adj, (a.rclip_oplen > 0 ? a.rclip_oplen : 100));
+            if (prev_gap) adj = imin(adj, (a.lclip_oplen > 0 ? a.lclip_oplen : 100));
+            if (adj < 3) return imin(q, prev_base_phred) + imin(P.bq_phred_added_misma, P.bq_phred_added_indel);
+            return imin(q, prev_base_phred) + P.bq_phred_added_misma;
+        }
+    }
+    return q + P.bq_phred_added_misma;
+}
+
+// ------------------------------------------------------------------------------------------------
+// P2 fast: updateByAln<SYMBOL_COUNT_SUM, bias> for simple alignments, one lane per position
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_uniform((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int64_t x0 = (int64_t)wave * 64;
+    if (x0 >= R.npos) return;
+    const int w0 = R.beg + (int)x0;
+    const int p = w0 + lane;
+    const int64_t x = x0 + lane;
+    const bool valid = x < R.npos;
+    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    const bool normal_filter_primers = (P.tn_is_paired && (0x1 & P.primer_flag));
+    const int my_ref = valid ? R.refsym[x] : 0;
+    PosThres T;
+    long long baq_p = 0, baq2_p = 0;
+    if (valid) { load_thres(R, T, x); baq_p = R.baq[x]; baq2_p = R.baq[R.npos + x]; }
+    else { for (int f = 0; f < UVC_NTHRES; f++) T.t[f] = 0; }
+    SegAcc Aref, Alink;
+    Aref.zero(); Alink.zero();
+    const int lo = wave_uniform(lower_bound_pos(R.fast, R.n_fast, w0 - R.max_aln_span + 1));
+    const int hi = wave_uniform(lower_bound_pos(R.fast, R.n_fast, w0 + 64));
+    for (int k = lo; k < hi; k++) {
+        const AlnRec &a = R.fast[k];
+        if (a.rend <= w0) continue;
+        const SegRead sr = make_segread(R, a);
+        const bool is_assay_amplicon = ((a.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag)));
+        int ibeg, iend;
+        primer_window(P, a, ibeg, iend);
+        if (valid && p >= a.pos && p < a.rend && ((normal_filter_primers || !is_assay_amplicon) || (ibeg <= p && p < iend))) {
+            const uint8_t *qq = R.quals + a.qbase;
+            if (p > a.pos) {
+                const int inc = simple_link_value(R, P, a, p, qq, proton);
+                Alink.bq += inc;
+                segbias<true>(Alink, P, sr, T, p, baq_p, baq2_p, inc, 0, C_MATCH, 0, 10000);
+            }
+            const int sym = R.bases[a.qbase + p];
+            const int inc = simple_base_value(P, a, p, qq, proton);
+            if (sym == my_ref) {
+                Aref.bq += inc;
+                segbias<false>(Aref, P, sr, T, p, baq_p, baq2_p, inc, a.bm1500[sym], C_MATCH, 0, 10000);
+            } else {
+                SegAcc A; A.zero();
+                A.bq = inc;
+                segbias<false>(A, P, sr, T, p, baq_p, baq2_p, inc, a.bm1500[sym], C_MATCH, 0, 10000);
+                seg_flush(R, A, sym, x);
+            }
+        }
+    }
+    if (!valid) return;
+    seg_flush(R, Aref, my_ref, x);
+    seg_flush(R, Alink, UVC_LINK_M, x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// sequential updateByAln for one complex alignment (main.hpp:1762-2296).
+//   BIAS = true : SYMBOL_COUNT_SUM + dealwith_segbias, flushed with atomics (P2)
+//   BIAS = false: BASE_QUALITY_MAX values written to the contribution table (used by P3/P4/P5)
+// ------------------------------------------------------------------------------------------------
+DEV int indel_len_rusize_phred_dev(int indel_len, int repeatunit_size) {   // main.hpp:757-790
+    const int t[19] = { 0, 0, 3, 5, 6, 7, 8, 8, 9, 10, 10, 10, 11, 11, 11, 12, 12, 12, 13 };
+    if (0 == (indel_len % repeatunit_size)) return t[imin(indel_len / repeatunit_size, 18)];
+    return t[imin(indel_len, 18)];
+}
+DEV int indel_phred_dev(double ampfact, int rs, int rn) {   // main.hpp:794-801
+    const int region_size = rs * rn;
+    const double num_slips = (region_size > 64 ? (double)(region_size - 8) : log1p(exp((double)region_size - (double)8))) * ampfact / ((double)(rs * rs));
+    const double pr = (1.0 - 2.220446049250313e-16) / (num_slips + 1.0);
+    return (int)floor(-10 * log(pr) / log(10.0));
+}
+DEV bool more_STR(int rulen1, int rc1, int rulen2, int rc2, int strmax) {   // is_indel_context_more_STR, main.hpp:699-721
+    if (rulen2 * rc2 == 0) return true;
+    if (rulen1 > strmax || rulen2 > strmax) return (rulen1 < rulen2 || (rulen1 == rulen2 && rc1 > rc2));
+    int rank1 = (rc1 <= 1 ? (-rc1 * rulen1) : ((rc1 - 1) * rulen1));
+    int rank2 = (rc2 <= 1 ? (-rc2 * rulen1) : ((rc2 - 1) * rulen2));
+    if (0 == rc1 || 0 == rulen1) rank1 = -100;
+    if (0 == rc2 || 0 == rulen2) rank2 = -100;
+    return rank1 > rank2;
+}
+DEV int ref_to_phredvalue_dev(int &n_units, int &max_rn, int &rs_at_max, const RegionDev &R, const UvcParams &P, int refidx, int max_phred, double ampfact, int oplen, int op) {   // main.hpp:876-922
+    const int n = (int)R.npos - 1;   // refstring.size()
+    max_rn = 0; rs_at_max = 0;
+    for (int rs = 1; rs <= P.indel_str_repeatsize_max; rs++) {
+        int q = refidx;
+        while (q + rs < n && R.refsym[q] == R.refsym[q + rs]) q++;
+        const int rn = (q - refidx) / rs + 1;
+        if (more_STR(rs, rn, rs_at_max, max_rn, P.indel_str_repeatsize_max)) { max_rn = rn; rs_at_max = rs; }
+    }
+    if (oplen == rs_at_max && op == C_DEL) ampfact *= P.indel_del_to_ins_err_ratio;
+    const int decphred = indel_phred_dev(ampfact, rs_at_max, max_rn);
+    if (rs_at_max * (max_rn - 1) >= 6 - 1) n_units = ((0 == oplen % rs_at_max) ? (oplen / rs_at_max) : ((1 == oplen) ? 1 : 0));
+    else n_units = 1 + (oplen / 6);
+    return max_phred - imin(max_phred, decphred) + indel_len_rusize_phred_dev(oplen, rs_at_max);
+}
+DEV int proton_cigarlen2phred(int cigarlen) { const int t[13] = { 0, 0, 9, 14, 18, 21, 23, 25, 27, 29, 30, 31, 32 }; return t[imin(cigarlen, 12)]; }
+
+DEV void table_put(const RegionDev &R, Contrib *row, int sym, int v) {
+    const uint8_t vv = (uint8_t)imin(v, 255);
+    if (sym <= UVC_BASE_NN) {
+        if (row->bsym == 0xFF || row->bsym == sym) { row->bval = (row->bsym == sym) ? (uint8_t)imax(row->bval, vv) : vv; row->bsym = (uint8_t)sym; }
+        else atomicExch(R.err, UVCGPU_EUNSUPPORTED);
+        return;
+    }
+    uint8_t *s[3] = { &row->l1sym, &row->l2sym, &row->l3sym };
+    uint8_t *q[3] = { &row->l1val, &row->l2val, &row->l3val };
+    for (int k = 0; k < 3; k++) {
+        if (*s[k] == sym) { *q[k] = (uint8_t)imax(*q[k], vv); return; }
+        if (*s[k] == 0xFF) { *s[k] = (uint8_t)sym; *q[k] = vv; return; }
+    }
+    atomicExch(R.err, UVCGPU_EUNSUPPORTED);   // more than three LINK symbols at one position of one read
+}
+
+template <bool BIAS>
+__global__ void __launch_bounds__(64) k_p2_slow(RegionDev R, UvcParams P) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= R.n_complex) return;
+    const AlnRec a = R.alns[R.complex_ids[t]];
+    const uint32_t *cigar = R.cigars + a.cigar_off;
+    const uint8_t *bases = R.bases + a.seq_off, *quals = R.quals + a.seq_off;
+    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    const int off = R.beg, rend = a.rend, n_cigar = a.n_cigar;
+    const bool is_assay_amplicon = ((a.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag)));
+    const bool normal_filter_primers = (P.tn_is_paired && (0x1 & P.primer_flag));
+    const int addMis = P.bq_phred_added_misma, addInd = P.bq_phred_added_indel;
+    const SegRead sr = make_segread(R, a);
+    Contrib *table = BIAS ? nullptr : (R.table + a.table_off);
+    auto Q = [&](int q) -> int { return (int)quals[imin(imax(q, 0), a.l_qseq - 1)]; };
+    auto emit = [&](bool gap, int epos, int sym, int v, int bm, int op, int indel_len, int dist) {
+        if (BIAS) {
+            SegAcc A; A.zero(); A.bq = v;
+            PosThres T; load_thres(R, T, epos - off);
+            if (gap) segbias<true>(A, P, sr, T, epos, BAQ1(R, epos), BAQ2(R, epos), v, bm, op, indel_len, dist);
+            else     segbias<false>(A, P, sr, T, epos, BAQ1(R, epos), BAQ2(R, epos), v, bm, op, indel_len, dist);
+            seg_flush(R, A, sym, epos - off);
+        } else table_put(R, table + (epos - a.pos), sym, v);
+    };
+    // low-BQ InDel positions (main.hpp:1817-1859); at most 16 tracked, more => unsupported
+    int indel_rposs[18]; int n_ir = 0; indel_rposs[n_ir++] = 0;
+    int nge = 0;
+    {
+        int qpos = 0, rpos = a.pos;
+        for (int i = 0; i < n_cigar; i++) {
+            const int op = cig_op(cigar[i]), len = cig_len(cigar[i]);
+            if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) { qpos += len; rpos += len; }
+            else if (op == C_INS) {
+                nge += len;
+                bool low = false;
+                for (int q2 = qpos - imin(qpos, 1); q2 < imin(qpos + len + 1, rend); q2++) if (Q(q2) < P.bias_thres_interfering_indel_BQ) low = true;
+                if (low) { if (n_ir < 17) indel_rposs[n_ir++] = rpos; else atomicExch(R.err, UVCGPU_EUNSUPPORTED); }
+                qpos += len;
+            } else if (op == C_DEL) {
+                nge += len;
+                const bool low = (imin(Q(imax(1, qpos) - 1), Q(qpos)) <= P.bias_thres_interfering_indel_BQ);
+                if (low) { if (n_ir < 17) indel_rposs[n_ir++] = rpos; else atomicExch(R.err, UVCGPU_EUNSUPPORTED); }
+                rpos += len;
+            } else if (op == C_REF_SKIP) rpos += len;
+            else if (op == C_SOFT_CLIP) qpos += len;
+        }
+        indel_rposs[n_ir++] = INT32_MAX;
+    }
+    int ir_idx = 0;
+    int ibeg, iend;
+    primer_window(P, a, ibeg, iend);
+    const int atd = P.indel_adj_tracklen_dist, nrtr = (int)R.npos;
+    const int xm1500 = a.xm1500;
+    int qpos = 0, rpos = a.pos, incvalue = 1;
+    for (int i = 0; i < n_cigar; i++) {
+        const int op = cig_op(cigar[i]), len = cig_len(cigar[i]);
+        if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) {
+            for (int i2 = 0; i2 < len; i2++) {
+                if ((normal_filter_primers || !is_assay_amplicon) || (ibeg <= rpos && rpos < iend)) {
+                    int dist = 10000;
+                    if (BIAS && nge > 0) {
+                        if (indel_rposs[ir_idx] <= rpos) ir_idx++;
+                        const int prev_ir = indel_rposs[ir_idx - 1], next_ir = indel_rposs[ir_idx];
+                        const int i1 = imax(rpos - off, atd) - atd, i2r = imin(rpos - off + atd, nrtr - 1);
+                        const long long prevlen = nnminus(rpos - prev_ir, imax(rpos - (off + RTRP(R, UVC_RTR_begpos, i1)), TH(R, UVC_T_aLP1t, rpos - off)));
+                        const long long nextlen = nnminus((long long)next_ir - rpos, imax((off + RTRP(R, UVC_RTR_begpos, i2r) + RTRP(R, UVC_RTR_tracklen, i2r)) - rpos, TH(R, UVC_T_aRP1t, rpos - off)));
+                        dist = (int)lmin(prevlen, nextlen);
+                    }
+                    if (i2 > 0) {
+                        const int noindel = imin(RTRP(R, UVC_RTR_indelphred, rpos - off - 1), RTRP(R, UVC_RTR_indelphred, rpos - off));
+                        const int qfromBQ2 = (proton ? imin(Q(qpos - 1), Q(qpos)) : 80);
+                        incvalue = (int)nnminus(imin(qfromBQ2, noindel), a.nogap_penal) + 1;
+                        emit(true, rpos, UVC_LINK_M, incvalue, 0, op, 0, dist);
+                    }
+                    const int symbol = bases[qpos];
+                    if (proton && ((0 == i2) || (len - 1 == i2))) {
+                        const bool next_gap = (len - 1 == i2), prev_gap = (0 == i2);   // packed words != op codes, main.hpp:1953-1956
+                        const bool isrc2 = (0 != i2);
+                        int prev_base_phred = 1;
+                        if (isrc2 && (qpos + 1 < a.l_qseq)) prev_base_phred = Q(qpos + 1);
+                        if ((!isrc2) && (qpos > 0)) prev_base_phred = Q(qpos - 1);
+                        int adj = 100;
+                        if (next_gap) adj = imin(adj, ((i + 1 < n_cigar) ? cig_len(cigar[i + 1]) : 100));
+                        if (prev_gap) adj = imin(adj, ((0 < i) ? cig_len(cigar[i - 1]) : 100));
+                        if (adj < 3) incvalue = imin(Q(qpos), prev_base_phred) + imin(addMis, addInd);
+                        else incvalue = imin(Q(qpos), prev_base_phred) + addMis;
+                    } else incvalue = Q(qpos) + addMis;
+                    emit(false, rpos, symbol, incvalue, a.bm1500[symbol], op, 0, dist);
+                }
+                rpos += 1; qpos += 1;
+            }
+        } else if (op == C_INS) {
+            if ((normal_filter_primers || !is_assay_amplicon) || (ibeg <= rpos && rpos < iend)) {
+                const int nbases2end = imin(qpos, a.l_qseq - (qpos + len));
+                int inslen = len;
+                if (nbases2end <= 0) {
+                    incvalue = (0 != qpos ? Q(qpos - 1) : ((qpos + len < a.l_qseq) ? Q(qpos + len) : 1)) + addInd;
+                } else {
+                    int max_rn, rs_at_max;
+                    int phredvalue = ref_to_phredvalue_dev(inslen, max_rn, rs_at_max, R, P, rpos - off, P.indel_BQ_max, P.indel_polymerase_slip_rate, len, op);
+                    const int64_t x = rpos - off;
+                    const int adp = P32(R, UVC_P_a_dp, x);
+                    const int phredinc = (int)round(2 * ((10.0 / log(10.0)) * log((double)adp / (double)(1.0 + nnminus(adp, P32(R, UVC_P_a_at_ins_dp, x) + P32(R, UVC_P_a_at_del_dp, x))))));
+                    const int ratiothres = (!P.tumor_vcf_is_provided ? 2 : 4);
+                    const bool multiallelic = (P64(R, UVC_P_a_near_ins_pow2len, x) * ratiothres > (long long)imax(1, P32(R, UVC_P_a_near_ins_dp, x)) * (long long)((unsigned)len * 3u));
+                    if (1 == inslen && !multiallelic) phredvalue += ibetween(phredinc - 3, 0, 4);
+                    const int thisdp = P32(R, UVC_P_a_at_ins_dp, x);
+                    const int neardp = imax(P32(R, UVC_P_a_near_ins_dp, x), P32(R, UVC_P_a_near_RTR_ins_dp, x));
+                    int insbase_minphred = 80;
+                    for (int q2 = qpos; q2 < qpos + len; q2++) insbase_minphred = imin(insbase_minphred, Q(q2));
+                    int ancbase_minphred = 80;
+                    if (qpos > 0) ancbase_minphred = imin(ancbase_minphred, Q(qpos - 1));
+                    if (qpos + len + 1 < a.l_qseq) ancbase_minphred = imin(ancbase_minphred, Q(qpos + len + 1));
+                    int minq = 80;
+                    if (proton && (1 == len) && (1 == rs_at_max) && (1 < max_rn))
+                        for (int qinc = 0; (qinc < max_rn + 2) && (qpos + qinc) < a.l_qseq; qinc++) if (bases[qpos + qinc] == bases[qpos]) minq = imin(minq, Q(qpos + qinc));
+                    const bool isrc = (a.flag & 0x10) != 0;
+                    const int qfromBQ1 = (proton ? imin(ancbase_minphred, minq) : imin(ancbase_minphred, insbase_minphred));
+                    const int qfromBQ2 = ((thisdp * ratiothres <= neardp || (1 == len && (xm1500 >= P.microadjust_xm
+                                 || ((a.lclip_len + P.microadjust_cliplen >= rpos - a.pos) && isrc) || ((a.rclip_len + P.microadjust_cliplen >= rend - a.pos) && !isrc))))
+                            ? qfromBQ1 : (proton ? imin(qfromBQ1 + proton_cigarlen2phred(len), imax(3, qfromBQ1) * len) : 80));
+                    incvalue = (int)nnminus(imin(qfromBQ2, phredvalue + addInd), a.indel_penal) + 1;
+                }
+                if (nbases2end >= P.indel_filter_edge_dist) {
+                    const int symbol = (1 == inslen ? UVC_LINK_I1 : ((2 == inslen) ? UVC_LINK_I2 : UVC_LINK_I3P));
+                    emit(true, rpos, symbol, imax(1, incvalue), 0, op, len, 10000);
+                }
+            }
+            qpos += len;
+        } else if (op == C_DEL) {
+            if ((normal_filter_primers || !is_assay_amplicon) || (ibeg <= rpos && rpos < iend)) {
+                const int nbases2end = imin(qpos, a.l_qseq - qpos);
+                int dellen = len;
+                if (nbases2end <= 0) {
+                    incvalue = (0 != qpos ? Q(qpos - 1) : ((qpos < a.l_qseq) ? Q(qpos) : 1)) + addInd;
+                } else {
+                    int max_rn, rs_at_max;
+                    int phredvalue = ref_to_phredvalue_dev(dellen, max_rn, rs_at_max, R, P, rpos - off, P.indel_BQ_max, P.indel_polymerase_slip_rate, len, op);
+                    const int64_t x = rpos - off;
+                    const int adp = P32(R, UVC_P_a_dp, x);
+                    const int phredinc = (int)round(2 * ((10.0 / log(10.0)) * log((double)adp / (double)(1.0 + nnminus(adp, P32(R, UVC_P_a_at_ins_dp, x) + P32(R, UVC_P_a_at_del_dp, x))))));
+                    if (1 == dellen) phredvalue += ibetween(phredinc - 3, 0, 4);
+                    const int thisdp = P32(R, UVC_P_a_at_del_dp, x);
+                    const int neardp = imax(P32(R, UVC_P_a_near_del_dp, x), P32(R, UVC_P_a_near_RTR_del_dp, x));
+                    int minq = 80;
+                    if (proton && (1 == len) && (1 == rs_at_max) && (1 < max_rn))
+                        for (int qinc = 0; qinc < (max_rn + 2) && (qpos + qinc) < a.l_qseq; qinc++) if (bases[qpos + qinc] == bases[qpos]) minq = imin(minq, Q(qpos + qinc));
+                    const int qfromBQ1 = imin(Q(qpos), imin(Q(qpos - 1), minq));
+                    const int ratiothres = (!P.tumor_vcf_is_provided ? 2 : 4);
+                    const int qfromBQ2 = ((thisdp * ratiothres <= neardp) ? (int)nnminus(qfromBQ1, 1) : (proton ? imin(qfromBQ1 + proton_cigarlen2phred(len), imax(3, qfromBQ1) * len) : 80));
+                    const double delFA = ((double)(thisdp + 0.5) / (double)(adp + 1));
+                    const int delFAQ = imax(0, P.microadjust_delFAQmax + (int)round(P.powlaw_exponent * ((10.0 / log(10.0)) * log(delFA))));
+                    int prev_cidx = i, prev_rpos = rpos;
+                    while ((0 != prev_cidx) && (C_INS != cig_op(cigar[prev_cidx]) || len != cig_len(cigar[prev_cidx]))) {
+                        prev_cidx--;
+                        const int o = cig_op(cigar[prev_cidx]);
+                        if (C_MATCH == o || C_EQUAL == o || C_DIFF == o || C_DEL == o || C_REF_SKIP == o) prev_rpos -= cig_len(cigar[prev_cidx]);
+                    }
+                    int next_cidx = i, next_rpos = rpos + len;
+                    while ((n_cigar - 1 != next_cidx) && (C_INS != cig_op(cigar[next_cidx]) || len != cig_len(cigar[next_cidx]))) {
+                        next_cidx++;
+                        const int o = cig_op(cigar[next_cidx]);
+                        if (C_MATCH == o || C_EQUAL == o || C_DIFF == o || C_DEL == o || C_REF_SKIP == o) next_rpos += cig_len(cigar[next_cidx]);
+                    }
+                    const int qfromBAQl = (int)(BAQ1(R, rpos) - BAQ1(R, prev_rpos));
+                    const int qfromBAQr = (int)(BAQ1(R, next_rpos) - BAQ1(R, rpos + len));
+                    const int qfromBAQ = imax(delFAQ, imax(qfromBQ1, imin(qfromBAQl, qfromBAQr)));
+                    incvalue = (int)nnminus(imin(qfromBQ2, imin(qfromBAQ, phredvalue + addInd)), a.indel_penal) + 1;
+                }
+                if (nbases2end >= P.indel_filter_edge_dist) {
+                    const int symbol = (1 == dellen ? UVC_LINK_D1 : ((2 == dellen) ? UVC_LINK_D2 : UVC_LINK_D3P));
+                    emit(true, rpos, symbol, imax(1, incvalue), 0, op, len, 10000);
+                    for (int r2 = rpos; r2 < imin(rpos + len, rend); r2++) {   // padded deletion, main.hpp:2219-2253
+                        for (int k = 0; k < 2; k++) {
+                            const int s = (k == 0 ? UVC_BASE_NN : UVC_LINK_NN);
+                            const int pp = ((UVC_BASE_NN == s) ? r2 : (r2 + 1));
+                            if (pp >= rend) continue;
+                            int dist = 0;
+                            if (BIAS) {
+                                if (indel_rposs[ir_idx] <= rpos) ir_idx++;
+                                const unsigned prev_ir = (unsigned)indel_rposs[ir_idx - 1], next_ir = (unsigned)indel_rposs[ir_idx];
+                                const unsigned d1 = (unsigned)rpos - prev_ir, d2 = next_ir - (unsigned)rpos;
+                                dist = (int)(d1 < d2 ? d1 : d2);
+                            }
+                            emit(true, pp, s, imax(1, incvalue), 0, op, len, dist);
+                        }
+                    }
+                }
+            }
+            rpos += len;
+        } else {
+            if (op == C_REF_SKIP) rpos += len; else if (op == C_SOFT_CLIP) qpos += len;
+        }
+    }
+}
+
+template __global__ void k_p2_slow<true>(RegionDev, UvcParams);
+template __global__ void k_p2_slow<false>(RegionDev, UvcParams);
+
+// ------------------------------------------------------------------------------------------------
+// contribution of ANY alignment at position p: simple ones are computed on the fly, complex ones
+// come from the table.  Values are merged into the per-fragment symbol counts with MAX.
+// ------------------------------------------------------------------------------------------------
+DEV void aln_contrib_max(const RegionDev &R, const UvcParams &P, const AlnRec &a, int p, bool proton, int *cnt /*[NSYM]*/) {
+    if (p < a.pos || p >= a.rend) return;
+    if (a.kind == 0) {
+        const bool is_assay_amplicon = ((a.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag)));
+        if (is_assay_amplicon && !(P.tn_is_paired && (0x1 & P.primer_flag))) {
+            int ibeg, iend; primer_window(P, a, ibeg, iend);
+            if (!(ibeg <= p && p < iend)) return;
+        }
+        const uint8_t *qq = R.quals + a.qbase;
+        if (p > a.pos) { const int v = simple_link_value(R, P, a, p, qq, proton); cnt[UVC_LINK_M] = imax(cnt[UVC_LINK_M], v); }
+        const int sym = R.bases[a.qbase + p];
+        const int v = simple_base_value(P, a, p, qq, proton);
+        cnt[sym] = imax(cnt[sym], v);
+    } else {
+        const Contrib c = R.table[a.table_off + (p - a.pos)];
+        if (c.bsym != 0xFF) cnt[c.bsym] = imax(cnt[c.bsym], (int)c.bval);
+        if (c.l1sym != 0xFF) cnt[c.l1sym] = imax(cnt[c.l1sym], (int)c.l1val);
+        if (c.l2sym != 0xFF) cnt[c.l2sym] = imax(cnt[c.l2sym], (int)c.l2val);
+        if (c.l3sym != 0xFF) cnt[c.l3sym] = imax(cnt[c.l3sym], (int)c.l3val);
+    }
+}
+
+DEV void frag_counts(const RegionDev &R, const UvcParams &P, const FragRec &f, int p, bool proton, int *cnt) {
+#pragma unroll
+    for (int s = 0; s < NSYM; s++) cnt[s] = 0;
+    for (int k = f.aln_beg; k < f.aln_end; k++) aln_contrib_max(R, P, R.alns[k], p, proton, cnt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_fragstat: per fragment, the counts of covered and near-mutation positions (main.hpp:2738-2756)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_fragstat(RegionDev R, UvcParams P) {
+    const int fi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (fi >= R.n_frags) return;
+    FragRec f = R.frags[fi];
+    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    const int nb = P.syserr_mut_region_n_bases;
+    int n_cov = 0, n_near = 0;
+    int last_mut = INT32_MIN / 2;      // last mutated position seen (for the backward half of the dilation)
+    // forward sweep: a covered position is "near" when a mutation lies within nb on either side.
+    // pending[] = covered positions within the last nb that are not yet known to be near.
+    int pend_cnt = 0, pend_first = 0;  // covered-but-not-near positions in (p - nb, p] form a contiguous tail: keep their count and oldest position
+    int tail[32]; int th = 0, tn = 0;   // ring of pending covered positions (nb <= 31 supported)
+    if (nb > 31) { atomicExch(R.err, UVCGPU_EUNSUPPORTED); return; }
+    int cnt[NSYM];
+    for (int p = f.beg; p < f.end; p++) {
+        frag_counts(R, P, f, p, proton, cnt);
+        bool covered = false, mut = false;
+        const int refsymbol = R.refsym[p - R.beg];
+        for (int vi = 0; vi < 2; vi++) {
+            const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
+            int cs, cc, ct;
+            fill_consensus(cnt, cs, cc, ct, st, st == UVC_LINK_SYMBOL, false);
+            if (0 == ct) continue;
+            covered = true;
+            const int con_qual = cc * 2 - ct;
+            const bool highBQ = (proton ? (UVC_BASE_SYMBOL == st || con_qual + 3 >= P.bias_thres_highBQ) : (UVC_LINK_SYMBOL == st || con_qual >= P.bias_thres_highBQ));
+            if (symbols_mutated(refsymbol, cs) && highBQ) mut = true;
+        }
+        // expire pending positions that can no longer be reached by a future mutation
+        while (tn > 0 && tail[th] < p - nb) { th = (th + 1) & 31; tn--; }
+        if (mut) { n_near += tn; tn = 0; last_mut = p; }          // everything pending within nb behind becomes near
+        if (covered) {
+            n_cov++;
+            if (p - last_mut <= nb) n_near++;                      // includes p == last_mut
+            else { tail[(th + tn) & 31] = p; tn++; }
+        }
+    }
+    (void)pend_cnt; (void)pend_first;
+    f.n_cov = n_cov; f.n_near = n_near;
+    R.frags[fi].n_cov = n_cov; R.frags[fi].n_near = n_near;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_frag: P3 + P3b for every fragment, and P4/P5 of singleton family-strand units.  One lane per
+// position; per-lane bucket histograms of the two dense symbols live in LDS, rare symbols use the
+// global bucket plane (each position has exactly one writer in this kernel).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
+    __shared__ int hist[256][2][NBUCKETS + 1];   // +1 pad: bank spread
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_uniform((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int64_t x0 = (int64_t)wave * 64;
+    if (x0 >= R.npos) return;
+    const int w0 = R.beg + (int)x0;
+    const int p = w0 + lane;
+    const int64_t x = x0 + lane;
+    const bool valid = x < R.npos;
+    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    const int my_ref = valid ? R.refsym[x] : 0;
+    for (int b = 0; b <= NBUCKETS; b++) { hist[threadIdx.x][0][b] = 0; hist[threadIdx.x][1][b] = 0; }
+    // avgBQ + 8 of the two dense symbols (get_avgBQ, main_conversion.hpp:791-796)
+    int maxq_ref = 8, maxq_link = 8;
+    if (valid) {
+        const int ad_r = S32(R, UVC_S_aDPff, my_ref, x) + S32(R, UVC_S_aDPfr, my_ref, x) + S32(R, UVC_S_aDPrf, my_ref, x) + S32(R, UVC_S_aDPrr, my_ref, x);
+        const int ad_l = S32(R, UVC_S_aDPff, UVC_LINK_M, x) + S32(R, UVC_S_aDPfr, UVC_LINK_M, x) + S32(R, UVC_S_aDPrf, UVC_LINK_M, x) + S32(R, UVC_S_aDPrr, UVC_LINK_M, x);
+        maxq_ref = 8 + BQS(R, my_ref, x) / imax(1, ad_r);
+        maxq_link = 8 + BQS(R, UVC_LINK_M, x) / imax(1, ad_l);
+    }
+    // dense accumulators: [strand][ref, link] x {bDP, bTA, bTB, cDP12, cDP21, cDP1}, bMQ x {ref, link}
+    int bDP[2][2] = {{0,0},{0,0}}, bTA[2][2] = {{0,0},{0,0}}, bTB[2][2] = {{0,0},{0,0}};
+    int c12[2][2] = {{0,0},{0,0}}, c21[2][2] = {{0,0},{0,0}}, c1[2][2] = {{0,0},{0,0}};
+    int bMQ[2] = {0, 0};
+    // fragments sorted by beg
+    int lo, hi;
+    {
+        int l = 0, h = R.n_frags;
+        const int key = w0 - R.max_frag_span + 1;
+        while (l < h) { int m = (l + h) >> 1; if (R.frags[R.frag_sorted[m]].beg < key) l = m + 1; else h = m; }
+        lo = wave_uniform(l);
+        l = lo; h = R.n_frags;
+        while (l < h) { int m = (l + h) >> 1; if (R.frags[R.frag_sorted[m]].beg < w0 + 64) l = m + 1; else h = m; }
+        hi = wave_uniform(l);
+    }
+    int cnt[NSYM];
+    for (int k = lo; k < hi; k++) {
+        const int fi = R.frag_sorted[k];
+        const FragRec &f = R.frags[fi];
+        if (f.end <= w0) continue;
+        if (!(valid && p >= f.beg && p < f.end)) continue;
+        frag_counts(R, P, f, p, proton, cnt);
+        const int strand = f.strand;
+        const int sq = (f.normMQ * f.normMQ) / SQR_QUAL_DIV;
+        for (int vi = 0; vi < 2; vi++) {
+            const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
+            int cs, cc, ct;
+            fill_consensus(cnt, cs, cc, ct, st, st == UVC_LINK_SYMBOL, false);
+            if (0 == ct) continue;
+            const int dense = (cs == my_ref ? 0 : (cs == UVC_LINK_M ? 1 : -1));
+            int max_qual;
+            if (dense == 0) max_qual = maxq_ref; else if (dense == 1) max_qual = maxq_link;
+            else {
+                const int ad = S32(R, UVC_S_aDPff, cs, x) + S32(R, UVC_S_aDPfr, cs, x) + S32(R, UVC_S_aDPrf, cs, x) + S32(R, UVC_S_aDPrr, cs, x);
+                max_qual = 8 + BQS(R, cs, x) / imax(1, ad);
+            }
+            const int con_qual = cc * 2 - ct;
+            int phredlike = imin(con_qual, max_qual);
+            if (0x1 & P.fam_flag) phredlike = imin(phredlike, sscs_phred(P, my_ref, cs));
+            const int pbucket = imax(0, max_qual - phredlike);
+            if (dense >= 0) {
+                if (pbucket < NBUCKETS) hist[threadIdx.x][dense][pbucket] += 1;
+                bDP[strand][dense] += 1; bTA[strand][dense] += f.n_cov; bTB[strand][dense] += f.n_near; bMQ[dense] += sq;
+            } else {
+                if (pbucket < NBUCKETS) BKP(R, 0, cs, pbucket, x) += 1;
+                FRP(R, strand, UVC_FRAG_bDP, cs, x) += 1; FRP(R, strand, UVC_FRAG_bTA, cs, x) += f.n_cov; FRP(R, strand, UVC_FRAG_bTB, cs, x) += f.n_near;
+                VQP(R, UVC_VQ_bMQ, cs, x) += sq;
+            }
+            // P4 / P5 of a singleton family-strand unit (identities derived in DESIGN.md section 4.5):
+            //   con = 1 vote for the fragment consensus when 2*max - tot passes the threshold (main.hpp:466-495),
+            //   mmm = 2*max - tot when positive (main.hpp:497-520); with one fragment tot_count <= 1.
+            if (f.singleton) {
+                int cs4, cc4, ct4;   // updateByFiltering uses fillConsensusCounts<true> for LINK and <false, padded?> for BASE
+                const bool padded_ignored = (P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0;
+                if (st == UVC_LINK_SYMBOL) { cs4 = cs; cc4 = cc; ct4 = ct; }
+                else fill_consensus(cnt, cs4, cc4, ct4, st, false, padded_ignored);
+                const int adj = imax(cc4 * 2, ct4) - ct4;
+                const int thr = (st == UVC_BASE_SYMBOL ? P.fam_thres_highBQ_snv : 0);
+                if (adj >= thr && adj > 0) {     // one vote -> cDP12 and cDP21 (tot_count == 1)
+                    const int d4 = (cs4 == my_ref ? 0 : (cs4 == UVC_LINK_M ? 1 : -1));
+                    if (d4 >= 0) { c12[strand][d4] += 1; c21[strand][d4] += 1; }
+                    else { FAP(R, strand, UVC_FAM_cDP12, cs4, x) += 1; FAP(R, strand, UVC_FAM_cDP21, cs4, x) += 1; }
+                }
+                // mmm uses fillConsensusCounts<true>/<false> without the padded-deletion exclusion
+                const int adj5 = imax(cc * 2, ct) - ct;
+                if (adj5 > 0 && P.inferred_is_vcf_generated) {
+                    if (dense >= 0) c1[strand][dense] += 1; else FAP(R, strand, UVC_FAM_cDP1, cs, x) += 1;
+                }
+            }
+        }
+    }
+    if (!valid) return;
+    // flush the dense accumulators (plain read-modify-write: one writer per position in this kernel)
+    for (int d = 0; d < 2; d++) {
+        const int sym = (d == 0 ? my_ref : UVC_LINK_M);
+        for (int s = 0; s < 2; s++) {
+            if (bDP[s][d]) { FRP(R, s, UVC_FRAG_bDP, sym, x) += bDP[s][d]; FRP(R, s, UVC_FRAG_bTA, sym, x) += bTA[s][d]; FRP(R, s, UVC_FRAG_bTB, sym, x) += bTB[s][d]; }
+            if (c12[s][d]) { FAP(R, s, UVC_FAM_cDP12, sym, x) += c12[s][d]; FAP(R, s, UVC_FAM_cDP21, sym, x) += c21[s][d]; }
+            if (c1[s][d]) FAP(R, s, UVC_FAM_cDP1, sym, x) += c1[s][d];
+        }
+        if (bMQ[d]) VQP(R, UVC_VQ_bMQ, sym, x) += bMQ[d];
+    }
+    // P3b (main.hpp:2801-2828)
+    for (int st = 0; st < 2; st++) {
+        const int sb = (st == 0 ? UVC_BASE_A : UVC_LINK_M), se = (st == 0 ? UVC_BASE_NN : UVC_LINK_NN);
+        int totDP = 0;
+        for (int s = sb; s <= se; s++) totDP += FRP(R, 0, UVC_FRAG_bDP, s, x) + FRP(R, 1, UVC_FRAG_bDP, s, x);
+        for (int s = sb; s <= se; s++) {
+            const int nfr = FRP(R, 0, UVC_FRAG_bDP, s, x) + FRP(R, 1, UVC_FRAG_bDP, s, x);
+            if (nfr == 0) continue;   // empty histogram -> all three outputs are 0
+            const int dense = (s == my_ref ? 0 : (s == UVC_LINK_M ? 1 : -1));
+            int max_qual;
+            if (dense == 0) max_qual = maxq_ref; else if (dense == 1) max_qual = maxq_link;
+            else {
+                const int ad = S32(R, UVC_S_aDPff, s, x) + S32(R, UVC_S_aDPfr, s, x) + S32(R, UVC_S_aDPrf, s, x) + S32(R, UVC_S_aDPrr, s, x);
+                max_qual = 8 + BQS(R, s, x) / imax(1, ad);
+            }
+            int mv, ad2, bq2;
+            if (dense >= 0) infer_max_qual(mv, ad2, bq2, max_qual, 1, totDP, [&](int b) { return hist[threadIdx.x][dense][b]; });
+            else {
+                infer_max_qual(mv, ad2, bq2, max_qual, 1, totDP, [&](int b) { return BKP(R, 0, s, b, x); });
+                for (int b = 0; b < NBUCKETS; b++) BKP(R, 0, s, b, x) = 0;   // clearSymbolBucketCount, main.hpp:2827
+            }
+            VQP(R, UVC_VQ_bIAQb, s, x) += mv; VQP(R, UVC_VQ_bIADb, s, x) += ad2; VQP(R, UVC_VQ_bIDQb, s, x) += bq2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic family-strand units (more than one fragment, or UMI / duplex): one thread per (unit, position)
+// ------------------------------------------------------------------------------------------------
+DEV int find_unit(const RegionDev &R, int64_t w) {   // last generic unit with work_off <= w
+    int lo = 0, hi = R.n_generic_fs;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (R.fss[R.generic_fs[mid]].work_off <= w) lo = mid; else hi = mid; }
+    return R.generic_fs[lo];
+}
+
+// builds con (votes) and optionally mmm (major-minus-minor BQ sums) of one unit at position p
+DEV void unit_counts(const RegionDev &R, const UvcParams &P, const FsRec &u, int p, bool proton, int *con, int *mmm) {
+    const bool padded_ignored = (P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0;
+    for (int s = 0; s < NSYM; s++) { con[s] = 0; if (mmm) mmm[s] = 0; }
+    int cnt[NSYM];
+    for (int fi = u.frag_beg; fi < u.frag_end; fi++) {
+        const FragRec &f = R.frags[fi];
+        if (p < f.beg || p >= f.end) continue;
+        frag_counts(R, P, f, p, proton, cnt);
+        for (int st = 0; st < 2; st++) {
+            int cs, cc, ct;
+            if (st == UVC_LINK_SYMBOL) fill_consensus(cnt, cs, cc, ct, st, true, false);
+            else fill_consensus(cnt, cs, cc, ct, st, false, padded_ignored);
+            const int adj = imax(cc * 2, ct) - ct;
+            if (adj >= (st == UVC_BASE_SYMBOL ? P.fam_thres_highBQ_snv : 0) && adj > 0) con[cs] += 1;
+            if (mmm) {
+                if (st == UVC_BASE_SYMBOL && padded_ignored) fill_consensus(cnt, cs, cc, ct, st, false, false);
+                const int adj5 = imax(cc * 2, ct) - ct;
+                if (adj5 > 0) mmm[cs] += adj5;
+            }
+        }
+    }
+}
+
+// per-unit scalars: medians of read ends "as filled" (main.hpp:2916-2940) and the no-strict-bias window (:2959-2998)
+__global__ void __launch_bounds__(64) k_fam_stat(RegionDev R, UvcParams P) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= R.n_generic_fs) return;
+    const int ui = R.generic_fs[t];
+    FsRec u = R.fss[ui];
+    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    int n_l2r = 0, n_r2l = 0, qsum = 0, nq = 0;
+    const int a_beg = R.frags[u.frag_beg].aln_beg, a_end = R.frags[u.frag_end - 1].aln_end;
+    for (int k = a_beg; k < a_end; k++) { const AlnRec &a = R.alns[k]; if (a.flag & 0x10) n_r2l++; else n_l2r++; qsum += a.l_qseq; nq++; }
+    auto nth = [&](bool rev, int idx) -> int {
+        int c = 0;
+        for (int k = a_beg; k < a_end; k++) { const AlnRec &a = R.alns[k]; if (((a.flag & 0x10) != 0) == rev) { if (c == idx) return rev ? a.pos : a.rend; c++; } }
+        return 0;
+    };
+    u.l2r_end_median = (n_l2r > 0 ? (nth(false, (n_l2r - 1) / 2) + nth(false, n_l2r / 2)) / 2 : u.end);
+    u.r2l_end_median = (n_r2l > 0 ? (nth(true, (n_r2l - 1) / 2) + nth(true, n_r2l / 2)) / 2 : u.beg);
+    int nsb_min = u.end, nsb_max = u.beg;
+    const int nfrags = u.frag_end - u.frag_beg;
+    if ((nfrags >= P.fam_thres_dup1add) && (qsum >= nq * P.fam_thres_qseqlen)) {
+        int con[NSYM];
+        for (int dir = 0; dir < 2; dir++) {
+            int b = (dir ? (u.end - 1) : u.beg), e = (dir ? (u.beg - 1) : u.end), step = (dir ? -1 : 1);
+            for (int p = b; p != e; p += step) {
+                unit_counts(R, P, u, p, proton, con, nullptr);
+                int cs, cc, ct;
+                fill_consensus(con, cs, cc, ct, UVC_BASE_SYMBOL, false, false);
+                if (0 == ct) continue;
+                const bool good = ((P.fam_thres_dup1add <= ct) && (cc * 100 >= ct * P.fam_thres_dup1perc) && ((u.dflag & 0x1) || (P.fam_flag & 0x2)));
+                if (good && (UVC_BASE_N != cs) && (UVC_BASE_NN != cs)) { if (dir) nsb_max = p; else nsb_min = p; break; }
+            }
+        }
+    }
+    u.nsb_min = nsb_min; u.nsb_max = nsb_max;
+    R.fss[ui] = u;
+}
+
+// P4 of generic units (main.hpp:2999-3355; consensus FASTQ left out)
+__global__ void __launch_bounds__(256) k_fam_p4(RegionDev R, UvcParams P) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= R.n_generic_work) return;
+    const FsRec u = R.fss[find_unit(R, w)];
+    const int p = u.beg + (int)(w - u.work_off);
+    const int64_t x = p - R.beg;
+    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    const int strand = u.strand;
+    int con[NSYM];
+    unit_counts(R, P, u, p, proton, con, nullptr);
+    for (int vi = 0; vi < 2; vi++) {
+        const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
+        int cs, cc, ct;
+        fill_consensus(con, cs, cc, ct, st, false, false);
+        if (0 == ct) continue;
+        const bool is_fam_good = ((P.fam_thres_dup1add <= ct) && (cc * 100 >= ct * P.fam_thres_dup1perc) && ((u.dflag & 0x1) || (P.fam_flag & 0x2)));
+        atomicAdd(&FAP(R, strand, UVC_FAM_cDP12, cs, x), 1);
+        if (1 == ct) atomicAdd(&FAP(R, strand, UVC_FAM_cDP21, cs, x), 1);
+        if (!P.inferred_is_vcf_generated) continue;
+        if (is_fam_good) {
+            atomicAdd(&FAP(R, strand, UVC_FAM_cDP2, cs, x), 1);
+            int rbeg = imin(u.nsb_min, p), rend = imax(u.nsb_max, p);
+            const bool nonconf_middle = (u.l2r_end_median <= (u.r2l_end_median + P.indel_adj_tracklen_dist));
+            if (nonconf_middle && p < u.r2l_end_median) rend = imax(imin(u.l2r_end_median, imin(u.r2l_end_median, rend)), p);
+            if (nonconf_middle && u.l2r_end_median < p) rbeg = imin(imax(u.l2r_end_median, imax(u.r2l_end_median, rbeg)), p);
+            const bool isGap = (UVC_LINK_SYMBOL == st);
+            const int bq = 90, dist = 1024 * 1024;
+            if (((!isGap) && bq >= P.bias_thres_highBQ) || (isGap && dist >= P.bias_thres_highBQ)) {
+                const bool tier2 = (isGap || bq >= P.bias_thres_highBQ);
+                const int l_nb = (int)nnminus(p + 1, rbeg), r_nb = (int)nnminus(rend, p);
+                const int _LPxT = TH(R, UVC_T_aLPxT, x), RPxT = TH(R, UVC_T_aRPxT, x);
+                const int LPxT = (isGap ? _LPxT : imin(_LPxT, RPxT));
+                // indel_len = majority COUNT of one inserted sequence among the unit's fragments (main.hpp:3239-3243): the
+                // sequence-keyed maps stay on the host; the number of votes for the symbol is an upper bound that
+                // equals it whenever all fragments carry the same inserted sequence.
+                const int indel_len = ((is_ins(cs) || is_del(cs)) ? con[cs] : 0);
+                const bool far = (l_nb + (is_ins(cs) ? (int)nnminus(indel_len, P.microadjust_nobias_pos_indel_maxlen) : 0) >= LPxT) && (r_nb >= RPxT);
+                if (far) {
+                    int LP1 = 0, LP2 = 0, RP1 = 0, RP2 = 0; long long LPL = 0, RPL = 0;
+                    bidir(LP1, LP2, RP1, RP2, LPL, RPL, TH(R, UVC_T_aLP1t, x), TH(R, UVC_T_aLP2t, x), TH(R, UVC_T_aRP1t, x), TH(R, UVC_T_aRP2t, x), l_nb, r_nb, true, 0);
+                    if (LP1) atomicAdd(&FIP(R, UVC_FI_c2LP1, cs, x), LP1);
+                    if (LP2) atomicAdd(&FIP(R, UVC_FI_c2LP2, cs, x), LP2);
+                    if (RP1) atomicAdd(&FIP(R, UVC_FI_c2RP1, cs, x), RP1);
+                    if (RP2) atomicAdd(&FIP(R, UVC_FI_c2RP2, cs, x), RP2);
+                    atomicAdd(&FIP(R, UVC_FI_c2LPL, cs, x), (int)LPL); atomicAdd(&FIP(R, UVC_FI_c2RPL, cs, x), (int)RPL);
+                }
+                if ((int)nnminus(p + 1, u.nsb_min) >= P.bias_thres_strict_c2LRP0) atomicAdd(&FIP(R, UVC_FI_c2LP0, cs, x), 1);
+                if ((int)nnminus(u.nsb_max, p) >= P.bias_thres_strict_c2LRP0) atomicAdd(&FIP(R, UVC_FI_c2RP0, cs, x), 1);
+                const long long baq_last = R.end - 1;
+                const int seg_l_baq = (int)(BAQ1(R, p) - BAQ1(R, lmax((long long)rbeg, nnminus(p, MAX_STR_N_BASES))) + 1);
+                const long long rr = lmin((long long)rend - 1, lmin((long long)p + MAX_STR_N_BASES, baq_last));
+                const int _seg_r_baq = (int)(BAQ1(R, rr) - BAQ1(R, p) + 1);
+                const int seg_r_baq = (isGap ? (int)lmin((long long)_seg_r_baq, BAQ2(R, rr) - BAQ2(R, p) + 7) : _seg_r_baq);
+                const int thres_highBAQ = P.bias_thres_highBAQ + (isGap ? 0 : 3);
+                if (seg_l_baq >= thres_highBAQ && seg_r_baq >= thres_highBAQ) {
+                    int LB1 = 0, LB2 = 0, RB1 = 0, RB2 = 0; long long LBL = 0, RBL = 0;
+                    bidir(LB1, LB2, RB1, RB2, LBL, RBL, P.bias_thres_BAQ1, P.bias_thres_BAQ2, P.bias_thres_BAQ1, P.bias_thres_BAQ2, seg_l_baq, seg_r_baq, tier2, 0);
+                    if (LB1) atomicAdd(&FIP(R, UVC_FI_c2LB1, cs, x), LB1);
+                    if (LB2) atomicAdd(&FIP(R, UVC_FI_c2LB2, cs, x), LB2);
+                    if (RB1) atomicAdd(&FIP(R, UVC_FI_c2RB1, cs, x), RB1);
+                    if (RB2) atomicAdd(&FIP(R, UVC_FI_c2RB2, cs, x), RB2);
+                    add64(&FI64P(R, UVC_FI64_c2LBL, cs, x), LBL); add64(&FI64P(R, UVC_FI64_c2RBL, cs, x), RBL);
+                }
+                atomicAdd(&FIP(R, UVC_FI_c2BQ2, cs, x), 1);
+            }
+        }
+        if (P.fam_thres_dup2add <= ct && (cc * 100 >= ct * P.fam_thres_dup2perc)) atomicAdd(&FAP(R, strand, UVC_FAM_cDP3, cs, x), 1);
+        const int flat = (is_subst(cs) ? P.fam_thres_emperr_all_flat_snv : P.fam_thres_emperr_all_flat_indel);
+        const int perc = (is_subst(cs) ? P.fam_thres_emperr_con_perc_snv : P.fam_thres_emperr_con_perc_indel);
+        if (ct < flat) continue;
+        if (cc * 100 < ct * perc) continue;
+        const int sb = (st == 0 ? UVC_BASE_A : UVC_LINK_M), se = (st == 0 ? UVC_BASE_NN : UVC_LINK_NN);
+        int m = 0, M = 0;
+        for (int s = sb; s <= se; s++) if (s != cs) { m += con[s]; M += ct; }
+        if (m) atomicAdd(&FAP(R, strand, UVC_FAM_cDPm, cs, x), m);
+        atomicAdd(&FAP(R, strand, UVC_FAM_cDPM, cs, x), M);
+    }
+}
+
+// P5 of generic units (main.hpp:3392-3513)
+__global__ void __launch_bounds__(256) k_fam_p5(RegionDev R, UvcParams P) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= R.n_generic_work) return;
+    const FsRec u = R.fss[find_unit(R, w)];
+    const int p = u.beg + (int)(w - u.work_off);
+    const int64_t x = p - R.beg;
+    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    const int strand = u.strand;
+    const bool is_duplex_fam = (0x2 == (u.dflag & 0x2));
+    const bool other_present = (u.other_fs >= 0);
+    const bool will_inc_dscs = is_duplex_fam && other_present;
+    const bool will_inc_sscs = is_duplex_fam && !other_present;
+    int con[NSYM], mmm[NSYM];
+    unit_counts(R, P, u, p, proton, con, mmm);
+    for (int vi = 0; vi < 2; vi++) {
+        const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
+        int cs, con_sumBQs, tot_sumBQs;
+        fill_consensus(mmm, cs, con_sumBQs, tot_sumBQs, st, false, false);
+        if (0 == tot_sumBQs) continue;
+        const int con_nfrags = con[cs];
+        int tot_nfrags = 0;
+        const int sb = (st == 0 ? UVC_BASE_A : UVC_LINK_M), se = (st == 0 ? UVC_BASE_NN : UVC_LINK_NN);
+        for (int s = sb; s <= se; s++) tot_nfrags += con[s];
+        atomicAdd(&FAP(R, strand, UVC_FAM_cDP1, cs, x), 1);
+        if (will_inc_sscs && (!will_inc_dscs) && (tot_nfrags >= P.fam_thres_dup1add) && (con_nfrags * 100 >= tot_nfrags * P.fam_thres_dup1perc))
+            atomicAdd(&FAP(R, strand, UVC_FAM_cDPD, cs, x), 1);
+        const int avgBQ = ((0 == tot_nfrags) ? 1 : (con_sumBQs / tot_nfrags));
+        const int majorcount = FAP(R, strand, UVC_FAM_cDPM, cs, x), minorcount = FAP(R, strand, UVC_FAM_cDPm, cs, x);
+        const double prior_weight = 1.0 / (minorcount + 1.0);
+        const double p2p = pow(10.0, (double)(-((float)avgBQ) / 10));   // phred2prob's float cast, main_conversion.hpp:885-888
+        const double prob = (minorcount + prior_weight) / (majorcount + minorcount + prior_weight / p2p);
+        const double realphred = -10 * log(prob) / log(10.0);
+        const int indep_frag_phred = (int)round(((con_nfrags * 2) - tot_nfrags) * realphred);
+        int confam_qual;
+        if (UVC_LINK_SYMBOL == st) confam_qual = imax(1, imin(indep_frag_phred, P.fam_phred_indel_inc_before_barcode_labeling + (int)round(realphred)));
+        else confam_qual = imax(1, imin(indep_frag_phred, (con_sumBQs * 2) - tot_sumBQs));
+        const int max_qual = sscs_phred(P, R.refsym[x], cs) + (!P.tumor_vcf_is_provided ? 0 : 4);
+        const int confam_qual2 = imin(confam_qual, max_qual);
+        if (tot_nfrags >= P.fam_thres_dup1add) {
+            const int pbucket = (max_qual - confam_qual2 + 2) / 4;
+            if (pbucket >= 0 && pbucket < NBUCKETS) atomicAdd(&BKP(R, strand, cs, pbucket, x), 1);
+        }
+    }
+}
+
+// duplex consensus (main.hpp:3427-3433, 3523-3550): one thread per (strand-0 unit of a duplex family with both strands, position)
+__global__ void __launch_bounds__(256) k_duplex(RegionDev R, UvcParams P, const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_work) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_work) return;
+    int lo = 0, hi = n_dup;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (dup_off[mid] <= w) lo = mid; else hi = mid; }
+    const FsRec u0 = R.fss[dup_units[lo]];
+    const FsRec u1 = R.fss[u0.other_fs];
+    const int dbeg = imin(u0.beg, u1.beg);
+    const int p = dbeg + (int)(w - dup_off[lo]);
+    const int64_t x = p - R.beg;
+    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    const bool padded_ignored = (P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0;
+    int dup[NSYM], con[NSYM];
+    for (int s = 0; s < NSYM; s++) dup[s] = 0;
+    for (int k = 0; k < 2; k++) {
+        const FsRec &u = (k == 0 ? u0 : u1);
+        if (p < u.beg || p >= u.end) continue;
+        unit_counts(R, P, u, p, proton, con, nullptr);
+        for (int st = 0; st < 2; st++) {   // updateByFiltering<true,false,false> with thresholds {1,1}
+            int cs, cc, ct;
+            fill_consensus(con, cs, cc, ct, st, false, st == UVC_BASE_SYMBOL && padded_ignored);
+            const int adj = imax(cc * 2, ct) - ct;
+            if (adj >= 1 && adj > 0) dup[cs] += 1;
+        }
+    }
+    for (int st = 0; st < 2; st++) {
+        int cs, cc, ct;
+        fill_consensus(dup, cs, cc, ct, st, false, false);
+        if (0 < ct) atomicAdd(&DUP(R, UVC_DUPLEX_dDP1, cs, x), 1);
+        if (1 < ct) atomicAdd(&DUP(R, UVC_DUPLEX_dDP2, cs, x), 1);
+    }
+}
+
+// P5b (main.hpp:3552-3591): one thread per (position, strand)
+__global__ void __launch_bounds__(256) k_p5b(RegionDev R, UvcParams P) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= R.npos * 2) return;
+    const int strand = (int)(t / R.npos);
+    const int64_t x = t % R.npos;
+    const int qIAQ = (strand ? UVC_VQ_cIAQr : UVC_VQ_cIAQf), qIAD = (strand ? UVC_VQ_cIADr : UVC_VQ_cIADf), qIDQ = (strand ? UVC_VQ_cIDQr : UVC_VQ_cIDQf);
+    const int ref_symbol = R.refsym[x];
+    for (int st = 0; st < 2; st++) {
+        const int sb = (st == 0 ? UVC_BASE_A : UVC_LINK_M), se = (st == 0 ? UVC_BASE_NN : UVC_LINK_NN);
+        int totDP = 0;
+        for (int s = sb; s <= se; s++) totDP += FAP(R, strand, UVC_FAM_cDP1, s, x);
+        if (totDP == 0) continue;
+        for (int s = sb; s <= se; s++) {
+            const int max_qual = sscs_phred(P, ref_symbol, s) + (!P.tumor_vcf_is_provided ? 0 : 4);
+            int mv, ad, bq;
+            infer_max_qual(mv, ad, bq, max_qual, 4, totDP, [&](int b) { return BKP(R, strand, s, b, x); });
+            if (mv | ad | bq) { VQP(R, qIAQ, s, x) += mv; VQP(R, qIAD, s, x) += ad; VQP(R, qIDQ, s, x) += bq; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-callable launchers
+// ------------------------------------------------------------------------------------------------
+static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
+
+extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const UvcParams *P, hipStream_t s) {
+    if (R->n_alns) hipLaunchKernelGGL(k_aln_prelude, dim3(nblk(R->n_alns, 256)), dim3(256), 0, s, *R, *W, *P);
+}
+extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, int half_ratio_phred,
+                                      const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s) {
+    const unsigned nwin = nblk(R->npos, 256);   // 4 waves x 64 positions per block
+    if (P->inferred_is_vcf_generated) {
+        hipLaunchKernelGGL(k_prep_fast, dim3(nwin), dim3(256), 0, s, *R, *P);
+        if (R->n_complex) hipLaunchKernelGGL(k_prep_slow, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P);
+        hipLaunchKernelGGL(k_thres, dim3(nblk(R->npos, 256)), dim3(256), 0, s, *R, *P, half_ratio_phred);
+        hipLaunchKernelGGL(k_p2_fast, dim3(nwin), dim3(256), 0, s, *R, *P);
+        if (R->n_complex) hipLaunchKernelGGL(k_p2_slow<true>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P);
+    } else {
+        hipLaunchKernelGGL(k_thres, dim3(nblk(R->npos, 256)), dim3(256), 0, s, *R, *P, half_ratio_phred);
+    }
+    if (R->n_complex) hipLaunchKernelGGL(k_p2_slow<false>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P);
+    if (P->inferred_is_vcf_generated) hipLaunchKernelGGL(k_fragstat, dim3(nblk(R->n_frags, 64)), dim3(64), 0, s, *R, *P);
+    hipLaunchKernelGGL(k_frag, dim3(nwin), dim3(256), 0, s, *R, *P);
+    if (R->n_generic_fs) {
+        hipLaunchKernelGGL(k_fam_stat, dim3(nblk(R->n_generic_fs, 64)), dim3(64), 0, s, *R, *P);
+        hipLaunchKernelGGL(k_fam_p4, dim3(nblk(R->n_generic_work, 256)), dim3(256), 0, s, *R, *P);
+        if (P->inferred_is_vcf_generated) {
+            hipLaunchKernelGGL(k_fam_p5, dim3(nblk(R->n_generic_work, 256)), dim3(256), 0, s, *R, *P);
+            if (n_dup) hipLaunchKernelGGL(k_duplex, dim3(nblk(n_dup_work, 256)), dim3(256), 0, s, *R, *P, dup_units, n_dup, dup_off, n_dup_work);
+        }
+    }
+    if (P->inferred_is_vcf_generated) hipLaunchKernelGGL(k_p5b, dim3(nblk(R->npos * 2, 256)), dim3(256), 0, s, *R, *P);
+}
