@@ -1,0 +1,63 @@
+"""GPU parity: every per-position plane of the HIP path equals the oracle bit for bit
+(integer class of SURVEY section 8d; the bucket->quality VQ slots bIAQb/cIAQ* are the outputs of a
+truncated fp64 log and are also required to match exactly here -- a flip would need a product
+within 1e-13 of an integer)."""
+import numpy as np
+import pytest
+
+from uvc_amd import synth
+from util import diff_groups, run_region
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "config1_10kb_30x": dict(region_len=10000, depth=30, seed=12345),
+    "config2shape_5kb_300x": dict(region_len=5000, depth=300, seed=7),
+    "nodedup_3kb_60x": dict(region_len=3000, depth=60, seed=3, dedup_by_position=False),
+    "umi_duplex_2kb_400x": dict(region_len=2000, depth=400, seed=11, umi=True),
+    "tiny_600bp_5x": dict(region_len=600, depth=5, seed=5),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_planes_match_oracle(name, oracle_lib, gpu_lib):
+    reads = synth.generate_region(**CASES[name])
+    Ro = run_region(oracle_lib, reads)
+    Rg = run_region(gpu_lib, reads)
+    bad = diff_groups(Ro, Rg)
+    assert not bad, "\n".join("%s: %d cells differ, e.g. %s" % (g, v[0], v[1]) for g, v in bad.items())
+
+
+# SURVEY section 8(d) tolerance classes for the scoring records
+EXACT_FIELDS = ["refpos", "symbol", "refsymbol", "DP", "AD", "bDP", "bAD", "c2DP", "c2AD", "bDPa", "cDP0a", "tier2", "FTS"]
+PCT_FIELDS = ["cDP1v", "cDP1w", "cDP1x", "cDP2v", "cDP2w", "cDP2x", "CDP1v0", "CDP1v1", "CDP1w0", "CDP1w1", "CDP1x0", "CDP1x1",
+              "CDP2v0", "CDP2v1", "CDP2w0", "CDP2w1", "CDP2x0", "CDP2x1"]
+
+
+def compare_records(ro, rg):
+    """oracle vs GPU records: exact class bit-exact, depth-like x100 fields within 1 %, everything else within 1 Phred."""
+    assert len(ro["refpos"]) == len(rg["refpos"]), (len(ro["refpos"]), len(rg["refpos"]))
+    worst = {}
+    for name in ro:
+        a, b = ro[name].astype(np.int64), rg[name].astype(np.int64)
+        d = np.abs(a - b)
+        if name in EXACT_FIELDS:
+            assert d.max(initial=0) == 0, (name, int(np.argmax(d)), int(a[np.argmax(d)]), int(b[np.argmax(d)]))
+        elif name in PCT_FIELDS:
+            tol = np.maximum(1, np.abs(a) // 100)
+            assert (d <= tol).all(), (name, int(np.argmax(d - tol)))
+        else:
+            assert d.max(initial=0) <= 1, (name, int(np.argmax(d)), int(a[np.argmax(d)]), int(b[np.argmax(d)]))
+        worst[name] = int(d.max(initial=0))
+    return worst
+
+
+@pytest.mark.parametrize("name,all_out", [("config1_10kb_30x", False), ("config1_10kb_30x", True), ("config2shape_5kb_300x", False), ("umi_duplex_2kb_400x", True)])
+def test_score_records_match_oracle(name, all_out, oracle_lib, gpu_lib):
+    reads = synth.generate_region(**CASES[name])
+    Ro = run_region(oracle_lib, reads)
+    Rg = run_region(gpu_lib, reads)
+    ro, rg = Ro.score(all_out=all_out), Rg.score(all_out=all_out)
+    assert len(ro["refpos"]) > 0
+    worst = compare_records(ro, rg)
+    print(name, all_out, len(ro["refpos"]), {k: v for k, v in worst.items() if v})

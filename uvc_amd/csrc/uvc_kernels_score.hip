@@ -1,3 +1,787 @@
-// placeholder until the scoring kernel lands (next commit)
+// uvc_kernels_score.hip -- per-position Bayesian / power-law scoring on gfx950 (fp64 VALU, no MFMA).
+//
+// Replaces the BcfFormat_symbol* call group of process_batch (main.cpp:608-1000):
+//   BcfFormat_symboltype_init  main.hpp:3889   -> group_totals()
+//   BcfFormat_symbol_init      main.hpp:4094   -> allele_load() (+ fill_symbol_VQ_fmts, main.hpp:3820)
+//   BcfFormat_symbol_calc_DPv  main.hpp:4274   -> calc_dpv()
+//   BcfFormat_symbol_sum_DPv   main.hpp:4888   -> in-thread reduction (one thread owns a (position, symbol type) group)
+//   BcfFormat_symbol_calc_qual main.hpp:4908   -> calc_qual()
+// Tumor-only (tpfa = -1, is_rescued = false); the T/N rescue arms are SURVEY next-row N2.
+//
+// Launch shape: k_score_count  one thread per (zerobased_pos, symbol type): number of emitted alleles (candidate gate, main.cpp:832-837)
+//               k_scan_*       exclusive prefix sum -> deterministic record slots, in the reference's emission order
+//               k_score        one thread per (zerobased_pos, symbol type): pass 1 = init + calc_DPv per allele and the
+//                              cross-allele sums, pass 2 = calc_qual per allele; records are written SoA [field][record].
 #include "uvc_device.h"
-extern "C" int uvc_launch_score(const RegionDev *, const UvcParams *, const UvcScoreRequest *, const UvcIndelAllele *, int32_t *, int64_t, int64_t *, hipStream_t) { return UVCGPU_EUNSUPPORTED; }
+
+#define DBL_EPS 2.220446049250313e-16
+#define FLT_EPS 1.1920928955078125e-07
+
+DEV double dmin(double a, double b) { return a < b ? a : b; }
+DEV double dmax(double a, double b) { return a > b ? a : b; }
+DEV double dbetween(double v, double a, double b) { return dmin(dmax(a, v), b); }
+DEV double nnminus_d(double a, double b) { return a > b ? a - b : 0.0; }
+DEV double phred2nat(double x) { return (log(10.0) / 10.0) * x; }                       // common.hpp:81
+DEV double numstates2phred(double x) { return (10.0 / log(10.0)) * log(x); }            // common.hpp:85
+DEV int numstates2deciphred(double x) { return (int)round((100.0 / log(10.0)) * log(x)); }   // common.hpp:87
+DEV double prob2odds(double p) { return p / (1.0 - p); }
+DEV double logit2(double a, double b) { return log(prob2odds((a + DBL_EPS) / (a + b + 2.0 * DBL_EPS))); }   // main_conversion.hpp:216-219
+
+// calc_binom_10log10_likeratio<false,false>, main_conversion.hpp:222-237
+DEV double binom_llr(double prob, double a, double b) {
+    prob = (prob + DBL_EPS) / (1.0 + (2.0 * DBL_EPS));
+    a += DBL_EPS; b += DBL_EPS;
+    const double A = (prob) * (a + b), B = (1.0 - prob) * (a + b);
+    if (a > A) return 10.0 / log(10.0) * (a * log(a / A) + b * log(b / B));
+    return 0.0;
+}
+
+// dp4_to_pcFA<TBidirectional, TIsOverseqFracDisabled>, main_conversion.hpp:798-849
+DEV void dp4(double out[2], bool bidir, bool overseq_disabled, double overseq_frac, double aADpass, double aADfail, double aDPpass, double aDPfail,
+             double pl_exponent, double n_nats, double aADavgKeyVal = -1, double aDPavgKeyVal = -1, double priorAD = 0.5, double priorDP = 1.0) {
+    if (!overseq_disabled) { aDPfail *= overseq_frac; aDPpass *= overseq_frac; aADfail *= overseq_frac; aADpass *= overseq_frac; }
+    aDPfail += priorDP; aDPpass += priorDP; aADfail += priorAD; aADpass += priorAD;
+    const double nobiasFA = (aADfail + aADpass) / (aDPfail + aDPpass);
+    if ((aADpass / aDPpass) >= (aADfail / aDPfail)) {
+        if (bidir) { double t = aDPfail; aDPfail = aDPpass; aDPpass = t; t = aADfail; aADfail = aADpass; aADpass = t; }
+        else { out[0] = (aADpass / aDPpass); out[1] = nobiasFA; return; }
+    }
+    const double aBDfail = aDPfail * 2 - aADfail * 1, aBDpass = aDPpass * 2 - aADpass * 1;
+    double aADpassfrac = aADpass / (aADpass + aADfail);
+    double aBDpassfrac = aBDpass / (aBDpass + aBDfail);
+    if ((!bidir) && (aADavgKeyVal >= 0) && (aDPavgKeyVal >= 0)) { aADpassfrac = aADavgKeyVal / (aADavgKeyVal + aDPavgKeyVal * 0.9); aBDpassfrac = 1.0 - aADpassfrac; }
+    double infogain = aADfail * log((1.0 - aADpassfrac) / (1.0 - aBDpassfrac));
+    if (bidir) infogain += aADpass * log(aADpassfrac / aBDpassfrac);
+    if (infogain <= n_nats) { out[0] = aADfail / aDPfail; out[1] = nobiasFA; }
+    else { out[0] = dmax(aADpass / aDPpass, (aADfail / aDPfail) * exp((n_nats - infogain) / pl_exponent)); out[1] = nobiasFA; }
+}
+
+DEV int indel_len_rusize_phred_s(int indel_len, int repeatunit_size) {   // main.hpp:757-790
+    const int t[19] = { 0, 0, 3, 5, 6, 7, 8, 8, 9, 10, 10, 10, 11, 11, 11, 12, 12, 12, 13 };
+    if (0 == (indel_len % repeatunit_size)) return t[imin(indel_len / repeatunit_size, 18)];
+    return t[imin(indel_len, 18)];
+}
+DEV int indel_phred_s(double ampfact, int rs, int rn) {   // main.hpp:794-801
+    const int region_size = rs * rn;
+    const double num_slips = (region_size > 64 ? (double)(region_size - 8) : log1p(exp((double)region_size - (double)8))) * ampfact / ((double)(rs * rs));
+    return (int)floor(-10 * log((1.0 - DBL_EPS) / (num_slips + 1.0)) / log(10.0));
+}
+DEV bool more_STR_s(int rulen1, int rc1, int rulen2, int rc2, int strmax) {   // main.hpp:699-721
+    if (rulen2 * rc2 == 0) return true;
+    if (rulen1 > strmax || rulen2 > strmax) return (rulen1 < rulen2 || (rulen1 == rulen2 && rc1 > rc2));
+    int rank1 = (rc1 <= 1 ? (-rc1 * rulen1) : ((rc1 - 1) * rulen1));
+    int rank2 = (rc2 <= 1 ? (-rc2 * rulen1) : ((rc2 - 1) * rulen2));
+    if (0 == rc1 || 0 == rulen1) rank1 = -100;
+    if (0 == rc2 || 0 == rulen2) rank2 = -100;
+    return rank1 > rank2;
+}
+// indelpos_to_context, main.hpp:733-755 -> (repeat unit length, repeat count)
+DEV void indel_context(const RegionDev &R, int refidx, int strmax, int &unit_len, int &repeatnum) {
+    const int n = (int)R.npos - 1;
+    repeatnum = 0; unit_len = 0;
+    if (refidx >= n) return;
+    int rs_at_max = 0;
+    for (int rs = 1; rs <= strmax; rs++) {
+        int q = refidx;
+        while ((q + rs < n) && R.refsym[q] == R.refsym[q + rs]) q++;
+        const int rn = (q - refidx) / rs + 1;
+        if (more_STR_s(rs, rn, rs_at_max, repeatnum, strmax)) { repeatnum = rn; rs_at_max = rs; }
+    }
+    unit_len = imin(rs_at_max, n - refidx);   // refstring.substr(refpos, n).size()
+}
+
+// symbol iteration order of SYMBOL_TYPE_TO_SYMBOLS (main_conversion.hpp:397-400)
+DEV int st_symbol(int st, int k) {
+    if (st == UVC_BASE_SYMBOL) return k;   // A C G T N NN
+    const int link[8] = { UVC_LINK_M, UVC_LINK_I1, UVC_LINK_I2, UVC_LINK_I3P, UVC_LINK_D1, UVC_LINK_D2, UVC_LINK_D3P, UVC_LINK_NN };
+    return link[k];
+}
+DEV int st_count(int st) { return st == UVC_BASE_SYMBOL ? 6 : 8; }
+
+struct Tot {   // symbol-type totals: [0] = sum over the type's symbols, [1] = the NN symbol (fill_symboltype_fmt, main.hpp:3745-3793)
+    long long APDP[12], APXM[8], APLRI[4];
+    long long A1BQf0, A1BQr0, AMQs0, AP10, AP20, ADPff0, ADPfr0, ADPrf0, ADPrr0, ALP10, ALP20, ALPL0, ARP20, ARPL0, ALB20, ALBL0, ARB20, ARBL0, ABQ20, APF20, ALI20, ARIf0, ARI20, ALIr0;
+    int BDPb[2], BTAb[2], BTBb[2], CDP1b[2], CDP12b[2], CDP2b[2], CDP3b[2];
+    long long C2LP20, C2LPL0, C2RP20, C2RPL0, C2LB20, C2LBL0, C2RB20, C2RBL0, C2BQ20, C2LP00, C2RP00;
+    int DDP10;
+};
+
+struct Al {   // one allele (index a = 0 everywhere in the reference)
+    int symbol;
+    int a1BQf, a1BQr, aMQs, aP1, aP2, aDPff, aDPfr, aDPrf, aDPrr, aLP1, aLP2, aRP1, aRP2, aLB1, aLB2, aRB1, aRB2;
+    long long aLPL, aRPL, aLBL, aRBL, aLIT, aRIT;
+    int a2XM2, a2BM2, aBQ2, aPF1, aPF2, aLI1, aLI2, aLIr, aRI1, aRI2, aRIf, aP3, aNC;
+    int bDPf, bTAf, bTBf, bDPr, bTAr, bTBr;
+    int cDP1f, cDP12f, cDP2f, cDP3f, cDPMf, cDPmf, cDP1r, cDP12r, cDP2r, cDP3r, cDPMr, cDPmr;
+    int c2LP1, c2LP2, c2RP1, c2RP2, c2LP0, c2RP0, c2LB1, c2LB2, c2RB1, c2RB2, c2BQ2;
+    long long c2LPL, c2RPL, c2LBL, c2RBL;
+    int dDP1, dDP2;
+    int AD, bAD;
+    int bMQ, a2BQf, a2BQr, aBQ, aBQQ, bIAQb, bIADb, cIAQf, cIADf, cIDQf, cIAQr, cIADr, cIDQr;
+    int bDPa, cDP0a, gap_len;
+    int tier2, bNMQ;
+    int cDP1v, cDP1w, cDP1x, cDP2v, cDP2w, cDP2x;
+};
+
+#define SUMSYM(expr) ({ long long r_ = 0; for (int k_ = 0; k_ < nsym; k_++) { const int s = st_symbol(st, k_); r_ += (long long)(expr); } r_; })
+
+DEV void group_totals(const RegionDev &R, int64_t x, int st, Tot &f) {
+    const int nsym = st_count(st);
+    const int pidx[12] = { UVC_P_a_dp, UVC_P_a_near_ins_dp, UVC_P_a_near_del_dp, UVC_P_a_near_RTR_ins_dp, UVC_P_a_near_RTR_del_dp, UVC_P_a_pcr_dp,
+                           UVC_P_a_snv_dp, UVC_P_a_dnv_dp, UVC_P_a_highBQ_dp, UVC_P_a_near_pcr_clip_dp, UVC_P_a_near_long_clip_dp, UVC_P_a_umi_dp };
+    for (int i = 0; i < 12; i++) f.APDP[i] = P32(R, pidx[i], x);
+    f.APXM[0] = P32(R, UVC_P_a_XM1500, x); f.APXM[1] = P32(R, UVC_P_a_GO1500, x); f.APXM[2] = P32(R, UVC_P_a_qlen, x); f.APXM[3] = P32(R, UVC_P_a_GAPLEN, x);
+    f.APXM[4] = P64(R, UVC_P_a_near_ins_pow2len, x); f.APXM[5] = P64(R, UVC_P_a_near_del_pow2len, x);
+    f.APXM[6] = P32(R, UVC_P_a_near_ins_inv100len, x); f.APXM[7] = P32(R, UVC_P_a_near_del_inv100len, x);
+    f.APLRI[0] = P64(R, UVC_P_a_LI, x); f.APLRI[1] = P32(R, UVC_P_a_LIDP, x); f.APLRI[2] = P64(R, UVC_P_a_RI, x); f.APLRI[3] = P32(R, UVC_P_a_RIDP, x);
+    // int32 FORMAT fields truncate the int64 sum on assignment; the *L fields are int64 (bcf_formats_generator1.cpp:220-245)
+    f.A1BQf0 = (int)SUMSYM(VQP(R, UVC_VQ_a1BQf, s, x)); f.A1BQr0 = (int)SUMSYM(VQP(R, UVC_VQ_a1BQr, s, x));
+    f.AMQs0 = (int)SUMSYM(S32(R, UVC_S_aMQs, s, x)); f.AP10 = (int)SUMSYM(S32(R, UVC_S_aP1, s, x)); f.AP20 = (int)SUMSYM(S32(R, UVC_S_aP2, s, x));
+    f.ADPff0 = (int)SUMSYM(S32(R, UVC_S_aDPff, s, x)); f.ADPfr0 = (int)SUMSYM(S32(R, UVC_S_aDPfr, s, x)); f.ADPrf0 = (int)SUMSYM(S32(R, UVC_S_aDPrf, s, x)); f.ADPrr0 = (int)SUMSYM(S32(R, UVC_S_aDPrr, s, x));
+    f.ALP10 = (int)SUMSYM(S32(R, UVC_S_aLP1, s, x)); f.ALP20 = (int)SUMSYM(S32(R, UVC_S_aLP2, s, x)); f.ALPL0 = SUMSYM(S32(R, UVC_S_aLPL, s, x));
+    f.ARP20 = (int)SUMSYM(S32(R, UVC_S_aRP2, s, x)); f.ARPL0 = SUMSYM(S32(R, UVC_S_aRPL, s, x));
+    f.ALB20 = (int)SUMSYM(S32(R, UVC_S_aLB2, s, x)); f.ALBL0 = SUMSYM(S64(R, UVC_S64_aLBL, s, x));
+    f.ARB20 = (int)SUMSYM(S32(R, UVC_S_aRB2, s, x)); f.ARBL0 = SUMSYM(S64(R, UVC_S64_aRBL, s, x));
+    f.ABQ20 = (int)SUMSYM(S32(R, UVC_S_aBQ2, s, x)); f.APF20 = (int)SUMSYM(S32(R, UVC_S_aPF2, s, x));
+    f.ALI20 = (int)SUMSYM(S32(R, UVC_S_aLI2, s, x)); f.ARIf0 = (int)SUMSYM(S32(R, UVC_S_aRIf, s, x)); f.ARI20 = (int)SUMSYM(S32(R, UVC_S_aRI2, s, x)); f.ALIr0 = (int)SUMSYM(S32(R, UVC_S_aLIr, s, x));
+    for (int sd = 0; sd < 2; sd++) {
+        f.BDPb[sd] = (int)SUMSYM(FRP(R, sd, UVC_FRAG_bDP, s, x)); f.BTAb[sd] = (int)SUMSYM(FRP(R, sd, UVC_FRAG_bTA, s, x)); f.BTBb[sd] = (int)SUMSYM(FRP(R, sd, UVC_FRAG_bTB, s, x));
+        f.CDP1b[sd] = (int)SUMSYM(FAP(R, sd, UVC_FAM_cDP1, s, x)); f.CDP12b[sd] = (int)SUMSYM(FAP(R, sd, UVC_FAM_cDP12, s, x));
+        f.CDP2b[sd] = (int)SUMSYM(FAP(R, sd, UVC_FAM_cDP2, s, x)); f.CDP3b[sd] = (int)SUMSYM(FAP(R, sd, UVC_FAM_cDP3, s, x));
+    }
+    f.C2LP20 = (int)SUMSYM(FIP(R, UVC_FI_c2LP2, s, x)); f.C2LPL0 = SUMSYM(FIP(R, UVC_FI_c2LPL, s, x)); f.C2RP20 = (int)SUMSYM(FIP(R, UVC_FI_c2RP2, s, x)); f.C2RPL0 = SUMSYM(FIP(R, UVC_FI_c2RPL, s, x));
+    f.C2LB20 = (int)SUMSYM(FIP(R, UVC_FI_c2LB2, s, x)); f.C2LBL0 = SUMSYM(FI64P(R, UVC_FI64_c2LBL, s, x)); f.C2RB20 = (int)SUMSYM(FIP(R, UVC_FI_c2RB2, s, x)); f.C2RBL0 = SUMSYM(FI64P(R, UVC_FI64_c2RBL, s, x));
+    f.C2BQ20 = (int)SUMSYM(FIP(R, UVC_FI_c2BQ2, s, x)); f.C2LP00 = (int)SUMSYM(FIP(R, UVC_FI_c2LP0, s, x)); f.C2RP00 = (int)SUMSYM(FIP(R, UVC_FI_c2RP0, s, x));
+    f.DDP10 = (int)SUMSYM(DUP(R, UVC_DUPLEX_dDP1, s, x));
+}
+
+// BcfFormat_symbol_init + fill_symbol_VQ_fmts, main.hpp:4094-4251, 3820-3887
+DEV void allele_load(const RegionDev &R, const UvcParams &P, int64_t x, int sym, const Tot &T, int bDPa, int cDP0a, int gap_len, int minABQ, Al &f) {
+    f.symbol = sym;
+    f.a1BQf = VQP(R, UVC_VQ_a1BQf, sym, x); f.a1BQr = VQP(R, UVC_VQ_a1BQr, sym, x);
+    f.aMQs = S32(R, UVC_S_aMQs, sym, x); f.aP1 = S32(R, UVC_S_aP1, sym, x); f.aP2 = S32(R, UVC_S_aP2, sym, x);
+    f.aDPff = S32(R, UVC_S_aDPff, sym, x); f.aDPfr = S32(R, UVC_S_aDPfr, sym, x); f.aDPrf = S32(R, UVC_S_aDPrf, sym, x); f.aDPrr = S32(R, UVC_S_aDPrr, sym, x);
+    f.aLP1 = S32(R, UVC_S_aLP1, sym, x); f.aLP2 = S32(R, UVC_S_aLP2, sym, x); f.aLPL = S32(R, UVC_S_aLPL, sym, x);
+    f.aRP1 = S32(R, UVC_S_aRP1, sym, x); f.aRP2 = S32(R, UVC_S_aRP2, sym, x); f.aRPL = S32(R, UVC_S_aRPL, sym, x);
+    f.aLB1 = S32(R, UVC_S_aLB1, sym, x); f.aLB2 = S32(R, UVC_S_aLB2, sym, x); f.aLBL = S64(R, UVC_S64_aLBL, sym, x);
+    f.aRB1 = S32(R, UVC_S_aRB1, sym, x); f.aRB2 = S32(R, UVC_S_aRB2, sym, x); f.aRBL = S64(R, UVC_S64_aRBL, sym, x);
+    f.a2XM2 = S32(R, UVC_S_a2XM2, sym, x); f.a2BM2 = S32(R, UVC_S_a2BM2, sym, x); f.aBQ2 = S32(R, UVC_S_aBQ2, sym, x);
+    f.aPF1 = S32(R, UVC_S_aPF1, sym, x); f.aPF2 = S32(R, UVC_S_aPF2, sym, x);
+    f.aLI1 = S32(R, UVC_S_aLI1, sym, x); f.aLI2 = S32(R, UVC_S_aLI2, sym, x); f.aLIr = S32(R, UVC_S_aLIr, sym, x);
+    f.aRI1 = S32(R, UVC_S_aRI1, sym, x); f.aRI2 = S32(R, UVC_S_aRI2, sym, x); f.aRIf = S32(R, UVC_S_aRIf, sym, x);
+    f.bDPf = FRP(R, 0, UVC_FRAG_bDP, sym, x); f.bTAf = FRP(R, 0, UVC_FRAG_bTA, sym, x); f.bTBf = FRP(R, 0, UVC_FRAG_bTB, sym, x);
+    f.bDPr = FRP(R, 1, UVC_FRAG_bDP, sym, x); f.bTAr = FRP(R, 1, UVC_FRAG_bTA, sym, x); f.bTBr = FRP(R, 1, UVC_FRAG_bTB, sym, x);
+    f.cDP1f = FAP(R, 0, UVC_FAM_cDP1, sym, x); f.cDP12f = FAP(R, 0, UVC_FAM_cDP12, sym, x); f.cDP2f = FAP(R, 0, UVC_FAM_cDP2, sym, x); f.cDP3f = FAP(R, 0, UVC_FAM_cDP3, sym, x);
+    f.cDPMf = FAP(R, 0, UVC_FAM_cDPM, sym, x); f.cDPmf = FAP(R, 0, UVC_FAM_cDPm, sym, x);
+    f.cDP1r = FAP(R, 1, UVC_FAM_cDP1, sym, x); f.cDP12r = FAP(R, 1, UVC_FAM_cDP12, sym, x); f.cDP2r = FAP(R, 1, UVC_FAM_cDP2, sym, x); f.cDP3r = FAP(R, 1, UVC_FAM_cDP3, sym, x);
+    f.cDPMr = FAP(R, 1, UVC_FAM_cDPM, sym, x); f.cDPmr = FAP(R, 1, UVC_FAM_cDPm, sym, x);
+    f.c2LP1 = FIP(R, UVC_FI_c2LP1, sym, x); f.c2LP2 = FIP(R, UVC_FI_c2LP2, sym, x); f.c2LPL = FIP(R, UVC_FI_c2LPL, sym, x);
+    f.c2RP1 = FIP(R, UVC_FI_c2RP1, sym, x); f.c2RP2 = FIP(R, UVC_FI_c2RP2, sym, x); f.c2RPL = FIP(R, UVC_FI_c2RPL, sym, x);
+    f.c2LB1 = FIP(R, UVC_FI_c2LB1, sym, x); f.c2LB2 = FIP(R, UVC_FI_c2LB2, sym, x); f.c2LBL = FI64P(R, UVC_FI64_c2LBL, sym, x);
+    f.c2RB1 = FIP(R, UVC_FI_c2RB1, sym, x); f.c2RB2 = FIP(R, UVC_FI_c2RB2, sym, x); f.c2RBL = FI64P(R, UVC_FI64_c2RBL, sym, x);
+    f.c2BQ2 = FIP(R, UVC_FI_c2BQ2, sym, x); f.c2LP0 = FIP(R, UVC_FI_c2LP0, sym, x); f.c2RP0 = FIP(R, UVC_FI_c2RP0, sym, x);
+    f.dDP1 = DUP(R, UVC_DUPLEX_dDP1, sym, x); f.dDP2 = DUP(R, UVC_DUPLEX_dDP2, sym, x);
+    f.aLIT = S64(R, UVC_S64_aLIT, sym, x); f.aRIT = S64(R, UVC_S64_aRIT, sym, x); f.aP3 = S32(R, UVC_S_aP3, sym, x); f.aNC = S32(R, UVC_S_aNC, sym, x);
+    f.AD = f.cDP1f + f.cDP1r; f.bAD = f.bDPf + f.bDPr;
+    const int a2BQf = VQP(R, UVC_VQ_a2BQf, sym, x), a2BQr = VQP(R, UVC_VQ_a2BQr, sym, x);
+    const int aDPf = f.aDPff + f.aDPrf, aDPr = f.aDPfr + f.aDPrr;
+    const int ADP = (int)(T.ADPff0 + T.ADPrf0 + T.ADPfr0 + T.ADPrr0);
+    const int rssf = (int)(aDPf * sqrt((double)(((long long)a2BQf * SQR_QUAL_DIV) / imax(1, aDPf))));
+    const int rssr = (int)(aDPr * sqrt((double)(((long long)a2BQr * SQR_QUAL_DIV) / imax(1, aDPr))));
+    const int rssb = (int)((aDPf + aDPr) * sqrt((double)((a2BQf + a2BQr) * SQR_QUAL_DIV / imax(1, aDPf + aDPr))));
+    const double t = dmax(0.0, ((aDPf + aDPr + 0.5) * 2.0 / (ADP + 1.0) - 1.0));
+    int minABQa = minABQ - (int)(5 * 10.0 * (t * t));
+    const double sbratio = (double)(imax(aDPf, aDPr) * 10 + 10) / (double)(imin(aDPf, aDPr) * 10 + 10);
+    minABQa += ibetween((int)(sbratio * sbratio) - P.syserr_BQ_sbratio_q_add, 0, P.syserr_BQ_sbratio_q_max);
+    const int xmratio = (P.syserr_BQ_xmratio_q_max * 10 * (aDPf + aDPr) / imax(1, f.a2XM2));
+    const int bmratio = (P.syserr_BQ_bmratio_q_max * 10 * (aDPf + aDPr) / imax(1, f.a2BM2));
+    minABQa += ibetween(xmratio - P.syserr_BQ_xmratio_q_add, 0, P.syserr_BQ_xmratio_q_max) + ibetween(bmratio - P.syserr_BQ_bmratio_q_add, 0, P.syserr_BQ_bmratio_q_max);
+    const int m = P.syserr_BQ_strand_favor_mul;
+    const int q_fw = (rssf * m - minABQa * aDPf * m / 10 + rssr - minABQa * aDPr / 10) / m;
+    const int q_rv = (rssr * m - minABQa * aDPr * m / 10 + rssf - minABQa * aDPf / 10) / m;
+    const int q_2d = rssb - minABQa * (aDPf + aDPr) / 10;
+    const int a_rmsBQ = rssb / imax(1, aDPf + aDPr);
+    const int bMQraw = VQP(R, UVC_VQ_bMQ, sym, x);
+    f.bMQ = (int)round(sqrt((double)(((long long)bMQraw * SQR_QUAL_DIV) / imax(f.bDPf + f.bDPr, 1))) + (double)(1.0 - FLT_EPS));
+    f.aBQQ = imax(a_rmsBQ, P.syserr_BQ_prior + imax(q_2d, imax(q_fw, q_rv)));
+    f.a2BQf = rssf; f.a2BQr = rssr; f.aBQ = a_rmsBQ;
+    f.bIAQb = VQP(R, UVC_VQ_bIAQb, sym, x); f.bIADb = VQP(R, UVC_VQ_bIADb, sym, x);
+    f.cIAQf = VQP(R, UVC_VQ_cIAQf, sym, x); f.cIADf = VQP(R, UVC_VQ_cIADf, sym, x); f.cIDQf = VQP(R, UVC_VQ_cIDQf, sym, x);
+    f.cIAQr = VQP(R, UVC_VQ_cIAQr, sym, x); f.cIADr = VQP(R, UVC_VQ_cIADr, sym, x); f.cIDQr = VQP(R, UVC_VQ_cIDQr, sym, x);
+    f.bDPa = bDPa; f.cDP0a = cDP0a; f.gap_len = gap_len;
+}
+
+DEV bool short_frag(const Tot &T, int wgs_min) { return (T.APLRI[0] + T.APLRI[2]) < (T.APLRI[1] + T.APLRI[3]) * (long long)wgs_min; }   // does_fmt_imply_short_frag, main.hpp:169-174
+DEV double norm_fa(double FA, double refbias) { return (FA + FA * refbias) / (FA + (1.0 - FA) / (1.0 + refbias) + FA * refbias); }           // main.hpp:4253-4256
+
+struct RtrLite { int tracklen, unitlen, anyTR_tracklen; };
+DEV RtrLite load_rtr(const RegionDev &R, int idx) { RtrLite r; r.tracklen = RTRP(R, UVC_RTR_tracklen, idx); r.unitlen = RTRP(R, UVC_RTR_unitlen, idx); r.anyTR_tracklen = RTRP(R, UVC_RTR_anyTR_tracklen, idx); return r; }
+
+#define OUT(fld, v) fields[(size_t)(fld) * capacity + rec] = (v)
+
+// BcfFormat_symbol_calc_DPv, main.hpp:4274-4844
+DEV void calc_dpv(const RegionDev &R, const UvcParams &P, int64_t x, const Tot &T, Al &f, const RtrLite &rtr1, const RtrLite &rtr2, int refsymbol,
+                  int32_t *fields, int64_t capacity, int64_t rec) {
+    const bool tprov = P.tumor_vcf_is_provided;
+    const double unbias_ratio = (!tprov ? 1.0 : sqrt(2.0));
+    const double unbias_qualadd = (!tprov ? 0 : 3);
+    const int allprior = (!tprov ? 0 : 31);
+    const int pcr_dp = (int)T.APDP[5], a_dp = (int)T.APDP[0], near_pcr_clip = (int)T.APDP[9];
+    const bool strong_amp = (pcr_dp * 100 > a_dp * 50), weak_amp = (pcr_dp * 100 > a_dp * 30);
+    const double pfa = 0.5, c2altpc = 0.025;
+    const int ADP1 = (int)(T.ADPff0 + T.ADPfr0 + T.ADPrf0 + T.ADPrr0);
+    const int aDP = (f.aDPff + f.aDPfr + f.aDPrf + f.aDPrr);
+    const int ADP = imax(ADP1, near_pcr_clip);
+    const int cDP1 = f.cDP1f + f.cDP1r, CDP1 = T.CDP1b[0] + T.CDP1b[1];
+    const int sumCDP2 = T.CDP2b[0] + T.CDP2b[1], sumCDP1 = CDP1;
+    const double cFA2 = (f.cDP2f + f.cDP2r + c2altpc) / (sumCDP2 + 1.0);
+    const double cFA3 = (f.cDP3f + f.cDP3r + c2altpc) / ((T.CDP3b[0] + T.CDP3b[1]) + 1.0);
+    const int symbol = f.symbol;
+    double cbP = 1e-9, cbBQ = 1e-9, dir_bias_div = 1.0;
+    const bool nmore_amp = (!tprov ? strong_amp : weak_amp);
+    if ((nmore_amp && (0x2 == (0x2 & P.nobias_flag))) || ((!nmore_amp) && (0x1 == (0x1 & P.nobias_flag)))) {
+        const double oddsA_bias = prob2odds((aDP - f.aP1 + 0.5) / (ADP - T.AP10 + 1.0));
+        const double oddsA_nobias = prob2odds((f.aP1 + 0.5) / (T.AP10 + 1.0));
+        const bool pos_cb = ((oddsA_bias * P.microadjust_counterbias_pos_odds_ratio < oddsA_nobias * (unbias_ratio - DBL_EPS))
+                && (f.aP1 * (unbias_ratio - DBL_EPS) > aDP - f.aP1)
+                && ((ADP - T.AP10) * P.microadjust_counterbias_pos_fold_ratio * (unbias_ratio - DBL_EPS) > T.AP10)
+                && ((0 == P.primerlen && 0 != P.primerlen2) || !is_subst(symbol)));
+        if (pos_cb) cbP = dmax(cbP, (f.aP1 + 0.5) / (lmax(T.AP10, (long long)near_pcr_clip) + 1.0)); else cbP = dmax(cbP, 2e-9);
+        if (is_subst(symbol)) {
+            const bool f_good = ((T.ADPfr0 + T.ADPrr0) + 150 <= (T.ADPff0 + T.ADPrf0) * 5 * unbias_ratio);
+            const bool r_good = ((T.ADPff0 + T.ADPrf0) + 150 <= (T.ADPfr0 + T.ADPrr0) * 5 * unbias_ratio);
+            const int avg_f_aBQ = (f.a1BQf / imax(1, f.aDPff + f.aDPrf)), avg_r_aBQ = (f.a1BQr / imax(1, f.aDPfr + f.aDPrr));
+            const int avg_f_ABQ = (int)(T.A1BQf0 / lmax(1, T.ADPff0 + T.ADPrf0)), avg_r_ABQ = (int)(T.A1BQr0 / lmax(1, T.ADPfr0 + T.ADPrr0));
+            if ((f.a1BQf >= f.a1BQr) && (f_good && r_good) && (avg_f_aBQ + unbias_qualadd >= avg_r_ABQ + 14) && (avg_r_ABQ <= 14 + unbias_qualadd))
+                cbBQ = dmax(cbBQ, (f.aDPff + f.aDPrf + 0.5) / (T.ADPff0 + T.ADPrf0 + 1.0));
+            if ((f.a1BQr >= f.a1BQf) && (f_good && r_good) && (avg_r_aBQ + unbias_qualadd >= avg_f_ABQ + 14) && (avg_f_ABQ <= 14 + unbias_qualadd))
+                cbBQ = dmax(cbBQ, (f.aDPfr + f.aDPrr + 0.5) / (T.ADPfr0 + T.ADPrr0 + 1.0));
+        } else dir_bias_div = (1.0 + (unsigned)f.gap_len / (unsigned)P.indel_str_repeatsize_max);
+    }
+    const long long aDPgap = nnminus(lmax(T.APDP[1], T.APDP[2]), f.aP3);
+    const double aDPFAgap = ((rtr1.tracklen + rtr2.tracklen < P.indel_str_repeatsize_max) ? 1.0 : ((f.aP3 + pfa) / (aDPgap + 1.0)));
+    const double aDPFA1 = ((aDP + pfa) / (ADP + 1.0));
+    const double labelFA = (f.aP2 + 1.5 + f.aP2) / (T.AP20 + 2.0 + f.aP2);
+    const double aDPFA = dmin((is_subst(symbol) ? dmin(aDPFA1, dmax(aDPFA1 / 3, aDPFAgap)) : aDPFA1), labelFA * (ADP + 1.0) / (T.AP20 + 0.5) * unbias_ratio);
+    const int aDPplus = (is_subst(symbol) ? 0 : ((aDP + 1) * P.bias_prior_DPadd_perc / 100));
+    const double dp_coef = ((symbol == UVC_LINK_M) ? dmax(P.contam_any_mul_frac, 1.0 - imax(rtr1.tracklen, rtr2.tracklen) / (lmax(1, lmax(T.ALPL0, T.ARPL0)) / dmax(1.0 / 150.0, (double)T.ABQ20))) : 1.0);
+    double aPprior = P.bias_priorfreq_pos, aBprior = P.bias_priorfreq_pos;
+    const bool in_indel_read = ((T.APXM[1]) / 15.0 * P.microadjust_bias_pos_indel_fold * (P.bias_prior_var_DP_mul) > (aDP + aDPplus) * dp_coef);
+    const bool in_indel_len = (lmax(T.APDP[1], T.APDP[2]) * (P.bias_prior_var_DP_mul) > (aDP + aDPplus) * dp_coef);
+    const bool in_indel_rtr = (lmax(T.APDP[3], T.APDP[4]) * (P.bias_prior_var_DP_mul) > (aDP + aDPplus) * dp_coef);
+    const bool in_rtr = (imax(rtr1.tracklen, rtr2.tracklen) > round(P.indel_polymerase_size));
+    const bool in_dnv_read = ((UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform) && (T.APDP[7] * 2 > T.APDP[6]));
+    if (in_indel_read || in_dnv_read || ((is_ins(symbol) || is_del(symbol)) && (T.APXM[0] > T.APXM[1] * P.microadjust_bias_pos_indel_misma_to_indel_ratio))) {
+        aPprior -= P.bias_priorfreq_indel_in_read_div; aBprior -= P.bias_priorfreq_indel_in_read_div;
+    }
+    if (UVC_LINK_M != symbol && UVC_LINK_NN != symbol) {
+        double maxpf = 0;
+        if (in_indel_len) maxpf = dmax(maxpf, P.bias_priorfreq_indel_in_var_div2);
+        if (in_indel_rtr) maxpf = dmax(maxpf, P.bias_priorfreq_indel_in_str_div2);
+        if (in_rtr) maxpf = dmax(maxpf, P.bias_priorfreq_var_in_str_div2);
+        aBprior -= maxpf; aPprior -= maxpf;
+    }
+    aPprior += allprior; aBprior += allprior;
+    OUT(UVC_O_nPF0, (int)round(aPprior)); OUT(UVC_O_nPF1, (int)round(aBprior));
+    const double aIprior = (is_subst(symbol) ? P.bias_priorfreq_ipos_snv : P.bias_priorfreq_ipos_indel) + allprior;
+    const int homopol_len = ((1 == rtr1.unitlen) ? rtr1.tracklen : 0) + ((1 == rtr2.unitlen) ? rtr2.tracklen : 0);
+    const double aSBprior = (is_subst(symbol)
+            ? (imin((int)nnminus(f.aBQ, (((UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform) && (homopol_len > 0)) ? imin(5 * homopol_len, 20) : 0)), f.bMQ) + P.bias_priorfreq_strand_snv_base)
+            : (P.bias_priorfreq_strand_indel)) + allprior;
+    const double dedup_A2C1 = dmin(1.0, (double)imax(CDP1, P.bias_reduction_by_high_sequencingDP_min_n_totDepth) / (double)imax(ADP1, 1));
+    const double dedup_a2c1 = dmin(1.0, (double)imax(cDP1, P.bias_reduction_by_high_sequencingDP_min_n_altDepth) / (double)imax(aDP, 1));
+    const double dff = dmax(dedup_A2C1, dedup_a2c1);
+    const double pc_read = (in_indel_read ? P.bias_FA_pseudocount_indel_in_read : 0.5);
+    const double aBQ2d = (double)imax(1, f.aBQ2), ABQ2d = (double)lmax(1, T.ABQ20);
+    double r2[2];
+    dp4(r2, false, false, dff, f.aLP1, aDP, T.ALP20 + f.aLP1 - f.aLP2, ADP, P.powlaw_exponent, phred2nat(aPprior), lmax(1, f.aLPL) / aBQ2d, lmax(1, T.ALPL0) / ABQ2d, pc_read); double aLPFA = r2[0];
+    dp4(r2, false, false, dff, f.aRP1, aDP, T.ARP20 + f.aRP1 - f.aRP2, ADP, P.powlaw_exponent, phred2nat(aPprior), lmax(1, f.aRPL) / aBQ2d, lmax(1, T.ARPL0) / ABQ2d, pc_read); double aRPFA = r2[0];
+    dp4(r2, false, false, dff, f.aLB1, aDP, T.ALB20 + f.aLB1 - f.aLB2, ADP, P.powlaw_exponent, phred2nat(aBprior), lmax(1, f.aLBL) / aBQ2d, lmax(1, T.ALBL0) / ABQ2d, pc_read); double aLBFA = r2[0];
+    dp4(r2, false, false, dff, f.aRB1, aDP, T.ARB20 + f.aRB1 - f.aRB2, ADP, P.powlaw_exponent, phred2nat(aBprior), lmax(1, f.aRBL) / aBQ2d, lmax(1, T.ARBL0) / ABQ2d, pc_read); double aRBFA = r2[0];
+    const bool tmore_amp = (!tprov ? weak_amp : strong_amp);
+    const int normCDP1 = (T.CDP12b[0] + T.CDP12b[1]) + 1, normBDP = (T.BDPb[0] + T.BDPb[1]) + 1;
+    const int c2DP = f.cDP2f + f.cDP2r;
+    f.tier2 = ((c2DP >= 2) && (normBDP * P.fam_bias_overseq_perc >= normCDP1 * 100) && (T.APDP[11] * 100 > (long long)a_dp * 50)) ? 1 : 0;
+    OUT(UVC_O_tier2, f.tier2);
+    const double cFA2L = (f.tier2 ? (((double)(((long long)f.c2LP0 * f.c2LP0) * 2 / lmax(1, (long long)imin(c2DP, f.c2LP0 * 4))) + c2altpc) / (T.C2LP00 + 1.0)) : 1.0);
+    const double cFA2R = (f.tier2 ? (((double)(((long long)f.c2RP0 * f.c2RP0) * 2 / lmax(1, (long long)imin(c2DP, f.c2RP0 * 4))) + c2altpc) / (T.C2RP00 + 1.0)) : 1.0);
+    double c2LPFA = 1.0, c2RPFA = 1.0, c2LBFA = 1.0, c2RBFA = 1.0;
+    if (f.tier2) {
+        const double c2Pp = dmax(0.0, aPprior), c2Bp = dmax(0.0, aBprior);
+        const double cb = (double)imax(1, f.c2BQ2), CB = (double)lmax(1, T.C2BQ20);
+        dp4(r2, false, true, -1, f.c2LP1, c2DP, T.C2LP20 + f.c2LP1 - f.c2LP2, sumCDP2, P.powlaw_exponent, phred2nat(c2Pp), lmax(1, f.c2LPL) / cb, lmax(1, T.C2LPL0) / CB, c2altpc, 1.0); c2LPFA = r2[0];
+        dp4(r2, false, true, -1, f.c2RP1, c2DP, T.C2RP20 + f.c2RP1 - f.c2RP2, sumCDP2, P.powlaw_exponent, phred2nat(c2Pp), lmax(1, f.c2RPL) / cb, lmax(1, T.C2RPL0) / CB, c2altpc, 1.0); c2RPFA = r2[0];
+        dp4(r2, false, true, -1, f.c2LB1, c2DP, T.C2LB20 + f.c2LB1 - f.c2LB2, sumCDP2, P.powlaw_exponent, phred2nat(c2Bp), lmax(1, f.c2LBL) / cb, lmax(1, T.C2LBL0) / CB, c2altpc, 1.0); c2LBFA = r2[0];
+        dp4(r2, false, true, -1, f.c2RB1, c2DP, T.C2RB20 + f.c2RB1 - f.c2RB2, sumCDP2, P.powlaw_exponent, phred2nat(c2Bp), lmax(1, f.c2RBL) / cb, lmax(1, T.C2RBL0) / CB, c2altpc, 1.0); c2RBFA = r2[0];
+    }
+    double LI2[2], RI2[2];
+    {
+        const double ALpd = (T.ALI20 + 0.5) / (T.ADPfr0 + T.ADPrr0 - T.ALI20 + 0.5);
+        const double aLpd = (f.aLI1 + ALpd / (1.0 + ALpd)) / (f.aDPfr + f.aDPrr - f.aLI1 + 1.0 / (1.0 + ALpd));
+        dp4(LI2, false, false, dff, f.aLI1, (f.aDPfr + f.aDPrr), (T.ALI20 + f.aLI1 - f.aLI2), (T.ADPfr0 + T.ADPrr0), P.powlaw_exponent, phred2nat(aIprior), aLpd, ALpd, 0.25, 0.5);
+        const double ARpd = (T.ARI20 + 0.5) / (T.ADPff0 + T.ADPrf0 - T.ARI20 + 0.5);
+        const double aRpd = (f.aRI1 + ARpd / (1.0 + ARpd)) / (f.aDPff + f.aDPrf - f.aRI1 + 1.0 / (1.0 + ARpd));
+        dp4(RI2, false, false, dff, f.aRI1, (f.aDPff + f.aDPrf), (T.ARI20 + f.aRI1 - f.aRI2), (T.ADPff0 + T.ADPrf0), P.powlaw_exponent, phred2nat(aIprior), aRpd, ARpd, 0.25, 0.5);
+    }
+    double aLIFA = LI2[0] * (tmore_amp ? dir_bias_div : dmax(dir_bias_div, aDPFA / LI2[1]));
+    double aRIFA = RI2[0] * (tmore_amp ? dir_bias_div : dmax(dir_bias_div, aDPFA / RI2[1]));
+    const double aSIFA = dmax((f.aLI1 + 0.5) / (T.ALI20 + f.aLI1 - f.aLI2 + 1.0), (f.aRI1 + 0.5) / (T.ARI20 + f.aRI1 - f.aRI2 + 1.0));
+    const int indel_size = f.gap_len;
+    if (is_ins(symbol) || is_del(symbol)) {
+        const double coef = imax(1, f.bDPa) / (double)imax(1, f.bDPf + f.bDPr);
+        const bool major_reg = ((lmax(T.APDP[1], T.APDP[3]) + lmax(T.APDP[2], T.APDP[4])) * 0.5 * (1.0 + (double)FLT_EPS) < aDP * coef);
+        if ((imin(indel_size, P.microadjust_nobias_pos_indel_maxlen) * aDPFA * coef >= P.nobias_pos_indel_lenfrac_thres) ||
+            (imax(rtr1.tracklen, rtr2.tracklen) >= P.nobias_pos_indel_str_track_len && major_reg && !(T.APXM[0] > T.APXM[1] * P.microadjust_nobias_pos_indel_misma_to_indel_ratio))) {
+            aLPFA += 2.0; aRPFA += 2.0; aLBFA += 2.0; aRBFA += 2.0;
+            if (f.tier2) { c2LPFA += 2.0; c2RPFA += 2.0; c2LBFA += 2.0; c2RBFA += 2.0; }
+        }
+        if (f.bMQ >= P.microadjust_nobias_pos_indel_bMQ && f.a2XM2 * 100 >= aDP * 100 * P.microadjust_nobias_pos_indel_perc) { aLIFA += 2.0; aRIFA += 2.0; }
+    } else if (UVC_LINK_M == symbol || UVC_LINK_NN == symbol) {
+        const double pc = P.bias_FA_pseudocount_indel_in_read;
+        aLBFA = dmin(aLBFA, (pc + f.aLB1) / (double)(pc * 2 + ADP));
+        aRBFA = dmin(aRBFA, (pc + f.aRB1) / (double)(pc * 2 + ADP));
+    } else if (refsymbol == symbol) { aLIFA = aRIFA = dmax(aLIFA, aRIFA); }
+    const long long avg_sqr = lmax(T.APXM[4] / lmax(1, T.APDP[1]), T.APXM[5] / lmax(1, T.APDP[2]));
+    if ((!is_subst(symbol)) && ((long long)P.microadjust_nobias_pos_indel_maxlen * P.microadjust_nobias_pos_indel_maxlen < avg_sqr)
+        && (UVC_LINK_M == symbol || UVC_LINK_NN == symbol || ((long long)(indel_size * 2) * (indel_size * 2) < avg_sqr))) {
+        const double pc = P.bias_FA_pseudocount_indel_in_read;
+        const double aLmin = (pc + f.aLP1) / (double)(pc * 2 + T.ALP10), aRmin = (pc + f.aRP1) / (double)(pc * 2 + T.ALP10);   // sic: ALP1 in both (main.hpp:4575-4576)
+        aLPFA = dmin(aLPFA, aLmin); aRPFA = dmin(aRPFA, aRmin);
+        if (f.tier2) { c2LPFA = dmin(c2LPFA, aLmin); c2RPFA = dmin(c2RPFA, aRmin); }
+    }
+    if (tprov || (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform)) aLIFA = aRIFA = dmax(aLIFA, aRIFA);
+    const double aPFFA = (f.aPF1 + pfa * 100.0) / (T.APF20 + (f.aPF1 - f.aPF2) + 100.0);
+    double SS2[2];
+    dp4(SS2, true, false, dff, f.aRIf, f.aLIr, T.ARIf0, T.ALIr0, P.powlaw_exponent, phred2nat(aSBprior));
+    const double ori_base = (is_subst(symbol) ? P.bias_priorfreq_orientation_snv_base : P.bias_priorfreq_orientation_indel_base) + allprior;
+    const double te = dmax(aDPFA, P.bias_orientation_min_effective_allelefrac);
+    const double ori_all = log(te * te) + phred2nat(ori_base);
+    double RO1[2], RO2[2];
+    dp4(RO1, true, false, dff, f.cDP1f, f.cDP1r, T.CDP1b[0], T.CDP1b[1], P.powlaw_exponent, ori_all);
+    if (P.bias_is_orientation_artifact_mixed_with_sequencing_error) {
+        double c12[2];
+        dp4(c12, true, false, dff, f.cDP12f, f.cDP12r, T.CDP12b[0], T.CDP12b[1], P.powlaw_exponent, ori_all);
+        if ((T.ADPff0 * 8 >= ADP) && (T.ADPfr0 * 8 >= ADP) && (T.ADPrf0 * 8 >= ADP) && (T.ADPrr0 * 8 >= ADP)) { RO1[0] = c12[0]; RO1[1] = c12[1]; }
+    }
+    dp4(RO2, true, true, -1, f.cDP2f, f.cDP2r, T.CDP2b[0], T.CDP2b[1], P.powlaw_exponent, ori_all, -1, -1, c2altpc, 1.0);
+    double aSSFA = SS2[0] * dir_bias_div, cROFA1 = RO1[0] * dir_bias_div, cROFA2 = RO2[0] * dir_bias_div;
+    if (is_ins(symbol) || is_del(symbol)) { f.bAD = imin(f.bAD, f.bDPa); f.AD = imin(f.AD, f.cDP0a); }
+    const double bFA = (f.bDPa + pfa) / ((T.BDPb[0] + T.BDPb[1]) + 1.0);
+    const double cFA0 = (f.cDP0a + pfa * (short_frag(T, P.lib_wgs_min_avg_fraglen) ? P.lib_nonwgs_ad_pseudocount : 1.0)) / (sumCDP1 + 1.0);
+    if ((T.ADPfr0 + T.ADPrr0) * P.microadjust_nobias_strand_all_fold < (T.ADPff0 + T.ADPrf0) * unbias_ratio) { aLIFA += 4.0; aSSFA += 4.0; }
+    if ((T.ADPff0 + T.ADPrf0) * P.microadjust_nobias_strand_all_fold < (T.ADPfr0 + T.ADPrr0) * unbias_ratio) { aRIFA += 4.0; aSSFA += 4.0; }
+    const double aLPFA2 = dmax(aDPFA * 0.01, aLPFA), aRPFA2 = dmax(aDPFA * 0.01, aRPFA), aLBFA2 = dmax(aDPFA * 0.01, aLBFA), aRBFA2 = dmax(aDPFA * 0.01, aRBFA);
+    const double c2LPFA2 = dmax(cFA2 * 0.01, c2LPFA), c2RPFA2 = dmax(cFA2 * 0.01, c2RPFA), c2LBFA2 = dmax(cFA2 * 0.01, c2LBFA), c2RBFA2 = dmax(cFA2 * 0.01, c2RBFA);
+    const double aLIFA2 = dmax(aDPFA * 0.01, aLIFA), aRIFA2 = dmax(aDPFA * 0.01, aRIFA), aSSFA2 = dmax(aDPFA * 0.05, aSSFA);
+    cROFA1 = dmax(aDPFA * 1e-4, cROFA1); cROFA2 = dmax(aDPFA * 1e-4, cROFA2);
+    const double fBTA = (double)((T.BTAb[0] + T.BTAb[1]) + 200), fBTB = (double)((T.BTBb[0] + T.BTBb[1]) + 6);
+    const double fbTA = (double)(f.bTAf + f.bTAr + 100), fbTB = (double)(f.bTBf + f.bTBr + 3);
+    const long long sl = lmin(
+            lmin(lmax(0, f.aLIT / lmax(1, (long long)(f.aDPfr + f.aDPrr)) - P.microadjust_longfrag_sidelength_min), (long long)P.microadjust_longfrag_sidelength_max),
+            lmin(lmax(0, f.aRIT / lmax(1, (long long)(f.aDPff + f.aDPrf)) - P.microadjust_longfrag_sidelength_min), (long long)P.microadjust_longfrag_sidelength_max));
+    const double sidelen_frac = 1.0 - sl / P.microadjust_longfrag_sidelength_zeroMQpenalty;
+    const double _alt_frac = fbTB / fbTA;
+    const double alt_frac = (nmore_amp ? (dmax(0.0, _alt_frac - 0.2) * 1.25) : _alt_frac);
+    const double nonalt_frac = (fBTB + P.contam_any_mul_frac * fbTB - fbTB) / (fBTA + P.contam_any_mul_frac * fbTA - fbTA);
+    const double frac_mut = dmax(P.syserr_MQ_NMR_expfrac, P.syserr_MQ_NMR_altfrac_coef * alt_frac * sidelen_frac - P.syserr_MQ_NMR_nonaltfrac_coef * nonalt_frac);
+    f.bNMQ = (int)round(numstates2phred(pow(frac_mut / P.syserr_MQ_NMR_expfrac, (P.syserr_MQ_NMR_pl_exponent))) * (frac_mut));
+    OUT(UVC_O_bNMQ, f.bNMQ); OUT(UVC_O_bNMa, (int)round(100 * alt_frac)); OUT(UVC_O_bNMb, (int)round(100 * nonalt_frac));
+    const bool tmore_primer = (tmore_amp || ((P.primerlen > 0) && !(0x4 & P.primer_flag)));
+    double t1only = dmin(cROFA1, dmin(aLPFA2, dmin(aRPFA2, dmin(aLBFA2, dmin(aRBFA2, cFA0)))));
+    t1only = dmin(t1only, dmin(aDPFA * dbetween(1.0 + aDPFA - alt_frac, 0.1, 1.0), aPFFA * aSSFA2 / dmax(aSSFA2, SS2[1])));
+    const double t1plus = dmin(aSSFA2, dmin(aLIFA2, dmin(aRIFA2, dmin(dmax(aDPFA * 0.01, aSIFA), bFA))));
+    const double cFA2a = (tmore_primer ? (cFA2 * (P.powlaw_amplicon_allele_fraction_coef)) : cFA2);
+    const double cFA3a = ((normBDP * 100 > normCDP1 * ((P.fam_tier3DP_bias_overseq_perc - 100) / 1 + 100)) ? cFA3 : 1.0);
+    const double c23FA = cFA2a;
+    const double t2only = dmin(cROFA2, dmin(c2LPFA2, dmin(c2RPFA2, dmin(c2LBFA2, dmin(c2RBFA2, dmin(cFA2a, dmin(cFA3a, dmin(cFA2L, cFA2R))))))));
+    OUT(UVC_O_nNFA0, -numstates2deciphred(cbP)); OUT(UVC_O_nNFA1, -numstates2deciphred(cbBQ)); OUT(UVC_O_nNFA2, -numstates2deciphred(aDPFA));
+    OUT(UVC_O_nNFA3, -numstates2deciphred(bFA)); OUT(UVC_O_nNFA4, -numstates2deciphred(cFA0)); OUT(UVC_O_nNFA5, -numstates2deciphred(cFA2));
+    int FTS = 0, bit = 0;
+    auto push = [&](int fld, double refFA, double biasFA) {   // fmt_bias_push, main.hpp:4258-4272
+        OUT(fld, -numstates2deciphred(biasFA));
+        if (biasFA < refFA * P.bias_thres_FTS_FA) FTS |= (1 << bit);
+        bit++;
+    };
+    push(UVC_O_nAFA0, aDPFA, aSSFA2); push(UVC_O_nAFA1, aDPFA, aPFFA); push(UVC_O_nAFA2, aDPFA, aSIFA); push(UVC_O_nAFA3, aDPFA, aLBFA2); push(UVC_O_nAFA4, aDPFA, aRBFA2);
+    push(UVC_O_nAFA5, aDPFA, aLPFA2); push(UVC_O_nAFA6, aDPFA, aRPFA2); push(UVC_O_nAFA7, aDPFA, aLIFA2); push(UVC_O_nAFA8, aDPFA, aRIFA2);
+    push(UVC_O_nBCFA0, bFA, cFA0); push(UVC_O_nBCFA1, cFA0, bFA); push(UVC_O_nBCFA2, cFA0, cROFA1); push(UVC_O_nBCFA3, cFA2, cROFA2);
+    push(UVC_O_nBCFA4, cFA2, c2LPFA2); push(UVC_O_nBCFA5, cFA2, c2RPFA2); push(UVC_O_nBCFA6, cFA2, c2LBFA2); push(UVC_O_nBCFA7, cFA2, c2RBFA2);
+    push(UVC_O_nBCFA8, cFA2, cFA2L); push(UVC_O_nBCFA9, cFA2, cFA2R);
+    OUT(UVC_O_FTS, FTS);
+    const double aNCFA = ((!tprov && short_frag(T, P.lib_wgs_min_avg_fraglen) && (is_ins(symbol) || is_del(symbol)) && indel_size >= P.lib_nonwgs_clip_penal_min_indelsize)
+            ? dmax((f.aNC + 0.5) / (ADP + 1.0), dbetween((f.cDP1f + f.cDP1r) / 300.0, 1.0 / 3.0, 2.0 / 3.0) * aDPFA) : 2.0);
+    const double cb_normalgerm = ((!tprov || !short_frag(T, P.lib_wgs_min_avg_fraglen)) ? 1e-9
+            : dbetween(aPFFA * aPFFA * (1.0 / P.lib_nonwgs_normal_full_self_rescue_fa), aPFFA * P.lib_nonwgs_normal_min_self_rescue_fa_ratio, aPFFA));
+    const double cbFA = dmax(cbP, dmax(cbBQ, cb_normalgerm));
+    const double dedup_FA = (!tprov ? dmin(bFA, cFA0) : dmax(bFA, cFA0));
+    const double frac_umi2seg = dmin(1.0, dmin(c23FA / aDPFA, aDPFA / c23FA));
+    const double refbias = 0;
+    f.cDP1v = (int)(norm_fa(dmax(dmin(dmin(t1plus, t1only), aNCFA), cbFA), refbias) * sumCDP1 * 100);
+    f.cDP1w = (int)(norm_fa(dmax(dmin(aLPFA2, dmin(aRPFA2, dmin(aLBFA2, dmin(aRBFA2, dmin(bFA, aNCFA))))), cbFA), refbias) * sumCDP1 * 100);
+    double abc_x = dmin(aPFFA, dedup_FA);
+    if (tprov) abc_x = dmax(abc_x, cbFA);
+    f.cDP1x = 1 + (int)(abc_x * sumCDP1 * 100);
+    const double cFA2c = cFA2 * cFA2 * cFA2;
+    const double c2XB = dbetween(3.0 * c2LBFA2 * c2RBFA2 * aSSFA2 / cFA2c, dmin(c2LBFA2, c2RBFA2) / 8.0, dmin(c2LBFA2, c2RBFA2));
+    const double c2XP = dbetween(3.0 * c2LPFA2 * c2RPFA2 * aSSFA2 / cFA2c, dmin(c2LPFA2, c2RPFA2) / 8.0, dmin(c2LPFA2, c2RPFA2));
+    const double c2XX = dmin(c2XB, c2XP);
+    f.cDP2v = (int)(norm_fa(dmax(dmin(dmin(t1plus, dmin(t2only, c2XX)), aNCFA), cbFA * frac_umi2seg), refbias) * sumCDP2 * 100);
+    f.cDP2w = (int)(norm_fa(dmax(dmin(c2LPFA2, dmin(c2RPFA2, dmin(c2XX, dmin(c2LBFA2, dmin(c2RBFA2, dmin(cFA2, aNCFA)))))), cbFA * frac_umi2seg), refbias) * sumCDP2 * 100);
+    f.cDP2x = 1 + (int)(dmin(aPFFA, c23FA) * sumCDP2 * 100);
+    OUT(UVC_O_cDP1v, f.cDP1v); OUT(UVC_O_cDP1w, f.cDP1w); OUT(UVC_O_cDP1x, f.cDP1x); OUT(UVC_O_cDP2v, f.cDP2v); OUT(UVC_O_cDP2w, f.cDP2w); OUT(UVC_O_cDP2x, f.cDP2x);
+    OUT(UVC_O_AD, f.AD); OUT(UVC_O_bAD, f.bAD);
+}
+
+// BcfFormat_symbol_calc_qual, main.hpp:4908-5343
+DEV void calc_qual(const RegionDev &R, const UvcParams &P, const Tot &T, const Al &f, const int CDP1v0, const int CDP1x0,
+                   int ins_cdepth, int del_cdepth, int ins1_cdepth, int del1_cdepth, int ru_size, int repeatnum, const RtrLite &rtr1, const RtrLite &rtr2, int refsymbol,
+                   int32_t *fields, int64_t capacity, int64_t rec) {
+    const bool tprov = P.tumor_vcf_is_provided, is_rescued = tprov;
+    const double tpfa = -1.0;
+    const int symbol = f.symbol, indel_size = f.gap_len;
+    const int sumCDP1 = T.CDP1b[0] + T.CDP1b[1], sumCDP2 = T.CDP2b[0] + T.CDP2b[1], sumBDP = T.BDPb[0] + T.BDPb[1], sumCDP12 = T.CDP12b[0] + T.CDP12b[1];
+    const double cFA2 = (f.cDP2f + f.cDP2r + 0.5) / (sumCDP2 + 1.0);
+    const int phrederr = sscs_phred(P, refsymbol, symbol) + (!tprov ? 0 : 4);
+    const double umi_cFA = (((double)(f.cDP2v) + 0.5) / ((double)(sumCDP2 * 100 + 1.0)));
+    const double umi_cFA_w = (((double)(f.cDP2w) + 0.5) / ((double)(sumCDP2 * 100 + 1.0)));
+    const int inc1 = (int)(phrederr - (is_subst(symbol)
+            ? (((UVC_BASE_A == refsymbol && UVC_BASE_T == symbol) || (UVC_BASE_T == refsymbol && UVC_BASE_A == symbol)) ? (double)P.fam_phred_pow_sscs_transversion_AT_TA_origin : P.fam_phred_pow_sscs_snv_origin)
+            : P.fam_phred_pow_sscs_indel_origin));
+    int inc4tn = (is_subst(symbol)
+            ? (int)(imax(imax(P.fam_phred_sscs_transition_CG_TA, P.fam_phred_sscs_transition_AT_GC), imax(P.fam_phred_sscs_transversion_CG_AT, P.fam_phred_sscs_transversion_other)) - (P.fam_phred_pow_sscs_snv_origin))
+            : inc1);
+    const bool oxid = ((UVC_BASE_C == refsymbol && UVC_BASE_A == symbol) || (UVC_BASE_G == refsymbol && UVC_BASE_T == symbol));
+    inc4tn += (oxid ? P.tn_q_inc_max_sscs_CG_AT : P.tn_q_inc_max_sscs_other);
+    const double t2n = (tpfa > 0 ? tpfa : 0) * P.contam_t2n_mul_frac;
+    const double contamfrac = P.contam_any_mul_frac + (1.0 - P.contam_any_mul_frac) * t2n;
+    const int aDP = (f.aDPff + f.aDPfr + f.aDPrf + f.aDPrr);
+    const int ADP = (int)(T.ADPff0 + T.ADPrf0 + T.ADPfr0 + T.ADPrr0);
+    const int cDP0 = (f.cDP1f + f.cDP1r), CDP0 = sumCDP1, cDP2 = (f.cDP2f + f.cDP2r), CDP2 = sumCDP2;
+    const int aavgMQ = (int)(f.aMQs / imax(1, aDP));
+    const int diffAaMQs = (int)((T.AMQs0 - f.aMQs) / imax(1, ADP - aDP)) - aavgMQ;
+    const int noUMI_inc = imin(P.bias_FA_powerlaw_noUMI_phred_inc_snv, aDP / 2);
+    const double pl_noUMI = P.powlaw_anyvar_base + (is_subst(symbol) ? noUMI_inc : P.bias_FA_powerlaw_noUMI_phred_inc_indel);
+    const int withUMI_inc = imin(P.bias_FA_powerlaw_withUMI_phred_inc_snv - P.bias_FA_powerlaw_noUMI_phred_inc_snv, cDP2 / 2) + noUMI_inc;
+    const double pl_withUMI = P.powlaw_anyvar_base + (is_subst(symbol) ? withUMI_inc : P.bias_FA_powerlaw_withUMI_phred_inc_indel);
+    const double prior_weight = 1.0 / (f.cDPmf + f.cDPmr + 1.0);
+    const int thres_highBQ = (is_subst(symbol) ? P.fam_thres_highBQ_snv : P.fam_thres_highBQ_indel);
+    const int cMmQ = (int)round(numstates2phred((f.cDPMf + f.cDPmf + f.cDPMr + f.cDPmr + pow(10.0, thres_highBQ / 10.0) * prior_weight) / (f.cDPmf + f.cDPmr + prior_weight)));
+    const int nb1 = f.bIADb * 100 + 1, nb2 = imin(nb1, f.cDP1v + 1);
+    const long long pq1 = 10 * f.bIAQb / imax(1, f.bIADb);
+    const long long pq2 = pq1 + (long long)round(10 * numstates2phred((double)nb2 / (double)nb1));
+    long long duped_binom = ((is_ins(symbol) || is_del(symbol)) ? pq1 : pq2) * nb2 / (10 * 100);
+    const long long contam_frag_q = (long long)round(binom_llr(t2n, cDP0, CDP0 - cDP0)) + 9 - 3;
+    const int h_snp = imax(0, 2 * P.germ_phred_hetero_snp - P.germ_phred_het3al_snp), h_indel = imax(0, 2 * P.germ_phred_hetero_indel - P.germ_phred_het3al_indel);
+    int het3al_inc = (is_subst(symbol) ? h_snp : h_indel);
+    if (is_ins(symbol) || is_del(symbol)) het3al_inc = (int)nnminus(h_indel + 1, indel_size);
+    const int normcDP1 = (f.cDP12f + f.cDP12r + 1), normCDP1 = sumCDP12 + 1, normBDP = sumBDP + 1;
+    const int ddiv = (is_rescued ? 2 : 1);
+    const long long dec1a = (((P.fam_min_n_copies / ddiv <= normCDP1) || (P.fam_min_n_copies_DPxAD / ddiv <= (long long)normCDP1 * normcDP1)) ? 0 : (inc1 + 3));
+    const long long dec1b = (((long long)((P.fam_min_overseq_perc - 100) / ddiv + 100) * normCDP1 <= (long long)100 * normBDP) ? 0 : (inc1 + 3));
+    const long long dec1 = lmax(dec1a, dec1b);
+    const long long dec2 = nnminus(thres_highBQ, cMmQ);
+    const long long cIADnorm = (long long)(f.cIADf + f.cIADr) * 100 + 1;
+    const long long cIADmin = lmin(cIADnorm, (long long)f.cDP2v + 1);
+    const long long bq_fw = f.cIAQf + ((long long)f.cIAQr * imin(P.fam_phred_dscs_all - f.cIDQf, f.cIDQr)) / imax(f.cIDQr, 1);
+    const long long bq_rv = f.cIAQr + ((long long)f.cIAQf * imin(P.fam_phred_dscs_all - f.cIDQr, f.cIDQf)) / imax(f.cIDQf, 1);
+    const long long contam_sscs_q = (long long)round(binom_llr(t2n, cDP2, CDP2 - cDP2)) + 9 - 3;
+    long long sscs_binom = ((long long)nnminus_d((double)lmax(bq_fw, bq_rv), numstates2phred(cIADnorm / (double)cIADmin) * cIADnorm / 100.0) * cIADmin) / (cIADnorm);
+    if (lmax(bq_fw, bq_rv) > P.microadjust_fam_binom_qual_halving_thres && is_subst(symbol))
+        sscs_binom = lmin(sscs_binom, P.microadjust_fam_binom_qual_halving_thres + (lmax(bq_fw, bq_rv) - P.microadjust_fam_binom_qual_halving_thres) / 2);
+    sscs_binom -= dec1 + dec2;
+    const double bcFA_v = (((double)(f.cDP1v) + 0.5) / (double)(sumCDP1 * 100 + 1.0));
+    int pl_v = (int)round(P.powlaw_exponent * numstates2phred(bcFA_v) + (pl_noUMI));
+    const double bcFA_w = (((double)(f.cDP1w) + 0.5) / (double)(sumCDP1 * 100 + 1.0));
+    int pl_w = (int)round(P.powlaw_exponent * numstates2phred(bcFA_w) + (pl_noUMI) + P.tn_q_inc_max);
+    const int ds_pl = (int)round(10 / log(10.0) * dmin(log((f.cDP12f + 0.5) / (T.CDP12b[0] + 1.0)), log((f.cDP12r + 0.5) / (T.CDP12b[1] + 1.0)))) + (phrederr);
+    const int ds_binom = 3 * imin(f.cDP2f, f.cDP2r);
+    const long long m5 = lmin(lmin(bq_fw, bq_rv), (long long)imin(ds_pl, imin(ds_binom, 3)));
+    const int inc2 = (int)lmax(0, m5) * ((cFA2 > 0.002) ? 1 : 0);
+    const int dec3 = (is_rescued ? (-3) : ((cFA2 >= 0.003) ? 0 : 5));
+    const int base_2 = (int)(pl_withUMI + inc1 + inc2 - dec1 - dec2 - dec3);
+    const int base_2tn = (int)(pl_withUMI + inc4tn + inc2 - dec1 - dec2 - dec3);
+    int sscs_pl_v = (int)round((P.powlaw_exponent * numstates2phred(umi_cFA) + base_2));
+    int sscs_pl_w = (int)round((P.powlaw_exponent * numstates2phred(umi_cFA_w) + base_2tn));
+    const double dFA = (double)(f.dDP2 + 0.5) / (double)(T.DDP10 + 1.0);
+    const double dSNR = (double)(f.dDP2 + 0.5) / (double)(f.dDP1 + 1.0);
+    const double dnormFA = dFA * pow(dSNR, 1.0 / P.powlaw_exponent);
+    const long long dscs_est = (long long)round((P.fam_phred_dscs_max + phrederr) / 2.0);
+    const long long dFA_binom = (dscs_est - (long long)round(numstates2phred(1.0 / (dnormFA)))) * (long long)f.dDP2 * cIADmin / cIADnorm;
+    const int dFA_pl = (int)(P.powlaw_anyvar_base + (dscs_est - P.fam_phred_pow_dscs_all_origin)
+            + (int)round(numstates2phred((dnormFA) * dmin(1.0, (double)((f.cDP1v) + 0.5) / (double)(sumCDP1 * 100 + 1.0)))));
+    OUT(UVC_O_cMmQ, cMmQ);
+    const double eps = (double)FLT_EPS;
+    const bool penal_applied = ((UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform) && !tprov);
+    const int penal_base = (penal_applied ? ((int)round(P.indel_multiallele_samepos_penal / log(2.0) * log((double)dmax(aDP + eps, (double)lmax(T.APDP[1], T.APDP[2])) / (double)(aDP + eps)))) : 0);
+    int penal4multi = 0, penal4multi_g = 0, penal4multi_soma = 0, indel_UMI_penal = 0;
+    if (indel_size > 0 && f.cDP0a > 0) {
+        const double indel_pq = (double)imin(indel_phred_s(P.indel_polymerase_slip_rate, ru_size, repeatnum), 24) + 2 - (double)10;
+        const int eff1 = (ru_size * imax(1, repeatnum) - ru_size);
+        const int eff2 = (imax(rtr1.tracklen - rtr1.unitlen, rtr2.tracklen - rtr2.unitlen) / 3);
+        const int effm = imax(eff1, eff2);
+        const double indel_ic = numstates2phred((double)imax(indel_size + (is_ins(symbol) ? 1 : 0), 1) / (double)(effm + 1))
+                + (is_ins(symbol) ? (numstates2phred(P.indel_del_to_ins_err_ratio) * imin(200, f.cDP0a) / 200) : 0);
+        int ic = (is_ins(symbol) ? ins_cdepth : del_cdepth);
+        if (UVC_LINK_D1 == symbol) ic += ins1_cdepth;
+        if (UVC_LINK_I1 == symbol) ic = (int)(ic + del1_cdepth / P.indel_del_to_ins_err_ratio);
+        const int nearInDelDP = (int)(is_ins(symbol) ? T.APDP[1] : T.APDP[2]);
+        int penal1 = (int)round(P.indel_multiallele_samepos_penal / log(2.0) * log((double)(ic + eps) / (double)(f.cDP0a + eps)));
+        if (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform) penal1 = (int)nnminus_d(penal1, P.indel_multiallele_samepos_penal);
+        const int penal2 = (int)round(P.indel_multiallele_diffpos_penal / log(2.0) * log((double)(nearInDelDP + eps) / (double)(imax(aDP, nearInDelDP) + eps)));
+        penal4multi_g = (int)((int)round(P.indel_tetraallele_germline_penal_value / log(2.0) * log((double)(ins_cdepth + del_cdepth + eps) / (double)(f.cDP0a + eps))) - P.indel_tetraallele_germline_penal_thres);
+        if (is_ins(symbol)) { penal4multi = (penal1 * P.indel_ins_penal_pseudocount / (P.indel_ins_penal_pseudocount + indel_size)); penal4multi_soma = penal4multi; }
+        else { penal4multi = imax(penal1, penal2); penal4multi_soma = penal1; }
+        pl_v += (int)round(indel_ic); pl_w += (int)round(indel_ic);
+        duped_binom += (long long)round(indel_pq);
+        const long long sz = imax(indel_size, 1);
+        const double sscs_ic = numstates2phred((double)(sz * sz) / (double)(effm + 1));
+        const int ivd = (int)round(P.powlaw_exponent * numstates2phred(P.indel_del_to_ins_err_ratio));
+        const int extra = (int)(nnminus_d(ivd, sscs_ic * (is_ins(symbol) ? 0 : effm) / round(P.indel_polymerase_size)) - (double)(ivd / 2));
+        sscs_pl_v += (int)round(sscs_ic) + extra; sscs_pl_w += (int)round(sscs_ic) + extra;
+        sscs_binom += (long long)round(indel_pq) + extra;
+        if (f.tier2) indel_UMI_penal = (int)nnminus_d((sumBDP + 1.0) / (double)(sumCDP1 + 1.0) * P.fam_indel_nonUMI_phred_dec_per_fold_overseq,
+                                                      (P.fam_thres_emperr_all_flat_indel + 1) * P.fam_indel_nonUMI_phred_dec_per_fold_overseq);
+    }
+    if (oxid && tprov) sscs_binom = lmax(sscs_binom, (long long)imin(aDP, 3));
+    OUT(UVC_O_aAaMQ, diffAaMQs);
+    const int readlenMQcap = (int)((T.APXM[2]) / lmax(1, T.APDP[0]) - 17);
+    const int diffMQ = imax(0, diffAaMQs);
+    const bool extra_accurate = (P.inferred_maxMQ > 60);
+    const int MQVQadd = ((symbol == refsymbol) ? 0 : (imin(P.germ_phred_homalt_snp, ADP * 3)));
+    const int MQVQadd_soma = ((symbol != refsymbol) ? 0 : (imin(P.germ_phred_homalt_snp, ADP * 3)));
+    const bool MQ_unadj = (extra_accurate || (!is_subst(symbol)) || (aDP > ADP * 3 / 4));
+    const int MQVQminus = (MQ_unadj ? 0 : ((int)nnminus((60 - 30), aavgMQ) * 2 / 5)) + ((MQ_unadj || (refsymbol != symbol)) ? 0 : (int)nnminus(imin(15, diffMQ), aavgMQ));
+    int diffMQ2 = diffMQ;
+    if (f.bMQ < 20 && !tprov) {
+        const double axf = (f.aDPff + f.aDPrf + 0.5), axr = (f.aDPfr + f.aDPrr + 0.5), Axf = (T.ADPff0 + T.ADPrf0 + 1.0), Axr = (T.ADPfr0 + T.ADPrr0 + 1.0);
+        if ((axr / Axr) * 2 < (axf / Axf) || (axf / Axf) * 2 < (axr / Axr)
+            || (f.aLI1 + 0.5) / (T.ALI20 + 1.0) * (2 * (1.0 + DBL_EPS)) < (axr) / (Axr) || (f.aRI1 + 0.5) / (T.ARI20 + 1.0) * (2 * (1.0 + DBL_EPS)) < (axf) / (Axf)) diffMQ2 = imax(diffMQ2, 20 - imin(f.bMQ, 20));
+    }
+    const double MQ_base = ((f.bMQ * (P.syserr_MQ_max - P.syserr_MQ_nonref_base) / P.syserr_MQ_max + P.syserr_MQ_nonref_base)) - (int)(diffMQ2) - (int)(f.bNMQ);
+    const int sysMQ = (((refsymbol == symbol) && (ADP > aDP * 2)) ? f.bMQ : (int)(MQ_base - (int)(numstates2phred((ADP + 1.0) / (aDP + 0.5)))));
+    const bool nonWGS = short_frag(T, P.lib_wgs_min_avg_fraglen);
+    const int rescued_MQ = imin((int)nnminus(readlenMQcap, 60), (nonWGS ? P.lib_nonwgs_normal_max_rescued_MQ : P.lib_wgs_normal_max_rescued_MQ));
+    int sysMQVQ1 = imin((imax(sysMQ, P.syserr_MQ_min) + MQVQadd), readlenMQcap);
+    const int sysBQVQ = (((UVC_PLATFORM_IONTORRENT != P.inferred_sequencing_platform) && is_subst(symbol)) ? f.aBQQ : 200);
+    const int pcr_dp = (int)T.APDP[5];
+    const bool strong_amp = ((pcr_dp * 100) > T.APDP[0] * 50), weak_amp = ((pcr_dp * 100) > T.APDP[0] * 30);
+    const bool tmore_amp = (!tprov ? weak_amp : strong_amp);
+    if (tmore_amp && (is_ins(symbol) || is_del(symbol)) && (sysMQVQ1 > 70) && (T.APXM[1] / lmax(T.APDP[0], 1) > 20))
+        sysMQVQ1 = (int)(70 + ((sysMQVQ1 - 70) * 5 / (T.APXM[1] / lmax(T.APDP[0], 1) - 15)));
+    int penal_add = 0;
+    if (!tprov) {
+        const long long delAPDP = lmax(T.APDP[2], T.APDP[4]);
+        const long long snv_dp = T.APDP[6];
+        if ((T.APDP[0] < 3 * delAPDP) && (T.APDP[0] < 3 * snv_dp) && (aDP * 3 < delAPDP) && (aDP * 3 < snv_dp) && is_subst(symbol) && (rtr2.tracklen >= 8 * rtr2.unitlen))
+            penal_add = P.microadjust_germline_mix_with_del_snv_penalty;
+        if (tmore_amp && is_del(symbol)) {
+            if (aDP * 4 < T.APDP[2]) penal_add = imax(penal_add, 5);
+            else if (f.cDP0a * 3 < 2 * (del_cdepth)) penal_add = imax(penal_add, 2);
+        }
+    }
+    const int sysMQVQ = imax(0, sysMQVQ1);
+    const int penal_base2 = penal_base + penal_add;
+    const long long fx = T.ADPff0 + T.ADPfr0, rx = T.ADPrf0 + T.ADPrr0, xf = T.ADPff0 + T.ADPrf0, xr = T.ADPfr0 + T.ADPrr0;
+    const bool frx = (lmax(fx, rx) > P.microadjust_strand_orientation_absence_DP_fold * (lmin(fx, rx) + 1));
+    const bool xfr = (lmax(xf, xr) > P.microadjust_strand_orientation_absence_DP_fold * (lmin(xf, xr) + 1));
+    const int v_minus = (is_subst(symbol) ? ((frx ? P.microadjust_orientation_absence_snv_penalty : 0) + (xfr ? P.microadjust_strand_absence_snv_penalty : 0)) : (tmore_amp ? P.microadjust_dedup_absence_indel_penalty : 0));
+    const int tn_syserr_q = sysMQVQ + P.tn_q_inc_max + rescued_MQ;
+    const int bIAQ = (int)(duped_binom - penal_base2), cIAQ = (int)(sscs_binom - penal_base);
+    const int cPCQ1 = imin(pl_w - penal_base2, tn_syserr_q), cPLQ1 = pl_v - penal_base2 - v_minus;
+    const int cPCQ2 = imin(sscs_pl_w - penal_base, tn_syserr_q), cPLQ2 = sscs_pl_v - penal_base;
+    const int bTINQ = (int)(contam_frag_q + het3al_inc), cTINQ = (int)(contam_sscs_q + het3al_inc);
+    OUT(UVC_O_bMQQ, sysMQVQ); OUT(UVC_O_bIAQ, bIAQ); OUT(UVC_O_cIAQ, cIAQ); OUT(UVC_O_cPCQ1, cPCQ1); OUT(UVC_O_cPLQ1, cPLQ1); OUT(UVC_O_cPCQ2, cPCQ2); OUT(UVC_O_cPLQ2, cPLQ2);
+    OUT(UVC_O_bTINQ, bTINQ); OUT(UVC_O_cTINQ, cTINQ);
+    const int aDPpc = ((refsymbol == symbol) ? 1 : 0);
+    const long long d_ = imax(1, aDP + aDPpc);
+    const int penal4BQerr = (is_subst(symbol) ? (5 + (int)(((long long)P.penal4lowdep) / (d_ * d_))) : 0);
+    const int indel_q_inc = ((((!is_ins(symbol)) && (!is_del(symbol))) || is_rescued) ? 0 : indel_len_rusize_phred_s(indel_size, repeatnum));
+    const double m3 = dmax(0.0, dmax(penal4multi - P.indel_multiallele_soma_penal_thres, (double)penal4multi_g));
+    OUT(UVC_O_gVQ1, (int)dmax(0.0, indel_q_inc + imin(imin(sysBQVQ, (int)nnminus(sysMQVQ, MQVQminus)), imin(bIAQ - penal4BQerr, cPLQ1)) - 2 * m3));
+    const int soma_minus = (is_rescued ? 0 : (15 - imin(ADP * 15 / 100, imin(aDP, 15))));
+    const int sysVQsoma = (int)nnminus(imin(sysBQVQ, sysMQVQ + MQVQadd_soma), soma_minus);
+    const int bcVQ1 = imin(sysVQsoma, imin(bIAQ - (is_rescued ? 0 : penal4BQerr), cPLQ1)) - penal4multi_soma;
+    OUT(UVC_O_cVQ1, imax(0, imin(bcVQ1, bTINQ) - indel_UMI_penal));
+    int mincVQ2 = 0;
+    if (is_ins(symbol) || is_del(symbol)) {
+        const int floor_v = (int)(dmin(P.germ_phred_homalt_indel + numstates2phred(umi_cFA), (double)(f.cDP2v * 3 / 100)) + (double)(((is_ins(symbol) ? 1 : 0) - 1) * 3));
+        mincVQ2 = imax(mincVQ2, floor_v);
+    }
+    const long long dVQinc = lmin(lmin(dFA_binom, (long long)dFA_pl) - imax(0, imin(cIAQ, cPLQ2)), (long long)P.fam_phred_dscs_inc_max);
+    OUT(UVC_O_dVQinc, (int)dVQinc);
+    const int cVQ2 = (int)lmin((long long)sysVQsoma, lmin(cIAQ + lmax(0, dVQinc), cPLQ2 + lmax(0, dVQinc))) - penal4multi;
+    OUT(UVC_O_cVQ2, imax(mincVQ2, imin(cVQ2, cTINQ)));
+    const int cDP1y = (is_rescued ? f.cDP1x : f.cDP1v), CDP1y0 = (is_rescued ? CDP1x0 : CDP1v0);
+    const double binom_contam = binom_llr(contamfrac, cDP1y, CDP1y0);
+    const double power_contam = round(10.0 / log(10.0) * P.powlaw_exponent * dmax(logit2((cDP1y + 1) / (double)(CDP1y0 + 1), contamfrac), 0.0));
+    OUT(UVC_O_CONTQ, (int)dmin(binom_contam, power_contam));
+}
+
+// ------------------------------------------------------------------------------------------------
+struct ScoreCtx {
+    int pos_beg, pos_end, all_out, is_amplicon;
+    const UvcIndelAllele *alleles; long long n_alleles;   // sorted by (refpos, symbol)
+    int32_t *fields; long long capacity;
+    long long *offsets;   // exclusive prefix of per-group allele counts, [2 * (pos_end - pos_beg) + 1]
+};
+
+DEV long long allele_lower_bound(const ScoreCtx &C, int refpos, int symbol) {
+    long long lo = 0, hi = C.n_alleles;
+    while (lo < hi) { long long mid = (lo + hi) >> 1; const UvcIndelAllele &a = C.alleles[mid]; if (a.refpos < refpos || (a.refpos == refpos && a.symbol < symbol)) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+DEV int allele_multiplicity(const ScoreCtx &C, int refpos, int symbol, long long &first) {
+    first = -1;
+    if (!(is_ins(symbol) || is_del(symbol)) || C.n_alleles == 0) return 1;
+    const long long lo = allele_lower_bound(C, refpos, symbol);
+    long long hi = lo;
+    while (hi < C.n_alleles && C.alleles[hi].refpos == refpos && C.alleles[hi].symbol == symbol) hi++;
+    if (hi == lo) return 1;
+    first = lo;
+    return (int)(hi - lo);
+}
+
+// candidate gate, main.cpp:801-837
+DEV bool gate(const RegionDev &R, const UvcParams &P, int64_t x, int st, int symbol, int refsymbol, int totBDP, bool all_out, int &bdepth, int &cdepth) {
+    bdepth = FRP(R, 0, UVC_FRAG_bDP, symbol, x) + FRP(R, 1, UVC_FRAG_bDP, symbol, x);
+    cdepth = imax(FAP(R, 0, UVC_FAM_cDP1, symbol, x), FAP(R, 0, UVC_FAM_cDP12, symbol, x)) + imax(FAP(R, 1, UVC_FAM_cDP1, symbol, x), FAP(R, 1, UVC_FAM_cDP12, symbol, x));
+    if (all_out) return true;
+    if (refsymbol != symbol) return !(bdepth < P.min_altdp_thres);
+    return !(totBDP - bdepth < P.min_altdp_thres);
+}
+
+DEV int group_refsymbol(const RegionDev &R, int zpos, int st) {   // symboltype_to_refsymbol, main.cpp:616-620
+    if (st == UVC_LINK_SYMBOL) return UVC_LINK_M;
+    const int refidx = zpos - R.beg, refsize = (int)R.npos - 1;
+    return ((refsize == (refidx - 1) || (-1 == (refidx - 1))) ? UVC_BASE_NN : (int)R.refsym[refidx - 1]);
+}
+
+__global__ void __launch_bounds__(256) k_score_count(RegionDev R, UvcParams P, ScoreCtx C, int *counts) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long ngroups = 2LL * (C.pos_end - C.pos_beg);
+    if (g >= ngroups) return;
+    const int zpos = C.pos_beg + (int)(g >> 1), st = (int)(g & 1);
+    int n = 0;
+    if (!(zpos == C.pos_beg && st == UVC_BASE_SYMBOL)) {
+        const int refpos = (st == UVC_BASE_SYMBOL ? zpos - 1 : zpos);
+        const int64_t x = refpos - R.beg;
+        const int refsymbol = group_refsymbol(R, zpos, st);
+        int totBDP = 0;
+        for (int k = 0; k < st_count(st); k++) { const int s = st_symbol(st, k); totBDP += FRP(R, 0, UVC_FRAG_bDP, s, x) + FRP(R, 1, UVC_FRAG_bDP, s, x); }
+        for (int k = 0; k < st_count(st); k++) {
+            const int s = st_symbol(st, k);
+            int bd, cd;
+            if (gate(R, P, x, st, s, refsymbol, totBDP, C.all_out, bd, cd)) { long long first; n += allele_multiplicity(C, refpos, s, first); }
+        }
+    }
+    counts[g] = n;
+}
+
+// single-block exclusive scan (n <= a few million): each thread owns a contiguous chunk
+__global__ void __launch_bounds__(1024) k_scan(const int *counts, long long *offsets, long long n, long long *total) {
+    __shared__ long long part[1024];
+    const long long chunk = (n + 1023) / 1024;
+    const long long b = threadIdx.x * chunk, e = (b + chunk < n ? b + chunk : n);
+    long long s = 0;
+    for (long long i = b; i < e; i++) s += counts[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { long long run = 0; for (int i = 0; i < 1024; i++) { const long long v = part[i]; part[i] = run; run += v; } *total = run; offsets[n] = run; }
+    __syncthreads();
+    long long run = part[threadIdx.x];
+    for (long long i = b; i < e; i++) { offsets[i] = run; run += counts[i]; }
+}
+
+__global__ void __launch_bounds__(128) k_score(RegionDev R, UvcParams P, ScoreCtx C) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long ngroups = 2LL * (C.pos_end - C.pos_beg);
+    if (g >= ngroups) return;
+    const long long rec0 = C.offsets[g], nrec = C.offsets[g + 1] - rec0;
+    if (nrec == 0 || rec0 + nrec > C.capacity) return;
+    const int zpos = C.pos_beg + (int)(g >> 1), st = (int)(g & 1);
+    const int refpos = (st == UVC_BASE_SYMBOL ? zpos - 1 : zpos);
+    const int64_t x = refpos - R.beg;
+    const int refidx = zpos - R.beg, refsize = (int)R.npos - 1;
+    const int refsymbol = group_refsymbol(R, zpos, st);
+    int32_t *fields = C.fields; const long long capacity = C.capacity;
+    Tot T;
+    group_totals(R, x, st, T);
+    const int totBDP = T.BDPb[0] + T.BDPb[1];
+    // homopolymer context for minABQ (main.cpp:623-626, 909-928)
+    const int prev1 = ((refidx >= 2) ? (int)R.refsym[refidx - 2] : UVC_BASE_NN), prev2 = ((refidx >= 3) ? (int)R.refsym[refidx - 3] : UVC_BASE_NN);
+    const int next1 = ((refidx < refsize) ? (int)R.refsym[refidx] : UVC_BASE_NN), next2 = ((refidx + 1 < refsize) ? (int)R.refsym[refidx + 1] : UVC_BASE_NN);
+    const bool hp1 = (prev1 == refsymbol && next1 == refsymbol), hp2 = (prev2 == refsymbol && next2 == refsymbol);
+    const int minABQ_snv = (C.is_amplicon ? P.syserr_minABQ_pcr_snv : P.syserr_minABQ_cap_snv), minABQ_indel = (C.is_amplicon ? P.syserr_minABQ_pcr_indel : P.syserr_minABQ_cap_indel);
+    const int nrtr = (int)R.npos;
+    const RtrLite rtr1 = load_rtr(R, imax(refpos - R.beg, 3) - 3), rtr2 = load_rtr(R, imin(refpos - R.beg + 3, nrtr - 1));
+    // InDel depths of the LINK group at zerobased_pos (main.cpp:817-831), shared by both groups of this zerobased_pos
+    int ins_cdepth = 0, del_cdepth = 0, ins1_cdepth = 0, del1_cdepth = 0;
+    {
+        const int64_t xz = zpos - R.beg;
+        for (int k = 1; k < 7; k++) {
+            const int s = st_symbol(UVC_LINK_SYMBOL, k);
+            const int cd = imax(FAP(R, 0, UVC_FAM_cDP1, s, xz), FAP(R, 0, UVC_FAM_cDP12, s, xz)) + imax(FAP(R, 1, UVC_FAM_cDP1, s, xz), FAP(R, 1, UVC_FAM_cDP12, s, xz));
+            if (is_ins(s)) { ins_cdepth += cd; if (UVC_LINK_I1 == s) ins1_cdepth += cd; } else { del_cdepth += cd; if (UVC_LINK_D1 == s) del1_cdepth += cd; }
+        }
+    }
+    int ru_size, repeatnum;
+    indel_context(R, refidx, P.indel_str_repeatsize_max, ru_size, repeatnum);
+    // pass 1: init + calc_DPv, cross-allele sums (BcfFormat_symbol_sum_DPv, main.hpp:4888-4906)
+    int s1[6] = { 0, 0, 0, 0, 0, 0 }, s2[6] = { 0, 0, 0, 0, 0, 0 };
+    long long rec = rec0;
+    for (int pass = 0; pass < 2; pass++) {
+        rec = rec0;
+        for (int k = 0; k < st_count(st); k++) {
+            const int symbol = st_symbol(st, k);
+            int bdepth, cdepth;
+            if (!gate(R, P, x, st, symbol, refsymbol, totBDP, C.all_out, bdepth, cdepth)) continue;
+            long long first;
+            const int mult = allele_multiplicity(C, refpos, symbol, first);
+            for (int ai = 0; ai < mult; ai++, rec++) {
+                int bDPa = bdepth, cDP0a = cdepth, glen = 0;
+                if (is_ins(symbol) || is_del(symbol)) {
+                    if (first >= 0) { const UvcIndelAllele &al = C.alleles[first + ai]; bDPa = al.bDPa; cDP0a = al.cDP0a; glen = al.indel_len; }
+                    else glen = ((symbol == UVC_LINK_I1 || symbol == UVC_LINK_D1) ? 1 : ((symbol == UVC_LINK_I2 || symbol == UVC_LINK_D2) ? 2 : 3));
+                }
+                const int minABQ = (is_subst(symbol) ? (int)nnminus(minABQ_snv, (hp1 ? (hp2 ? 20 : 10) : 0)) : minABQ_indel);
+                Al f;
+                allele_load(R, P, x, symbol, T, bDPa, cDP0a, glen, minABQ, f);
+                if (pass == 0) {
+                    OUT(UVC_O_refpos, refpos); OUT(UVC_O_symbol, symbol); OUT(UVC_O_refsymbol, refsymbol);
+                    OUT(UVC_O_DP, T.CDP1b[0] + T.CDP1b[1]); OUT(UVC_O_bDP, T.BDPb[0] + T.BDPb[1]); OUT(UVC_O_c2DP, T.CDP2b[0] + T.CDP2b[1]); OUT(UVC_O_c2AD, f.cDP2f + f.cDP2r);
+                    OUT(UVC_O_bDPa, bDPa); OUT(UVC_O_cDP0a, cDP0a);
+                    OUT(UVC_O_a2BQf, f.a2BQf); OUT(UVC_O_a2BQr, f.a2BQr); OUT(UVC_O_aBQ, f.aBQ); OUT(UVC_O_aBQQ, f.aBQQ); OUT(UVC_O_bMQ, f.bMQ);
+                    calc_dpv(R, P, x, T, f, rtr1, rtr2, refsymbol, fields, capacity, rec);
+                    const int v[6] = { f.cDP1v, f.cDP1w, f.cDP1x, f.cDP2v, f.cDP2w, f.cDP2x };
+                    for (int i = 0; i < 6; i++) s1[i] += v[i];
+                    if (UVC_BASE_NN == symbol || UVC_LINK_NN == symbol) for (int i = 0; i < 6; i++) s2[i] = v[i];
+                } else {
+                    // restore what calc_DPv produced for this allele
+                    f.tier2 = fields[(size_t)UVC_O_tier2 * capacity + rec]; f.bNMQ = fields[(size_t)UVC_O_bNMQ * capacity + rec];
+                    f.cDP1v = fields[(size_t)UVC_O_cDP1v * capacity + rec]; f.cDP1w = fields[(size_t)UVC_O_cDP1w * capacity + rec]; f.cDP1x = fields[(size_t)UVC_O_cDP1x * capacity + rec];
+                    f.cDP2v = fields[(size_t)UVC_O_cDP2v * capacity + rec]; f.cDP2w = fields[(size_t)UVC_O_cDP2w * capacity + rec]; f.cDP2x = fields[(size_t)UVC_O_cDP2x * capacity + rec];
+                    for (int i = 0; i < 6; i++) { OUT(UVC_O_CDP1v0 + 2 * i, s1[i]); OUT(UVC_O_CDP1v0 + 2 * i + 1, s2[i]); }
+                    calc_qual(R, P, T, f, s1[0], s1[2], ins_cdepth, del_cdepth, ins1_cdepth, del1_cdepth, ru_size, repeatnum, rtr1, rtr2, refsymbol, fields, capacity, rec);
+                }
+            }
+        }
+    }
+}
+
+extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles,
+                                int32_t *d_fields, int64_t capacity, int64_t *d_count, hipStream_t s) {
+    ScoreCtx C;
+    C.pos_beg = req->pos_beg; C.pos_end = req->pos_end; C.all_out = (req->all_out || P->should_output_all) ? 1 : 0; C.is_amplicon = req->is_amplicon;
+    C.alleles = d_alleles; C.n_alleles = req->n_indel_alleles; C.fields = d_fields; C.capacity = capacity;
+    const long long ngroups = 2LL * (C.pos_end - C.pos_beg);
+    if (ngroups <= 0) return 0;
+    int *counts = nullptr; long long *offsets = nullptr;
+    if (hipMalloc((void **)&counts, sizeof(int) * ngroups) != hipSuccess || hipMalloc((void **)&offsets, sizeof(long long) * (ngroups + 1)) != hipSuccess) return UVCGPU_ENOMEM;
+    C.offsets = offsets;
+    hipLaunchKernelGGL(k_score_count, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, s, *R, *P, C, counts);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, counts, offsets, ngroups, (long long *)d_count);
+    hipLaunchKernelGGL(k_score, dim3((unsigned)((ngroups + 127) / 128)), dim3(128), 0, s, *R, *P, C);
+    hipError_t e = hipStreamSynchronize(s);
+    hipFree(counts); hipFree(offsets);
+    return e == hipSuccess ? 0 : UVCGPU_EDEVICE;
+}
