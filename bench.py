@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- pileup positions scored per second at 300x depth (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the whole hot path (accumulate P1..P5b + default-gate scoring, scored records
+copied back to the host) over one synthetic chr20-shaped 300x non-UMI tile that is already resident
+in HBM.  Every rank owns one GPU and its own tile (different seed): regions shard with no data-path
+collective, so scaling is weak.  value = ranks * tile positions * K / max-over-ranks wall time.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel of the timed steps: algorithmic bytes per launch
+                / its HIP-event duration on the library's own stream, vs the 8 TB/s HBM peak.
+  cpu_baseline  the CPU oracle (a scalar port of the reference algorithm) on a bounded sample of the
+                same workload shape on the host cores (rank 0, N = 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+READ_LEN = 150
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_position(kernel, depth):
+    """Per-position algorithmic HBM bytes of each kernel.  Built from the SURVEY 8(d)
+    components: 1 B base + 1 B qual per read-base, 48 B per read, 5 544 B of accumulator records."""
+    d = float(depth)
+    reads = 2.0 * d + 48.0 * d / READ_LEN           # bases + quals + per-read record
+    table = {
+        "k_prep_fast": reads + 1 + 8 + 208,                         # + ref, baq ; writes SegFormatPrepSet
+        "k_thres": 208 + 28 + 72 + 4,                                # prep + rtr -> thres + indelphred
+        "k_p2_fast": reads + 1 + 72 + 16 + 8 + 14 * (152 + 16 + 4),  # + ref, thres, 2 baq, 2 indelphred ; writes seg info + a1/a2 BQ + bqsum
+        "k_fragstat": reads + 1 + 8,
+        "k_frag": reads + 48.0 * d / (2 * READ_LEN) + 1 + 8 + 14 * 20 + 14 * 4 * (6 + 6 + 4),   # + fragment records, avgBQ inputs ; writes frag, fam(3), VQ(4)
+        "k_p5b": 2 * 14 * 4 + 14 * 4 * 6,
+    }
+    return table.get(kernel, reads)
+
+
+def run_cpu_baseline(depth, n_regions=16, region_len=4000):
+    """Times the oracle (test infrastructure) on `n_regions` independent regions, one thread each."""
+    from concurrent.futures import ThreadPoolExecutor
+    from uvc_amd import _ffi, region, synth
+    lib = _ffi.Lib(_ffi.oracle_library_path(), "uvc_oracle_")
+    params = region.default_params(lib)
+    cores = min(16, os.cpu_count() or 1)
+    regs = []
+    for i in range(n_regions):
+        r = synth.generate_region(seed=777 + i, region_len=region_len, depth=depth)
+        R = region.Region(lib, params, r["tid"], r["beg"], r["end"], r["refseq"])
+        R.set_reads(r)
+        regs.append(R)
+
+    def work(R):
+        R.accumulate()
+        return len(R.score()["refpos"])
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(work, regs))
+    dt = time.perf_counter() - t0
+    return {"value": n_regions * region_len / dt, "unit": "positions/s", "cores": cores, "kind": "port",
+            "sample": "%d regions x %d bp at %dx, oracle (scalar C++ port), one region per thread, %.1f s wall" % (n_regions, region_len, depth, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tile-kb", type=int, default=1000, help="tile length in kb (chr20 is processed as 1 Mb tiles)")
+    ap.add_argument("--depth", type=int, default=300)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="CPU-only rehearsal of the multi-rank protocol (no kernels, used by the gloo tests)")
+    args = ap.parse_args()
+
+    from uvc_amd import shard
+    rank, local_rank, world = shard.dist_env()
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    region_len = args.tile_kb * 1000
+
+    if args.dry_run:
+        clock = shard.Clock(backend="gloo")
+        clock.barrier(); t0 = time.perf_counter()
+        for _ in range(args.steps):
+            time.sleep(0.01 * (1 + rank))
+        clock.barrier(); dt = clock.max_over_ranks(time.perf_counter() - t0)
+        if rank == 0:
+            print(json.dumps({"metric": "pileup positions scored/sec at 300x depth", "value": world * region_len * args.steps / dt, "unit": "positions/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic", "config": {"workload": "dry-run"}, "dry_run": True}))
+        clock.close()
+        return
+
+    import torch
+    torch.cuda.set_device(local_rank)
+    clock = shard.Clock(backend="nccl")
+    from uvc_amd import region, synth
+    lib = region.gpu_lib()
+    rc = lib.dll.uvcgpu_init(local_rank)
+    if rc != 0:
+        raise RuntimeError(lib.last_error())
+    lib.dll.uvcgpu_region_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    lib.dll.uvcgpu_region_kernel_times.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_float), C.c_int]
+    params = region.default_params(lib)
+    t_gen = time.perf_counter()
+    reads = synth.generate_region(seed=12345 + rank, region_len=region_len, depth=args.depth)
+    t_gen = time.perf_counter() - t_gen
+    R = region.Region(lib, params, reads["tid"], reads["beg"], reads["end"], reads["refseq"])
+    t_h2d = time.perf_counter()
+    R.set_reads(reads)
+    t_h2d = time.perf_counter() - t_h2d
+    n_read_bases = int(reads["n_reads"]) * READ_LEN
+
+    def step():
+        R.accumulate()
+        return R.score(capacity=max(65536, region_len // 4))
+
+    for _ in range(args.warmup):
+        step()
+    lib.dll.uvcgpu_region_set_profiling(R.h, 1)
+    ktimes = {}
+    names_buf = C.create_string_buffer(1024)
+    ms_buf = (C.c_float * 32)()
+    n_rec = 0
+    torch.cuda.synchronize(); clock.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rec = step()
+        n_rec = len(rec["refpos"])
+        n = lib.dll.uvcgpu_region_kernel_times(R.h, names_buf, 1024, ms_buf, 32)   # stream is already idle: score() is synchronous
+        for nm, ms in zip(names_buf.value.decode().split(";")[:n], list(ms_buf)[:n]):
+            ktimes.setdefault(nm, []).append(ms)
+    torch.cuda.synchronize(); clock.barrier()
+    dt = clock.max_over_ranks(time.perf_counter() - t0)
+    total_positions = clock.sum_over_ranks(float(region_len)) * args.steps
+
+    if rank == 0:
+        avg = {k: sum(v) / len(v) for k, v in ktimes.items()}
+        dom = max(avg, key=avg.get)
+        abytes = algorithmic_bytes_per_position(dom, args.depth) * R.npos
+        achieved = abytes / (avg[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "pileup positions scored/sec at 300x depth", "value": total_positions / dt, "unit": "positions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "chr20-shaped tumor-only non-UMI tile: %d kb at %dx, 150 bp paired-end, one tile per GPU resident in HBM; step = accumulate P1..P5b + default-gate scoring + D2H of records" % (args.tile_kb, args.depth),
+                       "tile_positions": region_len, "reads_per_tile": int(reads["n_reads"]), "read_bases_per_tile": n_read_bases, "scored_records_per_tile": n_rec,
+                       "parallelism": "region-shard x%d (no collective on the data path)" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": abytes, "kernel_ms": avg[dom]},
+            "kernel_ms": {k: round(v, 4) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])},
+            "read_bases_per_s": n_read_bases * world * args.steps / dt,
+            "host_prep_s": {"generate": round(t_gen, 2), "pack_and_h2d": round(t_h2d, 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = run_cpu_baseline(args.depth)
+        print(json.dumps(out))
+    R.close()
+    clock.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -127,7 +127,7 @@ enum UvcField {
     UVC_F_FAMINFO32 = 9,/* int32 [UVC_NFAMINFO32][14][npos]   FamFormatInfoSet i32 fields, main_conversion.hpp:701-720 */
     UVC_F_FAMINFO64 = 10,/* int64 [UVC_NFAMINFO64][14][npos]  FamFormatInfoSet i64 fields                             */
     UVC_F_DUPLEX = 11,  /* int32 [UVC_NDUPLEX][14][npos]      DuplexFormatDepthSet, main_conversion.hpp:736-741       */
-    UVC_F_RTR    = 12,  /* int32 [UVC_NRTR][npos+1]           RegionalTandemRepeat AFTER P1b edits indelphred, common.hpp:150-160 */
+    UVC_F_RTR    = 12,  /* int32 [UVC_NRTR][npos]             RegionalTandemRepeat AFTER P1b edits indelphred, common.hpp:150-160 */
     UVC_F_BAQ    = 13,  /* int64 [2][npos]                    baq_offsetarr, baq_offsetarr2, main.cpp:400-429         */
     UVC_NUM_FIELD_GROUPS = 14
 };
@@ -251,7 +251,9 @@ const char *uvcgpu_version(void);
 /* Replaces `Symbol2CountCoverageSet(tid, ext_beg, ext_end+1)` (main.cpp:569) together with the
  * region side arrays built just before it (main.cpp:553-563): refstring -> refstring2repeatvec
  * (main.hpp:803-874) -> the two BAQ prefix-sum arrays (main.cpp:400-429).
- * refseq = ASCII reference of [beg, end) (the caller's load_refstring result, +-MAX_STR_N_BASES halo). */
+ * refseq = ASCII reference of [beg, end) (the caller's load_refstring result, +-MAX_STR_N_BASES halo), beg/end =
+ * extended_inclu_beg_pos / extended_exclu_end_pos of main.cpp:529-530.  The per-position state then covers
+ * [beg, end + 1), i.e. npos = end - beg + 1 positions, exactly like Symbol2CountCoverageSet(tid, beg, end + 1). */
 int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params,
                          int32_t tid, int32_t beg, int32_t end, const char *refseq);
 /* Copies the reads to the device (the caller keeps ownership of its buffers). */
@@ -268,6 +270,10 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
 int64_t uvcgpu_region_field_bytes(const uvcgpu_region_t *r, int32_t field_group);
 int uvcgpu_region_fetch(uvcgpu_region_t *r, int32_t field_group, void *dst, int64_t dst_bytes);
 int uvcgpu_region_sync(uvcgpu_region_t *r);
+/* Measurement hooks (bench.py): HIP-event timing of every kernel of the LAST accumulate, recorded on the handle's stream.
+ * kernel_times returns the number of kernels; `names` receives their names separated by ';'. */
+int uvcgpu_region_set_profiling(uvcgpu_region_t *r, int on);
+int uvcgpu_region_kernel_times(uvcgpu_region_t *r, char *names, int names_bytes, float *ms, int capacity);
 void uvcgpu_region_destroy(uvcgpu_region_t *r);
 
 #ifdef __cplusplus

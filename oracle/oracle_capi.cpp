@@ -80,30 +80,31 @@ int uvc_oracle_set_reads(void *h, const UvcReadSoA *r) {
 
 int uvc_oracle_accumulate(void *h) { State &S = *(State *)h; return accumulate(S, g_err); }
 
+// transposes the position-major internal storage into the plane layout [field][symbol][pos] of uvcgpu.h
 static const void *group_ptr(State &S, int g, i64 &bytes, std::vector<i32> &tmp32, std::vector<i64> &tmp64) {
+    const i64 n = S.npos;
+    auto t32 = [&](size_t planes) { tmp32.assign(planes * (size_t)n, 0); bytes = (i64)tmp32.size() * 4; };
+    auto t64 = [&](size_t planes) { tmp64.assign(planes * (size_t)n, 0); bytes = (i64)tmp64.size() * 8; };
     switch (g) {
-        case UVC_F_PREP32: bytes = S.prep32.size() * 4; return S.prep32.data();
-        case UVC_F_PREP64: bytes = S.prep64.size() * 8; return S.prep64.data();
-        case UVC_F_THRES: bytes = S.thres.size() * 4; return S.thres.data();
-        case UVC_F_SEG32: bytes = S.seg32.size() * 4; return S.seg32.data();
-        case UVC_F_SEG64: bytes = S.seg64.size() * 8; return S.seg64.data();
-        case UVC_F_VQ: bytes = S.vq.size() * 4; return S.vq.data();
-        case UVC_F_BQSUM: bytes = S.bqsum.size() * 4; return S.bqsum.data();
-        case UVC_F_FRAG: bytes = S.frag.size() * 4; return S.frag.data();
-        case UVC_F_FAM: bytes = S.fam.size() * 4; return S.fam.data();
-        case UVC_F_FAMINFO32: bytes = S.faminfo32.size() * 4; return S.faminfo32.data();
-        case UVC_F_FAMINFO64: bytes = S.faminfo64.size() * 8; return S.faminfo64.data();
-        case UVC_F_DUPLEX: bytes = S.duplex.size() * 4; return S.duplex.data();
+        case UVC_F_PREP32: t32(UVC_NPREP32); for (i64 i = 0; i < n; i++) for (int f = 0; f < UVC_NPREP32; f++) tmp32[(size_t)f * n + i] = S.p32(f, i); return tmp32.data();
+        case UVC_F_PREP64: t64(UVC_NPREP64); for (i64 i = 0; i < n; i++) for (int f = 0; f < UVC_NPREP64; f++) tmp64[(size_t)f * n + i] = S.p64(f, i); return tmp64.data();
+        case UVC_F_THRES: t32(UVC_NTHRES); for (i64 i = 0; i < n; i++) for (int f = 0; f < UVC_NTHRES; f++) tmp32[(size_t)f * n + i] = S.th(f, i); return tmp32.data();
+        case UVC_F_SEG32: t32((size_t)UVC_NSEG32 * NSYM); for (i64 i = 0; i < n; i++) for (int s = 0; s < NSYM; s++) for (int f = 0; f < UVC_NSEG32; f++) tmp32[((size_t)f * NSYM + s) * n + i] = S.s32(f, s, i); return tmp32.data();
+        case UVC_F_SEG64: t64((size_t)UVC_NSEG64 * NSYM); for (i64 i = 0; i < n; i++) for (int s = 0; s < NSYM; s++) for (int f = 0; f < UVC_NSEG64; f++) tmp64[((size_t)f * NSYM + s) * n + i] = S.s64(f, s, i); return tmp64.data();
+        case UVC_F_VQ: t32((size_t)UVC_NVQ * NSYM); for (i64 i = 0; i < n; i++) for (int s = 0; s < NSYM; s++) for (int f = 0; f < UVC_NVQ; f++) tmp32[((size_t)f * NSYM + s) * n + i] = S.VQ(f, s, i); return tmp32.data();
+        case UVC_F_BQSUM: t32(NSYM); for (i64 i = 0; i < n; i++) for (int s = 0; s < NSYM; s++) tmp32[(size_t)s * n + i] = S.BQS(s, i); return tmp32.data();
+        case UVC_F_FRAG: t32((size_t)2 * UVC_NFRAG * NSYM); for (i64 i = 0; i < n; i++) for (int d = 0; d < 2; d++) for (int s = 0; s < NSYM; s++) for (int f = 0; f < UVC_NFRAG; f++) tmp32[(((size_t)d * UVC_NFRAG + f) * NSYM + s) * n + i] = S.FR(d, f, s, i); return tmp32.data();
+        case UVC_F_FAM: t32((size_t)2 * UVC_NFAM * NSYM); for (i64 i = 0; i < n; i++) for (int d = 0; d < 2; d++) for (int s = 0; s < NSYM; s++) for (int f = 0; f < UVC_NFAM; f++) tmp32[(((size_t)d * UVC_NFAM + f) * NSYM + s) * n + i] = S.FA(d, f, s, i); return tmp32.data();
+        case UVC_F_FAMINFO32: t32((size_t)UVC_NFAMINFO32 * NSYM); for (i64 i = 0; i < n; i++) for (int s = 0; s < NSYM; s++) for (int f = 0; f < UVC_NFAMINFO32; f++) tmp32[((size_t)f * NSYM + s) * n + i] = S.FI(f, s, i); return tmp32.data();
+        case UVC_F_FAMINFO64: t64((size_t)UVC_NFAMINFO64 * NSYM); for (i64 i = 0; i < n; i++) for (int s = 0; s < NSYM; s++) for (int f = 0; f < UVC_NFAMINFO64; f++) tmp64[((size_t)f * NSYM + s) * n + i] = S.FI64(f, s, i); return tmp64.data();
+        case UVC_F_DUPLEX: t32((size_t)UVC_NDUPLEX * NSYM); for (i64 i = 0; i < n; i++) for (int s = 0; s < NSYM; s++) for (int f = 0; f < UVC_NDUPLEX; f++) tmp32[((size_t)f * NSYM + s) * n + i] = S.DU(f, s, i); return tmp32.data();
         case UVC_F_RTR: {
-            tmp32.assign((size_t)UVC_NRTR * S.npos, 0);
-            for (i64 i = 0; i < S.npos; i++) { const Rtr &r = S.rtr[i];
+            t32(UVC_NRTR);
+            for (i64 i = 0; i < n; i++) { const Rtr &r = S.rtr[i];
                 const i32 v[UVC_NRTR] = { r.begpos, r.tracklen, r.unitlen, r.indelphred, r.anyTR_begpos, r.anyTR_tracklen, r.anyTR_unitlen };
-                for (int f = 0; f < UVC_NRTR; f++) tmp32[(size_t)f * S.npos + i] = v[f]; }
-            bytes = tmp32.size() * 4; return tmp32.data(); }
-        case UVC_F_BAQ: {
-            tmp64.assign((size_t)2 * S.npos, 0);
-            for (i64 i = 0; i < S.npos; i++) { tmp64[i] = S.baq[i]; tmp64[S.npos + i] = S.baq2[i]; }
-            bytes = tmp64.size() * 8; return tmp64.data(); }
+                for (int f = 0; f < UVC_NRTR; f++) tmp32[(size_t)f * n + i] = v[f]; }
+            return tmp32.data(); }
+        case UVC_F_BAQ: t64(2); for (i64 i = 0; i < n; i++) { tmp64[i] = S.baq[i]; tmp64[n + i] = S.baq2[i]; } return tmp64.data();
     }
     bytes = -1; return NULL;
 }

@@ -110,19 +110,21 @@ struct State {
     std::vector<u8> bases, quals; std::vector<u32> cigars;
     bool accumulated = false;
 
-    inline i32 &p32(int f, i64 i) { return prep32[(size_t)f * npos + i]; }
-    inline i64 &p64(int f, i64 i) { return prep64[(size_t)f * npos + i]; }
-    inline i32 &th(int f, i64 i) { return thres[(size_t)f * npos + i]; }
-    inline i32 &s32(int f, int s, i64 i) { return seg32[((size_t)f * NSYM + s) * npos + i]; }
-    inline i64 &s64(int f, int s, i64 i) { return seg64[((size_t)f * NSYM + s) * npos + i]; }
-    inline i32 &VQ(int f, int s, i64 i) { return vq[((size_t)f * NSYM + s) * npos + i]; }
-    inline i32 &BQS(int s, i64 i) { return bqsum[(size_t)s * npos + i]; }
-    inline i32 &FR(int strand, int f, int s, i64 i) { return frag[(((size_t)strand * UVC_NFRAG + f) * NSYM + s) * npos + i]; }
-    inline i32 &FA(int strand, int f, int s, i64 i) { return fam[(((size_t)strand * UVC_NFAM + f) * NSYM + s) * npos + i]; }
-    inline i32 &FI(int f, int s, i64 i) { return faminfo32[((size_t)f * NSYM + s) * npos + i]; }
-    inline i64 &FI64(int f, int s, i64 i) { return faminfo64[((size_t)f * NSYM + s) * npos + i]; }
-    inline i32 &DU(int f, int s, i64 i) { return duplex[((size_t)f * NSYM + s) * npos + i]; }
-    inline i32 &BK(int strand, int s, int b, i64 i) { return bucket[strand][((size_t)s * NBUCKETS + b) * npos + i]; }
+    // Internal storage is position-major (AoS, like the reference's std::vector<struct> per kind, main.hpp:523-604) so that
+    // the per-read scatter touches one or two cache lines per position; fetch() transposes to the plane layout of uvcgpu.h.
+    inline i32 &p32(int f, i64 i) { return prep32[(size_t)i * UVC_NPREP32 + f]; }
+    inline i64 &p64(int f, i64 i) { return prep64[(size_t)i * UVC_NPREP64 + f]; }
+    inline i32 &th(int f, i64 i) { return thres[(size_t)i * UVC_NTHRES + f]; }
+    inline i32 &s32(int f, int s, i64 i) { return seg32[((size_t)i * NSYM + s) * UVC_NSEG32 + f]; }
+    inline i64 &s64(int f, int s, i64 i) { return seg64[((size_t)i * NSYM + s) * UVC_NSEG64 + f]; }
+    inline i32 &VQ(int f, int s, i64 i) { return vq[((size_t)i * NSYM + s) * UVC_NVQ + f]; }
+    inline i32 &BQS(int s, i64 i) { return bqsum[(size_t)i * NSYM + s]; }
+    inline i32 &FR(int strand, int f, int s, i64 i) { return frag[(((size_t)i * 2 + strand) * NSYM + s) * UVC_NFRAG + f]; }
+    inline i32 &FA(int strand, int f, int s, i64 i) { return fam[(((size_t)i * 2 + strand) * NSYM + s) * UVC_NFAM + f]; }
+    inline i32 &FI(int f, int s, i64 i) { return faminfo32[((size_t)i * NSYM + s) * UVC_NFAMINFO32 + f]; }
+    inline i64 &FI64(int f, int s, i64 i) { return faminfo64[((size_t)i * NSYM + s) * UVC_NFAMINFO64 + f]; }
+    inline i32 &DU(int f, int s, i64 i) { return duplex[((size_t)i * NSYM + s) * UVC_NDUPLEX + f]; }
+    inline i32 &BK(int strand, int s, int b, i64 i) { return bucket[strand][((size_t)i * NSYM + s) * NBUCKETS + b]; }
     inline i32 seg_ad(int s, i64 i) {  // seg_format_get_ad, main_conversion.hpp:785-789
         return s32(UVC_S_aDPff, s, i) + s32(UVC_S_aDPfr, s, i) + s32(UVC_S_aDPrf, s, i) + s32(UVC_S_aDPrr, s, i);
     }

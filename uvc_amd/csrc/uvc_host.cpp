@@ -15,8 +15,9 @@ struct RawReads {
     const int64_t *seq_off, *cigar_off, *table_off;
 };
 extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const UvcParams *P, hipStream_t s);
+struct UvcProf { int on; int n; const char *name[24]; hipEvent_t ev[24][2]; };
 extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, int half_ratio_phred,
-                                      const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s);
+                                      const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof);
 extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles,
                                 int32_t *d_fields, int64_t capacity, int64_t *d_count, hipStream_t s);
 
@@ -38,6 +39,7 @@ struct uvcgpu_region {
     int32_t *d_dup_units = nullptr; int64_t *d_dup_off = nullptr; int n_dup = 0; int64_t n_dup_work = 0;
     size_t off[UVC_NUM_FIELD_GROUPS + 1];
     bool has_reads = false, accumulated = false;
+    UvcProf prof;
 };
 
 static size_t group_bytes(const uvcgpu_region *r, int g) {
@@ -180,6 +182,7 @@ int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params, int32_t
     if (params->struct_size != (int32_t)sizeof(UvcParams)) return fail(UVCGPU_EINVAL, "UvcParams::struct_size mismatch");
     if (params->indel_str_repeatsize_max < 1 || params->indel_vntr_repeatsize_max < params->indel_str_repeatsize_max) return fail(UVCGPU_EINVAL, "bad repeat-size parameters");
     uvcgpu_region *r = new uvcgpu_region();
+    memset(&r->prof, 0, sizeof(r->prof));
     r->P = *params; r->tid = tid; r->beg = beg; r->end = end + 1; r->npos = (int64_t)end - beg + 1;
     r->refstring.assign(refseq, (size_t)(end - beg));
     if (hipStreamCreate(&r->stream) != hipSuccess) { delete r; return fail(UVCGPU_EDEVICE, "hipStreamCreate failed (no GPU?)"); }
@@ -352,10 +355,27 @@ int uvcgpu_region_accumulate(uvcgpu_region_t *r) {
         // rows were set to 0xFF in set_reads and k_p2_slow<false> is idempotent under MAX, so no reset is needed
     }
     const int half = (int)std::round((10.0 / std::log(10.0)) * std::log(r->P.indel_del_to_ins_err_ratio)) / 2;   // main.hpp:1244
-    uvc_launch_accumulate(&r->R, &r->P, half, r->d_dup_units, r->n_dup, r->d_dup_off, r->n_dup_work, r->stream);
+    uvc_launch_accumulate(&r->R, &r->P, half, r->d_dup_units, r->n_dup, r->d_dup_off, r->n_dup_work, r->stream, &r->prof);
     HIP_OK(hipGetLastError());
     r->accumulated = true;
     return 0;
+}
+
+// Per-kernel timing of the LAST accumulate, measured with HIP events on the handle's own stream.
+int uvcgpu_region_set_profiling(uvcgpu_region_t *r, int on) { if (!r) return fail(UVCGPU_EINVAL, "null region"); r->prof.on = on ? 1 : 0; return 0; }
+int uvcgpu_region_kernel_times(uvcgpu_region_t *r, char *names, int names_bytes, float *ms, int capacity) {
+    if (!r || !names || !ms) return fail(UVCGPU_EINVAL, "bad argument");
+    HIP_OK(hipStreamSynchronize(r->stream));
+    std::string all;
+    int n = 0;
+    for (int i = 0; i < r->prof.n && n < capacity; i++, n++) {
+        float t = 0;
+        HIP_OK(hipEventElapsedTime(&t, r->prof.ev[i][0], r->prof.ev[i][1]));
+        ms[n] = t; all += r->prof.name[i]; all += ";";
+    }
+    if ((int)all.size() + 1 > names_bytes) return fail(UVCGPU_EINVAL, "names buffer too small");
+    memcpy(names, all.c_str(), all.size() + 1);
+    return n;
 }
 
 int uvcgpu_region_sync(uvcgpu_region_t *r) {

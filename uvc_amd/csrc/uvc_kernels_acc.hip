@@ -1302,31 +1302,41 @@ __global__ void __launch_bounds__(256) k_p5b(RegionDev R, UvcParams P) {
 // ------------------------------------------------------------------------------------------------
 static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
+// optional per-kernel HIP-event timing on the handle's own stream (bench.py roofline leg)
+struct UvcProf { int on; int n; const char *name[24]; hipEvent_t ev[24][2]; };
+#define TIMED(prof, kname, ...) do { \
+        UvcProf *p_ = (prof); int i_ = -1; \
+        if (p_ && p_->on && p_->n < 24) { i_ = p_->n++; p_->name[i_] = kname; if (!p_->ev[i_][0]) { hipEventCreate(&p_->ev[i_][0]); hipEventCreate(&p_->ev[i_][1]); } hipEventRecord(p_->ev[i_][0], s); } \
+        __VA_ARGS__; \
+        if (i_ >= 0) hipEventRecord(p_->ev[i_][1], s); \
+    } while (0)
+
 extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const UvcParams *P, hipStream_t s) {
     if (R->n_alns) hipLaunchKernelGGL(k_aln_prelude, dim3(nblk(R->n_alns, 256)), dim3(256), 0, s, *R, *W, *P);
 }
 extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, int half_ratio_phred,
-                                      const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s) {
+                                      const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof) {
     const unsigned nwin = nblk(R->npos, 256);   // 4 waves x 64 positions per block
+    if (prof) prof->n = 0;
     if (P->inferred_is_vcf_generated) {
-        hipLaunchKernelGGL(k_prep_fast, dim3(nwin), dim3(256), 0, s, *R, *P);
-        if (R->n_complex) hipLaunchKernelGGL(k_prep_slow, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P);
-        hipLaunchKernelGGL(k_thres, dim3(nblk(R->npos, 256)), dim3(256), 0, s, *R, *P, half_ratio_phred);
-        hipLaunchKernelGGL(k_p2_fast, dim3(nwin), dim3(256), 0, s, *R, *P);
-        if (R->n_complex) hipLaunchKernelGGL(k_p2_slow<true>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P);
+        TIMED(prof, "k_prep_fast", hipLaunchKernelGGL(k_prep_fast, dim3(nwin), dim3(256), 0, s, *R, *P));
+        if (R->n_complex) TIMED(prof, "k_prep_slow", hipLaunchKernelGGL(k_prep_slow, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
+        TIMED(prof, "k_thres", hipLaunchKernelGGL(k_thres, dim3(nblk(R->npos, 256)), dim3(256), 0, s, *R, *P, half_ratio_phred));
+        TIMED(prof, "k_p2_fast", hipLaunchKernelGGL(k_p2_fast, dim3(nwin), dim3(256), 0, s, *R, *P));
+        if (R->n_complex) TIMED(prof, "k_p2_slow_bias", hipLaunchKernelGGL(k_p2_slow<true>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
     } else {
-        hipLaunchKernelGGL(k_thres, dim3(nblk(R->npos, 256)), dim3(256), 0, s, *R, *P, half_ratio_phred);
+        TIMED(prof, "k_thres", hipLaunchKernelGGL(k_thres, dim3(nblk(R->npos, 256)), dim3(256), 0, s, *R, *P, half_ratio_phred));
     }
-    if (R->n_complex) hipLaunchKernelGGL(k_p2_slow<false>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P);
-    if (P->inferred_is_vcf_generated) hipLaunchKernelGGL(k_fragstat, dim3(nblk(R->n_frags, 64)), dim3(64), 0, s, *R, *P);
-    hipLaunchKernelGGL(k_frag, dim3(nwin), dim3(256), 0, s, *R, *P);
+    if (R->n_complex) TIMED(prof, "k_p2_slow_table", hipLaunchKernelGGL(k_p2_slow<false>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
+    if (P->inferred_is_vcf_generated) TIMED(prof, "k_fragstat", hipLaunchKernelGGL(k_fragstat, dim3(nblk(R->n_frags, 64)), dim3(64), 0, s, *R, *P));
+    TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag, dim3(nwin), dim3(256), 0, s, *R, *P));
     if (R->n_generic_fs) {
-        hipLaunchKernelGGL(k_fam_stat, dim3(nblk(R->n_generic_fs, 64)), dim3(64), 0, s, *R, *P);
-        hipLaunchKernelGGL(k_fam_p4, dim3(nblk(R->n_generic_work, 256)), dim3(256), 0, s, *R, *P);
+        TIMED(prof, "k_fam_stat", hipLaunchKernelGGL(k_fam_stat, dim3(nblk(R->n_generic_fs, 64)), dim3(64), 0, s, *R, *P));
+        TIMED(prof, "k_fam_p4", hipLaunchKernelGGL(k_fam_p4, dim3(nblk(R->n_generic_work, 256)), dim3(256), 0, s, *R, *P));
         if (P->inferred_is_vcf_generated) {
-            hipLaunchKernelGGL(k_fam_p5, dim3(nblk(R->n_generic_work, 256)), dim3(256), 0, s, *R, *P);
-            if (n_dup) hipLaunchKernelGGL(k_duplex, dim3(nblk(n_dup_work, 256)), dim3(256), 0, s, *R, *P, dup_units, n_dup, dup_off, n_dup_work);
+            TIMED(prof, "k_fam_p5", hipLaunchKernelGGL(k_fam_p5, dim3(nblk(R->n_generic_work, 256)), dim3(256), 0, s, *R, *P));
+            if (n_dup) TIMED(prof, "k_duplex", hipLaunchKernelGGL(k_duplex, dim3(nblk(n_dup_work, 256)), dim3(256), 0, s, *R, *P, dup_units, n_dup, dup_off, n_dup_work));
         }
     }
-    if (P->inferred_is_vcf_generated) hipLaunchKernelGGL(k_p5b, dim3(nblk(R->npos * 2, 256)), dim3(256), 0, s, *R, *P);
+    if (P->inferred_is_vcf_generated) TIMED(prof, "k_p5b", hipLaunchKernelGGL(k_p5b, dim3(nblk(R->npos * 2, 256)), dim3(256), 0, s, *R, *P));
 }

@@ -120,12 +120,11 @@ def generate_region(seed=12345, region_len=10000, depth=30, tid=19, beg=1000000,
 
     idx = r_pos[:, None] + np.arange(L)[None, :]
     bases = ref[idx].copy()                                   # [n_reads, L]
-    quals = (30 + rng.integers(0, 8, size=(n_reads, L))).astype(np.int16)
-    degr = rng.integers(0, 16, size=(n_reads, 15)).astype(np.int16)
+    quals = rng.integers(30, 38, size=(n_reads, L), dtype=np.uint8)
+    degr = rng.integers(0, 16, size=(n_reads, 15), dtype=np.uint8)
     fw = ~r_rev
     quals[fw, L - 15:] -= degr[fw]
     quals[r_rev, :15] -= degr[r_rev]
-    quals = np.clip(quals, 2, 37).astype(np.uint8)
 
     # SNVs (molecule-level genotype), applied where the read covers the site
     cig_special = {}  # read index -> (bases, quals, cigar list, pos)
@@ -162,12 +161,13 @@ def generate_region(seed=12345, region_len=10000, depth=30, tid=19, beg=1000000,
         bases[ri] = b
 
     # sequencing errors
-    err = rng.random((n_reads, L)) < err_rate
-    nerr = int(err.sum())
-    bases[err] = (bases[err] + rng.integers(1, 4, nerr)) % 4
+    flat = bases.reshape(-1)
+    nerr = int(rng.binomial(flat.size, err_rate))
+    eidx = rng.integers(0, flat.size, nerr)
+    flat[eidx] = (flat[eidx] + rng.integers(1, 4, nerr).astype(np.uint8)) % 4
     # occasional N
-    nmask = rng.random((n_reads, L)) < 2e-5
-    bases[nmask] = 4
+    nidx = rng.integers(0, flat.size, int(rng.binomial(flat.size, 2e-5)))
+    flat[nidx] = 4
 
     # soft clips on ~1 % of the plain reads
     clip_reads = np.nonzero(rng.random(n_reads) < clip_frac)[0]
@@ -186,7 +186,7 @@ def generate_region(seed=12345, region_len=10000, depth=30, tid=19, beg=1000000,
     # ---- CIGARs, end positions, NM ----
     n_cigar = np.ones(n_reads, dtype=np.int32)
     pos_out = r_pos.copy()
-    nm = (bases != ref[idx]).sum(axis=1).astype(np.int32)
+    nm = np.count_nonzero(bases != ref[idx], axis=1).astype(np.int32)
     special = {}
     for ri, (b, cig) in cig_special.items():
         q = 0; r = int(r_pos[ri]); mm = 0      # NM = mismatches in aligned bases + indel length
