@@ -44,7 +44,7 @@ def algorithmic_bytes_per_position(kernel, depth):
     return table.get(kernel, reads)
 
 
-def run_cpu_baseline(depth, n_regions=16, region_len=4000):
+def run_cpu_baseline(depth, n_regions=16, region_len=20000):
     """Times the oracle (test infrastructure) on `n_regions` independent regions, one thread each."""
     from concurrent.futures import ThreadPoolExecutor
     from uvc_amd import _ffi, region, synth
