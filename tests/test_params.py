@@ -1,0 +1,34 @@
+"""Parameter block: defaults pinned against the reference's own CmdLineArgs.hpp (compiled as-is by
+oracle/ref_params_dump.cpp -> tests/golden/params_default.json), struct layout shared by C and ctypes."""
+import ctypes as C
+import json
+import os
+
+from uvc_amd import _ffi, region
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_defaults_equal_reference_dump():
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "params_default.json")))
+    ours = dict(_ffi.PARAM_INTS + _ffi.PARAM_DBLS)
+    assert set(ref) == set(ours)
+    for k, v in ours.items():
+        assert ref[k] == v, (k, ref[k], v)
+
+
+def test_struct_size_and_defaults_through_the_c_abi(oracle_lib):
+    p = _ffi.UvcParams()
+    oracle_lib.call("params_default", C.byref(p))
+    assert p.struct_size == C.sizeof(_ffi.UvcParams)
+    for k, v in _ffi.PARAM_INTS + _ffi.PARAM_DBLS:
+        assert getattr(p, k) == v, k
+
+
+def test_platform_deltas(oracle_lib):
+    # CmdLineArgs.cpp:13-15, 113-134
+    p = region.default_params(oracle_lib, platform=1)
+    assert (p.syserr_minABQ_pcr_snv, p.syserr_minABQ_pcr_indel, p.syserr_minABQ_cap_snv, p.syserr_minABQ_cap_indel) == (200, 100, 200, 100)
+    assert p.central_readlen == 150 and p.inferred_sequencing_platform == 1
+    q = region.default_params(oracle_lib, platform=2)
+    assert (q.bq_phred_added_misma, q.fam_thres_highBQ_snv, q.fam_thres_highBQ_indel, q.bias_thres_PFBQ1, q.bias_thres_PFBQ2, q.bias_thres_highBQ) == (8, 0, 0, 0, 0, 7)

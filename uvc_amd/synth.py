@@ -66,14 +66,14 @@ def generate_region(seed=12345, region_len=10000, depth=30, tid=19, beg=1000000,
 
     # ---- variants (relative coordinates) ----
     variants = []  # (pos, kind, arg, af)
-    for p in range(lo + 500, hi - 500, snv_every):
+    for p in (range(lo + 500, hi - 500, snv_every) if snv_every else ()):
         q = p + int(rng.integers(0, 200))
         variants.append((q, "snv", int((ref[q] + 1 + rng.integers(0, 3)) % 4), 0.5))
-    for p in range(lo + 700, hi - 500, somatic_every):
+    for p in (range(lo + 700, hi - 500, somatic_every) if somatic_every else ()):
         q = p + int(rng.integers(0, 200))
         variants.append((q, "snv", int((ref[q] + 1 + rng.integers(0, 3)) % 4), float(rng.uniform(0.02, 0.1))))
     k = 0
-    for p in range(lo + 900, hi - 500, indel_every):
+    for p in (range(lo + 900, hi - 500, indel_every) if indel_every else ()):
         q = p + int(rng.integers(0, 200))
         kind = ("del", "ins")[k % 2]
         ln = (1, 3)[(k // 2) % 2]
