@@ -1,0 +1,17 @@
+#!/bin/bash
+# GPU-box helper: full -m gpu test suite, then the default bench (optionally without the CPU baseline).
+cd "${GRAFT_REPO_ROOT:-.}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1
+rc=$?
+tail -15 gpurun_out/gpu_tests.log
+[ $rc -ne 0 ] && exit $rc
+timeout -k 10 900 python bench.py $BENCH_ARGS > gpurun_out/bench_latest.json 2> gpurun_out/bench_latest.err || { tail -20 gpurun_out/bench_latest.err; exit 3; }
+python - <<'PY'
+import json
+j = json.load(open("gpurun_out/bench_latest.json"))
+print("value %.3e pos/s  ms/step %.2f  roofline %s frac %.4f" % (j["value"], j["ms_per_step"], j["roofline"]["kernel"], j["roofline"]["frac"]))
+print(j["kernel_ms"])
+print(j.get("cpu_baseline"))
+PY

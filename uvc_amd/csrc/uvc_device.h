@@ -18,6 +18,7 @@
 #define SQR_QUAL_DIV 32      // main_conversion.hpp:20
 #define MAX_INSERT_SIZE 2000 // common.hpp:64
 #define MAX_STR_N_BASES 100  // common.hpp:63
+#define UVC_MAXEV 8
 
 enum { C_MATCH = 0, C_INS = 1, C_DEL = 2, C_REF_SKIP = 3, C_SOFT_CLIP = 4, C_HARD_CLIP = 5, C_PAD = 6, C_EQUAL = 7, C_DIFF = 8 };
 
@@ -40,7 +41,7 @@ struct AlnRec {
     int32_t lclip_q;                    // query offset of the first aligned base
     int32_t m_index;                    // cigar index of the M op (simple)
     int32_t frag, fs;                   // owning fragment / family-strand unit
-    int32_t pad_;
+    int32_t id;                         // index in RegionDev::alns
 };
 
 struct FragRec {
@@ -49,7 +50,7 @@ struct FragRec {
     int32_t fs, strand, dflag, normMQ;
     int32_t n_cov, n_near;      // b10xSeqTlen / b10xSeqTNevents, main.hpp:2747-2756 (filled by k_fragstat)
     int32_t singleton;          // 1: the only fragment of its family-strand unit and the fast P4/P5 identities apply
-    int32_t pad_;
+    int32_t stat_kind;          // 0: n_cov/n_near from mutation events (<= 2 simple alignments, no primer gating); 1: per-fragment sweep
 };
 
 struct FsRec {                  // family x strand unit (alns2 of main.hpp:2869)
@@ -81,6 +82,9 @@ struct RegionDev {
     AlnRec *fast; int32_t n_fast;   // simple alignments, sorted by pos
     const int32_t *complex_ids; int32_t n_complex;
     FragRec *frags; int32_t n_frags;
+    int32_t *frag_nmut; int32_t *frag_mut;          // mutation events per fragment: count + up to UVC_MAXEV positions
+    const int32_t *sweep_frags; int32_t n_sweep;    // fragments that need the sequential sweep (host list)
+    int32_t *overflow_frags; int32_t *n_overflow;   // fragments whose event list overflowed (device list)
     const int32_t *frag_sorted;     // fragment ids sorted by FragRec::beg
     FsRec *fss; int32_t n_fs;
     const int32_t *generic_fs; int32_t n_generic_fs; int64_t n_generic_work;

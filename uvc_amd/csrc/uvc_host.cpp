@@ -19,7 +19,8 @@ struct UvcProf { int on; int n; const char *name[24]; hipEvent_t ev[24][2]; };
 extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, int half_ratio_phred,
                                       const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof);
 extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles,
-                                int32_t *d_fields, int64_t capacity, int64_t *d_count, hipStream_t s);
+                                int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch, hipStream_t s);
+extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -40,6 +41,9 @@ struct uvcgpu_region {
     size_t off[UVC_NUM_FIELD_GROUPS + 1];
     bool has_reads = false, accumulated = false;
     UvcProf prof;
+    // persistent scoring buffers (grown on demand)
+    long long *d_score_scratch = nullptr; size_t score_scratch_bytes = 0;
+    int32_t *d_score_fields = nullptr; int64_t score_capacity = 0; int64_t *d_score_count = nullptr;
 };
 
 static size_t group_bytes(const uvcgpu_region *r, int g) {
@@ -297,7 +301,16 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
             dup_work += std::max(u.end, std::min(o.end, r->end)) - std::min(u.beg, o.beg);
         }
     }
-    for (auto &f : frags) { f.end = std::min(f.end, r->end); f.singleton = fss[f.fs].generic ? 0 : 1; max_frag_span = std::max(max_frag_span, f.end - f.beg); }
+    std::vector<int32_t> sweep_frags;
+    for (size_t fi = 0; fi < frags.size(); fi++) {
+        FragRec &f = frags[fi];
+        f.end = std::min(f.end, r->end); f.singleton = fss[f.fs].generic ? 0 : 1; max_frag_span = std::max(max_frag_span, f.end - f.beg);
+        const bool amplicon_gated = (((f.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag))) && !(P.tn_is_paired && (0x1 & P.primer_flag)));
+        bool all_simple = true;
+        for (int k = f.aln_beg; k < f.aln_end; k++) all_simple = all_simple && (kind[k] == 0);
+        f.stat_kind = (all_simple && (f.aln_end - f.aln_beg) <= 2 && !amplicon_gated) ? 0 : 1;
+        if (f.stat_kind) sweep_frags.push_back((int32_t)fi);
+    }
     // pos-sorted order of the simple alignments, beg-sorted order of the fragments
     std::vector<int32_t> simple_ids, complex_ids, frag_sorted(frags.size());
     for (int64_t i = 0; i < n; i++) (kind[i] == 0 ? simple_ids : complex_ids).push_back((int32_t)i);
@@ -327,6 +340,9 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     { int32_t *d; if ((rc = upload(r, complex_ids, &d))) return rc; R.complex_ids = d; R.n_complex = (int32_t)complex_ids.size(); }
     { FragRec *d; if ((rc = upload(r, frags, &d))) return rc; R.frags = d; R.n_frags = (int32_t)frags.size(); }
     { int32_t *d; if ((rc = upload(r, frag_sorted, &d))) return rc; R.frag_sorted = d; }
+    { int32_t *d; if ((rc = upload(r, sweep_frags, &d))) return rc; R.sweep_frags = d; R.n_sweep = (int32_t)sweep_frags.size(); }
+    { std::vector<int32_t> z(frags.size() * (size_t)(UVC_MAXEV + 2) + 1, 0); int32_t *d; if ((rc = upload(r, z, &d))) return rc;
+      R.frag_nmut = d; R.frag_mut = d + frags.size(); R.overflow_frags = d + frags.size() * (size_t)(UVC_MAXEV + 1); R.n_overflow = d + frags.size() * (size_t)(UVC_MAXEV + 2); }
     { FsRec *d; if ((rc = upload(r, fss, &d))) return rc; R.fss = d; R.n_fs = (int32_t)fss.size(); }
     { int32_t *d; if ((rc = upload(r, generic_fs, &d))) return rc; R.generic_fs = d; R.n_generic_fs = (int32_t)generic_fs.size(); R.n_generic_work = work; }
     { std::vector<Contrib> v; Contrib *d = nullptr; const size_t bytes = std::max<int64_t>(table_rows, 1) * sizeof(Contrib);
@@ -350,6 +366,8 @@ int uvcgpu_region_accumulate(uvcgpu_region_t *r) {
     if (!r->has_reads) return fail(UVCGPU_ENOREADS, "no reads");   // process_batch returns -1, main.cpp:520-523
     HIP_OK(hipMemsetAsync(r->d_state, 0, r->state_bytes, r->stream));
     HIP_OK(hipMemcpyAsync(r->d_rtr, r->d_rtr0, (size_t)4 * UVC_NRTR * r->npos, hipMemcpyDeviceToDevice, r->stream));   // P1b edits indelphred in place
+    HIP_OK(hipMemsetAsync(r->R.frag_nmut, 0, sizeof(int32_t) * (size_t)r->R.n_frags, r->stream));
+    HIP_OK(hipMemsetAsync(r->R.n_overflow, 0, sizeof(int32_t), r->stream));
     // the table is rebuilt by k_p2_slow<false>: MAX-merge needs empty slots
     if (r->R.n_complex) {
         // rows were set to 0xFF in set_reads and k_p2_slow<false> is idempotent under MAX, so no reset is needed
@@ -423,22 +441,34 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
         HIP_OK(hipMalloc((void **)&d_al, sizeof(UvcIndelAllele) * rq.n_indel_alleles));
         HIP_OK(hipMemcpyAsync(d_al, rq.indel_alleles, sizeof(UvcIndelAllele) * rq.n_indel_alleles, hipMemcpyHostToDevice, r->stream));
     }
-    int32_t *d_fields = nullptr; int64_t *d_count = nullptr;
     const int64_t cap = std::max<int64_t>(out->capacity, 1);
-    HIP_OK(hipMalloc((void **)&d_fields, sizeof(int32_t) * UVC_NUM_SCORE_FIELDS * cap));
-    HIP_OK(hipMalloc((void **)&d_count, 8));
-    HIP_OK(hipMemsetAsync(d_count, 0, 8, r->stream));
-    int rc = uvc_launch_score(&r->R, &r->P, &rq, d_al, d_fields, out->capacity, d_count, r->stream);
+    if (cap > r->score_capacity) {
+        if (r->d_score_fields) hipFree(r->d_score_fields);
+        r->d_score_fields = nullptr; r->score_capacity = 0;
+        HIP_OK(hipMalloc((void **)&r->d_score_fields, sizeof(int32_t) * UVC_NUM_SCORE_FIELDS * cap));
+        r->score_capacity = cap;
+    }
+    if (!r->d_score_count) HIP_OK(hipMalloc((void **)&r->d_score_count, 8));
+    const size_t need = uvc_score_scratch_bytes(rq.pos_end - rq.pos_beg);
+    if (need > r->score_scratch_bytes) {
+        if (r->d_score_scratch) hipFree(r->d_score_scratch);
+        r->d_score_scratch = nullptr; r->score_scratch_bytes = 0;
+        HIP_OK(hipMalloc((void **)&r->d_score_scratch, need));
+        r->score_scratch_bytes = need;
+    }
+    HIP_OK(hipMemsetAsync(r->d_score_count, 0, 8, r->stream));
+    int rc = uvc_launch_score(&r->R, &r->P, &rq, d_al, r->d_score_fields, r->score_capacity, r->d_score_count, r->d_score_scratch, r->stream);
+    if (!rc && hipGetLastError() != hipSuccess) rc = fail(UVCGPU_EDEVICE, "score kernel launch failed");
     if (!rc) rc = uvcgpu_region_sync(r);
     int64_t cnt = 0;
-    if (!rc && hipMemcpy(&cnt, d_count, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(UVCGPU_EDEVICE, "hipMemcpy(count)");
+    if (!rc && hipMemcpy(&cnt, r->d_score_count, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(UVCGPU_EDEVICE, "hipMemcpy(count)");
     if (!rc) {
         out->n_records = cnt;
         if (cnt > out->capacity) rc = fail(UVCGPU_ENOMEM, "score output capacity too small");
-        else if (cnt > 0 && hipMemcpy2D(out->fields, sizeof(int32_t) * out->capacity, d_fields, sizeof(int32_t) * cap, sizeof(int32_t) * cnt, UVC_NUM_SCORE_FIELDS, hipMemcpyDeviceToHost) != hipSuccess)
+        else if (cnt > 0 && hipMemcpy2D(out->fields, sizeof(int32_t) * out->capacity, r->d_score_fields, sizeof(int32_t) * r->score_capacity, sizeof(int32_t) * cnt, UVC_NUM_SCORE_FIELDS, hipMemcpyDeviceToHost) != hipSuccess)
             rc = fail(UVCGPU_EDEVICE, "hipMemcpy2D(records)");
     }
-    hipFree(d_fields); hipFree(d_count); if (d_al) hipFree(d_al);
+    if (d_al) hipFree(d_al);
     return rc;
 }
 
@@ -452,6 +482,9 @@ void uvcgpu_region_destroy(uvcgpu_region_t *r) {
     if (r->d_baq) hipFree(r->d_baq);
     if (r->d_state) hipFree(r->d_state);
     if (r->R.err) hipFree(r->R.err);
+    if (r->d_score_scratch) hipFree(r->d_score_scratch);
+    if (r->d_score_fields) hipFree(r->d_score_fields);
+    if (r->d_score_count) hipFree(r->d_score_count);
     if (r->stream) hipStreamDestroy(r->stream);
     delete r;
 }

@@ -18,7 +18,8 @@
 //   k_p2_fast       per position  P2 + dealwith_segbias for simple reads         main.hpp:1360-1595, 1762-2296
 //   k_p2_slow       per read      P2 for reads with InDels (atomics) and, in TABLE mode, the
 //                                 BASE_QUALITY_MAX contribution table used by P3/P4/P5
-//   k_fragstat      per fragment  covered / near-mutation position counts        main.hpp:2738-2756
+//   k_fragstat_*    per fragment  covered / near-mutation position counts        main.hpp:2738-2756
+//                                 (closed form from mutation events; sequential sweep for InDel fragments)
 //   k_frag          per position  P3 + P3b, and P4/P5 of singleton families      main.hpp:2620-2830, 2832-3594
 //   k_fam_stat/p4/p5 per (family-strand unit, position): multi-fragment families main.hpp:2883-3522
 //   k_duplex        per (duplex family, position)                                main.hpp:3523-3550
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(256) k_aln_prelude(RegionDev R, RawReads W, Uv
     AlnRec a;
     a.pos = W.pos[id]; a.rend = W.endpos[id]; a.mpos = W.mpos[id]; a.isize = W.isize[id]; a.flag = W.flag[id]; a.mapq = W.mapq[id];
     a.dflag = W.dflag[id]; a.l_qseq = W.l_qseq[id]; a.seq_off = W.seq_off[id]; a.cigar_off = W.cigar_off[id]; a.table_off = W.table_off[id];
-    a.n_cigar = W.n_cigar[id]; a.kind = W.kind[id]; a.frag = W.frag[id]; a.fs = W.fs[id]; a.pad_ = 0;
+    a.n_cigar = W.n_cigar[id]; a.kind = W.kind[id]; a.frag = W.frag[id]; a.fs = W.fs[id]; a.id = id;
     const uint32_t *cigar = R.cigars + a.cigar_off;
     const uint8_t *bases = R.bases + a.seq_off;
     int nge = 0, ngo = 0, clip_cnt = 0;
@@ -261,6 +262,35 @@ DEV void clip_event(const RegionDev &R, const UvcParams &P, int rpos, int i, int
     }
 }
 
+DEV int simple_base_value(const UvcParams &P, const AlnRec &a, int p, const uint8_t *quals_qbase, bool proton);
+
+// A mismatching base of a simple alignment: decide with the reference's fragment consensus (main.hpp:2658-2726) whether
+// position p is a high-quality mutation of the fragment and, if so, record it once (by the first mismatching alignment).
+DEV void mut_event(const RegionDev &R, const UvcParams &P, const AlnRec &a, int p, int my_ref) {
+    const FragRec &f = R.frags[a.frag];
+    if (f.stat_kind != 0) return;
+    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    int m[6] = { 0, 0, 0, 0, 0, 0 };
+    int first_mis = -1;
+    for (int k = f.aln_beg; k < f.aln_end; k++) {
+        const AlnRec &al = R.alns[k];
+        if (p < al.pos || p >= al.rend) continue;
+        const int sym = R.bases[al.qbase + p];
+        if (sym != my_ref && first_mis < 0) first_mis = k;
+        const int v = simple_base_value(P, al, p, R.quals + al.qbase, proton);
+        m[sym] = imax(m[sym], v);
+    }
+    if (first_mis != a.id) return;
+    int cs = UVC_BASE_NN, cc = 0, ct = 0;
+    for (int s2 = 0; s2 < 6; s2++) { if (cc < m[s2]) { cs = s2; cc = m[s2]; } ct += m[s2]; }
+    const int con_qual = cc * 2 - ct;
+    const bool highBQ = (proton ? true : (con_qual >= P.bias_thres_highBQ));
+    if (symbols_mutated(my_ref, cs) && highBQ) {
+        const int idx = atomicAdd(&R.frag_nmut[a.frag], 1);
+        if (idx < UVC_MAXEV) R.frag_mut[(size_t)a.frag * UVC_MAXEV + idx] = p;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
@@ -291,7 +321,7 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
                 if (a.flag & 0x10) { li += imin(p - fl + 1, MAX_INSERT_SIZE); lidp += 1; }
                 else { ri += imin(fl + abs(a.isize) - p, MAX_INSERT_SIZE); ridp += 1; }
             }
-            if (b != my_ref) snv_dnv_scatter(R, R.bases + a.seq_off, (int)(a.qbase + p - a.seq_off), a.l_qseq, apos, rend, p);
+            if (b != my_ref) { snv_dnv_scatter(R, R.bases + a.seq_off, (int)(a.qbase + p - a.seq_off), a.l_qseq, apos, rend, p); mut_event(R, P, a, p, my_ref); }
             if (q >= P.bias_thres_highBQ) {
                 ldist += p - apos + 1; rdist += rend - p;
                 lbaq += (int)(my_baq - BAQ1(R, apos) + 1);
@@ -867,21 +897,16 @@ DEV void frag_counts(const RegionDev &R, const UvcParams &P, const FragRec &f, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_fragstat: per fragment, the counts of covered and near-mutation positions (main.hpp:2738-2756)
+// per fragment: counts of covered and near-mutation positions (b10xSeqTlen / b10xSeqTNevents, main.hpp:2738-2756)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_fragstat(RegionDev R, UvcParams P) {
-    const int fi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (fi >= R.n_frags) return;
-    FragRec f = R.frags[fi];
+// sequential sweep over the fragment span (fragments with InDel reads, > 2 reads, primer gating, or > UVC_MAXEV events)
+DEV void fragstat_sweep(const RegionDev &R, const UvcParams &P, int fi) {
+    const FragRec f = R.frags[fi];
     const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
     const int nb = P.syserr_mut_region_n_bases;
     int n_cov = 0, n_near = 0;
-    int last_mut = INT32_MIN / 2;      // last mutated position seen (for the backward half of the dilation)
-    // forward sweep: a covered position is "near" when a mutation lies within nb on either side.
-    // pending[] = covered positions within the last nb that are not yet known to be near.
-    int pend_cnt = 0, pend_first = 0;  // covered-but-not-near positions in (p - nb, p] form a contiguous tail: keep their count and oldest position
-    int tail[32]; int th = 0, tn = 0;   // ring of pending covered positions (nb <= 31 supported)
-    if (nb > 31) { atomicExch(R.err, UVCGPU_EUNSUPPORTED); return; }
+    int last_mut = INT32_MIN / 2;
+    int tail[32]; int th = 0, tn = 0;   // covered positions within the last nb that are not (yet) near a mutation
     int cnt[NSYM];
     for (int p = f.beg; p < f.end; p++) {
         frag_counts(R, P, f, p, proton, cnt);
@@ -897,17 +922,56 @@ __global__ void __launch_bounds__(64) k_fragstat(RegionDev R, UvcParams P) {
             const bool highBQ = (proton ? (UVC_BASE_SYMBOL == st || con_qual + 3 >= P.bias_thres_highBQ) : (UVC_LINK_SYMBOL == st || con_qual >= P.bias_thres_highBQ));
             if (symbols_mutated(refsymbol, cs) && highBQ) mut = true;
         }
-        // expire pending positions that can no longer be reached by a future mutation
-        while (tn > 0 && tail[th] < p - nb) { th = (th + 1) & 31; tn--; }
-        if (mut) { n_near += tn; tn = 0; last_mut = p; }          // everything pending within nb behind becomes near
+        while (tn > 0 && tail[th] < p - nb) { th = (th + 1) & 31; tn--; }   // can no longer be reached by a later mutation
+        if (mut) { n_near += tn; tn = 0; last_mut = p; }
         if (covered) {
             n_cov++;
-            if (p - last_mut <= nb) n_near++;                      // includes p == last_mut
+            if (p - last_mut <= nb) n_near++;
             else { tail[(th + tn) & 31] = p; tn++; }
         }
     }
-    (void)pend_cnt; (void)pend_first;
-    f.n_cov = n_cov; f.n_near = n_near;
+    R.frags[fi].n_cov = n_cov; R.frags[fi].n_near = n_near;
+}
+
+__global__ void __launch_bounds__(64) k_fragstat_sweep(RegionDev R, UvcParams P, const int32_t *list, const int32_t *n_dev, int n_host) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = (n_dev ? *n_dev : n_host);
+    if (t >= n) return;
+    if (P.syserr_mut_region_n_bases > 31) { atomicExch(R.err, UVCGPU_EUNSUPPORTED); return; }
+    fragstat_sweep(R, P, list[t]);
+}
+
+// closed form for fragments of <= 2 simple alignments: coverage = union of the alignment spans, mutations = the event list
+__global__ void __launch_bounds__(256) k_fragstat_fast(RegionDev R, UvcParams P) {
+    const int fi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (fi >= R.n_frags) return;
+    const FragRec f = R.frags[fi];
+    if (f.stat_kind != 0) return;
+    const int nm = R.frag_nmut[fi];
+    if (nm > UVC_MAXEV) { const int k = atomicAdd(R.n_overflow, 1); R.overflow_frags[k] = fi; return; }
+    // coverage intervals [a1,b1) u [a2,b2), disjoint and ordered
+    const AlnRec &x0 = R.alns[f.aln_beg];
+    int a1 = x0.pos, b1 = x0.rend, a2 = 0, b2 = 0;
+    if (f.aln_end - f.aln_beg == 2) {
+        const AlnRec &x1 = R.alns[f.aln_beg + 1];
+        int c = x1.pos, d = x1.rend;
+        if (c < a1) { int t = a1; a1 = c; c = t; t = b1; b1 = d; d = t; }
+        if (c <= b1) { b1 = imax(b1, d); } else { a2 = c; b2 = d; }
+    }
+    const int n_cov = (b1 - a1) + (b2 - a2);
+    int n_near = 0;
+    if (nm > 0) {
+        const int nb = P.syserr_mut_region_n_bases;
+        int ev[UVC_MAXEV];
+        for (int i = 0; i < nm; i++) ev[i] = R.frag_mut[(size_t)fi * UVC_MAXEV + i];
+        for (int i = 1; i < nm; i++) { const int v = ev[i]; int j = i - 1; while (j >= 0 && ev[j] > v) { ev[j + 1] = ev[j]; j--; } ev[j + 1] = v; }
+        int lo = ev[0] - nb, hi = ev[0] + nb + 1;   // merged dilation interval [lo, hi)
+        for (int i = 1; i <= nm; i++) {
+            if (i < nm && ev[i] - nb <= hi) { hi = ev[i] + nb + 1; continue; }
+            n_near += imax(0, imin(hi, b1) - imax(lo, a1)) + imax(0, imin(hi, b2) - imax(lo, a2));
+            if (i < nm) { lo = ev[i] - nb; hi = ev[i] + nb + 1; }
+        }
+    }
     R.frags[fi].n_cov = n_cov; R.frags[fi].n_near = n_near;
 }
 
@@ -1097,7 +1161,8 @@ __global__ void __launch_bounds__(64) k_fam_stat(RegionDev R, UvcParams P) {
     u.r2l_end_median = (n_r2l > 0 ? (nth(true, (n_r2l - 1) / 2) + nth(true, n_r2l / 2)) / 2 : u.beg);
     int nsb_min = u.end, nsb_max = u.beg;
     const int nfrags = u.frag_end - u.frag_beg;
-    if ((nfrags >= P.fam_thres_dup1add) && (qsum >= nq * P.fam_thres_qseqlen)) {
+    // the scan can only succeed for UMI families (or fam_flag & 0x2): is_fam_good needs it (main.hpp:2988-2989)
+    if ((nfrags >= P.fam_thres_dup1add) && (qsum >= nq * P.fam_thres_qseqlen) && ((u.dflag & 0x1) || (P.fam_flag & 0x2))) {
         int con[NSYM];
         for (int dir = 0; dir < 2; dir++) {
             int b = (dir ? (u.end - 1) : u.beg), e = (dir ? (u.beg - 1) : u.end), step = (dir ? -1 : 1);
@@ -1301,6 +1366,7 @@ __global__ void __launch_bounds__(256) k_p5b(RegionDev R, UvcParams P) {
 // host-callable launchers
 // ------------------------------------------------------------------------------------------------
 static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
+static inline int imin_h(int a, int b) { return a < b ? a : b; }
 
 // optional per-kernel HIP-event timing on the handle's own stream (bench.py roofline leg)
 struct UvcProf { int on; int n; const char *name[24]; hipEvent_t ev[24][2]; };
@@ -1328,7 +1394,12 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
         TIMED(prof, "k_thres", hipLaunchKernelGGL(k_thres, dim3(nblk(R->npos, 256)), dim3(256), 0, s, *R, *P, half_ratio_phred));
     }
     if (R->n_complex) TIMED(prof, "k_p2_slow_table", hipLaunchKernelGGL(k_p2_slow<false>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
-    if (P->inferred_is_vcf_generated) TIMED(prof, "k_fragstat", hipLaunchKernelGGL(k_fragstat, dim3(nblk(R->n_frags, 64)), dim3(64), 0, s, *R, *P));
+    if (P->inferred_is_vcf_generated) {
+        TIMED(prof, "k_fragstat_fast", hipLaunchKernelGGL(k_fragstat_fast, dim3(nblk(R->n_frags, 256)), dim3(256), 0, s, *R, *P));
+        if (R->n_sweep) TIMED(prof, "k_fragstat_sweep", hipLaunchKernelGGL(k_fragstat_sweep, dim3(nblk(R->n_sweep, 64)), dim3(64), 0, s, *R, *P, R->sweep_frags, (const int32_t *)nullptr, R->n_sweep));
+        // fragments whose event list overflowed (device-side list; the grid covers the worst case, surplus threads exit)
+        TIMED(prof, "k_fragstat_overflow", hipLaunchKernelGGL(k_fragstat_sweep, dim3(nblk(imin_h(R->n_frags, 4096), 64)), dim3(64), 0, s, *R, *P, (const int32_t *)R->overflow_frags, (const int32_t *)R->n_overflow, 0));
+    }
     TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag, dim3(nwin), dim3(256), 0, s, *R, *P));
     if (R->n_generic_fs) {
         TIMED(prof, "k_fam_stat", hipLaunchKernelGGL(k_fam_stat, dim3(nblk(R->n_generic_fs, 64)), dim3(64), 0, s, *R, *P));

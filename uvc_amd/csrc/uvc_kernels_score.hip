@@ -622,8 +622,11 @@ struct ScoreCtx {
     int pos_beg, pos_end, all_out, is_amplicon;
     const UvcIndelAllele *alleles; long long n_alleles;   // sorted by (refpos, symbol)
     int32_t *fields; long long capacity;
-    long long *offsets;   // exclusive prefix of per-group allele counts, [2 * (pos_end - pos_beg) + 1]
+    long long *offsets;   // exclusive prefix of per-group packed (flag << 32 | allele count), [2 * (pos_end - pos_beg) + 1]
+    int *active;          // groups with at least one allele, ascending
 };
+#define PK_COUNT(v) ((long long)((v) & 0xFFFFFFFFLL))
+#define PK_FLAGS(v) ((long long)((v) >> 32))
 
 DEV long long allele_lower_bound(const ScoreCtx &C, int refpos, int symbol) {
     long long lo = 0, hi = C.n_alleles;
@@ -656,7 +659,7 @@ DEV int group_refsymbol(const RegionDev &R, int zpos, int st) {   // symboltype_
     return ((refsize == (refidx - 1) || (-1 == (refidx - 1))) ? UVC_BASE_NN : (int)R.refsym[refidx - 1]);
 }
 
-__global__ void __launch_bounds__(256) k_score_count(RegionDev R, UvcParams P, ScoreCtx C, int *counts) {
+__global__ void __launch_bounds__(256) k_score_count(RegionDev R, UvcParams P, ScoreCtx C, long long *counts) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long ngroups = 2LL * (C.pos_end - C.pos_beg);
     if (g >= ngroups) return;
@@ -674,30 +677,65 @@ __global__ void __launch_bounds__(256) k_score_count(RegionDev R, UvcParams P, S
             if (gate(R, P, x, st, s, refsymbol, totBDP, C.all_out, bd, cd)) { long long first; n += allele_multiplicity(C, refpos, s, first); }
         }
     }
-    counts[g] = n;
+    counts[g] = (long long)n | (n > 0 ? (1LL << 32) : 0LL);
 }
 
-// single-block exclusive scan (n <= a few million): each thread owns a contiguous chunk
-__global__ void __launch_bounds__(1024) k_scan(const int *counts, long long *offsets, long long n, long long *total) {
-    __shared__ long long part[1024];
-    const long long chunk = (n + 1023) / 1024;
-    const long long b = threadIdx.x * chunk, e = (b + chunk < n ? b + chunk : n);
-    long long s = 0;
-    for (long long i = b; i < e; i++) s += counts[i];
-    part[threadIdx.x] = s;
+// three-kernel exclusive scan of the packed (flag, count) words: block-local scan, scan of the block sums, add-back.
+#define SCAN_ITEMS 8
+#define SCAN_BLOCK 256
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_local(const long long *in, long long *out, long long *block_sums, long long n) {
+    __shared__ long long sh[SCAN_BLOCK];
+    const long long base = ((long long)blockIdx.x * SCAN_BLOCK + threadIdx.x) * SCAN_ITEMS;
+    long long v[SCAN_ITEMS], s = 0;
+    for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = (base + i < n ? in[base + i] : 0); s += v[i]; }
+    sh[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x == 0) { long long run = 0; for (int i = 0; i < 1024; i++) { const long long v = part[i]; part[i] = run; run += v; } *total = run; offsets[n] = run; }
-    __syncthreads();
-    long long run = part[threadIdx.x];
-    for (long long i = b; i < e; i++) { offsets[i] = run; run += counts[i]; }
+    for (int d = 1; d < SCAN_BLOCK; d <<= 1) {   // Hillis-Steele inclusive scan of the per-thread sums
+        const long long t = (threadIdx.x >= (unsigned)d ? sh[threadIdx.x - d] : 0);
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    long long run = sh[threadIdx.x] - s;
+    for (int i = 0; i < SCAN_ITEMS; i++) { if (base + i < n) out[base + i] = run; run += v[i]; }
+    if (threadIdx.x == SCAN_BLOCK - 1) block_sums[blockIdx.x] = sh[threadIdx.x];
+}
+__global__ void __launch_bounds__(1024) k_scan_tops(long long *block_sums, int nblocks, long long *offsets, long long n, long long *total_records) {
+    __shared__ long long sh[1024];
+    long long carry = 0;
+    for (int b0 = 0; b0 < nblocks; b0 += 1024) {
+        const int i = b0 + threadIdx.x;
+        const long long v = (i < nblocks ? block_sums[i] : 0);
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const long long t = (threadIdx.x >= (unsigned)d ? sh[threadIdx.x - d] : 0);
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nblocks) block_sums[i] = carry + sh[threadIdx.x] - v;
+        const long long tot = sh[1023];
+        __syncthreads();
+        carry += tot;
+    }
+    if (threadIdx.x == 0) { offsets[n] = carry; *total_records = PK_COUNT(carry); }
+}
+__global__ void __launch_bounds__(256) k_scan_add(const long long *in, long long *offsets, const long long *block_sums, int *active, long long n) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const long long o = offsets[g] + block_sums[g / (SCAN_BLOCK * SCAN_ITEMS)];
+    offsets[g] = o;
+    if (PK_FLAGS(in[g])) active[PK_FLAGS(o)] = (int)g;
 }
 
 __global__ void __launch_bounds__(128) k_score(RegionDev R, UvcParams P, ScoreCtx C) {
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long ngroups = 2LL * (C.pos_end - C.pos_beg);
-    if (g >= ngroups) return;
-    const long long rec0 = C.offsets[g], nrec = C.offsets[g + 1] - rec0;
-    if (nrec == 0 || rec0 + nrec > C.capacity) return;
+    const long long n_active = PK_FLAGS(C.offsets[ngroups]);
+    for (long long ai_ = (long long)blockIdx.x * blockDim.x + threadIdx.x; ai_ < n_active; ai_ += (long long)gridDim.x * blockDim.x) {
+    const long long g = C.active[ai_];
+    const long long rec0 = PK_COUNT(C.offsets[g]), nrec = PK_COUNT(C.offsets[g + 1]) - rec0;
+    if (nrec == 0 || rec0 + nrec > C.capacity) continue;
     const int zpos = C.pos_beg + (int)(g >> 1), st = (int)(g & 1);
     const int refpos = (st == UVC_BASE_SYMBOL ? zpos - 1 : zpos);
     const int64_t x = refpos - R.beg;
@@ -766,22 +804,29 @@ __global__ void __launch_bounds__(128) k_score(RegionDev R, UvcParams P, ScoreCt
             }
         }
     }
+    }
 }
 
 extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles,
-                                int32_t *d_fields, int64_t capacity, int64_t *d_count, hipStream_t s) {
+                                int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch /* 2*ngroups + nblocks + 2 words + ngroups ints */, hipStream_t s) {
     ScoreCtx C;
     C.pos_beg = req->pos_beg; C.pos_end = req->pos_end; C.all_out = (req->all_out || P->should_output_all) ? 1 : 0; C.is_amplicon = req->is_amplicon;
     C.alleles = d_alleles; C.n_alleles = req->n_indel_alleles; C.fields = d_fields; C.capacity = capacity;
     const long long ngroups = 2LL * (C.pos_end - C.pos_beg);
     if (ngroups <= 0) return 0;
-    int *counts = nullptr; long long *offsets = nullptr;
-    if (hipMalloc((void **)&counts, sizeof(int) * ngroups) != hipSuccess || hipMalloc((void **)&offsets, sizeof(long long) * (ngroups + 1)) != hipSuccess) return UVCGPU_ENOMEM;
-    C.offsets = offsets;
+    const int nblocks = (int)((ngroups + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS));
+    long long *counts = scratch, *offsets = scratch + ngroups, *block_sums = offsets + ngroups + 1;
+    C.offsets = offsets; C.active = (int *)(block_sums + nblocks + 1);
     hipLaunchKernelGGL(k_score_count, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, s, *R, *P, C, counts);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, counts, offsets, ngroups, (long long *)d_count);
-    hipLaunchKernelGGL(k_score, dim3((unsigned)((ngroups + 127) / 128)), dim3(128), 0, s, *R, *P, C);
-    hipError_t e = hipStreamSynchronize(s);
-    hipFree(counts); hipFree(offsets);
-    return e == hipSuccess ? 0 : UVCGPU_EDEVICE;
+    hipLaunchKernelGGL(k_scan_local, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, counts, offsets, block_sums, ngroups);
+    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, block_sums, nblocks, offsets, ngroups, (long long *)d_count);
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, s, counts, offsets, block_sums, C.active, ngroups);
+    const unsigned grid = (unsigned)((ngroups / 16 + 127) / 128 < 2048 ? ((ngroups / 16 + 127) / 128 > 0 ? (ngroups / 16 + 127) / 128 : 1) : 2048);
+    hipLaunchKernelGGL(k_score, dim3(grid), dim3(128), 0, s, *R, *P, C);
+    return 0;
+}
+extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored) {
+    const long long ngroups = 2LL * npos_scored;
+    const long long nblocks = (ngroups + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
+    return (size_t)((2 * ngroups + 1 + nblocks + 1) * 8 + ngroups * 4 + 64);
 }
