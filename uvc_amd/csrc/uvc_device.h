@@ -31,6 +31,7 @@ struct AlnRec {
     int64_t qbase;              // simple: seq_off + lclip_q - pos, so that query byte of ref position p is qbase + p
     int64_t cigar_off;
     int64_t table_off;          // complex: first row of the contribution table (row = p - pos), else -1
+    int64_t item_off;           // complex: first slot of the P2 item list, else -1
     int32_t n_cigar, kind;      // kind: 0 simple, 1 complex
     int32_t xm1500, go1500;
     int32_t bm1500[5];          // per base symbol (main.hpp:1860-1863); LINK/NN symbols are always 0
@@ -63,6 +64,19 @@ struct FsRec {                  // family x strand unit (alns2 of main.hpp:2869)
     int32_t pad_;
 };
 
+// One P2 update of an InDel read: "add value `val` of symbol `sym` at position `epos` and run dealwith_segbias with these
+// arguments".  The sequential CIGAR walk (k_p2_slow<true>) only produces items; k_p2_items applies them in parallel.
+struct Item { int32_t epos; uint8_t sym, flags /* bit0 isGap, bits 1..4 cigar op */, val, pad; uint16_t dist, indel_len; int32_t pad2; };
+
+// compact per-fragment record for k_frag, stored in beg-sorted order (written by k_fragstat_fast)
+struct FragFast {
+    int32_t beg, end, fi, flags;        // flags: bit0 kind (1 = generic path), bit1 strand, bit2 singleton, bits 3.. number of alignments
+    int32_t pos0, rend0, pos1, rend1;
+    int64_t qbase0, qbase1;
+    int32_t nogap0, nogap1, sq, n_cov;  // sq = normMQ^2 / SQR_QUAL_DIV
+    int32_t n_near, pad0_, pad1_, pad2_;
+};
+
 // contribution of one alignment at one reference position under BASE_QUALITY_MAX (main.hpp:1980, 1924, 2077, 2192, 2223)
 struct Contrib { uint8_t bsym, bval, l1sym, l1val, l2sym, l2val, l3sym, l3val; };   // sym == 0xFF: empty slot
 
@@ -86,9 +100,12 @@ struct RegionDev {
     const int32_t *sweep_frags; int32_t n_sweep;    // fragments that need the sequential sweep (host list)
     int32_t *overflow_frags; int32_t *n_overflow;   // fragments whose event list overflowed (device list)
     const int32_t *frag_sorted;     // fragment ids sorted by FragRec::beg
+    const int32_t *frag_rank;       // inverse permutation of frag_sorted
+    FragFast *ffast;                // [n_frags] in beg-sorted order
     FsRec *fss; int32_t n_fs;
     const int32_t *generic_fs; int32_t n_generic_fs; int64_t n_generic_work;
     Contrib *table;
+    Item *items; int32_t *item_cnt;     // per complex alignment (indexed like complex_ids)
     int32_t max_aln_span, max_frag_span;
     int32_t *err;                   // device error flag (unsupported CIGAR shapes etc.)
 };

@@ -12,7 +12,7 @@
 
 struct RawReads {
     const int32_t *pos, *endpos, *mpos, *isize, *flag, *mapq, *nm, *l_qseq, *n_cigar, *frag, *fs, *dflag, *kind, *fast_rank;
-    const int64_t *seq_off, *cigar_off, *table_off;
+    const int64_t *seq_off, *cigar_off, *table_off, *item_off;
 };
 extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const UvcParams *P, hipStream_t s);
 struct UvcProf { int on; int n; const char *name[24]; hipEvent_t ev[24][2]; };
@@ -234,7 +234,8 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     if (n == 0) return 0;
     if (n > INT32_MAX / 2) return fail(UVCGPU_EUNSUPPORTED, "more than 2^30 reads in one region");
     std::vector<int32_t> endpos(n), frag_of(n), fs_of(n), dflag_of(n), kind(n), fast_rank(n, -1);
-    std::vector<int64_t> table_off(n, -1);
+    std::vector<int64_t> table_off(n, -1), item_off(n, -1);
+    int64_t item_slots = 0;
     std::vector<FragRec> frags; std::vector<FsRec> fss;
     std::vector<int32_t> fam_fs((size_t)in->n_fams * 2, -1);
     int prev_fam = -1, prev_strand = -1, prev_frag = -1;
@@ -280,7 +281,11 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
         u.frag_end = (int32_t)frags.size(); u.beg = std::min(u.beg, in->pos[i]); u.end = std::max(u.end, e) + 1;
         frag_of[i] = (int32_t)frags.size() - 1; fs_of[i] = (int32_t)fss.size() - 1; dflag_of[i] = in->fam_dflag[fam];
         kind[i] = simple ? 0 : 1;
-        if (!simple) { table_off[i] = table_rows; table_rows += (e - in->pos[i]); }
+        if (!simple) {
+            table_off[i] = table_rows; table_rows += (e - in->pos[i]);
+            int64_t del_total = 0; for (int k = 0; k < nc; k++) if ((cg[k] & 0xF) == C_DEL) del_total += (cg[k] >> 4);
+            item_off[i] = item_slots; item_slots += 2 * (int64_t)lq + 2 * del_total + nc + 4;   // upper bound of P2 updates of this read
+        }
         else max_aln_span = std::max(max_aln_span, e - in->pos[i]);
         prev_fam = fam; prev_strand = strand; prev_frag = in->frag_id[i];
     }
@@ -331,7 +336,7 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
         || (rc = up32(flag32.data(), &W.flag)) || (rc = up32(mapq32.data(), &W.mapq)) || (rc = up32(in->nm, &W.nm)) || (rc = up32(in->l_qseq, &W.l_qseq))
         || (rc = up32(in->n_cigar, &W.n_cigar)) || (rc = up32(frag_of.data(), &W.frag)) || (rc = up32(fs_of.data(), &W.fs)) || (rc = up32(dflag_of.data(), &W.dflag))
         || (rc = up32(kind.data(), &W.kind)) || (rc = up32(fast_rank.data(), &W.fast_rank))
-        || (rc = up64(in->seq_off, &W.seq_off)) || (rc = up64(in->cigar_off, &W.cigar_off)) || (rc = up64(table_off.data(), &W.table_off))) return rc;
+        || (rc = up64(in->seq_off, &W.seq_off)) || (rc = up64(in->cigar_off, &W.cigar_off)) || (rc = up64(table_off.data(), &W.table_off)) || (rc = up64(item_off.data(), &W.item_off))) return rc;
     { std::vector<uint8_t> v(in->bases, in->bases + in->n_bases); uint8_t *d; if ((rc = upload(r, v, &d))) return rc; R.bases = d; }
     { std::vector<uint8_t> v(in->quals, in->quals + in->n_bases); uint8_t *d; if ((rc = upload(r, v, &d))) return rc; R.quals = d; }
     { std::vector<uint32_t> v(in->cigars, in->cigars + in->n_cigar_ops); uint32_t *d; if ((rc = upload(r, v, &d))) return rc; R.cigars = d; }
@@ -340,6 +345,9 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     { int32_t *d; if ((rc = upload(r, complex_ids, &d))) return rc; R.complex_ids = d; R.n_complex = (int32_t)complex_ids.size(); }
     { FragRec *d; if ((rc = upload(r, frags, &d))) return rc; R.frags = d; R.n_frags = (int32_t)frags.size(); }
     { int32_t *d; if ((rc = upload(r, frag_sorted, &d))) return rc; R.frag_sorted = d; }
+    { std::vector<int32_t> rank(frags.size()); for (size_t k = 0; k < frag_sorted.size(); k++) rank[frag_sorted[k]] = (int32_t)k;
+      int32_t *d; if ((rc = upload(r, rank, &d))) return rc; R.frag_rank = d; }
+    { std::vector<FragFast> v(frags.size()); FragFast *d; if ((rc = upload(r, v, &d))) return rc; R.ffast = d; }
     { int32_t *d; if ((rc = upload(r, sweep_frags, &d))) return rc; R.sweep_frags = d; R.n_sweep = (int32_t)sweep_frags.size(); }
     { std::vector<int32_t> z(frags.size() * (size_t)(UVC_MAXEV + 2) + 1, 0); int32_t *d; if ((rc = upload(r, z, &d))) return rc;
       R.frag_nmut = d; R.frag_mut = d + frags.size(); R.overflow_frags = d + frags.size() * (size_t)(UVC_MAXEV + 1); R.n_overflow = d + frags.size() * (size_t)(UVC_MAXEV + 2); }
@@ -347,6 +355,8 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     { int32_t *d; if ((rc = upload(r, generic_fs, &d))) return rc; R.generic_fs = d; R.n_generic_fs = (int32_t)generic_fs.size(); R.n_generic_work = work; }
     { std::vector<Contrib> v; Contrib *d = nullptr; const size_t bytes = std::max<int64_t>(table_rows, 1) * sizeof(Contrib);
       if (hipMalloc((void **)&d, bytes) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(table)"); r->owned.push_back(d); R.table = d; r->state_bytes += 0; (void)v; }
+    { Item *d = nullptr; if (hipMalloc((void **)&d, std::max<int64_t>(item_slots, 1) * sizeof(Item)) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(items)"); r->owned.push_back(d); R.items = d;
+      std::vector<int32_t> z(complex_ids.size() + 1, 0); int32_t *c; if ((rc = upload(r, z, &c))) return rc; R.item_cnt = c; }
     { if ((rc = upload(r, dup_units, &r->d_dup_units)) || (rc = upload(r, dup_off, &r->d_dup_off))) return rc; r->n_dup = (int)dup_units.size(); r->n_dup_work = dup_work; }
     R.max_aln_span = max_aln_span; R.max_frag_span = max_frag_span;
     r->R.n_complex = (int32_t)complex_ids.size();

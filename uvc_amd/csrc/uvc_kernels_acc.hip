@@ -179,7 +179,7 @@ DEV void primer_window(const UvcParams &P, const AlnRec &a, int &ibeg, int &iend
 // ------------------------------------------------------------------------------------------------
 struct RawReads {
     const int32_t *pos, *endpos, *mpos, *isize, *flag, *mapq, *nm, *l_qseq, *n_cigar, *frag, *fs, *dflag, *kind, *fast_rank;
-    const int64_t *seq_off, *cigar_off, *table_off;
+    const int64_t *seq_off, *cigar_off, *table_off, *item_off;
 };
 
 __global__ void __launch_bounds__(256) k_aln_prelude(RegionDev R, RawReads W, UvcParams P) {
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(256) k_aln_prelude(RegionDev R, RawReads W, Uv
     if (id >= R.n_alns) return;
     AlnRec a;
     a.pos = W.pos[id]; a.rend = W.endpos[id]; a.mpos = W.mpos[id]; a.isize = W.isize[id]; a.flag = W.flag[id]; a.mapq = W.mapq[id];
-    a.dflag = W.dflag[id]; a.l_qseq = W.l_qseq[id]; a.seq_off = W.seq_off[id]; a.cigar_off = W.cigar_off[id]; a.table_off = W.table_off[id];
+    a.dflag = W.dflag[id]; a.l_qseq = W.l_qseq[id]; a.seq_off = W.seq_off[id]; a.cigar_off = W.cigar_off[id]; a.table_off = W.table_off[id]; a.item_off = W.item_off[id];
     a.n_cigar = W.n_cigar[id]; a.kind = W.kind[id]; a.frag = W.frag[id]; a.fs = W.fs[id]; a.id = id;
     const uint32_t *cigar = R.cigars + a.cigar_off;
     const uint8_t *bases = R.bases + a.seq_off;
@@ -347,18 +347,19 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
     }
 }
 
-// sequential P1 for one alignment whose CIGAR has InDels / unusual clip layouts
+// P1 for one alignment whose CIGAR has InDels / unusual clip layouts: one wave per read, lanes stride over the bases of
+// each CIGAR op (every update of P1 is an independent integer add once the per-read totals of the first loop are known)
 __global__ void __launch_bounds__(64) k_prep_slow(RegionDev R, UvcParams P) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x, lane = threadIdx.x;
     if (t >= R.n_complex) return;
-    const AlnRec a = R.alns[R.complex_ids[t]];
+    const AlnRec &a = R.alns[R.complex_ids[t]];
     const uint32_t *cigar = R.cigars + a.cigar_off;
     const uint8_t *bases = R.bases + a.seq_off, *quals = R.quals + a.seq_off;
-    const int off = R.beg, rend = a.rend;
+    const int off = R.beg, rend = a.rend, apos = a.pos, n_cigar = a.n_cigar;
     const long long baq_last = R.end - 1;
     int nge = 0, ngo = 0, insbaq_sum = 0, delbaq_sum = 0, inslen_sum = 0, dellen_sum = 0;
-    int qpos = 0, rpos = a.pos;
-    for (int i = 0; i < a.n_cigar; i++) {
+    int qpos = 0, rpos = apos;
+    for (int i = 0; i < n_cigar; i++) {
         const int op = cig_op(cigar[i]), len = cig_len(cigar[i]);
         if (C_INS == op) { nge += len; ngo++; insbaq_sum += (int)(BAQ1(R, lmin((long long)rpos + len, baq_last)) - BAQ1(R, rpos)); inslen_sum += len; qpos += len; }
         else if (C_DEL == op) { nge += len; ngo++; delbaq_sum += (int)(BAQ1(R, lmin((long long)rpos + len, baq_last)) - BAQ1(R, rpos)); dellen_sum += len; rpos += len; }
@@ -366,20 +367,23 @@ __global__ void __launch_bounds__(64) k_prep_slow(RegionDev R, UvcParams P) {
         else if (op == C_REF_SKIP) rpos += len;
         else if (op == C_SOFT_CLIP) qpos += len;
     }
-    const int qlen = rend - a.pos;
+    const int qlen = rend - apos;
     const int xm1500 = a.xm1500, go1500 = a.go1500;
     const int avg_gaplen = nge / imax(1, ngo);
-    const int frag_pos_L = imin(a.pos, a.mpos), frag_pos_R = frag_pos_L + abs(a.isize);
+    const int frag_pos_L = imin(apos, a.mpos), frag_pos_R = frag_pos_L + abs(a.isize);
     const bool isrc = (a.flag & 0x10) != 0;
     const int pcr_dp_inc = ((a.dflag & 0x4) ? 1 : 0), umi_dp_inc = ((a.dflag & 0x1) ? 1 : 0);
     const int atd = P.indel_adj_tracklen_dist;
     const int nrtr = (int)R.npos;
-    qpos = 0; rpos = a.pos;
-    for (int i = 0; i < a.n_cigar; i++) {
+    const int isize = a.isize, l_qseq = a.l_qseq;
+    const long long baq_apos = BAQ1(R, apos), baq_rlast = BAQ1(R, rend - 1);
+    qpos = 0; rpos = apos;
+    for (int i = 0; i < n_cigar; i++) {
         const int op = cig_op(cigar[i]), len = cig_len(cigar[i]);
         if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) {
-            for (int j = 0; j < len; j++) {
-                const int64_t x = rpos - off;
+            for (int j = lane; j < len; j += 64) {
+                const int rp = rpos + j, qp = qpos + j;
+                const int64_t x = rp - off;
                 if (pcr_dp_inc) atomicAdd(&P32(R, UVC_P_a_pcr_dp, x), pcr_dp_inc);
                 if (umi_dp_inc) atomicAdd(&P32(R, UVC_P_a_umi_dp, x), umi_dp_inc);
                 atomicAdd(&P32(R, UVC_P_a_dp, x), 1);
@@ -387,34 +391,34 @@ __global__ void __launch_bounds__(64) k_prep_slow(RegionDev R, UvcParams P) {
                 atomicAdd(&P32(R, UVC_P_a_XM1500, x), xm1500);
                 atomicAdd(&P32(R, UVC_P_a_GO1500, x), go1500);
                 atomicAdd(&P32(R, UVC_P_a_GAPLEN, x), avg_gaplen);
-                if (a.isize != 0) {
-                    if (isrc) { add64(&P64(R, UVC_P_a_LI, x), imin(rpos - frag_pos_L + 1, MAX_INSERT_SIZE)); atomicAdd(&P32(R, UVC_P_a_LIDP, x), 1); }
-                    else      { add64(&P64(R, UVC_P_a_RI, x), imin(frag_pos_R - rpos, MAX_INSERT_SIZE));     atomicAdd(&P32(R, UVC_P_a_RIDP, x), 1); }
+                if (isize != 0) {
+                    if (isrc) { add64(&P64(R, UVC_P_a_LI, x), imin(rp - frag_pos_L + 1, MAX_INSERT_SIZE)); atomicAdd(&P32(R, UVC_P_a_LIDP, x), 1); }
+                    else      { add64(&P64(R, UVC_P_a_RI, x), imin(frag_pos_R - rp, MAX_INSERT_SIZE));     atomicAdd(&P32(R, UVC_P_a_RIDP, x), 1); }
                 }
-                snv_dnv_scatter(R, bases, qpos, a.l_qseq, a.pos, rend, rpos);
-                if (quals[qpos] >= P.bias_thres_highBQ) {
-                    atomicAdd(&P32(R, UVC_P_a_l_dist_sum, x), rpos - a.pos + 1);
-                    atomicAdd(&P32(R, UVC_P_a_r_dist_sum, x), rend - rpos);
+                snv_dnv_scatter(R, bases, qp, l_qseq, apos, rend, rp);
+                if (quals[qp] >= P.bias_thres_highBQ) {
+                    atomicAdd(&P32(R, UVC_P_a_l_dist_sum, x), rp - apos + 1);
+                    atomicAdd(&P32(R, UVC_P_a_r_dist_sum, x), rend - rp);
                     atomicAdd(&P32(R, UVC_P_a_inslen_sum, x), inslen_sum);
                     atomicAdd(&P32(R, UVC_P_a_dellen_sum, x), dellen_sum);
-                    add64(&P64(R, UVC_P_a_l_BAQ_sum, x), (int)(BAQ1(R, rpos) - BAQ1(R, a.pos) + 1));
-                    add64(&P64(R, UVC_P_a_r_BAQ_sum, x), (int)(BAQ1(R, rend - 1) - BAQ1(R, rpos) + 1));
+                    add64(&P64(R, UVC_P_a_l_BAQ_sum, x), (int)(BAQ1(R, rp) - baq_apos + 1));
+                    add64(&P64(R, UVC_P_a_r_BAQ_sum, x), (int)(baq_rlast - BAQ1(R, rp) + 1));
                     add64(&P64(R, UVC_P_a_insBAQ_sum, x), insbaq_sum);
                     add64(&P64(R, UVC_P_a_delBAQ_sum, x), delbaq_sum);
                     atomicAdd(&P32(R, UVC_P_a_highBQ_dp, x), 1);
                 }
-                qpos++; rpos++;
             }
+            qpos += len; rpos += len;
         } else if (op == C_INS || op == C_DEL) {
             const int i1 = imax(atd, rpos - off) - atd, i2 = imin(rpos - off + atd, nrtr - 1);
             const int t1 = RTRP(R, UVC_RTR_tracklen, i1), t2 = RTRP(R, UVC_RTR_tracklen, i2);
             const int unitlen2 = imax(1, (t1 > t2) ? RTRP(R, UVC_RTR_unitlen, i1) : RTRP(R, UVC_RTR_unitlen, i2));
-            const int rtr_lo = imax((off + RTRP(R, UVC_RTR_begpos, i1)) - atd, a.pos);
+            const int rtr_lo = imax((off + RTRP(R, UVC_RTR_begpos, i1)) - atd, apos);
             const int rtr_hi = imin((off + RTRP(R, UVC_RTR_begpos, i2) + t2) + atd, rend);
             const int inv100 = (int)(100u / ((0 == (unsigned)len % (unsigned)unitlen2) ? ((unsigned)len / (unsigned)unitlen2) : 4u));
             if (op == C_INS) {
                 const int nbases = (int)((unsigned)len * (unsigned)P.indel_adj_indellen_perc / 100u);
-                for (int r2 = imax(rpos - nbases, a.pos); r2 < imin(rpos + nbases, rend); r2++) {
+                for (int r2 = imax(rpos - nbases, apos) + lane; r2 < imin(rpos + nbases, rend); r2 += 64) {
                     const int64_t x = r2 - off;
                     atomicAdd(&P32(R, UVC_P_a_near_ins_dp, x), 1);
                     add64(&P64(R, UVC_P_a_near_ins_pow2len, x), (long long)((unsigned)len * (unsigned)len));
@@ -422,11 +426,11 @@ __global__ void __launch_bounds__(64) k_prep_slow(RegionDev R, UvcParams P) {
                     add64(&P64(R, UVC_P_a_near_ins_r_pow2len, x), (long long)((rpos + nbases) - r2) * ((rpos + nbases) - r2));
                     atomicAdd(&P32(R, UVC_P_a_near_ins_inv100len, x), inv100);
                 }
-                for (int r2 = rtr_lo; r2 < rtr_hi; r2++) atomicAdd(&P32(R, UVC_P_a_near_RTR_ins_dp, r2 - off), 1);
-                atomicAdd(&P32(R, UVC_P_a_at_ins_dp, rpos - off), 1);
+                for (int r2 = rtr_lo + lane; r2 < rtr_hi; r2 += 64) atomicAdd(&P32(R, UVC_P_a_near_RTR_ins_dp, r2 - off), 1);
+                if (lane == 0) atomicAdd(&P32(R, UVC_P_a_at_ins_dp, rpos - off), 1);
                 qpos += len;
             } else {
-                for (int r2 = rpos; r2 < rpos + len; r2++) {
+                for (int r2 = rpos + lane; r2 < rpos + len; r2 += 64) {
                     const int64_t x = r2 - off;
                     if (pcr_dp_inc) atomicAdd(&P32(R, UVC_P_a_pcr_dp, x), pcr_dp_inc);
                     if (umi_dp_inc) atomicAdd(&P32(R, UVC_P_a_umi_dp, x), umi_dp_inc);
@@ -436,23 +440,23 @@ __global__ void __launch_bounds__(64) k_prep_slow(RegionDev R, UvcParams P) {
                     atomicAdd(&P32(R, UVC_P_a_XM1500, x), xm1500);
                     atomicAdd(&P32(R, UVC_P_a_GO1500, x), go1500);
                     atomicAdd(&P32(R, UVC_P_a_GAPLEN, x), avg_gaplen);
-                    if (a.isize != 0) {   // sic: the deletion start rpos, not r2 (main.hpp:1137-1145)
+                    if (isize != 0) {   // sic: the deletion start rpos, not r2 (main.hpp:1137-1145)
                         if (isrc) { add64(&P64(R, UVC_P_a_LI, x), imin(rpos - frag_pos_L + 1, MAX_INSERT_SIZE)); atomicAdd(&P32(R, UVC_P_a_LIDP, x), 1); }
                         else      { add64(&P64(R, UVC_P_a_RI, x), imin(frag_pos_R - rpos, MAX_INSERT_SIZE));     atomicAdd(&P32(R, UVC_P_a_RIDP, x), 1); }
                     }
-                    atomicAdd(&P32(R, UVC_P_a_l_dist_sum, x), rpos - a.pos + 1);
+                    atomicAdd(&P32(R, UVC_P_a_l_dist_sum, x), rpos - apos + 1);
                     atomicAdd(&P32(R, UVC_P_a_r_dist_sum, x), rend - rpos);
                     atomicAdd(&P32(R, UVC_P_a_inslen_sum, x), inslen_sum);
                     atomicAdd(&P32(R, UVC_P_a_dellen_sum, x), dellen_sum);
-                    add64(&P64(R, UVC_P_a_l_BAQ_sum, rpos - off), (int)(BAQ1(R, rpos) - BAQ1(R, a.pos) + 1));   // sic: at rpos (main.hpp:1156-1157)
-                    add64(&P64(R, UVC_P_a_r_BAQ_sum, rpos - off), (int)(BAQ1(R, rend - 1) - BAQ1(R, rpos) + 1));
+                    add64(&P64(R, UVC_P_a_l_BAQ_sum, rpos - off), (int)(BAQ1(R, rpos) - baq_apos + 1));   // sic: at rpos (main.hpp:1156-1157)
+                    add64(&P64(R, UVC_P_a_r_BAQ_sum, rpos - off), (int)(baq_rlast - BAQ1(R, rpos) + 1));
                     add64(&P64(R, UVC_P_a_insBAQ_sum, x), insbaq_sum);
                     add64(&P64(R, UVC_P_a_delBAQ_sum, x), delbaq_sum);
                 }
                 const int nbases_l = (int)((unsigned)len * (unsigned)(P.indel_adj_indellen_perc - 100) / 100u);
                 const int nbases_r = (int)((unsigned)len * (unsigned)P.indel_adj_indellen_perc / 100u);
-                const int lpos = imax(rpos - nbases_l, a.pos), rpos_r = imin(rpos + nbases_r, rend) - 1;
-                for (int r2 = lpos; r2 <= rpos_r; r2++) {
+                const int lpos = imax(rpos - nbases_l, apos), rpos_r = imin(rpos + nbases_r, rend) - 1;
+                for (int r2 = lpos + lane; r2 <= rpos_r; r2 += 64) {
                     const int64_t x = r2 - off;
                     atomicAdd(&P32(R, UVC_P_a_near_del_dp, x), 1);
                     add64(&P64(R, UVC_P_a_near_del_pow2len, x), (long long)((unsigned)len * (unsigned)len));
@@ -460,12 +464,12 @@ __global__ void __launch_bounds__(64) k_prep_slow(RegionDev R, UvcParams P) {
                     add64(&P64(R, UVC_P_a_near_del_r_pow2len, x), (long long)(rpos_r - r2 + 1) * (rpos_r - r2 + 1));
                     atomicAdd(&P32(R, UVC_P_a_near_del_inv100len, x), inv100);
                 }
-                for (int r2 = rtr_lo; r2 < rtr_hi; r2++) atomicAdd(&P32(R, UVC_P_a_near_RTR_del_dp, r2 - off), 1);
-                atomicAdd(&P32(R, UVC_P_a_at_del_dp, rpos - off), 1);
+                for (int r2 = rtr_lo + lane; r2 < rtr_hi; r2 += 64) atomicAdd(&P32(R, UVC_P_a_near_RTR_del_dp, r2 - off), 1);
+                if (lane == 0) atomicAdd(&P32(R, UVC_P_a_at_del_dp, rpos - off), 1);
                 rpos += len;
             }
         } else {
-            if (C_SOFT_CLIP == op || C_HARD_CLIP == op) clip_event(R, P, rpos, i, len, pcr_dp_inc);
+            if ((C_SOFT_CLIP == op || C_HARD_CLIP == op) && lane == 0) clip_event(R, P, rpos, i, len, pcr_dp_inc);
             if (op == C_REF_SKIP) rpos += len; else if (op == C_SOFT_CLIP) qpos += len;
         }
     }
@@ -677,16 +681,15 @@ __global__ void __launch_bounds__(64) k_p2_slow(RegionDev R, UvcParams P) {
     const bool is_assay_amplicon = ((a.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag)));
     const bool normal_filter_primers = (P.tn_is_paired && (0x1 & P.primer_flag));
     const int addMis = P.bq_phred_added_misma, addInd = P.bq_phred_added_indel;
-    const SegRead sr = make_segread(R, a);
     Contrib *table = BIAS ? nullptr : (R.table + a.table_off);
     auto Q = [&](int q) -> int { return (int)quals[imin(imax(q, 0), a.l_qseq - 1)]; };
+    Item *items = BIAS ? (R.items + a.item_off) : nullptr;
+    int n_items = 0;
     auto emit = [&](bool gap, int epos, int sym, int v, int bm, int op, int indel_len, int dist) {
-        if (BIAS) {
-            SegAcc A; A.zero(); A.bq = v;
-            PosThres T; load_thres(R, T, epos - off);
-            if (gap) segbias<true>(A, P, sr, T, epos, BAQ1(R, epos), BAQ2(R, epos), v, bm, op, indel_len, dist);
-            else     segbias<false>(A, P, sr, T, epos, BAQ1(R, epos), BAQ2(R, epos), v, bm, op, indel_len, dist);
-            seg_flush(R, A, sym, epos - off);
+        if (BIAS) {   // the bias update itself is applied by k_p2_items, in parallel over the items
+            Item it; it.epos = epos; it.sym = (uint8_t)sym; it.flags = (uint8_t)((gap ? 1 : 0) | (op << 1)); it.val = (uint8_t)imin(v, 255); it.pad = 0;
+            it.dist = (uint16_t)imin(imax(dist, 0), 65535); it.indel_len = (uint16_t)imin(indel_len, 65535); it.pad2 = 0;
+            items[n_items++] = it;
         } else table_put(R, table + (epos - a.pos), sym, v);
     };
     // low-BQ InDel positions (main.hpp:1817-1859); at most 16 tracked, more => unsupported
@@ -859,10 +862,32 @@ __global__ void __launch_bounds__(64) k_p2_slow(RegionDev R, UvcParams P) {
             if (op == C_REF_SKIP) rpos += len; else if (op == C_SOFT_CLIP) qpos += len;
         }
     }
+    if (BIAS) R.item_cnt[t] = n_items;
 }
 
 template __global__ void k_p2_slow<true>(RegionDev, UvcParams);
 template __global__ void k_p2_slow<false>(RegionDev, UvcParams);
+
+// applies the items of one InDel read: one wave per read, lanes stride over the items
+__global__ void __launch_bounds__(64) k_p2_items(RegionDev R, UvcParams P) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= R.n_complex) return;
+    const AlnRec &a = R.alns[R.complex_ids[t]];
+    const SegRead sr = make_segread(R, a);
+    const Item *items = R.items + a.item_off;
+    const int n = R.item_cnt[t];
+    for (int k = lane; k < n; k += 64) {
+        const Item it = items[k];
+        const int64_t x = it.epos - R.beg;
+        SegAcc A; A.zero(); A.bq = it.val;
+        PosThres T; load_thres(R, T, x);
+        const int op = (it.flags >> 1) & 0xF;
+        const int dist = (it.dist == 65535 ? 10000 : (int)it.dist);   // 10000 / large distances are clamped on emit; every use compares with small thresholds
+        if (it.flags & 1) segbias<true>(A, P, sr, T, it.epos, R.baq[x], R.baq[R.npos + x], it.val, 0, op, it.indel_len, dist);
+        else              segbias<false>(A, P, sr, T, it.epos, R.baq[x], R.baq[R.npos + x], it.val, a.bm1500[it.sym], op, it.indel_len, dist);
+        seg_flush(R, A, it.sym, x);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // contribution of ANY alignment at position p: simple ones are computed on the fly, complex ones
@@ -933,12 +958,51 @@ DEV void fragstat_sweep(const RegionDev &R, const UvcParams &P, int fi) {
     R.frags[fi].n_cov = n_cov; R.frags[fi].n_near = n_near;
 }
 
+// one wave per fragment: lanes classify positions (covered / mutated) into LDS, then count covered positions and those within
+// +-syserr_mut_region_n_bases of a mutation.  Spans beyond the LDS window fall back to the sequential sweep.
+#define SWEEP_MAXSPAN 4096
 __global__ void __launch_bounds__(64) k_fragstat_sweep(RegionDev R, UvcParams P, const int32_t *list, const int32_t *n_dev, int n_host) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint8_t flag[SWEEP_MAXSPAN];
+    __shared__ int tot[2];
+    const int t = blockIdx.x, lane = threadIdx.x;
     const int n = (n_dev ? *n_dev : n_host);
     if (t >= n) return;
-    if (P.syserr_mut_region_n_bases > 31) { atomicExch(R.err, UVCGPU_EUNSUPPORTED); return; }
-    fragstat_sweep(R, P, list[t]);
+    const int fi = list[t];
+    const FragRec &f = R.frags[fi];
+    const int span = f.end - f.beg, nb = P.syserr_mut_region_n_bases;
+    if (span > SWEEP_MAXSPAN) { if (lane == 0) { if (nb > 31) atomicExch(R.err, UVCGPU_EUNSUPPORTED); else fragstat_sweep(R, P, fi); } return; }
+    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    if (lane < 2) tot[lane] = 0;
+    int cnt[NSYM];
+    for (int i = lane; i < span; i += 64) {
+        const int p = f.beg + i;
+        frag_counts(R, P, f, p, proton, cnt);
+        int fl = 0;
+        const int refsymbol = R.refsym[p - R.beg];
+        for (int vi = 0; vi < 2; vi++) {
+            const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
+            int cs, cc, ct;
+            fill_consensus(cnt, cs, cc, ct, st, st == UVC_LINK_SYMBOL, false);
+            if (0 == ct) continue;
+            fl |= 1;
+            const int con_qual = cc * 2 - ct;
+            const bool highBQ = (proton ? (UVC_BASE_SYMBOL == st || con_qual + 3 >= P.bias_thres_highBQ) : (UVC_LINK_SYMBOL == st || con_qual >= P.bias_thres_highBQ));
+            if (symbols_mutated(refsymbol, cs) && highBQ) fl |= 2;
+        }
+        flag[i] = (uint8_t)fl;
+    }
+    __syncthreads();
+    int n_cov = 0, n_near = 0;
+    for (int i = lane; i < span; i += 64) {
+        if (!(flag[i] & 1)) continue;
+        n_cov++;
+        bool near = false;
+        for (int j = imax(0, i - nb); j <= imin(span - 1, i + nb) && !near; j++) near = (flag[j] & 2) != 0;
+        if (near) n_near++;
+    }
+    atomicAdd(&tot[0], n_cov); atomicAdd(&tot[1], n_near);
+    __syncthreads();
+    if (lane == 0) { R.frags[fi].n_cov = tot[0]; R.frags[fi].n_near = tot[1]; }
 }
 
 // closed form for fragments of <= 2 simple alignments: coverage = union of the alignment spans, mutations = the event list
@@ -946,20 +1010,30 @@ __global__ void __launch_bounds__(256) k_fragstat_fast(RegionDev R, UvcParams P)
     const int fi = blockIdx.x * blockDim.x + threadIdx.x;
     if (fi >= R.n_frags) return;
     const FragRec f = R.frags[fi];
-    if (f.stat_kind != 0) return;
+    FragFast ff;
+    ff.beg = f.beg; ff.end = f.end; ff.fi = fi;
+    ff.flags = (f.stat_kind ? 1 : 0) | (f.strand << 1) | (f.singleton << 2) | ((f.aln_end - f.aln_beg) << 3);
+    ff.pos0 = ff.rend0 = ff.pos1 = ff.rend1 = 0; ff.qbase0 = ff.qbase1 = 0; ff.nogap0 = ff.nogap1 = 0;
+    ff.sq = (f.normMQ * f.normMQ) / SQR_QUAL_DIV; ff.n_cov = 0; ff.n_near = 0; ff.pad0_ = ff.pad1_ = ff.pad2_ = 0;
+    if (f.stat_kind != 0) { R.ffast[R.frag_rank[fi]] = ff; return; }
     const int nm = R.frag_nmut[fi];
-    if (nm > UVC_MAXEV) { const int k = atomicAdd(R.n_overflow, 1); R.overflow_frags[k] = fi; return; }
     // coverage intervals [a1,b1) u [a2,b2), disjoint and ordered
     const AlnRec &x0 = R.alns[f.aln_beg];
+    ff.pos0 = x0.pos; ff.rend0 = x0.rend; ff.qbase0 = x0.qbase; ff.nogap0 = x0.nogap_penal;
     int a1 = x0.pos, b1 = x0.rend, a2 = 0, b2 = 0;
     if (f.aln_end - f.aln_beg == 2) {
         const AlnRec &x1 = R.alns[f.aln_beg + 1];
+        ff.pos1 = x1.pos; ff.rend1 = x1.rend; ff.qbase1 = x1.qbase; ff.nogap1 = x1.nogap_penal;
         int c = x1.pos, d = x1.rend;
         if (c < a1) { int t = a1; a1 = c; c = t; t = b1; b1 = d; d = t; }
         if (c <= b1) { b1 = imax(b1, d); } else { a2 = c; b2 = d; }
     }
     const int n_cov = (b1 - a1) + (b2 - a2);
     int n_near = 0;
+    if (nm > UVC_MAXEV) {   // too many events for the closed form: the sweep kernel fills n_cov / n_near, k_frag takes the generic path
+        const int k = atomicAdd(R.n_overflow, 1); R.overflow_frags[k] = fi;
+        ff.flags |= 1; R.ffast[R.frag_rank[fi]] = ff; return;
+    }
     if (nm > 0) {
         const int nb = P.syserr_mut_region_n_bases;
         int ev[UVC_MAXEV];
@@ -973,6 +1047,8 @@ __global__ void __launch_bounds__(256) k_fragstat_fast(RegionDev R, UvcParams P)
         }
     }
     R.frags[fi].n_cov = n_cov; R.frags[fi].n_near = n_near;
+    ff.n_cov = n_cov; ff.n_near = n_near;
+    R.ffast[R.frag_rank[fi]] = ff;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -991,84 +1067,115 @@ __global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
     const int64_t x = x0 + lane;
     const bool valid = x < R.npos;
     const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    const bool padded_ignored = (P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0;
     const int my_ref = valid ? R.refsym[x] : 0;
     for (int b = 0; b <= NBUCKETS; b++) { hist[threadIdx.x][0][b] = 0; hist[threadIdx.x][1][b] = 0; }
-    // avgBQ + 8 of the two dense symbols (get_avgBQ, main_conversion.hpp:791-796)
-    int maxq_ref = 8, maxq_link = 8;
+    // avgBQ + 8 of the two dense symbols (get_avgBQ, main_conversion.hpp:791-796); LINK_M value of a simple read at this position
+    int maxq_ref = 8, maxq_link = 8, noindel80 = 80;
     if (valid) {
         const int ad_r = S32(R, UVC_S_aDPff, my_ref, x) + S32(R, UVC_S_aDPfr, my_ref, x) + S32(R, UVC_S_aDPrf, my_ref, x) + S32(R, UVC_S_aDPrr, my_ref, x);
         const int ad_l = S32(R, UVC_S_aDPff, UVC_LINK_M, x) + S32(R, UVC_S_aDPfr, UVC_LINK_M, x) + S32(R, UVC_S_aDPrf, UVC_LINK_M, x) + S32(R, UVC_S_aDPrr, UVC_LINK_M, x);
         maxq_ref = 8 + BQS(R, my_ref, x) / imax(1, ad_r);
         maxq_link = 8 + BQS(R, UVC_LINK_M, x) / imax(1, ad_l);
+        if (x > 0) noindel80 = imin(80, imin(RTRP(R, UVC_RTR_indelphred, x - 1), RTRP(R, UVC_RTR_indelphred, x)));
     }
     // dense accumulators: [strand][ref, link] x {bDP, bTA, bTB, cDP12, cDP21, cDP1}, bMQ x {ref, link}
     int bDP[2][2] = {{0,0},{0,0}}, bTA[2][2] = {{0,0},{0,0}}, bTB[2][2] = {{0,0},{0,0}};
     int c12[2][2] = {{0,0},{0,0}}, c21[2][2] = {{0,0},{0,0}}, c1[2][2] = {{0,0},{0,0}};
     int bMQ[2] = {0, 0};
-    // fragments sorted by beg
     int lo, hi;
     {
         int l = 0, h = R.n_frags;
         const int key = w0 - R.max_frag_span + 1;
-        while (l < h) { int m = (l + h) >> 1; if (R.frags[R.frag_sorted[m]].beg < key) l = m + 1; else h = m; }
+        while (l < h) { int m = (l + h) >> 1; if (R.ffast[m].beg < key) l = m + 1; else h = m; }
         lo = wave_uniform(l);
         l = lo; h = R.n_frags;
-        while (l < h) { int m = (l + h) >> 1; if (R.frags[R.frag_sorted[m]].beg < w0 + 64) l = m + 1; else h = m; }
+        while (l < h) { int m = (l + h) >> 1; if (R.ffast[m].beg < w0 + 64) l = m + 1; else h = m; }
         hi = wave_uniform(l);
     }
-    int cnt[NSYM];
+    // one (fragment, position, symbol type) consensus -> P3 outputs and, for singleton units, the P4/P5 identities:
+    //   con = 1 vote for the fragment consensus when 2*max - tot passes the threshold (main.hpp:466-495) => cDP12, cDP21 (tot_count == 1)
+    //   mmm = 2*max - tot when positive (main.hpp:497-520)                                              => cDP1
+    auto apply = [&](int st, int cs, int cc, int ct, int cs4, int cc4, int ct4, int strand, int sq, int n_cov, int n_near, bool singleton) {
+        const int dense = (cs == my_ref ? 0 : (cs == UVC_LINK_M ? 1 : -1));
+        if (P.inferred_is_vcf_generated) {   // P3 belongs to updateByAlns3UsingBQ, skipped on FASTQ-only runs (main.hpp:3691)
+        int max_qual;
+        if (dense == 0) max_qual = maxq_ref; else if (dense == 1) max_qual = maxq_link;
+        else {
+            const int ad = S32(R, UVC_S_aDPff, cs, x) + S32(R, UVC_S_aDPfr, cs, x) + S32(R, UVC_S_aDPrf, cs, x) + S32(R, UVC_S_aDPrr, cs, x);
+            max_qual = 8 + BQS(R, cs, x) / imax(1, ad);
+        }
+        const int con_qual = cc * 2 - ct;
+        int phredlike = imin(con_qual, max_qual);
+        if (0x1 & P.fam_flag) phredlike = imin(phredlike, sscs_phred(P, my_ref, cs));
+        const int pbucket = imax(0, max_qual - phredlike);
+        if (dense >= 0) {
+            if (pbucket < NBUCKETS) hist[threadIdx.x][dense][pbucket] += 1;
+            bDP[strand][dense] += 1; bTA[strand][dense] += n_cov; bTB[strand][dense] += n_near; bMQ[dense] += sq;
+        } else {
+            if (pbucket < NBUCKETS) BKP(R, 0, cs, pbucket, x) += 1;
+            FRP(R, strand, UVC_FRAG_bDP, cs, x) += 1; FRP(R, strand, UVC_FRAG_bTA, cs, x) += n_cov; FRP(R, strand, UVC_FRAG_bTB, cs, x) += n_near;
+            VQP(R, UVC_VQ_bMQ, cs, x) += sq;
+        }
+        }
+        if (singleton) {
+            const int adj = imax(cc4 * 2, ct4) - ct4;
+            const int thr = (st == UVC_BASE_SYMBOL ? P.fam_thres_highBQ_snv : 0);
+            if (adj >= thr && adj > 0) {
+                const int d4 = (cs4 == my_ref ? 0 : (cs4 == UVC_LINK_M ? 1 : -1));
+                if (d4 >= 0) { c12[strand][d4] += 1; c21[strand][d4] += 1; }
+                else { FAP(R, strand, UVC_FAM_cDP12, cs4, x) += 1; FAP(R, strand, UVC_FAM_cDP21, cs4, x) += 1; }
+            }
+            const int adj5 = imax(cc * 2, ct) - ct;
+            if (adj5 > 0 && P.inferred_is_vcf_generated) {
+                if (dense >= 0) c1[strand][dense] += 1; else FAP(R, strand, UVC_FAM_cDP1, cs, x) += 1;
+            }
+        }
+    };
     for (int k = lo; k < hi; k++) {
-        const int fi = R.frag_sorted[k];
-        const FragRec &f = R.frags[fi];
-        if (f.end <= w0) continue;
-        if (!(valid && p >= f.beg && p < f.end)) continue;
-        frag_counts(R, P, f, p, proton, cnt);
-        const int strand = f.strand;
-        const int sq = (f.normMQ * f.normMQ) / SQR_QUAL_DIV;
-        for (int vi = 0; vi < 2; vi++) {
-            const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
-            int cs, cc, ct;
-            fill_consensus(cnt, cs, cc, ct, st, st == UVC_LINK_SYMBOL, false);
-            if (0 == ct) continue;
-            const int dense = (cs == my_ref ? 0 : (cs == UVC_LINK_M ? 1 : -1));
-            int max_qual;
-            if (dense == 0) max_qual = maxq_ref; else if (dense == 1) max_qual = maxq_link;
-            else {
-                const int ad = S32(R, UVC_S_aDPff, cs, x) + S32(R, UVC_S_aDPfr, cs, x) + S32(R, UVC_S_aDPrf, cs, x) + S32(R, UVC_S_aDPrr, cs, x);
-                max_qual = 8 + BQS(R, cs, x) / imax(1, ad);
+        const FragFast &ff = R.ffast[k];
+        if (ff.end <= w0) continue;
+        if (!(valid && p >= ff.beg && p < ff.end)) continue;
+        const int strand = (ff.flags >> 1) & 1;
+        const bool singleton = (ff.flags >> 2) & 1;
+        if ((ff.flags & 1) == 0 && !proton) {
+            // register-only consensus of <= 2 simple alignments (BASE_QUALITY_MAX merge, main.hpp:339-349)
+            int bs1 = -1, bv1 = 0, bs2 = -1, bv2 = 0, lv = 0;
+            if (p >= ff.pos0 && p < ff.rend0) {
+                bs1 = R.bases[ff.qbase0 + p]; bv1 = R.quals[ff.qbase0 + p] + P.bq_phred_added_misma;
+                if (p > ff.pos0) lv = (int)nnminus(noindel80, ff.nogap0) + 1;
             }
-            const int con_qual = cc * 2 - ct;
-            int phredlike = imin(con_qual, max_qual);
-            if (0x1 & P.fam_flag) phredlike = imin(phredlike, sscs_phred(P, my_ref, cs));
-            const int pbucket = imax(0, max_qual - phredlike);
-            if (dense >= 0) {
-                if (pbucket < NBUCKETS) hist[threadIdx.x][dense][pbucket] += 1;
-                bDP[strand][dense] += 1; bTA[strand][dense] += f.n_cov; bTB[strand][dense] += f.n_near; bMQ[dense] += sq;
-            } else {
-                if (pbucket < NBUCKETS) BKP(R, 0, cs, pbucket, x) += 1;
-                FRP(R, strand, UVC_FRAG_bDP, cs, x) += 1; FRP(R, strand, UVC_FRAG_bTA, cs, x) += f.n_cov; FRP(R, strand, UVC_FRAG_bTB, cs, x) += f.n_near;
-                VQP(R, UVC_VQ_bMQ, cs, x) += sq;
+            if ((ff.flags >> 3) == 2 && p >= ff.pos1 && p < ff.rend1) {
+                const int sy = R.bases[ff.qbase1 + p], v = R.quals[ff.qbase1 + p] + P.bq_phred_added_misma;
+                if (bs1 < 0) { bs1 = sy; bv1 = v; } else if (sy == bs1) bv1 = imax(bv1, v); else { bs2 = sy; bv2 = v; }
+                if (p > ff.pos1) lv = imax(lv, (int)nnminus(noindel80, ff.nogap1) + 1);
             }
-            // P4 / P5 of a singleton family-strand unit (identities derived in DESIGN.md section 4.5):
-            //   con = 1 vote for the fragment consensus when 2*max - tot passes the threshold (main.hpp:466-495),
-            //   mmm = 2*max - tot when positive (main.hpp:497-520); with one fragment tot_count <= 1.
-            if (f.singleton) {
-                int cs4, cc4, ct4;   // updateByFiltering uses fillConsensusCounts<true> for LINK and <false, padded?> for BASE
-                const bool padded_ignored = (P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0;
-                if (st == UVC_LINK_SYMBOL) { cs4 = cs; cc4 = cc; ct4 = ct; }
-                else fill_consensus(cnt, cs4, cc4, ct4, st, false, padded_ignored);
-                const int adj = imax(cc4 * 2, ct4) - ct4;
-                const int thr = (st == UVC_BASE_SYMBOL ? P.fam_thres_highBQ_snv : 0);
-                if (adj >= thr && adj > 0) {     // one vote -> cDP12 and cDP21 (tot_count == 1)
-                    const int d4 = (cs4 == my_ref ? 0 : (cs4 == UVC_LINK_M ? 1 : -1));
-                    if (d4 >= 0) { c12[strand][d4] += 1; c21[strand][d4] += 1; }
-                    else { FAP(R, strand, UVC_FAM_cDP12, cs4, x) += 1; FAP(R, strand, UVC_FAM_cDP21, cs4, x) += 1; }
+            if (lv > 0) apply(UVC_LINK_SYMBOL, UVC_LINK_M, lv, lv, UVC_LINK_M, lv, lv, strand, ff.sq, ff.n_cov, ff.n_near, singleton);
+            if (bs1 >= 0) {
+                int cs, cc, ct;
+                if (bs2 < 0) { cs = bs1; cc = bv1; ct = bv1; }
+                else { const bool first = (bv1 > bv2) || (bv1 == bv2 && bs1 < bs2); cs = first ? bs1 : bs2; cc = first ? bv1 : bv2; ct = bv1 + bv2; }
+                int cs4 = cs, cc4 = cc, ct4 = ct;
+                if (padded_ignored) {   // fillConsensusCounts<false, true>: only A..T take part (main.hpp:410)
+                    const int v1 = (bs1 <= UVC_BASE_T ? bv1 : 0), v2 = ((bs2 >= 0 && bs2 <= UVC_BASE_T) ? bv2 : 0);
+                    ct4 = v1 + v2;
+                    if (v1 == 0 && v2 == 0) { cs4 = UVC_BASE_T; cc4 = 0; }
+                    else { const bool first = (v1 > v2) || (v1 == v2 && (bs2 < 0 || bs1 < bs2)); cs4 = first ? bs1 : bs2; cc4 = first ? v1 : v2; }
                 }
-                // mmm uses fillConsensusCounts<true>/<false> without the padded-deletion exclusion
-                const int adj5 = imax(cc * 2, ct) - ct;
-                if (adj5 > 0 && P.inferred_is_vcf_generated) {
-                    if (dense >= 0) c1[strand][dense] += 1; else FAP(R, strand, UVC_FAM_cDP1, cs, x) += 1;
-                }
+                apply(UVC_BASE_SYMBOL, cs, cc, ct, cs4, cc4, ct4, strand, ff.sq, ff.n_cov, ff.n_near, singleton);
+            }
+        } else {
+            int cnt[NSYM];
+            const FragRec &f = R.frags[ff.fi];
+            frag_counts(R, P, f, p, proton, cnt);
+            for (int vi = 0; vi < 2; vi++) {
+                const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
+                int cs, cc, ct;
+                fill_consensus(cnt, cs, cc, ct, st, st == UVC_LINK_SYMBOL, false);
+                if (0 == ct) continue;
+                int cs4 = cs, cc4 = cc, ct4 = ct;
+                if (st == UVC_BASE_SYMBOL && padded_ignored) fill_consensus(cnt, cs4, cc4, ct4, st, false, true);
+                apply(st, cs, cc, ct, cs4, cc4, ct4, strand, ff.sq, f.n_cov, f.n_near, singleton);
             }
         }
     }
@@ -1084,7 +1191,7 @@ __global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
         if (bMQ[d]) VQP(R, UVC_VQ_bMQ, sym, x) += bMQ[d];
     }
     // P3b (main.hpp:2801-2828)
-    for (int st = 0; st < 2; st++) {
+    for (int st = 0; st < 2 && P.inferred_is_vcf_generated; st++) {
         const int sb = (st == 0 ? UVC_BASE_A : UVC_LINK_M), se = (st == 0 ? UVC_BASE_NN : UVC_LINK_NN);
         int totDP = 0;
         for (int s = sb; s <= se; s++) totDP += FRP(R, 0, UVC_FRAG_bDP, s, x) + FRP(R, 1, UVC_FRAG_bDP, s, x);
@@ -1386,19 +1493,22 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
     if (prof) prof->n = 0;
     if (P->inferred_is_vcf_generated) {
         TIMED(prof, "k_prep_fast", hipLaunchKernelGGL(k_prep_fast, dim3(nwin), dim3(256), 0, s, *R, *P));
-        if (R->n_complex) TIMED(prof, "k_prep_slow", hipLaunchKernelGGL(k_prep_slow, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
+        if (R->n_complex) TIMED(prof, "k_prep_slow", hipLaunchKernelGGL(k_prep_slow, dim3(R->n_complex), dim3(64), 0, s, *R, *P));
         TIMED(prof, "k_thres", hipLaunchKernelGGL(k_thres, dim3(nblk(R->npos, 256)), dim3(256), 0, s, *R, *P, half_ratio_phred));
         TIMED(prof, "k_p2_fast", hipLaunchKernelGGL(k_p2_fast, dim3(nwin), dim3(256), 0, s, *R, *P));
-        if (R->n_complex) TIMED(prof, "k_p2_slow_bias", hipLaunchKernelGGL(k_p2_slow<true>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
+        if (R->n_complex) {
+            TIMED(prof, "k_p2_slow_walk", hipLaunchKernelGGL(k_p2_slow<true>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
+            TIMED(prof, "k_p2_items", hipLaunchKernelGGL(k_p2_items, dim3(R->n_complex), dim3(64), 0, s, *R, *P));
+        }
     } else {
         TIMED(prof, "k_thres", hipLaunchKernelGGL(k_thres, dim3(nblk(R->npos, 256)), dim3(256), 0, s, *R, *P, half_ratio_phred));
     }
     if (R->n_complex) TIMED(prof, "k_p2_slow_table", hipLaunchKernelGGL(k_p2_slow<false>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
-    if (P->inferred_is_vcf_generated) {
+    {
         TIMED(prof, "k_fragstat_fast", hipLaunchKernelGGL(k_fragstat_fast, dim3(nblk(R->n_frags, 256)), dim3(256), 0, s, *R, *P));
-        if (R->n_sweep) TIMED(prof, "k_fragstat_sweep", hipLaunchKernelGGL(k_fragstat_sweep, dim3(nblk(R->n_sweep, 64)), dim3(64), 0, s, *R, *P, R->sweep_frags, (const int32_t *)nullptr, R->n_sweep));
+        if (R->n_sweep) TIMED(prof, "k_fragstat_sweep", hipLaunchKernelGGL(k_fragstat_sweep, dim3(R->n_sweep), dim3(64), 0, s, *R, *P, R->sweep_frags, (const int32_t *)nullptr, R->n_sweep));
         // fragments whose event list overflowed (device-side list; the grid covers the worst case, surplus threads exit)
-        TIMED(prof, "k_fragstat_overflow", hipLaunchKernelGGL(k_fragstat_sweep, dim3(nblk(imin_h(R->n_frags, 4096), 64)), dim3(64), 0, s, *R, *P, (const int32_t *)R->overflow_frags, (const int32_t *)R->n_overflow, 0));
+        TIMED(prof, "k_fragstat_overflow", hipLaunchKernelGGL(k_fragstat_sweep, dim3(imin_h(R->n_frags, 65535)), dim3(64), 0, s, *R, *P, (const int32_t *)R->overflow_frags, (const int32_t *)R->n_overflow, 0));
     }
     TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag, dim3(nwin), dim3(256), 0, s, *R, *P));
     if (R->n_generic_fs) {
