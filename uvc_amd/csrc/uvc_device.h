@@ -43,6 +43,17 @@ struct AlnRec {
     int32_t m_index;                    // cigar index of the M op (simple)
     int32_t frag, fs;                   // owning fragment / family-strand unit
     int32_t id;                         // index in RegionDev::alns
+    int64_t baq_pos, baq_last, baq2_last;   // baq[pos], baq[rend-1], baq2[rend-1] (region constants, main.hpp:1394-1396)
+};
+
+// 64-byte digest of a simple alignment for the position-centric kernels, stored pos-sorted.  A wave loads 64 consecutive
+// records (one per lane, coalesced) and broadcasts the fields of record j with v_readlane, so the per-read scalars never
+// cost a dependent memory round trip inside the loop.
+struct FastRec {
+    int32_t pos, rend, qb_lo, qb_hi;        // qbase split into two dwords
+    int32_t fmd, isize, mpos, xm1500;       // fmd = flag | mapq << 16 | dflag << 24
+    int32_t bm01, bm23, bm4c, clips;        // bm1500[0..4] as 16-bit halves; bm4c also holds clip_cnt << 16 | nogap_penal << 20; clips = lclip_oplen | rclip_oplen << 16
+    int32_t baq_pos, baq_last, baq2_last, pad;
 };
 
 struct FragRec {
@@ -94,6 +105,7 @@ struct RegionDev {
     const uint8_t *bases; const uint8_t *quals; const uint32_t *cigars;
     AlnRec *alns; int32_t n_alns;
     AlnRec *fast; int32_t n_fast;   // simple alignments, sorted by pos
+    FastRec *frec;                  // [n_fast] digest of fast[]
     const int32_t *complex_ids; int32_t n_complex;
     FragRec *frags; int32_t n_frags;
     int32_t *frag_nmut; int32_t *frag_mut;          // mutation events per fragment: count + up to UVC_MAXEV positions

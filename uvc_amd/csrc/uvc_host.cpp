@@ -342,6 +342,7 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     { std::vector<uint32_t> v(in->cigars, in->cigars + in->n_cigar_ops); uint32_t *d; if ((rc = upload(r, v, &d))) return rc; R.cigars = d; }
     { std::vector<AlnRec> v((size_t)n); AlnRec *d; if ((rc = upload(r, v, &d))) return rc; R.alns = d; R.n_alns = (int32_t)n; }
     { std::vector<AlnRec> v(simple_ids.size()); AlnRec *d; if ((rc = upload(r, v, &d))) return rc; R.fast = d; R.n_fast = (int32_t)simple_ids.size(); }
+    { std::vector<FastRec> v(simple_ids.size()); FastRec *d; if ((rc = upload(r, v, &d))) return rc; R.frec = d; }
     { int32_t *d; if ((rc = upload(r, complex_ids, &d))) return rc; R.complex_ids = d; R.n_complex = (int32_t)complex_ids.size(); }
     { FragRec *d; if ((rc = upload(r, frags, &d))) return rc; R.frags = d; R.n_frags = (int32_t)frags.size(); }
     { int32_t *d; if ((rc = upload(r, frag_sorted, &d))) return rc; R.frag_sorted = d; }

@@ -31,6 +31,24 @@
 // ------------------------------------------------------------------------------------------------
 DEV int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+DEV int bcast(int v, int j) { return __builtin_amdgcn_readlane(v, j); }   // j must be wave-uniform
+struct Chunk16 { int v[16]; };
+DEV void load_chunk16(const FastRec *base, int kk, int hi, Chunk16 &c) {   // lane <- record kk (zeros past the end: rend = 0 never overlaps)
+    if (kk < hi) {
+        const int4 *q = (const int4 *)(base + kk);
+        const int4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+        c.v[0] = a0.x; c.v[1] = a0.y; c.v[2] = a0.z; c.v[3] = a0.w; c.v[4] = a1.x; c.v[5] = a1.y; c.v[6] = a1.z; c.v[7] = a1.w;
+        c.v[8] = a2.x; c.v[9] = a2.y; c.v[10] = a2.z; c.v[11] = a2.w; c.v[12] = a3.x; c.v[13] = a3.y; c.v[14] = a3.z; c.v[15] = a3.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) c.v[i] = 0;
+    }
+}
+DEV int lower_bound_frec(const FastRec *a, int n, int key) {   // first index with a[i].pos >= key
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid].pos < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
 DEV int lower_bound_pos(const AlnRec *a, int n, int key) {   // first index with a[i].pos >= key
     int lo = 0, hi = n;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid].pos < key) lo = mid + 1; else hi = mid; }
@@ -69,7 +87,7 @@ DEV SegRead make_segread(const RegionDev &R, const AlnRec &a) {
     r.pos = a.pos; r.rend = a.rend; r.flag = a.flag; r.mapq = a.mapq; r.isize = a.isize;
     r.frag_pos_L = imin(a.pos, a.mpos); r.frag_pos_R = r.frag_pos_L + abs(a.isize);
     r.xm1500 = a.xm1500; r.clip_cnt = a.clip_cnt; r.dflag = a.dflag;
-    r.baq_pos = BAQ1(R, a.pos); r.baq_last = BAQ1(R, a.rend - 1); r.baq2_last = BAQ2(R, a.rend - 1);
+    r.baq_pos = a.baq_pos; r.baq_last = a.baq_last; r.baq2_last = a.baq2_last;
     return r;
 }
 
@@ -162,6 +180,108 @@ DEV void segbias(SegAcc &A, const UvcParams &P, const SegRead &r, const PosThres
     }
 }
 
+// dealwith_segbias<true> for LINK_M and dealwith_segbias<false> for the read base at the same position of a simple
+// alignment (cigar_op = M, indel_len = 0, dist_to_interfering_indel = 10000), fused: everything that does not depend on the
+// symbol is computed once, and all counters are updated branch-free.
+DEV void segbias_pair(SegAcc &AL, SegAcc &AB, const UvcParams &P, const SegRead &r, const PosThres &T, int rpos, long long baq_p, long long baq2_p,
+                      int bqL, int bqB, int bm1500B) {
+    const bool amplicon = ((r.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag)));
+    const bool normal_filter_primers = (P.tn_is_paired && (0x1 & P.primer_flag));
+    const bool is_assay_UMI = (r.dflag & 0x1);
+    const bool isrc = (r.flag & 0x10) != 0;
+    const bool strand = ((r.flag & 0x81) == 0x81) ? ((r.flag & 0x20) != 0) : ((r.flag & 0x10) != 0);
+    const bool is_normal = ((r.isize != 0) || (0 == (r.flag & 0x1)));
+    const bool mate_ok = ((0 == (r.flag & 0x8)) || (0 == (r.flag & 0x1)));
+    const bool hrl = (P.central_readlen >= P.microadjust_median_readlen_thres);
+    const int l_nb = rpos - r.pos + 1, r_nb = r.rend - rpos;
+    const int l_baq1 = (int)(baq_p - r.baq_pos + 1);
+    const int r_baq1B = (int)(r.baq_last - baq_p + 1);
+    const int r_baq1L = (int)lmin((long long)r_baq1B, r.baq2_last - baq2_p + 7);
+    const int kb = P.microadjust_BAQ_per_base_x1024;
+    const int l_baq = (hrl ? l_baq1 : imax(l_baq1, l_nb * kb / 1024));
+    const int r_baqB = (hrl ? r_baq1B : imax(r_baq1B, r_nb * kb / 1024));
+    const int r_baqL = (hrl ? r_baq1L : imax(r_baq1L, r_nb * kb / 1024));
+    const int fl2 = ((r.isize != 0) ? imin(rpos - r.frag_pos_L + 1, MAX_INSERT_SIZE) : MAX_INSERT_SIZE);
+    const int fr2 = ((r.isize != 0) ? imin(r.frag_pos_R - rpos, MAX_INSERT_SIZE) : MAX_INSERT_SIZE);
+    // symbol-independent increments
+    const int ff = (!strand && !isrc), fr = (!strand && isrc), rf = (strand && !isrc), rr = (strand && isrc);
+    const int p3 = (imin(10000, imin(l_nb, r_nb)) >= P.bias_thres_interfering_indel);
+    const int nc = (0 == r.clip_cnt);
+    const long long lit = (isrc && r.isize != 0) ? fl2 : 0, rit = (!isrc && r.isize != 0) ? fr2 : 0;
+    const int p2 = (is_assay_UMI || !amplicon);
+    AL.s[UVC_S_aMQs] += r.mapq; AB.s[UVC_S_aMQs] += r.mapq;
+    AL.s[UVC_S_aDPff] += ff; AL.s[UVC_S_aDPfr] += fr; AL.s[UVC_S_aDPrf] += rf; AL.s[UVC_S_aDPrr] += rr;
+    AB.s[UVC_S_aDPff] += ff; AB.s[UVC_S_aDPfr] += fr; AB.s[UVC_S_aDPrf] += rf; AB.s[UVC_S_aDPrr] += rr;
+    AL.s[UVC_S_aP3] += p3; AB.s[UVC_S_aP3] += p3; AL.s[UVC_S_aNC] += nc; AB.s[UVC_S_aNC] += nc;
+    AL.l[UVC_S64_aLIT] += lit; AB.l[UVC_S64_aLIT] += lit; AL.l[UVC_S64_aRIT] += rit; AB.l[UVC_S64_aRIT] += rit;
+    AL.s[UVC_S_aP2] += p2; AB.s[UVC_S_aP2] += p2;
+    // base-quality sums
+    if (isrc) { AL.a1BQr += bqL; AL.a2BQr += bqL * bqL / SQR_QUAL_DIV; AB.a1BQr += bqB; AB.a2BQr += bqB * bqB / SQR_QUAL_DIV; }
+    else      { AL.a1BQf += bqL; AL.a2BQf += bqL * bqL / SQR_QUAL_DIV; AB.a1BQf += bqB; AB.a2BQf += bqB * bqB / SQR_QUAL_DIV; }
+    // edge tests
+    const int LPxT_L = T.t[UVC_T_aLPxT], RPxT = T.t[UVC_T_aRPxT], LPxT_B = imin(LPxT_L, RPxT);
+    const bool farL = (l_nb >= LPxT_L) && (r_nb >= RPxT), farB = (l_nb >= LPxT_B) && (r_nb >= RPxT);
+    const bool unaffL = (l_baq >= P.bias_thres_highBAQ && r_baqL >= P.bias_thres_highBAQ);
+    const bool unaffB = (l_baq >= P.bias_thres_highBAQ + 3 && r_baqB >= P.bias_thres_highBAQ + 3);
+    const int min_dist2iend = ((r.flag & 0x1) ? imin(fl2, fr2) : (isrc ? r_nb : l_nb));
+    const bool iend_ok = (min_dist2iend > P.primerlen2 || !amplicon);
+    AL.s[UVC_S_aP1] += (farL && unaffL && iend_ok); AB.s[UVC_S_aP1] += (farB && unaffB && iend_ok);
+    // passing-filter sums
+    const int q1 = P.bias_thres_PFBQ1 * P.bias_thres_PFBQ1, q2 = P.bias_thres_PFBQ2 * P.bias_thres_PFBQ2;
+    AL.s[UVC_S_aPF1] += imin(100, (bqL < P.bias_thres_PFBQ1) ? 100 * (bqL * bqL) / q1 : 100);
+    AL.s[UVC_S_aPF2] += imin(100, (bqL < P.bias_thres_PFBQ2) ? 100 * (bqL * bqL) / q2 : 100);
+    AB.s[UVC_S_aPF1] += 100 * ((bqB < P.bias_thres_PFBQ1) ? 100 * (bqB * bqB) / q1 : 100) / 100;
+    AB.s[UVC_S_aPF2] += 100 * ((bqB < P.bias_thres_PFBQ2) ? 100 * (bqB * bqB) / q2 : 100) / 100;
+    AB.s[UVC_S_a2XM2] += (r.xm1500 > 20 ? (100 * (20 * 20) / (r.xm1500 * r.xm1500)) : 100);
+    AB.s[UVC_S_a2BM2] += (bm1500B > 20 ? (100 * (20 * 20) / (bm1500B * bm1500B)) : 100);
+    // position / BAQ bias blocks: gap side enters when 10000 >= bias_thres_interfering_indel, base side when bq >= highBQ (tier2 then holds)
+    const bool inL = (10000 >= P.bias_thres_interfering_indel), inB = (bqB >= P.bias_thres_highBQ);
+    {
+        const bool a = inL && farL;
+        AL.s[UVC_S_aLP1] += (a && l_nb >= T.t[UVC_T_aLP1t]); AL.s[UVC_S_aLP2] += (a && l_nb >= T.t[UVC_T_aLP2t]);
+        AL.s[UVC_S_aRP1] += (a && r_nb >= T.t[UVC_T_aRP1t]); AL.s[UVC_S_aRP2] += (a && r_nb >= T.t[UVC_T_aRP2t]);
+        AL.s[UVC_S_aLPL] += a ? l_nb : 0; AL.s[UVC_S_aRPL] += a ? r_nb : 0;
+        const bool b = inL && unaffL;
+        AL.s[UVC_S_aLB1] += (b && l_baq >= P.bias_thres_BAQ1); AL.s[UVC_S_aLB2] += (b && l_baq >= P.bias_thres_BAQ2);
+        AL.s[UVC_S_aRB1] += (b && r_baqL >= P.bias_thres_BAQ1); AL.s[UVC_S_aRB2] += (b && r_baqL >= P.bias_thres_BAQ2);
+        AL.l[UVC_S64_aLBL] += b ? l_baq : 0; AL.l[UVC_S64_aRBL] += b ? r_baqL : 0;
+        AL.s[UVC_S_aBQ2] += inL;
+    }
+    {
+        const bool a = inB && farB;
+        AB.s[UVC_S_aLP1] += (a && l_nb >= T.t[UVC_T_aLP1t]); AB.s[UVC_S_aLP2] += (a && l_nb >= T.t[UVC_T_aLP2t]);
+        AB.s[UVC_S_aRP1] += (a && r_nb >= T.t[UVC_T_aRP1t]); AB.s[UVC_S_aRP2] += (a && r_nb >= T.t[UVC_T_aRP2t]);
+        AB.s[UVC_S_aLPL] += a ? l_nb : 0; AB.s[UVC_S_aRPL] += a ? r_nb : 0;
+        const bool b = inB && unaffB;
+        AB.s[UVC_S_aLB1] += (b && l_baq >= P.bias_thres_BAQ1); AB.s[UVC_S_aLB2] += (b && l_baq >= P.bias_thres_BAQ2);
+        AB.s[UVC_S_aRB1] += (b && r_baqB >= P.bias_thres_BAQ1); AB.s[UVC_S_aRB2] += (b && r_baqB >= P.bias_thres_BAQ2);
+        AB.l[UVC_S64_aLBL] += b ? l_baq : 0; AB.l[UVC_S64_aRBL] += b ? r_baqB : 0;
+        AB.s[UVC_S_aBQ2] += inB;
+    }
+    // insert-end bias
+    const bool l_nonbiased = (mate_ok && l_nb > r_nb), r_nonbiased = (mate_ok && l_nb < r_nb);
+    const bool goodL = ((!amplicon) || (!normal_filter_primers) || (farL && unaffL)), goodB = ((!amplicon) || (!normal_filter_primers) || (farB && unaffB));
+    if (isrc) {
+        const int d = fl2;
+        const bool okL = (is_normal || l_nonbiased), okB = is_normal;
+        AL.s[UVC_S_aLI1] += ((d >= T.t[UVC_T_aLI1t]) && okL);
+        AL.s[UVC_S_aLI2] += ((d >= T.t[UVC_T_aLI2t]) && okL && goodL);
+        AL.s[UVC_S_aLIr] += goodL;
+        AB.s[UVC_S_aLI1] += ((d >= T.t[UVC_T_aLI1t]) && (d <= T.t[UVC_T_aLI1T]) && okB);
+        AB.s[UVC_S_aLI2] += ((d >= T.t[UVC_T_aLI2t]) && (d <= T.t[UVC_T_aLI2T]) && okB && goodB);
+        AB.s[UVC_S_aLIr] += goodB;
+    } else {
+        const int d = fr2;
+        const bool okL = (is_normal || r_nonbiased), okB = is_normal;
+        AL.s[UVC_S_aRI1] += ((d >= T.t[UVC_T_aRI1t]) && okL);
+        AL.s[UVC_S_aRI2] += ((d >= T.t[UVC_T_aRI2t]) && okL && goodL);
+        AL.s[UVC_S_aRIf] += goodL;
+        AB.s[UVC_S_aRI1] += ((d >= T.t[UVC_T_aRI1t]) && (d <= T.t[UVC_T_aRI1T]) && okB);
+        AB.s[UVC_S_aRI2] += ((d >= T.t[UVC_T_aRI2t]) && (d <= T.t[UVC_T_aRI2T]) && okB && goodB);
+        AB.s[UVC_S_aRIf] += goodB;
+    }
+}
+
 DEV void load_thres(const RegionDev &R, PosThres &T, int64_t x) {
 #pragma unroll
     for (int f = 0; f < UVC_NTHRES; f++) T.t[f] = TH(R, f, x);
@@ -227,9 +347,20 @@ __global__ void __launch_bounds__(256) k_aln_prelude(RegionDev R, RawReads W, Uv
         if (m_index + 1 < a.n_cigar) a.rclip_oplen = cig_len(cigar[m_index + 1]);
     }
     a.qbase = a.seq_off + lclip_q - a.pos;
+    a.baq_pos = BAQ1(R, a.pos); a.baq_last = BAQ1(R, a.rend - 1); a.baq2_last = BAQ2(R, a.rend - 1);
     R.alns[id] = a;
     const int rk = W.fast_rank[id];
-    if (rk >= 0) R.fast[rk] = a;
+    if (rk >= 0) {
+        R.fast[rk] = a;
+        FastRec f;
+        f.pos = a.pos; f.rend = a.rend; f.qb_lo = (int32_t)(a.qbase & 0xFFFFFFFFLL); f.qb_hi = (int32_t)(a.qbase >> 32);
+        f.fmd = (a.flag & 0xFFFF) | ((a.mapq & 0xFF) << 16) | ((a.dflag & 0xFF) << 24); f.isize = a.isize; f.mpos = a.mpos; f.xm1500 = a.xm1500;
+        f.bm01 = (a.bm1500[0] & 0xFFFF) | (a.bm1500[1] << 16); f.bm23 = (a.bm1500[2] & 0xFFFF) | (a.bm1500[3] << 16);
+        f.bm4c = (a.bm1500[4] & 0xFFFF) | ((a.clip_cnt & 0xF) << 16) | ((a.nogap_penal & 0xF) << 20);
+        f.clips = (a.lclip_oplen & 0xFFFF) | (a.rclip_oplen << 16);
+        f.baq_pos = (int32_t)a.baq_pos; f.baq_last = (int32_t)a.baq_last; f.baq2_last = (int32_t)a.baq2_last; f.pad = 0;
+        R.frec[rk] = f;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -301,35 +432,57 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
     const int64_t x = x0 + lane;
     const bool valid = x < R.npos;
     const int my_ref = valid ? R.refsym[x] : 0;
-    const long long my_baq = valid ? R.baq[x] : 0;
+    const int my_baq = valid ? (int)R.baq[x] : 0;
     int dp = 0, pcr = 0, umi = 0, qlen_s = 0, xm_s = 0, lidp = 0, ridp = 0, ldist = 0, rdist = 0, hbq = 0;
     long long li = 0, ri = 0, lbaq = 0, rbaq = 0;
-    const int lo = wave_uniform(lower_bound_pos(R.fast, R.n_fast, w0 - R.max_aln_span + 1));
-    const int hi = wave_uniform(lower_bound_pos(R.fast, R.n_fast, w0 + 64));
-    for (int k = lo; k < hi; k++) {
-        const AlnRec &a = R.fast[k];
-        const int apos = a.pos, rend = a.rend;
-        if (rend <= w0) continue;
-        if (valid && p >= apos && p < rend) {
-            const uint8_t b = R.bases[a.qbase + p];
-            const uint8_t q = R.quals[a.qbase + p];
-            const int pcr_inc = ((a.dflag & 0x4) ? 1 : 0);
-            dp += 1; pcr += pcr_inc; umi += ((a.dflag & 0x1) ? 1 : 0);
-            qlen_s += rend - apos; xm_s += a.xm1500;
-            if (a.isize != 0) {
-                const int fl = imin(apos, a.mpos);
-                if (a.flag & 0x10) { li += imin(p - fl + 1, MAX_INSERT_SIZE); lidp += 1; }
-                else { ri += imin(fl + abs(a.isize) - p, MAX_INSERT_SIZE); ridp += 1; }
+    const int lo = wave_uniform(lower_bound_frec(R.frec, R.n_fast, w0 - R.max_aln_span + 1));
+    const int hi = wave_uniform(lower_bound_frec(R.frec, R.n_fast, w0 + 64));
+    for (int k0 = lo; k0 < hi; k0 += 64) {
+        Chunk16 c;
+        load_chunk16(R.frec, k0 + lane, hi, c);
+        const int n = imin(64, hi - k0);
+        int bn = 0, qn = 0;
+        auto issue = [&](int j) {   // loads of record j: always a valid byte of the read, so no branch around the loads
+            const int pos = bcast(c.v[0], j), rend = bcast(c.v[1], j);
+            const long long qb = ((long long)bcast(c.v[3], j) << 32) | (unsigned)bcast(c.v[2], j);
+            const long long at = qb + ((valid && p >= pos && p < rend) ? p : pos);
+            bn = R.bases[at]; qn = R.quals[at];
+        };
+        issue(0);
+        for (int j = 0; j < n; j++) {
+            const int b = bn, q = qn;
+            if (j + 1 < n) issue(j + 1);
+            const int apos = bcast(c.v[0], j), rend = bcast(c.v[1], j);
+            if (rend <= w0) continue;
+            if (valid && p >= apos && p < rend) {
+                const int fmd = bcast(c.v[4], j), isize = bcast(c.v[5], j), mpos = bcast(c.v[6], j), xm1500 = bcast(c.v[7], j);
+                const int dflag = (fmd >> 24) & 0xFF;
+                const int pcr_inc = ((dflag & 0x4) ? 1 : 0);
+                dp += 1; pcr += pcr_inc; umi += ((dflag & 0x1) ? 1 : 0);
+                qlen_s += rend - apos; xm_s += xm1500;
+                if (isize != 0) {
+                    const int fl = imin(apos, mpos);
+                    if (fmd & 0x10) { li += imin(p - fl + 1, MAX_INSERT_SIZE); lidp += 1; }
+                    else { ri += imin(fl + abs(isize) - p, MAX_INSERT_SIZE); ridp += 1; }
+                }
+                if (b != my_ref) {   // rare: SNV / DNV runs and fragment mutation events need the full record
+                    const AlnRec &a = R.fast[k0 + j];
+                    snv_dnv_scatter(R, R.bases + a.seq_off, (int)(a.qbase + p - a.seq_off), a.l_qseq, apos, rend, p);
+                    mut_event(R, P, a, p, my_ref);
+                }
+                if (q >= P.bias_thres_highBQ) {
+                    ldist += p - apos + 1; rdist += rend - p;
+                    lbaq += (my_baq - bcast(c.v[12], j) + 1);
+                    rbaq += (bcast(c.v[13], j) - my_baq + 1);
+                    hbq += 1;
+                }
+                const int clips = bcast(c.v[11], j);
+                if (clips != 0) {
+                    const int lclip = clips & 0xFFFF, rclip = (clips >> 16) & 0xFFFF;
+                    if (p == apos && lclip > 0) clip_event(R, P, apos, 0, lclip, pcr_inc);
+                    if (p == rend - 1 && rclip > 0) clip_event(R, P, rend, 1, rclip, pcr_inc);   // any index > 0 gives rpos_delta = -1
+                }
             }
-            if (b != my_ref) { snv_dnv_scatter(R, R.bases + a.seq_off, (int)(a.qbase + p - a.seq_off), a.l_qseq, apos, rend, p); mut_event(R, P, a, p, my_ref); }
-            if (q >= P.bias_thres_highBQ) {
-                ldist += p - apos + 1; rdist += rend - p;
-                lbaq += (int)(my_baq - BAQ1(R, apos) + 1);
-                rbaq += (int)(BAQ1(R, rend - 1) - my_baq + 1);
-                hbq += 1;
-            }
-            if (p == apos && a.lclip_oplen > 0) clip_event(R, P, apos, a.m_index - 1, a.lclip_oplen, pcr_inc);
-            if (p == rend - 1 && a.rclip_oplen > 0) clip_event(R, P, rend, a.m_index + 1, a.rclip_oplen, pcr_inc);
         }
     }
     if (!valid) return;
@@ -577,31 +730,72 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
     else { for (int f = 0; f < UVC_NTHRES; f++) T.t[f] = 0; }
     SegAcc Aref, Alink;
     Aref.zero(); Alink.zero();
-    const int lo = wave_uniform(lower_bound_pos(R.fast, R.n_fast, w0 - R.max_aln_span + 1));
-    const int hi = wave_uniform(lower_bound_pos(R.fast, R.n_fast, w0 + 64));
-    for (int k = lo; k < hi; k++) {
-        const AlnRec &a = R.fast[k];
-        if (a.rend <= w0) continue;
-        const SegRead sr = make_segread(R, a);
-        const bool is_assay_amplicon = ((a.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag)));
-        int ibeg, iend;
-        primer_window(P, a, ibeg, iend);
-        if (valid && p >= a.pos && p < a.rend && ((normal_filter_primers || !is_assay_amplicon) || (ibeg <= p && p < iend))) {
-            const uint8_t *qq = R.quals + a.qbase;
-            if (p > a.pos) {
-                const int inc = simple_link_value(R, P, a, p, qq, proton);
-                Alink.bq += inc;
-                segbias<true>(Alink, P, sr, T, p, baq_p, baq2_p, inc, 0, C_MATCH, 0, 10000);
+    // LINK_M value of a simple read at this position is a per-position constant up to the read's penalty (main.hpp:1919-1923)
+    int noindel80 = 80;
+    if (valid && x > 0) noindel80 = imin(80, imin(RTRP(R, UVC_RTR_indelphred, x - 1), RTRP(R, UVC_RTR_indelphred, x)));
+    const int lo = wave_uniform(lower_bound_frec(R.frec, R.n_fast, w0 - R.max_aln_span + 1));
+    const int hi = wave_uniform(lower_bound_frec(R.frec, R.n_fast, w0 + 64));
+    for (int k0 = lo; k0 < hi; k0 += 64) {
+        Chunk16 c;
+        load_chunk16(R.frec, k0 + lane, hi, c);
+        const int n = imin(64, hi - k0);
+        int bn = 0, qn = 0;
+        auto issue = [&](int j) {
+            const int pos = bcast(c.v[0], j), rend = bcast(c.v[1], j);
+            const long long qb = ((long long)bcast(c.v[3], j) << 32) | (unsigned)bcast(c.v[2], j);
+            const long long at = qb + ((valid && p >= pos && p < rend) ? p : pos);
+            bn = R.bases[at]; qn = R.quals[at];
+        };
+        issue(0);
+        for (int j = 0; j < n; j++) {
+            const int sym = bn, q = qn;
+            if (j + 1 < n) issue(j + 1);
+            const int apos = bcast(c.v[0], j), rend = bcast(c.v[1], j);
+            if (rend <= w0) continue;
+            const int fmd = bcast(c.v[4], j);
+            SegRead sr;
+            sr.pos = apos; sr.rend = rend; sr.flag = fmd & 0xFFFF; sr.mapq = (fmd >> 16) & 0xFF; sr.dflag = (fmd >> 24) & 0xFF;
+            sr.isize = bcast(c.v[5], j);
+            const int mpos = bcast(c.v[6], j);
+            sr.frag_pos_L = imin(apos, mpos); sr.frag_pos_R = sr.frag_pos_L + abs(sr.isize);
+            sr.xm1500 = bcast(c.v[7], j);
+            const int bm4c = bcast(c.v[10], j);
+            sr.clip_cnt = (bm4c >> 16) & 0xF;
+            const int nogap = (bm4c >> 20) & 0xF;
+            sr.baq_pos = bcast(c.v[12], j); sr.baq_last = bcast(c.v[13], j); sr.baq2_last = bcast(c.v[14], j);
+            const bool is_assay_amplicon = ((sr.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag)));
+            bool gate = true;
+            if (is_assay_amplicon && !normal_filter_primers) {   // primer gating, main.hpp:1872-1875, 1895
+                const bool isrc = (sr.flag & 0x10) != 0;
+                const int ibeg = ((sr.isize != 0) ? (sr.frag_pos_L + P.primerlen) : ((isrc && (0x0 == (0x1 & sr.flag))) ? 0 : (apos + P.primerlen)));
+                const int iend = ((sr.isize != 0) ? (int)nnminus(sr.frag_pos_L + abs(sr.isize), P.primerlen) : ((isrc && (0x0 == (0x1 & sr.flag))) ? (int)nnminus(rend, P.primerlen) : INT32_MAX));
+                gate = (ibeg <= p && p < iend);
             }
-            const int sym = R.bases[a.qbase + p];
-            const int inc = simple_base_value(P, a, p, qq, proton);
+            if (!(valid && p >= apos && p < rend && gate)) continue;
+            const int bm01 = bcast(c.v[8], j), bm23 = bcast(c.v[9], j);
+            const int bmS = (sym == 0 ? (bm01 & 0xFFFF) : sym == 1 ? ((bm01 >> 16) & 0xFFFF) : sym == 2 ? (bm23 & 0xFFFF) : sym == 3 ? ((bm23 >> 16) & 0xFFFF) : (bm4c & 0xFFFF));
+            int inc, incL;
+            if (proton) {   // IonTorrent values need neighbouring qualities and clip lengths: take them from the full record
+                const AlnRec &a = R.fast[k0 + j];
+                inc = simple_base_value(P, a, p, R.quals + a.qbase, true);
+                incL = (p > apos ? simple_link_value(R, P, a, p, R.quals + a.qbase, true) : 0);
+            } else { inc = q + P.bq_phred_added_misma; incL = (int)nnminus(noindel80, nogap) + 1; }
+            if (p > apos && sym == my_ref) {   // the common case: both updates go to the two dense records
+                Alink.bq += incL; Aref.bq += inc;
+                segbias_pair(Alink, Aref, P, sr, T, p, baq_p, baq2_p, incL, inc, bmS);
+                continue;
+            }
+            if (p > apos) {
+                Alink.bq += incL;
+                segbias<true>(Alink, P, sr, T, p, baq_p, baq2_p, incL, 0, C_MATCH, 0, 10000);
+            }
             if (sym == my_ref) {
                 Aref.bq += inc;
-                segbias<false>(Aref, P, sr, T, p, baq_p, baq2_p, inc, a.bm1500[sym], C_MATCH, 0, 10000);
+                segbias<false>(Aref, P, sr, T, p, baq_p, baq2_p, inc, bmS, C_MATCH, 0, 10000);
             } else {
                 SegAcc A; A.zero();
                 A.bq = inc;
-                segbias<false>(A, P, sr, T, p, baq_p, baq2_p, inc, a.bm1500[sym], C_MATCH, 0, 10000);
+                segbias<false>(A, P, sr, T, p, baq_p, baq2_p, inc, bmS, C_MATCH, 0, 10000);
                 seg_flush(R, A, sym, x);
             }
         }
