@@ -52,7 +52,8 @@ struct AlnRec {
 struct FastRec {
     int32_t pos, rend, qb_lo, qb_hi;        // qbase split into two dwords
     int32_t fmd, isize, mpos, xm1500;       // fmd = flag | mapq << 16 | dflag << 24
-    int32_t bm01, bm23, bm4c, clips;        // bm1500[0..4] as 16-bit halves; bm4c also holds clip_cnt << 16 | nogap_penal << 20; clips = lclip_oplen | rclip_oplen << 16
+    int32_t bmv, xbv, bm4c, clips;          // bmv: a2BM2 increment (<= 100) of base symbols 0..3, one byte each; xbv: that of symbol 4 | a2XM2 increment << 8;
+                                            // bm4c: clip_cnt << 16 | nogap_penal << 20; clips = lclip_oplen | rclip_oplen << 16
     int32_t baq_pos, baq_last, baq2_last, pad;
 };
 

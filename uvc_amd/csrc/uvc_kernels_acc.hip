@@ -184,7 +184,7 @@ DEV void segbias(SegAcc &A, const UvcParams &P, const SegRead &r, const PosThres
 // alignment (cigar_op = M, indel_len = 0, dist_to_interfering_indel = 10000), fused: everything that does not depend on the
 // symbol is computed once, and all counters are updated branch-free.
 DEV void segbias_pair(SegAcc &AL, SegAcc &AB, const UvcParams &P, const SegRead &r, const PosThres &T, int rpos, long long baq_p, long long baq2_p,
-                      int bqL, int bqB, int bm1500B) {
+                      int bqL, int bqB, int xm_inc, int bm_inc, const int *amp1, const int *amp2) {
     const bool amplicon = ((r.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag)));
     const bool normal_filter_primers = (P.tn_is_paired && (0x1 & P.primer_flag));
     const bool is_assay_UMI = (r.dflag & 0x1);
@@ -227,13 +227,10 @@ DEV void segbias_pair(SegAcc &AL, SegAcc &AB, const UvcParams &P, const SegRead 
     const bool iend_ok = (min_dist2iend > P.primerlen2 || !amplicon);
     AL.s[UVC_S_aP1] += (farL && unaffL && iend_ok); AB.s[UVC_S_aP1] += (farB && unaffB && iend_ok);
     // passing-filter sums
-    const int q1 = P.bias_thres_PFBQ1 * P.bias_thres_PFBQ1, q2 = P.bias_thres_PFBQ2 * P.bias_thres_PFBQ2;
-    AL.s[UVC_S_aPF1] += imin(100, (bqL < P.bias_thres_PFBQ1) ? 100 * (bqL * bqL) / q1 : 100);
-    AL.s[UVC_S_aPF2] += imin(100, (bqL < P.bias_thres_PFBQ2) ? 100 * (bqL * bqL) / q2 : 100);
-    AB.s[UVC_S_aPF1] += 100 * ((bqB < P.bias_thres_PFBQ1) ? 100 * (bqB * bqB) / q1 : 100) / 100;
-    AB.s[UVC_S_aPF2] += 100 * ((bqB < P.bias_thres_PFBQ2) ? 100 * (bqB * bqB) / q2 : 100) / 100;
-    AB.s[UVC_S_a2XM2] += (r.xm1500 > 20 ? (100 * (20 * 20) / (r.xm1500 * r.xm1500)) : 100);
-    AB.s[UVC_S_a2BM2] += (bm1500B > 20 ? (100 * (20 * 20) / (bm1500B * bm1500B)) : 100);
+    // amp1[v] / amp2[v] = (v < PFBQ ? 100 v^2 / PFBQ^2 : 100), tabulated per block (main.hpp:1472-1519); "100 * amp / 100" == amp
+    AL.s[UVC_S_aPF1] += imin(100, amp1[bqL]); AL.s[UVC_S_aPF2] += imin(100, amp2[bqL]);
+    AB.s[UVC_S_aPF1] += amp1[bqB]; AB.s[UVC_S_aPF2] += amp2[bqB];
+    AB.s[UVC_S_a2XM2] += xm_inc; AB.s[UVC_S_a2BM2] += bm_inc;
     // position / BAQ bias blocks: gap side enters when 10000 >= bias_thres_interfering_indel, base side when bq >= highBQ (tier2 then holds)
     const bool inL = (10000 >= P.bias_thres_interfering_indel), inB = (bqB >= P.bias_thres_highBQ);
     {
@@ -355,8 +352,12 @@ __global__ void __launch_bounds__(256) k_aln_prelude(RegionDev R, RawReads W, Uv
         FastRec f;
         f.pos = a.pos; f.rend = a.rend; f.qb_lo = (int32_t)(a.qbase & 0xFFFFFFFFLL); f.qb_hi = (int32_t)(a.qbase >> 32);
         f.fmd = (a.flag & 0xFFFF) | ((a.mapq & 0xFF) << 16) | ((a.dflag & 0xFF) << 24); f.isize = a.isize; f.mpos = a.mpos; f.xm1500 = a.xm1500;
-        f.bm01 = (a.bm1500[0] & 0xFFFF) | (a.bm1500[1] << 16); f.bm23 = (a.bm1500[2] & 0xFFFF) | (a.bm1500[3] << 16);
-        f.bm4c = (a.bm1500[4] & 0xFFFF) | ((a.clip_cnt & 0xF) << 16) | ((a.nogap_penal & 0xF) << 20);
+        // per-read constants of dealwith_segbias<false>: the a2XM2 / a2BM2 increments (main.hpp:1521-1522), each <= 100
+        int bv[5];
+        for (int s2 = 0; s2 < 5; s2++) bv[s2] = (a.bm1500[s2] > 20 ? (100 * (20 * 20) / (a.bm1500[s2] * a.bm1500[s2])) : 100);
+        const int xv = (a.xm1500 > 20 ? (100 * (20 * 20) / (a.xm1500 * a.xm1500)) : 100);
+        f.bmv = bv[0] | (bv[1] << 8) | (bv[2] << 16) | (bv[3] << 24); f.xbv = bv[4] | (xv << 8);
+        f.bm4c = ((a.clip_cnt & 0xF) << 16) | ((a.nogap_penal & 0xF) << 20);
         f.clips = (a.lclip_oplen & 0xFFFF) | (a.rclip_oplen << 16);
         f.baq_pos = (int32_t)a.baq_pos; f.baq_last = (int32_t)a.baq_last; f.baq2_last = (int32_t)a.baq2_last; f.pad = 0;
         R.frec[rk] = f;
@@ -713,6 +714,13 @@ DEV int simple_base_value(const UvcParams &P, const AlnRec &a, int p, const uint
 // P2 fast: updateByAln<SYMBOL_COUNT_SUM, bias> for simple alignments, one lane per position
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
+    __shared__ int amp1[256], amp2[256];
+    {
+        const int v = threadIdx.x;
+        amp1[v] = (v < P.bias_thres_PFBQ1 ? 100 * (v * v) / (P.bias_thres_PFBQ1 * P.bias_thres_PFBQ1) : 100);
+        amp2[v] = (v < P.bias_thres_PFBQ2 ? 100 * (v * v) / (P.bias_thres_PFBQ2 * P.bias_thres_PFBQ2) : 100);
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const int64_t x0 = (int64_t)wave * 64;
@@ -772,8 +780,8 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
                 gate = (ibeg <= p && p < iend);
             }
             if (!(valid && p >= apos && p < rend && gate)) continue;
-            const int bm01 = bcast(c.v[8], j), bm23 = bcast(c.v[9], j);
-            const int bmS = (sym == 0 ? (bm01 & 0xFFFF) : sym == 1 ? ((bm01 >> 16) & 0xFFFF) : sym == 2 ? (bm23 & 0xFFFF) : sym == 3 ? ((bm23 >> 16) & 0xFFFF) : (bm4c & 0xFFFF));
+            const int bmv = bcast(c.v[8], j), xbv = bcast(c.v[9], j);
+            const int bm_inc = (sym < 4 ? ((bmv >> (8 * sym)) & 0xFF) : (xbv & 0xFF)), xm_inc = (xbv >> 8) & 0xFF;
             int inc, incL;
             if (proton) {   // IonTorrent values need neighbouring qualities and clip lengths: take them from the full record
                 const AlnRec &a = R.fast[k0 + j];
@@ -782,13 +790,14 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
             } else { inc = q + P.bq_phred_added_misma; incL = (int)nnminus(noindel80, nogap) + 1; }
             if (p > apos && sym == my_ref) {   // the common case: both updates go to the two dense records
                 Alink.bq += incL; Aref.bq += inc;
-                segbias_pair(Alink, Aref, P, sr, T, p, baq_p, baq2_p, incL, inc, bmS);
+                segbias_pair(Alink, Aref, P, sr, T, p, baq_p, baq2_p, incL, imin(inc, 255), xm_inc, bm_inc, amp1, amp2);
                 continue;
             }
             if (p > apos) {
                 Alink.bq += incL;
                 segbias<true>(Alink, P, sr, T, p, baq_p, baq2_p, incL, 0, C_MATCH, 0, 10000);
             }
+            const int bmS = R.fast[k0 + j].bm1500[sym];   // uncommon paths (first base of the read, mismatching base): full record
             if (sym == my_ref) {
                 Aref.bq += inc;
                 segbias<false>(Aref, P, sr, T, p, baq_p, baq2_p, inc, bmS, C_MATCH, 0, 10000);
@@ -1304,7 +1313,7 @@ __global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
         if (0x1 & P.fam_flag) phredlike = imin(phredlike, sscs_phred(P, my_ref, cs));
         const int pbucket = imax(0, max_qual - phredlike);
         if (dense >= 0) {
-            if (pbucket < NBUCKETS) hist[threadIdx.x][dense][pbucket] += 1;
+            if (pbucket < NBUCKETS) atomicAdd(&hist[threadIdx.x][dense][pbucket], 1);   // ds_add_u32 without return: no read-modify-write round trip
             bDP[strand][dense] += 1; bTA[strand][dense] += n_cov; bTB[strand][dense] += n_near; bMQ[dense] += sq;
         } else {
             if (pbucket < NBUCKETS) BKP(R, 0, cs, pbucket, x) += 1;
@@ -1326,50 +1335,80 @@ __global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
             }
         }
     };
-    for (int k = lo; k < hi; k++) {
-        const FragFast &ff = R.ffast[k];
-        if (ff.end <= w0) continue;
-        if (!(valid && p >= ff.beg && p < ff.end)) continue;
-        const int strand = (ff.flags >> 1) & 1;
-        const bool singleton = (ff.flags >> 2) & 1;
-        if ((ff.flags & 1) == 0 && !proton) {
-            // register-only consensus of <= 2 simple alignments (BASE_QUALITY_MAX merge, main.hpp:339-349)
-            int bs1 = -1, bv1 = 0, bs2 = -1, bv2 = 0, lv = 0;
-            if (p >= ff.pos0 && p < ff.rend0) {
-                bs1 = R.bases[ff.qbase0 + p]; bv1 = R.quals[ff.qbase0 + p] + P.bq_phred_added_misma;
-                if (p > ff.pos0) lv = (int)nnminus(noindel80, ff.nogap0) + 1;
-            }
-            if ((ff.flags >> 3) == 2 && p >= ff.pos1 && p < ff.rend1) {
-                const int sy = R.bases[ff.qbase1 + p], v = R.quals[ff.qbase1 + p] + P.bq_phred_added_misma;
-                if (bs1 < 0) { bs1 = sy; bv1 = v; } else if (sy == bs1) bv1 = imax(bv1, v); else { bs2 = sy; bv2 = v; }
-                if (p > ff.pos1) lv = imax(lv, (int)nnminus(noindel80, ff.nogap1) + 1);
-            }
-            if (lv > 0) apply(UVC_LINK_SYMBOL, UVC_LINK_M, lv, lv, UVC_LINK_M, lv, lv, strand, ff.sq, ff.n_cov, ff.n_near, singleton);
-            if (bs1 >= 0) {
-                int cs, cc, ct;
-                if (bs2 < 0) { cs = bs1; cc = bv1; ct = bv1; }
-                else { const bool first = (bv1 > bv2) || (bv1 == bv2 && bs1 < bs2); cs = first ? bs1 : bs2; cc = first ? bv1 : bv2; ct = bv1 + bv2; }
-                int cs4 = cs, cc4 = cc, ct4 = ct;
-                if (padded_ignored) {   // fillConsensusCounts<false, true>: only A..T take part (main.hpp:410)
-                    const int v1 = (bs1 <= UVC_BASE_T ? bv1 : 0), v2 = ((bs2 >= 0 && bs2 <= UVC_BASE_T) ? bv2 : 0);
-                    ct4 = v1 + v2;
-                    if (v1 == 0 && v2 == 0) { cs4 = UVC_BASE_T; cc4 = 0; }
-                    else { const bool first = (v1 > v2) || (v1 == v2 && (bs2 < 0 || bs1 < bs2)); cs4 = first ? bs1 : bs2; cc4 = first ? v1 : v2; }
-                }
-                apply(UVC_BASE_SYMBOL, cs, cc, ct, cs4, cc4, ct4, strand, ff.sq, ff.n_cov, ff.n_near, singleton);
-            }
+    for (int k0 = lo; k0 < hi; k0 += 64) {
+        // one FragFast (20 dwords) per lane, fields of record j broadcast with v_readlane; base/qual bytes of record j+1 are
+        // requested before record j is processed
+        int c[20];
+        if (k0 + lane < hi) {
+            const int4 *q4 = (const int4 *)(R.ffast + (k0 + lane));
+#pragma unroll
+            for (int i = 0; i < 5; i++) { const int4 t = q4[i]; c[4 * i] = t.x; c[4 * i + 1] = t.y; c[4 * i + 2] = t.z; c[4 * i + 3] = t.w; }
         } else {
-            int cnt[NSYM];
-            const FragRec &f = R.frags[ff.fi];
-            frag_counts(R, P, f, p, proton, cnt);
-            for (int vi = 0; vi < 2; vi++) {
-                const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
-                int cs, cc, ct;
-                fill_consensus(cnt, cs, cc, ct, st, st == UVC_LINK_SYMBOL, false);
-                if (0 == ct) continue;
-                int cs4 = cs, cc4 = cc, ct4 = ct;
-                if (st == UVC_BASE_SYMBOL && padded_ignored) fill_consensus(cnt, cs4, cc4, ct4, st, false, true);
-                apply(st, cs, cc, ct, cs4, cc4, ct4, strand, ff.sq, f.n_cov, f.n_near, singleton);
+#pragma unroll
+            for (int i = 0; i < 20; i++) c[i] = 0;
+        }
+        const int n = imin(64, hi - k0);
+        int b0n = 0, q0n = 0, b1n = 0, q1n = 0;
+        auto issue = [&](int j) {
+            const int pos0 = bcast(c[4], j), rend0 = bcast(c[5], j), pos1 = bcast(c[6], j), rend1 = bcast(c[7], j);
+            const long long qb0 = ((long long)bcast(c[9], j) << 32) | (unsigned)bcast(c[8], j);
+            const long long qb1 = ((long long)bcast(c[11], j) << 32) | (unsigned)bcast(c[10], j);
+            if ((bcast(c[3], j) & 1) == 0) {   // register path only: generic records have no qbase
+                const long long at0 = qb0 + ((valid && p >= pos0 && p < rend0) ? p : pos0);
+                b0n = R.bases[at0]; q0n = R.quals[at0];
+                if ((bcast(c[3], j) >> 3) == 2) { const long long at1 = qb1 + ((valid && p >= pos1 && p < rend1) ? p : pos1); b1n = R.bases[at1]; q1n = R.quals[at1]; }
+            }
+        };
+        issue(0);
+        for (int j = 0; j < n; j++) {
+            const int b0 = b0n, q0 = q0n, b1 = b1n, q1 = q1n;
+            if (j + 1 < n) issue(j + 1);
+            const int fbeg = bcast(c[0], j), fend = bcast(c[1], j), flags = bcast(c[3], j);
+            if (fend <= w0) continue;
+            if (!(valid && p >= fbeg && p < fend)) continue;
+            const int strand = (flags >> 1) & 1;
+            const bool singleton = (flags >> 2) & 1;
+            if ((flags & 1) == 0 && !proton) {
+                // register-only consensus of <= 2 simple alignments (BASE_QUALITY_MAX merge, main.hpp:339-349)
+                const int pos0 = bcast(c[4], j), rend0 = bcast(c[5], j), pos1 = bcast(c[6], j), rend1 = bcast(c[7], j);
+                const int nogap0 = bcast(c[12], j), nogap1 = bcast(c[13], j), sq = bcast(c[14], j), n_cov = bcast(c[15], j), n_near = bcast(c[16], j);
+                int bs1 = -1, bv1 = 0, bs2 = -1, bv2 = 0, lv = 0;
+                if (p >= pos0 && p < rend0) {
+                    bs1 = b0; bv1 = q0 + P.bq_phred_added_misma;
+                    if (p > pos0) lv = (int)nnminus(noindel80, nogap0) + 1;
+                }
+                if ((flags >> 3) == 2 && p >= pos1 && p < rend1) {
+                    const int sy = b1, v = q1 + P.bq_phred_added_misma;
+                    if (bs1 < 0) { bs1 = sy; bv1 = v; } else if (sy == bs1) bv1 = imax(bv1, v); else { bs2 = sy; bv2 = v; }
+                    if (p > pos1) lv = imax(lv, (int)nnminus(noindel80, nogap1) + 1);
+                }
+                if (lv > 0) apply(UVC_LINK_SYMBOL, UVC_LINK_M, lv, lv, UVC_LINK_M, lv, lv, strand, sq, n_cov, n_near, singleton);
+                if (bs1 >= 0) {
+                    int cs, cc, ct;
+                    if (bs2 < 0) { cs = bs1; cc = bv1; ct = bv1; }
+                    else { const bool first = (bv1 > bv2) || (bv1 == bv2 && bs1 < bs2); cs = first ? bs1 : bs2; cc = first ? bv1 : bv2; ct = bv1 + bv2; }
+                    int cs4 = cs, cc4 = cc, ct4 = ct;
+                    if (padded_ignored) {   // fillConsensusCounts<false, true>: only A..T take part (main.hpp:410)
+                        const int v1 = (bs1 <= UVC_BASE_T ? bv1 : 0), v2 = ((bs2 >= 0 && bs2 <= UVC_BASE_T) ? bv2 : 0);
+                        ct4 = v1 + v2;
+                        if (v1 == 0 && v2 == 0) { cs4 = UVC_BASE_T; cc4 = 0; }
+                        else { const bool first = (v1 > v2) || (v1 == v2 && (bs2 < 0 || bs1 < bs2)); cs4 = first ? bs1 : bs2; cc4 = first ? v1 : v2; }
+                    }
+                    apply(UVC_BASE_SYMBOL, cs, cc, ct, cs4, cc4, ct4, strand, sq, n_cov, n_near, singleton);
+                }
+            } else {
+                int cnt[NSYM];
+                const FragRec &f = R.frags[bcast(c[2], j)];
+                frag_counts(R, P, f, p, proton, cnt);
+                for (int vi = 0; vi < 2; vi++) {
+                    const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
+                    int cs, cc, ct;
+                    fill_consensus(cnt, cs, cc, ct, st, st == UVC_LINK_SYMBOL, false);
+                    if (0 == ct) continue;
+                    int cs4 = cs, cc4 = cc, ct4 = ct;
+                    if (st == UVC_BASE_SYMBOL && padded_ignored) fill_consensus(cnt, cs4, cc4, ct4, st, false, true);
+                    apply(st, cs, cc, ct, cs4, cc4, ct4, strand, (f.normMQ * f.normMQ) / SQR_QUAL_DIV, f.n_cov, f.n_near, singleton);
+                }
             }
         }
     }
