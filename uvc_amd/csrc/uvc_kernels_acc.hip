@@ -1282,10 +1282,11 @@ __global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
         maxq_link = 8 + BQS(R, UVC_LINK_M, x) / imax(1, ad_l);
         if (x > 0) noindel80 = imin(80, imin(RTRP(R, UVC_RTR_indelphred, x - 1), RTRP(R, UVC_RTR_indelphred, x)));
     }
-    // dense accumulators: [strand][ref, link] x {bDP, bTA, bTB, cDP12, cDP21, cDP1}, bMQ x {ref, link}
-    int bDP[2][2] = {{0,0},{0,0}}, bTA[2][2] = {{0,0},{0,0}}, bTB[2][2] = {{0,0},{0,0}};
-    int c12[2][2] = {{0,0},{0,0}}, c21[2][2] = {{0,0},{0,0}}, c1[2][2] = {{0,0},{0,0}};
-    int bMQ[2] = {0, 0};
+    // dense accumulators: [strand][ref, link] x {bDP, bTA, bTB, cDP12, cDP21, cDP1}, bMQ x {ref, link}.  Named structs, selected by
+    // a wave-uniform branch on the strand: runtime-indexed local arrays would live in scratch memory (one VMEM round trip per update).
+    struct DAcc { int bDP, bTA, bTB, c12, c1; };
+    DAcc a_fr = {0,0,0,0,0}, a_fl = {0,0,0,0,0}, a_rr = {0,0,0,0,0}, a_rl = {0,0,0,0,0};   // {fwd,rev} x {ref,link}
+    int bMQ_r = 0, bMQ_l = 0;
     int lo, hi;
     {
         int l = 0, h = R.n_frags;
@@ -1299,8 +1300,8 @@ __global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
     // one (fragment, position, symbol type) consensus -> P3 outputs and, for singleton units, the P4/P5 identities:
     //   con = 1 vote for the fragment consensus when 2*max - tot passes the threshold (main.hpp:466-495) => cDP12, cDP21 (tot_count == 1)
     //   mmm = 2*max - tot when positive (main.hpp:497-520)                                              => cDP1
-    auto apply = [&](int st, int cs, int cc, int ct, int cs4, int cc4, int ct4, int strand, int sq, int n_cov, int n_near, bool singleton) {
-        const int dense = (cs == my_ref ? 0 : (cs == UVC_LINK_M ? 1 : -1));
+    auto apply = [&](DAcc &ar, DAcc &al, int st, int cs, int cc, int ct, int cs4, int cc4, int ct4, int strand, int sq, int n_cov, int n_near, bool singleton) {
+        const int dense = (cs == UVC_LINK_M ? 1 : (cs == my_ref ? 0 : -1));
         if (P.inferred_is_vcf_generated) {   // P3 belongs to updateByAlns3UsingBQ, skipped on FASTQ-only runs (main.hpp:3691)
         int max_qual;
         if (dense == 0) max_qual = maxq_ref; else if (dense == 1) max_qual = maxq_link;
@@ -1314,7 +1315,8 @@ __global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
         const int pbucket = imax(0, max_qual - phredlike);
         if (dense >= 0) {
             if (pbucket < NBUCKETS) atomicAdd(&hist[threadIdx.x][dense][pbucket], 1);   // ds_add_u32 without return: no read-modify-write round trip
-            bDP[strand][dense] += 1; bTA[strand][dense] += n_cov; bTB[strand][dense] += n_near; bMQ[dense] += sq;
+            if (dense == 0) { ar.bDP += 1; ar.bTA += n_cov; ar.bTB += n_near; bMQ_r += sq; }
+            else { al.bDP += 1; al.bTA += n_cov; al.bTB += n_near; bMQ_l += sq; }
         } else {
             if (pbucket < NBUCKETS) BKP(R, 0, cs, pbucket, x) += 1;
             FRP(R, strand, UVC_FRAG_bDP, cs, x) += 1; FRP(R, strand, UVC_FRAG_bTA, cs, x) += n_cov; FRP(R, strand, UVC_FRAG_bTB, cs, x) += n_near;
@@ -1324,14 +1326,13 @@ __global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
         if (singleton) {
             const int adj = imax(cc4 * 2, ct4) - ct4;
             const int thr = (st == UVC_BASE_SYMBOL ? P.fam_thres_highBQ_snv : 0);
-            if (adj >= thr && adj > 0) {
-                const int d4 = (cs4 == my_ref ? 0 : (cs4 == UVC_LINK_M ? 1 : -1));
-                if (d4 >= 0) { c12[strand][d4] += 1; c21[strand][d4] += 1; }
+            if (adj >= thr && adj > 0) {   // cDP12 == cDP21 for a singleton unit
+                if (cs4 == UVC_LINK_M) al.c12 += 1; else if (cs4 == my_ref) ar.c12 += 1;
                 else { FAP(R, strand, UVC_FAM_cDP12, cs4, x) += 1; FAP(R, strand, UVC_FAM_cDP21, cs4, x) += 1; }
             }
             const int adj5 = imax(cc * 2, ct) - ct;
             if (adj5 > 0 && P.inferred_is_vcf_generated) {
-                if (dense >= 0) c1[strand][dense] += 1; else FAP(R, strand, UVC_FAM_cDP1, cs, x) += 1;
+                if (dense == 0) ar.c1 += 1; else if (dense == 1) al.c1 += 1; else FAP(R, strand, UVC_FAM_cDP1, cs, x) += 1;
             }
         }
     };
@@ -1382,7 +1383,8 @@ __global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
                     if (bs1 < 0) { bs1 = sy; bv1 = v; } else if (sy == bs1) bv1 = imax(bv1, v); else { bs2 = sy; bv2 = v; }
                     if (p > pos1) lv = imax(lv, (int)nnminus(noindel80, nogap1) + 1);
                 }
-                if (lv > 0) apply(UVC_LINK_SYMBOL, UVC_LINK_M, lv, lv, UVC_LINK_M, lv, lv, strand, sq, n_cov, n_near, singleton);
+                if (lv > 0) { if (strand) apply(a_rr, a_rl, UVC_LINK_SYMBOL, UVC_LINK_M, lv, lv, UVC_LINK_M, lv, lv, 1, sq, n_cov, n_near, singleton);
+                              else apply(a_fr, a_fl, UVC_LINK_SYMBOL, UVC_LINK_M, lv, lv, UVC_LINK_M, lv, lv, 0, sq, n_cov, n_near, singleton); }
                 if (bs1 >= 0) {
                     int cs, cc, ct;
                     if (bs2 < 0) { cs = bs1; cc = bv1; ct = bv1; }
@@ -1394,7 +1396,8 @@ __global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
                         if (v1 == 0 && v2 == 0) { cs4 = UVC_BASE_T; cc4 = 0; }
                         else { const bool first = (v1 > v2) || (v1 == v2 && (bs2 < 0 || bs1 < bs2)); cs4 = first ? bs1 : bs2; cc4 = first ? v1 : v2; }
                     }
-                    apply(UVC_BASE_SYMBOL, cs, cc, ct, cs4, cc4, ct4, strand, sq, n_cov, n_near, singleton);
+                    if (strand) apply(a_rr, a_rl, UVC_BASE_SYMBOL, cs, cc, ct, cs4, cc4, ct4, 1, sq, n_cov, n_near, singleton);
+                    else apply(a_fr, a_fl, UVC_BASE_SYMBOL, cs, cc, ct, cs4, cc4, ct4, 0, sq, n_cov, n_near, singleton);
                 }
             } else {
                 int cnt[NSYM];
@@ -1407,22 +1410,23 @@ __global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
                     if (0 == ct) continue;
                     int cs4 = cs, cc4 = cc, ct4 = ct;
                     if (st == UVC_BASE_SYMBOL && padded_ignored) fill_consensus(cnt, cs4, cc4, ct4, st, false, true);
-                    apply(st, cs, cc, ct, cs4, cc4, ct4, strand, (f.normMQ * f.normMQ) / SQR_QUAL_DIV, f.n_cov, f.n_near, singleton);
+                    const int fsq = (f.normMQ * f.normMQ) / SQR_QUAL_DIV;
+                    if (strand) apply(a_rr, a_rl, st, cs, cc, ct, cs4, cc4, ct4, 1, fsq, f.n_cov, f.n_near, singleton);
+                    else apply(a_fr, a_fl, st, cs, cc, ct, cs4, cc4, ct4, 0, fsq, f.n_cov, f.n_near, singleton);
                 }
             }
         }
     }
     if (!valid) return;
     // flush the dense accumulators (plain read-modify-write: one writer per position in this kernel)
-    for (int d = 0; d < 2; d++) {
-        const int sym = (d == 0 ? my_ref : UVC_LINK_M);
-        for (int s = 0; s < 2; s++) {
-            if (bDP[s][d]) { FRP(R, s, UVC_FRAG_bDP, sym, x) += bDP[s][d]; FRP(R, s, UVC_FRAG_bTA, sym, x) += bTA[s][d]; FRP(R, s, UVC_FRAG_bTB, sym, x) += bTB[s][d]; }
-            if (c12[s][d]) { FAP(R, s, UVC_FAM_cDP12, sym, x) += c12[s][d]; FAP(R, s, UVC_FAM_cDP21, sym, x) += c21[s][d]; }
-            if (c1[s][d]) FAP(R, s, UVC_FAM_cDP1, sym, x) += c1[s][d];
-        }
-        if (bMQ[d]) VQP(R, UVC_VQ_bMQ, sym, x) += bMQ[d];
-    }
+    auto flush = [&](const DAcc &a, int s, int sym) {
+        if (a.bDP) { FRP(R, s, UVC_FRAG_bDP, sym, x) += a.bDP; FRP(R, s, UVC_FRAG_bTA, sym, x) += a.bTA; FRP(R, s, UVC_FRAG_bTB, sym, x) += a.bTB; }
+        if (a.c12) { FAP(R, s, UVC_FAM_cDP12, sym, x) += a.c12; FAP(R, s, UVC_FAM_cDP21, sym, x) += a.c12; }
+        if (a.c1) FAP(R, s, UVC_FAM_cDP1, sym, x) += a.c1;
+    };
+    flush(a_fr, 0, my_ref); flush(a_rr, 1, my_ref); flush(a_fl, 0, UVC_LINK_M); flush(a_rl, 1, UVC_LINK_M);
+    if (bMQ_r) VQP(R, UVC_VQ_bMQ, my_ref, x) += bMQ_r;
+    if (bMQ_l) VQP(R, UVC_VQ_bMQ, UVC_LINK_M, x) += bMQ_l;
     // P3b (main.hpp:2801-2828)
     for (int st = 0; st < 2 && P.inferred_is_vcf_generated; st++) {
         const int sb = (st == 0 ? UVC_BASE_A : UVC_LINK_M), se = (st == 0 ? UVC_BASE_NN : UVC_LINK_NN);
