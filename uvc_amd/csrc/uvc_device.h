@@ -80,6 +80,10 @@ struct FsRec {                  // family x strand unit (alns2 of main.hpp:2869)
 // arguments".  The sequential CIGAR walk (k_p2_slow<true>) only produces items; k_p2_items applies them in parallel.
 struct Item { int32_t epos; uint8_t sym, flags /* bit0 isGap, bits 1..4 cigar op */, val, pad; uint16_t dist, indel_len; int32_t pad2; };
 
+// A base of a simple alignment that differs from the reference: its P2 update goes to a non-dense symbol, so k_p2_fast
+// queues it here and k_p2_mism applies it (one lane per item).  symval = sym | value << 8.
+struct MisItem { int32_t rank, epos, symval; };
+
 // compact per-fragment record for k_frag, stored in beg-sorted order (written by k_fragstat_fast)
 struct FragFast {
     int32_t beg, end, fi, flags;        // flags: bit0 kind (1 = generic path), bit1 strand, bit2 singleton, bits 3.. number of alignments
@@ -119,6 +123,7 @@ struct RegionDev {
     const int32_t *generic_fs; int32_t n_generic_fs; int64_t n_generic_work;
     Contrib *table;
     Item *items; int32_t *item_cnt;     // per complex alignment (indexed like complex_ids)
+    MisItem *mis; int32_t *mis_cnt; int32_t mis_cap;   // mismatch queue of k_p2_fast (overflow falls back to the in-lane path)
     int32_t max_aln_span, max_frag_span;
     int32_t *err;                   // device error flag (unsupported CIGAR shapes etc.)
 };

@@ -358,6 +358,9 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
       if (hipMalloc((void **)&d, bytes) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(table)"); r->owned.push_back(d); R.table = d; r->state_bytes += 0; (void)v; }
     { Item *d = nullptr; if (hipMalloc((void **)&d, std::max<int64_t>(item_slots, 1) * sizeof(Item)) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(items)"); r->owned.push_back(d); R.items = d;
       std::vector<int32_t> z(complex_ids.size() + 1, 0); int32_t *c; if ((rc = upload(r, z, &c))) return rc; R.item_cnt = c; }
+    { const int64_t cap = std::min<int64_t>(in->n_bases / 16 + 65536, (int64_t)1 << 28);
+      MisItem *d = nullptr; if (hipMalloc((void **)&d, cap * sizeof(MisItem)) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(mismatch queue)"); r->owned.push_back(d); R.mis = d; R.mis_cap = (int32_t)cap;
+      std::vector<int32_t> z(1, 0); int32_t *c; if ((rc = upload(r, z, &c))) return rc; R.mis_cnt = c; }
     { if ((rc = upload(r, dup_units, &r->d_dup_units)) || (rc = upload(r, dup_off, &r->d_dup_off))) return rc; r->n_dup = (int)dup_units.size(); r->n_dup_work = dup_work; }
     R.max_aln_span = max_aln_span; R.max_frag_span = max_frag_span;
     r->R.n_complex = (int32_t)complex_ids.size();
@@ -379,6 +382,7 @@ int uvcgpu_region_accumulate(uvcgpu_region_t *r) {
     HIP_OK(hipMemcpyAsync(r->d_rtr, r->d_rtr0, (size_t)4 * UVC_NRTR * r->npos, hipMemcpyDeviceToDevice, r->stream));   // P1b edits indelphred in place
     HIP_OK(hipMemsetAsync(r->R.frag_nmut, 0, sizeof(int32_t) * (size_t)r->R.n_frags, r->stream));
     HIP_OK(hipMemsetAsync(r->R.n_overflow, 0, sizeof(int32_t), r->stream));
+    HIP_OK(hipMemsetAsync(r->R.mis_cnt, 0, sizeof(int32_t), r->stream));
     // the table is rebuilt by k_p2_slow<false>: MAX-merge needs empty slots
     if (r->R.n_complex) {
         // rows were set to 0xFF in set_reads and k_p2_slow<false> is idempotent under MAX, so no reset is needed

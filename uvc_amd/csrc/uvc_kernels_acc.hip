@@ -180,11 +180,19 @@ DEV void segbias(SegAcc &A, const UvcParams &P, const SegRead &r, const PosThres
     }
 }
 
-// dealwith_segbias<true> for LINK_M and dealwith_segbias<false> for the read base at the same position of a simple
-// alignment (cigar_op = M, indel_len = 0, dist_to_interfering_indel = 10000), fused: everything that does not depend on the
-// symbol is computed once, and all counters are updated branch-free.
-DEV void segbias_pair(SegAcc &AL, SegAcc &AB, const UvcParams &P, const SegRead &r, const PosThres &T, int rpos, long long baq_p, long long baq2_p,
-                      int bqL, int bqB, int xm_inc, int bm_inc, const int *amp1, const int *amp2) {
+// Lane masks.  A per-lane condition is kept as the 64-bit ballot of its compare (an SGPR pair), conditions are combined
+// on the scalar unit, and a counter takes the mask as the carry-in of one v_addc: one vector instruction per counter.
+typedef unsigned long long wmask;
+#define BAL(c) __builtin_amdgcn_ballot_w64(c)
+DEV wmask umask(bool b) { return b ? ~0ull : 0ull; }   // wave-uniform condition
+DEV void addm(int &acc, wmask m) { asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(acc) : "s"(m) : "vcc"); }
+DEV int selm(wmask m, int v) { int r; asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m)); return r; }
+
+// dealwith_segbias<true> for LINK_M (lanes with hasL) and dealwith_segbias<false> for the read base (lanes with hasB) at one
+// position of a simple alignment: cigar_op = M, indel_len = 0, dist_to_interfering_indel = 10000 (main.hpp:1360-1595).
+// Everything that does not depend on the symbol is computed once for both.
+DEV void segbias_simple(SegAcc &AL, SegAcc &AB, const UvcParams &P, const SegRead &r, const PosThres &T, int rpos, long long baq_p, long long baq2_p,
+                        bool hasL, bool hasB, int bqL, int bqB, int xm_inc, int bm_inc, const int *amp1, const int *amp2) {
     const bool amplicon = ((r.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag)));
     const bool normal_filter_primers = (P.tn_is_paired && (0x1 & P.primer_flag));
     const bool is_assay_UMI = (r.dflag & 0x1);
@@ -194,88 +202,79 @@ DEV void segbias_pair(SegAcc &AL, SegAcc &AB, const UvcParams &P, const SegRead 
     const bool mate_ok = ((0 == (r.flag & 0x8)) || (0 == (r.flag & 0x1)));
     const bool hrl = (P.central_readlen >= P.microadjust_median_readlen_thres);
     const int l_nb = rpos - r.pos + 1, r_nb = r.rend - rpos;
-    const int l_baq1 = (int)(baq_p - r.baq_pos + 1);
-    const int r_baq1B = (int)(r.baq_last - baq_p + 1);
-    const int r_baq1L = (int)lmin((long long)r_baq1B, r.baq2_last - baq2_p + 7);
+    // differences of BAQ prefix sums: truncation to 32 bits commutes with the subtraction
+    const int l_baq1 = (int)((unsigned)baq_p - (unsigned)r.baq_pos + 1u);
+    const int r_baq1B = (int)((unsigned)r.baq_last - (unsigned)baq_p + 1u);
+    const int r_baq1L = imin(r_baq1B, (int)((unsigned)r.baq2_last - (unsigned)baq2_p + 7u));
     const int kb = P.microadjust_BAQ_per_base_x1024;
     const int l_baq = (hrl ? l_baq1 : imax(l_baq1, l_nb * kb / 1024));
     const int r_baqB = (hrl ? r_baq1B : imax(r_baq1B, r_nb * kb / 1024));
     const int r_baqL = (hrl ? r_baq1L : imax(r_baq1L, r_nb * kb / 1024));
-    const int fl2 = ((r.isize != 0) ? imin(rpos - r.frag_pos_L + 1, MAX_INSERT_SIZE) : MAX_INSERT_SIZE);
-    const int fr2 = ((r.isize != 0) ? imin(r.frag_pos_R - rpos, MAX_INSERT_SIZE) : MAX_INSERT_SIZE);
-    // symbol-independent increments
-    const int ff = (!strand && !isrc), fr = (!strand && isrc), rf = (strand && !isrc), rr = (strand && isrc);
-    const int p3 = (imin(10000, imin(l_nb, r_nb)) >= P.bias_thres_interfering_indel);
-    const int nc = (0 == r.clip_cnt);
-    const long long lit = (isrc && r.isize != 0) ? fl2 : 0, rit = (!isrc && r.isize != 0) ? fr2 : 0;
-    const int p2 = (is_assay_UMI || !amplicon);
-    AL.s[UVC_S_aMQs] += r.mapq; AB.s[UVC_S_aMQs] += r.mapq;
-    AL.s[UVC_S_aDPff] += ff; AL.s[UVC_S_aDPfr] += fr; AL.s[UVC_S_aDPrf] += rf; AL.s[UVC_S_aDPrr] += rr;
-    AB.s[UVC_S_aDPff] += ff; AB.s[UVC_S_aDPfr] += fr; AB.s[UVC_S_aDPrf] += rf; AB.s[UVC_S_aDPrr] += rr;
-    AL.s[UVC_S_aP3] += p3; AB.s[UVC_S_aP3] += p3; AL.s[UVC_S_aNC] += nc; AB.s[UVC_S_aNC] += nc;
-    AL.l[UVC_S64_aLIT] += lit; AB.l[UVC_S64_aLIT] += lit; AL.l[UVC_S64_aRIT] += rit; AB.l[UVC_S64_aRIT] += rit;
-    AL.s[UVC_S_aP2] += p2; AB.s[UVC_S_aP2] += p2;
-    // base-quality sums
-    if (isrc) { AL.a1BQr += bqL; AL.a2BQr += bqL * bqL / SQR_QUAL_DIV; AB.a1BQr += bqB; AB.a2BQr += bqB * bqB / SQR_QUAL_DIV; }
-    else      { AL.a1BQf += bqL; AL.a2BQf += bqL * bqL / SQR_QUAL_DIV; AB.a1BQf += bqB; AB.a2BQf += bqB * bqB / SQR_QUAL_DIV; }
-    // edge tests
+    const bool has_isize = (r.isize != 0);
+    const int fl2 = (has_isize ? imin(rpos - r.frag_pos_L + 1, MAX_INSERT_SIZE) : MAX_INSERT_SIZE);
+    const int fr2 = (has_isize ? imin(r.frag_pos_R - rpos, MAX_INSERT_SIZE) : MAX_INSERT_SIZE);
+    // masks
+    const wmask m_p3 = BAL(imin(10000, imin(l_nb, r_nb)) >= P.bias_thres_interfering_indel);
     const int LPxT_L = T.t[UVC_T_aLPxT], RPxT = T.t[UVC_T_aRPxT], LPxT_B = imin(LPxT_L, RPxT);
-    const bool farL = (l_nb >= LPxT_L) && (r_nb >= RPxT), farB = (l_nb >= LPxT_B) && (r_nb >= RPxT);
-    const bool unaffL = (l_baq >= P.bias_thres_highBAQ && r_baqL >= P.bias_thres_highBAQ);
-    const bool unaffB = (l_baq >= P.bias_thres_highBAQ + 3 && r_baqB >= P.bias_thres_highBAQ + 3);
+    const wmask m_rfar = BAL(r_nb >= RPxT);
+    const wmask m_farL = BAL(l_nb >= LPxT_L) & m_rfar, m_farB = BAL(l_nb >= LPxT_B) & m_rfar;
+    const int hb = P.bias_thres_highBAQ;
+    const wmask m_unaffL = BAL(l_baq >= hb) & BAL(r_baqL >= hb), m_unaffB = BAL(l_baq >= hb + 3) & BAL(r_baqB >= hb + 3);
     const int min_dist2iend = ((r.flag & 0x1) ? imin(fl2, fr2) : (isrc ? r_nb : l_nb));
-    const bool iend_ok = (min_dist2iend > P.primerlen2 || !amplicon);
-    AL.s[UVC_S_aP1] += (farL && unaffL && iend_ok); AB.s[UVC_S_aP1] += (farB && unaffB && iend_ok);
-    // passing-filter sums
-    // amp1[v] / amp2[v] = (v < PFBQ ? 100 v^2 / PFBQ^2 : 100), tabulated per block (main.hpp:1472-1519); "100 * amp / 100" == amp
-    AL.s[UVC_S_aPF1] += imin(100, amp1[bqL]); AL.s[UVC_S_aPF2] += imin(100, amp2[bqL]);
-    AB.s[UVC_S_aPF1] += amp1[bqB]; AB.s[UVC_S_aPF2] += amp2[bqB];
-    AB.s[UVC_S_a2XM2] += xm_inc; AB.s[UVC_S_a2BM2] += bm_inc;
-    // position / BAQ bias blocks: gap side enters when 10000 >= bias_thres_interfering_indel, base side when bq >= highBQ (tier2 then holds)
-    const bool inL = (10000 >= P.bias_thres_interfering_indel), inB = (bqB >= P.bias_thres_highBQ);
-    {
-        const bool a = inL && farL;
-        AL.s[UVC_S_aLP1] += (a && l_nb >= T.t[UVC_T_aLP1t]); AL.s[UVC_S_aLP2] += (a && l_nb >= T.t[UVC_T_aLP2t]);
-        AL.s[UVC_S_aRP1] += (a && r_nb >= T.t[UVC_T_aRP1t]); AL.s[UVC_S_aRP2] += (a && r_nb >= T.t[UVC_T_aRP2t]);
-        AL.s[UVC_S_aLPL] += a ? l_nb : 0; AL.s[UVC_S_aRPL] += a ? r_nb : 0;
-        const bool b = inL && unaffL;
-        AL.s[UVC_S_aLB1] += (b && l_baq >= P.bias_thres_BAQ1); AL.s[UVC_S_aLB2] += (b && l_baq >= P.bias_thres_BAQ2);
-        AL.s[UVC_S_aRB1] += (b && r_baqL >= P.bias_thres_BAQ1); AL.s[UVC_S_aRB2] += (b && r_baqL >= P.bias_thres_BAQ2);
-        AL.l[UVC_S64_aLBL] += b ? l_baq : 0; AL.l[UVC_S64_aRBL] += b ? r_baqL : 0;
-        AL.s[UVC_S_aBQ2] += inL;
-    }
-    {
-        const bool a = inB && farB;
-        AB.s[UVC_S_aLP1] += (a && l_nb >= T.t[UVC_T_aLP1t]); AB.s[UVC_S_aLP2] += (a && l_nb >= T.t[UVC_T_aLP2t]);
-        AB.s[UVC_S_aRP1] += (a && r_nb >= T.t[UVC_T_aRP1t]); AB.s[UVC_S_aRP2] += (a && r_nb >= T.t[UVC_T_aRP2t]);
-        AB.s[UVC_S_aLPL] += a ? l_nb : 0; AB.s[UVC_S_aRPL] += a ? r_nb : 0;
-        const bool b = inB && unaffB;
-        AB.s[UVC_S_aLB1] += (b && l_baq >= P.bias_thres_BAQ1); AB.s[UVC_S_aLB2] += (b && l_baq >= P.bias_thres_BAQ2);
-        AB.s[UVC_S_aRB1] += (b && r_baqB >= P.bias_thres_BAQ1); AB.s[UVC_S_aRB2] += (b && r_baqB >= P.bias_thres_BAQ2);
-        AB.l[UVC_S64_aLBL] += b ? l_baq : 0; AB.l[UVC_S64_aRBL] += b ? r_baqB : 0;
-        AB.s[UVC_S_aBQ2] += inB;
-    }
-    // insert-end bias
-    const bool l_nonbiased = (mate_ok && l_nb > r_nb), r_nonbiased = (mate_ok && l_nb < r_nb);
-    const bool goodL = ((!amplicon) || (!normal_filter_primers) || (farL && unaffL)), goodB = ((!amplicon) || (!normal_filter_primers) || (farB && unaffB));
+    const wmask m_iend = umask(!amplicon) | BAL(min_dist2iend > P.primerlen2);
+    const wmask m_lp1 = BAL(l_nb >= T.t[UVC_T_aLP1t]), m_lp2 = BAL(l_nb >= T.t[UVC_T_aLP2t]);
+    const wmask m_rp1 = BAL(r_nb >= T.t[UVC_T_aRP1t]), m_rp2 = BAL(r_nb >= T.t[UVC_T_aRP2t]);
+    const wmask m_lb1 = BAL(l_baq >= P.bias_thres_BAQ1), m_lb2 = BAL(l_baq >= P.bias_thres_BAQ2);
+    const wmask m_goodU = umask((!amplicon) || (!normal_filter_primers));
+    const wmask m_goodL = m_goodU | (m_farL & m_unaffL), m_goodB = m_goodU | (m_farB & m_unaffB);
+    // insert-end thresholds of this read's direction
+    const int d = (isrc ? fl2 : fr2);
+    wmask m_i1lo, m_i1hi, m_i2lo, m_i2hi, m_nonb;
     if (isrc) {
-        const int d = fl2;
-        const bool okL = (is_normal || l_nonbiased), okB = is_normal;
-        AL.s[UVC_S_aLI1] += ((d >= T.t[UVC_T_aLI1t]) && okL);
-        AL.s[UVC_S_aLI2] += ((d >= T.t[UVC_T_aLI2t]) && okL && goodL);
-        AL.s[UVC_S_aLIr] += goodL;
-        AB.s[UVC_S_aLI1] += ((d >= T.t[UVC_T_aLI1t]) && (d <= T.t[UVC_T_aLI1T]) && okB);
-        AB.s[UVC_S_aLI2] += ((d >= T.t[UVC_T_aLI2t]) && (d <= T.t[UVC_T_aLI2T]) && okB && goodB);
-        AB.s[UVC_S_aLIr] += goodB;
+        m_i1lo = BAL(d >= T.t[UVC_T_aLI1t]); m_i1hi = BAL(d <= T.t[UVC_T_aLI1T]); m_i2lo = BAL(d >= T.t[UVC_T_aLI2t]); m_i2hi = BAL(d <= T.t[UVC_T_aLI2T]);
+        m_nonb = BAL(l_nb > r_nb);
     } else {
-        const int d = fr2;
-        const bool okL = (is_normal || r_nonbiased), okB = is_normal;
-        AL.s[UVC_S_aRI1] += ((d >= T.t[UVC_T_aRI1t]) && okL);
-        AL.s[UVC_S_aRI2] += ((d >= T.t[UVC_T_aRI2t]) && okL && goodL);
-        AL.s[UVC_S_aRIf] += goodL;
-        AB.s[UVC_S_aRI1] += ((d >= T.t[UVC_T_aRI1t]) && (d <= T.t[UVC_T_aRI1T]) && okB);
-        AB.s[UVC_S_aRI2] += ((d >= T.t[UVC_T_aRI2t]) && (d <= T.t[UVC_T_aRI2T]) && okB && goodB);
-        AB.s[UVC_S_aRIf] += goodB;
+        m_i1lo = BAL(d >= T.t[UVC_T_aRI1t]); m_i1hi = BAL(d <= T.t[UVC_T_aRI1T]); m_i2lo = BAL(d >= T.t[UVC_T_aRI2t]); m_i2hi = BAL(d <= T.t[UVC_T_aRI2T]);
+        m_nonb = BAL(l_nb < r_nb);
+    }
+    const wmask m_okB = umask(is_normal), m_okL = m_okB | (umask(mate_ok) & m_nonb);
+    const int p2 = (is_assay_UMI || !amplicon), nc = (0 == r.clip_cnt);
+    auto common = [&](SegAcc &A, int bq) {
+        if (isrc) { A.a1BQr += bq; A.a2BQr += bq * bq / SQR_QUAL_DIV; } else { A.a1BQf += bq; A.a2BQf += bq * bq / SQR_QUAL_DIV; }
+        A.bq += bq;
+        A.s[UVC_S_aMQs] += r.mapq;
+        if (strand) { if (isrc) A.s[UVC_S_aDPrr] += 1; else A.s[UVC_S_aDPrf] += 1; }
+        else        { if (isrc) A.s[UVC_S_aDPfr] += 1; else A.s[UVC_S_aDPff] += 1; }
+        addm(A.s[UVC_S_aP3], m_p3);
+        A.s[UVC_S_aNC] += nc; A.s[UVC_S_aP2] += p2;
+        if (has_isize) { if (isrc) A.l[UVC_S64_aLIT] += (long long)fl2; else A.l[UVC_S64_aRIT] += (long long)fr2; }
+    };
+    auto bias = [&](SegAcc &A, bool in_all, wmask in, wmask far, wmask unaff, wmask m_rb1, wmask m_rb2, int r_baq) {
+        const wmask a = (in_all ? far : (in & far)), b = (in_all ? unaff : (in & unaff));
+        addm(A.s[UVC_S_aLP1], a & m_lp1); addm(A.s[UVC_S_aLP2], a & m_lp2); addm(A.s[UVC_S_aRP1], a & m_rp1); addm(A.s[UVC_S_aRP2], a & m_rp2);
+        A.s[UVC_S_aLPL] += selm(a, l_nb); A.s[UVC_S_aRPL] += selm(a, r_nb);
+        addm(A.s[UVC_S_aLB1], b & m_lb1); addm(A.s[UVC_S_aLB2], b & m_lb2); addm(A.s[UVC_S_aRB1], b & m_rb1); addm(A.s[UVC_S_aRB2], b & m_rb2);
+        A.l[UVC_S64_aLBL] += (long long)selm(b, l_baq); A.l[UVC_S64_aRBL] += (long long)selm(b, r_baq);
+        if (in_all) A.s[UVC_S_aBQ2] += 1; else addm(A.s[UVC_S_aBQ2], in);
+        addm(A.s[UVC_S_aP1], far & unaff & m_iend);
+    };
+    if (hasB) {
+        common(AB, bqB);
+        AB.s[UVC_S_aPF1] += amp1[imin(bqB, 255)]; AB.s[UVC_S_aPF2] += amp2[imin(bqB, 255)];   // "100 * amp / 100" == amp (main.hpp:1472-1519)
+        AB.s[UVC_S_a2XM2] += xm_inc; AB.s[UVC_S_a2BM2] += bm_inc;
+        // the base side enters the bias blocks when bq >= highBQ (tier2 then holds)
+        bias(AB, false, BAL(bqB >= P.bias_thres_highBQ), m_farB, m_unaffB, BAL(r_baqB >= P.bias_thres_BAQ1), BAL(r_baqB >= P.bias_thres_BAQ2), r_baqB);
+        if (isrc) { addm(AB.s[UVC_S_aLI1], m_i1lo & m_i1hi & m_okB); addm(AB.s[UVC_S_aLI2], m_i2lo & m_i2hi & m_okB & m_goodB); addm(AB.s[UVC_S_aLIr], m_goodB); }
+        else      { addm(AB.s[UVC_S_aRI1], m_i1lo & m_i1hi & m_okB); addm(AB.s[UVC_S_aRI2], m_i2lo & m_i2hi & m_okB & m_goodB); addm(AB.s[UVC_S_aRIf], m_goodB); }
+    }
+    if (hasL) {
+        common(AL, bqL);
+        AL.s[UVC_S_aPF1] += imin(100, amp1[bqL]); AL.s[UVC_S_aPF2] += imin(100, amp2[bqL]);
+        // the gap side enters when dist_to_interfering_indel (10000) >= bias_thres_interfering_indel
+        if (10000 >= P.bias_thres_interfering_indel) bias(AL, true, 0, m_farL, m_unaffL, BAL(r_baqL >= P.bias_thres_BAQ1), BAL(r_baqL >= P.bias_thres_BAQ2), r_baqL);
+        else addm(AL.s[UVC_S_aP1], m_farL & m_unaffL & m_iend);
+        if (isrc) { addm(AL.s[UVC_S_aLI1], m_i1lo & m_okL); addm(AL.s[UVC_S_aLI2], m_i2lo & m_okL & m_goodL); addm(AL.s[UVC_S_aLIr], m_goodL); }
+        else      { addm(AL.s[UVC_S_aRI1], m_i1lo & m_okL); addm(AL.s[UVC_S_aRI2], m_i2lo & m_okL & m_goodL); addm(AL.s[UVC_S_aRIf], m_goodL); }
     }
 }
 
@@ -710,11 +709,28 @@ DEV int simple_base_value(const UvcParams &P, const AlnRec &a, int p, const uint
     return q + P.bq_phred_added_misma;
 }
 
+// one queued mismatching base of a simple alignment: dealwith_segbias<false> into a scratch record, flushed with atomics
+DEV void mis_apply(const RegionDev &R, const UvcParams &P, const MisItem &it) {
+    const int64_t x = it.epos - R.beg;
+    const int sym = it.symval & 0xFF, inc = it.symval >> 8;
+    if ((unsigned)it.rank >= (unsigned)R.n_fast || x < 0 || x >= R.npos || sym > UVC_BASE_NN) { atomicExch(R.err, UVCGPU_EDEVICE); return; }   // corrupt queue entry
+    const AlnRec &a = R.fast[it.rank];
+    const SegRead sr = make_segread(R, a);
+    PosThres T;
+    load_thres(R, T, x);
+    SegAcc A; A.zero();
+    A.bq = inc;
+    segbias<false>(A, P, sr, T, it.epos, R.baq[x], R.baq[R.npos + x], inc, a.bm1500[sym], C_MATCH, 0, 10000);
+    seg_flush(R, A, sym, x);
+}
+
+#define MISQ_CAP 192   // per-wave LDS queue of mismatching bases (flushed to the global queue when fewer than 64 slots are left)
 // ------------------------------------------------------------------------------------------------
 // P2 fast: updateByAln<SYMBOL_COUNT_SUM, bias> for simple alignments, one lane per position
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
     __shared__ int amp1[256], amp2[256];
+    __shared__ MisItem misq[4][MISQ_CAP];
     {
         const int v = threadIdx.x;
         amp1[v] = (v < P.bias_thres_PFBQ1 ? 100 * (v * v) / (P.bias_thres_PFBQ1 * P.bias_thres_PFBQ1) : 100);
@@ -743,6 +759,18 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
     if (valid && x > 0) noindel80 = imin(80, imin(RTRP(R, UVC_RTR_indelphred, x - 1), RTRP(R, UVC_RTR_indelphred, x)));
     const int lo = wave_uniform(lower_bound_frec(R.frec, R.n_fast, w0 - R.max_aln_span + 1));
     const int hi = wave_uniform(lower_bound_frec(R.frec, R.n_fast, w0 + 64));
+    MisItem *myq = misq[threadIdx.x >> 6];
+    int nq = 0;   // wave-uniform: only updated in uniform control flow
+    auto flush_queue = [&]() {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(R.mis_cnt, nq);
+        base = wave_uniform(base);
+        for (int i = lane; i < nq; i += 64) {
+            if (base + i < R.mis_cap) R.mis[base + i] = myq[i];
+            else mis_apply(R, P, myq[i]);   // global queue full: apply in place
+        }
+        nq = 0;
+    };
     for (int k0 = lo; k0 < hi; k0 += 64) {
         Chunk16 c;
         load_chunk16(R.frec, k0 + lane, hi, c);
@@ -779,39 +807,42 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
                 const int iend = ((sr.isize != 0) ? (int)nnminus(sr.frag_pos_L + abs(sr.isize), P.primerlen) : ((isrc && (0x0 == (0x1 & sr.flag))) ? (int)nnminus(rend, P.primerlen) : INT32_MAX));
                 gate = (ibeg <= p && p < iend);
             }
-            if (!(valid && p >= apos && p < rend && gate)) continue;
-            const int bmv = bcast(c.v[8], j), xbv = bcast(c.v[9], j);
-            const int bm_inc = (sym < 4 ? ((bmv >> (8 * sym)) & 0xFF) : (xbv & 0xFF)), xm_inc = (xbv >> 8) & 0xFF;
-            int inc, incL;
+            // the queue bookkeeping below must run in wave-uniform control flow (nq is a scalar): no divergent `continue` before it
+            const bool cover = (valid && p >= apos && p < rend && gate);
+            const bool hasL = (p > apos), hasB = (sym == my_ref);
+            int inc = 0, incL = 0;
             if (proton) {   // IonTorrent values need neighbouring qualities and clip lengths: take them from the full record
-                const AlnRec &a = R.fast[k0 + j];
-                inc = simple_base_value(P, a, p, R.quals + a.qbase, true);
-                incL = (p > apos ? simple_link_value(R, P, a, p, R.quals + a.qbase, true) : 0);
+                if (cover) {
+                    const AlnRec &a = R.fast[k0 + j];
+                    inc = simple_base_value(P, a, p, R.quals + a.qbase, true);
+                    incL = (p > apos ? simple_link_value(R, P, a, p, R.quals + a.qbase, true) : 0);
+                }
             } else { inc = q + P.bq_phred_added_misma; incL = (int)nnminus(noindel80, nogap) + 1; }
-            if (p > apos && sym == my_ref) {   // the common case: both updates go to the two dense records
-                Alink.bq += incL; Aref.bq += inc;
-                segbias_pair(Alink, Aref, P, sr, T, p, baq_p, baq2_p, incL, imin(inc, 255), xm_inc, bm_inc, amp1, amp2);
-                continue;
+            const wmask mm = BAL(cover && !hasB);
+            if (mm) {   // bases that differ from the reference go to the wave's queue; k_p2_mism applies them
+                if (nq > MISQ_CAP - 64) flush_queue();
+                if (cover && !hasB) { MisItem it; it.rank = k0 + j; it.epos = p; it.symval = sym | (inc << 8); myq[nq + (int)__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = it; }
+                nq += (int)__builtin_popcountll(mm);
             }
-            if (p > apos) {
-                Alink.bq += incL;
-                segbias<true>(Alink, P, sr, T, p, baq_p, baq2_p, incL, 0, C_MATCH, 0, 10000);
-            }
-            const int bmS = R.fast[k0 + j].bm1500[sym];   // uncommon paths (first base of the read, mismatching base): full record
-            if (sym == my_ref) {
-                Aref.bq += inc;
-                segbias<false>(Aref, P, sr, T, p, baq_p, baq2_p, inc, bmS, C_MATCH, 0, 10000);
-            } else {
-                SegAcc A; A.zero();
-                A.bq = inc;
-                segbias<false>(A, P, sr, T, p, baq_p, baq2_p, inc, bmS, C_MATCH, 0, 10000);
-                seg_flush(R, A, sym, x);
+            if (cover) {
+                const int bmv = bcast(c.v[8], j), xbv = bcast(c.v[9], j);
+                const int bm_inc = (sym < 4 ? ((bmv >> (8 * sym)) & 0xFF) : (xbv & 0xFF)), xm_inc = (xbv >> 8) & 0xFF;
+                segbias_simple(Alink, Aref, P, sr, T, p, baq_p, baq2_p, hasL, hasB, incL, inc, xm_inc, bm_inc, amp1, amp2);
             }
         }
     }
+    if (nq > 0) flush_queue();
     if (!valid) return;
     seg_flush(R, Aref, my_ref, x);
     seg_flush(R, Alink, UVC_LINK_M, x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_p2_mism: the queued mismatching bases of simple alignments, one lane per item
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_p2_mism(RegionDev R, UvcParams P) {
+    const int n = imin(*R.mis_cnt, R.mis_cap);
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) mis_apply(R, P, R.mis[t]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1259,7 +1290,7 @@ __global__ void __launch_bounds__(256) k_fragstat_fast(RegionDev R, UvcParams P)
 // position; per-lane bucket histograms of the two dense symbols live in LDS, rare symbols use the
 // global bucket plane (each position has exactly one writer in this kernel).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4,4))) k_frag(RegionDev R, UvcParams P) {
     __shared__ int hist[256][2][NBUCKETS + 1];   // +1 pad: bank spread
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
@@ -1733,6 +1764,7 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
         if (R->n_complex) TIMED(prof, "k_prep_slow", hipLaunchKernelGGL(k_prep_slow, dim3(R->n_complex), dim3(64), 0, s, *R, *P));
         TIMED(prof, "k_thres", hipLaunchKernelGGL(k_thres, dim3(nblk(R->npos, 256)), dim3(256), 0, s, *R, *P, half_ratio_phred));
         TIMED(prof, "k_p2_fast", hipLaunchKernelGGL(k_p2_fast, dim3(nwin), dim3(256), 0, s, *R, *P));
+        TIMED(prof, "k_p2_mism", hipLaunchKernelGGL(k_p2_mism, dim3(2048), dim3(256), 0, s, *R, *P));
         if (R->n_complex) {
             TIMED(prof, "k_p2_slow_walk", hipLaunchKernelGGL(k_p2_slow<true>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
             TIMED(prof, "k_p2_items", hipLaunchKernelGGL(k_p2_items, dim3(R->n_complex), dim3(64), 0, s, *R, *P));
