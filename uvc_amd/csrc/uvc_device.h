@@ -123,7 +123,8 @@ struct RegionDev {
     const int32_t *generic_fs; int32_t n_generic_fs; int64_t n_generic_work;
     Contrib *table;
     Item *items; int32_t *item_cnt;     // per complex alignment (indexed like complex_ids)
-    MisItem *mis; int32_t *mis_cnt; int32_t mis_cap;   // mismatch queue of k_p2_fast (overflow falls back to the in-lane path)
+    MisItem *mis; int32_t *mis_cnt; int32_t mis_cap;   // mismatch queue of k_p2_fast, sized from the exact count below
+    unsigned long long *mis_total;  // number of read bases of simple alignments that differ from the reference (k_aln_prelude)
     int32_t max_aln_span, max_frag_span;
     int32_t *err;                   // device error flag (unsupported CIGAR shapes etc.)
 };

@@ -358,9 +358,7 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
       if (hipMalloc((void **)&d, bytes) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(table)"); r->owned.push_back(d); R.table = d; r->state_bytes += 0; (void)v; }
     { Item *d = nullptr; if (hipMalloc((void **)&d, std::max<int64_t>(item_slots, 1) * sizeof(Item)) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(items)"); r->owned.push_back(d); R.items = d;
       std::vector<int32_t> z(complex_ids.size() + 1, 0); int32_t *c; if ((rc = upload(r, z, &c))) return rc; R.item_cnt = c; }
-    { const int64_t cap = std::min<int64_t>(in->n_bases / 16 + 65536, (int64_t)1 << 28);
-      MisItem *d = nullptr; if (hipMalloc((void **)&d, cap * sizeof(MisItem)) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(mismatch queue)"); r->owned.push_back(d); R.mis = d; R.mis_cap = (int32_t)cap;
-      std::vector<int32_t> z(1, 0); int32_t *c; if ((rc = upload(r, z, &c))) return rc; R.mis_cnt = c; }
+    { std::vector<int32_t> z(4, 0); int32_t *c; if ((rc = upload(r, z, &c))) return rc; R.mis_cnt = c; R.mis_total = (unsigned long long *)(c + 2); R.mis = nullptr; R.mis_cap = 0; }
     { if ((rc = upload(r, dup_units, &r->d_dup_units)) || (rc = upload(r, dup_off, &r->d_dup_off))) return rc; r->n_dup = (int)dup_units.size(); r->n_dup_work = dup_work; }
     R.max_aln_span = max_aln_span; R.max_frag_span = max_frag_span;
     r->R.n_complex = (int32_t)complex_ids.size();
@@ -369,6 +367,14 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     uvc_launch_prelude(&R, &W, &r->P, r->stream);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(r->stream));   // the staging vectors above die here
+    {   // the queue of mismatching bases (k_p2_fast -> k_p2_mism) is sized from the count the prelude made
+        unsigned long long total = 0;
+        HIP_OK(hipMemcpy(&total, R.mis_total, sizeof(total), hipMemcpyDeviceToHost));
+        if (total > ((unsigned long long)1 << 30)) return fail(UVCGPU_EUNSUPPORTED, "more than 2^30 mismatching bases in one region");
+        MisItem *d = nullptr;
+        if (hipMalloc((void **)&d, (size_t)(total + 64) * sizeof(MisItem)) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(mismatch queue)");
+        r->owned.push_back(d); R.mis = d; R.mis_cap = (int32_t)(total + 64);
+    }
     r->has_reads = true;
     return 0;
 }

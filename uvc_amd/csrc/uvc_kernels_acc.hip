@@ -347,6 +347,8 @@ __global__ void __launch_bounds__(256) k_aln_prelude(RegionDev R, RawReads W, Uv
     R.alns[id] = a;
     const int rk = W.fast_rank[id];
     if (rk >= 0) {
+        const int n_mis = bm[0] + bm[1] + bm[2] + bm[3] + bm[4];
+        if (n_mis) atomicAdd(R.mis_total, (unsigned long long)n_mis);
         R.fast[rk] = a;
         FastRec f;
         f.pos = a.pos; f.rend = a.rend; f.qb_lo = (int32_t)(a.qbase & 0xFFFFFFFFLL); f.qb_hi = (int32_t)(a.qbase >> 32);
@@ -728,9 +730,12 @@ DEV void mis_apply(const RegionDev &R, const UvcParams &P, const MisItem &it) {
 // ------------------------------------------------------------------------------------------------
 // P2 fast: updateByAln<SYMBOL_COUNT_SUM, bias> for simple alignments, one lane per position
 // ------------------------------------------------------------------------------------------------
+// Two instantiations, <true,false> for LINK_M and <false,true> for the read bases: each keeps one SegAcc in registers,
+// which halves the accumulator footprint and doubles the waves per SIMD.
+template <bool DO_L, bool DO_B>
 __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
     __shared__ int amp1[256], amp2[256];
-    __shared__ MisItem misq[4][MISQ_CAP];
+    __shared__ MisItem misq[DO_B ? 4 : 1][DO_B ? MISQ_CAP : 1];
     {
         const int v = threadIdx.x;
         amp1[v] = (v < P.bias_thres_PFBQ1 ? 100 * (v * v) / (P.bias_thres_PFBQ1 * P.bias_thres_PFBQ1) : 100);
@@ -752,14 +757,14 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
     long long baq_p = 0, baq2_p = 0;
     if (valid) { load_thres(R, T, x); baq_p = R.baq[x]; baq2_p = R.baq[R.npos + x]; }
     else { for (int f = 0; f < UVC_NTHRES; f++) T.t[f] = 0; }
-    SegAcc Aref, Alink;
+    SegAcc Aref, Alink;   // only the one selected by the template arguments stays live
     Aref.zero(); Alink.zero();
     // LINK_M value of a simple read at this position is a per-position constant up to the read's penalty (main.hpp:1919-1923)
     int noindel80 = 80;
-    if (valid && x > 0) noindel80 = imin(80, imin(RTRP(R, UVC_RTR_indelphred, x - 1), RTRP(R, UVC_RTR_indelphred, x)));
+    if (DO_L && valid && x > 0) noindel80 = imin(80, imin(RTRP(R, UVC_RTR_indelphred, x - 1), RTRP(R, UVC_RTR_indelphred, x)));
     const int lo = wave_uniform(lower_bound_frec(R.frec, R.n_fast, w0 - R.max_aln_span + 1));
     const int hi = wave_uniform(lower_bound_frec(R.frec, R.n_fast, w0 + 64));
-    MisItem *myq = misq[threadIdx.x >> 6];
+    MisItem *myq = misq[DO_B ? (threadIdx.x >> 6) : 0];
     int nq = 0;   // wave-uniform: only updated in uniform control flow
     auto flush_queue = [&]() {
         int base = 0;
@@ -767,7 +772,7 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
         base = wave_uniform(base);
         for (int i = lane; i < nq; i += 64) {
             if (base + i < R.mis_cap) R.mis[base + i] = myq[i];
-            else mis_apply(R, P, myq[i]);   // global queue full: apply in place
+            else atomicExch(R.err, UVCGPU_EDEVICE);   // cannot happen: the queue holds every mismatching base of the simple alignments
         }
         nq = 0;
     };
@@ -782,10 +787,10 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
             const long long at = qb + ((valid && p >= pos && p < rend) ? p : pos);
             bn = R.bases[at]; qn = R.quals[at];
         };
-        issue(0);
+        if (DO_B) issue(0);
         for (int j = 0; j < n; j++) {
             const int sym = bn, q = qn;
-            if (j + 1 < n) issue(j + 1);
+            if (DO_B && j + 1 < n) issue(j + 1);
             const int apos = bcast(c.v[0], j), rend = bcast(c.v[1], j);
             if (rend <= w0) continue;
             const int fmd = bcast(c.v[4], j);
@@ -809,17 +814,17 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
             }
             // the queue bookkeeping below must run in wave-uniform control flow (nq is a scalar): no divergent `continue` before it
             const bool cover = (valid && p >= apos && p < rend && gate);
-            const bool hasL = (p > apos), hasB = (sym == my_ref);
+            const bool hasL = DO_L && (p > apos), hasB = DO_B && (sym == my_ref);
             int inc = 0, incL = 0;
             if (proton) {   // IonTorrent values need neighbouring qualities and clip lengths: take them from the full record
                 if (cover) {
                     const AlnRec &a = R.fast[k0 + j];
-                    inc = simple_base_value(P, a, p, R.quals + a.qbase, true);
-                    incL = (p > apos ? simple_link_value(R, P, a, p, R.quals + a.qbase, true) : 0);
+                    if (DO_B) inc = simple_base_value(P, a, p, R.quals + a.qbase, true);
+                    if (DO_L) incL = (p > apos ? simple_link_value(R, P, a, p, R.quals + a.qbase, true) : 0);
                 }
             } else { inc = q + P.bq_phred_added_misma; incL = (int)nnminus(noindel80, nogap) + 1; }
-            const wmask mm = BAL(cover && !hasB);
-            if (mm) {   // bases that differ from the reference go to the wave's queue; k_p2_mism applies them
+            const wmask mm = DO_B ? BAL(cover && !hasB) : 0ull;
+            if (DO_B && mm) {   // bases that differ from the reference go to the wave's queue; k_p2_mism applies them
                 if (nq > MISQ_CAP - 64) flush_queue();
                 if (cover && !hasB) { MisItem it; it.rank = k0 + j; it.epos = p; it.symval = sym | (inc << 8); myq[nq + (int)__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = it; }
                 nq += (int)__builtin_popcountll(mm);
@@ -831,10 +836,10 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
             }
         }
     }
-    if (nq > 0) flush_queue();
+    if (DO_B && nq > 0) flush_queue();
     if (!valid) return;
-    seg_flush(R, Aref, my_ref, x);
-    seg_flush(R, Alink, UVC_LINK_M, x);
+    if (DO_B) seg_flush(R, Aref, my_ref, x);
+    if (DO_L) seg_flush(R, Alink, UVC_LINK_M, x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1763,7 +1768,8 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
         TIMED(prof, "k_prep_fast", hipLaunchKernelGGL(k_prep_fast, dim3(nwin), dim3(256), 0, s, *R, *P));
         if (R->n_complex) TIMED(prof, "k_prep_slow", hipLaunchKernelGGL(k_prep_slow, dim3(R->n_complex), dim3(64), 0, s, *R, *P));
         TIMED(prof, "k_thres", hipLaunchKernelGGL(k_thres, dim3(nblk(R->npos, 256)), dim3(256), 0, s, *R, *P, half_ratio_phred));
-        TIMED(prof, "k_p2_fast", hipLaunchKernelGGL(k_p2_fast, dim3(nwin), dim3(256), 0, s, *R, *P));
+        TIMED(prof, "k_p2_fast_link", hipLaunchKernelGGL((k_p2_fast<true, false>), dim3(nwin), dim3(256), 0, s, *R, *P));
+        TIMED(prof, "k_p2_fast_base", hipLaunchKernelGGL((k_p2_fast<false, true>), dim3(nwin), dim3(256), 0, s, *R, *P));
         TIMED(prof, "k_p2_mism", hipLaunchKernelGGL(k_p2_mism, dim3(2048), dim3(256), 0, s, *R, *P));
         if (R->n_complex) {
             TIMED(prof, "k_p2_slow_walk", hipLaunchKernelGGL(k_p2_slow<true>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
