@@ -108,6 +108,7 @@ struct RegionDev {
     int32_t *frag; int32_t *fam; int32_t *faminfo32; int64_t *faminfo64; int32_t *duplex;
     int32_t *bucket;                // [2][NSYM][NBUCKETS][npos] dedup_ampDistr, main.hpp:2377
     const uint8_t *bases; const uint8_t *quals; const uint32_t *cigars;
+    const uint16_t *bq; uint32_t bq_bytes;   // base | qual << 8 per read base: one bounds-checked buffer load per (alignment, position)
     AlnRec *alns; int32_t n_alns;
     AlnRec *fast; int32_t n_fast;   // simple alignments, sorted by pos
     FastRec *frec;                  // [n_fast] digest of fast[]

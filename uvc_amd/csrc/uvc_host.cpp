@@ -14,6 +14,7 @@ struct RawReads {
     const int32_t *pos, *endpos, *mpos, *isize, *flag, *mapq, *nm, *l_qseq, *n_cigar, *frag, *fs, *dflag, *kind, *fast_rank;
     const int64_t *seq_off, *cigar_off, *table_off, *item_off;
 };
+extern "C" void uvc_launch_pack_bq(const uint8_t *bases, const uint8_t *quals, uint16_t *bq, int64_t n, hipStream_t s);
 extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const UvcParams *P, hipStream_t s);
 struct UvcProf { int on; int n; const char *name[24]; hipEvent_t ev[24][2]; };
 extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, int half_ratio_phred,
@@ -339,6 +340,10 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
         || (rc = up64(in->seq_off, &W.seq_off)) || (rc = up64(in->cigar_off, &W.cigar_off)) || (rc = up64(table_off.data(), &W.table_off)) || (rc = up64(item_off.data(), &W.item_off))) return rc;
     { std::vector<uint8_t> v(in->bases, in->bases + in->n_bases); uint8_t *d; if ((rc = upload(r, v, &d))) return rc; R.bases = d; }
     { std::vector<uint8_t> v(in->quals, in->quals + in->n_bases); uint8_t *d; if ((rc = upload(r, v, &d))) return rc; R.quals = d; }
+    { if (in->n_bases >= ((int64_t)1 << 31)) return fail(UVCGPU_EUNSUPPORTED, "more than 2^31 read bases in one region: split the region");
+      uint16_t *d = nullptr; if (hipMalloc((void **)&d, (size_t)std::max<int64_t>(in->n_bases, 1) * 2) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(bq)");
+      r->owned.push_back(d); R.bq = d; R.bq_bytes = (uint32_t)(in->n_bases * 2);
+      uvc_launch_pack_bq(R.bases, R.quals, d, in->n_bases, r->stream); }
     { std::vector<uint32_t> v(in->cigars, in->cigars + in->n_cigar_ops); uint32_t *d; if ((rc = upload(r, v, &d))) return rc; R.cigars = d; }
     { std::vector<AlnRec> v((size_t)n); AlnRec *d; if ((rc = upload(r, v, &d))) return rc; R.alns = d; R.n_alns = (int32_t)n; }
     { std::vector<AlnRec> v(simple_ids.size()); AlnRec *d; if ((rc = upload(r, v, &d))) return rc; R.fast = d; R.n_fast = (int32_t)simple_ids.size(); }

@@ -32,6 +32,9 @@
 DEV int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 DEV int bcast(int v, int j) { return __builtin_amdgcn_readlane(v, j); }   // j must be wave-uniform
+// base | qual << 8 of read byte `idx` through a raw buffer descriptor: out-of-range indices (lanes outside the read) return 0
+DEV __amdgpu_buffer_rsrc_t bq_rsrc(const RegionDev &R) { return __builtin_amdgcn_make_buffer_rsrc((void *)R.bq, 0, (int)R.bq_bytes, 0x00020000); }
+DEV int bq_load(__amdgpu_buffer_rsrc_t rs, int idx) { return (int)__builtin_amdgcn_raw_buffer_load_b16(rs, idx << 1, 0, 0); }
 struct Chunk16 { int v[16]; };
 DEV void load_chunk16(const FastRec *base, int kk, int hi, Chunk16 &c) {   // lane <- record kk (zeros past the end: rend = 0 never overlaps)
     if (kk < hi) {
@@ -439,20 +442,18 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
     long long li = 0, ri = 0, lbaq = 0, rbaq = 0;
     const int lo = wave_uniform(lower_bound_frec(R.frec, R.n_fast, w0 - R.max_aln_span + 1));
     const int hi = wave_uniform(lower_bound_frec(R.frec, R.n_fast, w0 + 64));
+    const __amdgpu_buffer_rsrc_t rs = bq_rsrc(R);
     for (int k0 = lo; k0 < hi; k0 += 64) {
         Chunk16 c;
         load_chunk16(R.frec, k0 + lane, hi, c);
         const int n = imin(64, hi - k0);
-        int bn = 0, qn = 0;
-        auto issue = [&](int j) {   // loads of record j: always a valid byte of the read, so no branch around the loads
-            const int pos = bcast(c.v[0], j), rend = bcast(c.v[1], j);
-            const long long qb = ((long long)bcast(c.v[3], j) << 32) | (unsigned)bcast(c.v[2], j);
-            const long long at = qb + ((valid && p >= pos && p < rend) ? p : pos);
-            bn = R.bases[at]; qn = R.quals[at];
+        int bqn = 0;
+        auto issue = [&](int j) {
+            bqn = bq_load(rs, bcast(c.v[2], j) + p);   // low word of qbase + p: exact for lanes inside the read, harmless elsewhere
         };
         issue(0);
         for (int j = 0; j < n; j++) {
-            const int b = bn, q = qn;
+            const int b = bqn & 0xFF, q = (bqn >> 8) & 0xFF;
             if (j + 1 < n) issue(j + 1);
             const int apos = bcast(c.v[0], j), rend = bcast(c.v[1], j);
             if (rend <= w0) continue;
@@ -776,20 +777,18 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
         }
         nq = 0;
     };
+    const __amdgpu_buffer_rsrc_t rs = bq_rsrc(R);
     for (int k0 = lo; k0 < hi; k0 += 64) {
         Chunk16 c;
         load_chunk16(R.frec, k0 + lane, hi, c);
         const int n = imin(64, hi - k0);
-        int bn = 0, qn = 0;
+        int bqn = 0;
         auto issue = [&](int j) {
-            const int pos = bcast(c.v[0], j), rend = bcast(c.v[1], j);
-            const long long qb = ((long long)bcast(c.v[3], j) << 32) | (unsigned)bcast(c.v[2], j);
-            const long long at = qb + ((valid && p >= pos && p < rend) ? p : pos);
-            bn = R.bases[at]; qn = R.quals[at];
+            bqn = bq_load(rs, bcast(c.v[2], j) + p);   // low word of qbase + p: exact for lanes inside the read, harmless elsewhere
         };
         if (DO_B) issue(0);
         for (int j = 0; j < n; j++) {
-            const int sym = bn, q = qn;
+            const int sym = bqn & 0xFF, q = (bqn >> 8) & 0xFF;
             if (DO_B && j + 1 < n) issue(j + 1);
             const int apos = bcast(c.v[0], j), rend = bcast(c.v[1], j);
             if (rend <= w0) continue;
@@ -1372,6 +1371,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4,4)))
             }
         }
     };
+    const __amdgpu_buffer_rsrc_t rs = bq_rsrc(R);
     for (int k0 = lo; k0 < hi; k0 += 64) {
         // one FragFast (20 dwords) per lane, fields of record j broadcast with v_readlane; base/qual bytes of record j+1 are
         // requested before record j is processed
@@ -1385,20 +1385,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4,4)))
             for (int i = 0; i < 20; i++) c[i] = 0;
         }
         const int n = imin(64, hi - k0);
-        int b0n = 0, q0n = 0, b1n = 0, q1n = 0;
+        int bq0n = 0, bq1n = 0;
         auto issue = [&](int j) {
-            const int pos0 = bcast(c[4], j), rend0 = bcast(c[5], j), pos1 = bcast(c[6], j), rend1 = bcast(c[7], j);
-            const long long qb0 = ((long long)bcast(c[9], j) << 32) | (unsigned)bcast(c[8], j);
-            const long long qb1 = ((long long)bcast(c[11], j) << 32) | (unsigned)bcast(c[10], j);
-            if ((bcast(c[3], j) & 1) == 0) {   // register path only: generic records have no qbase
-                const long long at0 = qb0 + ((valid && p >= pos0 && p < rend0) ? p : pos0);
-                b0n = R.bases[at0]; q0n = R.quals[at0];
-                if ((bcast(c[3], j) >> 3) == 2) { const long long at1 = qb1 + ((valid && p >= pos1 && p < rend1) ? p : pos1); b1n = R.bases[at1]; q1n = R.quals[at1]; }
-            }
+            bq0n = bq_load(rs, bcast(c[8], j) + p);
+            if ((bcast(c[3], j) >> 3) == 2) bq1n = bq_load(rs, bcast(c[10], j) + p);
         };
         issue(0);
         for (int j = 0; j < n; j++) {
-            const int b0 = b0n, q0 = q0n, b1 = b1n, q1 = q1n;
+            const int b0 = bq0n & 0xFF, q0 = (bq0n >> 8) & 0xFF, b1 = bq1n & 0xFF, q1 = (bq1n >> 8) & 0xFF;
             if (j + 1 < n) issue(j + 1);
             const int fbeg = bcast(c[0], j), fend = bcast(c[1], j), flags = bcast(c[3], j);
             if (fend <= w0) continue;
@@ -1757,6 +1751,13 @@ struct UvcProf { int on; int n; const char *name[24]; hipEvent_t ev[24][2]; };
         if (i_ >= 0) hipEventRecord(p_->ev[i_][1], s); \
     } while (0)
 
+__global__ void __launch_bounds__(256) k_pack_bq(const uint8_t *bases, const uint8_t *quals, uint16_t *bq, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        bq[i] = (uint16_t)(bases[i] | (quals[i] << 8));
+}
+extern "C" void uvc_launch_pack_bq(const uint8_t *bases, const uint8_t *quals, uint16_t *bq, int64_t n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_pack_bq, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65536)), dim3(256), 0, s, bases, quals, bq, n);
+}
 extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const UvcParams *P, hipStream_t s) {
     if (R->n_alns) hipLaunchKernelGGL(k_aln_prelude, dim3(nblk(R->n_alns, 256)), dim3(256), 0, s, *R, *W, *P);
 }
