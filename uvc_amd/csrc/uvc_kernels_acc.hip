@@ -31,6 +31,14 @@
 // ------------------------------------------------------------------------------------------------
 DEV int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Workgroups are dealt to the 8 XCDs round-robin (block b -> XCD b % 8) and each XCD has its own L2.  Position-window kernels
+// therefore give XCD k one contiguous eighth of the region, so that neighbouring windows, which read the same alignments,
+// share an L2.  Placement only affects speed, never results.
+DEV int xcd_block() {
+    const int nb = gridDim.x, b = blockIdx.x, q = nb >> 3, r = nb & 7, k = b & 7, i = b >> 3;
+    return k * q + (k < r ? k : r) + i;
+}
+
 DEV int bcast(int v, int j) { return __builtin_amdgcn_readlane(v, j); }   // j must be wave-uniform
 // base | qual << 8 of read byte `idx` through a raw buffer descriptor: out-of-range indices (lanes outside the read) return 0
 DEV __amdgpu_buffer_rsrc_t bq_rsrc(const RegionDev &R) { return __builtin_amdgcn_make_buffer_rsrc((void *)R.bq, 0, (int)R.bq_bytes, 0x00020000); }
@@ -429,7 +437,7 @@ DEV void mut_event(const RegionDev &R, const UvcParams &P, const AlnRec &a, int 
 
 __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
     const int lane = threadIdx.x & 63;
-    const int wave = wave_uniform((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int wave = wave_uniform((int)((xcd_block() * blockDim.x + threadIdx.x) >> 6));
     const int64_t x0 = (int64_t)wave * 64;
     if (x0 >= R.npos) return;
     const int w0 = R.beg + (int)x0;
@@ -744,7 +752,7 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int wave = wave_uniform((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int wave = wave_uniform((int)((xcd_block() * blockDim.x + threadIdx.x) >> 6));
     const int64_t x0 = (int64_t)wave * 64;
     if (x0 >= R.npos) return;
     const int w0 = R.beg + (int)x0;
@@ -1294,10 +1302,10 @@ __global__ void __launch_bounds__(256) k_fragstat_fast(RegionDev R, UvcParams P)
 // position; per-lane bucket histograms of the two dense symbols live in LDS, rare symbols use the
 // global bucket plane (each position has exactly one writer in this kernel).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4,4))) k_frag(RegionDev R, UvcParams P) {
+__global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
     __shared__ int hist[256][2][NBUCKETS + 1];   // +1 pad: bank spread
     const int lane = threadIdx.x & 63;
-    const int wave = wave_uniform((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int wave = wave_uniform((int)((xcd_block() * blockDim.x + threadIdx.x) >> 6));
     const int64_t x0 = (int64_t)wave * 64;
     if (x0 >= R.npos) return;
     const int w0 = R.beg + (int)x0;
@@ -1306,18 +1314,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4,4)))
     const bool valid = x < R.npos;
     const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
     const bool padded_ignored = (P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0;
+    const bool vcfgen = P.inferred_is_vcf_generated;   // P3 belongs to updateByAlns3UsingBQ, skipped on FASTQ-only runs (main.hpp:3691)
     const int my_ref = valid ? R.refsym[x] : 0;
     for (int b = 0; b <= NBUCKETS; b++) { hist[threadIdx.x][0][b] = 0; hist[threadIdx.x][1][b] = 0; }
-    // avgBQ + 8 of the two dense symbols (get_avgBQ, main_conversion.hpp:791-796); LINK_M value of a simple read at this position
-    int maxq_ref = 8, maxq_link = 8, noindel80 = 80;
+    // avgBQ + 8 (get_avgBQ, main_conversion.hpp:791-796) of the five read symbols and of LINK_M; LINK_M value of a simple read here
+    auto maxq_at = [&](int sym) {
+        const int ad = S32(R, UVC_S_aDPff, sym, x) + S32(R, UVC_S_aDPfr, sym, x) + S32(R, UVC_S_aDPrf, sym, x) + S32(R, UVC_S_aDPrr, sym, x);
+        return 8 + BQS(R, sym, x) / imax(1, ad);
+    };
+    // the five per-symbol values are packed 16 bits each (a value is 8 + an average base quality) so that the per-lane lookup by
+    // consensus symbol is a shift, not an indexed local array (which would live in scratch memory)
+    unsigned long long mq_acgt = 0x0008000800080008ull;
+    int mqN = 8, maxq_link = 8, noindel80 = 80;
     if (valid) {
-        const int ad_r = S32(R, UVC_S_aDPff, my_ref, x) + S32(R, UVC_S_aDPfr, my_ref, x) + S32(R, UVC_S_aDPrf, my_ref, x) + S32(R, UVC_S_aDPrr, my_ref, x);
-        const int ad_l = S32(R, UVC_S_aDPff, UVC_LINK_M, x) + S32(R, UVC_S_aDPfr, UVC_LINK_M, x) + S32(R, UVC_S_aDPrf, UVC_LINK_M, x) + S32(R, UVC_S_aDPrr, UVC_LINK_M, x);
-        maxq_ref = 8 + BQS(R, my_ref, x) / imax(1, ad_r);
-        maxq_link = 8 + BQS(R, UVC_LINK_M, x) / imax(1, ad_l);
+        mq_acgt = (unsigned long long)imin(maxq_at(UVC_BASE_A), 65535) | ((unsigned long long)imin(maxq_at(UVC_BASE_C), 65535) << 16)
+                | ((unsigned long long)imin(maxq_at(UVC_BASE_G), 65535) << 32) | ((unsigned long long)imin(maxq_at(UVC_BASE_T), 65535) << 48);
+        mqN = maxq_at(UVC_BASE_N);
+        maxq_link = maxq_at(UVC_LINK_M);
         if (x > 0) noindel80 = imin(80, imin(RTRP(R, UVC_RTR_indelphred, x - 1), RTRP(R, UVC_RTR_indelphred, x)));
     }
-    // dense accumulators: [strand][ref, link] x {bDP, bTA, bTB, cDP12, cDP21, cDP1}, bMQ x {ref, link}.  Named structs, selected by
+    auto maxq_base = [&](int cs) { return cs >= UVC_BASE_N ? mqN : (int)((mq_acgt >> (16 * cs)) & 0xFFFFull); };   // cs in A..N
+    const int maxq_ref = maxq_base(my_ref);
+    // dense accumulators: [strand][ref, link] x {bDP, bTA, bTB, cDP12 (== cDP21), cDP1}, bMQ x {ref, link}.  Named structs, selected by
     // a wave-uniform branch on the strand: runtime-indexed local arrays would live in scratch memory (one VMEM round trip per update).
     struct DAcc { int bDP, bTA, bTB, c12, c1; };
     DAcc a_fr = {0,0,0,0,0}, a_fl = {0,0,0,0,0}, a_rr = {0,0,0,0,0}, a_rl = {0,0,0,0,0};   // {fwd,rev} x {ref,link}
@@ -1332,45 +1350,43 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4,4)))
         while (l < h) { int m = (l + h) >> 1; if (R.ffast[m].beg < w0 + 64) l = m + 1; else h = m; }
         hi = wave_uniform(l);
     }
-    // one (fragment, position, symbol type) consensus -> P3 outputs and, for singleton units, the P4/P5 identities:
+    // One (fragment, position, symbol type) consensus (cs = symbol, cc = its value, ct = total) -> P3 outputs and, for singleton units,
+    // the P4/P5 identities:
     //   con = 1 vote for the fragment consensus when 2*max - tot passes the threshold (main.hpp:466-495) => cDP12, cDP21 (tot_count == 1)
     //   mmm = 2*max - tot when positive (main.hpp:497-520)                                              => cDP1
-    auto apply = [&](DAcc &ar, DAcc &al, int st, int cs, int cc, int ct, int cs4, int cc4, int ct4, int strand, int sq, int n_cov, int n_near, bool singleton) {
+    // The reference symbol and LINK_M accumulate in registers / LDS; every other symbol is rare and goes to the planes with
+    // fire-and-forget atomics (no returned value, so the wave never waits for them; the fence before P3b orders them).
+    auto apply = [&](DAcc &ar, DAcc &al, int st, int cs, int cc, int ct, int cs4, int cc4, int ct4, int max_qual, int strand, int sq, int n_cov, int n_near, bool singleton) {
         const int dense = (cs == UVC_LINK_M ? 1 : (cs == my_ref ? 0 : -1));
-        if (P.inferred_is_vcf_generated) {   // P3 belongs to updateByAlns3UsingBQ, skipped on FASTQ-only runs (main.hpp:3691)
-        int max_qual;
-        if (dense == 0) max_qual = maxq_ref; else if (dense == 1) max_qual = maxq_link;
-        else {
-            const int ad = S32(R, UVC_S_aDPff, cs, x) + S32(R, UVC_S_aDPfr, cs, x) + S32(R, UVC_S_aDPrf, cs, x) + S32(R, UVC_S_aDPrr, cs, x);
-            max_qual = 8 + BQS(R, cs, x) / imax(1, ad);
-        }
-        const int con_qual = cc * 2 - ct;
-        int phredlike = imin(con_qual, max_qual);
-        if (0x1 & P.fam_flag) phredlike = imin(phredlike, sscs_phred(P, my_ref, cs));
-        const int pbucket = imax(0, max_qual - phredlike);
-        if (dense >= 0) {
-            if (pbucket < NBUCKETS) atomicAdd(&hist[threadIdx.x][dense][pbucket], 1);   // ds_add_u32 without return: no read-modify-write round trip
-            if (dense == 0) { ar.bDP += 1; ar.bTA += n_cov; ar.bTB += n_near; bMQ_r += sq; }
-            else { al.bDP += 1; al.bTA += n_cov; al.bTB += n_near; bMQ_l += sq; }
-        } else {
-            if (pbucket < NBUCKETS) BKP(R, 0, cs, pbucket, x) += 1;
-            FRP(R, strand, UVC_FRAG_bDP, cs, x) += 1; FRP(R, strand, UVC_FRAG_bTA, cs, x) += n_cov; FRP(R, strand, UVC_FRAG_bTB, cs, x) += n_near;
-            VQP(R, UVC_VQ_bMQ, cs, x) += sq;
-        }
+        if (vcfgen) {
+            const int con_qual = cc * 2 - ct;
+            int phredlike = imin(con_qual, max_qual);
+            if (0x1 & P.fam_flag) phredlike = imin(phredlike, sscs_phred(P, my_ref, cs));
+            const int pbucket = imax(0, max_qual - phredlike);
+            if (dense >= 0) {
+                if (pbucket < NBUCKETS) atomicAdd(&hist[threadIdx.x][dense][pbucket], 1);   // ds_add_u32 without return
+                if (dense == 0) { ar.bDP += 1; ar.bTA += n_cov; ar.bTB += n_near; bMQ_r += sq; }
+                else { al.bDP += 1; al.bTA += n_cov; al.bTB += n_near; bMQ_l += sq; }
+            } else {
+                if (pbucket < NBUCKETS) atomicAdd(&BKP(R, 0, cs, pbucket, x), 1);
+                atomicAdd(&FRP(R, strand, UVC_FRAG_bDP, cs, x), 1); atomicAdd(&FRP(R, strand, UVC_FRAG_bTA, cs, x), n_cov); atomicAdd(&FRP(R, strand, UVC_FRAG_bTB, cs, x), n_near);
+                atomicAdd(&VQP(R, UVC_VQ_bMQ, cs, x), sq);
+            }
         }
         if (singleton) {
             const int adj = imax(cc4 * 2, ct4) - ct4;
             const int thr = (st == UVC_BASE_SYMBOL ? P.fam_thres_highBQ_snv : 0);
             if (adj >= thr && adj > 0) {   // cDP12 == cDP21 for a singleton unit
                 if (cs4 == UVC_LINK_M) al.c12 += 1; else if (cs4 == my_ref) ar.c12 += 1;
-                else { FAP(R, strand, UVC_FAM_cDP12, cs4, x) += 1; FAP(R, strand, UVC_FAM_cDP21, cs4, x) += 1; }
+                else { atomicAdd(&FAP(R, strand, UVC_FAM_cDP12, cs4, x), 1); atomicAdd(&FAP(R, strand, UVC_FAM_cDP21, cs4, x), 1); }
             }
             const int adj5 = imax(cc * 2, ct) - ct;
-            if (adj5 > 0 && P.inferred_is_vcf_generated) {
-                if (dense == 0) ar.c1 += 1; else if (dense == 1) al.c1 += 1; else FAP(R, strand, UVC_FAM_cDP1, cs, x) += 1;
+            if (adj5 > 0 && vcfgen) {
+                if (dense == 0) ar.c1 += 1; else if (dense == 1) al.c1 += 1; else atomicAdd(&FAP(R, strand, UVC_FAM_cDP1, cs, x), 1);
             }
         }
     };
+    auto maxq_generic = [&](int cs) { return cs == UVC_LINK_M ? maxq_link : (cs <= UVC_BASE_N ? maxq_base(cs) : maxq_at(cs)); };
     const __amdgpu_buffer_rsrc_t rs = bq_rsrc(R);
     for (int k0 = lo; k0 < hi; k0 += 64) {
         // one FragFast (20 dwords) per lane, fields of record j broadcast with v_readlane; base/qual bytes of record j+1 are
@@ -1400,34 +1416,33 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4,4)))
             const int strand = (flags >> 1) & 1;
             const bool singleton = (flags >> 2) & 1;
             if ((flags & 1) == 0 && !proton) {
-                // register-only consensus of <= 2 simple alignments (BASE_QUALITY_MAX merge, main.hpp:339-349)
+                // consensus of <= 2 simple alignments in registers, written with selects (BASE_QUALITY_MAX merge, main.hpp:339-349)
                 const int pos0 = bcast(c[4], j), rend0 = bcast(c[5], j), pos1 = bcast(c[6], j), rend1 = bcast(c[7], j);
                 const int nogap0 = bcast(c[12], j), nogap1 = bcast(c[13], j), sq = bcast(c[14], j), n_cov = bcast(c[15], j), n_near = bcast(c[16], j);
-                int bs1 = -1, bv1 = 0, bs2 = -1, bv2 = 0, lv = 0;
-                if (p >= pos0 && p < rend0) {
-                    bs1 = b0; bv1 = q0 + P.bq_phred_added_misma;
-                    if (p > pos0) lv = (int)nnminus(noindel80, nogap0) + 1;
-                }
-                if ((flags >> 3) == 2 && p >= pos1 && p < rend1) {
-                    const int sy = b1, v = q1 + P.bq_phred_added_misma;
-                    if (bs1 < 0) { bs1 = sy; bv1 = v; } else if (sy == bs1) bv1 = imax(bv1, v); else { bs2 = sy; bv2 = v; }
-                    if (p > pos1) lv = imax(lv, (int)nnminus(noindel80, nogap1) + 1);
-                }
-                if (lv > 0) { if (strand) apply(a_rr, a_rl, UVC_LINK_SYMBOL, UVC_LINK_M, lv, lv, UVC_LINK_M, lv, lv, 1, sq, n_cov, n_near, singleton);
-                              else apply(a_fr, a_fl, UVC_LINK_SYMBOL, UVC_LINK_M, lv, lv, UVC_LINK_M, lv, lv, 0, sq, n_cov, n_near, singleton); }
-                if (bs1 >= 0) {
-                    int cs, cc, ct;
-                    if (bs2 < 0) { cs = bs1; cc = bv1; ct = bv1; }
-                    else { const bool first = (bv1 > bv2) || (bv1 == bv2 && bs1 < bs2); cs = first ? bs1 : bs2; cc = first ? bv1 : bv2; ct = bv1 + bv2; }
+                const bool has2 = ((flags >> 3) == 2);
+                const bool in0 = (p >= pos0 && p < rend0), in1 = (has2 && p >= pos1 && p < rend1);
+                // LINK_M: value of the better mate
+                const int lv0 = ((in0 && p > pos0) ? imax(noindel80 - nogap0, 0) + 1 : 0), lv1 = ((in1 && p > pos1) ? imax(noindel80 - nogap1, 0) + 1 : 0);
+                const int lv = imax(lv0, lv1);
+                if (lv > 0) { if (strand) apply(a_rr, a_rl, UVC_LINK_SYMBOL, UVC_LINK_M, lv, lv, UVC_LINK_M, lv, lv, maxq_link, 1, sq, n_cov, n_near, singleton);
+                              else apply(a_fr, a_fl, UVC_LINK_SYMBOL, UVC_LINK_M, lv, lv, UVC_LINK_M, lv, lv, maxq_link, 0, sq, n_cov, n_near, singleton); }
+                if (in0 || in1) {
+                    const int v0 = q0 + P.bq_phred_added_misma, v1 = q1 + P.bq_phred_added_misma;
+                    const int A = (in0 ? v0 : 0), B = (in1 ? v1 : 0);
+                    const bool diff = (in0 && in1 && b0 != b1);
+                    const bool first = (v0 > v1) || (v0 == v1 && b0 < b1);
+                    const int cc = imax(A, B), ct = (diff ? A + B : cc);
+                    const int cs = ((in0 && (!diff || first)) ? b0 : b1);
                     int cs4 = cs, cc4 = cc, ct4 = ct;
                     if (padded_ignored) {   // fillConsensusCounts<false, true>: only A..T take part (main.hpp:410)
-                        const int v1 = (bs1 <= UVC_BASE_T ? bv1 : 0), v2 = ((bs2 >= 0 && bs2 <= UVC_BASE_T) ? bv2 : 0);
-                        ct4 = v1 + v2;
-                        if (v1 == 0 && v2 == 0) { cs4 = UVC_BASE_T; cc4 = 0; }
-                        else { const bool first = (v1 > v2) || (v1 == v2 && (bs2 < 0 || bs1 < bs2)); cs4 = first ? bs1 : bs2; cc4 = first ? v1 : v2; }
+                        const int A4 = ((in0 && b0 <= UVC_BASE_T) ? v0 : 0), B4 = ((in1 && b1 <= UVC_BASE_T) ? v1 : 0);
+                        const bool first4 = (A4 > B4) || (A4 == B4 && b0 < b1);
+                        cc4 = imax(A4, B4); ct4 = (diff ? A4 + B4 : cc4);
+                        cs4 = ((A4 == 0 && B4 == 0) ? UVC_BASE_T : (diff ? (first4 ? b0 : b1) : cs));
                     }
-                    if (strand) apply(a_rr, a_rl, UVC_BASE_SYMBOL, cs, cc, ct, cs4, cc4, ct4, 1, sq, n_cov, n_near, singleton);
-                    else apply(a_fr, a_fl, UVC_BASE_SYMBOL, cs, cc, ct, cs4, cc4, ct4, 0, sq, n_cov, n_near, singleton);
+                    const int mq = maxq_base(cs);
+                    if (strand) apply(a_rr, a_rl, UVC_BASE_SYMBOL, cs, cc, ct, cs4, cc4, ct4, mq, 1, sq, n_cov, n_near, singleton);
+                    else apply(a_fr, a_fl, UVC_BASE_SYMBOL, cs, cc, ct, cs4, cc4, ct4, mq, 0, sq, n_cov, n_near, singleton);
                 }
             } else {
                 int cnt[NSYM];
@@ -1441,14 +1456,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4,4)))
                     int cs4 = cs, cc4 = cc, ct4 = ct;
                     if (st == UVC_BASE_SYMBOL && padded_ignored) fill_consensus(cnt, cs4, cc4, ct4, st, false, true);
                     const int fsq = (f.normMQ * f.normMQ) / SQR_QUAL_DIV;
-                    if (strand) apply(a_rr, a_rl, st, cs, cc, ct, cs4, cc4, ct4, 1, fsq, f.n_cov, f.n_near, singleton);
-                    else apply(a_fr, a_fl, st, cs, cc, ct, cs4, cc4, ct4, 0, fsq, f.n_cov, f.n_near, singleton);
+                    const int mq = maxq_generic(cs);
+                    if (strand) apply(a_rr, a_rl, st, cs, cc, ct, cs4, cc4, ct4, mq, 1, fsq, f.n_cov, f.n_near, singleton);
+                    else apply(a_fr, a_fl, st, cs, cc, ct, cs4, cc4, ct4, mq, 0, fsq, f.n_cov, f.n_near, singleton);
                 }
             }
         }
     }
     if (!valid) return;
-    // flush the dense accumulators (plain read-modify-write: one writer per position in this kernel)
+    // the atomics above must have landed (and this CU's L1 must not hold older copies) before the planes are read back
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    // flush the dense accumulators (plain read-modify-write: nobody else touches these symbols at this position in this kernel)
     auto flush = [&](const DAcc &a, int s, int sym) {
         if (a.bDP) { FRP(R, s, UVC_FRAG_bDP, sym, x) += a.bDP; FRP(R, s, UVC_FRAG_bTA, sym, x) += a.bTA; FRP(R, s, UVC_FRAG_bTB, sym, x) += a.bTB; }
         if (a.c12) { FAP(R, s, UVC_FAM_cDP12, sym, x) += a.c12; FAP(R, s, UVC_FAM_cDP21, sym, x) += a.c12; }
@@ -1458,7 +1476,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4,4)))
     if (bMQ_r) VQP(R, UVC_VQ_bMQ, my_ref, x) += bMQ_r;
     if (bMQ_l) VQP(R, UVC_VQ_bMQ, UVC_LINK_M, x) += bMQ_l;
     // P3b (main.hpp:2801-2828)
-    for (int st = 0; st < 2 && P.inferred_is_vcf_generated; st++) {
+    for (int st = 0; st < 2 && vcfgen; st++) {
         const int sb = (st == 0 ? UVC_BASE_A : UVC_LINK_M), se = (st == 0 ? UVC_BASE_NN : UVC_LINK_NN);
         int totDP = 0;
         for (int s = sb; s <= se; s++) totDP += FRP(R, 0, UVC_FRAG_bDP, s, x) + FRP(R, 1, UVC_FRAG_bDP, s, x);
@@ -1466,12 +1484,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4,4)))
             const int nfr = FRP(R, 0, UVC_FRAG_bDP, s, x) + FRP(R, 1, UVC_FRAG_bDP, s, x);
             if (nfr == 0) continue;   // empty histogram -> all three outputs are 0
             const int dense = (s == my_ref ? 0 : (s == UVC_LINK_M ? 1 : -1));
-            int max_qual;
-            if (dense == 0) max_qual = maxq_ref; else if (dense == 1) max_qual = maxq_link;
-            else {
-                const int ad = S32(R, UVC_S_aDPff, s, x) + S32(R, UVC_S_aDPfr, s, x) + S32(R, UVC_S_aDPrf, s, x) + S32(R, UVC_S_aDPrr, s, x);
-                max_qual = 8 + BQS(R, s, x) / imax(1, ad);
-            }
+            const int max_qual = maxq_generic(s);
             int mv, ad2, bq2;
             if (dense >= 0) infer_max_qual(mv, ad2, bq2, max_qual, 1, totDP, [&](int b) { return hist[threadIdx.x][dense][b]; });
             else {
