@@ -1248,7 +1248,7 @@ __global__ void __launch_bounds__(64) k_fragstat_sweep(RegionDev R, UvcParams P,
     }
     atomicAdd(&tot[0], n_cov); atomicAdd(&tot[1], n_near);
     __syncthreads();
-    if (lane == 0) { R.frags[fi].n_cov = tot[0]; R.frags[fi].n_near = tot[1]; }
+    if (lane == 0) { R.frags[fi].n_cov = tot[0]; R.frags[fi].n_near = tot[1]; FragFast &ff = R.ffast[R.frag_rank[fi]]; ff.n_cov = tot[0]; ff.n_near = tot[1]; }
 }
 
 // closed form for fragments of <= 2 simple alignments: coverage = union of the alignment spans, mutations = the event list
@@ -1276,9 +1276,9 @@ __global__ void __launch_bounds__(256) k_fragstat_fast(RegionDev R, UvcParams P)
     }
     const int n_cov = (b1 - a1) + (b2 - a2);
     int n_near = 0;
-    if (nm > UVC_MAXEV) {   // too many events for the closed form: the sweep kernel fills n_cov / n_near, k_frag takes the generic path
+    if (nm > UVC_MAXEV) {   // too many events for the closed form: the sweep kernel (overflow pass) fills n_cov / n_near of this record
         const int k = atomicAdd(R.n_overflow, 1); R.overflow_frags[k] = fi;
-        ff.flags |= 1; R.ffast[R.frag_rank[fi]] = ff; return;
+        R.ffast[R.frag_rank[fi]] = ff; return;
     }
     if (nm > 0) {
         const int nb = P.syserr_mut_region_n_bases;
@@ -1298,12 +1298,62 @@ __global__ void __launch_bounds__(256) k_fragstat_fast(RegionDev R, UvcParams P)
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_frag_generic: the P3 / singleton P4-P5 contribution of the fragments k_frag cannot take in registers (InDel reads,
+// more than two alignments, primer-gated reads; every fragment on IonTorrent).  One wave per fragment, lanes over its
+// positions, everything added to the planes with atomics; the bucket histogram goes to the global bucket plane, which
+// k_frag merges in P3b.  Runs before k_frag.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_frag_generic(RegionDev R, UvcParams P, const int32_t *list, int n_list) {
+    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    const bool padded_ignored = (P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0;
+    const bool vcfgen = P.inferred_is_vcf_generated;
+    for (int t = blockIdx.x; t < n_list; t += gridDim.x) {
+        const int fi = (list ? list[t] : t);
+        const FragRec &f = R.frags[fi];
+        const int strand = f.strand;
+        const bool singleton = f.singleton;
+        const int fsq = (f.normMQ * f.normMQ) / SQR_QUAL_DIV;
+        for (int p = imax(f.beg, R.beg) + (int)threadIdx.x; p < imin(f.end, R.end); p += 64) {
+            const int64_t x = p - R.beg;
+            const int my_ref = R.refsym[x];
+            int cnt[NSYM];
+            frag_counts(R, P, f, p, proton, cnt);
+            for (int vi = 0; vi < 2; vi++) {
+                const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
+                int cs, cc, ct;
+                fill_consensus(cnt, cs, cc, ct, st, st == UVC_LINK_SYMBOL, false);
+                if (0 == ct) continue;
+                int cs4 = cs, cc4 = cc, ct4 = ct;
+                if (st == UVC_BASE_SYMBOL && padded_ignored) fill_consensus(cnt, cs4, cc4, ct4, st, false, true);
+                if (vcfgen) {
+                    const int ad = S32(R, UVC_S_aDPff, cs, x) + S32(R, UVC_S_aDPfr, cs, x) + S32(R, UVC_S_aDPrf, cs, x) + S32(R, UVC_S_aDPrr, cs, x);
+                    const int max_qual = 8 + BQS(R, cs, x) / imax(1, ad);   // get_avgBQ, main_conversion.hpp:791-796
+                    int phredlike = imin(cc * 2 - ct, max_qual);
+                    if (0x1 & P.fam_flag) phredlike = imin(phredlike, sscs_phred(P, my_ref, cs));
+                    const int pbucket = imax(0, max_qual - phredlike);
+                    if (pbucket < NBUCKETS) atomicAdd(&BKP(R, 0, cs, pbucket, x), 1);
+                    atomicAdd(&FRP(R, strand, UVC_FRAG_bDP, cs, x), 1); atomicAdd(&FRP(R, strand, UVC_FRAG_bTA, cs, x), f.n_cov); atomicAdd(&FRP(R, strand, UVC_FRAG_bTB, cs, x), f.n_near);
+                    atomicAdd(&VQP(R, UVC_VQ_bMQ, cs, x), fsq);
+                }
+                if (singleton) {   // con / mmm identities of a one-fragment unit (main.hpp:466-520)
+                    const int adj = imax(cc4 * 2, ct4) - ct4;
+                    const int thr = (st == UVC_BASE_SYMBOL ? P.fam_thres_highBQ_snv : 0);
+                    if (adj >= thr && adj > 0) { atomicAdd(&FAP(R, strand, UVC_FAM_cDP12, cs4, x), 1); atomicAdd(&FAP(R, strand, UVC_FAM_cDP21, cs4, x), 1); }
+                    const int adj5 = imax(cc * 2, ct) - ct;
+                    if (adj5 > 0 && vcfgen) atomicAdd(&FAP(R, strand, UVC_FAM_cDP1, cs, x), 1);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_frag: P3 + P3b for every fragment, and P4/P5 of singleton family-strand units.  One lane per
 // position; per-lane bucket histograms of the two dense symbols live in LDS, rare symbols use the
 // global bucket plane (each position has exactly one writer in this kernel).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
-    __shared__ int hist[256][2][NBUCKETS + 1];   // +1 pad: bank spread
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,5))) k_frag(RegionDev R, UvcParams P) {
+    __shared__ int hist[2][NBUCKETS][256];   // [dense symbol][bucket][thread]: conflict-free, 32 KiB so that five blocks share a CU
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform((int)((xcd_block() * blockDim.x + threadIdx.x) >> 6));
     const int64_t x0 = (int64_t)wave * 64;
@@ -1316,7 +1366,7 @@ __global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
     const bool padded_ignored = (P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0;
     const bool vcfgen = P.inferred_is_vcf_generated;   // P3 belongs to updateByAlns3UsingBQ, skipped on FASTQ-only runs (main.hpp:3691)
     const int my_ref = valid ? R.refsym[x] : 0;
-    for (int b = 0; b <= NBUCKETS; b++) { hist[threadIdx.x][0][b] = 0; hist[threadIdx.x][1][b] = 0; }
+    for (int b = 0; b < NBUCKETS; b++) { hist[0][b][threadIdx.x] = 0; hist[1][b][threadIdx.x] = 0; }
     // avgBQ + 8 (get_avgBQ, main_conversion.hpp:791-796) of the five read symbols and of LINK_M; LINK_M value of a simple read here
     auto maxq_at = [&](int sym) {
         const int ad = S32(R, UVC_S_aDPff, sym, x) + S32(R, UVC_S_aDPfr, sym, x) + S32(R, UVC_S_aDPrf, sym, x) + S32(R, UVC_S_aDPrr, sym, x);
@@ -1364,7 +1414,7 @@ __global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
             if (0x1 & P.fam_flag) phredlike = imin(phredlike, sscs_phred(P, my_ref, cs));
             const int pbucket = imax(0, max_qual - phredlike);
             if (dense >= 0) {
-                if (pbucket < NBUCKETS) atomicAdd(&hist[threadIdx.x][dense][pbucket], 1);   // ds_add_u32 without return
+                if (pbucket < NBUCKETS) atomicAdd(&hist[dense][pbucket][threadIdx.x], 1);   // ds_add_u32 without return
                 if (dense == 0) { ar.bDP += 1; ar.bTA += n_cov; ar.bTB += n_near; bMQ_r += sq; }
                 else { al.bDP += 1; al.bTA += n_cov; al.bTB += n_near; bMQ_l += sq; }
             } else {
@@ -1406,6 +1456,7 @@ __global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
             bq0n = bq_load(rs, bcast(c[8], j) + p);
             if ((bcast(c[3], j) >> 3) == 2) bq1n = bq_load(rs, bcast(c[10], j) + p);
         };
+        if (proton) break;   // IonTorrent values need neighbouring qualities: every fragment takes k_frag_generic
         issue(0);
         for (int j = 0; j < n; j++) {
             const int b0 = bq0n & 0xFF, q0 = (bq0n >> 8) & 0xFF, b1 = bq1n & 0xFF, q1 = (bq1n >> 8) & 0xFF;
@@ -1415,7 +1466,8 @@ __global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
             if (!(valid && p >= fbeg && p < fend)) continue;
             const int strand = (flags >> 1) & 1;
             const bool singleton = (flags >> 2) & 1;
-            if ((flags & 1) == 0 && !proton) {
+            if (flags & 1) continue;   // complex fragments were done by k_frag_generic
+            {
                 // consensus of <= 2 simple alignments in registers, written with selects (BASE_QUALITY_MAX merge, main.hpp:339-349)
                 const int pos0 = bcast(c[4], j), rend0 = bcast(c[5], j), pos1 = bcast(c[6], j), rend1 = bcast(c[7], j);
                 const int nogap0 = bcast(c[12], j), nogap1 = bcast(c[13], j), sq = bcast(c[14], j), n_cov = bcast(c[15], j), n_near = bcast(c[16], j);
@@ -1444,22 +1496,6 @@ __global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
                     if (strand) apply(a_rr, a_rl, UVC_BASE_SYMBOL, cs, cc, ct, cs4, cc4, ct4, mq, 1, sq, n_cov, n_near, singleton);
                     else apply(a_fr, a_fl, UVC_BASE_SYMBOL, cs, cc, ct, cs4, cc4, ct4, mq, 0, sq, n_cov, n_near, singleton);
                 }
-            } else {
-                int cnt[NSYM];
-                const FragRec &f = R.frags[bcast(c[2], j)];
-                frag_counts(R, P, f, p, proton, cnt);
-                for (int vi = 0; vi < 2; vi++) {
-                    const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
-                    int cs, cc, ct;
-                    fill_consensus(cnt, cs, cc, ct, st, st == UVC_LINK_SYMBOL, false);
-                    if (0 == ct) continue;
-                    int cs4 = cs, cc4 = cc, ct4 = ct;
-                    if (st == UVC_BASE_SYMBOL && padded_ignored) fill_consensus(cnt, cs4, cc4, ct4, st, false, true);
-                    const int fsq = (f.normMQ * f.normMQ) / SQR_QUAL_DIV;
-                    const int mq = maxq_generic(cs);
-                    if (strand) apply(a_rr, a_rl, st, cs, cc, ct, cs4, cc4, ct4, mq, 1, fsq, f.n_cov, f.n_near, singleton);
-                    else apply(a_fr, a_fl, st, cs, cc, ct, cs4, cc4, ct4, mq, 0, fsq, f.n_cov, f.n_near, singleton);
-                }
             }
         }
     }
@@ -1476,6 +1512,7 @@ __global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
     if (bMQ_r) VQP(R, UVC_VQ_bMQ, my_ref, x) += bMQ_r;
     if (bMQ_l) VQP(R, UVC_VQ_bMQ, UVC_LINK_M, x) += bMQ_l;
     // P3b (main.hpp:2801-2828)
+    const bool has_generic = (R.n_sweep > 0 || proton);
     for (int st = 0; st < 2 && vcfgen; st++) {
         const int sb = (st == 0 ? UVC_BASE_A : UVC_LINK_M), se = (st == 0 ? UVC_BASE_NN : UVC_LINK_NN);
         int totDP = 0;
@@ -1486,9 +1523,9 @@ __global__ void __launch_bounds__(256) k_frag(RegionDev R, UvcParams P) {
             const int dense = (s == my_ref ? 0 : (s == UVC_LINK_M ? 1 : -1));
             const int max_qual = maxq_generic(s);
             int mv, ad2, bq2;
-            if (dense >= 0) infer_max_qual(mv, ad2, bq2, max_qual, 1, totDP, [&](int b) { return hist[threadIdx.x][dense][b]; });
-            else {
-                infer_max_qual(mv, ad2, bq2, max_qual, 1, totDP, [&](int b) { return BKP(R, 0, s, b, x); });
+            if (dense >= 0 && !has_generic) infer_max_qual(mv, ad2, bq2, max_qual, 1, totDP, [&](int b) { return hist[dense][b][threadIdx.x]; });
+            else {   // the global buckets hold the rare symbols and everything k_frag_generic added
+                infer_max_qual(mv, ad2, bq2, max_qual, 1, totDP, [&](int b) { return BKP(R, 0, s, b, x) + (dense >= 0 ? hist[dense][b][threadIdx.x] : 0); });
                 for (int b = 0; b < NBUCKETS; b++) BKP(R, 0, s, b, x) = 0;   // clearSymbolBucketCount, main.hpp:2827
             }
             VQP(R, UVC_VQ_bIAQb, s, x) += mv; VQP(R, UVC_VQ_bIADb, s, x) += ad2; VQP(R, UVC_VQ_bIDQb, s, x) += bq2;
@@ -1798,6 +1835,11 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
         if (R->n_sweep) TIMED(prof, "k_fragstat_sweep", hipLaunchKernelGGL(k_fragstat_sweep, dim3(R->n_sweep), dim3(64), 0, s, *R, *P, R->sweep_frags, (const int32_t *)nullptr, R->n_sweep));
         // fragments whose event list overflowed (device-side list; the grid covers the worst case, surplus threads exit)
         TIMED(prof, "k_fragstat_overflow", hipLaunchKernelGGL(k_fragstat_sweep, dim3(imin_h(R->n_frags, 65535)), dim3(64), 0, s, *R, *P, (const int32_t *)R->overflow_frags, (const int32_t *)R->n_overflow, 0));
+    }
+    {
+        const bool proton = (UVC_PLATFORM_IONTORRENT == P->inferred_sequencing_platform);
+        const int n_gen = proton ? R->n_frags : R->n_sweep;
+        if (n_gen) TIMED(prof, "k_frag_generic", hipLaunchKernelGGL(k_frag_generic, dim3(imin_h(n_gen, 1 << 20)), dim3(64), 0, s, *R, *P, proton ? (const int32_t *)nullptr : R->sweep_frags, n_gen));
     }
     TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag, dim3(nwin), dim3(256), 0, s, *R, *P));
     if (R->n_generic_fs) {
