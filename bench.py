@@ -29,19 +29,39 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def algorithmic_bytes_per_position(kernel, depth):
-    """Per-position algorithmic HBM bytes of each kernel (DESIGN.md section 5).  Built from the SURVEY 8(d)
-    components: 1 B base + 1 B qual per read-base, 48 B per read, 5 544 B of accumulator records."""
+    """Per-position algorithmic HBM bytes of each kernel (DESIGN.md section 2).  Built from the SURVEY 8(d)
+    components: 1 B base + 1 B qual per read-base, one per-read record, 5 544 B of accumulator records."""
     d = float(depth)
     reads = 2.0 * d + 48.0 * d / READ_LEN           # bases + quals + per-read record
     table = {
         "k_prep_fast": reads + 1 + 8 + 208,                         # + ref, baq ; writes SegFormatPrepSet
         "k_thres": 208 + 28 + 72 + 4,                                # prep + rtr -> thres + indelphred
-        "k_p2_fast": reads + 1 + 72 + 16 + 8 + 14 * (152 + 16 + 4),  # + ref, thres, 2 baq, 2 indelphred ; writes seg info + a1/a2 BQ + bqsum
-        "k_fragstat": reads + 1 + 8,
+        "k_p2_fast_link": 48.0 * d / READ_LEN + 72 + 16 + 8 + (152 + 16 + 4),        # read records, thres, 2 baq, 2 indelphred ; writes LINK_M seg info + a1/a2 BQ + bqsum
+        "k_p2_fast_base": reads + 1 + 72 + 16 + 13 * (152 + 16 + 4),                 # + ref, thres, 2 baq ; writes the base symbols' seg info
         "k_frag": reads + 48.0 * d / (2 * READ_LEN) + 1 + 8 + 14 * 20 + 14 * 4 * (6 + 6 + 4),   # + fragment records, avgBQ inputs ; writes frag, fam(3), VQ(4)
         "k_p5b": 2 * 14 * 4 + 14 * 4 * 6,
     }
     return table.get(kernel, reads)
+
+
+PROFILE_NAMES = {"k_p2_fast_link": "k_p2_fast<true, false>", "k_p2_fast_base": "k_p2_fast<false, true>",
+                 "k_p2_slow_walk": "k_p2_slow<true>", "k_p2_slow_table": "k_p2_slow<false>"}
+
+
+def measured_traffic(kernel, tile_kb, depth):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/traffic_latest.json, made by
+    scripts/gpu_round_profile.sh: FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes), or None when the passes were taken on
+    another workload."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        t = json.load(open(path))
+        if t.get("_workload") != {"tile_kb": tile_kb, "depth": depth}:
+            return None
+        return t[PROFILE_NAMES.get(kernel, kernel)]["traffic_bytes_per_launch"]
+    except (KeyError, ValueError):
+        return None
 
 
 def run_cpu_baseline(depth, n_regions=16, region_len=20000):
@@ -155,7 +175,7 @@ def main():
             "config": {"workload": "chr20-shaped tumor-only non-UMI tile: %d kb at %dx, 150 bp paired-end, one tile per GPU resident in HBM; step = accumulate P1..P5b + default-gate scoring + D2H of records" % (args.tile_kb, args.depth),
                        "tile_positions": region_len, "reads_per_tile": int(reads["n_reads"]), "read_bases_per_tile": n_read_bases, "scored_records_per_tile": n_rec,
                        "parallelism": "region-shard x%d (no collective on the data path)" % world},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(dom, args.tile_kb, args.depth),
                          "algorithmic_bytes_per_launch": abytes, "kernel_ms": avg[dom]},
             "kernel_ms": {k: round(v, 4) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])},
             "read_bases_per_s": n_read_bases * world * args.steps / dt,

@@ -435,7 +435,9 @@ DEV void mut_event(const RegionDev &R, const UvcParams &P, const AlnRec &a, int 
     }
 }
 
+#define PREPQ_CAP 192   // per-wave LDS queue of (alignment, position) pairs whose base differs from the reference
 __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
+    __shared__ int2 prepq[4][PREPQ_CAP];
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform((int)((xcd_block() * blockDim.x + threadIdx.x) >> 6));
     const int64_t x0 = (int64_t)wave * 64;
@@ -451,6 +453,20 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
     const int lo = wave_uniform(lower_bound_frec(R.frec, R.n_fast, w0 - R.max_aln_span + 1));
     const int hi = wave_uniform(lower_bound_frec(R.frec, R.n_fast, w0 + 64));
     const __amdgpu_buffer_rsrc_t rs = bq_rsrc(R);
+    // Mismatching bases are rare per lane but present in a large share of the iterations of a wave, and their handling (SNV / DNV
+    // run detection, fragment mutation events) is a chain of dependent loads.  They are queued per wave and handled 64 at a time,
+    // one per lane, in wave-uniform control flow, so the main loop never waits on them.
+    int2 *myq = prepq[threadIdx.x >> 6];
+    int nq = 0;   // wave-uniform: only updated in uniform control flow
+    auto drain = [&]() {
+        for (int i = lane; i < nq; i += 64) {
+            const int2 e = myq[i];
+            const AlnRec &a = R.fast[e.x];
+            snv_dnv_scatter(R, R.bases + a.seq_off, (int)(a.qbase + e.y - a.seq_off), a.l_qseq, a.pos, a.rend, e.y);
+            mut_event(R, P, a, e.y, R.refsym[e.y - R.beg]);
+        }
+        nq = 0;
+    };
     for (int k0 = lo; k0 < hi; k0 += 64) {
         Chunk16 c;
         load_chunk16(R.frec, k0 + lane, hi, c);
@@ -465,7 +481,14 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
             if (j + 1 < n) issue(j + 1);
             const int apos = bcast(c.v[0], j), rend = bcast(c.v[1], j);
             if (rend <= w0) continue;
-            if (valid && p >= apos && p < rend) {
+            const bool cover = (valid && p >= apos && p < rend);
+            const wmask mm = BAL(cover && b != my_ref);
+            if (mm) {
+                if (nq > PREPQ_CAP - 64) drain();
+                if (cover && b != my_ref) myq[nq + (int)__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = make_int2(k0 + j, p);
+                nq += (int)__builtin_popcountll(mm);
+            }
+            if (cover) {
                 const int fmd = bcast(c.v[4], j), isize = bcast(c.v[5], j), mpos = bcast(c.v[6], j), xm1500 = bcast(c.v[7], j);
                 const int dflag = (fmd >> 24) & 0xFF;
                 const int pcr_inc = ((dflag & 0x4) ? 1 : 0);
@@ -475,11 +498,6 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
                     const int fl = imin(apos, mpos);
                     if (fmd & 0x10) { li += imin(p - fl + 1, MAX_INSERT_SIZE); lidp += 1; }
                     else { ri += imin(fl + abs(isize) - p, MAX_INSERT_SIZE); ridp += 1; }
-                }
-                if (b != my_ref) {   // rare: SNV / DNV runs and fragment mutation events need the full record
-                    const AlnRec &a = R.fast[k0 + j];
-                    snv_dnv_scatter(R, R.bases + a.seq_off, (int)(a.qbase + p - a.seq_off), a.l_qseq, apos, rend, p);
-                    mut_event(R, P, a, p, my_ref);
                 }
                 if (q >= P.bias_thres_highBQ) {
                     ldist += p - apos + 1; rdist += rend - p;
@@ -496,6 +514,7 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
             }
         }
     }
+    if (nq > 0) drain();
     if (!valid) return;
     if (dp) atomicAdd(&P32(R, UVC_P_a_dp, x), dp);
     if (pcr) atomicAdd(&P32(R, UVC_P_a_pcr_dp, x), pcr);
