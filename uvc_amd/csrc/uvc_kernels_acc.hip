@@ -85,6 +85,19 @@ DEV void seg_flush(const RegionDev &R, const SegAcc &A, int sym, int64_t x) {
     if (A.bq) atomicAdd(&BQS(R, sym, x), A.bq);
 }
 
+// first writer of (sym, x) after the planes were zeroed: plain stores, no read-modify-write
+DEV void seg_store(const RegionDev &R, const SegAcc &A, int sym, int64_t x) {
+#pragma unroll
+    for (int f = 0; f < UVC_NSEG32; f++) if (A.s[f]) S32(R, f, sym, x) = A.s[f];
+#pragma unroll
+    for (int f = 0; f < UVC_NSEG64; f++) if (A.l[f]) S64(R, f, sym, x) = A.l[f];
+    if (A.a1BQf) VQP(R, UVC_VQ_a1BQf, sym, x) = A.a1BQf;
+    if (A.a1BQr) VQP(R, UVC_VQ_a1BQr, sym, x) = A.a1BQr;
+    if (A.a2BQf) VQP(R, UVC_VQ_a2BQf, sym, x) = A.a2BQf;
+    if (A.a2BQr) VQP(R, UVC_VQ_a2BQr, sym, x) = A.a2BQr;
+    if (A.bq) BQS(R, sym, x) = A.bq;
+}
+
 struct PosThres { int t[UVC_NTHRES]; };
 
 // per-read quantities that dealwith_segbias needs; all wave-uniform in the fast kernels
@@ -516,17 +529,18 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
     }
     if (nq > 0) drain();
     if (!valid) return;
-    if (dp) atomicAdd(&P32(R, UVC_P_a_dp, x), dp);
-    if (pcr) atomicAdd(&P32(R, UVC_P_a_pcr_dp, x), pcr);
-    if (umi) atomicAdd(&P32(R, UVC_P_a_umi_dp, x), umi);
-    if (qlen_s) atomicAdd(&P32(R, UVC_P_a_qlen, x), qlen_s);
-    if (xm_s) atomicAdd(&P32(R, UVC_P_a_XM1500, x), xm_s);
-    if (lidp) { atomicAdd(&P32(R, UVC_P_a_LIDP, x), lidp); add64(&P64(R, UVC_P_a_LI, x), li); }
-    if (ridp) { atomicAdd(&P32(R, UVC_P_a_RIDP, x), ridp); add64(&P64(R, UVC_P_a_RI, x), ri); }
+    // first writer of these fields (k_prep_slow adds to them afterwards; the scatter updates above touch other fields): plain stores
+    if (dp) P32(R, UVC_P_a_dp, x) = dp;
+    if (pcr) P32(R, UVC_P_a_pcr_dp, x) = pcr;
+    if (umi) P32(R, UVC_P_a_umi_dp, x) = umi;
+    if (qlen_s) P32(R, UVC_P_a_qlen, x) = qlen_s;
+    if (xm_s) P32(R, UVC_P_a_XM1500, x) = xm_s;
+    if (lidp) { P32(R, UVC_P_a_LIDP, x) = lidp; P64(R, UVC_P_a_LI, x) = li; }
+    if (ridp) { P32(R, UVC_P_a_RIDP, x) = ridp; P64(R, UVC_P_a_RI, x) = ri; }
     if (hbq) {
-        atomicAdd(&P32(R, UVC_P_a_highBQ_dp, x), hbq);
-        atomicAdd(&P32(R, UVC_P_a_l_dist_sum, x), ldist); atomicAdd(&P32(R, UVC_P_a_r_dist_sum, x), rdist);
-        add64(&P64(R, UVC_P_a_l_BAQ_sum, x), lbaq); add64(&P64(R, UVC_P_a_r_BAQ_sum, x), rbaq);
+        P32(R, UVC_P_a_highBQ_dp, x) = hbq;
+        P32(R, UVC_P_a_l_dist_sum, x) = ldist; P32(R, UVC_P_a_r_dist_sum, x) = rdist;
+        P64(R, UVC_P_a_l_BAQ_sum, x) = lbaq; P64(R, UVC_P_a_r_BAQ_sum, x) = rbaq;
     }
 }
 
@@ -864,8 +878,10 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
     }
     if (DO_B && nq > 0) flush_queue();
     if (!valid) return;
-    if (DO_B) seg_flush(R, Aref, my_ref, x);
-    if (DO_L) seg_flush(R, Alink, UVC_LINK_M, x);
+    // k_p2_fast runs before every other writer of these planes (k_p2_mism, k_p2_items), and the two instantiations own
+    // different symbols: plain stores
+    if (DO_B) seg_store(R, Aref, my_ref, x);
+    if (DO_L) seg_store(R, Alink, UVC_LINK_M, x);
 }
 
 // ------------------------------------------------------------------------------------------------
