@@ -61,3 +61,27 @@ def test_score_records_match_oracle(name, all_out, oracle_lib, gpu_lib):
     assert len(ro["refpos"]) > 0
     worst = compare_records(ro, rg)
     print(name, all_out, len(ro["refpos"]), {k: v for k, v in worst.items() if v})
+
+
+@pytest.mark.parametrize("name", ["config2shape_5kb_300x", "umi_duplex_2kb_400x"])
+def test_accumulate_is_repeatable(name, oracle_lib, gpu_lib):
+    """A second accumulate on the same handle (what bench.py times) must reproduce the first: the transient
+    bucket planes are not re-zeroed between calls, their consumers (P3b, P5b) have to leave them clean."""
+    reads = synth.generate_region(**CASES[name])
+    Ro = run_region(oracle_lib, reads)
+    Rg = run_region(gpu_lib, reads)
+    Rg.accumulate()
+    Rg.accumulate()
+    bad = diff_groups(Ro, Rg)
+    assert not bad, "\n".join("%s: %d cells differ, e.g. %s" % (g, v[0], v[1]) for g, v in bad.items())
+
+
+def test_reads_with_many_mismatches_and_indels(oracle_lib, gpu_lib):
+    """Stress the rare-symbol paths: 3 % substitution errors, an InDel every 300 bp, 10 % clipped reads."""
+    reads = synth.generate_region(region_len=4000, depth=120, seed=21, err_rate=0.03, indel_every=300, snv_every=150, clip_frac=0.1)
+    Ro = run_region(oracle_lib, reads)
+    Rg = run_region(gpu_lib, reads)
+    bad = diff_groups(Ro, Rg)
+    assert not bad, "\n".join("%s: %d cells differ, e.g. %s" % (g, v[0], v[1]) for g, v in bad.items())
+    worst = compare_records(Ro.score(all_out=False), Rg.score(all_out=False))
+    print({k: v for k, v in worst.items() if v})

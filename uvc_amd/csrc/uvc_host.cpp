@@ -36,6 +36,7 @@ struct uvcgpu_region {
     // device buffers
     uint8_t *d_refsym = nullptr; int32_t *d_rtr = nullptr, *d_rtr0 = nullptr; int64_t *d_baq = nullptr;
     char *d_state = nullptr; size_t state_bytes = 0;
+    size_t bucket_off = 0; bool buckets_clean = false;   // the transient bucket planes (tail of the slab) are left zero by P3b / P5b
     std::vector<void *> owned;   // read-dependent device allocations
     RegionDev R;
     int32_t *d_dup_units = nullptr; int64_t *d_dup_off = nullptr; int n_dup = 0; int64_t n_dup_work = 0;
@@ -208,7 +209,7 @@ int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params, int32_t
     size_t o = 0;
     for (int g : order) { r->off[g] = o; o += group_bytes(r, g); }
     const size_t bucket_off = o; o += (size_t)4 * r->npos * 2 * NSYM * NBUCKETS;
-    r->state_bytes = o;
+    r->state_bytes = o; r->bucket_off = bucket_off; r->buckets_clean = false;
     if (hipMalloc((void **)&r->d_state, r->state_bytes) != hipSuccess) { uvcgpu_region_destroy(r); return fail(UVCGPU_ENOMEM, "hipMalloc(state planes) failed"); }
     int32_t *d_err = nullptr;
     if (hipMalloc((void **)&d_err, 4) != hipSuccess) { uvcgpu_region_destroy(r); return fail(UVCGPU_ENOMEM, "hipMalloc failed"); }
@@ -389,7 +390,8 @@ int uvcgpu_region_correct_bq(uvcgpu_region_t *) { return fail(UVCGPU_EUNSUPPORTE
 int uvcgpu_region_accumulate(uvcgpu_region_t *r) {
     if (!r) return fail(UVCGPU_EINVAL, "null region");
     if (!r->has_reads) return fail(UVCGPU_ENOREADS, "no reads");   // process_batch returns -1, main.cpp:520-523
-    HIP_OK(hipMemsetAsync(r->d_state, 0, r->state_bytes, r->stream));
+    HIP_OK(hipMemsetAsync(r->d_state, 0, r->buckets_clean ? r->bucket_off : r->state_bytes, r->stream));
+    r->buckets_clean = false;
     HIP_OK(hipMemcpyAsync(r->d_rtr, r->d_rtr0, (size_t)4 * UVC_NRTR * r->npos, hipMemcpyDeviceToDevice, r->stream));   // P1b edits indelphred in place
     HIP_OK(hipMemsetAsync(r->R.frag_nmut, 0, sizeof(int32_t) * (size_t)r->R.n_frags, r->stream));
     HIP_OK(hipMemsetAsync(r->R.n_overflow, 0, sizeof(int32_t), r->stream));
@@ -401,6 +403,7 @@ int uvcgpu_region_accumulate(uvcgpu_region_t *r) {
     const int half = (int)std::round((10.0 / std::log(10.0)) * std::log(r->P.indel_del_to_ins_err_ratio)) / 2;   // main.hpp:1244
     uvc_launch_accumulate(&r->R, &r->P, half, r->d_dup_units, r->n_dup, r->d_dup_off, r->n_dup_work, r->stream, &r->prof);
     HIP_OK(hipGetLastError());
+    r->buckets_clean = (r->P.inferred_is_vcf_generated != 0);   // k_frag (P3b) and k_p5b cleared every bucket they consumed
     r->accumulated = true;
     return 0;
 }

@@ -1813,10 +1813,13 @@ __global__ void __launch_bounds__(256) k_p5b(RegionDev R, UvcParams P) {
         for (int s = sb; s <= se; s++) totDP += FAP(R, strand, UVC_FAM_cDP1, s, x);
         if (totDP == 0) continue;
         for (int s = sb; s <= se; s++) {
+            if (0 == FAP(R, strand, UVC_FAM_cDP1, s, x)) continue;   // k_fam_p5 fills a bucket only next to a cDP1 increment of the same symbol: empty histogram, all outputs 0
             const int max_qual = sscs_phred(P, ref_symbol, s) + (!P.tumor_vcf_is_provided ? 0 : 4);
             int mv, ad, bq;
             infer_max_qual(mv, ad, bq, max_qual, 4, totDP, [&](int b) { return BKP(R, strand, s, b, x); });
             if (mv | ad | bq) { VQP(R, qIAQ, s, x) += mv; VQP(R, qIAD, s, x) += ad; VQP(R, qIDQ, s, x) += bq; }
+            // the bucket planes are transient: leave them zero so that the next accumulate need not clear them
+            for (int b = 0; b < NBUCKETS; b++) if (BKP(R, strand, s, b, x)) BKP(R, strand, s, b, x) = 0;
         }
     }
 }
