@@ -50,11 +50,12 @@ struct AlnRec {
 // records (one per lane, coalesced) and broadcasts the fields of record j with v_readlane, so the per-read scalars never
 // cost a dependent memory round trip inside the loop.
 struct FastRec {
-    int32_t pos, rend, qb_lo, qb_hi;        // qbase split into two dwords
+    int32_t pos, rend, qb_lo, aln;          // [pos, rend): covered positions (the whole read, or one M run of an InDel read); qb_lo: low word of
+                                            // (index of the base at position p) - p; aln: index into alns[]
     int32_t fmd, isize, mpos, xm1500;       // fmd = flag | mapq << 16 | dflag << 24
     int32_t bmv, xbv, bm4c, clips;          // bmv: a2BM2 increment (<= 100) of base symbols 0..3, one byte each; xbv: that of symbol 4 | a2XM2 increment << 8;
                                             // bm4c: clip_cnt << 16 | nogap_penal << 20; clips = lclip_oplen | rclip_oplen << 16
-    int32_t baq_pos, baq_last, baq2_last, pad;
+    int32_t baq_pos, baq_last, baq2_last, ext;   // ext: (pos - read start) | (read end - rend) << 16, zero for a whole read
 };
 
 struct FragRec {
@@ -112,6 +113,8 @@ struct RegionDev {
     AlnRec *alns; int32_t n_alns;
     AlnRec *fast; int32_t n_fast;   // simple alignments, sorted by pos
     FastRec *frec;                  // [n_fast] digest of fast[]
+    FastRec *frec2; int32_t n_fast2; int32_t max_p2_span;   // P2 work list, sorted by pos: simple alignments + the M runs of InDel reads whose
+                                    // InDels are all high-quality (kind 2), which behave like simple alignments in P2 (see k_p2_fast)
     const int32_t *complex_ids; int32_t n_complex;
     FragRec *frags; int32_t n_frags;
     int32_t *frag_nmut; int32_t *frag_mut;          // mutation events per fragment: count + up to UVC_MAXEV positions

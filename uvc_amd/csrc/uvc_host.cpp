@@ -15,6 +15,7 @@ struct RawReads {
     const int64_t *seq_off, *cigar_off, *table_off, *item_off;
 };
 extern "C" void uvc_launch_pack_bq(const uint8_t *bases, const uint8_t *quals, uint16_t *bq, int64_t n, hipStream_t s);
+extern "C" void uvc_launch_build_p2list(const RegionDev *R, const int32_t *aln, const int32_t *cbeg, const int32_t *cend, const int32_t *qb, hipStream_t s);
 extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const UvcParams *P, hipStream_t s);
 struct UvcProf { int on; int n; const char *name[24]; hipEvent_t ev[24][2]; };
 extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, int half_ratio_phred,
@@ -243,6 +244,12 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     int prev_fam = -1, prev_strand = -1, prev_frag = -1;
     int64_t table_rows = 0;
     int32_t max_aln_span = 1, max_frag_span = 1;
+    struct P2Seg { int32_t cbeg, cend, aln, qb; };
+    std::vector<P2Seg> p2; p2.reserve((size_t)n + 1024);
+    const UvcParams &P0 = r->P;
+    // see k_p2_fast: the M runs of an InDel read can take the simple path when its dist_to_interfering_indel is "far" everywhere, which
+    // needs no low-quality InDel in the read, a region that does not start next to coordinate 0 and the default-range threshold
+    const bool seg_eligible = (UVC_PLATFORM_IONTORRENT != P0.inferred_sequencing_platform) && r->beg >= 65536 && P0.bias_thres_interfering_indel <= 10000;
     for (int64_t i = 0; i < n; i++) {
         const int32_t nc = in->n_cigar[i], lq = in->l_qseq[i];
         if (in->seq_off[i] < 0 || in->seq_off[i] + lq > in->n_bases || in->cigar_off[i] < 0 || in->cigar_off[i] + nc > in->n_cigar_ops || nc < 1) return fail(UVCGPU_EINVAL, "read offsets out of range");
@@ -283,6 +290,31 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
         u.frag_end = (int32_t)frags.size(); u.beg = std::min(u.beg, in->pos[i]); u.end = std::max(u.end, e) + 1;
         frag_of[i] = (int32_t)frags.size() - 1; fs_of[i] = (int32_t)fss.size() - 1; dflag_of[i] = in->fam_dflag[fam];
         kind[i] = simple ? 0 : 1;
+        {   // P2 work list (k_p2_fast): a simple alignment is one entry; an InDel read whose InDels are all high-quality contributes its M runs
+            const size_t mark = p2.size();
+            bool ok = simple || seg_eligible;
+            int32_t rp = in->pos[i]; int64_t qp = 0;
+            const uint8_t *qq = in->quals + in->seq_off[i];
+            auto Q = [&](int64_t q2) -> int { return (int)qq[std::min<int64_t>(std::max<int64_t>(q2, 0), lq - 1)]; };
+            for (int k = 0; k < nc && ok; k++) {
+                const int op = (int)(cg[k] & 0xF); const int32_t len = (int32_t)(cg[k] >> 4);
+                if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) {
+                    if (rp - in->pos[i] > 65535 || e - (rp + len) > 65535) ok = false;
+                    p2.push_back(P2Seg{ rp, rp + len, (int32_t)i, (int32_t)((in->seq_off[i] + qp - rp) & 0xFFFFFFFFLL) });
+                    rp += len; qp += len;
+                } else if (op == C_INS) {   // low-quality InDels make dist_to_interfering_indel position dependent (main.hpp:1817-1859): not eligible
+                    for (int64_t q2 = qp - std::min<int64_t>(qp, 1); q2 < std::min<int64_t>(qp + len + 1, e); q2++) if (Q(q2) < P0.bias_thres_interfering_indel_BQ) ok = false;
+                    qp += len;
+                } else if (op == C_DEL) {
+                    if (std::min(Q(std::max<int64_t>(1, qp) - 1), Q(qp)) <= P0.bias_thres_interfering_indel_BQ) ok = false;
+                    rp += len;
+                } else if (op == C_SOFT_CLIP) qp += len;
+                else if (op == C_HARD_CLIP) {}
+                else ok = false;   // N / P: keep the sequential path
+            }
+            if (!ok) p2.resize(mark);
+            else if (!simple) kind[i] = 2;
+        }
         if (!simple) {
             table_off[i] = table_rows; table_rows += (e - in->pos[i]);
             int64_t del_total = 0; for (int k = 0; k < nc; k++) if ((cg[k] & 0xF) == C_DEL) del_total += (cg[k] >> 4);
@@ -371,6 +403,16 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     // table rows are written by k_p2_slow<false>; mark all slots empty (0xFF)
     HIP_OK(hipMemsetAsync(R.table, 0xFF, std::max<int64_t>(table_rows, 1) * sizeof(Contrib), r->stream));
     uvc_launch_prelude(&R, &W, &r->P, r->stream);
+    {
+        std::stable_sort(p2.begin(), p2.end(), [](const P2Seg &a, const P2Seg &b) { return a.cbeg < b.cbeg; });
+        std::vector<int32_t> v_aln(p2.size()), v_beg(p2.size()), v_end(p2.size()), v_qb(p2.size());
+        int32_t span = 1;
+        for (size_t j = 0; j < p2.size(); j++) { v_aln[j] = p2[j].aln; v_beg[j] = p2[j].cbeg; v_end[j] = p2[j].cend; v_qb[j] = p2[j].qb; span = std::max(span, p2[j].cend - p2[j].cbeg); }
+        int32_t *d_aln, *d_beg, *d_end, *d_qb;
+        if ((rc = upload(r, v_aln, &d_aln)) || (rc = upload(r, v_beg, &d_beg)) || (rc = upload(r, v_end, &d_end)) || (rc = upload(r, v_qb, &d_qb))) return rc;
+        { std::vector<FastRec> v(p2.size()); FastRec *d; if ((rc = upload(r, v, &d))) return rc; R.frec2 = d; R.n_fast2 = (int32_t)p2.size(); R.max_p2_span = span; }
+        uvc_launch_build_p2list(&R, d_aln, d_beg, d_end, d_qb, r->stream);
+    }
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(r->stream));   // the staging vectors above die here
     {   // the queue of mismatching bases (k_p2_fast -> k_p2_mism) is sized from the count the prelude made

@@ -322,6 +322,30 @@ struct RawReads {
     const int64_t *seq_off, *cigar_off, *table_off, *item_off;
 };
 
+// digest of alignment `a` (index `id`) for the position-centric kernels, covering [cbeg, cend) with query offset qb_lo
+DEV void fill_fastrec(FastRec &f, const AlnRec &a, int id, int cbeg, int cend, int32_t qb_lo) {
+    f.pos = cbeg; f.rend = cend; f.qb_lo = qb_lo; f.aln = id;
+    f.fmd = (a.flag & 0xFFFF) | ((a.mapq & 0xFF) << 16) | ((a.dflag & 0xFF) << 24); f.isize = a.isize; f.mpos = a.mpos; f.xm1500 = a.xm1500;
+    // per-read constants of dealwith_segbias<false>: the a2XM2 / a2BM2 increments (main.hpp:1521-1522), each <= 100
+    int bv[5];
+    for (int s2 = 0; s2 < 5; s2++) bv[s2] = (a.bm1500[s2] > 20 ? (100 * (20 * 20) / (a.bm1500[s2] * a.bm1500[s2])) : 100);
+    const int xv = (a.xm1500 > 20 ? (100 * (20 * 20) / (a.xm1500 * a.xm1500)) : 100);
+    f.bmv = bv[0] | (bv[1] << 8) | (bv[2] << 16) | (bv[3] << 24); f.xbv = bv[4] | (xv << 8);
+    f.bm4c = ((a.clip_cnt & 0xF) << 16) | ((a.nogap_penal & 0xF) << 20);
+    f.clips = (a.lclip_oplen & 0xFFFF) | (a.rclip_oplen << 16);
+    f.baq_pos = (int32_t)a.baq_pos; f.baq_last = (int32_t)a.baq_last; f.baq2_last = (int32_t)a.baq2_last;
+    f.ext = ((cbeg - a.pos) & 0xFFFF) | ((a.rend - cend) << 16);
+}
+
+// P2 work list: entry j covers [cbeg[j], cend[j]) of alignment aln[j] (host-sorted by cbeg)
+__global__ void __launch_bounds__(256) k_build_p2list(RegionDev R, const int32_t *aln, const int32_t *cbeg, const int32_t *cend, const int32_t *qb) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= R.n_fast2) return;
+    FastRec f;
+    fill_fastrec(f, R.alns[aln[j]], aln[j], cbeg[j], cend[j], qb[j]);
+    R.frec2[j] = f;
+}
+
 __global__ void __launch_bounds__(256) k_aln_prelude(RegionDev R, RawReads W, UvcParams P) {
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= R.n_alns) return;
@@ -370,21 +394,14 @@ __global__ void __launch_bounds__(256) k_aln_prelude(RegionDev R, RawReads W, Uv
     a.baq_pos = BAQ1(R, a.pos); a.baq_last = BAQ1(R, a.rend - 1); a.baq2_last = BAQ2(R, a.rend - 1);
     R.alns[id] = a;
     const int rk = W.fast_rank[id];
-    if (rk >= 0) {
+    if (rk >= 0 || a.kind == 2) {   // every alignment on the P2 work list: its mismatching bases go through the mismatch queue
         const int n_mis = bm[0] + bm[1] + bm[2] + bm[3] + bm[4];
         if (n_mis) atomicAdd(R.mis_total, (unsigned long long)n_mis);
+    }
+    if (rk >= 0) {
         R.fast[rk] = a;
         FastRec f;
-        f.pos = a.pos; f.rend = a.rend; f.qb_lo = (int32_t)(a.qbase & 0xFFFFFFFFLL); f.qb_hi = (int32_t)(a.qbase >> 32);
-        f.fmd = (a.flag & 0xFFFF) | ((a.mapq & 0xFF) << 16) | ((a.dflag & 0xFF) << 24); f.isize = a.isize; f.mpos = a.mpos; f.xm1500 = a.xm1500;
-        // per-read constants of dealwith_segbias<false>: the a2XM2 / a2BM2 increments (main.hpp:1521-1522), each <= 100
-        int bv[5];
-        for (int s2 = 0; s2 < 5; s2++) bv[s2] = (a.bm1500[s2] > 20 ? (100 * (20 * 20) / (a.bm1500[s2] * a.bm1500[s2])) : 100);
-        const int xv = (a.xm1500 > 20 ? (100 * (20 * 20) / (a.xm1500 * a.xm1500)) : 100);
-        f.bmv = bv[0] | (bv[1] << 8) | (bv[2] << 16) | (bv[3] << 24); f.xbv = bv[4] | (xv << 8);
-        f.bm4c = ((a.clip_cnt & 0xF) << 16) | ((a.nogap_penal & 0xF) << 20);
-        f.clips = (a.lclip_oplen & 0xFFFF) | (a.rclip_oplen << 16);
-        f.baq_pos = (int32_t)a.baq_pos; f.baq_last = (int32_t)a.baq_last; f.baq2_last = (int32_t)a.baq2_last; f.pad = 0;
+        fill_fastrec(f, a, id, a.pos, a.rend, (int32_t)(a.qbase & 0xFFFFFFFFLL));
         R.frec[rk] = f;
     }
 }
@@ -757,8 +774,8 @@ DEV int simple_base_value(const UvcParams &P, const AlnRec &a, int p, const uint
 DEV void mis_apply(const RegionDev &R, const UvcParams &P, const MisItem &it) {
     const int64_t x = it.epos - R.beg;
     const int sym = it.symval & 0xFF, inc = it.symval >> 8;
-    if ((unsigned)it.rank >= (unsigned)R.n_fast || x < 0 || x >= R.npos || sym > UVC_BASE_NN) { atomicExch(R.err, UVCGPU_EDEVICE); return; }   // corrupt queue entry
-    const AlnRec &a = R.fast[it.rank];
+    if ((unsigned)it.rank >= (unsigned)R.n_alns || x < 0 || x >= R.npos || sym > UVC_BASE_NN) { atomicExch(R.err, UVCGPU_EDEVICE); return; }   // corrupt queue entry
+    const AlnRec &a = R.alns[it.rank];
     const SegRead sr = make_segread(R, a);
     PosThres T;
     load_thres(R, T, x);
@@ -804,8 +821,8 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
     // LINK_M value of a simple read at this position is a per-position constant up to the read's penalty (main.hpp:1919-1923)
     int noindel80 = 80;
     if (DO_L && valid && x > 0) noindel80 = imin(80, imin(RTRP(R, UVC_RTR_indelphred, x - 1), RTRP(R, UVC_RTR_indelphred, x)));
-    const int lo = wave_uniform(lower_bound_frec(R.frec, R.n_fast, w0 - R.max_aln_span + 1));
-    const int hi = wave_uniform(lower_bound_frec(R.frec, R.n_fast, w0 + 64));
+    const int lo = wave_uniform(lower_bound_frec(R.frec2, R.n_fast2, w0 - R.max_p2_span + 1));
+    const int hi = wave_uniform(lower_bound_frec(R.frec2, R.n_fast2, w0 + 64));
     MisItem *myq = misq[DO_B ? (threadIdx.x >> 6) : 0];
     int nq = 0;   // wave-uniform: only updated in uniform control flow
     auto flush_queue = [&]() {
@@ -821,7 +838,7 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
     const __amdgpu_buffer_rsrc_t rs = bq_rsrc(R);
     for (int k0 = lo; k0 < hi; k0 += 64) {
         Chunk16 c;
-        load_chunk16(R.frec, k0 + lane, hi, c);
+        load_chunk16(R.frec2, k0 + lane, hi, c);
         const int n = imin(64, hi - k0);
         int bqn = 0;
         auto issue = [&](int j) {
@@ -834,11 +851,12 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
             const int apos = bcast(c.v[0], j), rend = bcast(c.v[1], j);
             if (rend <= w0) continue;
             const int fmd = bcast(c.v[4], j);
-            SegRead sr;
-            sr.pos = apos; sr.rend = rend; sr.flag = fmd & 0xFFFF; sr.mapq = (fmd >> 16) & 0xFF; sr.dflag = (fmd >> 24) & 0xFF;
+            const int ext = bcast(c.v[15], j);
+            SegRead sr;   // [apos, rend) is what this entry covers; the bias arithmetic uses the ends of the whole alignment
+            sr.pos = apos - (ext & 0xFFFF); sr.rend = rend + (int)((unsigned)ext >> 16); sr.flag = fmd & 0xFFFF; sr.mapq = (fmd >> 16) & 0xFF; sr.dflag = (fmd >> 24) & 0xFF;
             sr.isize = bcast(c.v[5], j);
             const int mpos = bcast(c.v[6], j);
-            sr.frag_pos_L = imin(apos, mpos); sr.frag_pos_R = sr.frag_pos_L + abs(sr.isize);
+            sr.frag_pos_L = imin(sr.pos, mpos); sr.frag_pos_R = sr.frag_pos_L + abs(sr.isize);
             sr.xm1500 = bcast(c.v[7], j);
             const int bm4c = bcast(c.v[10], j);
             sr.clip_cnt = (bm4c >> 16) & 0xF;
@@ -848,8 +866,8 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
             bool gate = true;
             if (is_assay_amplicon && !normal_filter_primers) {   // primer gating, main.hpp:1872-1875, 1895
                 const bool isrc = (sr.flag & 0x10) != 0;
-                const int ibeg = ((sr.isize != 0) ? (sr.frag_pos_L + P.primerlen) : ((isrc && (0x0 == (0x1 & sr.flag))) ? 0 : (apos + P.primerlen)));
-                const int iend = ((sr.isize != 0) ? (int)nnminus(sr.frag_pos_L + abs(sr.isize), P.primerlen) : ((isrc && (0x0 == (0x1 & sr.flag))) ? (int)nnminus(rend, P.primerlen) : INT32_MAX));
+                const int ibeg = ((sr.isize != 0) ? (sr.frag_pos_L + P.primerlen) : ((isrc && (0x0 == (0x1 & sr.flag))) ? 0 : (sr.pos + P.primerlen)));
+                const int iend = ((sr.isize != 0) ? (int)nnminus(sr.frag_pos_L + abs(sr.isize), P.primerlen) : ((isrc && (0x0 == (0x1 & sr.flag))) ? (int)nnminus(sr.rend, P.primerlen) : INT32_MAX));
                 gate = (ibeg <= p && p < iend);
             }
             // the queue bookkeeping below must run in wave-uniform control flow (nq is a scalar): no divergent `continue` before it
@@ -858,7 +876,7 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
             int inc = 0, incL = 0;
             if (proton) {   // IonTorrent values need neighbouring qualities and clip lengths: take them from the full record
                 if (cover) {
-                    const AlnRec &a = R.fast[k0 + j];
+                    const AlnRec &a = R.alns[bcast(c.v[3], j)];
                     if (DO_B) inc = simple_base_value(P, a, p, R.quals + a.qbase, true);
                     if (DO_L) incL = (p > apos ? simple_link_value(R, P, a, p, R.quals + a.qbase, true) : 0);
                 }
@@ -866,7 +884,7 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
             const wmask mm = DO_B ? BAL(cover && !hasB) : 0ull;
             if (DO_B && mm) {   // bases that differ from the reference go to the wave's queue; k_p2_mism applies them
                 if (nq > MISQ_CAP - 64) flush_queue();
-                if (cover && !hasB) { MisItem it; it.rank = k0 + j; it.epos = p; it.symval = sym | (inc << 8); myq[nq + (int)__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = it; }
+                if (cover && !hasB) { MisItem it; it.rank = bcast(c.v[3], j); it.epos = p; it.symval = sym | (inc << 8); myq[nq + (int)__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = it; }
                 nq += (int)__builtin_popcountll(mm);
             }
             if (cover) {
@@ -1006,6 +1024,7 @@ __global__ void __launch_bounds__(64) k_p2_slow(RegionDev R, UvcParams P) {
     for (int i = 0; i < n_cigar; i++) {
         const int op = cig_op(cigar[i]), len = cig_len(cigar[i]);
         if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) {
+            if (BIAS && a.kind == 2) { rpos += len; qpos += len; continue; }   // the M runs of this read are on the P2 work list of k_p2_fast
             for (int i2 = 0; i2 < len; i2++) {
                 if ((normal_filter_primers || !is_assay_amplicon) || (ibeg <= rpos && rpos < iend)) {
                     int dist = 10000;
@@ -1845,6 +1864,9 @@ __global__ void __launch_bounds__(256) k_pack_bq(const uint8_t *bases, const uin
 }
 extern "C" void uvc_launch_pack_bq(const uint8_t *bases, const uint8_t *quals, uint16_t *bq, int64_t n, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_pack_bq, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65536)), dim3(256), 0, s, bases, quals, bq, n);
+}
+extern "C" void uvc_launch_build_p2list(const RegionDev *R, const int32_t *aln, const int32_t *cbeg, const int32_t *cend, const int32_t *qb, hipStream_t s) {
+    if (R->n_fast2) hipLaunchKernelGGL(k_build_p2list, dim3(nblk(R->n_fast2, 256)), dim3(256), 0, s, *R, aln, cbeg, cend, qb);
 }
 extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const UvcParams *P, hipStream_t s) {
     if (R->n_alns) hipLaunchKernelGGL(k_aln_prelude, dim3(nblk(R->n_alns, 256)), dim3(256), 0, s, *R, *W, *P);
