@@ -85,13 +85,16 @@ struct Item { int32_t epos; uint8_t sym, flags /* bit0 isGap, bits 1..4 cigar op
 // queues it here and k_p2_mism applies it (one lane per item).  symval = sym | value << 8.
 struct MisItem { int32_t rank, epos, symval; };
 
-// compact per-fragment record for k_frag, stored in beg-sorted order (written by k_fragstat_fast)
+// compact per-fragment record for k_frag, stored in beg-sorted order (written by k_fragstat_fast).  A fragment of <= 2
+// alignments, each with at most one InDel, is described by up to two M runs per alignment (run B empty for a simple alignment)
+// plus, per alignment, the "special" positions around its InDel, which k_frag leaves to k_frag_generic.
 struct FragFast {
-    int32_t beg, end, fi, flags;        // flags: bit0 kind (1 = generic path), bit1 strand, bit2 singleton, bits 3.. number of alignments
-    int32_t pos0, rend0, pos1, rend1;
-    int64_t qbase0, qbase1;
-    int32_t nogap0, nogap1, sq, n_cov;  // sq = normMQ^2 / SQR_QUAL_DIV
-    int32_t n_near, pad0_, pad1_, pad2_;
+    int32_t beg, end, fi, flags;        // flags: bit0 generic path only, bit1 strand, bit2 singleton, bits 3..6 number of alignments, bit8 has runs B / special ranges
+    int32_t pos0, rend0, pos1, rend1;   // run A of alignment 0 / 1: [pos, rend)
+    int32_t qb0, qb1, nogap0, nogap1;   // low word of the query offset of run A; micro_nogap_penal of the alignment
+    int32_t sq, n_cov, n_near, pad_;    // sq = normMQ^2 / SQR_QUAL_DIV
+    int32_t bpos0, brend0, bqb0, sp0;   // run B of alignment 0, its query offset; sp = special range (beg - fragment beg) | length << 16
+    int32_t bpos1, brend1, bqb1, sp1;
 };
 
 // contribution of one alignment at one reference position under BASE_QUALITY_MAX (main.hpp:1980, 1924, 2077, 2192, 2223)

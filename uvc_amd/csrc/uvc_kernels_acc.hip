@@ -1306,24 +1306,68 @@ __global__ void __launch_bounds__(64) k_fragstat_sweep(RegionDev R, UvcParams P,
 }
 
 // closed form for fragments of <= 2 simple alignments: coverage = union of the alignment spans, mutations = the event list
+// M runs and special range of one alignment for k_frag; false when it has more than one InDel or a reference skip
+DEV bool aln_runs(const RegionDev &R, const AlnRec &a, int &pA, int &eA, int &qA, int &pB, int &eB, int &qB, int &sp_beg, int &sp_len) {
+    const uint32_t *cigar = R.cigars + a.cigar_off;
+    int rp = a.pos; long long qp = 0; int n_runs = 0, n_indel = 0;
+    pA = eA = qA = pB = eB = qB = 0; sp_beg = a.pos; sp_len = 0;
+    for (int i = 0; i < a.n_cigar; i++) {
+        const int op = cig_op(cigar[i]), len = cig_len(cigar[i]);
+        if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) {
+            const int qb = (int)((a.seq_off + qp - rp) & 0xFFFFFFFFLL);
+            if (n_runs == 0) { pA = rp; eA = rp + len; qA = qb; } else if (n_runs == 1) { pB = rp; eB = rp + len; qB = qb; } else return false;
+            n_runs++; rp += len; qp += len;
+        } else if (op == C_INS) { if (++n_indel > 1) return false; sp_beg = rp; sp_len = 1; qp += len; }
+        else if (op == C_DEL) { if (++n_indel > 1) return false; sp_beg = rp; sp_len = len + 1; rp += len; }
+        else if (op == C_SOFT_CLIP) qp += len;
+        else if (op == C_HARD_CLIP) {}
+        else return false;
+    }
+    if (sp_beg + sp_len > a.rend) sp_len = imax(0, a.rend - sp_beg);   // nothing is emitted at or past the end of the alignment
+    return n_runs >= 1 && sp_len < 32768;
+}
+
+// closed form for fragments of <= 2 simple alignments: coverage = union of the alignment spans, mutations = the event list
 __global__ void __launch_bounds__(256) k_fragstat_fast(RegionDev R, UvcParams P) {
     const int fi = blockIdx.x * blockDim.x + threadIdx.x;
     if (fi >= R.n_frags) return;
     const FragRec f = R.frags[fi];
     FragFast ff;
+    memset(&ff, 0, sizeof(ff));
     ff.beg = f.beg; ff.end = f.end; ff.fi = fi;
     ff.flags = (f.stat_kind ? 1 : 0) | (f.strand << 1) | (f.singleton << 2) | ((f.aln_end - f.aln_beg) << 3);
-    ff.pos0 = ff.rend0 = ff.pos1 = ff.rend1 = 0; ff.qbase0 = ff.qbase1 = 0; ff.nogap0 = ff.nogap1 = 0;
-    ff.sq = (f.normMQ * f.normMQ) / SQR_QUAL_DIV; ff.n_cov = 0; ff.n_near = 0; ff.pad0_ = ff.pad1_ = ff.pad2_ = 0;
-    if (f.stat_kind != 0) { R.ffast[R.frag_rank[fi]] = ff; return; }
+    ff.sq = (f.normMQ * f.normMQ) / SQR_QUAL_DIV;
+    if (f.stat_kind != 0) {
+        // fragments with InDel reads: k_frag can still take every position outside the InDels' neighbourhoods when the alignments
+        // decompose into <= 2 M runs each (n_cov / n_near arrive from k_fragstat_sweep)
+        const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+        const bool amplicon_gated = (((f.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag))) && !(P.tn_is_paired && (0x1 & P.primer_flag)));
+        const int n_aln = f.aln_end - f.aln_beg;
+        bool ok = (!proton && !amplicon_gated && n_aln <= 2 && f.end - f.beg < 65536);
+        int sb, sl;
+        if (ok) {
+            const AlnRec &x0 = R.alns[f.aln_beg];
+            ok = aln_runs(R, x0, ff.pos0, ff.rend0, ff.qb0, ff.bpos0, ff.brend0, ff.bqb0, sb, sl);
+            ff.nogap0 = x0.nogap_penal; ff.sp0 = (sb - f.beg) | (sl << 16);
+            if (sb < f.beg) ok = false;
+        }
+        if (ok && n_aln == 2) {
+            const AlnRec &x1 = R.alns[f.aln_beg + 1];
+            ok = aln_runs(R, x1, ff.pos1, ff.rend1, ff.qb1, ff.bpos1, ff.brend1, ff.bqb1, sb, sl);
+            ff.nogap1 = x1.nogap_penal; ff.sp1 = (sb - f.beg) | (sl << 16);
+            if (sb < f.beg) ok = false;
+        }
+        if (ok) ff.flags = (ff.flags & ~1) | 0x100;
+        R.ffast[R.frag_rank[fi]] = ff; return;
+    }
     const int nm = R.frag_nmut[fi];
     // coverage intervals [a1,b1) u [a2,b2), disjoint and ordered
     const AlnRec &x0 = R.alns[f.aln_beg];
-    ff.pos0 = x0.pos; ff.rend0 = x0.rend; ff.qbase0 = x0.qbase; ff.nogap0 = x0.nogap_penal;
+    ff.pos0 = x0.pos; ff.rend0 = x0.rend; ff.qb0 = (int32_t)(x0.qbase & 0xFFFFFFFFLL); ff.nogap0 = x0.nogap_penal;
     int a1 = x0.pos, b1 = x0.rend, a2 = 0, b2 = 0;
     if (f.aln_end - f.aln_beg == 2) {
         const AlnRec &x1 = R.alns[f.aln_beg + 1];
-        ff.pos1 = x1.pos; ff.rend1 = x1.rend; ff.qbase1 = x1.qbase; ff.nogap1 = x1.nogap_penal;
+        ff.pos1 = x1.pos; ff.rend1 = x1.rend; ff.qb1 = (int32_t)(x1.qbase & 0xFFFFFFFFLL); ff.nogap1 = x1.nogap_penal;
         int c = x1.pos, d = x1.rend;
         if (c < a1) { int t = a1; a1 = c; c = t; t = b1; b1 = d; d = t; }
         if (c <= b1) { b1 = imax(b1, d); } else { a2 = c; b2 = d; }
@@ -1361,13 +1405,29 @@ __global__ void __launch_bounds__(64) k_frag_generic(RegionDev R, UvcParams P, c
     const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
     const bool padded_ignored = (P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0;
     const bool vcfgen = P.inferred_is_vcf_generated;
+    // grid = (fragments, 64-position chunks of the longest fragment): the work of a fragment is a chain of dependent loads per
+    // position, so more, shorter waves hide it better than one wave striding over the whole span
     for (int t = blockIdx.x; t < n_list; t += gridDim.x) {
         const int fi = (list ? list[t] : t);
         const FragRec &f = R.frags[fi];
         const int strand = f.strand;
         const bool singleton = f.singleton;
         const int fsq = (f.normMQ * f.normMQ) / SQR_QUAL_DIV;
-        for (int p = imax(f.beg, R.beg) + (int)threadIdx.x; p < imin(f.end, R.end); p += 64) {
+        const FragFast &ff = R.ffast[R.frag_rank[fi]];
+        const bool special_only = (ff.flags & 0x100) != 0;   // k_frag takes every other position of this fragment
+        const int sp0 = ff.sp0, sp1 = ff.sp1;
+        const int n0 = (special_only ? (sp0 >> 16) : 0), n1 = (special_only ? (sp1 >> 16) : 0);
+        const int p_lo = imax(f.beg, R.beg), p_hi = imin(f.end, R.end);
+        const int n_work = (special_only ? n0 + n1 : p_hi - p_lo);
+        for (int w = (int)(blockIdx.y * 64 + threadIdx.x); w < n_work; w += 64 * gridDim.y) {
+            int p;
+            if (!special_only) p = p_lo + w;
+            else {
+                p = (w < n0 ? f.beg + (sp0 & 0xFFFF) + w : f.beg + (sp1 & 0xFFFF) + (w - n0));
+                // a position in both ranges is done once, by the first
+                if (w >= n0 && (unsigned)(p - (f.beg + (sp0 & 0xFFFF))) < (unsigned)n0) continue;
+                if (p < p_lo || p >= p_hi) continue;
+            }
             const int64_t x = p - R.beg;
             const int my_ref = R.refsym[x];
             int cnt[NSYM];
@@ -1493,22 +1553,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,5)))
     auto maxq_generic = [&](int cs) { return cs == UVC_LINK_M ? maxq_link : (cs <= UVC_BASE_N ? maxq_base(cs) : maxq_at(cs)); };
     const __amdgpu_buffer_rsrc_t rs = bq_rsrc(R);
     for (int k0 = lo; k0 < hi; k0 += 64) {
-        // one FragFast (20 dwords) per lane, fields of record j broadcast with v_readlane; base/qual bytes of record j+1 are
+        // one FragFast (24 dwords) per lane, fields of record j broadcast with v_readlane; base/qual bytes of record j+1 are
         // requested before record j is processed
-        int c[20];
+        int c[24];
         if (k0 + lane < hi) {
             const int4 *q4 = (const int4 *)(R.ffast + (k0 + lane));
 #pragma unroll
-            for (int i = 0; i < 5; i++) { const int4 t = q4[i]; c[4 * i] = t.x; c[4 * i + 1] = t.y; c[4 * i + 2] = t.z; c[4 * i + 3] = t.w; }
+            for (int i = 0; i < 6; i++) { const int4 t = q4[i]; c[4 * i] = t.x; c[4 * i + 1] = t.y; c[4 * i + 2] = t.z; c[4 * i + 3] = t.w; }
         } else {
 #pragma unroll
-            for (int i = 0; i < 20; i++) c[i] = 0;
+            for (int i = 0; i < 24; i++) c[i] = 0;
         }
         const int n = imin(64, hi - k0);
         int bq0n = 0, bq1n = 0;
         auto issue = [&](int j) {
-            bq0n = bq_load(rs, bcast(c[8], j) + p);
-            if ((bcast(c[3], j) >> 3) == 2) bq1n = bq_load(rs, bcast(c[10], j) + p);
+            const int fl = bcast(c[3], j);
+            int i0 = bcast(c[8], j), i1 = bcast(c[9], j);
+            if (fl & 0x100) {   // the lane's position may lie in run B of either alignment
+                if (p >= bcast(c[16], j) && p < bcast(c[17], j)) i0 = bcast(c[18], j);
+                if (p >= bcast(c[20], j) && p < bcast(c[21], j)) i1 = bcast(c[22], j);
+            }
+            bq0n = bq_load(rs, i0 + p);
+            if (((fl >> 3) & 0xF) == 2) bq1n = bq_load(rs, i1 + p);
         };
         if (proton) break;   // IonTorrent values need neighbouring qualities: every fragment takes k_frag_generic
         issue(0);
@@ -1517,18 +1583,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,5)))
             if (j + 1 < n) issue(j + 1);
             const int fbeg = bcast(c[0], j), fend = bcast(c[1], j), flags = bcast(c[3], j);
             if (fend <= w0) continue;
+            if (flags & 1) continue;   // done by k_frag_generic
             if (!(valid && p >= fbeg && p < fend)) continue;
             const int strand = (flags >> 1) & 1;
             const bool singleton = (flags >> 2) & 1;
-            if (flags & 1) continue;   // complex fragments were done by k_frag_generic
             {
-                // consensus of <= 2 simple alignments in registers, written with selects (BASE_QUALITY_MAX merge, main.hpp:339-349)
+                // consensus of <= 2 alignments in registers, written with selects (BASE_QUALITY_MAX merge, main.hpp:339-349)
                 const int pos0 = bcast(c[4], j), rend0 = bcast(c[5], j), pos1 = bcast(c[6], j), rend1 = bcast(c[7], j);
-                const int nogap0 = bcast(c[12], j), nogap1 = bcast(c[13], j), sq = bcast(c[14], j), n_cov = bcast(c[15], j), n_near = bcast(c[16], j);
-                const bool has2 = ((flags >> 3) == 2);
-                const bool in0 = (p >= pos0 && p < rend0), in1 = (has2 && p >= pos1 && p < rend1);
+                const int nogap0 = bcast(c[10], j), nogap1 = bcast(c[11], j), sq = bcast(c[12], j), n_cov = bcast(c[13], j), n_near = bcast(c[14], j);
+                const bool has2 = (((flags >> 3) & 0xF) == 2);
+                bool in0 = (p >= pos0 && p < rend0), in1 = (has2 && p >= pos1 && p < rend1);
+                bool lk0 = (in0 && p > pos0), lk1 = (in1 && p > pos1);   // LINK_M exists from the second base of a run on
+                if (flags & 0x100) {
+                    const int bpos0 = bcast(c[16], j), brend0 = bcast(c[17], j), bpos1 = bcast(c[20], j), brend1 = bcast(c[21], j);
+                    const int sp0 = bcast(c[19], j), sp1 = bcast(c[23], j);
+                    const bool inb0 = (p >= bpos0 && p < brend0), inb1 = (p >= bpos1 && p < brend1);
+                    in0 = in0 || inb0; in1 = in1 || inb1;
+                    lk0 = lk0 || (inb0 && p > bpos0); lk1 = lk1 || (inb1 && p > bpos1);
+                    // positions next to an InDel carry InDel symbols / padded-deletion symbols: k_frag_generic does them for this fragment
+                    const unsigned off = (unsigned)(p - fbeg);
+                    if (off - (unsigned)(sp0 & 0xFFFF) < (unsigned)(sp0 >> 16) || off - (unsigned)(sp1 & 0xFFFF) < (unsigned)(sp1 >> 16)) continue;
+                }
                 // LINK_M: value of the better mate
-                const int lv0 = ((in0 && p > pos0) ? imax(noindel80 - nogap0, 0) + 1 : 0), lv1 = ((in1 && p > pos1) ? imax(noindel80 - nogap1, 0) + 1 : 0);
+                const int lv0 = (lk0 ? imax(noindel80 - nogap0, 0) + 1 : 0), lv1 = (lk1 ? imax(noindel80 - nogap1, 0) + 1 : 0);
                 const int lv = imax(lv0, lv1);
                 if (lv > 0) { if (strand) apply(a_rr, a_rl, UVC_LINK_SYMBOL, UVC_LINK_M, lv, lv, UVC_LINK_M, lv, lv, maxq_link, 1, sq, n_cov, n_near, singleton);
                               else apply(a_fr, a_fl, UVC_LINK_SYMBOL, UVC_LINK_M, lv, lv, UVC_LINK_M, lv, lv, maxq_link, 0, sq, n_cov, n_near, singleton); }
@@ -1899,7 +1976,7 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
     {
         const bool proton = (UVC_PLATFORM_IONTORRENT == P->inferred_sequencing_platform);
         const int n_gen = proton ? R->n_frags : R->n_sweep;
-        if (n_gen) TIMED(prof, "k_frag_generic", hipLaunchKernelGGL(k_frag_generic, dim3(imin_h(n_gen, 1 << 20)), dim3(64), 0, s, *R, *P, proton ? (const int32_t *)nullptr : R->sweep_frags, n_gen));
+        if (n_gen) TIMED(prof, "k_frag_generic", hipLaunchKernelGGL(k_frag_generic, dim3(imin_h(n_gen, 1 << 20), imin_h((R->max_frag_span + 63) / 64, 16)), dim3(64), 0, s, *R, *P, proton ? (const int32_t *)nullptr : R->sweep_frags, n_gen));
     }
     TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag, dim3(nwin), dim3(256), 0, s, *R, *P));
     if (R->n_generic_fs) {
