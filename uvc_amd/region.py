@@ -135,7 +135,9 @@ class Region:
             npos = (pos_end - pos_beg) if pos_beg >= 0 else self.npos
             capacity = 14 * (npos + 1) if all_out else max(4096, 4 * (npos + 1))
         while True:
-            buf = np.zeros((_ffi.NUM_SCORE_FIELDS, capacity), dtype=np.int32)
+            buf = getattr(self, "_score_buf", None)   # reused across calls: the library fills n_records columns of every row
+            if buf is None or buf.shape[1] != capacity:
+                buf = self._score_buf = np.empty((_ffi.NUM_SCORE_FIELDS, capacity), dtype=np.int32)
             out = _ffi.UvcScoreOut(capacity, 0, buf.ctypes.data)
             rc = self.lib.call("score", self.h, C.byref(req), C.byref(out))
             if rc == -6 and out.n_records > capacity:
