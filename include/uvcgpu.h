@@ -260,6 +260,10 @@ int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params,
 int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *reads);
 /* Optional: apply_bq_err_correction3 (grouping.cpp:459-543) on the device copy of quals. */
 int uvcgpu_region_correct_bq(uvcgpu_region_t *r);
+/* The base qualities as they are on the device now (after uvcgpu_region_correct_bq if it was called); n must equal
+ * UvcReadSoA::n_bases of the last set_reads.  For callers that write the corrected qualities back (the reference edits the
+ * bam1_t in place, grouping.cpp:459-543) and for tests. */
+int uvcgpu_region_read_quals(uvcgpu_region_t *r, uint8_t *dst, int64_t n);
 /* Replaces updateByRegion3Aln (main.hpp:3665-3742): passes P1..P5b. Asynchronous on the handle's stream. */
 int uvcgpu_region_accumulate(uvcgpu_region_t *r);
 /* Upper bound of records a request can produce (2 symbol types x <= 8 symbols x positions). */

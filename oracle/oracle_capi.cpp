@@ -78,6 +78,68 @@ int uvc_oracle_set_reads(void *h, const UvcReadSoA *r) {
     return 0;
 }
 
+// apply_bq_err_correction3, grouping.cpp:459-543, on the oracle's copy of the reads.  The reference works on BAM 4-bit base codes
+// (A=1, C=2, G=4, T=8, N=15) with "no base yet" = 0; the SoA holds 0..4, mapped here before the comparisons.
+static void correct_bq_one(u8 *q, const u8 *b, int l, int flag, const u32 *cigar, int n_cigar, int bq_max, int bq_inc) {
+    if ((0 == l) || (flag & 0x4)) return;
+    auto code = [&](int i) -> int { const int v = b[i]; return v < 4 ? (1 << v) : 15; };
+    for (int i = 0; i < l; i++) { const int bq = q[i]; q[i] = (u8)std::min(bq + bq_inc, bq_max); }   // :462-465
+    const int isrc = ((flag & 0x10) ? 1 : 0);
+    int inclu_beg_poss[2] = { 0, l - 1 };
+    int exclu_end_poss[2] = { l, 0 - 1 };
+    int end_clip_len = 0;
+    if (n_cigar > 0) {                                                                               // :473-491
+        u32 c1 = cigar[0];
+        if (cig_op(c1) == C_SOFT_CLIP) {
+            if (0 == isrc) inclu_beg_poss[0] += (int)cig_len(c1);
+            else { exclu_end_poss[1] += (int)cig_len(c1); end_clip_len = (int)cig_len(c1); }
+        }
+        c1 = cigar[n_cigar - 1];
+        if (cig_op(c1) == C_SOFT_CLIP) {
+            if (1 == isrc) inclu_beg_poss[1] -= (int)cig_len(c1);
+            else { exclu_end_poss[0] -= (int)cig_len(c1); end_clip_len = (int)cig_len(c1); }
+        }
+    }
+    const int pos_incs[2] = { 1, -1 };
+    const int inc = pos_incs[isrc], ibeg = inclu_beg_poss[isrc], eend = exclu_end_poss[isrc];
+    // no aligned base left between the clips: the reference's loops would leave the arrays (undefined behaviour); skipped, as in the HIP kernel
+    if ((isrc ? (ibeg <= eend) : (ibeg >= eend)) || ibeg < 0 || ibeg >= l || eend < -1 || eend > l) return;
+    {                                                                                                // :494-522
+        int prev_b = 0; unsigned distinct_cnt = 0;
+        int termpos = eend - inc;
+        for (; termpos != ibeg - inc; termpos -= inc) {
+            const int bb = code(termpos); const int qq = q[termpos];
+            if (bb != prev_b && qq >= 20) { prev_b = bb; distinct_cnt += 1; if (2 == distinct_cnt) break; }
+        }
+        const int homopol_tracklen = abs(termpos - (eend - inc));
+        const int tail_penal = (end_clip_len >= 20 ? 1 : 0) + (homopol_tracklen >= 15 ? 2 : (homopol_tracklen >= 10 ? 1 : 0));
+        if (tail_penal > 0)
+            for (int pos = eend - inc; pos != (ibeg - inc) && pos != termpos; pos -= inc) q[pos] = (u8)(std::max((int)q[pos], tail_penal + 1) - tail_penal);
+    }
+    {                                                                                                // :523-539
+        int homopol_len = 0, prev_b = 0;
+        for (int pos = ibeg; pos != eend; pos += inc) {
+            const int bb = code(pos);
+            if (bb == prev_b) { homopol_len++; if (homopol_len >= 4 && bb == 4) q[pos] = (u8)(std::max((int)q[pos], 1 + 1) - 1); }
+            else { prev_b = bb; homopol_len = 1; }
+        }
+    }
+}
+
+int uvc_oracle_region_correct_bq(void *h) {
+    State &S = *(State *)h;
+    for (auto &a : S.alns) correct_bq_one(S.quals.data() + (a.quals - S.quals.data()), a.bases, a.l_qseq, a.flag, a.cigar, a.n_cigar, S.P.assay_sequencing_BQ_max, S.P.assay_sequencing_BQ_inc);
+    S.accumulated = false;
+    return 0;
+}
+
+int uvc_oracle_region_read_quals(void *h, uint8_t *dst, int64_t n) {
+    State &S = *(State *)h;
+    if ((size_t)n != S.quals.size()) { g_err = "n must equal n_bases"; return UVCGPU_EINVAL; }
+    memcpy(dst, S.quals.data(), (size_t)n);
+    return 0;
+}
+
 int uvc_oracle_accumulate(void *h) { State &S = *(State *)h; return accumulate(S, g_err); }
 
 // transposes the position-major internal storage into the plane layout [field][symbol][pos] of uvcgpu.h

@@ -14,6 +14,7 @@ struct RawReads {
     const int32_t *pos, *endpos, *mpos, *isize, *flag, *mapq, *nm, *l_qseq, *n_cigar, *frag, *fs, *dflag, *kind, *fast_rank;
     const int64_t *seq_off, *cigar_off, *table_off, *item_off;
 };
+extern "C" void uvc_launch_correct_bq(const RegionDev *R, int bq_max, int bq_inc, hipStream_t s);
 extern "C" void uvc_launch_pack_bq(const uint8_t *bases, const uint8_t *quals, uint16_t *bq, int64_t n, hipStream_t s);
 extern "C" void uvc_launch_build_p2list(const RegionDev *R, const int32_t *aln, const int32_t *cbeg, const int32_t *cend, const int32_t *qb, hipStream_t s);
 extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const UvcParams *P, hipStream_t s);
@@ -43,6 +44,9 @@ struct uvcgpu_region {
     int32_t *d_dup_units = nullptr; int64_t *d_dup_off = nullptr; int n_dup = 0; int64_t n_dup_work = 0;
     size_t off[UVC_NUM_FIELD_GROUPS + 1];
     bool has_reads = false, accumulated = false;
+    RawReads W;                  // per-read input columns on the device (kept: uvcgpu_region_correct_bq re-derives the per-read records)
+    int32_t *d_p2[4] = { nullptr, nullptr, nullptr, nullptr };   // P2 work list: alignment, begin, end, query offset
+    int64_t n_bases = 0;
     UvcProf prof;
     // persistent scoring buffers (grown on demand)
     long long *d_score_scratch = nullptr; size_t score_scratch_bytes = 0;
@@ -290,30 +294,25 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
         u.frag_end = (int32_t)frags.size(); u.beg = std::min(u.beg, in->pos[i]); u.end = std::max(u.end, e) + 1;
         frag_of[i] = (int32_t)frags.size() - 1; fs_of[i] = (int32_t)fss.size() - 1; dflag_of[i] = in->fam_dflag[fam];
         kind[i] = simple ? 0 : 1;
-        {   // P2 work list (k_p2_fast): a simple alignment is one entry; an InDel read whose InDels are all high-quality contributes its M runs
+        {   // P2 work list (k_p2_fast): a simple alignment is one entry; an InDel read contributes its M runs (used when its InDels are all high-quality)
             const size_t mark = p2.size();
             bool ok = simple || seg_eligible;
             int32_t rp = in->pos[i]; int64_t qp = 0;
-            const uint8_t *qq = in->quals + in->seq_off[i];
-            auto Q = [&](int64_t q2) -> int { return (int)qq[std::min<int64_t>(std::max<int64_t>(q2, 0), lq - 1)]; };
             for (int k = 0; k < nc && ok; k++) {
                 const int op = (int)(cg[k] & 0xF); const int32_t len = (int32_t)(cg[k] >> 4);
                 if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) {
                     if (rp - in->pos[i] > 65535 || e - (rp + len) > 65535) ok = false;
                     p2.push_back(P2Seg{ rp, rp + len, (int32_t)i, (int32_t)((in->seq_off[i] + qp - rp) & 0xFFFFFFFFLL) });
                     rp += len; qp += len;
-                } else if (op == C_INS) {   // low-quality InDels make dist_to_interfering_indel position dependent (main.hpp:1817-1859): not eligible
-                    for (int64_t q2 = qp - std::min<int64_t>(qp, 1); q2 < std::min<int64_t>(qp + len + 1, e); q2++) if (Q(q2) < P0.bias_thres_interfering_indel_BQ) ok = false;
-                    qp += len;
-                } else if (op == C_DEL) {
-                    if (std::min(Q(std::max<int64_t>(1, qp) - 1), Q(qp)) <= P0.bias_thres_interfering_indel_BQ) ok = false;
-                    rp += len;
-                } else if (op == C_SOFT_CLIP) qp += len;
+                } else if (op == C_INS) qp += len;
+                else if (op == C_DEL) rp += len;
+                else if (op == C_SOFT_CLIP) qp += len;
                 else if (op == C_HARD_CLIP) {}
                 else ok = false;   // N / P: keep the sequential path
             }
             if (!ok) p2.resize(mark);
-            else if (!simple) kind[i] = 2;
+            else if (!simple) kind[i] = 2;   // candidate: k_aln_prelude demotes it to 1 when the read has a low-quality InDel (that test reads the
+                                             // base qualities, which uvcgpu_region_correct_bq may still change on the device)
         }
         if (!simple) {
             table_off[i] = table_rows; table_rows += (e - in->pos[i]);
@@ -360,7 +359,7 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
 
     // uploads
     RegionDev &R = r->R;
-    RawReads W;
+    RawReads &W = r->W;
     int rc;
     auto up32 = [&](const int32_t *src, const int32_t **dst) { std::vector<int32_t> v(src, src + n); int32_t *d; int c = upload(r, v, &d); *dst = d; return c; };
     auto up64 = [&](const int64_t *src, const int64_t **dst) { std::vector<int64_t> v(src, src + n); int64_t *d; int c = upload(r, v, &d); *dst = d; return c; };
@@ -408,10 +407,9 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
         std::vector<int32_t> v_aln(p2.size()), v_beg(p2.size()), v_end(p2.size()), v_qb(p2.size());
         int32_t span = 1;
         for (size_t j = 0; j < p2.size(); j++) { v_aln[j] = p2[j].aln; v_beg[j] = p2[j].cbeg; v_end[j] = p2[j].cend; v_qb[j] = p2[j].qb; span = std::max(span, p2[j].cend - p2[j].cbeg); }
-        int32_t *d_aln, *d_beg, *d_end, *d_qb;
-        if ((rc = upload(r, v_aln, &d_aln)) || (rc = upload(r, v_beg, &d_beg)) || (rc = upload(r, v_end, &d_end)) || (rc = upload(r, v_qb, &d_qb))) return rc;
+        if ((rc = upload(r, v_aln, &r->d_p2[0])) || (rc = upload(r, v_beg, &r->d_p2[1])) || (rc = upload(r, v_end, &r->d_p2[2])) || (rc = upload(r, v_qb, &r->d_p2[3]))) return rc;
         { std::vector<FastRec> v(p2.size()); FastRec *d; if ((rc = upload(r, v, &d))) return rc; R.frec2 = d; R.n_fast2 = (int32_t)p2.size(); R.max_p2_span = span; }
-        uvc_launch_build_p2list(&R, d_aln, d_beg, d_end, d_qb, r->stream);
+        uvc_launch_build_p2list(&R, r->d_p2[0], r->d_p2[1], r->d_p2[2], r->d_p2[3], r->stream);
     }
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(r->stream));   // the staging vectors above die here
@@ -423,11 +421,36 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
         if (hipMalloc((void **)&d, (size_t)(total + 64) * sizeof(MisItem)) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(mismatch queue)");
         r->owned.push_back(d); R.mis = d; R.mis_cap = (int32_t)(total + 64);
     }
+    r->n_bases = in->n_bases;
     r->has_reads = true;
     return 0;
 }
 
-int uvcgpu_region_correct_bq(uvcgpu_region_t *) { return fail(UVCGPU_EUNSUPPORTED, "apply_bq_err_correction3 on device: not built yet (SURVEY row a11)"); }
+// apply_bq_err_correction3 (grouping.cpp:459-543) on the resident reads, then everything derived from the base qualities again:
+// the packed base|qual array and the per-read records (the low-quality-InDel test of k_aln_prelude reads them)
+int uvcgpu_region_correct_bq(uvcgpu_region_t *r) {
+    if (!r) return fail(UVCGPU_EINVAL, "null region");
+    if (!r->has_reads) return fail(UVCGPU_ENOREADS, "no reads");
+    uvc_launch_correct_bq(&r->R, r->P.assay_sequencing_BQ_max, r->P.assay_sequencing_BQ_inc, r->stream);
+    uvc_launch_pack_bq(r->R.bases, r->R.quals, (uint16_t *)r->R.bq, r->n_bases, r->stream);
+    HIP_OK(hipMemsetAsync(r->R.mis_total, 0, sizeof(unsigned long long), r->stream));
+    uvc_launch_prelude(&r->R, &r->W, &r->P, r->stream);
+    uvc_launch_build_p2list(&r->R, r->d_p2[0], r->d_p2[1], r->d_p2[2], r->d_p2[3], r->stream);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(r->stream));
+    r->accumulated = false;
+    return 0;
+}
+
+// the base qualities as they are on the device (after uvcgpu_region_correct_bq, if it was called)
+int uvcgpu_region_read_quals(uvcgpu_region_t *r, uint8_t *dst, int64_t n) {
+    if (!r || !dst) return fail(UVCGPU_EINVAL, "null argument");
+    if (!r->has_reads) return fail(UVCGPU_ENOREADS, "no reads");
+    if (n != r->n_bases) return fail(UVCGPU_EINVAL, "n must equal UvcReadSoA::n_bases");
+    HIP_OK(hipStreamSynchronize(r->stream));
+    if (n > 0) HIP_OK(hipMemcpy(dst, r->R.quals, (size_t)n, hipMemcpyDeviceToHost));
+    return 0;
+}
 
 int uvcgpu_region_accumulate(uvcgpu_region_t *r) {
     if (!r) return fail(UVCGPU_EINVAL, "null region");

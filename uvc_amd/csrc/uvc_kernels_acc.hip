@@ -322,6 +322,24 @@ struct RawReads {
     const int64_t *seq_off, *cigar_off, *table_off, *item_off;
 };
 
+// does the read have an InDel next to low base qualities (main.hpp:1817-1859)?  Then dist_to_interfering_indel varies along the
+// read and its M runs cannot take the simple path of k_p2_fast.
+DEV bool has_lowbq_indel(const UvcParams &P, const AlnRec &a, const uint32_t *cigar, const uint8_t *quals) {
+    auto Q = [&](int q) -> int { return (int)quals[imin(imax(q, 0), a.l_qseq - 1)]; };
+    int qpos = 0;
+    for (int i = 0; i < a.n_cigar; i++) {
+        const int op = cig_op(cigar[i]), len = cig_len(cigar[i]);
+        if (op == C_MATCH || op == C_EQUAL || op == C_DIFF || op == C_SOFT_CLIP) qpos += len;
+        else if (op == C_INS) {
+            for (int q2 = qpos - imin(qpos, 1); q2 < imin(qpos + len + 1, a.rend); q2++) if (Q(q2) < P.bias_thres_interfering_indel_BQ) return true;
+            qpos += len;
+        } else if (op == C_DEL) {
+            if (imin(Q(imax(1, qpos) - 1), Q(qpos)) <= P.bias_thres_interfering_indel_BQ) return true;
+        }
+    }
+    return false;
+}
+
 // digest of alignment `a` (index `id`) for the position-centric kernels, covering [cbeg, cend) with query offset qb_lo
 DEV void fill_fastrec(FastRec &f, const AlnRec &a, int id, int cbeg, int cend, int32_t qb_lo) {
     f.pos = cbeg; f.rend = cend; f.qb_lo = qb_lo; f.aln = id;
@@ -342,7 +360,9 @@ __global__ void __launch_bounds__(256) k_build_p2list(RegionDev R, const int32_t
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= R.n_fast2) return;
     FastRec f;
-    fill_fastrec(f, R.alns[aln[j]], aln[j], cbeg[j], cend[j], qb[j]);
+    const AlnRec &a = R.alns[aln[j]];
+    // an InDel read that k_aln_prelude found ineligible keeps its slot (the list stays sorted) but covers nothing
+    fill_fastrec(f, a, aln[j], cbeg[j], (a.kind == 1 ? cbeg[j] : cend[j]), qb[j]);
     R.frec2[j] = f;
 }
 
@@ -392,9 +412,10 @@ __global__ void __launch_bounds__(256) k_aln_prelude(RegionDev R, RawReads W, Uv
     }
     a.qbase = a.seq_off + lclip_q - a.pos;
     a.baq_pos = BAQ1(R, a.pos); a.baq_last = BAQ1(R, a.rend - 1); a.baq2_last = BAQ2(R, a.rend - 1);
+    if (a.kind == 2 && has_lowbq_indel(P, a, cigar, R.quals + a.seq_off)) a.kind = 1;
     R.alns[id] = a;
     const int rk = W.fast_rank[id];
-    if (rk >= 0 || a.kind == 2) {   // every alignment on the P2 work list: its mismatching bases go through the mismatch queue
+    if (rk >= 0 || W.kind[id] == 2) {   // every alignment that can be on the P2 work list: its mismatching bases go through the mismatch queue
         const int n_mis = bm[0] + bm[1] + bm[2] + bm[3] + bm[4];
         if (n_mis) atomicAdd(R.mis_total, (unsigned long long)n_mis);
     }
@@ -1934,6 +1955,64 @@ struct UvcProf { int on; int n; const char *name[24]; hipEvent_t ev[24][2]; };
         __VA_ARGS__; \
         if (i_ >= 0) hipEventRecord(p_->ev[i_][1], s); \
     } while (0)
+
+// apply_bq_err_correction3 (grouping.cpp:459-543): quality increment and cap, tail penalty behind a long soft clip / homopolymer at
+// the 3' end, and the poly-G penalty.  One thread per alignment; the base codes are mapped to the BAM 4-bit codes the reference
+// compares (A=1, C=2, G=4, T=8, N=15; "no base yet" = 0).
+__global__ void __launch_bounds__(256) k_correct_bq(RegionDev R, int bq_max, int bq_inc) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= R.n_alns) return;
+    const AlnRec &a = R.alns[id];
+    const int l = a.l_qseq;
+    if (0 == l || (a.flag & 0x4)) return;
+    uint8_t *q = (uint8_t *)R.quals + a.seq_off;
+    const uint8_t *b = R.bases + a.seq_off;
+    const uint32_t *cigar = R.cigars + a.cigar_off;
+    auto code = [&](int i) -> int { const int v = b[i]; return v < 4 ? (1 << v) : 15; };
+    for (int i = 0; i < l; i++) q[i] = (uint8_t)imin((int)q[i] + bq_inc, bq_max);
+    const int isrc = ((a.flag & 0x10) ? 1 : 0);
+    int inclu_beg_poss[2] = { 0, l - 1 };
+    int exclu_end_poss[2] = { l, 0 - 1 };
+    int end_clip_len = 0;
+    if (a.n_cigar > 0) {
+        uint32_t c1 = cigar[0];
+        if (cig_op(c1) == C_SOFT_CLIP) {
+            if (0 == isrc) inclu_beg_poss[0] += cig_len(c1);
+            else { exclu_end_poss[1] += cig_len(c1); end_clip_len = cig_len(c1); }
+        }
+        c1 = cigar[a.n_cigar - 1];
+        if (cig_op(c1) == C_SOFT_CLIP) {
+            if (1 == isrc) inclu_beg_poss[1] -= cig_len(c1);
+            else { exclu_end_poss[0] -= cig_len(c1); end_clip_len = cig_len(c1); }
+        }
+    }
+    const int inc = (isrc ? -1 : 1), ibeg = inclu_beg_poss[isrc], eend = exclu_end_poss[isrc];
+    // a read whose soft clips leave no aligned base would send the reference's loops out of the arrays (undefined there): skip it
+    if ((isrc ? (ibeg <= eend) : (ibeg >= eend)) || ibeg < 0 || ibeg >= l || eend < -1 || eend > l) return;
+    {
+        int prev_b = 0, distinct_cnt = 0;
+        int termpos = eend - inc;
+        for (; termpos != ibeg - inc; termpos -= inc) {
+            const int bb = code(termpos), qq = q[termpos];
+            if (bb != prev_b && qq >= 20) { prev_b = bb; distinct_cnt += 1; if (2 == distinct_cnt) break; }
+        }
+        const int homopol_tracklen = abs(termpos - (eend - inc));
+        const int tail_penal = (end_clip_len >= 20 ? 1 : 0) + (homopol_tracklen >= 15 ? 2 : (homopol_tracklen >= 10 ? 1 : 0));
+        if (tail_penal > 0)
+            for (int pos = eend - inc; pos != (ibeg - inc) && pos != termpos; pos -= inc) q[pos] = (uint8_t)(imax((int)q[pos], tail_penal + 1) - tail_penal);
+    }
+    {
+        int homopol_len = 0, prev_b = 0;
+        for (int pos = ibeg; pos != eend; pos += inc) {
+            const int bb = code(pos);
+            if (bb == prev_b) { homopol_len++; if (homopol_len >= 4 && bb == 4 /* G */) q[pos] = (uint8_t)(imax((int)q[pos], 1 + 1) - 1); }
+            else { prev_b = bb; homopol_len = 1; }
+        }
+    }
+}
+extern "C" void uvc_launch_correct_bq(const RegionDev *R, int bq_max, int bq_inc, hipStream_t s) {
+    if (R->n_alns) hipLaunchKernelGGL(k_correct_bq, dim3((unsigned)((R->n_alns + 255) / 256)), dim3(256), 0, s, *R, bq_max, bq_inc);
+}
 
 __global__ void __launch_bounds__(256) k_pack_bq(const uint8_t *bases, const uint8_t *quals, uint16_t *bq, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)

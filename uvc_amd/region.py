@@ -114,6 +114,19 @@ class Region:
     def accumulate(self):
         self._check(self.lib.call("accumulate", self.h))
 
+    def correct_bq(self):
+        """apply_bq_err_correction3 (grouping.cpp:459-543) on the library's copy of the base qualities."""
+        fn = getattr(self.lib.dll, self.lib.prefix + "region_correct_bq")
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p]
+        self._check(fn(self.h))
+
+    def read_quals(self, n_bases):
+        fn = getattr(self.lib.dll, self.lib.prefix + "region_read_quals")
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]
+        out = np.empty(n_bases, dtype=np.uint8)
+        self._check(fn(self.h, out.ctypes.data, n_bases))
+        return out
+
     def fetch(self, group):
         gid, dt, shape = _ffi.FIELD_GROUPS[group]
         nbytes = self.lib.call("field_bytes", self.h, gid)
