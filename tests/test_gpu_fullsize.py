@@ -1,0 +1,110 @@
+"""BASELINE.json's full bench tile (1 Mb at 300x, 2 M reads) through size-independent properties, and the edge cases of the
+boundary.  The oracle would need minutes here, so nothing below calls it: the expected values are recomputed with numpy
+directly from the read arrays, or are invariants (repeatability, additivity of independent regions)."""
+import zlib
+
+import numpy as np
+import pytest
+
+from uvc_amd import _ffi, region, synth
+
+pytestmark = pytest.mark.gpu
+E = _ffi.ENUMS
+
+
+def ref_consuming_coverage(reads):
+    """depth of reference-consuming CIGAR ops (M/=/X/D/N) per position, and of M/=/X only"""
+    n = reads["end"] - reads["beg"] + 1
+    d_all = np.zeros(n + 1, np.int64)
+    d_m = np.zeros(n + 1, np.int64)
+    op = (reads["cigars"] & 0xF).astype(np.int64)
+    ln = (reads["cigars"] >> 4).astype(np.int64)
+    owner = np.repeat(np.arange(reads["n_reads"]), reads["n_cigar"])
+    consumes = np.isin(op, (0, 2, 3, 7, 8))
+    step = np.where(consumes, ln, 0)
+    # start offset of every op inside its read = exclusive prefix sum of the ref-consuming lengths, restarted per read
+    cs = np.cumsum(step) - step
+    first = np.zeros(reads["n_reads"], np.int64)
+    first_idx = reads["cigar_off"].astype(np.int64)
+    first = cs[first_idx]
+    start = reads["pos"].astype(np.int64)[owner] - reads["beg"] + (cs - first[owner])
+    for mask, d in ((consumes, d_all), (np.isin(op, (0, 7, 8)), d_m)):
+        np.add.at(d, start[mask], 1)
+        np.add.at(d, start[mask] + ln[mask], -1)
+    return np.cumsum(d_all)[:n], np.cumsum(d_m)[:n]
+
+
+@pytest.fixture(scope="module")
+def full_tile(gpu_lib):
+    reads = synth.generate_region(seed=12345, region_len=1_000_000, depth=300)
+    R = region.Region(gpu_lib, region.default_params(gpu_lib), reads["tid"], reads["beg"], reads["end"], reads["refseq"])
+    R.set_reads(reads)
+    R.accumulate()
+    return reads, R
+
+
+def checksum(R, groups=("PREP32", "SEG32", "SEG64", "VQ", "BQSUM", "FRAG", "FAM", "FAMINFO32", "DUPLEX")):
+    return {g: zlib.crc32(R.fetch(g).tobytes()) for g in groups}
+
+
+def test_depth_planes_equal_a_numpy_pileup(full_tile):
+    reads, R = full_tile
+    cov_all, cov_m = ref_consuming_coverage(reads)
+    prep = R.fetch("PREP32")
+    assert np.array_equal(prep[E["UVC_P_a_dp"]], cov_all)                   # one count per reference position a read spans (M and D ops)
+    seg = R.fetch("SEG32")
+    ad = seg[E["UVC_S_aDPff"]] + seg[E["UVC_S_aDPfr"]] + seg[E["UVC_S_aDPrf"]] + seg[E["UVC_S_aDPrr"]]
+    base_depth = ad[:6].sum(axis=0)
+    # every aligned base adds one BASE symbol; a deleted base adds BASE_NN when the deletion is far enough from the read ends
+    assert (base_depth >= cov_m).all() and (base_depth - cov_m).sum() <= (seg[E["UVC_S_aDPff"]][5] + seg[E["UVC_S_aDPfr"]][5] + seg[E["UVC_S_aDPrf"]][5] + seg[E["UVC_S_aDPrr"]][5]).sum()
+    frag = R.fetch("FRAG")                                                   # [2][NFRAG][14][npos]
+    bdp = frag[:, E["UVC_FRAG_bDP"]].sum(axis=0)
+    assert (bdp[:6].sum(axis=0) <= base_depth).all()                         # a fragment counts once where both mates overlap
+    assert (bdp[:6].sum(axis=0) * 2 >= base_depth).all()
+
+
+def test_second_accumulate_reproduces_every_plane(full_tile):
+    _, R = full_tile
+    c1 = checksum(R)
+    rec1 = R.score(capacity=400_000)
+    R.accumulate()
+    assert checksum(R) == c1
+    rec2 = R.score(capacity=400_000)
+    assert all(np.array_equal(rec1[k], rec2[k]) for k in rec1)
+    assert len(rec1["refpos"]) > 10_000 and np.all(np.diff(rec1["refpos"]) >= 0)   # emission order: by position
+
+
+def test_two_half_tiles_add_up(gpu_lib):
+    """Regions are independent: the planes of two tiles laid side by side equal the planes of each tile alone."""
+    a = synth.generate_region(seed=5, region_len=20_000, depth=300, beg=2_000_000)
+    Ra = region.Region(gpu_lib, region.default_params(gpu_lib), a["tid"], a["beg"], a["end"], a["refseq"])
+    Ra.set_reads(a); Ra.accumulate()
+    before = checksum(Ra)
+    b = synth.generate_region(seed=6, region_len=20_000, depth=300, beg=3_000_000)
+    Rb = region.Region(gpu_lib, region.default_params(gpu_lib), b["tid"], b["beg"], b["end"], b["refseq"])
+    Rb.set_reads(b); Rb.accumulate()
+    assert checksum(Ra) == before        # another handle's work does not leak into this one
+
+
+def test_no_reads_and_bad_inputs(gpu_lib):
+    reads = synth.generate_region(seed=9, region_len=500, depth=5)
+    p = region.default_params(gpu_lib)
+    R = region.Region(gpu_lib, p, reads["tid"], reads["beg"], reads["end"], reads["refseq"])
+    with pytest.raises(region.UvcError) as e:
+        R.accumulate()
+    assert e.value.code == E["UVCGPU_ENOREADS"]                              # process_batch returns -1, main.cpp:520-523
+    empty = {k: (v[:0] if isinstance(v, np.ndarray) and k not in ("fam_dflag",) else v) for k, v in reads.items()}
+    empty.update(n_reads=0, n_fams=0, fam_dflag=np.zeros(0, np.uint8))
+    R.set_reads(empty)
+    with pytest.raises(region.UvcError):
+        R.accumulate()
+    outside = dict(reads); outside["pos"] = reads["pos"].copy(); outside["pos"][0] = reads["beg"] - 10
+    with pytest.raises(region.UvcError) as e:
+        R.set_reads(outside)
+    assert e.value.code == E["UVCGPU_EINVAL"]
+    ragged = dict(reads); ragged["l_qseq"] = reads["l_qseq"].copy(); ragged["l_qseq"][1] += 1   # CIGAR no longer spans the read
+    with pytest.raises(region.UvcError):
+        R.set_reads(ragged)
+    R.set_reads(reads)                                                       # the handle is still usable
+    R.accumulate()
+    assert R.fetch("PREP32")[E["UVC_P_a_dp"]].sum() == ref_consuming_coverage(reads)[0].sum()
