@@ -248,7 +248,7 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     int prev_fam = -1, prev_strand = -1, prev_frag = -1;
     int64_t table_rows = 0;
     int32_t max_aln_span = 1, max_frag_span = 1;
-    struct P2Seg { int32_t cbeg, cend, aln, qb; };
+    struct P2Seg { int32_t cbeg, cend, aln, qb; int32_t cls; };   // cls = is-reverse | bam_get_strand << 1 (common.hpp:89)
     std::vector<P2Seg> p2; p2.reserve((size_t)n + 1024);
     const UvcParams &P0 = r->P;
     // see k_p2_fast: the M runs of an InDel read can take the simple path when its dist_to_interfering_indel is "far" everywhere, which
@@ -296,13 +296,15 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
         kind[i] = simple ? 0 : 1;
         {   // P2 work list (k_p2_fast): a simple alignment is one entry; an InDel read contributes its M runs (used when its InDels are all high-quality)
             const size_t mark = p2.size();
+            const int fl = in->flag[i];
+            const int32_t p2cls = ((fl & 0x10) ? 1 : 0) | ((((fl & 0x81) == 0x81) ? ((fl & 0x20) != 0) : ((fl & 0x10) != 0)) ? 2 : 0);
             bool ok = simple || seg_eligible;
             int32_t rp = in->pos[i]; int64_t qp = 0;
             for (int k = 0; k < nc && ok; k++) {
                 const int op = (int)(cg[k] & 0xF); const int32_t len = (int32_t)(cg[k] >> 4);
                 if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) {
                     if (rp - in->pos[i] > 65535 || e - (rp + len) > 65535) ok = false;
-                    p2.push_back(P2Seg{ rp, rp + len, (int32_t)i, (int32_t)((in->seq_off[i] + qp - rp) & 0xFFFFFFFFLL) });
+                    p2.push_back(P2Seg{ rp, rp + len, (int32_t)i, (int32_t)((in->seq_off[i] + qp - rp) & 0xFFFFFFFFLL), p2cls });
                     rp += len; qp += len;
                 } else if (op == C_INS) qp += len;
                 else if (op == C_DEL) rp += len;
@@ -403,7 +405,9 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     HIP_OK(hipMemsetAsync(R.table, 0xFF, std::max<int64_t>(table_rows, 1) * sizeof(Contrib), r->stream));
     uvc_launch_prelude(&R, &W, &r->P, r->stream);
     {
-        std::stable_sort(p2.begin(), p2.end(), [](const P2Seg &a, const P2Seg &b) { return a.cbeg < b.cbeg; });
+        std::stable_sort(p2.begin(), p2.end(), [](const P2Seg &a, const P2Seg &b) { return a.cls != b.cls ? a.cls < b.cls : a.cbeg < b.cbeg; });
+        for (int c = 0; c <= 4; c++) R.p2_off[c] = 0;
+        for (const P2Seg &e : p2) for (int c = e.cls + 1; c <= 4; c++) R.p2_off[c]++;
         std::vector<int32_t> v_aln(p2.size()), v_beg(p2.size()), v_end(p2.size()), v_qb(p2.size());
         int32_t span = 1;
         for (size_t j = 0; j < p2.size(); j++) { v_aln[j] = p2[j].aln; v_beg[j] = p2[j].cbeg; v_end[j] = p2[j].cend; v_qb[j] = p2[j].qb; span = std::max(span, p2[j].cend - p2[j].cbeg); }

@@ -215,13 +215,15 @@ DEV int selm(wmask m, int v) { int r; asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=
 // dealwith_segbias<true> for LINK_M (lanes with hasL) and dealwith_segbias<false> for the read base (lanes with hasB) at one
 // position of a simple alignment: cigar_op = M, indel_len = 0, dist_to_interfering_indel = 10000 (main.hpp:1360-1595).
 // Everything that does not depend on the symbol is computed once for both.
+// ISRC / STRAND (bam_get_strand, common.hpp:89) are compile-time: the P2 work list is split by them, so the direction-specific
+// counters are fixed registers in each instantiation and the loop has no branch on the read's orientation.
+template <bool ISRC, bool STRAND>
 DEV void segbias_simple(SegAcc &AL, SegAcc &AB, const UvcParams &P, const SegRead &r, const PosThres &T, int rpos, long long baq_p, long long baq2_p,
                         bool hasL, bool hasB, int bqL, int bqB, int xm_inc, int bm_inc, const int *amp1, const int *amp2) {
     const bool amplicon = ((r.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag)));
     const bool normal_filter_primers = (P.tn_is_paired && (0x1 & P.primer_flag));
     const bool is_assay_UMI = (r.dflag & 0x1);
-    const bool isrc = (r.flag & 0x10) != 0;
-    const bool strand = ((r.flag & 0x81) == 0x81) ? ((r.flag & 0x20) != 0) : ((r.flag & 0x10) != 0);
+    constexpr bool isrc = ISRC, strand = STRAND;
     const bool is_normal = ((r.isize != 0) || (0 == (r.flag & 0x1)));
     const bool mate_ok = ((0 == (r.flag & 0x8)) || (0 == (r.flag & 0x1)));
     const bool hrl = (P.central_readlen >= P.microadjust_median_readlen_thres);
@@ -842,8 +844,6 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
     // LINK_M value of a simple read at this position is a per-position constant up to the read's penalty (main.hpp:1919-1923)
     int noindel80 = 80;
     if (DO_L && valid && x > 0) noindel80 = imin(80, imin(RTRP(R, UVC_RTR_indelphred, x - 1), RTRP(R, UVC_RTR_indelphred, x)));
-    const int lo = wave_uniform(lower_bound_frec(R.frec2, R.n_fast2, w0 - R.max_p2_span + 1));
-    const int hi = wave_uniform(lower_bound_frec(R.frec2, R.n_fast2, w0 + 64));
     MisItem *myq = misq[DO_B ? (threadIdx.x >> 6) : 0];
     int nq = 0;   // wave-uniform: only updated in uniform control flow
     auto flush_queue = [&]() {
@@ -857,6 +857,11 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
         nq = 0;
     };
     const __amdgpu_buffer_rsrc_t rs = bq_rsrc(R);
+    // the work list is stored as four pos-sorted sub-lists, one per (is-reverse, bam_get_strand) class
+    auto run_list = [&](auto IS, auto ST, int seg_beg, int seg_end) {
+    constexpr bool ISRC = decltype(IS)::value, STRAND = decltype(ST)::value;
+    const int lo = wave_uniform(seg_beg + lower_bound_frec(R.frec2 + seg_beg, seg_end - seg_beg, w0 - R.max_p2_span + 1));
+    const int hi = wave_uniform(seg_beg + lower_bound_frec(R.frec2 + seg_beg, seg_end - seg_beg, w0 + 64));
     for (int k0 = lo; k0 < hi; k0 += 64) {
         Chunk16 c;
         load_chunk16(R.frec2, k0 + lane, hi, c);
@@ -886,7 +891,7 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
             const bool is_assay_amplicon = ((sr.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag)));
             bool gate = true;
             if (is_assay_amplicon && !normal_filter_primers) {   // primer gating, main.hpp:1872-1875, 1895
-                const bool isrc = (sr.flag & 0x10) != 0;
+                constexpr bool isrc = ISRC;
                 const int ibeg = ((sr.isize != 0) ? (sr.frag_pos_L + P.primerlen) : ((isrc && (0x0 == (0x1 & sr.flag))) ? 0 : (sr.pos + P.primerlen)));
                 const int iend = ((sr.isize != 0) ? (int)nnminus(sr.frag_pos_L + abs(sr.isize), P.primerlen) : ((isrc && (0x0 == (0x1 & sr.flag))) ? (int)nnminus(sr.rend, P.primerlen) : INT32_MAX));
                 gate = (ibeg <= p && p < iend);
@@ -911,10 +916,15 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
             if (cover) {
                 const int bmv = bcast(c.v[8], j), xbv = bcast(c.v[9], j);
                 const int bm_inc = (sym < 4 ? ((bmv >> (8 * sym)) & 0xFF) : (xbv & 0xFF)), xm_inc = (xbv >> 8) & 0xFF;
-                segbias_simple(Alink, Aref, P, sr, T, p, baq_p, baq2_p, hasL, hasB, incL, inc, xm_inc, bm_inc, amp1, amp2);
+                segbias_simple<ISRC, STRAND>(Alink, Aref, P, sr, T, p, baq_p, baq2_p, hasL, hasB, incL, inc, xm_inc, bm_inc, amp1, amp2);
             }
         }
     }
+    };
+    run_list(std::false_type{}, std::false_type{}, R.p2_off[0], R.p2_off[1]);
+    run_list(std::true_type{}, std::false_type{}, R.p2_off[1], R.p2_off[2]);
+    run_list(std::false_type{}, std::true_type{}, R.p2_off[2], R.p2_off[3]);
+    run_list(std::true_type{}, std::true_type{}, R.p2_off[3], R.p2_off[4]);
     if (DO_B && nq > 0) flush_queue();
     if (!valid) return;
     // k_p2_fast runs before every other writer of these planes (k_p2_mism, k_p2_items), and the two instantiations own
