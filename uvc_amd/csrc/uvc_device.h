@@ -126,7 +126,8 @@ struct RegionDev {
     int32_t *overflow_frags; int32_t *n_overflow;   // fragments whose event list overflowed (device list)
     const int32_t *frag_sorted;     // fragment ids sorted by FragRec::beg
     const int32_t *frag_rank;       // inverse permutation of frag_sorted
-    FragFast *ffast;                // [n_frags] in beg-sorted order
+    int32_t frag_off[3];            // ffast = the strand-0 fragments sorted by beg, then the strand-1 fragments sorted by beg
+    FragFast *ffast;                // [n_frags] in (strand, beg)-sorted order
     FsRec *fss; int32_t n_fs;
     const int32_t *generic_fs; int32_t n_generic_fs; int64_t n_generic_work;
     Contrib *table;

@@ -357,7 +357,9 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     std::stable_sort(simple_ids.begin(), simple_ids.end(), [&](int32_t a, int32_t b) { return in->pos[a] < in->pos[b]; });
     for (size_t k = 0; k < simple_ids.size(); k++) fast_rank[simple_ids[k]] = (int32_t)k;
     std::iota(frag_sorted.begin(), frag_sorted.end(), 0);
-    std::stable_sort(frag_sorted.begin(), frag_sorted.end(), [&](int32_t a, int32_t b) { return frags[a].beg < frags[b].beg; });
+    // k_frag walks two beg-sorted sub-lists, one per strand, so that the strand-specific accumulators are fixed registers
+    std::stable_sort(frag_sorted.begin(), frag_sorted.end(), [&](int32_t a, int32_t b) { return frags[a].strand != frags[b].strand ? frags[a].strand < frags[b].strand : frags[a].beg < frags[b].beg; });
+    { int32_t n0 = 0; for (const FragRec &f : frags) if (f.strand == 0) n0++; r->R.frag_off[0] = 0; r->R.frag_off[1] = n0; r->R.frag_off[2] = (int32_t)frags.size(); }
 
     // uploads
     RegionDev &R = r->R;

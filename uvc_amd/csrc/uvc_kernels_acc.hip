@@ -1535,16 +1535,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,5)))
     struct DAcc { int bDP, bTA, bTB, c12, c1; };
     DAcc a_fr = {0,0,0,0,0}, a_fl = {0,0,0,0,0}, a_rr = {0,0,0,0,0}, a_rl = {0,0,0,0,0};   // {fwd,rev} x {ref,link}
     int bMQ_r = 0, bMQ_l = 0;
-    int lo, hi;
-    {
-        int l = 0, h = R.n_frags;
-        const int key = w0 - R.max_frag_span + 1;
-        while (l < h) { int m = (l + h) >> 1; if (R.ffast[m].beg < key) l = m + 1; else h = m; }
-        lo = wave_uniform(l);
-        l = lo; h = R.n_frags;
-        while (l < h) { int m = (l + h) >> 1; if (R.ffast[m].beg < w0 + 64) l = m + 1; else h = m; }
-        hi = wave_uniform(l);
-    }
     // One (fragment, position, symbol type) consensus (cs = symbol, cc = its value, ct = total) -> P3 outputs and, for singleton units,
     // the P4/P5 identities:
     //   con = 1 vote for the fragment consensus when 2*max - tot passes the threshold (main.hpp:466-495) => cDP12, cDP21 (tot_count == 1)
@@ -1583,6 +1573,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,5)))
     };
     auto maxq_generic = [&](int cs) { return cs == UVC_LINK_M ? maxq_link : (cs <= UVC_BASE_N ? maxq_base(cs) : maxq_at(cs)); };
     const __amdgpu_buffer_rsrc_t rs = bq_rsrc(R);
+    auto run_list = [&](auto ST, DAcc &ar, DAcc &al, int seg_beg, int seg_end) {
+    constexpr int strand = decltype(ST)::value ? 1 : 0;
+    int lo, hi;
+    {
+        int l = seg_beg, h = seg_end;
+        const int key = w0 - R.max_frag_span + 1;
+        while (l < h) { int m = (l + h) >> 1; if (R.ffast[m].beg < key) l = m + 1; else h = m; }
+        lo = wave_uniform(l);
+        l = lo; h = seg_end;
+        while (l < h) { int m = (l + h) >> 1; if (R.ffast[m].beg < w0 + 64) l = m + 1; else h = m; }
+        hi = wave_uniform(l);
+    }
     for (int k0 = lo; k0 < hi; k0 += 64) {
         // one FragFast (24 dwords) per lane, fields of record j broadcast with v_readlane; base/qual bytes of record j+1 are
         // requested before record j is processed
@@ -1616,7 +1618,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,5)))
             if (fend <= w0) continue;
             if (flags & 1) continue;   // done by k_frag_generic
             if (!(valid && p >= fbeg && p < fend)) continue;
-            const int strand = (flags >> 1) & 1;
             const bool singleton = (flags >> 2) & 1;
             {
                 // consensus of <= 2 alignments in registers, written with selects (BASE_QUALITY_MAX merge, main.hpp:339-349)
@@ -1638,8 +1639,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,5)))
                 // LINK_M: value of the better mate
                 const int lv0 = (lk0 ? imax(noindel80 - nogap0, 0) + 1 : 0), lv1 = (lk1 ? imax(noindel80 - nogap1, 0) + 1 : 0);
                 const int lv = imax(lv0, lv1);
-                if (lv > 0) { if (strand) apply(a_rr, a_rl, UVC_LINK_SYMBOL, UVC_LINK_M, lv, lv, UVC_LINK_M, lv, lv, maxq_link, 1, sq, n_cov, n_near, singleton);
-                              else apply(a_fr, a_fl, UVC_LINK_SYMBOL, UVC_LINK_M, lv, lv, UVC_LINK_M, lv, lv, maxq_link, 0, sq, n_cov, n_near, singleton); }
+                if (lv > 0) apply(ar, al, UVC_LINK_SYMBOL, UVC_LINK_M, lv, lv, UVC_LINK_M, lv, lv, maxq_link, strand, sq, n_cov, n_near, singleton);
                 if (in0 || in1) {
                     const int v0 = q0 + P.bq_phred_added_misma, v1 = q1 + P.bq_phred_added_misma;
                     const int A = (in0 ? v0 : 0), B = (in1 ? v1 : 0);
@@ -1655,12 +1655,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,5)))
                         cs4 = ((A4 == 0 && B4 == 0) ? UVC_BASE_T : (diff ? (first4 ? b0 : b1) : cs));
                     }
                     const int mq = maxq_base(cs);
-                    if (strand) apply(a_rr, a_rl, UVC_BASE_SYMBOL, cs, cc, ct, cs4, cc4, ct4, mq, 1, sq, n_cov, n_near, singleton);
-                    else apply(a_fr, a_fl, UVC_BASE_SYMBOL, cs, cc, ct, cs4, cc4, ct4, mq, 0, sq, n_cov, n_near, singleton);
+                    apply(ar, al, UVC_BASE_SYMBOL, cs, cc, ct, cs4, cc4, ct4, mq, strand, sq, n_cov, n_near, singleton);
                 }
             }
         }
     }
+    };
+    run_list(std::false_type{}, a_fr, a_fl, R.frag_off[0], R.frag_off[1]);
+    run_list(std::true_type{}, a_rr, a_rl, R.frag_off[1], R.frag_off[2]);
     if (!valid) return;
     // the atomics above must have landed (and this CU's L1 must not hold older copies) before the planes are read back
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
