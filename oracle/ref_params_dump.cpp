@@ -21,6 +21,12 @@ int main() {
 #define UVC_PI(n, d) printf("%s  \"%s\": %lld", first ? "" : ",\n", #n, (long long)(a.n)); first = false;
 #define UVC_PD(n, d) printf("%s  \"%s\": %.17g", first ? "" : ",\n", #n, (double)(a.n)); first = false;
 #include "uvc_params.def"
+#undef UVC_PI
+#undef UVC_PD
+    // the family-assignment parameters (include/uvc_group_params.def), prefixed "group."
+#define UVC_GI(n, d) printf(",\n  \"group.%s\": %lld", #n, (long long)(a.n));
+#define UVC_GD(n, d) printf(",\n  \"group.%s\": %.17g", #n, (double)(a.n));
+#include "uvc_group_params.def"
     printf("\n}\n");
     return 0;
 }

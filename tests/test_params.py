@@ -11,7 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_defaults_equal_reference_dump():
     ref = json.load(open(os.path.join(ROOT, "tests", "golden", "params_default.json")))
+    from uvc_amd import group
     ours = dict(_ffi.PARAM_INTS + _ffi.PARAM_DBLS)
+    ours.update({"group." + k: v for k, v in group.GROUP_INTS + group.GROUP_DBLS})   # family-assignment parameters (uvc_group_params.def)
     assert set(ref) == set(ours)
     for k, v in ours.items():
         assert ref[k] == v, (k, ref[k], v)
