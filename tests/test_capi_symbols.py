@@ -21,9 +21,12 @@ def dll():
 
 
 def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "uvcgpu.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(uvcgpu_[a-z_0-9]+)\s*\(", txt)))
+    names = set()
+    for hdr in ("uvcgpu.h", "uvcgroup.h"):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(uvcgpu_[a-z_0-9]+)\s*\(", txt))
+    return sorted(names)
 
 
 def test_every_declared_symbol_is_exported(dll):

@@ -27,6 +27,7 @@ extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+extern "C" int uvcgpu_set_error(int code, const char *msg) { return fail(code, msg ? msg : ""); }   // for the other translation units of the library
 #define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(UVCGPU_EDEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
 struct uvcgpu_region {
