@@ -21,6 +21,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -98,6 +100,7 @@ def main():
     ap.add_argument("--tile-kb", type=int, default=1000, help="tile length in kb (chr20 is processed as 1 Mb tiles)")
     ap.add_argument("--depth", type=int, default=300)
     ap.add_argument("--streams", type=int, default=1, help="split the tile into this many regions, each on its own HIP stream, accumulated concurrently")
+    ap.add_argument("--all-out", action="store_true", help="second series of SURVEY 8(d): score every symbol of every position (-A), not only the default-gate candidates")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="CPU-only rehearsal of the multi-rank protocol (no kernels, used by the gloo tests)")
     args = ap.parse_args()
@@ -149,8 +152,8 @@ def main():
     def step():
         for Ri in Rs:          # enqueue only: each region has its own stream
             Ri.accumulate()
-        recs = [Ri.score(capacity=max(65536, sub_len // 4)) for Ri in Rs]
-        return {"refpos": [x for r in recs for x in r["refpos"]]} if len(recs) > 1 else recs[0]
+        recs = [Ri.score(all_out=args.all_out, capacity=(15 * (sub_len + 2) if args.all_out else max(65536, sub_len // 4)), copy=False) for Ri in Rs]
+        return {"refpos": np.concatenate([r["refpos"] for r in recs])} if len(recs) > 1 else recs[0]
 
     for _ in range(args.warmup):
         step()
@@ -181,7 +184,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "chr20-shaped tumor-only non-UMI tile: %d kb at %dx, 150 bp paired-end, one tile per GPU resident in HBM; step = accumulate P1..P5b + default-gate scoring + D2H of records" % (args.tile_kb, args.depth),
-                       "tile_positions": region_len, "streams": args.streams, "reads_per_tile": n_reads_total, "read_bases_per_tile": n_read_bases, "scored_records_per_tile": n_rec,
+                       "tile_positions": region_len, "streams": args.streams, "all_out": bool(args.all_out), "reads_per_tile": n_reads_total, "read_bases_per_tile": n_read_bases, "scored_records_per_tile": n_rec,
                        "parallelism": "region-shard x%d (no collective on the data path)" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(dom, args.tile_kb, args.depth),
                          "algorithmic_bytes_per_launch": abytes, "kernel_ms": avg[dom]},

@@ -137,7 +137,7 @@ class Region:
         self._check(self.lib.call("fetch", self.h, gid, out.ctypes.data, out.nbytes))
         return out
 
-    def score(self, all_out=False, pos_beg=-1, pos_end=-1, is_amplicon=False, indel_alleles=None, capacity=None):
+    def score(self, all_out=False, pos_beg=-1, pos_end=-1, is_amplicon=False, indel_alleles=None, capacity=None, copy=True):
         req = _ffi.UvcScoreRequest()
         req.pos_beg, req.pos_end, req.all_out, req.is_amplicon = pos_beg, pos_end, int(all_out), int(is_amplicon)
         arr = None
@@ -157,7 +157,8 @@ class Region:
                 capacity = int(out.n_records)
                 continue
             self._check(rc)
-            return {name: buf[i, :out.n_records].copy() for i, name in enumerate(_ffi.SCORE_FIELDS)}
+            # copy=False returns views into the handle's reusable buffer (valid until the next score() call)
+            return {name: (buf[i, :out.n_records].copy() if copy else buf[i, :out.n_records]) for i, name in enumerate(_ffi.SCORE_FIELDS)}
 
     def close(self):
         if self.h:
