@@ -224,6 +224,17 @@ typedef struct UvcIndelAllele {
     int32_t indel_len;  /* indelstring.size(),                  main.cpp:907 */
 } UvcIndelAllele;
 
+/* One tumor-sample record of the T/N channel (TumorKeyInfo, main_conversion.hpp:490-529), reduced to what the scoring functions read:
+ * tpfa of calc_DPv = (cDP1x + 1) / (CDP1x + 2) (main.cpp:935), tpfa of calc_qual = (bDP + 0.5) / (BDP + 1) (main.cpp:985-986),
+ * enable_tier2_consensus_format_tags (main.hpp:4475), and for InDels the length of the tumor record's inserted / deleted string
+ * (main.cpp:867-880).  Only read when UvcParams::tumor_vcf_is_provided. */
+typedef struct UvcTumorKey {
+    int32_t refpos, symbol;     /* key (the VTI of the tumor record) */
+    int32_t cDP1x, CDP1x, bDP, BDP;
+    int32_t tier2;
+    int32_t indel_len;
+} UvcTumorKey;
+
 typedef struct UvcScoreRequest {
     int32_t pos_beg;            /* first zerobased_pos scored (rpos_inclu_beg, main.cpp:527); -1 = whole region core */
     int32_t pos_end;            /* exclusive */
@@ -231,6 +242,9 @@ typedef struct UvcScoreRequest {
     int32_t is_amplicon;        /* ASSAY_TYPE_AMPLICON == inferred_assay_type, main.cpp:510-525 */
     int64_t n_indel_alleles;
     const UvcIndelAllele *indel_alleles;
+    int64_t n_tumor_keys;       /* normal sample of a T/N pair: the tumor records of this region, sorted by (refpos, symbol); a position is
+                                 * scored iff it has a record (extended_posidx_to_is_rescued, main.cpp:532-538), every symbol of it */
+    const UvcTumorKey *tumor_keys;
 } UvcScoreRequest;
 
 typedef struct UvcScoreOut {

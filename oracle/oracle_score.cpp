@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE -- NOT PART OF THE PRODUCT (see oracle_common.hpp header).
 //
-// CPU restatement of the scoring half of the hot path, tumor-only (tpfa = -1, is_rescued = false):
+// CPU restatement of the scoring half of the hot path (tumor-only and, with UvcTumorKey records, the normal sample of a T/N pair):
 //   per-position driver loop             main.cpp:608-1000
 //   BcfFormat_symboltype_init            main.hpp:3889-4081
 //   BcfFormat_symbol_init + VQ fmts      main.hpp:3820-3887, 4094-4251
@@ -56,6 +56,7 @@ struct Fmt {
     // symbol-type totals: [0] = sum over the type's symbols, [1] = the NN symbol (fill_symboltype_fmt, main.hpp:3745-3793)
     i64 APDP[12], APXM[8], APLRI[4];
     i64 A1BQf[2], A1BQr[2], AMQs[2], AP1[2], AP2[2], ADPff[2], ADPfr[2], ADPrf[2], ADPrr[2];
+    double tpfa_dpv, tpfa_qual; int tki_tier2;   // T/N channel inputs of this allele (main.cpp:935, 985-986; main.hpp:4475); -1 / -1 / 0 without a tumor record
     i64 ALP1[2], ALP2[2], ALPL[2], ARP1[2], ARP2[2], ARPL[2], ALB2[2], ALBL[2], ARB2[2], ARBL[2], ABQ2[2], APF2[2], ALI2[2], ARIf[2], ARI2[2], ALIr[2];
     i32 BDPb[2], BTAb[2], BTBb[2], CDP1b[2], CDP12b[2], CDP2b[2], CDP3b[2];
     i64 C2LP2[2], C2LPL[2], C2RP2[2], C2RPL[2], C2LB2[2], C2LBL[2], C2RB2[2], C2RBL[2], C2BQ2[2], C2LP0[2], C2RP0[2];
@@ -188,7 +189,7 @@ static void symbol_init(Fmt &f, State &S, i32 refpos, int sym, i32 bDPa, i32 cDP
 static inline bool implies_short_frag(const Fmt &f, i32 wgs_min_avg_fragsize) { return (f.APLRI[0] + f.APLRI[2]) < (f.APLRI[1] + f.APLRI[3]) * (i64)wgs_min_avg_fragsize; }
 static inline double norm_fa(double FA, double refbias) { return (FA + FA * refbias) / (FA + (1.0 - FA) / (1.0 + refbias) + FA * refbias); }   // main.hpp:4253-4256
 
-// BcfFormat_symbol_calc_DPv, main.hpp:4274-4844 (tumor-only: tpfa = -1)
+// BcfFormat_symbol_calc_DPv, main.hpp:4274-4844
 static void calc_DPv(Fmt &fmt, const Rtr &rtr1, const Rtr &rtr2, int refsymbol, State &S, i32 refpos) {
     const UvcParams &P = S.P;
     const i64 x = refpos - S.beg;
@@ -200,8 +201,9 @@ static void calc_DPv(Fmt &fmt, const Rtr &rtr1, const Rtr &rtr2, int refsymbol, 
     const i32 pcr_dp = S.p32(UVC_P_a_pcr_dp, x), a_dp = S.p32(UVC_P_a_dp, x), near_pcr_clip = S.p32(UVC_P_a_near_pcr_clip_dp, x);
     const bool is_strong_amplicon = (pcr_dp * 100 > a_dp * 50);
     const bool is_weak_amplicon = (pcr_dp * 100 > a_dp * 30);
-    const bool is_rescued = false;
-    const double pfa = 0.5;
+    const double tpfa = fmt.tpfa_dpv;
+    const bool is_rescued = (tpfa >= 0);
+    const double pfa = (is_rescued ? tpfa : 0.5);
     const double c2altpc = 0.025;
     const i32 ADP1 = (i32)(f.ADPff[0] + f.ADPfr[0] + f.ADPrf[0] + f.ADPrr[0]);
     const i32 aDP1 = (f.aDPff + f.aDPfr + f.aDPrf + f.aDPrr);
@@ -291,7 +293,7 @@ static void calc_DPv(Fmt &fmt, const Rtr &rtr1, const Rtr &rtr2, int refsymbol, 
     const i32 normBDP = (f.BDPb[0] + f.BDPb[1]) + 1;
     const i32 c2DP = f.cDP2f + f.cDP2r;
     const bool try_tier2 = ((c2DP >= 2) && (normBDP * P.fam_bias_overseq_perc >= normCDP1 * 100) && (S.p32(UVC_P_a_umi_dp, x) * 100 > a_dp * 50));
-    fmt.tier2 = (is_rescued ? 0 : (try_tier2 ? 1 : 0));
+    fmt.tier2 = (is_rescued ? (fmt.tki_tier2 ? 1 : 0) : (try_tier2 ? 1 : 0));
     // sic: "fmt.c2LP0[0]" and "fmt.c2LP0[a]" are the same element (a = 0) in the MIN() of main.hpp:4477-4478
     const double cFA2L = (fmt.tier2 ? (((double)(((i64)f.c2LP0 * (i64)f.c2LP0) * 2 / max_((i64)1, (i64)min_(c2DP, f.c2LP0 * 4))) + c2altpc) / (f.C2LP0[0] + 1.0)) : 1.0);
     const double cFA2R = (fmt.tier2 ? (((double)(((i64)f.c2RP0 * (i64)f.c2RP0) * 2 / max_((i64)1, (i64)min_(c2DP, f.c2RP0 * 4))) + c2altpc) / (f.C2RP0[0] + 1.0)) : 1.0);
@@ -423,7 +425,13 @@ static void calc_DPv(Fmt &fmt, const Rtr &rtr1, const Rtr &rtr2, int refsymbol, 
     const double counterbias_FA = max_(counterbias_P_FA, max_(counterbias_BQ_FA, cb_normalgerm));
     const double dedup_FA = (!tprov ? min_(bFA, cFA0) : max_(bFA, cFA0));
     const double frac_umi2seg = min_(1.0, min_(c23FA / aDPFA, aDPFA / c23FA));
-    const double refbias = 0;   // only non-zero when is_rescued (main.hpp:4804-4810)
+    double refbias = 0;
+    if ((is_ins(symbol) || is_del(symbol)) && is_rescued) {   // main.hpp:4804-4810
+        const i32 isz = fmt.gapSa_len;
+        const i32 indel_noinfo_nbases = (isz * (is_ins(symbol) ? 2 : 1) + max_(isz, max_(rtr1.tracklen, rtr2.anyTR_tracklen)));
+        refbias = (double)(indel_noinfo_nbases) / ((double)(min_(f.ALPL[0], f.ARPL[0]) * 2 + indel_noinfo_nbases) / (double)(f.ABQ2[0] + 0.5));
+        refbias = min_(refbias, P.microadjust_refbias_indel_max);
+    }
     const i32 sumCDP1 = f.CDP1b[0] + f.CDP1b[1], sumCDP2 = f.CDP2b[0] + f.CDP2b[1];
     const double min_abcFA_v = max_(min_(min_(t1plus_min, t1only_min), aNCFA), counterbias_FA);
     fmt.cDP1v = (i32)(norm_fa(min_abcFA_v, refbias) * sumCDP1 * 100);
@@ -448,14 +456,14 @@ static void calc_DPv(Fmt &fmt, const Rtr &rtr1, const Rtr &rtr2, int refsymbol, 
     fmt.cDP2x = 1 + (i32)(min_c23FA_x * sumCDP2 * 100);
 }
 
-// BcfFormat_symbol_calc_qual, main.hpp:4908-5343 (tumor-only: is_rescued = false, tpfa = -1)
+// BcfFormat_symbol_calc_qual, main.hpp:4908-5343; is_rescued = IS_PROVIDED(vcf_tumor_fname) as the caller passes it (main.cpp:979)
 static void calc_qual(Fmt &fmt, i32 ins_cdepth, i32 del_cdepth, i32 ins1_cdepth, i32 del1_cdepth, i32 repeatunit_size, i32 repeatnum,
                       const Rtr &rtr1, const Rtr &rtr2, i32 refpos, int refsymbol, State &S) {
     const UvcParams &P = S.P;
     const i64 x = refpos - S.beg;
     const bool tprov = P.tumor_vcf_is_provided;
     const bool is_rescued = tprov;
-    const double tpfa = -1.0;
+    const double tpfa = fmt.tpfa_qual;
     const int symbol = fmt.symbol;
     const i32 indel_size = fmt.gapSa_len;
     const i32 sumCDP1 = fmt.CDP1b[0] + fmt.CDP1b[1], sumCDP2 = fmt.CDP2b[0] + fmt.CDP2b[1], sumBDP = fmt.BDPb[0] + fmt.BDPb[1], sumCDP12 = fmt.CDP12b[0] + fmt.CDP12b[1];
@@ -683,7 +691,9 @@ static void emit(const Fmt &f, std::vector<i32> &r) {
 int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &records, std::string &err) {
     if (!S.accumulated) { err = "score before accumulate"; return UVCGPU_ESTATE; }
     const UvcParams &P = S.P;
-    if (P.tumor_vcf_is_provided) { err = "T/N rescue scoring is SURVEY next-row N2"; return UVCGPU_EUNSUPPORTED; }
+    const bool tprov = P.tumor_vcf_is_provided;
+    const UvcTumorKey *tk = (req ? req->tumor_keys : NULL); const i64 ntk = (req ? req->n_tumor_keys : 0);
+    auto pos_rescued = [&](i32 refpos) { for (i64 q = 0; q < ntk; q++) if (tk[q].refpos == refpos) return true; return false; };   // extended_posidx_to_is_rescued
     const i32 ext_beg = S.beg;
     const i32 refsize = (i32)S.refstring.size();
     i32 pos_beg = (req && req->pos_beg >= 0) ? req->pos_beg : S.beg + 1;
@@ -719,16 +729,32 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
                 const i32 cdepth = max_(S.FA(0, UVC_FAM_cDP1, symbol, x), S.FA(0, UVC_FAM_cDP12, symbol, x)) + max_(S.FA(1, UVC_FAM_cDP1, symbol, x), S.FA(1, UVC_FAM_cDP12, symbol, x));
                 if (is_ins(symbol)) { ins_cdepth += cdepth; if (UVC_LINK_I1 == symbol) ins1_cdepth += cdepth; }
                 else if (is_del(symbol)) { del_cdepth += cdepth; if (UVC_LINK_D1 == symbol) del1_cdepth += cdepth; }
-                if ((((refsymbol != symbol) && (bdepth < P.min_altdp_thres)) || ((refsymbol == symbol) && (bDPcDP[0] - ref_bdepth < P.min_altdp_thres))) && (!all_out)) continue;
-                // allele list: host-supplied InDel alleles, else the single default allele (see UvcIndelAllele)
+                if ((!tprov) && (((refsymbol != symbol) && (bdepth < P.min_altdp_thres)) || ((refsymbol == symbol) && (bDPcDP[0] - ref_bdepth < P.min_altdp_thres))) && (!all_out)) continue;
+                if (tprov && !pos_rescued(refpos)) continue;                      // main.cpp:838-840
+                // allele list: the tumor records of this (position, symbol) if any (is_var_rescued, main.cpp:806, 864-900), else the
+                // host-supplied InDel alleles, else the single default allele (see UvcIndelAllele)
                 std::vector<UvcIndelAllele> alleles;
-                if (is_ins(symbol) || is_del(symbol)) {
+                std::vector<const UvcTumorKey *> akeys;
+                if (tprov) for (i64 q = 0; q < ntk; q++) if (tk[q].refpos == refpos && tk[q].symbol == symbol) {
+                    UvcIndelAllele d = { refpos, symbol, bdepth, cdepth, (is_ins(symbol) || is_del(symbol)) ? tk[q].indel_len : 0 };
+                    alleles.push_back(d); akeys.push_back(&tk[q]);
+                }
+                if (!alleles.empty()) {}
+                else if (is_ins(symbol) || is_del(symbol)) {
                     if (req) for (i64 q = 0; q < req->n_indel_alleles; q++) if (req->indel_alleles[q].refpos == refpos && req->indel_alleles[q].symbol == symbol) alleles.push_back(req->indel_alleles[q]);
                     if (alleles.empty()) { UvcIndelAllele d = { refpos, symbol, bdepth, cdepth, (symbol == UVC_LINK_I1 || symbol == UVC_LINK_D1) ? 1 : ((symbol == UVC_LINK_I2 || symbol == UVC_LINK_D2) ? 2 : 3) }; alleles.push_back(d); }
                 } else { UvcIndelAllele d = { refpos, symbol, bdepth, cdepth, 0 }; alleles.push_back(d); }
-                for (const UvcIndelAllele &al : alleles) {
+                for (size_t ai = 0; ai < alleles.size(); ai++) {
+                    const UvcIndelAllele &al = alleles[ai];
                     Fmt f = init;
                     f.refpos = refpos; f.refsymbol = refsymbol;
+                    f.tpfa_dpv = f.tpfa_qual = -1.0; f.tki_tier2 = 0;
+                    if (ai < akeys.size()) {
+                        const UvcTumorKey &k = *akeys[ai];
+                        f.tpfa_dpv = (double)(k.cDP1x + 1) / (double)(k.CDP1x + 2);          // main.cpp:935
+                        f.tpfa_qual = (double)(k.bDP + 0.5) / (double)(k.BDP + 1.0);         // main.cpp:985-986
+                        f.tki_tier2 = k.tier2;
+                    }
                     const bool homopol_1bp = (prev_base1 == refsymbol && next_base1 == refsymbol);
                     const bool homopol_2bp = (prev_base2 == refsymbol && next_base2 == refsymbol);
                     const i32 minABQ = (is_subst(symbol) ? (i32)nnminus(minABQ_snv, (homopol_1bp ? (homopol_2bp ? 20 : 10) : 0)) : minABQ_indel);

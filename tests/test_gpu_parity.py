@@ -85,3 +85,36 @@ def test_reads_with_many_mismatches_and_indels(oracle_lib, gpu_lib):
     assert not bad, "\n".join("%s: %d cells differ, e.g. %s" % (g, v[0], v[1]) for g, v in bad.items())
     worst = compare_records(Ro.score(all_out=False), Rg.score(all_out=False))
     print({k: v for k, v in worst.items() if v})
+
+
+def tumor_keys_from(records, every=2):
+    """A plausible tumor-sample channel made from the tumor-only records of the same data: every `every`-th record becomes a key."""
+    keys = []
+    for i in range(0, len(records["refpos"]), every):
+        sym = int(records["symbol"][i])
+        is_indel = sym in (7, 8, 9, 10, 11, 12)
+        keys.append((int(records["refpos"][i]), sym, int(records["cDP1x"][i]), int(records["CDP1x0"][i]), int(records["bAD"][i]), int(records["bDP"][i]),
+                     int(records["tier2"][i]) | (i % 2), (1 + i % 4) if is_indel else 0))
+    keys = sorted(set(keys), key=lambda k: (k[0], k[1]))
+    return keys
+
+
+@pytest.mark.parametrize("name", ["config1_10kb_30x", "umi_duplex_2kb_400x"])
+def test_normal_sample_of_a_tn_pair(name, oracle_lib, gpu_lib):
+    """SURVEY next-row N2: with vcf_tumor_fname provided only positions that carry a tumor record are scored, every symbol of them,
+    and tpfa / the tier-2 flag / the InDel length come from the record (main.cpp:806-986, main.hpp:4297, 4475, 4804-4810)."""
+    from uvc_amd import region
+    reads = synth.generate_region(**CASES[name])
+    keys = tumor_keys_from(run_region(oracle_lib, reads).score(all_out=False))
+    assert len(keys) >= 8
+    out = []
+    for lib in (oracle_lib, gpu_lib):
+        p = region.default_params(lib)
+        p.tumor_vcf_is_provided = 1
+        R = run_region(lib, reads, params=p)
+        out.append(R.score(tumor_keys=keys))
+    ro, rg = out
+    assert set(zip(ro["refpos"].tolist())) == set((k[0],) for k in keys)      # exactly the rescued positions
+    assert len(ro["refpos"]) >= 14 * len(set(k[0] for k in keys))              # every symbol of both symbol types at a rescued position
+    worst = compare_records(ro, rg)
+    print(name, len(ro["refpos"]), {k: v for k, v in worst.items() if v})

@@ -47,9 +47,14 @@ class UvcIndelAllele(C.Structure):
     _fields_ = [("refpos", C.c_int32), ("symbol", C.c_int32), ("bDPa", C.c_int32), ("cDP0a", C.c_int32), ("indel_len", C.c_int32)]
 
 
+class UvcTumorKey(C.Structure):
+    _fields_ = [("refpos", C.c_int32), ("symbol", C.c_int32), ("cDP1x", C.c_int32), ("CDP1x", C.c_int32), ("bDP", C.c_int32), ("BDP", C.c_int32),
+                ("tier2", C.c_int32), ("indel_len", C.c_int32)]
+
+
 class UvcScoreRequest(C.Structure):
     _fields_ = [("pos_beg", C.c_int32), ("pos_end", C.c_int32), ("all_out", C.c_int32), ("is_amplicon", C.c_int32),
-                ("n_indel_alleles", C.c_int64), ("indel_alleles", C.c_void_p)]
+                ("n_indel_alleles", C.c_int64), ("indel_alleles", C.c_void_p), ("n_tumor_keys", C.c_int64), ("tumor_keys", C.c_void_p)]
 
 
 class UvcScoreOut(C.Structure):

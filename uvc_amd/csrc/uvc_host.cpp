@@ -21,7 +21,7 @@ extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const 
 struct UvcProf { int on; int n; const char *name[24]; hipEvent_t ev[24][2]; };
 extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, int half_ratio_phred,
                                       const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof);
-extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles,
+extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles, const UvcTumorKey *d_tkeys,
                                 int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch, hipStream_t s);
 extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored);
 
@@ -526,13 +526,12 @@ int uvcgpu_region_fetch(uvcgpu_region_t *r, int32_t g, void *dst, int64_t dst_by
 int64_t uvcgpu_region_score_size(const uvcgpu_region_t *r, const UvcScoreRequest *req) {
     if (!r) return -1;
     const int64_t np = (req && req->pos_beg >= 0) ? (req->pos_end - req->pos_beg) : r->npos;
-    return NSYM * (np + 1) + (req ? req->n_indel_alleles : 0);
+    return NSYM * (np + 1) + (req ? req->n_indel_alleles + req->n_tumor_keys : 0);
 }
 
 int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScoreOut *out) {
     if (!r || !out || !out->fields) return fail(UVCGPU_EINVAL, "bad argument");
     if (!r->accumulated) return fail(UVCGPU_ESTATE, "score before accumulate");
-    if (r->P.tumor_vcf_is_provided) return fail(UVCGPU_EUNSUPPORTED, "T/N rescue scoring is SURVEY next-row N2");
     UvcScoreRequest rq; memset(&rq, 0, sizeof(rq)); rq.pos_beg = -1;
     if (req) rq = *req;
     if (rq.pos_beg < 0) { rq.pos_beg = r->beg + 1; rq.pos_end = r->end - 1; }
@@ -541,6 +540,15 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
     if (rq.n_indel_alleles > 0) {
         HIP_OK(hipMalloc((void **)&d_al, sizeof(UvcIndelAllele) * rq.n_indel_alleles));
         HIP_OK(hipMemcpyAsync(d_al, rq.indel_alleles, sizeof(UvcIndelAllele) * rq.n_indel_alleles, hipMemcpyHostToDevice, r->stream));
+    }
+    UvcTumorKey *d_tk = nullptr;
+    if (r->P.tumor_vcf_is_provided && rq.n_tumor_keys > 0) {   // normal sample of a T/N pair: the tumor records, sorted by (refpos, symbol)
+        for (int64_t q = 1; q < rq.n_tumor_keys; q++) {
+            const UvcTumorKey &a = rq.tumor_keys[q - 1], &b = rq.tumor_keys[q];
+            if (a.refpos > b.refpos || (a.refpos == b.refpos && a.symbol > b.symbol)) { if (d_al) hipFree(d_al); return fail(UVCGPU_EINVAL, "tumor_keys must be sorted by (refpos, symbol)"); }
+        }
+        HIP_OK(hipMalloc((void **)&d_tk, sizeof(UvcTumorKey) * rq.n_tumor_keys));
+        HIP_OK(hipMemcpyAsync(d_tk, rq.tumor_keys, sizeof(UvcTumorKey) * rq.n_tumor_keys, hipMemcpyHostToDevice, r->stream));
     }
     const int64_t cap = std::max<int64_t>(out->capacity, 1);
     if (cap > r->score_capacity) {
@@ -558,7 +566,7 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
         r->score_scratch_bytes = need;
     }
     HIP_OK(hipMemsetAsync(r->d_score_count, 0, 8, r->stream));
-    int rc = uvc_launch_score(&r->R, &r->P, &rq, d_al, r->d_score_fields, r->score_capacity, r->d_score_count, r->d_score_scratch, r->stream);
+    int rc = uvc_launch_score(&r->R, &r->P, &rq, d_al, d_tk, r->d_score_fields, r->score_capacity, r->d_score_count, r->d_score_scratch, r->stream);
     if (!rc && hipGetLastError() != hipSuccess) rc = fail(UVCGPU_EDEVICE, "score kernel launch failed");
     if (!rc) rc = uvcgpu_region_sync(r);
     int64_t cnt = 0;
@@ -570,6 +578,7 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
             rc = fail(UVCGPU_EDEVICE, "hipMemcpy2D(records)");
     }
     if (d_al) hipFree(d_al);
+    if (d_tk) hipFree(d_tk);
     return rc;
 }
 

@@ -6,7 +6,7 @@
 //   BcfFormat_symbol_calc_DPv  main.hpp:4274   -> calc_dpv()
 //   BcfFormat_symbol_sum_DPv   main.hpp:4888   -> in-thread reduction (one thread owns a (position, symbol type) group)
 //   BcfFormat_symbol_calc_qual main.hpp:4908   -> calc_qual()
-// Tumor-only (tpfa = -1, is_rescued = false); the T/N rescue arms are SURVEY next-row N2.
+// Tumor-only, and with UvcTumorKey records in the request the normal sample of a T/N pair (SURVEY next-row N2).
 //
 // Launch shape: k_score_count  one thread per (zerobased_pos, symbol type): number of emitted alleles (candidate gate, main.cpp:832-837)
 //               k_scan_*       exclusive prefix sum -> deterministic record slots, in the reference's emission order
@@ -221,14 +221,15 @@ DEV RtrLite load_rtr(const RegionDev &R, int idx) { RtrLite r; r.tracklen = RTRP
 
 // BcfFormat_symbol_calc_DPv, main.hpp:4274-4844
 DEV void calc_dpv(const RegionDev &R, const UvcParams &P, int64_t x, const Tot &T, Al &f, const RtrLite &rtr1, const RtrLite &rtr2, int refsymbol,
-                  int32_t *fields, int64_t capacity, int64_t rec) {
+                  double tpfa, int tki_tier2, int32_t *fields, int64_t capacity, int64_t rec) {
     const bool tprov = P.tumor_vcf_is_provided;
     const double unbias_ratio = (!tprov ? 1.0 : sqrt(2.0));
     const double unbias_qualadd = (!tprov ? 0 : 3);
     const int allprior = (!tprov ? 0 : 31);
     const int pcr_dp = (int)T.APDP[5], a_dp = (int)T.APDP[0], near_pcr_clip = (int)T.APDP[9];
     const bool strong_amp = (pcr_dp * 100 > a_dp * 50), weak_amp = (pcr_dp * 100 > a_dp * 30);
-    const double pfa = 0.5, c2altpc = 0.025;
+    const bool is_rescued = (tpfa >= 0);   // main.hpp:4297-4298
+    const double pfa = (is_rescued ? tpfa : 0.5), c2altpc = 0.025;
     const int ADP1 = (int)(T.ADPff0 + T.ADPfr0 + T.ADPrf0 + T.ADPrr0);
     const int aDP = (f.aDPff + f.aDPfr + f.aDPrf + f.aDPrr);
     const int ADP = imax(ADP1, near_pcr_clip);
@@ -301,7 +302,7 @@ DEV void calc_dpv(const RegionDev &R, const UvcParams &P, int64_t x, const Tot &
     const bool tmore_amp = (!tprov ? weak_amp : strong_amp);
     const int normCDP1 = (T.CDP12b[0] + T.CDP12b[1]) + 1, normBDP = (T.BDPb[0] + T.BDPb[1]) + 1;
     const int c2DP = f.cDP2f + f.cDP2r;
-    f.tier2 = ((c2DP >= 2) && (normBDP * P.fam_bias_overseq_perc >= normCDP1 * 100) && (T.APDP[11] * 100 > (long long)a_dp * 50)) ? 1 : 0;
+    f.tier2 = (is_rescued ? (tki_tier2 ? 1 : 0) : (((c2DP >= 2) && (normBDP * P.fam_bias_overseq_perc >= normCDP1 * 100) && (T.APDP[11] * 100 > (long long)a_dp * 50)) ? 1 : 0));   // main.hpp:4475
     OUT(UVC_O_tier2, f.tier2);
     const double cFA2L = (f.tier2 ? (((double)(((long long)f.c2LP0 * f.c2LP0) * 2 / lmax(1, (long long)imin(c2DP, f.c2LP0 * 4))) + c2altpc) / (T.C2LP00 + 1.0)) : 1.0);
     const double cFA2R = (f.tier2 ? (((double)(((long long)f.c2RP0 * f.c2RP0) * 2 / lmax(1, (long long)imin(c2DP, f.c2RP0 * 4))) + c2altpc) / (T.C2RP00 + 1.0)) : 1.0);
@@ -390,8 +391,8 @@ DEV void calc_dpv(const RegionDev &R, const UvcParams &P, int64_t x, const Tot &
     double t1only = dmin(cROFA1, dmin(aLPFA2, dmin(aRPFA2, dmin(aLBFA2, dmin(aRBFA2, cFA0)))));
     t1only = dmin(t1only, dmin(aDPFA * dbetween(1.0 + aDPFA - alt_frac, 0.1, 1.0), aPFFA * aSSFA2 / dmax(aSSFA2, SS2[1])));
     const double t1plus = dmin(aSSFA2, dmin(aLIFA2, dmin(aRIFA2, dmin(dmax(aDPFA * 0.01, aSIFA), bFA))));
-    const double cFA2a = (tmore_primer ? (cFA2 * (P.powlaw_amplicon_allele_fraction_coef)) : cFA2);
-    const double cFA3a = ((normBDP * 100 > normCDP1 * ((P.fam_tier3DP_bias_overseq_perc - 100) / 1 + 100)) ? cFA3 : 1.0);
+    const double cFA2a = ((tmore_primer && !is_rescued) ? (cFA2 * (P.powlaw_amplicon_allele_fraction_coef)) : cFA2);
+    const double cFA3a = ((normBDP * 100 > normCDP1 * ((P.fam_tier3DP_bias_overseq_perc - 100) / (is_rescued ? 2 : 1) + 100)) ? cFA3 : 1.0);
     const double c23FA = cFA2a;
     const double t2only = dmin(cROFA2, dmin(c2LPFA2, dmin(c2RPFA2, dmin(c2LBFA2, dmin(c2RBFA2, dmin(cFA2a, dmin(cFA3a, dmin(cFA2L, cFA2R))))))));
     OUT(UVC_O_nNFA0, -numstates2deciphred(cbP)); OUT(UVC_O_nNFA1, -numstates2deciphred(cbBQ)); OUT(UVC_O_nNFA2, -numstates2deciphred(aDPFA));
@@ -415,7 +416,13 @@ DEV void calc_dpv(const RegionDev &R, const UvcParams &P, int64_t x, const Tot &
     const double cbFA = dmax(cbP, dmax(cbBQ, cb_normalgerm));
     const double dedup_FA = (!tprov ? dmin(bFA, cFA0) : dmax(bFA, cFA0));
     const double frac_umi2seg = dmin(1.0, dmin(c23FA / aDPFA, aDPFA / c23FA));
-    const double refbias = 0;
+    double refbias = 0;
+    if ((is_ins(f.symbol) || is_del(f.symbol)) && is_rescued) {   // main.hpp:4804-4810
+        const int isz = f.gap_len;
+        const int noinfo = (isz * (is_ins(f.symbol) ? 2 : 1) + imax(isz, imax(rtr1.tracklen, rtr2.anyTR_tracklen)));
+        refbias = (double)(noinfo) / ((double)(lmin(T.ALPL0, T.ARPL0) * 2 + noinfo) / (double)(T.ABQ20 + 0.5));
+        refbias = dmin(refbias, P.microadjust_refbias_indel_max);
+    }
     f.cDP1v = (int)(norm_fa(dmax(dmin(dmin(t1plus, t1only), aNCFA), cbFA), refbias) * sumCDP1 * 100);
     f.cDP1w = (int)(norm_fa(dmax(dmin(aLPFA2, dmin(aRPFA2, dmin(aLBFA2, dmin(aRBFA2, dmin(bFA, aNCFA))))), cbFA), refbias) * sumCDP1 * 100);
     double abc_x = dmin(aPFFA, dedup_FA);
@@ -435,9 +442,8 @@ DEV void calc_dpv(const RegionDev &R, const UvcParams &P, int64_t x, const Tot &
 // BcfFormat_symbol_calc_qual, main.hpp:4908-5343
 DEV void calc_qual(const RegionDev &R, const UvcParams &P, const Tot &T, const Al &f, const int CDP1v0, const int CDP1x0,
                    int ins_cdepth, int del_cdepth, int ins1_cdepth, int del1_cdepth, int ru_size, int repeatnum, const RtrLite &rtr1, const RtrLite &rtr2, int refsymbol,
-                   int32_t *fields, int64_t capacity, int64_t rec) {
-    const bool tprov = P.tumor_vcf_is_provided, is_rescued = tprov;
-    const double tpfa = -1.0;
+                   double tpfa, int32_t *fields, int64_t capacity, int64_t rec) {
+    const bool tprov = P.tumor_vcf_is_provided, is_rescued = tprov;   // the caller passes IS_PROVIDED(vcf_tumor_fname), main.cpp:979
     const int symbol = f.symbol, indel_size = f.gap_len;
     const int sumCDP1 = T.CDP1b[0] + T.CDP1b[1], sumCDP2 = T.CDP2b[0] + T.CDP2b[1], sumBDP = T.BDPb[0] + T.BDPb[1], sumCDP12 = T.CDP12b[0] + T.CDP12b[1];
     const double cFA2 = (f.cDP2f + f.cDP2r + 0.5) / (sumCDP2 + 1.0);
@@ -621,6 +627,7 @@ DEV void calc_qual(const RegionDev &R, const UvcParams &P, const Tot &T, const A
 struct ScoreCtx {
     int pos_beg, pos_end, all_out, is_amplicon;
     const UvcIndelAllele *alleles; long long n_alleles;   // sorted by (refpos, symbol)
+    const UvcTumorKey *tkeys; long long n_tkeys;          // sorted by (refpos, symbol); only read when tumor_vcf_is_provided
     int32_t *fields; long long capacity;
     long long *offsets;   // exclusive prefix of per-group packed (flag << 32 | allele count), [2 * (pos_end - pos_beg) + 1]
     int *active;          // groups with at least one allele, ascending
@@ -644,10 +651,30 @@ DEV int allele_multiplicity(const ScoreCtx &C, int refpos, int symbol, long long
     return (int)(hi - lo);
 }
 
-// candidate gate, main.cpp:801-837
-DEV bool gate(const RegionDev &R, const UvcParams &P, int64_t x, int st, int symbol, int refsymbol, int totBDP, bool all_out, int &bdepth, int &cdepth) {
+DEV long long tkey_lower_bound(const ScoreCtx &C, int refpos, int symbol) {
+    long long lo = 0, hi = C.n_tkeys;
+    while (lo < hi) { long long mid = (lo + hi) >> 1; const UvcTumorKey &a = C.tkeys[mid]; if (a.refpos < refpos || (a.refpos == refpos && a.symbol < symbol)) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+// alleles of one (position, symbol): the tumor records when there are any (src = 2, is_var_rescued, main.cpp:806, 864-900), else the
+// host-supplied InDel alleles (src = 1), else the single default allele (src = 0)
+DEV int allele_source(const ScoreCtx &C, bool tprov, int refpos, int symbol, long long &first, int &src) {
+    if (tprov && C.n_tkeys) {
+        const long long lo = tkey_lower_bound(C, refpos, symbol);
+        long long hi = lo;
+        while (hi < C.n_tkeys && C.tkeys[hi].refpos == refpos && C.tkeys[hi].symbol == symbol) hi++;
+        if (hi > lo) { first = lo; src = 2; return (int)(hi - lo); }
+    }
+    const int m = allele_multiplicity(C, refpos, symbol, first);
+    src = (first >= 0 ? 1 : 0);
+    return m;
+}
+
+// candidate gate, main.cpp:801-840
+DEV bool gate(const RegionDev &R, const UvcParams &P, int64_t x, int st, int symbol, int refsymbol, int totBDP, bool all_out, bool pos_rescued, int &bdepth, int &cdepth) {
     bdepth = FRP(R, 0, UVC_FRAG_bDP, symbol, x) + FRP(R, 1, UVC_FRAG_bDP, symbol, x);
     cdepth = imax(FAP(R, 0, UVC_FAM_cDP1, symbol, x), FAP(R, 0, UVC_FAM_cDP12, symbol, x)) + imax(FAP(R, 1, UVC_FAM_cDP1, symbol, x), FAP(R, 1, UVC_FAM_cDP12, symbol, x));
+    if (P.tumor_vcf_is_provided) return pos_rescued;   // normal sample: every symbol of a position the tumor has a record at, nothing else (main.cpp:832-840)
     if (all_out) return true;
     if (refsymbol != symbol) return !(bdepth < P.min_altdp_thres);
     return !(totBDP - bdepth < P.min_altdp_thres);
@@ -671,10 +698,12 @@ __global__ void __launch_bounds__(256) k_score_count(RegionDev R, UvcParams P, S
         const int refsymbol = group_refsymbol(R, zpos, st);
         int totBDP = 0;
         for (int k = 0; k < st_count(st); k++) { const int s = st_symbol(st, k); totBDP += FRP(R, 0, UVC_FRAG_bDP, s, x) + FRP(R, 1, UVC_FRAG_bDP, s, x); }
+        bool pos_rescued = false;
+        if (P.tumor_vcf_is_provided && C.n_tkeys) { const long long q = tkey_lower_bound(C, refpos, 0); pos_rescued = (q < C.n_tkeys && C.tkeys[q].refpos == refpos); }
         for (int k = 0; k < st_count(st); k++) {
             const int s = st_symbol(st, k);
             int bd, cd;
-            if (gate(R, P, x, st, s, refsymbol, totBDP, C.all_out, bd, cd)) { long long first; n += allele_multiplicity(C, refpos, s, first); }
+            if (gate(R, P, x, st, s, refsymbol, totBDP, C.all_out, pos_rescued, bd, cd)) { long long first; int src; n += allele_source(C, P.tumor_vcf_is_provided, refpos, s, first, src); }
         }
     }
     counts[g] = (long long)n | (n > 0 ? (1LL << 32) : 0LL);
@@ -772,13 +801,18 @@ __global__ void __launch_bounds__(128) k_score(RegionDev R, UvcParams P, ScoreCt
         for (int k = 0; k < st_count(st); k++) {
             const int symbol = st_symbol(st, k);
             int bdepth, cdepth;
-            if (!gate(R, P, x, st, symbol, refsymbol, totBDP, C.all_out, bdepth, cdepth)) continue;
-            long long first;
-            const int mult = allele_multiplicity(C, refpos, symbol, first);
+            if (!gate(R, P, x, st, symbol, refsymbol, totBDP, C.all_out, true /* an active group of a normal sample is a rescued position */, bdepth, cdepth)) continue;
+            long long first; int src;
+            const int mult = allele_source(C, P.tumor_vcf_is_provided, refpos, symbol, first, src);
             for (int ai = 0; ai < mult; ai++, rec++) {
-                int bDPa = bdepth, cDP0a = cdepth, glen = 0;
-                if (is_ins(symbol) || is_del(symbol)) {
-                    if (first >= 0) { const UvcIndelAllele &al = C.alleles[first + ai]; bDPa = al.bDPa; cDP0a = al.cDP0a; glen = al.indel_len; }
+                int bDPa = bdepth, cDP0a = cdepth, glen = 0, tki_tier2 = 0;
+                double tpfa_dpv = -1.0, tpfa_qual = -1.0;
+                if (src == 2) {   // tumor record: main.cpp:935, 985-986
+                    const UvcTumorKey &tk = C.tkeys[first + ai];
+                    tpfa_dpv = (double)(tk.cDP1x + 1) / (double)(tk.CDP1x + 2); tpfa_qual = (double)(tk.bDP + 0.5) / (double)(tk.BDP + 1.0); tki_tier2 = tk.tier2;
+                    if (is_ins(symbol) || is_del(symbol)) glen = tk.indel_len;
+                } else if (is_ins(symbol) || is_del(symbol)) {
+                    if (src == 1) { const UvcIndelAllele &al = C.alleles[first + ai]; bDPa = al.bDPa; cDP0a = al.cDP0a; glen = al.indel_len; }
                     else glen = ((symbol == UVC_LINK_I1 || symbol == UVC_LINK_D1) ? 1 : ((symbol == UVC_LINK_I2 || symbol == UVC_LINK_D2) ? 2 : 3));
                 }
                 const int minABQ = (is_subst(symbol) ? (int)nnminus(minABQ_snv, (hp1 ? (hp2 ? 20 : 10) : 0)) : minABQ_indel);
@@ -789,7 +823,7 @@ __global__ void __launch_bounds__(128) k_score(RegionDev R, UvcParams P, ScoreCt
                     OUT(UVC_O_DP, T.CDP1b[0] + T.CDP1b[1]); OUT(UVC_O_bDP, T.BDPb[0] + T.BDPb[1]); OUT(UVC_O_c2DP, T.CDP2b[0] + T.CDP2b[1]); OUT(UVC_O_c2AD, f.cDP2f + f.cDP2r);
                     OUT(UVC_O_bDPa, bDPa); OUT(UVC_O_cDP0a, cDP0a);
                     OUT(UVC_O_a2BQf, f.a2BQf); OUT(UVC_O_a2BQr, f.a2BQr); OUT(UVC_O_aBQ, f.aBQ); OUT(UVC_O_aBQQ, f.aBQQ); OUT(UVC_O_bMQ, f.bMQ);
-                    calc_dpv(R, P, x, T, f, rtr1, rtr2, refsymbol, fields, capacity, rec);
+                    calc_dpv(R, P, x, T, f, rtr1, rtr2, refsymbol, tpfa_dpv, tki_tier2, fields, capacity, rec);
                     const int v[6] = { f.cDP1v, f.cDP1w, f.cDP1x, f.cDP2v, f.cDP2w, f.cDP2x };
                     for (int i = 0; i < 6; i++) s1[i] += v[i];
                     if (UVC_BASE_NN == symbol || UVC_LINK_NN == symbol) for (int i = 0; i < 6; i++) s2[i] = v[i];
@@ -799,7 +833,7 @@ __global__ void __launch_bounds__(128) k_score(RegionDev R, UvcParams P, ScoreCt
                     f.cDP1v = fields[(size_t)UVC_O_cDP1v * capacity + rec]; f.cDP1w = fields[(size_t)UVC_O_cDP1w * capacity + rec]; f.cDP1x = fields[(size_t)UVC_O_cDP1x * capacity + rec];
                     f.cDP2v = fields[(size_t)UVC_O_cDP2v * capacity + rec]; f.cDP2w = fields[(size_t)UVC_O_cDP2w * capacity + rec]; f.cDP2x = fields[(size_t)UVC_O_cDP2x * capacity + rec];
                     for (int i = 0; i < 6; i++) { OUT(UVC_O_CDP1v0 + 2 * i, s1[i]); OUT(UVC_O_CDP1v0 + 2 * i + 1, s2[i]); }
-                    calc_qual(R, P, T, f, s1[0], s1[2], ins_cdepth, del_cdepth, ins1_cdepth, del1_cdepth, ru_size, repeatnum, rtr1, rtr2, refsymbol, fields, capacity, rec);
+                    calc_qual(R, P, T, f, s1[0], s1[2], ins_cdepth, del_cdepth, ins1_cdepth, del1_cdepth, ru_size, repeatnum, rtr1, rtr2, refsymbol, tpfa_qual, fields, capacity, rec);
                 }
             }
         }
@@ -807,11 +841,11 @@ __global__ void __launch_bounds__(128) k_score(RegionDev R, UvcParams P, ScoreCt
     }
 }
 
-extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles,
+extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles, const UvcTumorKey *d_tkeys,
                                 int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch /* 2*ngroups + nblocks + 2 words + ngroups ints */, hipStream_t s) {
     ScoreCtx C;
     C.pos_beg = req->pos_beg; C.pos_end = req->pos_end; C.all_out = (req->all_out || P->should_output_all) ? 1 : 0; C.is_amplicon = req->is_amplicon;
-    C.alleles = d_alleles; C.n_alleles = req->n_indel_alleles; C.fields = d_fields; C.capacity = capacity;
+    C.alleles = d_alleles; C.n_alleles = req->n_indel_alleles; C.tkeys = d_tkeys; C.n_tkeys = (d_tkeys ? req->n_tumor_keys : 0); C.fields = d_fields; C.capacity = capacity;
     const long long ngroups = 2LL * (C.pos_end - C.pos_beg);
     if (ngroups <= 0) return 0;
     const int nblocks = (int)((ngroups + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS));

@@ -137,13 +137,17 @@ class Region:
         self._check(self.lib.call("fetch", self.h, gid, out.ctypes.data, out.nbytes))
         return out
 
-    def score(self, all_out=False, pos_beg=-1, pos_end=-1, is_amplicon=False, indel_alleles=None, capacity=None, copy=True):
+    def score(self, all_out=False, pos_beg=-1, pos_end=-1, is_amplicon=False, indel_alleles=None, capacity=None, copy=True, tumor_keys=None):
         req = _ffi.UvcScoreRequest()
         req.pos_beg, req.pos_end, req.all_out, req.is_amplicon = pos_beg, pos_end, int(all_out), int(is_amplicon)
         arr = None
         if indel_alleles:
             arr = (_ffi.UvcIndelAllele * len(indel_alleles))(*[_ffi.UvcIndelAllele(*a) for a in indel_alleles])
             req.n_indel_alleles, req.indel_alleles = len(indel_alleles), C.cast(arr, C.c_void_p)
+        tk = None
+        if tumor_keys:   # T/N: (refpos, symbol, cDP1x, CDP1x, bDP, BDP, tier2, indel_len) tuples, sorted by (refpos, symbol)
+            tk = (_ffi.UvcTumorKey * len(tumor_keys))(*[_ffi.UvcTumorKey(*t) for t in tumor_keys])
+            req.n_tumor_keys, req.tumor_keys = len(tumor_keys), C.cast(tk, C.c_void_p)
         if capacity is None:
             npos = (pos_end - pos_beg) if pos_beg >= 0 else self.npos
             capacity = 14 * (npos + 1) if all_out else max(4096, 4 * (npos + 1))
