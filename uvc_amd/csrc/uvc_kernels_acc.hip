@@ -2039,31 +2039,37 @@ extern "C" void uvc_launch_build_p2list(const RegionDev *R, const int32_t *aln, 
 extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const UvcParams *P, hipStream_t s) {
     if (R->n_alns) hipLaunchKernelGGL(k_aln_prelude, dim3(nblk(R->n_alns, 256)), dim3(256), 0, s, *R, *W, *P);
 }
+// The sequential, low-occupancy kernels of the InDel reads and the per-fragment statistics need P1 / P1b only, not P2: they run on
+// a side stream underneath the two issue-bound P2 kernels and join before anything reads their outputs.
+#define TIMED2(prof, kname, ...) do { hipStream_t s = s2; TIMED(prof, kname, __VA_ARGS__); } while (0)
 extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, int half_ratio_phred,
-                                      const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof) {
+                                      const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof,
+                                      hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join) {
     const unsigned nwin = nblk(R->npos, 256);   // 4 waves x 64 positions per block
     if (prof) prof->n = 0;
+    hipStream_t s2 = (side ? side : s);
     if (P->inferred_is_vcf_generated) {
         TIMED(prof, "k_prep_fast", hipLaunchKernelGGL(k_prep_fast, dim3(nwin), dim3(256), 0, s, *R, *P));
         if (R->n_complex) TIMED(prof, "k_prep_slow", hipLaunchKernelGGL(k_prep_slow, dim3(R->n_complex), dim3(64), 0, s, *R, *P));
-        TIMED(prof, "k_thres", hipLaunchKernelGGL(k_thres, dim3(nblk(R->npos, 256)), dim3(256), 0, s, *R, *P, half_ratio_phred));
+    }
+    TIMED(prof, "k_thres", hipLaunchKernelGGL(k_thres, dim3(nblk(R->npos, 256)), dim3(256), 0, s, *R, *P, half_ratio_phred));
+    if (side) { hipEventRecord(e_fork, s); hipStreamWaitEvent(s2, e_fork, 0); }
+    // ---- side stream
+    if (P->inferred_is_vcf_generated && R->n_complex) TIMED2(prof, "k_p2_slow_walk", hipLaunchKernelGGL(k_p2_slow<true>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
+    if (R->n_complex) TIMED2(prof, "k_p2_slow_table", hipLaunchKernelGGL(k_p2_slow<false>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
+    TIMED2(prof, "k_fragstat_fast", hipLaunchKernelGGL(k_fragstat_fast, dim3(nblk(R->n_frags, 256)), dim3(256), 0, s, *R, *P));
+    if (R->n_sweep) TIMED2(prof, "k_fragstat_sweep", hipLaunchKernelGGL(k_fragstat_sweep, dim3(R->n_sweep), dim3(64), 0, s, *R, *P, R->sweep_frags, (const int32_t *)nullptr, R->n_sweep));
+    // fragments whose event list overflowed (device-side list; the grid covers the worst case, surplus threads exit)
+    TIMED2(prof, "k_fragstat_overflow", hipLaunchKernelGGL(k_fragstat_sweep, dim3(imin_h(R->n_frags, 65535)), dim3(64), 0, s, *R, *P, (const int32_t *)R->overflow_frags, (const int32_t *)R->n_overflow, 0));
+    if (side) hipEventRecord(e_join, s2);
+    // ---- main stream
+    if (P->inferred_is_vcf_generated) {
         TIMED(prof, "k_p2_fast_link", hipLaunchKernelGGL((k_p2_fast<true, false>), dim3(nwin), dim3(256), 0, s, *R, *P));
         TIMED(prof, "k_p2_fast_base", hipLaunchKernelGGL((k_p2_fast<false, true>), dim3(nwin), dim3(256), 0, s, *R, *P));
         TIMED(prof, "k_p2_mism", hipLaunchKernelGGL(k_p2_mism, dim3(2048), dim3(256), 0, s, *R, *P));
-        if (R->n_complex) {
-            TIMED(prof, "k_p2_slow_walk", hipLaunchKernelGGL(k_p2_slow<true>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
-            TIMED(prof, "k_p2_items", hipLaunchKernelGGL(k_p2_items, dim3(R->n_complex), dim3(64), 0, s, *R, *P));
-        }
-    } else {
-        TIMED(prof, "k_thres", hipLaunchKernelGGL(k_thres, dim3(nblk(R->npos, 256)), dim3(256), 0, s, *R, *P, half_ratio_phred));
     }
-    if (R->n_complex) TIMED(prof, "k_p2_slow_table", hipLaunchKernelGGL(k_p2_slow<false>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
-    {
-        TIMED(prof, "k_fragstat_fast", hipLaunchKernelGGL(k_fragstat_fast, dim3(nblk(R->n_frags, 256)), dim3(256), 0, s, *R, *P));
-        if (R->n_sweep) TIMED(prof, "k_fragstat_sweep", hipLaunchKernelGGL(k_fragstat_sweep, dim3(R->n_sweep), dim3(64), 0, s, *R, *P, R->sweep_frags, (const int32_t *)nullptr, R->n_sweep));
-        // fragments whose event list overflowed (device-side list; the grid covers the worst case, surplus threads exit)
-        TIMED(prof, "k_fragstat_overflow", hipLaunchKernelGGL(k_fragstat_sweep, dim3(imin_h(R->n_frags, 65535)), dim3(64), 0, s, *R, *P, (const int32_t *)R->overflow_frags, (const int32_t *)R->n_overflow, 0));
-    }
+    if (side) hipStreamWaitEvent(s, e_join, 0);
+    if (P->inferred_is_vcf_generated && R->n_complex) TIMED(prof, "k_p2_items", hipLaunchKernelGGL(k_p2_items, dim3(R->n_complex), dim3(64), 0, s, *R, *P));
     {
         const bool proton = (UVC_PLATFORM_IONTORRENT == P->inferred_sequencing_platform);
         const int n_gen = proton ? R->n_frags : R->n_sweep;
