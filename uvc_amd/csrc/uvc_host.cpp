@@ -21,7 +21,7 @@ extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const 
 struct UvcProf { int on; int n; const char *name[24]; hipEvent_t ev[24][2]; };
 extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, int half_ratio_phred,
                                       const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof,
-                                      hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join);
+                                      hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join, hipEvent_t e_fork2);
 extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles, const UvcTumorKey *d_tkeys,
                                 int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch, hipStream_t s);
 extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored);
@@ -37,7 +37,7 @@ struct uvcgpu_region {
     int64_t npos;
     std::string refstring;
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr; hipEvent_t e_fork = nullptr, e_join = nullptr;   // fork/join inside accumulate (see uvc_launch_accumulate)
+    hipStream_t side = nullptr; hipEvent_t e_fork = nullptr, e_join = nullptr, e_fork2 = nullptr;   // fork/join inside accumulate (see uvc_launch_accumulate)
     // device buffers
     uint8_t *d_refsym = nullptr; int32_t *d_rtr = nullptr, *d_rtr0 = nullptr; int64_t *d_baq = nullptr;
     char *d_state = nullptr; size_t state_bytes = 0;
@@ -200,7 +200,7 @@ int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params, int32_t
     r->P = *params; r->tid = tid; r->beg = beg; r->end = end + 1; r->npos = (int64_t)end - beg + 1;
     r->refstring.assign(refseq, (size_t)(end - beg));
     if (hipStreamCreate(&r->stream) != hipSuccess) { delete r; return fail(UVCGPU_EDEVICE, "hipStreamCreate failed (no GPU?)"); }
-    if (hipStreamCreate(&r->side) != hipSuccess || hipEventCreateWithFlags(&r->e_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_join, hipEventDisableTiming) != hipSuccess) {
+    if (hipStreamCreate(&r->side) != hipSuccess || hipEventCreateWithFlags(&r->e_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_fork2, hipEventDisableTiming) != hipSuccess) {
         uvcgpu_region_destroy(r); return fail(UVCGPU_EDEVICE, "hipStreamCreate / hipEventCreate failed");
     }
     std::vector<Track> tr; std::vector<int64_t> baq;
@@ -478,7 +478,7 @@ int uvcgpu_region_accumulate(uvcgpu_region_t *r) {
         // rows were set to 0xFF in set_reads and k_p2_slow<false> is idempotent under MAX, so no reset is needed
     }
     const int half = (int)std::round((10.0 / std::log(10.0)) * std::log(r->P.indel_del_to_ins_err_ratio)) / 2;   // main.hpp:1244
-    uvc_launch_accumulate(&r->R, &r->P, half, r->d_dup_units, r->n_dup, r->d_dup_off, r->n_dup_work, r->stream, &r->prof, r->side, r->e_fork, r->e_join);
+    uvc_launch_accumulate(&r->R, &r->P, half, r->d_dup_units, r->n_dup, r->d_dup_off, r->n_dup_work, r->stream, &r->prof, r->side, r->e_fork, r->e_join, r->e_fork2);
     HIP_OK(hipGetLastError());
     r->buckets_clean = (r->P.inferred_is_vcf_generated != 0);   // k_frag (P3b) and k_p5b cleared every bucket they consumed
     r->accumulated = true;
@@ -598,6 +598,7 @@ void uvcgpu_region_destroy(uvcgpu_region_t *r) {
     if (r->side) hipStreamDestroy(r->side);
     if (r->e_fork) hipEventDestroy(r->e_fork);
     if (r->e_join) hipEventDestroy(r->e_join);
+    if (r->e_fork2) hipEventDestroy(r->e_fork2);
     if (r->d_state) hipFree(r->d_state);
     if (r->R.err) hipFree(r->R.err);
     if (r->d_score_scratch) hipFree(r->d_score_scratch);

@@ -569,18 +569,18 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
     }
     if (nq > 0) drain();
     if (!valid) return;
-    // first writer of these fields (k_prep_slow adds to them afterwards; the scatter updates above touch other fields): plain stores
-    if (dp) P32(R, UVC_P_a_dp, x) = dp;
-    if (pcr) P32(R, UVC_P_a_pcr_dp, x) = pcr;
-    if (umi) P32(R, UVC_P_a_umi_dp, x) = umi;
-    if (qlen_s) P32(R, UVC_P_a_qlen, x) = qlen_s;
-    if (xm_s) P32(R, UVC_P_a_XM1500, x) = xm_s;
-    if (lidp) { P32(R, UVC_P_a_LIDP, x) = lidp; P64(R, UVC_P_a_LI, x) = li; }
-    if (ridp) { P32(R, UVC_P_a_RIDP, x) = ridp; P64(R, UVC_P_a_RI, x) = ri; }
+    // k_prep_slow runs concurrently on the side stream and adds to the same fields: atomics
+    if (dp) atomicAdd(&P32(R, UVC_P_a_dp, x), dp);
+    if (pcr) atomicAdd(&P32(R, UVC_P_a_pcr_dp, x), pcr);
+    if (umi) atomicAdd(&P32(R, UVC_P_a_umi_dp, x), umi);
+    if (qlen_s) atomicAdd(&P32(R, UVC_P_a_qlen, x), qlen_s);
+    if (xm_s) atomicAdd(&P32(R, UVC_P_a_XM1500, x), xm_s);
+    if (lidp) { atomicAdd(&P32(R, UVC_P_a_LIDP, x), lidp); add64(&P64(R, UVC_P_a_LI, x), li); }
+    if (ridp) { atomicAdd(&P32(R, UVC_P_a_RIDP, x), ridp); add64(&P64(R, UVC_P_a_RI, x), ri); }
     if (hbq) {
-        P32(R, UVC_P_a_highBQ_dp, x) = hbq;
-        P32(R, UVC_P_a_l_dist_sum, x) = ldist; P32(R, UVC_P_a_r_dist_sum, x) = rdist;
-        P64(R, UVC_P_a_l_BAQ_sum, x) = lbaq; P64(R, UVC_P_a_r_BAQ_sum, x) = rbaq;
+        atomicAdd(&P32(R, UVC_P_a_highBQ_dp, x), hbq);
+        atomicAdd(&P32(R, UVC_P_a_l_dist_sum, x), ldist); atomicAdd(&P32(R, UVC_P_a_r_dist_sum, x), rdist);
+        add64(&P64(R, UVC_P_a_l_BAQ_sum, x), lbaq); add64(&P64(R, UVC_P_a_r_BAQ_sum, x), rbaq);
     }
 }
 
@@ -2044,13 +2044,17 @@ extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const 
 #define TIMED2(prof, kname, ...) do { hipStream_t s = s2; TIMED(prof, kname, __VA_ARGS__); } while (0)
 extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, int half_ratio_phred,
                                       const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof,
-                                      hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join) {
+                                      hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join, hipEvent_t e_fork2) {
     const unsigned nwin = nblk(R->npos, 256);   // 4 waves x 64 positions per block
     if (prof) prof->n = 0;
     hipStream_t s2 = (side ? side : s);
     if (P->inferred_is_vcf_generated) {
+        // P1: the InDel reads (one wave per read) underneath the position-centric pass
+        if (side && R->n_complex) { hipEventRecord(e_fork, s); hipStreamWaitEvent(s2, e_fork, 0); }
+        if (R->n_complex) TIMED2(prof, "k_prep_slow", hipLaunchKernelGGL(k_prep_slow, dim3(R->n_complex), dim3(64), 0, s, *R, *P));
+        if (side && R->n_complex) hipEventRecord(e_join, s2);
         TIMED(prof, "k_prep_fast", hipLaunchKernelGGL(k_prep_fast, dim3(nwin), dim3(256), 0, s, *R, *P));
-        if (R->n_complex) TIMED(prof, "k_prep_slow", hipLaunchKernelGGL(k_prep_slow, dim3(R->n_complex), dim3(64), 0, s, *R, *P));
+        if (side && R->n_complex) hipStreamWaitEvent(s, e_join, 0);
     }
     TIMED(prof, "k_thres", hipLaunchKernelGGL(k_thres, dim3(nblk(R->npos, 256)), dim3(256), 0, s, *R, *P, half_ratio_phred));
     if (side) { hipEventRecord(e_fork, s); hipStreamWaitEvent(s2, e_fork, 0); }
@@ -2061,14 +2065,15 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
     if (R->n_sweep) TIMED2(prof, "k_fragstat_sweep", hipLaunchKernelGGL(k_fragstat_sweep, dim3(R->n_sweep), dim3(64), 0, s, *R, *P, R->sweep_frags, (const int32_t *)nullptr, R->n_sweep));
     // fragments whose event list overflowed (device-side list; the grid covers the worst case, surplus threads exit)
     TIMED2(prof, "k_fragstat_overflow", hipLaunchKernelGGL(k_fragstat_sweep, dim3(imin_h(R->n_frags, 65535)), dim3(64), 0, s, *R, *P, (const int32_t *)R->overflow_frags, (const int32_t *)R->n_overflow, 0));
-    if (side) hipEventRecord(e_join, s2);
-    // ---- main stream
+    // ---- main stream: the base symbols first, so that the queued mismatches (rare symbols, atomics: disjoint from the planes the
+    // LINK_M pass stores to) are applied on the side stream while the LINK_M pass runs
     if (P->inferred_is_vcf_generated) {
-        TIMED(prof, "k_p2_fast_link", hipLaunchKernelGGL((k_p2_fast<true, false>), dim3(nwin), dim3(256), 0, s, *R, *P));
         TIMED(prof, "k_p2_fast_base", hipLaunchKernelGGL((k_p2_fast<false, true>), dim3(nwin), dim3(256), 0, s, *R, *P));
-        TIMED(prof, "k_p2_mism", hipLaunchKernelGGL(k_p2_mism, dim3(2048), dim3(256), 0, s, *R, *P));
+        if (side) { hipEventRecord(e_fork2, s); hipStreamWaitEvent(s2, e_fork2, 0); }
+        TIMED2(prof, "k_p2_mism", hipLaunchKernelGGL(k_p2_mism, dim3(2048), dim3(256), 0, s, *R, *P));
+        TIMED(prof, "k_p2_fast_link", hipLaunchKernelGGL((k_p2_fast<true, false>), dim3(nwin), dim3(256), 0, s, *R, *P));
     }
-    if (side) hipStreamWaitEvent(s, e_join, 0);
+    if (side) { hipEventRecord(e_join, s2); hipStreamWaitEvent(s, e_join, 0); }
     if (P->inferred_is_vcf_generated && R->n_complex) TIMED(prof, "k_p2_items", hipLaunchKernelGGL(k_p2_items, dim3(R->n_complex), dim3(64), 0, s, *R, *P));
     {
         const bool proton = (UVC_PLATFORM_IONTORRENT == P->inferred_sequencing_platform);
