@@ -118,3 +118,36 @@ def test_normal_sample_of_a_tn_pair(name, oracle_lib, gpu_lib):
     assert len(ro["refpos"]) >= 14 * len(set(k[0] for k in keys))              # every symbol of both symbol types at a rescued position
     worst = compare_records(ro, rg)
     print(name, len(ro["refpos"]), {k: v for k, v in worst.items() if v})
+
+
+VARIANTS = {
+    "iontorrent": dict(platform=2),                                            # neighbouring-quality values, every fragment on the generic path
+    "primer_gating": dict(set=dict(primerlen=12)),                             # amplicon primer window (main.hpp:1872-1875) gates P2 / P3
+    "paired_primer_filter": dict(set=dict(primerlen=12, tn_is_paired=1, primer_flag=1)),
+    "sscs_table": dict(set=dict(fam_flag=1)),                                  # PhredMutationTable cap in P3 (main.hpp:2758)
+    "short_reads_low_thresholds": dict(set=dict(central_readlen=75, bias_thres_highBQ=10, bias_thres_PFBQ1=40, bias_thres_PFBQ2=45, fam_thres_highBQ_snv=5)),
+    "bq_added": dict(set=dict(bq_phred_added_misma=6, bq_phred_added_indel=3, microadjust_padded_deletion_flag=3)),
+    "fastq_only": dict(set=dict(inferred_is_vcf_generated=0)),                 # P1/P2/P3 skipped (main.hpp:3691)
+}
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("name", ["nodedup_3kb_60x", "umi_duplex_2kb_400x"])
+def test_parameter_variants(name, variant, oracle_lib, gpu_lib):
+    """Non-default parameter arms of the hot path: planes bit-exact, records within tolerance."""
+    from uvc_amd import region
+    v = VARIANTS[variant]
+    kw = dict(CASES[name]); kw["indel_every"] = 400; kw["clip_frac"] = 0.05
+    reads = synth.generate_region(**kw)
+    out = []
+    for lib in (oracle_lib, gpu_lib):
+        p = region.default_params(lib, platform=v.get("platform", 1))
+        for k, val in v.get("set", {}).items():
+            assert hasattr(p, k), k
+            setattr(p, k, val)
+        out.append(run_region(lib, reads, params=p))
+    Ro, Rg = out
+    bad = diff_groups(Ro, Rg)
+    assert not bad, "\n".join("%s: %d cells differ, e.g. %s" % (g, vv[0], vv[1]) for g, vv in bad.items())
+    if variant != "fastq_only":
+        compare_records(Ro.score(all_out=False), Rg.score(all_out=False))

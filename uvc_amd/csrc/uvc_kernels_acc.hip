@@ -2056,7 +2056,8 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
         TIMED(prof, "k_prep_fast", hipLaunchKernelGGL(k_prep_fast, dim3(nwin), dim3(256), 0, s, *R, *P));
         if (side && R->n_complex) hipStreamWaitEvent(s, e_join, 0);
     }
-    TIMED(prof, "k_thres", hipLaunchKernelGGL(k_thres, dim3(nblk(R->npos, 256)), dim3(256), 0, s, *R, *P, half_ratio_phred));
+    // P1b is part of updateByAlns3UsingBQ too (main.hpp:3691-3702): on a FASTQ-only run the thresholds stay zero and rtr.indelphred unedited
+    if (P->inferred_is_vcf_generated) TIMED(prof, "k_thres", hipLaunchKernelGGL(k_thres, dim3(nblk(R->npos, 256)), dim3(256), 0, s, *R, *P, half_ratio_phred));
     if (side) { hipEventRecord(e_fork, s); hipStreamWaitEvent(s2, e_fork, 0); }
     // ---- side stream
     if (P->inferred_is_vcf_generated && R->n_complex) TIMED2(prof, "k_p2_slow_walk", hipLaunchKernelGGL(k_p2_slow<true>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
