@@ -151,3 +151,27 @@ def test_parameter_variants(name, variant, oracle_lib, gpu_lib):
     assert not bad, "\n".join("%s: %d cells differ, e.g. %s" % (g, vv[0], vv[1]) for g, vv in bad.items())
     if variant != "fastq_only":
         compare_records(Ro.score(all_out=False), Rg.score(all_out=False))
+
+
+def test_score_request_options(oracle_lib, gpu_lib):
+    """UvcScoreRequest arms: a sub-range (pos_beg / pos_end), the amplicon minABQ set (main.cpp:524-525), and host-supplied InDel
+    alleles (several alleles of one (position, symbol) with their own bDPa / cDP0a / length, main.cpp:853-904)."""
+    kw = dict(CASES["config2shape_5kb_300x"]); kw["indel_every"] = 300
+    reads = synth.generate_region(**kw)
+    Ro, Rg = run_region(oracle_lib, reads), run_region(gpu_lib, reads)
+    base = Ro.score()
+    indel = [i for i in range(len(base["refpos"])) if 7 <= base["symbol"][i] <= 12]
+    assert len(indel) >= 3
+    alleles = []
+    for i in indel[:6]:
+        pos, sym, b, c = int(base["refpos"][i]), int(base["symbol"][i]), int(base["bDPa"][i]), int(base["cDP0a"][i])
+        alleles += [(pos, sym, max(1, b - 1), max(1, c - 1), 1 + (i % 3)), (pos, sym, 1, 1, 4 + (i % 5))]     # two alleles each
+    alleles = sorted(set(alleles), key=lambda a: (a[0], a[1]))
+    beg, end = reads["beg"] + 1000, reads["beg"] + 4000
+    for kwargs in (dict(indel_alleles=alleles), dict(is_amplicon=True), dict(pos_beg=beg, pos_end=end), dict(pos_beg=beg, pos_end=end, all_out=True, indel_alleles=alleles, is_amplicon=True)):
+        ro, rg = Ro.score(**kwargs), Rg.score(**kwargs)
+        assert len(ro["refpos"]) > 0
+        compare_records(ro, rg)
+        if "pos_beg" in kwargs:
+            assert ro["refpos"].min() >= beg - 1 and ro["refpos"].max() < end
+    assert len(Ro.score(indel_alleles=alleles)["refpos"]) > len(base["refpos"])      # the extra alleles became extra records
