@@ -199,8 +199,8 @@ int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params, int32_t
     memset(&r->prof, 0, sizeof(r->prof));
     r->P = *params; r->tid = tid; r->beg = beg; r->end = end + 1; r->npos = (int64_t)end - beg + 1;
     r->refstring.assign(refseq, (size_t)(end - beg));
-    if (hipStreamCreate(&r->stream) != hipSuccess) { delete r; return fail(UVCGPU_EDEVICE, "hipStreamCreate failed (no GPU?)"); }
-    if (hipStreamCreate(&r->side) != hipSuccess || hipEventCreateWithFlags(&r->e_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_fork2, hipEventDisableTiming) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) { delete r; return fail(UVCGPU_EDEVICE, "hipStreamCreate failed (no GPU?)"); }
+    if (hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&r->e_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_fork2, hipEventDisableTiming) != hipSuccess) {
         uvcgpu_region_destroy(r); return fail(UVCGPU_EDEVICE, "hipStreamCreate / hipEventCreate failed");
     }
     std::vector<Track> tr; std::vector<int64_t> baq;
@@ -575,11 +575,13 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
     if (!rc && hipGetLastError() != hipSuccess) rc = fail(UVCGPU_EDEVICE, "score kernel launch failed");
     if (!rc) rc = uvcgpu_region_sync(r);
     int64_t cnt = 0;
-    if (!rc && hipMemcpy(&cnt, r->d_score_count, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(UVCGPU_EDEVICE, "hipMemcpy(count)");
+    // copies on the handle's own stream: a null-stream hipMemcpy would also wait for every other handle's work
+    if (!rc && (hipMemcpyAsync(&cnt, r->d_score_count, 8, hipMemcpyDeviceToHost, r->stream) != hipSuccess || hipStreamSynchronize(r->stream) != hipSuccess)) rc = fail(UVCGPU_EDEVICE, "hipMemcpy(count)");
     if (!rc) {
         out->n_records = cnt;
         if (cnt > out->capacity) rc = fail(UVCGPU_ENOMEM, "score output capacity too small");
-        else if (cnt > 0 && hipMemcpy2D(out->fields, sizeof(int32_t) * out->capacity, r->d_score_fields, sizeof(int32_t) * r->score_capacity, sizeof(int32_t) * cnt, UVC_NUM_SCORE_FIELDS, hipMemcpyDeviceToHost) != hipSuccess)
+        else if (cnt > 0 && (hipMemcpy2DAsync(out->fields, sizeof(int32_t) * out->capacity, r->d_score_fields, sizeof(int32_t) * r->score_capacity, sizeof(int32_t) * cnt, UVC_NUM_SCORE_FIELDS, hipMemcpyDeviceToHost, r->stream) != hipSuccess
+                             || hipStreamSynchronize(r->stream) != hipSuccess))
             rc = fail(UVCGPU_EDEVICE, "hipMemcpy2D(records)");
     }
     if (d_al) hipFree(d_al);
