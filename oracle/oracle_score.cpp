@@ -7,7 +7,7 @@
 //   BcfFormat_symbol_calc_DPv            main.hpp:4274-4844  (dp4_to_pcFA main_conversion.hpp:798-849)
 //   BcfFormat_symbol_sum_DPv             main.hpp:4888-4906
 //   BcfFormat_symbol_calc_qual           main.hpp:4908-5343  (calc_binom_10log10_likeratio main_conversion.hpp:222-237)
-// T/N rescue branches (tki, IS_PROVIDED(vcf_tumor_fname) arms that need a tumor record) are SURVEY "next" row N2.
+// The T/N rescue branches (tki, IS_PROVIDED(vcf_tumor_fname)) read their tumor records from UvcScoreRequest::tumor_keys.
 #include "oracle_common.hpp"
 
 namespace uvco {

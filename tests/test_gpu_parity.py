@@ -16,6 +16,8 @@ CASES = {
     "nodedup_3kb_60x": dict(region_len=3000, depth=60, seed=3, dedup_by_position=False),
     "umi_duplex_2kb_400x": dict(region_len=2000, depth=400, seed=11, umi=True),
     "tiny_600bp_5x": dict(region_len=600, depth=5, seed=5),
+    "config4shape_1kb_2000x_duplex": dict(region_len=1000, depth=2000, seed=13, umi=True),   # BASELINE config 4 shape: deep duplex-UMI panel
+    "deep_nonumi_800bp_3000x": dict(region_len=800, depth=3000, seed=14),                    # LDS queues / histograms far beyond one chunk
 }
 
 
@@ -52,7 +54,8 @@ def compare_records(ro, rg):
     return worst
 
 
-@pytest.mark.parametrize("name,all_out", [("config1_10kb_30x", False), ("config1_10kb_30x", True), ("config2shape_5kb_300x", False), ("umi_duplex_2kb_400x", True)])
+@pytest.mark.parametrize("name,all_out", [("config1_10kb_30x", False), ("config1_10kb_30x", True), ("config2shape_5kb_300x", False), ("umi_duplex_2kb_400x", True),
+                                          ("config4shape_1kb_2000x_duplex", False), ("deep_nonumi_800bp_3000x", True)])
 def test_score_records_match_oracle(name, all_out, oracle_lib, gpu_lib):
     reads = synth.generate_region(**CASES[name])
     Ro = run_region(oracle_lib, reads)
