@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--tile-kb", type=int, default=1000, help="tile length in kb (chr20 is processed as 1 Mb tiles)")
     ap.add_argument("--depth", type=int, default=300)
     ap.add_argument("--streams", type=int, default=1, help="split the tile into this many regions, each on its own HIP stream, accumulated concurrently")
+    ap.add_argument("--umi", action="store_true", help="duplex-UMI families (BASELINE config 4 shape when combined with --depth 2000 --tile-kb 200)")
     ap.add_argument("--pipeline", action="store_true", help="two resident tiles, software-pipelined: accumulate of tile k+1 is enqueued before the (synchronous) score of tile k; every step still does one full accumulate + score of a whole tile")
     ap.add_argument("--all-out", action="store_true", help="second series of SURVEY 8(d): score every symbol of every position (-A), not only the default-gate candidates")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -141,7 +142,7 @@ def main():
     if args.pipeline:
         assert args.streams == 1, "--pipeline uses its own two handles"
     n_tiles = 2 if args.pipeline else args.streams
-    tiles = [synth.generate_region(seed=12345 + rank + 1000 * i, region_len=sub_len, depth=args.depth, beg=1000000 + i * (sub_len + 1000)) for i in range(n_tiles)]
+    tiles = [synth.generate_region(seed=12345 + rank + 1000 * i, region_len=sub_len, depth=args.depth, beg=1000000 + i * (sub_len + 1000), umi=args.umi) for i in range(n_tiles)]
     reads = tiles[0]
     t_gen = time.perf_counter() - t_gen
     Rs = [region.Region(lib, params, t["tid"], t["beg"], t["end"], t["refseq"]) for t in tiles]
@@ -201,7 +202,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "chr20-shaped tumor-only non-UMI tile: %d kb at %dx, 150 bp paired-end, one tile per GPU resident in HBM; step = accumulate P1..P5b + default-gate scoring + D2H of records" % (args.tile_kb, args.depth),
-                       "tile_positions": region_len, "streams": args.streams, "pipeline": bool(args.pipeline), "all_out": bool(args.all_out), "reads_per_tile": n_reads_total, "read_bases_per_tile": n_read_bases, "scored_records_per_tile": n_rec,
+                       "tile_positions": region_len, "streams": args.streams, "pipeline": bool(args.pipeline), "all_out": bool(args.all_out), "umi": bool(args.umi), "reads_per_tile": n_reads_total, "read_bases_per_tile": n_read_bases, "scored_records_per_tile": n_rec,
                        "parallelism": "region-shard x%d (no collective on the data path)" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(dom, args.tile_kb, args.depth),
                          "algorithmic_bytes_per_launch": abytes, "kernel_ms": avg[dom]},
