@@ -176,8 +176,15 @@ DEV int cig_len(uint32_t c) { return (int)(c >> 4); }
 
 DEV void add64(int64_t *p, int64_t v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
 
+// per-thread symbol-count array kept in LDS ([symbol][thread], conflict-free): dynamic indexing by symbol without scratch memory
+template <int STRIDE> struct LdsCounts {
+    int *p;   // &array[0][threadIdx.x]
+    DEV int &operator[](int s) const { return p[s * STRIDE]; }
+};
+
 // GenericSymbol2Count::_fillConsensusCounts<TIsRefCountedOnlyOnce>, main.hpp:374-402
-DEV void fill_consensus(const int *c, int &argmax, int &cmax, int &csum, int st, bool ref_once_in_link, bool ignore_padded_del) {
+template <class Arr>
+DEV void fill_consensus(const Arr &c, int &argmax, int &cmax, int &csum, int st, bool ref_once_in_link, bool ignore_padded_del) {
     const int b = (st == UVC_BASE_SYMBOL ? UVC_BASE_A : UVC_LINK_M);
     const int e = (st == UVC_BASE_SYMBOL ? (ignore_padded_del ? UVC_BASE_T : UVC_BASE_NN) : UVC_LINK_NN);
     const bool once = (st == UVC_LINK_SYMBOL && ref_once_in_link);

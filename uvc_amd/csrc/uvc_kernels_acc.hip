@@ -1707,13 +1707,51 @@ DEV int find_unit(const RegionDev &R, int64_t w) {   // last generic unit with w
 }
 
 // builds con (votes) and optionally mmm (major-minus-minor BQ sums) of one unit at position p
-DEV void unit_counts(const RegionDev &R, const UvcParams &P, const FsRec &u, int p, bool proton, int *con, int *mmm) {
+// HAS_MMM selects the second output.  Fragments of <= 2 simple alignments (the FragFast record k_frag uses) are evaluated with the same
+// select-based consensus as in k_frag; the others go through the per-alignment contribution path.
+template <bool HAS_MMM, class Arr>
+DEV void unit_counts(const RegionDev &R, const UvcParams &P, const FsRec &u, int p, bool proton, Arr con, Arr mmm) {
     const bool padded_ignored = (P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0;
-    for (int s = 0; s < NSYM; s++) { con[s] = 0; if (mmm) mmm[s] = 0; }
+    for (int s = 0; s < NSYM; s++) { con[s] = 0; if (HAS_MMM) mmm[s] = 0; }
+    const int64_t x = p - R.beg;
+    const int noindel80 = (x > 0 ? imin(80, imin(RTRP(R, UVC_RTR_indelphred, x - 1), RTRP(R, UVC_RTR_indelphred, x))) : 80);
+    const __amdgpu_buffer_rsrc_t rs = bq_rsrc(R);
     int cnt[NSYM];
     for (int fi = u.frag_beg; fi < u.frag_end; fi++) {
+        const FragFast &ff = R.ffast[R.frag_rank[fi]];
+        const int fbeg = ff.beg, fend = ff.end, flags = ff.flags;
+        if (p < fbeg || p >= fend) continue;
+        if ((flags & 0x101) == 0 && !proton) {
+            // register path (see k_frag): LINK_M value of the better mate; BASE_QUALITY_MAX merge of the two mates' bases
+            const int pos0 = ff.pos0, rend0 = ff.rend0, pos1 = ff.pos1, rend1 = ff.rend1;
+            const bool has2 = (((flags >> 3) & 0xF) == 2);
+            const bool in0 = (p >= pos0 && p < rend0), in1 = (has2 && p >= pos1 && p < rend1);
+            const int lv0 = ((in0 && p > pos0) ? imax(noindel80 - ff.nogap0, 0) + 1 : 0), lv1 = ((in1 && p > pos1) ? imax(noindel80 - ff.nogap1, 0) + 1 : 0);
+            const int lv = imax(lv0, lv1);
+            if (lv > 0) { con[UVC_LINK_M] += 1; if (HAS_MMM) mmm[UVC_LINK_M] += lv; }   // one symbol: 2*max - tot = lv, threshold 0 (main.hpp:466-520)
+            if (in0 || in1) {
+                const int bq0 = (in0 ? bq_load(rs, ff.qb0 + p) : 0), bq1 = (in1 ? bq_load(rs, ff.qb1 + p) : 0);
+                const int b0 = bq0 & 0xFF, b1 = bq1 & 0xFF;
+                const int v0 = ((bq0 >> 8) & 0xFF) + P.bq_phred_added_misma, v1 = ((bq1 >> 8) & 0xFF) + P.bq_phred_added_misma;
+                const int A = (in0 ? v0 : 0), B = (in1 ? v1 : 0);
+                const bool diff = (in0 && in1 && b0 != b1);
+                const bool first = (v0 > v1) || (v0 == v1 && b0 < b1);
+                const int cc = imax(A, B), ct = (diff ? A + B : cc);
+                const int cs = ((in0 && (!diff || first)) ? b0 : b1);
+                int cs4 = cs, cc4 = cc, ct4 = ct;
+                if (padded_ignored) {   // fillConsensusCounts<false, true>: only A..T take part (main.hpp:410)
+                    const int A4 = ((in0 && b0 <= UVC_BASE_T) ? v0 : 0), B4 = ((in1 && b1 <= UVC_BASE_T) ? v1 : 0);
+                    const bool first4 = (A4 > B4) || (A4 == B4 && b0 < b1);
+                    cc4 = imax(A4, B4); ct4 = (diff ? A4 + B4 : cc4);
+                    cs4 = ((A4 == 0 && B4 == 0) ? UVC_BASE_T : (diff ? (first4 ? b0 : b1) : cs));
+                }
+                const int adj = imax(cc4 * 2, ct4) - ct4;
+                if (adj >= P.fam_thres_highBQ_snv && adj > 0) con[cs4] += 1;
+                if (HAS_MMM) { const int adj5 = imax(cc * 2, ct) - ct; if (adj5 > 0) mmm[cs] += adj5; }
+            }
+            continue;
+        }
         const FragRec &f = R.frags[fi];
-        if (p < f.beg || p >= f.end) continue;
         frag_counts(R, P, f, p, proton, cnt);
         for (int st = 0; st < 2; st++) {
             int cs, cc, ct;
@@ -1721,7 +1759,7 @@ DEV void unit_counts(const RegionDev &R, const UvcParams &P, const FsRec &u, int
             else fill_consensus(cnt, cs, cc, ct, st, false, padded_ignored);
             const int adj = imax(cc * 2, ct) - ct;
             if (adj >= (st == UVC_BASE_SYMBOL ? P.fam_thres_highBQ_snv : 0) && adj > 0) con[cs] += 1;
-            if (mmm) {
+            if (HAS_MMM) {
                 if (st == UVC_BASE_SYMBOL && padded_ignored) fill_consensus(cnt, cs, cc, ct, st, false, false);
                 const int adj5 = imax(cc * 2, ct) - ct;
                 if (adj5 > 0) mmm[cs] += adj5;
@@ -1755,7 +1793,7 @@ __global__ void __launch_bounds__(64) k_fam_stat(RegionDev R, UvcParams P) {
         for (int dir = 0; dir < 2; dir++) {
             int b = (dir ? (u.end - 1) : u.beg), e = (dir ? (u.beg - 1) : u.end), step = (dir ? -1 : 1);
             for (int p = b; p != e; p += step) {
-                unit_counts(R, P, u, p, proton, con, nullptr);
+                unit_counts<false>(R, P, u, p, proton, con, con);
                 int cs, cc, ct;
                 fill_consensus(con, cs, cc, ct, UVC_BASE_SYMBOL, false, false);
                 if (0 == ct) continue;
@@ -1777,8 +1815,9 @@ __global__ void __launch_bounds__(256) k_fam_p4(RegionDev R, UvcParams P) {
     const int64_t x = p - R.beg;
     const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
     const int strand = u.strand;
-    int con[NSYM];
-    unit_counts(R, P, u, p, proton, con, nullptr);
+    __shared__ int con_s[NSYM][256];
+    const LdsCounts<256> con = { &con_s[0][threadIdx.x] };
+    unit_counts<false>(R, P, u, p, proton, con, con);
     for (int vi = 0; vi < 2; vi++) {
         const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
         int cs, cc, ct;
@@ -1861,8 +1900,9 @@ __global__ void __launch_bounds__(256) k_fam_p5(RegionDev R, UvcParams P) {
     const bool other_present = (u.other_fs >= 0);
     const bool will_inc_dscs = is_duplex_fam && other_present;
     const bool will_inc_sscs = is_duplex_fam && !other_present;
-    int con[NSYM], mmm[NSYM];
-    unit_counts(R, P, u, p, proton, con, mmm);
+    __shared__ int con_s[NSYM][256], mmm_s[NSYM][256];
+    const LdsCounts<256> con = { &con_s[0][threadIdx.x] }, mmm = { &mmm_s[0][threadIdx.x] };
+    unit_counts<true>(R, P, u, p, proton, con, mmm);
     for (int vi = 0; vi < 2; vi++) {
         const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
         int cs, con_sumBQs, tot_sumBQs;
@@ -1907,12 +1947,13 @@ __global__ void __launch_bounds__(256) k_duplex(RegionDev R, UvcParams P, const 
     const int64_t x = p - R.beg;
     const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
     const bool padded_ignored = (P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0;
-    int dup[NSYM], con[NSYM];
+    __shared__ int con_s[NSYM][256], dup_s[NSYM][256];
+    const LdsCounts<256> con = { &con_s[0][threadIdx.x] }, dup = { &dup_s[0][threadIdx.x] };
     for (int s = 0; s < NSYM; s++) dup[s] = 0;
     for (int k = 0; k < 2; k++) {
         const FsRec &u = (k == 0 ? u0 : u1);
         if (p < u.beg || p >= u.end) continue;
-        unit_counts(R, P, u, p, proton, con, nullptr);
+        unit_counts<false>(R, P, u, p, proton, con, con);
         for (int st = 0; st < 2; st++) {   // updateByFiltering<true,false,false> with thresholds {1,1}
             int cs, cc, ct;
             fill_consensus(con, cs, cc, ct, st, false, st == UVC_BASE_SYMBOL && padded_ignored);
