@@ -4,6 +4,7 @@
 #include "uvc_device.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -150,6 +151,35 @@ template <class T> int upload(uvcgpu_region *r, const std::vector<T> &v, T **out
     if (!v.empty()) { e = hipMemcpyAsync(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, r->stream); if (e != hipSuccess) return fail(UVCGPU_EDEVICE, hipGetErrorString(e)); }
     return 0;
 }
+// device allocation without a host image (the prelude kernels write every element); optionally zero-filled on the stream
+template <class T> int dev_alloc(uvcgpu_region *r, size_t count, T **out, bool zero = false) {
+    *out = nullptr;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc((void **)out, bytes);
+    if (e != hipSuccess) return fail(UVCGPU_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    r->owned.push_back(*out);
+    if (zero && hipMemsetAsync(*out, 0, bytes, r->stream) != hipSuccess) return fail(UVCGPU_EDEVICE, "hipMemsetAsync");
+    return 0;
+}
+// straight from the caller's array (it stays valid until set_reads returns, which synchronises the stream)
+template <class T> int upload_raw(uvcgpu_region *r, const T *src, size_t count, T **out) {
+    int rc = dev_alloc(r, count, out);
+    if (rc) return rc;
+    if (count && hipMemcpyAsync(*out, src, count * sizeof(T), hipMemcpyHostToDevice, r->stream) != hipSuccess) return fail(UVCGPU_EDEVICE, "hipMemcpyAsync(H2D)");
+    return 0;
+}
+// stable LSD radix sort of ids by a non-negative 32-bit key (three 11-bit passes): the host orders are all "by position"
+void radix_sort_ids(std::vector<int32_t> &ids, const std::vector<uint32_t> &key_of_id) {
+    std::vector<int32_t> tmp(ids.size());
+    for (int pass = 0; pass < 3; pass++) {
+        const int shift = 11 * pass;
+        size_t cnt[2049] = { 0 };
+        for (int32_t id : ids) cnt[((key_of_id[id] >> shift) & 2047u) + 1]++;
+        for (int b = 0; b < 2048; b++) cnt[b + 1] += cnt[b];
+        for (int32_t id : ids) tmp[cnt[(key_of_id[id] >> shift) & 2047u]++] = id;
+        ids.swap(tmp);
+    }
+}
 void free_reads(uvcgpu_region *r) { for (void *p : r->owned) hipFree(p); r->owned.clear(); r->has_reads = false; r->accumulated = false; }
 }  // namespace
 
@@ -242,7 +272,12 @@ int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params, int32_t
 
 int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     if (!r || !in || in->n_reads < 0 || in->n_fams < 0) return fail(UVCGPU_EINVAL, "bad reads");
+    const bool timing = (getenv("UVCGPU_TIMING") != nullptr);   // stderr breakdown of the ingest, for tuning
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (!timing) return; hipStreamSynchronize(r->stream); const auto t = std::chrono::steady_clock::now();
+                                       fprintf(stderr, "[uvcgpu set_reads] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count()); t_prev = t; };
     free_reads(r);
+    struct SyncOnExit { hipStream_t s; ~SyncOnExit() { hipStreamSynchronize(s); } } sync_on_exit = { r->stream };   // no copy may outlive the host vectors below, on any return path
     const int64_t n = in->n_reads;
     if (n == 0) return 0;
     if (n > INT32_MAX / 2) return fail(UVCGPU_EUNSUPPORTED, "more than 2^30 reads in one region");
@@ -330,6 +365,7 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
         else max_aln_span = std::max(max_aln_span, e - in->pos[i]);
         prev_fam = fam; prev_strand = strand; prev_frag = in->frag_id[i];
     }
+    lap("classify reads (host)");
     const UvcParams &P = r->P;
     const bool singleton_ok = (P.fam_thres_dup1add >= 2 && P.fam_thres_dup2add >= 2 && P.fam_thres_emperr_all_flat_snv >= 2 && P.fam_thres_emperr_all_flat_indel >= 2);
     std::vector<int32_t> generic_fs, dup_units; std::vector<int64_t> dup_off;
@@ -357,22 +393,28 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
         f.stat_kind = (all_simple && (f.aln_end - f.aln_beg) <= 2 && !amplicon_gated) ? 0 : 1;
         if (f.stat_kind) sweep_frags.push_back((int32_t)fi);
     }
+    lap("units / fragments (host)");
     // pos-sorted order of the simple alignments, beg-sorted order of the fragments
     std::vector<int32_t> simple_ids, complex_ids, frag_sorted(frags.size());
     for (int64_t i = 0; i < n; i++) (kind[i] == 0 ? simple_ids : complex_ids).push_back((int32_t)i);
-    std::stable_sort(simple_ids.begin(), simple_ids.end(), [&](int32_t a, int32_t b) { return in->pos[a] < in->pos[b]; });
+    { std::vector<uint32_t> key((size_t)n); for (int64_t i = 0; i < n; i++) key[i] = (uint32_t)(in->pos[i] - r->beg);   // < 2^31, fits the 33 bits of three passes
+      radix_sort_ids(simple_ids, key); }
     for (size_t k = 0; k < simple_ids.size(); k++) fast_rank[simple_ids[k]] = (int32_t)k;
     std::iota(frag_sorted.begin(), frag_sorted.end(), 0);
     // k_frag walks two beg-sorted sub-lists, one per strand, so that the strand-specific accumulators are fixed registers
-    std::stable_sort(frag_sorted.begin(), frag_sorted.end(), [&](int32_t a, int32_t b) { return frags[a].strand != frags[b].strand ? frags[a].strand < frags[b].strand : frags[a].beg < frags[b].beg; });
+    { std::vector<uint32_t> key(frags.size());
+      if (r->npos >= ((int64_t)1 << 31)) return fail(UVCGPU_EUNSUPPORTED, "region longer than 2^31");
+      for (size_t k = 0; k < frags.size(); k++) key[k] = (uint32_t)(frags[k].beg - r->beg) | ((uint32_t)frags[k].strand << 31);
+      radix_sort_ids(frag_sorted, key); }
     { int32_t n0 = 0; for (const FragRec &f : frags) if (f.strand == 0) n0++; r->R.frag_off[0] = 0; r->R.frag_off[1] = n0; r->R.frag_off[2] = (int32_t)frags.size(); }
 
     // uploads
     RegionDev &R = r->R;
+    lap("sorts (host)");
     RawReads &W = r->W;
     int rc;
-    auto up32 = [&](const int32_t *src, const int32_t **dst) { std::vector<int32_t> v(src, src + n); int32_t *d; int c = upload(r, v, &d); *dst = d; return c; };
-    auto up64 = [&](const int64_t *src, const int64_t **dst) { std::vector<int64_t> v(src, src + n); int64_t *d; int c = upload(r, v, &d); *dst = d; return c; };
+    auto up32 = [&](const int32_t *src, const int32_t **dst) { int32_t *d; int c = upload_raw(r, src, (size_t)n, &d); *dst = d; return c; };
+    auto up64 = [&](const int64_t *src, const int64_t **dst) { int64_t *d; int c = upload_raw(r, src, (size_t)n, &d); *dst = d; return c; };
     std::vector<int32_t> flag32(n), mapq32(n);
     for (int64_t i = 0; i < n; i++) { flag32[i] = in->flag[i]; mapq32[i] = in->mapq[i]; }
     if ((rc = up32(in->pos, &W.pos)) || (rc = up32(endpos.data(), &W.endpos)) || (rc = up32(in->mpos, &W.mpos)) || (rc = up32(in->isize, &W.isize))
@@ -380,24 +422,24 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
         || (rc = up32(in->n_cigar, &W.n_cigar)) || (rc = up32(frag_of.data(), &W.frag)) || (rc = up32(fs_of.data(), &W.fs)) || (rc = up32(dflag_of.data(), &W.dflag))
         || (rc = up32(kind.data(), &W.kind)) || (rc = up32(fast_rank.data(), &W.fast_rank))
         || (rc = up64(in->seq_off, &W.seq_off)) || (rc = up64(in->cigar_off, &W.cigar_off)) || (rc = up64(table_off.data(), &W.table_off)) || (rc = up64(item_off.data(), &W.item_off))) return rc;
-    { std::vector<uint8_t> v(in->bases, in->bases + in->n_bases); uint8_t *d; if ((rc = upload(r, v, &d))) return rc; R.bases = d; }
-    { std::vector<uint8_t> v(in->quals, in->quals + in->n_bases); uint8_t *d; if ((rc = upload(r, v, &d))) return rc; R.quals = d; }
+    { uint8_t *d; if ((rc = upload_raw(r, in->bases, (size_t)in->n_bases, &d))) return rc; R.bases = d; }
+    { uint8_t *d; if ((rc = upload_raw(r, in->quals, (size_t)in->n_bases, &d))) return rc; R.quals = d; }
     { if (in->n_bases >= ((int64_t)1 << 31)) return fail(UVCGPU_EUNSUPPORTED, "more than 2^31 read bases in one region: split the region");
       uint16_t *d = nullptr; if (hipMalloc((void **)&d, (size_t)std::max<int64_t>(in->n_bases, 1) * 2) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(bq)");
       r->owned.push_back(d); R.bq = d; R.bq_bytes = (uint32_t)(in->n_bases * 2);
       uvc_launch_pack_bq(R.bases, R.quals, d, in->n_bases, r->stream); }
-    { std::vector<uint32_t> v(in->cigars, in->cigars + in->n_cigar_ops); uint32_t *d; if ((rc = upload(r, v, &d))) return rc; R.cigars = d; }
-    { std::vector<AlnRec> v((size_t)n); AlnRec *d; if ((rc = upload(r, v, &d))) return rc; R.alns = d; R.n_alns = (int32_t)n; }
-    { std::vector<AlnRec> v(simple_ids.size()); AlnRec *d; if ((rc = upload(r, v, &d))) return rc; R.fast = d; R.n_fast = (int32_t)simple_ids.size(); }
-    { std::vector<FastRec> v(simple_ids.size()); FastRec *d; if ((rc = upload(r, v, &d))) return rc; R.frec = d; }
+    { uint32_t *d; if ((rc = upload_raw(r, in->cigars, (size_t)in->n_cigar_ops, &d))) return rc; R.cigars = d; }
+    { AlnRec *d; if ((rc = dev_alloc(r, (size_t)n, &d))) return rc; R.alns = d; R.n_alns = (int32_t)n; }
+    { AlnRec *d; if ((rc = dev_alloc(r, simple_ids.size(), &d))) return rc; R.fast = d; R.n_fast = (int32_t)simple_ids.size(); }
+    { FastRec *d; if ((rc = dev_alloc(r, simple_ids.size(), &d))) return rc; R.frec = d; }
     { int32_t *d; if ((rc = upload(r, complex_ids, &d))) return rc; R.complex_ids = d; R.n_complex = (int32_t)complex_ids.size(); }
     { FragRec *d; if ((rc = upload(r, frags, &d))) return rc; R.frags = d; R.n_frags = (int32_t)frags.size(); }
     { int32_t *d; if ((rc = upload(r, frag_sorted, &d))) return rc; R.frag_sorted = d; }
     { std::vector<int32_t> rank(frags.size()); for (size_t k = 0; k < frag_sorted.size(); k++) rank[frag_sorted[k]] = (int32_t)k;
       int32_t *d; if ((rc = upload(r, rank, &d))) return rc; R.frag_rank = d; }
-    { std::vector<FragFast> v(frags.size()); FragFast *d; if ((rc = upload(r, v, &d))) return rc; R.ffast = d; }
+    { FragFast *d; if ((rc = dev_alloc(r, frags.size(), &d, true))) return rc; R.ffast = d; }
     { int32_t *d; if ((rc = upload(r, sweep_frags, &d))) return rc; R.sweep_frags = d; R.n_sweep = (int32_t)sweep_frags.size(); }
-    { std::vector<int32_t> z(frags.size() * (size_t)(UVC_MAXEV + 2) + 1, 0); int32_t *d; if ((rc = upload(r, z, &d))) return rc;
+    { int32_t *d; if ((rc = dev_alloc(r, frags.size() * (size_t)(UVC_MAXEV + 2) + 1, &d, true))) return rc;
       R.frag_nmut = d; R.frag_mut = d + frags.size(); R.overflow_frags = d + frags.size() * (size_t)(UVC_MAXEV + 1); R.n_overflow = d + frags.size() * (size_t)(UVC_MAXEV + 2); }
     { FsRec *d; if ((rc = upload(r, fss, &d))) return rc; R.fss = d; R.n_fs = (int32_t)fss.size(); }
     { int32_t *d; if ((rc = upload(r, generic_fs, &d))) return rc; R.generic_fs = d; R.n_generic_fs = (int32_t)generic_fs.size(); R.n_generic_work = work; }
@@ -411,16 +453,26 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     r->R.n_complex = (int32_t)complex_ids.size();
     // table rows are written by k_p2_slow<false>; mark all slots empty (0xFF)
     HIP_OK(hipMemsetAsync(R.table, 0xFF, std::max<int64_t>(table_rows, 1) * sizeof(Contrib), r->stream));
+    lap("uploads");
     uvc_launch_prelude(&R, &W, &r->P, r->stream);
+    lap("prelude kernel");
     {
-        std::stable_sort(p2.begin(), p2.end(), [](const P2Seg &a, const P2Seg &b) { return a.cls != b.cls ? a.cls < b.cls : a.cbeg < b.cbeg; });
+        {   // stable order by (class, begin); begin - region begin < 2^31 and the class takes the two bits above
+            std::vector<int32_t> ord(p2.size()); std::iota(ord.begin(), ord.end(), 0);
+            std::vector<uint32_t> key(p2.size());
+            if (r->npos >= ((int64_t)1 << 29)) return fail(UVCGPU_EUNSUPPORTED, "region longer than 2^29");
+            for (size_t j = 0; j < p2.size(); j++) key[j] = (uint32_t)(p2[j].cbeg - r->beg) | ((uint32_t)p2[j].cls << 29);
+            radix_sort_ids(ord, key);
+            std::vector<P2Seg> sorted(p2.size()); for (size_t j = 0; j < p2.size(); j++) sorted[j] = p2[ord[j]];
+            p2.swap(sorted);
+        }
         for (int c = 0; c <= 4; c++) R.p2_off[c] = 0;
         for (const P2Seg &e : p2) for (int c = e.cls + 1; c <= 4; c++) R.p2_off[c]++;
         std::vector<int32_t> v_aln(p2.size()), v_beg(p2.size()), v_end(p2.size()), v_qb(p2.size());
         int32_t span = 1;
         for (size_t j = 0; j < p2.size(); j++) { v_aln[j] = p2[j].aln; v_beg[j] = p2[j].cbeg; v_end[j] = p2[j].cend; v_qb[j] = p2[j].qb; span = std::max(span, p2[j].cend - p2[j].cbeg); }
         if ((rc = upload(r, v_aln, &r->d_p2[0])) || (rc = upload(r, v_beg, &r->d_p2[1])) || (rc = upload(r, v_end, &r->d_p2[2])) || (rc = upload(r, v_qb, &r->d_p2[3]))) return rc;
-        { std::vector<FastRec> v(p2.size()); FastRec *d; if ((rc = upload(r, v, &d))) return rc; R.frec2 = d; R.n_fast2 = (int32_t)p2.size(); R.max_p2_span = span; }
+        { FastRec *d; if ((rc = dev_alloc(r, p2.size(), &d))) return rc; R.frec2 = d; R.n_fast2 = (int32_t)p2.size(); R.max_p2_span = span; }
         uvc_launch_build_p2list(&R, r->d_p2[0], r->d_p2[1], r->d_p2[2], r->d_p2[3], r->stream);
     }
     HIP_OK(hipGetLastError());
@@ -433,6 +485,7 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
         if (hipMalloc((void **)&d, (size_t)(total + 64) * sizeof(MisItem)) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(mismatch queue)");
         r->owned.push_back(d); R.mis = d; R.mis_cap = (int32_t)(total + 64);
     }
+    lap("P2 list sort + build");
     r->n_bases = in->n_bases;
     r->has_reads = true;
     return 0;
