@@ -3,27 +3,34 @@
 // Decomposition.  The reference walks every read 5 times and scatters `+=`
 // into ~5.5 KB of per-position state (main.hpp:2543-3594).  Here the loops are turned inside out:
 // a wavefront owns 64 consecutive reference positions (one lane = one position), loops over the
-// alignments / fragments that overlap its window (wave-uniform control flow, read scalars through
-// scalar loads, base/qual bytes coalesced across lanes) and keeps the accumulators of the two
+// alignments / fragments that overlap its window (wave-uniform control flow; the per-read scalars of
+// 64 records are loaded one per lane and broadcast with v_readlane; base/qual bytes come through a
+// bounds-checked buffer descriptor, coalesced across lanes) and keeps the accumulators of the two
 // symbols that matter at a position -- the reference base and LINK_M -- in registers.  Everything
-// that is rare (mismatching bases, N, clips, reads with InDels) takes a sparse path: global integer
-// atomics for rare symbols, and one-thread-per-read sequential kernels for reads whose CIGAR has
-// InDels.  All updates are integer adds or maxima, so any order gives bit-identical results
-// (SURVEY Appendix B).
+// rare takes a sparse path: mismatching bases through per-wave LDS queues and a lane-per-item
+// kernel, InDel symbols through wave-per-read kernels, rare symbols of the fragment pass through
+// fire-and-forget atomics.  All updates are integer adds or maxima, so any order gives
+// bit-identical results.  The kernels are issue-bound:
+// the code below is written to minimise VALU + SALU instructions per (read, 64 positions).
 //
-//   k_aln_prelude   per read      nge/ngo/clips, xm1500, bm1500s, penalties      main.hpp:1795-1885
-//   k_prep_fast     per position  P1 for simple reads                            main.hpp:924-1204
-//   k_prep_slow     per read      P1 for reads with InDels (atomics)
-//   k_thres         per position  P1b, also edits rtr.indelphred                 main.hpp:1206-1299
-//   k_p2_fast       per position  P2 + dealwith_segbias for simple reads         main.hpp:1360-1595, 1762-2296
-//   k_p2_slow       per read      P2 for reads with InDels (atomics) and, in TABLE mode, the
-//                                 BASE_QUALITY_MAX contribution table used by P3/P4/P5
-//   k_fragstat_*    per fragment  covered / near-mutation position counts        main.hpp:2738-2756
-//                                 (closed form from mutation events; sequential sweep for InDel fragments)
-//   k_frag          per position  P3 + P3b, and P4/P5 of singleton families      main.hpp:2620-2830, 2832-3594
-//   k_fam_stat/p4/p5 per (family-strand unit, position): multi-fragment families main.hpp:2883-3522
-//   k_duplex        per (duplex family, position)                                main.hpp:3523-3550
-//   k_p5b           per position  bucket -> quality for family consensus         main.hpp:3552-3591
+//   k_pack_bq        per read base  base | qual << 8
+//   k_aln_prelude    per read       nge/ngo/clips, xm1500, bm1500s, penalties, eligibility   main.hpp:1795-1885
+//   k_build_p2list   per entry      P2 work list (simple reads + M runs of InDel reads), 4 orientation classes
+//   k_correct_bq     per read       apply_bq_err_correction3 (on request)                     grouping.cpp:459-543
+//   k_prep_fast      per position   P1 for simple reads                                       main.hpp:924-1204
+//   k_prep_slow      wave per read  P1 for reads with InDels (atomics)
+//   k_thres          per position   P1b, also edits rtr.indelphred                            main.hpp:1206-1299
+//   k_p2_fast<L,B>   per position   P2 + dealwith_segbias, LINK_M / read base instantiations   main.hpp:1360-1595, 1762-2296
+//   k_p2_mism        per queued base  the same for bases that differ from the reference
+//   k_p2_slow<BIAS>  wave per read  CIGAR walk of InDel reads: P2 items (BIAS) or the BASE_QUALITY_MAX contribution table
+//   k_p2_items       wave per read  applies the items
+//   k_fragstat_*     per fragment   covered / near-mutation position counts, M runs of InDel fragments   main.hpp:2738-2756
+//   k_frag_generic   wave per fragment chunk  P3 at the positions next to InDels / of fragments with > 2 alignments
+//   k_frag           per position   P3 + P3b, and P4/P5 of singleton families                 main.hpp:2620-2830, 2832-3594
+//   k_fam_stat/p4/p5 per (family-strand unit, position): multi-fragment families              main.hpp:2883-3522
+//   k_duplex         per (duplex family, position)                                            main.hpp:3523-3550
+//   k_p5b            per (position, strand)  bucket -> quality for family consensus           main.hpp:3552-3591
+// uvc_launch_accumulate at the end of the file orders them on two streams.
 #include "uvc_device.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -1336,7 +1343,6 @@ __global__ void __launch_bounds__(64) k_fragstat_sweep(RegionDev R, UvcParams P,
     if (lane == 0) { R.frags[fi].n_cov = tot[0]; R.frags[fi].n_near = tot[1]; FragFast &ff = R.ffast[R.frag_rank[fi]]; ff.n_cov = tot[0]; ff.n_near = tot[1]; }
 }
 
-// closed form for fragments of <= 2 simple alignments: coverage = union of the alignment spans, mutations = the event list
 // M runs and special range of one alignment for k_frag; false when it has more than one InDel or a reference skip
 DEV bool aln_runs(const RegionDev &R, const AlnRec &a, int &pA, int &eA, int &qA, int &pB, int &eB, int &qB, int &sp_beg, int &sp_len) {
     const uint32_t *cigar = R.cigars + a.cigar_off;
