@@ -130,6 +130,7 @@ struct RegionDev {
     FragFast *ffast;                // [n_frags] in (strand, beg)-sorted order
     FsRec *fss; int32_t n_fs;
     const int32_t *generic_fs; int32_t n_generic_fs; int64_t n_generic_work;
+    const int32_t *generic_sorted; int32_t max_unit_span;   // the generic units ordered by FsRec::beg (window kernels k_fam_win)
     Contrib *table;
     Item *items; int32_t *item_cnt;     // per complex alignment (indexed like complex_ids)
     MisItem *mis; int32_t *mis_cnt; int32_t mis_cap;   // mismatch queue of k_p2_fast, sized from the exact count below

@@ -443,6 +443,15 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
       R.frag_nmut = d; R.frag_mut = d + frags.size(); R.overflow_frags = d + frags.size() * (size_t)(UVC_MAXEV + 1); R.n_overflow = d + frags.size() * (size_t)(UVC_MAXEV + 2); }
     { FsRec *d; if ((rc = upload(r, fss, &d))) return rc; R.fss = d; R.n_fs = (int32_t)fss.size(); }
     { int32_t *d; if ((rc = upload(r, generic_fs, &d))) return rc; R.generic_fs = d; R.n_generic_fs = (int32_t)generic_fs.size(); R.n_generic_work = work; }
+    {   // the same units ordered by begin, for the position-window family kernels
+        std::vector<int32_t> ord(generic_fs.size()); std::iota(ord.begin(), ord.end(), 0);
+        std::vector<uint32_t> key(generic_fs.size());
+        int32_t span = 1;
+        for (size_t k = 0; k < generic_fs.size(); k++) { const FsRec &u = fss[generic_fs[k]]; key[k] = (uint32_t)(u.beg - r->beg); span = std::max(span, u.end - u.beg); }
+        radix_sort_ids(ord, key);
+        std::vector<int32_t> sorted(generic_fs.size()); for (size_t k = 0; k < ord.size(); k++) sorted[k] = generic_fs[ord[k]];
+        int32_t *d; if ((rc = upload(r, sorted, &d))) return rc; R.generic_sorted = d; R.max_unit_span = span;
+    }
     { std::vector<Contrib> v; Contrib *d = nullptr; const size_t bytes = std::max<int64_t>(table_rows, 1) * sizeof(Contrib);
       if (hipMalloc((void **)&d, bytes) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(table)"); r->owned.push_back(d); R.table = d; r->state_bytes += 0; (void)v; }
     { Item *d = nullptr; if (hipMalloc((void **)&d, std::max<int64_t>(item_slots, 1) * sizeof(Item)) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(items)"); r->owned.push_back(d); R.items = d;

@@ -1940,6 +1940,191 @@ __global__ void __launch_bounds__(256) k_fam_p5(RegionDev R, UvcParams P) {
     }
 }
 
+// P4 (PASS 4, main.hpp:2883-3390) and P5 (PASS 5, main.hpp:3392-3513) of the generic units, one block per 64-position window.
+// One thread per (unit, position) with an atomic per increment is bound by the L2 atomic units at depth (deep UMI panels put
+// hundreds of units on a position).  Here the four waves of a block share the units that overlap the window, every lane keeps its
+// position, and the increments of the two dense symbols (reference base, LINK_M) are collected in LDS and written once per position.
+#define FAMW_SLOTS (2 * UVC_NFAM + UVC_NFAMINFO32)   // [strand][FAM field], then the FamFormatInfoSet i32 fields
+struct FamAcc {
+    int (*a32)[FAMW_SLOTS][64]; unsigned long long (*a64)[UVC_NFAMINFO64][64]; int (*bk)[2][NBUCKETS][64];
+    const RegionDev *R; int64_t x; int lane, my_ref;
+    DEV int dense(int cs) const { return cs == my_ref ? 0 : (cs == UVC_LINK_M ? 1 : -1); }
+    DEV void fap(int strand, int f, int cs, int v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a32[d][strand * UVC_NFAM + f][lane], v); else atomicAdd(&FAP(*R, strand, f, cs, x), v); }
+    DEV void fi(int f, int cs, int v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a32[d][2 * UVC_NFAM + f][lane], v); else atomicAdd(&FIP(*R, f, cs, x), v); }
+    DEV void fi64(int f, int cs, long long v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a64[d][f][lane], (unsigned long long)v); else add64(&FI64P(*R, f, cs, x), v); }
+    DEV void bucket(int strand, int cs, int b) const { const int d = dense(cs); if (d >= 0) atomicAdd(&bk[d][strand][b][lane], 1); else atomicAdd(&BKP(*R, strand, cs, b, x), 1); }
+};
+
+template <int PASS>
+__global__ void __launch_bounds__(256) k_fam_win(RegionDev R, UvcParams P) {
+    __shared__ int con_s[4][NSYM][64];
+    __shared__ int mmm_s[PASS == 5 ? 4 : 1][NSYM][PASS == 5 ? 64 : 1];
+    __shared__ int a32[2][FAMW_SLOTS][64];
+    __shared__ unsigned long long a64[2][UVC_NFAMINFO64][64];
+    __shared__ int bk[PASS == 5 ? 2 : 1][2][NBUCKETS][PASS == 5 ? 64 : 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t x0 = (int64_t)xcd_block() * 64;
+    if (x0 >= R.npos) return;
+    const int w0 = R.beg + (int)x0;
+    // the units whose span can reach this window (sorted by begin)
+    int lo, hi;
+    {
+        int l = 0, h = R.n_generic_fs;
+        const int key = w0 - R.max_unit_span + 1;
+        while (l < h) { int m = (l + h) >> 1; if (R.fss[R.generic_sorted[m]].beg < key) l = m + 1; else h = m; }
+        lo = l; h = R.n_generic_fs;
+        while (l < h) { int m = (l + h) >> 1; if (R.fss[R.generic_sorted[m]].beg < w0 + 64) l = m + 1; else h = m; }
+        hi = l;
+    }
+    if (lo >= hi) return;   // block-uniform
+    for (int i = threadIdx.x; i < 2 * FAMW_SLOTS * 64; i += 256) (&a32[0][0][0])[i] = 0;
+    for (int i = threadIdx.x; i < 2 * UVC_NFAMINFO64 * 64; i += 256) (&a64[0][0][0])[i] = 0ull;
+    if (PASS == 5) for (int i = threadIdx.x; i < 2 * 2 * NBUCKETS * 64; i += 256) (&bk[0][0][0][0])[i] = 0;
+    __syncthreads();
+    const int p = w0 + lane;
+    const int64_t x = x0 + lane;
+    const bool valid = x < R.npos;
+    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    FamAcc A; A.a32 = a32; A.a64 = a64; A.bk = (int (*)[2][NBUCKETS][64])bk; A.R = &R; A.x = x; A.lane = lane; A.my_ref = (valid ? (int)R.refsym[x] : 0);
+    const LdsCounts<64> con = { &con_s[wv][0][lane] }, mmm = { &mmm_s[PASS == 5 ? wv : 0][0][PASS == 5 ? lane : 0] };
+    for (int k = lo + wv; k < hi; k += 4) {
+        const FsRec u = R.fss[R.generic_sorted[wave_uniform(k)]];
+        if (u.end <= w0) continue;
+        if (!(valid && p >= u.beg && p < u.end)) continue;
+        const int strand = u.strand;
+        if (PASS == 4) {
+            unit_counts<false>(R, P, u, p, proton, con, con);
+            for (int vi = 0; vi < 2; vi++) {
+                const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
+                int cs, cc, ct;
+                fill_consensus(con, cs, cc, ct, st, false, false);
+                if (0 == ct) continue;
+                const bool is_fam_good = ((P.fam_thres_dup1add <= ct) && (cc * 100 >= ct * P.fam_thres_dup1perc) && ((u.dflag & 0x1) || (P.fam_flag & 0x2)));
+                A.fap(strand, UVC_FAM_cDP12, cs, 1);
+                if (1 == ct) A.fap(strand, UVC_FAM_cDP21, cs, 1);
+                if (!P.inferred_is_vcf_generated) continue;
+                if (is_fam_good) {
+                    A.fap(strand, UVC_FAM_cDP2, cs, 1);
+                    int rbeg = imin(u.nsb_min, p), rend = imax(u.nsb_max, p);
+                    const bool nonconf_middle = (u.l2r_end_median <= (u.r2l_end_median + P.indel_adj_tracklen_dist));
+                    if (nonconf_middle && p < u.r2l_end_median) rend = imax(imin(u.l2r_end_median, imin(u.r2l_end_median, rend)), p);
+                    if (nonconf_middle && u.l2r_end_median < p) rbeg = imin(imax(u.l2r_end_median, imax(u.r2l_end_median, rbeg)), p);
+                    const bool isGap = (UVC_LINK_SYMBOL == st);
+                    const int bq = 90, dist = 1024 * 1024;
+                    if (((!isGap) && bq >= P.bias_thres_highBQ) || (isGap && dist >= P.bias_thres_highBQ)) {
+                        const bool tier2 = (isGap || bq >= P.bias_thres_highBQ);
+                        const int l_nb = (int)nnminus(p + 1, rbeg), r_nb = (int)nnminus(rend, p);
+                        const int _LPxT = TH(R, UVC_T_aLPxT, x), RPxT = TH(R, UVC_T_aRPxT, x);
+                        const int LPxT = (isGap ? _LPxT : imin(_LPxT, RPxT));
+                        // indel_len = majority COUNT of one inserted sequence among the unit's fragments (main.hpp:3239-3243): the
+                        // sequence-keyed maps stay on the host; the number of votes for the symbol is an upper bound that
+                        // equals it whenever all fragments carry the same inserted sequence.
+                        const int indel_len = ((is_ins(cs) || is_del(cs)) ? con[cs] : 0);
+                        const bool far = (l_nb + (is_ins(cs) ? (int)nnminus(indel_len, P.microadjust_nobias_pos_indel_maxlen) : 0) >= LPxT) && (r_nb >= RPxT);
+                        if (far) {
+                            int LP1 = 0, LP2 = 0, RP1 = 0, RP2 = 0; long long LPL = 0, RPL = 0;
+                            bidir(LP1, LP2, RP1, RP2, LPL, RPL, TH(R, UVC_T_aLP1t, x), TH(R, UVC_T_aLP2t, x), TH(R, UVC_T_aRP1t, x), TH(R, UVC_T_aRP2t, x), l_nb, r_nb, true, 0);
+                            if (LP1) A.fi(UVC_FI_c2LP1, cs, LP1);
+                            if (LP2) A.fi(UVC_FI_c2LP2, cs, LP2);
+                            if (RP1) A.fi(UVC_FI_c2RP1, cs, RP1);
+                            if (RP2) A.fi(UVC_FI_c2RP2, cs, RP2);
+                            A.fi(UVC_FI_c2LPL, cs, (int)LPL); A.fi(UVC_FI_c2RPL, cs, (int)RPL);
+                        }
+                        if ((int)nnminus(p + 1, u.nsb_min) >= P.bias_thres_strict_c2LRP0) A.fi(UVC_FI_c2LP0, cs, 1);
+                        if ((int)nnminus(u.nsb_max, p) >= P.bias_thres_strict_c2LRP0) A.fi(UVC_FI_c2RP0, cs, 1);
+                        const long long baq_last = R.end - 1;
+                        const int seg_l_baq = (int)(BAQ1(R, p) - BAQ1(R, lmax((long long)rbeg, nnminus(p, MAX_STR_N_BASES))) + 1);
+                        const long long rr = lmin((long long)rend - 1, lmin((long long)p + MAX_STR_N_BASES, baq_last));
+                        const int _seg_r_baq = (int)(BAQ1(R, rr) - BAQ1(R, p) + 1);
+                        const int seg_r_baq = (isGap ? (int)lmin((long long)_seg_r_baq, BAQ2(R, rr) - BAQ2(R, p) + 7) : _seg_r_baq);
+                        const int thres_highBAQ = P.bias_thres_highBAQ + (isGap ? 0 : 3);
+                        if (seg_l_baq >= thres_highBAQ && seg_r_baq >= thres_highBAQ) {
+                            int LB1 = 0, LB2 = 0, RB1 = 0, RB2 = 0; long long LBL = 0, RBL = 0;
+                            bidir(LB1, LB2, RB1, RB2, LBL, RBL, P.bias_thres_BAQ1, P.bias_thres_BAQ2, P.bias_thres_BAQ1, P.bias_thres_BAQ2, seg_l_baq, seg_r_baq, tier2, 0);
+                            if (LB1) A.fi(UVC_FI_c2LB1, cs, LB1);
+                            if (LB2) A.fi(UVC_FI_c2LB2, cs, LB2);
+                            if (RB1) A.fi(UVC_FI_c2RB1, cs, RB1);
+                            if (RB2) A.fi(UVC_FI_c2RB2, cs, RB2);
+                            A.fi64(UVC_FI64_c2LBL, cs, LBL); A.fi64(UVC_FI64_c2RBL, cs, RBL);
+                        }
+                        A.fi(UVC_FI_c2BQ2, cs, 1);
+                    }
+                }
+                if (P.fam_thres_dup2add <= ct && (cc * 100 >= ct * P.fam_thres_dup2perc)) A.fap(strand, UVC_FAM_cDP3, cs, 1);
+                const int flat = (is_subst(cs) ? P.fam_thres_emperr_all_flat_snv : P.fam_thres_emperr_all_flat_indel);
+                const int perc = (is_subst(cs) ? P.fam_thres_emperr_con_perc_snv : P.fam_thres_emperr_con_perc_indel);
+                if (ct < flat) continue;
+                if (cc * 100 < ct * perc) continue;
+                const int sb = (st == 0 ? UVC_BASE_A : UVC_LINK_M), se = (st == 0 ? UVC_BASE_NN : UVC_LINK_NN);
+                int m = 0, M = 0;
+                for (int s = sb; s <= se; s++) if (s != cs) { m += con[s]; M += ct; }
+                if (m) A.fap(strand, UVC_FAM_cDPm, cs, m);
+                A.fap(strand, UVC_FAM_cDPM, cs, M);
+            }
+        } else {
+            const bool is_duplex_fam = (0x2 == (u.dflag & 0x2));
+            const bool other_present = (u.other_fs >= 0);
+            const bool will_inc_dscs = is_duplex_fam && other_present;
+            const bool will_inc_sscs = is_duplex_fam && !other_present;
+            unit_counts<true>(R, P, u, p, proton, con, mmm);
+            for (int vi = 0; vi < 2; vi++) {
+                const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
+                int cs, con_sumBQs, tot_sumBQs;
+                fill_consensus(mmm, cs, con_sumBQs, tot_sumBQs, st, false, false);
+                if (0 == tot_sumBQs) continue;
+                const int con_nfrags = con[cs];
+                int tot_nfrags = 0;
+                const int sb = (st == 0 ? UVC_BASE_A : UVC_LINK_M), se = (st == 0 ? UVC_BASE_NN : UVC_LINK_NN);
+                for (int s = sb; s <= se; s++) tot_nfrags += con[s];
+                A.fap(strand, UVC_FAM_cDP1, cs, 1);
+                if (will_inc_sscs && (!will_inc_dscs) && (tot_nfrags >= P.fam_thres_dup1add) && (con_nfrags * 100 >= tot_nfrags * P.fam_thres_dup1perc))
+                    A.fap(strand, UVC_FAM_cDPD, cs, 1);
+                const int avgBQ = ((0 == tot_nfrags) ? 1 : (con_sumBQs / tot_nfrags));
+                const int majorcount = FAP(R, strand, UVC_FAM_cDPM, cs, x), minorcount = FAP(R, strand, UVC_FAM_cDPm, cs, x);   // complete: P4 ran before
+                const double prior_weight = 1.0 / (minorcount + 1.0);
+                const double p2p = pow(10.0, (double)(-((float)avgBQ) / 10));   // phred2prob's float cast, main_conversion.hpp:885-888
+                const double prob = (minorcount + prior_weight) / (majorcount + minorcount + prior_weight / p2p);
+                const double realphred = -10 * log(prob) / log(10.0);
+                const int indep_frag_phred = (int)round(((con_nfrags * 2) - tot_nfrags) * realphred);
+                int confam_qual;
+                if (UVC_LINK_SYMBOL == st) confam_qual = imax(1, imin(indep_frag_phred, P.fam_phred_indel_inc_before_barcode_labeling + (int)round(realphred)));
+                else confam_qual = imax(1, imin(indep_frag_phred, (con_sumBQs * 2) - tot_sumBQs));
+                const int max_qual = sscs_phred(P, R.refsym[x], cs) + (!P.tumor_vcf_is_provided ? 0 : 4);
+                const int confam_qual2 = imin(confam_qual, max_qual);
+                if (tot_nfrags >= P.fam_thres_dup1add) {
+                    const int pbucket = (max_qual - confam_qual2 + 2) / 4;
+                    if (pbucket >= 0 && pbucket < NBUCKETS) A.bucket(strand, cs, pbucket);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // one add per non-zero (field, dense symbol, position) of the window
+    for (int i = threadIdx.x; i < 2 * FAMW_SLOTS * 64; i += 256) {
+        const int v = (&a32[0][0][0])[i];
+        if (!v) continue;
+        const int ln = i & 63, slot = (i >> 6) % FAMW_SLOTS, d = (i >> 6) / FAMW_SLOTS;
+        const int64_t xx = x0 + ln;
+        const int sym = (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M);
+        if (slot < 2 * UVC_NFAM) atomicAdd(&FAP(R, slot / UVC_NFAM, slot % UVC_NFAM, sym, xx), v);
+        else atomicAdd(&FIP(R, slot - 2 * UVC_NFAM, sym, xx), v);
+    }
+    for (int i = threadIdx.x; i < 2 * UVC_NFAMINFO64 * 64; i += 256) {
+        const unsigned long long v = (&a64[0][0][0])[i];
+        if (!v) continue;
+        const int ln = i & 63, f = (i >> 6) % UVC_NFAMINFO64, d = (i >> 6) / UVC_NFAMINFO64;
+        const int64_t xx = x0 + ln;
+        add64(&FI64P(R, f, (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M), xx), (long long)v);
+    }
+    if (PASS == 5) for (int i = threadIdx.x; i < 2 * 2 * NBUCKETS * 64; i += 256) {
+        const int v = (&bk[0][0][0][0])[i];
+        if (!v) continue;
+        const int ln = i & 63, b = (i >> 6) % NBUCKETS, strand = ((i >> 6) / NBUCKETS) % 2, d = (i >> 6) / (2 * NBUCKETS);
+        const int64_t xx = x0 + ln;
+        atomicAdd(&BKP(R, strand, (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M), b, xx), v);
+    }
+}
+
 // duplex consensus (main.hpp:3427-3433, 3523-3550): one thread per (strand-0 unit of a duplex family with both strands, position)
 __global__ void __launch_bounds__(256) k_duplex(RegionDev R, UvcParams P, const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_work) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2131,7 +2316,11 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
     TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag, dim3(nwin), dim3(256), 0, s, *R, *P));
     if (R->n_generic_fs) {
         TIMED(prof, "k_fam_stat", hipLaunchKernelGGL(k_fam_stat, dim3(nblk(R->n_generic_fs, 64)), dim3(64), 0, s, *R, *P));
-        TIMED(prof, "k_fam_p4", hipLaunchKernelGGL(k_fam_p4, dim3(nblk(R->n_generic_work, 256)), dim3(256), 0, s, *R, *P));
+        // shallow data: one thread per (unit, position); deep data (many units per position, e.g. UMI panels): the window kernel, whose
+        // LDS collection removes most of the atomics that bound the per-thread form
+        const bool deep = (R->n_generic_work > 8 * R->npos);
+        if (deep) TIMED(prof, "k_fam_p4", hipLaunchKernelGGL(k_fam_win<4>, dim3(nblk(R->npos, 64)), dim3(256), 0, s, *R, *P));
+        else TIMED(prof, "k_fam_p4", hipLaunchKernelGGL(k_fam_p4, dim3(nblk(R->n_generic_work, 256)), dim3(256), 0, s, *R, *P));
         if (P->inferred_is_vcf_generated) {
             TIMED(prof, "k_fam_p5", hipLaunchKernelGGL(k_fam_p5, dim3(nblk(R->n_generic_work, 256)), dim3(256), 0, s, *R, *P));
             if (n_dup) TIMED(prof, "k_duplex", hipLaunchKernelGGL(k_duplex, dim3(nblk(n_dup_work, 256)), dim3(256), 0, s, *R, *P, dup_units, n_dup, dup_off, n_dup_work));
