@@ -50,6 +50,11 @@ void indelpos_to_context(i32 &repeatunit_len, i32 &max_repeatnum, const std::str
     repeatunit_len = (i32)refstring.substr(refpos, rs_at_max).size();
 }
 
+// a_dp == 0 (an insertion right after the last aligned base of the only covering read) makes the reference convert
+// round(-inf) to an integer and subtract 3 from it (main.hpp:2038-2044, 2147-2150): undefined behaviour, whose outcome
+// depends on the compiler.  Both this restatement and the HIP path DEFINE that case as "no bonus" (a very negative phredinc).
+static const i32 PHREDINC_NO_DEPTH = -1000000;
+
 // indel_len_rusize_phred, main.hpp:757-790
 i32 indel_len_rusize_phred(i32 indel_len, i32 repeatunit_size) {
     static const i32 n_units_to_phred[19] = { 0, 0, 3, 5, 6, 7, 8, 8, 9, 10, 10, 10, 11, 11, 11, 12, 12, 12, 13 };
@@ -682,7 +687,7 @@ static int update_by_aln(State &S, const Aln &a, int dflag, bool bias, Cov *tmp,
                     i32 phredvalue = ref_to_phredvalue(inslen, max_rn, rs_at_max, S, rpos - off, P.indel_BQ_max, P.indel_polymerase_slip_rate, len, op);
                     const i64 x = rpos - off;
                     const i32 adp = S.p32(UVC_P_a_dp, x);
-                    const i32 phredinc = (i32)round(2 * numstates2phred((double)adp / (double)(1.0 + nnminus(adp, S.p32(UVC_P_a_at_ins_dp, x) + S.p32(UVC_P_a_at_del_dp, x)))));
+                    const i32 phredinc = (adp > 0 ? (i32)round(2 * numstates2phred((double)adp / (double)(1.0 + nnminus(adp, S.p32(UVC_P_a_at_ins_dp, x) + S.p32(UVC_P_a_at_del_dp, x))))) : PHREDINC_NO_DEPTH);
                     const i32 ratiothres = (!P.tumor_vcf_is_provided ? 2 : 4);
                     const bool is_multiallelic_ins = (S.p64(UVC_P_a_near_ins_pow2len, x) * ratiothres > (i64)max_(1, S.p32(UVC_P_a_near_ins_dp, x)) * (i64)((u32)len * 3u));
                     if (1 == inslen && !is_multiallelic_ins) phredvalue += between_(phredinc - 3, 0, 4);
@@ -730,7 +735,7 @@ static int update_by_aln(State &S, const Aln &a, int dflag, bool bias, Cov *tmp,
                     i32 phredvalue = ref_to_phredvalue(dellen, max_rn, rs_at_max, S, rpos - off, P.indel_BQ_max, P.indel_polymerase_slip_rate, len, op);
                     const i64 x = rpos - off;
                     const i32 adp = S.p32(UVC_P_a_dp, x);
-                    const i32 phredinc = (i32)round(2 * numstates2phred((double)adp / (double)(1.0 + nnminus(adp, S.p32(UVC_P_a_at_ins_dp, x) + S.p32(UVC_P_a_at_del_dp, x)))));
+                    const i32 phredinc = (adp > 0 ? (i32)round(2 * numstates2phred((double)adp / (double)(1.0 + nnminus(adp, S.p32(UVC_P_a_at_ins_dp, x) + S.p32(UVC_P_a_at_del_dp, x))))) : PHREDINC_NO_DEPTH);
                     if (1 == dellen) phredvalue += between_(phredinc - 3, 0, 4);
                     const i32 thisdp = S.p32(UVC_P_a_at_del_dp, x);
                     const i32 neardp = max_(S.p32(UVC_P_a_near_del_dp, x), S.p32(UVC_P_a_near_RTR_del_dp, x));

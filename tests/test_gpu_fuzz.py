@@ -1,0 +1,158 @@
+"""Seeded random reads with the CIGAR shapes real aligners emit at the edges of what the hot path handles: several InDels per
+read, an insertion next to a deletion, InDels at the read ends, reference skips, hard clips, one-base reads, reads that touch
+the region borders, unpaired / mate-unmapped flags, odd isize / mpos values, MAPQ 0, N bases, low qualities, families of 1..9
+fragments with 1..3 alignments each.  The HIP path must agree with the oracle bit for bit -- or both must refuse the input with
+the same error code."""
+import numpy as np
+import pytest
+
+from uvc_amd import region
+from util import diff_groups
+
+pytestmark = pytest.mark.gpu
+
+M, I, D, N, S, H = 0, 1, 2, 3, 4, 5
+
+
+def weird_region(seed, n_frag=260, ref_len=700, beg=1_000_000, umi=False):
+    rng = np.random.default_rng(seed)
+    ref = rng.integers(0, 4, ref_len)
+    for _ in range(6):                                   # homopolymers / STRs so that the InDel context code is exercised
+        q = int(rng.integers(20, ref_len - 40)); ref[q:q + int(rng.integers(5, 14))] = rng.integers(0, 4)
+    refseq = "".join("ACGT"[b] for b in ref)
+    cols = dict(pos=[], mpos=[], isize=[], flag=[], mapq=[], nm=[], l_qseq=[], seq_off=[], cigar_off=[], n_cigar=[], frag_id=[], fam_id=[], fam_strand=[])
+    bases, quals, cigars, fam_dflag = [], [], [], []
+    frag = 0
+    fam = -1
+    left_in_fam = 0
+    while frag < n_frag:
+        if left_in_fam == 0:
+            fam += 1
+            left_in_fam = int(rng.integers(1, 10)) if umi else int(rng.choice([1, 1, 1, 2, 3]))
+            fam_dflag.append(int(rng.choice([0x3, 0x1, 0x0])) if umi else int(rng.choice([0, 0, 0, 4, 8])))
+            n_s0 = int(rng.integers(0, left_in_fam + 1))  # fragments on strand 0 first, then strand 1 (contiguous per strand)
+            order = [0] * n_s0 + [1] * (left_in_fam - n_s0)
+        strand = order[len(order) - left_in_fam]
+        left_in_fam -= 1
+        start = int(rng.integers(2, ref_len - 60))
+        for a in range(int(rng.choice([1, 2, 2, 2, 3]))):  # alignments of this fragment
+            ops = []
+            style = int(rng.integers(0, 10))
+            ref_room = ref_len - 2 - start
+            target = int(min(ref_room, rng.choice([1, 2, 5, 30, 60, 90, 120, 150])))
+            if target < 1: target = 1
+            if style == 0: ops = [(M, target)]
+            else:
+                if rng.random() < 0.3: ops.append((H, int(rng.integers(1, 20))))
+                if rng.random() < 0.4: ops.append((S, int(rng.integers(1, 30))))
+                if rng.random() < 0.15: ops.append((I, int(rng.integers(1, 4))))          # leading insertion
+                used = 0
+                while used < target:
+                    m = int(min(target - used, rng.integers(1, 40)))
+                    ops.append((M, m)); used += m
+                    if used >= target: break
+                    r = rng.random()
+                    if r < 0.35: ops.append((I, int(rng.integers(1, 5))))
+                    elif r < 0.7:
+                        d = int(min(rng.integers(1, 6), target - used - 1))
+                        if d >= 1: ops.append((D, d)); used += d
+                    elif r < 0.8: ops.append((I, int(rng.integers(1, 3)))); d = int(min(2, target - used - 1)); ops += ([(D, d)] if d >= 1 else []); used += max(d, 0)
+                    elif r < 0.86:
+                        d = int(min(rng.integers(1, 30), target - used - 1))
+                        if d >= 1: ops.append((N, d)); used += d
+                if ops[-1][0] in (D, N): ops.append((M, 1)) if start + sum(l for o, l in ops if o in (M, D, N)) < ref_len - 2 else ops.pop()
+                if rng.random() < 0.1: ops.append((I, int(rng.integers(1, 3))))            # trailing insertion
+                if rng.random() < 0.4: ops.append((S, int(rng.integers(1, 30))))
+                if rng.random() < 0.2: ops.append((H, int(rng.integers(1, 20))))
+            merged = []
+            for o, l in ops:                                   # no two adjacent ops of one kind
+                if merged and merged[-1][0] == o: merged[-1] = (o, merged[-1][1] + l)
+                else: merged.append((o, l))
+            ops = merged
+            qlen = sum(l for o, l in ops if o in (M, I, S))
+            rlen = sum(l for o, l in ops if o in (M, D, N))
+            if qlen < 1 or rlen < 1 or start + rlen > ref_len - 1: ops, qlen, rlen = [(M, 1)], 1, 1
+            q = []; rp = start
+            for o, l in ops:
+                if o == M:
+                    seg = ref[rp:rp + l].copy()
+                    mis = rng.random(l) < 0.03
+                    seg[mis] = rng.integers(0, 5, mis.sum())
+                    q += list(seg); rp += l
+                elif o in (I, S): q += list(rng.integers(0, 5, l))
+                elif o in (D, N): rp += l
+            fl = int(rng.choice([0x0, 0x10, 0x1 | 0x40, 0x1 | 0x80 | 0x10, 0x1 | 0x40 | 0x20, 0x1 | 0x8 | 0x40, 0x1 | 0x2 | 0x80 | 0x20 | 0x10]))
+            cols["pos"].append(beg + start); cols["flag"].append(fl); cols["mapq"].append(int(rng.choice([0, 3, 20, 40, 60])))
+            cols["mpos"].append(beg + int(rng.integers(0, ref_len - 1)) if fl & 1 else -1)
+            cols["isize"].append(int(rng.choice([0, 0, 150, -150, 320, -400, 1999, -2001, 5000])) if fl & 1 else 0)
+            cols["nm"].append(int(rng.choice([-1, 0, 1, 3, 9])))
+            cols["l_qseq"].append(qlen); cols["seq_off"].append(len(bases)); cols["cigar_off"].append(len(cigars)); cols["n_cigar"].append(len(ops))
+            cols["frag_id"].append(frag); cols["fam_id"].append(fam); cols["fam_strand"].append(strand)
+            bases += [int(b) for b in q]
+            quals += list(rng.choice([2, 8, 15, 20, 21, 22, 30, 37, 41], qlen))
+            cigars += [(l << 4) | o for o, l in ops]
+        frag += 1
+    dt = dict(pos=np.int32, mpos=np.int32, isize=np.int32, flag=np.uint16, mapq=np.uint8, nm=np.int32, l_qseq=np.int32, seq_off=np.int64, cigar_off=np.int64,
+              n_cigar=np.int32, frag_id=np.int32, fam_id=np.int32, fam_strand=np.uint8)
+    r = {k: np.array(v, dt[k]) for k, v in cols.items()}
+    r.update(n_reads=len(cols["pos"]), tid=3, beg=beg, end=beg + ref_len, refseq=refseq, n_fams=fam + 1, fam_dflag=np.array(fam_dflag, np.uint8),
+             bases=np.array(bases, np.uint8), quals=np.array(quals, np.uint8), cigars=np.array(cigars, np.uint32))
+    return r
+
+
+def run(lib, reads, platform=1, correct_bq=False):
+    R = region.Region(lib, region.default_params(lib, platform=platform), reads["tid"], reads["beg"], reads["end"], reads["refseq"])
+    R.set_reads(reads)
+    if correct_bq:
+        R.correct_bq()
+    R.accumulate()
+    R.fetch("PREP32")       # surfaces device-side error flags
+    return R
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_weird_reads(seed, oracle_lib, gpu_lib):
+    reads = weird_region(seed, umi=(seed % 3 == 2))
+    platform = 2 if seed % 4 == 3 else 1
+    outcome = []
+    for lib in (oracle_lib, gpu_lib):
+        try:
+            outcome.append(run(lib, reads, platform=platform, correct_bq=(seed % 2 == 1)))
+        except region.UvcError as e:
+            outcome.append(e.code)
+    o, g = outcome
+    if isinstance(o, int) or isinstance(g, int):
+        # the HIP path may refuse shapes the reference handles (documented limits: > 3 LINK symbols of one read at one position,
+        # > 16 low-quality InDels in one read) -- with UVCGPU_EUNSUPPORTED, never silently; anything else must be refused by both
+        assert (g == -3 and not isinstance(o, int)) or o == g, (o, g)
+        return
+    bad = diff_groups(o, g)
+    assert not bad, "\n".join("%s: %d cells differ, e.g. %s" % (k, v[0], v[1]) for k, v in bad.items())
+    ro, rg = o.score(all_out=True), g.score(all_out=True)
+    from test_gpu_parity import compare_records
+    compare_records(ro, rg)
+
+
+def test_fragment_longer_than_the_sweep_window(oracle_lib, gpu_lib):
+    """Two alignments of one read name 5 kb apart (a chimeric pair): the fragment span exceeds the LDS window of k_fragstat_sweep."""
+    rng = np.random.default_rng(5)
+    ref_len, beg = 6000, 2_000_000
+    ref = rng.integers(0, 4, ref_len)
+    reads = weird_region(3, n_frag=40, ref_len=ref_len, beg=beg)
+    # move the second alignment of every multi-alignment fragment far to the right (same CIGAR, bases re-drawn from the reference there)
+    pos = reads["pos"].copy(); bases = reads["bases"].copy()
+    refb = np.frombuffer(reads["refseq"].encode(), dtype=np.uint8)
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    seen = set()
+    for i in range(int(reads["n_reads"])):
+        f = int(reads["frag_id"][i])
+        if f in seen and int(reads["n_cigar"][i]) == 1 and (int(reads["cigars"][int(reads["cigar_off"][i])]) & 0xF) == 0:
+            ln = int(reads["l_qseq"][i]); newp = ref_len - 400 + (i % 100)
+            pos[i] = beg + newp
+            so = int(reads["seq_off"][i])
+            bases[so:so + ln] = [code[int(c)] for c in refb[newp:newp + ln]]
+        seen.add(f)
+    reads["pos"], reads["bases"] = pos, bases
+    o, g = run(oracle_lib, reads), run(gpu_lib, reads)
+    bad = diff_groups(o, g)
+    assert not bad, "\n".join("%s: %d cells differ, e.g. %s" % (k, v[0], v[1]) for k, v in bad.items())

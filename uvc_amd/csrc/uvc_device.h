@@ -54,7 +54,7 @@ struct FastRec {
                                             // (index of the base at position p) - p; aln: index into alns[]
     int32_t fmd, isize, mpos, xm1500;       // fmd = flag | mapq << 16 | dflag << 24
     int32_t bmv, xbv, bm4c, clips;          // bmv: a2BM2 increment (<= 100) of base symbols 0..3, one byte each; xbv: that of symbol 4 | a2XM2 increment << 8;
-                                            // bm4c: clip_cnt << 16 | nogap_penal << 20; clips = lclip_oplen | rclip_oplen << 16
+                                            // bm4c: clip_cnt << 16 | (nogap_penal & 0xFFFF); clips = lclip_oplen | rclip_oplen << 16
     int32_t baq_pos, baq_last, baq2_last, ext;   // ext: (pos - read start) | (read end - rend) << 16, zero for a whole read
 };
 

@@ -358,7 +358,7 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
                                              // base qualities, which uvcgpu_region_correct_bq may still change on the device)
         }
         if (!simple) {
-            table_off[i] = table_rows; table_rows += (e - in->pos[i]);
+            table_off[i] = table_rows; table_rows += (e - in->pos[i]) + 1;   // + the row of an insertion right behind the last aligned base (rpos == bam_endpos)
             int64_t del_total = 0; for (int k = 0; k < nc; k++) if ((cg[k] & 0xF) == C_DEL) del_total += (cg[k] >> 4);
             item_off[i] = item_slots; item_slots += 2 * (int64_t)lq + 2 * del_total + nc + 4;   // upper bound of P2 updates of this read
         }

@@ -358,7 +358,7 @@ DEV void fill_fastrec(FastRec &f, const AlnRec &a, int id, int cbeg, int cend, i
     for (int s2 = 0; s2 < 5; s2++) bv[s2] = (a.bm1500[s2] > 20 ? (100 * (20 * 20) / (a.bm1500[s2] * a.bm1500[s2])) : 100);
     const int xv = (a.xm1500 > 20 ? (100 * (20 * 20) / (a.xm1500 * a.xm1500)) : 100);
     f.bmv = bv[0] | (bv[1] << 8) | (bv[2] << 16) | (bv[3] << 24); f.xbv = bv[4] | (xv << 8);
-    f.bm4c = ((a.clip_cnt & 0xF) << 16) | ((a.nogap_penal & 0xF) << 20);
+    f.bm4c = ((a.clip_cnt & 0xF) << 16) | (a.nogap_penal & 0xFFFF);   // nogap_penal is negative when NM < the InDel lengths
     f.clips = (a.lclip_oplen & 0xFFFF) | (a.rclip_oplen << 16);
     f.baq_pos = (int32_t)a.baq_pos; f.baq_last = (int32_t)a.baq_last; f.baq2_last = (int32_t)a.baq2_last;
     f.ext = ((cbeg - a.pos) & 0xFFFF) | ((a.rend - cend) << 16);
@@ -413,6 +413,9 @@ __global__ void __launch_bounds__(256) k_aln_prelude(RegionDev R, RawReads W, Uv
     const int by_nm = (a.xm1500 + a.go1500) / 30;
     a.indel_penal = imin(1, by_nm + by_clip);
     a.nogap_penal = imin(4, by_nm + by_clip) + 1;
+    // NM below the InDel lengths (malformed, but the reference computes with it) makes the penalties negative; the 8-bit value
+    // fields of Item / Contrib hold the results only down to here
+    if (by_nm + by_clip < -150) atomicExch(R.err, UVCGPU_EUNSUPPORTED);
     a.lclip_q = lclip_q; a.m_index = m_index;
     a.lclip_oplen = 0; a.rclip_oplen = 0;
     if (a.kind == 0) {
@@ -893,7 +896,7 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
             sr.xm1500 = bcast(c.v[7], j);
             const int bm4c = bcast(c.v[10], j);
             sr.clip_cnt = (bm4c >> 16) & 0xF;
-            const int nogap = (bm4c >> 20) & 0xF;
+            const int nogap = (int)(short)(bm4c & 0xFFFF);
             sr.baq_pos = bcast(c.v[12], j); sr.baq_last = bcast(c.v[13], j); sr.baq2_last = bcast(c.v[14], j);
             const bool is_assay_amplicon = ((sr.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag)));
             bool gate = true;
@@ -1027,7 +1030,8 @@ __global__ void __launch_bounds__(64) k_p2_slow(RegionDev R, UvcParams P) {
             Item it; it.epos = epos; it.sym = (uint8_t)sym; it.flags = (uint8_t)((gap ? 1 : 0) | (op << 1)); it.val = (uint8_t)imin(v, 255); it.pad = 0;
             it.dist = (uint16_t)imin(imax(dist, 0), 65535); it.indel_len = (uint16_t)imin(indel_len, 65535); it.pad2 = 0;
             items[n_items++] = it;
-        } else table_put(R, table + (epos - a.pos), sym, v);
+        } else if (epos >= a.pos && epos <= a.rend) table_put(R, table + (epos - a.pos), sym, v);
+        else atomicExch(R.err, UVCGPU_EDEVICE);   // would leave the read's rows
     };
     // low-BQ InDel positions (main.hpp:1817-1859); at most 16 tracked, more => unsupported
     int indel_rposs[18]; int n_ir = 0; indel_rposs[n_ir++] = 0;
@@ -1108,7 +1112,8 @@ __global__ void __launch_bounds__(64) k_p2_slow(RegionDev R, UvcParams P) {
                     int phredvalue = ref_to_phredvalue_dev(inslen, max_rn, rs_at_max, R, P, rpos - off, P.indel_BQ_max, P.indel_polymerase_slip_rate, len, op);
                     const int64_t x = rpos - off;
                     const int adp = P32(R, UVC_P_a_dp, x);
-                    const int phredinc = (int)round(2 * ((10.0 / log(10.0)) * log((double)adp / (double)(1.0 + nnminus(adp, P32(R, UVC_P_a_at_ins_dp, x) + P32(R, UVC_P_a_at_del_dp, x))))));
+                    // adp == 0 is undefined behaviour in the reference (round(-inf) -> int); defined here and in the oracle as "no bonus"
+                    const int phredinc = (adp > 0 ? (int)round(2 * ((10.0 / log(10.0)) * log((double)adp / (double)(1.0 + nnminus(adp, P32(R, UVC_P_a_at_ins_dp, x) + P32(R, UVC_P_a_at_del_dp, x)))))) : -1000000);
                     const int ratiothres = (!P.tumor_vcf_is_provided ? 2 : 4);
                     const bool multiallelic = (P64(R, UVC_P_a_near_ins_pow2len, x) * ratiothres > (long long)imax(1, P32(R, UVC_P_a_near_ins_dp, x)) * (long long)((unsigned)len * 3u));
                     if (1 == inslen && !multiallelic) phredvalue += ibetween(phredinc - 3, 0, 4);
@@ -1146,7 +1151,8 @@ __global__ void __launch_bounds__(64) k_p2_slow(RegionDev R, UvcParams P) {
                     int phredvalue = ref_to_phredvalue_dev(dellen, max_rn, rs_at_max, R, P, rpos - off, P.indel_BQ_max, P.indel_polymerase_slip_rate, len, op);
                     const int64_t x = rpos - off;
                     const int adp = P32(R, UVC_P_a_dp, x);
-                    const int phredinc = (int)round(2 * ((10.0 / log(10.0)) * log((double)adp / (double)(1.0 + nnminus(adp, P32(R, UVC_P_a_at_ins_dp, x) + P32(R, UVC_P_a_at_del_dp, x))))));
+                    // adp == 0 is undefined behaviour in the reference (round(-inf) -> int); defined here and in the oracle as "no bonus"
+                    const int phredinc = (adp > 0 ? (int)round(2 * ((10.0 / log(10.0)) * log((double)adp / (double)(1.0 + nnminus(adp, P32(R, UVC_P_a_at_ins_dp, x) + P32(R, UVC_P_a_at_del_dp, x)))))) : -1000000);
                     if (1 == dellen) phredvalue += ibetween(phredinc - 3, 0, 4);
                     const int thisdp = P32(R, UVC_P_a_at_del_dp, x);
                     const int neardp = imax(P32(R, UVC_P_a_near_del_dp, x), P32(R, UVC_P_a_near_RTR_del_dp, x));
@@ -1232,7 +1238,8 @@ __global__ void __launch_bounds__(64) k_p2_items(RegionDev R, UvcParams P) {
 // come from the table.  Values are merged into the per-fragment symbol counts with MAX.
 // ------------------------------------------------------------------------------------------------
 DEV void aln_contrib_max(const RegionDev &R, const UvcParams &P, const AlnRec &a, int p, bool proton, int *cnt /*[NSYM]*/) {
-    if (p < a.pos || p >= a.rend) return;
+    // an InDel read can carry an insertion symbol at rpos == rend (CIGAR ...M I [S]): its table has one row more than the read spans
+    if (p < a.pos || p > a.rend || (p == a.rend && a.kind == 0)) return;
     if (a.kind == 0) {
         const bool is_assay_amplicon = ((a.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag)));
         if (is_assay_amplicon && !(P.tn_is_paired && (0x1 & P.primer_flag))) {
@@ -1294,6 +1301,7 @@ DEV void fragstat_sweep(const RegionDev &R, const UvcParams &P, int fi) {
         }
     }
     R.frags[fi].n_cov = n_cov; R.frags[fi].n_near = n_near;
+    FragFast &ff = R.ffast[R.frag_rank[fi]]; ff.n_cov = n_cov; ff.n_near = n_near;   // k_frag reads the digest
 }
 
 // one wave per fragment: lanes classify positions (covered / mutated) into LDS, then count covered positions and those within
@@ -1360,7 +1368,7 @@ DEV bool aln_runs(const RegionDev &R, const AlnRec &a, int &pA, int &eA, int &qA
         else if (op == C_HARD_CLIP) {}
         else return false;
     }
-    if (sp_beg + sp_len > a.rend) sp_len = imax(0, a.rend - sp_beg);   // nothing is emitted at or past the end of the alignment
+    if (sp_beg + sp_len > a.rend + 1) sp_len = imax(0, a.rend + 1 - sp_beg);   // the last position that can carry a symbol is rend itself (insertion behind the last base)
     return n_runs >= 1 && sp_len < 32768;
 }
 
