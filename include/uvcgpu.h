@@ -209,13 +209,17 @@ enum UvcScoreField {
     UVC_O_cMmQ, UVC_O_aAaMQ, UVC_O_bMQQ, UVC_O_bIAQ, UVC_O_cIAQ,
     UVC_O_cPCQ1, UVC_O_cPLQ1, UVC_O_cPCQ2, UVC_O_cPLQ2, UVC_O_bTINQ, UVC_O_cTINQ,
     UVC_O_gVQ1, UVC_O_cVQ1, UVC_O_dVQinc, UVC_O_cVQ2, UVC_O_CONTQ,
+    /* InDel alleles: gapSa = index (into uvcgpu_region_indel_alleles' rows) of the first row that carries this record's InDel string,
+     * or -1 (not an InDel, or the string came from the caller); gapSa_len = indelstring.size() (main.cpp:907) */
+    UVC_O_gapSa, UVC_O_gapSa_len,
     UVC_NUM_SCORE_FIELDS
 };
 
-/* Host-supplied allele refinement for InDel symbols.  In the reference these come from the
- * string-keyed maps walked by fill_by_indel_info / indel_get_majority (main.hpp:5350-5455,
- * instcode.hpp), which stay on the host.  Alleles not listed here are scored with
- * bDPa = bdepth, cDP0a = cdepth (main.cpp:809-816, 903) and indel_len = |units| of the symbol. */
+/* Caller-supplied InDel alleles (optional override).  By default the library derives the alleles of every scored InDel symbol
+ * itself, the way fill_by_indel_info / indel_get_majority do (main.hpp:5350-5455, instcode.hpp, main.cpp:853-896): one record per
+ * distinct inserted sequence / deleted length whose fragment support is at least a quarter of the best one, with
+ * bDPa / cDP0a = that allele's fragment / family support summed over both strands.  If the request lists alleles for a
+ * (refpos, symbol), those are scored instead. */
 typedef struct UvcIndelAllele {
     int32_t refpos;
     int32_t symbol;
@@ -234,6 +238,18 @@ typedef struct UvcTumorKey {
     int32_t tier2;
     int32_t indel_len;
 } UvcTumorKey;
+
+/* One row of the per-strand InDel allele tables that fill_by_indel_info pushes into gapSeq / gapbAD1 / gapcAD1 / gc2AD / gc2dAD
+ * (instcode.hpp:44-83): the allele counters kept beside FRAG_bDP, FAM_cDP12-after-filtering, FAM_cDP2 and FAM_cDPD / DUPLEX_dDP2
+ * (main.hpp:2710-2717, 3327-3336, 3196-3206, 3458-3469, 3535-3546).  Rows are ordered by (refpos, symbol, strand) and inside a
+ * group as the reference sorts them (descending (cAD1, bAD1, c2AD, c2dAD, sequence)). */
+typedef struct UvcGapRow {
+    int32_t refpos, symbol, strand;
+    int32_t len;                /* inserted / deleted length */
+    int64_t seq_off;            /* insertions: offset of `len` base codes (0..4 = ACGTN) in the sequence buffer; deletions: -1 (the deleted
+                                 * bases are refseq[refpos - beg, +len)) */
+    int32_t bAD1, cAD1, c2AD, c2dAD;
+} UvcGapRow;
 
 typedef struct UvcScoreRequest {
     int32_t pos_beg;            /* first zerobased_pos scored (rpos_inclu_beg, main.cpp:527); -1 = whole region core */
@@ -287,6 +303,11 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
 /* Raw state access (the reference reads members directly, main.cpp:682-688, 759-760, 801-816). */
 int64_t uvcgpu_region_field_bytes(const uvcgpu_region_t *r, int32_t field_group);
 int uvcgpu_region_fetch(uvcgpu_region_t *r, int32_t field_group, void *dst, int64_t dst_bytes);
+/* The InDel allele tables of the accumulated region (see UvcGapRow).  *n_rows / *seq_bytes receive the sizes needed; rows / seq are
+ * filled when the capacities suffice, else UVCGPU_ENOMEM is returned and nothing is written.  Replaces the direct reads of
+ * getPosToIseqToData / getPosToDlenToData / pos2iseq2data_cDP2 / pos2iseq2data_c2dDP in main.hpp:5350-5376. */
+int uvcgpu_region_indel_alleles(uvcgpu_region_t *r, UvcGapRow *rows, int64_t row_capacity, int64_t *n_rows,
+                                uint8_t *seq, int64_t seq_capacity, int64_t *seq_bytes);
 int uvcgpu_region_sync(uvcgpu_region_t *r);
 /* Measurement hooks (bench.py): HIP-event timing of every kernel of the LAST accumulate, recorded on the handle's stream.
  * kernel_times returns the number of kernels; `names` receives their names separated by ';'. */

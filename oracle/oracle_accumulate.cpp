@@ -897,6 +897,8 @@ static int using_bq(State &S, std::string &err) {
                     if (pbucket < NBUCKETS) S.BK(0, con_symbol, pbucket, x) += 1;
                     S.FR(strand, UVC_FRAG_bDP, con_symbol, x) += 1;
                     S.VQ(UVC_VQ_bMQ, con_symbol, x) += (normMQ * normMQ) / SQR_QUAL_DIV_;
+                    if (is_ins(con_symbol)) indel_update_by_consensus(S.gap_frag[strand].iseq[ins_idx(con_symbol)], tmp.iseq[ins_idx(con_symbol)], epos, 1);   // main.hpp:2710-2717
+                    if (is_del(con_symbol)) indel_update_by_consensus(S.gap_frag[strand].dlen[del_idx(con_symbol)], tmp.dlen[del_idx(con_symbol)], epos, 1);
                     cov_mut[epos - beg2] |= 0x1;
                     const bool is_var_of_highBQ = ((UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform)
                             ? (UVC_BASE_SYMBOL == st || con_qual + 3 >= P.bias_thres_highBQ)
@@ -1010,6 +1012,8 @@ static int using_fq(State &S, std::string &err) {
                 if (!P.inferred_is_vcf_generated) continue;
                 if (is_fam_good) {
                     S.FA(strand, UVC_FAM_cDP2, con_symbol, x) += 1;
+                    if (is_ins(con_symbol)) indel_update_by_consensus(S.gap_c2[strand].iseq[ins_idx(con_symbol)], con.iseq[ins_idx(con_symbol)], epos, 1);   // main.hpp:3196-3206
+                    if (is_del(con_symbol)) indel_update_by_consensus(S.gap_c2[strand].dlen[del_idx(con_symbol)], con.dlen[del_idx(con_symbol)], epos, 1);
                     // FAM2 bias, main.hpp:3208-3319
                     const i32 rpos = epos;
                     i32 rbeg = min_(nsb_min, epos), rend = max_(nsb_max, epos);
@@ -1059,6 +1063,8 @@ static int using_fq(State &S, std::string &err) {
                     }
                 }
                 if (P.fam_thres_dup2add <= tot_count && (con_count * 100 >= tot_count * P.fam_thres_dup2perc)) S.FA(strand, UVC_FAM_cDP3, con_symbol, x) += 1;
+                if (is_ins(con_symbol)) indel_update_by_consensus(S.gap_fam[strand].iseq[ins_idx(con_symbol)], con.iseq[ins_idx(con_symbol)], epos, 1);   // main.hpp:3327-3336
+                if (is_del(con_symbol)) indel_update_by_consensus(S.gap_fam[strand].dlen[del_idx(con_symbol)], con.dlen[del_idx(con_symbol)], epos, 1);
                 const i32 flat = (is_subst(con_symbol) ? P.fam_thres_emperr_all_flat_snv : P.fam_thres_emperr_all_flat_indel);
                 const i32 perc = (is_subst(con_symbol) ? P.fam_thres_emperr_con_perc_snv : P.fam_thres_emperr_con_perc_indel);
                 if (tot_count < flat) continue;
@@ -1114,7 +1120,11 @@ static int using_fq(State &S, std::string &err) {
                     for (int s = st_beg(st); s <= st_end(st); s++) tot_nfrags += con.row(epos)[s];
                     S.FA(strand, UVC_FAM_cDP1, con_symbol, x) += 1;
                     if (will_inc_sscs && (!will_inc_dscs) && (tot_nfrags >= P.fam_thres_dup1add) && (con_nfrags * 100 >= tot_nfrags * P.fam_thres_dup1perc))
+                    {
                         S.FA(strand, UVC_FAM_cDPD, con_symbol, x) += 1;
+                        if (is_ins(con_symbol)) indel_update_by_consensus(S.gap_c2d[strand].iseq[ins_idx(con_symbol)], con.iseq[ins_idx(con_symbol)], epos, 1);   // main.hpp:3458-3469
+                        if (is_del(con_symbol)) indel_update_by_consensus(S.gap_c2d[strand].dlen[del_idx(con_symbol)], con.dlen[del_idx(con_symbol)], epos, 1);
+                    }
                     const i32 avgBQ = ((0 == tot_nfrags) ? 1 : (con_sumBQs / tot_nfrags));
                     const i32 majorcount = S.FA(strand, UVC_FAM_cDPM, con_symbol, x);
                     const i32 minorcount = S.FA(strand, UVC_FAM_cDPm, con_symbol, x);
@@ -1141,7 +1151,13 @@ static int using_fq(State &S, std::string &err) {
                 int cs; i32 cc, ct;
                 fill_consensus(dup.row(epos), cs, cc, ct, st);
                 if (0 < ct) S.DU(UVC_DUPLEX_dDP1, cs, epos - S.beg) += 1;
-                if (1 < ct) S.DU(UVC_DUPLEX_dDP2, cs, epos - S.beg) += 1;
+                if (1 < ct) {
+                    S.DU(UVC_DUPLEX_dDP2, cs, epos - S.beg) += 1;
+                    for (int strand = 0; strand < 2; strand++) {   // main.hpp:3535-3546
+                        if (is_ins(cs)) indel_update_by_consensus(S.gap_c2d[strand].iseq[ins_idx(cs)], dup.iseq[ins_idx(cs)], epos, 1);
+                        if (is_del(cs)) indel_update_by_consensus(S.gap_c2d[strand].dlen[del_idx(cs)], dup.dlen[del_idx(cs)], epos, 1);
+                    }
+                }
             }
         }
     }
@@ -1180,6 +1196,7 @@ int accumulate(State &S, std::string &err) {
     zero32(S.faminfo32, (size_t)UVC_NFAMINFO32 * NSYM * S.npos); S.faminfo64.assign((size_t)UVC_NFAMINFO64 * NSYM * S.npos, 0);
     zero32(S.duplex, (size_t)UVC_NDUPLEX * NSYM * S.npos);
     for (int s = 0; s < 2; s++) zero32(S.bucket[s], (size_t)NSYM * NBUCKETS * S.npos);
+    for (int st = 0; st < 2; st++) { S.gap_frag[st].clear(); S.gap_fam[st].clear(); S.gap_c2[st].clear(); S.gap_c2d[st].clear(); }
     build_side_arrays(S);   // rtr.indelphred is mutated by P1b, so rebuild on every accumulate
     int rc;
     if (S.P.inferred_is_vcf_generated) { if ((rc = using_bq(S, err))) return rc; }

@@ -195,6 +195,19 @@ int uvc_oracle_score(void *h, const UvcScoreRequest *req, UvcScoreOut *out) {
     return 0;
 }
 
+int uvc_oracle_region_indel_alleles(void *h, UvcGapRow *rows, int64_t row_capacity, int64_t *n_rows, uint8_t *seq, int64_t seq_capacity, int64_t *seq_bytes) {
+    State &S = *(State *)h;
+    if (!S.accumulated) { g_err = "indel_alleles before accumulate"; return UVCGPU_ESTATE; }
+    std::vector<UvcGapRow> r; std::vector<u8> q;
+    indel_allele_rows(S, r, q);
+    if (n_rows) *n_rows = (i64)r.size();
+    if (seq_bytes) *seq_bytes = (i64)q.size();
+    if ((i64)r.size() > row_capacity || (i64)q.size() > seq_capacity) { g_err = "allele table capacity too small"; return UVCGPU_ENOMEM; }
+    if (!r.empty()) memcpy(rows, r.data(), r.size() * sizeof(UvcGapRow));
+    if (!q.empty()) memcpy(seq, q.data(), q.size());
+    return 0;
+}
+
 void uvc_oracle_destroy(void *h) { delete (State *)h; }
 
 // ---- unit-test hooks for the math primitives (tests/test_oracle_math.py) ----

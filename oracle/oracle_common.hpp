@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 #include <algorithm>
@@ -109,6 +110,15 @@ struct State {
     std::vector<Family> fams;
     std::vector<u8> bases, quals; std::vector<u32> cigars;
     bool accumulated = false;
+    // InDel allele counters beside the depth planes: index I1/D1 = 0, I2/D2 = 1, I3P/D3P = 2 (main.hpp:574-583)
+    struct GapMaps {
+        std::map<i32, std::map<std::string, i32>> iseq[3];
+        std::map<i32, std::map<i32, i32>> dlen[3];
+        void clear() { for (int i = 0; i < 3; i++) { iseq[i].clear(); dlen[i].clear(); } }
+    };
+    // [strand]: symbol_to_frag_format_depth_sets / symbol_to_fam_format_depth_sets_2strand side maps (main.hpp:529-530),
+    // pos2iseq2data_cDP2 / pos2dlen2data_cDP2, pos2iseq2data_c2dDP / pos2dlen2data_c2dDP (main.hpp:2380-2383)
+    GapMaps gap_frag[2], gap_fam[2], gap_c2[2], gap_c2d[2];
 
     // Internal storage is position-major (AoS, like the reference's std::vector<struct> per kind, main.hpp:523-604) so that
     // the per-read scatter touches one or two cache lines per position; fetch() transposes to the plane layout of uvcgpu.h.
@@ -134,6 +144,8 @@ struct State {
 void build_side_arrays(State &S);
 // accumulate passes
 int accumulate(State &S, std::string &err);
+// InDel allele rows (fill_by_indel_info, instcode.hpp) in the order documented at UvcGapRow
+void indel_allele_rows(State &S, std::vector<UvcGapRow> &rows, std::vector<u8> &seq);
 // scoring
 int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &records, std::string &err);
 

@@ -9,6 +9,8 @@
 //   BcfFormat_symbol_calc_qual           main.hpp:4908-5343  (calc_binom_10log10_likeratio main_conversion.hpp:222-237)
 // The T/N rescue branches (tki, IS_PROVIDED(vcf_tumor_fname)) read their tumor records from UvcScoreRequest::tumor_keys.
 #include "oracle_common.hpp"
+#include <array>
+#include <map>
 
 namespace uvco {
 
@@ -73,7 +75,7 @@ struct Fmt {
     i32 dDP1, dDP2;
     i32 DP, AD, bDP, bAD, c2DP, c2AD;
     i32 bMQ, a2BQf, a2BQr, aBQ, aBQQ, bIAQb, bIADb, bIDQb, cIAQf, cIADf, cIDQf, cIAQr, cIADr, cIDQr;
-    i32 bDPa, cDP0a, gapSa_len;
+    i32 bDPa, cDP0a, gapSa_len, gapSa_row;
     // outputs of calc_DPv
     i32 nPF[2], bNMa, bNMb, bNMQ, nNFA[6], nAFA[9], nBCFA[10], FTS, tier2;
     i32 cDP1v, cDP1w, cDP1x, cDP2v, cDP2w, cDP2x;
@@ -685,6 +687,100 @@ static void emit(const Fmt &f, std::vector<i32> &r) {
     r[UVC_O_cMmQ] = f.cMmQ; r[UVC_O_aAaMQ] = f.aAaMQ; r[UVC_O_bMQQ] = f.bMQQ; r[UVC_O_bIAQ] = f.bIAQ; r[UVC_O_cIAQ] = f.cIAQ;
     r[UVC_O_cPCQ1] = f.cPCQ1; r[UVC_O_cPLQ1] = f.cPLQ1; r[UVC_O_cPCQ2] = f.cPCQ2; r[UVC_O_cPLQ2] = f.cPLQ2; r[UVC_O_bTINQ] = f.bTINQ; r[UVC_O_cTINQ] = f.cTINQ;
     r[UVC_O_gVQ1] = f.gVQ1; r[UVC_O_cVQ1] = f.cVQ1; r[UVC_O_dVQinc] = f.dVQinc; r[UVC_O_cVQ2] = f.cVQ2; r[UVC_O_CONTQ] = f.CONTQ;
+    r[UVC_O_gapSa] = f.gapSa_row; r[UVC_O_gapSa_len] = f.gapSa_len;
+}
+
+// ------------------------------------------------------------------------------------------------
+// InDel alleles: fill_by_indel_info (instcode.hpp, main.hpp:5350-5376) and indel_get_majority (main.hpp:5406-5455)
+// ------------------------------------------------------------------------------------------------
+static inline int ins_idx_(int s) { return (UVC_LINK_I1 == s ? 0 : ((UVC_LINK_I2 == s) ? 1 : 2)); }
+static inline int del_idx_(int s) { return (UVC_LINK_D1 == s ? 0 : ((UVC_LINK_D2 == s) ? 1 : 2)); }
+struct GapTuple { i32 fq, bq, c2, c2d; std::string s; };
+static bool gap_tuple_less(const GapTuple &a, const GapTuple &b) {
+    if (a.fq != b.fq) return a.fq < b.fq;
+    if (a.bq != b.bq) return a.bq < b.bq;
+    if (a.c2 != b.c2) return a.c2 < b.c2;
+    if (a.c2d != b.c2d) return a.c2d < b.c2d;
+    return a.s < b.s;
+}
+template <class K> static i32 gap_get(const std::map<i32, std::map<K, i32>> &m, i32 refpos, const K &k) {   // posToIndelToData_get, main.hpp:65-71
+    auto it = m.find(refpos);
+    if (it == m.end()) return 0;
+    auto jt = it->second.find(k);
+    return (jt == it->second.end() ? 0 : jt->second);
+}
+// the tuples one strand pushes into gapSeq / gapbAD1 / gapcAD1 / gc2AD / gc2dAD, in the pushed order (instcode.hpp:44-83);
+// insertion strings are "ACGTN" text, deletion strings the deleted reference characters
+static void gap_tuples(State &S, int strand, i32 refpos, int symbol, std::vector<GapTuple> &out) {
+    out.clear();
+    if (is_ins(symbol)) {
+        const int k = ins_idx_(symbol);
+        auto it = S.gap_frag[strand].iseq[k].find(refpos);
+        if (it == S.gap_frag[strand].iseq[k].end()) return;
+        for (const auto &kv : it->second) {
+            if (kv.first.empty()) continue;
+            GapTuple t = { gap_get(S.gap_fam[strand].iseq[k], refpos, kv.first), kv.second, gap_get(S.gap_c2[strand].iseq[k], refpos, kv.first), gap_get(S.gap_c2d[strand].iseq[k], refpos, kv.first), kv.first };
+            out.push_back(t);
+        }
+    } else {
+        const int k = del_idx_(symbol);
+        auto it = S.gap_frag[strand].dlen[k].find(refpos);
+        if (it == S.gap_frag[strand].dlen[k].end()) return;
+        for (const auto &kv : it->second) {
+            const std::string str = S.refstring.substr((size_t)(refpos - S.beg), (size_t)kv.first);
+            if (str.empty()) continue;
+            GapTuple t = { gap_get(S.gap_fam[strand].dlen[k], refpos, kv.first), kv.second, gap_get(S.gap_c2[strand].dlen[k], refpos, kv.first), gap_get(S.gap_c2d[strand].dlen[k], refpos, kv.first), str };
+            out.push_back(t);
+        }
+    }
+    std::sort(out.rbegin(), out.rend(), gap_tuple_less);
+}
+
+void indel_allele_rows(State &S, std::vector<UvcGapRow> &rows, std::vector<u8> &seq) {
+    rows.clear(); seq.clear();
+    std::map<std::pair<i32, int>, int> keys;   // (refpos, symbol) that have a row on either strand
+    for (int strand = 0; strand < 2; strand++) for (int k = 0; k < 3; k++) {
+        const int isym[3] = { UVC_LINK_I1, UVC_LINK_I2, UVC_LINK_I3P }, dsym[3] = { UVC_LINK_D1, UVC_LINK_D2, UVC_LINK_D3P };
+        for (const auto &pv : S.gap_frag[strand].iseq[k]) keys[std::make_pair(pv.first, isym[k])] = 1;
+        for (const auto &pv : S.gap_frag[strand].dlen[k]) keys[std::make_pair(pv.first, dsym[k])] = 1;
+    }
+    std::vector<GapTuple> t;
+    for (const auto &kv : keys) for (int strand = 0; strand < 2; strand++) {
+        gap_tuples(S, strand, kv.first.first, kv.first.second, t);
+        for (const GapTuple &g : t) {
+            UvcGapRow r; memset(&r, 0, sizeof(r));
+            r.refpos = kv.first.first; r.symbol = kv.first.second; r.strand = strand; r.len = (i32)g.s.size();
+            r.seq_off = -1;
+            if (is_ins(r.symbol)) { r.seq_off = (i64)seq.size(); for (char c : g.s) seq.push_back((u8)(c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4)); }
+            r.bAD1 = g.bq; r.cAD1 = g.fq; r.c2AD = g.c2; r.c2dAD = g.c2d;
+            rows.push_back(r);
+        }
+    }
+}
+
+struct GapAllele { i32 bAD1, cAD1; std::string s; };
+static const char *SYMBOL_DESC[NSYM] = { "A", "C", "G", "T", "N", "*", "<LR>", "<LD3P>", "<LD2>", "<LD1>", "<LI3P>", "<LI2>", "<LI1>", "*" };   // main_conversion.hpp:336-346
+// The alleles the reference scores for one InDel symbol (main.cpp:853-896): strands with FRAG_bDP > 0 contribute their tuples, equal
+// strings are merged, alleles below a quarter of the best fragment support are dropped, the rest is ordered by descending
+// bAD1^2 * length.  The reference's std::sort over reverse iterators leaves ties in ascending string order for the small
+// vectors that occur (insertion sort); that order is taken as the definition here and in the HIP path.
+static void indel_majority(State &S, i32 refpos, int symbol, std::vector<GapAllele> &out) {
+    out.clear();
+    std::map<std::string, std::array<i32, 2>> indelmap;
+    std::vector<GapTuple> t;
+    size_t n_rows = 0;
+    for (int strand = 0; strand < 2; strand++) {
+        if (!(0 < S.FR(strand, UVC_FRAG_bDP, symbol, refpos - S.beg))) continue;
+        gap_tuples(S, strand, refpos, symbol, t);
+        n_rows += t.size();
+        for (const GapTuple &g : t) { auto &v = indelmap[g.s]; v[0] += g.bq; v[1] += g.fq; }
+    }
+    if (0 == n_rows) { GapAllele a = { 0, 0, SYMBOL_DESC[symbol] }; out.push_back(a); return; }   // "Invalid indel detected", main.hpp:5415-5423
+    i32 max_bAD1 = 0;
+    for (const auto &kv : indelmap) max_bAD1 = max_(max_bAD1, kv.second[0]);
+    for (const auto &kv : indelmap) if (kv.second[0] >= (max_bAD1 + 3) / 4) { GapAllele a = { kv.second[0], kv.second[1], kv.first }; out.push_back(a); }
+    std::stable_sort(out.begin(), out.end(), [](const GapAllele &x, const GapAllele &y) {
+        return ((i64)x.bAD1 * x.bAD1 * (i64)x.s.size()) > ((i64)y.bAD1 * y.bAD1 * (i64)y.s.size()); });
 }
 
 // per-position driver, main.cpp:608-1000
@@ -704,6 +800,10 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
     const i32 minABQ_indel = (amplicon ? P.syserr_minABQ_pcr_indel : P.syserr_minABQ_cap_indel);
     const i32 nrtr = (i32)S.rtr.size();
     records.clear();
+    std::vector<UvcGapRow> gap_rows; std::vector<u8> gap_seq;
+    indel_allele_rows(S, gap_rows, gap_seq);
+    std::map<std::pair<i32, int>, size_t> gap_first;   // (refpos, symbol) -> first row
+    for (size_t q = gap_rows.size(); q-- > 0;) gap_first[std::make_pair(gap_rows[q].refpos, gap_rows[q].symbol)] = q;
     for (i32 zpos = pos_beg; zpos < pos_end; zpos++) {
         i32 repeatunit_size = 0, repeatnum = 0;
         indelpos_to_context(repeatunit_size, repeatnum, S.refstring, zpos - ext_beg, P.indel_str_repeatsize_max);
@@ -734,6 +834,7 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
                 // allele list: the tumor records of this (position, symbol) if any (is_var_rescued, main.cpp:806, 864-900), else the
                 // host-supplied InDel alleles, else the single default allele (see UvcIndelAllele)
                 std::vector<UvcIndelAllele> alleles;
+                std::vector<i32> allele_rows;   // parallel to `alleles` when they were derived from the region's own allele tables
                 std::vector<const UvcTumorKey *> akeys;
                 if (tprov) for (i64 q = 0; q < ntk; q++) if (tk[q].refpos == refpos && tk[q].symbol == symbol) {
                     UvcIndelAllele d = { refpos, symbol, bdepth, cdepth, (is_ins(symbol) || is_del(symbol)) ? tk[q].indel_len : 0 };
@@ -742,7 +843,22 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
                 if (!alleles.empty()) {}
                 else if (is_ins(symbol) || is_del(symbol)) {
                     if (req) for (i64 q = 0; q < req->n_indel_alleles; q++) if (req->indel_alleles[q].refpos == refpos && req->indel_alleles[q].symbol == symbol) alleles.push_back(req->indel_alleles[q]);
-                    if (alleles.empty()) { UvcIndelAllele d = { refpos, symbol, bdepth, cdepth, (symbol == UVC_LINK_I1 || symbol == UVC_LINK_D1) ? 1 : ((symbol == UVC_LINK_I2 || symbol == UVC_LINK_D2) ? 2 : 3) }; alleles.push_back(d); }
+                    if (alleles.empty()) {   // fill_by_indel_info + indel_get_majority, main.cpp:853-896
+                        std::vector<GapAllele> ga;
+                        indel_majority(S, refpos, symbol, ga);
+                        for (const GapAllele &g : ga) {
+                            UvcIndelAllele d = { refpos, symbol, g.bAD1, g.cAD1, (i32)g.s.size() };
+                            alleles.push_back(d);
+                            i32 row = -1;
+                            auto gf = gap_first.find(std::make_pair(refpos, symbol));
+                            for (size_t q = (gf == gap_first.end() ? gap_rows.size() : gf->second); q < gap_rows.size() && row < 0 && gap_rows[q].refpos == refpos && gap_rows[q].symbol == symbol; q++) if (gap_rows[q].refpos == refpos && gap_rows[q].symbol == symbol && gap_rows[q].len == (i32)g.s.size()) {
+                                bool same = true;
+                                if (is_ins(symbol)) for (size_t c = 0; c < g.s.size(); c++) if ("ACGTN"[gap_seq[(size_t)gap_rows[q].seq_off + c]] != g.s[c]) same = false;
+                                if (same) row = (i32)q;
+                            }
+                            allele_rows.push_back(row);
+                        }
+                    }
                 } else { UvcIndelAllele d = { refpos, symbol, bdepth, cdepth, 0 }; alleles.push_back(d); }
                 for (size_t ai = 0; ai < alleles.size(); ai++) {
                     const UvcIndelAllele &al = alleles[ai];
@@ -759,6 +875,7 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
                     const bool homopol_2bp = (prev_base2 == refsymbol && next_base2 == refsymbol);
                     const i32 minABQ = (is_subst(symbol) ? (i32)nnminus(minABQ_snv, (homopol_1bp ? (homopol_2bp ? 20 : 10) : 0)) : minABQ_indel);
                     symbol_init(f, S, refpos, symbol, al.bDPa, al.cDP0a, al.indel_len, minABQ);
+                    f.gapSa_row = (ai < allele_rows.size() ? allele_rows[ai] : -1);
                     calc_DPv(f, S.rtr[max_(refpos - ext_beg, 3) - 3], S.rtr[min_(refpos - ext_beg + 3, nrtr - 1)], refsymbol, S, refpos);
                     fmts[st].push_back(f);
                 }

@@ -23,6 +23,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     if bad:
         nbad += 1
         print("seed", seed, "PLANES", {k: (v[0], v[1][:2]) for k, v in bad.items()}, flush=True); continue
+    if o.indel_alleles() != g.indel_alleles(): nbad += 1; print("seed", seed, "ALLELE ROWS differ", flush=True); continue
     try: compare_records(o.score(all_out=True), g.score(all_out=True))
     except AssertionError as e:
         nbad += 1; print("seed", seed, "RECORDS", str(e)[:400], flush=True)

@@ -128,6 +128,7 @@ def test_weird_reads(seed, oracle_lib, gpu_lib):
         return
     bad = diff_groups(o, g)
     assert not bad, "\n".join("%s: %d cells differ, e.g. %s" % (k, v[0], v[1]) for k, v in bad.items())
+    assert o.indel_alleles() == g.indel_alleles()
     ro, rg = o.score(all_out=True), g.score(all_out=True)
     from test_gpu_parity import compare_records
     compare_records(ro, rg)

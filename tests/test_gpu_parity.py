@@ -31,7 +31,7 @@ def test_planes_match_oracle(name, oracle_lib, gpu_lib):
 
 
 # SURVEY section 8(d) tolerance classes for the scoring records
-EXACT_FIELDS = ["refpos", "symbol", "refsymbol", "DP", "AD", "bDP", "bAD", "c2DP", "c2AD", "bDPa", "cDP0a", "tier2", "FTS"]
+EXACT_FIELDS = ["refpos", "symbol", "refsymbol", "DP", "AD", "bDP", "bAD", "c2DP", "c2AD", "bDPa", "cDP0a", "tier2", "FTS", "gapSa", "gapSa_len"]
 PCT_FIELDS = ["cDP1v", "cDP1w", "cDP1x", "cDP2v", "cDP2w", "cDP2x", "CDP1v0", "CDP1v1", "CDP1w0", "CDP1w1", "CDP1x0", "CDP1x1",
               "CDP2v0", "CDP2v1", "CDP2w0", "CDP2w1", "CDP2x0", "CDP2x1"]
 

@@ -52,6 +52,11 @@ class UvcTumorKey(C.Structure):
                 ("tier2", C.c_int32), ("indel_len", C.c_int32)]
 
 
+class UvcGapRow(C.Structure):
+    _fields_ = [("refpos", C.c_int32), ("symbol", C.c_int32), ("strand", C.c_int32), ("len", C.c_int32), ("seq_off", C.c_int64),
+                ("bAD1", C.c_int32), ("cAD1", C.c_int32), ("c2AD", C.c_int32), ("c2dAD", C.c_int32)]
+
+
 class UvcScoreRequest(C.Structure):
     _fields_ = [("pos_beg", C.c_int32), ("pos_end", C.c_int32), ("all_out", C.c_int32), ("is_amplicon", C.c_int32),
                 ("n_indel_alleles", C.c_int64), ("indel_alleles", C.c_void_p), ("n_tumor_keys", C.c_int64), ("tumor_keys", C.c_void_p)]

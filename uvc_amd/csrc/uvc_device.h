@@ -32,6 +32,7 @@ struct AlnRec {
     int64_t cigar_off;
     int64_t table_off;          // complex: first row of the contribution table (row = p - pos), else -1
     int64_t item_off;           // complex: first slot of the P2 item list, else -1
+    int64_t gap_off;            // complex: first slot of its InDel events (one per I / D op, in CIGAR order), else -1
     int32_t n_cigar, kind;      // kind: 0 simple, 1 complex
     int32_t xm1500, go1500;
     int32_t bm1500[5];          // per base symbol (main.hpp:1860-1863); LINK/NN symbols are always 0
@@ -97,6 +98,25 @@ struct FragFast {
     int32_t bpos1, brend1, bqb1, sp1;
 };
 
+// One I / D op of an alignment as the BASE_QUALITY_MAX walk sees it (incIns / incDel, main.hpp:2101-2113, 2216): the allele-keyed
+// counters of the reference (pos2iseq2data / pos2dlen2data) are rebuilt from these by k_gap_alleles.
+struct AlnGap {
+    int32_t epos, sym;          // sym < 0: gated by the primer window or closer than indel_filter_edge_dist to a read end
+    int32_t len, qpos;          // op length; query offset of the first inserted base
+    int32_t weight, aln;        // max(1, incvalue2) resp. max(1, incvalue); owning alignment
+    int32_t mark, pad_;         // scratch of k_gap_alleles
+};
+// allele-level increment: key = (epos - beg) << 38 | (sym - LINK_D3P) << 35 | allele code; val = representative event << 8 | strand * 4 + level
+struct GapRow { int32_t x, sym, len, ev; int64_t seq_off; int32_t cnt[8]; };   // cnt[strand * 4 + level], level: 0 fragments, 1 families, 2 cDP2, 3 c2dDP
+struct GapWork {
+    AlnGap *ev; int32_t n_ev;
+    unsigned long long *ckey, *ckey_s, *cval, *cval_s;       // candidate sort: (family, position) -> event
+    unsigned long long *ikey, *ikey_s, *ival, *ival_s;       // allele increments and their sorted copies
+    int32_t inc_cap; int32_t *n_inc;
+    GapRow *rows; int32_t *n_rows; uint8_t *seq; unsigned long long *seq_len; int64_t seq_cap;
+    void *sort_tmp; size_t sort_tmp_bytes;
+};
+
 // contribution of one alignment at one reference position under BASE_QUALITY_MAX (main.hpp:1980, 1924, 2077, 2192, 2223)
 struct Contrib { uint8_t bsym, bval, l1sym, l1val, l2sym, l2val, l3sym, l3val; };   // sym == 0xFF: empty slot
 
@@ -137,6 +157,7 @@ struct RegionDev {
     unsigned long long *mis_total;  // number of read bases of simple alignments that differ from the reference (k_aln_prelude)
     int32_t max_aln_span, max_frag_span;
     int32_t *err;                   // device error flag (unsupported CIGAR shapes etc.)
+    GapWork gap;                    // InDel allele tables
 };
 
 #define DEV __device__ __forceinline__

@@ -13,7 +13,7 @@
 
 struct RawReads {
     const int32_t *pos, *endpos, *mpos, *isize, *flag, *mapq, *nm, *l_qseq, *n_cigar, *frag, *fs, *dflag, *kind, *fast_rank;
-    const int64_t *seq_off, *cigar_off, *table_off, *item_off;
+    const int64_t *seq_off, *cigar_off, *table_off, *item_off, *gap_off;
 };
 extern "C" void uvc_launch_correct_bq(const RegionDev *R, int bq_max, int bq_inc, hipStream_t s);
 extern "C" void uvc_launch_pack_bq(const uint8_t *bases, const uint8_t *quals, uint16_t *bq, int64_t n, hipStream_t s);
@@ -23,9 +23,10 @@ struct UvcProf { int on; int n; const char *name[24]; hipEvent_t ev[24][2]; };
 extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, int half_ratio_phred,
                                       const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof,
                                       hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join, hipEvent_t e_fork2);
-extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles, const UvcTumorKey *d_tkeys,
-                                int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch, hipStream_t s);
+extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles, const int32_t *d_allele_rows, int64_t n_alleles,
+                                const UvcTumorKey *d_tkeys, int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch, hipStream_t s);
 extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored);
+extern "C" size_t uvc_gap_sort_tmp_bytes(size_t n);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -55,6 +56,11 @@ struct uvcgpu_region {
     // persistent scoring buffers (grown on demand)
     long long *d_score_scratch = nullptr; size_t score_scratch_bytes = 0;
     int32_t *d_score_fields = nullptr; int64_t score_capacity = 0; int64_t *d_score_count = nullptr;
+    // InDel allele tables of the last accumulate (built on first use by gap_tables)
+    bool gap_ready = false;
+    std::vector<UvcGapRow> gap_rows; std::vector<uint8_t> gap_seq;
+    std::vector<UvcIndelAllele> gap_alleles; std::vector<int32_t> gap_allele_row;   // what indel_get_majority yields, sorted by (refpos, symbol)
+    UvcIndelAllele *d_gap_alleles = nullptr; int32_t *d_gap_allele_row = nullptr; int64_t gap_alleles_cap = 0;
 };
 
 static size_t group_bytes(const uvcgpu_region *r, int g) {
@@ -282,8 +288,8 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     if (n == 0) return 0;
     if (n > INT32_MAX / 2) return fail(UVCGPU_EUNSUPPORTED, "more than 2^30 reads in one region");
     std::vector<int32_t> endpos(n), frag_of(n), fs_of(n), dflag_of(n), kind(n), fast_rank(n, -1);
-    std::vector<int64_t> table_off(n, -1), item_off(n, -1);
-    int64_t item_slots = 0;
+    std::vector<int64_t> table_off(n, -1), item_off(n, -1), gap_off(n, -1);
+    int64_t item_slots = 0, gap_slots = 0, ins_total = 0;
     std::vector<FragRec> frags; std::vector<FsRec> fss;
     std::vector<int32_t> fam_fs((size_t)in->n_fams * 2, -1);
     int prev_fam = -1, prev_strand = -1, prev_frag = -1;
@@ -361,6 +367,8 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
             table_off[i] = table_rows; table_rows += (e - in->pos[i]) + 1;   // + the row of an insertion right behind the last aligned base (rpos == bam_endpos)
             int64_t del_total = 0; for (int k = 0; k < nc; k++) if ((cg[k] & 0xF) == C_DEL) del_total += (cg[k] >> 4);
             item_off[i] = item_slots; item_slots += 2 * (int64_t)lq + 2 * del_total + nc + 4;   // upper bound of P2 updates of this read
+            gap_off[i] = gap_slots;   // one InDel event per I / D op
+            for (int k = 0; k < nc; k++) { const int op = (int)(cg[k] & 0xF); if (op == C_INS || op == C_DEL) gap_slots++; if (op == C_INS) ins_total += (cg[k] >> 4); }
         }
         else max_aln_span = std::max(max_aln_span, e - in->pos[i]);
         prev_fam = fam; prev_strand = strand; prev_frag = in->frag_id[i];
@@ -421,7 +429,7 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
         || (rc = up32(flag32.data(), &W.flag)) || (rc = up32(mapq32.data(), &W.mapq)) || (rc = up32(in->nm, &W.nm)) || (rc = up32(in->l_qseq, &W.l_qseq))
         || (rc = up32(in->n_cigar, &W.n_cigar)) || (rc = up32(frag_of.data(), &W.frag)) || (rc = up32(fs_of.data(), &W.fs)) || (rc = up32(dflag_of.data(), &W.dflag))
         || (rc = up32(kind.data(), &W.kind)) || (rc = up32(fast_rank.data(), &W.fast_rank))
-        || (rc = up64(in->seq_off, &W.seq_off)) || (rc = up64(in->cigar_off, &W.cigar_off)) || (rc = up64(table_off.data(), &W.table_off)) || (rc = up64(item_off.data(), &W.item_off))) return rc;
+        || (rc = up64(in->seq_off, &W.seq_off)) || (rc = up64(in->cigar_off, &W.cigar_off)) || (rc = up64(table_off.data(), &W.table_off)) || (rc = up64(item_off.data(), &W.item_off)) || (rc = up64(gap_off.data(), &W.gap_off))) return rc;
     { uint8_t *d; if ((rc = upload_raw(r, in->bases, (size_t)in->n_bases, &d))) return rc; R.bases = d; }
     { uint8_t *d; if ((rc = upload_raw(r, in->quals, (size_t)in->n_bases, &d))) return rc; R.quals = d; }
     { if (in->n_bases >= ((int64_t)1 << 31)) return fail(UVCGPU_EUNSUPPORTED, "more than 2^31 read bases in one region: split the region");
@@ -456,6 +464,19 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
       if (hipMalloc((void **)&d, bytes) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(table)"); r->owned.push_back(d); R.table = d; r->state_bytes += 0; (void)v; }
     { Item *d = nullptr; if (hipMalloc((void **)&d, std::max<int64_t>(item_slots, 1) * sizeof(Item)) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(items)"); r->owned.push_back(d); R.items = d;
       std::vector<int32_t> z(complex_ids.size() + 1, 0); int32_t *c; if ((rc = upload(r, z, &c))) return rc; R.item_cnt = c; }
+    {   // InDel allele pipeline (k_gap_*): events, two sort stages, rows
+        if (gap_slots >= ((int64_t)1 << 27)) return fail(UVCGPU_EUNSUPPORTED, "more than 2^27 InDel ops in one region");
+        GapWork &G = R.gap; memset(&G, 0, sizeof(G));
+        G.n_ev = (int32_t)gap_slots; G.inc_cap = (int32_t)(7 * gap_slots + 8); G.seq_cap = ins_total + 8;
+        const size_t ne = (size_t)std::max<int64_t>(gap_slots, 1), ni = (size_t)G.inc_cap;
+        unsigned long long *k8; int32_t *c4;
+        if ((rc = dev_alloc(r, ne, &G.ev)) || (rc = dev_alloc(r, 4 * ne + 4 * ni, &k8)) || (rc = dev_alloc(r, (size_t)4, &c4, true)) || (rc = dev_alloc(r, ne, &G.rows)) || (rc = dev_alloc(r, (size_t)G.seq_cap, &G.seq))) return rc;
+        G.ckey = k8; G.ckey_s = k8 + ne; G.cval = k8 + 2 * ne; G.cval_s = k8 + 3 * ne;
+        G.ikey = k8 + 4 * ne; G.ikey_s = G.ikey + ni; G.ival = G.ikey + 2 * ni; G.ival_s = G.ikey + 3 * ni;
+        G.n_inc = c4; G.n_rows = c4 + 1; G.seq_len = (unsigned long long *)(c4 + 2);
+        G.sort_tmp_bytes = uvc_gap_sort_tmp_bytes(std::max(ne, ni));
+        uint8_t *tmp; if ((rc = dev_alloc(r, G.sort_tmp_bytes + 16, &tmp))) return rc; G.sort_tmp = tmp;
+    }
     { std::vector<int32_t> z(4, 0); int32_t *c; if ((rc = upload(r, z, &c))) return rc; R.mis_cnt = c; R.mis_total = (unsigned long long *)(c + 2); R.mis = nullptr; R.mis_cap = 0; }
     { if ((rc = upload(r, dup_units, &r->d_dup_units)) || (rc = upload(r, dup_off, &r->d_dup_off))) return rc; r->n_dup = (int)dup_units.size(); r->n_dup_work = dup_work; }
     R.max_aln_span = max_aln_span; R.max_frag_span = max_frag_span;
@@ -543,7 +564,7 @@ int uvcgpu_region_accumulate(uvcgpu_region_t *r) {
     uvc_launch_accumulate(&r->R, &r->P, half, r->d_dup_units, r->n_dup, r->d_dup_off, r->n_dup_work, r->stream, &r->prof, r->side, r->e_fork, r->e_join, r->e_fork2);
     HIP_OK(hipGetLastError());
     r->buckets_clean = (r->P.inferred_is_vcf_generated != 0);   // k_frag (P3b) and k_p5b cleared every bucket they consumed
-    r->accumulated = true;
+    r->accumulated = true; r->gap_ready = false;
     return 0;
 }
 
@@ -590,10 +611,117 @@ int uvcgpu_region_fetch(uvcgpu_region_t *r, int32_t g, void *dst, int64_t dst_by
     return 0;
 }
 
+// ---- InDel allele tables: the host half of fill_by_indel_info / indel_get_majority (instcode.hpp, main.hpp:5350-5455) ----
+// The device reduces the allele-keyed counters to one GapRow per (position, symbol, allele) (k_gap_rows); what is left is per InDel
+// site: splitting by strand, the reference's two sorts, and the quarter-of-the-best filter.
+namespace {
+struct GapAl { int32_t len; const uint8_t *seq; bool del; };   // allele text: inserted bases (codes 0..4) or a deleted length
+inline int text_rank(int b) { return b == 4 ? 3 : (b == 3 ? 4 : b); }   // "ACGTN": A < C < G < N < T
+int gap_al_cmp(const GapAl &a, const GapAl &b) {   // std::string order of the reference's keys
+    if (a.del) return (a.len > b.len) - (a.len < b.len);   // prefixes of the same reference text
+    const int n = std::min(a.len, b.len);
+    for (int i = 0; i < n; i++) { const int ra = text_rank(a.seq[i]), rb = text_rank(b.seq[i]); if (ra != rb) return ra < rb ? -1 : 1; }
+    return (a.len > b.len) - (a.len < b.len);
+}
+}
+static int gap_tables(uvcgpu_region_t *r) {
+    if (r->gap_ready) return 0;
+    int rc = uvcgpu_region_sync(r);
+    if (rc) return rc;
+    r->gap_rows.clear(); r->gap_seq.clear(); r->gap_alleles.clear(); r->gap_allele_row.clear();
+    const GapWork &G = r->R.gap;
+    int32_t cnt[4] = { 0, 0, 0, 0 };
+    if (G.n_inc) HIP_OK(hipMemcpy(cnt, G.n_inc, 16, hipMemcpyDeviceToHost));
+    const int32_t n_rows = cnt[1];
+    unsigned long long seq_len = 0; memcpy(&seq_len, &cnt[2], 8);
+    std::vector<GapRow> dev((size_t)n_rows);
+    std::vector<uint8_t> dseq((size_t)seq_len);
+    if (n_rows) HIP_OK(hipMemcpy(dev.data(), G.rows, sizeof(GapRow) * (size_t)n_rows, hipMemcpyDeviceToHost));
+    if (seq_len) HIP_OK(hipMemcpy(dseq.data(), G.seq, (size_t)seq_len, hipMemcpyDeviceToHost));
+    auto al_of = [&](const GapRow &g) { GapAl a; a.len = g.len; a.del = (g.seq_off < 0); a.seq = (a.del ? nullptr : dseq.data() + g.seq_off); return a; };
+    std::sort(dev.begin(), dev.end(), [&](const GapRow &a, const GapRow &b) {
+        if (a.x != b.x) return a.x < b.x;
+        if (a.sym != b.sym) return a.sym < b.sym;
+        return gap_al_cmp(al_of(a), al_of(b)) < 0; });   // ascending allele text: the iteration order of the reference's maps
+    struct Tup { int32_t fq, bq, c2, c2d; const GapRow *g; };
+    for (size_t g0 = 0; g0 < dev.size();) {
+        size_t g1 = g0;
+        while (g1 < dev.size() && dev[g1].x == dev[g0].x && dev[g1].sym == dev[g0].sym) g1++;
+        const int32_t refpos = r->beg + dev[g0].x, symbol = dev[g0].sym;
+        const size_t first_row = r->gap_rows.size();
+        std::vector<const GapRow *> row_allele;   // parallel to the rows pushed for this site
+        for (int strand = 0; strand < 2; strand++) {   // fill_by_indel_info2_{1,2}: the strand's tuples, sorted descending (instcode.hpp:44-62)
+            std::vector<Tup> t;
+            for (size_t g = g0; g < g1; g++) if (dev[g].cnt[strand * 4] > 0) t.push_back(Tup{ dev[g].cnt[strand * 4 + 1], dev[g].cnt[strand * 4], dev[g].cnt[strand * 4 + 2], dev[g].cnt[strand * 4 + 3], &dev[g] });
+            std::sort(t.begin(), t.end(), [&](const Tup &a, const Tup &b) {
+                if (a.fq != b.fq) return a.fq > b.fq;
+                if (a.bq != b.bq) return a.bq > b.bq;
+                if (a.c2 != b.c2) return a.c2 > b.c2;
+                if (a.c2d != b.c2d) return a.c2d > b.c2d;
+                return gap_al_cmp(al_of(*a.g), al_of(*b.g)) > 0; });
+            for (const Tup &u : t) {
+                UvcGapRow o; memset(&o, 0, sizeof(o));
+                o.refpos = refpos; o.symbol = symbol; o.strand = strand; o.len = u.g->len; o.seq_off = -1;
+                if (u.g->seq_off >= 0) { o.seq_off = (int64_t)r->gap_seq.size(); r->gap_seq.insert(r->gap_seq.end(), dseq.begin() + u.g->seq_off, dseq.begin() + u.g->seq_off + u.g->len); }
+                o.bAD1 = u.bq; o.cAD1 = u.fq; o.c2AD = u.c2; o.c2dAD = u.c2d;
+                r->gap_rows.push_back(o); row_allele.push_back(u.g);
+            }
+        }
+        // indel_get_majority (main.hpp:5406-5455): merge the strands per allele, keep those with at least a quarter of the best fragment
+        // support, order by descending bAD1^2 * length (ties: ascending text, see oracle/oracle_score.cpp)
+        struct Maj { int32_t b, c; const GapRow *g; };
+        std::vector<Maj> m;
+        int32_t max_b = 0;
+        for (size_t g = g0; g < g1; g++) {
+            Maj a = { 0, 0, &dev[g] };
+            for (int strand = 0; strand < 2; strand++) if (dev[g].cnt[strand * 4] > 0) { a.b += dev[g].cnt[strand * 4]; a.c += dev[g].cnt[strand * 4 + 1]; }
+            if (a.b > 0) { m.push_back(a); max_b = std::max(max_b, a.b); }
+        }
+        std::vector<Maj> kept;
+        for (const Maj &a : m) if (a.b >= (max_b + 3) / 4) kept.push_back(a);
+        std::stable_sort(kept.begin(), kept.end(), [](const Maj &a, const Maj &b) { return (int64_t)a.b * a.b * (int64_t)a.g->len > (int64_t)b.b * b.b * (int64_t)b.g->len; });
+        for (const Maj &a : kept) {
+            r->gap_alleles.push_back(UvcIndelAllele{ refpos, symbol, a.b, a.c, a.g->len });
+            int32_t row = -1;
+            for (size_t q = 0; q < row_allele.size() && row < 0; q++) if (row_allele[q] == a.g) row = (int32_t)(first_row + q);
+            r->gap_allele_row.push_back(row);
+        }
+        g0 = g1;
+    }
+    const int64_t na = (int64_t)r->gap_alleles.size();
+    if (na > r->gap_alleles_cap) {
+        if (r->d_gap_alleles) hipFree(r->d_gap_alleles);
+        if (r->d_gap_allele_row) hipFree(r->d_gap_allele_row);
+        r->d_gap_alleles = nullptr; r->d_gap_allele_row = nullptr; r->gap_alleles_cap = 0;
+        HIP_OK(hipMalloc((void **)&r->d_gap_alleles, sizeof(UvcIndelAllele) * (size_t)(na + 64)));
+        HIP_OK(hipMalloc((void **)&r->d_gap_allele_row, sizeof(int32_t) * (size_t)(na + 64)));
+        r->gap_alleles_cap = na + 64;
+    }
+    if (na) {
+        HIP_OK(hipMemcpy(r->d_gap_alleles, r->gap_alleles.data(), sizeof(UvcIndelAllele) * (size_t)na, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(r->d_gap_allele_row, r->gap_allele_row.data(), sizeof(int32_t) * (size_t)na, hipMemcpyHostToDevice));
+    }
+    r->gap_ready = true;
+    return 0;
+}
+
+int uvcgpu_region_indel_alleles(uvcgpu_region_t *r, UvcGapRow *rows, int64_t row_capacity, int64_t *n_rows, uint8_t *seq, int64_t seq_capacity, int64_t *seq_bytes) {
+    if (!r) return fail(UVCGPU_EINVAL, "null region");
+    if (!r->accumulated) return fail(UVCGPU_ESTATE, "indel_alleles before accumulate");
+    int rc = gap_tables(r);
+    if (rc) return rc;
+    if (n_rows) *n_rows = (int64_t)r->gap_rows.size();
+    if (seq_bytes) *seq_bytes = (int64_t)r->gap_seq.size();
+    if ((int64_t)r->gap_rows.size() > row_capacity || (int64_t)r->gap_seq.size() > seq_capacity) return fail(UVCGPU_ENOMEM, "allele table capacity too small");
+    if (!r->gap_rows.empty()) memcpy(rows, r->gap_rows.data(), r->gap_rows.size() * sizeof(UvcGapRow));
+    if (!r->gap_seq.empty()) memcpy(seq, r->gap_seq.data(), r->gap_seq.size());
+    return 0;
+}
+
 int64_t uvcgpu_region_score_size(const uvcgpu_region_t *r, const UvcScoreRequest *req) {
     if (!r) return -1;
     const int64_t np = (req && req->pos_beg >= 0) ? (req->pos_end - req->pos_beg) : r->npos;
-    return NSYM * (np + 1) + (req ? req->n_indel_alleles + req->n_tumor_keys : 0);
+    return NSYM * (np + 1) + (req ? req->n_indel_alleles + req->n_tumor_keys : 0) + (int64_t)r->gap_alleles.size();
 }
 
 int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScoreOut *out) {
@@ -603,16 +731,34 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
     if (req) rq = *req;
     if (rq.pos_beg < 0) { rq.pos_beg = r->beg + 1; rq.pos_end = r->end - 1; }
     if (rq.pos_beg <= r->beg || rq.pos_end > r->end - 1 || rq.pos_end < rq.pos_beg) return fail(UVCGPU_EINVAL, "score range outside the region core");
-    UvcIndelAllele *d_al = nullptr;
+    // InDel alleles: the region's own tables (fill_by_indel_info / indel_get_majority); a (refpos, symbol) the caller lists is overridden
+    { int rc0 = gap_tables(r); if (rc0) return rc0; }
+    UvcIndelAllele *d_al = nullptr; int32_t *d_al_row = nullptr;
+    const UvcIndelAllele *use_al = r->d_gap_alleles; const int32_t *use_row = r->d_gap_allele_row; int64_t n_al = (int64_t)r->gap_alleles.size();
+    std::vector<UvcIndelAllele> merged; std::vector<int32_t> merged_row;
     if (rq.n_indel_alleles > 0) {
-        HIP_OK(hipMalloc((void **)&d_al, sizeof(UvcIndelAllele) * rq.n_indel_alleles));
-        HIP_OK(hipMemcpyAsync(d_al, rq.indel_alleles, sizeof(UvcIndelAllele) * rq.n_indel_alleles, hipMemcpyHostToDevice, r->stream));
+        auto less = [](const UvcIndelAllele &a, const UvcIndelAllele &b) { return a.refpos < b.refpos || (a.refpos == b.refpos && a.symbol < b.symbol); };
+        for (int64_t q = 1; q < rq.n_indel_alleles; q++) if (less(rq.indel_alleles[q], rq.indel_alleles[q - 1])) return fail(UVCGPU_EINVAL, "indel_alleles must be sorted by (refpos, symbol)");
+        size_t i = 0; int64_t j = 0;
+        while (i < r->gap_alleles.size() || j < rq.n_indel_alleles) {
+            const bool take_own = (j >= rq.n_indel_alleles) || (i < r->gap_alleles.size() && less(r->gap_alleles[i], rq.indel_alleles[j]));
+            if (take_own) { merged.push_back(r->gap_alleles[i]); merged_row.push_back(r->gap_allele_row[i]); i++; continue; }
+            const UvcIndelAllele key = rq.indel_alleles[j];
+            while (i < r->gap_alleles.size() && !less(key, r->gap_alleles[i])) i++;   // drop the library's alleles of this (refpos, symbol)
+            while (j < rq.n_indel_alleles && !less(key, rq.indel_alleles[j])) { merged.push_back(rq.indel_alleles[j]); merged_row.push_back(-1); j++; }
+        }
+        n_al = (int64_t)merged.size();
+        HIP_OK(hipMalloc((void **)&d_al, sizeof(UvcIndelAllele) * (size_t)n_al));
+        if (hipMalloc((void **)&d_al_row, sizeof(int32_t) * (size_t)n_al) != hipSuccess) { hipFree(d_al); return fail(UVCGPU_ENOMEM, "hipMalloc(alleles)"); }
+        HIP_OK(hipMemcpyAsync(d_al, merged.data(), sizeof(UvcIndelAllele) * (size_t)n_al, hipMemcpyHostToDevice, r->stream));
+        HIP_OK(hipMemcpyAsync(d_al_row, merged_row.data(), sizeof(int32_t) * (size_t)n_al, hipMemcpyHostToDevice, r->stream));
+        use_al = d_al; use_row = d_al_row;
     }
     UvcTumorKey *d_tk = nullptr;
     if (r->P.tumor_vcf_is_provided && rq.n_tumor_keys > 0) {   // normal sample of a T/N pair: the tumor records, sorted by (refpos, symbol)
         for (int64_t q = 1; q < rq.n_tumor_keys; q++) {
             const UvcTumorKey &a = rq.tumor_keys[q - 1], &b = rq.tumor_keys[q];
-            if (a.refpos > b.refpos || (a.refpos == b.refpos && a.symbol > b.symbol)) { if (d_al) hipFree(d_al); return fail(UVCGPU_EINVAL, "tumor_keys must be sorted by (refpos, symbol)"); }
+            if (a.refpos > b.refpos || (a.refpos == b.refpos && a.symbol > b.symbol)) { if (d_al) hipFree(d_al); if (d_al_row) hipFree(d_al_row); return fail(UVCGPU_EINVAL, "tumor_keys must be sorted by (refpos, symbol)"); }
         }
         HIP_OK(hipMalloc((void **)&d_tk, sizeof(UvcTumorKey) * rq.n_tumor_keys));
         HIP_OK(hipMemcpyAsync(d_tk, rq.tumor_keys, sizeof(UvcTumorKey) * rq.n_tumor_keys, hipMemcpyHostToDevice, r->stream));
@@ -633,7 +779,7 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
         r->score_scratch_bytes = need;
     }
     HIP_OK(hipMemsetAsync(r->d_score_count, 0, 8, r->stream));
-    int rc = uvc_launch_score(&r->R, &r->P, &rq, d_al, d_tk, r->d_score_fields, r->score_capacity, r->d_score_count, r->d_score_scratch, r->stream);
+    int rc = uvc_launch_score(&r->R, &r->P, &rq, use_al, use_row, n_al, d_tk, r->d_score_fields, r->score_capacity, r->d_score_count, r->d_score_scratch, r->stream);
     if (!rc && hipGetLastError() != hipSuccess) rc = fail(UVCGPU_EDEVICE, "score kernel launch failed");
     if (!rc) rc = uvcgpu_region_sync(r);
     int64_t cnt = 0;
@@ -647,6 +793,7 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
             rc = fail(UVCGPU_EDEVICE, "hipMemcpy2D(records)");
     }
     if (d_al) hipFree(d_al);
+    if (d_al_row) hipFree(d_al_row);
     if (d_tk) hipFree(d_tk);
     return rc;
 }
@@ -668,6 +815,8 @@ void uvcgpu_region_destroy(uvcgpu_region_t *r) {
     if (r->d_score_scratch) hipFree(r->d_score_scratch);
     if (r->d_score_fields) hipFree(r->d_score_fields);
     if (r->d_score_count) hipFree(r->d_score_count);
+    if (r->d_gap_alleles) hipFree(r->d_gap_alleles);
+    if (r->d_gap_allele_row) hipFree(r->d_gap_allele_row);
     if (r->stream) hipStreamDestroy(r->stream);
     delete r;
 }

@@ -328,7 +328,7 @@ DEV void primer_window(const UvcParams &P, const AlnRec &a, int &ibeg, int &iend
 // ------------------------------------------------------------------------------------------------
 struct RawReads {
     const int32_t *pos, *endpos, *mpos, *isize, *flag, *mapq, *nm, *l_qseq, *n_cigar, *frag, *fs, *dflag, *kind, *fast_rank;
-    const int64_t *seq_off, *cigar_off, *table_off, *item_off;
+    const int64_t *seq_off, *cigar_off, *table_off, *item_off, *gap_off;
 };
 
 // does the read have an InDel next to low base qualities (main.hpp:1817-1859)?  Then dist_to_interfering_indel varies along the
@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(256) k_aln_prelude(RegionDev R, RawReads W, Uv
     if (id >= R.n_alns) return;
     AlnRec a;
     a.pos = W.pos[id]; a.rend = W.endpos[id]; a.mpos = W.mpos[id]; a.isize = W.isize[id]; a.flag = W.flag[id]; a.mapq = W.mapq[id];
-    a.dflag = W.dflag[id]; a.l_qseq = W.l_qseq[id]; a.seq_off = W.seq_off[id]; a.cigar_off = W.cigar_off[id]; a.table_off = W.table_off[id]; a.item_off = W.item_off[id];
+    a.dflag = W.dflag[id]; a.l_qseq = W.l_qseq[id]; a.seq_off = W.seq_off[id]; a.cigar_off = W.cigar_off[id]; a.table_off = W.table_off[id]; a.item_off = W.item_off[id]; a.gap_off = W.gap_off[id];
     a.n_cigar = W.n_cigar[id]; a.kind = W.kind[id]; a.frag = W.frag[id]; a.fs = W.fs[id]; a.id = id;
     const uint32_t *cigar = R.cigars + a.cigar_off;
     const uint8_t *bases = R.bases + a.seq_off;
@@ -1063,6 +1063,11 @@ __global__ void __launch_bounds__(64) k_p2_slow(RegionDev R, UvcParams P) {
     const int atd = P.indel_adj_tracklen_dist, nrtr = (int)R.npos;
     const int xm1500 = a.xm1500;
     int qpos = 0, rpos = a.pos, incvalue = 1;
+    int gi = 0;   // ordinal of the I / D op: slot of its AlnGap event
+    auto gap_event = [&](int sym, int len, int weight) {
+        AlnGap g; g.epos = rpos; g.sym = sym; g.len = len; g.qpos = qpos; g.weight = weight; g.aln = a.id; g.mark = 0; g.pad_ = 0;
+        R.gap.ev[a.gap_off + gi] = g;
+    };
     for (int i = 0; i < n_cigar; i++) {
         const int op = cig_op(cigar[i]), len = cig_len(cigar[i]);
         if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) {
@@ -1102,6 +1107,7 @@ __global__ void __launch_bounds__(64) k_p2_slow(RegionDev R, UvcParams P) {
                 rpos += 1; qpos += 1;
             }
         } else if (op == C_INS) {
+            bool gapped = false;
             if ((normal_filter_primers || !is_assay_amplicon) || (ibeg <= rpos && rpos < iend)) {
                 const int nbases2end = imin(qpos, a.l_qseq - (qpos + len));
                 int inslen = len;
@@ -1137,10 +1143,17 @@ __global__ void __launch_bounds__(64) k_p2_slow(RegionDev R, UvcParams P) {
                 if (nbases2end >= P.indel_filter_edge_dist) {
                     const int symbol = (1 == inslen ? UVC_LINK_I1 : ((2 == inslen) ? UVC_LINK_I2 : UVC_LINK_I3P));
                     emit(true, rpos, symbol, imax(1, incvalue), 0, op, len, 10000);
+                    if (!BIAS) {   // incIns, main.hpp:2101-2113
+                        int incvalue2 = incvalue;
+                        for (int i2 = 0; i2 < len; i2++) incvalue2 = imin(incvalue2, Q(qpos + i2) + addInd);
+                        gap_event(symbol, len, imax(1, incvalue2)); gapped = true;
+                    }
                 }
             }
+            if (!BIAS) { if (!gapped) gap_event(-1, len, 0); gi++; }
             qpos += len;
         } else if (op == C_DEL) {
+            bool gapped = false;
             if ((normal_filter_primers || !is_assay_amplicon) || (ibeg <= rpos && rpos < iend)) {
                 const int nbases2end = imin(qpos, a.l_qseq - qpos);
                 int dellen = len;
@@ -1184,6 +1197,7 @@ __global__ void __launch_bounds__(64) k_p2_slow(RegionDev R, UvcParams P) {
                 if (nbases2end >= P.indel_filter_edge_dist) {
                     const int symbol = (1 == dellen ? UVC_LINK_D1 : ((2 == dellen) ? UVC_LINK_D2 : UVC_LINK_D3P));
                     emit(true, rpos, symbol, imax(1, incvalue), 0, op, len, 10000);
+                    if (!BIAS) { gap_event(symbol, len, imax(1, incvalue)); gapped = true; }   // incDel, main.hpp:2216
                     for (int r2 = rpos; r2 < imin(rpos + len, rend); r2++) {   // padded deletion, main.hpp:2219-2253
                         for (int k = 0; k < 2; k++) {
                             const int s = (k == 0 ? UVC_BASE_NN : UVC_LINK_NN);
@@ -1201,6 +1215,7 @@ __global__ void __launch_bounds__(64) k_p2_slow(RegionDev R, UvcParams P) {
                     }
                 }
             }
+            if (!BIAS) { if (!gapped) gap_event(-1, len, 0); gi++; }
             rpos += len;
         } else {
             if (op == C_REF_SKIP) rpos += len; else if (op == C_SOFT_CLIP) qpos += len;
@@ -2196,6 +2211,194 @@ __global__ void __launch_bounds__(256) k_p5b(RegionDev R, UvcParams P) {
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// InDel allele tables.  The reference keeps, beside FRAG_bDP / FAM_cDP12.. / FAM_cDP2 / FAM_cDPD + DUPLEX_dDP2, maps
+// position -> inserted sequence (or deleted length) -> count (main.hpp:2710-2717, 3327-3336, 3196-3206, 3458-3469, 3535-3546), and
+// scoring splits every InDel symbol into its alleles with them (fill_by_indel_info / indel_get_majority, main.hpp:5350-5455).
+// Here: k_p2_slow<false> leaves one AlnGap event per I / D op; the events are sorted by (family, position); k_gap_alleles takes
+// one (family, position) per thread, redoes the fragment / family / duplex consensus of the LINK symbol type at that position
+// and emits one increment per map update; the increments are sorted by (position, symbol, allele) and k_gap_rows sums the runs.
+// ------------------------------------------------------------------------------------------------
+DEV int base_text_rank(int b) { return b == UVC_BASE_N ? 3 : (b == UVC_BASE_T ? 4 : b); }   // order of the characters "ACGTN": A < C < G < N < T
+// order of two alleles of the same symbol: std::string resp. integer key order of the reference's maps
+DEV int gap_cmp(const RegionDev &R, const AlnGap &a, const AlnGap &b) {
+    if (is_del(a.sym)) return (a.len > b.len) - (a.len < b.len);
+    const uint8_t *sa = R.bases + R.alns[a.aln].seq_off + a.qpos, *sb = R.bases + R.alns[b.aln].seq_off + b.qpos;
+    const int n = imin(a.len, b.len);
+    for (int i = 0; i < n; i++) { const int ra = base_text_rank(sa[i]), rb = base_text_rank(sb[i]); if (ra != rb) return ra < rb ? -1 : 1; }
+    return (a.len > b.len) - (a.len < b.len);
+}
+// 35-bit allele code: exact for deletions and for insertions of up to 13 bases (base-5 digits behind a leading 1 < 5^14 < 2^33), a hash
+// with bit 34 set for longer insertions
+DEV unsigned long long gap_code(const RegionDev &R, const AlnGap &e) {
+    if (is_del(e.sym)) return (unsigned long long)e.len & ((1ull << 33) - 1ull);
+    const uint8_t *s = R.bases + R.alns[e.aln].seq_off + e.qpos;
+    if (e.len <= 13) { unsigned long long c = 1; for (int i = 0; i < e.len; i++) c = c * 5ull + s[i]; return c; }
+    unsigned long long h = 1469598103934665603ull ^ (unsigned long long)e.len;
+    for (int i = 0; i < e.len; i++) { h ^= s[i]; h *= 1099511628211ull; }
+    return (1ull << 34) | (h >> 30);
+}
+
+__global__ void __launch_bounds__(256) k_gap_keys(RegionDev R) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R.gap.n_ev) return;
+    const AlnGap e = R.gap.ev[i];
+    unsigned long long key = ~0ull;
+    if (e.sym >= 0) key = ((unsigned long long)R.fss[R.alns[e.aln].fs].fam << 26) | (unsigned long long)(e.epos - R.beg);
+    R.gap.ckey[i] = key; R.gap.cval[i] = (unsigned long long)i;
+}
+
+__global__ void __launch_bounds__(64) k_gap_alleles(RegionDev R, UvcParams P) {
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = R.gap.n_ev;
+    if (i0 >= n) return;
+    const unsigned long long key = R.gap.ckey_s[i0];
+    if (key == ~0ull || (i0 > 0 && R.gap.ckey_s[i0 - 1] == key)) return;   // one thread per (family, position): the head of the run
+    int i1 = i0 + 1;
+    while (i1 < n && R.gap.ckey_s[i1] == key) i1++;
+    const unsigned long long *order = R.gap.cval_s;
+    AlnGap *ev = R.gap.ev;
+    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    const int epos = ev[order[i0]].epos;
+    const long long x = epos - R.beg;
+    for (int i = i0; i < i1; i++) ev[order[i]].mark = 0;
+    auto emit = [&](int strand, int level, int sym, int e) {
+        const int k = atomicAdd(R.gap.n_inc, 1);
+        if (k >= R.gap.inc_cap) { atomicExch(R.err, UVCGPU_EDEVICE); return; }   // cannot happen: the capacity is 7 per event + 8
+        R.gap.ikey[k] = ((unsigned long long)x << 38) | ((unsigned long long)(sym - UVC_LINK_D3P) << 35) | gap_code(R, ev[e]);
+        R.gap.ival[k] = ((unsigned long long)e << 8) | (unsigned long long)(strand * 4 + level);
+    };
+    // the event among `cand(e)` whose allele has the largest total weight; ties go to the larger allele (indelToData_getMajority, main.hpp:50-63)
+    auto majority = [&](auto cand, auto weight) -> int {
+        int best = -1; long long best_w = 0;
+        for (int i = i0; i < i1; i++) {
+            const int e = (int)order[i];
+            if (!cand(e)) continue;
+            long long w = 0;
+            for (int j = i0; j < i1; j++) { const int e2 = (int)order[j]; if (cand(e2) && 0 == gap_cmp(R, ev[e], ev[e2])) w += weight(e2); }
+#ifdef GAP_DEBUG
+            printf("cand x=%lld e=%d sym=%d len=%d weight=%d mark=%x w=%lld best=%d best_w=%lld cmp=%d\n", x, e, ev[e].sym, ev[e].len, ev[e].weight, ev[e].mark, w, best, best_w, best >= 0 ? gap_cmp(R, ev[e], ev[best]) : -9);
+#endif
+            bool take = (best < 0 || w > best_w);
+            if (!take && w == best_w) { const int c = gap_cmp(R, ev[e], ev[best]); take = (c > 0); }
+            if (take) { best = e; best_w = w; }
+#ifdef GAP_DEBUG
+            printf("   after x=%lld best=%d\n", x, best);
+#endif
+        }
+        return best;
+    };
+    const FsRec u_first = R.fss[R.alns[ev[order[i0]].aln].fs];
+    int units[2] = { -1, -1 };
+    units[u_first.strand] = R.alns[ev[order[i0]].aln].fs; units[1 - u_first.strand] = u_first.other_fs;
+    const bool is_duplex_fam = (0x2 == (u_first.dflag & 0x2));
+    const bool will_inc_dscs = is_duplex_fam && units[0] >= 0 && units[1] >= 0;
+    const bool will_inc_sscs = is_duplex_fam && !will_inc_dscs;
+    int con[2][NSYM], mmm[2][NSYM], cnt[NSYM];
+    for (int s = 0; s < 2; s++) for (int k = 0; k < NSYM; k++) { con[s][k] = 0; mmm[s][k] = 0; }
+    // fragments: P3 consensus (main.hpp:2650-2717) and their votes for the unit (updateByFiltering / updateByMajorMinusMinor, main.hpp:1659-1725)
+    for (int s = 0; s < 2; s++) {
+        if (units[s] < 0) continue;
+        const FsRec u = R.fss[units[s]];
+        for (int fi = u.frag_beg; fi < u.frag_end; fi++) {
+            const FragRec f = R.frags[fi];
+            if (epos < f.beg || epos >= f.end) continue;
+            frag_counts(R, P, f, epos, proton, cnt);
+            int cs, cc, ct;
+            fill_consensus(cnt, cs, cc, ct, UVC_LINK_SYMBOL, true, false);
+            if (0 == ct) continue;
+            const int adj = imax(cc * 2, ct) - ct;
+            if (adj > 0) { con[s][cs] += 1; mmm[s][cs] += adj; }
+            if (!(is_ins(cs) || is_del(cs))) continue;
+            const int e = majority([&](int q) { return ev[q].sym == cs && ev[q].aln >= f.aln_beg && ev[q].aln < f.aln_end; }, [&](int q) { return (long long)ev[q].weight; });
+            if (e < 0) { atomicExch(R.err, UVCGPU_EDEVICE); continue; }   // an InDel consensus without an InDel event cannot happen
+#ifdef GAP_DEBUG
+            printf("FRAG x=%lld fi=%d s=%d cs=%d e=%d\n", x, fi, s, cs, e);
+#endif
+            ev[e].mark = 0x10000 | (s << 8) | cs;
+            emit(s, 0, cs, e);
+        }
+    }
+    // family x strand units: P4 (main.hpp:3180-3336) and P5 (main.hpp:3448-3469)
+    int dup[NSYM], dup_allele[2] = { -1, -1 }, dup_sym[2] = { -1, -1 };
+    for (int k = 0; k < NSYM; k++) dup[k] = 0;
+    for (int s = 0; s < 2; s++) {
+        if (units[s] < 0) continue;
+        const FsRec u = R.fss[units[s]];
+        auto unit_allele = [&](int sym) { return majority([&](int q) { return ev[q].mark == (0x10000 | (s << 8) | sym); }, [&](int q) { return 1LL; }); };
+        int cs, cc, ct;
+        fill_consensus(con[s], cs, cc, ct, UVC_LINK_SYMBOL, false, false);
+        if (ct > 0 && (is_ins(cs) || is_del(cs))) {
+            const int e = unit_allele(cs);
+            if (e < 0) atomicExch(R.err, UVCGPU_EDEVICE);
+            else {
+                const bool is_fam_good = ((P.fam_thres_dup1add <= ct) && (cc * 100 >= ct * P.fam_thres_dup1perc) && ((u.dflag & 0x1) || (P.fam_flag & 0x2)));
+                emit(s, 1, cs, e);
+                if (is_fam_good) emit(s, 2, cs, e);
+            }
+        }
+        if (will_inc_dscs) {   // updateByFiltering<true, false, false>(con, {1, 1}), main.hpp:3429-3432
+            const int adj = imax(cc * 2, ct) - ct;
+            if (adj >= 1) dup[cs] += 1;
+            if (is_ins(cs) || is_del(cs)) { dup_allele[s] = unit_allele(cs); dup_sym[s] = cs; }
+        }
+        int c5, cc5, ct5;
+        fill_consensus(mmm[s], c5, cc5, ct5, UVC_LINK_SYMBOL, false, false);
+        if (ct5 > 0 && (is_ins(c5) || is_del(c5))) {
+            const int con_nfrags = con[s][c5];
+            int tot_nfrags = 0;
+            for (int k = UVC_LINK_M; k <= UVC_LINK_NN; k++) tot_nfrags += con[s][k];
+            if (will_inc_sscs && (!will_inc_dscs) && (tot_nfrags >= P.fam_thres_dup1add) && (con_nfrags * 100 >= tot_nfrags * P.fam_thres_dup1perc)) {
+                const int e = unit_allele(c5);
+                if (e < 0) atomicExch(R.err, UVCGPU_EDEVICE); else emit(s, 3, c5, e);
+            }
+        }
+    }
+    if (will_inc_dscs) {   // main.hpp:3523-3548
+        int cs, cc, ct;
+        fill_consensus(dup, cs, cc, ct, UVC_LINK_SYMBOL, false, false);
+        if (1 < ct && (is_ins(cs) || is_del(cs))) {
+            int e = -1;
+            const bool h0 = (dup_sym[0] == cs && dup_allele[0] >= 0), h1 = (dup_sym[1] == cs && dup_allele[1] >= 0);
+            if (h0 && h1) e = (gap_cmp(R, ev[dup_allele[0]], ev[dup_allele[1]]) >= 0 ? dup_allele[0] : dup_allele[1]);
+            else if (h0) e = dup_allele[0];
+            else if (h1) e = dup_allele[1];
+            if (e < 0) atomicExch(R.err, UVCGPU_EDEVICE);
+            else { emit(0, 3, cs, e); emit(1, 3, cs, e); }
+        }
+    }
+}
+
+// one thread per run of equal (position, symbol, allele) keys of the sorted increments
+__global__ void __launch_bounds__(256) k_gap_rows(RegionDev R) {
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = imin(*R.gap.n_inc, R.gap.inc_cap);
+    if (i0 >= n) return;
+    const unsigned long long key = R.gap.ikey_s[i0];
+    if (i0 > 0 && R.gap.ikey_s[i0 - 1] == key) return;
+    GapRow row;
+    for (int k = 0; k < 8; k++) row.cnt[k] = 0;
+    int rep = INT32_MAX;
+    for (int i = i0; i < n && R.gap.ikey_s[i] == key; i++) {
+        const unsigned long long v = R.gap.ival_s[i];
+        row.cnt[v & 0xFF] += 1;
+        rep = imin(rep, (int)(v >> 8));
+    }
+    const AlnGap e = R.gap.ev[rep];
+    row.x = (int)(key >> 38); row.sym = e.sym; row.len = e.len; row.ev = rep; row.seq_off = -1;
+    if (is_ins(e.sym)) {
+        const long long off = (long long)atomicAdd(R.gap.seq_len, (unsigned long long)e.len);
+        if (off + e.len <= R.gap.seq_cap) {
+            const uint8_t *src = R.bases + R.alns[e.aln].seq_off + e.qpos;
+            for (int k = 0; k < e.len; k++) R.gap.seq[off + k] = src[k];
+            row.seq_off = off;
+        } else atomicExch(R.err, UVCGPU_EDEVICE);
+    }
+    R.gap.rows[atomicAdd(R.gap.n_rows, 1)] = row;
+}
+
+extern "C" int uvc_gap_sort(void *tmp, size_t tmp_bytes, const unsigned long long *kin, unsigned long long *kout, const unsigned long long *vin, unsigned long long *vout,
+                            size_t n, int end_bit, hipStream_t s);
 static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 static inline int imin_h(int a, int b) { return a < b ? a : b; }
 
@@ -2335,4 +2538,17 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
         }
     }
     if (P->inferred_is_vcf_generated) TIMED(prof, "k_p5b", hipLaunchKernelGGL(k_p5b, dim3(nblk(R->npos * 2, 256)), dim3(256), 0, s, *R, *P));
+    // InDel allele tables (read the contribution table and the reads only)
+    const GapWork &G = R->gap;
+    hipMemsetAsync(G.n_inc, 0, 16, s);   // n_inc, n_rows, seq_len
+    if (P->inferred_is_vcf_generated && G.n_ev > 0) {
+        TIMED(prof, "k_gap", {
+            hipLaunchKernelGGL(k_gap_keys, dim3(nblk(G.n_ev, 256)), dim3(256), 0, s, *R);
+            uvc_gap_sort(G.sort_tmp, G.sort_tmp_bytes, G.ckey, G.ckey_s, G.cval, G.cval_s, (size_t)G.n_ev, 64, s);
+            hipMemsetAsync(G.ikey, 0xFF, sizeof(unsigned long long) * (size_t)G.inc_cap, s);
+            hipLaunchKernelGGL(k_gap_alleles, dim3(nblk(G.n_ev, 64)), dim3(64), 0, s, *R, *P);
+            uvc_gap_sort(G.sort_tmp, G.sort_tmp_bytes, G.ikey, G.ikey_s, G.ival, G.ival_s, (size_t)G.inc_cap, 64, s);
+            hipLaunchKernelGGL(k_gap_rows, dim3(nblk(G.inc_cap, 256)), dim3(256), 0, s, *R);
+        });
+    }
 }

@@ -626,7 +626,8 @@ DEV void calc_qual(const RegionDev &R, const UvcParams &P, const Tot &T, const A
 // ------------------------------------------------------------------------------------------------
 struct ScoreCtx {
     int pos_beg, pos_end, all_out, is_amplicon;
-    const UvcIndelAllele *alleles; long long n_alleles;   // sorted by (refpos, symbol)
+    const UvcIndelAllele *alleles; long long n_alleles;   // sorted by (refpos, symbol): the region's own InDel alleles, or the caller's where it listed any
+    const int32_t *allele_rows;                           // parallel: row of uvcgpu_region_indel_alleles that carries the allele's string, or -1
     const UvcTumorKey *tkeys; long long n_tkeys;          // sorted by (refpos, symbol); only read when tumor_vcf_is_provided
     int32_t *fields; long long capacity;
     long long *offsets;   // exclusive prefix of per-group packed (flag << 32 | allele count), [2 * (pos_end - pos_beg) + 1]
@@ -805,15 +806,18 @@ __global__ void __launch_bounds__(128) k_score(RegionDev R, UvcParams P, ScoreCt
             long long first; int src;
             const int mult = allele_source(C, P.tumor_vcf_is_provided, refpos, symbol, first, src);
             for (int ai = 0; ai < mult; ai++, rec++) {
-                int bDPa = bdepth, cDP0a = cdepth, glen = 0, tki_tier2 = 0;
+                int bDPa = bdepth, cDP0a = cdepth, glen = 0, tki_tier2 = 0, gap_row = -1;
                 double tpfa_dpv = -1.0, tpfa_qual = -1.0;
                 if (src == 2) {   // tumor record: main.cpp:935, 985-986
                     const UvcTumorKey &tk = C.tkeys[first + ai];
                     tpfa_dpv = (double)(tk.cDP1x + 1) / (double)(tk.CDP1x + 2); tpfa_qual = (double)(tk.bDP + 0.5) / (double)(tk.BDP + 1.0); tki_tier2 = tk.tier2;
                     if (is_ins(symbol) || is_del(symbol)) glen = tk.indel_len;
                 } else if (is_ins(symbol) || is_del(symbol)) {
-                    if (src == 1) { const UvcIndelAllele &al = C.alleles[first + ai]; bDPa = al.bDPa; cDP0a = al.cDP0a; glen = al.indel_len; }
-                    else glen = ((symbol == UVC_LINK_I1 || symbol == UVC_LINK_D1) ? 1 : ((symbol == UVC_LINK_I2 || symbol == UVC_LINK_D2) ? 2 : 3));
+                    if (src == 1) { const UvcIndelAllele &al = C.alleles[first + ai]; bDPa = al.bDPa; cDP0a = al.cDP0a; glen = al.indel_len; gap_row = C.allele_rows[first + ai]; }
+                    else {   // no fragment carries this symbol here: "Invalid indel detected", the allele is the symbol's description text (main.hpp:5415-5423)
+                        bDPa = 0; cDP0a = 0;
+                        glen = ((symbol == UVC_LINK_D3P || symbol == UVC_LINK_I3P) ? 6 : 5);   // strlen("<LD3P>") / strlen("<LD2>") etc., main_conversion.hpp:336-346
+                    }
                 }
                 const int minABQ = (is_subst(symbol) ? (int)nnminus(minABQ_snv, (hp1 ? (hp2 ? 20 : 10) : 0)) : minABQ_indel);
                 Al f;
@@ -821,7 +825,7 @@ __global__ void __launch_bounds__(128) k_score(RegionDev R, UvcParams P, ScoreCt
                 if (pass == 0) {
                     OUT(UVC_O_refpos, refpos); OUT(UVC_O_symbol, symbol); OUT(UVC_O_refsymbol, refsymbol);
                     OUT(UVC_O_DP, T.CDP1b[0] + T.CDP1b[1]); OUT(UVC_O_bDP, T.BDPb[0] + T.BDPb[1]); OUT(UVC_O_c2DP, T.CDP2b[0] + T.CDP2b[1]); OUT(UVC_O_c2AD, f.cDP2f + f.cDP2r);
-                    OUT(UVC_O_bDPa, bDPa); OUT(UVC_O_cDP0a, cDP0a);
+                    OUT(UVC_O_bDPa, bDPa); OUT(UVC_O_cDP0a, cDP0a); OUT(UVC_O_gapSa, gap_row); OUT(UVC_O_gapSa_len, glen);
                     OUT(UVC_O_a2BQf, f.a2BQf); OUT(UVC_O_a2BQr, f.a2BQr); OUT(UVC_O_aBQ, f.aBQ); OUT(UVC_O_aBQQ, f.aBQQ); OUT(UVC_O_bMQ, f.bMQ);
                     calc_dpv(R, P, x, T, f, rtr1, rtr2, refsymbol, tpfa_dpv, tki_tier2, fields, capacity, rec);
                     const int v[6] = { f.cDP1v, f.cDP1w, f.cDP1x, f.cDP2v, f.cDP2w, f.cDP2x };
@@ -841,11 +845,11 @@ __global__ void __launch_bounds__(128) k_score(RegionDev R, UvcParams P, ScoreCt
     }
 }
 
-extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles, const UvcTumorKey *d_tkeys,
-                                int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch /* 2*ngroups + nblocks + 2 words + ngroups ints */, hipStream_t s) {
+extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles, const int32_t *d_allele_rows, int64_t n_alleles,
+                                const UvcTumorKey *d_tkeys, int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch /* 2*ngroups + nblocks + 2 words + ngroups ints */, hipStream_t s) {
     ScoreCtx C;
     C.pos_beg = req->pos_beg; C.pos_end = req->pos_end; C.all_out = (req->all_out || P->should_output_all) ? 1 : 0; C.is_amplicon = req->is_amplicon;
-    C.alleles = d_alleles; C.n_alleles = req->n_indel_alleles; C.tkeys = d_tkeys; C.n_tkeys = (d_tkeys ? req->n_tumor_keys : 0); C.fields = d_fields; C.capacity = capacity;
+    C.alleles = d_alleles; C.allele_rows = d_allele_rows; C.n_alleles = n_alleles; C.tkeys = d_tkeys; C.n_tkeys = (d_tkeys ? req->n_tumor_keys : 0); C.fields = d_fields; C.capacity = capacity;
     const long long ngroups = 2LL * (C.pos_end - C.pos_beg);
     if (ngroups <= 0) return 0;
     const int nblocks = (int)((ngroups + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS));

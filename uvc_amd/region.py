@@ -137,6 +137,26 @@ class Region:
         self._check(self.lib.call("fetch", self.h, gid, out.ctypes.data, out.nbytes))
         return out
 
+    def indel_alleles(self):
+        """The per-strand InDel allele rows fill_by_indel_info reads (instcode.hpp): list of dicts with the inserted sequence as text
+        (insertions) or None (deletions: the deleted bases are refseq[refpos - beg : + len])."""
+        fn = getattr(self.lib.dll, self.lib.prefix + "region_indel_alleles")
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        n, nb = C.c_int64(0), C.c_int64(0)
+        rc = fn(self.h, None, 0, C.byref(n), None, 0, C.byref(nb))
+        if rc not in (0, -6):
+            self._check(rc)
+        rows = (_ffi.UvcGapRow * max(1, n.value))()
+        seq = np.zeros(max(1, nb.value), dtype=np.uint8)
+        self._check(fn(self.h, rows, n.value, C.byref(n), seq.ctypes.data, nb.value, C.byref(nb)))
+        out = []
+        for i in range(n.value):
+            r = rows[i]
+            text = "".join("ACGTN"[b] for b in seq[r.seq_off:r.seq_off + r.len]) if r.seq_off >= 0 else None
+            out.append(dict(refpos=r.refpos, symbol=r.symbol, strand=r.strand, len=r.len, seq=text, bAD1=r.bAD1, cAD1=r.cAD1, c2AD=r.c2AD, c2dAD=r.c2dAD))
+        return out
+
     def score(self, all_out=False, pos_beg=-1, pos_end=-1, is_amplicon=False, indel_alleles=None, capacity=None, copy=True, tumor_keys=None):
         req = _ffi.UvcScoreRequest()
         req.pos_beg, req.pos_end, req.all_out, req.is_amplicon = pos_beg, pos_end, int(all_out), int(is_amplicon)
