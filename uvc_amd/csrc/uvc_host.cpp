@@ -668,7 +668,8 @@ static int gap_tables(uvcgpu_region_t *r) {
             }
         }
         // indel_get_majority (main.hpp:5406-5455): merge the strands per allele, keep those with at least a quarter of the best fragment
-        // support, order by descending bAD1^2 * length (ties: ascending text, see oracle/oracle_score.cpp)
+        // support, order by descending bAD1^2 * length (ties: ascending text -- what the reference's std::sort over
+        // reverse iterators leaves for the short vectors that occur)
         struct Maj { int32_t b, c; const GapRow *g; };
         std::vector<Maj> m;
         int32_t max_b = 0;
