@@ -626,18 +626,22 @@ int gap_al_cmp(const GapAl &a, const GapAl &b) {   // std::string order of the r
 }
 static int gap_tables(uvcgpu_region_t *r) {
     if (r->gap_ready) return 0;
-    int rc = uvcgpu_region_sync(r);
-    if (rc) return rc;
+    // The allele pipeline runs on the side stream and ends long before the main stream does (uvc_launch_accumulate): wait for it alone,
+    // so that this host step and the launches of the scoring kernels behind it stay hidden under the fragment / family kernels.
+    hipStream_t cs = (r->side ? r->side : r->stream);
+    if (r->side) HIP_OK(hipEventSynchronize(r->e_fork2)); else HIP_OK(hipStreamSynchronize(r->stream));
     r->gap_rows.clear(); r->gap_seq.clear(); r->gap_alleles.clear(); r->gap_allele_row.clear();
     const GapWork &G = r->R.gap;
     int32_t cnt[4] = { 0, 0, 0, 0 };
-    if (G.n_inc) HIP_OK(hipMemcpy(cnt, G.n_inc, 16, hipMemcpyDeviceToHost));
+    if (G.n_inc) { HIP_OK(hipMemcpyAsync(cnt, G.n_inc, 16, hipMemcpyDeviceToHost, cs)); HIP_OK(hipStreamSynchronize(cs)); }
     const int32_t n_rows = cnt[1];
     unsigned long long seq_len = 0; memcpy(&seq_len, &cnt[2], 8);
     std::vector<GapRow> dev((size_t)n_rows);
     std::vector<uint8_t> dseq((size_t)seq_len);
-    if (n_rows) HIP_OK(hipMemcpy(dev.data(), G.rows, sizeof(GapRow) * (size_t)n_rows, hipMemcpyDeviceToHost));
-    if (seq_len) HIP_OK(hipMemcpy(dseq.data(), G.seq, (size_t)seq_len, hipMemcpyDeviceToHost));
+    if (n_rows > G.n_ev || (int64_t)seq_len > G.seq_cap) return fail(UVCGPU_EDEVICE, "allele table overflow");
+    if (n_rows) HIP_OK(hipMemcpyAsync(dev.data(), G.rows, sizeof(GapRow) * (size_t)n_rows, hipMemcpyDeviceToHost, cs));
+    if (seq_len) HIP_OK(hipMemcpyAsync(dseq.data(), G.seq, (size_t)seq_len, hipMemcpyDeviceToHost, cs));
+    if (n_rows || seq_len) HIP_OK(hipStreamSynchronize(cs));
     auto al_of = [&](const GapRow &g) { GapAl a; a.len = g.len; a.del = (g.seq_off < 0); a.seq = (a.del ? nullptr : dseq.data() + g.seq_off); return a; };
     std::sort(dev.begin(), dev.end(), [&](const GapRow &a, const GapRow &b) {
         if (a.x != b.x) return a.x < b.x;
@@ -699,8 +703,9 @@ static int gap_tables(uvcgpu_region_t *r) {
         r->gap_alleles_cap = na + 64;
     }
     if (na) {
-        HIP_OK(hipMemcpy(r->d_gap_alleles, r->gap_alleles.data(), sizeof(UvcIndelAllele) * (size_t)na, hipMemcpyHostToDevice));
-        HIP_OK(hipMemcpy(r->d_gap_allele_row, r->gap_allele_row.data(), sizeof(int32_t) * (size_t)na, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpyAsync(r->d_gap_alleles, r->gap_alleles.data(), sizeof(UvcIndelAllele) * (size_t)na, hipMemcpyHostToDevice, cs));
+        HIP_OK(hipMemcpyAsync(r->d_gap_allele_row, r->gap_allele_row.data(), sizeof(int32_t) * (size_t)na, hipMemcpyHostToDevice, cs));
+        HIP_OK(hipStreamSynchronize(cs));
     }
     r->gap_ready = true;
     return 0;

@@ -30,6 +30,7 @@
 //   k_fam_stat/p4/p5 per (family-strand unit, position): multi-fragment families              main.hpp:2883-3522
 //   k_duplex         per (duplex family, position)                                            main.hpp:3523-3550
 //   k_p5b            per (position, strand)  bucket -> quality for family consensus           main.hpp:3552-3591
+//   k_gap_keys/alleles/rows  per (family, InDel position)  the allele-keyed counters of the InDel symbols   main.hpp:2710-2717, 3196-3546
 // uvc_launch_accumulate at the end of the file orders them on two streams.
 #include "uvc_device.h"
 
@@ -2518,6 +2519,21 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
         TIMED(prof, "k_p2_fast_link", hipLaunchKernelGGL((k_p2_fast<true, false>), dim3(nwin), dim3(256), 0, s, *R, *P));
     }
     if (side) { hipEventRecord(e_join, s2); hipStreamWaitEvent(s, e_join, 0); }
+    // InDel allele tables: they read the contribution table (side stream) and the reads only, so the pipeline stays on the side stream
+    // underneath the fragment / family kernels; the main stream picks it up at the end
+    const GapWork &G = R->gap;
+    hipMemsetAsync(G.n_inc, 0, 16, s2);   // n_inc, n_rows, seq_len
+    if (P->inferred_is_vcf_generated && G.n_ev > 0) {
+        TIMED2(prof, "k_gap", {
+            hipLaunchKernelGGL(k_gap_keys, dim3(nblk(G.n_ev, 256)), dim3(256), 0, s, *R);
+            uvc_gap_sort(G.sort_tmp, G.sort_tmp_bytes, G.ckey, G.ckey_s, G.cval, G.cval_s, (size_t)G.n_ev, 58, s);
+            hipMemsetAsync(G.ikey, 0xFF, sizeof(unsigned long long) * (size_t)G.inc_cap, s);
+            hipLaunchKernelGGL(k_gap_alleles, dim3(nblk(G.n_ev, 64)), dim3(64), 0, s, *R, *P);
+            uvc_gap_sort(G.sort_tmp, G.sort_tmp_bytes, G.ikey, G.ikey_s, G.ival, G.ival_s, (size_t)G.inc_cap, 64, s);
+            hipLaunchKernelGGL(k_gap_rows, dim3(nblk(G.inc_cap, 256)), dim3(256), 0, s, *R);
+        });
+    }
+    if (side) hipEventRecord(e_fork2, s2);
     if (P->inferred_is_vcf_generated && R->n_complex) TIMED(prof, "k_p2_items", hipLaunchKernelGGL(k_p2_items, dim3(R->n_complex), dim3(64), 0, s, *R, *P));
     {
         const bool proton = (UVC_PLATFORM_IONTORRENT == P->inferred_sequencing_platform);
@@ -2538,17 +2554,5 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
         }
     }
     if (P->inferred_is_vcf_generated) TIMED(prof, "k_p5b", hipLaunchKernelGGL(k_p5b, dim3(nblk(R->npos * 2, 256)), dim3(256), 0, s, *R, *P));
-    // InDel allele tables (read the contribution table and the reads only)
-    const GapWork &G = R->gap;
-    hipMemsetAsync(G.n_inc, 0, 16, s);   // n_inc, n_rows, seq_len
-    if (P->inferred_is_vcf_generated && G.n_ev > 0) {
-        TIMED(prof, "k_gap", {
-            hipLaunchKernelGGL(k_gap_keys, dim3(nblk(G.n_ev, 256)), dim3(256), 0, s, *R);
-            uvc_gap_sort(G.sort_tmp, G.sort_tmp_bytes, G.ckey, G.ckey_s, G.cval, G.cval_s, (size_t)G.n_ev, 64, s);
-            hipMemsetAsync(G.ikey, 0xFF, sizeof(unsigned long long) * (size_t)G.inc_cap, s);
-            hipLaunchKernelGGL(k_gap_alleles, dim3(nblk(G.n_ev, 64)), dim3(64), 0, s, *R, *P);
-            uvc_gap_sort(G.sort_tmp, G.sort_tmp_bytes, G.ikey, G.ikey_s, G.ival, G.ival_s, (size_t)G.inc_cap, 64, s);
-            hipLaunchKernelGGL(k_gap_rows, dim3(nblk(G.inc_cap, 256)), dim3(256), 0, s, *R);
-        });
-    }
+    if (side) hipStreamWaitEvent(s, e_fork2, 0);   // the allele tables
 }
