@@ -212,6 +212,25 @@ enum UvcScoreField {
     /* InDel alleles: gapSa = index (into uvcgpu_region_indel_alleles' rows) of the first row that carries this record's InDel string,
      * or -1 (not an InDel, or the string came from the caller); gapSa_len = indelstring.size() (main.cpp:907) */
     UVC_O_gapSa, UVC_O_gapSa_len,
+    UVC_O_tkey,                         /* index of the tumor record (UvcScoreRequest::tumor_keys) this allele was paired with, or -1 */
+    /* ---- the calling step behind calc_qual (main.cpp:990-1168): same value in every record of a (position, symbol type) group ---- */
+    /* the two best non-reference alleles of the group by (max(cVQ1, cVQ2), cVQ1, cVQ2, symbol, InDel string), main.cpp:996-1016:
+     * cVQ1M / cVQ2M, cVQAM as the symbol (14 = none), cVQSM as a row of uvcgpu_region_indel_alleles (-1 = no string) */
+    UVC_O_cVQ1M0, UVC_O_cVQ1M1, UVC_O_cVQ2M0, UVC_O_cVQ2M1, UVC_O_cVQAM0, UVC_O_cVQAM1, UVC_O_cVQSM0, UVC_O_cVQSM1,
+    UVC_O_vAC0, UVC_O_vAC1,             /* alleles at or above germ_phred_het3al per symbol type at this zerobased_pos, main.cpp:994-997, 1088 */
+    /* output_germline, main.hpp:5483-5775: vNLODQ[own symbol type] = GL4raw[0] - max(GL4raw[1..3]); GL4raw; GST = a0..a3 LODQ + the four
+     * het LODQs; best genotype index (0 "0/0", 1 "0/1", 2 "1/1", 3 "1/2"), its GQ; whether a GERMLINE line is written (needs
+     * OUTVAR_GERMLINE); the records chosen as ref / alt1 / alt2, as record indices (-1 = the padding allele) */
+    UVC_O_vNLODQ, UVC_O_GL4_0, UVC_O_GL4_1, UVC_O_GL4_2, UVC_O_GL4_3,
+    UVC_O_GST0, UVC_O_GST1, UVC_O_GST2, UVC_O_GST3, UVC_O_GST4, UVC_O_GST5, UVC_O_GST6, UVC_O_GST7,
+    UVC_O_germ_GT, UVC_O_germ_GQ, UVC_O_germ_emit, UVC_O_germ_ref, UVC_O_germ_alt1, UVC_O_germ_alt2,
+    /* ---- per record: main.cpp:1081-1147 and the arithmetic of append_vcf_record (main.hpp:6027-6272) ---- */
+    UVC_O_out,                          /* will_generate_out && !is_out_blocked: append_vcf_record is called for this record */
+    UVC_O_vHGQ, UVC_O_NLODQ, UVC_O_NLODV /* argmin_nlodq_symbol, 14 = none */, UVC_O_TLODQ, UVC_O_SomaticQ,
+    UVC_O_TNBQF0, UVC_O_TNBQF1, UVC_O_TNBQF2, UVC_O_TNBQF3, UVC_O_TNCQF0, UVC_O_TNCQF1, UVC_O_TNCQF2, UVC_O_TNCQF3,
+    UVC_O_QUAL,                         /* vcfqual: the bit pattern of the 32-bit float the reference prints with std::to_string */
+    UVC_O_FILTER,                       /* 0..5 = Q10..Q60 (bcfrec::FILTER_IDS), 6 = PASS */
+    UVC_O_keep,                         /* the record is written: keep_var && tki.bDP >= min_ad, main.hpp:6253-6262 */
     UVC_NUM_SCORE_FIELDS
 };
 
@@ -237,6 +256,8 @@ typedef struct UvcTumorKey {
     int32_t cDP1x, CDP1x, bDP, BDP;
     int32_t tier2;
     int32_t indel_len;
+    /* the rest of TumorKeyInfo that the somatic quality of the normal-sample record reads (main.cpp:1104-1147, main.hpp:6095-6206) */
+    int32_t cVQ1, cPCQ1, cDP2x, CDP2x, cVQ2, cPCQ2, bNMQ, vHGQ, tDP;
 } UvcTumorKey;
 
 /* One row of the per-strand InDel allele tables that fill_by_indel_info pushes into gapSeq / gapbAD1 / gapcAD1 / gc2AD / gc2dAD

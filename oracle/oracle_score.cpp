@@ -83,6 +83,11 @@ struct Fmt {
     // outputs of calc_qual
     i32 cMmQ, aAaMQ, bMQQ, bIAQ, cIAQ, cPCQ1, cPLQ1, cPCQ2, cPLQ2, bTINQ, cTINQ, gVQ1, cVQ1, dVQinc, cVQ2, CONTQ;
     i32 refpos, refsymbol;
+    // the calling step (main.cpp:990-1168, output_germline, append_vcf_record)
+    i32 cVQ1M[2], cVQ2M[2], cVQAM[2], cVQSM[2], vAC[2], vNLODQ, GL4[4], GST[8], germ_GT, germ_GQ, germ_emit, germ_ref, germ_alt1, germ_alt2;
+    i32 out, vHGQ, NLODQ, NLODV, TLODQ, SomaticQ, TNBQF[4], TNCQF[4], QUALbits, FILTER, keep;
+    int g_ref_rel, g_alt1_rel, g_alt2_rel;   // output_germline's ref / alt1 / alt2 as indices into the group (-1 = the padding allele)
+    const UvcTumorKey *tkey; i32 tkey_idx;   // the tumor record of this allele (normal sample of a T/N pair) and its index in the request, or NULL / -1
 };
 
 // BcfFormat_symboltype_init, main.hpp:3889-4081
@@ -687,7 +692,14 @@ static void emit(const Fmt &f, std::vector<i32> &r) {
     r[UVC_O_cMmQ] = f.cMmQ; r[UVC_O_aAaMQ] = f.aAaMQ; r[UVC_O_bMQQ] = f.bMQQ; r[UVC_O_bIAQ] = f.bIAQ; r[UVC_O_cIAQ] = f.cIAQ;
     r[UVC_O_cPCQ1] = f.cPCQ1; r[UVC_O_cPLQ1] = f.cPLQ1; r[UVC_O_cPCQ2] = f.cPCQ2; r[UVC_O_cPLQ2] = f.cPLQ2; r[UVC_O_bTINQ] = f.bTINQ; r[UVC_O_cTINQ] = f.cTINQ;
     r[UVC_O_gVQ1] = f.gVQ1; r[UVC_O_cVQ1] = f.cVQ1; r[UVC_O_dVQinc] = f.dVQinc; r[UVC_O_cVQ2] = f.cVQ2; r[UVC_O_CONTQ] = f.CONTQ;
-    r[UVC_O_gapSa] = f.gapSa_row; r[UVC_O_gapSa_len] = f.gapSa_len;
+    r[UVC_O_gapSa] = f.gapSa_row; r[UVC_O_gapSa_len] = f.gapSa_len; r[UVC_O_tkey] = f.tkey_idx;
+    for (int i = 0; i < 2; i++) { r[UVC_O_cVQ1M0 + i] = f.cVQ1M[i]; r[UVC_O_cVQ2M0 + i] = f.cVQ2M[i]; r[UVC_O_cVQAM0 + i] = f.cVQAM[i]; r[UVC_O_cVQSM0 + i] = f.cVQSM[i]; r[UVC_O_vAC0 + i] = f.vAC[i]; }
+    r[UVC_O_vNLODQ] = f.vNLODQ;
+    for (int i = 0; i < 4; i++) { r[UVC_O_GL4_0 + i] = f.GL4[i]; r[UVC_O_TNBQF0 + i] = f.TNBQF[i]; r[UVC_O_TNCQF0 + i] = f.TNCQF[i]; }
+    for (int i = 0; i < 8; i++) r[UVC_O_GST0 + i] = f.GST[i];
+    r[UVC_O_germ_GT] = f.germ_GT; r[UVC_O_germ_GQ] = f.germ_GQ; r[UVC_O_germ_emit] = f.germ_emit; r[UVC_O_germ_ref] = f.germ_ref; r[UVC_O_germ_alt1] = f.germ_alt1; r[UVC_O_germ_alt2] = f.germ_alt2;
+    r[UVC_O_out] = f.out; r[UVC_O_vHGQ] = f.vHGQ; r[UVC_O_NLODQ] = f.NLODQ; r[UVC_O_NLODV] = f.NLODV; r[UVC_O_TLODQ] = f.TLODQ; r[UVC_O_SomaticQ] = f.SomaticQ;
+    r[UVC_O_QUAL] = f.QUALbits; r[UVC_O_FILTER] = f.FILTER; r[UVC_O_keep] = f.keep;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -783,6 +795,197 @@ static void indel_majority(State &S, i32 refpos, int symbol, std::vector<GapAlle
         return ((i64)x.bAD1 * x.bAD1 * (i64)x.s.size()) > ((i64)y.bAD1 * y.bAD1 * (i64)y.s.size()); });
 }
 
+// ------------------------------------------------------------------------------------------------
+// The calling step behind calc_qual: main.cpp:990-1168, output_germline (main.hpp:5483-5775) and the arithmetic of
+// append_vcf_record (main.hpp:6027-6272).  Strings (GT text, REF / ALT, INFO, FORMAT) stay with the caller.
+// ------------------------------------------------------------------------------------------------
+static const int SYM_END = UVC_NUM_SYMBOLS;   // END_ALIGNMENT_SYMBOLS
+static i32 hetLODQ(double a1, double a2, double expfrac, double powlaw_exponent) {   // main.hpp:5457-5462
+    const i32 binomLODQ = (i32)calc_binom_10log10_likeratio(expfrac, a1, a2);
+    const i32 powerLODQ = (i32)round(10.0 / log(10.0) * powlaw_exponent * max_(logit2((a1 + 0.5) * 0.5 / expfrac, (a2 + 0.5) * 0.5 / (1.0 - expfrac)), 0.0));
+    return min_(binomLODQ, powerLODQ);
+}
+static inline int indel_n_units(int s) {   // SYMBOL_TO_INDEL_N_UNITS, main.hpp:271-279
+    switch (s) { case UVC_LINK_D3P: return -3; case UVC_LINK_D2: return -2; case UVC_LINK_D1: return -1; case UVC_LINK_I3P: return 3; case UVC_LINK_I2: return 2; case UVC_LINK_I1: return 1; default: return 0; }
+}
+// one entry of symbol_format_vec: a scored allele, or the padding allele init_fmt (main.cpp:1043-1053)
+struct GermAl { int symbol; i32 gVQ1, CONTQ, cDP0a, cDP1v; int rec; };
+static void call_germline(const UvcParams &P, int refsymbol, std::vector<Fmt> &fm, i64 rec0) {
+    const bool is_rescued = P.tumor_vcf_is_provided;
+    std::vector<GermAl> v;
+    for (size_t i = 0; i < fm.size(); i++) if (fm[i].symbol != UVC_BASE_NN) { GermAl a = { fm[i].symbol, fm[i].gVQ1, fm[i].CONTQ, fm[i].cDP0a, fm[i].cDP1v, (int)i }; v.push_back(a); }
+    while (v.size() <= 4) { GermAl a = { SYM_END, 0, 0, 0, 50, -1 }; v.push_back(a); }
+    // std::sort over reverse iterators with a comparator on ALODQ alone: descending gVQ1, equal values keep their order (insertion sort
+    // of the short vectors that occur)
+    std::stable_sort(v.begin(), v.end(), [](const GermAl &a, const GermAl &b) { return a.gVQ1 > b.gVQ1; });
+    const GermAl *sel[4] = { NULL, NULL, NULL, NULL };
+    int allele_idx = 1; i32 ref_alodq = INT32_MIN;
+    for (const GermAl &a : v) {
+        const bool isref = (refsymbol == a.symbol || UVC_BASE_NN == a.symbol || UVC_LINK_NN == a.symbol);
+        if (isref && a.gVQ1 > ref_alodq) { sel[0] = &a; ref_alodq = a.gVQ1; }
+        if ((!isref) && allele_idx <= 3) { sel[allele_idx] = &a; allele_idx++; }
+    }
+    i32 a0 = sel[0]->gVQ1, a1 = sel[1]->gVQ1, a2 = sel[2]->gVQ1, a3 = sel[3]->gVQ1;
+    const bool isSubst = is_subst(refsymbol);
+    const int symbolNN = ((isSubst || !is_rescued) ? UVC_BASE_NN : UVC_LINK_NN);
+    double ad0 = sel[0]->cDP1v / 100.0, ad1 = sel[1]->cDP1v / 100.0, ad2 = sel[2]->cDP1v / 100.0;   // compute_norm_ad
+    if (symbolNN == sel[1]->symbol) { ad0 += ad1; ad1 = 0; }
+    if (symbolNN == sel[2]->symbol) { ad0 += ad2; ad2 = 0; }
+    const i32 a0a1 = hetLODQ(ad0, ad1, 1.0 - P.germ_hetero_FA, P.powlaw_exponent), a1a0 = hetLODQ(ad1, ad0, P.germ_hetero_FA, P.powlaw_exponent);
+    const i32 a1a2 = hetLODQ(ad1, ad2, 0.5, P.powlaw_exponent), a2a1 = hetLODQ(ad2, ad1, 0.5, P.powlaw_exponent);
+    const i32 phred_homref = 0;
+    const i32 phred_hetero = (isSubst ? P.germ_phred_hetero_snp : P.germ_phred_hetero_indel), phred_homalt = (isSubst ? P.germ_phred_homalt_snp : P.germ_phred_homalt_indel);
+    const i32 phred_tri_al = (isSubst ? P.germ_phred_het3al_snp : P.germ_phred_het3al_indel);
+    // CONTQ[1] of the padding allele is read out of bounds by the reference in T/N mode; it is taken as 0 here
+    if (is_rescued) { a0 = min_(a0, sel[0]->CONTQ); a1 = min_(a1, sel[1]->CONTQ); a2 = min_(a2, sel[2]->CONTQ); a3 = min_(a3, sel[3]->CONTQ); }
+    else a0 = min_(a0, sel[0]->CONTQ);
+    const i32 a2penal = max_(a2 - (phred_tri_al - phred_hetero), 0), a3penal = max_(a3 - phred_hetero, 0);
+    const i32 a01hetp = max_(max_(a0a1, a1a0) - (0 - 0), 0), a12hetp = max_(max_(a1a2, a2a1) - (3 - 0), 0), a03trip = max_(a0, a3);
+    i32 tri_al_penal = 0;
+    const int symb1 = sel[1]->symbol, symb2 = sel[2]->symbol;
+    if (is_ins(symb1) && is_ins(symb2)) { tri_al_penal += 3; if (symb1 == symb2) { tri_al_penal += 3; if (UVC_LINK_I3P == symb1) tri_al_penal += 3; } }
+    { const int n1 = indel_n_units(symb1), n2 = indel_n_units(symb2); if (n1 != 0 && n2 != 0) tri_al_penal -= between_(abs(n1 - n2) * 3 - 5, 0, 9); }
+    const i32 GL4raw[4] = {
+        (-phred_homref - a1 - a2penal - a3penal),
+        (-phred_hetero - max_(a01hetp, a2) - max_(min_(a01hetp, a2) - phred_hetero, 0) - a3penal),
+        (-phred_homalt - max_(a0, a2) - max_(min_(a0, a2) - phred_hetero, 0) - a3penal),
+        (-phred_tri_al - max_(a12hetp, a03trip) - max_(min_(a12hetp, a03trip) - phred_hetero, 0) - max_(min_(a12hetp, min_(a0, a3)) - phred_hetero, 0) - tri_al_penal) };
+    const i32 ret = GL4raw[0] - max_(GL4raw[1], max_(GL4raw[2], GL4raw[3]));
+    // sort by (value, index) descending (PairSecondLess over reverse iterators, main.hpp:5464-5469): best genotype and the runner-up
+    int order[4] = { 0, 1, 2, 3 };
+    std::sort(order, order + 4, [&](int x, int y) { return GL4raw[x] > GL4raw[y] || (GL4raw[x] == GL4raw[y] && x > y); });
+    const int GLidx = order[0];
+    const i32 germ_GQ = GL4raw[order[0]] - GL4raw[order[1]];
+    int emit = ((0x1 /* OUTVAR_GERMLINE */ & P.outvar_flag) ? 1 : 0);
+    if (emit && 0 == GLidx && (!P.should_output_all_germline) && max_(sel[1]->cDP0a, sel[2]->cDP0a) <= 2) emit = 0;
+    for (Fmt &f : fm) {
+        f.vNLODQ = ret;
+        for (int i = 0; i < 4; i++) f.GL4[i] = GL4raw[i];
+        const i32 gst[8] = { a0, a1, a2, a3, a0a1, a1a0, a1a2, a2a1 };
+        for (int i = 0; i < 8; i++) f.GST[i] = gst[i];
+        f.germ_GT = GLidx; f.germ_GQ = germ_GQ; f.germ_emit = emit;
+        f.g_ref_rel = sel[0]->rec; f.g_alt1_rel = sel[1]->rec; f.g_alt2_rel = sel[2]->rec;
+        f.germ_ref = (sel[0]->rec < 0 ? -1 : (i32)(rec0 + sel[0]->rec)); f.germ_alt1 = (sel[1]->rec < 0 ? -1 : (i32)(rec0 + sel[1]->rec)); f.germ_alt2 = (sel[2]->rec < 0 ? -1 : (i32)(rec0 + sel[2]->rec));
+    }
+}
+
+// calc_binom_powlaw_syserr_normv_quals, main.hpp:5982-6009
+static void normv_quals(i32 out[4], double tAD, double tDP, i32 tVQ, i32 tnVQcap, double nAD, double nDP, i32 nVQ, double penal_dimret_coef, i32 prior_phred, i32 tn_dec_by_xm, double powlaw_exponent) {
+    const i32 binom_b10log10like = (i32)calc_binom_10log10_likeratio((tDP - tAD) / (tDP), nDP - nAD, nAD);
+    const double nADplus = nAD * between_(nDP / tDP - 1.0, 0.0, 1.0);
+    const double bjpfrac = ((tAD + 0.5) / (tDP + 1.0)) / ((nAD + 0.5 + nADplus) / (nDP + 1.0 + nADplus));
+    const i32 powlaw_b10log10like = (i32)round(powlaw_exponent * numstates2phred(bjpfrac));
+    const i32 tnVQinc = max_(-prior_phred, max_((-(i32)nAD) * 3, min_(binom_b10log10like - prior_phred, powlaw_b10log10like - prior_phred)));
+    const double l2 = log(max_(bjpfrac, 1.001)) / log(2);
+    i32 tnVQdec = max_(0, nVQ - max_(0, min_(binom_b10log10like - prior_phred, (i32)(l2 * l2 * penal_dimret_coef))));
+    tnVQdec = max_(tnVQdec, min_(nVQ + 9, tn_dec_by_xm));
+    out[0] = binom_b10log10like; out[1] = powlaw_b10log10like; out[2] = tnVQdec; out[3] = min_(tnVQcap, tVQ + tnVQinc) - tnVQdec;
+}
+// calc_binom_powlaw_syserr_normv_quals2, main.hpp:6011-6025
+static void normv_quals2(i32 out[4], double tAD, double tDP, i32 tVQ, i32 tnVQcap, double nAD, double nDP, i32 nVQ) {
+    const i32 binom = (i32)calc_binom_10log10_likeratio((tDP - tAD) / (tDP), nDP - nAD, nAD);
+    const i32 powlaw = (nAD <= 3 ? binom : (i32)round(binom * 3 / nAD));
+    const double m = max_((double)(min_(binom, powlaw) - 3), max_(-3 * nAD, -3.0));   // TVN_MICRO_VQ_DELTA = 3; MAX3 promotes to double
+    out[0] = binom; out[1] = powlaw; out[2] = nVQ; out[3] = (i32)between_((double)tVQ + m - (double)nVQ, 0.0, (double)tnVQcap);
+}
+
+// main.cpp:1081-1147 + append_vcf_record for one record; `fm` are the records of its group (front-pushed: reffmt = the reference allele)
+static void call_record(const UvcParams &P, Fmt &fmt, const Fmt &reffmt, const std::vector<Fmt> &fm, int st, int refsymbol, bool should_output_ref_allele) {
+    const int symbol = fmt.symbol;
+    const bool tprov = P.tumor_vcf_is_provided;
+    const UvcTumorKey *tk = fmt.tkey;
+    fmt.out = 0; fmt.vHGQ = 0; fmt.NLODQ = 0; fmt.NLODV = SYM_END; fmt.TLODQ = 0; fmt.SomaticQ = 0; fmt.QUALbits = 0; fmt.FILTER = 0; fmt.keep = 0;
+    for (int i = 0; i < 4; i++) { fmt.TNBQF[i] = 0; fmt.TNCQF[i] = 0; }
+    const bool will_generate_out = (!tprov ? ((P.outvar_flag & 0x4 /* OUTVAR_ANY */) != 0) : (tk != NULL && (P.outvar_flag & 0x2 /* OUTVAR_SOMATIC */)));
+    const bool is_out_blocked = (((UVC_BASE_NN == symbol) && !(0x20 & P.outvar_flag)) || ((UVC_LINK_NN == symbol) && !(0x40 & P.outvar_flag)));
+    if (!(will_generate_out && !is_out_blocked)) return;
+    fmt.out = 1;
+    const i32 germ_phred = (is_subst(symbol) ? P.germ_phred_hetero_snp : P.germ_phred_hetero_indel);
+    const i32 nlodq_singlesite = fmt.vNLODQ;
+    const i32 nlodq_singlesample = nlodq_singlesite - 3 + germ_phred;
+    i32 nlodq1 = ((UVC_BASE_SYMBOL == st) ? P.germ_phred_hetero_snp : P.germ_phred_hetero_indel);
+    int argmin_nlodq_symbol = SYM_END;
+    const i32 totBDP = fmt.BDPb[0] + fmt.BDPb[1];
+    // the TumorKeyInfo the arithmetic reads: the tumor record (normal sample) or this record itself (fill_tki, main.hpp:5912-5930)
+    i32 t_BDP, t_bDP, t_CDP1x, t_cDP1x, t_cVQ1, t_cPCQ1, t_CDP2x, t_cDP2x, t_cVQ2, t_cPCQ2, t_bNMQ, t_tDP = 0;
+    if (tprov) {
+        i32 nlodq_inc = 999;
+        const int ptr[2] = { fmt.g_alt1_rel, fmt.g_alt2_rel };
+        for (int k = 0; k < 2; k++) {
+            // fmtptr1 / fmtptr2 of output_germline; the padding allele has cDP1x = {} (collectget default 50), CDP1x[0] = 0 and VTI = END
+            const Fmt *fp = (ptr[k] >= 0 ? &fm[(size_t)ptr[k]] : NULL);
+            const int normsymbol = (fp ? fp->symbol : SYM_END);
+            const i32 bgerr_norm_max_ad = (fp ? fp->cDP1x : 50);
+            const double tAD = (tk->cDP1x + 1 * 50) / 100.0, tDP = (tk->CDP1x + 2 * 50) / 100.0;
+            const double nAD = (bgerr_norm_max_ad + 1 * 50) / 100.0, nDP = ((fp ? fp->CDPv[2][0] : 0) + 2 * 50) / 100.0;
+            const double bjpfrac = ((tAD) / (tDP)) / ((nAD) / (nDP));
+            const i32 binom_b10log10like = (i32)calc_binom_10log10_likeratio((tDP - tAD) / (tDP), nDP - nAD, nAD);
+            const i32 powlaw_b10log10like = (i32)(P.powlaw_exponent * 10 / log(10) * log(bjpfrac));
+            const i32 inc_snp = 2 * P.germ_phred_hetero_snp - P.germ_phred_het3al_snp, inc_indel = 2 * P.germ_phred_hetero_indel - P.germ_phred_het3al_indel;
+            const i32 triallele_inc = ((normsymbol != symbol) ? (is_subst(symbol) ? inc_snp : inc_indel) : 0);
+            const i32 new_nlodq_inc = (i32)between_((double)min_(binom_b10log10like, powlaw_b10log10like), -3.0, P.powlaw_anyvar_base) + triallele_inc;
+            if (nlodq_inc > new_nlodq_inc) { nlodq_inc = new_nlodq_inc; argmin_nlodq_symbol = normsymbol; }
+        }
+        const i32 n_norm_alts = (totBDP - (reffmt.bDPf + reffmt.bDPr)) + (fmt.bDPf + fmt.bDPr);
+        nlodq1 = max_(max_(nlodq_singlesite, germ_phred + nlodq_inc), tk->vHGQ + min_(3, totBDP - n_norm_alts * (i32)round(0.5 / P.contam_any_mul_frac)));
+        t_BDP = tk->BDP; t_bDP = tk->bDP; t_CDP1x = tk->CDP1x; t_cDP1x = tk->cDP1x; t_cVQ1 = tk->cVQ1; t_cPCQ1 = tk->cPCQ1;
+        t_CDP2x = tk->CDP2x; t_cDP2x = tk->cDP2x; t_cVQ2 = tk->cVQ2; t_cPCQ2 = tk->cPCQ2; t_bNMQ = tk->bNMQ; t_tDP = tk->tDP;
+    } else {
+        nlodq1 = nlodq_singlesample;
+        t_BDP = totBDP; t_bDP = fmt.bDPf + fmt.bDPr; t_CDP1x = fmt.CDPv[2][0]; t_cDP1x = fmt.cDP1x; t_cVQ1 = fmt.cVQ1; t_cPCQ1 = fmt.cPCQ1;
+        t_CDP2x = fmt.CDPv[5][0]; t_cDP2x = fmt.cDP2x; t_cVQ2 = fmt.cVQ2; t_cPCQ2 = fmt.cPCQ2; t_bNMQ = fmt.bNMQ;
+    }
+    fmt.vHGQ = nlodq_singlesample; fmt.NLODV = argmin_nlodq_symbol;
+    // ---- append_vcf_record ----
+    const bool is_processing_normal = tprov;   // tki.ref_alt.size() > 0
+    // nfm = the normal's record, or FORMAT_UNCOV (all zero / empty) for a single sample
+    const i32 nfm_cDP1x = (is_processing_normal ? fmt.cDP1x : 0), nfm_CDP1x = (is_processing_normal ? fmt.CDPv[2][0] : 0);
+    const i32 nfm_cDP2x = (is_processing_normal ? fmt.cDP2x : 0), nfm_CDP2x = (is_processing_normal ? fmt.CDPv[5][0] : 0);
+    const i32 nfm_cVQ1 = (is_processing_normal ? fmt.cVQ1 : 0), nfm_cVQ2 = (is_processing_normal ? fmt.cVQ2 : 0);
+    const i32 nfm_BDP = (is_processing_normal ? totBDP : 0), nfm_CDP1 = (is_processing_normal ? fmt.CDP1b[0] + fmt.CDP1b[1] : 0);
+    const i32 inc_snp = max_(0, 2 * P.germ_phred_hetero_snp - P.germ_phred_het3al_snp - 0), inc_indel = max_(0, 2 * P.germ_phred_hetero_indel - P.germ_phred_het3al_indel - 0);   // TIN_CONTAM_MICRO_VQ_DELTA = 0
+    i32 phred_het3al_chance_inc = (is_subst(symbol) ? inc_snp : inc_indel);
+    if (is_ins(symbol) || is_del(symbol)) phred_het3al_chance_inc = (i32)nnminus(inc_indel + 1, fmt.gapSa_len);
+    const i32 qmin = P.microadjust_syserr_MQ_NMR_tn_syserr_no_penal_qual_min, qmax = P.microadjust_syserr_MQ_NMR_tn_syserr_no_penal_qual_max;
+    const i32 tn_dec_by_xm = between_(min_(fmt.bNMQ, t_bNMQ), qmin, qmax) - qmin;
+    double add1 = 0, add2 = 0;
+    if (is_processing_normal && implies_short_frag(fmt, P.lib_wgs_min_avg_fraglen)) { add1 = P.lib_nonwgs_normal_add_mul_ad * nfm_cDP1x / 100.0; add2 = P.lib_nonwgs_normal_add_mul_ad * nfm_cDP2x / 100.0; }
+    i32 tn_dec_both = 0;
+    if (is_processing_normal && t_tDP > 500 && fmt.DP > 500 && is_del(symbol) && fmt.APDP[2] * 3 > fmt.APDP[0]) tn_dec_both = min_((i32)nnminus(nfm_cVQ1, 31), 9);
+    const i32 prior_phred = ((UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform) ? (3 + 8) : 3);
+    i32 bq4[4], cq4[4];
+    if (P.tn_syserr_norm_devqual >= 0) normv_quals(bq4, (t_cDP1x + 0.5) / 100.0 + 0.0, (t_CDP1x + 1.0) / 100.0 + 0.0, t_cVQ1, t_cPCQ1, (nfm_cDP1x + 0.5) / 100.0 + 0.0 + add1, (nfm_CDP1x + 1.0) / 100.0 + 0.0 + add1,
+                                               (i32)nnminus(nfm_cVQ1, phred_het3al_chance_inc), P.tn_syserr_norm_devqual, prior_phred, tn_dec_by_xm, P.powlaw_exponent);
+    else normv_quals2(bq4, (t_cDP1x + 0.5) / 100.0 + 0.0, (t_CDP1x + 1.0) / 100.0 + 0.0, t_cVQ1, t_cPCQ1, (nfm_cDP1x + 0.5) / 100.0 + 0.0 + add1, (nfm_CDP1x + 1.0) / 100.0 + 0.0 + add1, (i32)nnminus(nfm_cVQ1, phred_het3al_chance_inc));
+    const i32 converted_nfm_cVQ2 = nfm_cVQ1 - (3 * (nfm_BDP + 1) / (nfm_CDP1 + 1));
+    const i32 norm_norm_vq = (i32)nnminus(nfm_cVQ2, max_(phred_het3al_chance_inc, 3) - 3);
+    if (P.tn_syserr_norm_devqual >= 0) normv_quals(cq4, (t_cDP2x + 0.5) / 100.0 + 0.0, (t_CDP2x + 1.0) / 100.0 + 0.0, t_cVQ2, t_cPCQ2, (nfm_cDP2x + 0.5) / 100.0 + 0.0 + add2, (nfm_CDP2x + 1.0) / 100.0 + 0.0 + add2,
+                                               norm_norm_vq, P.tn_syserr_norm_devqual, prior_phred, max_(tn_dec_by_xm, min_(max_(nfm_cVQ2, converted_nfm_cVQ2), 8 + 4)), P.powlaw_exponent);
+    else normv_quals2(cq4, (t_cDP2x + 0.5) / 100.0 + 0.0, (t_CDP2x + 1.0) / 100.0 + 0.0, t_cVQ2, t_cPCQ2, (nfm_cDP2x + 0.0) / 100.0 + 0.5 + add2, (nfm_CDP2x + 0.0) / 100.0 + 1.0 + add2, norm_norm_vq);
+    const i32 tlodq1 = max_(bq4[3], cq4[3] + 0);
+    const bool is_cytosine_deanim_CT = ((UVC_BASE_C == refsymbol && UVC_BASE_T == symbol) || (UVC_BASE_G == refsymbol && UVC_BASE_A == symbol));
+    auto prob2realphred = [](double p) { return -10 * log(p) / log(10); };
+    const double b_min_tlodq = 2 + 3 - prob2realphred((t_bDP + 1e-3) / (t_BDP + 1)) / 10.0;
+    const double c2v_min_tlodq = 2 + 5 - prob2realphred((t_cDP2x * 0.01 + 1e-5) / (t_CDP2x * 0.01 + 1) / (is_cytosine_deanim_CT ? 5 : 1)) / 10.0;
+    const float lowestVAQ = (float)max_(b_min_tlodq, c2v_min_tlodq);
+    const i32 tlodq = ((tlodq1 >= 10) ? tlodq1 : (tlodq1 * 3 - 20)) - tn_dec_both;
+    const i32 nlodq = nlodq1 - tn_dec_both;
+    const i32 somaticq = min_(tlodq, nlodq);
+    float v = (is_processing_normal ? ((float)somaticq) : max_((float)tlodq, lowestVAQ));
+    { const float base = (float)pow(10.0, 0.1); if (v < 10.0f) v = log1pf(powf(base, v)) / logf(base); }   // calc_non_negative<float>, main_conversion.hpp:163-171
+    const float vcfqual = v;
+    fmt.TLODQ = tlodq; fmt.NLODQ = nlodq; fmt.SomaticQ = somaticq;
+    for (int i = 0; i < 4; i++) { fmt.TNBQF[i] = bq4[i]; fmt.TNCQF[i] = cq4[i]; }
+    memcpy(&fmt.QUALbits, &vcfqual, 4);
+    fmt.FILTER = (vcfqual < 10 ? 0 : vcfqual < 20 ? 1 : vcfqual < 30 ? 2 : vcfqual < 40 ? 3 : vcfqual < 50 ? 4 : vcfqual < 60 ? 5 : 6);
+    const i32 vad1curr = fmt.aBQ2; const i64 vdp1curr = fmt.ABQ2[0];
+    const i32 vad2curr = t_bDP, vdp2curr = t_BDP;
+    const bool keep_var = (((vcfqual >= P.vqual) || ((!tprov) && ((vad1curr >= P.vad1 && vdp1curr >= P.vdp1 && (vdp1curr * P.vfa1) <= vad1curr) || (vad2curr >= P.vad2 && vdp2curr >= P.vdp2 && (vdp2curr * P.vfa2) <= vad2curr))))
+                           && (symbol != refsymbol || should_output_ref_allele));
+    const i32 min_ad = ((symbol == refsymbol) ? P.min_r_ad : P.min_a_ad);
+    fmt.keep = (keep_var && t_bDP >= min_ad) ? 1 : 0;
+}
+
 // per-position driver, main.cpp:608-1000
 int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &records, std::string &err) {
     if (!S.accumulated) { err = "score before accumulate"; return UVCGPU_ESTATE; }
@@ -813,6 +1016,8 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
         const int prev_base1 = ((refidx >= 2) ? symat(refidx - 2) : UVC_BASE_NN), prev_base2 = ((refidx >= 3) ? symat(refidx - 3) : UVC_BASE_NN);
         const int next_base1 = ((refidx < refsize) ? symat(refidx) : UVC_BASE_NN), next_base2 = ((refidx + 1 < refsize) ? symat(refidx + 1) : UVC_BASE_NN);
         std::vector<Fmt> fmts[2];
+        std::vector<std::string> texts[2];
+        i32 curr_vAC[2] = { 0, 0 };
         i32 ins_cdepth = 0, del_cdepth = 0, ins1_cdepth = 0, del1_cdepth = 0;
         for (int st = 0; st < 2; st++) {
             if (zpos == pos_beg && UVC_BASE_SYMBOL == st) continue;
@@ -835,6 +1040,7 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
                 // host-supplied InDel alleles, else the single default allele (see UvcIndelAllele)
                 std::vector<UvcIndelAllele> alleles;
                 std::vector<i32> allele_rows;   // parallel to `alleles` when they were derived from the region's own allele tables
+                std::vector<std::string> allele_texts;
                 std::vector<const UvcTumorKey *> akeys;
                 if (tprov) for (i64 q = 0; q < ntk; q++) if (tk[q].refpos == refpos && tk[q].symbol == symbol) {
                     UvcIndelAllele d = { refpos, symbol, bdepth, cdepth, (is_ins(symbol) || is_del(symbol)) ? tk[q].indel_len : 0 };
@@ -856,7 +1062,7 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
                                 if (is_ins(symbol)) for (size_t c = 0; c < g.s.size(); c++) if ("ACGTN"[gap_seq[(size_t)gap_rows[q].seq_off + c]] != g.s[c]) same = false;
                                 if (same) row = (i32)q;
                             }
-                            allele_rows.push_back(row);
+                            allele_rows.push_back(row); allele_texts.push_back(g.s);
                         }
                     }
                 } else { UvcIndelAllele d = { refpos, symbol, bdepth, cdepth, 0 }; alleles.push_back(d); }
@@ -864,9 +1070,10 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
                     const UvcIndelAllele &al = alleles[ai];
                     Fmt f = init;
                     f.refpos = refpos; f.refsymbol = refsymbol;
-                    f.tpfa_dpv = f.tpfa_qual = -1.0; f.tki_tier2 = 0;
+                    f.tpfa_dpv = f.tpfa_qual = -1.0; f.tki_tier2 = 0; f.tkey = NULL; f.tkey_idx = -1;
                     if (ai < akeys.size()) {
                         const UvcTumorKey &k = *akeys[ai];
+                        f.tkey = &k; f.tkey_idx = (i32)(&k - tk);
                         f.tpfa_dpv = (double)(k.cDP1x + 1) / (double)(k.CDP1x + 2);          // main.cpp:935
                         f.tpfa_qual = (double)(k.bDP + 0.5) / (double)(k.BDP + 1.0);         // main.cpp:985-986
                         f.tki_tier2 = k.tier2;
@@ -877,7 +1084,7 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
                     symbol_init(f, S, refpos, symbol, al.bDPa, al.cDP0a, al.indel_len, minABQ);
                     f.gapSa_row = (ai < allele_rows.size() ? allele_rows[ai] : -1);
                     calc_DPv(f, S.rtr[max_(refpos - ext_beg, 3) - 3], S.rtr[min_(refpos - ext_beg + 3, nrtr - 1)], refsymbol, S, refpos);
-                    fmts[st].push_back(f);
+                    fmts[st].push_back(f); texts[st].push_back(ai < allele_texts.size() ? allele_texts[ai] : std::string());   // InDel string as text, for the order of cVQSM
                 }
             }
         }
@@ -893,9 +1100,40 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
                 if (UVC_BASE_NN == f.symbol || UVC_LINK_NN == f.symbol) for (int i = 0; i < 6; i++) s2[i] = v[i];
             }
             for (Fmt &f : fmts[st]) for (int i = 0; i < 6; i++) { f.CDPv[i][0] = s1[i]; f.CDPv[i][1] = s2[i]; }
-            for (Fmt &f : fmts[st]) {
+            struct Top { i32 mx, v1, v2; int symbol; std::string str; i32 row; };
+            std::vector<Top> tops;
+            for (size_t fi = 0; fi < fmts[st].size(); fi++) {
+                Fmt &f = fmts[st][fi];
                 calc_qual(f, ins_cdepth, del_cdepth, ins1_cdepth, del1_cdepth, repeatunit_size, repeatnum,
                           S.rtr[max_(refpos - ext_beg, 3) - 3], S.rtr[min_(refpos - ext_beg + 3, nrtr - 1)], refpos, st_refsymbol[st], S);
+                if (st_refsymbol[st] != f.symbol) {   // main.cpp:990-998
+                    Top t = { max_(f.cVQ1, f.cVQ2), f.cVQ1, f.cVQ2, f.symbol, texts[st][fi], f.gapSa_row }; tops.push_back(t);
+                    if (max_(f.cVQ1, f.cVQ2) >= ((UVC_BASE_SYMBOL == st) ? P.germ_phred_het3al_snp : P.germ_phred_het3al_indel)) curr_vAC[st] += 1;
+                }
+            }
+            std::sort(tops.begin(), tops.end(), [](const Top &a, const Top &b) {   // descending tuple order, main.cpp:1000
+                if (a.mx != b.mx) return a.mx > b.mx;
+                if (a.v1 != b.v1) return a.v1 > b.v1;
+                if (a.v2 != b.v2) return a.v2 > b.v2;
+                if (a.symbol != b.symbol) return a.symbol > b.symbol;
+                return a.str > b.str; });
+            for (Fmt &f : fmts[st]) for (int i = 0; i < 2; i++) {   // cVQ1M / cVQ2M / cVQAM / cVQSM, main.cpp:1001-1016
+                const bool has = ((size_t)i < tops.size());
+                f.cVQ1M[i] = (has ? tops[i].v1 : -999); f.cVQ2M[i] = (has ? tops[i].v2 : -999); f.cVQAM[i] = (has ? tops[i].symbol : SYM_END); f.cVQSM[i] = (has ? tops[i].row : -1);
+            }
+            i64 rec0 = (i64)records.size();
+            for (int t = 0; t < st; t++) if (!(zpos == pos_beg && UVC_BASE_SYMBOL == t)) rec0 += (i64)fmts[t].size();
+            call_germline(P, st_refsymbol[st], fmts[st], rec0);
+        }
+        const bool is_germline_var_generated = ((!fmts[0].empty() && fmts[0][0].germ_emit) || (!fmts[1].empty() && fmts[1][0].germ_emit));
+        for (int st = 0; st < 2; st++) {   // main.cpp:1073-1168
+            if (zpos == pos_beg && UVC_BASE_SYMBOL == st) continue;
+            const Fmt *reffmt = NULL;
+            for (const Fmt &f : fmts[st]) if (f.symbol == st_refsymbol[st]) reffmt = &f;
+            for (Fmt &f : fmts[st]) {
+                f.vAC[0] = curr_vAC[0]; f.vAC[1] = curr_vAC[1];
+                if (!reffmt) { err = "a scored position has no REF allele"; return UVCGPU_ESTATE; }   // the reference aborts, main.cpp:1025-1029
+                call_record(P, f, *reffmt, fmts[st], st, st_refsymbol[st], (all_out || is_germline_var_generated));
                 std::vector<i32> r; emit(f, r); records.push_back(r);
             }
         }

@@ -24,7 +24,7 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
                                       const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof,
                                       hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join, hipEvent_t e_fork2);
 extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles, const int32_t *d_allele_rows, int64_t n_alleles,
-                                const UvcTumorKey *d_tkeys, int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch, hipStream_t s);
+                                const UvcGapRow *d_gap_rows, const uint8_t *d_gap_seq, const UvcTumorKey *d_tkeys, int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch, hipStream_t s);
 extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored);
 extern "C" size_t uvc_gap_sort_tmp_bytes(size_t n);
 
@@ -61,6 +61,7 @@ struct uvcgpu_region {
     std::vector<UvcGapRow> gap_rows; std::vector<uint8_t> gap_seq;
     std::vector<UvcIndelAllele> gap_alleles; std::vector<int32_t> gap_allele_row;   // what indel_get_majority yields, sorted by (refpos, symbol)
     UvcIndelAllele *d_gap_alleles = nullptr; int32_t *d_gap_allele_row = nullptr; int64_t gap_alleles_cap = 0;
+    UvcGapRow *d_gap_rows = nullptr; int64_t gap_rows_cap = 0; uint8_t *d_gap_seq = nullptr; int64_t gap_seq_cap = 0;   // device copies for k_call
 };
 
 static size_t group_bytes(const uvcgpu_region *r, int g) {
@@ -702,6 +703,12 @@ static int gap_tables(uvcgpu_region_t *r) {
         HIP_OK(hipMalloc((void **)&r->d_gap_allele_row, sizeof(int32_t) * (size_t)(na + 64)));
         r->gap_alleles_cap = na + 64;
     }
+    const int64_t nr = (int64_t)r->gap_rows.size(), ns = (int64_t)r->gap_seq.size();
+    if (nr > r->gap_rows_cap) { if (r->d_gap_rows) hipFree(r->d_gap_rows); r->d_gap_rows = nullptr; r->gap_rows_cap = 0; HIP_OK(hipMalloc((void **)&r->d_gap_rows, sizeof(UvcGapRow) * (size_t)(nr + 64))); r->gap_rows_cap = nr + 64; }
+    if (ns > r->gap_seq_cap) { if (r->d_gap_seq) hipFree(r->d_gap_seq); r->d_gap_seq = nullptr; r->gap_seq_cap = 0; HIP_OK(hipMalloc((void **)&r->d_gap_seq, (size_t)(ns + 64))); r->gap_seq_cap = ns + 64; }
+    if (nr) HIP_OK(hipMemcpyAsync(r->d_gap_rows, r->gap_rows.data(), sizeof(UvcGapRow) * (size_t)nr, hipMemcpyHostToDevice, cs));
+    if (ns) HIP_OK(hipMemcpyAsync(r->d_gap_seq, r->gap_seq.data(), (size_t)ns, hipMemcpyHostToDevice, cs));
+    if (nr || ns) HIP_OK(hipStreamSynchronize(cs));
     if (na) {
         HIP_OK(hipMemcpyAsync(r->d_gap_alleles, r->gap_alleles.data(), sizeof(UvcIndelAllele) * (size_t)na, hipMemcpyHostToDevice, cs));
         HIP_OK(hipMemcpyAsync(r->d_gap_allele_row, r->gap_allele_row.data(), sizeof(int32_t) * (size_t)na, hipMemcpyHostToDevice, cs));
@@ -785,7 +792,7 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
         r->score_scratch_bytes = need;
     }
     HIP_OK(hipMemsetAsync(r->d_score_count, 0, 8, r->stream));
-    int rc = uvc_launch_score(&r->R, &r->P, &rq, use_al, use_row, n_al, d_tk, r->d_score_fields, r->score_capacity, r->d_score_count, r->d_score_scratch, r->stream);
+    int rc = uvc_launch_score(&r->R, &r->P, &rq, use_al, use_row, n_al, r->d_gap_rows, r->d_gap_seq, d_tk, r->d_score_fields, r->score_capacity, r->d_score_count, r->d_score_scratch, r->stream);
     if (!rc && hipGetLastError() != hipSuccess) rc = fail(UVCGPU_EDEVICE, "score kernel launch failed");
     if (!rc) rc = uvcgpu_region_sync(r);
     int64_t cnt = 0;
@@ -823,6 +830,8 @@ void uvcgpu_region_destroy(uvcgpu_region_t *r) {
     if (r->d_score_count) hipFree(r->d_score_count);
     if (r->d_gap_alleles) hipFree(r->d_gap_alleles);
     if (r->d_gap_allele_row) hipFree(r->d_gap_allele_row);
+    if (r->d_gap_rows) hipFree(r->d_gap_rows);
+    if (r->d_gap_seq) hipFree(r->d_gap_seq);
     if (r->stream) hipStreamDestroy(r->stream);
     delete r;
 }
