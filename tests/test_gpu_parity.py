@@ -124,7 +124,13 @@ def test_normal_sample_of_a_tn_pair(name, oracle_lib, gpu_lib):
         p.tumor_vcf_is_provided = 1
         R = run_region(lib, reads, params=p)
         out.append(R.score(tumor_keys=keys))
-    ro, rg = out
+        p.tn_syserr_norm_devqual = -1.0; p.outvar_flag = 63      # the other arm of the somatic quality + germline lines in the normal
+        R2 = run_region(lib, reads, params=p)
+        out.append(R2.score(tumor_keys=keys))
+    compare_records(out[1], out[3])
+    ro, rg = out[0], out[2]
+    assert (ro["tkey"] >= 0).sum() >= len(keys) and ro["out"].sum() == (ro["tkey"] >= 0).sum() - ((ro["tkey"] >= 0) & (ro["symbol"] == 13)).sum()   # records with a tumor key are written (LINK_NN is blocked)
+    assert len(set(ro["NLODV"][ro["out"] == 1].tolist())) > 1
     assert set(zip(ro["refpos"].tolist())) == set((k[0],) for k in keys)      # exactly the rescued positions
     assert len(ro["refpos"]) >= 14 * len(set(k[0] for k in keys))              # every symbol of both symbol types at a rescued position
     worst = compare_records(ro, rg)
@@ -139,6 +145,9 @@ VARIANTS = {
     "short_reads_low_thresholds": dict(set=dict(central_readlen=75, bias_thres_highBQ=10, bias_thres_PFBQ1=40, bias_thres_PFBQ2=45, fam_thres_highBQ_snv=5)),
     "bq_added": dict(set=dict(bq_phred_added_misma=6, bq_phred_added_indel=3, microadjust_padded_deletion_flag=3)),
     "fastq_only": dict(set=dict(inferred_is_vcf_generated=0)),                 # P1/P2/P3 skipped (main.hpp:3691)
+    "germline_lines": dict(set=dict(outvar_flag=63, should_output_all_germline=1, vqual=5.0)),   # OUTVAR_GERMLINE: GERMLINE lines are written, so REF alleles are kept too
+    "germline_default_gate": dict(set=dict(outvar_flag=63)),
+    "normv_quals2": dict(set=dict(tn_syserr_norm_devqual=-1.0, min_a_ad=3, vad1=2, vdp1=50)),   # calc_binom_powlaw_syserr_normv_quals2 arm + the AD / DP keep rules
 }
 
 
