@@ -101,7 +101,8 @@ def main():
     ap.add_argument("--depth", type=int, default=300)
     ap.add_argument("--streams", type=int, default=1, help="split the tile into this many regions, each on its own HIP stream, accumulated concurrently")
     ap.add_argument("--umi", action="store_true", help="duplex-UMI families (BASELINE config 4 shape when combined with --depth 2000 --tile-kb 200)")
-    ap.add_argument("--pipeline", action="store_true", help="two resident tiles, software-pipelined: accumulate of tile k+1 is enqueued before the (synchronous) score of tile k; every step still does one full accumulate + score of a whole tile")
+    ap.add_argument("--serial", action="store_true", help="one resident tile, accumulate then score, strictly one after the other (the default streams tiles through two handles, see --pipeline)")
+    ap.add_argument("--pipeline", action="store_true", help="(default unless --serial / --streams > 1) two resident tiles, software-pipelined: accumulate of tile k+1 is enqueued before the (synchronous) score of tile k; every step still does one full accumulate + score of a whole tile")
     ap.add_argument("--all-out", action="store_true", help="second series of SURVEY 8(d): score every symbol of every position (-A), not only the default-gate candidates")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="CPU-only rehearsal of the multi-rank protocol (no kernels, used by the gloo tests)")
@@ -139,6 +140,7 @@ def main():
     params = region.default_params(lib)
     t_gen = time.perf_counter()
     sub_len = region_len // args.streams
+    args.pipeline = (not args.serial) and args.streams == 1
     if args.pipeline:
         assert args.streams == 1, "--pipeline uses its own two handles"
     n_tiles = 2 if args.pipeline else args.streams
@@ -163,6 +165,7 @@ def main():
     def score_one(Ri):
         return Ri.score(all_out=args.all_out, capacity=(15 * (sub_len + 2) if args.all_out else max(65536, sub_len // 4)), copy=False)
 
+    lib.dll.uvcgpu_region_set_profiling(R.h, 1)          # HIP events around the kernels of handle 0 (the roofline leg reads them)
     if args.pipeline:
         n_reads_total //= 2; n_read_bases //= 2          # per step: one tile
         k_state = [0]
@@ -175,22 +178,38 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    lib.dll.uvcgpu_region_set_profiling(R.h, 1)
     ktimes = {}
     names_buf = C.create_string_buffer(1024)
     ms_buf = (C.c_float * 32)()
     n_rec = 0
     torch.cuda.synchronize(); clock.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for it in range(args.steps):
         rec = step()
         n_rec = len(rec["refpos"])
-        n = lib.dll.uvcgpu_region_kernel_times(R.h, names_buf, 1024, ms_buf, 32)   # stream is already idle: score() is synchronous
+        if args.pipeline and (args.warmup + it) % 2 == 1:
+            continue   # handle 0 has its next accumulate in flight: asking for its kernel times would wait for it and stall the pipeline
+        n = lib.dll.uvcgpu_region_kernel_times(R.h, names_buf, 1024, ms_buf, 32)   # the handle's stream is idle here: its score() was synchronous
         for nm, ms in zip(names_buf.value.decode().split(";")[:n], list(ms_buf)[:n]):
             ktimes.setdefault(nm, []).append(ms)
     torch.cuda.synchronize(); clock.barrier()
     dt = clock.max_over_ranks(time.perf_counter() - t0)
     total_positions = clock.sum_over_ranks(float(region_len)) * args.steps
+
+    # outside the timed region: the same step on one handle, strictly serial, so that the kernel durations are also known without
+    # the other tile's scoring kernels running beside them (reported as "serial", never as `value`)
+    serial = None
+    if args.pipeline:
+        torch.cuda.synchronize()
+        score_one(Rs[k_state[0] % 2])                      # drain the accumulate the last step left in flight
+        sk = {}
+        ts = time.perf_counter()
+        for _ in range(2):
+            R.accumulate(); score_one(R)
+            n = lib.dll.uvcgpu_region_kernel_times(R.h, names_buf, 1024, ms_buf, 32)
+            for nm, ms in zip(names_buf.value.decode().split(";")[:n], list(ms_buf)[:n]):
+                sk.setdefault(nm, []).append(ms)
+        serial = {"ms_per_step": 1e3 * (time.perf_counter() - ts) / 2, "kernel_ms": {k: sum(v) / len(v) for k, v in sk.items()}}
 
     if rank == 0:
         avg = {k: sum(v) / len(v) for k, v in ktimes.items()}
@@ -201,7 +220,7 @@ def main():
             "metric": "pileup positions scored/sec at 300x depth", "value": total_positions / dt, "unit": "positions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "chr20-shaped tumor-only non-UMI tile: %d kb at %dx, 150 bp paired-end, one tile per GPU resident in HBM; step = accumulate P1..P5b + default-gate scoring + D2H of records" % (args.tile_kb, args.depth),
+            "config": {"workload": "chr20-shaped tumor-only non-UMI tile: %d kb at %dx, 150 bp paired-end, resident in HBM; step = accumulate P1..P5b + default-gate scoring / calling + D2H of the records of one tile%s" % (args.tile_kb, args.depth, "; tiles stream through two handles (the accumulate of tile k+1 is enqueued before the synchronous score of tile k)" if args.pipeline else ""),
                        "tile_positions": region_len, "streams": args.streams, "pipeline": bool(args.pipeline), "all_out": bool(args.all_out), "umi": bool(args.umi), "reads_per_tile": n_reads_total, "read_bases_per_tile": n_read_bases, "scored_records_per_tile": n_rec,
                        "parallelism": "region-shard x%d (no collective on the data path)" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(dom, args.tile_kb, args.depth),
@@ -210,6 +229,11 @@ def main():
             "read_bases_per_s": n_read_bases * world * args.steps / dt,
             "host_prep_s": {"generate": round(t_gen, 2), "pack_and_h2d": round(t_h2d, 3)},
         }
+        if serial:
+            sd = serial["kernel_ms"].get(dom)
+            out["serial"] = {"ms_per_step": round(serial["ms_per_step"], 3), "kernel": dom, "kernel_ms": round(sd, 4) if sd else None,
+                             "roofline_frac": (abytes / (sd * 1e-3) / 1e9 / HBM_PEAK_GBS) if sd else None,
+                             "note": "one handle, accumulate then score with nothing overlapped; measured after the timed region"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline(args.depth)
         print(json.dumps(out))
