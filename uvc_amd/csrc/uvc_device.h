@@ -156,6 +156,7 @@ struct RegionDev {
     MisItem *mis; int32_t *mis_cnt; int32_t mis_cap;   // mismatch queue of k_p2_fast, sized from the exact count below
     unsigned long long *mis_total;  // number of read bases of simple alignments that differ from the reference (k_aln_prelude)
     int32_t max_aln_span, max_frag_span;
+    int32_t any_amplicon;           // some family carries the amplicon flag (fam_dflag & 0x4)
     int32_t *err;                   // device error flag (unsupported CIGAR shapes etc.)
     GapWork gap;                    // InDel allele tables
 };

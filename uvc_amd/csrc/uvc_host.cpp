@@ -481,6 +481,7 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     { std::vector<int32_t> z(4, 0); int32_t *c; if ((rc = upload(r, z, &c))) return rc; R.mis_cnt = c; R.mis_total = (unsigned long long *)(c + 2); R.mis = nullptr; R.mis_cap = 0; }
     { if ((rc = upload(r, dup_units, &r->d_dup_units)) || (rc = upload(r, dup_off, &r->d_dup_off))) return rc; r->n_dup = (int)dup_units.size(); r->n_dup_work = dup_work; }
     R.max_aln_span = max_aln_span; R.max_frag_span = max_frag_span;
+    R.any_amplicon = 0; for (int64_t f = 0; f < in->n_fams; f++) if (in->fam_dflag[f] & 0x4) { R.any_amplicon = 1; break; }
     r->R.n_complex = (int32_t)complex_ids.size();
     // table rows are written by k_p2_slow<false>; mark all slots empty (0xFF)
     HIP_OK(hipMemsetAsync(R.table, 0xFF, std::max<int64_t>(table_rows, 1) * sizeof(Contrib), r->stream));

@@ -225,10 +225,11 @@ DEV int selm(wmask m, int v) { int r; asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=
 // Everything that does not depend on the symbol is computed once for both.
 // ISRC / STRAND (bam_get_strand, common.hpp:89) are compile-time: the P2 work list is split by them, so the direction-specific
 // counters are fixed registers in each instantiation and the loop has no branch on the read's orientation.
-template <bool ISRC, bool STRAND>
+// PLAIN: the region holds no amplicon-flagged family and no primer length is set, so the amplicon arms are compiled out.
+template <bool ISRC, bool STRAND, bool PLAIN>
 DEV void segbias_simple(SegAcc &AL, SegAcc &AB, const UvcParams &P, const SegRead &r, const PosThres &T, int rpos, long long baq_p, long long baq2_p,
                         bool hasL, bool hasB, int bqL, int bqB, int xm_inc, int bm_inc, const int *amp1, const int *amp2) {
-    const bool amplicon = ((r.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag)));
+    const bool amplicon = (PLAIN ? false : ((r.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag))));
     const bool normal_filter_primers = (P.tn_is_paired && (0x1 & P.primer_flag));
     const bool is_assay_UMI = (r.dflag & 0x1);
     constexpr bool isrc = ISRC, strand = STRAND;
@@ -825,7 +826,7 @@ DEV void mis_apply(const RegionDev &R, const UvcParams &P, const MisItem &it) {
 // ------------------------------------------------------------------------------------------------
 // Two instantiations, <true,false> for LINK_M and <false,true> for the read bases: each keeps one SegAcc in registers,
 // which halves the accumulator footprint and doubles the waves per SIMD.
-template <bool DO_L, bool DO_B>
+template <bool DO_L, bool DO_B, bool PLAIN>
 __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
     __shared__ int amp1[256], amp2[256];
     __shared__ MisItem misq[DO_B ? 4 : 1][DO_B ? MISQ_CAP : 1];
@@ -843,7 +844,7 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
     const int p = w0 + lane;
     const int64_t x = x0 + lane;
     const bool valid = x < R.npos;
-    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    const bool proton = (PLAIN ? false : (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform));
     const bool normal_filter_primers = (P.tn_is_paired && (0x1 & P.primer_flag));
     const int my_ref = valid ? R.refsym[x] : 0;
     PosThres T;
@@ -899,7 +900,7 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
             sr.clip_cnt = (bm4c >> 16) & 0xF;
             const int nogap = (int)(short)(bm4c & 0xFFFF);
             sr.baq_pos = bcast(c.v[12], j); sr.baq_last = bcast(c.v[13], j); sr.baq2_last = bcast(c.v[14], j);
-            const bool is_assay_amplicon = ((sr.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag)));
+            const bool is_assay_amplicon = (PLAIN ? false : ((sr.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag))));
             bool gate = true;
             if (is_assay_amplicon && !normal_filter_primers) {   // primer gating, main.hpp:1872-1875, 1895
                 constexpr bool isrc = ISRC;
@@ -927,7 +928,7 @@ __global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
             if (cover) {
                 const int bmv = bcast(c.v[8], j), xbv = bcast(c.v[9], j);
                 const int bm_inc = (sym < 4 ? ((bmv >> (8 * sym)) & 0xFF) : (xbv & 0xFF)), xm_inc = (xbv >> 8) & 0xFF;
-                segbias_simple<ISRC, STRAND>(Alink, Aref, P, sr, T, p, baq_p, baq2_p, hasL, hasB, incL, inc, xm_inc, bm_inc, amp1, amp2);
+                segbias_simple<ISRC, STRAND, PLAIN>(Alink, Aref, P, sr, T, p, baq_p, baq2_p, hasL, hasB, incL, inc, xm_inc, bm_inc, amp1, amp2);
             }
         }
     }
@@ -1527,6 +1528,8 @@ __global__ void __launch_bounds__(64) k_frag_generic(RegionDev R, UvcParams P, c
 // position; per-lane bucket histograms of the two dense symbols live in LDS, rare symbols use the
 // global bucket plane (each position has exactly one writer in this kernel).
 // ------------------------------------------------------------------------------------------------
+// PLAIN: VCF run, Illumina-like values, no SSCS table cap (fam_flag & 1), padded deletions counted: the common case without those arms
+template <bool PLAIN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,5))) k_frag(RegionDev R, UvcParams P) {
     __shared__ int hist[2][NBUCKETS][256];   // [dense symbol][bucket][thread]: conflict-free, 32 KiB so that five blocks share a CU
     const int lane = threadIdx.x & 63;
@@ -1537,9 +1540,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,5)))
     const int p = w0 + lane;
     const int64_t x = x0 + lane;
     const bool valid = x < R.npos;
-    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
-    const bool padded_ignored = (P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0;
-    const bool vcfgen = P.inferred_is_vcf_generated;   // P3 belongs to updateByAlns3UsingBQ, skipped on FASTQ-only runs (main.hpp:3691)
+    const bool proton = (PLAIN ? false : (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform));
+    const bool padded_ignored = (PLAIN ? false : ((P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0));
+    const bool vcfgen = (PLAIN ? true : (P.inferred_is_vcf_generated != 0));   // P3 belongs to updateByAlns3UsingBQ, skipped on FASTQ-only runs (main.hpp:3691)
     const int my_ref = valid ? R.refsym[x] : 0;
     for (int b = 0; b < NBUCKETS; b++) { hist[0][b][threadIdx.x] = 0; hist[1][b][threadIdx.x] = 0; }
     // avgBQ + 8 (get_avgBQ, main_conversion.hpp:791-796) of the five read symbols and of LINK_M; LINK_M value of a simple read here
@@ -1576,7 +1579,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,5)))
         if (vcfgen) {
             const int con_qual = cc * 2 - ct;
             int phredlike = imin(con_qual, max_qual);
-            if (0x1 & P.fam_flag) phredlike = imin(phredlike, sscs_phred(P, my_ref, cs));
+            if (!PLAIN && (0x1 & P.fam_flag)) phredlike = imin(phredlike, sscs_phred(P, my_ref, cs));
             const int pbucket = imax(0, max_qual - phredlike);
             if (dense >= 0) {
                 if (pbucket < NBUCKETS) atomicAdd(&hist[dense][pbucket][threadIdx.x], 1);   // ds_add_u32 without return
@@ -2513,10 +2516,14 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
     // ---- main stream: the base symbols first, so that the queued mismatches (rare symbols, atomics: disjoint from the planes the
     // LINK_M pass stores to) are applied on the side stream while the LINK_M pass runs
     if (P->inferred_is_vcf_generated) {
-        TIMED(prof, "k_p2_fast_base", hipLaunchKernelGGL((k_p2_fast<false, true>), dim3(nwin), dim3(256), 0, s, *R, *P));
+        // no IonTorrent values, no amplicon-flagged family, no primer length: the specialisation without those arms
+        const bool plain = (UVC_PLATFORM_IONTORRENT != P->inferred_sequencing_platform) && !R->any_amplicon && !(P->primerlen > 0 && !(0x2 & P->primer_flag));
+        if (plain) TIMED(prof, "k_p2_fast_base", hipLaunchKernelGGL((k_p2_fast<false, true, true>), dim3(nwin), dim3(256), 0, s, *R, *P));
+        else TIMED(prof, "k_p2_fast_base", hipLaunchKernelGGL((k_p2_fast<false, true, false>), dim3(nwin), dim3(256), 0, s, *R, *P));
         if (side) { hipEventRecord(e_fork2, s); hipStreamWaitEvent(s2, e_fork2, 0); }
         TIMED2(prof, "k_p2_mism", hipLaunchKernelGGL(k_p2_mism, dim3(2048), dim3(256), 0, s, *R, *P));
-        TIMED(prof, "k_p2_fast_link", hipLaunchKernelGGL((k_p2_fast<true, false>), dim3(nwin), dim3(256), 0, s, *R, *P));
+        if (plain) TIMED(prof, "k_p2_fast_link", hipLaunchKernelGGL((k_p2_fast<true, false, true>), dim3(nwin), dim3(256), 0, s, *R, *P));
+        else TIMED(prof, "k_p2_fast_link", hipLaunchKernelGGL((k_p2_fast<true, false, false>), dim3(nwin), dim3(256), 0, s, *R, *P));
     }
     if (side) { hipEventRecord(e_join, s2); hipStreamWaitEvent(s, e_join, 0); }
     // InDel allele tables: they read the contribution table (side stream) and the reads only, so the pipeline stays on the side stream
@@ -2540,7 +2547,11 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
         const int n_gen = proton ? R->n_frags : R->n_sweep;
         if (n_gen) TIMED(prof, "k_frag_generic", hipLaunchKernelGGL(k_frag_generic, dim3(imin_h(n_gen, 1 << 20), imin_h((R->max_frag_span + 63) / 64, 16)), dim3(64), 0, s, *R, *P, proton ? (const int32_t *)nullptr : R->sweep_frags, n_gen));
     }
-    TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag, dim3(nwin), dim3(256), 0, s, *R, *P));
+    {
+        const bool plain = P->inferred_is_vcf_generated && (UVC_PLATFORM_IONTORRENT != P->inferred_sequencing_platform) && !(0x1 & P->fam_flag) && !(P->microadjust_padded_deletion_flag & 0x1);
+        if (plain) TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag<true>, dim3(nwin), dim3(256), 0, s, *R, *P));
+        else TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag<false>, dim3(nwin), dim3(256), 0, s, *R, *P));
+    }
     if (R->n_generic_fs) {
         TIMED(prof, "k_fam_stat", hipLaunchKernelGGL(k_fam_stat, dim3(nblk(R->n_generic_fs, 64)), dim3(64), 0, s, *R, *P));
         // shallow data: one thread per (unit, position); deep data (many units per position, e.g. UMI panels): the window kernel, whose
