@@ -46,8 +46,9 @@ def algorithmic_bytes_per_position(kernel, depth):
     return table.get(kernel, reads)
 
 
-PROFILE_NAMES = {"k_p2_fast_link": "k_p2_fast<true, false>", "k_p2_fast_base": "k_p2_fast<false, true>",
-                 "k_p2_slow_walk": "k_p2_slow<true>", "k_p2_slow_table": "k_p2_slow<false>"}
+# bench kernel label -> name(s) in the rocprofv3 output (template instantiations; the default workload runs the PLAIN ones)
+PROFILE_NAMES = {"k_p2_fast_link": ("k_p2_fast<true, false, true>", "k_p2_fast<true, false, false>"), "k_p2_fast_base": ("k_p2_fast<false, true, true>", "k_p2_fast<false, true, false>"),
+                 "k_p2_slow_walk": ("k_p2_slow<true>",), "k_p2_slow_table": ("k_p2_slow<false>",), "k_frag": ("k_frag<true>", "k_frag<false>")}
 
 
 def measured_traffic(kernel, tile_kb, depth):
@@ -61,7 +62,10 @@ def measured_traffic(kernel, tile_kb, depth):
         t = json.load(open(path))
         if t.get("_workload") != {"tile_kb": tile_kb, "depth": depth}:
             return None
-        return t[PROFILE_NAMES.get(kernel, kernel)]["traffic_bytes_per_launch"]
+        for name in PROFILE_NAMES.get(kernel, (kernel,)):
+            if name in t:
+                return t[name]["traffic_bytes_per_launch"]
+        return None
     except (KeyError, ValueError):
         return None
 
