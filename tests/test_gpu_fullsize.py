@@ -74,6 +74,47 @@ def test_second_accumulate_reproduces_every_plane(full_tile):
     assert len(rec1["refpos"]) > 10_000 and np.all(np.diff(rec1["refpos"]) >= 0)   # emission order: by position
 
 
+def test_allele_rows_and_call_fields_are_consistent_with_the_planes(full_tile):
+    """Size-independent properties of the InDel allele tables and of the calling step on the full tile:
+    every fragment that votes for an InDel symbol carries exactly one allele of it (rows.bAD1 sums to FRAG_bDP per strand), the
+    per-allele records of a site split that support, a record's NLODQ / QUAL / FILTER / keep follow from its own fields."""
+    reads, R = full_tile
+    rows = R.indel_alleles()
+    assert len(rows) > 200
+    frag = R.fetch("FRAG")
+    fam = R.fetch("FAM")
+    by_site = {}
+    for r in rows:
+        k = (r["strand"], r["symbol"], r["refpos"] - reads["beg"])
+        by_site.setdefault(k, [0, 0]); by_site[k][0] += r["bAD1"]; by_site[k][1] += r["cAD1"]
+    for (s, sym, x), (b, c) in by_site.items():
+        assert b == frag[s, E["UVC_FRAG_bDP"], sym, x], (s, sym, x)
+        assert c == fam[s, E["UVC_FAM_cDP12"], sym, x], (s, sym, x)                 # non-UMI data: every family votes after filtering
+    indel = np.isin(frag[:, E["UVC_FRAG_bDP"], 7:13].sum(axis=0) > 0, True)
+    assert int((frag[:, E["UVC_FRAG_bDP"], 7:13] > 0).sum()) == len(by_site)        # no (strand, symbol, position) without rows
+    rec = R.score(capacity=400_000)
+    ind = rec["gapSa_len"] > 0
+    assert ind.sum() > 100 and (rec["gapSa"][ind] >= 0).all()
+    for i in np.nonzero(ind)[0][:500]:
+        row = rows[rec["gapSa"][i]]
+        assert (row["refpos"], row["symbol"], row["len"]) == (rec["refpos"][i], rec["symbol"][i], rec["gapSa_len"][i])
+    # tumor-only arithmetic of main.cpp:1081-1147 / append_vcf_record on the record's own fields
+    out = rec["out"] == 1
+    assert (out == (rec["symbol"] != 13)).all()                                      # everything but LINK_NN reaches append_vcf_record by default
+    germ = np.where(rec["symbol"] <= 5, 31, 40)
+    assert np.array_equal(rec["vHGQ"][out], (rec["vNLODQ"] - 3 + germ)[out]) and np.array_equal(rec["NLODQ"][out], rec["vHGQ"][out])
+    assert np.array_equal(rec["SomaticQ"][out], np.minimum(rec["TLODQ"], rec["NLODQ"])[out])
+    tl1 = np.maximum(rec["TNBQF3"], rec["TNCQF3"])
+    assert np.array_equal(rec["TLODQ"][out], np.where(tl1 >= 10, tl1, tl1 * 3 - 20)[out])
+    q = rec["QUAL"].view(np.float32)
+    assert (q[out] >= np.maximum(rec["TLODQ"][out], 0) - 1e-3).all() and (q[out] > 0).all()
+    assert np.array_equal(rec["FILTER"][out], np.minimum(np.floor(q[out] / 10), 6).astype(np.int32))
+    alt = out & (rec["symbol"] != rec["refsymbol"])
+    assert (rec["keep"][alt & (q >= 15)] == 1).all() and (rec["keep"][out & ~alt] == 0).all()   # REF alleles are only written with -A or a GERMLINE line
+    assert rec["keep"].sum() > 500
+    assert (rec["germ_GT"] >= 0).all() and (rec["germ_GT"] <= 3).all() and (rec["vNLODQ"] == rec["GL4_0"] - np.maximum(np.maximum(rec["GL4_1"], rec["GL4_2"]), rec["GL4_3"])).all()
+
+
 def test_two_half_tiles_add_up(gpu_lib):
     """Regions are independent: the planes of two tiles laid side by side equal the planes of each tile alone."""
     a = synth.generate_region(seed=5, region_len=20_000, depth=300, beg=2_000_000)
