@@ -75,6 +75,9 @@ uint64_t uvcgpu_strnhash(const char *s, size_t n, uint64_t base);
 uint64_t uvcgpu_hash2hash(uint64_t h1, uint64_t h2);
 /* grouping.cpp:763-786: hashes of the read name and of its UMI ("name#UMI" or "name#UMI#..."); returns umi_kind */
 int uvcgpu_qname_digest(const char *qname, int molecule_tag, int disable_duplex, uint64_t *qname_hash31, uint64_t *qname_hash17, uint64_t *umi_hash31, uint64_t *umi_hash17);
+/* the same for n NUL-terminated names stored back to back (names + off[i]), e.g. UvcBamBatch::qnames / qname_off of uvcio.h */
+int uvcgpu_qname_digest_batch(const char *names, const int64_t *off, int64_t n, int molecule_tag, int disable_duplex,
+                              uint64_t *qname_hash31, uint64_t *qname_hash17, uint64_t *umi_hash31, uint64_t *umi_hash17, uint8_t *umi_kind);
 /* 0 or a negative UVCGPU_E* code (uvcgpu_last_error() has the text) */
 int uvcgpu_group_families(const UvcGroupParams *params, const UvcGroupInput *in, UvcGroupOut *out);
 

@@ -110,6 +110,10 @@ int uvc_oracle_qname_digest(const char *qname, int molecule_tag, int disable_dup
     const bool duplex = ((umi_len % 2 == 1) && ('+' == umi_beg[umi_half]) && (!disable_duplex));
     return 1 | (duplex ? 2 : 0);
 }
+int uvc_oracle_qname_digest_batch(const char *names, const int64_t *off, int64_t n, int molecule_tag, int disable_duplex, uint64_t *q31, uint64_t *q17, uint64_t *u31, uint64_t *u17, uint8_t *umi_kind) {
+    for (int64_t i = 0; i < n; i++) umi_kind[i] = (uint8_t)uvc_oracle_qname_digest(names + off[i], molecule_tag, disable_duplex, &q31[i], &q17[i], &u31[i], &u17[i]);
+    return 0;
+}
 
 int uvc_oracle_group_families(const UvcGroupParams *Pp, const UvcGroupInput *in, UvcGroupOut *out) {
     const UvcGroupParams &P = *Pp;

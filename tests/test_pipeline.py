@@ -1,0 +1,52 @@
+"""BAM + FASTA -> records through the whole chain (uvc_amd/pipeline.py): the HIP libraries against the oracle libraries on files
+written by tests/bamwriter.py, UMI and non-UMI.  The -m "not gpu" part runs the chain on the oracle alone (sanity of the glue)."""
+import io
+
+import numpy as np
+import pytest
+
+from uvc_amd import io as uio, pipeline, synth
+import bamwriter
+
+
+def make_files(d, umi):
+    reads = synth.generate_region(seed=41 + umi, region_len=6000, depth=60 if not umi else 150, beg=30000, umi=bool(umi), snv_every=300, somatic_every=900, indel_every=500)
+    rng = np.random.default_rng(5)
+    umis = None
+    if umi:   # duplex-structured UMIs in the read names, "name#ALPHA+BETA"
+        umis = ["".join("ACGT"[i] for i in rng.integers(0, 4, 6)) + "+" + "".join("ACGT"[i] for i in rng.integers(0, 4, 6)) for _ in range(int(reads["n_fams"]))]
+    recs = bamwriter.records_from_reads(reads, tid=0, umis=umis)
+    chrom_len = reads["end"] + 5000
+    ref = rng.integers(0, 4, chrom_len)
+    seq = "".join("ACGT"[i] for i in ref)
+    seq = seq[:reads["beg"]] + reads["refseq"] + seq[reads["end"]:]
+    bamwriter.write_bam(str(d / ("u%d.bam" % umi)), [("chrT", chrom_len)], recs)
+    bamwriter.write_fasta(str(d / ("u%d.fa" % umi)), [("chrT", seq)])
+    return reads
+
+
+def test_chain_on_the_oracle(tmp_path, oracle_lib):
+    reads = make_files(tmp_path, 0)
+    bam, fa = uio.Bam(str(tmp_path / "u0.bam")), uio.Fasta(str(tmp_path / "u0.fa"))
+    res = pipeline.call_region(oracle_lib, bam, fa, "chrT", reads["beg"] + 500, reads["beg"] + 5500)
+    rec = res["records"]
+    assert res["n_reads"] > 1000 and res["rpos"] == (reads["beg"] + 500, reads["beg"] + 5500)
+    assert rec["keep"].sum() >= 5 and (rec["refpos"] >= reads["beg"] + 499).all() and (rec["refpos"] <= reads["beg"] + 5500).all()
+    out = io.StringIO(); pipeline.write_tsv(res, out)
+    lines = out.getvalue().splitlines()
+    assert len(lines) == 1 + int(rec["keep"].sum()) and lines[1].split("\t")[0] == "chrT"
+    assert pipeline.call_region(oracle_lib, bam, fa, "chrT", 100, 2000) is None          # nothing aligned there
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("umi", [0, 1])
+def test_chain_gpu_equals_oracle(tmp_path, umi, oracle_lib, gpu_lib):
+    from test_gpu_parity import compare_records
+    reads = make_files(tmp_path, umi)
+    bam, fa = uio.Bam(str(tmp_path / ("u%d.bam" % umi))), uio.Fasta(str(tmp_path / ("u%d.fa" % umi)))
+    ro = pipeline.call_region(oracle_lib, bam, fa, "chrT", reads["beg"] + 200, reads["beg"] + 5800, molecule_tag=0)
+    rg = pipeline.call_region(gpu_lib, bam, fa, "chrT", reads["beg"] + 200, reads["beg"] + 5800, molecule_tag=0)
+    assert (ro["n_reads"], ro["n_fams"], ro["rpos"], ro["ext"]) == (rg["n_reads"], rg["n_fams"], rg["rpos"], rg["ext"])
+    assert ro["alleles"] == rg["alleles"]
+    compare_records(ro["records"], rg["records"])
+    assert ro["records"]["keep"].sum() >= 5

@@ -267,6 +267,14 @@ int uvcgpu_qname_digest(const char *qname, int molecule_tag, int disable_duplex,
     return 1 | (((umi_len % 2 == 1) && ('+' == umi_beg[umi_half]) && !disable_duplex) ? 2 : 0);
 }
 
+// the same for a batch of NUL-terminated names (names + off[i]): what a BAM reader hands over
+int uvcgpu_qname_digest_batch(const char *names, const int64_t *off, int64_t n, int molecule_tag, int disable_duplex,
+                              uint64_t *q31, uint64_t *q17, uint64_t *u31, uint64_t *u17, uint8_t *umi_kind) {
+    if (n < 0 || (n > 0 && (!names || !off || !q31 || !q17 || !u31 || !u17 || !umi_kind))) return uvcgpu_set_error(UVCGPU_EINVAL, "bad argument");
+    for (int64_t i = 0; i < n; i++) umi_kind[i] = (uint8_t)uvcgpu_qname_digest(names + off[i], molecule_tag, disable_duplex, &q31[i], &q17[i], &u31[i], &u17[i]);
+    return 0;
+}
+
 int uvcgpu_group_families(const UvcGroupParams *Pp, const UvcGroupInput *in, UvcGroupOut *out) {
     if (!Pp || !in || !out || Pp->struct_size != (int32_t)sizeof(UvcGroupParams)) return uvcgpu_set_error(UVCGPU_EINVAL, "bad argument / UvcGroupParams::struct_size");
     if (Pp->fetch_tend <= Pp->fetch_tbeg || in->n_alns < 0 || in->n_alns >= ((int64_t)1 << 31)) return uvcgpu_set_error(UVCGPU_EINVAL, "bad region or alignment count");

@@ -72,6 +72,28 @@ def qname_digest(lib, qname, molecule_tag=0, disable_duplex=0):
     return (k,) + tuple(x.value for x in v)
 
 
+def qname_digest_batch(lib, names):
+    """list of read names -> (umi_kind uint8[n], hashes uint64[4][n]: qname31, qname17, umi31, umi17), in one library call"""
+    return _digest_batch(lib, names, 0, 0)
+
+
+def _digest_batch(lib, names, molecule_tag, disable_duplex):
+    n = len(names)
+    if hasattr(names, "raw"):                        # uvc_amd.io batch: the names are already one buffer + offsets
+        raw, off = names.raw, np.ascontiguousarray(names.off, dtype=np.int64)
+    else:
+        raw = b"".join(q.encode() + b"\0" for q in names)
+        off = np.zeros(n, np.int64)
+        if n > 1:
+            off[1:] = np.cumsum([len(q.encode()) + 1 for q in names[:-1]])
+    h = np.zeros((4, max(n, 1)), np.uint64); kind = np.zeros(max(n, 1), np.uint8)
+    f = _fn(lib, "qname_digest_batch", C.c_int, [C.c_char_p, C.c_void_p, C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 5)
+    rc = f(raw, off.ctypes.data, n, molecule_tag, disable_duplex, h[0].ctypes.data, h[1].ctypes.data, h[2].ctypes.data, h[3].ctypes.data, kind.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("qname_digest_batch failed: %d" % rc)
+    return kind[:n], h[:, :n]
+
+
 def group_families(lib, params, cols):
     """cols: dict of the UvcGroupInput columns (numpy).  Returns a dict of numpy outputs (trimmed to n_kept / n_fams)."""
     n = len(cols["pos"])

@@ -52,6 +52,23 @@ def _check(rc):
         raise IOError("uvcio error %d: %s" % (rc, dll().uvcio_last_error().decode()))
 
 
+class _Names:
+    """read names of a batch, decoded on demand (a list of two million Python strings is the slowest part of a fetch)"""
+
+    def __init__(self, raw, off):
+        self.raw, self.off = raw, off
+
+    def __len__(self):
+        return len(self.off)
+
+    def __getitem__(self, i):
+        o = int(self.off[i])
+        return self.raw[o:self.raw.index(b"\0", o)].decode()
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
 class Bam:
     def __init__(self, path):
         self.h = C.c_void_p()
@@ -73,7 +90,8 @@ class Bam:
         out = {name: col(getattr(b, name), dt, n) for name, dt in _COLS}
         out["bases"] = col(b.bases, np.uint8, b.n_bases); out["quals"] = col(b.quals, np.uint8, b.n_bases); out["cigars"] = col(b.cigars, np.uint32, b.n_cigar_ops)
         raw = C.string_at(b.qnames, b.n_qname_bytes) if b.n_qname_bytes else b""
-        out["qnames"] = [raw[o:raw.index(b"\0", o)].decode() for o in out["qname_off"]]
+        out["qnames_raw"] = raw                      # NUL-terminated names back to back, qname_off[i] = start of the i-th
+        out["qnames"] = _Names(raw, out["qname_off"])
         out["n_alns"] = n
         return out
 

@@ -1,0 +1,108 @@
+"""BAM + FASTA -> scored records for one region: the chain process_batch runs (main.cpp:458-1193), on the C ABIs of this package.
+
+    fetch reads (uvcio, replaces sam_itr_queryi / faidx_fetch_seq)        grouping.cpp:664, main.cpp:529-531
+    family assignment (uvcgpu_group_families)                              grouping.cpp:608-997
+    region bounds + reference (+-100 bp STR halo)                          main.cpp:523-552
+    apply_bq_err_correction3 / updateByRegion3Aln / scoring + calling      main.cpp:567-1168
+
+`lib` is the HIP library (`region.gpu_lib()`); tests also run the chain on the oracle library to compare.  Text output here is a
+tab-separated table of the integer fields (the reference's VCF FORMAT strings are not rebuilt).
+
+    python -m uvc_amd.pipeline in.bam ref.fa chr20:1000000-1100000 > out.tsv
+"""
+import sys
+
+import numpy as np
+
+from . import _ffi, group, io as uio, region
+
+MAX_INSERT_SIZE = 2000   # common.hpp:64
+MAX_STR_N_BASES = 100    # common.hpp:63
+SYMBOL_DESC = ["A", "C", "G", "T", "N", "*", "<LR>", "<LD3P>", "<LD2>", "<LD1>", "<LI3P>", "<LI2>", "<LI1>", "*"]
+FILTERS = ["Q10", "Q20", "Q30", "Q40", "Q50", "Q60", "PASS"]
+
+
+def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None, molecule_tag=0, disable_duplex=0, correct_bq=True, all_out=False, keep_handle=False):
+    """Scores [beg, end) of `chrom`.  Returns None when no read passes the filters (process_batch returns -1, main.cpp:520-523), else a
+    dict: records (field -> int32 array), alleles (InDel allele rows), score range, region handle (if keep_handle)."""
+    tid = bam.tid(chrom)
+    tlen = bam.refs[tid][1]
+    cols = bam.fetch(tid, max(0, beg - MAX_INSERT_SIZE), end + MAX_INSERT_SIZE)
+    n = cols["n_alns"]
+    if n == 0:
+        return None
+    kind, h = group._digest_batch(lib, cols["qnames"], molecule_tag, disable_duplex)
+    gp = group_params if group_params is not None else group.default_params(lib, beg, end, platform=(params.inferred_sequencing_platform if params is not None else 1))
+    gp.fetch_tbeg, gp.fetch_tend = beg, end
+    g = group.group_families(lib, gp, dict(tid=cols["tid"], pos=cols["pos"], endpos=cols["endpos"], mtid=cols["mtid"], mpos=cols["mpos"], isize=cols["isize"], flag=cols["flag"], mapq=cols["mapq"],
+                                           qname_hash31=h[0], qname_hash17=h[1], umi_hash31=h[2], umi_hash17=h[3], umi_kind=kind))
+    if g["n_kept"] == 0:
+        return None
+    o = g["order"]
+    bam_beg, bam_end = g["ext_beg"], g["ext_end"]                                      # bam_inclu_beg_pos / bam_exclu_end_pos
+    rpos_beg, rpos_end = max(beg, bam_beg), min(end, bam_end)                          # main.cpp:523-524
+    ext_beg = max(0, max(min(beg, bam_beg) - MAX_STR_N_BASES, 0))                      # main.cpp:525
+    ext_end = min(tlen, max(end, bam_end) + MAX_STR_N_BASES)                           # main.cpp:526
+    refseq = fasta.fetch(chrom, ext_beg, ext_end)
+    reads = dict(n_reads=int(g["n_kept"]), pos=cols["pos"][o], mpos=cols["mpos"][o], isize=g["isize_norm"][o], flag=cols["flag"][o], mapq=cols["mapq"][o], nm=cols["nm"][o],
+                 l_qseq=cols["l_qseq"][o], seq_off=cols["seq_off"][o], cigar_off=cols["cigar_off"][o], n_cigar=cols["n_cigar"][o],
+                 frag_id=g["frag_id"], fam_id=g["fam_id"], fam_strand=g["fam_strand"], n_fams=int(g["n_fams"]), fam_dflag=g["fam_dflag"],
+                 bases=cols["bases"], quals=cols["quals"], cigars=cols["cigars"])
+    p = params if params is not None else region.default_params(lib)
+    R = region.Region(lib, p, tid, ext_beg, ext_end, refseq)
+    R.set_reads(reads)
+    if correct_bq:
+        R.correct_bq()
+    R.accumulate()
+    is_amplicon = (g["n_amplicon"] * 2 > g["n_kept"])                                  # !is_by_capture, main.cpp:507-508
+    rec = R.score(all_out=all_out, pos_beg=rpos_beg, pos_end=min(rpos_end + 1, ext_end - 0), is_amplicon=bool(is_amplicon))
+    out = dict(records=rec, alleles=R.indel_alleles(), rpos=(rpos_beg, rpos_end), ext=(ext_beg, ext_end), n_reads=int(g["n_kept"]), n_fams=int(g["n_fams"]), chrom=chrom, refseq=refseq)
+    if keep_handle:
+        out["region"] = R
+    else:
+        R.close()
+    return out
+
+
+def write_tsv(res, fh, kept_only=True):
+    rec, rows = res["records"], res["alleles"]
+    ext_beg = res["ext"][0]
+    fh.write("#CHROM\tPOS\tREF\tALT\tQUAL\tFILTER\tSYMBOL\tDP\tAD\tbDP\tbAD\tcVQ1\tcVQ2\tTLODQ\tNLODQ\tGT_IDX\tGQ\n")
+    q = rec["QUAL"].view(np.float32)
+    for i in range(len(rec["refpos"])):
+        if kept_only and not rec["keep"][i]:
+            continue
+        sym, refpos = int(rec["symbol"][i]), int(rec["refpos"][i])
+        x = refpos - ext_beg
+        if sym <= 5:
+            pos, ref, alt = refpos + 1, res["refseq"][x], SYMBOL_DESC[sym]
+        else:                                                                          # append_vcf_record, main.hpp:6066-6090
+            pos, ref = refpos, (res["refseq"][x - 1] if x > 0 else "n")
+            alt = ref
+            row = rows[rec["gapSa"][i]] if rec["gapSa"][i] >= 0 else None
+            if row is None: alt = SYMBOL_DESC[sym]
+            elif row["seq"] is not None: alt = ref + row["seq"]
+            else: ref = ref + res["refseq"][x:x + row["len"]]
+        fh.write("%s\t%d\t%s\t%s\t%.6f\t%s\t%s\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n" % (
+            res["chrom"], pos, ref, alt, q[i], FILTERS[int(rec["FILTER"][i])], SYMBOL_DESC[sym], rec["DP"][i], rec["AD"][i], rec["bDP"][i], rec["bAD"][i],
+            rec["cVQ1"][i], rec["cVQ2"][i], rec["TLODQ"][i], rec["NLODQ"][i], rec["germ_GT"][i], rec["germ_GQ"][i]))
+
+
+def main(argv):
+    if len(argv) != 4:
+        sys.stderr.write(__doc__); return 2
+    chrom, rng = argv[3].split(":")
+    beg, end = (int(v.replace(",", "")) for v in rng.split("-"))
+    lib = region.gpu_lib()
+    if lib.dll.uvcgpu_init(0) != 0:
+        raise RuntimeError(lib.last_error())
+    bam, fasta = uio.Bam(argv[1]), uio.Fasta(argv[2])
+    res = call_region(lib, bam, fasta, chrom, beg, end)
+    if res is None:
+        sys.stderr.write("no reads pass the filters in %s\n" % argv[3]); return 1
+    write_tsv(res, sys.stdout)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))
