@@ -36,6 +36,16 @@ def test_every_declared_symbol_is_exported(dll):
         assert hasattr(dll, n), n
 
 
+def test_reader_library_exports_its_header():
+    """libuvcio.so (host-only file readers) exports every entry point of include/uvcio.h"""
+    from uvc_amd import io as uio
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "uvcio.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(uvcio_[a-z_0-9]+)\s*\(", txt)))
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(uio.dll(), n), n
+
+
 def test_no_cpu_fallback(dll):
     import torch
     if torch.cuda.is_available():

@@ -36,6 +36,13 @@ def test_chain_on_the_oracle(tmp_path, oracle_lib):
     lines = out.getvalue().splitlines()
     assert len(lines) == 1 + int(rec["keep"].sum()) and lines[1].split("\t")[0] == "chrT"
     assert pipeline.call_region(oracle_lib, bam, fa, "chrT", 100, 2000) is None          # nothing aligned there
+    tiles = list(pipeline.call_contig(oracle_lib, bam, fa, "chrT", tile=2500))
+    assert len(tiles) == 3 and [t["rpos"][0] for t in tiles] == sorted(t["rpos"][0] for t in tiles)
+    # a position scored in two different tilings gets the same record: every tile re-reads its own halo
+    a = {(int(p), int(s)): int(q) for t in tiles for p, s, q in zip(t["records"]["refpos"], t["records"]["symbol"], t["records"]["TLODQ"])}
+    b = {(int(p), int(s)): int(q) for p, s, q in zip(rec["refpos"], rec["symbol"], rec["TLODQ"])}
+    common = [k for k in b if k in a and reads["beg"] + 600 < k[0] < reads["beg"] + 5400 and abs((k[0] - 30000) % 2500) > 150 and abs((k[0] - 30000) % 2500 - 2500) > 150]
+    assert len(common) >= 50 and all(a[k] == b[k] for k in common)
 
 
 @pytest.mark.gpu

@@ -8,7 +8,7 @@
 `lib` is the HIP library (`region.gpu_lib()`); tests also run the chain on the oracle library to compare.  Text output here is a
 tab-separated table of the integer fields (the reference's VCF FORMAT strings are not rebuilt).
 
-    python -m uvc_amd.pipeline in.bam ref.fa chr20:1000000-1100000 > out.tsv
+    python -m uvc_amd.pipeline in.bam ref.fa chr20:1000000-1100000 > out.tsv      (or just `chr20`: the whole contig in 1 Mb tiles)
 """
 import sys
 
@@ -64,10 +64,23 @@ def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None
     return out
 
 
-def write_tsv(res, fh, kept_only=True):
+def call_contig(lib, bam, fasta, chrom, beg=0, end=None, tile=1_000_000, **kw):
+    """Tiles [beg, end) of a contig (default: all of it) and yields the result of every tile that has reads.  The reference cuts its
+    regions by read and position counts (SamIter, grouping.cpp:28-67, 157-314); results at a position do not depend on the cut because
+    every region re-reads its own +-2000 bp halo, so fixed tiles of the size the state slab is laid out for are used here."""
+    tlen = bam.refs[bam.tid(chrom)][1]
+    end = tlen if end is None else min(end, tlen)
+    for b in range(beg, end, tile):
+        res = call_region(lib, bam, fasta, chrom, b, min(b + tile, end), **kw)
+        if res is not None:
+            yield res
+
+
+def write_tsv(res, fh, kept_only=True, header=True):
     rec, rows = res["records"], res["alleles"]
     ext_beg = res["ext"][0]
-    fh.write("#CHROM\tPOS\tREF\tALT\tQUAL\tFILTER\tSYMBOL\tDP\tAD\tbDP\tbAD\tcVQ1\tcVQ2\tTLODQ\tNLODQ\tGT_IDX\tGQ\n")
+    if header:
+        fh.write("#CHROM\tPOS\tREF\tALT\tQUAL\tFILTER\tSYMBOL\tDP\tAD\tbDP\tbAD\tcVQ1\tcVQ2\tTLODQ\tNLODQ\tGT_IDX\tGQ\n")
     q = rec["QUAL"].view(np.float32)
     for i in range(len(rec["refpos"])):
         if kept_only and not rec["keep"][i]:
@@ -91,16 +104,17 @@ def write_tsv(res, fh, kept_only=True):
 def main(argv):
     if len(argv) != 4:
         sys.stderr.write(__doc__); return 2
-    chrom, rng = argv[3].split(":")
-    beg, end = (int(v.replace(",", "")) for v in rng.split("-"))
+    chrom, _, rng = argv[3].partition(":")
+    beg, end = ((int(v.replace(",", "")) for v in rng.split("-")) if rng else (0, None))
     lib = region.gpu_lib()
     if lib.dll.uvcgpu_init(0) != 0:
         raise RuntimeError(lib.last_error())
     bam, fasta = uio.Bam(argv[1]), uio.Fasta(argv[2])
-    res = call_region(lib, bam, fasta, chrom, beg, end)
-    if res is None:
+    n = 0
+    for res in call_contig(lib, bam, fasta, chrom, beg, end):
+        write_tsv(res, sys.stdout, header=(n == 0)); n += 1
+    if n == 0:
         sys.stderr.write("no reads pass the filters in %s\n" % argv[3]); return 1
-    write_tsv(res, sys.stdout)
     return 0
 
 
