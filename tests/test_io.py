@@ -37,9 +37,12 @@ def expected(recs, tid, beg, end):
     return out
 
 
+@pytest.mark.parametrize("batch", [None, "65536", "70001"])
 @pytest.mark.parametrize("name", ["t.bam", "noidx.bam"])
-def test_fetch_equals_the_overlap_definition(files, name):
+def test_fetch_equals_the_overlap_definition(files, name, batch, monkeypatch):
     d, refs, recs, _ = files
+    if batch: monkeypatch.setenv("UVCIO_BATCH_BYTES", batch)     # several batches per query: records and blocks straddle them
+    else: monkeypatch.delenv("UVCIO_BATCH_BYTES", raising=False)
     b = uio.Bam(str(d / name))
     assert b.refs == refs and b.has_index == (name == "t.bam")
     for tid, beg, end in [(1, 100000, 140000), (1, 118000, 121000), (1, 0, 100001), (1, 139990, 200000), (0, 0, 5000), (0, 100, 101), (1, 16384 * 7, 16384 * 7 + 1), (1, 150000, 160000)]:

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 static thread_local std::string g_err;
@@ -187,42 +188,43 @@ extern "C" int64_t uvcio_bam_ref_len(const uvcio_bam_t *b, int32_t tid) { return
 extern "C" int uvcio_bam_has_index(const uvcio_bam_t *b) { return b && b->has_index; }
 extern "C" void uvcio_bam_close(uvcio_bam_t *b) { if (!b) return; if (b->z.fp) fclose(b->z.fp); delete b; }
 
-// reads the alignment at the current position into b->rec; 1 = got one, 0 = end of file, < 0 = error
-static int next_record(uvcio_bam *b) {
-    uint8_t h[4];
-    const size_t got = b->z.read(h, 4);
-    if (got == 0) return 0;
-    if (got != 4) return fail(UVCGPU_EINVAL, "truncated BAM record");
-    const uint32_t bs = le32(h);
-    if (bs < 32 || bs > (1u << 28)) return fail(UVCGPU_EINVAL, "implausible BAM record size");
-    b->rec.resize(bs);
-    if (b->z.read(b->rec.data(), bs) != bs) return fail(UVCGPU_EINVAL, "truncated BAM record");
-    return 1;
-}
+// ---- region query: compressed blocks are read in batches, inflated in parallel (BGZF blocks are independent), the records of a
+// batch are located by one sequential walk over their size fields and decoded in parallel into the output columns ----
+namespace {
 
-// appends b->rec to the batch when it overlaps [beg, end) of tid; *past = the record starts at or behind `end` (or on a later reference)
-static int take_record(uvcio_bam *b, int32_t want_tid, int64_t beg, int64_t end, bool *past) {
-    static const uint8_t nt16_int[16] = { 4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4 };   // seq_nt16_int of htslib: =ACMGRSVTWYHKDBN
-    const uint8_t *r = b->rec.data();
-    const size_t bs = b->rec.size();
-    const int32_t tid = (int32_t)le32(r), pos = (int32_t)le32(r + 4);
-    const int l_name = r[8], mq = r[9];
-    const int n_cig = le16(r + 12), flg = le16(r + 14);
-    const int32_t l_seq = (int32_t)le32(r + 16), mtid = (int32_t)le32(r + 20), mpos = (int32_t)le32(r + 24), tlen = (int32_t)le32(r + 28);
-    *past = (tid > want_tid || tid < 0 || (tid == want_tid && pos >= end));
-    if (tid != want_tid) return 0;
-    const size_t o_cig = 32 + (size_t)l_name, o_seq = o_cig + 4 * (size_t)n_cig, o_qual = o_seq + ((size_t)l_seq + 1) / 2, o_aux = o_qual + (size_t)l_seq;
-    if (l_seq < 0 || o_aux > bs) return fail(UVCGPU_EINVAL, "corrupt BAM record");
-    int64_t e = pos;
-    for (int k = 0; k < n_cig; k++) {
-        const uint32_t c = le32(r + o_cig + 4 * (size_t)k); const int op = (int)(c & 0xF);
-        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) e += (int64_t)(c >> 4);   // M D N = X consume the reference
-    }
-    if (e == pos) e = pos + 1;
-    if (!(pos < end && e > beg)) return 0;
-    // NM:  aux = tag[2] type value ...
-    int32_t nm = -1;
-    for (size_t o = o_aux; o + 3 <= bs;) {
+struct BlockRef { int64_t addr; uint32_t csize /* whole block */, isize; size_t in_off /* in the batch's compressed buffer */, out_off /* in its inflated buffer */; };
+struct RecRef { const uint8_t *r; uint32_t size; int32_t endpos; int64_t base_off, cig_off, name_off; };
+
+int n_threads() {
+    static const int n = [] { const char *e = getenv("UVCIO_THREADS"); int v = e ? atoi(e) : (int)std::thread::hardware_concurrency(); return std::max(1, std::min(v, 32)); }();
+    return n;
+}
+template <class F> void parallel_for(size_t n, F f) {   // f(first, last) on contiguous slices
+    const size_t nt = std::min<size_t>((size_t)n_threads(), std::max<size_t>(n / 64, 1));
+    if (nt <= 1) { f((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; t++) th.emplace_back([=] { f(n * t / nt, n * (t + 1) / nt); });
+    for (std::thread &x : th) x.join();
+}
+bool inflate_block(const uint8_t *blk, uint32_t csize, uint8_t *dst, uint32_t isize) {
+    const int xlen = le16(blk + 10);
+    const uint8_t *cdata = blk + 12 + xlen;
+    const int clen = (int)csize - xlen - 20;
+    if (clen < 0) return false;
+    if (isize == 0) return true;
+    z_stream zs; memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<uint8_t *>(cdata); zs.avail_in = (uInt)clen; zs.next_out = dst; zs.avail_out = isize;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    return rc == Z_STREAM_END && zs.total_out == isize && (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, isize) == le32(blk + csize - 8);
+}
+const uint8_t NT16_INT[16] = { 4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4 };   // seq_nt16_int of htslib: =ACMGRSVTWYHKDBN
+
+// NM aux tag of the record at r (bam_aux_get + bam_aux2i), -1 if absent; false on a corrupt aux area
+bool aux_nm(const uint8_t *r, size_t bs, size_t o, int32_t &nm) {
+    nm = -1;
+    while (o + 3 <= bs) {
         const char t0 = (char)r[o], t1 = (char)r[o + 1], ty = (char)r[o + 2];
         o += 3;
         size_t sz = 0; long long val = 0; bool is_int = true;
@@ -237,27 +239,21 @@ static int take_record(uvcio_bam *b, int32_t want_tid, int64_t beg, int64_t end,
             case 'f': sz = 4; is_int = false; break;
             case 'Z': case 'H': { size_t k = o; while (k < bs && r[k]) k++; sz = k - o + 1; is_int = false; break; }
             case 'B': {
-                if (o + 5 > bs) return fail(UVCGPU_EINVAL, "corrupt aux array");
+                if (o + 5 > bs) return false;
                 const char sub = (char)r[o]; const uint32_t cnt = le32(r + o + 1);
                 const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
                 sz = 5 + es * (size_t)cnt; is_int = false; break;
             }
-            default: return fail(UVCGPU_EINVAL, "unknown aux type in BAM record");
+            default: return false;
         }
-        if (o + sz > bs) return fail(UVCGPU_EINVAL, "corrupt aux field");
+        if (o + sz > bs) return false;
         if (t0 == 'N' && t1 == 'M' && is_int) nm = (int32_t)val;
         o += sz;
     }
-    b->tid.push_back(tid); b->pos.push_back(pos); b->endpos.push_back((int32_t)e); b->mtid.push_back(mtid); b->mpos.push_back(mpos); b->isize.push_back(tlen);
-    b->flag.push_back((uint16_t)flg); b->mapq.push_back((uint8_t)mq); b->nm.push_back(nm); b->l_qseq.push_back(l_seq); b->n_cigar.push_back(n_cig);
-    b->seq_off.push_back((int64_t)b->bases.size()); b->cigar_off.push_back((int64_t)b->cigars.size()); b->qname_off.push_back((int64_t)b->qnames.size());
-    for (int k = 0; k < n_cig; k++) b->cigars.push_back(le32(r + o_cig + 4 * (size_t)k));
-    for (int32_t i = 0; i < l_seq; i++) { const uint8_t by = r[o_seq + (size_t)(i >> 1)]; b->bases.push_back(nt16_int[(i & 1) ? (by & 0xF) : (by >> 4)]); }
-    b->quals.insert(b->quals.end(), r + o_qual, r + o_qual + l_seq);
-    b->qnames.insert(b->qnames.end(), (const char *)r + 32, (const char *)r + 32 + l_name);
-    if (l_name == 0 || r[32 + l_name - 1] != 0) b->qnames.push_back('\0');
-    return 0;
+    return true;
 }
+
+}  // namespace
 
 extern "C" int uvcio_bam_fetch(uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t end, UvcBamBatch *out) {
     if (!b || !out) return fail(UVCGPU_EINVAL, "null argument");
@@ -266,7 +262,6 @@ extern "C" int uvcio_bam_fetch(uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t
     if (end > b->ref_lens[tid]) end = b->ref_lens[tid];
     b->tid.clear(); b->pos.clear(); b->endpos.clear(); b->mtid.clear(); b->mpos.clear(); b->isize.clear(); b->nm.clear(); b->l_qseq.clear(); b->n_cigar.clear();
     b->flag.clear(); b->mapq.clear(); b->seq_off.clear(); b->cigar_off.clear(); b->qname_off.clear(); b->bases.clear(); b->quals.clear(); b->cigars.clear(); b->qnames.clear();
-    int rc = 0;
     if (end > beg) {
         std::vector<Chunk> chunks;
         if (b->has_index) {
@@ -280,17 +275,111 @@ extern "C" int uvcio_bam_fetch(uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t
             for (const Chunk &c : chunks) { if (!merged.empty() && c.beg <= merged.back().end) merged.back().end = std::max(merged.back().end, c.end); else merged.push_back(c); }
             chunks.swap(merged);
         } else chunks.push_back(Chunk{ b->first_record, ~0ull });
+        // compressed bytes per batch (UVCIO_BATCH_BYTES: tests use small batches to exercise records that straddle two)
+        const char *be = getenv("UVCIO_BATCH_BYTES");
+        const size_t BATCH = (be && atol(be) >= (1 << 16)) ? (size_t)atol(be) : ((size_t)64 << 20);
+        std::vector<uint8_t> comp, infl, carry;
+        std::vector<BlockRef> blocks;
+        std::vector<RecRef> recs;
         bool past = false;
         for (const Chunk &c : chunks) {
             if (past) break;
-            if (!b->z.seek(c.beg)) return fail(UVCGPU_EINVAL, "bad virtual offset in the index");
-            while (b->z.tell() < c.end) {
-                rc = next_record(b);
-                if (rc <= 0) break;
-                rc = take_record(b, tid, beg, end, &past);
-                if (rc < 0 || past) break;
+            int64_t addr = (int64_t)(c.beg >> 16);
+            size_t skip = (size_t)(c.beg & 0xFFFF);            // bytes of the first block that lie in front of the chunk
+            const int64_t last_addr = (c.end == ~0ull ? INT64_MAX : (int64_t)(c.end >> 16));
+            const size_t last_u = (size_t)(c.end & 0xFFFF);
+            carry.clear();
+            bool chunk_done = false;
+            while (!chunk_done && !past) {
+                // 1. read whole blocks of this batch
+                if (fseeko(b->z.fp, (off_t)addr, SEEK_SET) != 0) return fail(UVCGPU_EINVAL, "seek failed");
+                comp.resize(BATCH + (1 << 16));
+                const size_t got = fread(comp.data(), 1, comp.size(), b->z.fp);
+                blocks.clear();
+                size_t o = 0, out_bytes = 0;
+                bool hit_last = false;
+                while (o + 18 <= got && !hit_last) {
+                    const uint8_t *h = comp.data() + o;
+                    if (h[0] != 31 || h[1] != 139 || !(h[3] & 4)) return fail(UVCGPU_EINVAL, "not a BGZF block where the index points");
+                    const int xlen = le16(h + 10);
+                    if (o + 12 + (size_t)xlen > got) break;
+                    int bsize = -1;
+                    for (int i = 0; i + 4 <= xlen;) { const int slen = le16(h + 12 + i + 2); if (h[12 + i] == 'B' && h[12 + i + 1] == 'C' && slen == 2) bsize = le16(h + 12 + i + 4); i += 4 + slen; }
+                    if (bsize < 0) return fail(UVCGPU_EINVAL, "BGZF block without a BC field");
+                    const size_t csize = (size_t)bsize + 1;
+                    if (o + csize > got) break;                 // incomplete block: next batch starts here
+                    const uint32_t isize = le32(h + csize - 4);
+                    blocks.push_back(BlockRef{ addr + (int64_t)o, (uint32_t)csize, isize, o, out_bytes });
+                    out_bytes += isize; o += csize;
+                    if (addr + (int64_t)(o - csize) >= last_addr) hit_last = true;   // the block that holds the chunk end
+                    if (o >= BATCH) break;
+                }
+                if (blocks.empty()) { if (got >= 18 && o == 0 && got == comp.size()) return fail(UVCGPU_EINVAL, "BGZF block larger than the batch"); chunk_done = true; break; }
+                // 2. inflate in parallel
+                infl.resize(carry.size() + out_bytes);
+                if (!carry.empty()) memcpy(infl.data(), carry.data(), carry.size());
+                bool ok = true;
+                parallel_for(blocks.size(), [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; i++) if (!inflate_block(comp.data() + blocks[i].in_off, blocks[i].csize, infl.data() + carry.size() + blocks[i].out_off, blocks[i].isize)) ok = false; });
+                if (!ok) return fail(UVCGPU_EINVAL, "corrupt BGZF block (inflate / CRC)");
+                // the usable byte range of this batch
+                size_t lo = (carry.empty() ? skip : 0), hi = infl.size();
+                skip = 0;
+                if (hit_last) { const BlockRef &L = blocks.back(); if (L.addr == last_addr) hi = carry.size() + L.out_off + std::min<size_t>(last_u, L.isize); chunk_done = true; }
+                if (got < comp.size() && o >= got - std::min<size_t>(got, 17)) chunk_done = true;   // end of file
+                // 3. sequential walk over the record sizes: which records overlap, where their outputs go
+                recs.clear();
+                size_t p = lo;
+                int64_t nb = (int64_t)b->bases.size(), nc = (int64_t)b->cigars.size(), nq = (int64_t)b->qnames.size();
+                while (p + 4 <= hi) {
+                    const uint32_t bs = le32(infl.data() + p);
+                    if (bs < 32 || bs > (1u << 28)) return fail(UVCGPU_EINVAL, "implausible BAM record size");
+                    if (p + 4 + bs > hi) break;
+                    const uint8_t *r = infl.data() + p + 4;
+                    const int32_t rt = (int32_t)le32(r), rp = (int32_t)le32(r + 4);
+                    const int l_name = r[8], n_cig = le16(r + 12); const int32_t l_seq = (int32_t)le32(r + 16);
+                    if (rt > tid || rt < 0 || (rt == tid && rp >= end)) { past = true; break; }
+                    if (rt == tid) {
+                        const size_t o_cig = 32 + (size_t)l_name;
+                        if (l_seq < 0 || o_cig + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq > bs) return fail(UVCGPU_EINVAL, "corrupt BAM record");
+                        int64_t e = rp;
+                        for (int k = 0; k < n_cig; k++) { const uint32_t cg = le32(r + o_cig + 4 * (size_t)k); const int op = (int)(cg & 0xF); if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) e += (int64_t)(cg >> 4); }
+                        if (e == rp) e = rp + 1;
+                        if (rp < end && e > beg) {
+                            recs.push_back(RecRef{ r, bs, (int32_t)e, nb, nc, nq });
+                            nb += l_seq; nc += n_cig; nq += l_name + ((l_name == 0 || r[32 + l_name - 1] != 0) ? 1 : 0);
+                        }
+                    }
+                    p += 4 + bs;
+                }
+                // 4. decode in parallel
+                const size_t r0 = b->pos.size(), nr = recs.size();
+                b->tid.resize(r0 + nr); b->pos.resize(r0 + nr); b->endpos.resize(r0 + nr); b->mtid.resize(r0 + nr); b->mpos.resize(r0 + nr); b->isize.resize(r0 + nr); b->nm.resize(r0 + nr);
+                b->l_qseq.resize(r0 + nr); b->n_cigar.resize(r0 + nr); b->flag.resize(r0 + nr); b->mapq.resize(r0 + nr); b->seq_off.resize(r0 + nr); b->cigar_off.resize(r0 + nr); b->qname_off.resize(r0 + nr);
+                b->bases.resize((size_t)nb); b->quals.resize((size_t)nb); b->cigars.resize((size_t)nc); b->qnames.resize((size_t)nq);
+                bool aux_ok = true;
+                parallel_for(nr, [&](size_t i0, size_t i1) {
+                    for (size_t i = i0; i < i1; i++) {
+                        const RecRef &q = recs[i]; const uint8_t *r = q.r; const size_t k = r0 + i;
+                        const int l_name = r[8], n_cig = le16(r + 12); const int32_t l_seq = (int32_t)le32(r + 16);
+                        const size_t o_cig = 32 + (size_t)l_name, o_seq = o_cig + 4 * (size_t)n_cig, o_qual = o_seq + ((size_t)l_seq + 1) / 2, o_aux = o_qual + (size_t)l_seq;
+                        b->tid[k] = (int32_t)le32(r); b->pos[k] = (int32_t)le32(r + 4); b->endpos[k] = q.endpos; b->mapq[k] = r[9]; b->flag[k] = le16(r + 14);
+                        b->mtid[k] = (int32_t)le32(r + 20); b->mpos[k] = (int32_t)le32(r + 24); b->isize[k] = (int32_t)le32(r + 28);
+                        b->l_qseq[k] = l_seq; b->n_cigar[k] = n_cig; b->seq_off[k] = q.base_off; b->cigar_off[k] = q.cig_off; b->qname_off[k] = q.name_off;
+                        int32_t nm; if (!aux_nm(r, q.size, o_aux, nm)) aux_ok = false;
+                        b->nm[k] = nm;
+                        for (int c = 0; c < n_cig; c++) b->cigars[(size_t)q.cig_off + c] = le32(r + o_cig + 4 * (size_t)c);
+                        uint8_t *bd = b->bases.data() + q.base_off;
+                        for (int32_t j = 0; j < l_seq; j++) { const uint8_t by = r[o_seq + (size_t)(j >> 1)]; bd[j] = NT16_INT[(j & 1) ? (by & 0xF) : (by >> 4)]; }
+                        memcpy(b->quals.data() + q.base_off, r + o_qual, (size_t)l_seq);
+                        memcpy(b->qnames.data() + q.name_off, r + 32, (size_t)l_name);
+                        if (l_name == 0 || r[32 + l_name - 1] != 0) b->qnames[(size_t)q.name_off + l_name] = '\0';
+                    }
+                });
+                if (!aux_ok) return fail(UVCGPU_EINVAL, "corrupt aux fields in a BAM record");
+                // 5. what is left of a record that continues in the next batch
+                if (!chunk_done && !past) { std::vector<uint8_t> rest(infl.begin() + (long)p, infl.begin() + (long)hi); carry.swap(rest); addr = blocks.back().addr + blocks.back().csize; }
+                else if (!past && p < hi && hit_last && blocks.back().addr == last_addr) { /* the chunk ends inside a record only in a broken index */ }
             }
-            if (rc < 0) return rc;
         }
     }
     out->n_alns = (int64_t)b->pos.size();
