@@ -7,6 +7,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -94,6 +95,12 @@ struct Bgzf {
     }
 };
 
+// grow-only byte buffer without value initialisation (a fresh std::vector of tens of MB costs its page faults on every query)
+struct RawBuf {
+    uint8_t *p = nullptr; size_t cap = 0;
+    uint8_t *need(size_t n) { if (n > cap) { cap = n + n / 4 + 4096; p = (uint8_t *)realloc(p, cap); } return p; }
+    ~RawBuf() { free(p); }
+};
 struct Chunk { uint64_t beg, end; };
 struct RefIndex { std::map<uint32_t, std::vector<Chunk>> bins; std::vector<uint64_t> linear; };
 
@@ -121,7 +128,7 @@ struct uvcio_bam {
     std::vector<uint16_t> flag; std::vector<uint8_t> mapq;
     std::vector<int64_t> seq_off, cigar_off, qname_off;
     std::vector<uint8_t> bases, quals; std::vector<uint32_t> cigars; std::vector<char> qnames;
-    std::vector<uint8_t> rec;
+    RawBuf comp, infl;             // compressed / inflated bytes of the current batch (kept between queries)
 };
 
 static bool load_bai(uvcio_bam *b, const std::string &path) {
@@ -272,13 +279,20 @@ extern "C" int uvcio_bam_fetch(uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t
             for (uint32_t bin : bins) { auto it = ri.bins.find(bin); if (it != ri.bins.end()) for (const Chunk &c : it->second) if (c.end > min_off) chunks.push_back(Chunk{ std::max(c.beg, min_off), c.end }); }
             std::sort(chunks.begin(), chunks.end(), [](const Chunk &a, const Chunk &c) { return a.beg < c.beg; });
             std::vector<Chunk> merged;
-            for (const Chunk &c : chunks) { if (!merged.empty() && c.beg <= merged.back().end) merged.back().end = std::max(merged.back().end, c.end); else merged.push_back(c); }
+            // chunks that continue in the block behind the previous one are read as one run (an index written record by record ends every
+            // chunk at its block's end; what lies between is at most one block of records, which the overlap test drops again)
+            for (const Chunk &c : chunks) { if (!merged.empty() && (int64_t)(c.beg >> 16) <= (int64_t)(merged.back().end >> 16) + 65536) merged.back().end = std::max(merged.back().end, c.end); else merged.push_back(c); }
             chunks.swap(merged);
         } else chunks.push_back(Chunk{ b->first_record, ~0ull });
         // compressed bytes per batch (UVCIO_BATCH_BYTES: tests use small batches to exercise records that straddle two)
         const char *be = getenv("UVCIO_BATCH_BYTES");
         const size_t BATCH = (be && atol(be) >= (1 << 16)) ? (size_t)atol(be) : ((size_t)64 << 20);
-        std::vector<uint8_t> comp, infl, carry;
+        const bool timing = (getenv("UVCIO_TIMING") != nullptr);
+        double t_read = 0, t_inf = 0, t_walk = 0, t_dec = 0;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        std::vector<uint8_t> carry;
+        int64_t file_size = -1;
+        if (fseeko(b->z.fp, 0, SEEK_END) == 0) file_size = (int64_t)ftello(b->z.fp);
         std::vector<BlockRef> blocks;
         std::vector<RecRef> recs;
         bool past = false;
@@ -292,14 +306,20 @@ extern "C" int uvcio_bam_fetch(uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t
             bool chunk_done = false;
             while (!chunk_done && !past) {
                 // 1. read whole blocks of this batch
+                double t0 = now();
                 if (fseeko(b->z.fp, (off_t)addr, SEEK_SET) != 0) return fail(UVCGPU_EINVAL, "seek failed");
-                comp.resize(BATCH + (1 << 16));
-                const size_t got = fread(comp.data(), 1, comp.size(), b->z.fp);
+                // no more than the chunk (plus its last block) or the rest of the file
+                size_t want = BATCH + (1 << 16);
+                if (last_addr != INT64_MAX) want = std::min<size_t>(want, (size_t)(last_addr - addr) + (1 << 16) + 18);
+                if (file_size >= 0) want = std::min<size_t>(want, (size_t)std::max<int64_t>(file_size - addr, 0));
+                uint8_t *const cbuf = b->comp.need(std::max<size_t>(want, 1));
+                const size_t got = fread(cbuf, 1, want, b->z.fp);
+                const bool at_eof = (file_size >= 0 ? (addr + (int64_t)got >= file_size) : (got < want));
                 blocks.clear();
                 size_t o = 0, out_bytes = 0;
                 bool hit_last = false;
                 while (o + 18 <= got && !hit_last) {
-                    const uint8_t *h = comp.data() + o;
+                    const uint8_t *h = cbuf + o;
                     if (h[0] != 31 || h[1] != 139 || !(h[3] & 4)) return fail(UVCGPU_EINVAL, "not a BGZF block where the index points");
                     const int xlen = le16(h + 10);
                     if (o + 12 + (size_t)xlen > got) break;
@@ -314,27 +334,30 @@ extern "C" int uvcio_bam_fetch(uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t
                     if (addr + (int64_t)(o - csize) >= last_addr) hit_last = true;   // the block that holds the chunk end
                     if (o >= BATCH) break;
                 }
-                if (blocks.empty()) { if (got >= 18 && o == 0 && got == comp.size()) return fail(UVCGPU_EINVAL, "BGZF block larger than the batch"); chunk_done = true; break; }
+                if (blocks.empty()) { if (got >= 18 && o == 0 && !at_eof && got == want) return fail(UVCGPU_EINVAL, "BGZF block larger than the batch"); chunk_done = true; break; }
+                t_read += now() - t0; t0 = now();
                 // 2. inflate in parallel
-                infl.resize(carry.size() + out_bytes);
-                if (!carry.empty()) memcpy(infl.data(), carry.data(), carry.size());
+                const size_t infl_size = carry.size() + out_bytes;
+                uint8_t *const ibuf = b->infl.need(std::max<size_t>(infl_size, 1));
+                if (!carry.empty()) memcpy(ibuf, carry.data(), carry.size());
                 bool ok = true;
-                parallel_for(blocks.size(), [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; i++) if (!inflate_block(comp.data() + blocks[i].in_off, blocks[i].csize, infl.data() + carry.size() + blocks[i].out_off, blocks[i].isize)) ok = false; });
+                parallel_for(blocks.size(), [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; i++) if (!inflate_block(cbuf + blocks[i].in_off, blocks[i].csize, ibuf + carry.size() + blocks[i].out_off, blocks[i].isize)) ok = false; });
                 if (!ok) return fail(UVCGPU_EINVAL, "corrupt BGZF block (inflate / CRC)");
+                t_inf += now() - t0; t0 = now();
                 // the usable byte range of this batch
-                size_t lo = (carry.empty() ? skip : 0), hi = infl.size();
+                size_t lo = (carry.empty() ? skip : 0), hi = infl_size;
                 skip = 0;
                 if (hit_last) { const BlockRef &L = blocks.back(); if (L.addr == last_addr) hi = carry.size() + L.out_off + std::min<size_t>(last_u, L.isize); chunk_done = true; }
-                if (got < comp.size() && o >= got - std::min<size_t>(got, 17)) chunk_done = true;   // end of file
+                if (at_eof && o >= got - std::min<size_t>(got, 17)) chunk_done = true;   // end of file
                 // 3. sequential walk over the record sizes: which records overlap, where their outputs go
                 recs.clear();
                 size_t p = lo;
                 int64_t nb = (int64_t)b->bases.size(), nc = (int64_t)b->cigars.size(), nq = (int64_t)b->qnames.size();
                 while (p + 4 <= hi) {
-                    const uint32_t bs = le32(infl.data() + p);
+                    const uint32_t bs = le32(ibuf + p);
                     if (bs < 32 || bs > (1u << 28)) return fail(UVCGPU_EINVAL, "implausible BAM record size");
                     if (p + 4 + bs > hi) break;
-                    const uint8_t *r = infl.data() + p + 4;
+                    const uint8_t *r = ibuf + p + 4;
                     const int32_t rt = (int32_t)le32(r), rp = (int32_t)le32(r + 4);
                     const int l_name = r[8], n_cig = le16(r + 12); const int32_t l_seq = (int32_t)le32(r + 16);
                     if (rt > tid || rt < 0 || (rt == tid && rp >= end)) { past = true; break; }
@@ -351,6 +374,7 @@ extern "C" int uvcio_bam_fetch(uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t
                     }
                     p += 4 + bs;
                 }
+                t_walk += now() - t0; t0 = now();
                 // 4. decode in parallel
                 const size_t r0 = b->pos.size(), nr = recs.size();
                 b->tid.resize(r0 + nr); b->pos.resize(r0 + nr); b->endpos.resize(r0 + nr); b->mtid.resize(r0 + nr); b->mpos.resize(r0 + nr); b->isize.resize(r0 + nr); b->nm.resize(r0 + nr);
@@ -376,11 +400,13 @@ extern "C" int uvcio_bam_fetch(uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t
                     }
                 });
                 if (!aux_ok) return fail(UVCGPU_EINVAL, "corrupt aux fields in a BAM record");
+                t_dec += now() - t0;
                 // 5. what is left of a record that continues in the next batch
-                if (!chunk_done && !past) { std::vector<uint8_t> rest(infl.begin() + (long)p, infl.begin() + (long)hi); carry.swap(rest); addr = blocks.back().addr + blocks.back().csize; }
+                if (!chunk_done && !past) { std::vector<uint8_t> rest(ibuf + p, ibuf + hi); carry.swap(rest); addr = blocks.back().addr + blocks.back().csize; }
                 else if (!past && p < hi && hit_last && blocks.back().addr == last_addr) { /* the chunk ends inside a record only in a broken index */ }
             }
         }
+        if (timing) fprintf(stderr, "[uvcio fetch] threads %d: read+headers %.3f s, inflate %.3f s, record walk %.3f s, decode %.3f s\n", n_threads(), t_read, t_inf, t_walk, t_dec);
     }
     out->n_alns = (int64_t)b->pos.size();
     out->tid = b->tid.data(); out->pos = b->pos.data(); out->endpos = b->endpos.data(); out->mtid = b->mtid.data(); out->mpos = b->mpos.data(); out->isize = b->isize.data();
