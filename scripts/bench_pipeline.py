@@ -33,3 +33,13 @@ for rep in range(3):
     res = pipeline.call_region(lib, bam, fa, "chrT", beg, end); t.append(time.perf_counter())
     print("rep %d: fetch+decode %.3f s, digests %.3f s, grouping %.3f s | whole call_region %.3f s = %.2f M positions/s, %d reads kept, %d records kept" % (
         rep, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], (end - beg) / (t[4] - t[3]) / 1e6, res["n_reads"], int(res["records"]["keep"].sum())), flush=True)
+
+# whole "contig" in 100 kb tiles, serial and with several tiles in flight
+if tile_kb >= 200:
+    for workers in (1, 2, 4, 8):
+        t = time.perf_counter()
+        n_rec = 0; n_pos = 0
+        for res in pipeline.call_contig(lib, os.path.join(d, "t.bam"), os.path.join(d, "t.fa"), "chrT", beg, end, tile=100_000, workers=workers):
+            n_rec += int(res["records"]["keep"].sum()); n_pos += res["rpos"][1] - res["rpos"][0]
+        dt = time.perf_counter() - t
+        print("tiles of 100 kb, %d in flight: %.3f s for %d positions = %.2f M positions/s (files -> records), %d records kept" % (workers, dt, n_pos, n_pos / dt / 1e6, n_rec), flush=True)

@@ -37,6 +37,8 @@ def test_chain_on_the_oracle(tmp_path, oracle_lib):
     assert len(lines) == 1 + int(rec["keep"].sum()) and lines[1].split("\t")[0] == "chrT"
     assert pipeline.call_region(oracle_lib, bam, fa, "chrT", 100, 2000) is None          # nothing aligned there
     tiles = list(pipeline.call_contig(oracle_lib, bam, fa, "chrT", tile=2500))
+    par = list(pipeline.call_contig(oracle_lib, str(tmp_path / "u0.bam"), str(tmp_path / "u0.fa"), "chrT", tile=2500, workers=3))   # three tiles in flight, own handles each
+    assert [t["rpos"] for t in par] == [t["rpos"] for t in tiles] and all(np.array_equal(a["records"]["TLODQ"], b["records"]["TLODQ"]) for a, b in zip(par, tiles))
     assert len(tiles) == 3 and [t["rpos"][0] for t in tiles] == sorted(t["rpos"][0] for t in tiles)
     # a position scored in two different tilings gets the same record: every tile re-reads its own halo
     a = {(int(p), int(s)): int(q) for t in tiles for p, s, q in zip(t["records"]["refpos"], t["records"]["symbol"], t["records"]["TLODQ"])}

@@ -25,9 +25,14 @@ FILTERS = ["Q10", "Q20", "Q30", "Q40", "Q50", "Q60", "PASS"]
 def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None, molecule_tag=0, disable_duplex=0, correct_bq=True, all_out=False, keep_handle=False):
     """Scores [beg, end) of `chrom`.  Returns None when no read passes the filters (process_batch returns -1, main.cpp:520-523), else a
     dict: records (field -> int32 array), alleles (InDel allele rows), score range, region handle (if keep_handle)."""
+    import os, time
+    timing = bool(os.environ.get("UVC_PIPELINE_TIMING"))
+    laps = [("start", time.perf_counter())]
+    lap = (lambda name: laps.append((name, time.perf_counter()))) if timing else (lambda name: None)
     tid = bam.tid(chrom)
     tlen = bam.refs[tid][1]
     cols = bam.fetch(tid, max(0, beg - MAX_INSERT_SIZE), end + MAX_INSERT_SIZE)
+    lap("fetch")
     n = cols["n_alns"]
     if n == 0:
         return None
@@ -36,6 +41,7 @@ def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None
     gp.fetch_tbeg, gp.fetch_tend = beg, end
     g = group.group_families(lib, gp, dict(tid=cols["tid"], pos=cols["pos"], endpos=cols["endpos"], mtid=cols["mtid"], mpos=cols["mpos"], isize=cols["isize"], flag=cols["flag"], mapq=cols["mapq"],
                                            qname_hash31=h[0], qname_hash17=h[1], umi_hash31=h[2], umi_hash17=h[3], umi_kind=kind))
+    lap("digest+group")
     if g["n_kept"] == 0:
         return None
     o = g["order"]
@@ -49,31 +55,66 @@ def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None
                  frag_id=g["frag_id"], fam_id=g["fam_id"], fam_strand=g["fam_strand"], n_fams=int(g["n_fams"]), fam_dflag=g["fam_dflag"],
                  bases=cols["bases"], quals=cols["quals"], cigars=cols["cigars"])
     p = params if params is not None else region.default_params(lib)
+    lap("columns+refseq")
     R = region.Region(lib, p, tid, ext_beg, ext_end, refseq)
+    lap("region_create")
     R.set_reads(reads)
+    lap("set_reads")
     if correct_bq:
         R.correct_bq()
     R.accumulate()
     is_amplicon = (g["n_amplicon"] * 2 > g["n_kept"])                                  # !is_by_capture, main.cpp:507-508
     rec = R.score(all_out=all_out, pos_beg=rpos_beg, pos_end=min(rpos_end + 1, ext_end - 0), is_amplicon=bool(is_amplicon))
+    lap("bq+accumulate+score")
     out = dict(records=rec, alleles=R.indel_alleles(), rpos=(rpos_beg, rpos_end), ext=(ext_beg, ext_end), n_reads=int(g["n_kept"]), n_fams=int(g["n_fams"]), chrom=chrom, refseq=refseq)
     if keep_handle:
         out["region"] = R
     else:
         R.close()
+    lap("alleles+close")
+    if timing:
+        sys.stderr.write("[pipeline] " + ", ".join("%s %.1f ms" % (b[0], 1e3 * (b[1] - a[1])) for a, b in zip(laps, laps[1:])) + "\n")
     return out
 
 
-def call_contig(lib, bam, fasta, chrom, beg=0, end=None, tile=1_000_000, **kw):
-    """Tiles [beg, end) of a contig (default: all of it) and yields the result of every tile that has reads.  The reference cuts its
-    regions by read and position counts (SamIter, grouping.cpp:28-67, 157-314); results at a position do not depend on the cut because
-    every region re-reads its own +-2000 bp halo, so fixed tiles of the size the state slab is laid out for are used here."""
-    tlen = bam.refs[bam.tid(chrom)][1]
+def call_contig(lib, bam, fasta, chrom, beg=0, end=None, tile=1_000_000, workers=1, **kw):
+    """Tiles [beg, end) of a contig (default: all of it) and yields the result of every tile that has reads, in order.  The reference cuts
+    its regions by read and position counts (SamIter, grouping.cpp:28-67, 157-314); results at a position do not depend on the cut because
+    every region re-reads its own +-2000 bp halo, so fixed tiles of the size the state slab is laid out for are used here.
+    workers > 1: that many tiles in flight on host threads, each with its own file handles and region handle (the library calls release
+    the GIL; the reference runs process_batch on `nthreads` OpenMP threads the same way, main.cpp:1478-1520).  `bam` / `fasta` may be
+    paths or open handles; with workers > 1 they must be paths."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    paths = (bam, fasta) if isinstance(bam, str) else None
+    if workers > 1 and paths is None:
+        raise ValueError("workers > 1 needs the BAM / FASTA paths: every worker opens its own handles")
+    local = threading.local()
+
+    def handles():
+        if paths is None:
+            return bam, fasta
+        if not hasattr(local, "h"):
+            local.h = (uio.Bam(paths[0]), uio.Fasta(paths[1]))
+        return local.h
+    b0 = handles()[0]
+    tlen = b0.refs[b0.tid(chrom)][1]
     end = tlen if end is None else min(end, tlen)
-    for b in range(beg, end, tile):
-        res = call_region(lib, bam, fasta, chrom, b, min(b + tile, end), **kw)
-        if res is not None:
-            yield res
+    starts = list(range(beg, end, tile))
+
+    def one(b):
+        hb, hf = handles()
+        return call_region(lib, hb, hf, chrom, b, min(b + tile, end), **kw)
+    if workers <= 1:
+        for b in starts:
+            res = one(b)
+            if res is not None:
+                yield res
+        return
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        for res in ex.map(one, starts):
+            if res is not None:
+                yield res
 
 
 def write_tsv(res, fh, kept_only=True, header=True):
