@@ -308,6 +308,9 @@ const char *uvcgpu_version(void);
 int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params,
                          int32_t tid, int32_t beg, int32_t end, const char *refseq);
 /* Copies the reads to the device (the caller keeps ownership of its buffers). */
+/* Re-binds the handle to another region (the next tile of a stream of tiles): as destroy + create, but the streams and, when the new
+ * region is not longer than the longest one the handle has held, the device buffers are kept -- no hipMalloc / hipFree per tile. */
+int uvcgpu_region_reset(uvcgpu_region_t *r, int32_t tid, int32_t beg, int32_t end, const char *refseq);
 int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *reads);
 /* Optional: apply_bq_err_correction3 (grouping.cpp:459-543) on the device copy of quals. */
 int uvcgpu_region_correct_bq(uvcgpu_region_t *r);

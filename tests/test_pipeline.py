@@ -59,3 +59,21 @@ def test_chain_gpu_equals_oracle(tmp_path, umi, oracle_lib, gpu_lib):
     assert ro["alleles"] == rg["alleles"]
     compare_records(ro["records"], rg["records"])
     assert ro["records"]["keep"].sum() >= 5
+
+
+@pytest.mark.gpu
+def test_a_reset_handle_equals_a_fresh_one(tmp_path, gpu_lib):
+    """Tiles of different lengths through one handle (uvcgpu_region_reset: buffers kept while the region does not grow, reallocated when
+    it does) give the records of a fresh handle per tile."""
+    reads = make_files(tmp_path, 1)
+    bam, fa = uio.Bam(str(tmp_path / "u1.bam")), uio.Fasta(str(tmp_path / "u1.fa"))
+    b0 = reads["beg"]
+    spans = [(b0 + 100, b0 + 1500), (b0 + 1500, b0 + 2100), (b0 + 2100, b0 + 5900), (b0 + 300, b0 + 900)]   # shrink, grow, shrink
+    holder = {}
+    for beg, end in spans:
+        a = pipeline.call_region(gpu_lib, bam, fa, "chrT", beg, end, reuse=holder)
+        b = pipeline.call_region(gpu_lib, bam, fa, "chrT", beg, end)
+        assert a["rpos"] == b["rpos"] and a["alleles"] == b["alleles"]
+        assert all(np.array_equal(a["records"][k], b["records"][k]) for k in a["records"]), (beg, end)
+    tiles = list(pipeline.call_contig(gpu_lib, str(tmp_path / "u1.bam"), str(tmp_path / "u1.fa"), "chrT", b0, b0 + 6000, tile=1500, workers=2))
+    assert len(tiles) == 4

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 struct RawReads {
@@ -43,6 +44,7 @@ struct uvcgpu_region {
     // device buffers
     uint8_t *d_refsym = nullptr; int32_t *d_rtr = nullptr, *d_rtr0 = nullptr; int64_t *d_baq = nullptr;
     char *d_state = nullptr; size_t state_bytes = 0;
+    int64_t npos_cap = 0;         // positions the side arrays and the slab were allocated for (uvcgpu_region_reset reuses them)
     size_t bucket_off = 0; bool buckets_clean = false;   // the transient bucket planes (tail of the slab) are left zero by P3b / P5b
     std::vector<void *> owned;   // read-dependent device allocations
     RegionDev R;
@@ -110,18 +112,38 @@ void build_tracks(const std::string &ref, const UvcParams &P, std::vector<Track>
     tr.assign(n, Track());
     for (auto &t : tr) t.indelphred = P.indel_BQ_max;
     const int32_t smax = P.indel_str_repeatsize_max, vmax = P.indel_vntr_repeatsize_max;
+    // The walk below visits start positions one after the other (the step depends on the repeat found), but what it finds at a start
+    // depends on the reference alone: the candidates of all positions are computed on the host cores first, the walk then only follows them.
+    struct Cand { int32_t best_u, best_c, best_end, any_u, any_end, dec; };
+    std::vector<Cand> cand((size_t)n);
+    auto fill_cands = [&](int32_t a0, int32_t a1) {
+        for (int32_t at = a0; at < a1; at++) {
+            int32_t best_u = 0, best_c = 0, best_end = at, any_u = 0, any_c = 0, any_end = at;
+            for (int32_t u = 1; u <= vmax; u++) {
+                int32_t q = at;
+                while (q + u < n && ref[q] == ref[q + u]) q++;
+                const int32_t c = (q - at) / u + 1;
+                if (u <= smax && str_better(u, c, best_u, best_c, smax)) { best_u = u; best_c = c; best_end = q + u; }
+                if (str_better(u, c, any_u, any_c, vmax)) { any_u = u; any_c = c; any_end = q + u; }
+            }
+            const int32_t len = std::min(best_end, n) - at;
+            cand[(size_t)at] = Cand{ best_u, best_c, best_end, any_u, any_end, slip_phred(P.indel_polymerase_slip_rate * P.indel_del_to_ins_err_ratio, best_u, len / best_u) };
+        }
+    };
+    {
+        const int nt = (int)std::min<int64_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), 16u)), std::max<int64_t>(n / 8192, 1));
+        if (nt <= 1) fill_cands(0, n);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; t++) th.emplace_back(fill_cands, (int32_t)((int64_t)n * t / nt), (int32_t)((int64_t)n * (t + 1) / nt));
+            for (std::thread &x : th) x.join();
+        }
+    }
     int32_t at = 0;
     while (at < n) {
-        int32_t best_u = 0, best_c = 0, best_end = at, any_u = 0, any_c = 0, any_end = at;
-        for (int32_t u = 1; u <= vmax; u++) {
-            int32_t q = at;
-            while (q + u < n && ref[q] == ref[q + u]) q++;
-            const int32_t c = (q - at) / u + 1;
-            if (u <= smax && str_better(u, c, best_u, best_c, smax)) { best_u = u; best_c = c; best_end = q + u; }
-            if (str_better(u, c, any_u, any_c, vmax)) { any_u = u; any_c = c; any_end = q + u; }
-        }
+        const Cand &c = cand[(size_t)at];
+        const int32_t best_u = c.best_u, best_c = c.best_c, best_end = c.best_end, any_u = c.any_u, any_end = c.any_end, dec = c.dec;
         const int32_t stop = std::min(best_end, n), len = stop - at;
-        const int32_t dec = slip_phred(P.indel_polymerase_slip_rate * P.indel_del_to_ins_err_ratio, best_u, len / best_u);
         for (int32_t i = at; i != stop; i++) if (len > tr[i].tracklen) {
             tr[i].begpos = at; tr[i].tracklen = len; tr[i].unitlen = best_u; tr[i].indelphred = P.indel_BQ_max - std::min(P.indel_BQ_max - 1, dec);
         }
@@ -228,18 +250,12 @@ void uvcgpu_params_apply_platform(UvcParams *p, int32_t platform, int32_t centra
     }
 }
 
-int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params, int32_t tid, int32_t beg, int32_t end, const char *refseq) {
-    if (!out || !params || !refseq || end <= beg) return fail(UVCGPU_EINVAL, "bad argument");
-    if (params->struct_size != (int32_t)sizeof(UvcParams)) return fail(UVCGPU_EINVAL, "UvcParams::struct_size mismatch");
-    if (params->indel_str_repeatsize_max < 1 || params->indel_vntr_repeatsize_max < params->indel_str_repeatsize_max) return fail(UVCGPU_EINVAL, "bad repeat-size parameters");
-    uvcgpu_region *r = new uvcgpu_region();
-    memset(&r->prof, 0, sizeof(r->prof));
-    r->P = *params; r->tid = tid; r->beg = beg; r->end = end + 1; r->npos = (int64_t)end - beg + 1;
+// (Re)binds a handle to a region: side arrays of the reference (C10) and the plane layout.  Device buffers are kept when they are large
+// enough, so that a caller that streams tiles of one size through a handle pays hipMalloc / hipFree once (uvcgpu_region_reset).
+static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t end, const char *refseq) {
+    r->tid = tid; r->beg = beg; r->end = end + 1; r->npos = (int64_t)end - beg + 1;
     r->refstring.assign(refseq, (size_t)(end - beg));
-    if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) { delete r; return fail(UVCGPU_EDEVICE, "hipStreamCreate failed (no GPU?)"); }
-    if (hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&r->e_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_fork2, hipEventDisableTiming) != hipSuccess) {
-        uvcgpu_region_destroy(r); return fail(UVCGPU_EDEVICE, "hipStreamCreate / hipEventCreate failed");
-    }
+    r->accumulated = false; r->gap_ready = false; r->buckets_clean = false;
     std::vector<Track> tr; std::vector<int64_t> baq;
     build_tracks(r->refstring, r->P, tr, baq);
     std::vector<uint8_t> refsym((size_t)r->npos + 1, 0);
@@ -250,18 +266,25 @@ int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params, int32_t
         const int32_t v[UVC_NRTR] = { t.begpos, t.tracklen, t.unitlen, t.indelphred, t.a_begpos, t.a_tracklen, t.a_unitlen };
         for (int f = 0; f < UVC_NRTR; f++) rtr[(size_t)f * r->npos + i] = v[f];
     }
-    int rc;
-    if ((rc = upload(r, refsym, &r->d_refsym, false)) || (rc = upload(r, rtr, &r->d_rtr0, false)) || (rc = upload(r, rtr, &r->d_rtr, false)) || (rc = upload(r, baq, &r->d_baq, false))) { uvcgpu_region_destroy(r); return rc; }
     // one slab for all per-position planes (+ the transient bucket planes), 8-byte groups first
     const int order[] = { UVC_F_PREP64, UVC_F_SEG64, UVC_F_FAMINFO64, UVC_F_PREP32, UVC_F_THRES, UVC_F_SEG32, UVC_F_VQ, UVC_F_BQSUM, UVC_F_FRAG, UVC_F_FAM, UVC_F_FAMINFO32, UVC_F_DUPLEX };
     size_t o = 0;
     for (int g : order) { r->off[g] = o; o += group_bytes(r, g); }
-    const size_t bucket_off = o; o += (size_t)4 * r->npos * 2 * NSYM * NBUCKETS;
-    r->state_bytes = o; r->bucket_off = bucket_off; r->buckets_clean = false;
-    if (hipMalloc((void **)&r->d_state, r->state_bytes) != hipSuccess) { uvcgpu_region_destroy(r); return fail(UVCGPU_ENOMEM, "hipMalloc(state planes) failed"); }
-    int32_t *d_err = nullptr;
-    if (hipMalloc((void **)&d_err, 4) != hipSuccess) { uvcgpu_region_destroy(r); return fail(UVCGPU_ENOMEM, "hipMalloc failed"); }
-    hipMemsetAsync(d_err, 0, 4, r->stream);
+    r->bucket_off = o; o += (size_t)4 * r->npos * 2 * NSYM * NBUCKETS;
+    r->state_bytes = o;
+    if (r->npos > r->npos_cap) {
+        for (void *p : { (void *)r->d_refsym, (void *)r->d_rtr, (void *)r->d_rtr0, (void *)r->d_baq, (void *)r->d_state }) if (p) hipFree(p);
+        r->d_refsym = nullptr; r->d_rtr = r->d_rtr0 = nullptr; r->d_baq = nullptr; r->d_state = nullptr; r->npos_cap = 0;
+        if (hipMalloc((void **)&r->d_refsym, (size_t)r->npos + 1) != hipSuccess || hipMalloc((void **)&r->d_rtr, sizeof(int32_t) * rtr.size()) != hipSuccess
+            || hipMalloc((void **)&r->d_rtr0, sizeof(int32_t) * rtr.size()) != hipSuccess || hipMalloc((void **)&r->d_baq, sizeof(int64_t) * baq.size()) != hipSuccess
+            || hipMalloc((void **)&r->d_state, r->state_bytes) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(region planes) failed");
+        r->npos_cap = r->npos;
+    }
+    HIP_OK(hipMemcpyAsync(r->d_refsym, refsym.data(), refsym.size(), hipMemcpyHostToDevice, r->stream));
+    HIP_OK(hipMemcpyAsync(r->d_rtr0, rtr.data(), sizeof(int32_t) * rtr.size(), hipMemcpyHostToDevice, r->stream));
+    HIP_OK(hipMemcpyAsync(r->d_rtr, rtr.data(), sizeof(int32_t) * rtr.size(), hipMemcpyHostToDevice, r->stream));
+    HIP_OK(hipMemcpyAsync(r->d_baq, baq.data(), sizeof(int64_t) * baq.size(), hipMemcpyHostToDevice, r->stream));
+    int32_t *d_err = r->R.err;
     RegionDev &R = r->R;
     memset(&R, 0, sizeof(R));
     R.beg = r->beg; R.end = r->end; R.npos = r->npos; R.refsym = r->d_refsym; R.rtr = r->d_rtr; R.baq = r->d_baq;
@@ -270,11 +293,40 @@ int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params, int32_t
     R.prep32 = (int32_t *)(b + r->off[UVC_F_PREP32]); R.thres = (int32_t *)(b + r->off[UVC_F_THRES]); R.seg32 = (int32_t *)(b + r->off[UVC_F_SEG32]);
     R.vq = (int32_t *)(b + r->off[UVC_F_VQ]); R.bqsum = (int32_t *)(b + r->off[UVC_F_BQSUM]); R.frag = (int32_t *)(b + r->off[UVC_F_FRAG]);
     R.fam = (int32_t *)(b + r->off[UVC_F_FAM]); R.faminfo32 = (int32_t *)(b + r->off[UVC_F_FAMINFO32]); R.duplex = (int32_t *)(b + r->off[UVC_F_DUPLEX]);
-    R.bucket = (int32_t *)(b + bucket_off);
+    R.bucket = (int32_t *)(b + r->bucket_off);
     R.err = d_err;
-    HIP_OK(hipStreamSynchronize(r->stream));
+    HIP_OK(hipMemsetAsync(d_err, 0, 4, r->stream));
+    HIP_OK(hipStreamSynchronize(r->stream));   // the staging vectors above die here
+    return 0;
+}
+
+int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params, int32_t tid, int32_t beg, int32_t end, const char *refseq) {
+    if (!out || !params || !refseq || end <= beg) return fail(UVCGPU_EINVAL, "bad argument");
+    if (params->struct_size != (int32_t)sizeof(UvcParams)) return fail(UVCGPU_EINVAL, "UvcParams::struct_size mismatch");
+    if (params->indel_str_repeatsize_max < 1 || params->indel_vntr_repeatsize_max < params->indel_str_repeatsize_max) return fail(UVCGPU_EINVAL, "bad repeat-size parameters");
+    uvcgpu_region *r = new uvcgpu_region();
+    memset(&r->prof, 0, sizeof(r->prof));
+    memset(&r->R, 0, sizeof(r->R));
+    r->P = *params;
+    if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) { delete r; return fail(UVCGPU_EDEVICE, "hipStreamCreate failed (no GPU?)"); }
+    if (hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&r->e_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_fork2, hipEventDisableTiming) != hipSuccess) {
+        uvcgpu_region_destroy(r); return fail(UVCGPU_EDEVICE, "hipStreamCreate / hipEventCreate failed");
+    }
+    if (hipMalloc((void **)&r->R.err, 4) != hipSuccess) { uvcgpu_region_destroy(r); return fail(UVCGPU_ENOMEM, "hipMalloc failed"); }
+    const int rc = configure_region(r, tid, beg, end, refseq);
+    if (rc) { uvcgpu_region_destroy(r); return rc; }
     *out = r;
     return 0;
+}
+
+// The same handle for another region (the next tile): reads, results and the plane contents of the previous region are dropped, streams,
+// events and -- when the new region is not longer than the longest one the handle has seen -- the device buffers are kept.
+int uvcgpu_region_reset(uvcgpu_region_t *r, int32_t tid, int32_t beg, int32_t end, const char *refseq) {
+    if (!r || !refseq || end <= beg) return fail(UVCGPU_EINVAL, "bad argument");
+    HIP_OK(hipStreamSynchronize(r->stream));
+    if (r->side) HIP_OK(hipStreamSynchronize(r->side));
+    free_reads(r);
+    return configure_region(r, tid, beg, end, refseq);
 }
 
 int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {

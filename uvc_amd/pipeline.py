@@ -22,9 +22,11 @@ SYMBOL_DESC = ["A", "C", "G", "T", "N", "*", "<LR>", "<LD3P>", "<LD2>", "<LD1>",
 FILTERS = ["Q10", "Q20", "Q30", "Q40", "Q50", "Q60", "PASS"]
 
 
-def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None, molecule_tag=0, disable_duplex=0, correct_bq=True, all_out=False, keep_handle=False):
+def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None, molecule_tag=0, disable_duplex=0, correct_bq=True, all_out=False, keep_handle=False, reuse=None):
     """Scores [beg, end) of `chrom`.  Returns None when no read passes the filters (process_batch returns -1, main.cpp:520-523), else a
-    dict: records (field -> int32 array), alleles (InDel allele rows), score range, region handle (if keep_handle)."""
+    dict: records (field -> int32 array), alleles (InDel allele rows), score range, region handle (if keep_handle).
+    `reuse`: a dict the caller keeps between calls; the region handle lives in it and is reset for every new region instead of being
+    created and destroyed (its device buffers survive while the regions do not grow)."""
     import os, time
     timing = bool(os.environ.get("UVC_PIPELINE_TIMING"))
     laps = [("start", time.perf_counter())]
@@ -56,7 +58,12 @@ def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None
                  bases=cols["bases"], quals=cols["quals"], cigars=cols["cigars"])
     p = params if params is not None else region.default_params(lib)
     lap("columns+refseq")
-    R = region.Region(lib, p, tid, ext_beg, ext_end, refseq)
+    if reuse is not None and reuse.get("region") is not None:
+        R = reuse["region"]; R.reset(tid, ext_beg, ext_end, refseq)
+    else:
+        R = region.Region(lib, p, tid, ext_beg, ext_end, refseq)
+        if reuse is not None:
+            reuse["region"] = R
     lap("region_create")
     R.set_reads(reads)
     lap("set_reads")
@@ -69,7 +76,7 @@ def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None
     out = dict(records=rec, alleles=R.indel_alleles(), rpos=(rpos_beg, rpos_end), ext=(ext_beg, ext_end), n_reads=int(g["n_kept"]), n_fams=int(g["n_fams"]), chrom=chrom, refseq=refseq)
     if keep_handle:
         out["region"] = R
-    else:
+    elif reuse is None:
         R.close()
     lap("alleles+close")
     if timing:
@@ -104,7 +111,9 @@ def call_contig(lib, bam, fasta, chrom, beg=0, end=None, tile=1_000_000, workers
 
     def one(b):
         hb, hf = handles()
-        return call_region(lib, hb, hf, chrom, b, min(b + tile, end), **kw)
+        if not hasattr(local, "reuse"):
+            local.reuse = {}                                   # one region handle per worker, reset from tile to tile
+        return call_region(lib, hb, hf, chrom, b, min(b + tile, end), reuse=local.reuse, **kw)
     if workers <= 1:
         for b in starts:
             res = one(b)

@@ -107,6 +107,22 @@ class Region:
         if rc != 0:
             raise UvcError(rc, self.lib.last_error())
 
+    def reset(self, tid, beg, end, refseq):
+        """Re-binds the handle to another region (uvcgpu_region_reset): streams and, if the region is not longer, device buffers are kept.
+        Libraries without that entry point (the test oracle) get a fresh handle instead."""
+        ref = refseq.encode() if isinstance(refseq, str) else bytes(refseq)
+        if len(ref) != end - beg:
+            raise ValueError("refseq must cover [beg, end)")
+        fn = getattr(self.lib.dll, self.lib.prefix + "region_reset", None)
+        if fn is None:
+            self.close()
+            self._check(self.lib.call("create", C.byref(self.h), C.byref(self._params), tid, beg, end, ref))
+        else:
+            fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p]
+            self._check(fn(self.h, tid, beg, end, ref))
+        self.tid, self.beg, self.end, self.npos = tid, beg, end, end - beg + 1
+        self._score_buf = None
+
     def set_reads(self, reads):
         soa, keep = pack_reads(reads)
         self._check(self.lib.call("set_reads", self.h, C.byref(soa)))
