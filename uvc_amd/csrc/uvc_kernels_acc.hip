@@ -827,7 +827,7 @@ DEV void mis_apply(const RegionDev &R, const UvcParams &P, const MisItem &it) {
 // Two instantiations, <true,false> for LINK_M and <false,true> for the read bases: each keeps one SegAcc in registers,
 // which halves the accumulator footprint and doubles the waves per SIMD.
 template <bool DO_L, bool DO_B, bool PLAIN>
-__global__ void __launch_bounds__(256) k_p2_fast(RegionDev R, UvcParams P) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k_p2_fast(RegionDev R, UvcParams P) {
     __shared__ int amp1[256], amp2[256];
     __shared__ MisItem misq[DO_B ? 4 : 1][DO_B ? MISQ_CAP : 1];
     {
