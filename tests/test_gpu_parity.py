@@ -195,3 +195,25 @@ def test_score_request_options(oracle_lib, gpu_lib):
         if "pos_beg" in kwargs:
             assert ro["refpos"].min() >= beg - 1 and ro["refpos"].max() < end
     assert len(Ro.score(indel_alleles=alleles)["refpos"]) > len(base["refpos"])      # the extra alleles became extra records
+
+
+def test_more_than_65535_fragments_on_one_position(oracle_lib, gpu_lib):
+    """k_frag packs two 16-bit bucket counters per LDS word while no position is covered by 65 536 fragments or more; this pile-up
+    (a 70 000-read amplicon stack) takes the 32-bit variant."""
+    rng = np.random.default_rng(8)
+    n, L, ref_len, beg = 70000, 60, 400, 7_000_000
+    ref = rng.integers(0, 4, ref_len)
+    start = 150 + rng.integers(0, 3, n)
+    bases = ref[start[:, None] + np.arange(L)[None, :]]
+    err = rng.random((n, L)) < 0.004
+    bases = np.where(err, rng.integers(0, 4, (n, L)), bases).astype(np.uint8)
+    reads = dict(n_reads=n, pos=(beg + start).astype(np.int32), mpos=np.full(n, -1, np.int32), isize=np.zeros(n, np.int32), flag=np.where(np.arange(n) % 2, 16, 0).astype(np.uint16),
+                 mapq=np.full(n, 60, np.uint8), nm=np.full(n, -1, np.int32), l_qseq=np.full(n, L, np.int32), seq_off=(np.arange(n, dtype=np.int64) * L), cigar_off=np.arange(n, dtype=np.int64),
+                 n_cigar=np.ones(n, np.int32), frag_id=np.arange(n, dtype=np.int32), fam_id=np.arange(n, dtype=np.int32), fam_strand=(np.arange(n) % 2).astype(np.uint8), n_fams=n,
+                 fam_dflag=np.zeros(n, np.uint8), bases=bases.reshape(-1), quals=rng.choice([20, 30, 37], n * L).astype(np.uint8), cigars=np.full(n, (L << 4) | 0, np.uint32),
+                 tid=1, beg=beg, end=beg + ref_len, refseq="".join("ACGT"[b] for b in ref))
+    Ro, Rg = run_region(oracle_lib, reads), run_region(gpu_lib, reads)
+    bad = diff_groups(Ro, Rg)
+    assert not bad, "\n".join("%s: %d cells differ, e.g. %s" % (g, v[0], v[1]) for g, v in bad.items())
+    assert Rg.fetch("FRAG")[:, 0].sum(axis=(0, 1)).max() >= 65536
+    compare_records(Ro.score(), Rg.score())

@@ -534,6 +534,16 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     { if ((rc = upload(r, dup_units, &r->d_dup_units)) || (rc = upload(r, dup_off, &r->d_dup_off))) return rc; r->n_dup = (int)dup_units.size(); r->n_dup_work = dup_work; }
     R.max_aln_span = max_aln_span; R.max_frag_span = max_frag_span;
     R.any_amplicon = 0; for (int64_t f = 0; f < in->n_fams; f++) if (in->fam_dflag[f] & 0x4) { R.any_amplicon = 1; break; }
+    {   // fragment depth bound (k_frag packs two 16-bit bucket counters per LDS word when it is below 65 536)
+        if (frags.size() < 65536) R.max_frag_depth = (int32_t)frags.size();
+        else {
+            std::vector<int32_t> diff((size_t)r->npos + 2, 0);
+            for (const FragRec &f : frags) { diff[(size_t)(f.beg - r->beg)]++; diff[(size_t)(std::min(f.end, r->end) - r->beg)]--; }
+            int32_t run = 0, mx = 0;
+            for (size_t i = 0; i <= (size_t)r->npos; i++) { run += diff[i]; mx = std::max(mx, run); }
+            R.max_frag_depth = mx;
+        }
+    }
     r->R.n_complex = (int32_t)complex_ids.size();
     // table rows are written by k_p2_slow<false>; mark all slots empty (0xFF)
     HIP_OK(hipMemsetAsync(R.table, 0xFF, std::max<int64_t>(table_rows, 1) * sizeof(Contrib), r->stream));

@@ -1529,9 +1529,16 @@ __global__ void __launch_bounds__(64) k_frag_generic(RegionDev R, UvcParams P, c
 // global bucket plane (each position has exactly one writer in this kernel).
 // ------------------------------------------------------------------------------------------------
 // PLAIN: VCF run, Illumina-like values, no SSCS table cap (fam_flag & 1), padded deletions counted: the common case without those arms
-template <bool PLAIN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,5))) k_frag(RegionDev R, UvcParams P) {
-    __shared__ int hist[2][NBUCKETS][256];   // [dense symbol][bucket][thread]: conflict-free, 32 KiB so that five blocks share a CU
+// H16: no position is covered by 65 536 fragments or more (host bound, RegionDev::max_frag_depth), so two buckets share one LDS word:
+// 16 KiB per block instead of 32, six waves per SIMD instead of five.
+template <bool PLAIN, bool H16>
+DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUCKETS / (H16 ? 2 : 1)][256]) {
+    auto hist_add = [&](int dense, int b) {   // ds_add_u32 without return
+        if (H16) atomicAdd(&hist[dense][b >> 1][threadIdx.x], 1u << (16 * (b & 1))); else atomicAdd(&hist[dense][b][threadIdx.x], 1u);
+    };
+    auto hist_get = [&](int dense, int b) -> int {
+        return H16 ? (int)((hist[dense][b >> 1][threadIdx.x] >> (16 * (b & 1))) & 0xFFFFu) : (int)hist[dense][b][threadIdx.x];
+    };
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform((int)((xcd_block() * blockDim.x + threadIdx.x) >> 6));
     const int64_t x0 = (int64_t)wave * 64;
@@ -1544,7 +1551,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,5)))
     const bool padded_ignored = (PLAIN ? false : ((P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0));
     const bool vcfgen = (PLAIN ? true : (P.inferred_is_vcf_generated != 0));   // P3 belongs to updateByAlns3UsingBQ, skipped on FASTQ-only runs (main.hpp:3691)
     const int my_ref = valid ? R.refsym[x] : 0;
-    for (int b = 0; b < NBUCKETS; b++) { hist[0][b][threadIdx.x] = 0; hist[1][b][threadIdx.x] = 0; }
+    for (int b = 0; b < NBUCKETS / (H16 ? 2 : 1); b++) { hist[0][b][threadIdx.x] = 0; hist[1][b][threadIdx.x] = 0; }
     // avgBQ + 8 (get_avgBQ, main_conversion.hpp:791-796) of the five read symbols and of LINK_M; LINK_M value of a simple read here
     auto maxq_at = [&](int sym) {
         const int ad = S32(R, UVC_S_aDPff, sym, x) + S32(R, UVC_S_aDPfr, sym, x) + S32(R, UVC_S_aDPrf, sym, x) + S32(R, UVC_S_aDPrr, sym, x);
@@ -1582,7 +1589,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,5)))
             if (!PLAIN && (0x1 & P.fam_flag)) phredlike = imin(phredlike, sscs_phred(P, my_ref, cs));
             const int pbucket = imax(0, max_qual - phredlike);
             if (dense >= 0) {
-                if (pbucket < NBUCKETS) atomicAdd(&hist[dense][pbucket][threadIdx.x], 1);   // ds_add_u32 without return
+                if (pbucket < NBUCKETS) hist_add(dense, pbucket);
                 if (dense == 0) { ar.bDP += 1; ar.bTA += n_cov; ar.bTB += n_near; bMQ_r += sq; }
                 else { al.bDP += 1; al.bTA += n_cov; al.bTB += n_near; bMQ_l += sq; }
             } else {
@@ -1720,14 +1727,25 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,5)))
             const int dense = (s == my_ref ? 0 : (s == UVC_LINK_M ? 1 : -1));
             const int max_qual = maxq_generic(s);
             int mv, ad2, bq2;
-            if (dense >= 0 && !has_generic) infer_max_qual(mv, ad2, bq2, max_qual, 1, totDP, [&](int b) { return hist[dense][b][threadIdx.x]; });
+            if (dense >= 0 && !has_generic) infer_max_qual(mv, ad2, bq2, max_qual, 1, totDP, [&](int b) { return hist_get(dense, b); });
             else {   // the global buckets hold the rare symbols and everything k_frag_generic added
-                infer_max_qual(mv, ad2, bq2, max_qual, 1, totDP, [&](int b) { return BKP(R, 0, s, b, x) + (dense >= 0 ? hist[dense][b][threadIdx.x] : 0); });
+                infer_max_qual(mv, ad2, bq2, max_qual, 1, totDP, [&](int b) { return BKP(R, 0, s, b, x) + (dense >= 0 ? hist_get(dense, b) : 0); });
                 for (int b = 0; b < NBUCKETS; b++) BKP(R, 0, s, b, x) = 0;   // clearSymbolBucketCount, main.hpp:2827
             }
             VQP(R, UVC_VQ_bIAQb, s, x) += mv; VQP(R, UVC_VQ_bIADb, s, x) += ad2; VQP(R, UVC_VQ_bIDQb, s, x) += bq2;
         }
     }
+}
+
+template <bool PLAIN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,5))) k_frag(RegionDev R, UvcParams P) {
+    __shared__ unsigned hist[2][NBUCKETS][256];   // [dense symbol][bucket][thread]: conflict-free, 32 KiB so that five blocks share a CU
+    frag_body<PLAIN, false>(R, P, hist);
+}
+template <bool PLAIN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6,6))) k_frag16(RegionDev R, UvcParams P) {
+    __shared__ unsigned hist[2][NBUCKETS / 2][256];
+    frag_body<PLAIN, true>(R, P, hist);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2549,7 +2567,10 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
     }
     {
         const bool plain = P->inferred_is_vcf_generated && (UVC_PLATFORM_IONTORRENT != P->inferred_sequencing_platform) && !(0x1 & P->fam_flag) && !(P->microadjust_padded_deletion_flag & 0x1);
-        if (plain) TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag<true>, dim3(nwin), dim3(256), 0, s, *R, *P));
+        const bool h16 = (R->max_frag_depth < 65536);
+        if (plain && h16) TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag16<true>, dim3(nwin), dim3(256), 0, s, *R, *P));
+        else if (plain) TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag<true>, dim3(nwin), dim3(256), 0, s, *R, *P));
+        else if (h16) TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag16<false>, dim3(nwin), dim3(256), 0, s, *R, *P));
         else TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag<false>, dim3(nwin), dim3(256), 0, s, *R, *P));
     }
     if (R->n_generic_fs) {
