@@ -48,7 +48,7 @@ def algorithmic_bytes_per_position(kernel, depth):
 
 # bench kernel label -> name(s) in the rocprofv3 output (template instantiations; the default workload runs the PLAIN ones)
 PROFILE_NAMES = {"k_p2_fast_link": ("k_p2_fast<true, false, true>", "k_p2_fast<true, false, false>"), "k_p2_fast_base": ("k_p2_fast<false, true, true>", "k_p2_fast<false, true, false>"),
-                 "k_p2_slow_walk": ("k_p2_slow<true>",), "k_p2_slow_table": ("k_p2_slow<false>",), "k_frag": ("k_frag<true>", "k_frag<false>")}
+                 "k_p2_slow_walk": ("k_p2_slow<true>",), "k_p2_slow_table": ("k_p2_slow<false>",), "k_frag": ("k_frag16<true>", "k_frag16<false>", "k_frag<true>", "k_frag<false>")}
 
 
 def measured_traffic(kernel, tile_kb, depth):
