@@ -519,6 +519,7 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
       std::vector<int32_t> z(complex_ids.size() + 1, 0); int32_t *c; if ((rc = upload(r, z, &c))) return rc; R.item_cnt = c; }
     {   // InDel allele pipeline (k_gap_*): events, two sort stages, rows
         if (gap_slots >= ((int64_t)1 << 27)) return fail(UVCGPU_EUNSUPPORTED, "more than 2^27 InDel ops in one region");
+        if (gap_slots > 0 && r->npos >= ((int64_t)1 << 26)) return fail(UVCGPU_EUNSUPPORTED, "region longer than 2^26 positions: split it (the InDel allele keys hold 26 position bits)");
         GapWork &G = R.gap; memset(&G, 0, sizeof(G));
         G.n_ev = (int32_t)gap_slots; G.inc_cap = (int32_t)(7 * gap_slots + 8); G.seq_cap = ins_total + 8;
         const size_t ne = (size_t)std::max<int64_t>(gap_slots, 1), ni = (size_t)G.inc_cap;
