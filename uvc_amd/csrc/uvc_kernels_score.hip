@@ -760,10 +760,15 @@ __global__ void __launch_bounds__(256) k_scan_add(const long long *in, long long
     if (PK_FLAGS(in[g])) active[PK_FLAGS(o)] = (int)g;
 }
 
+#define SCORE_LPG 2
 __global__ void __launch_bounds__(128) k_score(RegionDev R, UvcParams P, ScoreCtx C) {
     const long long ngroups = 2LL * (C.pos_end - C.pos_beg);
     const long long n_active = PK_FLAGS(C.offsets[ngroups]);
-    for (long long ai_ = (long long)blockIdx.x * blockDim.x + threadIdx.x; ai_ < n_active; ai_ += (long long)gridDim.x * blockDim.x) {
+    // SCORE_LPG adjacent lanes share one (position, symbol type) group: its records are dealt to them round-robin, the cross-allele sums
+    // of BcfFormat_symbol_sum_DPv are combined with lane shuffles.  A default-gate group has two records (REF + one ALT): the serial
+    // chain of a lane is halved.
+    const int sub = (int)(threadIdx.x % SCORE_LPG);
+    for (long long ai_ = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / SCORE_LPG; ai_ < n_active; ai_ += ((long long)gridDim.x * blockDim.x) / SCORE_LPG) {
     const long long g = C.active[ai_];
     const long long rec0 = PK_COUNT(C.offsets[g]), nrec = PK_COUNT(C.offsets[g + 1]) - rec0;
     if (nrec == 0 || rec0 + nrec > C.capacity) continue;
@@ -799,14 +804,23 @@ __global__ void __launch_bounds__(128) k_score(RegionDev R, UvcParams P, ScoreCt
     int s1[6] = { 0, 0, 0, 0, 0, 0 }, s2[6] = { 0, 0, 0, 0, 0, 0 };
     long long rec = rec0;
     for (int pass = 0; pass < 2; pass++) {
-        rec = rec0;
-        for (int k = 0; k < st_count(st); k++) {
-            const int symbol = st_symbol(st, k);
-            int bdepth, cdepth;
-            if (!gate(R, P, x, st, symbol, refsymbol, totBDP, C.all_out, true /* an active group of a normal sample is a rescued position */, bdepth, cdepth)) continue;
-            long long first; int src;
-            const int mult = allele_source(C, P.tumor_vcf_is_provided, refpos, symbol, first, src);
-            for (int ai = 0; ai < mult; ai++, rec++) {
+        for (long long my = sub; my < nrec; my += SCORE_LPG) {   // this lane's records; all lanes run the body below at the same time
+            rec = rec0 + my;
+            int symbol = -1, ai = 0, src = 0, bdepth = 0, cdepth = 0; long long first = -1;
+            {   // which (symbol, allele) is record `my` of the group: the enumeration of k_score_count again
+                long long cnt = 0;
+                for (int k = 0; k < st_count(st) && symbol < 0; k++) {
+                    const int s2_ = st_symbol(st, k);
+                    int bd, cd;
+                    if (!gate(R, P, x, st, s2_, refsymbol, totBDP, C.all_out, true /* an active group of a normal sample is a rescued position */, bd, cd)) continue;
+                    long long f1; int sr;
+                    const int m = allele_source(C, P.tumor_vcf_is_provided, refpos, s2_, f1, sr);
+                    if (my < cnt + m) { symbol = s2_; ai = (int)(my - cnt); first = f1; src = sr; bdepth = bd; cdepth = cd; }
+                    cnt += m;
+                }
+            }
+            if (symbol < 0) continue;   // cannot happen: nrec is the count of this enumeration
+            {
                 int bDPa = bdepth, cDP0a = cdepth, glen = 0, tki_tier2 = 0, gap_row = -1;
                 double tpfa_dpv = -1.0, tpfa_qual = -1.0;
                 int tkey_idx = -1;
@@ -843,6 +857,10 @@ __global__ void __launch_bounds__(128) k_score(RegionDev R, UvcParams P, ScoreCt
                     calc_qual(R, P, T, f, s1[0], s1[2], ins_cdepth, del_cdepth, ins1_cdepth, del1_cdepth, ru_size, repeatnum, rtr1, rtr2, refsymbol, tpfa_qual, fields, capacity, rec);
                 }
             }
+        }
+        if (pass == 0) {   // the lanes of the group add up their parts of the sums (the NN allele is with exactly one of them)
+#pragma unroll
+            for (int d = 1; d < SCORE_LPG; d <<= 1) for (int i = 0; i < 6; i++) { s1[i] += __shfl_xor(s1[i], d); s2[i] += __shfl_xor(s2[i], d); }
         }
     }
     }
@@ -1121,7 +1139,8 @@ extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const Uv
     hipLaunchKernelGGL(k_scan_local, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, counts, offsets, block_sums, ngroups);
     hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, block_sums, nblocks, offsets, ngroups, (long long *)d_count);
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, s, counts, offsets, block_sums, C.active, ngroups);
-    const unsigned grid = (unsigned)((ngroups / 16 + 127) / 128 < 2048 ? ((ngroups / 16 + 127) / 128 > 0 ? (ngroups / 16 + 127) / 128 : 1) : 2048);
+    const long long want_blocks = (ngroups / 16 * SCORE_LPG + 127) / 128;
+    const unsigned grid = (unsigned)(want_blocks < 4096 ? (want_blocks > 0 ? want_blocks : 1) : 4096);
     hipLaunchKernelGGL(k_score, dim3(grid), dim3(128), 0, s, *R, *P, C);
     const long long npos_scored = C.pos_end - C.pos_beg;
     hipLaunchKernelGGL(k_call, dim3((unsigned)((npos_scored + 127) / 128 < 4096 ? (npos_scored + 127) / 128 : 4096)), dim3(128), 0, s, *R, *P, C);
