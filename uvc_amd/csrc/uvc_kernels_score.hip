@@ -916,7 +916,12 @@ __global__ void __launch_bounds__(128) k_call(RegionDev R, UvcParams P, ScoreCtx
     const long long npos = C.pos_end - C.pos_beg;
     int32_t *fields = C.fields; const long long capacity = C.capacity;
     const bool tprov = (P.tumor_vcf_is_provided != 0);
-    for (long long zi = (long long)blockIdx.x * blockDim.x + threadIdx.x; zi < npos; zi += (long long)gridDim.x * blockDim.x) {
+    // one thread per zerobased_pos that has records: the first active group of the position stands for it
+    const long long n_active = PK_FLAGS(C.offsets[2 * npos]);
+    for (long long ai_ = (long long)blockIdx.x * blockDim.x + threadIdx.x; ai_ < n_active; ai_ += (long long)gridDim.x * blockDim.x) {
+        const long long g0 = C.active[ai_];
+        if ((g0 & 1) && ai_ > 0 && C.active[ai_ - 1] == g0 - 1) continue;   // the BASE group of this position is active too and does the work
+        const long long zi = g0 >> 1;
         const int zpos = C.pos_beg + (int)zi;
         long long rec0[2], nrec[2];
         for (int st = 0; st < 2; st++) { const long long g = 2 * zi + st; rec0[st] = PK_COUNT(C.offsets[g]); nrec[st] = PK_COUNT(C.offsets[g + 1]) - rec0[st]; if (rec0[st] + nrec[st] > capacity) nrec[st] = 0; }
@@ -1143,7 +1148,7 @@ extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const Uv
     const unsigned grid = (unsigned)(want_blocks < 4096 ? (want_blocks > 0 ? want_blocks : 1) : 4096);
     hipLaunchKernelGGL(k_score, dim3(grid), dim3(128), 0, s, *R, *P, C);
     const long long npos_scored = C.pos_end - C.pos_beg;
-    hipLaunchKernelGGL(k_call, dim3((unsigned)((npos_scored + 127) / 128 < 4096 ? (npos_scored + 127) / 128 : 4096)), dim3(128), 0, s, *R, *P, C);
+    hipLaunchKernelGGL(k_call, dim3((unsigned)((npos_scored / 8 + 127) / 128 < 2048 ? (npos_scored / 8 + 127) / 128 + 1 : 2048)), dim3(128), 0, s, *R, *P, C);
     return 0;
 }
 extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored) {
