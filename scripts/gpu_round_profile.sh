@@ -35,4 +35,5 @@ for k, v in sorted(res.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"
 PY
 timeout -k 10 900 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 13; }
 cat $OUT/bench.json
+timeout -k 10 900 python3 bench.py --streamed --no-cpu-baseline > $OUT/bench_streamed.json 2>> $OUT/bench.err || exit 14
 rm -rf $OUT/trace $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
