@@ -165,11 +165,11 @@ def main():
     def step():
         for Ri in Rs:          # enqueue only: each region has its own stream
             Ri.accumulate()
-        recs = [Ri.score(all_out=args.all_out, capacity=(15 * (sub_len + 2) if args.all_out else max(65536, sub_len // 4)), copy=False) for Ri in Rs]
+        recs = [Ri.score(all_out=args.all_out, capacity=(15 * (sub_len + 2) if args.all_out else max(65536, sub_len // 4)), copy=False, release_state=True) for Ri in Rs]
         return {"refpos": np.concatenate([r["refpos"] for r in recs])} if len(recs) > 1 else recs[0]
 
     def score_one(Ri):
-        return Ri.score(all_out=args.all_out, capacity=(15 * (sub_len + 2) if args.all_out else max(65536, sub_len // 4)), copy=False)
+        return Ri.score(all_out=args.all_out, capacity=(15 * (sub_len + 2) if args.all_out else max(65536, sub_len // 4)), copy=False, release_state=True)
 
     lib.dll.uvcgpu_region_set_profiling(R.h, 1)          # HIP events around the kernels of handle 0 (the roofline leg reads them)
     if args.pipeline:
@@ -247,7 +247,7 @@ def main():
             "metric": "pileup positions scored/sec at 300x depth", "value": total_positions / dt, "unit": "positions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "chr20-shaped tumor-only non-UMI tile: %d kb at %dx, 150 bp paired-end, resident in HBM; step = accumulate P1..P5b + default-gate scoring / calling + D2H of the records of one tile%s" % (args.tile_kb, args.depth, "; tiles stream through two handles (the accumulate of tile k+1 is enqueued before the synchronous score of tile k)" if args.pipeline else ""),
+            "config": {"workload": "chr20-shaped tumor-only non-UMI tile: %d kb at %dx, 150 bp paired-end, resident in HBM; step = accumulate P1..P5b + default-gate scoring / calling + D2H of the records of one tile (planes released with the score call: they are zeroed for the next tile under the D2H)%s" % (args.tile_kb, args.depth, "; tiles stream through two handles (the accumulate of tile k+1 is enqueued before the synchronous score of tile k)" if args.pipeline else ""),
                        "tile_positions": region_len, "streams": args.streams, "pipeline": bool(args.pipeline), "all_out": bool(args.all_out), "umi": bool(args.umi), "reads_per_tile": n_reads_total, "read_bases_per_tile": n_read_bases, "scored_records_per_tile": n_rec,
                        "parallelism": "region-shard x%d (no collective on the data path)" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(dom, args.tile_kb, args.depth),

@@ -282,6 +282,10 @@ typedef struct UvcScoreRequest {
     int64_t n_tumor_keys;       /* normal sample of a T/N pair: the tumor records of this region, sorted by (refpos, symbol); a position is
                                  * scored iff it has a record (extended_posidx_to_is_rescued, main.cpp:532-538), every symbol of it */
     const UvcTumorKey *tumor_keys;
+    int32_t release_state;      /* 1: the caller is done with the planes of this region after this call (no further score / fetch until the next
+                                 * accumulate, which return UVCGPU_ESTATE): the library zeroes them for the next accumulate while the records
+                                 * travel to the host, instead of in front of the next accumulate's kernels */
+    int32_t reserved_;
 } UvcScoreRequest;
 
 typedef struct UvcScoreOut {

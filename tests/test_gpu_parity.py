@@ -217,3 +217,23 @@ def test_more_than_65535_fragments_on_one_position(oracle_lib, gpu_lib):
     assert not bad, "\n".join("%s: %d cells differ, e.g. %s" % (g, v[0], v[1]) for g, v in bad.items())
     assert Rg.fetch("FRAG")[:, 0].sum(axis=(0, 1)).max() >= 65536
     compare_records(Ro.score(), Rg.score())
+
+
+def test_release_state(gpu_lib):
+    """UvcScoreRequest::release_state: the planes are zeroed behind the scoring kernels instead of in front of the next accumulate;
+    until then fetch / score refuse, the allele tables stay readable, and the next accumulate gives the same results."""
+    from uvc_amd import region
+    reads = synth.generate_region(**CASES["config2shape_5kb_300x"])
+    R = run_region(gpu_lib, reads)
+    planes = {g: R.fetch(g).copy() for g in ("SEG32", "FRAG", "FAM", "VQ", "PREP32")}
+    rec = R.score(release_state=True)
+    alleles = R.indel_alleles()
+    for call in (lambda: R.fetch("SEG32"), lambda: R.score()):
+        with pytest.raises(region.UvcError) as e:
+            call()
+        assert e.value.code == -5
+    for _ in range(2):                       # released -> zeroed path, then the ordinary memset path
+        R.accumulate()
+        assert all(np.array_equal(R.fetch(g), planes[g]) for g in planes)
+        rec2 = R.score()
+        assert all(np.array_equal(rec[k], rec2[k]) for k in rec) and R.indel_alleles() == alleles

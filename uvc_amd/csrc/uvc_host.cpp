@@ -51,6 +51,7 @@ struct uvcgpu_region {
     int32_t *d_dup_units = nullptr; int64_t *d_dup_off = nullptr; int n_dup = 0; int64_t n_dup_work = 0;
     size_t off[UVC_NUM_FIELD_GROUPS + 1];
     bool has_reads = false, accumulated = false;
+    bool state_released = false, state_zeroed = false;   // UvcScoreRequest::release_state: planes given up / already zeroed on the side stream (e_join marks the end)
     RawReads W;                  // per-read input columns on the device (kept: uvcgpu_region_correct_bq re-derives the per-read records)
     int32_t *d_p2[4] = { nullptr, nullptr, nullptr, nullptr };   // P2 work list: alignment, begin, end, query offset
     int64_t n_bases = 0;
@@ -255,7 +256,7 @@ void uvcgpu_params_apply_platform(UvcParams *p, int32_t platform, int32_t centra
 static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t end, const char *refseq) {
     r->tid = tid; r->beg = beg; r->end = end + 1; r->npos = (int64_t)end - beg + 1;
     r->refstring.assign(refseq, (size_t)(end - beg));
-    r->accumulated = false; r->gap_ready = false; r->buckets_clean = false;
+    r->accumulated = false; r->gap_ready = false; r->buckets_clean = false; r->state_released = false; r->state_zeroed = false;
     std::vector<Track> tr; std::vector<int64_t> baq;
     build_tracks(r->refstring, r->P, tr, baq);
     std::vector<uint8_t> refsym((size_t)r->npos + 1, 0);
@@ -615,7 +616,9 @@ int uvcgpu_region_read_quals(uvcgpu_region_t *r, uint8_t *dst, int64_t n) {
 int uvcgpu_region_accumulate(uvcgpu_region_t *r) {
     if (!r) return fail(UVCGPU_EINVAL, "null region");
     if (!r->has_reads) return fail(UVCGPU_ENOREADS, "no reads");   // process_batch returns -1, main.cpp:520-523
-    HIP_OK(hipMemsetAsync(r->d_state, 0, r->buckets_clean ? r->bucket_off : r->state_bytes, r->stream));
+    if (r->state_zeroed) HIP_OK(hipStreamWaitEvent(r->stream, r->e_join, 0));   // zeroed behind the last score (release_state)
+    else HIP_OK(hipMemsetAsync(r->d_state, 0, r->buckets_clean ? r->bucket_off : r->state_bytes, r->stream));
+    r->state_zeroed = false; r->state_released = false;
     r->buckets_clean = false;
     HIP_OK(hipMemcpyAsync(r->d_rtr, r->d_rtr0, (size_t)4 * UVC_NRTR * r->npos, hipMemcpyDeviceToDevice, r->stream));   // P1b edits indelphred in place
     HIP_OK(hipMemsetAsync(r->R.frag_nmut, 0, sizeof(int32_t) * (size_t)r->R.n_frags, r->stream));
@@ -668,6 +671,7 @@ int64_t uvcgpu_region_field_bytes(const uvcgpu_region_t *r, int32_t g) {
 int uvcgpu_region_fetch(uvcgpu_region_t *r, int32_t g, void *dst, int64_t dst_bytes) {
     if (!r || !dst || g < 0 || g >= UVC_NUM_FIELD_GROUPS) return fail(UVCGPU_EINVAL, "bad argument");
     if (g != UVC_F_RTR && g != UVC_F_BAQ && !r->accumulated) return fail(UVCGPU_ESTATE, "fetch before accumulate");
+    if (g != UVC_F_RTR && g != UVC_F_BAQ && r->state_released) return fail(UVCGPU_ESTATE, "the planes were released by the last score (UvcScoreRequest::release_state)");
     if ((int64_t)group_bytes(r, g) != dst_bytes) return fail(UVCGPU_EINVAL, "bad destination size");
     int rc = uvcgpu_region_sync(r);
     if (rc) return rc;
@@ -804,6 +808,7 @@ int64_t uvcgpu_region_score_size(const uvcgpu_region_t *r, const UvcScoreRequest
 int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScoreOut *out) {
     if (!r || !out || !out->fields) return fail(UVCGPU_EINVAL, "bad argument");
     if (!r->accumulated) return fail(UVCGPU_ESTATE, "score before accumulate");
+    if (r->state_released) return fail(UVCGPU_ESTATE, "the planes were released by the last score (UvcScoreRequest::release_state)");
     UvcScoreRequest rq; memset(&rq, 0, sizeof(rq)); rq.pos_beg = -1;
     if (req) rq = *req;
     if (rq.pos_beg < 0) { rq.pos_beg = r->beg + 1; rq.pos_end = r->end - 1; }
@@ -858,6 +863,12 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
     HIP_OK(hipMemsetAsync(r->d_score_count, 0, 8, r->stream));
     int rc = uvc_launch_score(&r->R, &r->P, &rq, use_al, use_row, n_al, r->d_gap_rows, r->d_gap_seq, d_tk, r->d_score_fields, r->score_capacity, r->d_score_count, r->d_score_scratch, r->stream);
     if (!rc && hipGetLastError() != hipSuccess) rc = fail(UVCGPU_EDEVICE, "score kernel launch failed");
+    if (!rc && rq.release_state && r->side) {   // zero the planes on the side stream as soon as the scoring kernels are done, under the D2H of the records
+        if (hipEventRecord(r->e_fork, r->stream) == hipSuccess && hipStreamWaitEvent(r->side, r->e_fork, 0) == hipSuccess
+            && hipMemsetAsync(r->d_state, 0, r->buckets_clean ? r->bucket_off : r->state_bytes, r->side) == hipSuccess && hipEventRecord(r->e_join, r->side) == hipSuccess) {
+            r->state_released = true; r->state_zeroed = true;
+        }
+    }
     if (!rc) rc = uvcgpu_region_sync(r);
     int64_t cnt = 0;
     // copies on the handle's own stream: a null-stream hipMemcpy would also wait for every other handle's work

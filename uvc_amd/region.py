@@ -173,9 +173,10 @@ class Region:
             out.append(dict(refpos=r.refpos, symbol=r.symbol, strand=r.strand, len=r.len, seq=text, bAD1=r.bAD1, cAD1=r.cAD1, c2AD=r.c2AD, c2dAD=r.c2dAD))
         return out
 
-    def score(self, all_out=False, pos_beg=-1, pos_end=-1, is_amplicon=False, indel_alleles=None, capacity=None, copy=True, tumor_keys=None):
+    def score(self, all_out=False, pos_beg=-1, pos_end=-1, is_amplicon=False, indel_alleles=None, capacity=None, copy=True, tumor_keys=None, release_state=False):
         req = _ffi.UvcScoreRequest()
         req.pos_beg, req.pos_end, req.all_out, req.is_amplicon = pos_beg, pos_end, int(all_out), int(is_amplicon)
+        req.release_state = int(release_state)   # the planes may be zeroed for the next accumulate as soon as the scoring kernels are done
         arr = None
         if indel_alleles:
             arr = (_ffi.UvcIndelAllele * len(indel_alleles))(*[_ffi.UvcIndelAllele(*a) for a in indel_alleles])
