@@ -2298,15 +2298,11 @@ __global__ void __launch_bounds__(64) k_gap_alleles(RegionDev R, UvcParams P) {
             if (!cand(e)) continue;
             long long w = 0;
             for (int j = i0; j < i1; j++) { const int e2 = (int)order[j]; if (cand(e2) && 0 == gap_cmp(R, ev[e], ev[e2])) w += weight(e2); }
-#ifdef GAP_DEBUG
-            printf("cand x=%lld e=%d sym=%d len=%d weight=%d mark=%x w=%lld best=%d best_w=%lld cmp=%d\n", x, e, ev[e].sym, ev[e].len, ev[e].weight, ev[e].mark, w, best, best_w, best >= 0 ? gap_cmp(R, ev[e], ev[best]) : -9);
-#endif
+            // two steps on purpose: written as one expression `best < 0 || w > best_w || (w == best_w && gap_cmp(...) > 0)` the tie arm was
+            // never taken in the code hipcc 7.2 generated at -O3 (found with device printf; tests/test_gpu_indel_alleles.py covers it)
             bool take = (best < 0 || w > best_w);
             if (!take && w == best_w) { const int c = gap_cmp(R, ev[e], ev[best]); take = (c > 0); }
             if (take) { best = e; best_w = w; }
-#ifdef GAP_DEBUG
-            printf("   after x=%lld best=%d\n", x, best);
-#endif
         }
         return best;
     };
@@ -2334,9 +2330,6 @@ __global__ void __launch_bounds__(64) k_gap_alleles(RegionDev R, UvcParams P) {
             if (!(is_ins(cs) || is_del(cs))) continue;
             const int e = majority([&](int q) { return ev[q].sym == cs && ev[q].aln >= f.aln_beg && ev[q].aln < f.aln_end; }, [&](int q) { return (long long)ev[q].weight; });
             if (e < 0) { atomicExch(R.err, UVCGPU_EDEVICE); continue; }   // an InDel consensus without an InDel event cannot happen
-#ifdef GAP_DEBUG
-            printf("FRAG x=%lld fi=%d s=%d cs=%d e=%d\n", x, fi, s, cs, e);
-#endif
             ev[e].mark = 0x10000 | (s << 8) | cs;
             emit(s, 0, cs, e);
         }
