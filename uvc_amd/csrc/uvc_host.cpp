@@ -28,6 +28,9 @@ extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const Uv
                                 const UvcGapRow *d_gap_rows, const uint8_t *d_gap_seq, const UvcTumorKey *d_tkeys, int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch, hipStream_t s);
 extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored);
 extern "C" size_t uvc_gap_sort_tmp_bytes(size_t n);
+extern "C" int uvc_sort_by_pos_cls(const int32_t *d_pos, const int32_t *d_cls, int32_t beg, int shift, int64_t n, unsigned long long *work, void *tmp, size_t tmp_bytes, hipStream_t s);
+extern "C" void uvc_launch_gather4(const unsigned long long *perm, int64_t n, const int32_t *a0, const int32_t *a1, const int32_t *a2, const int32_t *a3, int32_t *o0, int32_t *o1, int32_t *o2, int32_t *o3, hipStream_t s);
+extern "C" void uvc_launch_rank_from_sorted(const unsigned long long *perm, int64_t n, int64_t n_first, int32_t *out_ids, int32_t *rank, hipStream_t s);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -341,7 +344,7 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     const int64_t n = in->n_reads;
     if (n == 0) return 0;
     if (n > INT32_MAX / 2) return fail(UVCGPU_EUNSUPPORTED, "more than 2^30 reads in one region");
-    std::vector<int32_t> endpos(n), frag_of(n), fs_of(n), dflag_of(n), kind(n), fast_rank(n, -1);
+    std::vector<int32_t> endpos(n), frag_of(n), fs_of(n), dflag_of(n), kind(n);
     std::vector<int64_t> table_off(n, -1), item_off(n, -1), gap_off(n, -1);
     int64_t item_slots = 0, gap_slots = 0, ins_total = 0;
     std::vector<FragRec> frags; std::vector<FsRec> fss;
@@ -456,18 +459,11 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
         if (f.stat_kind) sweep_frags.push_back((int32_t)fi);
     }
     lap("units / fragments (host)");
-    // pos-sorted order of the simple alignments, beg-sorted order of the fragments
-    std::vector<int32_t> simple_ids, complex_ids, frag_sorted(frags.size());
-    for (int64_t i = 0; i < n; i++) (kind[i] == 0 ? simple_ids : complex_ids).push_back((int32_t)i);
-    { std::vector<uint32_t> key((size_t)n); for (int64_t i = 0; i < n; i++) key[i] = (uint32_t)(in->pos[i] - r->beg);   // < 2^31, fits the 33 bits of three passes
-      radix_sort_ids(simple_ids, key); }
-    for (size_t k = 0; k < simple_ids.size(); k++) fast_rank[simple_ids[k]] = (int32_t)k;
-    std::iota(frag_sorted.begin(), frag_sorted.end(), 0);
-    // k_frag walks two beg-sorted sub-lists, one per strand, so that the strand-specific accumulators are fixed registers
-    { std::vector<uint32_t> key(frags.size());
-      if (r->npos >= ((int64_t)1 << 31)) return fail(UVCGPU_EUNSUPPORTED, "region longer than 2^31");
-      for (size_t k = 0; k < frags.size(); k++) key[k] = (uint32_t)(frags[k].beg - r->beg) | ((uint32_t)frags[k].strand << 31);
-      radix_sort_ids(frag_sorted, key); }
+    // pos-sorted order of the simple alignments, beg-sorted order of the fragments: made on the device below (after the uploads)
+    std::vector<int32_t> complex_ids;
+    int64_t n_simple = 0;
+    for (int64_t i = 0; i < n; i++) { if (kind[i] == 0) n_simple++; else complex_ids.push_back((int32_t)i); }
+    if (r->npos >= ((int64_t)1 << 31)) return fail(UVCGPU_EUNSUPPORTED, "region longer than 2^31");
     { int32_t n0 = 0; for (const FragRec &f : frags) if (f.strand == 0) n0++; r->R.frag_off[0] = 0; r->R.frag_off[1] = n0; r->R.frag_off[2] = (int32_t)frags.size(); }
 
     // uploads
@@ -482,7 +478,7 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     if ((rc = up32(in->pos, &W.pos)) || (rc = up32(endpos.data(), &W.endpos)) || (rc = up32(in->mpos, &W.mpos)) || (rc = up32(in->isize, &W.isize))
         || (rc = up32(flag32.data(), &W.flag)) || (rc = up32(mapq32.data(), &W.mapq)) || (rc = up32(in->nm, &W.nm)) || (rc = up32(in->l_qseq, &W.l_qseq))
         || (rc = up32(in->n_cigar, &W.n_cigar)) || (rc = up32(frag_of.data(), &W.frag)) || (rc = up32(fs_of.data(), &W.fs)) || (rc = up32(dflag_of.data(), &W.dflag))
-        || (rc = up32(kind.data(), &W.kind)) || (rc = up32(fast_rank.data(), &W.fast_rank))
+        || (rc = up32(kind.data(), &W.kind))
         || (rc = up64(in->seq_off, &W.seq_off)) || (rc = up64(in->cigar_off, &W.cigar_off)) || (rc = up64(table_off.data(), &W.table_off)) || (rc = up64(item_off.data(), &W.item_off)) || (rc = up64(gap_off.data(), &W.gap_off))) return rc;
     { uint8_t *d; if ((rc = upload_raw(r, in->bases, (size_t)in->n_bases, &d))) return rc; R.bases = d; }
     { uint8_t *d; if ((rc = upload_raw(r, in->quals, (size_t)in->n_bases, &d))) return rc; R.quals = d; }
@@ -492,13 +488,27 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
       uvc_launch_pack_bq(R.bases, R.quals, d, in->n_bases, r->stream); }
     { uint32_t *d; if ((rc = upload_raw(r, in->cigars, (size_t)in->n_cigar_ops, &d))) return rc; R.cigars = d; }
     { AlnRec *d; if ((rc = dev_alloc(r, (size_t)n, &d))) return rc; R.alns = d; R.n_alns = (int32_t)n; }
-    { AlnRec *d; if ((rc = dev_alloc(r, simple_ids.size(), &d))) return rc; R.fast = d; R.n_fast = (int32_t)simple_ids.size(); }
-    { FastRec *d; if ((rc = dev_alloc(r, simple_ids.size(), &d))) return rc; R.frec = d; }
+    { AlnRec *d; if ((rc = dev_alloc(r, (size_t)n_simple, &d))) return rc; R.fast = d; R.n_fast = (int32_t)n_simple; }
+    { FastRec *d; if ((rc = dev_alloc(r, (size_t)n_simple, &d))) return rc; R.frec = d; }
     { int32_t *d; if ((rc = upload(r, complex_ids, &d))) return rc; R.complex_ids = d; R.n_complex = (int32_t)complex_ids.size(); }
     { FragRec *d; if ((rc = upload(r, frags, &d))) return rc; R.frags = d; R.n_frags = (int32_t)frags.size(); }
-    { int32_t *d; if ((rc = upload(r, frag_sorted, &d))) return rc; R.frag_sorted = d; }
-    { std::vector<int32_t> rank(frags.size()); for (size_t k = 0; k < frag_sorted.size(); k++) rank[frag_sorted[k]] = (int32_t)k;
-      int32_t *d; if ((rc = upload(r, rank, &d))) return rc; R.frag_rank = d; }
+    {   // stable device sorts: simple alignments by begin (the others go behind them), fragments by (strand, begin) -- k_frag walks two
+        // beg-sorted sub-lists, one per strand, so that the strand-specific accumulators are fixed registers
+        const size_t nf = frags.size(), nmax = std::max<size_t>(std::max<size_t>((size_t)n, nf), 1);
+        std::vector<int32_t> fb(nf), fst(nf), notsimple((size_t)n);
+        for (size_t k = 0; k < nf; k++) { fb[k] = frags[k].beg; fst[k] = frags[k].strand; }
+        for (int64_t i = 0; i < n; i++) notsimple[(size_t)i] = (kind[i] == 0 ? 0 : 1);
+        int32_t *d_fb, *d_fst, *d_ns, *d_rank, *d_fsorted, *d_frank; unsigned long long *work; uint8_t *tmp;
+        const size_t tmp_bytes = uvc_gap_sort_tmp_bytes(nmax);
+        if ((rc = upload(r, fb, &d_fb)) || (rc = upload(r, fst, &d_fst)) || (rc = upload(r, notsimple, &d_ns)) || (rc = dev_alloc(r, (size_t)n, &d_rank)) || (rc = dev_alloc(r, nf, &d_fsorted))
+            || (rc = dev_alloc(r, nf, &d_frank)) || (rc = dev_alloc(r, 4 * nmax, &work)) || (rc = dev_alloc(r, tmp_bytes + 16, &tmp))) return rc;
+        if (uvc_sort_by_pos_cls(W.pos, d_ns, r->beg, 31, n, work, tmp, tmp_bytes, r->stream) != 0) return fail(UVCGPU_EDEVICE, "device sort of the alignments failed");
+        uvc_launch_rank_from_sorted(work + 3 * n, n, n_simple, nullptr, d_rank, r->stream);
+        W.fast_rank = d_rank;
+        if (uvc_sort_by_pos_cls(d_fb, d_fst, r->beg, 31, (int64_t)nf, work, tmp, tmp_bytes, r->stream) != 0) return fail(UVCGPU_EDEVICE, "device sort of the fragments failed");
+        uvc_launch_rank_from_sorted(work + 3 * nf, (int64_t)nf, (int64_t)nf, d_fsorted, d_frank, r->stream);
+        R.frag_sorted = d_fsorted; R.frag_rank = d_frank;
+    }
     { FragFast *d; if ((rc = dev_alloc(r, frags.size(), &d, true))) return rc; R.ffast = d; }
     { int32_t *d; if ((rc = upload(r, sweep_frags, &d))) return rc; R.sweep_frags = d; R.n_sweep = (int32_t)sweep_frags.size(); }
     { int32_t *d; if ((rc = dev_alloc(r, frags.size() * (size_t)(UVC_MAXEV + 2) + 1, &d, true))) return rc;
@@ -553,21 +563,23 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     uvc_launch_prelude(&R, &W, &r->P, r->stream);
     lap("prelude kernel");
     {
-        {   // stable order by (class, begin); begin - region begin < 2^31 and the class takes the two bits above
-            std::vector<int32_t> ord(p2.size()); std::iota(ord.begin(), ord.end(), 0);
-            std::vector<uint32_t> key(p2.size());
-            if (r->npos >= ((int64_t)1 << 29)) return fail(UVCGPU_EUNSUPPORTED, "region longer than 2^29");
-            for (size_t j = 0; j < p2.size(); j++) key[j] = (uint32_t)(p2[j].cbeg - r->beg) | ((uint32_t)p2[j].cls << 29);
-            radix_sort_ids(ord, key);
-            std::vector<P2Seg> sorted(p2.size()); for (size_t j = 0; j < p2.size(); j++) sorted[j] = p2[ord[j]];
-            p2.swap(sorted);
-        }
+        // stable order by (class, begin) on the device: begin - region begin < 2^29 and the class takes the two bits above
+        if (r->npos >= ((int64_t)1 << 29)) return fail(UVCGPU_EUNSUPPORTED, "region longer than 2^29");
+        const size_t np2 = p2.size();
         for (int c = 0; c <= 4; c++) R.p2_off[c] = 0;
-        for (const P2Seg &e : p2) for (int c = e.cls + 1; c <= 4; c++) R.p2_off[c]++;
-        std::vector<int32_t> v_aln(p2.size()), v_beg(p2.size()), v_end(p2.size()), v_qb(p2.size());
+        std::vector<int32_t> v_aln(np2), v_beg(np2), v_end(np2), v_qb(np2), v_cls(np2);
         int32_t span = 1;
-        for (size_t j = 0; j < p2.size(); j++) { v_aln[j] = p2[j].aln; v_beg[j] = p2[j].cbeg; v_end[j] = p2[j].cend; v_qb[j] = p2[j].qb; span = std::max(span, p2[j].cend - p2[j].cbeg); }
-        if ((rc = upload(r, v_aln, &r->d_p2[0])) || (rc = upload(r, v_beg, &r->d_p2[1])) || (rc = upload(r, v_end, &r->d_p2[2])) || (rc = upload(r, v_qb, &r->d_p2[3]))) return rc;
+        for (size_t j = 0; j < np2; j++) {
+            v_aln[j] = p2[j].aln; v_beg[j] = p2[j].cbeg; v_end[j] = p2[j].cend; v_qb[j] = p2[j].qb; v_cls[j] = p2[j].cls; span = std::max(span, p2[j].cend - p2[j].cbeg);
+            for (int c = p2[j].cls + 1; c <= 4; c++) R.p2_off[c]++;
+        }
+        int32_t *u_aln, *u_beg, *u_end, *u_qb, *u_cls; unsigned long long *work; uint8_t *tmp;
+        const size_t tmp_bytes = uvc_gap_sort_tmp_bytes(std::max<size_t>(np2, 1));
+        if ((rc = upload(r, v_aln, &u_aln)) || (rc = upload(r, v_beg, &u_beg)) || (rc = upload(r, v_end, &u_end)) || (rc = upload(r, v_qb, &u_qb)) || (rc = upload(r, v_cls, &u_cls))
+            || (rc = dev_alloc(r, 4 * np2, &work)) || (rc = dev_alloc(r, tmp_bytes + 16, &tmp))) return rc;
+        for (int k = 0; k < 4; k++) if ((rc = dev_alloc(r, np2, &r->d_p2[k]))) return rc;
+        if (uvc_sort_by_pos_cls(u_beg, u_cls, r->beg, 29, (int64_t)np2, work, tmp, tmp_bytes, r->stream) != 0) return fail(UVCGPU_EDEVICE, "device sort of the P2 work list failed");
+        uvc_launch_gather4(work + 3 * np2, (int64_t)np2, u_aln, u_beg, u_end, u_qb, r->d_p2[0], r->d_p2[1], r->d_p2[2], r->d_p2[3], r->stream);
         { FastRec *d; if ((rc = dev_alloc(r, p2.size(), &d))) return rc; R.frec2 = d; R.n_fast2 = (int32_t)p2.size(); R.max_p2_span = span; }
         uvc_launch_build_p2list(&R, r->d_p2[0], r->d_p2[1], r->d_p2[2], r->d_p2[3], r->stream);
     }
