@@ -353,30 +353,69 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
     int64_t table_rows = 0;
     int32_t max_aln_span = 1, max_frag_span = 1;
     struct P2Seg { int32_t cbeg, cend, aln, qb; int32_t cls; };   // cls = is-reverse | bam_get_strand << 1 (common.hpp:89)
-    std::vector<P2Seg> p2; p2.reserve((size_t)n + 1024);
     const UvcParams &P0 = r->P;
     // see k_p2_fast: the M runs of an InDel read can take the simple path when its dist_to_interfering_indel is "far" everywhere, which
     // needs no low-quality InDel in the read, a region that does not start next to coordinate 0 and the default-range threshold
     const bool seg_eligible = (UVC_PLATFORM_IONTORRENT != P0.inferred_sequencing_platform) && r->beg >= 65536 && P0.bias_thres_interfering_indel <= 10000;
-    for (int64_t i = 0; i < n; i++) {
-        const int32_t nc = in->n_cigar[i], lq = in->l_qseq[i];
-        if (in->seq_off[i] < 0 || in->seq_off[i] + lq > in->n_bases || in->cigar_off[i] < 0 || in->cigar_off[i] + nc > in->n_cigar_ops || nc < 1) return fail(UVCGPU_EINVAL, "read offsets out of range");
-        const uint32_t *cg = in->cigars + in->cigar_off[i];
-        int32_t e = in->pos[i]; int64_t q = 0; int n_m = 0; bool simple = true;
-        for (int k = 0; k < nc; k++) {
-            const int op = (int)(cg[k] & 0xF); const int32_t len = (int32_t)(cg[k] >> 4);
-            if (op > C_DIFF) return fail(UVCGPU_EUNSUPPORTED, "unsupported CIGAR op (process_cigar throws, main_conversion.hpp:902-916)");
-            if (op == C_MATCH || op == C_DEL || op == C_REF_SKIP || op == C_EQUAL || op == C_DIFF) e += len;
-            if (op == C_MATCH || op == C_INS || op == C_SOFT_CLIP || op == C_EQUAL || op == C_DIFF) q += len;
-            if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) n_m++;
-            else if (!(op == C_SOFT_CLIP || op == C_HARD_CLIP)) simple = false;
+    // Phase A, on all host cores: what the CIGAR of each read says (nothing here depends on another read)
+    struct ReadFacts { int32_t e; int32_t n_p2; int64_t items; int32_t trows, gaps, ins; int8_t simple, p2ok, err; };
+    std::vector<ReadFacts> facts((size_t)n);
+    auto host_parallel = [&](auto fn) {
+        const int nt = (int)std::min<int64_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), 16u)), std::max<int64_t>(n / 65536, 1));
+        if (nt <= 1) { fn((int64_t)0, n); return; }
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++) th.emplace_back(fn, n * t / nt, n * (t + 1) / nt);
+        for (std::thread &x : th) x.join();
+    };
+    host_parallel([&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; i++) {
+            ReadFacts F; memset(&F, 0, sizeof(F));
+            const int32_t nc = in->n_cigar[i], lq = in->l_qseq[i];
+            if (in->seq_off[i] < 0 || in->seq_off[i] + lq > in->n_bases || in->cigar_off[i] < 0 || in->cigar_off[i] + nc > in->n_cigar_ops || nc < 1) { F.err = 1; facts[(size_t)i] = F; continue; }
+            const uint32_t *cg = in->cigars + in->cigar_off[i];
+            int32_t e = in->pos[i]; int64_t q = 0, del_total = 0; int n_m = 0; bool simple = true;
+            for (int k = 0; k < nc && !F.err; k++) {
+                const int op = (int)(cg[k] & 0xF); const int32_t len = (int32_t)(cg[k] >> 4);
+                if (op > C_DIFF) { F.err = 2; break; }
+                if (op == C_MATCH || op == C_DEL || op == C_REF_SKIP || op == C_EQUAL || op == C_DIFF) e += len;
+                if (op == C_MATCH || op == C_INS || op == C_SOFT_CLIP || op == C_EQUAL || op == C_DIFF) q += len;
+                if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) n_m++;
+                else if (!(op == C_SOFT_CLIP || op == C_HARD_CLIP)) simple = false;
+                if (op == C_INS || op == C_DEL) F.gaps++;
+                if (op == C_INS) F.ins += len;
+                if (op == C_DEL) del_total += len;
+            }
+            if (F.err) { facts[(size_t)i] = F; continue; }
+            if (e == in->pos[i]) e = in->pos[i] + 1;   // bam_endpos of a read without reference-consuming ops
+            if (q != lq) { F.err = 3; facts[(size_t)i] = F; continue; }
+            if (n_m != 1 || nc > 3) simple = false;
+            if (simple && nc == 3) { const int o0 = cg[0] & 0xF, o2 = cg[2] & 0xF; if ((o0 == C_MATCH || o0 == C_EQUAL || o0 == C_DIFF) || (o2 == C_MATCH || o2 == C_EQUAL || o2 == C_DIFF)) simple = false; }
+            if (in->pos[i] < r->beg || e > r->end - 1) { F.err = 4; facts[(size_t)i] = F; continue; }
+            // P2 work list (k_p2_fast): a simple alignment is one entry; an InDel read contributes its M runs (used when its InDels are all high-quality)
+            bool ok = simple || seg_eligible;
+            int32_t rp = in->pos[i], n_p2 = 0;
+            for (int k = 0; k < nc && ok; k++) {
+                const int op = (int)(cg[k] & 0xF); const int32_t len = (int32_t)(cg[k] >> 4);
+                if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) { if (rp - in->pos[i] > 65535 || e - (rp + len) > 65535) ok = false; n_p2++; rp += len; }
+                else if (op == C_DEL) rp += len;
+                else if (op == C_INS || op == C_SOFT_CLIP || op == C_HARD_CLIP) {}
+                else ok = false;   // N / P: keep the sequential path
+            }
+            F.e = e; F.simple = simple; F.p2ok = ok; F.n_p2 = (ok ? n_p2 : 0);
+            if (!simple) { F.trows = (e - in->pos[i]) + 1; F.items = 2 * (int64_t)lq + 2 * del_total + nc + 4; } else { F.gaps = 0; F.ins = 0; }
+            facts[(size_t)i] = F;
         }
-        if (e == in->pos[i]) e = in->pos[i] + 1;   // bam_endpos of a read without reference-consuming ops
-        if (q != lq) return fail(UVCGPU_EINVAL, "CIGAR query length != l_qseq");
-        if (n_m != 1 || nc > 3) simple = false;
-        if (simple && nc == 3) { const int o0 = cg[0] & 0xF, o2 = cg[2] & 0xF; if ((o0 == C_MATCH || o0 == C_EQUAL || o0 == C_DIFF) || (o2 == C_MATCH || o2 == C_EQUAL || o2 == C_DIFF)) simple = false; }
+    });
+    // Phase B, in read order: the first malformed read, family / fragment boundaries, offsets
+    std::vector<int64_t> p2_first((size_t)n + 1, 0);
+    for (int64_t i = 0; i < n; i++) {
+        const ReadFacts &F = facts[(size_t)i];
+        if (F.err == 1) return fail(UVCGPU_EINVAL, "read offsets out of range");
+        if (F.err == 2) return fail(UVCGPU_EUNSUPPORTED, "unsupported CIGAR op (process_cigar throws, main_conversion.hpp:902-916)");
+        if (F.err == 3) return fail(UVCGPU_EINVAL, "CIGAR query length != l_qseq");
+        if (F.err == 4) return fail(UVCGPU_EINVAL, "read outside region");
+        const int32_t e = F.e;
         endpos[i] = e;
-        if (in->pos[i] < r->beg || e > r->end - 1) return fail(UVCGPU_EINVAL, "read outside region");
         const int fam = in->fam_id[i], strand = in->fam_strand[i];
         if (fam < 0 || fam >= in->n_fams || strand > 1) return fail(UVCGPU_EINVAL, "fam_id / fam_strand out of range");
         const bool new_fs = (fam != prev_fam || strand != prev_strand);
@@ -397,39 +436,36 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
         f.normMQ = std::max(f.normMQ, (int32_t)in->mapq[i]);
         u.frag_end = (int32_t)frags.size(); u.beg = std::min(u.beg, in->pos[i]); u.end = std::max(u.end, e) + 1;
         frag_of[i] = (int32_t)frags.size() - 1; fs_of[i] = (int32_t)fss.size() - 1; dflag_of[i] = in->fam_dflag[fam];
-        kind[i] = simple ? 0 : 1;
-        {   // P2 work list (k_p2_fast): a simple alignment is one entry; an InDel read contributes its M runs (used when its InDels are all high-quality)
-            const size_t mark = p2.size();
-            const int fl = in->flag[i];
-            const int32_t p2cls = ((fl & 0x10) ? 1 : 0) | ((((fl & 0x81) == 0x81) ? ((fl & 0x20) != 0) : ((fl & 0x10) != 0)) ? 2 : 0);
-            bool ok = simple || seg_eligible;
-            int32_t rp = in->pos[i]; int64_t qp = 0;
-            for (int k = 0; k < nc && ok; k++) {
-                const int op = (int)(cg[k] & 0xF); const int32_t len = (int32_t)(cg[k] >> 4);
-                if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) {
-                    if (rp - in->pos[i] > 65535 || e - (rp + len) > 65535) ok = false;
-                    p2.push_back(P2Seg{ rp, rp + len, (int32_t)i, (int32_t)((in->seq_off[i] + qp - rp) & 0xFFFFFFFFLL), p2cls });
-                    rp += len; qp += len;
-                } else if (op == C_INS) qp += len;
-                else if (op == C_DEL) rp += len;
-                else if (op == C_SOFT_CLIP) qp += len;
-                else if (op == C_HARD_CLIP) {}
-                else ok = false;   // N / P: keep the sequential path
-            }
-            if (!ok) p2.resize(mark);
-            else if (!simple) kind[i] = 2;   // candidate: k_aln_prelude demotes it to 1 when the read has a low-quality InDel (that test reads the
-                                             // base qualities, which uvcgpu_region_correct_bq may still change on the device)
-        }
-        if (!simple) {
-            table_off[i] = table_rows; table_rows += (e - in->pos[i]) + 1;   // + the row of an insertion right behind the last aligned base (rpos == bam_endpos)
-            int64_t del_total = 0; for (int k = 0; k < nc; k++) if ((cg[k] & 0xF) == C_DEL) del_total += (cg[k] >> 4);
-            item_off[i] = item_slots; item_slots += 2 * (int64_t)lq + 2 * del_total + nc + 4;   // upper bound of P2 updates of this read
-            gap_off[i] = gap_slots;   // one InDel event per I / D op
-            for (int k = 0; k < nc; k++) { const int op = (int)(cg[k] & 0xF); if (op == C_INS || op == C_DEL) gap_slots++; if (op == C_INS) ins_total += (cg[k] >> 4); }
+        // kind 2 = candidate for the simple path: k_aln_prelude demotes it to 1 when the read has a low-quality InDel (that test reads the
+        // base qualities, which uvcgpu_region_correct_bq may still change on the device)
+        kind[i] = F.simple ? 0 : (F.p2ok ? 2 : 1);
+        p2_first[(size_t)i + 1] = p2_first[(size_t)i] + F.n_p2;
+        if (!F.simple) {
+            table_off[i] = table_rows; table_rows += F.trows;   // + the row of an insertion right behind the last aligned base (rpos == bam_endpos)
+            item_off[i] = item_slots; item_slots += F.items;    // upper bound of P2 updates of this read
+            gap_off[i] = gap_slots; gap_slots += F.gaps; ins_total += F.ins;   // one InDel event per I / D op
         }
         else max_aln_span = std::max(max_aln_span, e - in->pos[i]);
         prev_fam = fam; prev_strand = strand; prev_frag = in->frag_id[i];
     }
+    // Phase C, on all host cores: the P2 work-list entries at their places
+    std::vector<P2Seg> p2((size_t)p2_first[(size_t)n]);
+    host_parallel([&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; i++) {
+            if (facts[(size_t)i].n_p2 == 0) continue;
+            const int32_t nc = in->n_cigar[i];
+            const uint32_t *cg = in->cigars + in->cigar_off[i];
+            const int fl = in->flag[i];
+            const int32_t p2cls = ((fl & 0x10) ? 1 : 0) | ((((fl & 0x81) == 0x81) ? ((fl & 0x20) != 0) : ((fl & 0x10) != 0)) ? 2 : 0);
+            int32_t rp = in->pos[i]; int64_t qp = 0; size_t w = (size_t)p2_first[(size_t)i];
+            for (int k = 0; k < nc; k++) {
+                const int op = (int)(cg[k] & 0xF); const int32_t len = (int32_t)(cg[k] >> 4);
+                if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) { p2[w++] = P2Seg{ rp, rp + len, (int32_t)i, (int32_t)((in->seq_off[i] + qp - rp) & 0xFFFFFFFFLL), p2cls }; rp += len; qp += len; }
+                else if (op == C_INS || op == C_SOFT_CLIP) qp += len;
+                else if (op == C_DEL) rp += len;
+            }
+        }
+    });
     lap("classify reads (host)");
     const UvcParams &P = r->P;
     const bool singleton_ok = (P.fam_thres_dup1add >= 2 && P.fam_thres_dup2add >= 2 && P.fam_thres_emperr_all_flat_snv >= 2 && P.fam_thres_emperr_all_flat_indel >= 2);
