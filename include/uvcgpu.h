@@ -258,6 +258,8 @@ typedef struct UvcTumorKey {
     int32_t indel_len;
     /* the rest of TumorKeyInfo that the somatic quality of the normal-sample record reads (main.cpp:1104-1147, main.hpp:6095-6206) */
     int32_t cVQ1, cPCQ1, cDP2x, CDP2x, cVQ2, cPCQ2, bNMQ, vHGQ, tDP;
+    /* INFO values the record of the normal sample repeats from the tumor record (main.cpp:366-372, main.hpp:6214-6218): tADR, tDPC */
+    int32_t tAD0, tAD1, t2DP;
 } UvcTumorKey;
 
 /* One row of the per-strand InDel allele tables that fill_by_indel_info pushes into gapSeq / gapbAD1 / gapcAD1 / gc2AD / gc2dAD
@@ -336,6 +338,29 @@ int uvcgpu_region_fetch(uvcgpu_region_t *r, int32_t field_group, void *dst, int6
  * getPosToIseqToData / getPosToDlenToData / pos2iseq2data_cDP2 / pos2iseq2data_c2dDP in main.hpp:5350-5376. */
 int uvcgpu_region_indel_alleles(uvcgpu_region_t *r, UvcGapRow *rows, int64_t row_capacity, int64_t *n_rows,
                                 uint8_t *seq, int64_t seq_capacity, int64_t *seq_bytes);
+/* Every plane value of chosen positions, one row of uvcgpu_region_n_columns() int64 values per position: the groups in UvcField order
+ * (PREP32 .. DUPLEX; RTR and BAQ are not part of a row), the planes of a group in the group's array order, i.e. column =
+ * uvcgpu_region_column_base(group) + plane.  Positions outside the region give a row of zeros.  Replaces the getByPos() reads of
+ * BcfFormat_symboltype_init / BcfFormat_symbol_init for the few positions whose records are written (main.hpp:3889-4251). */
+int32_t uvcgpu_region_n_columns(void);
+int32_t uvcgpu_region_column_base(int32_t field_group);   /* -1 for RTR / BAQ / out of range */
+int uvcgpu_region_fetch_columns(uvcgpu_region_t *r, const int32_t *refpos, int64_t n, int64_t *dst /* [n][n_columns] */);
+
+/* ---------------------------------------------------------------- VCF text ------ */
+/* The header and the record lines of the reference's output for the scored records of a region: generate_vcf_header (the ##FILTER /
+ * ##FORMAT / ##INFO / ##contig lines and the #CHROM line) and append_vcf_record + bcfrec::streamAppendBcfFormat (main.hpp:6027-6272,
+ * bcf_formats_generator1.cpp:135-527, 643-690): CHROM POS ID REF ALT QUAL FILTER INFO FORMAT and the sample column with every FORMAT tag
+ * of FORMAT_STRING_PER_REC(_WITHOUT_SSCS), in the reference's order and separators.  Not produced here: the read-level haplotype strings
+ * bHap / cHap / c2Hap (always "."), FORMAT/note, and the GERMLINE / gVCF-block / ADDITIONAL_INDEL_CANDIDATE lines.
+ * Both return UVCGPU_ENOMEM with *len = the size needed when `capacity` is too small. */
+const char *uvcgpu_vcf_format_keys(int32_t with_tier2_consensus_tags);
+int uvcgpu_vcf_header(const UvcParams *params, const char *sample_name, const char *const *contig_names, const int64_t *contig_lens,
+                      int32_t n_contigs, char *dst, int64_t capacity, int64_t *len);
+/* `scored` is what uvcgpu_region_score filled for this region (all records, in order: the REF record of a position supplies the first
+ * value of every Number=R tag); the lines of the records with out != 0 and keep != 0 are written.  The planes must not have been
+ * released (UvcScoreRequest::release_state = 0).  `tumor_keys` as in the score request (NULL for a tumor-only sample). */
+int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *contig_name, const UvcScoreOut *scored,
+                              const UvcTumorKey *tumor_keys, int64_t n_tumor_keys, char *dst, int64_t capacity, int64_t *len);
 int uvcgpu_region_sync(uvcgpu_region_t *r);
 /* Measurement hooks (bench.py): HIP-event timing of every kernel of the LAST accumulate, recorded on the handle's stream.
  * kernel_times returns the number of kernels; `names` receives their names separated by ';'. */

@@ -208,6 +208,24 @@ int uvc_oracle_region_indel_alleles(void *h, UvcGapRow *rows, int64_t row_capaci
     return 0;
 }
 
+// The text of the records the request writes: per record "<CHROM..INFO> \x1e <tier2 flag> \x1e <FORMAT field lines>", records joined by \x1d.
+// The test streams the field lines through the reference's own streamAppendBcfFormat (oracle/_ref/libref_vcf.so).
+int uvc_oracle_region_vcf(void *h, const UvcScoreRequest *req, const char *tname, char *dst, int64_t cap, int64_t *len) {
+    State &S = *(State *)h;
+    VcfSink sink; sink.tname = tname;
+    S.vcf_sink = &sink;
+    std::vector<std::vector<i32>> recs;
+    int rc = score(S, req, recs, g_err);
+    S.vcf_sink = nullptr;
+    if (rc) return rc;
+    std::string out;
+    for (size_t i = 0; i < sink.fixed.size(); i++) { if (i) out += '\x1d'; out += sink.fixed[i]; out += '\x1e'; out += (sink.tier2[i] ? "1" : "0"); out += '\x1e'; out += sink.spec[i]; }
+    *len = (int64_t)out.size();
+    if (!dst || cap < (int64_t)out.size()) { g_err = "destination too small"; return UVCGPU_ENOMEM; }
+    memcpy(dst, out.data(), out.size());
+    return 0;
+}
+
 void uvc_oracle_destroy(void *h) { delete (State *)h; }
 
 // ---- unit-test hooks for the math primitives (tests/test_oracle_math.py) ----

@@ -93,7 +93,10 @@ struct FamStrand { int frag_beg, frag_end; };
 struct Family { FamStrand fs[2]; int dflag; };
 
 // dense per-position state, same plane layout as the uvcgpu fetch groups
+struct VcfSink { std::string tname; std::vector<std::string> fixed, spec; std::vector<int> tier2; };   // text of the written records (vcf_emit, oracle_score.cpp)
+
 struct State {
+    VcfSink *vcf_sink = nullptr;
     i32 tid, beg, end;      // state covers [beg, end): end = caller's `end` + 1 (main.cpp:569)
     i64 npos;
     std::vector<u8> refsym;            // region_symbolvec (string2symbolseq, main_conversion.hpp:531-539), npos-1 entries + 1 pad

@@ -78,6 +78,7 @@ struct Fmt {
     i32 bDPa, cDP0a, gapSa_len, gapSa_row;
     // outputs of calc_DPv
     i32 nPF[2], bNMa, bNMb, bNMQ, nNFA[6], nAFA[9], nBCFA[10], FTS, tier2;
+    i32 FTSpct[19];   // round(100 * biasFA / refFA) of each fmt_bias_push, the number FORMAT/FTS prints behind the bias name (main.hpp:4268)
     i32 cDP1v, cDP1w, cDP1x, cDP2v, cDP2w, cDP2x;
     i32 CDPv[6][2];
     // outputs of calc_qual
@@ -417,6 +418,7 @@ static void calc_DPv(Fmt &fmt, const Rtr &rtr1, const Rtr &rtr2, int refsymbol, 
     auto push = [&](i32 *vec, int idx, double refFA, double biasFA) {   // fmt_bias_push, main.hpp:4258-4272
         vec[idx] = -numstates2deciphred(biasFA);
         if (biasFA < refFA * P.bias_thres_FTS_FA) fmt.FTS |= (1 << bit);
+        fmt.FTSpct[bit] = (i32)round(100.0 * biasFA / refFA);
         bit++;
     };
     push(fmt.nAFA, 0, aDPFA, aSSFA2); push(fmt.nAFA, 1, aDPFA, aPFFA); push(fmt.nAFA, 2, aDPFA, aSIFA);
@@ -987,6 +989,147 @@ static void call_record(const UvcParams &P, Fmt &fmt, const Fmt &reffmt, const s
 }
 
 // per-position driver, main.cpp:608-1000
+// ---- VCF text of one written record: the string half of append_vcf_record (main.hpp:6050-6067, 6206-6270) and, for the sample column,
+// the field values of the bcfrec::BcfFormat it streams, as "TAG \t N \t v1 \x1f v2 ..." lines.  The test feeds those lines to the
+// REFERENCE's own streamAppendBcfFormat (oracle/ref_vcf_driver.cpp over the header its generator prints), so the layout of the sample
+// column is the reference's, not a restatement.  Not carried: bHap / cHap / c2Hap and note (left at the reference's defaults).
+static void vcf_emit(State &S, const Fmt &f, const Fmt &rf, const std::string &indelstring, const std::vector<UvcGapRow> &gap_rows, const std::vector<u8> &gap_seq, i32 zpos) {
+    const UvcParams &P = S.P;
+    const int symbol = f.symbol, refsymbol = f.refsymbol;
+    const int st = (symbol <= UVC_BASE_NN ? UVC_BASE_SYMBOL : UVC_LINK_SYMBOL), nn = (st == UVC_BASE_SYMBOL ? UVC_BASE_NN : UVC_LINK_NN);
+    const i32 refpos = f.refpos; const i64 x = refpos - S.beg;
+    const i32 regionpos = refpos - S.beg;
+    auto row_text = [&](const UvcGapRow &g) { std::string t; if (g.seq_off >= 0) for (int c = 0; c < g.len; c++) t += "ACGTN"[gap_seq[(size_t)g.seq_off + c]]; else t = S.refstring.substr((size_t)(g.refpos - S.beg), (size_t)g.len); return t; };
+    // ---- CHROM .. INFO ----
+    i32 vcfpos; std::string vcfref, vcfalt;
+    if (indelstring.size() > 0) {
+        vcfpos = refpos; vcfref = (regionpos > 0 ? S.refstring.substr((size_t)regionpos - 1, 1) : "n"); vcfalt = vcfref;
+        if ('<' == indelstring[0]) vcfalt = indelstring; else if (is_ins(symbol)) vcfalt += indelstring; else vcfref += indelstring;
+    } else {
+        if (is_subst(symbol)) { vcfpos = refpos + 1; vcfref = S.refstring.substr((size_t)regionpos, 1); }
+        else { vcfpos = refpos; vcfref = (regionpos > 0 ? S.refstring.substr((size_t)regionpos - 1, 1) : "n"); }
+        vcfalt = (symbol < NSYM ? SYMBOL_DESC[symbol] : "<NONE>");
+    }
+    float vcfqual; memcpy(&vcfqual, &f.QUALbits, 4);
+    const char *const FILTERS[7] = { "Q10", "Q20", "Q30", "Q40", "Q50", "Q60", "PASS" };
+    i32 cdpd_b[2] = { 0, 0 }, ddp2_sum = 0;
+    for (int k = 0; k < ST_NSYMBOLS[st]; k++) { const int sy = ST_SYMBOLS[st][k]; cdpd_b[0] += S.FA(0, UVC_FAM_cDPD, sy, x); cdpd_b[1] += S.FA(1, UVC_FAM_cDPD, sy, x); ddp2_sum += S.DU(UVC_DUPLEX_dDP2, sy, x); }
+    const i32 DDP2[2] = { ddp2_sum, S.DU(UVC_DUPLEX_dDP2, nn, x) };
+    std::vector<size_t> own_rows;   // fill_by_indel_info: forward rows, then reverse rows (main.cpp:858-869)
+    if (is_ins(symbol) || is_del(symbol)) for (size_t q = 0; q < gap_rows.size(); q++) if (gap_rows[q].refpos == refpos && gap_rows[q].symbol == symbol) own_rows.push_back(q);
+    i32 cond_altDP;   // fill_conditional_tki, main.hpp:5943-5979
+    if (is_ins(symbol) || is_del(symbol)) { cond_altDP = 0; for (size_t q : own_rows) if (row_text(gap_rows[q]) == indelstring) cond_altDP += gap_rows[q].c2dAD; }
+    else cond_altDP = f.cDPDf + f.cDPDr + f.dDP2;
+    const i32 tADCR[2] = { rf.cDPDf + rf.cDPDr + rf.dDP2, cond_altDP };
+    const bool normal = (f.tkey != NULL);
+    std::string info = (normal ? "SOMATIC" : "ANY_VAR");
+    info += ";SomaticQ=" + std::to_string(f.SomaticQ) + ";TLODQ=" + std::to_string(f.TLODQ) + ";NLODQ=" + std::to_string(f.NLODQ);
+    info += std::string(";NLODV=") + (f.NLODV < NSYM ? SYMBOL_DESC[f.NLODV] : "<NONE>");
+    info += ";TNBQF=" + std::to_string(f.TNBQF[0]) + "," + std::to_string(f.TNBQF[1]) + "," + std::to_string(f.TNBQF[2]) + "," + std::to_string(f.TNBQF[3]);
+    info += ";TNCQF=" + std::to_string(f.TNCQF[0]) + "," + std::to_string(f.TNCQF[1]) + "," + std::to_string(f.TNCQF[2]) + "," + std::to_string(f.TNCQF[3]);
+    if (!normal) {
+        info += ";tbDP=" + std::to_string(f.BDPb[0] + f.BDPb[1]) + ";tDP=" + std::to_string(f.DP) + ";tAD=" + std::to_string(rf.AD) + "," + std::to_string(f.AD);
+        info += ";t2DP=" + std::to_string((cdpd_b[0] + cdpd_b[1]) + (DDP2[0] + DDP2[1])) + ";t2AD=" + std::to_string(tADCR[0]) + "," + std::to_string(tADCR[1]);
+    } else {
+        const UvcTumorKey &k = *f.tkey;
+        info += ";tbDP=" + std::to_string(k.BDP) + ";tDP=" + std::to_string(k.tDP) + ";tAD=" + std::to_string(k.tAD0) + "," + std::to_string(k.tAD1);
+        info += ";t2DP=" + std::to_string(k.t2DP) + ";t2AD=" + std::to_string(tADCR[0]) + "," + std::to_string(tADCR[1]);
+        info += ";nDP=" + std::to_string(f.DP) + ";nAD=" + std::to_string(rf.AD) + "," + std::to_string(f.AD) + ";n2AD=0,0";
+    }
+    {   // RU / RC: indelpos_to_context at this zerobased_pos (main.cpp:609-613)
+        i32 us = 0, rn = 0;
+        indelpos_to_context(us, rn, S.refstring, zpos - S.beg, P.indel_str_repeatsize_max);
+        const i32 at = zpos - S.beg;
+        info += ";RU=" + ((at >= 0 && at < (i32)S.refstring.size()) ? S.refstring.substr((size_t)at, (size_t)us) : std::string()) + ";RC=" + std::to_string(rn);
+    }
+    {
+        const i32 d = P.indel_adj_tracklen_dist, nr = (i32)S.rtr.size();
+        const Rtr &r1 = S.rtr[(size_t)(max_(regionpos, d) - d)], &r2 = S.rtr[(size_t)min_(regionpos + d, nr - d)];
+        info += ";R3X2=" + std::to_string(r1.tracklen ? S.beg + r1.begpos : 0) + "," + std::to_string(r1.tracklen) + "," + std::to_string(r1.unitlen) + ","
+              + std::to_string(r2.tracklen ? S.beg + r2.begpos : 0) + "," + std::to_string(r2.tracklen) + "," + std::to_string(r2.unitlen);
+    }
+    std::string fixed = S.vcf_sink->tname + "\t" + std::to_string(vcfpos) + "\t.\t" + vcfref + "\t" + vcfalt + "\t" + std::to_string(vcfqual) + "\t" + FILTERS[min_(max_(f.FILTER, 0), 6)] + "\t" + info;
+    // ---- the bcfrec::BcfFormat of this record ----
+    std::string spec;
+    auto L = [&](const char *tag, std::initializer_list<i64> v) { spec += tag; spec += '\t'; spec += std::to_string(v.size()); spec += '\t'; bool first = true; for (i64 e : v) { if (!first) spec += '\x1f'; first = false; spec += std::to_string(e); } spec += '\n'; };
+    auto LS = [&](const char *tag, const std::vector<std::string> &v) { spec += tag; spec += '\t'; spec += std::to_string(v.size()); spec += '\t'; for (size_t q = 0; q < v.size(); q++) { if (q) spec += '\x1f'; spec += v[q]; } spec += '\n'; };
+    auto LV = [&](const char *tag, const std::vector<i64> &v) { spec += tag; spec += '\t'; spec += std::to_string(v.size()); spec += '\t'; for (size_t q = 0; q < v.size(); q++) { if (q) spec += '\x1f'; spec += std::to_string(v[q]); } spec += '\n'; };
+    L("enable_tier2_consensus_format_tags", { f.tier2 });
+    LS("GT", { "./1" });   // main.cpp:1097; GQ / HQ / FT keep the defaults
+    {
+        static const char *const NAMES[19] = { "aStrand", "aBQXM", "aInsertSize", "aAlignL", "aAlignR", "aPositionL", "aPositionR", "abPositionL", "abPositionR",
+                                               "bcDup", "cbDup", "c0Orientation", "c2Orientation", "c2PositionL", "c2PositionR", "c2AlignL", "c2AlignR", "c2StrictPosL", "c2StrictPosR" };
+        std::string fts;
+        for (int b = 0; b < 19; b++) if (f.FTS & (1 << b)) { if (!fts.empty()) fts += "|"; fts += std::string(NAMES[b]) + "-" + std::to_string(f.FTSpct[b]); }
+        LS("FTS", { fts.empty() ? std::string("PASS") : fts });
+    }
+    L("DP", { f.DP }); L("AD", { rf.AD, f.AD }); L("bDP", { f.bDP }); L("bAD", { rf.bAD, f.bAD }); L("c2DP", { f.c2DP }); L("c2AD", { rf.c2AD, f.c2AD });
+    LV("APDP", std::vector<i64>(f.APDP, f.APDP + 12)); LV("APXM", std::vector<i64>(f.APXM, f.APXM + 8));
+    L("APLRID", { S.p64(UVC_P_a_near_ins_l_pow2len, x), S.p64(UVC_P_a_near_ins_r_pow2len, x), S.p64(UVC_P_a_near_del_l_pow2len, x), S.p64(UVC_P_a_near_del_r_pow2len, x) });
+    LV("APLRI", std::vector<i64>(f.APLRI, f.APLRI + 4));
+    L("APLRP", { S.p32(UVC_P_a_l_dist_sum, x), S.p32(UVC_P_a_r_dist_sum, x), S.p32(UVC_P_a_inslen_sum, x), S.p32(UVC_P_a_dellen_sum, x) });
+    L("ALRPxT", { S.th(UVC_T_aLPxT, x), S.th(UVC_T_aRPxT, x) });
+    L("ALRIT", { S.th(UVC_T_aLI1T, x), S.th(UVC_T_aLI2T, x), S.th(UVC_T_aRI1T, x), S.th(UVC_T_aRI2T, x) });
+    L("ALRIt", { S.th(UVC_T_aLI1t, x), S.th(UVC_T_aLI2t, x), S.th(UVC_T_aRI1t, x), S.th(UVC_T_aRI2t, x) });
+    L("ALRPt", { S.th(UVC_T_aLP1t, x), S.th(UVC_T_aLP2t, x), S.th(UVC_T_aRP1t, x), S.th(UVC_T_aRP2t, x) });
+    L("ALRBt", { S.th(UVC_T_aLB1t, x), S.th(UVC_T_aLB2t, x), S.th(UVC_T_aRB1t, x), S.th(UVC_T_aRB2t, x) });
+#define RR(tag) L(#tag, { rf.tag, f.tag })
+#define T2(tag) L(#tag, { f.tag[0], f.tag[1] })
+    RR(aMQs); T2(AMQs); RR(a1BQf); T2(A1BQf); RR(a1BQr); T2(A1BQr);
+    RR(aDPff); T2(ADPff); RR(aDPfr); T2(ADPfr); RR(aDPrf); T2(ADPrf); RR(aDPrr); T2(ADPrr);
+    RR(aLP1); T2(ALP1); RR(aLP2); T2(ALP2); RR(aLPL); T2(ALPL);
+    RR(aRP1); T2(ARP1);
+    RR(aRP2); T2(ARP2); RR(aRPL); T2(ARPL);
+    RR(aLB1); RR(aLB2); T2(ALB2); RR(aLBL); T2(ALBL); RR(aRB1); RR(aRB2); T2(ARB2); RR(aRBL); T2(ARBL);
+    RR(aLI1); RR(aLI2); T2(ALI2); RR(aLIr); T2(ALIr); RR(aRI1); RR(aRI2); T2(ARI2); RR(aRIf); T2(ARIf);
+    RR(aBQ2); T2(ABQ2); RR(aPF2); T2(APF2); RR(aP1); T2(AP1); RR(aP2); T2(AP2);
+    RR(aPF1); RR(aLIT); RR(aRIT); RR(aP3); RR(aNC);
+    RR(bDPf); RR(bDPr); T2(BDPb); RR(bTAf); RR(bTAr); T2(BTAb); RR(bTBf); RR(bTBr); T2(BTBb);   // BDPd is never filled
+    RR(cDP1f); RR(cDP1r); T2(CDP1b); L("CDP1d", { S.FA(0, UVC_FAM_cDP1, nn, x), S.FA(0, UVC_FAM_cDP1, nn, x) });   // fill_symboltype_nn_fmt, main.hpp:3774-3786
+    RR(cDP12f); RR(cDP12r); T2(CDP12b); RR(cDP2f); RR(cDP2r); T2(CDP2b);
+    RR(c2BQ2); T2(C2BQ2); RR(c2LP0); T2(C2LP0); RR(c2RP0); T2(C2RP0);
+    RR(c2LP1); RR(c2LP2); T2(C2LP2); RR(c2RP1); RR(c2RP2); T2(C2RP2); RR(c2LPL); T2(C2LPL); RR(c2RPL); T2(C2RPL);
+    RR(c2LB1); RR(c2LB2); T2(C2LB2); RR(c2RB1); RR(c2RB2); T2(C2RB2); RR(c2LBL); T2(C2LBL); RR(c2RBL); T2(C2RBL);
+    RR(cDP3f); RR(cDP3r); T2(CDP3b); RR(cDP21f); RR(cDP21r); RR(cDPMf); RR(cDPMr); RR(cDPmf); RR(cDPmr); RR(cDPDf); RR(cDPDr);
+    {
+        auto frsum = [&](int fld, i64 out2[2]) { for (int sd = 0; sd < 2; sd++) { i32 acc = 0; for (int k = 0; k < ST_NSYMBOLS[st]; k++) acc += S.FA(sd, fld, ST_SYMBOLS[st][k], x); out2[sd] = acc; } };
+        i64 v2[2];
+        frsum(UVC_FAM_cDP21, v2); L("CDP21b", { v2[0], v2[1] }); frsum(UVC_FAM_cDPM, v2); L("CDPMb", { v2[0], v2[1] });
+        frsum(UVC_FAM_cDPm, v2); L("CDPmb", { v2[0], v2[1] }); frsum(UVC_FAM_cDPD, v2); L("CDPDb", { v2[0], v2[1] });
+    }
+    T2(DDP1); RR(dDP1); L("DDP2", { DDP2[0], DDP2[1] }); RR(dDP2);
+    RR(aBQ); RR(a2BQf); RR(a2BQr); RR(a2XM2); RR(a2BM2); RR(aBQQ);
+    RR(bMQ); RR(aAaMQ); RR(bNMQ); RR(bNMa); RR(bNMb); RR(bMQQ);
+    RR(bIAQb); RR(bIADb); RR(bIDQb); RR(cIAQf); RR(cIADf); RR(cIDQf); RR(cIAQr); RR(cIADr); RR(cIDQr);
+    RR(bIAQ); RR(cIAQ); RR(bTINQ); RR(cTINQ); RR(cPCQ1); RR(cPLQ1); RR(cVQ1); RR(gVQ1); RR(cPCQ2); RR(cPLQ2); RR(cVQ2); RR(cMmQ); RR(dVQinc);
+    RR(cDP1v); RR(cDP1w); RR(cDP1x); RR(cDP2v); RR(cDP2w); RR(cDP2x);
+    { static const char *const NM[6] = { "CDP1v", "CDP1w", "CDP1x", "CDP2v", "CDP2w", "CDP2x" }; for (int q = 0; q < 6; q++) L(NM[q], { f.CDPv[q][0], f.CDPv[q][1] }); }
+    RR(CONTQ);
+    LV("nPF", std::vector<i64>(f.nPF, f.nPF + 2)); LV("nNFA", std::vector<i64>(f.nNFA, f.nNFA + 6)); LV("nAFA", std::vector<i64>(f.nAFA, f.nAFA + 9)); LV("nBCFA", std::vector<i64>(f.nBCFA, f.nBCFA + 10));
+    L("VTI", { refsymbol, symbol }); LS("VTD", { SYMBOL_DESC[refsymbol], SYMBOL_DESC[symbol] });
+    T2(cVQ1M); T2(cVQ2M);
+    {
+        std::vector<std::string> am, sm;
+        for (int q = 0; q < 2; q++) { am.push_back(f.cVQAM[q] < NSYM ? SYMBOL_DESC[f.cVQAM[q]] : "<NONE>"); sm.push_back((f.cVQSM[q] >= 0 && f.cVQSM[q] < (i32)gap_rows.size()) ? row_text(gap_rows[(size_t)f.cVQSM[q]]) : std::string()); }
+        LS("cVQAM", am); LS("cVQSM", sm);
+    }
+    {
+        std::vector<i64> nf, nr, b1, c1, c2, c2d; std::vector<std::string> seqs;
+        if (is_ins(symbol) || is_del(symbol)) for (int sd = 0; sd < 2; sd++) if (0 < S.FR(sd, UVC_FRAG_bDP, symbol, x)) {
+            i64 cnt = 0;
+            for (size_t q : own_rows) if (gap_rows[q].strand == sd) { cnt++; seqs.push_back(row_text(gap_rows[q])); b1.push_back(gap_rows[q].bAD1); c1.push_back(gap_rows[q].cAD1); c2.push_back(gap_rows[q].c2AD); c2d.push_back(gap_rows[q].c2dAD); }
+            (sd ? nr : nf).push_back(cnt);
+        }
+        LV("gapNf", nf); LV("gapNr", nr); LS("gapSeq", seqs); LV("gapbAD1", b1); LV("gapcAD1", c1); LV("gc2AD", c2); LV("gc2dAD", c2d);
+    }
+    RR(bDPa); RR(cDP0a); LS("gapSa", { std::string(), indelstring });
+    L("vHGQ", { f.vHGQ }); T2(vAC);
+    if (st == UVC_BASE_SYMBOL) L("vNLODQ", { f.vNLODQ, 0 }); else L("vNLODQ", { 0, f.vNLODQ });
+#undef RR
+#undef T2
+    S.vcf_sink->fixed.push_back(fixed); S.vcf_sink->spec.push_back(spec); S.vcf_sink->tier2.push_back(f.tier2);
+}
+
 int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &records, std::string &err) {
     if (!S.accumulated) { err = "score before accumulate"; return UVCGPU_ESTATE; }
     const UvcParams &P = S.P;
@@ -1135,6 +1278,7 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
                 if (!reffmt) { err = "a scored position has no REF allele"; return UVCGPU_ESTATE; }   // the reference aborts, main.cpp:1025-1029
                 call_record(P, f, *reffmt, fmts[st], st, st_refsymbol[st], (all_out || is_germline_var_generated));
                 std::vector<i32> r; emit(f, r); records.push_back(r);
+                if (S.vcf_sink && f.keep && f.out) vcf_emit(S, f, *reffmt, texts[st][(size_t)(&f - &fmts[st][0])], gap_rows, gap_seq, zpos);
             }
         }
     }

@@ -1,0 +1,203 @@
+"""VCF text.  The layout side is pinned on the REFERENCE's own generated code: oracle/_ref/libref_vcf.so wraps the header that
+the reference's bcf_formats_generator1.cpp prints (built from where it lies by oracle/Makefile, as the reference's Makefile:55-59 does):
+its FORMAT key strings, ##FORMAT / ##FILTER lines and streamAppendBcfFormat are reference code, not a restatement.
+
+CPU tests: the product's FORMAT key strings equal the reference's; the ID / Number / Type of every ##FORMAT line and the ##FILTER IDs equal
+the reference's (the Description texts are this repository's own wording).
+GPU tests: for the same reads, every record line of the HIP path equals the line made from the oracle's values with the fixed columns
+of the oracle's restatement of append_vcf_record and the sample column streamed by the reference's streamAppendBcfFormat -- integer depth /
+count tags exactly, Phred-like tags within 1, x100 depth tags within 1 %, QUAL within 1e-3."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from uvc_amd import _ffi, region, synth
+from util import run_region
+
+REF_SO = os.path.join(_ffi.ROOT, "oracle", "_ref", "libref_vcf.so")
+
+
+@pytest.fixture(scope="module")
+def ref_vcf():
+    if not os.path.exists(REF_SO):
+        pytest.skip("oracle/_ref/libref_vcf.so not built (make -C oracle ref_formats needs /root/reference)")
+    L = C.CDLL(REF_SO)
+    for n in ("uvc_ref_format_string", "uvc_ref_format_id", "uvc_ref_format_line", "uvc_ref_filter_id", "uvc_ref_filter_line"):
+        getattr(L, n).restype = C.c_char_p
+    L.uvc_ref_stream_format.restype = C.c_int64
+    L.uvc_ref_stream_format.argtypes = [C.c_char_p, C.c_char_p, C.c_int64]
+    return L
+
+
+@pytest.fixture(scope="module")
+def product_dll():
+    return C.CDLL(_ffi.gpu_library_path())   # loading needs no GPU; the text entry points used on the CPU are host-only
+
+
+class _HostLib:
+    def __init__(self, dll):
+        self.dll = dll
+
+    def last_error(self):
+        self.dll.uvcgpu_last_error.restype = C.c_char_p
+        return (self.dll.uvcgpu_last_error() or b"").decode()
+
+
+def test_format_keys_equal_reference(ref_vcf, product_dll):
+    lib = _HostLib(product_dll)
+    for tier2 in (0, 1):
+        assert region.vcf_format_keys(lib, tier2) == ref_vcf.uvc_ref_format_string(tier2).decode()
+
+
+def _parse_meta(line):
+    m = re.match(r'##(\w+)=<ID=([^,]+)(?:,Number=([^,]+),Type=([^,]+))?,Description="(.*)">$', line)
+    assert m, line
+    return m.groups()
+
+
+def test_header_lines_match_reference_ids_numbers_types(ref_vcf, product_dll):
+    lib = _HostLib(product_dll)
+    p = _ffi.UvcParams()
+    product_dll.uvcgpu_params_default.argtypes = [C.POINTER(_ffi.UvcParams)]
+    product_dll.uvcgpu_params_default(C.byref(p))
+    hdr = region.vcf_header(lib, p, "S1", [("chr20", 64444167), ("chrM", 16569)]).splitlines()
+    assert hdr[0] == "##fileformat=VCFv4.2" and hdr[1] == "##contig=<ID=chr20,length=64444167>" and hdr[2] == "##contig=<ID=chrM,length=16569>"
+    assert hdr[-1] == "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1"
+    mine_fmt = [_parse_meta(l) for l in hdr if l.startswith("##FORMAT=")]
+    ref_fmt = [_parse_meta(ref_vcf.uvc_ref_format_line(i).decode()) for i in range(ref_vcf.uvc_ref_n_format())]
+    skipped = {"C2LP2", "C2RP2", "C2LPL", "C2RPL", "C2LB2", "C2RB2", "C2LBL", "C2RBL"}   # not_put_in_vcf(): declared by the reference, never written
+    ref_fmt = [r for r in ref_fmt if r[1] not in skipped]
+    assert [m[1:4] for m in mine_fmt] == [r[1:4] for r in ref_fmt]
+    for m, r in zip(mine_fmt, ref_fmt):
+        assert m[4].startswith("SUB-HEADER: ") == r[4].startswith("SUB-HEADER: "), m[1]
+    mine_flt = [_parse_meta(l)[1] for l in hdr if l.startswith("##FILTER=")]
+    assert mine_flt == [ref_vcf.uvc_ref_filter_id(i).decode() for i in range(ref_vcf.uvc_ref_n_filter())]
+    info_ids = [_parse_meta(l)[1] for l in hdr if l.startswith("##INFO=")]
+    for k in ("ANY_VAR", "SOMATIC", "SomaticQ", "TLODQ", "NLODQ", "NLODV", "TNBQF", "TNCQF", "tbDP", "tDP", "tAD", "t2DP", "t2AD", "nDP", "nAD", "n2AD", "RU", "RC", "R3X2"):
+        assert k in info_ids
+
+
+# ---- GPU: record lines ----
+PHRED_TAGS = {"aBQ", "a2BQf", "a2BQr", "aBQQ", "bMQ", "aAaMQ", "bNMQ", "bNMa", "bNMb", "bMQQ", "bIAQ", "cIAQ", "bTINQ", "cTINQ", "cPCQ1", "cPLQ1", "cVQ1", "gVQ1",
+              "cPCQ2", "cPLQ2", "cVQ2", "cMmQ", "dVQinc", "CONTQ", "nPF", "nNFA", "nAFA", "nBCFA", "cVQ1M", "cVQ2M", "vHGQ", "vNLODQ"}
+PCT_TAGS = {"cDP1v", "CDP1v", "cDP1w", "CDP1w", "cDP1x", "CDP1x", "cDP2v", "CDP2v", "cDP2w", "CDP2w", "cDP2x", "CDP2x"}
+PHRED_INFO = {"SomaticQ", "TLODQ", "NLODQ", "TNBQF", "TNCQF"}
+
+
+def _oracle_lines(oracle_lib, ref_vcf, Ro, tname, **score_kw):
+    fn = oracle_lib.dll.uvc_oracle_region_vcf
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.POINTER(_ffi.UvcScoreRequest), C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    req = _ffi.UvcScoreRequest()
+    req.pos_beg, req.pos_end, req.all_out, req.is_amplicon = -1, -1, int(score_kw.get("all_out", False)), 0
+    ln = C.c_int64(0)
+    fn(Ro.h, C.byref(req), tname.encode(), None, 0, C.byref(ln))
+    buf = C.create_string_buffer(max(1, ln.value))
+    assert fn(Ro.h, C.byref(req), tname.encode(), buf, ln.value, C.byref(ln)) == 0
+    text = buf.raw[:ln.value].decode()
+    out = []
+    sbuf = C.create_string_buffer(1 << 20)
+    for rec in (text.split("\x1d") if text else []):
+        fixed, tier2, spec = rec.split("\x1e")
+        n = ref_vcf.uvc_ref_stream_format(spec.encode(), sbuf, 1 << 20)
+        assert n > 0, n
+        out.append(fixed + "\t" + ref_vcf.uvc_ref_format_string(int(tier2)).decode() + "\t" + sbuf.value.decode())
+    return out
+
+
+def _cmp_ints(tag, a, b, tol_kind):
+    xa, xb = a.split(","), b.split(",")
+    assert len(xa) == len(xb), (tag, a, b)
+    for u, v in zip(xa, xb):
+        if u == v:
+            continue
+        iu, iv = int(u), int(v)
+        if tol_kind == "phred":
+            assert abs(iu - iv) <= 1, (tag, a, b)
+        elif tol_kind == "pct":
+            assert abs(iu - iv) <= max(1, abs(iu) // 100), (tag, a, b)
+        else:
+            raise AssertionError((tag, a, b))
+
+
+def compare_lines(mine, want):
+    assert len(mine) == len(want), (len(mine), len(want))
+    n_tags = 0
+    for lm, lw in zip(mine, want):
+        cm, cw = lm.split("\t"), lw.split("\t")
+        assert len(cm) == len(cw) == 10, (len(cm), len(cw))
+        assert cm[:5] == cw[:5], (cm[:5], cw[:5])                               # CHROM POS ID REF ALT
+        assert abs(float(cm[5]) - float(cw[5])) <= 1e-3 * max(1.0, abs(float(cw[5]))), (cm[5], cw[5])
+        if abs(float(cm[5]) - round(float(cw[5]), -1)) > 0.01:                  # FILTER steps at multiples of 10
+            assert cm[6] == cw[6], (cm[:7], cw[:7])
+        im, iw = cm[7].split(";"), cw[7].split(";")
+        assert [e.split("=")[0] for e in im] == [e.split("=")[0] for e in iw], (cm[7], cw[7])
+        for em, ew in zip(im, iw):
+            if em == ew:
+                continue
+            k = em.split("=")[0]
+            assert k in PHRED_INFO, (em, ew)
+            _cmp_ints(k, em.split("=")[1], ew.split("=")[1], "phred")
+        assert cm[8] == cw[8]
+        keys, vm, vw = cm[8].split(":"), cm[9].split(":"), cw[9].split(":")
+        assert len(keys) == len(vm) == len(vw), (len(keys), len(vm), len(vw))
+        for k, a, b in zip(keys, vm, vw):
+            n_tags += 1
+            if a == b:
+                continue
+            if k == "FTS":   # names must agree; the percentages are rebuilt from deciPhred values on the product side
+                pa, pb = a.split("|"), b.split("|")
+                assert [e.rsplit("-", 1)[0] for e in pa] == [e.rsplit("-", 1)[0] for e in pb], (a, b)
+                for ea, eb in zip(pa, pb):
+                    if "-" in ea:
+                        assert abs(int(ea.rsplit("-", 1)[1]) - int(eb.rsplit("-", 1)[1])) <= 1, (a, b)
+                continue
+            _cmp_ints(k, a, b, "phred" if k in PHRED_TAGS else "pct" if k in PCT_TAGS else "exact")
+    return n_tags
+
+
+CASES = {
+    "config1_10kb_30x": dict(region_len=10000, depth=30, seed=12345),
+    "config2shape_5kb_300x": dict(region_len=5000, depth=300, seed=7),
+    "umi_duplex_2kb_400x": dict(region_len=2000, depth=400, seed=11, umi=True),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CASES))
+def test_record_lines_match_oracle_and_reference_stream(name, oracle_lib, gpu_lib, ref_vcf):
+    reads = synth.generate_region(**CASES[name])
+    Ro, Rg = run_region(oracle_lib, reads), run_region(gpu_lib, reads)
+    rg = Rg.score()
+    mine = Rg.vcf_records("chr20", rg).splitlines()
+    want = _oracle_lines(oracle_lib, ref_vcf, Ro, "chr20")
+    assert len(want) > 0
+    n = compare_lines(mine, want)
+    print(name, len(mine), "lines", n, "tags compared")
+
+
+@pytest.mark.gpu
+def test_columns_equal_planes(gpu_lib):
+    reads = synth.generate_region(region_len=2000, depth=100, seed=21, umi=True)
+    Rg = run_region(gpu_lib, reads)
+    pos = np.array([reads["beg"] + 5, reads["beg"] + 777, reads["end"] - 3, reads["beg"] - 10, reads["end"] + 50], dtype=np.int32)
+    cols = Rg.fetch_columns(pos)
+    assert (cols[3] == 0).all() and (cols[4] == 0).all()   # outside the region
+    for g in ["PREP32", "PREP64", "THRES", "SEG32", "SEG64", "VQ", "BQSUM", "FRAG", "FAM", "FAMINFO32", "FAMINFO64", "DUPLEX"]:
+        planes = Rg.fetch(g)
+        flat = planes.reshape(-1, planes.shape[-1])
+        base = Rg.column_base(g)
+        for i in range(3):
+            assert np.array_equal(cols[i, base:base + flat.shape[0]], flat[:, pos[i] - reads["beg"]].astype(np.int64)), g
+
+
+@pytest.mark.gpu
+def test_vcf_records_need_the_planes(gpu_lib):
+    reads = synth.generate_region(region_len=1000, depth=60, seed=4)
+    Rg = run_region(gpu_lib, reads)
+    rg = Rg.score(release_state=True)
+    with pytest.raises(region.UvcError):
+        Rg.vcf_records("chr20", rg)

@@ -50,7 +50,7 @@ class UvcIndelAllele(C.Structure):
 class UvcTumorKey(C.Structure):
     _fields_ = [("refpos", C.c_int32), ("symbol", C.c_int32), ("cDP1x", C.c_int32), ("CDP1x", C.c_int32), ("bDP", C.c_int32), ("BDP", C.c_int32),
                 ("tier2", C.c_int32), ("indel_len", C.c_int32)]
-    _fields_ += [(n, C.c_int32) for n in ("cVQ1", "cPCQ1", "cDP2x", "CDP2x", "cVQ2", "cPCQ2", "bNMQ", "vHGQ", "tDP")]
+    _fields_ += [(n, C.c_int32) for n in ("cVQ1", "cPCQ1", "cDP2x", "CDP2x", "cVQ2", "cPCQ2", "bNMQ", "vHGQ", "tDP", "tAD0", "tAD1", "t2DP")]
 
 
 class UvcGapRow(C.Structure):

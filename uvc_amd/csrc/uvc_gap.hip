@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <stdint.h>
+#include "uvcgpu.h"
 
 extern "C" size_t uvc_gap_sort_tmp_bytes(size_t n) {
     size_t bytes = 0;
@@ -52,4 +53,31 @@ extern "C" void uvc_launch_gather4(const unsigned long long *perm, int64_t n, co
 }
 extern "C" void uvc_launch_rank_from_sorted(const unsigned long long *perm, int64_t n, int64_t n_first, int32_t *out_ids, int32_t *rank, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_rank_from_sorted, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perm, n, n_first, out_ids, rank);
+}
+
+// ---- columns of chosen positions (uvcgpu_region_fetch_columns): every plane value of a position as one int64 row ----
+// The planes are position-fastest, so the columns of one position are n_cols separate cache lines; a thread takes one (position, column)
+// and the rows are written coalesced.  This is the read side of the record writer (O(emitted records)), not of the hot path.
+struct ColGroups { const char *base[UVC_NUM_FIELD_GROUPS]; int32_t first_col[UVC_NUM_FIELD_GROUPS + 1]; int32_t elem[UVC_NUM_FIELD_GROUPS]; };
+__global__ void __launch_bounds__(256) k_gather_columns(ColGroups G, int64_t npos, const int32_t *xs, int64_t n, int32_t n_cols, long long *out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * n_cols) return;
+    const int64_t i = t / n_cols; const int32_t c = (int32_t)(t - i * n_cols);
+    const int64_t x = xs[i];
+    long long v = 0;
+    if (x >= 0 && x < npos) {
+        int g = 0;
+        while (g + 1 < UVC_NUM_FIELD_GROUPS && c >= G.first_col[g + 1]) g++;
+        const int64_t at = (int64_t)(c - G.first_col[g]) * npos + x;
+        v = (G.elem[g] == 8) ? ((const long long *)G.base[g])[at] : (long long)((const int32_t *)G.base[g])[at];
+    }
+    out[t] = v;
+}
+extern "C" void uvc_launch_gather_columns(const char *const *base, const int32_t *first_col, const int32_t *elem, int64_t npos, const int32_t *d_xs, int64_t n, long long *d_out, hipStream_t s) {
+    ColGroups G;
+    for (int g = 0; g < UVC_NUM_FIELD_GROUPS; g++) { G.base[g] = base[g]; G.first_col[g] = first_col[g]; G.elem[g] = elem[g]; }
+    G.first_col[UVC_NUM_FIELD_GROUPS] = first_col[UVC_NUM_FIELD_GROUPS];
+    const int32_t n_cols = first_col[UVC_NUM_FIELD_GROUPS];
+    const int64_t total = n * n_cols;
+    if (total > 0) hipLaunchKernelGGL(k_gather_columns, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, G, npos, d_xs, n, n_cols, d_out);
 }

@@ -28,6 +28,7 @@ extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const Uv
                                 const UvcGapRow *d_gap_rows, const uint8_t *d_gap_seq, const UvcTumorKey *d_tkeys, int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch, hipStream_t s);
 extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored);
 extern "C" size_t uvc_gap_sort_tmp_bytes(size_t n);
+extern "C" void uvc_launch_gather_columns(const char *const *base, const int32_t *first_col, const int32_t *elem, int64_t npos, const int32_t *d_xs, int64_t n, long long *d_out, hipStream_t s);
 extern "C" int uvc_sort_by_pos_cls(const int32_t *d_pos, const int32_t *d_cls, int32_t beg, int shift, int64_t n, unsigned long long *work, void *tmp, size_t tmp_bytes, hipStream_t s);
 extern "C" void uvc_launch_gather4(const unsigned long long *perm, int64_t n, const int32_t *a0, const int32_t *a1, const int32_t *a2, const int32_t *a3, int32_t *o0, int32_t *o1, int32_t *o2, int32_t *o3, hipStream_t s);
 extern "C" void uvc_launch_rank_from_sorted(const unsigned long long *perm, int64_t n, int64_t n_first, int32_t *out_ids, int32_t *rank, hipStream_t s);
@@ -42,6 +43,7 @@ struct uvcgpu_region {
     int32_t tid, beg, end;     // state covers [beg, end): end = caller's end + 1 (main.cpp:569)
     int64_t npos;
     std::string refstring;
+    std::vector<int32_t> h_rtr;   // host copy of the repeat tracks as built (the record writer reads begpos / tracklen / unitlen)
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr; hipEvent_t e_fork = nullptr, e_join = nullptr, e_fork2 = nullptr;   // fork/join inside accumulate (see uvc_launch_accumulate)
     // device buffers
@@ -270,6 +272,7 @@ static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t 
         const int32_t v[UVC_NRTR] = { t.begpos, t.tracklen, t.unitlen, t.indelphred, t.a_begpos, t.a_tracklen, t.a_unitlen };
         for (int f = 0; f < UVC_NRTR; f++) rtr[(size_t)f * r->npos + i] = v[f];
     }
+    r->h_rtr = rtr;
     // one slab for all per-position planes (+ the transient bucket planes), 8-byte groups first
     const int order[] = { UVC_F_PREP64, UVC_F_SEG64, UVC_F_FAMINFO64, UVC_F_PREP32, UVC_F_THRES, UVC_F_SEG32, UVC_F_VQ, UVC_F_BQSUM, UVC_F_FRAG, UVC_F_FAM, UVC_F_FAMINFO32, UVC_F_DUPLEX };
     size_t o = 0;
@@ -727,6 +730,56 @@ int uvcgpu_region_fetch(uvcgpu_region_t *r, int32_t g, void *dst, int64_t dst_by
     HIP_OK(hipMemcpy(dst, src, (size_t)dst_bytes, hipMemcpyDeviceToHost));
     return 0;
 }
+
+// ---- columns of chosen positions (the read side of the record writer, uvc_vcf.cpp) ----
+namespace {
+int group_elem(int g) { return (g == UVC_F_PREP64 || g == UVC_F_SEG64 || g == UVC_F_FAMINFO64 || g == UVC_F_BAQ) ? 8 : 4; }
+int group_planes(int g) {
+    switch (g) {
+        case UVC_F_PREP32: return UVC_NPREP32; case UVC_F_PREP64: return UVC_NPREP64; case UVC_F_THRES: return UVC_NTHRES; case UVC_F_SEG32: return UVC_NSEG32 * NSYM;
+        case UVC_F_SEG64: return UVC_NSEG64 * NSYM; case UVC_F_VQ: return UVC_NVQ * NSYM; case UVC_F_BQSUM: return NSYM; case UVC_F_FRAG: return 2 * UVC_NFRAG * NSYM;
+        case UVC_F_FAM: return 2 * UVC_NFAM * NSYM; case UVC_F_FAMINFO32: return UVC_NFAMINFO32 * NSYM; case UVC_F_FAMINFO64: return UVC_NFAMINFO64 * NSYM; case UVC_F_DUPLEX: return UVC_NDUPLEX * NSYM;
+    }
+    return 0;   // RTR / BAQ are not part of a row
+}
+}
+int32_t uvcgpu_region_column_base(int32_t g) {
+    if (g < 0 || g >= UVC_NUM_FIELD_GROUPS || group_planes(g) == 0) return -1;
+    int32_t at = 0;
+    for (int q = 0; q < g; q++) at += group_planes(q);
+    return at;
+}
+int32_t uvcgpu_region_n_columns(void) { int32_t at = 0; for (int q = 0; q < UVC_NUM_FIELD_GROUPS; q++) at += group_planes(q); return at; }
+int uvcgpu_region_fetch_columns(uvcgpu_region_t *r, const int32_t *refpos, int64_t n, int64_t *dst) {
+    if (!r || n < 0 || (n > 0 && (!refpos || !dst))) return fail(UVCGPU_EINVAL, "bad argument");
+    if (!r->accumulated) return fail(UVCGPU_ESTATE, "fetch before accumulate");
+    if (r->state_released) return fail(UVCGPU_ESTATE, "the planes were released by the last score (UvcScoreRequest::release_state)");
+    if (n == 0) return 0;
+    int rc = uvcgpu_region_sync(r);
+    if (rc) return rc;
+    const int32_t ncol = uvcgpu_region_n_columns();
+    const char *base[UVC_NUM_FIELD_GROUPS]; int32_t first[UVC_NUM_FIELD_GROUPS + 1], elem[UVC_NUM_FIELD_GROUPS];
+    int32_t at = 0;
+    for (int g = 0; g < UVC_NUM_FIELD_GROUPS; g++) { first[g] = at; at += group_planes(g); elem[g] = group_elem(g); base[g] = (group_planes(g) ? r->d_state + r->off[g] : r->d_state); }
+    first[UVC_NUM_FIELD_GROUPS] = at;
+    std::vector<int32_t> xs((size_t)n);
+    for (int64_t i = 0; i < n; i++) xs[(size_t)i] = refpos[i] - r->beg;   // out of range -> a row of zeros (checked in the kernel)
+    int32_t *d_xs = nullptr; long long *d_out = nullptr;
+    if (hipMalloc((void **)&d_xs, sizeof(int32_t) * (size_t)n) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(column positions) failed");
+    if (hipMalloc((void **)&d_out, sizeof(long long) * (size_t)n * ncol) != hipSuccess) { hipFree(d_xs); return fail(UVCGPU_ENOMEM, "hipMalloc(columns) failed"); }
+    hipError_t e = hipMemcpyAsync(d_xs, xs.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, r->stream);
+    if (e == hipSuccess) { uvc_launch_gather_columns(base, first, elem, r->npos, d_xs, n, d_out, r->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, d_out, sizeof(long long) * (size_t)n * ncol, hipMemcpyDeviceToHost, r->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+    hipFree(d_xs); hipFree(d_out);
+    if (e != hipSuccess) return fail(UVCGPU_EDEVICE, hipGetErrorString(e));
+    return 0;
+}
+// what uvc_vcf.cpp reads of a handle besides the public calls
+const char *uvcgpu_region_refseq(const uvcgpu_region_t *r, int32_t *beg, int32_t *end) { if (beg) *beg = r->beg; if (end) *end = r->end - 1; return r->refstring.c_str(); }
+const int32_t *uvcgpu_region_repeat_tracks(const uvcgpu_region_t *r, int64_t *npos) { if (npos) *npos = r->npos; return r->h_rtr.data(); }
+const UvcParams *uvcgpu_region_params(const uvcgpu_region_t *r) { return &r->P; }
+int uvcgpu_fail_(int code, const char *msg) { return fail(code, msg); }
 
 // ---- InDel allele tables: the host half of fill_by_indel_info / indel_get_majority (instcode.hpp, main.hpp:5350-5455) ----
 // The device reduces the allele-keyed counters to one GapRow per (position, symbol, allele) (k_gap_rows); what is left is per InDel

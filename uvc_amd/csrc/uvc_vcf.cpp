@@ -1,0 +1,612 @@
+// uvc_vcf.cpp -- VCF text of the scored records of a region: the host half of append_vcf_record and of the generated
+// bcfrec::streamAppendBcfFormat (main.hpp:6027-6272, bcf_formats_generator1.cpp:135-527, 643-690), on top of the public C ABI:
+// the score records (uvcgpu_region_score), the plane columns of the positions that are written (uvcgpu_region_fetch_columns, one small
+// gather kernel) and the InDel allele rows (uvcgpu_region_indel_alleles).  O(emitted records); nothing here is on the hot path.
+#include "uvcgpu.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" const char *uvcgpu_region_refseq(const uvcgpu_region_t *r, int32_t *beg, int32_t *end);   // uvc_host.cpp
+extern "C" const int32_t *uvcgpu_region_repeat_tracks(const uvcgpu_region_t *r, int64_t *npos);    // host copy, [UVC_NRTR][npos]
+extern "C" const UvcParams *uvcgpu_region_params(const uvcgpu_region_t *r);
+extern "C" int uvcgpu_fail_(int code, const char *msg);
+
+namespace {
+const int NSYM = 14;
+const char *const SYMBOL_DESC[NSYM + 1] = { "A", "C", "G", "T", "N", "*", "<LR>", "<LD3P>", "<LD2>", "<LD1>", "<LI3P>", "<LI2>", "<LI1>", "*", "<NONE>" };   // main_conversion.hpp:336-346
+const char *const FILTER_Q[7] = { "Q10", "Q20", "Q30", "Q40", "Q50", "Q60", "PASS" };
+// the FORMAT/FTS names in the order BcfFormat_symbol_calc_DPv pushes them (main.hpp:4745-4769): 9 against nAFA, 10 against nBCFA
+const char *const FTS_NAMES[19] = { "aStrand", "aBQXM", "aInsertSize", "aAlignL", "aAlignR", "aPositionL", "aPositionR", "abPositionL", "abPositionR",
+                                    "bcDup", "cbDup", "c0Orientation", "c2Orientation", "c2PositionL", "c2PositionR", "c2AlignL", "c2AlignR", "c2StrictPosL", "c2StrictPosR" };
+// the allele fraction each FTS entry is compared with, as an index into nNFA (2 = aDPFA, 3 = bFA, 4 = cFA0, 5 = cFA2)
+const int FTS_REF[19] = { 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 4, 4, 5, 5, 5, 5, 5, 5, 5 };
+
+inline bool is_base(int s) { return s <= UVC_BASE_NN; }
+inline bool is_ins(int s) { return s == UVC_LINK_I1 || s == UVC_LINK_I2 || s == UVC_LINK_I3P; }
+inline bool is_del(int s) { return s == UVC_LINK_D1 || s == UVC_LINK_D2 || s == UVC_LINK_D3P; }
+
+// ---- the FORMAT tags, in the order of the reference's FORMAT_VEC ----
+enum Kind {
+    K_SEP, K_SPECIAL,
+    K_R_S32, K_R_S64, K_R_VQ, K_R_FRf, K_R_FRr, K_R_FAf, K_R_FAr, K_R_FI, K_R_FI64, K_R_DU,   // Number=R from the planes of the REF and ALT symbol
+    K_T1_S32, K_T1L_S32, K_T1_S64, K_T1_VQ, K_T1_FI,   // "2,1": the sum over the symbols of the type (int32 tags truncate it)
+    K_T2_S32, K_T2_DU,                                   // "2": that sum and the value of the type's NN symbol
+    K_FR2_FR, K_FR2_FA, K_NN2_FA, K_ZERO2,               // "2": forward and reverse sums; the NN symbol twice (CDP1d); never filled (BDPd, CDP2d)
+    K_POS,                                               // position-level lists
+    K_R_REC, K_1_REC, K_N_REC,                           // from the score record(s): Number=R, one value, n consecutive fields
+};
+struct Tag { const char *name; const char *number; const char *type; int kind; int a; int n; bool sscs; const char *desc; };
+#define SEG "sequenced-segment (read) statistic"
+#define FRA "fragment statistic, duplicates kept"
+#define FAM "de-duplicated fragment / UMI-family statistic"
+#define SSC "tier-2 single-strand consensus (SSCS) statistic"
+const Tag TAGS[] = {
+    { "GT", "1", "String", K_SPECIAL, 0, 0, false, "Genotype (a guess for tumor samples)" },
+    { "GQ", "1", "Integer", K_SPECIAL, 0, 0, false, "Genotype quality" },
+    { "HQ", "2", "Integer", K_SPECIAL, 0, 0, false, "Haplotype quality" },
+    { "FT", "1", "String", K_SPECIAL, 0, 0, false, "Genotype filter" },
+    { "FTS", "A", "String", K_SPECIAL, 0, 0, false, "Variant filter: PASS or a |-separated list of bias names, each followed by the percent of the unbiased allele fraction that remains" },
+    { "_A_", "1", "String", K_SEP, 0, 0, false, "Summary depths" },
+    { "DP", "1", "Integer", K_1_REC, UVC_O_DP, 1, false, "De-duplicated fragment depth" },
+    { "AD", "R", "Integer", K_R_REC, UVC_O_AD, 1, false, "De-duplicated fragment depth of the REF and ALT allele" },
+    { "bDP", "1", "Integer", K_1_REC, UVC_O_bDP, 1, false, "Fragment depth, duplicates kept" },
+    { "bAD", "R", "Integer", K_R_REC, UVC_O_bAD, 1, false, "Fragment depth of the REF and ALT allele, duplicates kept" },
+    { "c2DP", "1", "Integer", K_1_REC, UVC_O_c2DP, 1, false, "Tier-2 consensus family depth" },
+    { "c2AD", "R", "Integer", K_R_REC, UVC_O_c2AD, 1, false, "Tier-2 consensus family depth of the REF and ALT allele" },
+    { "_Aa", "1", "String", K_SEP, 0, 0, false, "Position-level segment statistics" },
+    { "APDP", "12", "Integer", K_POS, 0, 12, false, "Segment depths: all, near insertions / deletions, inside repeat tracks of insertions / deletions, amplicon, SNV, DNV, high-BQ, near-clip, confident, UMI-labelled" },
+    { "APXM", "8", "Integer", K_POS, 1, 8, false, "Mismatches and gap openings per 1500 bp, query length, InDel length, squared and inverse InDel lengths (insertions, deletions)" },
+    { "_Ab", "1", "String", K_SEP, 0, 0, false, "Position-level segment statistics" },
+    { "APLRID", "4", "Integer", K_POS, 2, 4, false, "Squared insertion and deletion lengths towards the left and right end of the InDel-affected region" },
+    { "APLRI", "4", "Integer", K_POS, 3, 4, false, "Summed distance to the left insert end and the number of such inserts; the same for the right end" },
+    { "APLRP", "4", "Integer", K_POS, 4, 4, false, "Summed distance to the left and right segment end, summed insertion and deletion length" },
+    { "_Ac", "1", "String", K_SEP, 0, 0, false, "Bias thresholds (tier 1 = weak, tier 2 = strong)" },
+    { "ALRPxT", "2", "Integer", K_POS, 5, 2, false, "Distance to the left / right segment end above which a segment is not used for position bias" },
+    { "ALRIT", "4", "Integer", K_POS, 6, 4, false, "Distance to the left / right insert end above which there is tier-1 / tier-2 insert bias" },
+    { "ALRIt", "4", "Integer", K_POS, 7, 4, false, "Distance to the left / right insert end below which there is tier-1 / tier-2 insert bias" },
+    { "ALRPt", "4", "Integer", K_POS, 8, 4, false, "Distance to the left / right segment end below which there is tier-1 / tier-2 position bias" },
+    { "ALRBt", "4", "Integer", K_POS, 9, 4, false, "Base-alignment quality to the left / right segment end below which there is tier-1 / tier-2 bias" },
+    { "_AQ", "1", "String", K_SEP, 0, 0, false, "Sums of qualities. Lower-case first letter: REF and ALT allele; upper-case: all alleles of the symbol type by sum" },
+    { "aMQs", "R", "Integer", K_R_S32, UVC_S_aMQs, 1, false, SEG ": sum of mapping qualities" },
+    { "AMQs", "1", "Integer", K_T1_S32, UVC_S_aMQs, 1, false, SEG ": sum of mapping qualities" },
+    { "a1BQf", "R", "Integer", K_R_VQ, UVC_VQ_a1BQf, 1, false, SEG ": sum of base qualities, forward strand" },
+    { "A1BQf", "1", "Integer", K_T1_VQ, UVC_VQ_a1BQf, 1, false, SEG ": sum of base qualities, forward strand" },
+    { "a1BQr", "R", "Integer", K_R_VQ, UVC_VQ_a1BQr, 1, false, SEG ": sum of base qualities, reverse strand" },
+    { "A1BQr", "1", "Integer", K_T1_VQ, UVC_VQ_a1BQr, 1, false, SEG ": sum of base qualities, reverse strand" },
+    { "_ADPf", "1", "String", K_SEP, 0, 0, false, "Segment depths, forward orientation" },
+    { "aDPff", "R", "Integer", K_R_S32, UVC_S_aDPff, 1, false, SEG ": depth, R1 forward" },
+    { "ADPff", "2", "Integer", K_T2_S32, UVC_S_aDPff, 1, false, SEG ": depth, R1 forward" },
+    { "aDPfr", "R", "Integer", K_R_S32, UVC_S_aDPfr, 1, false, SEG ": depth, R2 reverse" },
+    { "ADPfr", "2", "Integer", K_T2_S32, UVC_S_aDPfr, 1, false, SEG ": depth, R2 reverse" },
+    { "_ADPr", "1", "String", K_SEP, 0, 0, false, "Segment depths, reverse orientation" },
+    { "aDPrf", "R", "Integer", K_R_S32, UVC_S_aDPrf, 1, false, SEG ": depth, R2 forward" },
+    { "ADPrf", "2", "Integer", K_T2_S32, UVC_S_aDPrf, 1, false, SEG ": depth, R2 forward" },
+    { "aDPrr", "R", "Integer", K_R_S32, UVC_S_aDPrr, 1, false, SEG ": depth, R1 reverse" },
+    { "ADPrr", "2", "Integer", K_T2_S32, UVC_S_aDPrr, 1, false, SEG ": depth, R1 reverse" },
+    { "_ALP", "1", "String", K_SEP, 0, 0, false, "Position bias, left side" },
+    { "aLP1", "R", "Integer", K_R_S32, UVC_S_aLP1, 1, false, SEG ": depth free of tier-1 left position bias" },
+    { "ALP1", "1", "Integer", K_T1_S32, UVC_S_aLP1, 1, false, SEG ": depth free of tier-1 left position bias" },
+    { "aLP2", "R", "Integer", K_R_S32, UVC_S_aLP2, 1, false, SEG ": depth free of tier-2 left position bias" },
+    { "ALP2", "1", "Integer", K_T1_S32, UVC_S_aLP2, 1, false, SEG ": depth free of tier-2 left position bias" },
+    { "aLPL", "R", "Integer", K_R_S32, UVC_S_aLPL, 1, false, SEG ": summed distance to the left segment end" },
+    { "ALPL", "1", "Integer", K_T1L_S32, UVC_S_aLPL, 1, false, SEG ": summed distance to the left segment end" },
+    { "_ARP", "1", "String", K_SEP, 0, 0, false, "Position bias, right side" },
+    { "aRP1", "R", "Integer", K_R_S32, UVC_S_aRP1, 1, false, SEG ": depth free of tier-1 right position bias" },
+    { "ARP1", "1", "Integer", K_T1_S32, UVC_S_aRP1, 1, false, SEG ": depth free of tier-1 right position bias" },
+    { "aRP2", "R", "Integer", K_R_S32, UVC_S_aRP2, 1, false, SEG ": depth free of tier-2 right position bias" },
+    { "ARP2", "1", "Integer", K_T1_S32, UVC_S_aRP2, 1, false, SEG ": depth free of tier-2 right position bias" },
+    { "aRPL", "R", "Integer", K_R_S32, UVC_S_aRPL, 1, false, SEG ": summed distance to the right segment end" },
+    { "ARPL", "1", "Integer", K_T1L_S32, UVC_S_aRPL, 1, false, SEG ": summed distance to the right segment end" },
+    { "_ALB", "1", "String", K_SEP, 0, 0, false, "Base-alignment-quality bias, left side" },
+    { "aLB1", "R", "Integer", K_R_S32, UVC_S_aLB1, 1, false, SEG ": depth free of tier-1 left alignment bias" },
+    { "aLB2", "R", "Integer", K_R_S32, UVC_S_aLB2, 1, false, SEG ": depth free of tier-2 left alignment bias" },
+    { "ALB2", "1", "Integer", K_T1_S32, UVC_S_aLB2, 1, false, SEG ": depth free of tier-2 left alignment bias" },
+    { "aLBL", "R", "Integer", K_R_S64, UVC_S64_aLBL, 1, false, SEG ": summed base-alignment quality to the left end" },
+    { "ALBL", "1", "Integer", K_T1_S64, UVC_S64_aLBL, 1, false, SEG ": summed base-alignment quality to the left end" },
+    { "_ARB", "1", "String", K_SEP, 0, 0, false, "Base-alignment-quality bias, right side" },
+    { "aRB1", "R", "Integer", K_R_S32, UVC_S_aRB1, 1, false, SEG ": depth free of tier-1 right alignment bias" },
+    { "aRB2", "R", "Integer", K_R_S32, UVC_S_aRB2, 1, false, SEG ": depth free of tier-2 right alignment bias" },
+    { "ARB2", "1", "Integer", K_T1_S32, UVC_S_aRB2, 1, false, SEG ": depth free of tier-2 right alignment bias" },
+    { "aRBL", "R", "Integer", K_R_S64, UVC_S64_aRBL, 1, false, SEG ": summed base-alignment quality to the right end" },
+    { "ARBL", "1", "Integer", K_T1_S64, UVC_S64_aRBL, 1, false, SEG ": summed base-alignment quality to the right end" },
+    { "_ALI", "1", "String", K_SEP, 0, 0, false, "Insert-end bias, left side" },
+    { "aLI1", "R", "Integer", K_R_S32, UVC_S_aLI1, 1, false, SEG ": depth free of tier-1 left insert bias" },
+    { "aLI2", "R", "Integer", K_R_S32, UVC_S_aLI2, 1, false, SEG ": depth free of tier-2 left insert bias" },
+    { "ALI2", "1", "Integer", K_T1_S32, UVC_S_aLI2, 1, false, SEG ": depth free of tier-2 left insert bias" },
+    { "aLIr", "R", "Integer", K_R_S32, UVC_S_aLIr, 1, false, SEG ": depth eligible for left reverse-strand bias" },
+    { "ALIr", "1", "Integer", K_T1_S32, UVC_S_aLIr, 1, false, SEG ": depth eligible for left reverse-strand bias" },
+    { "_ARI", "1", "String", K_SEP, 0, 0, false, "Insert-end bias, right side" },
+    { "aRI1", "R", "Integer", K_R_S32, UVC_S_aRI1, 1, false, SEG ": depth free of tier-1 right insert bias" },
+    { "aRI2", "R", "Integer", K_R_S32, UVC_S_aRI2, 1, false, SEG ": depth free of tier-2 right insert bias" },
+    { "ARI2", "1", "Integer", K_T1_S32, UVC_S_aRI2, 1, false, SEG ": depth free of tier-2 right insert bias" },
+    { "aRIf", "R", "Integer", K_R_S32, UVC_S_aRIf, 1, false, SEG ": depth eligible for right forward-strand bias" },
+    { "ARIf", "1", "Integer", K_T1_S32, UVC_S_aRIf, 1, false, SEG ": depth eligible for right forward-strand bias" },
+    { "_AX", "1", "String", K_SEP, 0, 0, false, "Further segment statistics" },
+    { "aBQ2", "R", "Integer", K_R_S32, UVC_S_aBQ2, 1, false, SEG ": depth free of tier-2 base-quality bias" },
+    { "ABQ2", "1", "Integer", K_T1_S32, UVC_S_aBQ2, 1, false, SEG ": depth free of tier-2 base-quality bias" },
+    { "aPF2", "R", "Integer", K_R_S32, UVC_S_aPF2, 1, false, SEG ": depth free of tier-2 mismatch and base-quality bias" },
+    { "APF2", "1", "Integer", K_T1_S32, UVC_S_aPF2, 1, false, SEG ": depth free of tier-2 mismatch and base-quality bias" },
+    { "aP1", "R", "Integer", K_R_S32, UVC_S_aP1, 1, false, SEG ": depth passing the distance-to-end thresholds" },
+    { "AP1", "1", "Integer", K_T1_S32, UVC_S_aP1, 1, false, SEG ": depth passing the distance-to-end thresholds" },
+    { "aP2", "R", "Integer", K_R_S32, UVC_S_aP2, 1, false, SEG ": depth that is UMI-labelled or not from amplicons" },
+    { "AP2", "1", "Integer", K_T1_S32, UVC_S_aP2, 1, false, SEG ": depth that is UMI-labelled or not from amplicons" },
+    { "_Ax", "1", "String", K_SEP, 0, 0, false, "Further segment statistics of the REF and ALT allele" },
+    { "aPF1", "R", "Integer", K_R_S32, UVC_S_aPF1, 1, false, SEG ": depth free of tier-1 mismatch and base-quality bias" },
+    { "aLIT", "R", "Integer", K_R_S64, UVC_S64_aLIT, 1, false, SEG ": summed distance to the left insert end" },
+    { "aRIT", "R", "Integer", K_R_S64, UVC_S64_aRIT, 1, false, SEG ": summed distance to the right insert end" },
+    { "aP3", "R", "Integer", K_R_S32, UVC_S_aP3, 1, false, SEG ": depth not affected by nearby InDels" },
+    { "aNC", "R", "Integer", K_R_S32, UVC_S_aNC, 1, false, SEG ": depth without clips" },
+    { "_BDP", "1", "String", K_SEP, 0, 0, false, "Fragment depths with duplicates" },
+    { "bDPf", "R", "Integer", K_R_FRf, UVC_FRAG_bDP, 1, false, FRA ": depth, forward" },
+    { "bDPr", "R", "Integer", K_R_FRr, UVC_FRAG_bDP, 1, false, FRA ": depth, reverse" },
+    { "BDPb", "2", "Integer", K_FR2_FR, UVC_FRAG_bDP, 1, false, FRA ": depth of all alleles, forward and reverse" },
+    { "BDPd", "2", "Integer", K_ZERO2, 0, 0, false, FRA ": depth of the padded deletion allele (not filled)" },
+    { "bTAf", "R", "Integer", K_R_FRf, UVC_FRAG_bTA, 1, false, FRA ": sequenced fragment positions, forward" },
+    { "bTAr", "R", "Integer", K_R_FRr, UVC_FRAG_bTA, 1, false, FRA ": sequenced fragment positions, reverse" },
+    { "BTAb", "2", "Integer", K_FR2_FR, UVC_FRAG_bTA, 1, false, FRA ": sequenced fragment positions of all alleles, forward and reverse" },
+    { "bTBf", "R", "Integer", K_R_FRf, UVC_FRAG_bTB, 1, false, FRA ": fragment positions near mutations, forward" },
+    { "bTBr", "R", "Integer", K_R_FRr, UVC_FRAG_bTB, 1, false, FRA ": fragment positions near mutations, reverse" },
+    { "BTBb", "2", "Integer", K_FR2_FR, UVC_FRAG_bTB, 1, false, FRA ": fragment positions near mutations of all alleles, forward and reverse" },
+    { "_CDP1", "1", "String", K_SEP, 0, 0, false, "De-duplicated fragment depths" },
+    { "cDP1f", "R", "Integer", K_R_FAf, UVC_FAM_cDP1, 1, false, FAM ": unfiltered depth, forward" },
+    { "cDP1r", "R", "Integer", K_R_FAr, UVC_FAM_cDP1, 1, false, FAM ": unfiltered depth, reverse" },
+    { "CDP1b", "2", "Integer", K_FR2_FA, UVC_FAM_cDP1, 1, false, FAM ": unfiltered depth of all alleles, forward and reverse" },
+    { "CDP1d", "2", "Integer", K_NN2_FA, UVC_FAM_cDP1, 1, false, FAM ": unfiltered depth of the padded deletion allele" },
+    { "cDP12f", "R", "Integer", K_R_FAf, UVC_FAM_cDP12, 1, false, FAM ": BQ-filtered depth, forward" },
+    { "cDP12r", "R", "Integer", K_R_FAr, UVC_FAM_cDP12, 1, false, FAM ": BQ-filtered depth, reverse" },
+    { "CDP12b", "2", "Integer", K_FR2_FA, UVC_FAM_cDP12, 1, false, FAM ": BQ-filtered depth of all alleles, forward and reverse" },
+    { "_CDP2", "1", "String", K_SEP, 0, 0, false, "Tier-2 single-strand consensus depths" },
+    { "cDP2f", "R", "Integer", K_R_FAf, UVC_FAM_cDP2, 1, false, SSC ": depth, forward" },
+    { "cDP2r", "R", "Integer", K_R_FAr, UVC_FAM_cDP2, 1, false, SSC ": depth, reverse" },
+    { "CDP2b", "2", "Integer", K_FR2_FA, UVC_FAM_cDP2, 1, false, SSC ": depth of all alleles, forward and reverse" },
+    { "CDP2d", "2", "Integer", K_ZERO2, 0, 0, false, SSC ": depth of the padded deletion allele (not filled)" },
+    { "c2BQ2", "R", "Integer", K_R_FI, UVC_FI_c2BQ2, 1, true, SSC ": depth free of tier-2 base-quality bias" },
+    { "C2BQ2", "1", "Integer", K_T1_FI, UVC_FI_c2BQ2, 1, true, SSC ": depth free of tier-2 base-quality bias" },
+    { "c2LP0", "R", "Integer", K_R_FI, UVC_FI_c2LP0, 1, true, SSC ": depth free of strict left position bias" },
+    { "C2LP0", "1", "Integer", K_T1_FI, UVC_FI_c2LP0, 1, true, SSC ": depth free of strict left position bias" },
+    { "c2RP0", "R", "Integer", K_R_FI, UVC_FI_c2RP0, 1, true, SSC ": depth free of strict right position bias" },
+    { "C2RP0", "1", "Integer", K_T1_FI, UVC_FI_c2RP0, 1, true, SSC ": depth free of strict right position bias" },
+    { "_C2XP", "1", "String", K_SEP, 0, 0, true, "SSCS position bias; present exactly when the SSCS tags are" },
+    { "c2LP1", "R", "Integer", K_R_FI, UVC_FI_c2LP1, 1, true, SSC ": depth free of tier-1 left position bias" },
+    { "c2LP2", "R", "Integer", K_R_FI, UVC_FI_c2LP2, 1, true, SSC ": depth free of tier-2 left position bias" },
+    { "c2RP1", "R", "Integer", K_R_FI, UVC_FI_c2RP1, 1, true, SSC ": depth free of tier-1 right position bias" },
+    { "c2RP2", "R", "Integer", K_R_FI, UVC_FI_c2RP2, 1, true, SSC ": depth free of tier-2 right position bias" },
+    { "c2LPL", "R", "Integer", K_R_FI, UVC_FI_c2LPL, 1, true, SSC ": summed distance to the left consensus end" },
+    { "c2RPL", "R", "Integer", K_R_FI, UVC_FI_c2RPL, 1, true, SSC ": summed distance to the right consensus end" },
+    { "_C2XB", "1", "String", K_SEP, 0, 0, true, "SSCS alignment-quality bias" },
+    { "c2LB1", "R", "Integer", K_R_FI, UVC_FI_c2LB1, 1, true, SSC ": depth free of tier-1 left alignment bias" },
+    { "c2LB2", "R", "Integer", K_R_FI, UVC_FI_c2LB2, 1, true, SSC ": depth free of tier-2 left alignment bias" },
+    { "c2RB1", "R", "Integer", K_R_FI, UVC_FI_c2RB1, 1, true, SSC ": depth free of tier-1 right alignment bias" },
+    { "c2RB2", "R", "Integer", K_R_FI, UVC_FI_c2RB2, 1, true, SSC ": depth free of tier-2 right alignment bias" },
+    { "c2LBL", "R", "Integer", K_R_FI64, UVC_FI64_c2LBL, 1, true, SSC ": summed base-alignment quality to the left end" },
+    { "c2RBL", "R", "Integer", K_R_FI64, UVC_FI64_c2RBL, 1, true, SSC ": summed base-alignment quality to the right end" },
+    { "_CDPx", "1", "String", K_SEP, 0, 0, true, "Further UMI-family statistics" },
+    { "cDP3f", "R", "Integer", K_R_FAf, UVC_FAM_cDP3, 1, true, FAM ": strong consensus depth, forward" },
+    { "cDP3r", "R", "Integer", K_R_FAr, UVC_FAM_cDP3, 1, true, FAM ": strong consensus depth, reverse" },
+    { "CDP3b", "2", "Integer", K_FR2_FA, UVC_FAM_cDP3, 1, true, FAM ": strong consensus depth of all alleles, forward and reverse" },
+    { "cDP21f", "R", "Integer", K_R_FAf, UVC_FAM_cDP21, 1, true, FAM ": singleton families, forward" },
+    { "cDP21r", "R", "Integer", K_R_FAr, UVC_FAM_cDP21, 1, true, FAM ": singleton families, reverse" },
+    { "CDP21b", "2", "Integer", K_FR2_FA, UVC_FAM_cDP21, 1, true, FAM ": singleton families of all alleles, forward and reverse" },
+    { "_cDPMm", "1", "String", K_SEP, 0, 0, true, "Fragments agreeing / disagreeing with the consensus of their family" },
+    { "cDPMf", "R", "Integer", K_R_FAf, UVC_FAM_cDPM, 1, true, FAM ": fragments supporting the family consensus, forward" },
+    { "cDPMr", "R", "Integer", K_R_FAr, UVC_FAM_cDPM, 1, true, FAM ": fragments supporting the family consensus, reverse" },
+    { "CDPMb", "2", "Integer", K_FR2_FA, UVC_FAM_cDPM, 1, true, FAM ": fragments supporting the family consensus, all alleles, forward and reverse" },
+    { "cDPmf", "R", "Integer", K_R_FAf, UVC_FAM_cDPm, 1, true, FAM ": fragments against the family consensus, forward" },
+    { "cDPmr", "R", "Integer", K_R_FAr, UVC_FAM_cDPm, 1, true, FAM ": fragments against the family consensus, reverse" },
+    { "CDPmb", "2", "Integer", K_FR2_FA, UVC_FAM_cDPm, 1, true, FAM ": fragments against the family consensus, all alleles, forward and reverse" },
+    { "CDPDb", "2", "Integer", K_FR2_FA, UVC_FAM_cDPD, 1, false, FAM ": SSCS depth outside duplex families, all alleles, forward and reverse" },
+    { "cDPDf", "R", "Integer", K_R_FAf, UVC_FAM_cDPD, 1, false, FAM ": SSCS depth outside duplex families, forward" },
+    { "cDPDr", "R", "Integer", K_R_FAr, UVC_FAM_cDPD, 1, false, FAM ": SSCS depth outside duplex families, reverse" },
+    { "_DDP", "1", "String", K_SEP, 0, 0, false, "Duplex consensus depths" },
+    { "DDP1", "2", "Integer", K_T2_DU, UVC_DUPLEX_dDP1, 1, false, "Duplex depth regardless of strand agreement: all alleles and the padded deletion allele" },
+    { "dDP1", "R", "Integer", K_R_DU, UVC_DUPLEX_dDP1, 1, false, "Duplex depth regardless of strand agreement" },
+    { "DDP2", "2", "Integer", K_T2_DU, UVC_DUPLEX_dDP2, 1, false, "Duplex depth with both strands agreeing: all alleles and the padded deletion allele" },
+    { "dDP2", "R", "Integer", K_R_DU, UVC_DUPLEX_dDP2, 1, false, "Duplex depth with both strands agreeing" },
+    { "_ea", "1", "String", K_SEP, 0, 0, false, "Systematic error seen in base qualities" },
+    { "aBQ", "R", "Integer", K_R_REC, UVC_O_aBQ, 1, false, "Root-mean-square base quality of the segments" },
+    { "a2BQf", "R", "Integer", K_R_REC, UVC_O_a2BQf, 1, false, "Root-sum-square base quality, forward strand" },
+    { "a2BQr", "R", "Integer", K_R_REC, UVC_O_a2BQr, 1, false, "Root-sum-square base quality, reverse strand" },
+    { "a2XM2", "R", "Integer", K_R_S32, UVC_S_a2XM2, 1, false, SEG ": depth free of absolute mismatch bias" },
+    { "a2BM2", "R", "Integer", K_R_S32, UVC_S_a2BM2, 1, false, SEG ": depth free of base-specific mismatch bias" },
+    { "aBQQ", "R", "Integer", K_R_REC, UVC_O_aBQQ, 1, false, "Variant quality cap from base-quality systematic error" },
+    { "_eb", "1", "String", K_SEP, 0, 0, false, "Systematic error seen in mapping qualities" },
+    { "bMQ", "R", "Integer", K_R_REC, UVC_O_bMQ, 1, false, "Root-mean-square mapping quality of the fragments" },
+    { "aAaMQ", "R", "Integer", K_R_REC, UVC_O_aAaMQ, 1, false, "Difference of average mapping quality between ALT and non-ALT segments" },
+    { "bNMQ", "R", "Integer", K_R_REC, UVC_O_bNMQ, 1, false, "Mapping-quality penalty inferred from nearby high-BQ mismatches" },
+    { "bNMa", "R", "Integer", K_R_REC, UVC_O_bNMa, 1, false, "Percent of ALT fragment positions near high-BQ mismatches" },
+    { "bNMb", "R", "Integer", K_R_REC, UVC_O_bNMb, 1, false, "Percent of non-ALT fragment positions near high-BQ mismatches" },
+    { "bMQQ", "R", "Integer", K_R_REC, UVC_O_bMQQ, 1, false, "Variant quality cap from mapping-quality systematic error" },
+    { "_eB", "1", "String", K_SEP, 0, 0, false, "Independent-read-support qualities, duplicates kept" },
+    { "bIAQb", "R", "Integer", K_R_VQ, UVC_VQ_bIAQb, 1, false, "IID allele quality" },
+    { "bIADb", "R", "Integer", K_R_VQ, UVC_VQ_bIADb, 1, false, "IID allele depth" },
+    { "bIDQb", "R", "Integer", K_R_VQ, UVC_VQ_bIDQb, 1, false, "IID quality per read" },
+    { "_eC", "1", "String", K_SEP, 0, 0, false, "Independent-read-support qualities, de-duplicated" },
+    { "cIAQf", "R", "Integer", K_R_VQ, UVC_VQ_cIAQf, 1, false, "IID allele quality, forward" },
+    { "cIADf", "R", "Integer", K_R_VQ, UVC_VQ_cIADf, 1, false, "IID allele depth, forward" },
+    { "cIDQf", "R", "Integer", K_R_VQ, UVC_VQ_cIDQf, 1, false, "IID quality per read, forward" },
+    { "cIAQr", "R", "Integer", K_R_VQ, UVC_VQ_cIAQr, 1, false, "IID allele quality, reverse" },
+    { "cIADr", "R", "Integer", K_R_VQ, UVC_VQ_cIADr, 1, false, "IID allele depth, reverse" },
+    { "cIDQr", "R", "Integer", K_R_VQ, UVC_VQ_cIDQr, 1, false, "IID quality per read, reverse" },
+    { "_eE", "1", "String", K_SEP, 0, 0, false, "Binomial variant qualities" },
+    { "bIAQ", "R", "Integer", K_R_REC, UVC_O_bIAQ, 1, false, "Binomial variant quality, duplicates kept" },
+    { "cIAQ", "R", "Integer", K_R_REC, UVC_O_cIAQ, 1, false, "Binomial variant quality, de-duplicated" },
+    { "bTINQ", "R", "Integer", K_R_REC, UVC_O_bTINQ, 1, false, "Binomial tumor-in-normal quality, fragments" },
+    { "cTINQ", "R", "Integer", K_R_REC, UVC_O_cTINQ, 1, false, "Binomial tumor-in-normal quality, consensus families" },
+    { "_eQ1", "1", "String", K_SEP, 0, 0, false, "Power-law qualities, de-duplicated fragments" },
+    { "cPCQ1", "R", "Integer", K_R_REC, UVC_O_cPCQ1, 1, false, "Power-law quality cap" },
+    { "cPLQ1", "R", "Integer", K_R_REC, UVC_O_cPLQ1, 1, false, "Power-law quality" },
+    { "cVQ1", "R", "Integer", K_R_REC, UVC_O_cVQ1, 1, false, "Final variant quality from de-duplicated fragments" },
+    { "gVQ1", "R", "Integer", K_R_REC, UVC_O_gVQ1, 1, false, "Final variant quality used for germline calls" },
+    { "_eQ2", "1", "String", K_SEP, 0, 0, false, "Power-law qualities, UMI families" },
+    { "cPCQ2", "R", "Integer", K_R_REC, UVC_O_cPCQ2, 1, false, "Power-law quality cap, families" },
+    { "cPLQ2", "R", "Integer", K_R_REC, UVC_O_cPLQ2, 1, false, "Power-law quality, families" },
+    { "cVQ2", "R", "Integer", K_R_REC, UVC_O_cVQ2, 1, false, "Final variant quality from UMI families" },
+    { "cMmQ", "R", "Integer", K_R_REC, UVC_O_cMmQ, 1, false, "Empirical base quality from within-family disagreement" },
+    { "dVQinc", "R", "Integer", K_R_REC, UVC_O_dVQinc, 1, false, "Increase of cVQ2 contributed by duplex families" },
+    { "_CDP1vx", "1", "String", K_SEP, 0, 0, false, "Effective support x 100, de-duplicated fragments" },
+    { "cDP1v", "R", "Integer", K_R_REC, UVC_O_cDP1v, 1, false, "Effective allele support x 100, within-sample" },
+    { "CDP1v", "2", "Integer", K_N_REC, UVC_O_CDP1v0, 2, false, "Effective total support x 100, within-sample" },
+    { "cDP1w", "R", "Integer", K_R_REC, UVC_O_cDP1w, 1, false, "Effective allele support x 100, quality cap" },
+    { "CDP1w", "1", "Integer", K_N_REC, UVC_O_CDP1w0, 1, false, "Effective total support x 100, quality cap" },
+    { "cDP1x", "R", "Integer", K_R_REC, UVC_O_cDP1x, 1, false, "Effective allele support x 100, between samples" },
+    { "CDP1x", "1", "Integer", K_N_REC, UVC_O_CDP1x0, 1, false, "Effective total support x 100, between samples" },
+    { "_CDP2vx", "1", "String", K_SEP, 0, 0, false, "Effective support x 100, UMI families" },
+    { "cDP2v", "R", "Integer", K_R_REC, UVC_O_cDP2v, 1, false, "Effective allele family support x 100, within-sample" },
+    { "CDP2v", "2", "Integer", K_N_REC, UVC_O_CDP2v0, 2, false, "Effective total family support x 100, within-sample" },
+    { "cDP2w", "R", "Integer", K_R_REC, UVC_O_cDP2w, 1, false, "Effective allele family support x 100, quality cap" },
+    { "CDP2w", "1", "Integer", K_N_REC, UVC_O_CDP2w0, 1, false, "Effective total family support x 100, quality cap" },
+    { "cDP2x", "R", "Integer", K_R_REC, UVC_O_cDP2x, 1, false, "Effective allele family support x 100, between samples" },
+    { "CDP2x", "1", "Integer", K_N_REC, UVC_O_CDP2x0, 1, false, "Effective total family support x 100, between samples" },
+    { "_f1", "1", "String", K_SEP, 0, 0, false, "Filter-related values" },
+    { "CONTQ", "R", "Integer", K_R_REC, UVC_O_CONTQ, 1, false, "Likelihood of the signal under contamination" },
+    { "nPF", ".", "Integer", K_N_REC, UVC_O_nPF0, 2, false, "Phred prior bias probabilities (position, alignment quality)" },
+    { "nNFA", ".", "Integer", K_N_REC, UVC_O_nNFA0, 6, false, "DeciPhred allele fractions with nullified bias" },
+    { "nAFA", ".", "Integer", K_N_REC, UVC_O_nAFA0, 9, false, "DeciPhred allele fractions from segment depths, each reduced by one bias" },
+    { "nBCFA", ".", "Integer", K_N_REC, UVC_O_nBCFA0, 10, false, "DeciPhred allele fractions from fragment and family depths" },
+    { "_g1", "1", "String", K_SEP, 0, 0, false, "Variant description" },
+    { "VTI", "R", "Integer", K_SPECIAL, 0, 0, false, "Variant-type ID of each allele" },
+    { "VTD", "R", "String", K_SPECIAL, 0, 0, false, "Variant-type description of each allele" },
+    { "cVQ1M", "2", "Integer", K_N_REC, UVC_O_cVQ1M0, 2, false, "cVQ1 of the two best alleles at this position" },
+    { "cVQ2M", "2", "Integer", K_N_REC, UVC_O_cVQ2M0, 2, false, "cVQ2 of the two best alleles at this position" },
+    { "cVQAM", "2", "String", K_SPECIAL, 0, 0, false, "Symbols of the two best alleles at this position" },
+    { "cVQSM", "2", "String", K_SPECIAL, 0, 0, false, "InDel strings of the two best alleles at this position" },
+    { "_g2", "1", "String", K_SEP, 0, 0, false, "All observed InDel sequences of this symbol" },
+    { "gapNf", ".", "Integer", K_SPECIAL, 0, 0, false, "Number of InDel sequences, forward" },
+    { "gapNr", ".", "Integer", K_SPECIAL, 0, 0, false, "Number of InDel sequences, reverse" },
+    { "gapSeq", ".", "String", K_SPECIAL, 0, 0, false, "InDel sequences" },
+    { "gapbAD1", ".", "Integer", K_SPECIAL, 0, 0, false, "Fragment count of each sequence, duplicates kept" },
+    { "gapcAD1", ".", "Integer", K_SPECIAL, 0, 0, false, "De-duplicated fragment count of each sequence" },
+    { "gc2AD", ".", "Integer", K_SPECIAL, 0, 0, false, "Tier-2 consensus family count of each sequence" },
+    { "gc2dAD", ".", "Integer", K_SPECIAL, 0, 0, false, "Tier-2 consensus family count of each sequence with duplex rescue" },
+    { "_g3", "1", "String", K_SEP, 0, 0, false, "The InDel allele of this record" },
+    { "bDPa", "R", "Integer", K_R_REC, UVC_O_bDPa, 1, false, "Fragments supporting exactly this InDel sequence, duplicates kept" },
+    { "cDP0a", "R", "Integer", K_R_REC, UVC_O_cDP0a, 1, false, "De-duplicated fragments supporting exactly this InDel sequence" },
+    { "gapSa", "R", "String", K_SPECIAL, 0, 0, false, "InDel string of each allele" },
+    { "_h1", "1", "String", K_SEP, 0, 0, false, "Haplotype information" },
+    { "bHap", "1", "String", K_SPECIAL, 0, 0, false, "Read-level linkage of nearby variants, duplicates kept (not produced by this writer)" },
+    { "cHap", "1", "String", K_SPECIAL, 0, 0, false, "Read-level linkage of nearby variants, de-duplicated (not produced by this writer)" },
+    { "c2Hap", "1", "String", K_SPECIAL, 0, 0, false, "Read-level linkage of nearby variants, tier-2 families (not produced by this writer)" },
+    { "_i1", "1", "String", K_SEP, 0, 0, false, "Other" },
+    { "vHGQ", "1", "Integer", K_1_REC, UVC_O_vHGQ, 1, false, "Phred odds of the allele distribution under an all-germline model" },
+    { "vAC", "2", "Integer", K_N_REC, UVC_O_vAC0, 2, false, "Number of SNV and InDel alleles above their quality thresholds at this position" },
+    { "vNLODQ", "2", "Integer", K_SPECIAL, 0, 0, false, "Germline-origin likelihood quality of the SNV and InDel sub-position" },
+    { "note", "1", "String", K_SPECIAL, 0, 0, false, "Free-text note" },
+};
+const int N_TAGS = (int)(sizeof(TAGS) / sizeof(TAGS[0]));
+
+// position-level lists (BcfFormat_symboltype_init, main.hpp:3897-3962): (group, plane) pairs
+struct PosSrc { int g, p; };
+const PosSrc POS_LISTS[10][12] = {
+    { { UVC_F_PREP32, UVC_P_a_dp }, { UVC_F_PREP32, UVC_P_a_near_ins_dp }, { UVC_F_PREP32, UVC_P_a_near_del_dp }, { UVC_F_PREP32, UVC_P_a_near_RTR_ins_dp },
+      { UVC_F_PREP32, UVC_P_a_near_RTR_del_dp }, { UVC_F_PREP32, UVC_P_a_pcr_dp }, { UVC_F_PREP32, UVC_P_a_snv_dp }, { UVC_F_PREP32, UVC_P_a_dnv_dp },
+      { UVC_F_PREP32, UVC_P_a_highBQ_dp }, { UVC_F_PREP32, UVC_P_a_near_pcr_clip_dp }, { UVC_F_PREP32, UVC_P_a_near_long_clip_dp }, { UVC_F_PREP32, UVC_P_a_umi_dp } },
+    { { UVC_F_PREP32, UVC_P_a_XM1500 }, { UVC_F_PREP32, UVC_P_a_GO1500 }, { UVC_F_PREP32, UVC_P_a_qlen }, { UVC_F_PREP32, UVC_P_a_GAPLEN },
+      { UVC_F_PREP64, UVC_P_a_near_ins_pow2len }, { UVC_F_PREP64, UVC_P_a_near_del_pow2len }, { UVC_F_PREP32, UVC_P_a_near_ins_inv100len }, { UVC_F_PREP32, UVC_P_a_near_del_inv100len } },
+    { { UVC_F_PREP64, UVC_P_a_near_ins_l_pow2len }, { UVC_F_PREP64, UVC_P_a_near_ins_r_pow2len }, { UVC_F_PREP64, UVC_P_a_near_del_l_pow2len }, { UVC_F_PREP64, UVC_P_a_near_del_r_pow2len } },
+    { { UVC_F_PREP64, UVC_P_a_LI }, { UVC_F_PREP32, UVC_P_a_LIDP }, { UVC_F_PREP64, UVC_P_a_RI }, { UVC_F_PREP32, UVC_P_a_RIDP } },
+    { { UVC_F_PREP32, UVC_P_a_l_dist_sum }, { UVC_F_PREP32, UVC_P_a_r_dist_sum }, { UVC_F_PREP32, UVC_P_a_inslen_sum }, { UVC_F_PREP32, UVC_P_a_dellen_sum } },
+    { { UVC_F_THRES, UVC_T_aLPxT }, { UVC_F_THRES, UVC_T_aRPxT } },
+    { { UVC_F_THRES, UVC_T_aLI1T }, { UVC_F_THRES, UVC_T_aLI2T }, { UVC_F_THRES, UVC_T_aRI1T }, { UVC_F_THRES, UVC_T_aRI2T } },
+    { { UVC_F_THRES, UVC_T_aLI1t }, { UVC_F_THRES, UVC_T_aLI2t }, { UVC_F_THRES, UVC_T_aRI1t }, { UVC_F_THRES, UVC_T_aRI2t } },
+    { { UVC_F_THRES, UVC_T_aLP1t }, { UVC_F_THRES, UVC_T_aLP2t }, { UVC_F_THRES, UVC_T_aRP1t }, { UVC_F_THRES, UVC_T_aRP2t } },
+    { { UVC_F_THRES, UVC_T_aLB1t }, { UVC_F_THRES, UVC_T_aLB2t }, { UVC_F_THRES, UVC_T_aRB1t }, { UVC_F_THRES, UVC_T_aRB2t } },
+};
+
+std::string g_keys[2];
+struct KeysInit { KeysInit() { for (int t2 = 0; t2 < 2; t2++) for (int i = 0; i < N_TAGS; i++) { if (TAGS[i].sscs && !t2) continue; if (!g_keys[t2].empty()) g_keys[t2] += ":"; g_keys[t2] += TAGS[i].name; } } } g_keys_init;
+
+// one row of uvcgpu_region_fetch_columns
+struct Cols {
+    const int64_t *v; int base[UVC_NUM_FIELD_GROUPS];
+    int64_t pos(int g, int p) const { return v[base[g] + p]; }
+    int64_t sym(int g, int f, int s) const { return v[base[g] + f * NSYM + s]; }                      // [field][symbol]
+    int64_t fr(int g, int nf, int sd, int f, int s) const { return v[base[g] + (sd * nf + f) * NSYM + s]; }   // [strand][field][symbol]
+};
+inline void st_symbols(int st, int &first, int &count, int &nn) { if (st == UVC_BASE_SYMBOL) { first = UVC_BASE_A; count = 6; nn = UVC_BASE_NN; } else { first = UVC_LINK_M; count = 8; nn = UVC_LINK_NN; } }
+
+void put(std::string &o, int64_t v) { char b[32]; snprintf(b, sizeof(b), "%lld", (long long)v); o += b; }
+void put2(std::string &o, int64_t a, int64_t b) { put(o, a); o += ','; put(o, b); }
+
+// indelpos_to_context, main.hpp:733-755
+void repeat_context(const std::string &ref, int32_t at, int32_t smax, std::string &unit, int32_t &num) {
+    num = 0; unit.clear();
+    const int32_t n = (int32_t)ref.size();
+    if (at >= n || at < 0) return;
+    int32_t best_size = 0;
+    for (int32_t u = 1; u <= smax; u++) {
+        int32_t q = at;
+        while (q + u < n && ref[(size_t)q] == ref[(size_t)(q + u)]) q++;
+        const int32_t c = (q - at) / u + 1;
+        bool better;   // is_indel_context_more_STR(u, c, best_size, num, smax), main.hpp:699-721
+        if (best_size * num == 0) better = true;
+        else if (u > smax || best_size > smax) better = (u < best_size || (u == best_size && c > num));
+        else {
+            int r1 = (c <= 1 ? (-c * u) : ((c - 1) * u)), r2 = (num <= 1 ? (-num * u) : ((num - 1) * best_size));
+            if (0 == c) r1 = -100;
+            if (0 == num || 0 == best_size) r2 = -100;
+            better = r1 > r2;
+        }
+        if (better) { num = c; best_size = u; }
+    }
+    unit = ref.substr((size_t)at, (size_t)best_size);
+}
+
+struct Rows {   // uvcgpu_region_indel_alleles
+    std::vector<UvcGapRow> rows; std::vector<uint8_t> seq;
+    std::string text(const UvcGapRow &g, const std::string &ref, int32_t beg) const {
+        std::string s;
+        if (g.seq_off >= 0) { for (int i = 0; i < g.len; i++) s += "ACGTN"[seq[(size_t)g.seq_off + i] > 4 ? 4 : seq[(size_t)g.seq_off + i]]; }
+        else { const int64_t a = (int64_t)g.refpos - beg; if (a >= 0 && a + g.len <= (int64_t)ref.size()) s = ref.substr((size_t)a, (size_t)g.len); }
+        return s;
+    }
+    // the rows of (refpos, symbol): forward rows first, then reverse (main.cpp:858-869)
+    void range(int32_t refpos, int32_t symbol, size_t &lo, size_t &hi) const {
+        lo = std::lower_bound(rows.begin(), rows.end(), std::make_pair(refpos, symbol), [](const UvcGapRow &a, const std::pair<int32_t, int32_t> &k) {
+            return a.refpos < k.first || (a.refpos == k.first && a.symbol < k.second); }) - rows.begin();
+        hi = lo;
+        while (hi < rows.size() && rows[hi].refpos == refpos && rows[hi].symbol == symbol) hi++;
+    }
+};
+}   // namespace
+
+extern "C" const char *uvcgpu_vcf_format_keys(int32_t with_tier2) { return g_keys[with_tier2 ? 1 : 0].c_str(); }
+
+extern "C" int uvcgpu_vcf_header(const UvcParams *P, const char *sample, const char *const *names, const int64_t *lens, int32_t n_contigs, char *dst, int64_t cap, int64_t *len) {
+    if (!P || !len || (n_contigs > 0 && (!names || !lens))) return uvcgpu_fail_(UVCGPU_EINVAL, "bad argument");
+    std::string h = "##fileformat=VCFv4.2\n";
+    for (int i = 0; i < n_contigs; i++) h += std::string("##contig=<ID=") + names[i] + ",length=" + std::to_string((long long)lens[i]) + ">\n";
+    h += "##ALT=<ID=NON_REF,Description=\"Any possible alternative allele at this location\">\n";
+    const char *const flt[][2] = { { "noVar", "Not a variant" }, { "upstreamDel", "Deletion extended from an upstream deletion" }, { "s50", "Less than half of the samples have data" },
+        { "Q10", "Quality below 10" }, { "Q20", "Quality below 20" }, { "Q30", "Quality below 30" }, { "Q40", "Quality below 40" }, { "Q50", "Quality below 50" }, { "Q60", "Quality below 60" },
+        { "aInsertSize", "FORMAT/FTS: stranded insert-size bias" }, { "aBQXM", "FORMAT/FTS: base-quality and mismatch bias" }, { "bcDup", "FORMAT/FTS: duplication bias, raw against de-duplicated" },
+        { "cbDup", "FORMAT/FTS: duplication bias, de-duplicated against raw" }, { "aAlignL", "FORMAT/FTS: alignment bias, left" }, { "aAlignR", "FORMAT/FTS: alignment bias, right" },
+        { "aPositionL", "FORMAT/FTS: position bias, left" }, { "aPositionR", "FORMAT/FTS: position bias, right" }, { "abPositionL", "FORMAT/FTS: insert-end position bias, left" },
+        { "abPositionR", "FORMAT/FTS: insert-end position bias, right" }, { "aStrand", "FORMAT/FTS: strand bias" }, { "c0Orientation", "FORMAT/FTS: read-orientation bias, de-duplicated fragments" },
+        { "c2Orientation", "FORMAT/FTS: read-orientation bias, tier-2 families" }, { "c2AlignL", "FORMAT/FTS: alignment bias of tier-2 families, left" }, { "c2AlignR", "FORMAT/FTS: alignment bias of tier-2 families, right" },
+        { "c2PositionL", "FORMAT/FTS: position bias of tier-2 families, left" }, { "c2PositionR", "FORMAT/FTS: position bias of tier-2 families, right" },
+        { "c2StrictPosL", "FORMAT/FTS: strict position bias of tier-2 families, left" }, { "c2StrictPosR", "FORMAT/FTS: strict position bias of tier-2 families, right" } };
+    for (const auto &f : flt) h += std::string("##FILTER=<ID=") + f[0] + ",Description=\"" + f[1] + "\">\n";
+    h += "##INFO=<ID=ANY_VAR,Number=0,Type=Flag,Description=\"Variant of germline or somatic origin\">\n";
+    h += "##INFO=<ID=GERMLINE,Number=0,Type=Flag,Description=\"Germline variant\">\n";
+    h += "##INFO=<ID=SOMATIC,Number=0,Type=Flag,Description=\"Somatic variant\">\n";
+    h += "##INFO=<ID=SomaticQ,Number=A,Type=Float,Description=\"Phred odds that the variant is not somatic\">\n";
+    h += "##INFO=<ID=TLODQ,Number=A,Type=Float,Description=\"Phred odds that the variant is an artifact\">\n";
+    h += "##INFO=<ID=NLODQ,Number=A,Type=Float,Description=\"Phred odds that the variant is of germline origin\">\n";
+    h += "##INFO=<ID=NLODV,Number=A,Type=String,Description=\"The symbol that minimizes NLODQ\">\n";
+    h += "##INFO=<ID=TNBQF,Number=4,Type=Float,Description=\"Binomial reward, power-law reward, systematic-error penalty and normal-adjusted quality, de-duplicated fragments\">\n";
+    h += "##INFO=<ID=TNCQF,Number=4,Type=Float,Description=\"Binomial reward, power-law reward, systematic-error penalty and normal-adjusted quality, consensus families\">\n";
+    h += "##INFO=<ID=tbDP,Number=1,Type=Integer,Description=\"Tumor fragment depth, duplicates kept\">\n";
+    h += "##INFO=<ID=tDP,Number=1,Type=Integer,Description=\"Tumor de-duplicated depth\">\n";
+    h += "##INFO=<ID=tAD,Number=R,Type=Integer,Description=\"Tumor de-duplicated depth of each allele\">\n";
+    h += "##INFO=<ID=t2DP,Number=1,Type=Integer,Description=\"Tumor family depth with duplex rescue\">\n";
+    h += "##INFO=<ID=t2AD,Number=R,Type=Integer,Description=\"Tumor family depth of each allele with duplex rescue\">\n";
+    h += "##INFO=<ID=nDP,Number=1,Type=Integer,Description=\"Normal de-duplicated depth\">\n";
+    h += "##INFO=<ID=nAD,Number=R,Type=Integer,Description=\"Normal de-duplicated depth of each allele\">\n";
+    h += "##INFO=<ID=n2AD,Number=R,Type=Integer,Description=\"Normal family depth of each allele\">\n";
+    h += "##INFO=<ID=RU,Number=1,Type=String,Description=\"Shortest repeating unit in the reference\">\n";
+    h += "##INFO=<ID=RC,Number=1,Type=Integer,Description=\"Number of uninterrupted repeating units in the reference\">\n";
+    h += "##INFO=<ID=R3X2,Number=6,Type=Integer,Description=\"Repeat start, track length and unit size at the positions before and after this one\">\n";
+    for (int i = 0; i < N_TAGS; i++)
+        h += std::string("##FORMAT=<ID=") + TAGS[i].name + ",Number=" + TAGS[i].number + ",Type=" + TAGS[i].type + ",Description=\"" + (TAGS[i].kind == K_SEP ? "SUB-HEADER: " : "") + TAGS[i].desc + "\">\n";
+    h += "##phasing=partial\n";
+    h += std::string("##variantCallerInferredParameters=(inferred_sequencing_platform=") + (P->inferred_sequencing_platform == UVC_PLATFORM_IONTORRENT ? "IonTorrent" : "Illumina/BGI")
+       + ",central_readlen=" + std::to_string(P->central_readlen) + ")\n";
+    h += std::string("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t") + (sample ? sample : "SAMPLE") + "\n";
+    *len = (int64_t)h.size();
+    if (!dst || cap < (int64_t)h.size()) return uvcgpu_fail_(UVCGPU_ENOMEM, "destination too small");
+    memcpy(dst, h.data(), h.size());
+    return 0;
+}
+
+extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, const UvcScoreOut *scored, const UvcTumorKey *tkeys, int64_t n_tkeys,
+                                         char *dst, int64_t cap, int64_t *len) {
+    if (!r || !tname || !len || !scored || (scored->n_records > 0 && !scored->fields) || scored->n_records > scored->capacity) return uvcgpu_fail_(UVCGPU_EINVAL, "bad argument");
+    const int32_t *recs = scored->fields; const int64_t n = scored->n_records, stride = scored->capacity;
+    { const int rc0 = uvcgpu_region_fetch_columns(r, nullptr, 0, nullptr); if (rc0) return rc0; }   // accumulated, planes not released
+    const UvcParams &P = *uvcgpu_region_params(r);
+    int32_t beg = 0, end = 0;
+    const char *refp = uvcgpu_region_refseq(r, &beg, &end);
+    const std::string ref(refp, (size_t)(end - beg));
+    int64_t npos = 0;
+    const int32_t *rtr = uvcgpu_region_repeat_tracks(r, &npos);
+    auto F = [&](int64_t i, int f) { return recs[(int64_t)f * stride + i]; };
+    // the records that are written, and the ref record of each
+    std::vector<int64_t> kept, refrec;
+    for (int64_t i = 0; i < n; i++) {
+        if (!F(i, UVC_O_keep) || !F(i, UVC_O_out)) continue;
+        const int st = is_base(F(i, UVC_O_symbol)) ? UVC_BASE_SYMBOL : UVC_LINK_SYMBOL;
+        int64_t j = i, found = -1;
+        while (j > 0 && F(j - 1, UVC_O_refpos) == F(i, UVC_O_refpos)) j--;
+        for (; j < n && F(j, UVC_O_refpos) == F(i, UVC_O_refpos); j++)
+            if ((is_base(F(j, UVC_O_symbol)) ? UVC_BASE_SYMBOL : UVC_LINK_SYMBOL) == st && F(j, UVC_O_symbol) == F(i, UVC_O_refsymbol)) { found = j; break; }
+        if (found < 0) return uvcgpu_fail_(UVCGPU_EINVAL, "a kept record has no REF record at its position (pass all records of the score call)");
+        kept.push_back(i); refrec.push_back(found);
+    }
+    std::string out;
+    if (!kept.empty()) {
+        const int32_t ncol = uvcgpu_region_n_columns();
+        std::vector<int32_t> where(kept.size());
+        for (size_t k = 0; k < kept.size(); k++) where[k] = F(kept[k], UVC_O_refpos);
+        std::vector<int64_t> cols((size_t)ncol * kept.size());
+        int rc = uvcgpu_region_fetch_columns(r, where.data(), (int64_t)where.size(), cols.data());
+        if (rc) return rc;
+        Rows G; int64_t nr = 0, nb = 0;
+        rc = uvcgpu_region_indel_alleles(r, nullptr, 0, &nr, nullptr, 0, &nb);
+        if (rc && rc != UVCGPU_ENOMEM) return rc;
+        G.rows.resize((size_t)nr); G.seq.resize((size_t)nb + 1);
+        if (nr) { rc = uvcgpu_region_indel_alleles(r, G.rows.data(), nr, &nr, G.seq.data(), nb + 1, &nb); if (rc) return rc; }
+        Cols C; for (int g = 0; g < UVC_NUM_FIELD_GROUPS; g++) C.base[g] = uvcgpu_region_column_base(g);
+        const bool tprov = (P.tumor_vcf_is_provided != 0);
+        for (size_t k = 0; k < kept.size(); k++) {
+            const int64_t ia = kept[k], ir = refrec[k];
+            C.v = cols.data() + (size_t)ncol * k;
+            const int32_t refpos = F(ia, UVC_O_refpos), symbol = F(ia, UVC_O_symbol), refsymbol = F(ia, UVC_O_refsymbol);
+            const int st = is_base(symbol) ? UVC_BASE_SYMBOL : UVC_LINK_SYMBOL;
+            int s0, sn, nn; st_symbols(st, s0, sn, nn);
+            const int64_t regionpos = (int64_t)refpos - beg;
+            // the InDel string of this record
+            std::string indel;
+            const int32_t garow = F(ia, UVC_O_gapSa);
+            if (garow >= 0 && garow < (int32_t)G.rows.size()) indel = G.text(G.rows[(size_t)garow], ref, beg);
+            else if (F(ia, UVC_O_gapSa_len) > 0) indel = std::string(is_ins(symbol) ? "<INS>" : "<DEL>");   // placeholder: the string came from the caller
+            // CHROM POS ID REF ALT
+            int64_t vcfpos; std::string vref, valt;
+            auto ref_at = [&](int64_t p) { return (p >= 0 && p < (int64_t)ref.size()) ? std::string(1, ref[(size_t)p]) : std::string("n"); };
+            if (!indel.empty()) {
+                vcfpos = refpos; vref = (regionpos > 0 ? ref_at(regionpos - 1) : std::string("n")); valt = vref;
+                if (indel[0] == '<') valt = indel; else if (is_ins(symbol)) valt += indel; else vref += indel;
+            } else if (is_base(symbol)) { vcfpos = (int64_t)refpos + 1; vref = ref_at(regionpos); valt = SYMBOL_DESC[symbol]; }
+            else { vcfpos = refpos; vref = (regionpos > 0 ? ref_at(regionpos - 1) : std::string("n")); valt = SYMBOL_DESC[symbol]; }
+            float qual; { int32_t b = F(ia, UVC_O_QUAL); memcpy(&qual, &b, 4); }
+            out += tname; out += '\t'; put(out, vcfpos); out += "\t.\t"; out += vref; out += '\t'; out += valt; out += '\t';
+            out += std::to_string(qual); out += '\t'; out += FILTER_Q[std::min(std::max(F(ia, UVC_O_FILTER), 0), 6)]; out += '\t';
+            // INFO (main.hpp:6206-6235)
+            const int32_t tk = F(ia, UVC_O_tkey);
+            const UvcTumorKey *T = (tprov && tkeys && tk >= 0 && tk < n_tkeys) ? &tkeys[tk] : nullptr;
+            int64_t cdpd_all = 0, ddp2_all = 0;
+            for (int s = s0; s < s0 + sn; s++) { cdpd_all += C.fr(UVC_F_FAM, UVC_NFAM, 0, UVC_FAM_cDPD, s) + C.fr(UVC_F_FAM, UVC_NFAM, 1, UVC_FAM_cDPD, s); ddp2_all += C.sym(UVC_F_DUPLEX, UVC_DUPLEX_dDP2, s); }
+            const int64_t t2dp_own = (int32_t)cdpd_all + ((int32_t)ddp2_all + C.sym(UVC_F_DUPLEX, UVC_DUPLEX_dDP2, nn));   // SUMPAIR(CDPDb) + SUMPAIR(DDP2)
+            auto adc = [&](int s) { return C.fr(UVC_F_FAM, UVC_NFAM, 0, UVC_FAM_cDPD, s) + C.fr(UVC_F_FAM, UVC_NFAM, 1, UVC_FAM_cDPD, s) + C.sym(UVC_F_DUPLEX, UVC_DUPLEX_dDP2, s); };
+            size_t glo = 0, ghi = 0;
+            if (is_ins(symbol) || is_del(symbol)) G.range(refpos, symbol, glo, ghi);
+            int64_t alt_adc;
+            if (is_ins(symbol) || is_del(symbol)) { alt_adc = 0; for (size_t g = glo; g < ghi; g++) if (G.text(G.rows[g], ref, beg) == indel) alt_adc += G.rows[g].c2dAD; }
+            else alt_adc = adc(symbol);
+            out += (T ? "SOMATIC" : "ANY_VAR");
+            out += ";SomaticQ="; put(out, F(ia, UVC_O_SomaticQ)); out += ";TLODQ="; put(out, F(ia, UVC_O_TLODQ)); out += ";NLODQ="; put(out, F(ia, UVC_O_NLODQ));
+            out += ";NLODV="; out += SYMBOL_DESC[std::min(std::max(F(ia, UVC_O_NLODV), 0), NSYM)];
+            out += ";TNBQF="; for (int q = 0; q < 4; q++) { if (q) out += ','; put(out, F(ia, UVC_O_TNBQF0 + q)); }
+            out += ";TNCQF="; for (int q = 0; q < 4; q++) { if (q) out += ','; put(out, F(ia, UVC_O_TNCQF0 + q)); }
+            if (T) {
+                out += ";tbDP="; put(out, T->BDP); out += ";tDP="; put(out, T->tDP); out += ";tAD="; put2(out, T->tAD0, T->tAD1);
+                out += ";t2DP="; put(out, T->t2DP); out += ";t2AD="; put2(out, adc(refsymbol), alt_adc);   // fill_conditional_tki<false> stores the normal's counts in tADCR
+                out += ";nDP="; put(out, F(ia, UVC_O_DP)); out += ";nAD="; put2(out, F(ir, UVC_O_AD), F(ia, UVC_O_AD)); out += ";n2AD=0,0";
+            } else {
+                out += ";tbDP="; put(out, F(ia, UVC_O_bDP)); out += ";tDP="; put(out, F(ia, UVC_O_DP)); out += ";tAD="; put2(out, F(ir, UVC_O_AD), F(ia, UVC_O_AD));
+                out += ";t2DP="; put(out, t2dp_own); out += ";t2AD="; put2(out, adc(refsymbol), alt_adc);
+            }
+            std::string ru; int32_t rcn = 0;
+            repeat_context(ref, (int32_t)(regionpos + (st == UVC_BASE_SYMBOL ? 1 : 0)), P.indel_str_repeatsize_max, ru, rcn);
+            out += ";RU="; out += ru; out += ";RC="; put(out, rcn);
+            {   // R3X2: the repeat tracks indel_adj_tracklen_dist before and behind (main.hpp:6100-6103)
+                const int64_t d = P.indel_adj_tracklen_dist;
+                const int64_t i1 = std::max(regionpos, d) - d, i2 = std::min(regionpos + d, npos - d);   // region_repeatvec has npos entries (refstring2repeatvec repeats the last one)
+                auto tr = [&](int f, int64_t i) { return (i >= 0 && i < npos) ? rtr[(size_t)f * npos + i] : 0; };
+                const int32_t l1 = tr(UVC_RTR_tracklen, i1), l2 = tr(UVC_RTR_tracklen, i2);
+                out += ";R3X2="; put(out, l1 ? beg + tr(UVC_RTR_begpos, i1) : 0); out += ','; put(out, l1); out += ','; put(out, tr(UVC_RTR_unitlen, i1)); out += ',';
+                put(out, l2 ? beg + tr(UVC_RTR_begpos, i2) : 0); out += ','; put(out, l2); out += ','; put(out, tr(UVC_RTR_unitlen, i2));
+            }
+            const bool tier2 = F(ia, UVC_O_tier2) != 0;
+            out += '\t'; out += g_keys[tier2 ? 1 : 0]; out += '\t';
+            // the sample column (streamAppendBcfFormat)
+            bool first = true;
+            for (int t = 0; t < N_TAGS; t++) {
+                const Tag &tg = TAGS[t];
+                if (tg.sscs && !tier2) continue;
+                if (!first) out += ':';
+                first = false;
+                auto sumst = [&](auto fn) { int64_t acc = 0; for (int s = s0; s < s0 + sn; s++) acc += fn(s); return acc; };
+                switch (tg.kind) {
+                case K_SEP: out += tg.name; break;
+                case K_R_S32: put2(out, C.sym(UVC_F_SEG32, tg.a, refsymbol), C.sym(UVC_F_SEG32, tg.a, symbol)); break;
+                case K_R_S64: put2(out, C.sym(UVC_F_SEG64, tg.a, refsymbol), C.sym(UVC_F_SEG64, tg.a, symbol)); break;
+                case K_R_VQ: put2(out, C.sym(UVC_F_VQ, tg.a, refsymbol), C.sym(UVC_F_VQ, tg.a, symbol)); break;
+                case K_R_FRf: put2(out, C.fr(UVC_F_FRAG, UVC_NFRAG, 0, tg.a, refsymbol), C.fr(UVC_F_FRAG, UVC_NFRAG, 0, tg.a, symbol)); break;
+                case K_R_FRr: put2(out, C.fr(UVC_F_FRAG, UVC_NFRAG, 1, tg.a, refsymbol), C.fr(UVC_F_FRAG, UVC_NFRAG, 1, tg.a, symbol)); break;
+                case K_R_FAf: put2(out, C.fr(UVC_F_FAM, UVC_NFAM, 0, tg.a, refsymbol), C.fr(UVC_F_FAM, UVC_NFAM, 0, tg.a, symbol)); break;
+                case K_R_FAr: put2(out, C.fr(UVC_F_FAM, UVC_NFAM, 1, tg.a, refsymbol), C.fr(UVC_F_FAM, UVC_NFAM, 1, tg.a, symbol)); break;
+                case K_R_FI: put2(out, C.sym(UVC_F_FAMINFO32, tg.a, refsymbol), C.sym(UVC_F_FAMINFO32, tg.a, symbol)); break;
+                case K_R_FI64: put2(out, C.sym(UVC_F_FAMINFO64, tg.a, refsymbol), C.sym(UVC_F_FAMINFO64, tg.a, symbol)); break;
+                case K_R_DU: put2(out, C.sym(UVC_F_DUPLEX, tg.a, refsymbol), C.sym(UVC_F_DUPLEX, tg.a, symbol)); break;
+                case K_T1_S32: put(out, (int32_t)sumst([&](int s) { return C.sym(UVC_F_SEG32, tg.a, s); })); break;
+                case K_T1L_S32: put(out, sumst([&](int s) { return C.sym(UVC_F_SEG32, tg.a, s); })); break;
+                case K_T1_S64: put(out, sumst([&](int s) { return C.sym(UVC_F_SEG64, tg.a, s); })); break;
+                case K_T1_VQ: put(out, (int32_t)sumst([&](int s) { return C.sym(UVC_F_VQ, tg.a, s); })); break;
+                case K_T1_FI: put(out, (int32_t)sumst([&](int s) { return C.sym(UVC_F_FAMINFO32, tg.a, s); })); break;
+                case K_T2_S32: put2(out, (int32_t)sumst([&](int s) { return C.sym(UVC_F_SEG32, tg.a, s); }), C.sym(UVC_F_SEG32, tg.a, nn)); break;
+                case K_T2_DU: put2(out, (int32_t)sumst([&](int s) { return C.sym(UVC_F_DUPLEX, tg.a, s); }), C.sym(UVC_F_DUPLEX, tg.a, nn)); break;
+                case K_FR2_FR: put2(out, (int32_t)sumst([&](int s) { return C.fr(UVC_F_FRAG, UVC_NFRAG, 0, tg.a, s); }), (int32_t)sumst([&](int s) { return C.fr(UVC_F_FRAG, UVC_NFRAG, 1, tg.a, s); })); break;
+                case K_FR2_FA: put2(out, (int32_t)sumst([&](int s) { return C.fr(UVC_F_FAM, UVC_NFAM, 0, tg.a, s); }), (int32_t)sumst([&](int s) { return C.fr(UVC_F_FAM, UVC_NFAM, 1, tg.a, s); })); break;
+                case K_NN2_FA: put2(out, C.fr(UVC_F_FAM, UVC_NFAM, 0, tg.a, nn), C.fr(UVC_F_FAM, UVC_NFAM, 0, tg.a, nn)); break;   // fill_symboltype_nn_fmt reads strand 0 twice
+                case K_ZERO2: out += "0,0"; break;
+                case K_POS: for (int q = 0; q < tg.n; q++) { if (q) out += ','; const PosSrc &ps = POS_LISTS[tg.a][q]; int64_t v = C.pos(ps.g, ps.p); if (!strcmp(tg.name, "APDP") || !strcmp(tg.name, "APLRP")) v = (int32_t)v; put(out, v); } break;
+                case K_R_REC: put2(out, F(ir, tg.a), F(ia, tg.a)); break;
+                case K_1_REC: put(out, F(ia, tg.a)); break;
+                case K_N_REC: for (int q = 0; q < tg.n; q++) { if (q) out += ','; put(out, F(ia, tg.a + q)); } break;
+                case K_SPECIAL: {
+                    const std::string nm = tg.name;
+                    if (nm == "GT") out += "./1";
+                    else if (nm == "GQ") out += "0";
+                    else if (nm == "HQ") out += "0,0";
+                    else if (nm == "FT" || nm == "bHap" || nm == "cHap" || nm == "c2Hap" || nm == "note") out += ".";
+                    else if (nm == "FTS") {
+                        // fmt_bias_push appends "<name>-<round(100 * biasFA / refFA)>" for each bias that fired; the percentage is rebuilt from the
+                        // deciPhred fractions of the record (nAFA / nBCFA against nNFA), i.e. within the rounding of those (+-1)
+                        const uint32_t bits = (uint32_t)F(ia, UVC_O_FTS);
+                        std::string s;
+                        for (int b = 0; b < 19; b++) if (bits & (1u << b)) {
+                            const int bias = (b < 9 ? F(ia, UVC_O_nAFA0 + b) : F(ia, UVC_O_nBCFA0 + (b - 9))), whole = F(ia, UVC_O_nNFA0 + FTS_REF[b]);
+                            const long pct = std::lround(100.0 * std::pow(10.0, (double)(whole - bias) / 100.0));
+                            if (!s.empty()) s += '|';
+                            s += FTS_NAMES[b]; s += '-'; s += std::to_string(pct);
+                        }
+                        out += (s.empty() ? std::string("PASS") : s);
+                    }
+                    else if (nm == "VTI") put2(out, refsymbol, symbol);
+                    else if (nm == "VTD") { out += SYMBOL_DESC[refsymbol]; out += ','; out += SYMBOL_DESC[symbol]; }
+                    else if (nm == "cVQAM") { out += SYMBOL_DESC[std::min(std::max(F(ia, UVC_O_cVQAM0), 0), NSYM)]; out += ','; out += SYMBOL_DESC[std::min(std::max(F(ia, UVC_O_cVQAM1), 0), NSYM)]; }
+                    else if (nm == "cVQSM") { for (int q = 0; q < 2; q++) { if (q) out += ','; const int32_t row = F(ia, UVC_O_cVQSM0 + q); if (row >= 0 && row < (int32_t)G.rows.size()) out += G.text(G.rows[(size_t)row], ref, beg); } }
+                    else if (nm == "gapNf" || nm == "gapNr") {
+                        const int sd = (nm == "gapNf" ? 0 : 1); int cnt = 0;
+                        for (size_t g = glo; g < ghi; g++) if (G.rows[g].strand == sd) cnt++;
+                        // the count is pushed when the symbol has fragments on the strand (main.cpp:859-869), even if none of them kept an allele string
+                        const bool pushed = (is_ins(symbol) || is_del(symbol)) && C.fr(UVC_F_FRAG, UVC_NFRAG, sd, UVC_FRAG_bDP, symbol) > 0;
+                        if (pushed) put(out, cnt); else out += ".";
+                    }
+                    else if (nm == "gapSeq" || nm == "gapbAD1" || nm == "gapcAD1" || nm == "gc2AD" || nm == "gc2dAD") {
+                        if (glo == ghi) out += ".";
+                        for (size_t g = glo; g < ghi; g++) {
+                            if (g > glo) out += ',';
+                            const UvcGapRow &gr = G.rows[g];
+                            if (nm == "gapSeq") out += G.text(gr, ref, beg);
+                            else put(out, nm == "gapbAD1" ? gr.bAD1 : nm == "gapcAD1" ? gr.cAD1 : nm == "gc2AD" ? gr.c2AD : gr.c2dAD);
+                        }
+                    }
+                    else if (nm == "gapSa") { out += ','; out += indel; }   // the REF allele has no string
+                    else if (nm == "vNLODQ") { if (st == UVC_BASE_SYMBOL) put2(out, F(ia, UVC_O_vNLODQ), 0); else put2(out, 0, F(ia, UVC_O_vNLODQ)); }
+                    break; }
+                }
+            }
+            out += '\n';
+        }
+    }
+    *len = (int64_t)out.size();
+    if (!dst || cap < (int64_t)out.size()) return uvcgpu_fail_(UVCGPU_ENOMEM, "destination too small");
+    memcpy(dst, out.data(), out.size());
+    return 0;
+}

@@ -92,6 +92,28 @@ def pack_reads(reads):
     return soa, keep
 
 
+def vcf_format_keys(lib, tier2=False):
+    fn = getattr(lib.dll, "uvcgpu_vcf_format_keys")
+    fn.restype, fn.argtypes = C.c_char_p, [C.c_int32]
+    return fn(int(tier2)).decode()
+
+
+def vcf_header(lib, params, sample, contigs):
+    """##-lines and the #CHROM line (uvcgpu_vcf_header); contigs = [(name, length), ...]."""
+    fn = getattr(lib.dll, "uvcgpu_vcf_header")
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(_ffi.UvcParams), C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    names = (C.c_char_p * max(1, len(contigs)))(*[c[0].encode() for c in contigs])
+    lens = (C.c_int64 * max(1, len(contigs)))(*[int(c[1]) for c in contigs])
+    ln = C.c_int64(0)
+    fn(C.byref(params), sample.encode(), names, lens, len(contigs), None, 0, C.byref(ln))
+    dst = C.create_string_buffer(max(1, ln.value))
+    rc = fn(C.byref(params), sample.encode(), names, lens, len(contigs), dst, ln.value, C.byref(ln))
+    if rc:
+        raise UvcError(rc, lib.last_error())
+    return dst.raw[:ln.value].decode()
+
+
 class Region:
     def __init__(self, lib, params, tid, beg, end, refseq):
         self.lib, self.tid, self.beg, self.end = lib, tid, beg, end
@@ -200,6 +222,43 @@ class Region:
             self._check(rc)
             # copy=False returns views into the handle's reusable buffer (valid until the next score() call)
             return {name: (buf[i, :out.n_records].copy() if copy else buf[i, :out.n_records]) for i, name in enumerate(_ffi.SCORE_FIELDS)}
+
+    def fetch_columns(self, refpos):
+        """Every plane value of the given positions (uvcgpu_region_fetch_columns): int64 [len(refpos), n_columns]; `column_base(group)`
+        gives the first column of a plane group, the planes of a group follow in the order of `fetch(group)`."""
+        fn = getattr(self.lib.dll, self.lib.prefix + "region_fetch_columns")
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        ncol = getattr(self.lib.dll, self.lib.prefix + "region_n_columns")
+        ncol.restype, ncol.argtypes = C.c_int32, []
+        pos = np.ascontiguousarray(refpos, dtype=np.int32)
+        out = np.zeros((len(pos), ncol()), dtype=np.int64)
+        self._check(fn(self.h, pos.ctypes.data, len(pos), out.ctypes.data))
+        return out
+
+    def column_base(self, group):
+        fn = getattr(self.lib.dll, self.lib.prefix + "region_column_base")
+        fn.restype, fn.argtypes = C.c_int32, [C.c_int32]
+        return fn(_ffi.FIELD_GROUPS[group][0])
+
+    def vcf_records(self, contig_name, records, tumor_keys=None):
+        """The VCF lines (text) of the records `score()` returned that are written (out and keep set): uvcgpu_region_vcf_records.
+        Needs the planes, i.e. a score call without release_state."""
+        fn = getattr(self.lib.dll, self.lib.prefix + "region_vcf_records")
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(_ffi.UvcScoreOut), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        n = len(records["refpos"])
+        buf = np.ascontiguousarray(np.stack([np.asarray(records[name], dtype=np.int32) for name in _ffi.SCORE_FIELDS])) if n else np.zeros((_ffi.NUM_SCORE_FIELDS, 1), dtype=np.int32)
+        so = _ffi.UvcScoreOut(max(n, 1), n, buf.ctypes.data)
+        tk, ntk = None, 0
+        if tumor_keys:
+            tk = (_ffi.UvcTumorKey * len(tumor_keys))(*[_ffi.UvcTumorKey(*t) for t in tumor_keys]); ntk = len(tumor_keys)
+        ln = C.c_int64(0)
+        rc = fn(self.h, contig_name.encode(), C.byref(so), tk, ntk, None, 0, C.byref(ln))
+        if rc not in (0, -6):
+            self._check(rc)
+        dst = C.create_string_buffer(max(1, ln.value))
+        self._check(fn(self.h, contig_name.encode(), C.byref(so), tk, ntk, dst, ln.value, C.byref(ln)))
+        return dst.raw[:ln.value].decode()
 
     def close(self):
         if self.h:
