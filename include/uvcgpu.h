@@ -231,6 +231,9 @@ enum UvcScoreField {
     UVC_O_QUAL,                         /* vcfqual: the bit pattern of the 32-bit float the reference prints with std::to_string */
     UVC_O_FILTER,                       /* 0..5 = Q10..Q60 (bcfrec::FILTER_IDS), 6 = PASS */
     UVC_O_keep,                         /* the record is written: keep_var && tki.bDP >= min_ad, main.hpp:6253-6262 */
+    /* FORMAT/FTS prints "<bias name>-<round(100 * biasFA / refFA)>" for every bias that fired (fmt_bias_push, main.hpp:4266-4269): those
+     * percentages, 8 bits each (bias i of UVC_O_FTS in byte i % 4 of field i / 4, 0 where the bias did not fire, capped at 255) */
+    UVC_O_FTSpct0, UVC_O_FTSpct1, UVC_O_FTSpct2, UVC_O_FTSpct3, UVC_O_FTSpct4,
     UVC_NUM_SCORE_FIELDS
 };
 

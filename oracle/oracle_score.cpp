@@ -702,6 +702,7 @@ static void emit(const Fmt &f, std::vector<i32> &r) {
     r[UVC_O_germ_GT] = f.germ_GT; r[UVC_O_germ_GQ] = f.germ_GQ; r[UVC_O_germ_emit] = f.germ_emit; r[UVC_O_germ_ref] = f.germ_ref; r[UVC_O_germ_alt1] = f.germ_alt1; r[UVC_O_germ_alt2] = f.germ_alt2;
     r[UVC_O_out] = f.out; r[UVC_O_vHGQ] = f.vHGQ; r[UVC_O_NLODQ] = f.NLODQ; r[UVC_O_NLODV] = f.NLODV; r[UVC_O_TLODQ] = f.TLODQ; r[UVC_O_SomaticQ] = f.SomaticQ;
     r[UVC_O_QUAL] = f.QUALbits; r[UVC_O_FILTER] = f.FILTER; r[UVC_O_keep] = f.keep;
+    for (int b = 0; b < 19; b++) if (f.FTS & (1 << b)) r[UVC_O_FTSpct0 + b / 4] |= (i32)((u32)min_(max_(f.FTSpct[b], 0), 255) << (8 * (b % 4)));
 }
 
 // ------------------------------------------------------------------------------------------------

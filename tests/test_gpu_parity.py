@@ -48,6 +48,11 @@ def compare_records(ro, rg):
             worst[name] = 0
             continue
         a, b = ro[name].astype(np.int64), rg[name].astype(np.int64)
+        if name.startswith("FTSpct"):   # four 8-bit percentages per field: each within 1
+            d = np.max([np.abs(((a >> s) & 0xFF) - ((b >> s) & 0xFF)) for s in (0, 8, 16, 24)], axis=0)
+            assert d.max(initial=0) <= 1, (name, int(np.argmax(d)))
+            worst[name] = int(d.max(initial=0))
+            continue
         d = np.abs(a - b)
         if name in EXACT_FIELDS:
             assert d.max(initial=0) == 0, (name, int(np.argmax(d)), int(a[np.argmax(d)]), int(b[np.argmax(d)]))

@@ -87,12 +87,15 @@ PCT_TAGS = {"cDP1v", "CDP1v", "cDP1w", "CDP1w", "cDP1x", "CDP1x", "cDP2v", "CDP2
 PHRED_INFO = {"SomaticQ", "TLODQ", "NLODQ", "TNBQF", "TNCQF"}
 
 
-def _oracle_lines(oracle_lib, ref_vcf, Ro, tname, **score_kw):
+def _oracle_lines(oracle_lib, ref_vcf, Ro, tname, tumor_keys=None, **score_kw):
     fn = oracle_lib.dll.uvc_oracle_region_vcf
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.POINTER(_ffi.UvcScoreRequest), C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     req = _ffi.UvcScoreRequest()
     req.pos_beg, req.pos_end, req.all_out, req.is_amplicon = -1, -1, int(score_kw.get("all_out", False)), 0
+    if tumor_keys:
+        tk = (_ffi.UvcTumorKey * len(tumor_keys))(*[_ffi.UvcTumorKey(*t) for t in tumor_keys])
+        req.n_tumor_keys, req.tumor_keys = len(tumor_keys), C.cast(tk, C.c_void_p)
     ln = C.c_int64(0)
     fn(Ro.h, C.byref(req), tname.encode(), None, 0, C.byref(ln))
     buf = C.create_string_buffer(max(1, ln.value))
@@ -148,7 +151,7 @@ def compare_lines(mine, want):
             n_tags += 1
             if a == b:
                 continue
-            if k == "FTS":   # names must agree; the percentages are rebuilt from deciPhred values on the product side
+            if k == "FTS":   # names must agree, the percentages within 1
                 pa, pb = a.split("|"), b.split("|")
                 assert [e.rsplit("-", 1)[0] for e in pa] == [e.rsplit("-", 1)[0] for e in pb], (a, b)
                 for ea, eb in zip(pa, pb):
@@ -177,6 +180,45 @@ def test_record_lines_match_oracle_and_reference_stream(name, oracle_lib, gpu_li
     assert len(want) > 0
     n = compare_lines(mine, want)
     print(name, len(mine), "lines", n, "tags compared")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 2, 3, 5, 7, 10])
+def test_record_lines_of_weird_reads(seed, oracle_lib, gpu_lib, ref_vcf):
+    """InDel-heavy, clipped, multi-allelic reads (the fuzz generator), every symbol written (all_out: REF alleles and both NN symbols too)."""
+    from test_gpu_fuzz import run, weird_region
+    reads = weird_region(seed, umi=(seed % 3 == 2))
+    platform = 2 if seed % 4 == 3 else 1
+    try:
+        Ro, Rg = run(oracle_lib, reads, platform=platform), run(gpu_lib, reads, platform=platform)
+    except region.UvcError:
+        pytest.skip("shape refused (covered by test_gpu_fuzz)")
+    rg = Rg.score(all_out=True)
+    mine = Rg.vcf_records("chrF", rg).splitlines()
+    want = _oracle_lines(oracle_lib, ref_vcf, Ro, "chrF", all_out=True)
+    assert len(want) > 20
+    n_indel = sum(1 for l in want if len(l.split("\t")[3]) != len(l.split("\t")[4]) and not l.split("\t")[4].startswith("<"))
+    compare_lines(mine, want)
+    print(seed, len(want), "lines,", n_indel, "with an InDel string")
+
+
+@pytest.mark.gpu
+def test_record_lines_of_the_normal_sample(oracle_lib, gpu_lib, ref_vcf):
+    """T/N: SOMATIC lines; tbDP / tDP / tAD / t2DP repeat the tumor record, nDP / nAD / n2AD are the normal's (main.hpp:6214-6224)."""
+    from test_gpu_parity import tumor_keys_from
+    reads = synth.generate_region(region_len=10000, depth=30, seed=12345)
+    keys = [k + (7 + i, 3 + i % 5, 2 * i) for i, k in enumerate(tumor_keys_from(run_region(oracle_lib, reads).score(all_out=False)))]
+    out = []
+    for lib in (oracle_lib, gpu_lib):
+        p = region.default_params(lib)
+        p.tumor_vcf_is_provided = 1
+        out.append(run_region(lib, reads, params=p))
+    Ro, Rg = out
+    rg = Rg.score(tumor_keys=keys)
+    mine = Rg.vcf_records("chr20", rg, tumor_keys=keys).splitlines()
+    want = _oracle_lines(oracle_lib, ref_vcf, Ro, "chr20", tumor_keys=keys)
+    assert len(want) > 0 and all(l.split("\t")[7].startswith("SOMATIC;") for l in want)
+    compare_lines(mine, want)
 
 
 @pytest.mark.gpu

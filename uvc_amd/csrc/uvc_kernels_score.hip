@@ -398,9 +398,15 @@ DEV void calc_dpv(const RegionDev &R, const UvcParams &P, int64_t x, const Tot &
     OUT(UVC_O_nNFA0, -numstates2deciphred(cbP)); OUT(UVC_O_nNFA1, -numstates2deciphred(cbBQ)); OUT(UVC_O_nNFA2, -numstates2deciphred(aDPFA));
     OUT(UVC_O_nNFA3, -numstates2deciphred(bFA)); OUT(UVC_O_nNFA4, -numstates2deciphred(cFA0)); OUT(UVC_O_nNFA5, -numstates2deciphred(cFA2));
     int FTS = 0, bit = 0;
+    unsigned pct0 = 0, pct1 = 0, pct2 = 0, pct3 = 0, pct4 = 0;
     auto push = [&](int fld, double refFA, double biasFA) {   // fmt_bias_push, main.hpp:4258-4272
         OUT(fld, -numstates2deciphred(biasFA));
-        if (biasFA < refFA * P.bias_thres_FTS_FA) FTS |= (1 << bit);
+        if (biasFA < refFA * P.bias_thres_FTS_FA) {
+            FTS |= (1 << bit);
+            const unsigned v = (unsigned)imin(imax((int)round(100.0 * biasFA / refFA), 0), 255) << (8 * (bit & 3));
+            const int q = bit >> 2;
+            if (q == 0) pct0 |= v; else if (q == 1) pct1 |= v; else if (q == 2) pct2 |= v; else if (q == 3) pct3 |= v; else pct4 |= v;
+        }
         bit++;
     };
     push(UVC_O_nAFA0, aDPFA, aSSFA2); push(UVC_O_nAFA1, aDPFA, aPFFA); push(UVC_O_nAFA2, aDPFA, aSIFA); push(UVC_O_nAFA3, aDPFA, aLBFA2); push(UVC_O_nAFA4, aDPFA, aRBFA2);
@@ -409,6 +415,7 @@ DEV void calc_dpv(const RegionDev &R, const UvcParams &P, int64_t x, const Tot &
     push(UVC_O_nBCFA4, cFA2, c2LPFA2); push(UVC_O_nBCFA5, cFA2, c2RPFA2); push(UVC_O_nBCFA6, cFA2, c2LBFA2); push(UVC_O_nBCFA7, cFA2, c2RBFA2);
     push(UVC_O_nBCFA8, cFA2, cFA2L); push(UVC_O_nBCFA9, cFA2, cFA2R);
     OUT(UVC_O_FTS, FTS);
+    OUT(UVC_O_FTSpct0, (int)pct0); OUT(UVC_O_FTSpct1, (int)pct1); OUT(UVC_O_FTSpct2, (int)pct2); OUT(UVC_O_FTSpct3, (int)pct3); OUT(UVC_O_FTSpct4, (int)pct4);
     const double aNCFA = ((!tprov && short_frag(T, P.lib_wgs_min_avg_fraglen) && (is_ins(symbol) || is_del(symbol)) && indel_size >= P.lib_nonwgs_clip_penal_min_indelsize)
             ? dmax((f.aNC + 0.5) / (ADP + 1.0), dbetween((f.cDP1f + f.cDP1r) / 300.0, 1.0 / 3.0, 2.0 / 3.0) * aDPFA) : 2.0);
     const double cb_normalgerm = ((!tprov || !short_frag(T, P.lib_wgs_min_avg_fraglen)) ? 1e-9

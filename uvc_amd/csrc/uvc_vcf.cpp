@@ -23,8 +23,6 @@ const char *const FILTER_Q[7] = { "Q10", "Q20", "Q30", "Q40", "Q50", "Q60", "PAS
 // the FORMAT/FTS names in the order BcfFormat_symbol_calc_DPv pushes them (main.hpp:4745-4769): 9 against nAFA, 10 against nBCFA
 const char *const FTS_NAMES[19] = { "aStrand", "aBQXM", "aInsertSize", "aAlignL", "aAlignR", "aPositionL", "aPositionR", "abPositionL", "abPositionR",
                                     "bcDup", "cbDup", "c0Orientation", "c2Orientation", "c2PositionL", "c2PositionR", "c2AlignL", "c2AlignR", "c2StrictPosL", "c2StrictPosR" };
-// the allele fraction each FTS entry is compared with, as an index into nNFA (2 = aDPFA, 3 = bFA, 4 = cFA0, 5 = cFA2)
-const int FTS_REF[19] = { 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 4, 4, 5, 5, 5, 5, 5, 5, 5 };
 
 inline bool is_base(int s) { return s <= UVC_BASE_NN; }
 inline bool is_ins(int s) { return s == UVC_LINK_I1 || s == UVC_LINK_I2 || s == UVC_LINK_I3P; }
@@ -473,7 +471,7 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
             std::string indel;
             const int32_t garow = F(ia, UVC_O_gapSa);
             if (garow >= 0 && garow < (int32_t)G.rows.size()) indel = G.text(G.rows[(size_t)garow], ref, beg);
-            else if (F(ia, UVC_O_gapSa_len) > 0) indel = std::string(is_ins(symbol) ? "<INS>" : "<DEL>");   // placeholder: the string came from the caller
+            // (an InDel whose length came from the caller -- UvcIndelAllele / UvcTumorKey carry no text -- is written with its symbolic allele)
             // CHROM POS ID REF ALT
             int64_t vcfpos; std::string vref, valt;
             auto ref_at = [&](int64_t p) { return (p >= 0 && p < (int64_t)ref.size()) ? std::string(1, ref[(size_t)p]) : std::string("n"); };
@@ -565,13 +563,11 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
                     else if (nm == "HQ") out += "0,0";
                     else if (nm == "FT" || nm == "bHap" || nm == "cHap" || nm == "c2Hap" || nm == "note") out += ".";
                     else if (nm == "FTS") {
-                        // fmt_bias_push appends "<name>-<round(100 * biasFA / refFA)>" for each bias that fired; the percentage is rebuilt from the
-                        // deciPhred fractions of the record (nAFA / nBCFA against nNFA), i.e. within the rounding of those (+-1)
+                        // fmt_bias_push appends "<name>-<round(100 * biasFA / refFA)>" for each bias that fired
                         const uint32_t bits = (uint32_t)F(ia, UVC_O_FTS);
                         std::string s;
                         for (int b = 0; b < 19; b++) if (bits & (1u << b)) {
-                            const int bias = (b < 9 ? F(ia, UVC_O_nAFA0 + b) : F(ia, UVC_O_nBCFA0 + (b - 9))), whole = F(ia, UVC_O_nNFA0 + FTS_REF[b]);
-                            const long pct = std::lround(100.0 * std::pow(10.0, (double)(whole - bias) / 100.0));
+                            const uint32_t pct = ((uint32_t)F(ia, UVC_O_FTSpct0 + b / 4) >> (8 * (b % 4))) & 0xFF;
                             if (!s.empty()) s += '|';
                             s += FTS_NAMES[b]; s += '-'; s += std::to_string(pct);
                         }
