@@ -56,6 +56,21 @@ int64_t uvcio_fasta_seq_len(const uvcio_fasta_t *f, const char *name);      /* -
 int uvcio_fasta_fetch(uvcio_fasta_t *f, const char *name, int64_t beg, int64_t end, char *dst /* [end - beg] */);
 void uvcio_fasta_close(uvcio_fasta_t *f);
 
+/* BGZF writer: the block-gzipped stream the reference writes its VCF through (bgzf_open / bgzf_write / bgzf_close, main.cpp:1196-1215,
+ * 1571-1583): blocks of at most 0xff00 input bytes and the 28-byte end-of-file marker.  level 0..9, anything else = 6. */
+typedef struct uvcio_bgzf_writer uvcio_bgzf_writer_t;
+int uvcio_bgzf_write_open(uvcio_bgzf_writer_t **out, const char *path, int32_t level);
+int uvcio_bgzf_write(uvcio_bgzf_writer_t *w, const void *data, int64_t n);
+int uvcio_bgzf_write_close(uvcio_bgzf_writer_t *w);
+
+/* The region planner: SamIter::iternext without a BED file (grouping.cpp:225-312; its memory model grouping.cpp:28-67) over the
+ * alignment columns of a file or query in file order.  One cut per block the reference would hand to process_batch: `flag` = 16 contig
+ * changed | 8 gap of more than 200 bp | 4 per-thread memory budget | 2 end of file, `batch` = the iternext() call that returns it. */
+typedef struct UvcRegionCut { int32_t tid, beg, end, flag, batch; int64_t n_reads; } UvcRegionCut;
+int uvcio_plan_regions(const int32_t *tid, const int32_t *pos, const int32_t *endpos, const uint16_t *flag, int64_t n,
+                       const int64_t *target_len, int32_t n_targets, int32_t nthreads, int64_t mem_per_thread_mb,
+                       UvcRegionCut *out, int64_t capacity, int64_t *n_out);
+
 #ifdef __cplusplus
 }
 #endif

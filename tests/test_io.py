@@ -80,3 +80,113 @@ def test_bad_files_are_refused(tmp_path):
         uio.Bam(str(p))
     with pytest.raises(IOError):
         uio.Fasta(str(tmp_path / "missing.fa"))
+
+
+# ---- BGZF writer and the region planner ----
+def test_bgzf_writer_blocks_and_eof_marker(tmp_path):
+    import gzip
+    import struct
+    from uvc_amd import io as uio
+    rng = np.random.default_rng(5)
+    payload = b"".join(b"chr20\t%d\t.\tA\tC\t%d\n" % (i, rng.integers(0, 99)) for i in range(40000)) + bytes(rng.integers(0, 256, 200000, dtype=np.uint8))
+    path = str(tmp_path / "out.vcf.gz")
+    with uio.BgzfWriter(path) as w:
+        for at in range(0, len(payload), 77777):     # writes that do not line up with block boundaries
+            w.write(payload[at:at + 77777])
+    raw = open(path, "rb").read()
+    assert gzip.decompress(raw) == payload          # a BGZF file is a multi-member gzip file
+    assert raw[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")   # SAMv1 4.1.2 end-of-file marker
+    at, sizes = 0, []
+    while at < len(raw):                              # every member carries the BC extra field with its own size
+        assert raw[at:at + 4] == b"\x1f\x8b\x08\x04" and raw[at + 12:at + 16] == b"BC\x02\x00"
+        bsize = struct.unpack("<H", raw[at + 16:at + 18])[0] + 1
+        isize = struct.unpack("<I", raw[at + bsize - 4:at + bsize])[0]
+        assert isize <= 0xff00
+        sizes.append(isize)
+        at += bsize
+    assert at == len(raw) and sum(sizes) == len(payload) and sizes[-1] == 0 and all(s == 0xff00 for s in sizes[:-2])
+
+
+def _plan_py(tid, pos, endpos, flag, tlen, nthreads, mem):
+    """An independent restatement of SamIter::iternext (no BED), written as the reference's control flow: one generator turn per iternext call."""
+    B_POS, B_READ, STR, UNITS = 8192, 512, 100, 8
+    cuts, state = [], dict(tid=-1, beg=-1, end=-1)
+    i, n, batch = 0, len(tid), 0
+    done = (n == 0)
+    while not done:
+        tot = [0, 0, 0, 0]
+        rr = rp = rpa = 0
+        cur, early = -1, False
+        while True:
+            ret = 0 if i < n else -1
+            if ret >= 0:
+                cur = i; i += 1
+            if cur < 0:
+                break
+            if not (flag[cur] & 4):
+                ct, cb, ce = int(tid[cur]), int(pos[cur]), int(endpos[cur])
+                memfree = (1024 * 1024 // UNITS) * mem
+                used = rr * B_READ + (rp + rpa) * (B_POS + 1024)
+                ovl = min(max(max(state["end"], 0) - cb, 0), 150)
+                sub = used > memfree + memfree * ovl // 150
+                changed = ct != state["tid"]
+                far = (not changed) and state["end"] + 2 * STR < cb
+                rflag = 16 * changed + 8 * far + 4 * sub + 2 * (ret == -1)
+                if rflag:
+                    first = state["tid"] == -1
+                    norm_end = min(state["end"], (2 ** 31 - 1) if first else int(tlen[state["tid"]]))
+                    if not first and state["beg"] < norm_end:
+                        cuts.append(dict(tid=state["tid"], beg=state["beg"], end=norm_end, flag=rflag, batch=batch, n_reads=rr))
+                        s = rp + rpa
+                        tot = [tot[0] + rr, tot[1] + rr * rr, tot[2] + s, tot[3] + s * s]
+                        rr = rp = rpa = 0
+                    state["tid"] = ct
+                    state["beg"] = cb if changed else max(max(state["beg"], cb), norm_end)
+                    by_reads = min(tot[1] // max(1, tot[0]) * nthreads, tot[0]) * B_READ
+                    by_pos = (min(tot[3] // max(1, tot[2]) * nthreads, tot[2]) + 2 * STR * nthreads) * B_POS
+                    if by_reads + by_pos + tot[2] * 1024 > 1024 * 1024 * mem * nthreads:
+                        state["end"] = max(state["beg"], norm_end)
+                        early = True
+                        break
+                if changed:
+                    state["beg"], state["end"] = cb, ce
+                    rpa += rp
+                else:
+                    state["end"] = max(state["end"], ce)
+                rr += 1
+                rp = state["end"] - state["beg"]
+            if ret < 0:
+                break
+        done = not early
+        batch += 1
+    return cuts
+
+
+@pytest.mark.parametrize("seed,mem,nthreads", [(1, 1536, 1), (2, 1, 1), (3, 1, 4), (4, 2, 2), (5, 1536, 8)])
+def test_region_planner_follows_samiter(seed, mem, nthreads):
+    from uvc_amd import io as uio
+    rng = np.random.default_rng(seed)
+    tlen = [50000, 8000, 120000]
+    tid, pos = [], []
+    for t, L in enumerate(tlen):
+        at = int(rng.integers(0, 300))
+        while at < L - 200:
+            if rng.random() < 0.002:
+                at += int(rng.integers(150, 2500))          # coverage gaps on both sides of the 200 bp threshold
+            else:
+                at += int(rng.integers(0, 3))
+            if at < L - 200:
+                tid.append(t); pos.append(at)
+    tid, pos = np.array(tid, dtype=np.int32), np.array(pos, dtype=np.int32)
+    endpos = pos + rng.integers(30, 151, len(pos)).astype(np.int32)
+    flag = np.where(rng.random(len(pos)) < 0.01, 4, 0).astype(np.uint16)   # a few unmapped mates placed on the contig
+    got = uio.plan_regions(tid, pos, endpos, flag, tlen, nthreads=nthreads, mem_per_thread_mb=mem)
+    want = _plan_py(tid, pos, endpos, flag, tlen, nthreads, mem)
+    assert got == want
+    assert len(got) >= 3 and {16, 8} <= {c["flag"] & 24 for c in got} | {c["flag"] & 16 for c in got} | {c["flag"] & 8 for c in got}
+    if mem == 1:
+        assert any(c["flag"] & 4 for c in got) and max(c["batch"] for c in got) > 0   # the memory model cuts blocks and closes batches
+    for a, b in zip(got, got[1:]):      # blocks are disjoint and ordered
+        assert (a["tid"], a["end"]) <= (b["tid"], b["beg"]) or a["tid"] < b["tid"]
+    mapped = (flag & 4) == 0
+    assert sum(c["n_reads"] for c in got) <= int(mapped.sum())

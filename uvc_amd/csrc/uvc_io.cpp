@@ -457,3 +457,134 @@ extern "C" int uvcio_fasta_fetch(uvcio_fasta_t *f, const char *name, int64_t beg
     return 0;
 }
 extern "C" void uvcio_fasta_close(uvcio_fasta_t *f) { if (!f) return; if (f->fp) fclose(f->fp); delete f; }
+
+// ---- BGZF writer (SAMv1 section 4.1): what the reference writes its VCF through (bgzf_open / bgzf_write / bgzf_flush, main.cpp:1196-1215) ----
+struct uvcio_bgzf_writer { FILE *fp = nullptr; std::vector<uint8_t> pending; int level = 6; };
+namespace {
+const size_t BGZF_INPUT_BLOCK = 0xff00;   // uncompressed bytes per block, as htslib
+int bgzf_put_block(uvcio_bgzf_writer *w, const uint8_t *src, size_t n) {
+    uint8_t out[65536 + 64];
+    z_stream zs; memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, w->level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return fail(UVCGPU_EINVAL, "deflateInit2 failed");
+    zs.next_in = const_cast<uint8_t *>(src); zs.avail_in = (uInt)n; zs.next_out = out + 18; zs.avail_out = (uInt)(sizeof(out) - 18 - 8);
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t clen = zs.total_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END || clen + 26 > 65536) return fail(UVCGPU_EINVAL, "BGZF block does not fit 64 KiB");
+    const uint8_t head[18] = { 31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, 0, 0 };
+    memcpy(out, head, 18);
+    const uint32_t bsize = (uint32_t)(clen + 26 - 1);
+    out[16] = (uint8_t)(bsize & 0xFF); out[17] = (uint8_t)(bsize >> 8);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)n), isize = (uint32_t)n;
+    uint8_t *t = out + 18 + clen;
+    for (int i = 0; i < 4; i++) { t[i] = (uint8_t)(crc >> (8 * i)); t[4 + i] = (uint8_t)(isize >> (8 * i)); }
+    if (fwrite(out, 1, clen + 26, w->fp) != clen + 26) return fail(UVCGPU_EINVAL, "short write");
+    return 0;
+}
+}
+extern "C" int uvcio_bgzf_write_open(uvcio_bgzf_writer_t **out, const char *path, int32_t level) {
+    if (!out || !path) return fail(UVCGPU_EINVAL, "null argument");
+    uvcio_bgzf_writer *w = new uvcio_bgzf_writer();
+    w->fp = fopen(path, "wb");
+    if (!w->fp) { delete w; return fail(UVCGPU_EINVAL, std::string("cannot create ") + path); }
+    w->level = (level < 0 || level > 9) ? 6 : level;
+    *out = w;
+    return 0;
+}
+extern "C" int uvcio_bgzf_write(uvcio_bgzf_writer_t *w, const void *data, int64_t n) {
+    if (!w || (n > 0 && !data) || n < 0) return fail(UVCGPU_EINVAL, "bad argument");
+    const uint8_t *p = (const uint8_t *)data;
+    w->pending.insert(w->pending.end(), p, p + n);
+    size_t at = 0;
+    while (w->pending.size() - at >= BGZF_INPUT_BLOCK) { const int rc = bgzf_put_block(w, w->pending.data() + at, BGZF_INPUT_BLOCK); if (rc) return rc; at += BGZF_INPUT_BLOCK; }
+    w->pending.erase(w->pending.begin(), w->pending.begin() + (ptrdiff_t)at);
+    return 0;
+}
+// flushes the pending bytes as a (short) block and appends the 28-byte end-of-file marker block
+extern "C" int uvcio_bgzf_write_close(uvcio_bgzf_writer_t *w) {
+    if (!w) return 0;
+    int rc = 0;
+    if (!w->pending.empty()) rc = bgzf_put_block(w, w->pending.data(), w->pending.size());
+    if (!rc) rc = bgzf_put_block(w, nullptr, 0);
+    if (fclose(w->fp) != 0 && !rc) rc = fail(UVCGPU_EINVAL, "close failed");
+    delete w;
+    return rc;
+}
+
+// ---- the region planner: SamIter::iternext without a BED file (grouping.cpp:225-312) over the alignment columns in file order ----
+// A block of the reference is cut when the contig changes (flag 16), the next read starts more than 2 * MAX_STR_N_BASES behind the
+// running end (8), the block's estimated memory exceeds the per-thread budget (4, check_if_sub_is_over_mem_lim, grouping.cpp:49-67) or
+// the file ends (2); check_if_is_over_mem_lim (grouping.cpp:28-47) closes a batch of blocks, which drops the read that triggered the
+// cut from the running end of the next block exactly as the reference's early return does.
+namespace {
+const int64_t PLAN_BYTES_PER_REF_POS = 1024 * 8, PLAN_BYTES_PER_READ = 512, PLAN_MAX_STR_N_BASES = 100, PLAN_UNITS_PER_THREAD = 8;
+bool plan_batch_over(int64_t n_reads, int64_t reads_sq, int64_t n_rposs, int64_t rposs_sq, int64_t nthreads, int64_t mem_mb) {
+    const uint64_t by_reads = (uint64_t)(std::min<uint64_t>((uint64_t)(reads_sq / std::max<int64_t>(1, n_reads)) * (uint64_t)nthreads, (uint64_t)n_reads) * (uint64_t)PLAN_BYTES_PER_READ);
+    const uint64_t by_rposs = (uint64_t)((std::min<uint64_t>((uint64_t)(rposs_sq / std::max<int64_t>(1, n_rposs)) * (uint64_t)nthreads, (uint64_t)n_rposs) + (uint64_t)(2 * PLAN_MAX_STR_N_BASES * nthreads)) * (uint64_t)PLAN_BYTES_PER_REF_POS);
+    const uint64_t by_vcf = (uint64_t)n_rposs * 1024;
+    return (by_reads + by_rposs + by_vcf) > (uint64_t)(1024 * 1024) * (uint64_t)mem_mb * (uint64_t)nthreads;
+}
+bool plan_block_over(int64_t n_reads, int64_t n_rposs, int64_t mem_mb, int64_t curr_beg, int64_t running_end) {
+    const uint64_t used = (uint64_t)(n_reads * PLAN_BYTES_PER_READ) + (uint64_t)(n_rposs * (PLAN_BYTES_PER_REF_POS + 1024));
+    const uint64_t memfree = (uint64_t)((1024 * 1024) / PLAN_UNITS_PER_THREAD) * (uint64_t)mem_mb;
+    const uint64_t ovl = (uint64_t)std::min<int64_t>(running_end > curr_beg ? running_end - curr_beg : 0, 150);   // size_t arithmetic in the reference: both are non-negative here
+    return used > memfree + memfree * ovl / 150;
+}
+}
+extern "C" int uvcio_plan_regions(const int32_t *tid, const int32_t *pos, const int32_t *endpos, const uint16_t *flag, int64_t n,
+                                  const int64_t *target_len, int32_t n_targets, int32_t nthreads, int64_t mem_per_thread_mb,
+                                  UvcRegionCut *out, int64_t capacity, int64_t *n_out) {
+    if (!n_out || n < 0 || (n > 0 && (!tid || !pos || !endpos || !flag)) || nthreads < 1 || mem_per_thread_mb < 1) return fail(UVCGPU_EINVAL, "bad argument");
+    std::vector<UvcRegionCut> cuts;
+    int64_t block_tid = -1, block_beg = -1, block_running_end = -1;   // last_it_* (grouping.hpp)
+    int64_t i = 0; bool file_done = (n == 0);
+    int32_t batch = 0;
+    while (!file_done) {   // one iternext() call per turn
+        int64_t total_reads = 0, total_rposs = 0, total_reads_sq = 0, total_rposs_sq = 0;
+        int64_t region_reads = 0, region_rposs = 0, region_rposs_add = 0;
+        bool returned_early = false;
+        int64_t cur = -1;   // the record alnrecord holds (stays the last one when the read call reports the end of the file)
+        int ret;
+        do {
+            ret = (i < n) ? 0 : -1;
+            if (ret >= 0) { cur = i; i++; }
+            if (cur < 0) break;
+            if (flag[cur] & 0x4) continue;   // BAM_FUNMAP
+            const int64_t curr_tid = tid[cur], curr_beg = pos[cur], curr_end = endpos[cur];
+            const bool sub_over = plan_block_over(region_reads, region_rposs + region_rposs_add, mem_per_thread_mb, curr_beg, block_running_end < 0 ? 0 : block_running_end);
+            const bool tmpl_changed = (curr_tid != block_tid);
+            const bool far_jumped = ((curr_tid == block_tid) && (block_running_end + (PLAN_MAX_STR_N_BASES * 2) < curr_beg));
+            const int32_t rflag = (tmpl_changed ? 16 : 0) + (far_jumped ? 8 : 0) + (sub_over ? 4 : 0) + ((-1 == ret) ? 2 : 0);
+            if (rflag) {
+                const bool first = (-1 == block_tid);
+                const int64_t tlen = first ? (int64_t)INT32_MAX : ((block_tid < n_targets && target_len) ? target_len[block_tid] : (int64_t)INT32_MAX);
+                const int64_t norm_end = std::min(block_running_end, tlen);
+                const bool zero = (block_beg >= norm_end);
+                if (!first && !zero) {
+                    cuts.push_back(UvcRegionCut{ (int32_t)block_tid, (int32_t)block_beg, (int32_t)norm_end, rflag, batch, region_reads });
+                    const int64_t s_rposs = region_rposs + region_rposs_add;
+                    total_reads += region_reads; total_rposs += s_rposs; total_reads_sq += region_reads * region_reads; total_rposs_sq += s_rposs * s_rposs;
+                    region_rposs = 0; region_rposs_add = 0; region_reads = 0;
+                }
+                block_tid = curr_tid;
+                const int64_t new_beg = std::max(block_beg, curr_beg);
+                block_beg = (tmpl_changed ? curr_beg : std::max(new_beg, norm_end));
+                if (plan_batch_over(total_reads, total_reads_sq, total_rposs, total_rposs_sq, nthreads, mem_per_thread_mb)) {
+                    block_running_end = std::max(block_beg, norm_end);
+                    returned_early = true;
+                    break;
+                }
+            }
+            if (tmpl_changed) { block_beg = curr_beg; block_running_end = curr_end; region_rposs_add += region_rposs; }
+            else block_running_end = std::max(block_running_end, curr_end);
+            region_reads++;
+            region_rposs = block_running_end - block_beg;
+        } while (ret >= 0);
+        if (!returned_early) file_done = true;
+        batch++;
+    }
+    *n_out = (int64_t)cuts.size();
+    if ((int64_t)cuts.size() > capacity || (!out && !cuts.empty())) return fail(UVCGPU_ENOMEM, "destination too small");
+    for (size_t k = 0; k < cuts.size(); k++) out[k] = cuts[k];
+    return 0;
+}

@@ -128,3 +128,50 @@ class Fasta:
             self.close()
         except Exception:
             pass
+
+
+class UvcRegionCut(C.Structure):
+    _fields_ = [("tid", C.c_int32), ("beg", C.c_int32), ("end", C.c_int32), ("flag", C.c_int32), ("batch", C.c_int32), ("n_reads", C.c_int64)]
+
+
+class BgzfWriter:
+    """uvcio_bgzf_write_*: the block-gzipped stream the reference writes its VCF through (main.cpp:1196-1215)."""
+
+    def __init__(self, path, level=6):
+        d = dll()
+        d.uvcio_bgzf_write_open.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_int32]
+        d.uvcio_bgzf_write.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        d.uvcio_bgzf_write_close.argtypes = [C.c_void_p]
+        self.h = C.c_void_p()
+        _check(d.uvcio_bgzf_write_open(C.byref(self.h), path.encode(), level))
+
+    def write(self, data):
+        b = data.encode() if isinstance(data, str) else bytes(data)
+        _check(dll().uvcio_bgzf_write(self.h, b, len(b)))
+
+    def close(self):
+        if self.h:
+            h, self.h = self.h, C.c_void_p()
+            _check(dll().uvcio_bgzf_write_close(h))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def plan_regions(tid, pos, endpos, flag, target_lens, nthreads=1, mem_per_thread_mb=1536):
+    """SamIter::iternext without a BED file (grouping.cpp:225-312) over alignment columns in file order: the blocks the reference hands
+    to process_batch, as dicts (tid, beg, end, flag, batch, n_reads)."""
+    d = dll()
+    d.uvcio_plan_regions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    a = [np.ascontiguousarray(tid, dtype=np.int32), np.ascontiguousarray(pos, dtype=np.int32), np.ascontiguousarray(endpos, dtype=np.int32), np.ascontiguousarray(flag, dtype=np.uint16)]
+    tl = np.ascontiguousarray(target_lens, dtype=np.int64)
+    n = C.c_int64(0)
+    rc = d.uvcio_plan_regions(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, len(a[0]), tl.ctypes.data, len(tl), nthreads, mem_per_thread_mb, None, 0, C.byref(n))
+    if rc not in (0, -6):
+        _check(rc)
+    out = (UvcRegionCut * max(1, n.value))()
+    _check(d.uvcio_plan_regions(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, len(a[0]), tl.ctypes.data, len(tl), nthreads, mem_per_thread_mb, out, n.value, C.byref(n)))
+    return [dict(tid=c.tid, beg=c.beg, end=c.end, flag=c.flag, batch=c.batch, n_reads=c.n_reads) for c in out[:n.value]]
