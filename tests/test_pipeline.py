@@ -77,3 +77,30 @@ def test_a_reset_handle_equals_a_fresh_one(tmp_path, gpu_lib):
         assert all(np.array_equal(a["records"][k], b["records"][k]) for k in a["records"]), (beg, end)
     tiles = list(pipeline.call_contig(gpu_lib, str(tmp_path / "u1.bam"), str(tmp_path / "u1.fa"), "chrT", b0, b0 + 6000, tile=1500, workers=2))
     assert len(tiles) == 4
+
+
+@pytest.mark.gpu
+def test_files_to_vcf(tmp_path, gpu_lib):
+    """BAM + FASTA -> block-gzipped VCF: header of the library, record lines of every tile (uvcgpu_region_vcf_records), BGZF writer."""
+    import gzip
+    reads = make_files(tmp_path, 0)
+    out = str(tmp_path / "calls.vcf.gz")
+    b0 = reads["beg"]
+    n = pipeline.write_vcf(gpu_lib, str(tmp_path / "u0.bam"), str(tmp_path / "u0.fa"), "chrT", b0, b0 + 6000, out, sample="T1", tile=2000)
+    text = gzip.open(out, "rt").read().splitlines()
+    head, body = [l for l in text if l.startswith("#")], [l for l in text if not l.startswith("#")]
+    assert head[0] == "##fileformat=VCFv4.2" and head[-1].split("\t")[-1] == "T1" and any(l.startswith("##contig=<ID=chrT,") for l in head)
+    assert n == len(body) >= 5
+    declared = {l.split("ID=")[1].split(",")[0] for l in head if l.startswith("##FORMAT=")}
+    pos = []
+    for l in body:
+        c = l.split("\t")
+        assert len(c) == 10 and c[0] == "chrT" and c[6] in pipeline.FILTERS and c[7].startswith("ANY_VAR;")
+        keys, vals = c[8].split(":"), c[9].split(":")
+        assert len(keys) == len(vals) and set(keys) <= declared and keys[0] == "GT" and vals[0] == "./1"
+        pos.append(int(c[1]))
+    assert pos == sorted(pos)
+    # the same records as the table writer sees them
+    bam, fa = uio.Bam(str(tmp_path / "u0.bam")), uio.Fasta(str(tmp_path / "u0.fa"))
+    kept = sum(int(t["records"]["keep"].sum()) for t in pipeline.call_contig(gpu_lib, bam, fa, "chrT", b0, b0 + 6000, tile=2000))
+    assert kept == len(body)

@@ -5,10 +5,11 @@
     region bounds + reference (+-100 bp STR halo)                          main.cpp:523-552
     apply_bq_err_correction3 / updateByRegion3Aln / scoring + calling      main.cpp:567-1168
 
-`lib` is the HIP library (`region.gpu_lib()`); tests also run the chain on the oracle library to compare.  Text output here is a
-tab-separated table of the integer fields (the reference's VCF FORMAT strings are not rebuilt).
+`lib` is the HIP library (`region.gpu_lib()`); tests also run the chain on the oracle library to compare.  Output: the reference's VCF
+record lines (uvcgpu_vcf_header / uvcgpu_region_vcf_records, block-gzipped by libuvcio's BGZF writer) or a short tab-separated table.
 
-    python -m uvc_amd.pipeline in.bam ref.fa chr20:1000000-1100000 > out.tsv      (or just `chr20`: the whole contig in 1 Mb tiles)
+    python -m uvc_amd.pipeline in.bam ref.fa chr20:1000000-1100000 --vcf out.vcf.gz --sample TUMOR
+    python -m uvc_amd.pipeline in.bam ref.fa chr20 > out.tsv                       (the whole contig in 1 Mb tiles)
 """
 import sys
 
@@ -22,7 +23,7 @@ SYMBOL_DESC = ["A", "C", "G", "T", "N", "*", "<LR>", "<LD3P>", "<LD2>", "<LD1>",
 FILTERS = ["Q10", "Q20", "Q30", "Q40", "Q50", "Q60", "PASS"]
 
 
-def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None, molecule_tag=0, disable_duplex=0, correct_bq=True, all_out=False, keep_handle=False, reuse=None):
+def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None, molecule_tag=0, disable_duplex=0, correct_bq=True, all_out=False, keep_handle=False, reuse=None, vcf=False):
     """Scores [beg, end) of `chrom`.  Returns None when no read passes the filters (process_batch returns -1, main.cpp:520-523), else a
     dict: records (field -> int32 array), alleles (InDel allele rows), score range, region handle (if keep_handle).
     `reuse`: a dict the caller keeps between calls; the region handle lives in it and is reset for every new region instead of being
@@ -74,6 +75,8 @@ def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None
     rec = R.score(all_out=all_out, pos_beg=rpos_beg, pos_end=min(rpos_end + 1, ext_end - 0), is_amplicon=bool(is_amplicon))
     lap("bq+accumulate+score")
     out = dict(records=rec, alleles=R.indel_alleles(), rpos=(rpos_beg, rpos_end), ext=(ext_beg, ext_end), n_reads=int(g["n_kept"]), n_fams=int(g["n_fams"]), chrom=chrom, refseq=refseq)
+    if vcf:
+        out["vcf"] = R.vcf_records(chrom, rec)          # the record lines of append_vcf_record (uvcgpu_region_vcf_records), before the handle moves on
     if keep_handle:
         out["region"] = R
     elif reuse is None:
@@ -151,7 +154,33 @@ def write_tsv(res, fh, kept_only=True, header=True):
             rec["cVQ1"][i], rec["cVQ2"][i], rec["TLODQ"][i], rec["NLODQ"][i], rec["germ_GT"][i], rec["germ_GQ"][i]))
 
 
+def write_vcf(lib, bam, fasta, chrom, beg, end, path, sample="SAMPLE", params=None, **kw):
+    """BAM + FASTA -> VCF: the header (uvcgpu_vcf_header) and the record lines of every tile, through the BGZF writer when `path` ends in
+    .gz (what the reference does with bgzf_write, main.cpp:1196-1215, 1571-1583), else as plain text ("-" = stdout).  Returns the number
+    of record lines."""
+    p = params if params is not None else region.default_params(lib)
+    b = bam if not isinstance(bam, str) else uio.Bam(bam)
+    header = region.vcf_header(lib, p, sample, [(name, ln) for name, ln in b.refs])
+    sink = uio.BgzfWriter(path) if path.endswith(".gz") else (sys.stdout if path == "-" else open(path, "w"))
+    n = 0
+    try:
+        sink.write(header)
+        for res in call_contig(lib, bam, fasta, chrom, beg, end, vcf=True, params=params, **kw):
+            sink.write(res["vcf"]); n += res["vcf"].count("\n")
+    finally:
+        if sink is not sys.stdout:
+            sink.close()
+    return n
+
+
 def main(argv):
+    args, vcf_path, sample = [], None, "SAMPLE"
+    it = iter(argv[1:])
+    for a in it:
+        if a == "--vcf": vcf_path = next(it, None)
+        elif a == "--sample": sample = next(it, "SAMPLE")
+        else: args.append(a)
+    argv = argv[:1] + args
     if len(argv) != 4:
         sys.stderr.write(__doc__); return 2
     chrom, _, rng = argv[3].partition(":")
@@ -160,6 +189,10 @@ def main(argv):
     if lib.dll.uvcgpu_init(0) != 0:
         raise RuntimeError(lib.last_error())
     bam, fasta = uio.Bam(argv[1]), uio.Fasta(argv[2])
+    if vcf_path:
+        n = write_vcf(lib, bam, fasta, chrom, beg, end, vcf_path, sample=sample)
+        sys.stderr.write("%d records written to %s\n" % (n, vcf_path))
+        return 0
     n = 0
     for res in call_contig(lib, bam, fasta, chrom, beg, end):
         write_tsv(res, sys.stdout, header=(n == 0)); n += 1
