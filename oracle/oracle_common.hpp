@@ -8,7 +8,9 @@
 //   * the parameter defaults (pinned against the reference's own CmdLineArgs.hpp, compiled as-is:
 //     oracle/ref_params_dump.cpp -> tests/golden/params_default.json), and
 //   * calc_binom_10log10_likeratio / prob2odds / odds2prob, pinned by the reference's own
-//     known-answer static_asserts (main_conversion.hpp:205-209, 251-254) in tests/test_oracle_math.py.
+//     known-answer static_asserts (main_conversion.hpp:205-209, 251-254) in tests/test_oracle_math.py, and
+//   * the layout of the VCF sample column, which is not restated at all: oracle/ref_vcf_driver.cpp streams the oracle's values through
+//     the reference's own generated bcfrec::streamAppendBcfFormat (oracle/_ref/, built by `make ref_formats` from bcf_formats_generator1.cpp).
 // The reference's hot-path headers #include htslib, which is absent here and may not be
 // stood-in for, so the reference itself cannot be compiled in this environment.
 #ifndef UVC_ORACLE_COMMON_HPP
