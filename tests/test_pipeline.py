@@ -104,3 +104,29 @@ def test_files_to_vcf(tmp_path, gpu_lib):
     bam, fa = uio.Bam(str(tmp_path / "u0.bam")), uio.Fasta(str(tmp_path / "u0.fa"))
     kept = sum(int(t["records"]["keep"].sum()) for t in pipeline.call_contig(gpu_lib, bam, fa, "chrT", b0, b0 + 6000, tile=2000))
     assert kept == len(body)
+
+
+@pytest.mark.gpu
+def test_native_command_line_equals_the_python_chain(tmp_path, gpu_lib):
+    """uvc_amd/csrc/uvc1-mi355x (the chain in C++, tiles in flight on threads) writes the record lines of uvc_amd/pipeline.py."""
+    import gzip
+    import os
+    import subprocess
+    from uvc_amd import _ffi
+    exe = os.path.join(_ffi.ROOT, "uvc_amd", "csrc", "uvc1-mi355x")
+    assert os.path.exists(exe), "build it: make -C uvc_amd/csrc"
+    for umi in (0, 1):
+        reads = make_files(tmp_path, umi)
+        bam, fa = str(tmp_path / ("u%d.bam" % umi)), str(tmp_path / ("u%d.fa" % umi))
+        b0 = reads["beg"]
+        target = "chrT:%d-%d" % (b0 + 1, b0 + 6000)
+        out_c, out_py = str(tmp_path / "c.vcf.gz"), str(tmp_path / "py.vcf.gz")
+        r = subprocess.run([exe, bam, "-f", fa, "-o", out_c, "-s", "T1", "--targets", target, "--tile", "2000", "-t", "3", "--timing"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert "record lines" in r.stderr
+        pipeline.write_vcf(gpu_lib, bam, fa, "chrT", b0, b0 + 6000, out_py, sample="T1", tile=2000)
+        a, b = gzip.open(out_c, "rt").read().splitlines(), gzip.open(out_py, "rt").read().splitlines()
+        assert [l for l in a if not l.startswith("##")] == [l for l in b if not l.startswith("##")]
+        assert len([l for l in a if not l.startswith("#")]) >= 5
+    r = subprocess.run([exe, bam, "-f", fa, "-o", out_c, "--no-such-option"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "unknown option" in r.stderr

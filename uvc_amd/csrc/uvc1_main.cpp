@@ -1,0 +1,251 @@
+// uvc1-mi355x -- BAM + FASTA -> block-gzipped VCF: the host chain of the reference's uvc1 (main.cpp:1196-1603, process_batch :458-1193)
+// in C++ on the three C ABIs of this repository (uvcio.h readers / writer, uvcgroup.h family assignment, uvcgpu.h hot path + record text).
+// The frequently used options keep the reference's names (CmdLineArgs.cpp:188-262): inputBAM -f -o -s --targets -t -A -q --outvar-flag.
+// Worker threads = tiles in flight: each owns its file handles and one region handle that is reset from tile to tile; the lines are
+// written in tile order.  Regions are fixed tiles (--tile); results at a position do not depend on the cut.
+#include "uvcgpu.h"
+#include "uvcgroup.h"
+#include "uvcio.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+const int32_t MAX_INSERT_SIZE = 2000, MAX_STR_N_BASES = 100;   // common.hpp:63-64
+
+struct Opts {
+    std::string bam, fasta, out, sample = "-", targets;
+    int threads = 2, device = 0, outvar_flag = -1;
+    int64_t tile = 1000000;
+    bool all_out = false, timing = false;
+    double vqual = -1e9;
+};
+[[noreturn]] void die(const std::string &m) { fprintf(stderr, "uvc1-mi355x: %s\n", m.c_str()); exit(2); }
+void usage() {
+    fprintf(stderr, "usage: uvc1-mi355x inputBAM -f ref.fa -o out.vcf.gz [-s sample] [--targets chr[:beg-end]] [-t threads] [-A] [-q vqual]\n"
+                    "                   [--outvar-flag bits] [--tile bp] [--device id] [--timing]\n");
+}
+Opts parse(int argc, char **argv) {
+    Opts o;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto val = [&]() -> std::string { if (i + 1 >= argc) die("missing value of " + a); return argv[++i]; };
+        if (a == "-f" || a == "--fasta") o.fasta = val();
+        else if (a == "-o" || a == "--output") o.out = val();
+        else if (a == "-s" || a == "--sample") o.sample = val();
+        else if (a == "--targets") o.targets = val();
+        else if (a == "-t" || a == "--threads") o.threads = std::max(1, atoi(val().c_str()));
+        else if (a == "-A" || a == "--all-out") o.all_out = true;
+        else if (a == "-q" || a == "--vqual") o.vqual = atof(val().c_str());
+        else if (a == "--outvar-flag") o.outvar_flag = atoi(val().c_str());
+        else if (a == "--tile") o.tile = std::max<int64_t>(1000, atoll(val().c_str()));
+        else if (a == "--device") o.device = atoi(val().c_str());
+        else if (a == "--timing") o.timing = true;
+        else if (a == "-h" || a == "--help") { usage(); exit(0); }
+        else if (!a.empty() && a[0] == '-') die("unknown option " + a + " (the hot-path parameters keep the reference's defaults)");
+        else if (o.bam.empty()) o.bam = a;
+        else die("more than one inputBAM");
+    }
+    if (o.bam.empty() || o.fasta.empty() || o.out.empty()) { usage(); exit(2); }
+    return o;
+}
+
+struct Tile { int32_t tid; std::string chrom; int64_t beg, end; };
+
+// one worker: its own handles, one region handle for all of its tiles
+struct Worker {
+    uvcio_bam_t *bam = nullptr; uvcio_fasta_t *fa = nullptr; uvcgpu_region_t *reg = nullptr;
+    std::vector<uint64_t> h31, h17, u31, u17; std::vector<uint8_t> kind;
+    std::vector<int32_t> filt, isz, order, fam, frag; std::vector<uint8_t> fstrand, dflag, idflag;
+    std::vector<int32_t> pos, mpos, isize, nm, lq, ncig, fragp, famp; std::vector<uint16_t> flag; std::vector<uint8_t> mapq, strandp; std::vector<int64_t> soff, coff;
+    std::vector<int32_t> fields; std::string ref;
+    double t_fetch = 0, t_group = 0, t_region = 0, t_reads = 0, t_gpu = 0, t_text = 0;
+};
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// process_batch for one tile; appends the record lines to `lines`; false = nothing to call there
+bool call_tile(Worker &w, const Opts &o, const UvcParams &P, const Tile &t, int64_t tlen, std::string &lines) {
+    double t0 = now();
+    UvcBamBatch b;
+    if (uvcio_bam_fetch(w.bam, t.tid, std::max<int64_t>(0, t.beg - MAX_INSERT_SIZE), t.end + MAX_INSERT_SIZE, &b)) die(uvcio_last_error());
+    w.t_fetch += now() - t0; t0 = now();
+    const int64_t n = b.n_alns;
+    if (n == 0) return false;
+    w.h31.resize(n); w.h17.resize(n); w.u31.resize(n); w.u17.resize(n); w.kind.resize(n);
+    uvcgpu_qname_digest_batch(b.qnames, b.qname_off, n, 0, 0, w.h31.data(), w.h17.data(), w.u31.data(), w.u17.data(), w.kind.data());
+    UvcGroupParams gp; uvcgpu_group_params_default(&gp);
+    gp.fetch_tbeg = (int32_t)t.beg; gp.fetch_tend = (int32_t)t.end; gp.inferred_sequencing_platform = P.inferred_sequencing_platform;
+    UvcGroupInput gi; memset(&gi, 0, sizeof(gi));
+    gi.n_alns = n; gi.tid = b.tid; gi.pos = b.pos; gi.endpos = b.endpos; gi.mtid = b.mtid; gi.mpos = b.mpos; gi.isize = b.isize; gi.flag = b.flag; gi.mapq = b.mapq;
+    gi.qname_hash31 = w.h31.data(); gi.qname_hash17 = w.h17.data(); gi.umi_hash31 = w.u31.data(); gi.umi_hash17 = w.u17.data(); gi.umi_kind = w.kind.data();
+    w.filt.resize(n); w.isz.resize(n); w.order.resize(n); w.fam.resize(n); w.frag.resize(n); w.fstrand.resize(n); w.dflag.resize(n); w.idflag.resize(n);
+    UvcGroupOut go; memset(&go, 0, sizeof(go));
+    go.filter_reason = w.filt.data(); go.isize_norm = w.isz.data(); go.order = w.order.data(); go.fam_id = w.fam.data(); go.frag_id = w.frag.data();
+    go.fam_strand = w.fstrand.data(); go.fam_dflag = w.dflag.data(); go.fam_idflag = w.idflag.data();
+    if (uvcgpu_group_families(&gp, &gi, &go)) die(uvcgpu_last_error());
+    w.t_group += now() - t0; t0 = now();
+    const int64_t k = go.n_kept;
+    if (k == 0) return false;
+    // region bounds and reference, main.cpp:523-552
+    const int64_t bam_beg = go.extended_inclu_beg_pos, bam_end = go.extended_exclu_end_pos;
+    const int64_t rpos_beg = std::max(t.beg, bam_beg), rpos_end = std::min(t.end, bam_end);
+    const int64_t ext_beg = std::max<int64_t>(0, std::min(t.beg, bam_beg) - MAX_STR_N_BASES), ext_end = std::min(tlen, std::max(t.end, bam_end) + MAX_STR_N_BASES);
+    w.ref.resize((size_t)(ext_end - ext_beg));
+    if (uvcio_fasta_fetch(w.fa, t.chrom.c_str(), ext_beg, ext_end, &w.ref[0])) die(uvcio_last_error());
+    int rc = w.reg ? uvcgpu_region_reset(w.reg, t.tid, (int32_t)ext_beg, (int32_t)ext_end, w.ref.c_str())
+                   : uvcgpu_region_create(&w.reg, &P, t.tid, (int32_t)ext_beg, (int32_t)ext_end, w.ref.c_str());
+    if (rc) die(uvcgpu_last_error());
+    w.t_region += now() - t0; t0 = now();
+    // the kept alignments in alns3 order
+    auto gather = [&](auto &dst, const auto *src) { dst.resize((size_t)k); for (int64_t i = 0; i < k; i++) dst[(size_t)i] = src[w.order[(size_t)i]]; };
+    gather(w.pos, b.pos); gather(w.mpos, b.mpos); gather(w.isize, w.isz.data()); gather(w.flag, b.flag); gather(w.mapq, b.mapq); gather(w.nm, b.nm);
+    gather(w.lq, b.l_qseq); gather(w.soff, b.seq_off); gather(w.coff, b.cigar_off); gather(w.ncig, b.n_cigar);
+    UvcReadSoA rs; memset(&rs, 0, sizeof(rs));
+    rs.n_reads = k; rs.pos = w.pos.data(); rs.mpos = w.mpos.data(); rs.isize = w.isize.data(); rs.flag = w.flag.data(); rs.mapq = w.mapq.data(); rs.nm = w.nm.data();
+    rs.l_qseq = w.lq.data(); rs.seq_off = w.soff.data(); rs.cigar_off = w.coff.data(); rs.n_cigar = w.ncig.data();
+    rs.frag_id = w.frag.data(); rs.fam_id = w.fam.data(); rs.fam_strand = w.fstrand.data();
+    rs.n_bases = b.n_bases; rs.bases = b.bases; rs.quals = b.quals; rs.n_cigar_ops = b.n_cigar_ops; rs.cigars = b.cigars;
+    rs.n_fams = go.n_fams; rs.fam_dflag = w.dflag.data();
+    if (uvcgpu_region_set_reads(w.reg, &rs)) die(uvcgpu_last_error());
+    w.t_reads += now() - t0; t0 = now();
+    if (uvcgpu_region_correct_bq(w.reg) || uvcgpu_region_accumulate(w.reg)) die(uvcgpu_last_error());
+    UvcScoreRequest rq; memset(&rq, 0, sizeof(rq));
+    rq.pos_beg = (int32_t)rpos_beg; rq.pos_end = (int32_t)std::min(rpos_end + 1, ext_end); rq.all_out = o.all_out; rq.is_amplicon = (go.n_amplicon * 2 > k);
+    int64_t cap = std::max<int64_t>(4096, uvcgpu_region_score_size(w.reg, &rq) / (o.all_out ? 1 : 4));
+    UvcScoreOut so;
+    for (;;) {
+        w.fields.resize((size_t)UVC_NUM_SCORE_FIELDS * (size_t)cap);
+        so.capacity = cap; so.n_records = 0; so.fields = w.fields.data();
+        rc = uvcgpu_region_score(w.reg, &rq, &so);
+        if (rc == UVCGPU_ENOMEM && so.n_records > cap) { cap = so.n_records; continue; }
+        if (rc) die(uvcgpu_last_error());
+        break;
+    }
+    w.t_gpu += now() - t0; t0 = now();
+    int64_t len = 0;
+    rc = uvcgpu_region_vcf_records(w.reg, t.chrom.c_str(), &so, nullptr, 0, nullptr, 0, &len);
+    if (rc && rc != UVCGPU_ENOMEM) die(uvcgpu_last_error());
+    const size_t at = lines.size();
+    lines.resize(at + (size_t)len);
+    if (len && uvcgpu_region_vcf_records(w.reg, t.chrom.c_str(), &so, nullptr, 0, &lines[at], len, &len)) die(uvcgpu_last_error());
+    w.t_text += now() - t0;
+    return true;
+}
+}   // namespace
+
+int main(int argc, char **argv) {
+    const Opts o = parse(argc, argv);
+    if (uvcgpu_init(o.device)) die(uvcgpu_last_error());
+    uvcio_bam_t *bam0 = nullptr;
+    if (uvcio_bam_open(&bam0, o.bam.c_str())) die(uvcio_last_error());
+    if (!uvcio_bam_has_index(bam0)) fprintf(stderr, "uvc1-mi355x: no .bai next to %s, every tile scans the file\n", o.bam.c_str());
+    const int32_t nref = uvcio_bam_n_refs(bam0);
+    std::vector<std::string> names; std::vector<int64_t> lens; std::vector<const char *> cnames;
+    for (int32_t i = 0; i < nref; i++) { names.push_back(uvcio_bam_ref_name(bam0, i)); lens.push_back(uvcio_bam_ref_len(bam0, i)); }
+    for (auto &s : names) cnames.push_back(s.c_str());
+    // the tiles: --targets "chr" or "chr:beg-end" (1-based inclusive as in samtools), else every contig
+    std::vector<Tile> tiles;
+    auto add = [&](int32_t tid, int64_t beg, int64_t end) { for (int64_t b = beg; b < end; b += o.tile) tiles.push_back(Tile{ tid, names[(size_t)tid], b, std::min(b + o.tile, end) }); };
+    if (!o.targets.empty()) {
+        std::string chrom = o.targets; int64_t beg = 0, end = -1;
+        const size_t c = o.targets.rfind(':');
+        if (c != std::string::npos && o.targets.find('-', c) != std::string::npos) {
+            chrom = o.targets.substr(0, c);
+            std::string rng = o.targets.substr(c + 1); rng.erase(std::remove(rng.begin(), rng.end(), ','), rng.end());
+            beg = std::max<int64_t>(0, atoll(rng.c_str()) - 1); end = atoll(rng.substr(rng.find('-') + 1).c_str());
+        }
+        int32_t tid = -1;
+        for (int32_t i = 0; i < nref; i++) if (names[(size_t)i] == chrom) tid = i;
+        if (tid < 0) die("--targets names a contig that is not in the BAM header: " + chrom);
+        add(tid, beg, end < 0 ? lens[(size_t)tid] : std::min(end, lens[(size_t)tid]));
+    } else for (int32_t i = 0; i < nref; i++) add(i, 0, lens[(size_t)i]);
+
+    // parameters: the reference's defaults; platform and read length inferred from the first alignments that are seen (CmdLineArgs.cpp:34-111
+    // reads the first 5000 records of the file; here: of the first tile that has any)
+    UvcParams P; uvcgpu_params_default(&P);
+    if (o.vqual > -1e8) P.vqual = o.vqual;
+    if (o.outvar_flag >= 0) P.outvar_flag = o.outvar_flag;
+    P.should_output_all = o.all_out;
+    {
+        int platform = UVC_PLATFORM_ILLUMINA, readlen = 150, maxmq = 0; bool seen = false;
+        for (size_t ti = 0; ti < tiles.size() && !seen; ti++) {
+            UvcBamBatch b;
+            if (uvcio_bam_fetch(bam0, tiles[ti].tid, tiles[ti].beg, tiles[ti].end, &b)) die(uvcio_last_error());
+            if (b.n_alns == 0) continue;
+            seen = true;
+            const int64_t m = std::min<int64_t>(b.n_alns, 5000);
+            std::vector<int32_t> ql{ 150 }; uint64_t pe = 0, q20f = 0, q30f = 0, q30p = 0;
+            for (int64_t i = 0; i < m; i++) {
+                maxmq = std::max<int>(maxmq, b.mapq[i]); pe += (b.flag[i] & 1); ql.push_back(b.l_qseq[i]);
+                for (int32_t q = 0; q < b.l_qseq[i]; q++) { const uint8_t bq = b.quals[b.seq_off[i] + q]; if (bq < 30) q30f++; else q30p++; if (bq < 20) q20f++; }
+            }
+            std::sort(ql.begin(), ql.end());
+            readlen = ql[ql.size() / 2];
+            const bool fix = ((int64_t)ql[ql.size() / 2] * 100 > (int64_t)ql.back() * 95);
+            if (!(pe > 0 || 4 * (q30f - q20f) < q30p || (2 * (q30f - q20f) < q30p && fix))) platform = UVC_PLATFORM_IONTORRENT;
+        }
+        uvcgpu_params_apply_platform(&P, platform, readlen, maxmq);
+    }
+    uvcio_bam_close(bam0);
+
+    // output: header, then the lines of every tile in tile order
+    uvcio_bgzf_writer_t *zw = nullptr;
+    if (uvcio_bgzf_write_open(&zw, o.out.c_str(), 6)) die(uvcio_last_error());
+    {
+        int64_t len = 0;
+        uvcgpu_vcf_header(&P, o.sample.c_str(), cnames.data(), lens.data(), nref, nullptr, 0, &len);
+        std::string h((size_t)len, '\0');
+        if (uvcgpu_vcf_header(&P, o.sample.c_str(), cnames.data(), lens.data(), nref, &h[0], len, &len)) die(uvcgpu_last_error());
+        if (uvcio_bgzf_write(zw, h.data(), (int64_t)h.size())) die(uvcio_last_error());
+    }
+    const double t_start = now();
+    std::vector<std::string> done(tiles.size()); std::vector<char> ready(tiles.size(), 0);
+    std::mutex mu; std::condition_variable cv; std::atomic<size_t> next{ 0 };
+    const int nthreads = (int)std::min<size_t>((size_t)o.threads, std::max<size_t>(tiles.size(), 1));
+    std::vector<Worker> workers((size_t)nthreads);
+    std::vector<std::thread> th;
+    for (int wi = 0; wi < nthreads; wi++) th.emplace_back([&, wi]() {
+        Worker &w = workers[(size_t)wi];
+        if (uvcgpu_init(o.device)) die(uvcgpu_last_error());
+        if (uvcio_bam_open(&w.bam, o.bam.c_str()) || uvcio_fasta_open(&w.fa, o.fasta.c_str())) die(uvcio_last_error());
+        for (;;) {
+            const size_t ti = next.fetch_add(1);
+            if (ti >= tiles.size()) break;
+            // bounded run-ahead: a worker does not start a tile more than 4 * threads in front of the writer
+            std::string lines;
+            call_tile(w, o, P, tiles[ti], lens[(size_t)tiles[ti].tid], lines);
+            { std::lock_guard<std::mutex> g(mu); done[ti].swap(lines); ready[ti] = 1; }
+            cv.notify_all();
+        }
+        if (w.reg) uvcgpu_region_destroy(w.reg);
+        uvcio_bam_close(w.bam); uvcio_fasta_close(w.fa);
+    });
+    int64_t n_lines = 0, n_pos = 0;
+    for (size_t ti = 0; ti < tiles.size(); ti++) {
+        std::string lines;
+        { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return ready[ti] != 0; }); lines.swap(done[ti]); }
+        n_lines += std::count(lines.begin(), lines.end(), '\n'); n_pos += tiles[ti].end - tiles[ti].beg;
+        if (!lines.empty() && uvcio_bgzf_write(zw, lines.data(), (int64_t)lines.size())) die(uvcio_last_error());
+    }
+    for (auto &t : th) t.join();
+    if (uvcio_bgzf_write_close(zw)) die(uvcio_last_error());
+    const double dt = now() - t_start;
+    fprintf(stderr, "uvc1-mi355x: %lld record lines from %zu tiles (%lld positions) in %.2f s = %.2f M positions/s, %d tiles in flight\n",
+            (long long)n_lines, tiles.size(), (long long)n_pos, dt, n_pos / dt / 1e6, nthreads);
+    if (o.timing) {
+        double f = 0, g = 0, r = 0, s = 0, k = 0, x = 0;
+        for (auto &w : workers) { f += w.t_fetch; g += w.t_group; r += w.t_region; s += w.t_reads; k += w.t_gpu; x += w.t_text; }
+        fprintf(stderr, "  thread-seconds: fetch %.2f, digest+group %.2f, reference+region %.2f, set_reads %.2f, bq+accumulate+score %.2f, record text %.2f\n", f, g, r, s, k, x);
+    }
+    return 0;
+}
