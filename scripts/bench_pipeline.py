@@ -43,3 +43,14 @@ if tile_kb >= 200:
             n_rec += int(res["records"]["keep"].sum()); n_pos += res["rpos"][1] - res["rpos"][0]
         dt = time.perf_counter() - t
         print("tiles of 100 kb, %d in flight: %.3f s for %d positions = %.2f M positions/s (files -> records), %d records kept" % (workers, dt, n_pos, n_pos / dt / 1e6, n_rec), flush=True)
+
+# the native command line (uvc_amd/csrc/uvc1-mi355x): files -> block-gzipped VCF
+import subprocess
+exe = "/root/repo/uvc_amd/csrc/uvc1-mi355x"
+if os.path.exists(exe):
+    for tile, threads in ((100_000, 1), (100_000, 4), (100_000, 8), (100_000, 16), (250_000, 4), (250_000, 8), (500_000, 2), (500_000, 4), (1_000_000, 1), (1_000_000, 2), (1_000_000, 4)):
+        if tile > tile_kb * 1000:
+            continue
+        r = subprocess.run([exe, os.path.join(d, "t.bam"), "-f", os.path.join(d, "t.fa"), "-o", os.path.join(d, "o.vcf.gz"), "--targets", "chrT:%d-%d" % (beg + 1, end),
+                            "--tile", str(tile), "-t", str(threads), "--timing", "--repeat", "4"], capture_output=True, text=True)
+        print("uvc1-mi355x tile %d, -t %d: %s" % (tile, threads, " | ".join(l.strip() for l in r.stderr.splitlines()[-3:])), flush=True)

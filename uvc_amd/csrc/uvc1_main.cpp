@@ -25,7 +25,7 @@ const int32_t MAX_INSERT_SIZE = 2000, MAX_STR_N_BASES = 100;   // common.hpp:63-
 
 struct Opts {
     std::string bam, fasta, out, sample = "-", targets;
-    int threads = 2, device = 0, outvar_flag = -1;
+    int threads = 2, device = 0, outvar_flag = -1, repeat = 1;
     int64_t tile = 1000000;
     bool all_out = false, timing = false;
     double vqual = -1e9;
@@ -51,6 +51,7 @@ Opts parse(int argc, char **argv) {
         else if (a == "--tile") o.tile = std::max<int64_t>(1000, atoll(val().c_str()));
         else if (a == "--device") o.device = atoi(val().c_str());
         else if (a == "--timing") o.timing = true;
+        else if (a == "--repeat") o.repeat = std::max(1, atoi(val().c_str()));   // benchmark aid: the tile list n times (steady state on a small file)
         else if (a == "-h" || a == "--help") { usage(); exit(0); }
         else if (!a.empty() && a[0] == '-') die("unknown option " + a + " (the hot-path parameters keep the reference's defaults)");
         else if (o.bam.empty()) o.bam = a;
@@ -169,6 +170,8 @@ int main(int argc, char **argv) {
         if (tid < 0) die("--targets names a contig that is not in the BAM header: " + chrom);
         add(tid, beg, end < 0 ? lens[(size_t)tid] : std::min(end, lens[(size_t)tid]));
     } else for (int32_t i = 0; i < nref; i++) add(i, 0, lens[(size_t)i]);
+    const size_t tiles_per_pass = tiles.size();
+    for (int rep = 1; rep < o.repeat; rep++) for (size_t q = 0; q < tiles_per_pass; q++) tiles.push_back(tiles[q]);
 
     // parameters: the reference's defaults; platform and read length inferred from the first alignments that are seen (CmdLineArgs.cpp:34-111
     // reads the first 5000 records of the file; here: of the first tile that has any)
@@ -230,8 +233,9 @@ int main(int argc, char **argv) {
         if (w.reg) uvcgpu_region_destroy(w.reg);
         uvcio_bam_close(w.bam); uvcio_fasta_close(w.fa);
     });
-    int64_t n_lines = 0, n_pos = 0;
+    int64_t n_lines = 0, n_pos = 0; double t_first_pass = 0; int64_t pos_first_pass = 0;
     for (size_t ti = 0; ti < tiles.size(); ti++) {
+        if (ti == tiles_per_pass) { t_first_pass = now() - t_start; pos_first_pass = n_pos; }
         std::string lines;
         { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return ready[ti] != 0; }); lines.swap(done[ti]); }
         n_lines += std::count(lines.begin(), lines.end(), '\n'); n_pos += tiles[ti].end - tiles[ti].beg;
@@ -242,6 +246,7 @@ int main(int argc, char **argv) {
     const double dt = now() - t_start;
     fprintf(stderr, "uvc1-mi355x: %lld record lines from %zu tiles (%lld positions) in %.2f s = %.2f M positions/s, %d tiles in flight\n",
             (long long)n_lines, tiles.size(), (long long)n_pos, dt, n_pos / dt / 1e6, nthreads);
+    if (o.repeat > 1) fprintf(stderr, "  passes 2..%d (steady state): %.2f M positions/s\n", o.repeat, (n_pos - pos_first_pass) / (dt - t_first_pass) / 1e6);
     if (o.timing) {
         double f = 0, g = 0, r = 0, s = 0, k = 0, x = 0;
         for (auto &w : workers) { f += w.t_fetch; g += w.t_group; r += w.t_region; s += w.t_reads; k += w.t_gpu; x += w.t_text; }

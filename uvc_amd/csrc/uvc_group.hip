@@ -18,6 +18,9 @@
 #include <vector>
 #include "uvcgpu.h"
 #include "uvcgroup.h"
+#include "uvc_alloc.h"
+#define hipMalloc(p, n) uvc_dev_malloc((void **)(p), (n))
+#define hipFree(p) uvc_dev_free((void *)(p))
 
 #define G_MAX_INSERT 2000        // MAX_INSERT_SIZE, common.hpp:64
 #define G_MARGIN G_MAX_INSERT    // ARRPOS_MARGIN, grouping.cpp:22
@@ -224,7 +227,7 @@ __global__ void __launch_bounds__(256) k_g_gather(const u64 *src, const int32_t 
 namespace {
 struct Pool {   // frees everything it handed out
     std::vector<void *> p;
-    ~Pool() { for (void *q : p) hipFree(q); }
+    ~Pool() { (void)hipStreamSynchronize(0); for (void *q : p) hipFree(q); }   // the cache reuses a freed block at once: nothing may still run on it
     template <class T> T *get(size_t n, bool zero = false) {
         void *q = nullptr;
         if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;

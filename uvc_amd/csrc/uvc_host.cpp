@@ -2,6 +2,7 @@
 // alns3-equivalent SoA into device records, kernel sequencing on the handle's HIP stream.
 // There is no CPU compute fallback in this library: every entry point that computes launches HIP kernels.
 #include "uvc_device.h"
+#include "uvc_alloc.h"
 
 #include <algorithm>
 #include <chrono>
@@ -11,6 +12,9 @@
 #include <string>
 #include <thread>
 #include <vector>
+// device memory through the caching allocator (uvc_alloc.h): freed blocks are reused without the device-wide synchronisation of hipFree
+#define hipMalloc(p, n) uvc_dev_malloc((void **)(p), (n))
+#define hipFree(p) uvc_dev_free((void *)(p))
 
 struct RawReads {
     const int32_t *pos, *endpos, *mpos, *isize, *flag, *mapq, *nm, *l_qseq, *n_cigar, *frag, *fs, *dflag, *kind, *fast_rank;
@@ -215,7 +219,9 @@ void radix_sort_ids(std::vector<int32_t> &ids, const std::vector<uint32_t> &key_
         ids.swap(tmp);
     }
 }
-void free_reads(uvcgpu_region *r) { for (void *p : r->owned) hipFree(p); r->owned.clear(); r->has_reads = false; r->accumulated = false; }
+// (the cache hands freed blocks to other handles at once: nothing of this handle may still be running on them)
+void quiesce(uvcgpu_region *r) { if (r->stream) (void)hipStreamSynchronize(r->stream); if (r->side) (void)hipStreamSynchronize(r->side); }
+void free_reads(uvcgpu_region *r) { if (!r->owned.empty()) quiesce(r); for (void *p : r->owned) hipFree(p); r->owned.clear(); r->has_reads = false; r->accumulated = false; }
 }  // namespace
 
 extern "C" {
@@ -280,6 +286,7 @@ static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t 
     r->bucket_off = o; o += (size_t)4 * r->npos * 2 * NSYM * NBUCKETS;
     r->state_bytes = o;
     if (r->npos > r->npos_cap) {
+        quiesce(r);
         for (void *p : { (void *)r->d_refsym, (void *)r->d_rtr, (void *)r->d_rtr0, (void *)r->d_baq, (void *)r->d_state }) if (p) hipFree(p);
         r->d_refsym = nullptr; r->d_rtr = r->d_rtr0 = nullptr; r->d_baq = nullptr; r->d_state = nullptr; r->npos_cap = 0;
         if (hipMalloc((void **)&r->d_refsym, (size_t)r->npos + 1) != hipSuccess || hipMalloc((void **)&r->d_rtr, sizeof(int32_t) * rtr.size()) != hipSuccess
@@ -989,7 +996,7 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
 
 void uvcgpu_region_destroy(uvcgpu_region_t *r) {
     if (!r) return;
-    if (r->stream) hipStreamSynchronize(r->stream);
+    quiesce(r);
     free_reads(r);
     if (r->d_refsym) hipFree(r->d_refsym);
     if (r->d_rtr) hipFree(r->d_rtr);
