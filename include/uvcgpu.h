@@ -354,15 +354,17 @@ int uvcgpu_region_fetch_columns(uvcgpu_region_t *r, const int32_t *refpos, int64
  * ##FORMAT / ##INFO / ##contig lines and the #CHROM line) and append_vcf_record + bcfrec::streamAppendBcfFormat (main.hpp:6027-6272,
  * bcf_formats_generator1.cpp:135-527, 643-690): CHROM POS ID REF ALT QUAL FILTER INFO FORMAT and the sample column with every FORMAT tag
  * of FORMAT_STRING_PER_REC(_WITHOUT_SSCS), in the reference's order and separators.  Not produced here: the read-level haplotype strings
- * bHap / cHap / c2Hap (always "."), FORMAT/note, and the GERMLINE / gVCF-block / ADDITIONAL_INDEL_CANDIDATE lines.
+ * bHap / cHap / c2Hap (always "."), FORMAT/note and the GERMLINE lines of output_germline.
  * Both return UVCGPU_ENOMEM with *len = the size needed when `capacity` is too small. */
 const char *uvcgpu_vcf_format_keys(int32_t with_tier2_consensus_tags);
 int uvcgpu_vcf_header(const UvcParams *params, const char *sample_name, const char *const *contig_names, const int64_t *contig_lens,
                       int32_t n_contigs, char *dst, int64_t capacity, int64_t *len);
 /* `scored` is what uvcgpu_region_score filled for this region (all records, in order: the REF record of a position supplies the first
  * value of every Number=R tag); the lines of the records with out != 0 and keep != 0 are written.  The planes must not have been
- * released (UvcScoreRequest::release_state = 0).  `tumor_keys` as in the score request (NULL for a tumor-only sample). */
-int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *contig_name, const UvcScoreOut *scored,
+ * released (UvcScoreRequest::release_state = 0).  `tumor_keys` as in the score request (NULL for a tumor-only sample).
+ * [pos_beg, pos_end) is the zerobased_pos range of that score request (-1 = its default): the MGVCF block lines (OUTVAR_MGVCF, main.cpp:655-735)
+ * and the ADDITIONAL_INDEL_CANDIDATE lines (main.cpp:759-799) of the range are written in front of the records of their position. */
+int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *contig_name, const UvcScoreOut *scored, int32_t pos_beg, int32_t pos_end,
                               const UvcTumorKey *tumor_keys, int64_t n_tumor_keys, char *dst, int64_t capacity, int64_t *len);
 int uvcgpu_region_sync(uvcgpu_region_t *r);
 /* Measurement hooks (bench.py): HIP-event timing of every kernel of the LAST accumulate, recorded on the handle's stream.

@@ -219,7 +219,7 @@ int uvc_oracle_region_vcf(void *h, const UvcScoreRequest *req, const char *tname
     S.vcf_sink = nullptr;
     if (rc) return rc;
     std::string out;
-    for (size_t i = 0; i < sink.fixed.size(); i++) { if (i) out += '\x1d'; out += sink.fixed[i]; out += '\x1e'; out += (sink.tier2[i] ? "1" : "0"); out += '\x1e'; out += sink.spec[i]; }
+    for (size_t i = 0; i < sink.fixed.size(); i++) { if (i) out += '\x1d'; out += sink.fixed[i]; out += '\x1e'; out += (sink.tier2[i] < 0 ? "-1" : sink.tier2[i] ? "1" : "0"); out += '\x1e'; out += sink.spec[i]; }
     *len = (int64_t)out.size();
     if (!dst || cap < (int64_t)out.size()) { g_err = "destination too small"; return UVCGPU_ENOMEM; }
     memcpy(dst, out.data(), out.size());

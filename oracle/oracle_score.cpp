@@ -1131,6 +1131,60 @@ static void vcf_emit(State &S, const Fmt &f, const Fmt &rf, const std::string &i
     S.vcf_sink->fixed.push_back(fixed); S.vcf_sink->spec.push_back(spec); S.vcf_sink->tier2.push_back(f.tier2);
 }
 
+// The two position-level lines written in front of the records of a zerobased_pos: the MGVCF block (main.cpp:655-735) and
+// ADDITIONAL_INDEL_CANDIDATE (main.cpp:759-799).  Whole lines; the sink marks them with tier2 = -1.
+static void position_lines(State &S, i32 refpos, i32 zpos, i32 prev_tracklen, i32 curr_tracklen, i32 repeatunit_size, i32 repeatnum) {
+    const UvcParams &P = S.P;
+    const std::string &tname = S.vcf_sink->tname;
+    auto sym_of = [](char c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; case 'I': case 'i': return 6; case '-': case '_': return 9; default: return 4; } };
+    auto put_line = [&](const std::string &l) { S.vcf_sink->fixed.push_back(l); S.vcf_sink->spec.push_back(std::string()); S.vcf_sink->tier2.push_back(-1); };
+    if ((P.outvar_flag & 0x8) && (((refpos % 1000) == 0) || (refpos == S.beg))) {
+        const i32 init_refQ = (INT_MAX / 2 + 1);
+        i32 prev_b = 0, prev_c = 0, prev_c12 = 0, prev_q = init_refQ;
+        auto depths_diff = [](i32 cur, i32 prev, i32 mul, i32 add) { const i32 lo = min_(cur, prev), hi = max_(cur, prev); if ((i64)lo * mul >= (i64)hi * 100) return false; if (lo + add >= hi) return false; return true; };
+        std::vector<i64> v;
+        const i32 rp2end = min_(refpos + 1000 + 1, S.end);
+        for (i32 rp2 = refpos; rp2 < rp2end; rp2++) {
+            const int stypes[2] = { UVC_LINK_SYMBOL, UVC_BASE_SYMBOL };   // SYMBOL_TYPES_IN_VCF_ORDER
+            for (int stype : stypes) {
+                const i64 x = rp2 - S.beg;
+                const i32 off = rp2 - S.beg;
+                const int base_m = (off < (i32)S.refstring.size()) ? sym_of(S.refstring[(size_t)off]) : UVC_BASE_N;
+                const int refsymbol = (UVC_BASE_SYMBOL == stype ? base_m : UVC_LINK_M);
+                i32 b = 0, c = 0, c12 = 0;
+                for (int sd = 0; sd < 2; sd++) for (int k = 0; k < ST_NSYMBOLS[stype]; k++) { const int sy = ST_SYMBOLS[stype][k]; b += S.FR(sd, UVC_FRAG_bDP, sy, x); c += S.FA(sd, UVC_FAM_cDP1, sy, x); c12 += S.FA(sd, UVC_FAM_cDP12, sy, x); }
+                const i32 ref_c = S.FA(0, UVC_FAM_cDP12, refsymbol, x) + S.FA(1, UVC_FAM_cDP12, refsymbol, x);
+                const i32 nonref_c = c12 - ref_c;
+                const double ref_like_binom = -calc_binom_10log10_likeratio(P.contam_any_mul_frac, nonref_c + 0.5, c + 1.0);
+                const double ref_like_powlaw = -max_(0.0, P.powlaw_exponent * (10 / log(10)) * logit2((nonref_c + 0.5) / (c + 1.0), P.contam_any_mul_frac));
+                const double nonref_like_binom = -calc_binom_10log10_likeratio(P.germ_hetero_FA, ref_c + 0.5, c + 1.0);
+                const double nonref_like_powlaw = -max_(0.0, P.powlaw_exponent * (10 / log(10)) * logit2((ref_c + 0.5) / (c + 1.0), P.germ_hetero_FA));
+                const i32 q = P.germ_phred_hetero_snp + (i32)round(max_(ref_like_binom, ref_like_powlaw) - (i32)round(max_(nonref_like_binom, nonref_like_powlaw)));
+                if ((init_refQ == prev_q) || (abs(q - prev_q) > 10) || depths_diff(b, prev_b, 130, 3) || depths_diff(c, prev_c, 130, 3) || depths_diff(c12, prev_c12, 130, 3)) {
+                    const i64 e[8] = { rp2 + ((UVC_BASE_SYMBOL == stype) ? 1 : 0), 1 + stype, INT32_MIN, b, c, c12, q, INT32_MIN };
+                    v.insert(v.end(), e, e + 8);
+                    prev_b = b; prev_c = c; prev_c12 = c12; prev_q = q;
+                }
+            }
+        }
+        std::string joined;
+        for (i64 e : v) joined += (e == INT32_MIN ? std::string(".") : std::to_string(e)) + ",";
+        const std::string vcfREF = S.refstring.substr((size_t)(refpos - S.beg), 1);
+        put_line(tname + "\t" + std::to_string(refpos + 1) + "\t.\t" + vcfREF + "\t<NON_REF>\t.\t.\tMGVCF_BLOCK\tGT:VTI:POS_VT_BDP_CDP_HomRefQ\t.:" + std::to_string(sym_of(vcfREF[0])) + ",15:" + joined + std::to_string(rp2end));
+    }
+    const i64 x = refpos - S.beg;
+    const i32 aCDP = S.p32(UVC_P_a_near_long_clip_dp, x), ADP = S.p32(UVC_P_a_dp, x);
+    const bool is_in_long_track = (curr_tracklen > max_(P.microadjust_alignment_tracklen_min - 1, prev_tracklen));
+    const bool is_in_clip_region = ((aCDP >= P.microadjust_alignment_clip_min_count) && (aCDP >= ADP * (P.microadjust_alignment_clip_min_frac - DBL_EPSILON)));
+    if ((0x10 & P.outvar_flag) && (is_in_long_track || is_in_clip_region) && (ADP >= 2 * P.microadjust_alignment_clip_min_count)) {
+        const std::string vcfREF = S.refstring.substr((size_t)(refpos - S.beg), 1);
+        const i32 at = zpos - S.beg;
+        const std::string ru = ((at >= 0 && at < (i32)S.refstring.size()) ? S.refstring.substr((size_t)at, (size_t)repeatunit_size) : std::string());
+        put_line(tname + "\t" + std::to_string(refpos + 1) + "\t.\t" + vcfREF + "\t<ADDITIONAL_INDEL_CANDIDATE>\t.\t.\tADDITIONAL_INDEL_CANDIDATE;RU=" + ru + ";RC=" + std::to_string(repeatnum)
+                 + "\tGT:VTI:clipDP\t.:" + std::to_string(sym_of(vcfREF[0])) + ",16:" + std::to_string(ADP) + "," + std::to_string(aCDP));
+    }
+}
+
 int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &records, std::string &err) {
     if (!S.accumulated) { err = "score before accumulate"; return UVCGPU_ESTATE; }
     const UvcParams &P = S.P;
@@ -1151,9 +1205,11 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
     indel_allele_rows(S, gap_rows, gap_seq);
     std::map<std::pair<i32, int>, size_t> gap_first;   // (refpos, symbol) -> first row
     for (size_t q = gap_rows.size(); q-- > 0;) gap_first[std::make_pair(gap_rows[q].refpos, gap_rows[q].symbol)] = q;
-    for (i32 zpos = pos_beg; zpos < pos_end; zpos++) {
+    i32 prev_tracklen = 0, curr_tracklen = 0;
+    for (i32 zpos = pos_beg; zpos < pos_end; zpos++, prev_tracklen = curr_tracklen) {
         i32 repeatunit_size = 0, repeatnum = 0;
         indelpos_to_context(repeatunit_size, repeatnum, S.refstring, zpos - ext_beg, P.indel_str_repeatsize_max);
+        curr_tracklen = repeatnum * repeatunit_size;   // main.cpp:614
         const i32 refidx = zpos - ext_beg;
         auto symat = [&](i32 i) -> int { return (int)S.refsym[i]; };
         const int st_refsymbol[2] = { ((refsize == (refidx - 1) || (-1 == (refidx - 1))) ? UVC_BASE_NN : symat(refidx - 1)), UVC_LINK_M };
@@ -1171,6 +1227,7 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
             Fmt init; memset(&init, 0, sizeof(init));
             i32 bDPcDP[2];
             symboltype_init(init, S, refpos, st, bDPcDP);
+            if (S.vcf_sink && UVC_BASE_SYMBOL == st) position_lines(S, refpos, zpos, prev_tracklen, curr_tracklen, repeatunit_size, repeatnum);
             const i32 ref_bdepth = S.FR(0, UVC_FRAG_bDP, refsymbol, x) + S.FR(1, UVC_FRAG_bDP, refsymbol, x);
             for (int k = 0; k < ST_NSYMBOLS[st]; k++) {
                 const int symbol = ST_SYMBOLS[st][k];

@@ -134,11 +134,11 @@ bool call_tile(Worker &w, const Opts &o, const UvcParams &P, const Tile &t, int6
     }
     w.t_gpu += now() - t0; t0 = now();
     int64_t len = 0;
-    rc = uvcgpu_region_vcf_records(w.reg, t.chrom.c_str(), &so, nullptr, 0, nullptr, 0, &len);
+    rc = uvcgpu_region_vcf_records(w.reg, t.chrom.c_str(), &so, rq.pos_beg, rq.pos_end, nullptr, 0, nullptr, 0, &len);
     if (rc && rc != UVCGPU_ENOMEM) die(uvcgpu_last_error());
     const size_t at = lines.size();
     lines.resize(at + (size_t)len);
-    if (len && uvcgpu_region_vcf_records(w.reg, t.chrom.c_str(), &so, nullptr, 0, &lines[at], len, &len)) die(uvcgpu_last_error());
+    if (len && uvcgpu_region_vcf_records(w.reg, t.chrom.c_str(), &so, rq.pos_beg, rq.pos_end, nullptr, 0, &lines[at], len, &len)) die(uvcgpu_last_error());
     w.t_text += now() - t0;
     return true;
 }

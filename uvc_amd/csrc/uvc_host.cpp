@@ -31,6 +31,7 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
 extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles, const int32_t *d_allele_rows, int64_t n_alleles,
                                 const UvcGapRow *d_gap_rows, const uint8_t *d_gap_seq, const UvcTumorKey *d_tkeys, int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch, hipStream_t s);
 extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored);
+extern "C" void uvc_launch_block_stats(const RegionDev *R, const UvcParams *P, int64_t x0, int64_t n, int32_t *d_out, hipStream_t s);
 extern "C" size_t uvc_gap_sort_tmp_bytes(size_t n);
 extern "C" void uvc_launch_gather_columns(const char *const *base, const int32_t *first_col, const int32_t *elem, int64_t npos, const int32_t *d_xs, int64_t n, long long *d_out, hipStream_t s);
 extern "C" int uvc_sort_by_pos_cls(const int32_t *d_pos, const int32_t *d_cls, int32_t beg, int shift, int64_t n, unsigned long long *work, void *tmp, size_t tmp_bytes, hipStream_t s);
@@ -779,6 +780,26 @@ int uvcgpu_region_fetch_columns(uvcgpu_region_t *r, const int32_t *refpos, int64
     if (e == hipSuccess) e = hipMemcpyAsync(dst, d_out, sizeof(long long) * (size_t)n * ncol, hipMemcpyDeviceToHost, r->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
     hipFree(d_xs); hipFree(d_out);
+    if (e != hipSuccess) return fail(UVCGPU_EDEVICE, hipGetErrorString(e));
+    return 0;
+}
+// position-level numbers for the MGVCF block and ADDITIONAL_INDEL_CANDIDATE lines of the record writer: 10 ints per position of
+// [refpos_beg, refpos_end), see k_block_stats
+int uvcgpu_region_block_stats_(uvcgpu_region_t *r, int32_t refpos_beg, int32_t refpos_end, int32_t *dst) {
+    if (!r || !dst || refpos_end < refpos_beg) return fail(UVCGPU_EINVAL, "bad argument");
+    if (!r->accumulated) return fail(UVCGPU_ESTATE, "fetch before accumulate");
+    if (r->state_released) return fail(UVCGPU_ESTATE, "the planes were released by the last score (UvcScoreRequest::release_state)");
+    const int64_t n = (int64_t)refpos_end - refpos_beg;
+    if (n == 0) return 0;
+    int rc = uvcgpu_region_sync(r);
+    if (rc) return rc;
+    int32_t *d = nullptr;
+    if (hipMalloc((void **)&d, sizeof(int32_t) * 10 * (size_t)n) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(block stats) failed");
+    uvc_launch_block_stats(&r->R, &r->P, (int64_t)refpos_beg - r->beg, n, d, r->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, d, sizeof(int32_t) * 10 * (size_t)n, hipMemcpyDeviceToHost, r->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(r->stream);
+    hipFree(d);
     if (e != hipSuccess) return fail(UVCGPU_EDEVICE, hipGetErrorString(e));
     return 0;
 }

@@ -1163,3 +1163,34 @@ extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored) {
     const long long nblocks = (ngroups + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
     return (size_t)((2 * ngroups + 1 + nblocks + 1) * 8 + ngroups * 4 + 64);
 }
+
+// ---- position-level numbers of the VCF writer: the MGVCF block lines (main.cpp:655-735) and ADDITIONAL_INDEL_CANDIDATE (main.cpp:759-799) ----
+// Per position 10 ints: for LINK then BASE (SYMBOL_TYPES_IN_VCF_ORDER) the total fragment depth, the de-duplicated depth, the BQ-filtered
+// de-duplicated depth and the homozygous-reference quality; then segprep_a_dp and segprep_a_near_long_clip_dp.
+__global__ void __launch_bounds__(256) k_block_stats(RegionDev R, UvcParams P, long long x0, long long n, int *out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t x = x0 + i;
+    int *o = out + i * 10;
+    if (x < 0 || x >= R.npos) { for (int q = 0; q < 10; q++) o[q] = 0; return; }
+    for (int t = 0; t < 2; t++) {
+        const int st = (t == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
+        const int nsym = st_count(st);
+        const int refsymbol = (st == UVC_BASE_SYMBOL ? (x < R.npos - 1 ? (int)R.refsym[x] : UVC_BASE_N) : UVC_LINK_M);
+        int bdepth = 0, cdepth = 0, cdep12 = 0;
+        for (int sd = 0; sd < 2; sd++) for (int k = 0; k < nsym; k++) { const int s = st_symbol(st, k); bdepth += FRP(R, sd, UVC_FRAG_bDP, s, x); cdepth += FAP(R, sd, UVC_FAM_cDP1, s, x); cdep12 += FAP(R, sd, UVC_FAM_cDP12, s, x); }
+        const int ref_c = FAP(R, 0, UVC_FAM_cDP12, refsymbol, x) + FAP(R, 1, UVC_FAM_cDP12, refsymbol, x);
+        const int nonref_c = cdep12 - ref_c;
+        const double k10 = 10.0 / log(10.0);
+        const double rb = -binom_llr(P.contam_any_mul_frac, nonref_c + 0.5, cdepth + 1.0);
+        const double rp = -dmax(0.0, P.powlaw_exponent * k10 * logit2((nonref_c + 0.5) / (cdepth + 1.0), P.contam_any_mul_frac));
+        const double nb = -binom_llr(P.germ_hetero_FA, ref_c + 0.5, cdepth + 1.0);
+        const double np = -dmax(0.0, P.powlaw_exponent * k10 * logit2((ref_c + 0.5) / (cdepth + 1.0), P.germ_hetero_FA));
+        o[t * 4 + 0] = bdepth; o[t * 4 + 1] = cdepth; o[t * 4 + 2] = cdep12;
+        o[t * 4 + 3] = P.germ_phred_hetero_snp + (int)round(dmax(rb, rp) - (double)(int)round(dmax(nb, np)));
+    }
+    o[8] = P32(R, UVC_P_a_dp, x); o[9] = P32(R, UVC_P_a_near_long_clip_dp, x);
+}
+extern "C" void uvc_launch_block_stats(const RegionDev *R, const UvcParams *P, int64_t x0, int64_t n, int32_t *d_out, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_block_stats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, *R, *P, (long long)x0, (long long)n, d_out);
+}

@@ -15,6 +15,7 @@ extern "C" const char *uvcgpu_region_refseq(const uvcgpu_region_t *r, int32_t *b
 extern "C" const int32_t *uvcgpu_region_repeat_tracks(const uvcgpu_region_t *r, int64_t *npos);    // host copy, [UVC_NRTR][npos]
 extern "C" const UvcParams *uvcgpu_region_params(const uvcgpu_region_t *r);
 extern "C" int uvcgpu_fail_(int code, const char *msg);
+extern "C" int uvcgpu_region_block_stats_(uvcgpu_region_t *r, int32_t refpos_beg, int32_t refpos_end, int32_t *dst);   // 10 ints per position, k_block_stats
 
 namespace {
 const int NSYM = 14;
@@ -392,6 +393,8 @@ extern "C" int uvcgpu_vcf_header(const UvcParams *P, const char *sample, const c
     h += "##INFO=<ID=ANY_VAR,Number=0,Type=Flag,Description=\"Variant of germline or somatic origin\">\n";
     h += "##INFO=<ID=GERMLINE,Number=0,Type=Flag,Description=\"Germline variant\">\n";
     h += "##INFO=<ID=SOMATIC,Number=0,Type=Flag,Description=\"Somatic variant\">\n";
+    h += "##INFO=<ID=MGVCF_BLOCK,Number=0,Type=Flag,Description=\"Block of up to 1000 consecutive positions summarised by FORMAT/POS_VT_BDP_CDP_HomRefQ\">\n";
+    h += "##INFO=<ID=ADDITIONAL_INDEL_CANDIDATE,Number=0,Type=Flag,Description=\"Position with many clipped alignments next to it or at the start of a long repeat track\">\n";
     h += "##INFO=<ID=SomaticQ,Number=A,Type=Float,Description=\"Phred odds that the variant is not somatic\">\n";
     h += "##INFO=<ID=TLODQ,Number=A,Type=Float,Description=\"Phred odds that the variant is an artifact\">\n";
     h += "##INFO=<ID=NLODQ,Number=A,Type=Float,Description=\"Phred odds that the variant is of germline origin\">\n";
@@ -411,6 +414,12 @@ extern "C" int uvcgpu_vcf_header(const UvcParams *P, const char *sample, const c
     h += "##INFO=<ID=R3X2,Number=6,Type=Integer,Description=\"Repeat start, track length and unit size at the positions before and after this one\">\n";
     for (int i = 0; i < N_TAGS; i++)
         h += std::string("##FORMAT=<ID=") + TAGS[i].name + ",Number=" + TAGS[i].number + ",Type=" + TAGS[i].type + ",Description=\"" + (TAGS[i].kind == K_SEP ? "SUB-HEADER: " : "") + TAGS[i].desc + "\">\n";
+    h += "##FORMAT=<ID=GL4,Number=4,Type=Integer,Description=\"Genotype likelihoods of 0/0, 0/1, 1/1 and 1/2\">\n";
+    h += "##FORMAT=<ID=GST,Number=.,Type=Integer,Description=\"Genotype statistics\">\n";
+    h += "##FORMAT=<ID=CDP1,Number=2,Type=Integer,Description=\"De-duplicated depth of all alleles and of the padded deletion allele\">\n";
+    h += "##FORMAT=<ID=cDP1,Number=2,Type=Integer,Description=\"De-duplicated depth of the alleles\">\n";
+    h += "##FORMAT=<ID=POS_VT_BDP_CDP_HomRefQ,Number=.,Type=Integer,Description=\"MGVCF block: runs of (position, sub-position type 1 = SNV 2 = InDel, ., depth with duplicates, de-duplicated depth, BQ-filtered de-duplicated depth, homozygous-reference quality, .), then the end position\">\n";
+    h += "##FORMAT=<ID=clipDP,Number=2,Type=Integer,Description=\"Segment depth and segment depth with long clips next to the position\">\n";
     h += "##phasing=partial\n";
     h += std::string("##variantCallerInferredParameters=(inferred_sequencing_platform=") + (P->inferred_sequencing_platform == UVC_PLATFORM_IONTORRENT ? "IonTorrent" : "Illumina/BGI")
        + ",central_readlen=" + std::to_string(P->central_readlen) + ")\n";
@@ -421,8 +430,8 @@ extern "C" int uvcgpu_vcf_header(const UvcParams *P, const char *sample, const c
     return 0;
 }
 
-extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, const UvcScoreOut *scored, const UvcTumorKey *tkeys, int64_t n_tkeys,
-                                         char *dst, int64_t cap, int64_t *len) {
+extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, const UvcScoreOut *scored, int32_t pos_beg, int32_t pos_end,
+                                         const UvcTumorKey *tkeys, int64_t n_tkeys, char *dst, int64_t cap, int64_t *len) {
     if (!r || !tname || !len || !scored || (scored->n_records > 0 && !scored->fields) || scored->n_records > scored->capacity) return uvcgpu_fail_(UVCGPU_EINVAL, "bad argument");
     const int32_t *recs = scored->fields; const int64_t n = scored->n_records, stride = scored->capacity;
     { const int rc0 = uvcgpu_region_fetch_columns(r, nullptr, 0, nullptr); if (rc0) return rc0; }   // accumulated, planes not released
@@ -445,7 +454,7 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
         if (found < 0) return uvcgpu_fail_(UVCGPU_EINVAL, "a kept record has no REF record at its position (pass all records of the score call)");
         kept.push_back(i); refrec.push_back(found);
     }
-    std::string out;
+    std::vector<std::pair<int32_t, std::string>> rec_lines;   // (zerobased_pos of the iteration that writes it, line)
     if (!kept.empty()) {
         const int32_t ncol = uvcgpu_region_n_columns();
         std::vector<int32_t> where(kept.size());
@@ -462,6 +471,7 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
         const bool tprov = (P.tumor_vcf_is_provided != 0);
         for (size_t k = 0; k < kept.size(); k++) {
             const int64_t ia = kept[k], ir = refrec[k];
+            std::string out;
             C.v = cols.data() + (size_t)ncol * k;
             const int32_t refpos = F(ia, UVC_O_refpos), symbol = F(ia, UVC_O_symbol), refsymbol = F(ia, UVC_O_refsymbol);
             const int st = is_base(symbol) ? UVC_BASE_SYMBOL : UVC_LINK_SYMBOL;
@@ -599,6 +609,68 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
                 }
             }
             out += '\n';
+            rec_lines.emplace_back(F(ia, UVC_O_refpos) + (is_base(F(ia, UVC_O_symbol)) ? 1 : 0), std::move(out));
+        }
+    }
+    std::string out;
+// ---- the position-level lines, in front of the records of their zerobased_pos (main.cpp:607-799) ----
+    {
+        if (pos_beg < 0) { pos_beg = beg + 1; pos_end = end; }   // the default range of uvcgpu_region_score
+        const bool want_block = (P.outvar_flag & 0x8) != 0, want_cand = (P.outvar_flag & 0x10) != 0;
+        std::vector<std::pair<int32_t, std::string>> pos_lines;
+        if ((want_block || want_cand) && pos_end > pos_beg + 1) {
+            const int32_t state_end = end + 1;                                   // getUnifiedExcluEndPosition (main.cpp:569)
+            const int32_t s_beg = pos_beg - 1, s_end = std::min<int64_t>((int64_t)pos_end - 1 + 1001, state_end);
+            std::vector<int32_t> st((size_t)10 * (size_t)std::max(0, s_end - s_beg));
+            if (s_end > s_beg) { const int rc = uvcgpu_region_block_stats_(r, s_beg, s_end, st.data()); if (rc) return rc; }
+            auto S = [&](int32_t refpos, int q) { return st[(size_t)10 * (size_t)(refpos - s_beg) + (size_t)q]; };
+            auto refchar = [&](int64_t off) { return (off >= 0 && off < (int64_t)ref.size()) ? ref[(size_t)off] : 'N'; };
+            auto code_of = [](char c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; case 'I': case 'i': return 6; case '-': case '_': return 9; default: return 4; } };
+            int32_t prev_track = 0;
+            for (int32_t z = pos_beg; z < pos_end; z++) {
+                std::string ru; int32_t rcn = 0;
+                if (want_cand) repeat_context(ref, z - beg, P.indel_str_repeatsize_max, ru, rcn);
+                const int32_t curr_track = rcn * (int32_t)ru.size();
+                if (z != pos_beg) {
+                    const int32_t refpos = z - 1;
+                    std::string line;
+                    if (want_block && ((refpos % 1000) == 0 || refpos == beg)) {
+                        // runs of similar depth and hom-ref quality over the next <= 1001 positions, LINK then BASE sub-position
+                        const int32_t rp2end = std::min<int64_t>((int64_t)refpos + 1001, state_end);
+                        int32_t pb = 0, pc = 0, p12 = 0, pq = INT32_MAX / 2 + 1; const int32_t init_q = INT32_MAX / 2 + 1;
+                        auto differ = [](int32_t a, int32_t b) { const int32_t lo = std::min(a, b), hi = std::max(a, b); return !((int64_t)lo * 130 >= (int64_t)hi * 100) && !(lo + 3 >= hi); };
+                        std::string body;
+                        for (int32_t rp2 = refpos; rp2 < rp2end; rp2++) for (int t = 0; t < 2; t++) {
+                            const int32_t b = S(rp2, t * 4), c = S(rp2, t * 4 + 1), c12 = S(rp2, t * 4 + 2), q = S(rp2, t * 4 + 3);
+                            if (pq == init_q || std::abs((int64_t)q - pq) > 10 || differ(b, pb) || differ(c, pc) || differ(c12, p12)) {
+                                put(body, rp2 + (t == 1 ? 1 : 0)); body += ','; put(body, 1 + (t == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL)); body += ",.,";
+                                put(body, b); body += ','; put(body, c); body += ','; put(body, c12); body += ','; put(body, q); body += ",.,";
+                                pb = b; pc = c; p12 = c12; pq = q;
+                            }
+                        }
+                        const char rc1 = refchar((int64_t)refpos - beg);
+                        line += tname; line += '\t'; put(line, (int64_t)refpos + 1); line += "\t.\t"; line += rc1; line += "\t<NON_REF>\t.\t.\tMGVCF_BLOCK\tGT:VTI:POS_VT_BDP_CDP_HomRefQ\t.:";
+                        put(line, code_of(rc1)); line += ",15:"; line += body; put(line, rp2end); line += '\n';
+                    }
+                    if (want_cand) {
+                        const int32_t ADP = S(refpos, 8), aCDP = S(refpos, 9);
+                        const bool long_track = (curr_track > std::max(P.microadjust_alignment_tracklen_min - 1, prev_track));
+                        const bool clip_region = (aCDP >= P.microadjust_alignment_clip_min_count) && (aCDP >= ADP * (P.microadjust_alignment_clip_min_frac - 2.220446049250313e-16));
+                        if ((long_track || clip_region) && ADP >= 2 * P.microadjust_alignment_clip_min_count) {
+                            const char rc1 = refchar((int64_t)refpos - beg);
+                            line += tname; line += '\t'; put(line, (int64_t)refpos + 1); line += "\t.\t"; line += rc1; line += "\t<ADDITIONAL_INDEL_CANDIDATE>\t.\t.\tADDITIONAL_INDEL_CANDIDATE;RU=";
+                            line += ru; line += ";RC="; put(line, rcn); line += "\tGT:VTI:clipDP\t.:"; put(line, code_of(rc1)); line += ",16:"; put(line, ADP); line += ','; put(line, aCDP); line += '\n';
+                        }
+                    }
+                    if (!line.empty()) pos_lines.emplace_back(z, std::move(line));
+                }
+                prev_track = curr_track;
+            }
+        }
+        size_t a = 0, b = 0;
+        while (a < pos_lines.size() || b < rec_lines.size()) {
+            if (b >= rec_lines.size() || (a < pos_lines.size() && pos_lines[a].first <= rec_lines[b].first)) out += pos_lines[a++].second;
+            else out += rec_lines[b++].second;
         }
     }
     *len = (int64_t)out.size();

@@ -72,11 +72,12 @@ def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None
         R.correct_bq()
     R.accumulate()
     is_amplicon = (g["n_amplicon"] * 2 > g["n_kept"])                                  # !is_by_capture, main.cpp:507-508
-    rec = R.score(all_out=all_out, pos_beg=rpos_beg, pos_end=min(rpos_end + 1, ext_end - 0), is_amplicon=bool(is_amplicon))
+    score_range = (rpos_beg, min(rpos_end + 1, ext_end - 0))
+    rec = R.score(all_out=all_out, pos_beg=score_range[0], pos_end=score_range[1], is_amplicon=bool(is_amplicon))
     lap("bq+accumulate+score")
     out = dict(records=rec, alleles=R.indel_alleles(), rpos=(rpos_beg, rpos_end), ext=(ext_beg, ext_end), n_reads=int(g["n_kept"]), n_fams=int(g["n_fams"]), chrom=chrom, refseq=refseq)
     if vcf:
-        out["vcf"] = R.vcf_records(chrom, rec)          # the record lines of append_vcf_record (uvcgpu_region_vcf_records), before the handle moves on
+        out["vcf"] = R.vcf_records(chrom, rec, pos_beg=score_range[0], pos_end=score_range[1])          # the record lines of append_vcf_record (uvcgpu_region_vcf_records), before the handle moves on
     if keep_handle:
         out["region"] = R
     elif reuse is None:

@@ -240,12 +240,12 @@ class Region:
         fn.restype, fn.argtypes = C.c_int32, [C.c_int32]
         return fn(_ffi.FIELD_GROUPS[group][0])
 
-    def vcf_records(self, contig_name, records, tumor_keys=None):
+    def vcf_records(self, contig_name, records, tumor_keys=None, pos_beg=-1, pos_end=-1):
         """The VCF lines (text) of the records `score()` returned that are written (out and keep set): uvcgpu_region_vcf_records.
         Needs the planes, i.e. a score call without release_state."""
         fn = getattr(self.lib.dll, self.lib.prefix + "region_vcf_records")
         fn.restype = C.c_int
-        fn.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(_ffi.UvcScoreOut), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        fn.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(_ffi.UvcScoreOut), C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         n = len(records["refpos"])
         buf = np.ascontiguousarray(np.stack([np.asarray(records[name], dtype=np.int32) for name in _ffi.SCORE_FIELDS])) if n else np.zeros((_ffi.NUM_SCORE_FIELDS, 1), dtype=np.int32)
         so = _ffi.UvcScoreOut(max(n, 1), n, buf.ctypes.data)
@@ -253,11 +253,11 @@ class Region:
         if tumor_keys:
             tk = (_ffi.UvcTumorKey * len(tumor_keys))(*[_ffi.UvcTumorKey(*t) for t in tumor_keys]); ntk = len(tumor_keys)
         ln = C.c_int64(0)
-        rc = fn(self.h, contig_name.encode(), C.byref(so), tk, ntk, None, 0, C.byref(ln))
+        rc = fn(self.h, contig_name.encode(), C.byref(so), pos_beg, pos_end, tk, ntk, None, 0, C.byref(ln))
         if rc not in (0, -6):
             self._check(rc)
         dst = C.create_string_buffer(max(1, ln.value))
-        self._check(fn(self.h, contig_name.encode(), C.byref(so), tk, ntk, dst, ln.value, C.byref(ln)))
+        self._check(fn(self.h, contig_name.encode(), C.byref(so), pos_beg, pos_end, tk, ntk, dst, ln.value, C.byref(ln)))
         return dst.raw[:ln.value].decode()
 
     def close(self):
