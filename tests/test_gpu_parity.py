@@ -242,3 +242,7 @@ def test_release_state(gpu_lib):
         assert all(np.array_equal(R.fetch(g), planes[g]) for g in planes)
         rec2 = R.score()
         assert all(np.array_equal(rec[k], rec2[k]) for k in rec) and R.indel_alleles() == alleles
+    # a buffer that is too small: UVCGPU_ENOMEM with the count, and the planes are still there for the second call (region.py retries)
+    R.accumulate()
+    rec3 = R.score(release_state=True, capacity=8)
+    assert all(np.array_equal(rec[k], rec3[k]) for k in rec)

@@ -992,20 +992,20 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
     HIP_OK(hipMemsetAsync(r->d_score_count, 0, 8, r->stream));
     int rc = uvc_launch_score(&r->R, &r->P, &rq, use_al, use_row, n_al, r->d_gap_rows, r->d_gap_seq, d_tk, r->d_score_fields, r->score_capacity, r->d_score_count, r->d_score_scratch, r->stream);
     if (!rc && hipGetLastError() != hipSuccess) rc = fail(UVCGPU_EDEVICE, "score kernel launch failed");
-    if (!rc && rq.release_state && r->side) {   // zero the planes on the side stream as soon as the scoring kernels are done, under the D2H of the records
-        if (hipEventRecord(r->e_fork, r->stream) == hipSuccess && hipStreamWaitEvent(r->side, r->e_fork, 0) == hipSuccess
-            && hipMemsetAsync(r->d_state, 0, r->buckets_clean ? r->bucket_off : r->state_bytes, r->side) == hipSuccess && hipEventRecord(r->e_join, r->side) == hipSuccess) {
-            r->state_released = true; r->state_zeroed = true;
-        }
-    }
     if (!rc) rc = uvcgpu_region_sync(r);
     int64_t cnt = 0;
     // copies on the handle's own stream: a null-stream hipMemcpy would also wait for every other handle's work
     if (!rc && (hipMemcpyAsync(&cnt, r->d_score_count, 8, hipMemcpyDeviceToHost, r->stream) != hipSuccess || hipStreamSynchronize(r->stream) != hipSuccess)) rc = fail(UVCGPU_EDEVICE, "hipMemcpy(count)");
     if (!rc) {
         out->n_records = cnt;
-        if (cnt > out->capacity) rc = fail(UVCGPU_ENOMEM, "score output capacity too small");
-        else if (cnt > 0 && (hipMemcpy2DAsync(out->fields, sizeof(int32_t) * out->capacity, r->d_score_fields, sizeof(int32_t) * r->score_capacity, sizeof(int32_t) * cnt, UVC_NUM_SCORE_FIELDS, hipMemcpyDeviceToHost, r->stream) != hipSuccess
+        if (cnt > out->capacity) rc = fail(UVCGPU_ENOMEM, "score output capacity too small");   // the planes stay: the caller comes back with a larger buffer
+        else if (rq.release_state && r->side) {   // the scoring kernels are done: zero the planes on the side stream under the D2H of the records
+            if (hipEventRecord(r->e_fork, r->stream) == hipSuccess && hipStreamWaitEvent(r->side, r->e_fork, 0) == hipSuccess
+                && hipMemsetAsync(r->d_state, 0, r->buckets_clean ? r->bucket_off : r->state_bytes, r->side) == hipSuccess && hipEventRecord(r->e_join, r->side) == hipSuccess) {
+                r->state_released = true; r->state_zeroed = true;
+            }
+        }
+        if (!rc && cnt > 0 && (hipMemcpy2DAsync(out->fields, sizeof(int32_t) * out->capacity, r->d_score_fields, sizeof(int32_t) * r->score_capacity, sizeof(int32_t) * cnt, UVC_NUM_SCORE_FIELDS, hipMemcpyDeviceToHost, r->stream) != hipSuccess
                              || hipStreamSynchronize(r->stream) != hipSuccess))
             rc = fail(UVCGPU_EDEVICE, "hipMemcpy2D(records)");
     }
