@@ -562,6 +562,13 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
       R.frag_nmut = d; R.frag_mut = d + frags.size(); R.overflow_frags = d + frags.size() * (size_t)(UVC_MAXEV + 1); R.n_overflow = d + frags.size() * (size_t)(UVC_MAXEV + 2); }
     { FsRec *d; if ((rc = upload(r, fss, &d))) return rc; R.fss = d; R.n_fs = (int32_t)fss.size(); }
     { int32_t *d; if ((rc = upload(r, generic_fs, &d))) return rc; R.generic_fs = d; R.n_generic_fs = (int32_t)generic_fs.size(); R.n_generic_work = work; }
+    R.fam_digest = nullptr;
+    int32_t max_unit_frags = 0;
+    for (int32_t ui : generic_fs) max_unit_frags = std::max(max_unit_frags, fss[(size_t)ui].frag_end - fss[(size_t)ui].frag_beg);
+    if (work > 8 * r->npos && (size_t)work * 32 <= ((size_t)48 << 30) && max_unit_frags < 16384) {   // (the digest packs vote counts in 14 bits)
+      // deep data (the window family kernels): 32 B per (unit, position) so that P5 and the duplex pass do not walk the fragments again
+        uint32_t *d = nullptr; if ((rc = dev_alloc(r, (size_t)work * 8, &d))) return rc; R.fam_digest = d;
+    }
     {   // the same units ordered by begin, for the position-window family kernels
         std::vector<int32_t> ord(generic_fs.size()); std::iota(ord.begin(), ord.end(), 0);
         std::vector<uint32_t> key(generic_fs.size());

@@ -2000,10 +2000,12 @@ struct FamAcc {
     DEV void bucket(int strand, int cs, int b) const { const int d = dense(cs); if (d >= 0) atomicAdd(&bk[d][strand][b][lane], 1); else atomicAdd(&BKP(*R, strand, cs, b, x), 1); }
 };
 
-template <int PASS>
+// DG: P4 leaves a digest per (unit, position) -- the BQ-sum consensus P5 needs and the {1, 1}-threshold vote consensus of the duplex pass --
+// so that the unit's fragments are walked once instead of three times (R.fam_digest, 32 B per cell); P5 then only reads it.
+template <int PASS, bool DG>
 __global__ void __launch_bounds__(256) k_fam_win(RegionDev R, UvcParams P) {
-    __shared__ int con_s[4][NSYM][64];
-    __shared__ int mmm_s[PASS == 5 ? 4 : 1][NSYM][PASS == 5 ? 64 : 1];
+    __shared__ int con_s[(PASS == 5 && DG) ? 1 : 4][NSYM][(PASS == 5 && DG) ? 1 : 64];
+    __shared__ int mmm_s[((PASS == 5) != DG) ? 4 : 1][NSYM][((PASS == 5) != DG) ? 64 : 1];   // needed by P4 with a digest and by P5 without
     __shared__ int a32[2][FAMW_SLOTS][64];
     __shared__ unsigned long long a64[2][UVC_NFAMINFO64][64];
     __shared__ int bk[PASS == 5 ? 2 : 1][2][NBUCKETS][PASS == 5 ? 64 : 1];
@@ -2031,14 +2033,36 @@ __global__ void __launch_bounds__(256) k_fam_win(RegionDev R, UvcParams P) {
     const bool valid = x < R.npos;
     const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
     FamAcc A; A.a32 = a32; A.a64 = a64; A.bk = (int (*)[2][NBUCKETS][64])bk; A.R = &R; A.x = x; A.lane = lane; A.my_ref = (valid ? (int)R.refsym[x] : 0);
-    const LdsCounts<64> con = { &con_s[wv][0][lane] }, mmm = { &mmm_s[PASS == 5 ? wv : 0][0][PASS == 5 ? lane : 0] };
+    const LdsCounts<64> con = { &con_s[(PASS == 5 && DG) ? 0 : wv][0][(PASS == 5 && DG) ? 0 : lane] }, mmm = { &mmm_s[((PASS == 5) != DG) ? wv : 0][0][((PASS == 5) != DG) ? lane : 0] };
+    const bool padded_ignored_w = (P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0;
     for (int k = lo + wv; k < hi; k += 4) {
         const FsRec u = R.fss[R.generic_sorted[wave_uniform(k)]];
         if (u.end <= w0) continue;
         if (!(valid && p >= u.beg && p < u.end)) continue;
         const int strand = u.strand;
         if (PASS == 4) {
-            unit_counts<false>(R, P, u, p, proton, con, con);
+            if (DG) {
+                // one pass over the unit's fragments serves P4, P5 and the duplex pass: P5 needs the BQ-sum consensus (mmm) and the vote
+                // counts of its symbol, the duplex pass the vote consensus with thresholds {1, 1}; both are left here per (unit, position)
+                unit_counts<true>(R, P, u, p, proton, con, mmm);
+                uint32_t dg[8]; dg[6] = 0; dg[7] = 0;
+                for (int vi = 0; vi < 2; vi++) {
+                    const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
+                    int cs, csum, tsum;
+                    fill_consensus(mmm, cs, csum, tsum, st, false, false);
+                    int tot_nfrags = 0;
+                    const int sb = (st == 0 ? UVC_BASE_A : UVC_LINK_M), se = (st == 0 ? UVC_BASE_NN : UVC_LINK_NN);
+                    for (int sy = sb; sy <= se; sy++) tot_nfrags += con[sy];
+                    dg[3 * vi] = (uint32_t)cs | ((uint32_t)imin(con[cs], 16383) << 4) | ((uint32_t)imin(tot_nfrags, 16383) << 18);
+                    dg[3 * vi + 1] = (uint32_t)csum; dg[3 * vi + 2] = (uint32_t)tsum;
+                    int ds, dc, dt;
+                    fill_consensus(con, ds, dc, dt, st, false, st == UVC_BASE_SYMBOL && padded_ignored_w);
+                    const int adj = imax(dc * 2, dt) - dt;
+                    dg[6] |= ((uint32_t)ds | ((adj >= 1) ? 16u : 0u)) << (8 * vi);
+                }
+                uint4 *dst = (uint4 *)(R.fam_digest + 8 * (u.work_off + (int64_t)(p - u.beg)));
+                dst[0] = make_uint4(dg[0], dg[1], dg[2], dg[3]); dst[1] = make_uint4(dg[4], dg[5], dg[6], dg[7]);
+            } else unit_counts<false>(R, P, u, p, proton, con, con);
             for (int vi = 0; vi < 2; vi++) {
                 const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
                 int cs, cc, ct;
@@ -2111,16 +2135,24 @@ __global__ void __launch_bounds__(256) k_fam_win(RegionDev R, UvcParams P) {
             const bool other_present = (u.other_fs >= 0);
             const bool will_inc_dscs = is_duplex_fam && other_present;
             const bool will_inc_sscs = is_duplex_fam && !other_present;
-            unit_counts<true>(R, P, u, p, proton, con, mmm);
+            uint4 d0 = make_uint4(0, 0, 0, 0), d1 = make_uint4(0, 0, 0, 0);
+            if (DG) { const uint4 *src = (const uint4 *)(R.fam_digest + 8 * (u.work_off + (int64_t)(p - u.beg))); d0 = src[0]; d1 = src[1]; }
+            else unit_counts<true>(R, P, u, p, proton, con, mmm);
             for (int vi = 0; vi < 2; vi++) {
                 const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
-                int cs, con_sumBQs, tot_sumBQs;
-                fill_consensus(mmm, cs, con_sumBQs, tot_sumBQs, st, false, false);
-                if (0 == tot_sumBQs) continue;
-                const int con_nfrags = con[cs];
-                int tot_nfrags = 0;
-                const int sb = (st == 0 ? UVC_BASE_A : UVC_LINK_M), se = (st == 0 ? UVC_BASE_NN : UVC_LINK_NN);
-                for (int s = sb; s <= se; s++) tot_nfrags += con[s];
+                int cs, con_sumBQs, tot_sumBQs, con_nfrags, tot_nfrags = 0;
+                if (DG) {
+                    const uint32_t a = (vi == 0 ? d0.x : d0.w);
+                    cs = (int)(a & 15u); con_nfrags = (int)((a >> 4) & 16383u); tot_nfrags = (int)(a >> 18);
+                    con_sumBQs = (int)(vi == 0 ? d0.y : d1.x); tot_sumBQs = (int)(vi == 0 ? d0.z : d1.y);
+                    if (0 == tot_sumBQs) continue;
+                } else {
+                    fill_consensus(mmm, cs, con_sumBQs, tot_sumBQs, st, false, false);
+                    if (0 == tot_sumBQs) continue;
+                    con_nfrags = con[cs];
+                    const int sb = (st == 0 ? UVC_BASE_A : UVC_LINK_M), se = (st == 0 ? UVC_BASE_NN : UVC_LINK_NN);
+                    for (int s = sb; s <= se; s++) tot_nfrags += con[s];
+                }
                 A.fap(strand, UVC_FAM_cDP1, cs, 1);
                 if (will_inc_sscs && (!will_inc_dscs) && (tot_nfrags >= P.fam_thres_dup1add) && (con_nfrags * 100 >= tot_nfrags * P.fam_thres_dup1perc))
                     A.fap(strand, UVC_FAM_cDPD, cs, 1);
@@ -2202,6 +2234,31 @@ __global__ void __launch_bounds__(256) k_duplex(RegionDev R, UvcParams P, const 
         fill_consensus(dup, cs, cc, ct, st, false, false);
         if (0 < ct) atomicAdd(&DUP(R, UVC_DUPLEX_dDP1, cs, x), 1);
         if (1 < ct) atomicAdd(&DUP(R, UVC_DUPLEX_dDP2, cs, x), 1);
+    }
+}
+
+// the duplex pass from the digests P4 left (k_fam_win<4, true>): the votes of the two strand units of a duplex family at a position
+__global__ void __launch_bounds__(256) k_duplex_d(RegionDev R, const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_work) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_work) return;
+    int lo = 0, hi = n_dup;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (dup_off[mid] <= w) lo = mid; else hi = mid; }
+    const FsRec u0 = R.fss[dup_units[lo]];
+    const FsRec u1 = R.fss[u0.other_fs];
+    const int p = imin(u0.beg, u1.beg) + (int)(w - dup_off[lo]);
+    const int64_t x = p - R.beg;
+    uint32_t v[2] = { 0, 0 };
+    if (p >= u0.beg && p < u0.end) v[0] = R.fam_digest[8 * (u0.work_off + (int64_t)(p - u0.beg)) + 6];
+    if (p >= u1.beg && p < u1.end) v[1] = R.fam_digest[8 * (u1.work_off + (int64_t)(p - u1.beg)) + 6];
+    for (int vi = 0; vi < 2; vi++) {   // fill_consensus over at most two votes: the larger count wins, the smaller symbol on a tie
+        const uint32_t a = (v[0] >> (8 * vi)) & 31u, b = (v[1] >> (8 * vi)) & 31u;
+        const bool va = (a & 16u) != 0, vb = (b & 16u) != 0;
+        if (!va && !vb) continue;
+        const int sa = (int)(a & 15u), sb = (int)(b & 15u);
+        const int ct = (va ? 1 : 0) + (vb ? 1 : 0);
+        const int cs = (va && vb) ? ((sa == sb) ? sa : imin(sa, sb)) : (va ? sa : sb);
+        atomicAdd(&DUP(R, UVC_DUPLEX_dDP1, cs, x), 1);
+        if (1 < ct) atomicAdd(&DUP(R, UVC_DUPLEX_dDP2, cs, x), 1);   // tot_count of the two votes, as fill_consensus sums it (main.hpp:3540-3546)
     }
 }
 
@@ -2571,11 +2628,15 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
         // shallow data: one thread per (unit, position); deep data (many units per position, e.g. UMI panels): the window kernel, whose
         // LDS collection removes most of the atomics that bound the per-thread form
         const bool deep = (R->n_generic_work > 8 * R->npos);
-        if (deep) TIMED(prof, "k_fam_p4", hipLaunchKernelGGL(k_fam_win<4>, dim3(nblk(R->npos, 64)), dim3(256), 0, s, *R, *P));
+        const bool digest = deep && R->fam_digest && P->inferred_is_vcf_generated;   // one walk over the fragments of a unit instead of three
+        if (digest) TIMED(prof, "k_fam_p4", hipLaunchKernelGGL((k_fam_win<4, true>), dim3(nblk(R->npos, 64)), dim3(256), 0, s, *R, *P));
+        else if (deep) TIMED(prof, "k_fam_p4", hipLaunchKernelGGL((k_fam_win<4, false>), dim3(nblk(R->npos, 64)), dim3(256), 0, s, *R, *P));
         else TIMED(prof, "k_fam_p4", hipLaunchKernelGGL(k_fam_p4, dim3(nblk(R->n_generic_work, 256)), dim3(256), 0, s, *R, *P));
         if (P->inferred_is_vcf_generated) {
-            TIMED(prof, "k_fam_p5", hipLaunchKernelGGL(k_fam_p5, dim3(nblk(R->n_generic_work, 256)), dim3(256), 0, s, *R, *P));
-            if (n_dup) TIMED(prof, "k_duplex", hipLaunchKernelGGL(k_duplex, dim3(nblk(n_dup_work, 256)), dim3(256), 0, s, *R, *P, dup_units, n_dup, dup_off, n_dup_work));
+            if (digest) TIMED(prof, "k_fam_p5", hipLaunchKernelGGL((k_fam_win<5, true>), dim3(nblk(R->npos, 64)), dim3(256), 0, s, *R, *P));
+            else TIMED(prof, "k_fam_p5", hipLaunchKernelGGL(k_fam_p5, dim3(nblk(R->n_generic_work, 256)), dim3(256), 0, s, *R, *P));
+            if (n_dup && digest) TIMED(prof, "k_duplex", hipLaunchKernelGGL(k_duplex_d, dim3(nblk(n_dup_work, 256)), dim3(256), 0, s, *R, dup_units, n_dup, dup_off, n_dup_work));
+            else if (n_dup) TIMED(prof, "k_duplex", hipLaunchKernelGGL(k_duplex, dim3(nblk(n_dup_work, 256)), dim3(256), 0, s, *R, *P, dup_units, n_dup, dup_off, n_dup_work));
         }
     }
     if (P->inferred_is_vcf_generated) TIMED(prof, "k_p5b", hipLaunchKernelGGL(k_p5b, dim3(nblk(R->npos * 2, 256)), dim3(256), 0, s, *R, *P));
