@@ -2000,6 +2000,74 @@ struct FamAcc {
     DEV void bucket(int strand, int cs, int b) const { const int d = dense(cs); if (d >= 0) atomicAdd(&bk[d][strand][b][lane], 1); else atomicAdd(&BKP(*R, strand, cs, b, x), 1); }
 };
 
+// The P4 increments of one (unit, position, symbol type) once the vote consensus (cs = symbol, cc = its votes, ct = all votes) is known
+// (main.hpp:2999-3355); the body of k_fam_win<4> with con[] reduced to what it uses of it.
+DEV void p4_apply(const FamAcc &A, const RegionDev &R, const UvcParams &P, const FsRec &u, int p, int64_t x, int st, int cs, int cc, int ct) {
+    const int strand = u.strand;
+    {
+                const bool is_fam_good = ((P.fam_thres_dup1add <= ct) && (cc * 100 >= ct * P.fam_thres_dup1perc) && ((u.dflag & 0x1) || (P.fam_flag & 0x2)));
+                A.fap(strand, UVC_FAM_cDP12, cs, 1);
+                if (1 == ct) A.fap(strand, UVC_FAM_cDP21, cs, 1);
+                if (!P.inferred_is_vcf_generated) return;
+                if (is_fam_good) {
+                    A.fap(strand, UVC_FAM_cDP2, cs, 1);
+                    int rbeg = imin(u.nsb_min, p), rend = imax(u.nsb_max, p);
+                    const bool nonconf_middle = (u.l2r_end_median <= (u.r2l_end_median + P.indel_adj_tracklen_dist));
+                    if (nonconf_middle && p < u.r2l_end_median) rend = imax(imin(u.l2r_end_median, imin(u.r2l_end_median, rend)), p);
+                    if (nonconf_middle && u.l2r_end_median < p) rbeg = imin(imax(u.l2r_end_median, imax(u.r2l_end_median, rbeg)), p);
+                    const bool isGap = (UVC_LINK_SYMBOL == st);
+                    const int bq = 90, dist = 1024 * 1024;
+                    if (((!isGap) && bq >= P.bias_thres_highBQ) || (isGap && dist >= P.bias_thres_highBQ)) {
+                        const bool tier2 = (isGap || bq >= P.bias_thres_highBQ);
+                        const int l_nb = (int)nnminus(p + 1, rbeg), r_nb = (int)nnminus(rend, p);
+                        const int _LPxT = TH(R, UVC_T_aLPxT, x), RPxT = TH(R, UVC_T_aRPxT, x);
+                        const int LPxT = (isGap ? _LPxT : imin(_LPxT, RPxT));
+                        // indel_len = majority COUNT of one inserted sequence among the unit's fragments (main.hpp:3239-3243): the
+                        // sequence-keyed maps stay on the host; the number of votes for the symbol is an upper bound that
+                        // equals it whenever all fragments carry the same inserted sequence.
+                        const int indel_len = ((is_ins(cs) || is_del(cs)) ? cc : 0);   // con[cs] of the vote consensus
+                        const bool far = (l_nb + (is_ins(cs) ? (int)nnminus(indel_len, P.microadjust_nobias_pos_indel_maxlen) : 0) >= LPxT) && (r_nb >= RPxT);
+                        if (far) {
+                            int LP1 = 0, LP2 = 0, RP1 = 0, RP2 = 0; long long LPL = 0, RPL = 0;
+                            bidir(LP1, LP2, RP1, RP2, LPL, RPL, TH(R, UVC_T_aLP1t, x), TH(R, UVC_T_aLP2t, x), TH(R, UVC_T_aRP1t, x), TH(R, UVC_T_aRP2t, x), l_nb, r_nb, true, 0);
+                            if (LP1) A.fi(UVC_FI_c2LP1, cs, LP1);
+                            if (LP2) A.fi(UVC_FI_c2LP2, cs, LP2);
+                            if (RP1) A.fi(UVC_FI_c2RP1, cs, RP1);
+                            if (RP2) A.fi(UVC_FI_c2RP2, cs, RP2);
+                            A.fi(UVC_FI_c2LPL, cs, (int)LPL); A.fi(UVC_FI_c2RPL, cs, (int)RPL);
+                        }
+                        if ((int)nnminus(p + 1, u.nsb_min) >= P.bias_thres_strict_c2LRP0) A.fi(UVC_FI_c2LP0, cs, 1);
+                        if ((int)nnminus(u.nsb_max, p) >= P.bias_thres_strict_c2LRP0) A.fi(UVC_FI_c2RP0, cs, 1);
+                        const long long baq_last = R.end - 1;
+                        const int seg_l_baq = (int)(BAQ1(R, p) - BAQ1(R, lmax((long long)rbeg, nnminus(p, MAX_STR_N_BASES))) + 1);
+                        const long long rr = lmin((long long)rend - 1, lmin((long long)p + MAX_STR_N_BASES, baq_last));
+                        const int _seg_r_baq = (int)(BAQ1(R, rr) - BAQ1(R, p) + 1);
+                        const int seg_r_baq = (isGap ? (int)lmin((long long)_seg_r_baq, BAQ2(R, rr) - BAQ2(R, p) + 7) : _seg_r_baq);
+                        const int thres_highBAQ = P.bias_thres_highBAQ + (isGap ? 0 : 3);
+                        if (seg_l_baq >= thres_highBAQ && seg_r_baq >= thres_highBAQ) {
+                            int LB1 = 0, LB2 = 0, RB1 = 0, RB2 = 0; long long LBL = 0, RBL = 0;
+                            bidir(LB1, LB2, RB1, RB2, LBL, RBL, P.bias_thres_BAQ1, P.bias_thres_BAQ2, P.bias_thres_BAQ1, P.bias_thres_BAQ2, seg_l_baq, seg_r_baq, tier2, 0);
+                            if (LB1) A.fi(UVC_FI_c2LB1, cs, LB1);
+                            if (LB2) A.fi(UVC_FI_c2LB2, cs, LB2);
+                            if (RB1) A.fi(UVC_FI_c2RB1, cs, RB1);
+                            if (RB2) A.fi(UVC_FI_c2RB2, cs, RB2);
+                            A.fi64(UVC_FI64_c2LBL, cs, LBL); A.fi64(UVC_FI64_c2RBL, cs, RBL);
+                        }
+                        A.fi(UVC_FI_c2BQ2, cs, 1);
+                    }
+                }
+                if (P.fam_thres_dup2add <= ct && (cc * 100 >= ct * P.fam_thres_dup2perc)) A.fap(strand, UVC_FAM_cDP3, cs, 1);
+                const int flat = (is_subst(cs) ? P.fam_thres_emperr_all_flat_snv : P.fam_thres_emperr_all_flat_indel);
+                const int perc = (is_subst(cs) ? P.fam_thres_emperr_con_perc_snv : P.fam_thres_emperr_con_perc_indel);
+                if (ct < flat) return;
+                if (cc * 100 < ct * perc) return;
+                const int sb = (st == 0 ? UVC_BASE_A : UVC_LINK_M), se = (st == 0 ? UVC_BASE_NN : UVC_LINK_NN);
+                const int m = ct - cc, M = ct * (se - sb);   // sum over the other symbols of the type of (their votes, all votes)
+                if (m) A.fap(strand, UVC_FAM_cDPm, cs, m);
+                A.fap(strand, UVC_FAM_cDPM, cs, M);
+    }
+}
+
 // DG: P4 leaves a digest per (unit, position) -- the BQ-sum consensus P5 needs and the {1, 1}-threshold vote consensus of the duplex pass --
 // so that the unit's fragments are walked once instead of three times (R.fam_digest, 32 B per cell); P5 then only reads it.
 template <int PASS, bool DG>
@@ -2199,6 +2267,178 @@ __global__ void __launch_bounds__(256) k_fam_win(RegionDev R, UvcParams P) {
         const int ln = i & 63, b = (i >> 6) % NBUCKETS, strand = ((i >> 6) / NBUCKETS) % 2, d = (i >> 6) / (2 * NBUCKETS);
         const int64_t xx = x0 + ln;
         atomicAdd(&BKP(R, strand, (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M), b, xx), v);
+    }
+}
+
+// the consensus numbers of a (unit, position) that has a fragment of the general kind: out of line, so that its registers do not count
+// against the occupancy of k_fam_p4d (the call is rare)
+__attribute__((noinline)) DEV void general_unit(const RegionDev &R, const UvcParams &P, const FsRec &u, int p, bool proton, bool padded_ignored,
+                                                int *vcs, int *vcc, int *vct, int *mcs, int *msum, int *mtot, int *mcon, int *dcs, int *dadj) {
+    int con_l[NSYM], mmm_l[NSYM];
+    unit_counts<true>(R, P, u, p, proton, con_l, mmm_l);
+    for (int vi = 0; vi < 2; vi++) {
+        const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
+        fill_consensus(con_l, vcs[vi], vcc[vi], vct[vi], st, false, false);
+        fill_consensus(mmm_l, mcs[vi], msum[vi], mtot[vi], st, false, false);
+        mcon[vi] = con_l[mcs[vi]];
+        int dc, dt;
+        fill_consensus(con_l, dcs[vi], dc, dt, st, false, st == UVC_BASE_SYMBOL && padded_ignored);
+        dadj[vi] = imax(dc * 2, dt) - dt;
+    }
+}
+
+// k_fam_p4d: P4 of the generic units on deep data, writing the digest (see k_fam_win).  Same window structure, but the votes (con) and the
+// BQ sums (mmm) of a (unit, position) live in registers: a fragment of <= 2 simple alignments can only vote for LINK_M and for one of
+// A C G T N, so the updates are a fixed LINK_M add and a select chain over five symbols.  Without the two per-wave LDS count arrays the
+// block needs 17 KiB of LDS instead of 45, and the read-modify-write chains through LDS are gone.  A lane that meets a fragment of the
+// general kind (InDel next to the position, > 2 alignments) redoes its unit through unit_counts<true> on local arrays (rare).
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_fam_p4d(RegionDev R, UvcParams P) {
+    __shared__ int a32[2][FAMW_SLOTS][64];
+    __shared__ unsigned long long a64[2][UVC_NFAMINFO64][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t x0 = (int64_t)xcd_block() * 64;
+    if (x0 >= R.npos) return;
+    const int w0 = R.beg + (int)x0;
+    int lo, hi;
+    {
+        int l = 0, h = R.n_generic_fs;
+        const int key = w0 - R.max_unit_span + 1;
+        while (l < h) { int m = (l + h) >> 1; if (R.fss[R.generic_sorted[m]].beg < key) l = m + 1; else h = m; }
+        lo = l; h = R.n_generic_fs;
+        while (l < h) { int m = (l + h) >> 1; if (R.fss[R.generic_sorted[m]].beg < w0 + 64) l = m + 1; else h = m; }
+        hi = l;
+    }
+    if (lo >= hi) return;   // block-uniform
+    for (int i = threadIdx.x; i < 2 * FAMW_SLOTS * 64; i += 256) (&a32[0][0][0])[i] = 0;
+    for (int i = threadIdx.x; i < 2 * UVC_NFAMINFO64 * 64; i += 256) (&a64[0][0][0])[i] = 0ull;
+    __syncthreads();
+    const int p = w0 + lane;
+    const int64_t x = x0 + lane;
+    const bool valid = x < R.npos;
+    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    const bool padded_ignored = (P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0;
+    FamAcc A; A.a32 = a32; A.a64 = a64; A.bk = nullptr; A.R = &R; A.x = x; A.lane = lane; A.my_ref = (valid ? (int)R.refsym[x] : 0);
+    const int noindel80 = ((valid && x > 0) ? imin(80, imin(RTRP(R, UVC_RTR_indelphred, x - 1), RTRP(R, UVC_RTR_indelphred, x))) : 80);
+    const __amdgpu_buffer_rsrc_t rs = bq_rsrc(R);
+    for (int k = lo + wv; k < hi; k += 4) {
+        const FsRec u = R.fss[R.generic_sorted[wave_uniform(k)]];
+        if (u.end <= w0) continue;
+        const bool mine = (valid && p >= u.beg && p < u.end);
+        // votes / BQ sums of LINK_M and of A C G T N (registers); the other eight symbols only through the general path
+        int cL = 0, mL = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0;
+        bool general = false;
+        // the fragment records of the unit: one per lane (12 dwords), fields of record j broadcast with v_readlane, the base / quality
+        // bytes of record j + 1 requested before record j is evaluated -- three dependent memory round trips per unit instead of three per fragment
+        const int nfr = u.frag_end - u.frag_beg;
+        for (int f0 = 0; f0 < nfr; f0 += 64) {
+            int c[12];
+            if (f0 + lane < nfr) {
+                const int4 *q4 = (const int4 *)(R.ffast + R.frag_rank[u.frag_beg + f0 + lane]);
+#pragma unroll
+                for (int i = 0; i < 3; i++) { const int4 t = q4[i]; c[4 * i] = t.x; c[4 * i + 1] = t.y; c[4 * i + 2] = t.z; c[4 * i + 3] = t.w; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 12; i++) c[i] = 0;
+            }
+            const int n = imin(64, nfr - f0);
+            int bq0n = 0, bq1n = 0;
+            auto issue = [&](int j) {
+                const int fl = bcast(c[3], j);
+                bq0n = bq_load(rs, bcast(c[8], j) + p);
+                if (((fl >> 3) & 0xF) == 2) bq1n = bq_load(rs, bcast(c[9], j) + p);
+            };
+            issue(0);
+            for (int j = 0; j < n; j++) {
+                const int bq0 = bq0n, bq1 = bq1n;
+                if (j + 1 < n) issue(j + 1);
+                const int fbeg = bcast(c[0], j), fend = bcast(c[1], j), flags = bcast(c[3], j);
+                if (!(mine && p >= fbeg && p < fend)) continue;
+                if ((flags & 0x101) != 0 || proton) { general = true; continue; }
+                const int pos0 = bcast(c[4], j), rend0 = bcast(c[5], j), pos1 = bcast(c[6], j), rend1 = bcast(c[7], j);
+                const int nogap0 = bcast(c[10], j), nogap1 = bcast(c[11], j);
+                const bool has2 = (((flags >> 3) & 0xF) == 2);
+                const bool in0 = (p >= pos0 && p < rend0), in1 = (has2 && p >= pos1 && p < rend1);
+                const int lv0 = ((in0 && p > pos0) ? imax(noindel80 - nogap0, 0) + 1 : 0), lv1 = ((in1 && p > pos1) ? imax(noindel80 - nogap1, 0) + 1 : 0);
+                const int lv = imax(lv0, lv1);
+                if (lv > 0) { cL += 1; mL += lv; }
+                if (in0 || in1) {
+                    const int b0 = bq0 & 0xFF, b1 = bq1 & 0xFF;
+                    const int v0 = ((bq0 >> 8) & 0xFF) + P.bq_phred_added_misma, v1 = ((bq1 >> 8) & 0xFF) + P.bq_phred_added_misma;
+                    const int Aq = (in0 ? v0 : 0), Bq = (in1 ? v1 : 0);
+                    const bool diff = (in0 && in1 && b0 != b1);
+                    const bool first = (v0 > v1) || (v0 == v1 && b0 < b1);
+                    const int cc = imax(Aq, Bq), ct = (diff ? Aq + Bq : cc);
+                    const int cs = ((in0 && (!diff || first)) ? b0 : b1);
+                    int cs4 = cs, cc4 = cc, ct4 = ct;
+                    if (padded_ignored) {
+                        const int A4 = ((in0 && b0 <= UVC_BASE_T) ? v0 : 0), B4 = ((in1 && b1 <= UVC_BASE_T) ? v1 : 0);
+                        const bool first4 = (A4 > B4) || (A4 == B4 && b0 < b1);
+                        cc4 = imax(A4, B4); ct4 = (diff ? A4 + B4 : cc4);
+                        cs4 = ((A4 == 0 && B4 == 0) ? UVC_BASE_T : (diff ? (first4 ? b0 : b1) : cs));
+                    }
+                    if (cs > UVC_BASE_N || cs4 > UVC_BASE_N) { general = true; continue; }   // cannot happen for packed base codes 0..4; kept as a guard
+                    const int adj = imax(cc4 * 2, ct4) - ct4;
+                    const int vote = ((adj >= P.fam_thres_highBQ_snv && adj > 0) ? 1 : 0);
+                    c0 += (cs4 == 0 ? vote : 0); c1 += (cs4 == 1 ? vote : 0); c2 += (cs4 == 2 ? vote : 0); c3 += (cs4 == 3 ? vote : 0); c4 += (cs4 == 4 ? vote : 0);
+                    const int adj5 = imax(imax(cc * 2, ct) - ct, 0);
+                    m0 += (cs == 0 ? adj5 : 0); m1 += (cs == 1 ? adj5 : 0); m2 += (cs == 2 ? adj5 : 0); m3 += (cs == 3 ? adj5 : 0); m4 += (cs == 4 ? adj5 : 0);
+                }
+            }
+        }
+        if (!mine) continue;
+        // per symbol type: vote consensus (cs, cc, ct), BQ-sum consensus (ms, msum, mtot) with the votes of its symbol, duplex vote
+        int vcs[2], vcc[2], vct[2], mcs[2], msum[2], mtot[2], mcon[2], dcs[2], dadj[2];
+        if (!general) {
+            // LINK: only LINK_M can be non-zero; an empty type gives the last symbol of the type (fill_consensus starts from it)
+            vcs[0] = (cL > 0 ? UVC_LINK_M : UVC_LINK_NN); vcc[0] = cL; vct[0] = cL;
+            mcs[0] = (mL > 0 ? UVC_LINK_M : UVC_LINK_NN); msum[0] = mL; mtot[0] = mL; mcon[0] = (mL > 0 ? cL : 0);
+            dcs[0] = vcs[0]; dadj[0] = cL;   // imax(2 * cc, ct) - ct with cc == ct
+            // BASE: first maximum in symbol order A C G T N (NN is zero)
+            int bs = UVC_BASE_NN, bc = 0;
+            if (c0 > bc) { bs = 0; bc = c0; } if (c1 > bc) { bs = 1; bc = c1; } if (c2 > bc) { bs = 2; bc = c2; } if (c3 > bc) { bs = 3; bc = c3; } if (c4 > bc) { bs = 4; bc = c4; }
+            vcs[1] = bs; vcc[1] = bc; vct[1] = c0 + c1 + c2 + c3 + c4;
+            int qs = UVC_BASE_NN, qc = 0;
+            if (m0 > qc) { qs = 0; qc = m0; } if (m1 > qc) { qs = 1; qc = m1; } if (m2 > qc) { qs = 2; qc = m2; } if (m3 > qc) { qs = 3; qc = m3; } if (m4 > qc) { qs = 4; qc = m4; }
+            mcs[1] = qs; msum[1] = qc; mtot[1] = m0 + m1 + m2 + m3 + m4;
+            mcon[1] = (qs == 0 ? c0 : qs == 1 ? c1 : qs == 2 ? c2 : qs == 3 ? c3 : qs == 4 ? c4 : 0);
+            // the duplex vote looks at A..T only when padded deletions are ignored (fill_consensus(..., ignore_padded_del)): then the start
+            // symbol is T and N does not take part
+            if (padded_ignored) {
+                int ds = UVC_BASE_T, dc = 0;
+                if (c0 > dc) { ds = 0; dc = c0; } if (c1 > dc) { ds = 1; dc = c1; } if (c2 > dc) { ds = 2; dc = c2; } if (c3 > dc) { ds = 3; dc = c3; }
+                const int dt = c0 + c1 + c2 + c3;
+                dcs[1] = ds; dadj[1] = imax(dc * 2, dt) - dt;
+            } else { dcs[1] = bs; dadj[1] = imax(bc * 2, vct[1]) - vct[1]; }
+        } else general_unit(R, P, u, p, proton, padded_ignored, vcs, vcc, vct, mcs, msum, mtot, mcon, dcs, dadj);
+        uint32_t dg6 = 0;
+        uint32_t dga[2];
+        for (int vi = 0; vi < 2; vi++) {
+            dga[vi] = (uint32_t)mcs[vi] | ((uint32_t)imin(mcon[vi], 16383) << 4) | ((uint32_t)imin(vct[vi], 16383) << 18);
+            dg6 |= ((uint32_t)dcs[vi] | ((dadj[vi] >= 1) ? 16u : 0u)) << (8 * vi);
+        }
+        uint4 *dst = (uint4 *)(R.fam_digest + 8 * (u.work_off + (int64_t)(p - u.beg)));
+        dst[0] = make_uint4(dga[0], (uint32_t)msum[0], (uint32_t)mtot[0], dga[1]); dst[1] = make_uint4((uint32_t)msum[1], (uint32_t)mtot[1], dg6, 0u);
+        for (int vi = 0; vi < 2; vi++) {
+            if (0 == vct[vi]) continue;
+            p4_apply(A, R, P, u, p, x, (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL), vcs[vi], vcc[vi], vct[vi]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * FAMW_SLOTS * 64; i += 256) {
+        const int v = (&a32[0][0][0])[i];
+        if (!v) continue;
+        const int ln = i & 63, slot = (i >> 6) % FAMW_SLOTS, d = (i >> 6) / FAMW_SLOTS;
+        const int64_t xx = x0 + ln;
+        const int sym = (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M);
+        if (slot < 2 * UVC_NFAM) atomicAdd(&FAP(R, slot / UVC_NFAM, slot % UVC_NFAM, sym, xx), v);
+        else atomicAdd(&FIP(R, slot - 2 * UVC_NFAM, sym, xx), v);
+    }
+    for (int i = threadIdx.x; i < 2 * UVC_NFAMINFO64 * 64; i += 256) {
+        const unsigned long long v = (&a64[0][0][0])[i];
+        if (!v) continue;
+        const int ln = i & 63, f = (i >> 6) % UVC_NFAMINFO64, d = (i >> 6) / UVC_NFAMINFO64;
+        const int64_t xx = x0 + ln;
+        add64(&FI64P(R, f, (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M), xx), (long long)v);
     }
 }
 
@@ -2629,7 +2869,7 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
         // LDS collection removes most of the atomics that bound the per-thread form
         const bool deep = (R->n_generic_work > 8 * R->npos);
         const bool digest = deep && R->fam_digest && P->inferred_is_vcf_generated;   // one walk over the fragments of a unit instead of three
-        if (digest) TIMED(prof, "k_fam_p4", hipLaunchKernelGGL((k_fam_win<4, true>), dim3(nblk(R->npos, 64)), dim3(256), 0, s, *R, *P));
+        if (digest) TIMED(prof, "k_fam_p4", hipLaunchKernelGGL(k_fam_p4d, dim3(nblk(R->npos, 64)), dim3(256), 0, s, *R, *P));
         else if (deep) TIMED(prof, "k_fam_p4", hipLaunchKernelGGL((k_fam_win<4, false>), dim3(nblk(R->npos, 64)), dim3(256), 0, s, *R, *P));
         else TIMED(prof, "k_fam_p4", hipLaunchKernelGGL(k_fam_p4, dim3(nblk(R->n_generic_work, 256)), dim3(256), 0, s, *R, *P));
         if (P->inferred_is_vcf_generated) {
