@@ -77,6 +77,7 @@ struct FsRec {                  // family x strand unit (alns2 of main.hpp:2869)
     int32_t other_fs;           // the opposite-strand unit of the same family, or -1
     int32_t pad_;
 };
+static_assert(sizeof(FsRec) == 64, "k_fam_p4d fetches a unit record as four 16-byte words per lane");
 
 // One P2 update of an InDel read: "add value `val` of symbol `sym` at position `epos` and run dealwith_segbias with these
 // arguments".  The sequential CIGAR walk (k_p2_slow<true>) only produces items; k_p2_items applies them in parallel.

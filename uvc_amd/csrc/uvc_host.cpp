@@ -577,6 +577,7 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
         radix_sort_ids(ord, key);
         std::vector<int32_t> sorted(generic_fs.size()); for (size_t k = 0; k < ord.size(); k++) sorted[k] = generic_fs[ord[k]];
         int32_t *d; if ((rc = upload(r, sorted, &d))) return rc; R.generic_sorted = d; R.max_unit_span = span;
+        if (timing) fprintf(stderr, "[uvcgpu set_reads] %zu fragments, %zu units, %zu generic units, %lld (unit, position) cells, longest unit %d, %lld positions\n", frags.size(), fss.size(), generic_fs.size(), (long long)work, span, (long long)r->npos);
     }
     { std::vector<Contrib> v; Contrib *d = nullptr; const size_t bytes = std::max<int64_t>(table_rows, 1) * sizeof(Contrib);
       if (hipMalloc((void **)&d, bytes) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(table)"); r->owned.push_back(d); R.table = d; r->state_bytes += 0; (void)v; }

@@ -2002,7 +2002,9 @@ struct FamAcc {
 
 // The P4 increments of one (unit, position, symbol type) once the vote consensus (cs = symbol, cc = its votes, ct = all votes) is known
 // (main.hpp:2999-3355); the body of k_fam_win<4> with con[] reduced to what it uses of it.
-DEV void p4_apply(const FamAcc &A, const RegionDev &R, const UvcParams &P, const FsRec &u, int p, int64_t x, int st, int cs, int cc, int ct) {
+// what p4_apply reads of the position alone (thresholds, BAQ prefix sums): loaded once per lane, not once per unit
+struct P4Pos { int LPxT, RPxT, LP1t, LP2t, RP1t, RP2t; long long baq1, baq2; };
+DEV void p4_apply(const FamAcc &A, const RegionDev &R, const UvcParams &P, const FsRec &u, int p, int64_t x, int st, int cs, int cc, int ct, const P4Pos &Q) {
     const int strand = u.strand;
     {
                 const bool is_fam_good = ((P.fam_thres_dup1add <= ct) && (cc * 100 >= ct * P.fam_thres_dup1perc) && ((u.dflag & 0x1) || (P.fam_flag & 0x2)));
@@ -2020,7 +2022,7 @@ DEV void p4_apply(const FamAcc &A, const RegionDev &R, const UvcParams &P, const
                     if (((!isGap) && bq >= P.bias_thres_highBQ) || (isGap && dist >= P.bias_thres_highBQ)) {
                         const bool tier2 = (isGap || bq >= P.bias_thres_highBQ);
                         const int l_nb = (int)nnminus(p + 1, rbeg), r_nb = (int)nnminus(rend, p);
-                        const int _LPxT = TH(R, UVC_T_aLPxT, x), RPxT = TH(R, UVC_T_aRPxT, x);
+                        const int _LPxT = Q.LPxT, RPxT = Q.RPxT;
                         const int LPxT = (isGap ? _LPxT : imin(_LPxT, RPxT));
                         // indel_len = majority COUNT of one inserted sequence among the unit's fragments (main.hpp:3239-3243): the
                         // sequence-keyed maps stay on the host; the number of votes for the symbol is an upper bound that
@@ -2029,7 +2031,7 @@ DEV void p4_apply(const FamAcc &A, const RegionDev &R, const UvcParams &P, const
                         const bool far = (l_nb + (is_ins(cs) ? (int)nnminus(indel_len, P.microadjust_nobias_pos_indel_maxlen) : 0) >= LPxT) && (r_nb >= RPxT);
                         if (far) {
                             int LP1 = 0, LP2 = 0, RP1 = 0, RP2 = 0; long long LPL = 0, RPL = 0;
-                            bidir(LP1, LP2, RP1, RP2, LPL, RPL, TH(R, UVC_T_aLP1t, x), TH(R, UVC_T_aLP2t, x), TH(R, UVC_T_aRP1t, x), TH(R, UVC_T_aRP2t, x), l_nb, r_nb, true, 0);
+                            bidir(LP1, LP2, RP1, RP2, LPL, RPL, Q.LP1t, Q.LP2t, Q.RP1t, Q.RP2t, l_nb, r_nb, true, 0);
                             if (LP1) A.fi(UVC_FI_c2LP1, cs, LP1);
                             if (LP2) A.fi(UVC_FI_c2LP2, cs, LP2);
                             if (RP1) A.fi(UVC_FI_c2RP1, cs, RP1);
@@ -2039,10 +2041,10 @@ DEV void p4_apply(const FamAcc &A, const RegionDev &R, const UvcParams &P, const
                         if ((int)nnminus(p + 1, u.nsb_min) >= P.bias_thres_strict_c2LRP0) A.fi(UVC_FI_c2LP0, cs, 1);
                         if ((int)nnminus(u.nsb_max, p) >= P.bias_thres_strict_c2LRP0) A.fi(UVC_FI_c2RP0, cs, 1);
                         const long long baq_last = R.end - 1;
-                        const int seg_l_baq = (int)(BAQ1(R, p) - BAQ1(R, lmax((long long)rbeg, nnminus(p, MAX_STR_N_BASES))) + 1);
+                        const int seg_l_baq = (int)(Q.baq1 - BAQ1(R, lmax((long long)rbeg, nnminus(p, MAX_STR_N_BASES))) + 1);
                         const long long rr = lmin((long long)rend - 1, lmin((long long)p + MAX_STR_N_BASES, baq_last));
-                        const int _seg_r_baq = (int)(BAQ1(R, rr) - BAQ1(R, p) + 1);
-                        const int seg_r_baq = (isGap ? (int)lmin((long long)_seg_r_baq, BAQ2(R, rr) - BAQ2(R, p) + 7) : _seg_r_baq);
+                        const int _seg_r_baq = (int)(BAQ1(R, rr) - Q.baq1 + 1);
+                        const int seg_r_baq = (isGap ? (int)lmin((long long)_seg_r_baq, BAQ2(R, rr) - Q.baq2 + 7) : _seg_r_baq);
                         const int thres_highBAQ = P.bias_thres_highBAQ + (isGap ? 0 : 3);
                         if (seg_l_baq >= thres_highBAQ && seg_r_baq >= thres_highBAQ) {
                             int LB1 = 0, LB2 = 0, RB1 = 0, RB2 = 0; long long LBL = 0, RBL = 0;
@@ -2320,9 +2322,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     FamAcc A; A.a32 = a32; A.a64 = a64; A.bk = nullptr; A.R = &R; A.x = x; A.lane = lane; A.my_ref = (valid ? (int)R.refsym[x] : 0);
     const int noindel80 = ((valid && x > 0) ? imin(80, imin(RTRP(R, UVC_RTR_indelphred, x - 1), RTRP(R, UVC_RTR_indelphred, x))) : 80);
     const __amdgpu_buffer_rsrc_t rs = bq_rsrc(R);
-    for (int k = lo + wv; k < hi; k += 4) {
-        const FsRec u = R.fss[R.generic_sorted[wave_uniform(k)]];
-        if (u.end <= w0) continue;
+    P4Pos Q = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (valid) { Q.LPxT = TH(R, UVC_T_aLPxT, x); Q.RPxT = TH(R, UVC_T_aRPxT, x); Q.LP1t = TH(R, UVC_T_aLP1t, x); Q.LP2t = TH(R, UVC_T_aLP2t, x); Q.RP1t = TH(R, UVC_T_aRP1t, x); Q.RP2t = TH(R, UVC_T_aRP2t, x);
+                 Q.baq1 = BAQ1(R, p); Q.baq2 = BAQ2(R, p); }
+    // the unit records of this wave, 64 at a time: one per lane, those that reach the window picked by ballot, their fields broadcast --
+    // a unit that ends in front of the window costs no memory round trip of its own
+    for (int kb = lo + wv; kb < hi; kb += 4 * 64) {
+        int ur[16];
+        const int kmine = kb + 4 * lane;
+        if (kmine < hi) {
+            const int4 *q4 = (const int4 *)(R.fss + R.generic_sorted[kmine]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const int4 t = q4[i]; ur[4 * i] = t.x; ur[4 * i + 1] = t.y; ur[4 * i + 2] = t.z; ur[4 * i + 3] = t.w; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) ur[i] = 0;
+        }
+        unsigned long long todo = __ballot(kmine < hi && ur[3] > w0 && ur[2] < w0 + 64);   // FsRec::end, FsRec::beg
+      while (todo) {
+        const int uj = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        FsRec u;
+        u.frag_beg = bcast(ur[0], uj); u.frag_end = bcast(ur[1], uj); u.beg = bcast(ur[2], uj); u.end = bcast(ur[3], uj);
+        u.strand = bcast(ur[4], uj); u.dflag = bcast(ur[5], uj); u.fam = bcast(ur[6], uj); u.generic = bcast(ur[7], uj);
+        u.work_off = (int64_t)(((unsigned long long)(unsigned)bcast(ur[9], uj) << 32) | (unsigned long long)(unsigned)bcast(ur[8], uj));
+        u.l2r_end_median = bcast(ur[10], uj); u.r2l_end_median = bcast(ur[11], uj); u.nsb_min = bcast(ur[12], uj); u.nsb_max = bcast(ur[13], uj);
+        u.other_fs = bcast(ur[14], uj); u.pad_ = 0;
         const bool mine = (valid && p >= u.beg && p < u.end);
         // votes / BQ sums of LINK_M and of A C G T N (registers); the other eight symbols only through the general path
         int cL = 0, mL = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0;
@@ -2420,8 +2445,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
         dst[0] = make_uint4(dga[0], (uint32_t)msum[0], (uint32_t)mtot[0], dga[1]); dst[1] = make_uint4((uint32_t)msum[1], (uint32_t)mtot[1], dg6, 0u);
         for (int vi = 0; vi < 2; vi++) {
             if (0 == vct[vi]) continue;
-            p4_apply(A, R, P, u, p, x, (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL), vcs[vi], vcc[vi], vct[vi]);
+            p4_apply(A, R, P, u, p, x, (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL), vcs[vi], vcc[vi], vct[vi], Q);
         }
+      }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * FAMW_SLOTS * 64; i += 256) {
