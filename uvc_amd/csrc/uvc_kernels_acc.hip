@@ -2105,9 +2105,28 @@ __global__ void __launch_bounds__(256) k_fam_win(RegionDev R, UvcParams P) {
     FamAcc A; A.a32 = a32; A.a64 = a64; A.bk = (int (*)[2][NBUCKETS][64])bk; A.R = &R; A.x = x; A.lane = lane; A.my_ref = (valid ? (int)R.refsym[x] : 0);
     const LdsCounts<64> con = { &con_s[(PASS == 5 && DG) ? 0 : wv][0][(PASS == 5 && DG) ? 0 : lane] }, mmm = { &mmm_s[((PASS == 5) != DG) ? wv : 0][0][((PASS == 5) != DG) ? lane : 0] };
     const bool padded_ignored_w = (P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0;
-    for (int k = lo + wv; k < hi; k += 4) {
-        const FsRec u = R.fss[R.generic_sorted[wave_uniform(k)]];
-        if (u.end <= w0) continue;
+    // the unit records of this wave, 64 at a time: one per lane, those that reach the window picked by ballot (see k_fam_p4d)
+    for (int kb = lo + wv; kb < hi; kb += 4 * 64) {
+        int ur[16];
+        const int kmine = kb + 4 * lane;
+        if (kmine < hi) {
+            const int4 *q4 = (const int4 *)(R.fss + R.generic_sorted[kmine]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const int4 t = q4[i]; ur[4 * i] = t.x; ur[4 * i + 1] = t.y; ur[4 * i + 2] = t.z; ur[4 * i + 3] = t.w; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) ur[i] = 0;
+        }
+        unsigned long long todo = __ballot(kmine < hi && ur[3] > w0 && ur[2] < w0 + 64);
+      while (todo) {
+        const int uj = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        FsRec u;
+        u.frag_beg = bcast(ur[0], uj); u.frag_end = bcast(ur[1], uj); u.beg = bcast(ur[2], uj); u.end = bcast(ur[3], uj);
+        u.strand = bcast(ur[4], uj); u.dflag = bcast(ur[5], uj); u.fam = bcast(ur[6], uj); u.generic = bcast(ur[7], uj);
+        u.work_off = (int64_t)(((unsigned long long)(unsigned)bcast(ur[9], uj) << 32) | (unsigned long long)(unsigned)bcast(ur[8], uj));
+        u.l2r_end_median = bcast(ur[10], uj); u.r2l_end_median = bcast(ur[11], uj); u.nsb_min = bcast(ur[12], uj); u.nsb_max = bcast(ur[13], uj);
+        u.other_fs = bcast(ur[14], uj); u.pad_ = 0;
         if (!(valid && p >= u.beg && p < u.end)) continue;
         const int strand = u.strand;
         if (PASS == 4) {
@@ -2244,6 +2263,7 @@ __global__ void __launch_bounds__(256) k_fam_win(RegionDev R, UvcParams P) {
                 }
             }
         }
+      }
     }
     __syncthreads();
     // one add per non-zero (field, dense symbol, position) of the window
