@@ -210,6 +210,7 @@ class Region:
         if capacity is None:
             npos = (pos_end - pos_beg) if pos_beg >= 0 else self.npos
             capacity = 14 * (npos + 1) if all_out else max(4096, 4 * (npos + 1))
+        capacity = max(capacity, getattr(self, "_score_cap", 0))   # a handle that needed a larger buffer once asks for it at once the next time
         while True:
             buf = getattr(self, "_score_buf", None)   # reused across calls: the library fills n_records columns of every row
             if buf is None or buf.shape[1] != capacity:
@@ -217,7 +218,7 @@ class Region:
             out = _ffi.UvcScoreOut(capacity, 0, buf.ctypes.data)
             rc = self.lib.call("score", self.h, C.byref(req), C.byref(out))
             if rc == -6 and out.n_records > capacity:
-                capacity = int(out.n_records)
+                capacity = self._score_cap = int(out.n_records) + int(out.n_records) // 8
                 continue
             self._check(rc)
             # copy=False returns views into the handle's reusable buffer (valid until the next score() call)
