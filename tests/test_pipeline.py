@@ -133,5 +133,12 @@ def test_native_command_line_equals_the_python_chain(tmp_path, gpu_lib):
         a, b = gzip.open(out_c, "rt").read().splitlines(), gzip.open(out_py, "rt").read().splitlines()
         assert [l for l in a if not l.startswith("##")] == [l for l in b if not l.startswith("##")]
         assert len([l for l in a if not l.startswith("#") and "ANY_VAR" in l]) >= 5
+    # -R regions.bed: the same three tiles as BED lines
+    bed = str(tmp_path / "r.bed")
+    open(bed, "w").write("# comment\n" + "".join("chrT\t%d\t%d\n" % (b0 + k, b0 + k + 2000) for k in (0, 2000, 4000)))
+    out_b = str(tmp_path / "b.vcf.gz")
+    r = subprocess.run([exe, bam, "-f", fa, "-o", out_b, "-s", "T1", "-R", bed, "-t", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert gzip.open(out_b, "rt").read() == gzip.open(out_c, "rt").read()
     r = subprocess.run([exe, bam, "-f", fa, "-o", out_c, "--no-such-option"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "unknown option" in r.stderr

@@ -24,7 +24,7 @@ namespace {
 const int32_t MAX_INSERT_SIZE = 2000, MAX_STR_N_BASES = 100;   // common.hpp:63-64
 
 struct Opts {
-    std::string bam, fasta, out, sample = "-", targets;
+    std::string bam, fasta, out, sample = "-", targets, bed;
     int threads = 2, device = 0, outvar_flag = -1, repeat = 1;
     int64_t tile = 1000000;
     bool all_out = false, timing = false;
@@ -32,7 +32,7 @@ struct Opts {
 };
 [[noreturn]] void die(const std::string &m) { fprintf(stderr, "uvc1-mi355x: %s\n", m.c_str()); exit(2); }
 void usage() {
-    fprintf(stderr, "usage: uvc1-mi355x inputBAM -f ref.fa -o out.vcf.gz [-s sample] [--targets chr[:beg-end]] [-t threads] [-A] [-q vqual]\n"
+    fprintf(stderr, "usage: uvc1-mi355x inputBAM -f ref.fa -o out.vcf.gz [-s sample] [--targets chr[:beg-end] | -R regions.bed] [-t threads] [-A] [-q vqual]\n"
                     "                   [--outvar-flag bits] [--tile bp] [--device id] [--timing]\n");
 }
 Opts parse(int argc, char **argv) {
@@ -44,6 +44,7 @@ Opts parse(int argc, char **argv) {
         else if (a == "-o" || a == "--output") o.out = val();
         else if (a == "-s" || a == "--sample") o.sample = val();
         else if (a == "--targets") o.targets = val();
+        else if (a == "-R" || a == "--regions-file") o.bed = val();
         else if (a == "-t" || a == "--threads") o.threads = std::max(1, atoi(val().c_str()));
         else if (a == "-A" || a == "--all-out") o.all_out = true;
         else if (a == "-q" || a == "--vqual") o.vqual = atof(val().c_str());
@@ -157,7 +158,20 @@ int main(int argc, char **argv) {
     // the tiles: --targets "chr" or "chr:beg-end" (1-based inclusive as in samtools), else every contig
     std::vector<Tile> tiles;
     auto add = [&](int32_t tid, int64_t beg, int64_t end) { for (int64_t b = beg; b < end; b += o.tile) tiles.push_back(Tile{ tid, names[(size_t)tid], b, std::min(b + o.tile, end) }); };
-    if (!o.targets.empty()) {
+    if (!o.bed.empty()) {   // -R: one region per BED line (0-based, half-open), cut into tiles; overrides --targets as in the reference
+        FILE *fb = fopen(o.bed.c_str(), "r");
+        if (!fb) die("cannot open " + o.bed);
+        char line[4096], chrom[1024]; long long b = 0, e = 0;
+        while (fgets(line, sizeof(line), fb)) {
+            if (line[0] == '#' || !strncmp(line, "track", 5) || !strncmp(line, "browser", 7)) continue;
+            if (sscanf(line, "%1023s %lld %lld", chrom, &b, &e) != 3) continue;
+            int32_t tid = -1;
+            for (int32_t i = 0; i < nref; i++) if (names[(size_t)i] == chrom) tid = i;
+            if (tid < 0) die(std::string("the BED file names a contig that is not in the BAM header: ") + chrom);
+            add(tid, std::max<long long>(0, b), std::min<long long>(e, lens[(size_t)tid]));
+        }
+        fclose(fb);
+    } else if (!o.targets.empty()) {
         std::string chrom = o.targets; int64_t beg = 0, end = -1;
         const size_t c = o.targets.rfind(':');
         if (c != std::string::npos && o.targets.find('-', c) != std::string::npos) {
