@@ -263,3 +263,27 @@ def test_vcf_records_need_the_planes(gpu_lib):
     rg = Rg.score(release_state=True)
     with pytest.raises(region.UvcError):
         Rg.vcf_records("chr20", rg)
+
+
+@pytest.mark.gpu
+def test_record_lines_of_a_sub_range_and_of_thin_data(gpu_lib):
+    """Scoring and writing a sub-range gives exactly the record lines of the full run that lie in it; a region with almost no reads
+    writes position-level lines only (or nothing) without failing."""
+    reads = synth.generate_region(region_len=6000, depth=80, seed=77)
+    Rg = run_region(gpu_lib, reads)
+    sym = ("<NON_REF>", "<ADDITIONAL_INDEL_CANDIDATE>")
+    full = [l for l in Rg.vcf_records("c", Rg.score()).splitlines() if l.split("\t")[4] not in sym]
+    lo, hi = reads["beg"] + 1500, reads["beg"] + 4200
+    part_rec = Rg.score(pos_beg=lo, pos_end=hi)
+    part = [l for l in Rg.vcf_records("c", part_rec, pos_beg=lo, pos_end=hi).splitlines() if l.split("\t")[4] not in sym]
+    def zpos(l):   # the zerobased_pos iteration that wrote the line: SNV lines carry refpos + 1 = zpos, InDel lines refpos = zpos
+        return int(l.split("\t")[1])
+    want = [l for l in full if lo < zpos(l) < hi or (zpos(l) == lo and len(l.split("\t")[3]) != len(l.split("\t")[4]))]
+    assert len(part) >= 3 and set(part) <= set(full)
+    assert [l for l in part if lo + 1 < zpos(l) < hi - 1] == [l for l in want if lo + 1 < zpos(l) < hi - 1]
+    thin = synth.generate_region(region_len=2500, depth=2, seed=5)
+    Rt = run_region(gpu_lib, thin)
+    rec = Rt.score()
+    lines = Rt.vcf_records("c", rec).splitlines()
+    assert all(len(l.split("\t")) == 10 for l in lines)
+    assert sum(1 for l in lines if l.split("\t")[4] not in sym) == int(rec["keep"].sum())
