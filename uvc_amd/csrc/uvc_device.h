@@ -152,6 +152,7 @@ struct RegionDev {
     FsRec *fss; int32_t n_fs;
     const int32_t *generic_fs; int32_t n_generic_fs; int64_t n_generic_work;
     const int32_t *generic_sorted; int32_t max_unit_span;   // the generic units ordered by FsRec::beg (window kernels k_fam_win)
+    uint8_t *p5flag;                // [2][npos]: a P5 bucket of this (strand, position) was filled
     uint32_t *fam_digest;           // [n_generic_work][8] or NULL: what P4 leaves per (unit, position) for P5 and the duplex pass (k_fam_win<4> / k_fam_win5d / k_duplex_d)
     Contrib *table;
     Item *items; int32_t *item_cnt;     // per complex alignment (indexed like complex_ids)

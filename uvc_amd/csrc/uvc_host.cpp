@@ -61,6 +61,7 @@ struct uvcgpu_region {
     int32_t *d_dup_units = nullptr; int64_t *d_dup_off = nullptr; int n_dup = 0; int64_t n_dup_work = 0;
     size_t off[UVC_NUM_FIELD_GROUPS + 1];
     bool has_reads = false, accumulated = false;
+    size_t p5flag_off = 0;
     bool state_released = false, state_zeroed = false;   // UvcScoreRequest::release_state: planes given up / already zeroed on the side stream (e_join marks the end)
     RawReads W;                  // per-read input columns on the device (kept: uvcgpu_region_correct_bq re-derives the per-read records)
     int32_t *d_p2[4] = { nullptr, nullptr, nullptr, nullptr };   // P2 work list: alignment, begin, end, query offset
@@ -284,6 +285,7 @@ static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t 
     const int order[] = { UVC_F_PREP64, UVC_F_SEG64, UVC_F_FAMINFO64, UVC_F_PREP32, UVC_F_THRES, UVC_F_SEG32, UVC_F_VQ, UVC_F_BQSUM, UVC_F_FRAG, UVC_F_FAM, UVC_F_FAMINFO32, UVC_F_DUPLEX };
     size_t o = 0;
     for (int g : order) { r->off[g] = o; o += group_bytes(r, g); }
+    r->p5flag_off = o; o += ((size_t)2 * r->npos + 255) & ~(size_t)255;   // one byte per (strand, position): a P5 bucket was filled (k_p5b skips the others); zeroed with the planes
     r->bucket_off = o; o += (size_t)4 * r->npos * 2 * NSYM * NBUCKETS;
     r->state_bytes = o;
     if (r->npos > r->npos_cap) {
@@ -308,7 +310,7 @@ static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t 
     R.prep32 = (int32_t *)(b + r->off[UVC_F_PREP32]); R.thres = (int32_t *)(b + r->off[UVC_F_THRES]); R.seg32 = (int32_t *)(b + r->off[UVC_F_SEG32]);
     R.vq = (int32_t *)(b + r->off[UVC_F_VQ]); R.bqsum = (int32_t *)(b + r->off[UVC_F_BQSUM]); R.frag = (int32_t *)(b + r->off[UVC_F_FRAG]);
     R.fam = (int32_t *)(b + r->off[UVC_F_FAM]); R.faminfo32 = (int32_t *)(b + r->off[UVC_F_FAMINFO32]); R.duplex = (int32_t *)(b + r->off[UVC_F_DUPLEX]);
-    R.bucket = (int32_t *)(b + r->bucket_off);
+    R.bucket = (int32_t *)(b + r->bucket_off); R.p5flag = (uint8_t *)(b + r->p5flag_off);
     R.err = d_err;
     HIP_OK(hipMemsetAsync(d_err, 0, 4, r->stream));
     HIP_OK(hipStreamSynchronize(r->stream));   // the staging vectors above die here

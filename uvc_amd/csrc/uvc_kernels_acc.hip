@@ -1980,7 +1980,7 @@ __global__ void __launch_bounds__(256) k_fam_p5(RegionDev R, UvcParams P) {
         const int confam_qual2 = imin(confam_qual, max_qual);
         if (tot_nfrags >= P.fam_thres_dup1add) {
             const int pbucket = (max_qual - confam_qual2 + 2) / 4;
-            if (pbucket >= 0 && pbucket < NBUCKETS) atomicAdd(&BKP(R, strand, cs, pbucket, x), 1);
+            if (pbucket >= 0 && pbucket < NBUCKETS) { atomicAdd(&BKP(R, strand, cs, pbucket, x), 1); R.p5flag[(size_t)strand * R.npos + x] = 1; }
         }
     }
 }
@@ -1997,7 +1997,7 @@ struct FamAcc {
     DEV void fap(int strand, int f, int cs, int v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a32[d][strand * UVC_NFAM + f][lane], v); else atomicAdd(&FAP(*R, strand, f, cs, x), v); }
     DEV void fi(int f, int cs, int v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a32[d][2 * UVC_NFAM + f][lane], v); else atomicAdd(&FIP(*R, f, cs, x), v); }
     DEV void fi64(int f, int cs, long long v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a64[d][f][lane], (unsigned long long)v); else add64(&FI64P(*R, f, cs, x), v); }
-    DEV void bucket(int strand, int cs, int b) const { const int d = dense(cs); if (d >= 0) atomicAdd(&bk[d][strand][b][lane], 1); else atomicAdd(&BKP(*R, strand, cs, b, x), 1); }
+    DEV void bucket(int strand, int cs, int b) const { const int d = dense(cs); if (d >= 0) atomicAdd(&bk[d][strand][b][lane], 1); else atomicAdd(&BKP(*R, strand, cs, b, x), 1); R->p5flag[(size_t)strand * R->npos + x] = 1; }
 };
 
 // The P4 increments of one (unit, position, symbol type) once the vote consensus (cs = symbol, cc = its votes, ct = all votes) is known
@@ -2552,6 +2552,7 @@ __global__ void __launch_bounds__(256) k_duplex_d(RegionDev R, const int32_t *du
 __global__ void __launch_bounds__(256) k_p5b(RegionDev R, UvcParams P) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= R.npos * 2) return;
+    if (!R.p5flag[t]) return;   // no P5 bucket was filled at this (strand, position): every output is 0 (the flag index is strand * npos + x)
     const int strand = (int)(t / R.npos);
     const int64_t x = t % R.npos;
     const int qIAQ = (strand ? UVC_VQ_cIAQr : UVC_VQ_cIAQf), qIAD = (strand ? UVC_VQ_cIADr : UVC_VQ_cIADf), qIDQ = (strand ? UVC_VQ_cIDQr : UVC_VQ_cIDQf);
