@@ -366,6 +366,10 @@ int uvcgpu_vcf_header(const UvcParams *params, const char *sample_name, const ch
  * and the ADDITIONAL_INDEL_CANDIDATE lines (main.cpp:759-799) of the range are written in front of the records of their position. */
 int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *contig_name, const UvcScoreOut *scored, int32_t pos_beg, int32_t pos_end,
                               const UvcTumorKey *tumor_keys, int64_t n_tumor_keys, char *dst, int64_t capacity, int64_t *len);
+/* Optional: page-lock a caller buffer that is handed to the library again and again (the records buffer of uvcgpu_region_score, read
+ * arrays of uvcgpu_region_set_reads): copies then run at PCIe speed.  Unpin before freeing the buffer. */
+int uvcgpu_pin_host_buffer(void *p, int64_t bytes);
+int uvcgpu_unpin_host_buffer(void *p);
 int uvcgpu_region_sync(uvcgpu_region_t *r);
 /* Measurement hooks (bench.py): HIP-event timing of every kernel of the LAST accumulate, recorded on the handle's stream.
  * kernel_times returns the number of kernels; `names` receives their names separated by ';'. */

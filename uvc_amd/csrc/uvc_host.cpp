@@ -813,6 +813,21 @@ int uvcgpu_region_block_stats_(uvcgpu_region_t *r, int32_t refpos_beg, int32_t r
     if (e != hipSuccess) return fail(UVCGPU_EDEVICE, hipGetErrorString(e));
     return 0;
 }
+// Page-locks a caller buffer (the records buffer of uvcgpu_region_score, the read arrays of uvcgpu_region_set_reads) so that copies to
+// and from it run at PCIe speed instead of through the runtime's staging buffers.  Optional; the buffer must be unpinned before it is freed.
+int uvcgpu_pin_host_buffer(void *p, int64_t bytes) {
+    if (!p || bytes <= 0) return fail(UVCGPU_EINVAL, "bad argument");
+    hipError_t e = hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(UVCGPU_EDEVICE, std::string("hipHostRegister: ") + hipGetErrorString(e)); }
+    return 0;
+}
+int uvcgpu_unpin_host_buffer(void *p) {
+    if (!p) return 0;
+    hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(UVCGPU_EDEVICE, std::string("hipHostUnregister: ") + hipGetErrorString(e)); }
+    return 0;
+}
+
 // what uvc_vcf.cpp reads of a handle besides the public calls
 const char *uvcgpu_region_refseq(const uvcgpu_region_t *r, int32_t *beg, int32_t *end) { if (beg) *beg = r->beg; if (end) *end = r->end - 1; return r->refstring.c_str(); }
 const int32_t *uvcgpu_region_repeat_tracks(const uvcgpu_region_t *r, int64_t *npos) { if (npos) *npos = r->npos; return r->h_rtr.data(); }

@@ -143,6 +143,7 @@ class Region:
             fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p]
             self._check(fn(self.h, tid, beg, end, ref))
         self.tid, self.beg, self.end, self.npos = tid, beg, end, end - beg + 1
+        self._unpin_score_buf()
         self._score_buf = None
 
     def set_reads(self, reads):
@@ -214,7 +215,12 @@ class Region:
         while True:
             buf = getattr(self, "_score_buf", None)   # reused across calls: the library fills n_records columns of every row
             if buf is None or buf.shape[1] != capacity:
+                self._unpin_score_buf()
                 buf = self._score_buf = np.empty((_ffi.NUM_SCORE_FIELDS, capacity), dtype=np.int32)
+                pin = getattr(self.lib.dll, self.lib.prefix + "pin_host_buffer", None)   # page-locked: the D2H of the records runs at PCIe speed
+                if pin is not None:
+                    pin.restype, pin.argtypes = C.c_int, [C.c_void_p, C.c_int64]
+                    self._score_buf_pinned = (pin(buf.ctypes.data, buf.nbytes) == 0)
             out = _ffi.UvcScoreOut(capacity, 0, buf.ctypes.data)
             rc = self.lib.call("score", self.h, C.byref(req), C.byref(out))
             if rc == -6 and out.n_records > capacity:
@@ -261,7 +267,16 @@ class Region:
         self._check(fn(self.h, contig_name.encode(), C.byref(so), pos_beg, pos_end, tk, ntk, dst, ln.value, C.byref(ln)))
         return dst.raw[:ln.value].decode()
 
+    def _unpin_score_buf(self):
+        if getattr(self, "_score_buf_pinned", False) and getattr(self, "_score_buf", None) is not None:
+            fn = getattr(self.lib.dll, self.lib.prefix + "unpin_host_buffer")
+            fn.restype, fn.argtypes = C.c_int, [C.c_void_p]
+            fn(self._score_buf.ctypes.data)
+        self._score_buf_pinned = False
+
     def close(self):
+        self._unpin_score_buf()
+        self._score_buf = None
         if self.h:
             self.lib.call("destroy", self.h)
             self.h = C.c_void_p()
