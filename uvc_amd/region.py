@@ -10,6 +10,7 @@
 gfx950); there is NO CPU fallback here -- `gpu_lib()` raises when the extension is missing.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -218,7 +219,7 @@ class Region:
                 self._unpin_score_buf()
                 buf = self._score_buf = np.empty((_ffi.NUM_SCORE_FIELDS, capacity), dtype=np.int32)
                 pin = getattr(self.lib.dll, self.lib.prefix + "pin_host_buffer", None)   # page-locked: the D2H of the records runs at PCIe speed
-                if pin is not None:
+                if pin is not None and not os.environ.get("UVC_NO_PIN"):
                     pin.restype, pin.argtypes = C.c_int, [C.c_void_p, C.c_int64]
                     self._score_buf_pinned = (pin(buf.ctypes.data, buf.nbytes) == 0)
             out = _ffi.UvcScoreOut(capacity, 0, buf.ctypes.data)
