@@ -77,9 +77,26 @@ void pos2pcenter(std::vector<int> &center, const std::vector<int> &count, double
         }
     }
 }
+
+// MolecularBarcode::createKey (MolecularID.hpp:20-52) with the strings replaced by their hash pairs (an absent UMI is the empty string: 0, 0)
+typedef std::tuple<int, int, int, int, u64, u64, u64, u64, int, int> Key;
+Key molecular_key(int begtid, int beg, int endtid, int end, u64 q31, u64 q17, u64 u31, u64 u17, int dflag, int idflag) {
+    std::pair<int, int> bp(begtid, beg), ep(endtid, end), kb(-1, -1), ke(-1, -1);
+    if (0x3 == (0x3 & idflag)) { kb = std::min(bp, ep); ke = std::max(bp, ep); }
+    else if (0x1 & idflag) kb = bp;
+    else if (0x2 & idflag) ke = ep;
+    return Key(kb.first, kb.second, ke.first, ke.second, (0x4 & idflag) ? q31 : 0, (0x4 & idflag) ? q17 : 0, (0x8 & idflag) ? u31 : 0, (0x8 & idflag) ? u17 : 0, dflag, idflag);
+}
 }  // namespace
 
 extern "C" {
+// the family key as ten 64-bit values (test hook: checked against the reference's createKey / operator< in tests/test_ref_molid.py)
+void uvc_oracle_molecular_key(int begtid, int beg, int endtid, int end, uint64_t q31, uint64_t q17, uint64_t u31, uint64_t u17, int dflag, int idflag, int64_t *out10) {
+    const Key k = molecular_key(begtid, beg, endtid, end, q31, q17, u31, u17, dflag, idflag);
+    out10[0] = std::get<0>(k); out10[1] = std::get<1>(k); out10[2] = std::get<2>(k); out10[3] = std::get<3>(k);
+    out10[4] = (int64_t)std::get<4>(k); out10[5] = (int64_t)std::get<5>(k); out10[6] = (int64_t)std::get<6>(k); out10[7] = (int64_t)std::get<7>(k);
+    out10[8] = std::get<8>(k); out10[9] = std::get<9>(k);
+}
 
 void uvc_oracle_group_params_default(UvcGroupParams *p) {
     memset(p, 0, sizeof(*p));
@@ -144,7 +161,6 @@ int uvc_oracle_group_families(const UvcGroupParams *Pp, const UvcGroupInput *in,
         pos2pcenter(b2c[c], begc[c], P.dedup_center_mult);
         pos2pcenter(e2c[c], endc[c], P.dedup_center_mult);
     }
-    typedef std::tuple<int, int, int, int, u64, u64, u64, u64, int, int> Key;   // createKey'd MolecularBarcode (MolecularID.hpp:20-52)
     struct Fam { std::array<std::map<u64, std::vector<int64_t>>, 2> strands; int dflag, idflag; };
     std::map<Key, Fam> fams;
     out->extended_inclu_beg_pos = INT32_MAX; out->extended_exclu_end_pos = 0; out->n_amplicon = 0;
@@ -189,12 +205,7 @@ int uvc_oracle_group_families(const UvcGroupParams *Pp, const UvcGroupInput *in,
         const int end3 = (preserved ? in->mpos[i] : (end2 - ARRPOS_MARGIN + P.fetch_tbeg));
         const int strand = (((flag & 0x81) == 0x81) ? ((flag & 0x20) != 0) : ((flag & 0x10) != 0));
         const int dflag = (is_umi_found ? 0x1 : 0) + (is_duplex_found ? 0x2 : 0) + (amplicon ? 0x4 : 0) + (preserved ? 0x8 : 0);
-        std::pair<int, int> bp(begtid, beg3), ep(endtid, end3), kb(-1, -1), ke(-1, -1);
-        if (0x3 == (0x3 & idflag)) { kb = std::min(bp, ep); ke = std::max(bp, ep); }
-        else if (0x1 & idflag) kb = bp;
-        else if (0x2 & idflag) ke = ep;
-        const Key key(kb.first, kb.second, ke.first, ke.second, (0x4 & idflag) ? in->qname_hash31[i] : 0, (0x4 & idflag) ? in->qname_hash17[i] : 0,
-                      ((0x8 & idflag) && is_umi_found) ? in->umi_hash31[i] : 0, ((0x8 & idflag) && is_umi_found) ? in->umi_hash17[i] : 0, dflag, idflag);
+        const Key key = molecular_key(begtid, beg3, endtid, end3, in->qname_hash31[i], in->qname_hash17[i], is_umi_found ? in->umi_hash31[i] : 0, is_umi_found ? in->umi_hash17[i] : 0, dflag, idflag);
         Fam &f = fams[key];
         f.dflag = dflag; f.idflag = idflag;
         f.strands[strand][in->qname_hash17[i]].push_back(i);
