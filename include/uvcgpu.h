@@ -250,6 +250,7 @@ typedef struct UvcIndelAllele {
     int32_t indel_len;  /* indelstring.size(),                  main.cpp:907 */
 } UvcIndelAllele;
 
+enum { UVC_MGVCF_SYMBOL = 15, UVC_ADDITIONAL_INDEL_CANDIDATE_SYMBOL = 16 };   /* main_conversion.hpp: the VTI of the two position-level line types */
 /* One tumor-sample record of the T/N channel (TumorKeyInfo, main_conversion.hpp:490-529), reduced to what the scoring functions read:
  * tpfa of calc_DPv = (cDP1x + 1) / (CDP1x + 2) (main.cpp:935), tpfa of calc_qual = (bDP + 0.5) / (BDP + 1) (main.cpp:985-986),
  * enable_tier2_consensus_format_tags (main.hpp:4475), and for InDels the length of the tumor record's inserted / deleted string
@@ -290,7 +291,16 @@ typedef struct UvcScoreRequest {
     int32_t release_state;      /* 1: the caller is done with the planes of this region after this call (no further score / fetch until the next
                                  * accumulate, which return UVCGPU_ESTATE): the library zeroes them for the next accumulate while the records
                                  * travel to the host, instead of in front of the next accumulate's kernels */
+    int32_t base_at_pos_beg;    /* 0: as process_batch at the start of a region, the BASE sub-position of pos_beg (refpos pos_beg - 1) is not
+                                 * scored (main.cpp:643).  1: it is -- for a region that continues an adjacent one whose last zerobased_pos was
+                                 * pos_beg - 1 (fixed tiles of one covered stretch): a run of such tiles then yields each (position, symbol type)
+                                 * exactly once, the records of one uncut region.  Needs pos_beg > region begin */
+    int32_t region_beg;         /* incluBegPosition of the BED line this region belongs to (main.cpp:655-656): besides every refpos that is a
+                                 * multiple of 1000 an MGVCF block also opens at refpos == region_beg.  0 = nothing beyond the multiples */
     int32_t reserved_;
+    const char *const *tumor_sample_columns;   /* [n_tumor_keys] or NULL: the sample column of each tumor record as text.  Only the record writer reads
+                                 * it: with is_tumor_format_retrieved the normal-sample line ends with the tumor's column (bcf1_to_string,
+                                 * main.hpp:5897-5910, 6269; MGVCF / ADDITIONAL_INDEL_CANDIDATE lines: main.cpp:739-757, 784-798) */
 } UvcScoreRequest;
 
 typedef struct UvcScoreOut {
@@ -305,6 +315,8 @@ typedef struct uvcgpu_region uvcgpu_region_t;
 /* Once per host thread / process.  Fails with UVCGPU_EDEVICE when there is no gfx950 device:
  * there is no CPU fallback inside this library. */
 int uvcgpu_init(int device_id);
+/* Number of HIP devices visible to the process (0 when there is none); the region-shard dispatchers spread their workers over them. */
+int uvcgpu_device_count(void);
 const char *uvcgpu_last_error(void);
 const char *uvcgpu_version(void);
 
@@ -357,15 +369,18 @@ int uvcgpu_region_fetch_columns(uvcgpu_region_t *r, const int32_t *refpos, int64
  * bHap / cHap / c2Hap (always "."), FORMAT/note and the GERMLINE lines of output_germline.
  * Both return UVCGPU_ENOMEM with *len = the size needed when `capacity` is too small. */
 const char *uvcgpu_vcf_format_keys(int32_t with_tier2_consensus_tags);
-int uvcgpu_vcf_header(const UvcParams *params, const char *sample_name, const char *const *contig_names, const int64_t *contig_lens,
-                      int32_t n_contigs, char *dst, int64_t capacity, int64_t *len);
+/* tumor_sample_name: NULL, or -- for the normal sample of a T/N pair with is_tumor_format_retrieved -- the name of the tumor VCF's sample,
+ * which becomes a second sample column of the #CHROM line (generate_vcf_header, main.hpp:5785, 5881) */
+int uvcgpu_vcf_header(const UvcParams *params, const char *sample_name, const char *tumor_sample_name, const char *const *contig_names,
+                      const int64_t *contig_lens, int32_t n_contigs, char *dst, int64_t capacity, int64_t *len);
 /* `scored` is what uvcgpu_region_score filled for this region (all records, in order: the REF record of a position supplies the first
  * value of every Number=R tag); the lines of the records with out != 0 and keep != 0 are written.  The planes must not have been
- * released (UvcScoreRequest::release_state = 0).  `tumor_keys` as in the score request (NULL for a tumor-only sample).
- * [pos_beg, pos_end) is the zerobased_pos range of that score request (-1 = its default): the MGVCF block lines (OUTVAR_MGVCF, main.cpp:655-735)
- * and the ADDITIONAL_INDEL_CANDIDATE lines (main.cpp:759-799) of the range are written in front of the records of their position. */
-int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *contig_name, const UvcScoreOut *scored, int32_t pos_beg, int32_t pos_end,
-                              const UvcTumorKey *tumor_keys, int64_t n_tumor_keys, char *dst, int64_t capacity, int64_t *len);
+ * released (UvcScoreRequest::release_state = 0).  `req` is the request of that score call (NULL = its defaults): its tumor_keys (normal
+ * sample of a T/N pair), and its zerobased_pos range [pos_beg, pos_end), base_at_pos_beg and region_beg for the MGVCF block lines
+ * (OUTVAR_MGVCF, main.cpp:655-735) and the ADDITIONAL_INDEL_CANDIDATE lines (main.cpp:759-799), which are written in front of the
+ * records of their position. */
+int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *contig_name, const UvcScoreOut *scored, const UvcScoreRequest *req,
+                              char *dst, int64_t capacity, int64_t *len);
 /* Optional: page-lock a caller buffer that is handed to the library again and again (the records buffer of uvcgpu_region_score, read
  * arrays of uvcgpu_region_set_reads): copies then run at PCIe speed.  Unpin before freeing the buffer. */
 int uvcgpu_pin_host_buffer(void *p, int64_t bytes);

@@ -11,6 +11,7 @@
 #define UVCIO_H
 #include <stddef.h>
 #include <stdint.h>
+#include "uvcgpu.h"   /* UvcTumorKey, UVCGPU_E* */
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -70,6 +71,37 @@ typedef struct UvcRegionCut { int32_t tid, beg, end, flag, batch; int64_t n_read
 int uvcio_plan_regions(const int32_t *tid, const int32_t *pos, const int32_t *endpos, const uint16_t *flag, int64_t n,
                        const int64_t *target_len, int32_t n_targets, int32_t nthreads, int64_t mem_per_thread_mb,
                        UvcRegionCut *out, int64_t capacity, int64_t *n_out);
+
+/* ---- the tumor VCF of a T/N pair: rescue_variants_from_vcf, main.cpp:183-398 ----
+ * Reads the (block-gzipped or plain) VCF the tumor pass wrote and turns every record into the integers the normal pass reads:
+ * key (contig, symbolpos, VTI[1]) with symbolpos = POS - 1 for substitutions / MGVCF block / ADDITIONAL_INDEL_CANDIDATE lines and POS for
+ * InDels (main.cpp:279), FORMAT BDPb, bDPf, bDPr, CDP1x, cDP1x, cVQ1, cPCQ1, CDP2x, cDP2x, cVQ2, cPCQ2, bNMQ, vHGQ, CDP1b, cDP1f, cDP1r,
+ * CDP2b (main.cpp:294-372), the presence of _C2XP (:386-388) and the length of the inserted / deleted string (REF / ALT, main.cpp:867-880).
+ * Lines with a symbolic ALT other than <NON_REF> / <ADDITIONAL_INDEL_CANDIDATE> are skipped, and those two as well unless
+ * is_tumor_format_retrieved (main.cpp:265-272); lines without FORMAT/VTI are skipped (:275).  The reference reads through htslib's synced
+ * reader restricted to the regions of the batch; here the file is read once and queried per region.
+ * `contig_names` maps CHROM to tid (the BAM header's order). */
+typedef struct uvcio_tumor_vcf uvcio_tumor_vcf_t;
+int uvcio_tumor_vcf_open(uvcio_tumor_vcf_t **out, const char *path, const char *const *contig_names, int32_t n_contigs, int32_t is_tumor_format_retrieved);
+const char *uvcio_tumor_vcf_sample_name(const uvcio_tumor_vcf_t *v);   /* last column of the #CHROM line ("" if there is none) */
+int64_t uvcio_tumor_vcf_n_records(const uvcio_tumor_vcf_t *v);
+/* The records of `tid` with pos_beg <= symbolpos <= pos_end, sorted by (symbolpos, symbol) -- tkis_beg .. tkis_end of main.cpp:532-533 --
+ * as UvcScoreRequest::tumor_keys / tumor_sample_columns take them.  The arrays belong to the handle (valid until it is closed). */
+int uvcio_tumor_vcf_fetch(const uvcio_tumor_vcf_t *v, int32_t tid, int32_t pos_beg, int32_t pos_end, const UvcTumorKey **keys, const char *const **sample_columns, int64_t *n);
+void uvcio_tumor_vcf_close(uvcio_tumor_vcf_t *v);
+
+/* ---- region shards ----
+ * The reference balances its chunks by reads and positions (main.cpp:1380-1400).  Without reading the alignments the cost of a tile is
+ * estimated from the BAI linear index: the compressed bytes between the 16 kb windows that hold its two ends (0 without an index). */
+int64_t uvcio_bam_region_bytes(const uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t end);
+/* Cuts an ordered list of n tiles with the given costs into n_shards contiguous runs of about equal total cost: shard_of[i] is
+ * non-decreasing in i, so that the outputs of the shards, concatenated in shard order, are in tile order (uvcTN.sh:92-101 does the
+ * same per chromosome with bcftools concat).  A tile goes to the shard that holds the midpoint of its cost interval. */
+int uvcio_plan_shards(const int64_t *cost, int64_t n, int32_t n_shards, int32_t *shard_of);
+/* bcftools concat -n (uvcTN.sh:100): the BGZF files one after the other, the 28-byte end-of-file marker of all but the last dropped. */
+int uvcio_bgzf_concat(const char *out_path, const char *const *in_paths, int32_t n_in);
+/* The whole text of a (block-)gzipped or plain file (the tumor VCF of a T/N pair); *buf is malloc'ed, the caller frees it. */
+int uvcio_read_text_file(const char *path, char **buf, int64_t *len);
 
 #ifdef __cplusplus
 }

@@ -1133,12 +1133,12 @@ static void vcf_emit(State &S, const Fmt &f, const Fmt &rf, const std::string &i
 
 // The two position-level lines written in front of the records of a zerobased_pos: the MGVCF block (main.cpp:655-735) and
 // ADDITIONAL_INDEL_CANDIDATE (main.cpp:759-799).  Whole lines; the sink marks them with tier2 = -1.
-static void position_lines(State &S, i32 refpos, i32 zpos, i32 prev_tracklen, i32 curr_tracklen, i32 repeatunit_size, i32 repeatnum) {
+static void position_lines(State &S, i32 region_beg, i32 refpos, i32 zpos, i32 prev_tracklen, i32 curr_tracklen, i32 repeatunit_size, i32 repeatnum) {
     const UvcParams &P = S.P;
     const std::string &tname = S.vcf_sink->tname;
     auto sym_of = [](char c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; case 'I': case 'i': return 6; case '-': case '_': return 9; default: return 4; } };
     auto put_line = [&](const std::string &l) { S.vcf_sink->fixed.push_back(l); S.vcf_sink->spec.push_back(std::string()); S.vcf_sink->tier2.push_back(-1); };
-    if ((P.outvar_flag & 0x8) && (((refpos % 1000) == 0) || (refpos == S.beg))) {
+    if ((P.outvar_flag & 0x8) && (((refpos % 1000) == 0) || (refpos == region_beg))) {   // main.cpp:655-656: refpos == incluBegPosition, the begin of the BED line
         const i32 init_refQ = (INT_MAX / 2 + 1);
         i32 prev_b = 0, prev_c = 0, prev_c12 = 0, prev_q = init_refQ;
         auto depths_diff = [](i32 cur, i32 prev, i32 mul, i32 add) { const i32 lo = min_(cur, prev), hi = max_(cur, prev); if ((i64)lo * mul >= (i64)hi * 100) return false; if (lo + add >= hi) return false; return true; };
@@ -1205,7 +1205,11 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
     indel_allele_rows(S, gap_rows, gap_seq);
     std::map<std::pair<i32, int>, size_t> gap_first;   // (refpos, symbol) -> first row
     for (size_t q = gap_rows.size(); q-- > 0;) gap_first[std::make_pair(gap_rows[q].refpos, gap_rows[q].symbol)] = q;
+    const bool base_at_beg = (req && req->base_at_pos_beg && req->pos_beg >= 0);   // the region continues an adjacent one (include/uvcgpu.h)
+    const i32 region_beg = (req ? req->region_beg : 0);
+    if (pos_beg < S.beg + (base_at_beg ? 1 : 0) || pos_end > S.end - 1 || pos_end < pos_beg) { err = "score range outside the region"; return UVCGPU_EINVAL; }
     i32 prev_tracklen = 0, curr_tracklen = 0;
+    if (base_at_beg) { i32 us = 0, rn = 0; indelpos_to_context(us, rn, S.refstring, pos_beg - 1 - ext_beg, P.indel_str_repeatsize_max); prev_tracklen = rn * us; }   // what the adjacent region's last iteration left
     for (i32 zpos = pos_beg; zpos < pos_end; zpos++, prev_tracklen = curr_tracklen) {
         i32 repeatunit_size = 0, repeatnum = 0;
         indelpos_to_context(repeatunit_size, repeatnum, S.refstring, zpos - ext_beg, P.indel_str_repeatsize_max);
@@ -1220,14 +1224,14 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
         i32 curr_vAC[2] = { 0, 0 };
         i32 ins_cdepth = 0, del_cdepth = 0, ins1_cdepth = 0, del1_cdepth = 0;
         for (int st = 0; st < 2; st++) {
-            if (zpos == pos_beg && UVC_BASE_SYMBOL == st) continue;
+            if (zpos == pos_beg && UVC_BASE_SYMBOL == st && !base_at_beg) continue;
             const i32 refpos = (UVC_BASE_SYMBOL == st ? (zpos - 1) : zpos);
             const i64 x = refpos - S.beg;
             const int refsymbol = st_refsymbol[st];
             Fmt init; memset(&init, 0, sizeof(init));
             i32 bDPcDP[2];
             symboltype_init(init, S, refpos, st, bDPcDP);
-            if (S.vcf_sink && UVC_BASE_SYMBOL == st) position_lines(S, refpos, zpos, prev_tracklen, curr_tracklen, repeatunit_size, repeatnum);
+            if (S.vcf_sink && UVC_BASE_SYMBOL == st) position_lines(S, region_beg, refpos, zpos, prev_tracklen, curr_tracklen, repeatunit_size, repeatnum);
             const i32 ref_bdepth = S.FR(0, UVC_FRAG_bDP, refsymbol, x) + S.FR(1, UVC_FRAG_bDP, refsymbol, x);
             for (int k = 0; k < ST_NSYMBOLS[st]; k++) {
                 const int symbol = ST_SYMBOLS[st][k];
@@ -1290,7 +1294,7 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
             }
         }
         for (int st = 0; st < 2; st++) {
-            if (zpos == pos_beg && UVC_BASE_SYMBOL == st) continue;
+            if (zpos == pos_beg && UVC_BASE_SYMBOL == st && !base_at_beg) continue;
             if (fmts[st].empty()) continue;
             const i32 refpos = (UVC_BASE_SYMBOL == st ? (zpos - 1) : zpos);
             // BcfFormat_symbol_sum_DPv, main.hpp:4888-4906
@@ -1323,12 +1327,12 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
                 f.cVQ1M[i] = (has ? tops[i].v1 : -999); f.cVQ2M[i] = (has ? tops[i].v2 : -999); f.cVQAM[i] = (has ? tops[i].symbol : SYM_END); f.cVQSM[i] = (has ? tops[i].row : -1);
             }
             i64 rec0 = (i64)records.size();
-            for (int t = 0; t < st; t++) if (!(zpos == pos_beg && UVC_BASE_SYMBOL == t)) rec0 += (i64)fmts[t].size();
+            for (int t = 0; t < st; t++) if (!(zpos == pos_beg && UVC_BASE_SYMBOL == t && !base_at_beg)) rec0 += (i64)fmts[t].size();
             call_germline(P, st_refsymbol[st], fmts[st], rec0);
         }
         const bool is_germline_var_generated = ((!fmts[0].empty() && fmts[0][0].germ_emit) || (!fmts[1].empty() && fmts[1][0].germ_emit));
         for (int st = 0; st < 2; st++) {   // main.cpp:1073-1168
-            if (zpos == pos_beg && UVC_BASE_SYMBOL == st) continue;
+            if (zpos == pos_beg && UVC_BASE_SYMBOL == st && !base_at_beg) continue;
             const Fmt *reffmt = NULL;
             for (const Fmt &f : fmts[st]) if (f.symbol == st_refsymbol[st]) reffmt = &f;
             for (Fmt &f : fmts[st]) {

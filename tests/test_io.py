@@ -190,3 +190,43 @@ def test_region_planner_follows_samiter(seed, mem, nthreads):
         assert (a["tid"], a["end"]) <= (b["tid"], b["beg"]) or a["tid"] < b["tid"]
     mapped = (flag & 4) == 0
     assert sum(c["n_reads"] for c in got) <= int(mapped.sum())
+
+
+def test_tumor_vcf_reader(tmp_path):
+    """uvcio_tumor_vcf_*: rescue_variants_from_vcf (main.cpp:183-398) on text.  Keys: symbolpos = POS - 1 for substitutions and the two
+    position-level line types, POS for InDels (:279); symbolic ALTs other than <NON_REF> / <ADDITIONAL_INDEL_CANDIDATE> are skipped (:265-272),
+    lines without FORMAT/VTI too (:275); the integers are the ones :294-372 read."""
+    fmt = "GT:VTI:BDPb:bDPf:bDPr:CDP1x:cDP1x:cVQ1:cPCQ1:CDP2x:cDP2x:cVQ2:cPCQ2:bNMQ:vHGQ:CDP1b:cDP1f:cDP1r:CDP2b"
+    def smp(vti, k):
+        return "./1:%s:%d,%d:9,%d:8,%d:%d:100,%d:50,%d:60,%d:%d:10,%d:40,%d:45,%d:30,%d:%d:70,%d:20,%d:21,%d:5,%d" % (
+            vti, 100 + k, 90 + k, 3 + k, 4 + k, 9000 + k, 300 + k, 31 + k, 32 + k, 800 + k, 30 + k, 41 + k, 42 + k, 17 + k, 55 + k, 60 + k, 6 + k, 7 + k, 1 + k)
+    lines = ["##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tTUMOR1",
+             "chrB\t101\t.\tA\tG\t50\tPASS\tANY_VAR\t" + fmt + "\t" + smp("0,2", 0),
+             "chrA\t501\t.\tC\tT\t50\tPASS\tANY_VAR\t" + fmt + ":_C2XP\t" + smp("1,3", 1) + ":x",
+             "chrA\t700\t.\tGAC\tG\t50\tPASS\tANY_VAR\t" + fmt + "\t" + smp("6,8", 2),          # deletion of 2: symbolpos = POS
+             "chrA\t700\t.\tG\tGTTT\t50\tPASS\tANY_VAR\t" + fmt + "\t" + smp("6,10", 3),        # insertion of 3 at the same place
+             "chrA\t800\t.\tG\t<LD3P>\t50\tPASS\tANY_VAR\t" + fmt + "\t" + smp("6,7", 4),       # symbolic: skipped
+             "chrA\t1001\t.\tT\t<NON_REF>\t.\t.\tMGVCF_BLOCK\tGT:VTI:POS_VT_BDP_CDP_HomRefQ\t.:3,15:1000,2,.,5,5,5,30,.,2001",
+             "chrA\t1200\t.\tT\t<ADDITIONAL_INDEL_CANDIDATE>\t.\t.\tADDITIONAL_INDEL_CANDIDATE;RU=A;RC=9\tGT:VTI:clipDP\t.:3,16:40,12",
+             "chrA\t1300\t.\tT\tA\t50\tPASS\tANY_VAR\tGT:DP\t./1:5",                           # no VTI: skipped
+             "chrZ\t5\t.\tT\tA\t50\tPASS\tANY_VAR\t" + fmt + "\t" + smp("3,0", 5)]              # contig the BAM does not have
+    path = str(tmp_path / "t.vcf.gz")
+    w = uio.BgzfWriter(path); w.write("\n".join(lines) + "\n"); w.close()
+    T = uio.TumorVcf(path, ["chrA", "chrB"])
+    assert T.sample == "TUMOR1" and T.n_records == 6
+    keys, cols = T.fetch(0, 0, 10 ** 9)
+    got = [(k.refpos, k.symbol) for k in keys]
+    assert got == [(500, 3), (700, 8), (700, 10), (1000, 15), (1199, 16)]
+    k = keys[0]
+    assert (k.BDP, k.bDP, k.CDP1x, k.cDP1x, k.cVQ1, k.cPCQ1, k.CDP2x, k.cDP2x, k.cVQ2, k.cPCQ2, k.bNMQ, k.vHGQ, k.tDP, k.tAD0, k.tAD1, k.t2DP, k.tier2, k.indel_len) == \
+        (101 + 91, 4 + 5, 9001, 301, 32, 33, 801, 31, 42, 43, 18, 56, 61 + 70, 20 + 21, 7 + 8, 5 + 2, 1, 0)
+    assert (keys[1].indel_len, keys[2].indel_len, keys[1].tier2) == (2, 3, 0) and cols[1] == smp("6,8", 2) and cols[3].startswith(".:3,15:")
+    assert [(k.refpos, k.symbol) for k in T.fetch(0, 700, 1000)[0]] == [(700, 8), (700, 10), (1000, 15)]
+    assert T.fetch(0, 701, 999) == (None, []) and [(k.refpos, k.symbol) for k in T.fetch(1, 0, 200)[0]] == [(100, 2)]
+    T2 = uio.TumorVcf(path, ["chrA", "chrB"], is_tumor_format_retrieved=False)   # then the two position-level line types are dropped as well
+    assert T2.n_records == 4
+    T.close(); T2.close()
+    bad = str(tmp_path / "bad.vcf")
+    open(bad, "w").write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\nchrA\t5\t.\tA\tC\t1\t.\t.\tGT:VTI:BDPb\t./1:0,1:7\n")
+    with pytest.raises(IOError):
+        uio.TumorVcf(bad, ["chrA"])

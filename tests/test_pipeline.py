@@ -142,3 +142,125 @@ def test_native_command_line_equals_the_python_chain(tmp_path, gpu_lib):
     assert gzip.open(out_b, "rt").read() == gzip.open(out_c, "rt").read()
     r = subprocess.run([exe, bam, "-f", fa, "-o", out_c, "--no-such-option"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "unknown option" in r.stderr
+
+
+def _run_cli(args, timeout=600):
+    import os
+    import subprocess
+    from uvc_amd import _ffi
+    exe = os.path.join(_ffi.ROOT, "uvc_amd", "csrc", "uvc1-mi355x")
+    assert os.path.exists(exe), "build it: make -C uvc_amd/csrc"
+    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr
+    return r.stderr
+
+
+@pytest.mark.gpu
+def test_region_shards_write_the_single_worker_output(tmp_path, gpu_lib):
+    """SURVEY 8e / BASELINE config 3 in small: eight tiles of one BAM through (a) one worker, (b) four workers spread over two device
+    slots (--devices 0,0: both slots are GPU 0 here, the dispatch is the same as with two GPUs), (c) two processes with --shard i/2 whose
+    outputs are joined by --concat.  All three byte-identical: ownership of every position is a property of the tile list."""
+    import gzip
+    reads = make_files(tmp_path, 0)
+    bam, fa = str(tmp_path / "u0.bam"), str(tmp_path / "u0.fa")
+    b0 = reads["beg"]
+    common = [bam, "-f", fa, "-s", "T1", "--targets", "chrT:%d-%d" % (b0 + 1, b0 + 6000), "--tile", "750"]
+    one, many = str(tmp_path / "one.vcf.gz"), str(tmp_path / "many.vcf.gz")
+    _run_cli(common + ["-o", one, "--devices", "0", "-t", "1"])
+    err = _run_cli(common + ["-o", many, "--devices", "0,0", "-t", "4", "--timing"])
+    assert "8 tiles" in err and "on 2 device(s)" in err and err.count("worker ") == 4
+    assert gzip.open(one, "rb").read() == gzip.open(many, "rb").read()
+    body = [l for l in gzip.open(one, "rt").read().splitlines() if not l.startswith("#")]
+    assert len(body) >= 10 and len(set(body)) == len(body)                      # no line twice: every zerobased_pos has one owner
+    shards = [str(tmp_path / ("shard%d.vcf.gz" % i)) for i in range(2)]
+    for i in range(2):
+        err = _run_cli(common + ["-o", shards[i], "--shard", "%d/2" % i, "-t", "2"])
+        assert "shard %d of 2 takes" % i in err
+    joined = str(tmp_path / "joined.vcf.gz")
+    _run_cli(["--concat", joined] + shards)
+    assert gzip.open(joined, "rb").read() == gzip.open(one, "rb").read()
+    assert all(len([l for l in gzip.open(s, "rt").read().splitlines() if not l.startswith("#")]) >= 1 for s in shards)
+
+
+def make_tn_files(d):
+    """Tumor (120x) and normal (50x) BAMs over one reference: same seed and length = same reference, different molecules and variants."""
+    out = {}
+    ref = None
+    for name, depth in (("tumor", 120), ("normal", 50)):
+        reads = synth.generate_region(seed=99, region_len=5000, depth=depth, beg=40000, snv_every=400, somatic_every=700, indel_every=900)
+        ref = ref or reads["refseq"]
+        assert reads["refseq"] == ref
+        recs = bamwriter.records_from_reads(reads, tid=0)
+        chrom_len = reads["end"] + 4000
+        rng = np.random.default_rng(6)
+        seq = "".join("ACGT"[i] for i in rng.integers(0, 4, chrom_len))
+        seq = seq[:reads["beg"]] + reads["refseq"] + seq[reads["end"]:]
+        bamwriter.write_bam(str(d / (name + ".bam")), [("chrT", chrom_len)], recs)
+        bamwriter.write_fasta(str(d / "tn.fa"), [("chrT", seq)])
+        out[name] = reads
+    return out
+
+
+@pytest.mark.gpu
+def test_tumor_normal_two_pass_flow(tmp_path, gpu_lib, oracle_lib):
+    """BASELINE config 5 in small, the flow of bin/uvcTN.sh:120-127: tumor pass (--tn-is-paired 1 --bed-out-fname) -> tumor VCF + region
+    table -> normal pass (--bed-in-fname, --tumor-vcf).  The tumor VCF is read back by libuvcio's restatement of rescue_variants_from_vcf
+    (main.cpp:183-398); the normal pass is compared with the same chain on the oracle fed with the same tumor records."""
+    import gzip
+    from test_gpu_parity import compare_records
+    from uvc_amd import region
+    rd = make_tn_files(tmp_path)
+    tb, nb, fa = str(tmp_path / "tumor.bam"), str(tmp_path / "normal.bam"), str(tmp_path / "tn.fa")
+    tv, nv, bed = str(tmp_path / "T.vcf.gz"), str(tmp_path / "N.vcf.gz"), str(tmp_path / "T.bed")
+    b0 = rd["tumor"]["beg"]
+    target = "chrT:%d-%d" % (b0 + 1, b0 + 5000)
+    _run_cli([tb, "-f", fa, "-o", tv, "-s", "TUM", "--targets", target, "--tile", "2000", "--tn-is-paired", "1", "--bed-out-fname", bed, "-t", "2"])
+    bed_lines = [l.split("\t") for l in open(bed).read().splitlines()]
+    assert [(l[0], int(l[1]), int(l[2])) for l in bed_lines] == [("chrT", b0, b0 + 2000), ("chrT", b0 + 2000, b0 + 4000), ("chrT", b0 + 4000, b0 + 5000)]
+    assert all(l[3] == "BedLineFlag" and l[5] == "NumberOfReadsInThisInterval" and int(l[6]) > 100 for l in bed_lines)   # main.cpp:1415-1436
+    err = _run_cli([nb, "-f", fa, "-o", nv, "-s", "NOR", "--tn-is-paired", "1", "--bed-in-fname", bed, "--tumor-vcf", tv, "-t", "2"])
+    assert "tumor records from" in err
+    t_lines = [l for l in gzip.open(tv, "rt").read().splitlines() if not l.startswith("##")]
+    n_text = gzip.open(nv, "rt").read().splitlines()
+    n_lines = [l for l in n_text if not l.startswith("##")]
+    assert n_lines[0].split("\t")[-2:] == ["NOR", "TUM"]                       # generate_vcf_header with the tumor sample name (main.hpp:5881)
+    t_rec = {tuple(l.split("\t")[:5]): l.split("\t")[9] for l in t_lines[1:]}
+    som = [l.split("\t") for l in n_lines[1:] if l.split("\t")[7].startswith("SOMATIC")]
+    assert len(som) >= 3
+    for c in som:                                                               # every normal-sample record repeats the tumor's sample column of the same variant
+        assert len(c) == 11 and t_rec[tuple(c[:5])] == c[10]
+    # the reader against the text: every non-symbolic tumor line is one key
+    names = ["chrT"]
+    T = uio.TumorVcf(tv, names)
+    assert T.sample == "TUM"
+    keys, cols = T.fetch(0, 0, 10 ** 9)
+    n_symbolic = sum(1 for l in t_lines[1:] if l.split("\t")[4] in ("<NON_REF>", "<ADDITIONAL_INDEL_CANDIDATE>"))
+    assert len(keys) == len(t_lines) - 1 and sum(1 for k in keys if k.symbol >= 15) == n_symbolic
+    for k, col in zip(keys, cols):
+        if k.symbol >= 15:
+            continue
+        c = next(l.split("\t") for l in t_lines[1:] if l.split("\t")[9] == col)
+        f = dict(zip(c[8].split(":"), c[9].split(":")))
+        assert int(f["VTI"].split(",")[1]) == k.symbol and k.refpos == int(c[1]) - (1 if k.symbol <= 5 else 0)
+        assert k.bDP == int(f["bDPf"].split(",")[1]) + int(f["bDPr"].split(",")[1]) and k.BDP == sum(int(v) for v in f["BDPb"].split(","))
+        assert k.cDP1x == int(f["cDP1x"].split(",")[1]) and k.CDP1x == int(f["CDP1x"]) and k.cVQ1 == int(f["cVQ1"].split(",")[1]) and k.vHGQ == int(f["vHGQ"])
+        assert k.tier2 == int("_C2XP" in f) and k.indel_len == abs(len(c[3]) - len(c[4])) * int(7 <= k.symbol <= 12)
+    # the normal pass, GPU against oracle, tile by tile with the keys the reader made
+    bam, fasta = uio.Bam(nb), uio.Fasta(fa)
+    n_rec = 0
+    for lib in (gpu_lib, oracle_lib):
+        p = region.default_params(lib)
+        p.tumor_vcf_is_provided, p.tn_is_paired = 1, 1
+        res = list(pipeline.call_contig(lib, bam, fasta, "chrT", b0, b0 + 5000, tile=2000, params=p, tumor_vcf=T, vcf=(lib is gpu_lib)))
+        if lib is gpu_lib:
+            got = res
+        else:
+            assert len(res) == len(got) == 3
+            for a, b in zip(res, got):
+                assert a["score_range"] == b["score_range"]
+                compare_records(a["records"], b["records"])
+                n_rec += len(a["records"]["refpos"])
+    assert n_rec > 50
+    # and the command line wrote what the Python chain writes
+    assert "".join(t["vcf"] for t in got).splitlines() == n_lines[1:]
+    T.close()

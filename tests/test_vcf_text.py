@@ -20,8 +20,7 @@ from util import run_region
 REF_SO = os.path.join(_ffi.ROOT, "oracle", "_ref", "libref_vcf.so")
 
 
-@pytest.fixture(scope="module")
-def ref_vcf():
+def _load_ref_vcf():
     if not os.path.exists(REF_SO):
         pytest.skip("oracle/_ref/libref_vcf.so not built (make -C oracle ref_formats needs /root/reference)")
     L = C.CDLL(REF_SO)
@@ -30,6 +29,11 @@ def ref_vcf():
     L.uvc_ref_stream_format.restype = C.c_int64
     L.uvc_ref_stream_format.argtypes = [C.c_char_p, C.c_char_p, C.c_int64]
     return L
+
+
+@pytest.fixture(scope="module")
+def ref_vcf():
+    return _load_ref_vcf()
 
 
 @pytest.fixture(scope="module")
@@ -95,11 +99,7 @@ def _oracle_lines(oracle_lib, ref_vcf, Ro, tname, tumor_keys=None, **score_kw):
     fn = oracle_lib.dll.uvc_oracle_region_vcf
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.POINTER(_ffi.UvcScoreRequest), C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
-    req = _ffi.UvcScoreRequest()
-    req.pos_beg, req.pos_end, req.all_out, req.is_amplicon = -1, -1, int(score_kw.get("all_out", False)), 0
-    if tumor_keys:
-        tk = (_ffi.UvcTumorKey * len(tumor_keys))(*[_ffi.UvcTumorKey(*t) for t in tumor_keys])
-        req.n_tumor_keys, req.tumor_keys = len(tumor_keys), C.cast(tk, C.c_void_p)
+    req, _keep = region.Region.make_request(tumor_keys=tumor_keys, **score_kw)   # pos_beg / pos_end / all_out / base_at_pos_beg / region_beg
     ln = C.c_int64(0)
     fn(Ro.h, C.byref(req), tname.encode(), None, 0, C.byref(ln))
     buf = C.create_string_buffer(max(1, ln.value))
@@ -239,6 +239,48 @@ def test_record_lines_of_the_normal_sample(oracle_lib, gpu_lib, ref_vcf):
     recs = [l for l in want if l.split("\t")[4] not in ("<NON_REF>", "<ADDITIONAL_INDEL_CANDIDATE>")]
     assert len(recs) > 0 and all(l.split("\t")[7].startswith("SOMATIC;") for l in recs) and len(recs) < len(want)
     compare_lines(mine, want)
+
+
+@pytest.mark.gpu
+def test_tumor_sample_column_is_carried_over(oracle_lib, gpu_lib, ref_vcf):
+    """is_tumor_format_retrieved (the default): every line of the normal sample ends with the sample column of the tumor's own line --
+    records: bcf1_to_string(tki.bcf1_record) (main.hpp:6269); MGVCF block / ADDITIONAL_INDEL_CANDIDATE lines: the tumor's line of that
+    position when it has exactly one, else the fillers of main.cpp:739-757, 784-798."""
+    from test_gpu_parity import tumor_keys_from
+    reads = synth.generate_region(region_len=10000, depth=30, seed=12345)
+    keys = [k + (7 + i, 3 + i % 5, 2 * i) for i, k in enumerate(tumor_keys_from(run_region(oracle_lib, reads).score(all_out=False)))]
+    b0 = reads["beg"] - reads["beg"] % 1000
+    zero = (0,) * 18
+    keys += [(b0 + 1000, 15) + zero, (b0 + 3000, 15) + zero, (b0 + 3000, 15) + zero]            # tumor MGVCF lines: one at +1000, two at +3000, none elsewhere
+    keys = sorted(keys, key=lambda k: (k[0], k[1]))
+    cols = ["T%d:x,%d" % (i, k[1]) for i, k in enumerate(keys)]
+    out = []
+    for lib in (oracle_lib, gpu_lib):
+        p = region.default_params(lib)
+        p.tumor_vcf_is_provided = 1
+        out.append(run_region(lib, reads, params=p))
+    Ro, Rg = out
+    rg = Rg.score(tumor_keys=keys)
+    plain = Rg.vcf_records("chr20", rg, tumor_keys=keys).splitlines()
+    mine = Rg.vcf_records("chr20", rg, tumor_keys=keys, tumor_sample_columns=cols).splitlines()
+    assert len(mine) == len(plain) > 10
+    n_rec = n_blk = 0
+    for a, b in zip(plain, mine):
+        c = b.split("\t")
+        assert len(c) == 11 and "\t".join(c[:10]) == a
+        if c[4] == "<NON_REF>":
+            refpos = int(c[1]) - 1
+            want = {b0 + 1000: cols[[k[:2] for k in keys].index((b0 + 1000, 15))], b0 + 3000: ".:.,.:-1"}.get(refpos, ".:.,.:.")
+            assert c[10] == want, (refpos, c[10], want); n_blk += 1
+        elif c[4] == "<ADDITIONAL_INDEL_CANDIDATE>":
+            assert c[10] == ".:.,.:.,."
+        else:
+            vti = c[9].split(":")[c[8].split(":").index("VTI")].split(",")
+            symbol = int(vti[1])
+            refpos = int(c[1]) - 1 if symbol <= 5 else int(c[1])
+            cand = [cols[i] for i, k in enumerate(keys) if k[:2] == (refpos, symbol)]
+            assert c[10] in cand, (c[:5], c[10], cand); n_rec += 1
+    assert n_rec > 0 and n_blk >= 5
 
 
 @pytest.mark.gpu

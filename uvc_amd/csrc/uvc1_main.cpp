@@ -1,8 +1,18 @@
 // uvc1-mi355x -- BAM + FASTA -> block-gzipped VCF: the host chain of the reference's uvc1 (main.cpp:1196-1603, process_batch :458-1193)
 // in C++ on the three C ABIs of this repository (uvcio.h readers / writer, uvcgroup.h family assignment, uvcgpu.h hot path + record text).
-// The frequently used options keep the reference's names (CmdLineArgs.cpp:188-262): inputBAM -f -o -s --targets -t -A -q --outvar-flag.
-// Worker threads = tiles in flight: each owns its file handles and one region handle that is reset from tile to tile; the lines are
-// written in tile order.  Regions are fixed tiles (--tile); results at a position do not depend on the cut.
+// The frequently used options keep the reference's names (CmdLineArgs.cpp:188-262): inputBAM -f -o -s --targets -R -t -A -q --outvar-flag
+// --tumor-vcf --tn-is-paired --bed-out-fname --bed-in-fname.
+//
+// Region shards.  The reference fans its regions out over threads with `schedule(dynamic, 1)` and writes the chunk outputs in
+// order (main.cpp:1478-1551); uvcTN.sh:92-101 adds one process per chromosome and `bcftools concat -n`.  Here:
+//   * one process, several GPUs: --devices 0,1,.. (default: all visible).  Worker thread w binds to devices[w % n]; the workers pull tiles
+//     from one queue (dynamic balance: a tile costs what its reads cost), each owns its file handles and one region handle that is reset
+//     from tile to tile; the lines are written in tile order and a worker never runs more than 4 * threads tiles ahead of the writer.
+//   * several processes: --shard i/n takes the i-th of n contiguous runs of the tile list, balanced by the compressed bytes the BAM index
+//     attributes to each tile plus its length (reads and positions, main.cpp:1390-1392); shard 0 writes the header; `--concat out in..`
+//     joins the shard outputs like bcftools concat -n.  No GPU ever talks to another one: there is no collective on this path.
+// Regions are fixed tiles (--tile); every zerobased_pos has exactly one owner (UvcScoreRequest::base_at_pos_beg), so the tiles of one
+// covered stretch write the records of one uncut region.
 #include "uvcgpu.h"
 #include "uvcgroup.h"
 #include "uvcio.h"
@@ -24,16 +34,19 @@ namespace {
 const int32_t MAX_INSERT_SIZE = 2000, MAX_STR_N_BASES = 100;   // common.hpp:63-64
 
 struct Opts {
-    std::string bam, fasta, out, sample = "-", targets, bed;
-    int threads = 2, device = 0, outvar_flag = -1, repeat = 1;
+    std::string bam, fasta, out, sample = "-", targets, bed, tumor_vcf, bed_out, bed_in;
+    std::vector<int> devices;
+    int threads = 0, outvar_flag = -1, repeat = 1, shard = 0, n_shards = 1, tn_is_paired = 0, tumor_format = 1;
     int64_t tile = 1000000;
-    bool all_out = false, timing = false;
+    bool all_out = false, timing = false, no_header = false;
     double vqual = -1e9;
 };
 [[noreturn]] void die(const std::string &m) { fprintf(stderr, "uvc1-mi355x: %s\n", m.c_str()); exit(2); }
 void usage() {
     fprintf(stderr, "usage: uvc1-mi355x inputBAM -f ref.fa -o out.vcf.gz [-s sample] [--targets chr[:beg-end] | -R regions.bed] [-t threads] [-A] [-q vqual]\n"
-                    "                   [--outvar-flag bits] [--tile bp] [--device id] [--timing]\n");
+                    "                   [--outvar-flag bits] [--tile bp] [--devices 0,1,..] [--shard i/n] [--no-header] [--timing]\n"
+                    "                   [--tn-is-paired 0|1] [--tumor-vcf tumor.vcf.gz] [--is-tumor-format-retrieved 0|1] [--bed-out-fname f] [--bed-in-fname f]\n"
+                    "       uvc1-mi355x --concat out.vcf.gz shard0.vcf.gz shard1.vcf.gz ...\n");
 }
 Opts parse(int argc, char **argv) {
     Opts o;
@@ -50,8 +63,20 @@ Opts parse(int argc, char **argv) {
         else if (a == "-q" || a == "--vqual") o.vqual = atof(val().c_str());
         else if (a == "--outvar-flag") o.outvar_flag = atoi(val().c_str());
         else if (a == "--tile") o.tile = std::max<int64_t>(1000, atoll(val().c_str()));
-        else if (a == "--device") o.device = atoi(val().c_str());
+        else if (a == "--device" || a == "--devices") {   // comma-separated HIP device ids; an id may repeat (two workers sets on one GPU)
+            o.devices.clear();
+            const std::string v = val(); size_t at = 0;
+            while (at <= v.size()) { size_t c = v.find(',', at); if (c == std::string::npos) c = v.size(); if (c > at) o.devices.push_back(atoi(v.substr(at, c - at).c_str())); at = c + 1; }
+            if (o.devices.empty()) die("--devices needs at least one id");
+        }
+        else if (a == "--shard") { const std::string v = val(); if (sscanf(v.c_str(), "%d/%d", &o.shard, &o.n_shards) != 2 || o.n_shards < 1 || o.shard < 0 || o.shard >= o.n_shards) die("--shard takes i/n with 0 <= i < n"); }
+        else if (a == "--no-header") o.no_header = true;
         else if (a == "--timing") o.timing = true;
+        else if (a == "--tumor-vcf") o.tumor_vcf = val();
+        else if (a == "--tn-is-paired") o.tn_is_paired = atoi(val().c_str());
+        else if (a == "--is-tumor-format-retrieved") o.tumor_format = atoi(val().c_str());
+        else if (a == "--bed-out-fname") o.bed_out = val();
+        else if (a == "--bed-in-fname") o.bed_in = val();
         else if (a == "--repeat") o.repeat = std::max(1, atoi(val().c_str()));   // benchmark aid: the tile list n times (steady state on a small file)
         else if (a == "-h" || a == "--help") { usage(); exit(0); }
         else if (!a.empty() && a[0] == '-') die("unknown option " + a + " (the hot-path parameters keep the reference's defaults)");
@@ -62,7 +87,11 @@ Opts parse(int argc, char **argv) {
     return o;
 }
 
-struct Tile { int32_t tid; std::string chrom; int64_t beg, end; };
+// A tile of a run of adjacent tiles.  The reference scores zerobased_pos rpos_beg .. rpos_end inclusive without the BASE sub-position of
+// the first (main.cpp:608, 643): adjacent regions both write the LINK records of their shared end point.  Here a tile owns the positions
+// [beg, end): `continues` (a tile ends where this one begins) = it scores `beg` completely, `has_next` = it leaves `end` to the next one.
+// `run_beg` = begin of the run (incluBegPosition of the BED line the run came from, main.cpp:655-656).
+struct Tile { int32_t tid; std::string chrom; int64_t beg, end; bool continues, has_next; int64_t run_beg; };
 
 // one worker: its own handles, one region handle for all of its tiles
 struct Worker {
@@ -72,12 +101,14 @@ struct Worker {
     std::vector<int32_t> pos, mpos, isize, nm, lq, ncig, fragp, famp; std::vector<uint16_t> flag; std::vector<uint8_t> mapq, strandp; std::vector<int64_t> soff, coff;
     std::vector<int32_t> fields; std::string ref;
     double t_fetch = 0, t_group = 0, t_region = 0, t_reads = 0, t_gpu = 0, t_text = 0;
+    int64_t n_tiles = 0;
 };
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// process_batch for one tile; appends the record lines to `lines`; false = nothing to call there
-bool call_tile(Worker &w, const Opts &o, const UvcParams &P, const Tile &t, int64_t tlen, std::string &lines) {
+// process_batch for one tile; appends the record lines to `lines`; false = nothing to call there.  *n_kept_reads: reads that passed the filters.
+bool call_tile(Worker &w, const Opts &o, const UvcParams &P, const Tile &t, int64_t tlen, const uvcio_tumor_vcf_t *tvcf, std::string &lines, int64_t *n_kept_reads) {
     double t0 = now();
+    *n_kept_reads = 0;
     UvcBamBatch b;
     if (uvcio_bam_fetch(w.bam, t.tid, std::max<int64_t>(0, t.beg - MAX_INSERT_SIZE), t.end + MAX_INSERT_SIZE, &b)) die(uvcio_last_error());
     w.t_fetch += now() - t0; t0 = now();
@@ -97,11 +128,15 @@ bool call_tile(Worker &w, const Opts &o, const UvcParams &P, const Tile &t, int6
     if (uvcgpu_group_families(&gp, &gi, &go)) die(uvcgpu_last_error());
     w.t_group += now() - t0; t0 = now();
     const int64_t k = go.n_kept;
+    *n_kept_reads = k;
     if (k == 0) return false;
     // region bounds and reference, main.cpp:523-552
     const int64_t bam_beg = go.extended_inclu_beg_pos, bam_end = go.extended_exclu_end_pos;
     const int64_t rpos_beg = std::max(t.beg, bam_beg), rpos_end = std::min(t.end, bam_end);
     const int64_t ext_beg = std::max<int64_t>(0, std::min(t.beg, bam_beg) - MAX_STR_N_BASES), ext_end = std::min(tlen, std::max(t.end, bam_end) + MAX_STR_N_BASES);
+    const int64_t first = rpos_beg;
+    const int64_t last_excl = t.has_next ? std::min(t.end, bam_end + 1) : std::min(rpos_end + 1, ext_end);   // zerobased_pos t.end belongs to the next tile
+    if (last_excl <= first) return false;
     w.ref.resize((size_t)(ext_end - ext_beg));
     if (uvcio_fasta_fetch(w.fa, t.chrom.c_str(), ext_beg, ext_end, &w.ref[0])) die(uvcio_last_error());
     int rc = w.reg ? uvcgpu_region_reset(w.reg, t.tid, (int32_t)ext_beg, (int32_t)ext_end, w.ref.c_str())
@@ -122,7 +157,13 @@ bool call_tile(Worker &w, const Opts &o, const UvcParams &P, const Tile &t, int6
     w.t_reads += now() - t0; t0 = now();
     if (uvcgpu_region_correct_bq(w.reg) || uvcgpu_region_accumulate(w.reg)) die(uvcgpu_last_error());
     UvcScoreRequest rq; memset(&rq, 0, sizeof(rq));
-    rq.pos_beg = (int32_t)rpos_beg; rq.pos_end = (int32_t)std::min(rpos_end + 1, ext_end); rq.all_out = o.all_out; rq.is_amplicon = (go.n_amplicon * 2 > k);
+    rq.pos_beg = (int32_t)first; rq.pos_end = (int32_t)last_excl; rq.all_out = o.all_out; rq.is_amplicon = (go.n_amplicon * 2 > k);
+    rq.base_at_pos_beg = (t.continues && first == t.beg && t.beg > ext_beg) ? 1 : 0; rq.region_beg = (int32_t)t.run_beg;
+    if (tvcf) {   // normal sample of a T/N pair: the tumor records of this region (tkis_beg .. tkis_end, main.cpp:532-533)
+        const UvcTumorKey *keys = nullptr; const char *const *cols = nullptr; int64_t nk = 0;
+        if (uvcio_tumor_vcf_fetch(tvcf, t.tid, (int32_t)ext_beg, (int32_t)ext_end, &keys, &cols, &nk)) die(uvcio_last_error());
+        rq.tumor_keys = keys; rq.n_tumor_keys = nk; rq.tumor_sample_columns = (o.tumor_format ? cols : nullptr);
+    }
     int64_t cap = std::max<int64_t>(4096, uvcgpu_region_score_size(w.reg, &rq) / (o.all_out ? 1 : 4));
     UvcScoreOut so;
     for (;;) {
@@ -135,19 +176,26 @@ bool call_tile(Worker &w, const Opts &o, const UvcParams &P, const Tile &t, int6
     }
     w.t_gpu += now() - t0; t0 = now();
     int64_t len = 0;
-    rc = uvcgpu_region_vcf_records(w.reg, t.chrom.c_str(), &so, rq.pos_beg, rq.pos_end, nullptr, 0, nullptr, 0, &len);
+    rc = uvcgpu_region_vcf_records(w.reg, t.chrom.c_str(), &so, &rq, nullptr, 0, &len);
     if (rc && rc != UVCGPU_ENOMEM) die(uvcgpu_last_error());
     const size_t at = lines.size();
     lines.resize(at + (size_t)len);
-    if (len && uvcgpu_region_vcf_records(w.reg, t.chrom.c_str(), &so, rq.pos_beg, rq.pos_end, nullptr, 0, &lines[at], len, &len)) die(uvcgpu_last_error());
+    if (len && uvcgpu_region_vcf_records(w.reg, t.chrom.c_str(), &so, &rq, &lines[at], len, &len)) die(uvcgpu_last_error());
     w.t_text += now() - t0;
     return true;
 }
 }   // namespace
 
 int main(int argc, char **argv) {
-    const Opts o = parse(argc, argv);
-    if (uvcgpu_init(o.device)) die(uvcgpu_last_error());
+    if (argc >= 3 && !strcmp(argv[1], "--concat")) {   // bcftools concat -n (uvcTN.sh:100)
+        std::vector<const char *> in; for (int i = 3; i < argc; i++) in.push_back(argv[i]);
+        if (uvcio_bgzf_concat(argv[2], in.data(), (int32_t)in.size())) die(uvcio_last_error());
+        return 0;
+    }
+    Opts o = parse(argc, argv);
+    if (o.devices.empty()) { const int nd = uvcgpu_device_count(); if (nd <= 0) die("no HIP device: uvc1-mi355x has no CPU path"); for (int d = 0; d < nd; d++) o.devices.push_back(d); }
+    if (o.threads <= 0) o.threads = 4 * (int)o.devices.size();
+    if (uvcgpu_init(o.devices[0])) die(uvcgpu_last_error());
     uvcio_bam_t *bam0 = nullptr;
     if (uvcio_bam_open(&bam0, o.bam.c_str())) die(uvcio_last_error());
     if (!uvcio_bam_has_index(bam0)) fprintf(stderr, "uvc1-mi355x: no .bai next to %s, every tile scans the file\n", o.bam.c_str());
@@ -155,12 +203,13 @@ int main(int argc, char **argv) {
     std::vector<std::string> names; std::vector<int64_t> lens; std::vector<const char *> cnames;
     for (int32_t i = 0; i < nref; i++) { names.push_back(uvcio_bam_ref_name(bam0, i)); lens.push_back(uvcio_bam_ref_len(bam0, i)); }
     for (auto &s : names) cnames.push_back(s.c_str());
-    // the tiles: --targets "chr" or "chr:beg-end" (1-based inclusive as in samtools), else every contig
+    // the tiles: --bed-in-fname / -R regions, --targets "chr" or "chr:beg-end" (1-based inclusive as in samtools), else every contig
     std::vector<Tile> tiles;
-    auto add = [&](int32_t tid, int64_t beg, int64_t end) { for (int64_t b = beg; b < end; b += o.tile) tiles.push_back(Tile{ tid, names[(size_t)tid], b, std::min(b + o.tile, end) }); };
-    if (!o.bed.empty()) {   // -R: one region per BED line (0-based, half-open), cut into tiles; overrides --targets as in the reference
-        FILE *fb = fopen(o.bed.c_str(), "r");
-        if (!fb) die("cannot open " + o.bed);
+    auto add = [&](int32_t tid, int64_t beg, int64_t end) { for (int64_t b = beg; b < end; b += o.tile) tiles.push_back(Tile{ tid, names[(size_t)tid], b, std::min(b + o.tile, end), false, false, b }); };
+    const std::string bed_path = (!o.bed_in.empty() ? o.bed_in : o.bed);
+    if (!bed_path.empty()) {   // one region per BED line (0-based, half-open), cut into tiles; overrides --targets as in the reference
+        FILE *fb = fopen(bed_path.c_str(), "r");
+        if (!fb) die("cannot open " + bed_path);
         char line[4096], chrom[1024]; long long b = 0, e = 0;
         while (fgets(line, sizeof(line), fb)) {
             if (line[0] == '#' || !strncmp(line, "track", 5) || !strncmp(line, "browser", 7)) continue;
@@ -184,6 +233,19 @@ int main(int argc, char **argv) {
         if (tid < 0) die("--targets names a contig that is not in the BAM header: " + chrom);
         add(tid, beg, end < 0 ? lens[(size_t)tid] : std::min(end, lens[(size_t)tid]));
     } else for (int32_t i = 0; i < nref; i++) add(i, 0, lens[(size_t)i]);
+    // ownership of the shared end points: a tile whose predecessor ends where it begins continues that one's run
+    for (size_t q = 1; q < tiles.size(); q++) if (tiles[q].tid == tiles[q - 1].tid && tiles[q].beg == tiles[q - 1].end) { tiles[q].continues = true; tiles[q - 1].has_next = true; tiles[q].run_beg = tiles[q - 1].run_beg; }
+    // --shard i/n: the i-th of n contiguous runs of the list, balanced by index bytes + positions
+    if (o.n_shards > 1) {
+        std::vector<int64_t> cost(tiles.size()); std::vector<int32_t> shard_of(tiles.size());
+        for (size_t q = 0; q < tiles.size(); q++) cost[q] = uvcio_bam_region_bytes(bam0, tiles[q].tid, tiles[q].beg, tiles[q].end) + (tiles[q].end - tiles[q].beg) / 8 + 1;
+        if (uvcio_plan_shards(cost.data(), (int64_t)cost.size(), o.n_shards, shard_of.data())) die(uvcio_last_error());
+        std::vector<Tile> mine;
+        for (size_t q = 0; q < tiles.size(); q++) if (shard_of[q] == o.shard) mine.push_back(tiles[q]);
+        fprintf(stderr, "uvc1-mi355x: shard %d of %d takes %zu of %zu tiles\n", o.shard, o.n_shards, mine.size(), tiles.size());
+        tiles.swap(mine);
+        if (o.shard > 0) o.no_header = true;
+    }
     const size_t tiles_per_pass = tiles.size();
     for (int rep = 1; rep < o.repeat; rep++) for (size_t q = 0; q < tiles_per_pass; q++) tiles.push_back(tiles[q]);
 
@@ -193,6 +255,7 @@ int main(int argc, char **argv) {
     if (o.vqual > -1e8) P.vqual = o.vqual;
     if (o.outvar_flag >= 0) P.outvar_flag = o.outvar_flag;
     P.should_output_all = o.all_out;
+    P.tn_is_paired = o.tn_is_paired;
     {
         int platform = UVC_PLATFORM_ILLUMINA, readlen = 150, maxmq = 0; bool seen = false;
         for (size_t ti = 0; ti < tiles.size() && !seen; ti++) {
@@ -214,34 +277,47 @@ int main(int argc, char **argv) {
         uvcgpu_params_apply_platform(&P, platform, readlen, maxmq);
     }
     uvcio_bam_close(bam0);
+    // T/N: the tumor pass's records (rescue_variants_from_vcf, main.cpp:183-398)
+    uvcio_tumor_vcf_t *tvcf = nullptr;
+    if (!o.tumor_vcf.empty()) {
+        if (uvcio_tumor_vcf_open(&tvcf, o.tumor_vcf.c_str(), cnames.data(), nref, o.tumor_format)) die(uvcio_last_error());
+        P.tumor_vcf_is_provided = 1;
+        fprintf(stderr, "uvc1-mi355x: %lld tumor records from %s\n", (long long)uvcio_tumor_vcf_n_records(tvcf), o.tumor_vcf.c_str());
+    }
 
     // output: header, then the lines of every tile in tile order
     uvcio_bgzf_writer_t *zw = nullptr;
     if (uvcio_bgzf_write_open(&zw, o.out.c_str(), 6)) die(uvcio_last_error());
-    {
+    if (!o.no_header) {
         int64_t len = 0;
-        uvcgpu_vcf_header(&P, o.sample.c_str(), cnames.data(), lens.data(), nref, nullptr, 0, &len);
+        const char *tsample = (tvcf && o.tumor_format) ? uvcio_tumor_vcf_sample_name(tvcf) : nullptr;
+        uvcgpu_vcf_header(&P, o.sample.c_str(), tsample, cnames.data(), lens.data(), nref, nullptr, 0, &len);
         std::string h((size_t)len, '\0');
-        if (uvcgpu_vcf_header(&P, o.sample.c_str(), cnames.data(), lens.data(), nref, &h[0], len, &len)) die(uvcgpu_last_error());
+        if (uvcgpu_vcf_header(&P, o.sample.c_str(), tsample, cnames.data(), lens.data(), nref, &h[0], len, &len)) die(uvcgpu_last_error());
         if (uvcio_bgzf_write(zw, h.data(), (int64_t)h.size())) die(uvcio_last_error());
     }
     const double t_start = now();
-    std::vector<std::string> done(tiles.size()); std::vector<char> ready(tiles.size(), 0);
+    std::vector<std::string> done(tiles.size()); std::vector<char> ready(tiles.size(), 0); std::vector<int64_t> tile_reads(tiles.size(), 0);
     std::mutex mu; std::condition_variable cv; std::atomic<size_t> next{ 0 };
+    size_t written = 0;   // tiles the writer has taken (guarded by mu)
     const int nthreads = (int)std::min<size_t>((size_t)o.threads, std::max<size_t>(tiles.size(), 1));
+    const size_t max_ahead = (size_t)4 * (size_t)nthreads;
     std::vector<Worker> workers((size_t)nthreads);
     std::vector<std::thread> th;
     for (int wi = 0; wi < nthreads; wi++) th.emplace_back([&, wi]() {
         Worker &w = workers[(size_t)wi];
-        if (uvcgpu_init(o.device)) die(uvcgpu_last_error());
+        if (uvcgpu_init(o.devices[(size_t)wi % o.devices.size()])) die(uvcgpu_last_error());   // binds this host thread to its device
         if (uvcio_bam_open(&w.bam, o.bam.c_str()) || uvcio_fasta_open(&w.fa, o.fasta.c_str())) die(uvcio_last_error());
         for (;;) {
             const size_t ti = next.fetch_add(1);
             if (ti >= tiles.size()) break;
-            // bounded run-ahead: a worker does not start a tile more than 4 * threads in front of the writer
-            std::string lines;
-            call_tile(w, o, P, tiles[ti], lens[(size_t)tiles[ti].tid], lines);
-            { std::lock_guard<std::mutex> g(mu); done[ti].swap(lines); ready[ti] = 1; }
+            // bounded run-ahead: finished tiles wait in `done` for the in-order writer; a worker does not start a tile more than
+            // 4 * threads in front of it, so a slow early tile cannot make the rest of the genome pile up in memory
+            { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return ti < written + max_ahead; }); }
+            std::string lines; int64_t nk = 0;
+            call_tile(w, o, P, tiles[ti], lens[(size_t)tiles[ti].tid], tvcf, lines, &nk);
+            w.n_tiles++;
+            { std::lock_guard<std::mutex> g(mu); done[ti].swap(lines); ready[ti] = 1; tile_reads[ti] = nk; }
             cv.notify_all();
         }
         if (w.reg) uvcgpu_region_destroy(w.reg);
@@ -251,20 +327,31 @@ int main(int argc, char **argv) {
     for (size_t ti = 0; ti < tiles.size(); ti++) {
         if (ti == tiles_per_pass) { t_first_pass = now() - t_start; pos_first_pass = n_pos; }
         std::string lines;
-        { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return ready[ti] != 0; }); lines.swap(done[ti]); }
+        { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return ready[ti] != 0; }); lines.swap(done[ti]); written = ti + 1; }
+        cv.notify_all();
         n_lines += std::count(lines.begin(), lines.end(), '\n'); n_pos += tiles[ti].end - tiles[ti].beg;
         if (!lines.empty() && uvcio_bgzf_write(zw, lines.data(), (int64_t)lines.size())) die(uvcio_last_error());
     }
     for (auto &t : th) t.join();
     if (uvcio_bgzf_write_close(zw)) die(uvcio_last_error());
+    if (tvcf) uvcio_tumor_vcf_close(tvcf);
+    if (!o.bed_out.empty()) {   // the region table of main.cpp:1415-1436 (--bed-out-fname): the shard manifest of the normal pass of a T/N pair
+        FILE *fo = fopen(o.bed_out.c_str(), "w");
+        if (!fo) die("cannot create " + o.bed_out);
+        for (size_t ti = 0; ti < tiles_per_pass; ti++)
+            fprintf(fo, "%s\t%lld\t%lld\tBedLineFlag\t%d\tNumberOfReadsInThisInterval\t%lld\tNumberOfRefBasesInThisInterval\t%lld\tTier1regionIndex\t0\tTier2regionIndex\t%d\tTier3regionIndex\t%zu\n",
+                    tiles[ti].chrom.c_str(), (long long)tiles[ti].beg, (long long)tiles[ti].end, tiles[ti].continues ? 4 : 16, (long long)tile_reads[ti], (long long)(tiles[ti].end - tiles[ti].beg), o.shard, ti);
+        fclose(fo);
+    }
     const double dt = now() - t_start;
-    fprintf(stderr, "uvc1-mi355x: %lld record lines from %zu tiles (%lld positions) in %.2f s = %.2f M positions/s, %d tiles in flight\n",
-            (long long)n_lines, tiles.size(), (long long)n_pos, dt, n_pos / dt / 1e6, nthreads);
+    fprintf(stderr, "uvc1-mi355x: %lld record lines from %zu tiles (%lld positions) in %.2f s = %.2f M positions/s, %d tiles in flight on %zu device(s)\n",
+            (long long)n_lines, tiles.size(), (long long)n_pos, dt, n_pos / dt / 1e6, nthreads, o.devices.size());
     if (o.repeat > 1) fprintf(stderr, "  passes 2..%d (steady state): %.2f M positions/s\n", o.repeat, (n_pos - pos_first_pass) / (dt - t_first_pass) / 1e6);
     if (o.timing) {
         double f = 0, g = 0, r = 0, s = 0, k = 0, x = 0;
         for (auto &w : workers) { f += w.t_fetch; g += w.t_group; r += w.t_region; s += w.t_reads; k += w.t_gpu; x += w.t_text; }
         fprintf(stderr, "  thread-seconds: fetch %.2f, digest+group %.2f, reference+region %.2f, set_reads %.2f, bq+accumulate+score %.2f, record text %.2f\n", f, g, r, s, k, x);
+        for (size_t wi = 0; wi < workers.size(); wi++) fprintf(stderr, "  worker %zu on device %d: %lld tiles\n", wi, o.devices[wi % o.devices.size()], (long long)workers[wi].n_tiles);
     }
     return 0;
 }

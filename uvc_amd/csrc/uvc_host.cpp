@@ -241,6 +241,8 @@ int uvcgpu_init(int device_id) {
     return 0;
 }
 
+int uvcgpu_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
+
 void uvcgpu_params_default(UvcParams *p) {
     memset(p, 0, sizeof(*p));
     p->struct_size = (int32_t)sizeof(UvcParams);
@@ -966,7 +968,9 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
     UvcScoreRequest rq; memset(&rq, 0, sizeof(rq)); rq.pos_beg = -1;
     if (req) rq = *req;
     if (rq.pos_beg < 0) { rq.pos_beg = r->beg + 1; rq.pos_end = r->end - 1; }
-    if (rq.pos_beg <= r->beg || rq.pos_end > r->end - 1 || rq.pos_end < rq.pos_beg) return fail(UVCGPU_EINVAL, "score range outside the region core");
+    // zerobased_pos == region begin is legal (a contig that starts inside the region: main.cpp:617-619 guards its "base in front" with BASE_NN);
+    // with base_at_pos_beg the BASE sub-position of pos_beg reads refpos pos_beg - 1, which must be inside the region
+    if (rq.pos_beg < r->beg + (rq.base_at_pos_beg ? 1 : 0) || rq.pos_end > r->end - 1 || rq.pos_end < rq.pos_beg) return fail(UVCGPU_EINVAL, "score range outside the region");
     // InDel alleles: the region's own tables (fill_by_indel_info / indel_get_majority); a (refpos, symbol) the caller lists is overridden
     { int rc0 = gap_tables(r); if (rc0) return rc0; }
     UvcIndelAllele *d_al = nullptr; int32_t *d_al_row = nullptr;

@@ -588,3 +588,196 @@ extern "C" int uvcio_plan_regions(const int32_t *tid, const int32_t *pos, const 
     for (size_t k = 0; k < cuts.size(); k++) out[k] = cuts[k];
     return 0;
 }
+
+// ---- region shards: cost estimate, contiguous balanced partition, concatenation of the shard outputs ----
+extern "C" int64_t uvcio_bam_region_bytes(const uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t end) {
+    if (!b || !b->has_index || tid < 0 || tid >= (int32_t)b->idx.size() || end <= beg) return 0;
+    const std::vector<uint64_t> &lin = b->idx[(size_t)tid].linear;
+    if (lin.empty()) return 0;
+    // a virtual offset = compressed offset of the block << 16 | offset inside the inflated block; inside one block only the second part
+    // moves (small files), so it counts too, at the usual ~4:1 ratio.  Windows without alignments carry offset 0 in files written by
+    // some tools: take the nearest filled window in front.
+    auto filled = [&](size_t w) { if (w >= lin.size()) w = lin.size() - 1; while (w > 0 && lin[w] == 0) w--; return (int64_t)(lin[w] >> 16) + (int64_t)(lin[w] & 0xFFFF) / 4; };
+    // the index knows the offset of the first alignment that overlaps each 16 kb window: between two windows interpolate
+    auto at = [&](int64_t p) { p = std::max<int64_t>(p, 0); const size_t w = (size_t)(p >> 14); const int64_t lo = filled(w), hi = std::max(lo, filled(w + 1)); return lo + (hi - lo) * (p & 16383) / 16384; };
+    const int64_t a = at(beg), z = at(end);
+    return z > a ? z - a : 0;
+}
+extern "C" int uvcio_plan_shards(const int64_t *cost, int64_t n, int32_t n_shards, int32_t *shard_of) {
+    if (n < 0 || n_shards < 1 || (n > 0 && (!cost || !shard_of))) return fail(UVCGPU_EINVAL, "bad argument");
+    long double total = 0;
+    for (int64_t i = 0; i < n; i++) { if (cost[i] < 0) return fail(UVCGPU_EINVAL, "negative cost"); total += (long double)cost[i]; }
+    long double run = 0;
+    int32_t prev = 0;
+    for (int64_t i = 0; i < n; i++) {
+        int32_t s = (total > 0) ? (int32_t)(((run + (long double)cost[i] / 2) * n_shards) / total) : (int32_t)((i * n_shards) / std::max<int64_t>(n, 1));
+        s = std::min(std::max(s, prev), n_shards - 1);
+        shard_of[i] = s; prev = s; run += (long double)cost[i];
+    }
+    return 0;
+}
+extern "C" int uvcio_bgzf_concat(const char *out_path, const char *const *in_paths, int32_t n_in) {
+    if (!out_path || n_in < 0 || (n_in > 0 && !in_paths)) return fail(UVCGPU_EINVAL, "bad argument");
+    static const uint8_t eof_marker[28] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    FILE *fo = fopen(out_path, "wb");
+    if (!fo) return fail(UVCGPU_EINVAL, std::string("cannot create ") + out_path);
+    std::vector<uint8_t> buf;
+    for (int32_t k = 0; k < n_in; k++) {
+        FILE *fi = fopen(in_paths[k], "rb");
+        if (!fi) { fclose(fo); return fail(UVCGPU_EINVAL, std::string("cannot open ") + in_paths[k]); }
+        fseeko(fi, 0, SEEK_END); const int64_t sz = (int64_t)ftello(fi); fseeko(fi, 0, SEEK_SET);
+        buf.resize((size_t)sz);
+        if (sz && fread(buf.data(), 1, (size_t)sz, fi) != (size_t)sz) { fclose(fi); fclose(fo); return fail(UVCGPU_EINVAL, std::string("short read of ") + in_paths[k]); }
+        fclose(fi);
+        int64_t keep = sz;
+        if (sz >= 28 && !memcmp(buf.data() + sz - 28, eof_marker, 28)) keep = sz - 28;
+        if (keep && fwrite(buf.data(), 1, (size_t)keep, fo) != (size_t)keep) { fclose(fo); return fail(UVCGPU_EINVAL, "write failed"); }
+    }
+    const bool ok = (fwrite(eof_marker, 1, 28, fo) == 28);
+    if (fclose(fo) != 0 || !ok) return fail(UVCGPU_EINVAL, "write failed");
+    return 0;
+}
+extern "C" int uvcio_read_text_file(const char *path, char **out, int64_t *len) {
+    if (!path || !out || !len) return fail(UVCGPU_EINVAL, "bad argument");
+    gzFile g = gzopen(path, "rb");   // zlib reads multi-member gzip (= BGZF) and plain files alike
+    if (!g) return fail(UVCGPU_EINVAL, std::string("cannot open ") + path);
+    gzbuffer(g, 1 << 20);
+    size_t cap = (size_t)1 << 22, n = 0;
+    char *b = (char *)malloc(cap);
+    if (!b) { gzclose(g); return fail(UVCGPU_ENOMEM, "malloc"); }
+    for (;;) {
+        if (cap - n < ((size_t)1 << 20)) { cap *= 2; char *nb = (char *)realloc(b, cap); if (!nb) { free(b); gzclose(g); return fail(UVCGPU_ENOMEM, "realloc"); } b = nb; }
+        const int got = gzread(g, b + n, (unsigned)std::min<size_t>(cap - n - 1, (size_t)1 << 30));
+        if (got < 0) { free(b); gzclose(g); return fail(UVCGPU_EINVAL, std::string("cannot inflate ") + path); }
+        if (got == 0) break;
+        n += (size_t)got;
+    }
+    gzclose(g);
+    b[n] = 0; *out = b; *len = (int64_t)n;
+    return 0;
+}
+
+// ---- the tumor VCF of a T/N pair: rescue_variants_from_vcf (main.cpp:183-398) on plain text ----
+struct uvcio_tumor_vcf {
+    std::string sample;
+    std::vector<int32_t> tid;                   // per record, parallel to keys
+    std::vector<UvcTumorKey> keys;              // sorted by (tid, refpos, symbol); records of one key keep their file order
+    std::vector<std::string> cols_text;         // sample column of each record
+    std::vector<const char *> cols;             // c_str() of the above
+    std::vector<int64_t> tid_first;             // [n_contigs + 1] first record of each tid
+};
+namespace {
+// the comma-separated integers of one FORMAT value ("." = missing -> none)
+int parse_ints(const char *p, const char *e, int32_t *out, int cap) {
+    int n = 0;
+    while (p < e) {
+        const char *q = p; while (q < e && *q != ',') q++;
+        if (q - p == 1 && *p == '.') return -1;
+        if (n < cap) out[n] = (int32_t)strtol(std::string(p, q).c_str(), nullptr, 10);
+        n++;
+        p = (q < e ? q + 1 : q);
+    }
+    return n;
+}
+}
+extern "C" int uvcio_tumor_vcf_open(uvcio_tumor_vcf_t **out, const char *path, const char *const *contig_names, int32_t n_contigs, int32_t is_tumor_format_retrieved) {
+    if (!out || !path || n_contigs < 0 || (n_contigs > 0 && !contig_names)) return fail(UVCGPU_EINVAL, "bad argument");
+    char *text = nullptr; int64_t len = 0;
+    int rc = uvcio_read_text_file(path, &text, &len);
+    if (rc) return rc;
+    std::map<std::string, int32_t> tid_of;
+    for (int32_t i = 0; i < n_contigs; i++) tid_of[contig_names[i]] = i;
+    uvcio_tumor_vcf *v = new uvcio_tumor_vcf();
+    struct Rec { int32_t tid; UvcTumorKey k; std::string col; int64_t ord; };
+    std::vector<Rec> recs;
+    std::string err;
+    const char *p = text, *end = text + len;
+    int64_t lineno = 0;
+    while (p < end && err.empty()) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        const char *line = p; p = nl ? nl + 1 : end; lineno++;
+        if (le > line && le[-1] == '\r') le--;
+        if (le == line) continue;
+        if (line[0] == '#') {
+            if (le - line > 6 && !strncmp(line, "#CHROM", 6)) { const char *t = le; int tabs = 0; for (const char *q = line; q < le; q++) if (*q == '\t') tabs++; while (t > line && t[-1] != '\t') t--; v->sample = (tabs >= 9 ? std::string(t, le) : std::string()); }
+            continue;
+        }
+        const char *f[11]; int nf = 0; f[nf++] = line;
+        for (const char *q = line; q < le && nf < 11; q++) if (*q == '\t') f[nf++] = q + 1;
+        if (nf < 10) continue;   // no sample column: nothing to rescue
+        auto fld = [&](int i) { return std::string(f[i], (i + 1 < nf ? f[i + 1] - 1 : le)); };
+        const std::string chrom = fld(0), ref = fld(3), alt = fld(4), fmt = fld(8), smp = fld(9);
+        auto ti = tid_of.find(chrom);
+        if (ti == tid_of.end()) continue;   // a contig the BAM does not have can never be asked for
+        // symbolic alleles: only <NON_REF> and <ADDITIONAL_INDEL_CANDIDATE> pass, and only when the tumor FORMAT is carried over (main.cpp:265-272)
+        bool skip = false;
+        {   size_t a = 0;
+            while (a <= alt.size()) { size_t c = alt.find(',', a); if (c == std::string::npos) c = alt.size();
+                const std::string one = alt.substr(a, c - a);
+                if (!one.empty() && one[0] == '<' && ((one != "<NON_REF>" && one != "<ADDITIONAL_INDEL_CANDIDATE>") || !is_tumor_format_retrieved)) skip = true;
+                a = c + 1; } }
+        if (skip) continue;
+        // FORMAT keys -> sample values
+        std::vector<std::pair<const char *, const char *>> keys, vals;
+        { const char *a = fmt.data(), *z = a + fmt.size(); while (a <= z) { const char *c = a; while (c < z && *c != ':') c++; keys.emplace_back(a, c); a = c + 1; } }
+        { const char *a = smp.data(), *z = a + smp.size(); while (a <= z) { const char *c = a; while (c < z && *c != ':') c++; vals.emplace_back(a, c); a = c + 1; } }
+        auto get = [&](const char *name, int32_t *dst, int cap) -> int {   // number of values, 0 = tag absent, -1 = "."
+            const size_t nl2 = strlen(name);
+            for (size_t k = 0; k < keys.size() && k < vals.size(); k++) if ((size_t)(keys[k].second - keys[k].first) == nl2 && !memcmp(keys[k].first, name, nl2)) return parse_ints(vals[k].first, vals[k].second, dst, cap);
+            return 0;
+        };
+        int32_t a2[4];
+        if (get("VTI", a2, 4) != 2) continue;   // valsize <= 0 -> continue (main.cpp:275)
+        Rec r; memset(&r.k, 0, sizeof(r.k));
+        r.tid = ti->second; r.ord = (int64_t)recs.size(); r.col = smp;
+        const int symbol = a2[1];
+        const long pos0 = strtol(fld(1).c_str(), nullptr, 10) - 1;   // line->pos
+        const bool at_pos = (symbol <= UVC_BASE_NN || symbol == UVC_MGVCF_SYMBOL || symbol == UVC_ADDITIONAL_INDEL_CANDIDATE_SYMBOL);   // isSymbolSubstitution covers BASE_A .. BASE_NN
+        r.k.refpos = (int32_t)(at_pos ? pos0 : pos0 + 1); r.k.symbol = symbol;
+        if (symbol != UVC_MGVCF_SYMBOL && symbol != UVC_ADDITIONAL_INDEL_CANDIDATE_SYMBOL) {
+            auto need = [&](const char *name, int n_expect, int32_t *dst) { if (get(name, dst, 4) != n_expect && err.empty()) err = std::string("FORMAT/") + name + " of line " + std::to_string(lineno) + " does not have " + std::to_string(n_expect) + " integers (main.cpp:294-372 asserts it)"; };
+            need("BDPb", 2, a2); r.k.BDP = a2[0] + a2[1];
+            need("bDPf", 2, a2); r.k.bDP = a2[1]; need("bDPr", 2, a2); r.k.bDP += a2[1];
+            need("CDP1x", 1, a2); r.k.CDP1x = a2[0]; need("cDP1x", 2, a2); r.k.cDP1x = a2[1];
+            need("cVQ1", 2, a2); r.k.cVQ1 = a2[1]; need("cPCQ1", 2, a2); r.k.cPCQ1 = a2[1];
+            need("CDP2x", 1, a2); r.k.CDP2x = a2[0]; need("cDP2x", 2, a2); r.k.cDP2x = a2[1];
+            need("cVQ2", 2, a2); r.k.cVQ2 = a2[1]; need("cPCQ2", 2, a2); r.k.cPCQ2 = a2[1];
+            need("bNMQ", 2, a2); r.k.bNMQ = a2[1]; need("vHGQ", 1, a2); r.k.vHGQ = a2[0];
+            need("CDP1b", 2, a2); r.k.tDP = a2[0] + a2[1];
+            need("cDP1f", 2, a2); r.k.tAD0 = a2[0]; r.k.tAD1 = a2[1]; need("cDP1r", 2, a2); r.k.tAD0 += a2[0]; r.k.tAD1 += a2[1];
+            need("CDP2b", 2, a2); r.k.t2DP = a2[0] + a2[1];
+            if (symbol >= UVC_LINK_D3P && symbol <= UVC_LINK_I1)   // the InDel string of the record: REF / ALT without their common head (main.cpp:867-880)
+                r.k.indel_len = (int32_t)(ref.size() > alt.size() ? ref.size() - alt.size() : alt.size() - ref.size());
+        }
+        for (size_t k = 0; k < keys.size(); k++) if ((keys[k].second - keys[k].first) == 5 && !memcmp(keys[k].first, "_C2XP", 5)) r.k.tier2 = 1;   // enable_tier2_consensus_format_tags, main.cpp:386-388
+        recs.push_back(std::move(r));
+    }
+    free(text);
+    if (!err.empty()) { delete v; return fail(UVCGPU_EINVAL, err); }
+    std::stable_sort(recs.begin(), recs.end(), [](const Rec &a, const Rec &b) {
+        if (a.tid != b.tid) return a.tid < b.tid;
+        if (a.k.refpos != b.k.refpos) return a.k.refpos < b.k.refpos;
+        return a.k.symbol < b.k.symbol; });
+    v->tid_first.assign((size_t)n_contigs + 1, 0);
+    for (const Rec &r : recs) { v->tid.push_back(r.tid); v->keys.push_back(r.k); v->cols_text.push_back(r.col); v->tid_first[(size_t)r.tid + 1]++; }
+    for (int32_t i = 0; i < n_contigs; i++) v->tid_first[(size_t)i + 1] += v->tid_first[(size_t)i];
+    for (const std::string &s : v->cols_text) v->cols.push_back(s.c_str());
+    *out = v;
+    return 0;
+}
+extern "C" const char *uvcio_tumor_vcf_sample_name(const uvcio_tumor_vcf_t *v) { return v ? v->sample.c_str() : ""; }
+extern "C" int64_t uvcio_tumor_vcf_n_records(const uvcio_tumor_vcf_t *v) { return v ? (int64_t)v->keys.size() : 0; }
+extern "C" int uvcio_tumor_vcf_fetch(const uvcio_tumor_vcf_t *v, int32_t tid, int32_t pos_beg, int32_t pos_end, const UvcTumorKey **keys, const char *const **cols, int64_t *n) {
+    if (!v || !n) return fail(UVCGPU_EINVAL, "bad argument");
+    *n = 0; if (keys) *keys = nullptr; if (cols) *cols = nullptr;
+    if (tid < 0 || (size_t)tid + 1 >= v->tid_first.size()) return 0;
+    const int64_t lo0 = v->tid_first[(size_t)tid], hi0 = v->tid_first[(size_t)tid + 1];
+    const auto b = v->keys.begin();
+    const int64_t lo = std::lower_bound(b + lo0, b + hi0, pos_beg, [](const UvcTumorKey &k, int32_t p) { return k.refpos < p; }) - b;
+    const int64_t hi = std::upper_bound(b + lo, b + hi0, pos_end, [](int32_t p, const UvcTumorKey &k) { return p < k.refpos; }) - b;
+    *n = hi - lo;
+    if (*n > 0) { if (keys) *keys = v->keys.data() + lo; if (cols) *cols = v->cols.data() + lo; }
+    return 0;
+}
+extern "C" void uvcio_tumor_vcf_close(uvcio_tumor_vcf_t *v) { delete v; }

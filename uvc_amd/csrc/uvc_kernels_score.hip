@@ -632,7 +632,7 @@ DEV void calc_qual(const RegionDev &R, const UvcParams &P, const Tot &T, const A
 
 // ------------------------------------------------------------------------------------------------
 struct ScoreCtx {
-    int pos_beg, pos_end, all_out, is_amplicon;
+    int pos_beg, pos_end, all_out, is_amplicon, base_at_beg;
     const UvcIndelAllele *alleles; long long n_alleles;   // sorted by (refpos, symbol): the region's own InDel alleles, or the caller's where it listed any
     const UvcGapRow *gap_rows; const uint8_t *gap_seq;   // the allele table rows (text order of InDel strings in k_call)
     const int32_t *allele_rows;                           // parallel: row of uvcgpu_region_indel_alleles that carries the allele's string, or -1
@@ -701,7 +701,7 @@ __global__ void __launch_bounds__(256) k_score_count(RegionDev R, UvcParams P, S
     if (g >= ngroups) return;
     const int zpos = C.pos_beg + (int)(g >> 1), st = (int)(g & 1);
     int n = 0;
-    if (!(zpos == C.pos_beg && st == UVC_BASE_SYMBOL)) {
+    if (!(zpos == C.pos_beg && st == UVC_BASE_SYMBOL && !C.base_at_beg)) {   // main.cpp:643
         const int refpos = (st == UVC_BASE_SYMBOL ? zpos - 1 : zpos);
         const int64_t x = refpos - R.beg;
         const int refsymbol = group_refsymbol(R, zpos, st);
@@ -1140,7 +1140,7 @@ __global__ void __launch_bounds__(128) k_call(RegionDev R, UvcParams P, ScoreCtx
 extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles, const int32_t *d_allele_rows, int64_t n_alleles,
                                 const UvcGapRow *d_gap_rows, const uint8_t *d_gap_seq, const UvcTumorKey *d_tkeys, int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch /* 2*ngroups + nblocks + 2 words + ngroups ints */, hipStream_t s) {
     ScoreCtx C;
-    C.pos_beg = req->pos_beg; C.pos_end = req->pos_end; C.all_out = (req->all_out || P->should_output_all) ? 1 : 0; C.is_amplicon = req->is_amplicon;
+    C.pos_beg = req->pos_beg; C.pos_end = req->pos_end; C.all_out = (req->all_out || P->should_output_all) ? 1 : 0; C.is_amplicon = req->is_amplicon; C.base_at_beg = req->base_at_pos_beg ? 1 : 0;
     C.alleles = d_alleles; C.allele_rows = d_allele_rows; C.n_alleles = n_alleles; C.gap_rows = d_gap_rows; C.gap_seq = d_gap_seq; C.tkeys = d_tkeys; C.n_tkeys = (d_tkeys ? req->n_tumor_keys : 0); C.fields = d_fields; C.capacity = capacity;
     const long long ngroups = 2LL * (C.pos_end - C.pos_beg);
     if (ngroups <= 0) return 0;

@@ -375,7 +375,7 @@ struct Rows {   // uvcgpu_region_indel_alleles
 
 extern "C" const char *uvcgpu_vcf_format_keys(int32_t with_tier2) { return g_keys[with_tier2 ? 1 : 0].c_str(); }
 
-extern "C" int uvcgpu_vcf_header(const UvcParams *P, const char *sample, const char *const *names, const int64_t *lens, int32_t n_contigs, char *dst, int64_t cap, int64_t *len) {
+extern "C" int uvcgpu_vcf_header(const UvcParams *P, const char *sample, const char *tumor_sample, const char *const *names, const int64_t *lens, int32_t n_contigs, char *dst, int64_t cap, int64_t *len) {
     if (!P || !len || (n_contigs > 0 && (!names || !lens))) return uvcgpu_fail_(UVCGPU_EINVAL, "bad argument");
     std::string h = "##fileformat=VCFv4.2\n";
     for (int i = 0; i < n_contigs; i++) h += std::string("##contig=<ID=") + names[i] + ",length=" + std::to_string((long long)lens[i]) + ">\n";
@@ -423,16 +423,21 @@ extern "C" int uvcgpu_vcf_header(const UvcParams *P, const char *sample, const c
     h += "##phasing=partial\n";
     h += std::string("##variantCallerInferredParameters=(inferred_sequencing_platform=") + (P->inferred_sequencing_platform == UVC_PLATFORM_IONTORRENT ? "IonTorrent" : "Illumina/BGI")
        + ",central_readlen=" + std::to_string(P->central_readlen) + ")\n";
-    h += std::string("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t") + (sample ? sample : "SAMPLE") + "\n";
+    h += std::string("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t") + (sample ? sample : "SAMPLE") + ((tumor_sample && *tumor_sample) ? std::string("\t") + tumor_sample : std::string()) + "\n";
     *len = (int64_t)h.size();
     if (!dst || cap < (int64_t)h.size()) return uvcgpu_fail_(UVCGPU_ENOMEM, "destination too small");
     memcpy(dst, h.data(), h.size());
     return 0;
 }
 
-extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, const UvcScoreOut *scored, int32_t pos_beg, int32_t pos_end,
-                                         const UvcTumorKey *tkeys, int64_t n_tkeys, char *dst, int64_t cap, int64_t *len) {
+extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, const UvcScoreOut *scored, const UvcScoreRequest *req,
+                                         char *dst, int64_t cap, int64_t *len) {
     if (!r || !tname || !len || !scored || (scored->n_records > 0 && !scored->fields) || scored->n_records > scored->capacity) return uvcgpu_fail_(UVCGPU_EINVAL, "bad argument");
+    int32_t pos_beg = (req ? req->pos_beg : -1), pos_end = (req ? req->pos_end : -1);
+    const bool base_at_beg = (req && req->base_at_pos_beg && pos_beg >= 0);
+    const int32_t region_beg = (req ? req->region_beg : 0);
+    const UvcTumorKey *tkeys = (req ? req->tumor_keys : nullptr); const int64_t n_tkeys = (req ? req->n_tumor_keys : 0);
+    const char *const *tcols = (req && tkeys ? req->tumor_sample_columns : nullptr);
     const int32_t *recs = scored->fields; const int64_t n = scored->n_records, stride = scored->capacity;
     { const int rc0 = uvcgpu_region_fetch_columns(r, nullptr, 0, nullptr); if (rc0) return rc0; }   // accumulated, planes not released
     const UvcParams &P = *uvcgpu_region_params(r);
@@ -608,6 +613,7 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
                     break; }
                 }
             }
+            if (T && tcols && tcols[tk]) { out += '\t'; out += tcols[tk]; }   // is_tumor_format_retrieved: bcf1_to_string of the tumor record, main.hpp:6269
             out += '\n';
             rec_lines.emplace_back(F(ia, UVC_O_refpos) + (is_base(F(ia, UVC_O_symbol)) ? 1 : 0), std::move(out));
         }
@@ -618,7 +624,7 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
         if (pos_beg < 0) { pos_beg = beg + 1; pos_end = end; }   // the default range of uvcgpu_region_score
         const bool want_block = (P.outvar_flag & 0x8) != 0, want_cand = (P.outvar_flag & 0x10) != 0;
         std::vector<std::pair<int32_t, std::string>> pos_lines;
-        if ((want_block || want_cand) && pos_end > pos_beg + 1) {
+        if ((want_block || want_cand) && pos_end > pos_beg + (base_at_beg ? 0 : 1)) {
             const int32_t state_end = end + 1;                                   // getUnifiedExcluEndPosition (main.cpp:569)
             const int32_t s_beg = pos_beg - 1, s_end = std::min<int64_t>((int64_t)pos_end - 1 + 1001, state_end);
             std::vector<int32_t> st((size_t)10 * (size_t)std::max(0, s_end - s_beg));
@@ -626,15 +632,26 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
             auto S = [&](int32_t refpos, int q) { return st[(size_t)10 * (size_t)(refpos - s_beg) + (size_t)q]; };
             auto refchar = [&](int64_t off) { return (off >= 0 && off < (int64_t)ref.size()) ? ref[(size_t)off] : 'N'; };
             auto code_of = [](char c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; case 'I': case 'i': return 6; case '-': case '_': return 9; default: return 4; } };
+            // normal sample with the tumor's FORMAT carried over: the tumor's own line of this position, if it has exactly one
+            const bool tcols_pos = (P.tumor_vcf_is_provided && tcols != nullptr);
+            auto tumor_column = [&](int32_t refpos, int32_t symbol, const char *if_many, const char *if_none) -> std::string {
+                int64_t lo = 0, hi = n_tkeys;
+                while (lo < hi) { const int64_t mid = (lo + hi) >> 1; const UvcTumorKey &a = tkeys[mid]; if (a.refpos < refpos || (a.refpos == refpos && a.symbol < symbol)) lo = mid + 1; else hi = mid; }
+                int64_t e = lo; while (e < n_tkeys && tkeys[e].refpos == refpos && tkeys[e].symbol == symbol) e++;
+                if (e == lo) return if_none;
+                if (e - lo != 1 || !tcols[lo]) return if_many;
+                return std::string("\t") + tcols[lo];
+            };
             int32_t prev_track = 0;
+            if (base_at_beg && want_cand) { std::string ru0; int32_t rcn0 = 0; repeat_context(ref, pos_beg - 1 - beg, P.indel_str_repeatsize_max, ru0, rcn0); prev_track = rcn0 * (int32_t)ru0.size(); }   // the track of the zerobased_pos in front, which the adjacent region iterated
             for (int32_t z = pos_beg; z < pos_end; z++) {
                 std::string ru; int32_t rcn = 0;
                 if (want_cand) repeat_context(ref, z - beg, P.indel_str_repeatsize_max, ru, rcn);
                 const int32_t curr_track = rcn * (int32_t)ru.size();
-                if (z != pos_beg) {
+                if (z != pos_beg || base_at_beg) {
                     const int32_t refpos = z - 1;
                     std::string line;
-                    if (want_block && ((refpos % 1000) == 0 || refpos == beg)) {
+                    if (want_block && ((refpos % 1000) == 0 || refpos == region_beg)) {   // main.cpp:655-656: refpos == incluBegPosition
                         // runs of similar depth and hom-ref quality over the next <= 1001 positions, LINK then BASE sub-position
                         const int32_t rp2end = std::min<int64_t>((int64_t)refpos + 1001, state_end);
                         int32_t pb = 0, pc = 0, p12 = 0, pq = INT32_MAX / 2 + 1; const int32_t init_q = INT32_MAX / 2 + 1;
@@ -650,7 +667,9 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
                         }
                         const char rc1 = refchar((int64_t)refpos - beg);
                         line += tname; line += '\t'; put(line, (int64_t)refpos + 1); line += "\t.\t"; line += rc1; line += "\t<NON_REF>\t.\t.\tMGVCF_BLOCK\tGT:VTI:POS_VT_BDP_CDP_HomRefQ\t.:";
-                        put(line, code_of(rc1)); line += ",15:"; line += body; put(line, rp2end); line += '\n';
+                        put(line, code_of(rc1)); line += ",15:"; line += body; put(line, rp2end);
+                        if (tcols_pos) line += tumor_column(refpos, UVC_MGVCF_SYMBOL, "\t.:.,.:-1", "\t.:.,.:.");   // main.cpp:739-757
+                        line += '\n';
                     }
                     if (want_cand) {
                         const int32_t ADP = S(refpos, 8), aCDP = S(refpos, 9);
@@ -659,7 +678,9 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
                         if ((long_track || clip_region) && ADP >= 2 * P.microadjust_alignment_clip_min_count) {
                             const char rc1 = refchar((int64_t)refpos - beg);
                             line += tname; line += '\t'; put(line, (int64_t)refpos + 1); line += "\t.\t"; line += rc1; line += "\t<ADDITIONAL_INDEL_CANDIDATE>\t.\t.\tADDITIONAL_INDEL_CANDIDATE;RU=";
-                            line += ru; line += ";RC="; put(line, rcn); line += "\tGT:VTI:clipDP\t.:"; put(line, code_of(rc1)); line += ",16:"; put(line, ADP); line += ','; put(line, aCDP); line += '\n';
+                            line += ru; line += ";RC="; put(line, rcn); line += "\tGT:VTI:clipDP\t.:"; put(line, code_of(rc1)); line += ",16:"; put(line, ADP); line += ','; put(line, aCDP);
+                            if (tcols_pos) line += tumor_column(refpos, UVC_ADDITIONAL_INDEL_CANDIDATE_SYMBOL, "\t.:-1,-1:-1,-1", "\t.:.,.:.,.");   // main.cpp:784-798
+                            line += '\n';
                         }
                     }
                     if (!line.empty()) pos_lines.emplace_back(z, std::move(line));

@@ -43,6 +43,14 @@ def dll():
         d.uvcio_fasta_seq_len.restype, d.uvcio_fasta_seq_len.argtypes = C.c_int64, [C.c_void_p, C.c_char_p]
         d.uvcio_fasta_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_char_p]
         d.uvcio_fasta_close.argtypes = [C.c_void_p]
+        d.uvcio_bam_region_bytes.restype, d.uvcio_bam_region_bytes.argtypes = C.c_int64, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64]
+        d.uvcio_plan_shards.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+        d.uvcio_bgzf_concat.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_int32]
+        d.uvcio_tumor_vcf_open.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.c_int32]
+        d.uvcio_tumor_vcf_sample_name.restype, d.uvcio_tumor_vcf_sample_name.argtypes = C.c_char_p, [C.c_void_p]
+        d.uvcio_tumor_vcf_n_records.restype, d.uvcio_tumor_vcf_n_records.argtypes = C.c_int64, [C.c_void_p]
+        d.uvcio_tumor_vcf_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        d.uvcio_tumor_vcf_close.argtypes = [C.c_void_p]
         _dll = d
     return _dll
 
@@ -175,3 +183,35 @@ def plan_regions(tid, pos, endpos, flag, target_lens, nthreads=1, mem_per_thread
     out = (UvcRegionCut * max(1, n.value))()
     _check(d.uvcio_plan_regions(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, len(a[0]), tl.ctypes.data, len(tl), nthreads, mem_per_thread_mb, out, n.value, C.byref(n)))
     return [dict(tid=c.tid, beg=c.beg, end=c.end, flag=c.flag, batch=c.batch, n_reads=c.n_reads) for c in out[:n.value]]
+
+
+class TumorVcf:
+    """The tumor VCF of a T/N pair as the normal pass reads it (uvcio_tumor_vcf_*: rescue_variants_from_vcf, main.cpp:183-398)."""
+
+    def __init__(self, path, contig_names, is_tumor_format_retrieved=True):
+        self.h = C.c_void_p()
+        names = (C.c_char_p * max(1, len(contig_names)))(*[n.encode() for n in contig_names])
+        _check(dll().uvcio_tumor_vcf_open(C.byref(self.h), path.encode(), names, len(contig_names), int(is_tumor_format_retrieved)))
+        self.sample = dll().uvcio_tumor_vcf_sample_name(self.h).decode()
+        self.n_records = dll().uvcio_tumor_vcf_n_records(self.h)
+
+    def fetch(self, tid, pos_beg, pos_end):
+        """-> (ctypes array of UvcTumorKey or None, list of sample-column strings): the records with pos_beg <= symbolpos <= pos_end."""
+        keys, cols, n = C.c_void_p(), C.c_void_p(), C.c_int64(0)
+        _check(dll().uvcio_tumor_vcf_fetch(self.h, tid, pos_beg, pos_end, C.byref(keys), C.byref(cols), C.byref(n)))
+        if n.value == 0:
+            return None, []
+        arr = (_ffi.UvcTumorKey * n.value).from_address(keys.value)
+        texts = [s.decode() for s in (C.c_char_p * n.value).from_address(cols.value)]
+        return arr, texts
+
+    def close(self):
+        if self.h:
+            dll().uvcio_tumor_vcf_close(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

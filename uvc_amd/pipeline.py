@@ -23,9 +23,17 @@ SYMBOL_DESC = ["A", "C", "G", "T", "N", "*", "<LR>", "<LD3P>", "<LD2>", "<LD1>",
 FILTERS = ["Q10", "Q20", "Q30", "Q40", "Q50", "Q60", "PASS"]
 
 
-def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None, molecule_tag=0, disable_duplex=0, correct_bq=True, all_out=False, keep_handle=False, reuse=None, vcf=False):
+def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None, molecule_tag=0, disable_duplex=0, correct_bq=True, all_out=False, keep_handle=False, reuse=None, vcf=False,
+                continues=False, has_next=False, region_beg=None, tumor_vcf=None):
     """Scores [beg, end) of `chrom`.  Returns None when no read passes the filters (process_batch returns -1, main.cpp:520-523), else a
     dict: records (field -> int32 array), alleles (InDel allele rows), score range, region handle (if keep_handle).
+    Tiles of one stretch: the reference scores zerobased_pos rpos_beg .. rpos_end inclusive and skips the BASE sub-position of the first
+    (main.cpp:608, 643), so two adjacent regions both write the LINK records of their shared end point.  Here every zerobased_pos has one
+    owner: `has_next` (an adjacent tile [end, ..) follows) leaves zerobased_pos `end` to that tile, and `continues` (an adjacent tile
+    [.., beg) is in front) makes this one score `beg` completely, BASE sub-position included (UvcScoreRequest::base_at_pos_beg) -- a run of
+    tiles writes the records of one uncut region.  `region_beg`: begin of the BED line / contig range the run belongs to (incluBegPosition
+    of main.cpp:655-656, default `beg`).  `tumor_vcf`: normal sample of a T/N pair -- the tumor pass's VCF as `uvc_amd.io.TumorVcf` (its records
+    of this region become UvcScoreRequest::tumor_keys; `params.tumor_vcf_is_provided` must be set).
     `reuse`: a dict the caller keeps between calls; the region handle lives in it and is reset for every new region instead of being
     created and destroyed (its device buffers survive while the regions do not grow)."""
     import os, time
@@ -72,12 +80,19 @@ def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None
         R.correct_bq()
     R.accumulate()
     is_amplicon = (g["n_amplicon"] * 2 > g["n_kept"])                                  # !is_by_capture, main.cpp:507-508
-    score_range = (rpos_beg, min(rpos_end + 1, ext_end - 0))
-    rec = R.score(all_out=all_out, pos_beg=score_range[0], pos_end=score_range[1], is_amplicon=bool(is_amplicon))
+    last_excl = min(end, bam_end + 1) if has_next else min(rpos_end + 1, ext_end)      # zerobased_pos `end` belongs to the tile behind, if there is one
+    skw = dict(pos_beg=rpos_beg, pos_end=last_excl, base_at_pos_beg=bool(continues and rpos_beg == beg and beg > ext_beg), region_beg=(beg if region_beg is None else region_beg))
+    score_range = (skw["pos_beg"], skw["pos_end"])
+    if score_range[1] <= score_range[0]:
+        return None
+    tk, tcols = None, None
+    if tumor_vcf is not None:                                                          # the tumor records inside this region (tkis_beg .. tkis_end, main.cpp:532-533)
+        tk, tcols = tumor_vcf.fetch(tid, ext_beg, ext_end)
+    rec = R.score(all_out=all_out, is_amplicon=bool(is_amplicon), tumor_keys=tk, **skw)
     lap("bq+accumulate+score")
-    out = dict(records=rec, alleles=R.indel_alleles(), rpos=(rpos_beg, rpos_end), ext=(ext_beg, ext_end), n_reads=int(g["n_kept"]), n_fams=int(g["n_fams"]), chrom=chrom, refseq=refseq)
+    out = dict(records=rec, alleles=R.indel_alleles(), rpos=(rpos_beg, rpos_end), ext=(ext_beg, ext_end), n_reads=int(g["n_kept"]), n_fams=int(g["n_fams"]), chrom=chrom, refseq=refseq, score_range=score_range)
     if vcf:
-        out["vcf"] = R.vcf_records(chrom, rec, pos_beg=score_range[0], pos_end=score_range[1])          # the record lines of append_vcf_record (uvcgpu_region_vcf_records), before the handle moves on
+        out["vcf"] = R.vcf_records(chrom, rec, tumor_keys=tk, tumor_sample_columns=tcols, **skw)          # the record lines of append_vcf_record (uvcgpu_region_vcf_records), before the handle moves on
     if keep_handle:
         out["region"] = R
     elif reuse is None:
@@ -88,13 +103,22 @@ def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None
     return out
 
 
-def call_contig(lib, bam, fasta, chrom, beg=0, end=None, tile=1_000_000, workers=1, **kw):
+def contig_tiles(beg, end, tile):
+    """The fixed tiles of [beg, end) with their ownership flags (see call_region): list of dicts beg, end, continues, has_next, region_beg."""
+    return [dict(beg=b, end=min(b + tile, end), continues=(b != beg), has_next=(b + tile < end), region_beg=beg) for b in range(beg, end, tile)]
+
+
+def call_contig(lib, bam, fasta, chrom, beg=0, end=None, tile=1_000_000, workers=1, device=None, only=None, **kw):
     """Tiles [beg, end) of a contig (default: all of it) and yields the result of every tile that has reads, in order.  The reference cuts
-    its regions by read and position counts (SamIter, grouping.cpp:28-67, 157-314); results at a position do not depend on the cut because
-    every region re-reads its own +-2000 bp halo, so fixed tiles of the size the state slab is laid out for are used here.
+    its regions by read and position counts (SamIter, grouping.cpp:28-67, 157-314) and scores the shared end point of two adjacent
+    regions in both; here fixed tiles of the size the state slab is laid out for are used and every zerobased_pos has one owner
+    (`continues` of call_region), so that the tiles of [beg, end) together give the records of one uncut region [beg, end).
     workers > 1: that many tiles in flight on host threads, each with its own file handles and region handle (the library calls release
     the GIL; the reference runs process_batch on `nthreads` OpenMP threads the same way, main.cpp:1478-1520).  `bam` / `fasta` may be
-    paths or open handles; with workers > 1 they must be paths."""
+    paths or open handles; with workers > 1 they must be paths.  `device`: the GPU the worker threads bind to (uvcgpu_init is per host
+    thread); None = the device the calling thread initialised the library with is NOT inherited, so pass it when it is not 0.
+    `only`: indices into the tile list -- the shard of a multi-process run (uvc_amd.shard.plan_contiguous): ownership is a property of the
+    list, not of who runs a tile, so the shards' outputs concatenate to the single-process output."""
     import threading
     from concurrent.futures import ThreadPoolExecutor
     paths = (bam, fasta) if isinstance(bam, str) else None
@@ -111,13 +135,17 @@ def call_contig(lib, bam, fasta, chrom, beg=0, end=None, tile=1_000_000, workers
     b0 = handles()[0]
     tlen = b0.refs[b0.tid(chrom)][1]
     end = tlen if end is None else min(end, tlen)
-    starts = list(range(beg, end, tile))
+    starts = contig_tiles(beg, end, tile)
+    if only is not None:
+        starts = [starts[i] for i in only]
 
-    def one(b):
+    def one(t):
         hb, hf = handles()
         if not hasattr(local, "reuse"):
             local.reuse = {}                                   # one region handle per worker, reset from tile to tile
-        return call_region(lib, hb, hf, chrom, b, min(b + tile, end), reuse=local.reuse, **kw)
+            if device is not None and lib.prefix == "uvcgpu_" and lib.dll.uvcgpu_init(int(device)) != 0:   # hipSetDevice is per thread
+                raise RuntimeError(lib.last_error())
+        return call_region(lib, hb, hf, chrom, t["beg"], t["end"], reuse=local.reuse, continues=t["continues"], has_next=t["has_next"], region_beg=t["region_beg"], **kw)
     if workers <= 1:
         for b in starts:
             res = one(b)
@@ -155,13 +183,15 @@ def write_tsv(res, fh, kept_only=True, header=True):
             rec["cVQ1"][i], rec["cVQ2"][i], rec["TLODQ"][i], rec["NLODQ"][i], rec["germ_GT"][i], rec["germ_GQ"][i]))
 
 
-def write_vcf(lib, bam, fasta, chrom, beg, end, path, sample="SAMPLE", params=None, **kw):
+def write_vcf(lib, bam, fasta, chrom, beg, end, path, sample="SAMPLE", params=None, tumor_vcf=None, **kw):
     """BAM + FASTA -> VCF: the header (uvcgpu_vcf_header) and the record lines of every tile, through the BGZF writer when `path` ends in
     .gz (what the reference does with bgzf_write, main.cpp:1196-1215, 1571-1583), else as plain text ("-" = stdout).  Returns the number
     of record lines."""
     p = params if params is not None else region.default_params(lib)
     b = bam if not isinstance(bam, str) else uio.Bam(bam)
-    header = region.vcf_header(lib, p, sample, [(name, ln) for name, ln in b.refs])
+    header = region.vcf_header(lib, p, sample, [(name, ln) for name, ln in b.refs], tumor_sample=(tumor_vcf.sample if tumor_vcf is not None else None))
+    if tumor_vcf is not None:
+        kw["tumor_vcf"] = tumor_vcf
     sink = uio.BgzfWriter(path) if path.endswith(".gz") else (sys.stdout if path == "-" else open(path, "w"))
     n = 0
     try:

@@ -99,17 +99,19 @@ def vcf_format_keys(lib, tier2=False):
     return fn(int(tier2)).decode()
 
 
-def vcf_header(lib, params, sample, contigs):
-    """##-lines and the #CHROM line (uvcgpu_vcf_header); contigs = [(name, length), ...]."""
+def vcf_header(lib, params, sample, contigs, tumor_sample=None):
+    """##-lines and the #CHROM line (uvcgpu_vcf_header); contigs = [(name, length), ...]; tumor_sample: the second sample column of a
+    normal-sample VCF that carries the tumor's FORMAT over (is_tumor_format_retrieved)."""
     fn = getattr(lib.dll, "uvcgpu_vcf_header")
     fn.restype = C.c_int
-    fn.argtypes = [C.POINTER(_ffi.UvcParams), C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    fn.argtypes = [C.POINTER(_ffi.UvcParams), C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     names = (C.c_char_p * max(1, len(contigs)))(*[c[0].encode() for c in contigs])
     lens = (C.c_int64 * max(1, len(contigs)))(*[int(c[1]) for c in contigs])
     ln = C.c_int64(0)
-    fn(C.byref(params), sample.encode(), names, lens, len(contigs), None, 0, C.byref(ln))
+    ts = tumor_sample.encode() if tumor_sample else None
+    fn(C.byref(params), sample.encode(), ts, names, lens, len(contigs), None, 0, C.byref(ln))
     dst = C.create_string_buffer(max(1, ln.value))
-    rc = fn(C.byref(params), sample.encode(), names, lens, len(contigs), dst, ln.value, C.byref(ln))
+    rc = fn(C.byref(params), sample.encode(), ts, names, lens, len(contigs), dst, ln.value, C.byref(ln))
     if rc:
         raise UvcError(rc, lib.last_error())
     return dst.raw[:ln.value].decode()
@@ -197,18 +199,31 @@ class Region:
             out.append(dict(refpos=r.refpos, symbol=r.symbol, strand=r.strand, len=r.len, seq=text, bAD1=r.bAD1, cAD1=r.cAD1, c2AD=r.c2AD, c2dAD=r.c2dAD))
         return out
 
-    def score(self, all_out=False, pos_beg=-1, pos_end=-1, is_amplicon=False, indel_alleles=None, capacity=None, copy=True, tumor_keys=None, release_state=False):
+    @staticmethod
+    def make_request(all_out=False, pos_beg=-1, pos_end=-1, is_amplicon=False, indel_alleles=None, tumor_keys=None, release_state=False, base_at_pos_beg=False, region_beg=0,
+                     tumor_sample_columns=None):
+        """UvcScoreRequest + the ctypes arrays it points into (keep both alive for the call)."""
         req = _ffi.UvcScoreRequest()
         req.pos_beg, req.pos_end, req.all_out, req.is_amplicon = pos_beg, pos_end, int(all_out), int(is_amplicon)
         req.release_state = int(release_state)   # the planes may be zeroed for the next accumulate as soon as the scoring kernels are done
+        req.base_at_pos_beg, req.region_beg = int(base_at_pos_beg), int(region_beg)
         arr = None
         if indel_alleles:
             arr = (_ffi.UvcIndelAllele * len(indel_alleles))(*[_ffi.UvcIndelAllele(*a) for a in indel_alleles])
             req.n_indel_alleles, req.indel_alleles = len(indel_alleles), C.cast(arr, C.c_void_p)
         tk = None
-        if tumor_keys:   # T/N: (refpos, symbol, cDP1x, CDP1x, bDP, BDP, tier2, indel_len) tuples, sorted by (refpos, symbol)
-            tk = (_ffi.UvcTumorKey * len(tumor_keys))(*[_ffi.UvcTumorKey(*t) for t in tumor_keys])
-            req.n_tumor_keys, req.tumor_keys = len(tumor_keys), C.cast(tk, C.c_void_p)
+        if tumor_keys is not None and len(tumor_keys):   # T/N: UvcTumorKey field tuples (or a ready ctypes array), sorted by (refpos, symbol)
+            tk = tumor_keys if isinstance(tumor_keys, C.Array) else (_ffi.UvcTumorKey * len(tumor_keys))(*[_ffi.UvcTumorKey(*t) for t in tumor_keys])
+            req.n_tumor_keys, req.tumor_keys = len(tk), C.cast(tk, C.c_void_p)
+        cols = None
+        if tk is not None and tumor_sample_columns:   # is_tumor_format_retrieved: the tumor's sample column of every key, appended by the record writer
+            assert len(tumor_sample_columns) == len(tk)
+            cols = (C.c_char_p * len(tk))(*[c.encode() if isinstance(c, str) else c for c in tumor_sample_columns])
+            req.tumor_sample_columns = C.cast(cols, C.c_void_p)
+        return req, (arr, tk, cols)
+
+    def score(self, all_out=False, pos_beg=-1, pos_end=-1, is_amplicon=False, indel_alleles=None, capacity=None, copy=True, tumor_keys=None, release_state=False, base_at_pos_beg=False, region_beg=0):
+        req, _keep = self.make_request(all_out, pos_beg, pos_end, is_amplicon, indel_alleles, tumor_keys, release_state, base_at_pos_beg, region_beg)
         if capacity is None:
             npos = (pos_end - pos_beg) if pos_beg >= 0 else self.npos
             capacity = 14 * (npos + 1) if all_out else max(4096, 4 * (npos + 1))
@@ -248,24 +263,22 @@ class Region:
         fn.restype, fn.argtypes = C.c_int32, [C.c_int32]
         return fn(_ffi.FIELD_GROUPS[group][0])
 
-    def vcf_records(self, contig_name, records, tumor_keys=None, pos_beg=-1, pos_end=-1):
+    def vcf_records(self, contig_name, records, tumor_keys=None, pos_beg=-1, pos_end=-1, base_at_pos_beg=False, region_beg=0, tumor_sample_columns=None):
         """The VCF lines (text) of the records `score()` returned that are written (out and keep set): uvcgpu_region_vcf_records.
-        Needs the planes, i.e. a score call without release_state."""
+        Needs the planes, i.e. a score call without release_state.  The keyword arguments repeat those of the score call."""
         fn = getattr(self.lib.dll, self.lib.prefix + "region_vcf_records")
         fn.restype = C.c_int
-        fn.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(_ffi.UvcScoreOut), C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        fn.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(_ffi.UvcScoreOut), C.POINTER(_ffi.UvcScoreRequest), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         n = len(records["refpos"])
         buf = np.ascontiguousarray(np.stack([np.asarray(records[name], dtype=np.int32) for name in _ffi.SCORE_FIELDS])) if n else np.zeros((_ffi.NUM_SCORE_FIELDS, 1), dtype=np.int32)
         so = _ffi.UvcScoreOut(max(n, 1), n, buf.ctypes.data)
-        tk, ntk = None, 0
-        if tumor_keys:
-            tk = (_ffi.UvcTumorKey * len(tumor_keys))(*[_ffi.UvcTumorKey(*t) for t in tumor_keys]); ntk = len(tumor_keys)
+        req, _keep = self.make_request(pos_beg=pos_beg, pos_end=pos_end, tumor_keys=tumor_keys, base_at_pos_beg=base_at_pos_beg, region_beg=region_beg, tumor_sample_columns=tumor_sample_columns)
         ln = C.c_int64(0)
-        rc = fn(self.h, contig_name.encode(), C.byref(so), pos_beg, pos_end, tk, ntk, None, 0, C.byref(ln))
+        rc = fn(self.h, contig_name.encode(), C.byref(so), C.byref(req), None, 0, C.byref(ln))
         if rc not in (0, -6):
             self._check(rc)
         dst = C.create_string_buffer(max(1, ln.value))
-        self._check(fn(self.h, contig_name.encode(), C.byref(so), pos_beg, pos_end, tk, ntk, dst, ln.value, C.byref(ln)))
+        self._check(fn(self.h, contig_name.encode(), C.byref(so), C.byref(req), dst, ln.value, C.byref(ln)))
         return dst.raw[:ln.value].decode()
 
     def _unpin_score_buf(self):

@@ -3,27 +3,40 @@
 `process_batch` regions are independent (main.cpp:458-475), so multi-GPU is plain data parallelism
 over regions: no collective on the data path.  Ranks only meet for the benchmark's barrier and the
 max-over-ranks clock (torch.distributed; backend "nccl" = RCCL on the GPU box, "gloo" in CPU tests).
-Assignment mirrors the reference's own balance rule -- reads AND positions (main.cpp:1390-1392) --
-with a greedy longest-processing-time pass over contiguous region runs.
+Assignment mirrors the reference's own balance rule -- reads AND positions (main.cpp:1390-1392): the ordered tile list is cut into
+contiguous runs of about equal cost (`plan_contiguous`, the same planner as `uvc1-mi355x --shard i/n`), so that the shard outputs
+concatenate in genome order like `bcftools concat -n` in uvcTN.sh:100 (`concat_bgzf`).
 """
 import os
 
 
-def plan_shards(region_costs, world_size):
-    """region_costs: list of (n_reads, n_positions).  Returns per-rank lists of region indices.
+def plan_contiguous(costs, n_shards):
+    """Cuts an ordered tile list into n_shards contiguous runs of about equal total cost (uvcio_plan_shards, the planner uvc1-mi355x
+    --shard i/n uses): returns the shard of every tile, non-decreasing, so that the shard outputs concatenate in tile order."""
+    import ctypes as C
+    import numpy as np
+    from . import io as uio
+    c = np.ascontiguousarray(costs, dtype=np.int64)
+    out = np.zeros(len(c), dtype=np.int32)
+    rc = uio.dll().uvcio_plan_shards(c.ctypes.data, len(c), int(n_shards), out.ctypes.data)
+    if rc != 0:
+        raise ValueError(uio.dll().uvcio_last_error().decode())
+    return out
 
-    Greedy LPT: regions sorted by cost descending go to the least-loaded rank; each rank's list is
-    then sorted so its output is a sequence of genome-ordered slices (host-side concatenation restores
-    the global order, like `bcftools concat -n` in uvcTN.sh:100)."""
-    cost = [r * 2 + p for r, p in region_costs]   # a read costs about as much as two positions of fixed overhead
-    order = sorted(range(len(cost)), key=lambda i: (-cost[i], i))
-    load = [0] * world_size
-    out = [[] for _ in range(world_size)]
-    for i in order:
-        k = min(range(world_size), key=lambda j: (load[j], j))
-        out[k].append(i)
-        load[k] += cost[i]
-    return [sorted(v) for v in out]
+
+def tile_costs(bam, tiles):
+    """Cost of every (tid, beg, end) tile as uvc1-mi355x prices it: compressed bytes the BAI linear index attributes to it + length / 8 + 1."""
+    from . import io as uio
+    return [int(uio.dll().uvcio_bam_region_bytes(bam.h, tid, beg, end)) + (end - beg) // 8 + 1 for tid, beg, end in tiles]
+
+
+def concat_bgzf(out_path, in_paths):
+    """bcftools concat -n (uvcTN.sh:100): the shard outputs one after the other, one end-of-file marker at the end."""
+    import ctypes as C
+    from . import io as uio
+    arr = (C.c_char_p * max(1, len(in_paths)))(*[p.encode() for p in in_paths])
+    if uio.dll().uvcio_bgzf_concat(out_path.encode(), arr, len(in_paths)) != 0:
+        raise IOError(uio.dll().uvcio_last_error().decode())
 
 
 def dist_env():
@@ -64,6 +77,14 @@ class Clock:
         t = torch.tensor([value], dtype=torch.float64, device=dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
+
+    def gather_objects(self, obj):
+        """Every rank's object on rank 0 (a list there, None elsewhere): the host-side gather of the shard outputs."""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world if self.rank == 0 else None
+        self.dist.gather_object(obj, out, dst=0)
+        return out
 
     def close(self):
         if self.dist is not None and self.dist.is_initialized():
