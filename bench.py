@@ -3,21 +3,35 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the whole hot path (accumulate P1..P5b + default-gate scoring, scored records
-copied back to the host) over one synthetic chr20-shaped 300x non-UMI tile that is already resident
-in HBM.  Every rank owns one GPU and its own tile (different seed): regions shard with no data-path
-collective, so scaling is weak.  value = ranks * tile positions * K / max-over-ranks wall time.
+A step = ONE TILE through the whole per-tile hot path, on a stream of DISTINCT synthetic chr20-shaped 300x non-UMI tiles (1 Mb each,
+`--tiles` of them, visited round-robin) whose raw UvcReadSoA columns and region side arrays are resident in HBM when the timed region
+starts:
+
+    uvcgpu_region_set_reads_device   the device half of set_reads: CIGAR facts + family / fragment nesting (uvc_prep.hip), the three
+                                     radix orders, k_pack_bq, k_aln_prelude (updateByAln's per-read prelude), k_build_p2list
+    uvcgpu_region_accumulate         P1 .. P5b
+    uvcgpu_region_score              default-gate scoring + calling, D2H of the records
+
+Tiles are software-pipelined over their handles (the next tile's preparation and accumulate are enqueued before the synchronous score of
+the current one), which is how a caller streams chr20 through the library.  Every rank owns one GPU and its own tiles (different seeds):
+regions shard with no data-path collective, scaling is weak.  value = ranks * tile positions * K / max-over-ranks wall time.
+`--gpus N` without a launcher starts its own N ranks (children are spawned before anything touches a GPU).
 
 Extra objects on the JSON line:
-  roofline      dominant kernel of the timed steps: algorithmic bytes per launch
-                / its HIP-event duration on the library's own stream, vs the 8 TB/s HBM peak.
-  cpu_baseline  the CPU oracle (a scalar port of the reference algorithm) on a bounded sample of the
-                same workload shape on the host cores (rank 0, N = 1 only).
+  roofline        dominant kernel of the timed steps: algorithmic bytes per launch / its HIP-event duration on the
+                  library's own stream, vs the 8 TB/s HBM peak; `traffic` is REPLAYED from the committed PMC passes (profiles/).
+  cpu_baseline    the CPU oracle (a scalar port of the reference algorithm) on a bounded sample of the same workload shape on the host
+                  cores (rank 0, N = 1 only).
+  pcie_inclusive  the same stream with the columns starting in (pinned) host memory: uvcgpu_region_set_reads copies them (650 MB per tile)
+                  before the device half runs.  Reported beside `value`, never as `value` (inputs resident in HBM is the metric's contract).
+  resident        one prepared tile accumulated + scored again and again with nothing overlapped (the round-1 figure): clean per-kernel
+                  durations without another tile's kernels beside them.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,6 +42,7 @@ sys.path.insert(0, ROOT)
 
 READ_LEN = 150
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+METRIC = "pileup positions scored/sec at 300x depth"
 
 
 def algorithmic_bytes_per_position(kernel, depth):
@@ -51,10 +66,10 @@ PROFILE_NAMES = {"k_p2_fast_link": ("k_p2_fast<true, false, true>", "k_p2_fast<t
                  "k_p2_slow_walk": ("k_p2_slow<true>",), "k_p2_slow_table": ("k_p2_slow<false>",), "k_frag": ("k_frag16<true>", "k_frag16<false>", "k_frag<true>", "k_frag<false>")}
 
 
-def measured_traffic(kernel, tile_kb, depth):
-    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/traffic_latest.json, made by
-    scripts/gpu_round_profile.sh: FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes), or None when the passes were taken on
-    another workload."""
+def replayed_traffic(kernel, tile_kb, depth):
+    """HBM-side bytes per launch of `kernel`, REPLAYED from the committed PMC passes (profiles/traffic_latest.json, made by
+    scripts/gpu_round_profile.sh: FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes) -- not measured in this run.  None when the passes were
+    taken on another workload."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if not os.path.exists(path):
         return None
@@ -70,16 +85,22 @@ def measured_traffic(kernel, tile_kb, depth):
         return None
 
 
-def run_cpu_baseline(depth, n_regions=16, region_len=20000):
-    """Times the oracle (test infrastructure) on `n_regions` independent regions, one thread each."""
+def _cpu_region(args):
+    from uvc_amd import synth
+    seed, region_len, depth = args
+    return synth.generate_region(seed=seed, region_len=region_len, depth=depth)
+
+
+def run_cpu_baseline(depth, n_regions=64, region_len=20000):
+    """Times the oracle (test infrastructure) on `n_regions` independent regions, one thread each: accumulate + default-gate scoring."""
     from concurrent.futures import ThreadPoolExecutor
-    from uvc_amd import _ffi, region, synth
+    from uvc_amd import _ffi, region
     lib = _ffi.Lib(_ffi.oracle_library_path(), "uvc_oracle_")
     params = region.default_params(lib)
     cores = min(16, os.cpu_count() or 1)
     regs = []
     for i in range(n_regions):
-        r = synth.generate_region(seed=777 + i, region_len=region_len, depth=depth)
+        r = _cpu_region((777 + i, region_len, depth))
         R = region.Region(lib, params, r["tid"], r["beg"], r["end"], r["refseq"])
         R.set_reads(r)
         regs.append(R)
@@ -92,32 +113,56 @@ def run_cpu_baseline(depth, n_regions=16, region_len=20000):
     with ThreadPoolExecutor(max_workers=cores) as ex:
         list(ex.map(work, regs))
     dt = time.perf_counter() - t0
+    for R in regs:
+        R.close()
     return {"value": n_regions * region_len / dt, "unit": "positions/s", "cores": cores, "kind": "port",
-            "sample": "%d regions x %d bp at %dx, oracle (scalar C++ port), one region per thread, %.1f s wall" % (n_regions, region_len, depth, dt)}
+            "sample": "%d regions x %d bp = %.2f Mb at %dx, oracle (scalar C++ port of the reference algorithm), one region per thread, accumulate + default-gate scoring, %.1f s wall"
+                      % (n_regions, region_len, n_regions * region_len / 1e6, depth, dt)}
+
+
+def _gen_tile(a):
+    from uvc_amd import synth
+    seed, region_len, depth, beg, umi = a
+    return synth.generate_region(seed=seed, region_len=region_len, depth=depth, beg=beg, umi=umi)
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (this process has not touched a GPU and never will),
+    wait for them, pass rank 0's JSON line through."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=(None if rank == 0 else subprocess.DEVNULL)))
+    rc = 0
+    for p in procs:
+        rc = rc or p.wait()
+    return rc
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--tile-kb", type=int, default=1000, help="tile length in kb (chr20 is processed as 1 Mb tiles)")
+    ap.add_argument("--tiles", type=int, default=8, help="number of distinct tiles per rank in the stream")
     ap.add_argument("--depth", type=int, default=300)
-    ap.add_argument("--streams", type=int, default=1, help="split the tile into this many regions, each on its own HIP stream, accumulated concurrently")
     ap.add_argument("--umi", action="store_true", help="duplex-UMI families (BASELINE config 4 shape when combined with --depth 2000 --tile-kb 200)")
-    ap.add_argument("--serial", action="store_true", help="(the default) one resident tile, accumulate then score, strictly one after the other")
-    ap.add_argument("--pipeline", action="store_true", help="time the streamed mode instead: two resident tiles, the accumulate of tile k+1 is enqueued before the (synchronous) score of tile k; every step still does one full accumulate + score of a whole tile.  bench.py --streamed reports this mode beside the timed one")
-    ap.add_argument("--streamed", action="store_true", help="behind the timed region, also measure the streamed mode (two handles) and report it as \"streamed\"; off by default so that a profiler run of the default command sees the timed launches only")
-    ap.add_argument("--no-streamed", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--all-out", action="store_true", help="second series of SURVEY 8(d): score every symbol of every position (-A), not only the default-gate candidates")
+    ap.add_argument("--serial", action="store_true", help="no pipelining across tiles: preparation, accumulate and score of a tile strictly one after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dry-run", action="store_true", help="CPU-only rehearsal of the multi-rank protocol (no kernels, used by the gloo tests)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the pcie_inclusive and resident measurements behind the timed region (profiler runs)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU-only rehearsal of the launch protocol (no kernels): ranks, barrier, max-over-ranks clock")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     from uvc_amd import shard
     rank, local_rank, world = shard.dist_env()
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    args.gpus = world
     region_len = args.tile_kb * 1000
 
     if args.dry_run:
@@ -127,16 +172,29 @@ def main():
             time.sleep(0.01 * (1 + rank))
         clock.barrier(); dt = clock.max_over_ranks(time.perf_counter() - t0)
         if rank == 0:
-            print(json.dumps({"metric": "pileup positions scored/sec at 300x depth", "value": world * region_len * args.steps / dt, "unit": "positions/s",
+            print(json.dumps({"metric": METRIC, "value": world * region_len * args.steps / dt, "unit": "positions/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic", "config": {"workload": "dry-run"}, "dry_run": True}))
         clock.close()
         return
 
+    # ---- synthetic tiles (host, before any GPU call so that the generator may fork) ----
+    t_gen = time.perf_counter()
+    specs = [(12345 + rank + 1000 * i, region_len, args.depth, 1000000 + i * (region_len + 1000), args.umi) for i in range(args.tiles)]
+    workers = min(len(specs), 4 if world == 1 else 2, max(1, (os.cpu_count() or 2) // max(1, world)))
+    if workers > 1:
+        from concurrent.futures import ProcessPoolExecutor
+        with ProcessPoolExecutor(max_workers=workers) as ex:
+            tiles = list(ex.map(_gen_tile, specs))
+    else:
+        tiles = [_gen_tile(sp) for sp in specs]
+    t_gen = time.perf_counter() - t_gen
+
     import torch
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     clock = shard.Clock(backend="nccl")
-    from uvc_amd import region, synth
+    from uvc_amd import region
     lib = region.gpu_lib()
     rc = lib.dll.uvcgpu_init(local_rank)
     if rc != 0:
@@ -144,131 +202,135 @@ def main():
     lib.dll.uvcgpu_region_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.dll.uvcgpu_region_kernel_times.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_float), C.c_int]
     params = region.default_params(lib)
-    t_gen = time.perf_counter()
-    sub_len = region_len // args.streams
-    args.pipeline = bool(args.pipeline) and not args.serial and args.streams == 1
-    if args.pipeline:
-        assert args.streams == 1, "--pipeline uses its own two handles"
-    n_tiles = 2 if args.pipeline else args.streams
-    tiles = [synth.generate_region(seed=12345 + rank + 1000 * i, region_len=sub_len, depth=args.depth, beg=1000000 + i * (sub_len + 1000), umi=args.umi) for i in range(n_tiles)]
-    reads = tiles[0]
-    t_gen = time.perf_counter() - t_gen
-    Rs = [region.Region(lib, params, t["tid"], t["beg"], t["end"], t["refseq"]) for t in tiles]
-    R = Rs[0]
+
+    # inputs resident in HBM: the raw columns of every tile + one handle per tile bound to its region (reference side arrays, planes)
     t_h2d = time.perf_counter()
-    for Ri, t in zip(Rs, tiles):
-        Ri.set_reads(t)
+    dreads = [region.device_reads(t, dev) for t in tiles]
     t_h2d = time.perf_counter() - t_h2d
-    n_reads_total = sum(int(t["n_reads"]) for t in tiles)
-    n_read_bases = n_reads_total * READ_LEN
+    Rs = [region.Region(lib, params, t["tid"], t["beg"], t["end"], t["refseq"]) for t in tiles]
+    for R in Rs:
+        lib.dll.uvcgpu_region_set_profiling(R.h, 1)          # HIP events around the kernels of every accumulate (the roofline leg reads them)
+    T = len(tiles)
+    cap = 15 * (region_len + 2) if args.all_out else max(65536, region_len // 4)
+    n_reads_tile = int(np.mean([int(t["n_reads"]) for t in tiles]))
+    input_bytes_tile = int(np.mean([sum(int(np.asarray(t[k]).nbytes) for k in ("pos", "mpos", "isize", "flag", "mapq", "nm", "l_qseq", "seq_off", "cigar_off", "n_cigar", "frag_id", "fam_id", "fam_strand", "bases", "quals", "cigars")) for t in tiles]))
 
-    def step():
-        for Ri in Rs:          # enqueue only: each region has its own stream
-            Ri.accumulate()
-        recs = [Ri.score(all_out=args.all_out, capacity=(15 * (sub_len + 2) if args.all_out else max(65536, sub_len // 4)), copy=False, release_state=True) for Ri in Rs]
-        return {"refpos": np.concatenate([r["refpos"] for r in recs])} if len(recs) > 1 else recs[0]
+    def prepare(k, host=False):
+        R = Rs[k % T]
+        if host:
+            R.set_reads(tiles[k % T])                          # PCIe-inclusive variant: the columns start in (pinned) host memory
+        else:
+            R.set_reads_device(dreads[k % T])
+        R.accumulate()
 
-    def score_one(Ri):
-        return Ri.score(all_out=args.all_out, capacity=(15 * (sub_len + 2) if args.all_out else max(65536, sub_len // 4)), copy=False, release_state=True)
+    def finish(k):
+        return Rs[k % T].score(all_out=args.all_out, capacity=cap, copy=False, release_state=True)
 
-    lib.dll.uvcgpu_region_set_profiling(R.h, 1)          # HIP events around the kernels of handle 0 (the roofline leg reads them)
-    if args.pipeline:
-        n_reads_total //= 2; n_read_bases //= 2          # per step: one tile
-        k_state = [0]
-        Rs[0].accumulate()                                # prologue: the pipeline is primed outside the timed region ...
+    names_buf = C.create_string_buffer(2048)
+    ms_buf = (C.c_float * 48)()
 
-        def step():                                       # ... and every step enqueues the next tile's accumulate, then scores the current one
-            k = k_state[0]; k_state[0] += 1
-            Rs[(k + 1) % 2].accumulate()
-            return score_one(Rs[k % 2])
+    def kernel_times(R, into):
+        n = lib.dll.uvcgpu_region_kernel_times(R.h, names_buf, 2048, ms_buf, 48)   # the handle's stream is idle here: its score() was synchronous
+        for nm, ms in zip(names_buf.value.decode().split(";")[:n], list(ms_buf)[:n]):
+            into.setdefault(nm, []).append(ms)
 
-    for _ in range(args.warmup):
-        step()
+    def run_stream(k0, n_steps, host=False, ktimes=None):
+        """n_steps tiles, software-pipelined: tile k + 1 is prepared and its accumulate enqueued before tile k is scored."""
+        n_rec = 0
+        if args.serial or T < 2:   # one handle cannot hold the next tile's reads while the current one is still being scored
+            for k in range(k0, k0 + n_steps):
+                prepare(k, host); n_rec = len(finish(k)["refpos"])
+                if ktimes is not None:
+                    kernel_times(Rs[k % T], ktimes)
+            return n_rec
+        prepare(k0, host)
+        for k in range(k0, k0 + n_steps):
+            if k + 1 < k0 + n_steps:
+                prepare(k + 1, host)
+            n_rec = len(finish(k)["refpos"])
+            if ktimes is not None:
+                kernel_times(Rs[k % T], ktimes)
+        return n_rec
+
+    run_stream(0, args.warmup)
     ktimes = {}
-    names_buf = C.create_string_buffer(1024)
-    ms_buf = (C.c_float * 32)()
-    n_rec = 0
     torch.cuda.synchronize(); clock.barrier()
     t0 = time.perf_counter()
-    for it in range(args.steps):
-        rec = step()
-        n_rec = len(rec["refpos"])
-        if args.pipeline and (args.warmup + it) % 2 == 1:
-            continue   # handle 0 has its next accumulate in flight: asking for its kernel times would wait for it and stall the pipeline
-        n = lib.dll.uvcgpu_region_kernel_times(R.h, names_buf, 1024, ms_buf, 32)   # the handle's stream is idle here: its score() was synchronous
-        for nm, ms in zip(names_buf.value.decode().split(";")[:n], list(ms_buf)[:n]):
-            ktimes.setdefault(nm, []).append(ms)
+    n_rec = run_stream(args.warmup, args.steps, ktimes=ktimes)
     torch.cuda.synchronize(); clock.barrier()
     dt = clock.max_over_ranks(time.perf_counter() - t0)
     total_positions = clock.sum_over_ranks(float(region_len)) * args.steps
 
-    # outside the timed region: the same step on one handle, strictly serial, so that the kernel durations are also known without
-    # the other tile's scoring kernels running beside them (reported as "serial", never as `value`)
-    serial = None
-    if args.pipeline:
-        torch.cuda.synchronize()
-        score_one(Rs[k_state[0] % 2])                      # drain the accumulate the last step left in flight
+    pcie = resident = None
+    if not args.no_extras:
+        # (1) the same stream with the columns in pinned host memory: H2D of every column inside the step
+        pinned = []
+        for t in tiles:
+            for k in ("pos", "mpos", "isize", "flag", "mapq", "nm", "l_qseq", "seq_off", "cigar_off", "n_cigar", "frag_id", "fam_id", "fam_strand", "bases", "quals", "cigars"):
+                a = t[k] = np.ascontiguousarray(t[k])
+                if a.nbytes and lib.dll.uvcgpu_pin_host_buffer(C.c_void_p(a.ctypes.data), C.c_int64(a.nbytes)) == 0:
+                    pinned.append(a)
+        n_extra = max(4, min(args.steps, 2 * T))
+        run_stream(0, 2, host=True)
+        torch.cuda.synchronize(); clock.barrier(); ts = time.perf_counter()
+        run_stream(2, n_extra, host=True)
+        torch.cuda.synchronize(); clock.barrier(); sdt = clock.max_over_ranks(time.perf_counter() - ts)
+        pcie = {"value": clock.sum_over_ranks(float(region_len)) * n_extra / sdt, "unit": "positions/s", "ms_per_step": 1e3 * sdt / n_extra, "steps": n_extra,
+                "h2d_bytes_per_tile": input_bytes_tile,
+                "note": "as `value`, but every tile's columns start in pinned host memory and uvcgpu_region_set_reads copies them first; measured behind the timed region"}
+        for a in pinned:
+            lib.dll.uvcgpu_unpin_host_buffer(C.c_void_p(a.ctypes.data))
+        # (2) one prepared tile, accumulate + score again and again, nothing overlapped
+        R = Rs[0]
+        R.set_reads_device(dreads[0])
         sk = {}
-        ts = time.perf_counter()
-        for _ in range(2):
-            R.accumulate(); score_one(R)
-            n = lib.dll.uvcgpu_region_kernel_times(R.h, names_buf, 1024, ms_buf, 32)
-            for nm, ms in zip(names_buf.value.decode().split(";")[:n], list(ms_buf)[:n]):
-                sk.setdefault(nm, []).append(ms)
-        serial = {"ms_per_step": 1e3 * (time.perf_counter() - ts) / 2, "kernel_ms": {k: sum(v) / len(v) for k, v in sk.items()}}
-
-    # outside the timed region as well: what a caller gets that streams tiles through two handles (the same tile in both here)
-    streamed = None
-    if args.streamed and (not args.pipeline) and args.streams == 1 and not args.all_out:
-        R2 = region.Region(lib, params, reads["tid"], reads["beg"], reads["end"], reads["refseq"])
-        R2.set_reads(reads)
-        pair = [R, R2]
-        pair[0].accumulate()
-        def sstep(k):
-            pair[(k + 1) % 2].accumulate()
-            return score_one(pair[k % 2])
-        sstep(0)
-        torch.cuda.synchronize()
-        ts = time.perf_counter()
-        for k in range(1, 1 + args.steps):
-            sstep(k)
-        torch.cuda.synchronize()
-        sdt = clock.max_over_ranks(time.perf_counter() - ts)
-        streamed = {"ms_per_step": 1e3 * sdt / args.steps, "value": clock.sum_over_ranks(float(region_len)) * args.steps / sdt}
-        score_one(pair[(1 + args.steps) % 2])
-        R2.close()
+        R.accumulate(); finish(0)
+        torch.cuda.synchronize(); ts = time.perf_counter()
+        n_res = 8
+        for _ in range(n_res):
+            R.accumulate(); finish(0)
+            kernel_times(R, sk)
+        torch.cuda.synchronize(); rdt = clock.max_over_ranks(time.perf_counter() - ts)
+        resident = {"value": clock.sum_over_ranks(float(region_len)) * n_res / rdt, "unit": "positions/s", "ms_per_step": 1e3 * rdt / n_res,
+                    "kernel_ms": {k: round(sum(v) / len(v), 4) for k, v in sorted(sk.items(), key=lambda kv: -sum(kv[1]))},
+                    "note": "one tile whose reads are already prepared (set_reads done once): accumulate P1..P5b + scoring + D2H per step, one handle, nothing overlapped; measured behind the timed region"}
 
     if rank == 0:
         avg = {k: sum(v) / len(v) for k, v in ktimes.items()}
         dom = max(avg, key=avg.get)
-        abytes = algorithmic_bytes_per_position(dom, args.depth) * R.npos   # per launch: one region
+        abytes = algorithmic_bytes_per_position(dom, args.depth) * Rs[0].npos   # per launch: one region
         achieved = abytes / (avg[dom] * 1e-3) / 1e9
         out = {
-            "metric": "pileup positions scored/sec at 300x depth", "value": total_positions / dt, "unit": "positions/s",
+            "metric": METRIC, "value": total_positions / dt, "unit": "positions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "chr20-shaped tumor-only non-UMI tile: %d kb at %dx, 150 bp paired-end, resident in HBM; step = accumulate P1..P5b + default-gate scoring / calling + D2H of the records of one tile (planes released with the score call: they are zeroed for the next tile under the D2H)%s" % (args.tile_kb, args.depth, "; tiles stream through two handles (the accumulate of tile k+1 is enqueued before the synchronous score of tile k)" if args.pipeline else ""),
-                       "tile_positions": region_len, "streams": args.streams, "pipeline": bool(args.pipeline), "all_out": bool(args.all_out), "umi": bool(args.umi), "reads_per_tile": n_reads_total, "read_bases_per_tile": n_read_bases, "scored_records_per_tile": n_rec,
+            "config": {"workload": "stream of %d DISTINCT chr20-shaped tumor-only %s tiles per GPU (%d kb at %dx, 150 bp paired-end), raw UvcReadSoA columns + region side arrays resident in HBM; "
+                                   "step = one tile: set_reads(device half: CIGAR facts + family/fragment nesting, radix orders, k_pack_bq, k_aln_prelude, k_build_p2list) + accumulate P1..P5b + "
+                                   "default-gate scoring / calling + D2H of the records%s" % (T, "duplex-UMI" if args.umi else "non-UMI", args.tile_kb, args.depth,
+                                   "; tiles strictly one after the other" if args.serial else "; tiles software-pipelined over their handles (tile k+1 is prepared and accumulating while tile k is scored)"),
+                       "tile_positions": region_len, "distinct_tiles": T, "pipelined": (not args.serial) and T >= 2, "all_out": bool(args.all_out), "umi": bool(args.umi), "reads_per_tile": n_reads_tile,
+                       "read_bases_per_tile": n_reads_tile * READ_LEN, "input_bytes_per_tile": input_bytes_tile, "scored_records_last_tile": n_rec,
                        "parallelism": "region-shard x%d (no collective on the data path)" % world},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(dom, args.tile_kb, args.depth),
-                         "algorithmic_bytes_per_launch": abytes, "kernel_ms": avg[dom]},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": replayed_traffic(dom, args.tile_kb, args.depth), "traffic_source": "replayed from profiles/traffic_latest.json (two separate rocprofv3 --pmc passes), not measured in this run",
+                         "algorithmic_bytes_per_launch": abytes, "kernel_ms": avg[dom],
+                         "note": "HIP events on the library's stream over the timed steps; with pipelining another tile's preparation kernels may run beside the kernel (see resident.kernel_ms for the undisturbed durations)"},
             "kernel_ms": {k: round(v, 4) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])},
-            "read_bases_per_s": n_read_bases * world * args.steps / dt,
-            "host_prep_s": {"generate": round(t_gen, 2), "pack_and_h2d": round(t_h2d, 3)},
+            "read_bases_per_s": n_reads_tile * READ_LEN * world * args.steps / dt,
+            "host_prep_s": {"generate": round(t_gen, 2), "columns_to_hbm": round(t_h2d, 3)},
         }
-        if serial:
-            sd = serial["kernel_ms"].get(dom)
-            out["serial"] = {"ms_per_step": round(serial["ms_per_step"], 3), "kernel": dom, "kernel_ms": round(sd, 4) if sd else None,
-                             "roofline_frac": (abytes / (sd * 1e-3) / 1e9 / HBM_PEAK_GBS) if sd else None,
-                             "note": "one handle, accumulate then score with nothing overlapped; measured after the timed region"}
-        if streamed:
-            out["streamed"] = {"ms_per_step": round(streamed["ms_per_step"], 3), "value": streamed["value"], "unit": "positions/s",
-                               "note": "two handles, the accumulate of tile k+1 enqueued before the synchronous score of tile k (bench.py --pipeline times this mode); measured after the timed region"}
+        if pcie:
+            out["pcie_inclusive"] = pcie
+        if resident:
+            rd = resident["kernel_ms"].get(dom)
+            if rd:
+                resident["roofline_frac"] = abytes / (rd * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["resident"] = resident
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline(args.depth)
         print(json.dumps(out))
-    for Ri in Rs:
-        Ri.close()
+    for R in Rs:
+        R.close()
     clock.close()
 
 

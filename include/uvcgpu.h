@@ -333,6 +333,11 @@ int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params,
  * region is not longer than the longest one the handle has held, the device buffers are kept -- no hipMalloc / hipFree per tile. */
 int uvcgpu_region_reset(uvcgpu_region_t *r, int32_t tid, int32_t beg, int32_t end, const char *refseq);
 int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *reads);
+/* The same for columns that are already in HBM: every pointer of `reads` is a device pointer (on the handle's device), nothing is copied.
+ * The arrays must stay valid and unchanged until the handle gets other reads, is reset or destroyed; uvcgpu_region_correct_bq then edits
+ * `quals` in place, as the reference edits its bam1_t (grouping.cpp:459-543).  For callers whose decoder already writes to the device, and
+ * for measuring the path without the PCIe copy. */
+int uvcgpu_region_set_reads_device(uvcgpu_region_t *r, const UvcReadSoA *reads);
 /* Optional: apply_bq_err_correction3 (grouping.cpp:459-543) on the device copy of quals. */
 int uvcgpu_region_correct_bq(uvcgpu_region_t *r);
 /* The base qualities as they are on the device now (after uvcgpu_region_correct_bq if it was called); n must equal

@@ -14,5 +14,5 @@ j = json.load(open("gpurun_out/bench_latest.json"))
 print("value %.3e pos/s  ms/step %.2f  roofline %s frac %.4f" % (j["value"], j["ms_per_step"], j["roofline"]["kernel"], j["roofline"]["frac"]))
 print(j["kernel_ms"])
 print(j.get("cpu_baseline"))
-print("serial:", j.get("serial")); print("streamed:", j.get("streamed"))
+print("pcie_inclusive:", j.get("pcie_inclusive")); print("resident:", j.get("resident"))
 PY

@@ -4,7 +4,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
 tag=$1; shift
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc/$tag -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --tile-kb ${TILE_KB:-200} > gpurun_out/pmc/$tag.json 2> gpurun_out/pmc/$tag.err
+timeout -k 10 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc/$tag -- python3 bench.py --steps 2 --warmup 0 --tiles 2 --serial --no-cpu-baseline --no-extras --tile-kb ${TILE_KB:-200} > gpurun_out/pmc/$tag.json 2> gpurun_out/pmc/$tag.err
 rc=$?
 f=$(find gpurun_out/pmc/$tag -name "*counter_collection.csv" | head -1)
 echo "file: $f rc=$rc"

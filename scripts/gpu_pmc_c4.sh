@@ -4,7 +4,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
 tag=$1; shift
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc/$tag -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --umi --depth 2000 --tile-kb 100 > gpurun_out/pmc/$tag.json 2> gpurun_out/pmc/$tag.err
+timeout -k 10 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc/$tag -- python3 bench.py --steps 2 --warmup 0 --tiles 2 --serial --no-cpu-baseline --no-extras --umi --depth 2000 --tile-kb 100 > gpurun_out/pmc/$tag.json 2> gpurun_out/pmc/$tag.err
 f=$(find gpurun_out/pmc/$tag -name "*counter_collection.csv" | head -1)
 [ -n "$f" ] && python3 - "$f" <<'PY'
 import csv, sys, collections

@@ -8,10 +8,10 @@ TAG=${1:-r01}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || exit 11
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 8 --warmup 2 --tiles 4 --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || exit 11
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats.csv
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_$ctr -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_$ctr.json 2> $OUT/pmc_$ctr.err || exit 12
+  timeout -k 10 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_$ctr -- python3 bench.py --steps 2 --warmup 0 --tiles 2 --serial --no-cpu-baseline --no-extras > $OUT/pmc_$ctr.json 2> $OUT/pmc_$ctr.err || exit 12
 done
 python3 - $OUT <<'PY'
 import csv, sys, glob, json, collections
@@ -35,5 +35,5 @@ for k, v in sorted(res.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"
 PY
 timeout -k 10 900 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 13; }
 cat $OUT/bench.json
-timeout -k 10 900 python3 bench.py --streamed --no-cpu-baseline > $OUT/bench_streamed.json 2>> $OUT/bench.err || exit 14
+timeout -k 10 900 python3 bench.py --serial --no-cpu-baseline --no-extras > $OUT/bench_serial.json 2>> $OUT/bench.err || exit 14
 rm -rf $OUT/trace $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE

@@ -37,3 +37,18 @@ def test_two_ranks_shard_a_bam_and_rank0_joins_the_outputs(tmp_path):
     assert j["equal_to_serial"] and j["lines"] >= 10
     assert min(j["called_per_rank"]) >= 2        # both ranks had tiles with reads: the cut falls inside the covered stretch
     assert max(j["cost_per_rank"]) <= 0.75 * sum(j["cost_per_rank"])
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher spawns two ranks itself (children first, nothing in the parent touches a GPU) and
+    rank 0 reports n_gpus = 2; --dry-run keeps it on the CPU (gloo barrier + max-over-ranks clock, no kernels)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0", "--tile-kb", "10", "--dry-run"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                       # only rank 0 prints
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 3
+    assert j["ms_per_step"] >= 19.0              # max over ranks: rank 1 sleeps 20 ms per step, rank 0 only 10 ms
+    assert abs(j["value"] - 2 * 10000 * 3 / (j["ms_per_step"] * 3 / 1e3)) / j["value"] < 1e-6

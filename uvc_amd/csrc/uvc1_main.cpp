@@ -62,7 +62,7 @@ Opts parse(int argc, char **argv) {
         else if (a == "-A" || a == "--all-out") o.all_out = true;
         else if (a == "-q" || a == "--vqual") o.vqual = atof(val().c_str());
         else if (a == "--outvar-flag") o.outvar_flag = atoi(val().c_str());
-        else if (a == "--tile") o.tile = std::max<int64_t>(1000, atoll(val().c_str()));
+        else if (a == "--tile") o.tile = std::max<int64_t>(100, atoll(val().c_str()));
         else if (a == "--device" || a == "--devices") {   // comma-separated HIP device ids; an id may repeat (two workers sets on one GPU)
             o.devices.clear();
             const std::string v = val(); size_t at = 0;

@@ -342,7 +342,7 @@ int uvcgpu_group_families(const UvcGroupParams *Pp, const UvcGroupInput *in, Uvc
         hipMemcpy(&n_fams, fam_scan + (n_kept - 1), 4, hipMemcpyDeviceToHost);
         hipMemcpy(&n_frags, frag_scan + (n_kept - 1), 4, hipMemcpyDeviceToHost);
         hipMemcpy(counters, W.counters, sizeof(counters), hipMemcpyDeviceToHost);
-        if (counters[3]) return uvcgpu_set_error(UVCGPU_EDEVICE, "family-key hash collision: refusing to group (rerun on the host path)");
+        if (counters[3]) return uvcgpu_set_error(UVCGPU_EDEVICE, "family-key hash collision (two different keys agree in one of the two 64-bit key mixes, probability ~2^-64 per pair): refusing to group rather than merge or split families silently");
     }
     int32_t ext[2];
     hipMemcpy(ext, W.ext, sizeof(ext), hipMemcpyDeviceToHost);

@@ -3,6 +3,7 @@
 // There is no CPU compute fallback in this library: every entry point that computes launches HIP kernels.
 #include "uvc_device.h"
 #include "uvc_alloc.h"
+#include "uvc_prep.h"
 
 #include <algorithm>
 #include <chrono>
@@ -17,7 +18,8 @@
 #define hipFree(p) uvc_dev_free((void *)(p))
 
 struct RawReads {
-    const int32_t *pos, *endpos, *mpos, *isize, *flag, *mapq, *nm, *l_qseq, *n_cigar, *frag, *fs, *dflag, *kind, *fast_rank;
+    const int32_t *pos, *endpos, *mpos, *isize, *nm, *l_qseq, *n_cigar, *frag, *fs, *dflag, *kind, *fast_rank;
+    const uint16_t *flag; const uint8_t *mapq;
     const int64_t *seq_off, *cigar_off, *table_off, *item_off, *gap_off;
 };
 extern "C" void uvc_launch_correct_bq(const RegionDev *R, int bq_max, int bq_inc, hipStream_t s);
@@ -209,18 +211,6 @@ template <class T> int upload_raw(uvcgpu_region *r, const T *src, size_t count, 
     if (count && hipMemcpyAsync(*out, src, count * sizeof(T), hipMemcpyHostToDevice, r->stream) != hipSuccess) return fail(UVCGPU_EDEVICE, "hipMemcpyAsync(H2D)");
     return 0;
 }
-// stable LSD radix sort of ids by a non-negative 32-bit key (three 11-bit passes): the host orders are all "by position"
-void radix_sort_ids(std::vector<int32_t> &ids, const std::vector<uint32_t> &key_of_id) {
-    std::vector<int32_t> tmp(ids.size());
-    for (int pass = 0; pass < 3; pass++) {
-        const int shift = 11 * pass;
-        size_t cnt[2049] = { 0 };
-        for (int32_t id : ids) cnt[((key_of_id[id] >> shift) & 2047u) + 1]++;
-        for (int b = 0; b < 2048; b++) cnt[b + 1] += cnt[b];
-        for (int32_t id : ids) tmp[cnt[(key_of_id[id] >> shift) & 2047u]++] = id;
-        ids.swap(tmp);
-    }
-}
 // (the cache hands freed blocks to other handles at once: nothing of this handle may still be running on them)
 void quiesce(uvcgpu_region *r) { if (r->stream) (void)hipStreamSynchronize(r->stream); if (r->side) (void)hipStreamSynchronize(r->side); }
 void free_reads(uvcgpu_region *r) { if (!r->owned.empty()) quiesce(r); for (void *p : r->owned) hipFree(p); r->owned.clear(); r->has_reads = false; r->accumulated = false; }
@@ -348,246 +338,72 @@ int uvcgpu_region_reset(uvcgpu_region_t *r, int32_t tid, int32_t beg, int32_t en
     return configure_region(r, tid, beg, end, refseq);
 }
 
-int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
-    if (!r || !in || in->n_reads < 0 || in->n_fams < 0) return fail(UVCGPU_EINVAL, "bad reads");
-    const bool timing = (getenv("UVCGPU_TIMING") != nullptr);   // stderr breakdown of the ingest, for tuning
-    auto t_prev = std::chrono::steady_clock::now();
+// The read-dependent preparation runs on the device (uvc_prep.hip) over the caller's columns; `d` holds DEVICE pointers.
+static void *prep_alloc(void *ctx, size_t bytes, int zero) {
+    uvcgpu_region *r = (uvcgpu_region *)ctx;
+    char *p = nullptr;
+    if (dev_alloc(r, bytes, &p, zero != 0)) return nullptr;
+    return p;
+}
+static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool timing, std::chrono::steady_clock::time_point t_prev) {
     auto lap = [&](const char *what) { if (!timing) return; hipStreamSynchronize(r->stream); const auto t = std::chrono::steady_clock::now();
                                        fprintf(stderr, "[uvcgpu set_reads] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count()); t_prev = t; };
-    free_reads(r);
-    struct SyncOnExit { hipStream_t s; ~SyncOnExit() { hipStreamSynchronize(s); } } sync_on_exit = { r->stream };   // no copy may outlive the host vectors below, on any return path
-    const int64_t n = in->n_reads;
-    if (n == 0) return 0;
-    if (n > INT32_MAX / 2) return fail(UVCGPU_EUNSUPPORTED, "more than 2^30 reads in one region");
-    std::vector<int32_t> endpos(n), frag_of(n), fs_of(n), dflag_of(n), kind(n);
-    std::vector<int64_t> table_off(n, -1), item_off(n, -1), gap_off(n, -1);
-    int64_t item_slots = 0, gap_slots = 0, ins_total = 0;
-    std::vector<FragRec> frags; std::vector<FsRec> fss;
-    std::vector<int32_t> fam_fs((size_t)in->n_fams * 2, -1);
-    int prev_fam = -1, prev_strand = -1, prev_frag = -1;
-    int64_t table_rows = 0;
-    int32_t max_aln_span = 1, max_frag_span = 1;
-    struct P2Seg { int32_t cbeg, cend, aln, qb; int32_t cls; };   // cls = is-reverse | bam_get_strand << 1 (common.hpp:89)
-    const UvcParams &P0 = r->P;
-    // see k_p2_fast: the M runs of an InDel read can take the simple path when its dist_to_interfering_indel is "far" everywhere, which
-    // needs no low-quality InDel in the read, a region that does not start next to coordinate 0 and the default-range threshold
-    const bool seg_eligible = (UVC_PLATFORM_IONTORRENT != P0.inferred_sequencing_platform) && r->beg >= 65536 && P0.bias_thres_interfering_indel <= 10000;
-    // Phase A, on all host cores: what the CIGAR of each read says (nothing here depends on another read)
-    struct ReadFacts { int32_t e; int32_t n_p2; int64_t items; int32_t trows, gaps, ins; int8_t simple, p2ok, err; };
-    std::vector<ReadFacts> facts((size_t)n);
-    auto host_parallel = [&](auto fn) {
-        const int nt = (int)std::min<int64_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), 16u)), std::max<int64_t>(n / 65536, 1));
-        if (nt <= 1) { fn((int64_t)0, n); return; }
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; t++) th.emplace_back(fn, n * t / nt, n * (t + 1) / nt);
-        for (std::thread &x : th) x.join();
-    };
-    host_parallel([&](int64_t i0, int64_t i1) {
-        for (int64_t i = i0; i < i1; i++) {
-            ReadFacts F; memset(&F, 0, sizeof(F));
-            const int32_t nc = in->n_cigar[i], lq = in->l_qseq[i];
-            if (in->seq_off[i] < 0 || in->seq_off[i] + lq > in->n_bases || in->cigar_off[i] < 0 || in->cigar_off[i] + nc > in->n_cigar_ops || nc < 1) { F.err = 1; facts[(size_t)i] = F; continue; }
-            const uint32_t *cg = in->cigars + in->cigar_off[i];
-            int32_t e = in->pos[i]; int64_t q = 0, del_total = 0; int n_m = 0; bool simple = true;
-            for (int k = 0; k < nc && !F.err; k++) {
-                const int op = (int)(cg[k] & 0xF); const int32_t len = (int32_t)(cg[k] >> 4);
-                if (op > C_DIFF) { F.err = 2; break; }
-                if (op == C_MATCH || op == C_DEL || op == C_REF_SKIP || op == C_EQUAL || op == C_DIFF) e += len;
-                if (op == C_MATCH || op == C_INS || op == C_SOFT_CLIP || op == C_EQUAL || op == C_DIFF) q += len;
-                if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) n_m++;
-                else if (!(op == C_SOFT_CLIP || op == C_HARD_CLIP)) simple = false;
-                if (op == C_INS || op == C_DEL) F.gaps++;
-                if (op == C_INS) F.ins += len;
-                if (op == C_DEL) del_total += len;
-            }
-            if (F.err) { facts[(size_t)i] = F; continue; }
-            if (e == in->pos[i]) e = in->pos[i] + 1;   // bam_endpos of a read without reference-consuming ops
-            if (q != lq) { F.err = 3; facts[(size_t)i] = F; continue; }
-            if (n_m != 1 || nc > 3) simple = false;
-            if (simple && nc == 3) { const int o0 = cg[0] & 0xF, o2 = cg[2] & 0xF; if ((o0 == C_MATCH || o0 == C_EQUAL || o0 == C_DIFF) || (o2 == C_MATCH || o2 == C_EQUAL || o2 == C_DIFF)) simple = false; }
-            if (in->pos[i] < r->beg || e > r->end - 1) { F.err = 4; facts[(size_t)i] = F; continue; }
-            // P2 work list (k_p2_fast): a simple alignment is one entry; an InDel read contributes its M runs (used when its InDels are all high-quality)
-            bool ok = simple || seg_eligible;
-            int32_t rp = in->pos[i], n_p2 = 0;
-            for (int k = 0; k < nc && ok; k++) {
-                const int op = (int)(cg[k] & 0xF); const int32_t len = (int32_t)(cg[k] >> 4);
-                if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) { if (rp - in->pos[i] > 65535 || e - (rp + len) > 65535) ok = false; n_p2++; rp += len; }
-                else if (op == C_DEL) rp += len;
-                else if (op == C_INS || op == C_SOFT_CLIP || op == C_HARD_CLIP) {}
-                else ok = false;   // N / P: keep the sequential path
-            }
-            F.e = e; F.simple = simple; F.p2ok = ok; F.n_p2 = (ok ? n_p2 : 0);
-            if (!simple) { F.trows = (e - in->pos[i]) + 1; F.items = 2 * (int64_t)lq + 2 * del_total + nc + 4; } else { F.gaps = 0; F.ins = 0; }
-            facts[(size_t)i] = F;
-        }
-    });
-    // Phase B, in read order: the first malformed read, family / fragment boundaries, offsets
-    std::vector<int64_t> p2_first((size_t)n + 1, 0);
-    for (int64_t i = 0; i < n; i++) {
-        const ReadFacts &F = facts[(size_t)i];
-        if (F.err == 1) return fail(UVCGPU_EINVAL, "read offsets out of range");
-        if (F.err == 2) return fail(UVCGPU_EUNSUPPORTED, "unsupported CIGAR op (process_cigar throws, main_conversion.hpp:902-916)");
-        if (F.err == 3) return fail(UVCGPU_EINVAL, "CIGAR query length != l_qseq");
-        if (F.err == 4) return fail(UVCGPU_EINVAL, "read outside region");
-        const int32_t e = F.e;
-        endpos[i] = e;
-        const int fam = in->fam_id[i], strand = in->fam_strand[i];
-        if (fam < 0 || fam >= in->n_fams || strand > 1) return fail(UVCGPU_EINVAL, "fam_id / fam_strand out of range");
-        const bool new_fs = (fam != prev_fam || strand != prev_strand);
-        if (new_fs) {
-            if (fam_fs[(size_t)fam * 2 + strand] >= 0) return fail(UVCGPU_EINVAL, "reads of one (fam_id, fam_strand) are not contiguous");
-            fam_fs[(size_t)fam * 2 + strand] = (int32_t)fss.size();
-            FsRec u; memset(&u, 0, sizeof(u));
-            u.frag_beg = u.frag_end = (int32_t)frags.size(); u.beg = INT32_MAX; u.end = 0; u.strand = strand; u.dflag = in->fam_dflag[fam]; u.fam = fam; u.other_fs = -1;
-            fss.push_back(u);
-        }
-        if (new_fs || in->frag_id[i] != prev_frag) {
-            FragRec f; memset(&f, 0, sizeof(f));
-            f.aln_beg = f.aln_end = (int32_t)i; f.beg = INT32_MAX; f.end = 0; f.fs = (int32_t)fss.size() - 1; f.strand = strand; f.dflag = in->fam_dflag[fam];
-            frags.push_back(f);
-        }
-        FragRec &f = frags.back(); FsRec &u = fss.back();
-        f.aln_end = (int32_t)i + 1; f.beg = std::min(f.beg, in->pos[i]); f.end = std::max(f.end, e) + 1;   // fillTidBegEndFromAlns1, main.hpp:658-673
-        f.normMQ = std::max(f.normMQ, (int32_t)in->mapq[i]);
-        u.frag_end = (int32_t)frags.size(); u.beg = std::min(u.beg, in->pos[i]); u.end = std::max(u.end, e) + 1;
-        frag_of[i] = (int32_t)frags.size() - 1; fs_of[i] = (int32_t)fss.size() - 1; dflag_of[i] = in->fam_dflag[fam];
-        // kind 2 = candidate for the simple path: k_aln_prelude demotes it to 1 when the read has a low-quality InDel (that test reads the
-        // base qualities, which uvcgpu_region_correct_bq may still change on the device)
-        kind[i] = F.simple ? 0 : (F.p2ok ? 2 : 1);
-        p2_first[(size_t)i + 1] = p2_first[(size_t)i] + F.n_p2;
-        if (!F.simple) {
-            table_off[i] = table_rows; table_rows += F.trows;   // + the row of an insertion right behind the last aligned base (rpos == bam_endpos)
-            item_off[i] = item_slots; item_slots += F.items;    // upper bound of P2 updates of this read
-            gap_off[i] = gap_slots; gap_slots += F.gaps; ins_total += F.ins;   // one InDel event per I / D op
-        }
-        else max_aln_span = std::max(max_aln_span, e - in->pos[i]);
-        prev_fam = fam; prev_strand = strand; prev_frag = in->frag_id[i];
-    }
-    // Phase C, on all host cores: the P2 work-list entries at their places
-    std::vector<P2Seg> p2((size_t)p2_first[(size_t)n]);
-    host_parallel([&](int64_t i0, int64_t i1) {
-        for (int64_t i = i0; i < i1; i++) {
-            if (facts[(size_t)i].n_p2 == 0) continue;
-            const int32_t nc = in->n_cigar[i];
-            const uint32_t *cg = in->cigars + in->cigar_off[i];
-            const int fl = in->flag[i];
-            const int32_t p2cls = ((fl & 0x10) ? 1 : 0) | ((((fl & 0x81) == 0x81) ? ((fl & 0x20) != 0) : ((fl & 0x10) != 0)) ? 2 : 0);
-            int32_t rp = in->pos[i]; int64_t qp = 0; size_t w = (size_t)p2_first[(size_t)i];
-            for (int k = 0; k < nc; k++) {
-                const int op = (int)(cg[k] & 0xF); const int32_t len = (int32_t)(cg[k] >> 4);
-                if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) { p2[w++] = P2Seg{ rp, rp + len, (int32_t)i, (int32_t)((in->seq_off[i] + qp - rp) & 0xFFFFFFFFLL), p2cls }; rp += len; qp += len; }
-                else if (op == C_INS || op == C_SOFT_CLIP) qp += len;
-                else if (op == C_DEL) rp += len;
-            }
-        }
-    });
-    lap("classify reads (host)");
-    const UvcParams &P = r->P;
-    const bool singleton_ok = (P.fam_thres_dup1add >= 2 && P.fam_thres_dup2add >= 2 && P.fam_thres_emperr_all_flat_snv >= 2 && P.fam_thres_emperr_all_flat_indel >= 2);
-    std::vector<int32_t> generic_fs, dup_units; std::vector<int64_t> dup_off;
-    int64_t work = 0, dup_work = 0;
-    for (size_t ui = 0; ui < fss.size(); ui++) {
-        FsRec &u = fss[ui];
-        u.end = std::min(u.end, r->end);
-        u.other_fs = fam_fs[(size_t)u.fam * 2 + (1 - u.strand)];
-        const bool duplex = ((u.dflag & 0x2) && u.other_fs >= 0);
-        u.generic = ((u.frag_end - u.frag_beg) >= 2 || duplex || !singleton_ok) ? 1 : 0;
-        if (u.generic) { u.work_off = work; work += (u.end - u.beg); generic_fs.push_back((int32_t)ui); }
-        if (duplex && u.strand == 0) {
-            const FsRec &o = fss[u.other_fs];
-            dup_units.push_back((int32_t)ui); dup_off.push_back(dup_work);
-            dup_work += std::max(u.end, std::min(o.end, r->end)) - std::min(u.beg, o.beg);
-        }
-    }
-    std::vector<int32_t> sweep_frags;
-    for (size_t fi = 0; fi < frags.size(); fi++) {
-        FragRec &f = frags[fi];
-        f.end = std::min(f.end, r->end); f.singleton = fss[f.fs].generic ? 0 : 1; max_frag_span = std::max(max_frag_span, f.end - f.beg);
-        const bool amplicon_gated = (((f.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag))) && !(P.tn_is_paired && (0x1 & P.primer_flag)));
-        bool all_simple = true;
-        for (int k = f.aln_beg; k < f.aln_end; k++) all_simple = all_simple && (kind[k] == 0);
-        f.stat_kind = (all_simple && (f.aln_end - f.aln_beg) <= 2 && !amplicon_gated) ? 0 : 1;
-        if (f.stat_kind) sweep_frags.push_back((int32_t)fi);
-    }
-    lap("units / fragments (host)");
-    // pos-sorted order of the simple alignments, beg-sorted order of the fragments: made on the device below (after the uploads)
-    std::vector<int32_t> complex_ids;
-    int64_t n_simple = 0;
-    for (int64_t i = 0; i < n; i++) { if (kind[i] == 0) n_simple++; else complex_ids.push_back((int32_t)i); }
-    if (r->npos >= ((int64_t)1 << 31)) return fail(UVCGPU_EUNSUPPORTED, "region longer than 2^31");
-    { int32_t n0 = 0; for (const FragRec &f : frags) if (f.strand == 0) n0++; r->R.frag_off[0] = 0; r->R.frag_off[1] = n0; r->R.frag_off[2] = (int32_t)frags.size(); }
-
-    // uploads
+    const int64_t n = d->n_reads;
+    if (r->npos >= ((int64_t)1 << 29)) return fail(UVCGPU_EUNSUPPORTED, "region longer than 2^29");
+    if (d->n_bases >= ((int64_t)1 << 31)) return fail(UVCGPU_EUNSUPPORTED, "more than 2^31 read bases in one region: split the region");
+    UvcPrepIn in; memset(&in, 0, sizeof(in));
+    in.n_reads = n; in.n_bases = d->n_bases; in.n_cigar_ops = d->n_cigar_ops; in.n_fams = d->n_fams;
+    in.pos = d->pos; in.mpos = d->mpos; in.isize = d->isize; in.nm = d->nm; in.l_qseq = d->l_qseq; in.n_cigar = d->n_cigar; in.frag_id = d->frag_id; in.fam_id = d->fam_id;
+    in.flag = d->flag; in.mapq = d->mapq; in.fam_strand = d->fam_strand; in.fam_dflag = d->fam_dflag; in.seq_off = d->seq_off; in.cigar_off = d->cigar_off; in.cigars = d->cigars;
+    UvcPrepOut o; char msg[256];
+    int rc = uvc_prep_reads(&in, &r->P, r->beg, r->end, r->npos, prep_alloc, r, r->stream, &o, msg, (int)sizeof(msg));
+    if (rc) return fail(rc, msg);
+    lap("nesting + CIGAR facts (device)");
     RegionDev &R = r->R;
-    lap("sorts (host)");
     RawReads &W = r->W;
-    int rc;
-    auto up32 = [&](const int32_t *src, const int32_t **dst) { int32_t *d; int c = upload_raw(r, src, (size_t)n, &d); *dst = d; return c; };
-    auto up64 = [&](const int64_t *src, const int64_t **dst) { int64_t *d; int c = upload_raw(r, src, (size_t)n, &d); *dst = d; return c; };
-    std::vector<int32_t> flag32(n), mapq32(n);
-    for (int64_t i = 0; i < n; i++) { flag32[i] = in->flag[i]; mapq32[i] = in->mapq[i]; }
-    if ((rc = up32(in->pos, &W.pos)) || (rc = up32(endpos.data(), &W.endpos)) || (rc = up32(in->mpos, &W.mpos)) || (rc = up32(in->isize, &W.isize))
-        || (rc = up32(flag32.data(), &W.flag)) || (rc = up32(mapq32.data(), &W.mapq)) || (rc = up32(in->nm, &W.nm)) || (rc = up32(in->l_qseq, &W.l_qseq))
-        || (rc = up32(in->n_cigar, &W.n_cigar)) || (rc = up32(frag_of.data(), &W.frag)) || (rc = up32(fs_of.data(), &W.fs)) || (rc = up32(dflag_of.data(), &W.dflag))
-        || (rc = up32(kind.data(), &W.kind))
-        || (rc = up64(in->seq_off, &W.seq_off)) || (rc = up64(in->cigar_off, &W.cigar_off)) || (rc = up64(table_off.data(), &W.table_off)) || (rc = up64(item_off.data(), &W.item_off)) || (rc = up64(gap_off.data(), &W.gap_off))) return rc;
-    { uint8_t *d; if ((rc = upload_raw(r, in->bases, (size_t)in->n_bases, &d))) return rc; R.bases = d; }
-    { uint8_t *d; if ((rc = upload_raw(r, in->quals, (size_t)in->n_bases, &d))) return rc; R.quals = d; }
-    { if (in->n_bases >= ((int64_t)1 << 31)) return fail(UVCGPU_EUNSUPPORTED, "more than 2^31 read bases in one region: split the region");
-      uint16_t *d = nullptr; if (hipMalloc((void **)&d, (size_t)std::max<int64_t>(in->n_bases, 1) * 2) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(bq)");
-      r->owned.push_back(d); R.bq = d; R.bq_bytes = (uint32_t)(in->n_bases * 2);
-      uvc_launch_pack_bq(R.bases, R.quals, d, in->n_bases, r->stream); }
-    { uint32_t *d; if ((rc = upload_raw(r, in->cigars, (size_t)in->n_cigar_ops, &d))) return rc; R.cigars = d; }
-    { AlnRec *d; if ((rc = dev_alloc(r, (size_t)n, &d))) return rc; R.alns = d; R.n_alns = (int32_t)n; }
-    { AlnRec *d; if ((rc = dev_alloc(r, (size_t)n_simple, &d))) return rc; R.fast = d; R.n_fast = (int32_t)n_simple; }
-    { FastRec *d; if ((rc = dev_alloc(r, (size_t)n_simple, &d))) return rc; R.frec = d; }
-    { int32_t *d; if ((rc = upload(r, complex_ids, &d))) return rc; R.complex_ids = d; R.n_complex = (int32_t)complex_ids.size(); }
-    { FragRec *d; if ((rc = upload(r, frags, &d))) return rc; R.frags = d; R.n_frags = (int32_t)frags.size(); }
+    W.pos = d->pos; W.endpos = o.endpos; W.mpos = d->mpos; W.isize = d->isize; W.flag = d->flag; W.mapq = d->mapq; W.nm = d->nm; W.l_qseq = d->l_qseq; W.n_cigar = d->n_cigar;
+    W.frag = o.frag_of; W.fs = o.fs_of; W.dflag = o.dflag_of; W.kind = o.kind; W.seq_off = d->seq_off; W.cigar_off = d->cigar_off; W.table_off = o.table_off; W.item_off = o.item_off; W.gap_off = o.gap_off;
+    R.bases = d->bases; R.quals = d->quals; R.cigars = d->cigars;
+    R.frag_off[0] = 0; R.frag_off[1] = o.n_frag_strand0; R.frag_off[2] = o.n_frags;
+    const int64_t n_simple = o.n_simple; const size_t nf = (size_t)o.n_frags;
+    { uint16_t *b = nullptr; if ((rc = dev_alloc(r, (size_t)std::max<int64_t>(d->n_bases, 1), &b))) return rc; R.bq = b; R.bq_bytes = (uint32_t)(d->n_bases * 2);
+      uvc_launch_pack_bq(R.bases, R.quals, b, d->n_bases, r->stream); }
+    { AlnRec *a; if ((rc = dev_alloc(r, (size_t)n, &a))) return rc; R.alns = a; R.n_alns = (int32_t)n; }
+    { AlnRec *a; if ((rc = dev_alloc(r, (size_t)n_simple, &a))) return rc; R.fast = a; R.n_fast = (int32_t)n_simple; }
+    { FastRec *f; if ((rc = dev_alloc(r, (size_t)n_simple, &f))) return rc; R.frec = f; }
+    R.complex_ids = o.complex_ids; R.n_complex = o.n_complex;
+    R.frags = o.frags; R.n_frags = o.n_frags;
     {   // stable device sorts: simple alignments by begin (the others go behind them), fragments by (strand, begin) -- k_frag walks two
         // beg-sorted sub-lists, one per strand, so that the strand-specific accumulators are fixed registers
-        const size_t nf = frags.size(), nmax = std::max<size_t>(std::max<size_t>((size_t)n, nf), 1);
-        std::vector<int32_t> fb(nf), fst(nf), notsimple((size_t)n);
-        for (size_t k = 0; k < nf; k++) { fb[k] = frags[k].beg; fst[k] = frags[k].strand; }
-        for (int64_t i = 0; i < n; i++) notsimple[(size_t)i] = (kind[i] == 0 ? 0 : 1);
-        int32_t *d_fb, *d_fst, *d_ns, *d_rank, *d_fsorted, *d_frank; unsigned long long *work; uint8_t *tmp;
+        const size_t nmax = std::max<size_t>(std::max<size_t>((size_t)n, nf), 1);
+        int32_t *d_rank, *d_fsorted, *d_frank; unsigned long long *work; uint8_t *tmp;
         const size_t tmp_bytes = uvc_gap_sort_tmp_bytes(nmax);
-        if ((rc = upload(r, fb, &d_fb)) || (rc = upload(r, fst, &d_fst)) || (rc = upload(r, notsimple, &d_ns)) || (rc = dev_alloc(r, (size_t)n, &d_rank)) || (rc = dev_alloc(r, nf, &d_fsorted))
-            || (rc = dev_alloc(r, nf, &d_frank)) || (rc = dev_alloc(r, 4 * nmax, &work)) || (rc = dev_alloc(r, tmp_bytes + 16, &tmp))) return rc;
-        if (uvc_sort_by_pos_cls(W.pos, d_ns, r->beg, 31, n, work, tmp, tmp_bytes, r->stream) != 0) return fail(UVCGPU_EDEVICE, "device sort of the alignments failed");
+        if ((rc = dev_alloc(r, (size_t)n, &d_rank)) || (rc = dev_alloc(r, nf, &d_fsorted)) || (rc = dev_alloc(r, nf, &d_frank)) || (rc = dev_alloc(r, 4 * nmax, &work)) || (rc = dev_alloc(r, tmp_bytes + 16, &tmp))) return rc;
+        if (uvc_sort_by_pos_cls(W.pos, o.is_complex, r->beg, 31, n, work, tmp, tmp_bytes, r->stream) != 0) return fail(UVCGPU_EDEVICE, "device sort of the alignments failed");
         uvc_launch_rank_from_sorted(work + 3 * n, n, n_simple, nullptr, d_rank, r->stream);
         W.fast_rank = d_rank;
-        if (uvc_sort_by_pos_cls(d_fb, d_fst, r->beg, 31, (int64_t)nf, work, tmp, tmp_bytes, r->stream) != 0) return fail(UVCGPU_EDEVICE, "device sort of the fragments failed");
+        if (uvc_sort_by_pos_cls(o.frag_beg, o.frag_strand, r->beg, 31, (int64_t)nf, work, tmp, tmp_bytes, r->stream) != 0) return fail(UVCGPU_EDEVICE, "device sort of the fragments failed");
         uvc_launch_rank_from_sorted(work + 3 * nf, (int64_t)nf, (int64_t)nf, d_fsorted, d_frank, r->stream);
         R.frag_sorted = d_fsorted; R.frag_rank = d_frank;
     }
-    { FragFast *d; if ((rc = dev_alloc(r, frags.size(), &d, true))) return rc; R.ffast = d; }
-    { int32_t *d; if ((rc = upload(r, sweep_frags, &d))) return rc; R.sweep_frags = d; R.n_sweep = (int32_t)sweep_frags.size(); }
-    { int32_t *d; if ((rc = dev_alloc(r, frags.size() * (size_t)(UVC_MAXEV + 2) + 1, &d, true))) return rc;
-      R.frag_nmut = d; R.frag_mut = d + frags.size(); R.overflow_frags = d + frags.size() * (size_t)(UVC_MAXEV + 1); R.n_overflow = d + frags.size() * (size_t)(UVC_MAXEV + 2); }
-    { FsRec *d; if ((rc = upload(r, fss, &d))) return rc; R.fss = d; R.n_fs = (int32_t)fss.size(); }
-    { int32_t *d; if ((rc = upload(r, generic_fs, &d))) return rc; R.generic_fs = d; R.n_generic_fs = (int32_t)generic_fs.size(); R.n_generic_work = work; }
+    { FragFast *f; if ((rc = dev_alloc(r, nf, &f, true))) return rc; R.ffast = f; }
+    R.sweep_frags = o.sweep_frags; R.n_sweep = o.n_sweep;
+    { int32_t *q; if ((rc = dev_alloc(r, nf * (size_t)(UVC_MAXEV + 2) + 1, &q, true))) return rc;
+      R.frag_nmut = q; R.frag_mut = q + nf; R.overflow_frags = q + nf * (size_t)(UVC_MAXEV + 1); R.n_overflow = q + nf * (size_t)(UVC_MAXEV + 2); }
+    R.fss = o.fss; R.n_fs = o.n_fs;
+    R.generic_fs = o.generic_fs; R.n_generic_fs = o.n_generic; R.n_generic_work = o.work;
+    R.generic_sorted = o.generic_sorted; R.max_unit_span = o.max_unit_span;
     R.fam_digest = nullptr;
-    int32_t max_unit_frags = 0;
-    for (int32_t ui : generic_fs) max_unit_frags = std::max(max_unit_frags, fss[(size_t)ui].frag_end - fss[(size_t)ui].frag_beg);
-    if (work > 8 * r->npos && (size_t)work * 32 <= ((size_t)48 << 30) && max_unit_frags < 16384) {   // (the digest packs vote counts in 14 bits)
-      // deep data (the window family kernels): 32 B per (unit, position) so that P5 and the duplex pass do not walk the fragments again
-        uint32_t *d = nullptr; if ((rc = dev_alloc(r, (size_t)work * 8, &d))) return rc; R.fam_digest = d;
+    if (o.work > 8 * r->npos && (size_t)o.work * 32 <= ((size_t)48 << 30) && o.max_unit_frags < 16384) {   // (the digest packs vote counts in 14 bits)
+        // deep data (the window family kernels): 32 B per (unit, position) so that P5 and the duplex pass do not walk the fragments again
+        uint32_t *q = nullptr; if ((rc = dev_alloc(r, (size_t)o.work * 8, &q))) return rc; R.fam_digest = q;
     }
-    {   // the same units ordered by begin, for the position-window family kernels
-        std::vector<int32_t> ord(generic_fs.size()); std::iota(ord.begin(), ord.end(), 0);
-        std::vector<uint32_t> key(generic_fs.size());
-        int32_t span = 1;
-        for (size_t k = 0; k < generic_fs.size(); k++) { const FsRec &u = fss[generic_fs[k]]; key[k] = (uint32_t)(u.beg - r->beg); span = std::max(span, u.end - u.beg); }
-        radix_sort_ids(ord, key);
-        std::vector<int32_t> sorted(generic_fs.size()); for (size_t k = 0; k < ord.size(); k++) sorted[k] = generic_fs[ord[k]];
-        int32_t *d; if ((rc = upload(r, sorted, &d))) return rc; R.generic_sorted = d; R.max_unit_span = span;
-        if (timing) fprintf(stderr, "[uvcgpu set_reads] %zu fragments, %zu units, %zu generic units, %lld (unit, position) cells, longest unit %d, %lld positions\n", frags.size(), fss.size(), generic_fs.size(), (long long)work, span, (long long)r->npos);
-    }
-    { std::vector<Contrib> v; Contrib *d = nullptr; const size_t bytes = std::max<int64_t>(table_rows, 1) * sizeof(Contrib);
-      if (hipMalloc((void **)&d, bytes) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(table)"); r->owned.push_back(d); R.table = d; r->state_bytes += 0; (void)v; }
-    { Item *d = nullptr; if (hipMalloc((void **)&d, std::max<int64_t>(item_slots, 1) * sizeof(Item)) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(items)"); r->owned.push_back(d); R.items = d;
-      std::vector<int32_t> z(complex_ids.size() + 1, 0); int32_t *c; if ((rc = upload(r, z, &c))) return rc; R.item_cnt = c; }
+    if (timing) fprintf(stderr, "[uvcgpu set_reads] %d fragments, %d units, %d generic units, %lld (unit, position) cells, longest unit %d, %lld positions\n", o.n_frags, o.n_fs, o.n_generic, (long long)o.work, o.max_unit_span, (long long)r->npos);
+    { Contrib *t; if ((rc = dev_alloc(r, (size_t)std::max<int64_t>(o.table_rows, 1), &t))) return rc; R.table = t; }
+    { Item *t; if ((rc = dev_alloc(r, (size_t)std::max<int64_t>(o.item_slots, 1), &t))) return rc; R.items = t;
+      int32_t *c; if ((rc = dev_alloc(r, (size_t)o.n_complex + 1, &c, true))) return rc; R.item_cnt = c; }
     {   // InDel allele pipeline (k_gap_*): events, two sort stages, rows
+        const int64_t gap_slots = o.gap_slots, ins_total = o.ins_total;
         if (gap_slots >= ((int64_t)1 << 27)) return fail(UVCGPU_EUNSUPPORTED, "more than 2^27 InDel ops in one region");
         if (gap_slots > 0 && r->npos >= ((int64_t)1 << 26)) return fail(UVCGPU_EUNSUPPORTED, "region longer than 2^26 positions: split it (the InDel allele keys hold 26 position bits)");
         GapWork &G = R.gap; memset(&G, 0, sizeof(G));
@@ -601,61 +417,76 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
         G.sort_tmp_bytes = uvc_gap_sort_tmp_bytes(std::max(ne, ni));
         uint8_t *tmp; if ((rc = dev_alloc(r, G.sort_tmp_bytes + 16, &tmp))) return rc; G.sort_tmp = tmp;
     }
-    { std::vector<int32_t> z(4, 0); int32_t *c; if ((rc = upload(r, z, &c))) return rc; R.mis_cnt = c; R.mis_total = (unsigned long long *)(c + 2); R.mis = nullptr; R.mis_cap = 0; }
-    { if ((rc = upload(r, dup_units, &r->d_dup_units)) || (rc = upload(r, dup_off, &r->d_dup_off))) return rc; r->n_dup = (int)dup_units.size(); r->n_dup_work = dup_work; }
-    R.max_aln_span = max_aln_span; R.max_frag_span = max_frag_span;
-    R.any_amplicon = 0; for (int64_t f = 0; f < in->n_fams; f++) if (in->fam_dflag[f] & 0x4) { R.any_amplicon = 1; break; }
-    {   // fragment depth bound (k_frag packs two 16-bit bucket counters per LDS word when it is below 65 536)
-        if (frags.size() < 65536) R.max_frag_depth = (int32_t)frags.size();
-        else {
-            std::vector<int32_t> diff((size_t)r->npos + 2, 0);
-            for (const FragRec &f : frags) { diff[(size_t)(f.beg - r->beg)]++; diff[(size_t)(std::min(f.end, r->end) - r->beg)]--; }
-            int32_t run = 0, mx = 0;
-            for (size_t i = 0; i <= (size_t)r->npos; i++) { run += diff[i]; mx = std::max(mx, run); }
-            R.max_frag_depth = mx;
-        }
-    }
-    r->R.n_complex = (int32_t)complex_ids.size();
+    { int32_t *c; if ((rc = dev_alloc(r, (size_t)4, &c, true))) return rc; R.mis_cnt = c; R.mis_total = (unsigned long long *)(c + 2); R.mis = nullptr; R.mis_cap = 0; }
+    r->d_dup_units = o.dup_units; r->d_dup_off = o.dup_off; r->n_dup = o.n_dup; r->n_dup_work = o.dup_work;
+    R.max_aln_span = o.max_aln_span; R.max_frag_span = o.max_frag_span;
+    R.any_amplicon = o.any_amplicon;
+    R.max_frag_depth = o.max_frag_depth;   // k_frag packs two 16-bit bucket counters per LDS word when it is below 65 536
     // table rows are written by k_p2_slow<false>; mark all slots empty (0xFF)
-    HIP_OK(hipMemsetAsync(R.table, 0xFF, std::max<int64_t>(table_rows, 1) * sizeof(Contrib), r->stream));
-    lap("uploads");
+    HIP_OK(hipMemsetAsync(R.table, 0xFF, (size_t)std::max<int64_t>(o.table_rows, 1) * sizeof(Contrib), r->stream));
+    lap("allocations + orders");
     uvc_launch_prelude(&R, &W, &r->P, r->stream);
     lap("prelude kernel");
-    {
-        // stable order by (class, begin) on the device: begin - region begin < 2^29 and the class takes the two bits above
-        if (r->npos >= ((int64_t)1 << 29)) return fail(UVCGPU_EUNSUPPORTED, "region longer than 2^29");
-        const size_t np2 = p2.size();
-        for (int c = 0; c <= 4; c++) R.p2_off[c] = 0;
-        std::vector<int32_t> v_aln(np2), v_beg(np2), v_end(np2), v_qb(np2), v_cls(np2);
-        int32_t span = 1;
-        for (size_t j = 0; j < np2; j++) {
-            v_aln[j] = p2[j].aln; v_beg[j] = p2[j].cbeg; v_end[j] = p2[j].cend; v_qb[j] = p2[j].qb; v_cls[j] = p2[j].cls; span = std::max(span, p2[j].cend - p2[j].cbeg);
-            for (int c = p2[j].cls + 1; c <= 4; c++) R.p2_off[c]++;
-        }
-        int32_t *u_aln, *u_beg, *u_end, *u_qb, *u_cls; unsigned long long *work; uint8_t *tmp;
+    {   // the P2 work list: stable order by (class, begin) on the device -- begin - region begin < 2^29 and the class takes the two bits above
+        const size_t np2 = (size_t)o.n_p2;
+        for (int c = 0; c <= 4; c++) R.p2_off[c] = o.p2_off[c];
+        unsigned long long *work; uint8_t *tmp;
         const size_t tmp_bytes = uvc_gap_sort_tmp_bytes(std::max<size_t>(np2, 1));
-        if ((rc = upload(r, v_aln, &u_aln)) || (rc = upload(r, v_beg, &u_beg)) || (rc = upload(r, v_end, &u_end)) || (rc = upload(r, v_qb, &u_qb)) || (rc = upload(r, v_cls, &u_cls))
-            || (rc = dev_alloc(r, 4 * np2, &work)) || (rc = dev_alloc(r, tmp_bytes + 16, &tmp))) return rc;
+        if ((rc = dev_alloc(r, 4 * np2, &work)) || (rc = dev_alloc(r, tmp_bytes + 16, &tmp))) return rc;
         for (int k = 0; k < 4; k++) if ((rc = dev_alloc(r, np2, &r->d_p2[k]))) return rc;
-        if (uvc_sort_by_pos_cls(u_beg, u_cls, r->beg, 29, (int64_t)np2, work, tmp, tmp_bytes, r->stream) != 0) return fail(UVCGPU_EDEVICE, "device sort of the P2 work list failed");
-        uvc_launch_gather4(work + 3 * np2, (int64_t)np2, u_aln, u_beg, u_end, u_qb, r->d_p2[0], r->d_p2[1], r->d_p2[2], r->d_p2[3], r->stream);
-        { FastRec *d; if ((rc = dev_alloc(r, p2.size(), &d))) return rc; R.frec2 = d; R.n_fast2 = (int32_t)p2.size(); R.max_p2_span = span; }
+        if (uvc_sort_by_pos_cls(o.p2_beg, o.p2_cls, r->beg, 29, (int64_t)np2, work, tmp, tmp_bytes, r->stream) != 0) return fail(UVCGPU_EDEVICE, "device sort of the P2 work list failed");
+        uvc_launch_gather4(work + 3 * np2, (int64_t)np2, o.p2_aln, o.p2_beg, o.p2_end, o.p2_qb, r->d_p2[0], r->d_p2[1], r->d_p2[2], r->d_p2[3], r->stream);
+        { FastRec *f; if ((rc = dev_alloc(r, np2, &f))) return rc; R.frec2 = f; R.n_fast2 = (int32_t)np2; R.max_p2_span = o.max_p2_span; }
         uvc_launch_build_p2list(&R, r->d_p2[0], r->d_p2[1], r->d_p2[2], r->d_p2[3], r->stream);
     }
     HIP_OK(hipGetLastError());
-    HIP_OK(hipStreamSynchronize(r->stream));   // the staging vectors above die here
     {   // the queue of mismatching bases (k_p2_fast -> k_p2_mism) is sized from the count the prelude made
         unsigned long long total = 0;
-        HIP_OK(hipMemcpy(&total, R.mis_total, sizeof(total), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpyAsync(&total, R.mis_total, sizeof(total), hipMemcpyDeviceToHost, r->stream));
+        HIP_OK(hipStreamSynchronize(r->stream));
         if (total > ((unsigned long long)1 << 30)) return fail(UVCGPU_EUNSUPPORTED, "more than 2^30 mismatching bases in one region");
-        MisItem *d = nullptr;
-        if (hipMalloc((void **)&d, (size_t)(total + 64) * sizeof(MisItem)) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(mismatch queue)");
-        r->owned.push_back(d); R.mis = d; R.mis_cap = (int32_t)(total + 64);
+        MisItem *q = nullptr;
+        if ((rc = dev_alloc(r, (size_t)(total + 64), &q))) return rc;
+        R.mis = q; R.mis_cap = (int32_t)(total + 64);
     }
     lap("P2 list sort + build");
-    r->n_bases = in->n_bases;
+    r->n_bases = d->n_bases;
     r->has_reads = true;
     return 0;
+}
+
+// Host columns: they are copied to the device as they are (no host pass over the reads), then prepared there.
+int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
+    if (!r || !in || in->n_reads < 0 || in->n_fams < 0) return fail(UVCGPU_EINVAL, "bad reads");
+    const bool timing = (getenv("UVCGPU_TIMING") != nullptr);   // stderr breakdown of the ingest, for tuning
+    auto t_prev = std::chrono::steady_clock::now();
+    free_reads(r);
+    struct SyncOnExit { hipStream_t s; ~SyncOnExit() { hipStreamSynchronize(s); } } sync_on_exit = { r->stream };   // no copy may outlive the caller's arrays, on any return path
+    const int64_t n = in->n_reads;
+    if (n == 0) return 0;
+    if (n > INT32_MAX / 2) return fail(UVCGPU_EUNSUPPORTED, "more than 2^30 reads in one region");
+    if (in->n_bases < 0 || in->n_cigar_ops < 0) return fail(UVCGPU_EINVAL, "bad reads");
+    UvcReadSoA d = *in;
+    int rc;
+#define UP(field, T, count) { T *q; if ((rc = upload_raw(r, in->field, (size_t)(count), &q))) return rc; d.field = q; }
+    UP(pos, int32_t, n) UP(mpos, int32_t, n) UP(isize, int32_t, n) UP(flag, uint16_t, n) UP(mapq, uint8_t, n) UP(nm, int32_t, n) UP(l_qseq, int32_t, n)
+    UP(seq_off, int64_t, n) UP(cigar_off, int64_t, n) UP(n_cigar, int32_t, n) UP(frag_id, int32_t, n) UP(fam_id, int32_t, n) UP(fam_strand, uint8_t, n)
+    UP(bases, uint8_t, in->n_bases) UP(quals, uint8_t, in->n_bases) UP(cigars, uint32_t, in->n_cigar_ops) UP(fam_dflag, uint8_t, in->n_fams)
+#undef UP
+    if (timing) { hipStreamSynchronize(r->stream); const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[uvcgpu set_reads] %-28s %8.2f ms\n", "H2D of the columns", std::chrono::duration<double, std::milli>(t - t_prev).count()); t_prev = t; }
+    return set_reads_on_device(r, &d, timing, t_prev);
+}
+
+// The same with the columns already in HBM (every pointer of `in` is a device pointer on the handle's device): nothing is copied.  The
+// arrays must stay valid and unchanged until the handle gets other reads, is reset or destroyed -- the kernels of every accumulate
+// read bases / quals / cigars in place -- and uvcgpu_region_correct_bq edits `quals` in place, as the reference edits its bam1_t.
+int uvcgpu_region_set_reads_device(uvcgpu_region_t *r, const UvcReadSoA *in) {
+    if (!r || !in || in->n_reads < 0 || in->n_fams < 0 || in->n_bases < 0 || in->n_cigar_ops < 0) return fail(UVCGPU_EINVAL, "bad reads");
+    const bool timing = (getenv("UVCGPU_TIMING") != nullptr);
+    free_reads(r);
+    if (in->n_reads == 0) return 0;
+    if (in->n_reads > INT32_MAX / 2) return fail(UVCGPU_EUNSUPPORTED, "more than 2^30 reads in one region");
+    return set_reads_on_device(r, in, timing, std::chrono::steady_clock::now());
 }
 
 // apply_bq_err_correction3 (grouping.cpp:459-543) on the resident reads, then everything derived from the base qualities again:
@@ -973,9 +804,13 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
     if (rq.pos_beg < r->beg + (rq.base_at_pos_beg ? 1 : 0) || rq.pos_end > r->end - 1 || rq.pos_end < rq.pos_beg) return fail(UVCGPU_EINVAL, "score range outside the region");
     // InDel alleles: the region's own tables (fill_by_indel_info / indel_get_majority); a (refpos, symbol) the caller lists is overridden
     { int rc0 = gap_tables(r); if (rc0) return rc0; }
-    UvcIndelAllele *d_al = nullptr; int32_t *d_al_row = nullptr;
-    const UvcIndelAllele *use_al = r->d_gap_alleles; const int32_t *use_row = r->d_gap_allele_row; int64_t n_al = (int64_t)r->gap_alleles.size();
+    UvcIndelAllele *d_al = nullptr; int32_t *d_al_row = nullptr; UvcTumorKey *d_tk = nullptr;
     std::vector<UvcIndelAllele> merged; std::vector<int32_t> merged_row;
+    // the temporaries go back to the caching allocator, which hands them to other handles at once: on every return path the stream is
+    // drained first (async copies from `merged` / the caller's keys, kernels that read the blocks), then they are freed
+    struct Temps { uvcgpu_region *r; UvcIndelAllele *&a; int32_t *&b; UvcTumorKey *&c;
+                   ~Temps() { if (a || b || c) (void)hipStreamSynchronize(r->stream); if (a) hipFree(a); if (b) hipFree(b); if (c) hipFree(c); } } temps = { r, d_al, d_al_row, d_tk };
+    const UvcIndelAllele *use_al = r->d_gap_alleles; const int32_t *use_row = r->d_gap_allele_row; int64_t n_al = (int64_t)r->gap_alleles.size();
     if (rq.n_indel_alleles > 0) {
         auto less = [](const UvcIndelAllele &a, const UvcIndelAllele &b) { return a.refpos < b.refpos || (a.refpos == b.refpos && a.symbol < b.symbol); };
         for (int64_t q = 1; q < rq.n_indel_alleles; q++) if (less(rq.indel_alleles[q], rq.indel_alleles[q - 1])) return fail(UVCGPU_EINVAL, "indel_alleles must be sorted by (refpos, symbol)");
@@ -989,16 +824,15 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
         }
         n_al = (int64_t)merged.size();
         HIP_OK(hipMalloc((void **)&d_al, sizeof(UvcIndelAllele) * (size_t)n_al));
-        if (hipMalloc((void **)&d_al_row, sizeof(int32_t) * (size_t)n_al) != hipSuccess) { hipFree(d_al); return fail(UVCGPU_ENOMEM, "hipMalloc(alleles)"); }
+        HIP_OK(hipMalloc((void **)&d_al_row, sizeof(int32_t) * (size_t)n_al));
         HIP_OK(hipMemcpyAsync(d_al, merged.data(), sizeof(UvcIndelAllele) * (size_t)n_al, hipMemcpyHostToDevice, r->stream));
         HIP_OK(hipMemcpyAsync(d_al_row, merged_row.data(), sizeof(int32_t) * (size_t)n_al, hipMemcpyHostToDevice, r->stream));
         use_al = d_al; use_row = d_al_row;
     }
-    UvcTumorKey *d_tk = nullptr;
     if (r->P.tumor_vcf_is_provided && rq.n_tumor_keys > 0) {   // normal sample of a T/N pair: the tumor records, sorted by (refpos, symbol)
         for (int64_t q = 1; q < rq.n_tumor_keys; q++) {
             const UvcTumorKey &a = rq.tumor_keys[q - 1], &b = rq.tumor_keys[q];
-            if (a.refpos > b.refpos || (a.refpos == b.refpos && a.symbol > b.symbol)) { if (d_al) hipFree(d_al); if (d_al_row) hipFree(d_al_row); return fail(UVCGPU_EINVAL, "tumor_keys must be sorted by (refpos, symbol)"); }
+            if (a.refpos > b.refpos || (a.refpos == b.refpos && a.symbol > b.symbol)) return fail(UVCGPU_EINVAL, "tumor_keys must be sorted by (refpos, symbol)");
         }
         HIP_OK(hipMalloc((void **)&d_tk, sizeof(UvcTumorKey) * rq.n_tumor_keys));
         HIP_OK(hipMemcpyAsync(d_tk, rq.tumor_keys, sizeof(UvcTumorKey) * rq.n_tumor_keys, hipMemcpyHostToDevice, r->stream));
@@ -1038,10 +872,7 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
                              || hipStreamSynchronize(r->stream) != hipSuccess))
             rc = fail(UVCGPU_EDEVICE, "hipMemcpy2D(records)");
     }
-    if (d_al) hipFree(d_al);
-    if (d_al_row) hipFree(d_al_row);
-    if (d_tk) hipFree(d_tk);
-    return rc;
+    return rc;   // ~Temps frees the temporaries
 }
 
 void uvcgpu_region_destroy(uvcgpu_region_t *r) {

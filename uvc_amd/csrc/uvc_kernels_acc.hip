@@ -328,8 +328,9 @@ DEV void primer_window(const UvcParams &P, const AlnRec &a, int &ibeg, int &iend
 // ------------------------------------------------------------------------------------------------
 // k_aln_prelude: one thread per alignment (main.hpp:1795-1885 prelude of updateByAln)
 // ------------------------------------------------------------------------------------------------
-struct RawReads {
-    const int32_t *pos, *endpos, *mpos, *isize, *flag, *mapq, *nm, *l_qseq, *n_cigar, *frag, *fs, *dflag, *kind, *fast_rank;
+struct RawReads {   // the caller's columns as they are (uvcgpu_region_set_reads) + what uvc_prep.hip derives per read
+    const int32_t *pos, *endpos, *mpos, *isize, *nm, *l_qseq, *n_cigar, *frag, *fs, *dflag, *kind, *fast_rank;
+    const uint16_t *flag; const uint8_t *mapq;
     const int64_t *seq_off, *cigar_off, *table_off, *item_off, *gap_off;
 };
 

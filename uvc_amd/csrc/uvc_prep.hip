@@ -1,0 +1,348 @@
+// uvc_prep.hip -- the read-dependent preparation of uvcgpu_region_set_reads as device kernels: what every later kernel needs to know
+// about the alns3 nesting (family -> strand -> fragment -> alignment, main.hpp:3672) and about each CIGAR before the first pass runs.
+// Input: the caller's UvcReadSoA columns, already in HBM.  Output: per-read facts (bam_endpos, simple / InDel kind, table / item /
+// InDel-event offsets), FragRec / FsRec records with the reference's span rules (fillTidBegEndFromAlns1 / 2, main.hpp:658-697), the
+// unit lists of the family kernels, the fragment lists of the statistics kernels and the P2 work-list entries.
+// Everything is a per-read map, a prefix sum (rocPRIM) or a per-fragment / per-unit fold; two small read-backs size the allocations.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_scan.hpp>
+#include <stdint.h>
+#include "uvc_prep.h"
+
+namespace {
+#define PDEV __device__ __forceinline__
+PDEV int pmin(int a, int b) { return a < b ? a : b; }
+PDEV int pmax(int a, int b) { return a > b ? a : b; }
+enum { PC_MATCH = 0, PC_INS = 1, PC_DEL = 2, PC_REF_SKIP = 3, PC_SOFT_CLIP = 4, PC_HARD_CLIP = 5, PC_PAD = 6, PC_EQUAL = 7, PC_DIFF = 8 };
+PDEV bool is_m(int op) { return op == PC_MATCH || op == PC_EQUAL || op == PC_DIFF; }
+
+struct Stage1 {   // device counters of the first stage (read back once)
+    int32_t err, max_aln_span, n_frags, n_fs, n_complex, any_amplicon;
+    int32_t p2_cls[4]; int32_t max_p2_span, pad_;
+    int64_t n_p2, table_rows, item_slots, gap_slots, ins_total;
+};
+struct Stage2 {
+    int32_t err, max_frag_span, max_unit_span, max_unit_frags, n_generic, n_dup, n_sweep, n_frag_strand0, max_frag_depth, pad_;
+    int64_t work, dup_work;
+};
+
+// ---- stage 1: what the CIGAR of each read says (nothing here depends on another read except the two "is a new ..." flags) ----
+__global__ void __launch_bounds__(256) k_read_facts(UvcPrepIn in, int32_t rbeg, int32_t rend, int seg_eligible,
+                                                    int32_t *endpos, int32_t *kind, int32_t *dflag_of, int32_t *new_frag, int32_t *new_fs, int32_t *is_complex,
+                                                    int32_t *n_p2, int64_t *gaps, int64_t *trows, int64_t *items, int64_t *ins, Stage1 *T) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= in.n_reads) return;
+    const int32_t nc = in.n_cigar[i], lq = in.l_qseq[i], pos = in.pos[i];
+    int32_t o_end = pos + 1, o_kind = 1, o_np2 = 0; int64_t o_gaps = 0, o_trows = 0, o_items = 0, o_ins = 0;
+    int err = 0;
+    const int fam = in.fam_id[i], strand = in.fam_strand[i];
+    if (fam < 0 || fam >= in.n_fams || strand > 1) err = 5;
+    if (in.seq_off[i] < 0 || in.seq_off[i] + lq > in.n_bases || in.cigar_off[i] < 0 || in.cigar_off[i] + nc > in.n_cigar_ops || nc < 1) err = 1;
+    if (!err) {
+        const uint32_t *cg = in.cigars + in.cigar_off[i];
+        int32_t e = pos; int64_t q = 0, del_total = 0; int n_m = 0; bool simple = true;
+        for (int k = 0; k < nc; k++) {
+            const int op = (int)(cg[k] & 0xF); const int32_t len = (int32_t)(cg[k] >> 4);
+            if (op > PC_DIFF) { err = 2; break; }
+            if (is_m(op) || op == PC_DEL || op == PC_REF_SKIP) e += len;
+            if (is_m(op) || op == PC_INS || op == PC_SOFT_CLIP) q += len;
+            if (is_m(op)) n_m++;
+            else if (!(op == PC_SOFT_CLIP || op == PC_HARD_CLIP)) simple = false;
+            if (op == PC_INS || op == PC_DEL) o_gaps++;
+            if (op == PC_INS) o_ins += len;
+            if (op == PC_DEL) del_total += len;
+        }
+        if (!err) {
+            if (e == pos) e = pos + 1;   // bam_endpos of a read without reference-consuming ops
+            if (q != lq) err = 3;
+        }
+        if (!err) {
+            if (n_m != 1 || nc > 3) simple = false;
+            if (simple && nc == 3) { const int o0 = cg[0] & 0xF, o2 = cg[2] & 0xF; if (is_m(o0) || is_m(o2)) simple = false; }
+            if (pos < rbeg || e > rend - 1) err = 4;
+        }
+        if (!err) {
+            // P2 work list (k_p2_fast): a simple alignment is one entry; an InDel read contributes its M runs (used when its InDels are all high-quality)
+            bool ok = simple || seg_eligible;
+            int32_t rp = pos, np2 = 0, span = 1;
+            for (int k = 0; k < nc && ok; k++) {
+                const int op = (int)(cg[k] & 0xF); const int32_t len = (int32_t)(cg[k] >> 4);
+                if (is_m(op)) { if (rp - pos > 65535 || e - (rp + len) > 65535) ok = false; np2++; span = pmax(span, len); rp += len; }
+                else if (op == PC_DEL) rp += len;
+                else if (op == PC_INS || op == PC_SOFT_CLIP || op == PC_HARD_CLIP) {}
+                else ok = false;   // N / P: keep the sequential path
+            }
+            o_end = e; o_np2 = (ok ? np2 : 0);
+            // kind 2 = candidate for the simple path: k_aln_prelude demotes it to 1 when the read has a low-quality InDel
+            o_kind = simple ? 0 : (ok ? 2 : 1);
+            if (!simple) { o_trows = (e - pos) + 1; o_items = 2 * (int64_t)lq + 2 * del_total + nc + 4; }
+            else { o_gaps = 0; o_ins = 0; atomicMax(&T->max_aln_span, e - pos); }
+            if (o_np2) {
+                const int fl = in.flag[i];
+                const int cls = ((fl & 0x10) ? 1 : 0) | ((((fl & 0x81) == 0x81) ? ((fl & 0x20) != 0) : ((fl & 0x10) != 0)) ? 2 : 0);   // is-reverse | bam_get_strand << 1 (common.hpp:89)
+                atomicAdd(&T->p2_cls[cls], o_np2); atomicMax(&T->max_p2_span, span);
+            }
+        }
+    }
+    if (err) { atomicMax(&T->err, err); o_kind = 1; o_gaps = 0; o_ins = 0; o_np2 = 0; }
+    endpos[i] = o_end; kind[i] = o_kind; n_p2[i] = o_np2; gaps[i] = o_gaps; trows[i] = o_trows; items[i] = o_items; ins[i] = o_ins; is_complex[i] = (o_kind != 0);
+    const bool ok_fam = (err != 5);
+    const int df = ok_fam ? (int)in.fam_dflag[fam] : 0;
+    dflag_of[i] = df;
+    if (df & 0x4) T->any_amplicon = 1;
+    const bool nfs = (i == 0) || in.fam_id[i - 1] != fam || in.fam_strand[i - 1] != strand;
+    new_fs[i] = nfs; new_frag[i] = (nfs || in.frag_id[i - 1] != in.frag_id[i]);
+}
+
+// the prefix sums of stage 1 -> indices / offsets; -1 offsets for simple alignments
+__global__ void __launch_bounds__(256) k_finish_facts(int64_t n, const int32_t *kind, int32_t *frag_of /* inclusive scan of new_frag, in place */, int32_t *fs_of,
+                                                      const int32_t *complex_rank, int64_t *table_off, int64_t *item_off, int64_t *gap_off, int32_t *complex_ids) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    frag_of[i] -= 1; fs_of[i] -= 1;
+    if (kind[i] == 0) { table_off[i] = -1; item_off[i] = -1; gap_off[i] = -1; }
+    else complex_ids[complex_rank[i]] = (int32_t)i;
+}
+__global__ void k_stage1_totals(int64_t n, const int32_t *frag_incl, const int32_t *fs_incl, const int32_t *complex_rank, const int32_t *is_complex,
+                                const int32_t *p2_first, const int32_t *n_p2, const int64_t *t_off, const int64_t *trows, const int64_t *i_off, const int64_t *items,
+                                const int64_t *g_off, const int64_t *gaps, const int64_t *ins_off, const int64_t *ins, Stage1 *T) {
+    if (n <= 0) return;
+    const int64_t l = n - 1;
+    T->n_frags = frag_incl[l]; T->n_fs = fs_incl[l]; T->n_complex = complex_rank[l] + is_complex[l];
+    T->n_p2 = (int64_t)p2_first[l] + n_p2[l]; T->table_rows = t_off[l] + trows[l]; T->item_slots = i_off[l] + items[l]; T->gap_slots = g_off[l] + gaps[l]; T->ins_total = ins_off[l] + ins[l];
+}
+
+// ---- stage 2: the nesting ----
+__global__ void __launch_bounds__(256) k_mark_first(UvcPrepIn in, const int32_t *new_frag, const int32_t *new_fs, const int32_t *frag_of, const int32_t *fs_of,
+                                                    int32_t *frag_first, int32_t *fs_first_frag, int32_t *fam_fs, int32_t n_frags, int32_t n_fs, Stage2 *T) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { frag_first[n_frags] = (int32_t)in.n_reads; fs_first_frag[n_fs] = n_frags; }
+    if (i >= in.n_reads) return;
+    if (new_frag[i]) frag_first[frag_of[i]] = (int32_t)i;
+    if (new_fs[i]) {
+        fs_first_frag[fs_of[i]] = frag_of[i];
+        const int slot = in.fam_id[i] * 2 + in.fam_strand[i];
+        if (atomicCAS(&fam_fs[slot], -1, fs_of[i]) != -1) atomicMax(&T->err, 6);   // reads of one (fam_id, fam_strand) are not contiguous
+    }
+}
+// one thread per fragment: fillTidBegEndFromAlns1 (main.hpp:658-673) with its cumulative "+1 per alignment"
+__global__ void __launch_bounds__(256) k_build_frags(UvcPrepIn in, UvcParams P, int32_t rend, const int32_t *endpos, const int32_t *kind, const int32_t *fs_of, const int32_t *dflag_of,
+                                                     const int32_t *frag_first, int32_t n_frags, FragRec *frags, int32_t *sweep_flag, int32_t *frag_beg, int32_t *frag_strand, Stage2 *T) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frags) return;
+    FragRec r; memset(&r, 0, sizeof(r));
+    const int a0 = frag_first[f], a1 = frag_first[f + 1];
+    r.aln_beg = a0; r.aln_end = a1; r.beg = INT32_MAX; r.end = 0; r.fs = fs_of[a0]; r.strand = in.fam_strand[a0]; r.dflag = dflag_of[a0];
+    bool all_simple = true;
+    for (int k = a0; k < a1; k++) {
+        r.beg = pmin(r.beg, in.pos[k]); r.end = pmax(r.end, endpos[k]) + 1;
+        r.normMQ = pmax(r.normMQ, (int)in.mapq[k]);
+        all_simple = all_simple && (kind[k] == 0);
+    }
+    r.end = pmin(r.end, rend);
+    const bool amplicon_gated = (((r.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag))) && !(P.tn_is_paired && (0x1 & P.primer_flag)));
+    r.stat_kind = (all_simple && (a1 - a0) <= 2 && !amplicon_gated) ? 0 : 1;
+    sweep_flag[f] = r.stat_kind; frag_beg[f] = r.beg; frag_strand[f] = r.strand;
+    frags[f] = r;
+    atomicMax(&T->max_frag_span, r.end - r.beg);
+    if (r.strand == 0) atomicAdd(&T->n_frag_strand0, 1);
+}
+// one thread per family-strand unit: fillTidBegEndFromAlns2 (main.hpp:675-697), the duplex partner, which kernels take it
+__global__ void __launch_bounds__(256) k_build_units(UvcPrepIn in, UvcParams P, int32_t rend, const int32_t *endpos, const int32_t *dflag_of, const int32_t *frag_first, const int32_t *fs_first_frag,
+                                                     const int32_t *fam_fs, int32_t n_fs, FsRec *fss, int32_t *generic_flag, int64_t *gen_span, Stage2 *T) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_fs) return;
+    FsRec r; memset(&r, 0, sizeof(r));
+    r.frag_beg = fs_first_frag[u]; r.frag_end = fs_first_frag[u + 1];
+    const int a0 = frag_first[r.frag_beg], a1 = frag_first[r.frag_end];
+    r.beg = INT32_MAX; r.end = 0; r.strand = in.fam_strand[a0]; r.fam = in.fam_id[a0]; r.dflag = dflag_of[a0];
+    for (int k = a0; k < a1; k++) { r.beg = pmin(r.beg, in.pos[k]); r.end = pmax(r.end, endpos[k]) + 1; }
+    r.end = pmin(r.end, rend);
+    r.other_fs = fam_fs[r.fam * 2 + (1 - r.strand)];
+    const bool singleton_ok = (P.fam_thres_dup1add >= 2 && P.fam_thres_dup2add >= 2 && P.fam_thres_emperr_all_flat_snv >= 2 && P.fam_thres_emperr_all_flat_indel >= 2);
+    const bool duplex = ((r.dflag & 0x2) && r.other_fs >= 0);
+    r.generic = ((r.frag_end - r.frag_beg) >= 2 || duplex || !singleton_ok) ? 1 : 0;
+    r.work_off = 0;
+    fss[u] = r;
+    generic_flag[u] = r.generic; gen_span[u] = r.generic ? (int64_t)(r.end - r.beg) : 0;
+    if (r.generic) { atomicMax(&T->max_unit_span, r.end - r.beg); atomicMax(&T->max_unit_frags, r.frag_end - r.frag_beg); }
+}
+__global__ void __launch_bounds__(256) k_units_post(int32_t rend, int32_t n_fs, FsRec *fss, const int32_t *generic_rank, const int64_t *work_off, int32_t *generic_fs,
+                                                    int32_t *dup_flag, int64_t *dup_span) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_fs) return;
+    FsRec &r = fss[u];
+    int32_t df = 0; int64_t ds = 0;
+    if (r.generic) { r.work_off = work_off[u]; generic_fs[generic_rank[u]] = u; }
+    if ((r.dflag & 0x2) && r.other_fs >= 0 && r.strand == 0) {
+        const FsRec &o = fss[r.other_fs];
+        df = 1; ds = (int64_t)(pmax(r.end, pmin(o.end, rend)) - pmin(r.beg, o.beg));
+    }
+    dup_flag[u] = df; dup_span[u] = ds;
+}
+__global__ void __launch_bounds__(256) k_compact_dups(int32_t n_fs, const int32_t *dup_flag, const int32_t *dup_rank, const int64_t *dup_off_all, int32_t *dup_units, int64_t *dup_off) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_fs || !dup_flag[u]) return;
+    dup_units[dup_rank[u]] = u; dup_off[dup_rank[u]] = dup_off_all[u];
+}
+__global__ void __launch_bounds__(256) k_frags_post(int32_t n_frags, FragRec *frags, const FsRec *fss, const int32_t *sweep_flag, const int32_t *sweep_rank, int32_t *sweep_frags,
+                                                    int32_t rbeg, int32_t *depth_diff) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frags) return;
+    frags[f].singleton = fss[frags[f].fs].generic ? 0 : 1;
+    if (sweep_flag[f]) sweep_frags[sweep_rank[f]] = f;
+    if (depth_diff) { atomicAdd(&depth_diff[frags[f].beg - rbeg], 1); atomicAdd(&depth_diff[frags[f].end - rbeg], -1); }
+}
+__global__ void k_stage2_totals(int32_t n_fs, int32_t n_frags, const int32_t *generic_rank, const int32_t *generic_flag, const int64_t *work_off, const int64_t *gen_span,
+                                const int32_t *dup_rank, const int32_t *dup_flag, const int64_t *dup_off_all, const int64_t *dup_span,
+                                const int32_t *sweep_rank, const int32_t *sweep_flag, Stage2 *T) {
+    if (n_fs > 0) { const int l = n_fs - 1; T->n_generic = generic_rank[l] + generic_flag[l]; T->work = work_off[l] + gen_span[l]; T->n_dup = dup_rank[l] + dup_flag[l]; T->dup_work = dup_off_all[l] + dup_span[l]; }
+    if (n_frags > 0) { const int l = n_frags - 1; T->n_sweep = sweep_rank[l] + sweep_flag[l]; }
+}
+__global__ void __launch_bounds__(256) k_max_i32(const int32_t *v, int64_t n, int32_t *out) {
+    int32_t m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = pmax(m, v[i]);
+    for (int d = 32; d > 0; d >>= 1) m = pmax(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+// the P2 work-list entries at their places (one thread per alignment; the order by (class, begin) is made afterwards)
+__global__ void __launch_bounds__(256) k_p2_entries(UvcPrepIn in, const int32_t *n_p2, const int32_t *p2_first, int32_t *p_aln, int32_t *p_beg, int32_t *p_end, int32_t *p_qb, int32_t *p_cls) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= in.n_reads || n_p2[i] == 0) return;
+    const int32_t nc = in.n_cigar[i];
+    const uint32_t *cg = in.cigars + in.cigar_off[i];
+    const int fl = in.flag[i];
+    const int32_t cls = ((fl & 0x10) ? 1 : 0) | ((((fl & 0x81) == 0x81) ? ((fl & 0x20) != 0) : ((fl & 0x10) != 0)) ? 2 : 0);
+    int32_t rp = in.pos[i]; int64_t qp = 0; int64_t w = p2_first[i];
+    for (int k = 0; k < nc; k++) {
+        const int op = (int)(cg[k] & 0xF); const int32_t len = (int32_t)(cg[k] >> 4);
+        if (is_m(op)) { p_aln[w] = (int32_t)i; p_beg[w] = rp; p_end[w] = rp + len; p_qb[w] = (int32_t)((in.seq_off[i] + qp - rp) & 0xFFFFFFFFLL); p_cls[w] = cls; w++; rp += len; qp += len; }
+        else if (op == PC_INS || op == PC_SOFT_CLIP) qp += len;
+        else if (op == PC_DEL) rp += len;
+    }
+}
+__global__ void __launch_bounds__(256) k_unit_keys(const FsRec *fss, const int32_t *generic_fs, int32_t n, int32_t *beg_of, int32_t *zero) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    beg_of[k] = fss[generic_fs[k]].beg; zero[k] = 0;
+}
+__global__ void __launch_bounds__(256) k_take_units(const unsigned long long *perm, const int32_t *generic_fs, int32_t n, int32_t *sorted) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    sorted[k] = generic_fs[(int32_t)perm[k]];
+}
+
+unsigned nblk(int64_t n, int b) { return (unsigned)std::max<int64_t>((n + b - 1) / b, 1); }
+template <class T> size_t scan_tmp_bytes(int64_t n) { size_t b = 0; T *p = nullptr; rocprim::exclusive_scan(nullptr, b, p, p, T(0), (size_t)std::max<int64_t>(n, 1), rocprim::plus<T>(), (hipStream_t)0); return b; }
+}   // namespace
+
+extern "C" int uvc_sort_by_pos_cls(const int32_t *d_pos, const int32_t *d_cls, int32_t beg, int shift, int64_t n, unsigned long long *work, void *tmp, size_t tmp_bytes, hipStream_t s);
+extern "C" size_t uvc_gap_sort_tmp_bytes(size_t n);
+
+#define PREP_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf(errmsg, (size_t)errcap, "%s: %s", #call, hipGetErrorString(e_)); return UVCGPU_EDEVICE; } } while (0)
+
+extern "C" int uvc_prep_reads(const UvcPrepIn *inp, const UvcParams *P, int32_t rbeg, int32_t rend, int64_t npos, UvcPrepAlloc alloc, void *ctx, hipStream_t s,
+                              UvcPrepOut *out, char *errmsg, int errcap) {
+    const UvcPrepIn &in = *inp;
+    const int64_t n = in.n_reads;
+    memset(out, 0, sizeof(*out));
+    errmsg[0] = 0;
+    auto A = [&](size_t bytes, int zero) -> void * { return alloc(ctx, std::max<size_t>(bytes, 8), zero); };
+#define ALLOC(ptr, T, count, zero) do { ptr = (T *)A(sizeof(T) * (size_t)(count), zero); if (!ptr) { snprintf(errmsg, (size_t)errcap, "hipMalloc(%s)", #ptr); return UVCGPU_ENOMEM; } } while (0)
+    const int seg_eligible = (UVC_PLATFORM_IONTORRENT != P->inferred_sequencing_platform) && rbeg >= 65536 && P->bias_thres_interfering_indel <= 10000;
+    // ---- stage 1
+    int32_t *new_frag, *new_fs, *is_complex, *complex_rank, *n_p2; int64_t *gaps, *trows, *items, *ins, *ins_off;
+    ALLOC(out->endpos, int32_t, n, 0); ALLOC(out->kind, int32_t, n, 0); ALLOC(out->dflag_of, int32_t, n, 0); ALLOC(out->frag_of, int32_t, n, 0); ALLOC(out->fs_of, int32_t, n, 0);
+    ALLOC(out->table_off, int64_t, n, 0); ALLOC(out->item_off, int64_t, n, 0); ALLOC(out->gap_off, int64_t, n, 0); ALLOC(out->p2_first, int32_t, n, 0);
+    ALLOC(new_frag, int32_t, n, 0); ALLOC(new_fs, int32_t, n, 0); ALLOC(is_complex, int32_t, n, 0); out->is_complex = is_complex; ALLOC(complex_rank, int32_t, n, 0); ALLOC(n_p2, int32_t, n, 0); ALLOC(gaps, int64_t, n, 0);
+    ALLOC(trows, int64_t, n, 0); ALLOC(items, int64_t, n, 0); ALLOC(ins, int64_t, n, 0); ALLOC(ins_off, int64_t, n, 0);
+    Stage1 *dT1; ALLOC(dT1, Stage1, 1, 1);
+    Stage2 *dT2; ALLOC(dT2, Stage2, 1, 1);
+    const size_t tmp_bytes = std::max(scan_tmp_bytes<int32_t>(n), scan_tmp_bytes<int64_t>(n)) + 64;
+    void *tmp; ALLOC(tmp, char, tmp_bytes, 0);
+    hipLaunchKernelGGL(k_read_facts, dim3(nblk(n, 256)), dim3(256), 0, s, in, rbeg, rend, seg_eligible, out->endpos, out->kind, out->dflag_of, new_frag, new_fs, is_complex, n_p2, gaps, trows, items, ins, dT1);
+    size_t tb = tmp_bytes;
+    int64_t *gap_off64 = out->gap_off;
+    PREP_HIP(rocprim::inclusive_scan(tmp, tb, new_frag, out->frag_of, (size_t)n, rocprim::plus<int32_t>(), s)); tb = tmp_bytes;
+    PREP_HIP(rocprim::inclusive_scan(tmp, tb, new_fs, out->fs_of, (size_t)n, rocprim::plus<int32_t>(), s)); tb = tmp_bytes;
+    PREP_HIP(rocprim::exclusive_scan(tmp, tb, is_complex, complex_rank, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), s)); tb = tmp_bytes;
+    PREP_HIP(rocprim::exclusive_scan(tmp, tb, n_p2, out->p2_first, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), s)); tb = tmp_bytes;
+    PREP_HIP(rocprim::exclusive_scan(tmp, tb, trows, out->table_off, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s)); tb = tmp_bytes;
+    PREP_HIP(rocprim::exclusive_scan(tmp, tb, items, out->item_off, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s)); tb = tmp_bytes;
+    PREP_HIP(rocprim::exclusive_scan(tmp, tb, ins, ins_off, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s)); tb = tmp_bytes;
+    PREP_HIP(rocprim::exclusive_scan(tmp, tb, gaps, gap_off64, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s)); tb = tmp_bytes;
+    hipLaunchKernelGGL(k_stage1_totals, dim3(1), dim3(1), 0, s, n, out->frag_of, out->fs_of, complex_rank, is_complex, out->p2_first, n_p2, out->table_off, trows, out->item_off, items, gap_off64, gaps, ins_off, ins, dT1);
+    Stage1 T1;
+    PREP_HIP(hipMemcpyAsync(&T1, dT1, sizeof(T1), hipMemcpyDeviceToHost, s));
+    PREP_HIP(hipStreamSynchronize(s));
+    if (T1.err) {
+        const char *m = T1.err == 1 ? "read offsets out of range" : T1.err == 2 ? "unsupported CIGAR op (process_cigar throws, main_conversion.hpp:902-916)" : T1.err == 3 ? "CIGAR query length != l_qseq"
+                      : T1.err == 4 ? "read outside region" : "fam_id / fam_strand out of range";
+        snprintf(errmsg, (size_t)errcap, "%s", m);
+        return T1.err == 2 ? UVCGPU_EUNSUPPORTED : UVCGPU_EINVAL;
+    }
+    out->n_frags = T1.n_frags; out->n_fs = T1.n_fs; out->n_complex = T1.n_complex; out->n_simple = (int32_t)(n - T1.n_complex); out->n_p2 = T1.n_p2; out->table_rows = T1.table_rows;
+    out->item_slots = T1.item_slots; out->gap_slots = T1.gap_slots; out->ins_total = T1.ins_total; out->max_aln_span = std::max(T1.max_aln_span, 1); out->any_amplicon = T1.any_amplicon;
+    out->max_p2_span = std::max(T1.max_p2_span, 1);
+    out->p2_off[0] = 0; for (int c = 0; c < 4; c++) out->p2_off[c + 1] = out->p2_off[c] + T1.p2_cls[c];
+    ALLOC(out->complex_ids, int32_t, T1.n_complex, 0);
+    hipLaunchKernelGGL(k_finish_facts, dim3(nblk(n, 256)), dim3(256), 0, s, n, out->kind, out->frag_of, out->fs_of, complex_rank, out->table_off, out->item_off, out->gap_off, out->complex_ids);
+    // ---- stage 2
+    const int32_t nf = T1.n_frags, nu = T1.n_fs;
+    int32_t *frag_first, *fs_first_frag, *fam_fs, *sweep_flag, *sweep_rank, *generic_flag, *generic_rank, *dup_flag, *dup_rank; int64_t *gen_span, *work_off, *dup_span, *dup_off_all;
+    ALLOC(frag_first, int32_t, nf + 1, 0); ALLOC(fs_first_frag, int32_t, nu + 1, 0); ALLOC(fam_fs, int32_t, (size_t)in.n_fams * 2, 0);
+    PREP_HIP(hipMemsetAsync(fam_fs, 0xFF, sizeof(int32_t) * std::max<size_t>((size_t)in.n_fams * 2, 1), s));
+    ALLOC(sweep_flag, int32_t, nf, 0); ALLOC(sweep_rank, int32_t, nf, 0); ALLOC(generic_flag, int32_t, nu, 0); ALLOC(generic_rank, int32_t, nu, 0); ALLOC(dup_flag, int32_t, nu, 0); ALLOC(dup_rank, int32_t, nu, 0);
+    ALLOC(gen_span, int64_t, nu, 0); ALLOC(work_off, int64_t, nu, 0); ALLOC(dup_span, int64_t, nu, 0); ALLOC(dup_off_all, int64_t, nu, 0);
+    ALLOC(out->frags, FragRec, nf, 0); ALLOC(out->fss, FsRec, nu, 0); ALLOC(out->frag_beg, int32_t, nf, 0); ALLOC(out->frag_strand, int32_t, nf, 0);
+    hipLaunchKernelGGL(k_mark_first, dim3(nblk(n, 256)), dim3(256), 0, s, in, new_frag, new_fs, out->frag_of, out->fs_of, frag_first, fs_first_frag, fam_fs, nf, nu, dT2);
+    hipLaunchKernelGGL(k_build_frags, dim3(nblk(nf, 256)), dim3(256), 0, s, in, *P, rend, out->endpos, out->kind, out->fs_of, out->dflag_of, frag_first, nf, out->frags, sweep_flag, out->frag_beg, out->frag_strand, dT2);
+    hipLaunchKernelGGL(k_build_units, dim3(nblk(nu, 256)), dim3(256), 0, s, in, *P, rend, out->endpos, out->dflag_of, frag_first, fs_first_frag, fam_fs, nu, out->fss, generic_flag, gen_span, dT2);
+    PREP_HIP(rocprim::exclusive_scan(tmp, tb, generic_flag, generic_rank, (int32_t)0, (size_t)std::max(nu, 1), rocprim::plus<int32_t>(), s)); tb = tmp_bytes;
+    PREP_HIP(rocprim::exclusive_scan(tmp, tb, gen_span, work_off, (int64_t)0, (size_t)std::max(nu, 1), rocprim::plus<int64_t>(), s)); tb = tmp_bytes;
+    PREP_HIP(rocprim::exclusive_scan(tmp, tb, sweep_flag, sweep_rank, (int32_t)0, (size_t)std::max(nf, 1), rocprim::plus<int32_t>(), s)); tb = tmp_bytes;
+    // generic_fs needs its size before k_units_post can fill it: the upper bound n_fs is small (4 B per unit)
+    ALLOC(out->generic_fs, int32_t, nu, 0);
+    hipLaunchKernelGGL(k_units_post, dim3(nblk(nu, 256)), dim3(256), 0, s, rend, nu, out->fss, generic_rank, work_off, out->generic_fs, dup_flag, dup_span);
+    PREP_HIP(rocprim::exclusive_scan(tmp, tb, dup_flag, dup_rank, (int32_t)0, (size_t)std::max(nu, 1), rocprim::plus<int32_t>(), s)); tb = tmp_bytes;
+    PREP_HIP(rocprim::exclusive_scan(tmp, tb, dup_span, dup_off_all, (int64_t)0, (size_t)std::max(nu, 1), rocprim::plus<int64_t>(), s)); tb = tmp_bytes;
+    ALLOC(out->dup_units, int32_t, nu, 0); ALLOC(out->dup_off, int64_t, nu, 0);
+    hipLaunchKernelGGL(k_compact_dups, dim3(nblk(nu, 256)), dim3(256), 0, s, nu, dup_flag, dup_rank, dup_off_all, out->dup_units, out->dup_off);
+    ALLOC(out->sweep_frags, int32_t, nf, 0);
+    int32_t *depth = nullptr;
+    if (nf >= 65536) { ALLOC(depth, int32_t, npos + 2, 1); }   // fragment depth bound: below 65 536 fragments the count itself bounds it
+    hipLaunchKernelGGL(k_frags_post, dim3(nblk(nf, 256)), dim3(256), 0, s, nf, out->frags, out->fss, sweep_flag, sweep_rank, out->sweep_frags, rbeg, depth);
+    if (depth) {
+        PREP_HIP(rocprim::inclusive_scan(tmp, tb, depth, depth, (size_t)(npos + 1), rocprim::plus<int32_t>(), s)); tb = tmp_bytes;
+        hipLaunchKernelGGL(k_max_i32, dim3(256), dim3(256), 0, s, depth, npos + 1, &dT2->max_frag_depth);
+    }
+    hipLaunchKernelGGL(k_stage2_totals, dim3(1), dim3(1), 0, s, nu, nf, generic_rank, generic_flag, work_off, gen_span, dup_rank, dup_flag, dup_off_all, dup_span, sweep_rank, sweep_flag, dT2);
+    // the P2 work-list entries (unsorted) while the totals travel
+    const int64_t np2 = T1.n_p2;
+    ALLOC(out->p2_aln, int32_t, np2, 0); ALLOC(out->p2_beg, int32_t, np2, 0); ALLOC(out->p2_end, int32_t, np2, 0); ALLOC(out->p2_qb, int32_t, np2, 0); ALLOC(out->p2_cls, int32_t, np2, 0);
+    hipLaunchKernelGGL(k_p2_entries, dim3(nblk(n, 256)), dim3(256), 0, s, in, n_p2, out->p2_first, out->p2_aln, out->p2_beg, out->p2_end, out->p2_qb, out->p2_cls);
+    Stage2 T2;
+    PREP_HIP(hipMemcpyAsync(&T2, dT2, sizeof(T2), hipMemcpyDeviceToHost, s));
+    PREP_HIP(hipStreamSynchronize(s));
+    if (T2.err) { snprintf(errmsg, (size_t)errcap, "reads of one (fam_id, fam_strand) are not contiguous"); return UVCGPU_EINVAL; }
+    out->n_generic = T2.n_generic; out->n_dup = T2.n_dup; out->n_sweep = T2.n_sweep; out->work = T2.work; out->dup_work = T2.dup_work;
+    out->max_frag_span = std::max(T2.max_frag_span, 1); out->max_unit_span = std::max(T2.max_unit_span, 1); out->max_unit_frags = T2.max_unit_frags; out->n_frag_strand0 = T2.n_frag_strand0;
+    out->max_frag_depth = (nf < 65536 ? nf : T2.max_frag_depth);
+    // the generic units ordered by begin, for the position-window family kernels (stable: equal begins keep the unit order)
+    ALLOC(out->generic_sorted, int32_t, std::max(T2.n_generic, 1), 0);
+    if (T2.n_generic > 0) {
+        const int32_t ng = T2.n_generic;
+        int32_t *beg_of, *zero; unsigned long long *work; void *stmp;
+        const size_t sb = uvc_gap_sort_tmp_bytes((size_t)ng);
+        ALLOC(beg_of, int32_t, ng, 0); ALLOC(zero, int32_t, ng, 0); ALLOC(work, unsigned long long, 4 * (size_t)ng, 0); ALLOC(stmp, char, sb + 16, 0);
+        hipLaunchKernelGGL(k_unit_keys, dim3(nblk(ng, 256)), dim3(256), 0, s, out->fss, out->generic_fs, ng, beg_of, zero);
+        if (uvc_sort_by_pos_cls(beg_of, zero, rbeg, 31, ng, work, stmp, sb, s) != 0) { snprintf(errmsg, (size_t)errcap, "device sort of the units failed"); return UVCGPU_EDEVICE; }
+        hipLaunchKernelGGL(k_take_units, dim3(nblk(ng, 256)), dim3(256), 0, s, work + 3 * (size_t)ng, out->generic_fs, ng, out->generic_sorted);
+    }
+    PREP_HIP(hipGetLastError());
+    return 0;
+#undef ALLOC
+}

@@ -93,6 +93,31 @@ def pack_reads(reads):
     return soa, keep
 
 
+def device_reads(reads, device):
+    """The UvcReadSoA columns of `reads` as torch tensors on `device` (torch is only the owner of the HBM here) -> (UvcReadSoA of device
+    pointers, keepalive) for Region.set_reads_device: what a caller has whose decoder writes straight to the GPU."""
+    import torch
+    keep = []
+    soa = _ffi.UvcReadSoA()
+    soa.n_reads = int(reads["n_reads"])
+
+    def put(a, dt):
+        a = np.ascontiguousarray(a, dtype=dt)
+        # torch has no uint16 / uint32 tensors everywhere: ship the bytes
+        t = torch.from_numpy(a.view(np.uint8).reshape(-1)).to(device)
+        keep.append(t)
+        return t.data_ptr() if t.numel() else 0
+    for name, dt in _READ_FIELDS:
+        setattr(soa, name, put(reads[name], dt))
+    for name, dt, cnt in (("bases", np.uint8, "n_bases"), ("quals", np.uint8, "n_bases"), ("cigars", np.uint32, "n_cigar_ops")):
+        setattr(soa, name, put(reads[name], dt))
+        setattr(soa, cnt, int(np.asarray(reads[name]).size))
+    soa.n_fams = int(reads["n_fams"])
+    soa.fam_dflag = put(reads["fam_dflag"], np.uint8)
+    torch.cuda.synchronize(device)
+    return soa, keep
+
+
 def vcf_format_keys(lib, tier2=False):
     fn = getattr(lib.dll, "uvcgpu_vcf_format_keys")
     fn.restype, fn.argtypes = C.c_char_p, [C.c_int32]
@@ -152,6 +177,15 @@ class Region:
     def set_reads(self, reads):
         soa, keep = pack_reads(reads)
         self._check(self.lib.call("set_reads", self.h, C.byref(soa)))
+
+    def set_reads_device(self, dev):
+        """uvcgpu_region_set_reads_device: `dev` = (UvcReadSoA of device pointers, keepalive) as `device_reads` makes it.  The arrays must
+        outlive the reads of the handle."""
+        soa, keep = dev
+        fn = getattr(self.lib.dll, self.lib.prefix + "region_set_reads_device")
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.POINTER(_ffi.UvcReadSoA)]
+        self._dev_reads = keep
+        self._check(fn(self.h, C.byref(soa)))
 
     def accumulate(self):
         self._check(self.lib.call("accumulate", self.h))
