@@ -301,6 +301,9 @@ typedef struct UvcScoreRequest {
     const char *const *tumor_sample_columns;   /* [n_tumor_keys] or NULL: the sample column of each tumor record as text.  Only the record writer reads
                                  * it: with is_tumor_format_retrieved the normal-sample line ends with the tumor's column (bcf1_to_string,
                                  * main.hpp:5897-5910, 6269; MGVCF / ADDITIONAL_INDEL_CANDIDATE lines: main.cpp:739-757, 784-798) */
+    const char *const *tumor_ref_alt;          /* [n_tumor_keys] or NULL: "REF\tALT" of each tumor record (TumorKeyInfo::ref_alt, main.cpp:380).  Record writer
+                                 * only: the InDel string of a rescued InDel record is the tumor's (main.cpp:867-880); without it such a record
+                                 * is written with its symbolic allele */
 } UvcScoreRequest;
 
 typedef struct UvcScoreOut {

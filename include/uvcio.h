@@ -86,8 +86,9 @@ int uvcio_tumor_vcf_open(uvcio_tumor_vcf_t **out, const char *path, const char *
 const char *uvcio_tumor_vcf_sample_name(const uvcio_tumor_vcf_t *v);   /* last column of the #CHROM line ("" if there is none) */
 int64_t uvcio_tumor_vcf_n_records(const uvcio_tumor_vcf_t *v);
 /* The records of `tid` with pos_beg <= symbolpos <= pos_end, sorted by (symbolpos, symbol) -- tkis_beg .. tkis_end of main.cpp:532-533 --
- * as UvcScoreRequest::tumor_keys / tumor_sample_columns take them.  The arrays belong to the handle (valid until it is closed). */
-int uvcio_tumor_vcf_fetch(const uvcio_tumor_vcf_t *v, int32_t tid, int32_t pos_beg, int32_t pos_end, const UvcTumorKey **keys, const char *const **sample_columns, int64_t *n);
+ * as UvcScoreRequest::tumor_keys / tumor_sample_columns / tumor_ref_alt take them.  The arrays belong to the handle (valid until it is closed). */
+int uvcio_tumor_vcf_fetch(const uvcio_tumor_vcf_t *v, int32_t tid, int32_t pos_beg, int32_t pos_end, const UvcTumorKey **keys, const char *const **sample_columns,
+                          const char *const **ref_alts, int64_t *n);
 void uvcio_tumor_vcf_close(uvcio_tumor_vcf_t *v);
 
 /* ---- region shards ----

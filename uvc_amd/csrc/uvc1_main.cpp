@@ -160,9 +160,9 @@ bool call_tile(Worker &w, const Opts &o, const UvcParams &P, const Tile &t, int6
     rq.pos_beg = (int32_t)first; rq.pos_end = (int32_t)last_excl; rq.all_out = o.all_out; rq.is_amplicon = (go.n_amplicon * 2 > k);
     rq.base_at_pos_beg = (t.continues && first == t.beg && t.beg > ext_beg) ? 1 : 0; rq.region_beg = (int32_t)t.run_beg;
     if (tvcf) {   // normal sample of a T/N pair: the tumor records of this region (tkis_beg .. tkis_end, main.cpp:532-533)
-        const UvcTumorKey *keys = nullptr; const char *const *cols = nullptr; int64_t nk = 0;
-        if (uvcio_tumor_vcf_fetch(tvcf, t.tid, (int32_t)ext_beg, (int32_t)ext_end, &keys, &cols, &nk)) die(uvcio_last_error());
-        rq.tumor_keys = keys; rq.n_tumor_keys = nk; rq.tumor_sample_columns = (o.tumor_format ? cols : nullptr);
+        const UvcTumorKey *keys = nullptr; const char *const *cols = nullptr, *const *ras = nullptr; int64_t nk = 0;
+        if (uvcio_tumor_vcf_fetch(tvcf, t.tid, (int32_t)ext_beg, (int32_t)ext_end, &keys, &cols, &ras, &nk)) die(uvcio_last_error());
+        rq.tumor_keys = keys; rq.n_tumor_keys = nk; rq.tumor_sample_columns = (o.tumor_format ? cols : nullptr); rq.tumor_ref_alt = ras;
     }
     int64_t cap = std::max<int64_t>(4096, uvcgpu_region_score_size(w.reg, &rq) / (o.all_out ? 1 : 4));
     UvcScoreOut so;

@@ -1,5 +1,6 @@
 // uvc_gap.hip -- device radix sorts of the InDel allele pipeline (k_gap_keys / k_gap_alleles / k_gap_rows in uvc_kernels_acc.hip).
 // rocPRIM lives in its own translation unit: its headers do not compile together with the kernel file's helpers.
+#include <algorithm>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -21,12 +22,13 @@ extern "C" int uvc_gap_sort(void *tmp, size_t tmp_bytes, const unsigned long lon
 }
 
 // ---- device-side orders of set_reads (they replace host radix sorts of millions of ids) ----
-__global__ void __launch_bounds__(256) k_keys_pos_cls(const int32_t *pos, const int32_t *cls, int32_t beg, int shift, int64_t n, unsigned long long *key, unsigned long long *val) {
+// 32-bit keys and 32-bit ids: half the bytes of the 64-bit pair sort per radix pass
+__global__ void __launch_bounds__(256) k_keys_pos_cls(const int32_t *pos, const int32_t *cls, int32_t beg, int shift, int64_t n, uint32_t *key, uint32_t *val) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    key[i] = (unsigned long long)((uint32_t)(pos[i] - beg) | ((uint32_t)cls[i] << shift)); val[i] = (unsigned long long)i;
+    key[i] = ((uint32_t)(pos[i] - beg) | ((uint32_t)cls[i] << shift)); val[i] = (uint32_t)i;
 }
-__global__ void __launch_bounds__(256) k_gather4(const unsigned long long *perm, int64_t n, const int32_t *a0, const int32_t *a1, const int32_t *a2, const int32_t *a3,
+__global__ void __launch_bounds__(256) k_gather4(const uint32_t *perm, int64_t n, const int32_t *a0, const int32_t *a1, const int32_t *a2, const int32_t *a3,
                                                  int32_t *o0, int32_t *o1, int32_t *o2, int32_t *o3) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -34,24 +36,30 @@ __global__ void __launch_bounds__(256) k_gather4(const unsigned long long *perm,
     o0[i] = a0[j]; o1[i] = a1[j]; o2[i] = a2[j]; o3[i] = a3[j];
 }
 // ids sorted by key: out_ids[k] = the k-th id, rank[id] = k for the first n_first ids (the others get -1)
-__global__ void __launch_bounds__(256) k_rank_from_sorted(const unsigned long long *perm, int64_t n, int64_t n_first, int32_t *out_ids, int32_t *rank) {
+__global__ void __launch_bounds__(256) k_rank_from_sorted(const uint32_t *perm, int64_t n, int64_t n_first, int32_t *out_ids, int32_t *rank) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const int32_t id = (int32_t)perm[k];
     if (out_ids && k < n_first) out_ids[k] = id;
     if (rank) rank[id] = (k < n_first ? (int32_t)k : -1);
 }
-// stable sort of ids 0..n-1 by (pos - beg) | cls << shift (32-bit keys), all on the stream; work = 4 * n words
-extern "C" int uvc_sort_by_pos_cls(const int32_t *d_pos, const int32_t *d_cls, int32_t beg, int shift, int64_t n, unsigned long long *work /* [4 n] */, void *tmp, size_t tmp_bytes, hipStream_t s) {
-    if (n <= 0) return 0;
-    unsigned long long *key = work, *key_s = work + n, *val = work + 2 * n, *val_s = work + 3 * n;
-    hipLaunchKernelGGL(k_keys_pos_cls, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_pos, d_cls, beg, shift, n, key, val);
-    return uvc_gap_sort(tmp, tmp_bytes, key, key_s, val, val_s, (size_t)n, 32, s);   // sorted ids are in work + 3 n
+extern "C" size_t uvc_sort32_tmp_bytes(size_t n) {
+    size_t bytes = 0;
+    uint32_t *k = nullptr;
+    rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, std::max<size_t>(n, 1), 0, 32, (hipStream_t)0);
+    return bytes;
 }
-extern "C" void uvc_launch_gather4(const unsigned long long *perm, int64_t n, const int32_t *a0, const int32_t *a1, const int32_t *a2, const int32_t *a3, int32_t *o0, int32_t *o1, int32_t *o2, int32_t *o3, hipStream_t s) {
+// stable sort of ids 0..n-1 by (pos - beg) | cls << shift, all on the stream; work = 4 * n 32-bit words, the sorted ids are work + 3 * n
+extern "C" int uvc_sort_by_pos_cls(const int32_t *d_pos, const int32_t *d_cls, int32_t beg, int shift, int64_t n, uint32_t *work /* [4 n] */, void *tmp, size_t tmp_bytes, hipStream_t s) {
+    if (n <= 0) return 0;
+    uint32_t *key = work, *key_s = work + n, *val = work + 2 * n, *val_s = work + 3 * n;
+    hipLaunchKernelGGL(k_keys_pos_cls, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_pos, d_cls, beg, shift, n, key, val);
+    return rocprim::radix_sort_pairs(tmp, tmp_bytes, key, key_s, val, val_s, (size_t)n, 0, 32, s) == hipSuccess ? 0 : -1;
+}
+extern "C" void uvc_launch_gather4(const uint32_t *perm, int64_t n, const int32_t *a0, const int32_t *a1, const int32_t *a2, const int32_t *a3, int32_t *o0, int32_t *o1, int32_t *o2, int32_t *o3, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_gather4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perm, n, a0, a1, a2, a3, o0, o1, o2, o3);
 }
-extern "C" void uvc_launch_rank_from_sorted(const unsigned long long *perm, int64_t n, int64_t n_first, int32_t *out_ids, int32_t *rank, hipStream_t s) {
+extern "C" void uvc_launch_rank_from_sorted(const uint32_t *perm, int64_t n, int64_t n_first, int32_t *out_ids, int32_t *rank, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_rank_from_sorted, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perm, n, n_first, out_ids, rank);
 }
 

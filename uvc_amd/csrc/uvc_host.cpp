@@ -36,9 +36,10 @@ extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored);
 extern "C" void uvc_launch_block_stats(const RegionDev *R, const UvcParams *P, int64_t x0, int64_t n, int32_t *d_out, hipStream_t s);
 extern "C" size_t uvc_gap_sort_tmp_bytes(size_t n);
 extern "C" void uvc_launch_gather_columns(const char *const *base, const int32_t *first_col, const int32_t *elem, int64_t npos, const int32_t *d_xs, int64_t n, long long *d_out, hipStream_t s);
-extern "C" int uvc_sort_by_pos_cls(const int32_t *d_pos, const int32_t *d_cls, int32_t beg, int shift, int64_t n, unsigned long long *work, void *tmp, size_t tmp_bytes, hipStream_t s);
-extern "C" void uvc_launch_gather4(const unsigned long long *perm, int64_t n, const int32_t *a0, const int32_t *a1, const int32_t *a2, const int32_t *a3, int32_t *o0, int32_t *o1, int32_t *o2, int32_t *o3, hipStream_t s);
-extern "C" void uvc_launch_rank_from_sorted(const unsigned long long *perm, int64_t n, int64_t n_first, int32_t *out_ids, int32_t *rank, hipStream_t s);
+extern "C" int uvc_sort_by_pos_cls(const int32_t *d_pos, const int32_t *d_cls, int32_t beg, int shift, int64_t n, uint32_t *work, void *tmp, size_t tmp_bytes, hipStream_t s);
+extern "C" size_t uvc_sort32_tmp_bytes(size_t n);
+extern "C" void uvc_launch_gather4(const uint32_t *perm, int64_t n, const int32_t *a0, const int32_t *a1, const int32_t *a2, const int32_t *a3, int32_t *o0, int32_t *o1, int32_t *o2, int32_t *o3, hipStream_t s);
+extern "C" void uvc_launch_rank_from_sorted(const uint32_t *perm, int64_t n, int64_t n_first, int32_t *out_ids, int32_t *rank, hipStream_t s);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -376,8 +377,8 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
     {   // stable device sorts: simple alignments by begin (the others go behind them), fragments by (strand, begin) -- k_frag walks two
         // beg-sorted sub-lists, one per strand, so that the strand-specific accumulators are fixed registers
         const size_t nmax = std::max<size_t>(std::max<size_t>((size_t)n, nf), 1);
-        int32_t *d_rank, *d_fsorted, *d_frank; unsigned long long *work; uint8_t *tmp;
-        const size_t tmp_bytes = uvc_gap_sort_tmp_bytes(nmax);
+        int32_t *d_rank, *d_fsorted, *d_frank; uint32_t *work; uint8_t *tmp;
+        const size_t tmp_bytes = uvc_sort32_tmp_bytes(nmax);
         if ((rc = dev_alloc(r, (size_t)n, &d_rank)) || (rc = dev_alloc(r, nf, &d_fsorted)) || (rc = dev_alloc(r, nf, &d_frank)) || (rc = dev_alloc(r, 4 * nmax, &work)) || (rc = dev_alloc(r, tmp_bytes + 16, &tmp))) return rc;
         if (uvc_sort_by_pos_cls(W.pos, o.is_complex, r->beg, 31, n, work, tmp, tmp_bytes, r->stream) != 0) return fail(UVCGPU_EDEVICE, "device sort of the alignments failed");
         uvc_launch_rank_from_sorted(work + 3 * n, n, n_simple, nullptr, d_rank, r->stream);
@@ -430,8 +431,8 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
     {   // the P2 work list: stable order by (class, begin) on the device -- begin - region begin < 2^29 and the class takes the two bits above
         const size_t np2 = (size_t)o.n_p2;
         for (int c = 0; c <= 4; c++) R.p2_off[c] = o.p2_off[c];
-        unsigned long long *work; uint8_t *tmp;
-        const size_t tmp_bytes = uvc_gap_sort_tmp_bytes(std::max<size_t>(np2, 1));
+        uint32_t *work; uint8_t *tmp;
+        const size_t tmp_bytes = uvc_sort32_tmp_bytes(std::max<size_t>(np2, 1));
         if ((rc = dev_alloc(r, 4 * np2, &work)) || (rc = dev_alloc(r, tmp_bytes + 16, &tmp))) return rc;
         for (int k = 0; k < 4; k++) if ((rc = dev_alloc(r, np2, &r->d_p2[k]))) return rc;
         if (uvc_sort_by_pos_cls(o.p2_beg, o.p2_cls, r->beg, 29, (int64_t)np2, work, tmp, tmp_bytes, r->stream) != 0) return fail(UVCGPU_EDEVICE, "device sort of the P2 work list failed");

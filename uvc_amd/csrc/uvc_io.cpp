@@ -664,6 +664,8 @@ struct uvcio_tumor_vcf {
     std::vector<UvcTumorKey> keys;              // sorted by (tid, refpos, symbol); records of one key keep their file order
     std::vector<std::string> cols_text;         // sample column of each record
     std::vector<const char *> cols;             // c_str() of the above
+    std::vector<std::string> ra_text;           // "REF\tALT" of each record (TumorKeyInfo::ref_alt)
+    std::vector<const char *> ras;
     std::vector<int64_t> tid_first;             // [n_contigs + 1] first record of each tid
 };
 namespace {
@@ -688,7 +690,7 @@ extern "C" int uvcio_tumor_vcf_open(uvcio_tumor_vcf_t **out, const char *path, c
     std::map<std::string, int32_t> tid_of;
     for (int32_t i = 0; i < n_contigs; i++) tid_of[contig_names[i]] = i;
     uvcio_tumor_vcf *v = new uvcio_tumor_vcf();
-    struct Rec { int32_t tid; UvcTumorKey k; std::string col; int64_t ord; };
+    struct Rec { int32_t tid; UvcTumorKey k; std::string col, ra; int64_t ord; };
     std::vector<Rec> recs;
     std::string err;
     const char *p = text, *end = text + len;
@@ -730,7 +732,7 @@ extern "C" int uvcio_tumor_vcf_open(uvcio_tumor_vcf_t **out, const char *path, c
         int32_t a2[4];
         if (get("VTI", a2, 4) != 2) continue;   // valsize <= 0 -> continue (main.cpp:275)
         Rec r; memset(&r.k, 0, sizeof(r.k));
-        r.tid = ti->second; r.ord = (int64_t)recs.size(); r.col = smp;
+        r.tid = ti->second; r.ord = (int64_t)recs.size(); r.col = smp; r.ra = ref + "\t" + alt;
         const int symbol = a2[1];
         const long pos0 = strtol(fld(1).c_str(), nullptr, 10) - 1;   // line->pos
         const bool at_pos = (symbol <= UVC_BASE_NN || symbol == UVC_MGVCF_SYMBOL || symbol == UVC_ADDITIONAL_INDEL_CANDIDATE_SYMBOL);   // isSymbolSubstitution covers BASE_A .. BASE_NN
@@ -760,24 +762,25 @@ extern "C" int uvcio_tumor_vcf_open(uvcio_tumor_vcf_t **out, const char *path, c
         if (a.k.refpos != b.k.refpos) return a.k.refpos < b.k.refpos;
         return a.k.symbol < b.k.symbol; });
     v->tid_first.assign((size_t)n_contigs + 1, 0);
-    for (const Rec &r : recs) { v->tid.push_back(r.tid); v->keys.push_back(r.k); v->cols_text.push_back(r.col); v->tid_first[(size_t)r.tid + 1]++; }
+    for (const Rec &r : recs) { v->tid.push_back(r.tid); v->keys.push_back(r.k); v->cols_text.push_back(r.col); v->ra_text.push_back(r.ra); v->tid_first[(size_t)r.tid + 1]++; }
     for (int32_t i = 0; i < n_contigs; i++) v->tid_first[(size_t)i + 1] += v->tid_first[(size_t)i];
     for (const std::string &s : v->cols_text) v->cols.push_back(s.c_str());
+    for (const std::string &s : v->ra_text) v->ras.push_back(s.c_str());
     *out = v;
     return 0;
 }
 extern "C" const char *uvcio_tumor_vcf_sample_name(const uvcio_tumor_vcf_t *v) { return v ? v->sample.c_str() : ""; }
 extern "C" int64_t uvcio_tumor_vcf_n_records(const uvcio_tumor_vcf_t *v) { return v ? (int64_t)v->keys.size() : 0; }
-extern "C" int uvcio_tumor_vcf_fetch(const uvcio_tumor_vcf_t *v, int32_t tid, int32_t pos_beg, int32_t pos_end, const UvcTumorKey **keys, const char *const **cols, int64_t *n) {
+extern "C" int uvcio_tumor_vcf_fetch(const uvcio_tumor_vcf_t *v, int32_t tid, int32_t pos_beg, int32_t pos_end, const UvcTumorKey **keys, const char *const **cols, const char *const **ref_alts, int64_t *n) {
     if (!v || !n) return fail(UVCGPU_EINVAL, "bad argument");
-    *n = 0; if (keys) *keys = nullptr; if (cols) *cols = nullptr;
+    *n = 0; if (keys) *keys = nullptr; if (cols) *cols = nullptr; if (ref_alts) *ref_alts = nullptr;
     if (tid < 0 || (size_t)tid + 1 >= v->tid_first.size()) return 0;
     const int64_t lo0 = v->tid_first[(size_t)tid], hi0 = v->tid_first[(size_t)tid + 1];
     const auto b = v->keys.begin();
     const int64_t lo = std::lower_bound(b + lo0, b + hi0, pos_beg, [](const UvcTumorKey &k, int32_t p) { return k.refpos < p; }) - b;
     const int64_t hi = std::upper_bound(b + lo, b + hi0, pos_end, [](int32_t p, const UvcTumorKey &k) { return p < k.refpos; }) - b;
     *n = hi - lo;
-    if (*n > 0) { if (keys) *keys = v->keys.data() + lo; if (cols) *cols = v->cols.data() + lo; }
+    if (*n > 0) { if (keys) *keys = v->keys.data() + lo; if (cols) *cols = v->cols.data() + lo; if (ref_alts) *ref_alts = v->ras.data() + lo; }
     return 0;
 }
 extern "C" void uvcio_tumor_vcf_close(uvcio_tumor_vcf_t *v) { delete v; }

@@ -378,9 +378,48 @@ __global__ void __launch_bounds__(256) k_build_p2list(RegionDev R, const int32_t
     R.frec2[j] = f;
 }
 
-__global__ void __launch_bounds__(256) k_aln_prelude(RegionDev R, RawReads W, UvcParams P) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= R.n_alns) return;
+// Mismatching bases per base symbol (bm1500s, main.hpp:1860-1863) of the simple alignments: one wave per alignment, lanes = consecutive
+// bases (coalesced loads of the read and of the reference), counts by ballot.  One thread per alignment walking 150 bases (the form the
+// InDel reads keep) cost 2.0 ms per 2 M reads, this costs a tenth.  The five counts wait in the alignment's own FastRec slot.
+__global__ void __launch_bounds__(256) k_aln_bm(RegionDev R, RawReads W) {
+    const int lane = threadIdx.x & 63;
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    // a wave takes 64 alignments at a time: their scalars are fetched one per lane (coalesced, one round trip for all 64) and broadcast
+    // with v_readlane, so that an alignment costs one more round trip -- its bases and the reference under them
+    for (int id0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64; id0 < R.n_alns; id0 += nwaves * 64) {
+        const int mine = id0 + lane;
+        int rk = -1, pos = 0, len = 0, qlo = 0, qhi = 0;
+        if (mine < R.n_alns) {
+            rk = W.fast_rank[mine];
+            if (rk >= 0) {
+                pos = W.pos[mine]; len = W.endpos[mine] - pos;
+                const uint32_t c0 = R.cigars[W.cigar_off[mine]];
+                const int64_t qb = W.seq_off[mine] + (cig_op(c0) == C_SOFT_CLIP ? cig_len(c0) : 0);
+                qlo = (int)(qb & 0xFFFFFFFFLL); qhi = (int)(qb >> 32);
+            }
+        }
+        const int nhere = imin(64, R.n_alns - id0);
+        for (int j = 0; j < nhere; j++) {
+            const int rkj = __builtin_amdgcn_readlane(rk, j);
+            if (rkj < 0) continue;   // wave-uniform
+            const int posj = __builtin_amdgcn_readlane(pos, j), lenj = __builtin_amdgcn_readlane(len, j);
+            const int64_t qbj = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(qhi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane(qlo, j));
+            int cnt[5] = { 0, 0, 0, 0, 0 };
+            for (int k0 = 0; k0 < lenj; k0 += 64) {
+                const int k = k0 + lane;
+                int b = -1; bool mis = false;
+                if (k < lenj) { b = R.bases[qbj + k]; mis = (R.refsym[posj - R.beg + k] != b); }
+#pragma unroll
+                for (int s2 = 0; s2 < 5; s2++) cnt[s2] += __popcll(__ballot(mis && b == s2));
+            }
+            int32_t *dst = (int32_t *)&R.frec[rkj];
+            if (lane < 5) dst[lane] = (lane == 0 ? cnt[0] : lane == 1 ? cnt[1] : lane == 2 ? cnt[2] : lane == 3 ? cnt[3] : cnt[4]);
+        }
+    }
+}
+
+// the prelude of one alignment; returns the number of its bases that go through the mismatch queue of k_p2_fast
+DEV int aln_prelude_one(const RegionDev &R, const RawReads &W, const UvcParams &P, const int id) {
     AlnRec a;
     a.pos = W.pos[id]; a.rend = W.endpos[id]; a.mpos = W.mpos[id]; a.isize = W.isize[id]; a.flag = W.flag[id]; a.mapq = W.mapq[id];
     a.dflag = W.dflag[id]; a.l_qseq = W.l_qseq[id]; a.seq_off = W.seq_off[id]; a.cigar_off = W.cigar_off[id]; a.table_off = W.table_off[id]; a.item_off = W.item_off[id]; a.gap_off = W.gap_off[id];
@@ -401,6 +440,16 @@ __global__ void __launch_bounds__(256) k_aln_prelude(RegionDev R, RawReads W, Uv
     a.clip_cnt = clip_cnt;
     int bm[5] = { 0, 0, 0, 0, 0 };
     int qpos = 0, rpos = a.pos, lclip_q = 0, m_index = -1;
+    const int rk0 = W.fast_rank[id];
+    if (rk0 >= 0) {   // simple alignment: k_aln_bm counted its mismatching bases with a whole wave and left them in this read's own FastRec slot
+        const int32_t *pre = (const int32_t *)&R.frec[rk0];
+        for (int s2 = 0; s2 < 5; s2++) bm[s2] = pre[s2];
+        for (int i = 0; i < a.n_cigar && m_index < 0; i++) {
+            const int op = cig_op(cigar[i]);
+            if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) { m_index = i; lclip_q = qpos; }
+            else if (op == C_SOFT_CLIP) qpos += cig_len(cigar[i]);
+        }
+    } else
     for (int i = 0; i < a.n_cigar; i++) {
         const int op = cig_op(cigar[i]), len = cig_len(cigar[i]);
         if (op == C_MATCH || op == C_EQUAL || op == C_DIFF) {
@@ -430,16 +479,21 @@ __global__ void __launch_bounds__(256) k_aln_prelude(RegionDev R, RawReads W, Uv
     if (a.kind == 2 && has_lowbq_indel(P, a, cigar, R.quals + a.seq_off)) a.kind = 1;
     R.alns[id] = a;
     const int rk = W.fast_rank[id];
-    if (rk >= 0 || W.kind[id] == 2) {   // every alignment that can be on the P2 work list: its mismatching bases go through the mismatch queue
-        const int n_mis = bm[0] + bm[1] + bm[2] + bm[3] + bm[4];
-        if (n_mis) atomicAdd(R.mis_total, (unsigned long long)n_mis);
-    }
+    int n_mis = 0;
+    if (rk >= 0 || W.kind[id] == 2) n_mis = bm[0] + bm[1] + bm[2] + bm[3] + bm[4];   // every alignment that can be on the P2 work list: its mismatching bases go through the mismatch queue
     if (rk >= 0) {
         R.fast[rk] = a;
         FastRec f;
         fill_fastrec(f, a, id, a.pos, a.rend, (int32_t)(a.qbase & 0xFFFFFFFFLL));
         R.frec[rk] = f;
     }
+    return n_mis;
+}
+__global__ void __launch_bounds__(256) k_aln_prelude(RegionDev R, RawReads W, UvcParams P) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    int n_mis = (id < R.n_alns) ? aln_prelude_one(R, W, P, id) : 0;
+    for (int d = 32; d > 0; d >>= 1) n_mis += __shfl_xor(n_mis, d);   // one atomic per wave: same-address atomics of every read serialise
+    if ((threadIdx.x & 63) == 0 && n_mis) atomicAdd(R.mis_total, (unsigned long long)n_mis);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2840,6 +2894,7 @@ extern "C" void uvc_launch_build_p2list(const RegionDev *R, const int32_t *aln, 
     if (R->n_fast2) hipLaunchKernelGGL(k_build_p2list, dim3(nblk(R->n_fast2, 256)), dim3(256), 0, s, *R, aln, cbeg, cend, qb);
 }
 extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const UvcParams *P, hipStream_t s) {
+    if (R->n_alns && R->n_fast) hipLaunchKernelGGL(k_aln_bm, dim3(imin_h((int)nblk(R->n_alns, 256), 8192)), dim3(256), 0, s, *R, *W);
     if (R->n_alns) hipLaunchKernelGGL(k_aln_prelude, dim3(nblk(R->n_alns, 256)), dim3(256), 0, s, *R, *W, *P);
 }
 // The sequential, low-occupancy kernels of the InDel reads and the per-fragment statistics need P1 / P1b only, not P2: they run on

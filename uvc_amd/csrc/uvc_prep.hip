@@ -18,6 +18,9 @@ PDEV int pmin(int a, int b) { return a < b ? a : b; }
 PDEV int pmax(int a, int b) { return a > b ? a : b; }
 enum { PC_MATCH = 0, PC_INS = 1, PC_DEL = 2, PC_REF_SKIP = 3, PC_SOFT_CLIP = 4, PC_HARD_CLIP = 5, PC_PAD = 6, PC_EQUAL = 7, PC_DIFF = 8 };
 PDEV bool is_m(int op) { return op == PC_MATCH || op == PC_EQUAL || op == PC_DIFF; }
+// one atomic per wave instead of one per lane: millions of same-address atomics serialise (k_read_facts took 8.6 ms with them, 0.2 without)
+PDEV int wave_max(int v) { for (int d = 32; d > 0; d >>= 1) v = pmax(v, __shfl_xor(v, d)); return v; }
+PDEV int wave_sum(int v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d); return v; }
 
 struct Stage1 {   // device counters of the first stage (read back once)
     int32_t err, max_aln_span, n_frags, n_fs, n_complex, any_amplicon;
@@ -33,8 +36,8 @@ struct Stage2 {
 __global__ void __launch_bounds__(256) k_read_facts(UvcPrepIn in, int32_t rbeg, int32_t rend, int seg_eligible,
                                                     int32_t *endpos, int32_t *kind, int32_t *dflag_of, int32_t *new_frag, int32_t *new_fs, int32_t *is_complex,
                                                     int32_t *n_p2, int64_t *gaps, int64_t *trows, int64_t *items, int64_t *ins, Stage1 *T) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= in.n_reads) return;
+    int w_err = 0, w_span = 0, w_p2span = 0, w_cls[4] = { 0, 0, 0, 0 }, w_amp = 0;   // this lane's contributions to the region-wide counters
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < in.n_reads; i += (int64_t)gridDim.x * blockDim.x) {
     const int32_t nc = in.n_cigar[i], lq = in.l_qseq[i], pos = in.pos[i];
     int32_t o_end = pos + 1, o_kind = 1, o_np2 = 0; int64_t o_gaps = 0, o_trows = 0, o_items = 0, o_ins = 0;
     int err = 0;
@@ -79,22 +82,39 @@ __global__ void __launch_bounds__(256) k_read_facts(UvcPrepIn in, int32_t rbeg, 
             // kind 2 = candidate for the simple path: k_aln_prelude demotes it to 1 when the read has a low-quality InDel
             o_kind = simple ? 0 : (ok ? 2 : 1);
             if (!simple) { o_trows = (e - pos) + 1; o_items = 2 * (int64_t)lq + 2 * del_total + nc + 4; }
-            else { o_gaps = 0; o_ins = 0; atomicMax(&T->max_aln_span, e - pos); }
+            else { o_gaps = 0; o_ins = 0; w_span = pmax(w_span, e - pos); }
             if (o_np2) {
                 const int fl = in.flag[i];
                 const int cls = ((fl & 0x10) ? 1 : 0) | ((((fl & 0x81) == 0x81) ? ((fl & 0x20) != 0) : ((fl & 0x10) != 0)) ? 2 : 0);   // is-reverse | bam_get_strand << 1 (common.hpp:89)
-                atomicAdd(&T->p2_cls[cls], o_np2); atomicMax(&T->max_p2_span, span);
+                w_cls[0] += (cls == 0) * o_np2; w_cls[1] += (cls == 1) * o_np2; w_cls[2] += (cls == 2) * o_np2; w_cls[3] += (cls == 3) * o_np2; w_p2span = pmax(w_p2span, span);
             }
         }
     }
-    if (err) { atomicMax(&T->err, err); o_kind = 1; o_gaps = 0; o_ins = 0; o_np2 = 0; }
+    if (err) { w_err = pmax(w_err, err); o_kind = 1; o_gaps = 0; o_ins = 0; o_np2 = 0; }
     endpos[i] = o_end; kind[i] = o_kind; n_p2[i] = o_np2; gaps[i] = o_gaps; trows[i] = o_trows; items[i] = o_items; ins[i] = o_ins; is_complex[i] = (o_kind != 0);
     const bool ok_fam = (err != 5);
     const int df = ok_fam ? (int)in.fam_dflag[fam] : 0;
     dflag_of[i] = df;
-    if (df & 0x4) T->any_amplicon = 1;
+    if (df & 0x4) w_amp = 1;
     const bool nfs = (i == 0) || in.fam_id[i - 1] != fam || in.fam_strand[i - 1] != strand;
     new_fs[i] = nfs; new_frag[i] = (nfs || in.frag_id[i - 1] != in.frag_id[i]);
+    }
+    // wave, then block, then one set of atomics per block (the grid is a few thousand blocks)
+    __shared__ int sh[4][8];
+    w_err = wave_max(w_err); w_span = wave_max(w_span); w_p2span = wave_max(w_p2span); w_amp = wave_max(w_amp);
+    for (int c = 0; c < 4; c++) w_cls[c] = wave_sum(w_cls[c]);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[wv][0] = w_err; sh[wv][1] = w_span; sh[wv][2] = w_p2span; sh[wv][3] = w_amp; for (int c = 0; c < 4; c++) sh[wv][4 + c] = w_cls[c]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int v[8];
+        for (int q = 0; q < 8; q++) { v[q] = sh[0][q]; for (int w = 1; w < 4; w++) v[q] = (q < 4 ? pmax(v[q], sh[w][q]) : v[q] + sh[w][q]); }
+        if (v[0]) atomicMax(&T->err, v[0]);
+        if (v[1]) atomicMax(&T->max_aln_span, v[1]);
+        if (v[2]) atomicMax(&T->max_p2_span, v[2]);
+        if (v[3]) T->any_amplicon = 1;
+        for (int c = 0; c < 4; c++) if (v[4 + c]) atomicAdd(&T->p2_cls[c], v[4 + c]);
+    }
 }
 
 // the prefix sums of stage 1 -> indices / offsets; -1 offsets for simple alignments
@@ -132,7 +152,8 @@ __global__ void __launch_bounds__(256) k_mark_first(UvcPrepIn in, const int32_t 
 __global__ void __launch_bounds__(256) k_build_frags(UvcPrepIn in, UvcParams P, int32_t rend, const int32_t *endpos, const int32_t *kind, const int32_t *fs_of, const int32_t *dflag_of,
                                                      const int32_t *frag_first, int32_t n_frags, FragRec *frags, int32_t *sweep_flag, int32_t *frag_beg, int32_t *frag_strand, Stage2 *T) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n_frags) return;
+    int w_span = 0, w_s0 = 0;
+    if (f < n_frags) {
     FragRec r; memset(&r, 0, sizeof(r));
     const int a0 = frag_first[f], a1 = frag_first[f + 1];
     r.aln_beg = a0; r.aln_end = a1; r.beg = INT32_MAX; r.end = 0; r.fs = fs_of[a0]; r.strand = in.fam_strand[a0]; r.dflag = dflag_of[a0];
@@ -147,14 +168,17 @@ __global__ void __launch_bounds__(256) k_build_frags(UvcPrepIn in, UvcParams P, 
     r.stat_kind = (all_simple && (a1 - a0) <= 2 && !amplicon_gated) ? 0 : 1;
     sweep_flag[f] = r.stat_kind; frag_beg[f] = r.beg; frag_strand[f] = r.strand;
     frags[f] = r;
-    atomicMax(&T->max_frag_span, r.end - r.beg);
-    if (r.strand == 0) atomicAdd(&T->n_frag_strand0, 1);
+    w_span = r.end - r.beg; w_s0 = (r.strand == 0);
+    }
+    w_span = wave_max(w_span); w_s0 = wave_sum(w_s0);
+    if ((threadIdx.x & 63) == 0) { if (w_span) atomicMax(&T->max_frag_span, w_span); if (w_s0) atomicAdd(&T->n_frag_strand0, w_s0); }
 }
 // one thread per family-strand unit: fillTidBegEndFromAlns2 (main.hpp:675-697), the duplex partner, which kernels take it
 __global__ void __launch_bounds__(256) k_build_units(UvcPrepIn in, UvcParams P, int32_t rend, const int32_t *endpos, const int32_t *dflag_of, const int32_t *frag_first, const int32_t *fs_first_frag,
                                                      const int32_t *fam_fs, int32_t n_fs, FsRec *fss, int32_t *generic_flag, int64_t *gen_span, Stage2 *T) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= n_fs) return;
+    int w_span = 0, w_frags = 0;
+    if (u < n_fs) {
     FsRec r; memset(&r, 0, sizeof(r));
     r.frag_beg = fs_first_frag[u]; r.frag_end = fs_first_frag[u + 1];
     const int a0 = frag_first[r.frag_beg], a1 = frag_first[r.frag_end];
@@ -168,7 +192,10 @@ __global__ void __launch_bounds__(256) k_build_units(UvcPrepIn in, UvcParams P, 
     r.work_off = 0;
     fss[u] = r;
     generic_flag[u] = r.generic; gen_span[u] = r.generic ? (int64_t)(r.end - r.beg) : 0;
-    if (r.generic) { atomicMax(&T->max_unit_span, r.end - r.beg); atomicMax(&T->max_unit_frags, r.frag_end - r.frag_beg); }
+    if (r.generic) { w_span = r.end - r.beg; w_frags = r.frag_end - r.frag_beg; }
+    }
+    w_span = wave_max(w_span); w_frags = wave_max(w_frags);
+    if ((threadIdx.x & 63) == 0) { if (w_span) atomicMax(&T->max_unit_span, w_span); if (w_frags) atomicMax(&T->max_unit_frags, w_frags); }
 }
 __global__ void __launch_bounds__(256) k_units_post(int32_t rend, int32_t n_fs, FsRec *fss, const int32_t *generic_rank, const int64_t *work_off, int32_t *generic_fs,
                                                     int32_t *dup_flag, int64_t *dup_span) {
@@ -229,7 +256,7 @@ __global__ void __launch_bounds__(256) k_unit_keys(const FsRec *fss, const int32
     if (k >= n) return;
     beg_of[k] = fss[generic_fs[k]].beg; zero[k] = 0;
 }
-__global__ void __launch_bounds__(256) k_take_units(const unsigned long long *perm, const int32_t *generic_fs, int32_t n, int32_t *sorted) {
+__global__ void __launch_bounds__(256) k_take_units(const uint32_t *perm, const int32_t *generic_fs, int32_t n, int32_t *sorted) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     sorted[k] = generic_fs[(int32_t)perm[k]];
@@ -239,8 +266,8 @@ unsigned nblk(int64_t n, int b) { return (unsigned)std::max<int64_t>((n + b - 1)
 template <class T> size_t scan_tmp_bytes(int64_t n) { size_t b = 0; T *p = nullptr; rocprim::exclusive_scan(nullptr, b, p, p, T(0), (size_t)std::max<int64_t>(n, 1), rocprim::plus<T>(), (hipStream_t)0); return b; }
 }   // namespace
 
-extern "C" int uvc_sort_by_pos_cls(const int32_t *d_pos, const int32_t *d_cls, int32_t beg, int shift, int64_t n, unsigned long long *work, void *tmp, size_t tmp_bytes, hipStream_t s);
-extern "C" size_t uvc_gap_sort_tmp_bytes(size_t n);
+extern "C" int uvc_sort_by_pos_cls(const int32_t *d_pos, const int32_t *d_cls, int32_t beg, int shift, int64_t n, uint32_t *work, void *tmp, size_t tmp_bytes, hipStream_t s);
+extern "C" size_t uvc_sort32_tmp_bytes(size_t n);
 
 #define PREP_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf(errmsg, (size_t)errcap, "%s: %s", #call, hipGetErrorString(e_)); return UVCGPU_EDEVICE; } } while (0)
 
@@ -263,7 +290,7 @@ extern "C" int uvc_prep_reads(const UvcPrepIn *inp, const UvcParams *P, int32_t 
     Stage2 *dT2; ALLOC(dT2, Stage2, 1, 1);
     const size_t tmp_bytes = std::max(scan_tmp_bytes<int32_t>(n), scan_tmp_bytes<int64_t>(n)) + 64;
     void *tmp; ALLOC(tmp, char, tmp_bytes, 0);
-    hipLaunchKernelGGL(k_read_facts, dim3(nblk(n, 256)), dim3(256), 0, s, in, rbeg, rend, seg_eligible, out->endpos, out->kind, out->dflag_of, new_frag, new_fs, is_complex, n_p2, gaps, trows, items, ins, dT1);
+    hipLaunchKernelGGL(k_read_facts, dim3(std::min(nblk(n, 256), 2048u)), dim3(256), 0, s, in, rbeg, rend, seg_eligible, out->endpos, out->kind, out->dflag_of, new_frag, new_fs, is_complex, n_p2, gaps, trows, items, ins, dT1);
     size_t tb = tmp_bytes;
     int64_t *gap_off64 = out->gap_off;
     PREP_HIP(rocprim::inclusive_scan(tmp, tb, new_frag, out->frag_of, (size_t)n, rocprim::plus<int32_t>(), s)); tb = tmp_bytes;
@@ -335,9 +362,9 @@ extern "C" int uvc_prep_reads(const UvcPrepIn *inp, const UvcParams *P, int32_t 
     ALLOC(out->generic_sorted, int32_t, std::max(T2.n_generic, 1), 0);
     if (T2.n_generic > 0) {
         const int32_t ng = T2.n_generic;
-        int32_t *beg_of, *zero; unsigned long long *work; void *stmp;
-        const size_t sb = uvc_gap_sort_tmp_bytes((size_t)ng);
-        ALLOC(beg_of, int32_t, ng, 0); ALLOC(zero, int32_t, ng, 0); ALLOC(work, unsigned long long, 4 * (size_t)ng, 0); ALLOC(stmp, char, sb + 16, 0);
+        int32_t *beg_of, *zero; uint32_t *work; void *stmp;
+        const size_t sb = uvc_sort32_tmp_bytes((size_t)ng);
+        ALLOC(beg_of, int32_t, ng, 0); ALLOC(zero, int32_t, ng, 0); ALLOC(work, uint32_t, 4 * (size_t)ng, 0); ALLOC(stmp, char, sb + 16, 0);
         hipLaunchKernelGGL(k_unit_keys, dim3(nblk(ng, 256)), dim3(256), 0, s, out->fss, out->generic_fs, ng, beg_of, zero);
         if (uvc_sort_by_pos_cls(beg_of, zero, rbeg, 31, ng, work, stmp, sb, s) != 0) { snprintf(errmsg, (size_t)errcap, "device sort of the units failed"); return UVCGPU_EDEVICE; }
         hipLaunchKernelGGL(k_take_units, dim3(nblk(ng, 256)), dim3(256), 0, s, work + 3 * (size_t)ng, out->generic_fs, ng, out->generic_sorted);

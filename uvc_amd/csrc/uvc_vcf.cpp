@@ -438,6 +438,7 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
     const int32_t region_beg = (req ? req->region_beg : 0);
     const UvcTumorKey *tkeys = (req ? req->tumor_keys : nullptr); const int64_t n_tkeys = (req ? req->n_tumor_keys : 0);
     const char *const *tcols = (req && tkeys ? req->tumor_sample_columns : nullptr);
+    const char *const *tref_alt = (req && tkeys ? req->tumor_ref_alt : nullptr);
     const int32_t *recs = scored->fields; const int64_t n = scored->n_records, stride = scored->capacity;
     { const int rc0 = uvcgpu_region_fetch_columns(r, nullptr, 0, nullptr); if (rc0) return rc0; }   // accumulated, planes not released
     const UvcParams &P = *uvcgpu_region_params(r);
@@ -486,7 +487,18 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
             std::string indel;
             const int32_t garow = F(ia, UVC_O_gapSa);
             if (garow >= 0 && garow < (int32_t)G.rows.size()) indel = G.text(G.rows[(size_t)garow], ref, beg);
-            // (an InDel whose length came from the caller -- UvcIndelAllele / UvcTumorKey carry no text -- is written with its symbolic allele)
+            {   // a rescued InDel of the normal sample takes the tumor record's string: REF / ALT without their common head (main.cpp:867-880)
+                const int32_t tk0 = F(ia, UVC_O_tkey);
+                if (indel.empty() && (is_ins(symbol) || is_del(symbol)) && tref_alt && tkeys && tk0 >= 0 && tk0 < n_tkeys && tref_alt[tk0]) {
+                    const std::string ra = tref_alt[tk0];
+                    const size_t tab = ra.find('\t');
+                    if (tab != std::string::npos) {
+                        const std::string vr = ra.substr(0, tab), va = ra.substr(tab + 1);
+                        if (vr.size() > va.size()) indel = vr.substr(va.size()); else if (va.size() > vr.size()) indel = va.substr(vr.size());
+                    }
+                }
+            }
+            // (an InDel whose length came from the caller without text -- UvcIndelAllele, or UvcTumorKey without tumor_ref_alt -- is written with its symbolic allele)
             // CHROM POS ID REF ALT
             int64_t vcfpos; std::string vref, valt;
             auto ref_at = [&](int64_t p) { return (p >= 0 && p < (int64_t)ref.size()) ? std::string(1, ref[(size_t)p]) : std::string("n"); };

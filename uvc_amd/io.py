@@ -49,7 +49,7 @@ def dll():
         d.uvcio_tumor_vcf_open.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.c_int32]
         d.uvcio_tumor_vcf_sample_name.restype, d.uvcio_tumor_vcf_sample_name.argtypes = C.c_char_p, [C.c_void_p]
         d.uvcio_tumor_vcf_n_records.restype, d.uvcio_tumor_vcf_n_records.argtypes = C.c_int64, [C.c_void_p]
-        d.uvcio_tumor_vcf_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        d.uvcio_tumor_vcf_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         d.uvcio_tumor_vcf_close.argtypes = [C.c_void_p]
         _dll = d
     return _dll
@@ -196,13 +196,16 @@ class TumorVcf:
         self.n_records = dll().uvcio_tumor_vcf_n_records(self.h)
 
     def fetch(self, tid, pos_beg, pos_end):
-        """-> (ctypes array of UvcTumorKey or None, list of sample-column strings): the records with pos_beg <= symbolpos <= pos_end."""
-        keys, cols, n = C.c_void_p(), C.c_void_p(), C.c_int64(0)
-        _check(dll().uvcio_tumor_vcf_fetch(self.h, tid, pos_beg, pos_end, C.byref(keys), C.byref(cols), C.byref(n)))
+        """-> (ctypes array of UvcTumorKey or None, list of sample-column strings): the records with pos_beg <= symbolpos <= pos_end;
+        `last_ref_alt` holds their "REF\tALT" strings."""
+        keys, cols, ras, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64(0)
+        _check(dll().uvcio_tumor_vcf_fetch(self.h, tid, pos_beg, pos_end, C.byref(keys), C.byref(cols), C.byref(ras), C.byref(n)))
+        self.last_ref_alt = []
         if n.value == 0:
             return None, []
         arr = (_ffi.UvcTumorKey * n.value).from_address(keys.value)
         texts = [s.decode() for s in (C.c_char_p * n.value).from_address(cols.value)]
+        self.last_ref_alt = [s.decode() for s in (C.c_char_p * n.value).from_address(ras.value)]   # "REF\tALT" of the same records
         return arr, texts
 
     def close(self):

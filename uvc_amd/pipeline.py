@@ -85,14 +85,15 @@ def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None
     score_range = (skw["pos_beg"], skw["pos_end"])
     if score_range[1] <= score_range[0]:
         return None
-    tk, tcols = None, None
+    tk, tcols, tras = None, None, None
     if tumor_vcf is not None:                                                          # the tumor records inside this region (tkis_beg .. tkis_end, main.cpp:532-533)
         tk, tcols = tumor_vcf.fetch(tid, ext_beg, ext_end)
+        tras = tumor_vcf.last_ref_alt
     rec = R.score(all_out=all_out, is_amplicon=bool(is_amplicon), tumor_keys=tk, **skw)
     lap("bq+accumulate+score")
     out = dict(records=rec, alleles=R.indel_alleles(), rpos=(rpos_beg, rpos_end), ext=(ext_beg, ext_end), n_reads=int(g["n_kept"]), n_fams=int(g["n_fams"]), chrom=chrom, refseq=refseq, score_range=score_range)
     if vcf:
-        out["vcf"] = R.vcf_records(chrom, rec, tumor_keys=tk, tumor_sample_columns=tcols, **skw)          # the record lines of append_vcf_record (uvcgpu_region_vcf_records), before the handle moves on
+        out["vcf"] = R.vcf_records(chrom, rec, tumor_keys=tk, tumor_sample_columns=tcols, tumor_ref_alt=tras, **skw)          # the record lines of append_vcf_record (uvcgpu_region_vcf_records), before the handle moves on
     if keep_handle:
         out["region"] = R
     elif reuse is None:

@@ -235,7 +235,7 @@ class Region:
 
     @staticmethod
     def make_request(all_out=False, pos_beg=-1, pos_end=-1, is_amplicon=False, indel_alleles=None, tumor_keys=None, release_state=False, base_at_pos_beg=False, region_beg=0,
-                     tumor_sample_columns=None):
+                     tumor_sample_columns=None, tumor_ref_alt=None):
         """UvcScoreRequest + the ctypes arrays it points into (keep both alive for the call)."""
         req = _ffi.UvcScoreRequest()
         req.pos_beg, req.pos_end, req.all_out, req.is_amplicon = pos_beg, pos_end, int(all_out), int(is_amplicon)
@@ -254,7 +254,12 @@ class Region:
             assert len(tumor_sample_columns) == len(tk)
             cols = (C.c_char_p * len(tk))(*[c.encode() if isinstance(c, str) else c for c in tumor_sample_columns])
             req.tumor_sample_columns = C.cast(cols, C.c_void_p)
-        return req, (arr, tk, cols)
+        ras = None
+        if tk is not None and tumor_ref_alt:          # "REF\tALT" of every key: the InDel strings of rescued InDel records (record writer)
+            assert len(tumor_ref_alt) == len(tk)
+            ras = (C.c_char_p * len(tk))(*[c.encode() if isinstance(c, str) else c for c in tumor_ref_alt])
+            req.tumor_ref_alt = C.cast(ras, C.c_void_p)
+        return req, (arr, tk, cols, ras)
 
     def score(self, all_out=False, pos_beg=-1, pos_end=-1, is_amplicon=False, indel_alleles=None, capacity=None, copy=True, tumor_keys=None, release_state=False, base_at_pos_beg=False, region_beg=0):
         req, _keep = self.make_request(all_out, pos_beg, pos_end, is_amplicon, indel_alleles, tumor_keys, release_state, base_at_pos_beg, region_beg)
@@ -297,7 +302,7 @@ class Region:
         fn.restype, fn.argtypes = C.c_int32, [C.c_int32]
         return fn(_ffi.FIELD_GROUPS[group][0])
 
-    def vcf_records(self, contig_name, records, tumor_keys=None, pos_beg=-1, pos_end=-1, base_at_pos_beg=False, region_beg=0, tumor_sample_columns=None):
+    def vcf_records(self, contig_name, records, tumor_keys=None, pos_beg=-1, pos_end=-1, base_at_pos_beg=False, region_beg=0, tumor_sample_columns=None, tumor_ref_alt=None):
         """The VCF lines (text) of the records `score()` returned that are written (out and keep set): uvcgpu_region_vcf_records.
         Needs the planes, i.e. a score call without release_state.  The keyword arguments repeat those of the score call."""
         fn = getattr(self.lib.dll, self.lib.prefix + "region_vcf_records")
@@ -306,7 +311,7 @@ class Region:
         n = len(records["refpos"])
         buf = np.ascontiguousarray(np.stack([np.asarray(records[name], dtype=np.int32) for name in _ffi.SCORE_FIELDS])) if n else np.zeros((_ffi.NUM_SCORE_FIELDS, 1), dtype=np.int32)
         so = _ffi.UvcScoreOut(max(n, 1), n, buf.ctypes.data)
-        req, _keep = self.make_request(pos_beg=pos_beg, pos_end=pos_end, tumor_keys=tumor_keys, base_at_pos_beg=base_at_pos_beg, region_beg=region_beg, tumor_sample_columns=tumor_sample_columns)
+        req, _keep = self.make_request(pos_beg=pos_beg, pos_end=pos_end, tumor_keys=tumor_keys, base_at_pos_beg=base_at_pos_beg, region_beg=region_beg, tumor_sample_columns=tumor_sample_columns, tumor_ref_alt=tumor_ref_alt)
         ln = C.c_int64(0)
         rc = fn(self.h, contig_name.encode(), C.byref(so), C.byref(req), None, 0, C.byref(ln))
         if rc not in (0, -6):
