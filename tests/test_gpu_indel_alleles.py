@@ -120,3 +120,88 @@ def test_caller_alleles_override_the_tables(oracle_lib, gpu_lib):
     m = (so["refpos"] == p) & (so["symbol"] == s)
     assert so["bDPa"][m].tolist() == [7, 3] and so["gapSa"][m].tolist() == [-1, -1] and so["gapSa_len"][m].tolist() == [2, 9]
     assert (so["gapSa"][(so["gapSa_len"] > 0) & ~m] >= 0).all()
+
+
+def _colliding_insertions(length=16, n=600_000, seed=123):
+    """Two different insertions of `length` bases whose 34-bit allele codes (k_gap's FNV hash of insertions longer than 13 bases) agree:
+    a birthday search over random sequences, with the hash restated here."""
+    rng = np.random.default_rng(seed)
+    seqs = rng.integers(0, 4, (n, length), dtype=np.uint8)
+    h = np.full(n, np.uint64(1469598103934665603) ^ np.uint64(length), dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for i in range(length):
+            h = (h ^ seqs[:, i].astype(np.uint64)) * np.uint64(1099511628211)
+    code = h >> np.uint64(30)
+    order = np.argsort(code, kind="stable")
+    same = np.nonzero(code[order][1:] == code[order][:-1])[0]
+    for k in same:
+        a, b = seqs[order[k]], seqs[order[k + 1]]
+        if not np.array_equal(a, b):
+            return a.tolist(), b.tolist()
+    raise AssertionError("no collision found: enlarge n")
+
+
+def test_long_insertions_with_one_hash_stay_two_alleles(oracle_lib, gpu_lib, monkeypatch):
+    """insertions longer than 13 bases are keyed by a 34-bit hash; two alleles of one site that collide must not be
+    merged -- k_gap_rows splits a run of equal keys by comparing the sequences."""
+    import test_gpu_indel_alleles as me
+    a, b = _colliding_insertions()
+    assert a != b and len(a) == len(b) == 16
+    monkeypatch.setattr(me, "INS_ALLELES", [a, b, a, b, a, b, [2], a, b])
+    for seed, umi in ((11, True), (12, False)):
+        reads = indel_sites_region(seed, n_fam=140 if umi else 300, umi=umi)
+        o, g = run(oracle_lib, reads), run(gpu_lib, reads)
+        assert not diff_groups(o, g)
+        ro, rg = o.indel_alleles(), g.indel_alleles()
+        ta, tb = "".join("ACGT"[x] for x in a), "".join("ACGT"[x] for x in b)
+        sites_a = {(r["refpos"], r["symbol"], r["strand"]) for r in ro if r["seq"] == ta}
+        sites_b = {(r["refpos"], r["symbol"], r["strand"]) for r in ro if r["seq"] == tb}
+        assert len(sites_a & sites_b) >= 2                       # both alleles on one (site, strand): the colliding keys meet
+        assert ro == rg, next((x, y) for x, y in zip(ro + [None], rg + [None]) if x != y)
+        compare_records(o.score(), g.score())
+
+
+def big_family_region(two_alleles, n_frag=24, beg=3_000_000, ref_len=400):
+    """One UMI family of `n_frag` single-read fragments that all carry a 3-base insertion right behind their first few bases; with
+    `two_alleles` 14 of them insert ACG and the others ACT (one insertion symbol, two sequences)."""
+    rng = np.random.default_rng(4)
+    ref = rng.integers(0, 4, ref_len)
+    refseq = "".join("ACGT"[b] for b in ref)
+    cols = dict(pos=[], mpos=[], isize=[], flag=[], mapq=[], nm=[], l_qseq=[], seq_off=[], cigar_off=[], n_cigar=[], frag_id=[], fam_id=[], fam_strand=[])
+    bases, quals, cigars = [], [], []
+    frag = 0
+    for fam, site_off in enumerate(range(4, 40, 3)):           # insertion 4 .. 37 bases behind the start of the family's reads
+        start = 20 + 3 * fam
+        for k in range(n_frag):
+            ins = [0, 1, 2] if (not two_alleles or k < 14) else [0, 1, 3]
+            left, right = site_off, 100
+            q = [int(x) for x in ref[start:start + left]] + ins + [int(x) for x in ref[start + left:start + left + right]]
+            cols["pos"].append(beg + start); cols["flag"].append(0); cols["mapq"].append(60); cols["mpos"].append(beg + start); cols["isize"].append(0)
+            cols["nm"].append(3); cols["l_qseq"].append(len(q)); cols["seq_off"].append(len(bases)); cols["cigar_off"].append(len(cigars)); cols["n_cigar"].append(3)
+            cols["frag_id"].append(frag); cols["fam_id"].append(fam); cols["fam_strand"].append(0)
+            bases += q; quals += [37] * len(q); cigars += [(left << 4) | M, (3 << 4) | I, (right << 4) | M]
+            frag += 1
+    n_fam = fam + 1
+    dt = dict(pos=np.int32, mpos=np.int32, isize=np.int32, flag=np.uint16, mapq=np.uint8, nm=np.int32, l_qseq=np.int32, seq_off=np.int64, cigar_off=np.int64,
+              n_cigar=np.int32, frag_id=np.int32, fam_id=np.int32, fam_strand=np.uint8)
+    r = {k: np.array(v, dt[k]) for k, v in cols.items()}
+    r.update(n_reads=len(cols["pos"]), tid=5, beg=beg, end=beg + ref_len, refseq=refseq, n_fams=n_fam, fam_dflag=np.full(n_fam, 0x1, np.uint8),
+             bases=np.array(bases, np.uint8), quals=np.array(quals, np.uint8), cigars=np.array(cigars, np.uint32))
+    return r
+
+
+def test_family_position_bias_counts_the_majority_sequence(oracle_lib, gpu_lib):
+    """`indel_len` of the FAM2 position-bias test is the number of fragments that carry the MAJORITY inserted
+    sequence (read_family_con_ampl_getMajority_ins, main.hpp:188-198, 3239-3246), not the number of votes for the insertion symbol.  Families
+    of 24 fragments, 14 with one inserted sequence and 10 with another, at sites 4 .. 37 bases behind the read start: the two counts (14 and
+    24) fall on different sides of microadjust_nobias_pos_indel_maxlen + the distance threshold at some of the sites."""
+    mixed, pure = big_family_region(True), big_family_region(False)
+    om, op = run(oracle_lib, mixed), run(oracle_lib, pure)
+    fm, fp = om.fetch("FAMINFO32"), op.fetch("FAMINFO32")
+    ins = slice(10, 13)                                          # LINK_I3P .. LINK_I1
+    assert not np.array_equal(fm[:, ins, :], fp[:, ins, :])      # the oracle is sensitive to the count at these sites: the case does provoke the difference
+    gm = run(gpu_lib, mixed)
+    assert not diff_groups(om, gm)
+    gp = run(gpu_lib, pure)
+    assert not diff_groups(op, gp)
+    compare_records(om.score(), gm.score())

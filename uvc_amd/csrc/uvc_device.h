@@ -115,6 +115,8 @@ struct GapWork {
     unsigned long long *ikey, *ikey_s, *ival, *ival_s;       // allele increments and their sorted copies
     int32_t inc_cap; int32_t *n_inc;
     GapRow *rows; int32_t *n_rows; uint8_t *seq; unsigned long long *seq_len; int64_t seq_cap;
+    int32_t *maj;               // [2 * n_ev], at the head of each (family, position) run of the sorted candidates: per strand the largest number of
+                                // fragments of the unit that agree on one inserted sequence (read_family_con_ampl_getMajority_ins, main.hpp:188-198)
     void *sort_tmp; size_t sort_tmp_bytes;
 };
 

@@ -411,7 +411,7 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
         G.n_ev = (int32_t)gap_slots; G.inc_cap = (int32_t)(7 * gap_slots + 8); G.seq_cap = ins_total + 8;
         const size_t ne = (size_t)std::max<int64_t>(gap_slots, 1), ni = (size_t)G.inc_cap;
         unsigned long long *k8; int32_t *c4;
-        if ((rc = dev_alloc(r, ne, &G.ev)) || (rc = dev_alloc(r, 4 * ne + 4 * ni, &k8)) || (rc = dev_alloc(r, (size_t)4, &c4, true)) || (rc = dev_alloc(r, ne, &G.rows)) || (rc = dev_alloc(r, (size_t)G.seq_cap, &G.seq))) return rc;
+        if ((rc = dev_alloc(r, ne, &G.ev)) || (rc = dev_alloc(r, 4 * ne + 4 * ni, &k8)) || (rc = dev_alloc(r, (size_t)4, &c4, true)) || (rc = dev_alloc(r, ne, &G.rows)) || (rc = dev_alloc(r, (size_t)G.seq_cap, &G.seq)) || (rc = dev_alloc(r, 2 * ne, &G.maj))) return rc;
         G.ckey = k8; G.ckey_s = k8 + ne; G.cval = k8 + 2 * ne; G.cval_s = k8 + 3 * ne;
         G.ikey = k8 + 4 * ne; G.ikey_s = G.ikey + ni; G.ival = G.ikey + 2 * ni; G.ival_s = G.ikey + 3 * ni;
         G.n_inc = c4; G.n_rows = c4 + 1; G.seq_len = (unsigned long long *)(c4 + 2);

@@ -1806,6 +1806,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6,6)))
 // ------------------------------------------------------------------------------------------------
 // generic family-strand units (more than one fragment, or UMI / duplex): one thread per (unit, position)
 // ------------------------------------------------------------------------------------------------
+// indel_len of the FAM2 position-bias test (main.hpp:3236-3246) for an insertion consensus: the number of fragments of the unit that carry
+// the majority inserted sequence.  While the unit has no more insertion votes than microadjust_nobias_pos_indel_maxlen the value cannot
+// matter (non_neg_minus gives 0 either way); above it the exact count comes from the allele pipeline (k_gap_alleles), found by the
+// (family, position) key of the sorted candidates.
+DEV int fam2_ins_len(const RegionDev &R, const UvcParams &P, const FsRec &u, int p, int votes) {
+    if (votes <= P.microadjust_nobias_pos_indel_maxlen || R.gap.n_ev <= 0) return votes;
+    const unsigned long long key = ((unsigned long long)u.fam << 26) | (unsigned long long)(p - R.beg);
+    int lo = 0, hi = R.gap.n_ev;
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (R.gap.ckey_s[m] < key) lo = m + 1; else hi = m; }
+    if (lo >= R.gap.n_ev || R.gap.ckey_s[lo] != key) return votes;   // cannot happen: an insertion vote comes from an insertion event
+    return R.gap.maj[2 * lo + u.strand];
+}
 DEV int find_unit(const RegionDev &R, int64_t w) {   // last generic unit with work_off <= w
     int lo = 0, hi = R.n_generic_fs;
     while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (R.fss[R.generic_fs[mid]].work_off <= w) lo = mid; else hi = mid; }
@@ -1946,10 +1958,8 @@ __global__ void __launch_bounds__(256) k_fam_p4(RegionDev R, UvcParams P) {
                 const int l_nb = (int)nnminus(p + 1, rbeg), r_nb = (int)nnminus(rend, p);
                 const int _LPxT = TH(R, UVC_T_aLPxT, x), RPxT = TH(R, UVC_T_aRPxT, x);
                 const int LPxT = (isGap ? _LPxT : imin(_LPxT, RPxT));
-                // indel_len = majority COUNT of one inserted sequence among the unit's fragments (main.hpp:3239-3243): the
-                // sequence-keyed maps stay on the host; the number of votes for the symbol is an upper bound that
-                // equals it whenever all fragments carry the same inserted sequence.
-                const int indel_len = ((is_ins(cs) || is_del(cs)) ? con[cs] : 0);
+                // indel_len = majority COUNT of one inserted sequence among the unit's fragments (main.hpp:3239-3243): see fam2_ins_len
+                const int indel_len = (is_ins(cs) ? fam2_ins_len(R, P, u, p, con[cs]) : 0);   // (a deletion's count is never read: main.hpp:3245)
                 const bool far = (l_nb + (is_ins(cs) ? (int)nnminus(indel_len, P.microadjust_nobias_pos_indel_maxlen) : 0) >= LPxT) && (r_nb >= RPxT);
                 if (far) {
                     int LP1 = 0, LP2 = 0, RP1 = 0, RP2 = 0; long long LPL = 0, RPL = 0;
@@ -2079,10 +2089,8 @@ DEV void p4_apply(const FamAcc &A, const RegionDev &R, const UvcParams &P, const
                         const int l_nb = (int)nnminus(p + 1, rbeg), r_nb = (int)nnminus(rend, p);
                         const int _LPxT = Q.LPxT, RPxT = Q.RPxT;
                         const int LPxT = (isGap ? _LPxT : imin(_LPxT, RPxT));
-                        // indel_len = majority COUNT of one inserted sequence among the unit's fragments (main.hpp:3239-3243): the
-                        // sequence-keyed maps stay on the host; the number of votes for the symbol is an upper bound that
-                        // equals it whenever all fragments carry the same inserted sequence.
-                        const int indel_len = ((is_ins(cs) || is_del(cs)) ? cc : 0);   // con[cs] of the vote consensus
+                        // indel_len = majority COUNT of one inserted sequence among the unit's fragments (main.hpp:3239-3243): see fam2_ins_len
+                        const int indel_len = (is_ins(cs) ? fam2_ins_len(R, P, u, p, cc) : 0);   // cc = con[cs] of the vote consensus
                         const bool far = (l_nb + (is_ins(cs) ? (int)nnminus(indel_len, P.microadjust_nobias_pos_indel_maxlen) : 0) >= LPxT) && (r_nb >= RPxT);
                         if (far) {
                             int LP1 = 0, LP2 = 0, RP1 = 0, RP2 = 0; long long LPL = 0, RPL = 0;
@@ -2229,10 +2237,8 @@ __global__ void __launch_bounds__(256) k_fam_win(RegionDev R, UvcParams P) {
                         const int l_nb = (int)nnminus(p + 1, rbeg), r_nb = (int)nnminus(rend, p);
                         const int _LPxT = TH(R, UVC_T_aLPxT, x), RPxT = TH(R, UVC_T_aRPxT, x);
                         const int LPxT = (isGap ? _LPxT : imin(_LPxT, RPxT));
-                        // indel_len = majority COUNT of one inserted sequence among the unit's fragments (main.hpp:3239-3243): the
-                        // sequence-keyed maps stay on the host; the number of votes for the symbol is an upper bound that
-                        // equals it whenever all fragments carry the same inserted sequence.
-                        const int indel_len = ((is_ins(cs) || is_del(cs)) ? con[cs] : 0);
+                        // indel_len = majority COUNT of one inserted sequence among the unit's fragments (main.hpp:3239-3243): see fam2_ins_len
+                        const int indel_len = (is_ins(cs) ? fam2_ins_len(R, P, u, p, con[cs]) : 0);
                         const bool far = (l_nb + (is_ins(cs) ? (int)nnminus(indel_len, P.microadjust_nobias_pos_indel_maxlen) : 0) >= LPxT) && (r_nb >= RPxT);
                         if (far) {
                             int LP1 = 0, LP2 = 0, RP1 = 0, RP2 = 0; long long LPL = 0, RPL = 0;
@@ -2690,8 +2696,9 @@ __global__ void __launch_bounds__(64) k_gap_alleles(RegionDev R, UvcParams P) {
         R.gap.ival[k] = ((unsigned long long)e << 8) | (unsigned long long)(strand * 4 + level);
     };
     // the event among `cand(e)` whose allele has the largest total weight; ties go to the larger allele (indelToData_getMajority, main.hpp:50-63)
+    long long best_w = 0;   // weight of the last majority() winner
     auto majority = [&](auto cand, auto weight) -> int {
-        int best = -1; long long best_w = 0;
+        int best = -1; best_w = 0;
         for (int i = i0; i < i1; i++) {
             const int e = (int)order[i];
             if (!cand(e)) continue;
@@ -2713,6 +2720,7 @@ __global__ void __launch_bounds__(64) k_gap_alleles(RegionDev R, UvcParams P) {
     const bool will_inc_sscs = is_duplex_fam && !will_inc_dscs;
     int con[2][NSYM], mmm[2][NSYM], cnt[NSYM];
     for (int s = 0; s < 2; s++) for (int k = 0; k < NSYM; k++) { con[s][k] = 0; mmm[s][k] = 0; }
+    R.gap.maj[2 * i0] = 0; R.gap.maj[2 * i0 + 1] = 0;
     // fragments: P3 consensus (main.hpp:2650-2717) and their votes for the unit (updateByFiltering / updateByMajorMinusMinor, main.hpp:1659-1725)
     for (int s = 0; s < 2; s++) {
         if (units[s] < 0) continue;
@@ -2740,6 +2748,12 @@ __global__ void __launch_bounds__(64) k_gap_alleles(RegionDev R, UvcParams P) {
         if (units[s] < 0) continue;
         const FsRec u = R.fss[units[s]];
         auto unit_allele = [&](int sym) { return majority([&](int q) { return ev[q].mark == (0x10000 | (s << 8) | sym); }, [&](int q) { return 1LL; }); };
+        {   // the count read_family_con_ampl_getMajority_ins returns: the inserted sequence most fragments of the unit agree on, over all three
+            // insertion symbols (main.hpp:188-198); the FAM2 position-bias test of the family kernels reads it (main.hpp:3239-3246)
+            long long m = 0;
+            for (int sym = UVC_LINK_I3P; sym <= UVC_LINK_I1; sym++) if (unit_allele(sym) >= 0) m = (best_w > m ? best_w : m);   // (the map is fed by every fragment whose consensus is the symbol, main.hpp:1670-1676)
+            R.gap.maj[2 * i0 + s] = (int32_t)m;
+        }
         int cs, cc, ct;
         fill_consensus(con[s], cs, cc, ct, UVC_LINK_SYMBOL, false, false);
         if (ct > 0 && (is_ins(cs) || is_del(cs))) {
@@ -2790,25 +2804,39 @@ __global__ void __launch_bounds__(256) k_gap_rows(RegionDev R) {
     if (i0 >= n) return;
     const unsigned long long key = R.gap.ikey_s[i0];
     if (i0 > 0 && R.gap.ikey_s[i0 - 1] == key) return;
-    GapRow row;
-    for (int k = 0; k < 8; k++) row.cnt[k] = 0;
-    int rep = INT32_MAX;
-    for (int i = i0; i < n && R.gap.ikey_s[i] == key; i++) {
-        const unsigned long long v = R.gap.ival_s[i];
-        row.cnt[v & 0xFF] += 1;
-        rep = imin(rep, (int)(v >> 8));
+    // The allele code of an insertion longer than 13 bases is a hash: equal keys need not be equal sequences.  Such a run is split by
+    // comparing the sequences themselves (one pass when they all agree, which is the case unless two long insertions of one site collide
+    // in 34 bits); bit 63 of a value marks an increment that has found its row.
+    const bool hashed = ((key >> 34) & 1ull) != 0;
+    int i1 = i0;
+    while (i1 < n && R.gap.ikey_s[i1] == key) i1++;
+    for (int ib = i0; ib < i1; ib++) {
+        if (R.gap.ival_s[ib] >> 63) continue;
+        const AlnGap first = R.gap.ev[(int)((R.gap.ival_s[ib] & ~(1ull << 63)) >> 8)];
+        GapRow row;
+        for (int k = 0; k < 8; k++) row.cnt[k] = 0;
+        int rep = INT32_MAX;
+        for (int i = ib; i < i1; i++) {
+            const unsigned long long v = R.gap.ival_s[i];
+            if (v >> 63) continue;
+            if (hashed && i != ib && 0 != gap_cmp(R, first, R.gap.ev[(int)(v >> 8)])) continue;   // another sequence under the same hash: a later row
+            row.cnt[v & 0xFF] += 1;
+            rep = imin(rep, (int)(v >> 8));
+            R.gap.ival_s[i] = v | (1ull << 63);
+        }
+        const AlnGap e = R.gap.ev[rep];
+        row.x = (int)(key >> 38); row.sym = e.sym; row.len = e.len; row.ev = rep; row.seq_off = -1;
+        if (is_ins(e.sym)) {
+            const long long off = (long long)atomicAdd(R.gap.seq_len, (unsigned long long)e.len);
+            if (off + e.len <= R.gap.seq_cap) {
+                const uint8_t *src = R.bases + R.alns[e.aln].seq_off + e.qpos;
+                for (int k = 0; k < e.len; k++) R.gap.seq[off + k] = src[k];
+                row.seq_off = off;
+            } else atomicExch(R.err, UVCGPU_EDEVICE);
+        }
+        R.gap.rows[atomicAdd(R.gap.n_rows, 1)] = row;
+        if (!hashed) break;   // exact codes: the whole run is one row
     }
-    const AlnGap e = R.gap.ev[rep];
-    row.x = (int)(key >> 38); row.sym = e.sym; row.len = e.len; row.ev = rep; row.seq_off = -1;
-    if (is_ins(e.sym)) {
-        const long long off = (long long)atomicAdd(R.gap.seq_len, (unsigned long long)e.len);
-        if (off + e.len <= R.gap.seq_cap) {
-            const uint8_t *src = R.bases + R.alns[e.aln].seq_off + e.qpos;
-            for (int k = 0; k < e.len; k++) R.gap.seq[off + k] = src[k];
-            row.seq_off = off;
-        } else atomicExch(R.err, UVCGPU_EDEVICE);
-    }
-    R.gap.rows[atomicAdd(R.gap.n_rows, 1)] = row;
 }
 
 extern "C" int uvc_gap_sort(void *tmp, size_t tmp_bytes, const unsigned long long *kin, unsigned long long *kout, const unsigned long long *vin, unsigned long long *vout,
@@ -2967,6 +2995,7 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
         else TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag<false>, dim3(nwin), dim3(256), 0, s, *R, *P));
     }
     if (R->n_generic_fs) {
+        if (side && G.n_ev > 0) hipStreamWaitEvent(s, e_fork2, 0);   // fam2_ins_len reads what k_gap_alleles left (done long before: it ran under k_frag)
         TIMED(prof, "k_fam_stat", hipLaunchKernelGGL(k_fam_stat, dim3(nblk(R->n_generic_fs, 64)), dim3(64), 0, s, *R, *P));
         // shallow data: one thread per (unit, position); deep data (many units per position, e.g. UMI panels): the window kernel, whose
         // LDS collection removes most of the atomics that bound the per-thread form
