@@ -2696,9 +2696,8 @@ __global__ void __launch_bounds__(64) k_gap_alleles(RegionDev R, UvcParams P) {
         R.gap.ival[k] = ((unsigned long long)e << 8) | (unsigned long long)(strand * 4 + level);
     };
     // the event among `cand(e)` whose allele has the largest total weight; ties go to the larger allele (indelToData_getMajority, main.hpp:50-63)
-    long long best_w = 0;   // weight of the last majority() winner
     auto majority = [&](auto cand, auto weight) -> int {
-        int best = -1; best_w = 0;
+        int best = -1; long long best_w = 0;
         for (int i = i0; i < i1; i++) {
             const int e = (int)order[i];
             if (!cand(e)) continue;
@@ -2750,9 +2749,16 @@ __global__ void __launch_bounds__(64) k_gap_alleles(RegionDev R, UvcParams P) {
         auto unit_allele = [&](int sym) { return majority([&](int q) { return ev[q].mark == (0x10000 | (s << 8) | sym); }, [&](int q) { return 1LL; }); };
         {   // the count read_family_con_ampl_getMajority_ins returns: the inserted sequence most fragments of the unit agree on, over all three
             // insertion symbols (main.hpp:188-198); the FAM2 position-bias test of the family kernels reads it (main.hpp:3239-3246)
-            long long m = 0;
-            for (int sym = UVC_LINK_I3P; sym <= UVC_LINK_I1; sym++) if (unit_allele(sym) >= 0) m = (best_w > m ? best_w : m);   // (the map is fed by every fragment whose consensus is the symbol, main.hpp:1670-1676)
-            R.gap.maj[2 * i0 + s] = (int32_t)m;
+            // (the map is fed by every fragment whose consensus is an insertion symbol, main.hpp:1670-1676: the marked events of the unit)
+            int m = 0;
+            for (int i = i0; i < i1; i++) {
+                const int e = (int)order[i];
+                if ((ev[e].mark >> 8) != (0x100 | s) || !is_ins(ev[e].mark & 0xFF)) continue;
+                int w = 0;
+                for (int j = i0; j < i1; j++) { const int e2 = (int)order[j]; if (ev[e2].mark == ev[e].mark && 0 == gap_cmp(R, ev[e], ev[e2])) w++; }
+                m = imax(m, w);
+            }
+            R.gap.maj[2 * i0 + s] = m;
         }
         int cs, cc, ct;
         fill_consensus(con[s], cs, cc, ct, UVC_LINK_SYMBOL, false, false);
