@@ -361,6 +361,21 @@ int uvcgpu_region_fetch(uvcgpu_region_t *r, int32_t field_group, void *dst, int6
  * getPosToIseqToData / getPosToDlenToData / pos2iseq2data_cDP2 / pos2iseq2data_c2dDP in main.hpp:5350-5376. */
 int uvcgpu_region_indel_alleles(uvcgpu_region_t *r, UvcGapRow *rows, int64_t row_capacity, int64_t *n_rows,
                                 uint8_t *seq, int64_t seq_capacity, int64_t *seq_bytes);
+/* The haplotype links of the accumulated region: the three std::vector<HapLink> that updateByRegion3Aln hands back (hap_bq, hap_fq,
+ * hap_f2q, main.hpp:3665-3670) -- per link the mutated (refpos, symbol) pairs that one fragment (bq) / one UMI family (fq; f2q: confirmed by
+ * the family vote) carried together, how many fragments / families on each strand carried exactly this set, and, for the three most
+ * frequent sets, how many carried a superset (updateHapMap, main.hpp:3596-3663).  Links come grouped by `which` in the reference's order;
+ * FORMAT/bHap, cHap, c2Hap of a record list the links that contain its (refpos, symbol) (main.cpp:82-97, main.hpp:5380-5404).
+ * Sizes first (UVCGPU_ENOMEM with *n_links / *n_mut_ints set), then the data, as for uvcgpu_region_indel_alleles.  Needs the planes. */
+typedef struct UvcHapLink {
+    int32_t which;              /* 0 bq (fragments, duplicates kept), 1 fq (families), 2 f2q (families, tier-2 consensus) */
+    int32_t n_muts;             /* pairs of this link */
+    int64_t mut_off;            /* index of its first int in `muts`: refpos, symbol, refpos, symbol, ... */
+    int32_t fr_cnt[2];          /* HapLink::fr_cnts */
+    int32_t other_cnt[2];       /* HapLink::other_hap_cnts, -1 -1 beyond the phasing_haplotype_max_detail_cnt most frequent links */
+} UvcHapLink;
+int uvcgpu_region_hap_links(uvcgpu_region_t *r, UvcHapLink *links, int64_t link_capacity, int64_t *n_links,
+                            int32_t *muts, int64_t mut_capacity, int64_t *n_mut_ints);
 /* Every plane value of chosen positions, one row of uvcgpu_region_n_columns() int64 values per position: the groups in UvcField order
  * (PREP32 .. DUPLEX; RTR and BAQ are not part of a row), the planes of a group in the group's array order, i.e. column =
  * uvcgpu_region_column_base(group) + plane.  Positions outside the region give a row of zeros.  Replaces the getByPos() reads of
@@ -373,8 +388,8 @@ int uvcgpu_region_fetch_columns(uvcgpu_region_t *r, const int32_t *refpos, int64
 /* The header and the record lines of the reference's output for the scored records of a region: generate_vcf_header (the ##FILTER /
  * ##FORMAT / ##INFO / ##contig lines and the #CHROM line) and append_vcf_record + bcfrec::streamAppendBcfFormat (main.hpp:6027-6272,
  * bcf_formats_generator1.cpp:135-527, 643-690): CHROM POS ID REF ALT QUAL FILTER INFO FORMAT and the sample column with every FORMAT tag
- * of FORMAT_STRING_PER_REC(_WITHOUT_SSCS), in the reference's order and separators.  Not produced here: the read-level haplotype strings
- * bHap / cHap / c2Hap (always "."), FORMAT/note and the GERMLINE lines of output_germline.
+ * of FORMAT_STRING_PER_REC(_WITHOUT_SSCS), in the reference's order and separators, bHap / cHap / c2Hap from uvcgpu_region_hap_links.
+ * Not produced here: FORMAT/note (should_add_note) and the GERMLINE lines of output_germline.
  * Both return UVCGPU_ENOMEM with *len = the size needed when `capacity` is too small. */
 const char *uvcgpu_vcf_format_keys(int32_t with_tier2_consensus_tags);
 /* tumor_sample_name: NULL, or -- for the normal sample of a T/N pair with is_tumor_format_retrieved -- the name of the tumor VCF's sample,

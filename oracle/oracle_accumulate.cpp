@@ -11,6 +11,7 @@
 // Out of scope here exactly as in SURVEY.md section 2: consensus FASTQ (C6), haplotype maps (a12).
 #include "oracle_common.hpp"
 #include <map>
+#include <tuple>
 
 namespace uvco {
 
@@ -880,6 +881,7 @@ static int using_bq(State &S, std::string &err) {
             }
             const size_t tlen = (size_t)(end2 - beg2);
             cov_mut.assign(tlen, 0); cm_base.assign(tlen, UVC_NUM_SYMBOLS); cm_link.assign(tlen, UVC_NUM_SYMBOLS);
+            State::MutForm pos_symbol_string;   // main.hpp:2650, 2734-2737
             for (i32 epos = beg2; epos < end2; epos++) {
                 const i64 x = epos - S.beg;
                 for (int vi = 0; vi < 2; vi++) {
@@ -903,10 +905,11 @@ static int using_bq(State &S, std::string &err) {
                     const bool is_var_of_highBQ = ((UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform)
                             ? (UVC_BASE_SYMBOL == st || con_qual + 3 >= P.bias_thres_highBQ)
                             : (UVC_LINK_SYMBOL == st || con_qual >= P.bias_thres_highBQ));
-                    if (symbols_mutated(refsymbol, con_symbol) && is_var_of_highBQ) cov_mut[epos - beg2] |= 0x2;
+                    if (symbols_mutated(refsymbol, con_symbol) && is_var_of_highBQ) { pos_symbol_string.push_back(std::make_pair(epos, con_symbol)); cov_mut[epos - beg2] |= 0x2; }
                     if (UVC_LINK_SYMBOL == st) cm_link[epos - beg2] = con_symbol; else cm_base[epos - beg2] = con_symbol;
                 }
             }
+            if (pos_symbol_string.size() > 1) { auto &c = S.hapmap[0][pos_symbol_string]; c[strand]++; }   // (a fresh entry is value-initialised to {0, 0})
             for (size_t i = 0; i < tlen; i++) if (cov_mut[i] & 0x2) {
                 for (int j = (int)i - (int)P.syserr_mut_region_n_bases; j < (int)(i + P.syserr_mut_region_n_bases + 1); j++)
                     if ((0 <= j) && (j < (int)tlen)) cov_mut[j] |= 0x4;
@@ -1108,6 +1111,7 @@ static int using_fq(State &S, std::string &err) {
                 cov_update_by_mmm(mmm, tmp);
             }
             if (will_inc_dscs) cov_update_by_filtering(dup, con, 1, 1, padded_del_ignored, false);   // <true,false,false>, main.hpp:3429-3432
+            State::MutForm pos_symbol_string, pos_symbol_string_confam;   // main.hpp:3434-3435
             for (i32 epos = mmm.beg; epos < mmm.end; epos++) {
                 const i64 x = epos - S.beg;
                 for (int vi = 0; vi < 2; vi++) {
@@ -1137,6 +1141,14 @@ static int using_fq(State &S, std::string &err) {
                     if (UVC_LINK_SYMBOL == st) confam_qual = max_(1, min_(indep_frag_phred, (i32)P.fam_phred_indel_inc_before_barcode_labeling + (i32)round(realphred)));
                     else confam_qual = max_(1, min_(indep_frag_phred, (con_sumBQs * 2) - tot_sumBQs));
                     const int ref_symbol = S.refsym[x];
+                    const bool is_var_of_highBQ = (proton ? (UVC_BASE_SYMBOL == st || max_(confam_qual + 3, avgBQ) >= P.bias_thres_highBQ)
+                                                          : (UVC_LINK_SYMBOL == st || confam_qual >= P.bias_thres_highBQ));   // main.hpp:3490-3505
+                    if (symbols_mutated(ref_symbol, con_symbol) && is_var_of_highBQ) {
+                        pos_symbol_string.push_back(std::make_pair(epos, con_symbol));
+                        int con_symbol1; i32 con_count1, tot_count1;
+                        fill_consensus(con.row(epos), con_symbol1, con_count1, tot_count1, st);
+                        if (con_symbol == con_symbol1 && P.fam_thres_dup1add <= tot_count1 && (con_count1 * 100 >= tot_count1 * P.fam_thres_dup1perc)) pos_symbol_string_confam.push_back(std::make_pair(epos, con_symbol));
+                    }
                     const i32 max_qual = sscs_phred(P, ref_symbol, con_symbol) + (!P.tumor_vcf_is_provided ? 0 : 4);
                     const i32 confam_qual2 = min_(confam_qual, max_qual);
                     if (tot_nfrags >= P.fam_thres_dup1add) {
@@ -1145,6 +1157,8 @@ static int using_fq(State &S, std::string &err) {
                     }
                 }
             }
+            if (pos_symbol_string.size() > 1) { auto &c = S.hapmap[1][pos_symbol_string]; c[strand]++; }               // main.hpp:3514-3517
+            if (pos_symbol_string_confam.size() > 1) { auto &c = S.hapmap[2][pos_symbol_string_confam]; c[strand]++; }   // main.hpp:3518-3521
         }
         if (will_inc_dscs) {
             for (i32 epos = dup.beg; epos < dup.end; epos++) for (int st = 0; st < 2; st++) {
@@ -1184,6 +1198,53 @@ static int using_fq(State &S, std::string &err) {
     return 0;
 }
 
+// updateHapMap, main.hpp:3596-3663.  (tsum_depth only lends its range to the per-position counter tsum_depth_2.)
+static void update_hap_map(State &S, int which) {
+    const UvcParams &P = S.P;
+    typedef std::tuple<i32, State::MutForm, std::array<i32, 2>> Row;
+    std::vector<Row> v;
+    for (const auto &it : S.hapmap[which]) v.push_back(Row(it.second[0] + it.second[1], it.first, it.second));
+    std::sort(v.rbegin(), v.rend());
+    const size_t num_dst = min_((size_t)P.phasing_haplotype_max_detail_cnt, v.size());
+    std::vector<i32> inc_fw(num_dst, 0), inc_rv(num_dst, 0);
+    for (size_t i = 0; i < num_dst; i++) {
+        const State::MutForm &dst = std::get<1>(v[i]);
+        for (size_t j = i + 1; j < v.size(); j++) {
+            const State::MutForm &src = std::get<1>(v[j]);
+            bool skipped = false;
+            for (const auto &al : dst) if (std::find(src.begin(), src.end(), al) == src.end()) { skipped = true; break; }
+            if (!skipped) { inc_fw[i] += std::get<2>(v[j])[0]; inc_rv[i] += std::get<2>(v[j])[1]; }
+        }
+    }
+    std::vector<i32> tsum((size_t)S.npos + 1, 0);
+    for (size_t i = 0; i < v.size(); i++) {
+        const State::MutForm &form = std::get<1>(v[i]);
+        const std::array<i32, 2> &cnt = std::get<2>(v[i]);
+        if ((cnt[0] + cnt[1]) < (P.phasing_haplotype_min_ad + (i32)form.size())) continue;
+        i32 haplo_totDP = 0;
+        for (const auto &sm : form) { tsum[(size_t)(sm.first - S.beg)] += 1; haplo_totDP += tsum[(size_t)(sm.first - S.beg)]; }
+        if ((i64)haplo_totDP > (i64)P.phasing_haplotype_max_count * (i64)form.size()) continue;
+        State::HapLink h; h.form = form; h.fr[0] = cnt[0]; h.fr[1] = cnt[1];
+        h.other[0] = (i >= num_dst ? -1 : inc_fw[i]); h.other[1] = (i >= num_dst ? -1 : inc_rv[i]);
+        S.haplinks[which].push_back(h);
+    }
+}
+// mutform2count4vec_to_simplemut2indices (main.cpp:82-97) + mutform2count4map_to_phase (main.hpp:5380-5404) for one (refpos, symbol)
+std::string hap_phase_string(const State &S, int which, i32 refpos, int symbol) {
+    static const char *const DESC[] = { "A", "C", "G", "T", "N", "*", "<LR>", "<LD3P>", "<LD2>", "<LD1>", "<LI3P>", "<LI2>", "<LI1>", "*" };
+    std::string out;
+    for (const State::HapLink &h : S.haplinks[which]) {
+        if (h.fr[0] + h.fr[1] < 2) continue;
+        if (std::find(h.form.begin(), h.form.end(), std::make_pair(refpos, symbol)) == h.form.end()) continue;
+        if (!((h.fr[0] + h.fr[1]) > 1)) continue;
+        out += "(";
+        for (const auto &ps : h.form) out += std::string("(") + std::to_string(ps.first + (ps.second <= UVC_BASE_NN ? 1 : 0)) + "&" + DESC[ps.second] + ")";
+        const std::string add = ((-1 < h.other[0]) ? ("&&" + std::to_string(h.other[0] + h.fr[0]) + "&" + std::to_string(h.other[1] + h.fr[1])) : std::string());
+        out += std::string("&") + std::to_string(h.fr[0]) + "&" + std::to_string(h.fr[1]) + add + ")";
+    }
+    return out;
+}
+
 // updateByRegion3Aln, main.hpp:3665-3742
 int accumulate(State &S, std::string &err) {
     if (S.alns.empty()) { err = "no reads"; return UVCGPU_ENOREADS; }
@@ -1197,10 +1258,12 @@ int accumulate(State &S, std::string &err) {
     zero32(S.duplex, (size_t)UVC_NDUPLEX * NSYM * S.npos);
     for (int s = 0; s < 2; s++) zero32(S.bucket[s], (size_t)NSYM * NBUCKETS * S.npos);
     for (int st = 0; st < 2; st++) { S.gap_frag[st].clear(); S.gap_fam[st].clear(); S.gap_c2[st].clear(); S.gap_c2d[st].clear(); }
+    for (int k = 0; k < 3; k++) { S.hapmap[k].clear(); S.haplinks[k].clear(); }
     build_side_arrays(S);   // rtr.indelphred is mutated by P1b, so rebuild on every accumulate
     int rc;
-    if (S.P.inferred_is_vcf_generated) { if ((rc = using_bq(S, err))) return rc; }
+    if (S.P.inferred_is_vcf_generated) { if ((rc = using_bq(S, err))) return rc; update_hap_map(S, 0); }
     if ((rc = using_fq(S, err))) return rc;
+    update_hap_map(S, 1); update_hap_map(S, 2);
     S.accumulated = true;
     return 0;
 }

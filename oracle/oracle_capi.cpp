@@ -226,6 +226,24 @@ int uvc_oracle_region_vcf(void *h, const UvcScoreRequest *req, const char *tname
     return 0;
 }
 
+// hap_bq / hap_fq / hap_f2q of updateByRegion3Aln, as uvcgpu_region_hap_links returns them
+int uvc_oracle_region_hap_links(void *h, UvcHapLink *links, int64_t link_capacity, int64_t *n_links, int32_t *muts, int64_t mut_capacity, int64_t *n_mut_ints) {
+    State &S = *(State *)h;
+    if (!S.accumulated) { g_err = "haplotype links before accumulate"; return UVCGPU_ESTATE; }
+    int64_t nl = 0, nm = 0;
+    for (int w = 0; w < 3; w++) for (const State::HapLink &l : S.haplinks[w]) { nl++; nm += 2 * (int64_t)l.form.size(); }
+    if (n_links) *n_links = nl;
+    if (n_mut_ints) *n_mut_ints = nm;
+    if (nl > link_capacity || nm > mut_capacity) { g_err = "haplotype link capacity too small"; return UVCGPU_ENOMEM; }
+    int64_t li = 0, mi = 0;
+    for (int w = 0; w < 3; w++) for (const State::HapLink &l : S.haplinks[w]) {
+        UvcHapLink &o = links[li++];
+        o.which = w; o.n_muts = (int32_t)l.form.size(); o.mut_off = mi; o.fr_cnt[0] = l.fr[0]; o.fr_cnt[1] = l.fr[1]; o.other_cnt[0] = l.other[0]; o.other_cnt[1] = l.other[1];
+        for (const auto &ps : l.form) { muts[mi++] = ps.first; muts[mi++] = ps.second; }
+    }
+    return 0;
+}
+
 void uvc_oracle_destroy(void *h) { delete (State *)h; }
 
 // ---- unit-test hooks for the math primitives (tests/test_oracle_math.py) ----

@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <map>
 #include <string>
 #include <vector>
@@ -124,6 +125,12 @@ struct State {
     // [strand]: symbol_to_frag_format_depth_sets / symbol_to_fam_format_depth_sets_2strand side maps (main.hpp:529-530),
     // pos2iseq2data_cDP2 / pos2dlen2data_cDP2, pos2iseq2data_c2dDP / pos2dlen2data_c2dDP (main.hpp:2380-2383)
     GapMaps gap_frag[2], gap_fam[2], gap_c2[2], gap_c2d[2];
+    // haplotype links (a12): the mutated (position, symbol) strings of fragments / families -> [forward, reverse] counts
+    // (mutform2count4map_bq / _fq / _f2q, main.hpp:3685-3687) and what updateHapMap makes of them (main.hpp:3596-3663)
+    typedef std::vector<std::pair<i32, int>> MutForm;
+    struct HapLink { MutForm form; i32 fr[2]; i32 other[2]; };
+    std::map<MutForm, std::array<i32, 2>> hapmap[3];     // 0 bq, 1 fq, 2 f2q
+    std::vector<HapLink> haplinks[3];
 
     // Internal storage is position-major (AoS, like the reference's std::vector<struct> per kind, main.hpp:523-604) so that
     // the per-read scatter touches one or two cache lines per position; fetch() transposes to the plane layout of uvcgpu.h.
@@ -149,6 +156,7 @@ struct State {
 void build_side_arrays(State &S);
 // accumulate passes
 int accumulate(State &S, std::string &err);
+std::string hap_phase_string(const State &S, int which, i32 refpos, int symbol);
 // InDel allele rows (fill_by_indel_info, instcode.hpp) in the order documented at UvcGapRow
 void indel_allele_rows(State &S, std::vector<UvcGapRow> &rows, std::vector<u8> &seq);
 // scoring

@@ -993,7 +993,7 @@ static void call_record(const UvcParams &P, Fmt &fmt, const Fmt &reffmt, const s
 // ---- VCF text of one written record: the string half of append_vcf_record (main.hpp:6050-6067, 6206-6270) and, for the sample column,
 // the field values of the bcfrec::BcfFormat it streams, as "TAG \t N \t v1 \x1f v2 ..." lines.  The test feeds those lines to the
 // REFERENCE's own streamAppendBcfFormat (oracle/ref_vcf_driver.cpp over the header its generator prints), so the layout of the sample
-// column is the reference's, not a restatement.  Not carried: bHap / cHap / c2Hap and note (left at the reference's defaults).
+// column is the reference's, not a restatement.  Not carried: note (left at the reference's default).
 static void vcf_emit(State &S, const Fmt &f, const Fmt &rf, const std::string &indelstring, const std::vector<UvcGapRow> &gap_rows, const std::vector<u8> &gap_seq, i32 zpos) {
     const UvcParams &P = S.P;
     const int symbol = f.symbol, refsymbol = f.refsymbol;
@@ -1124,6 +1124,7 @@ static void vcf_emit(State &S, const Fmt &f, const Fmt &rf, const std::string &i
         LV("gapNf", nf); LV("gapNr", nr); LS("gapSeq", seqs); LV("gapbAD1", b1); LV("gapcAD1", c1); LV("gc2AD", c2); LV("gc2dAD", c2d);
     }
     RR(bDPa); RR(cDP0a); LS("gapSa", { std::string(), indelstring });
+    LS("bHap", { hap_phase_string(S, 0, f.refpos, f.symbol) }); LS("cHap", { hap_phase_string(S, 1, f.refpos, f.symbol) }); LS("c2Hap", { hap_phase_string(S, 2, f.refpos, f.symbol) });   // main.hpp:4242-4244
     L("vHGQ", { f.vHGQ }); T2(vAC);
     if (st == UVC_BASE_SYMBOL) L("vNLODQ", { f.vNLODQ, 0 }); else L("vNLODQ", { 0, f.vNLODQ });
 #undef RR

@@ -329,3 +329,52 @@ def test_record_lines_of_a_sub_range_and_of_thin_data(gpu_lib):
     lines = Rt.vcf_records("c", rec).splitlines()
     assert all(len(l.split("\t")) == 10 for l in lines)
     assert sum(1 for l in lines if l.split("\t")[4] not in sym) == int(rec["keep"].sum())
+
+
+HAP_CASES = {
+    "dense_snvs_80x": dict(region_len=3000, depth=80, seed=5, snv_every=90, somatic_every=400, indel_every=350),
+    "dense_umi_300x": dict(region_len=2500, depth=300, seed=6, snv_every=90, somatic_every=400, indel_every=300, umi=True),
+    "dense_indels_120x": dict(region_len=2000, depth=120, seed=8, snv_every=150, somatic_every=0, indel_every=110),
+}
+
+
+def test_haplotype_links_on_the_oracle(oracle_lib):
+    """fragments / families that carry several high-quality mutations are linked (updateHapMap, main.hpp:3596-3663)."""
+    reads = synth.generate_region(**HAP_CASES["dense_umi_300x"])
+    R = run_region(oracle_lib, reads)
+    bq, fq, f2q = R.hap_links()
+    assert len(bq) > 20 and len(fq) > 10 and len(f2q) > 5
+    for links in (bq, fq, f2q):
+        for muts, fr, other in links:
+            assert len(muts) >= 2 and list(muts) == sorted(muts, key=lambda ps: (ps[0], 0 if ps[1] >= 6 else 1)) or len({p for p, _ in muts}) < len(muts)
+            assert fr[0] + fr[1] >= 1 + len(muts)                                  # phasing_haplotype_min_ad + size
+        assert sum(1 for l in links if l[2] != (-1, -1)) <= 3                      # phasing_haplotype_max_detail_cnt
+    # families are fewer than fragments: the de-duplicated counts do not exceed the raw ones for a link both have
+    raw = {l[0]: l[1] for l in bq}
+    assert any(l[0] in raw and sum(l[1]) <= sum(raw[l[0]]) for l in fq)
+    R.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(HAP_CASES))
+def test_haplotype_links_match_the_oracle(name, oracle_lib, gpu_lib, ref_vcf):
+    """bHap / cHap / c2Hap: the link vectors (uvcgpu_region_hap_links) equal the oracle's, and so do the strings of every written record."""
+    reads = synth.generate_region(**HAP_CASES[name])
+    Ro, Rg = run_region(oracle_lib, reads), run_region(gpu_lib, reads)
+    lo, lg = Ro.hap_links(), Rg.hap_links()
+    assert sum(len(l) for l in lo) > 10
+    for w in range(3):
+        assert lo[w] == lg[w], (w, next((a, b) for a, b in zip(lo[w] + [None], lg[w] + [None]) if a != b))
+    rg = Rg.score()
+    mine = Rg.vcf_records("chr20", rg).splitlines()
+    want = _oracle_lines(oracle_lib, ref_vcf, Ro, "chr20")
+    compare_lines(mine, want)
+    n_linked = 0
+    for l in mine:
+        c = l.split("\t")
+        if c[4].startswith("<N") or c[4].startswith("<ADD"):
+            continue
+        f = dict(zip(c[8].split(":"), c[9].split(":")))
+        n_linked += f["bHap"] != "."
+    assert n_linked >= 5
+    Ro.close(); Rg.close()

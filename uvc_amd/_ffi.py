@@ -58,6 +58,10 @@ class UvcGapRow(C.Structure):
                 ("bAD1", C.c_int32), ("cAD1", C.c_int32), ("c2AD", C.c_int32), ("c2dAD", C.c_int32)]
 
 
+class UvcHapLink(C.Structure):
+    _fields_ = [("which", C.c_int32), ("n_muts", C.c_int32), ("mut_off", C.c_int64), ("fr_cnt", C.c_int32 * 2), ("other_cnt", C.c_int32 * 2)]
+
+
 class UvcScoreRequest(C.Structure):
     _fields_ = [("pos_beg", C.c_int32), ("pos_end", C.c_int32), ("all_out", C.c_int32), ("is_amplicon", C.c_int32),
                 ("n_indel_alleles", C.c_int64), ("indel_alleles", C.c_void_p), ("n_tumor_keys", C.c_int64), ("tumor_keys", C.c_void_p),

@@ -44,6 +44,8 @@ struct AlnRec {
     int32_t m_index;                    // cigar index of the M op (simple)
     int32_t frag, fs;                   // owning fragment / family-strand unit
     int32_t id;                         // index in RegionDev::alns
+    int32_t n_mutc;                     // bases that differ from the reference + I / D ops: an upper bound of the mutated (position, symbol) pairs the
+                                        // alignment can add to a haplotype string (k_hap_*)
     int64_t baq_pos, baq_last, baq2_last;   // baq[pos], baq[rend-1], baq2[rend-1] (region constants, main.hpp:1394-1396)
 };
 
@@ -122,6 +124,10 @@ struct GapWork {
 
 // contribution of one alignment at one reference position under BASE_QUALITY_MAX (main.hpp:1980, 1924, 2077, 2192, 2223)
 struct Contrib { uint8_t bsym, bval, l1sym, l1val, l2sym, l2val, l3sym, l3val; };   // sym == 0xFF: empty slot
+
+// haplotype links: the candidates (fragments / family-strand units with at least two possible mutations), where each one's
+// events go in the event buffer, and the buffer.  An event list: [strand | kind << 1, count, (x << 4 | symbol) ...], kind 0 bq, 1 fq, 2 f2q.
+struct HapWork { int32_t *cand, *cand_off, *cand_cap; int32_t *n_cand; unsigned long long *total; int32_t *events; };
 
 struct DevParams { UvcParams P; };
 

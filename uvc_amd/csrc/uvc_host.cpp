@@ -4,6 +4,7 @@
 #include "uvc_device.h"
 #include "uvc_alloc.h"
 #include "uvc_prep.h"
+#include "uvc_hap.h"
 
 #include <algorithm>
 #include <chrono>
@@ -35,6 +36,8 @@ extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const Uv
 extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored);
 extern "C" void uvc_launch_block_stats(const RegionDev *R, const UvcParams *P, int64_t x0, int64_t n, int32_t *d_out, hipStream_t s);
 extern "C" size_t uvc_gap_sort_tmp_bytes(size_t n);
+extern "C" void uvc_launch_hap_cand(const RegionDev *R, const HapWork *H, int units, hipStream_t s);
+extern "C" void uvc_launch_hap_events(const RegionDev *R, const UvcParams *P, const HapWork *H, int units, int n_cand, hipStream_t s);
 extern "C" void uvc_launch_gather_columns(const char *const *base, const int32_t *first_col, const int32_t *elem, int64_t npos, const int32_t *d_xs, int64_t n, long long *d_out, hipStream_t s);
 extern "C" int uvc_sort_by_pos_cls(const int32_t *d_pos, const int32_t *d_cls, int32_t beg, int shift, int64_t n, uint32_t *work, void *tmp, size_t tmp_bytes, hipStream_t s);
 extern "C" size_t uvc_sort32_tmp_bytes(size_t n);
@@ -79,6 +82,9 @@ struct uvcgpu_region {
     std::vector<UvcIndelAllele> gap_alleles; std::vector<int32_t> gap_allele_row;   // what indel_get_majority yields, sorted by (refpos, symbol)
     UvcIndelAllele *d_gap_alleles = nullptr; int32_t *d_gap_allele_row = nullptr; int64_t gap_alleles_cap = 0;
     UvcGapRow *d_gap_rows = nullptr; int64_t gap_rows_cap = 0; uint8_t *d_gap_seq = nullptr; int64_t gap_seq_cap = 0;   // device copies for k_call
+    // haplotype links of the last accumulate (built on first use by hap_tables): hap_bq, hap_fq, hap_f2q of updateByRegion3Aln
+    bool hap_ready = false;
+    std::vector<UvcHapLinkHost> hap[3];
 };
 
 static size_t group_bytes(const uvcgpu_region *r, int g) {
@@ -262,7 +268,7 @@ void uvcgpu_params_apply_platform(UvcParams *p, int32_t platform, int32_t centra
 static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t end, const char *refseq) {
     r->tid = tid; r->beg = beg; r->end = end + 1; r->npos = (int64_t)end - beg + 1;
     r->refstring.assign(refseq, (size_t)(end - beg));
-    r->accumulated = false; r->gap_ready = false; r->buckets_clean = false; r->state_released = false; r->state_zeroed = false;
+    r->accumulated = false; r->gap_ready = false; r->hap_ready = false; r->buckets_clean = false; r->state_released = false; r->state_zeroed = false;
     std::vector<Track> tr; std::vector<int64_t> baq;
     build_tracks(r->refstring, r->P, tr, baq);
     std::vector<uint8_t> refsym((size_t)r->npos + 1, 0);
@@ -535,7 +541,7 @@ int uvcgpu_region_accumulate(uvcgpu_region_t *r) {
     uvc_launch_accumulate(&r->R, &r->P, half, r->d_dup_units, r->n_dup, r->d_dup_off, r->n_dup_work, r->stream, &r->prof, r->side, r->e_fork, r->e_join, r->e_fork2);
     HIP_OK(hipGetLastError());
     r->buckets_clean = (r->P.inferred_is_vcf_generated != 0);   // k_frag (P3b) and k_p5b cleared every bucket they consumed
-    r->accumulated = true; r->gap_ready = false;
+    r->accumulated = true; r->gap_ready = false; r->hap_ready = false;
     return 0;
 }
 
@@ -784,6 +790,68 @@ int uvcgpu_region_indel_alleles(uvcgpu_region_t *r, UvcGapRow *rows, int64_t row
     if ((int64_t)r->gap_rows.size() > row_capacity || (int64_t)r->gap_seq.size() > seq_capacity) return fail(UVCGPU_ENOMEM, "allele table capacity too small");
     if (!r->gap_rows.empty()) memcpy(rows, r->gap_rows.data(), r->gap_rows.size() * sizeof(UvcGapRow));
     if (!r->gap_seq.empty()) memcpy(seq, r->gap_seq.data(), r->gap_seq.size());
+    return 0;
+}
+
+// ---- haplotype links: hap_bq / hap_fq / hap_f2q of updateByRegion3Aln (main.hpp:3665-3742) ----
+// Built on request (the record writer and uvcgpu_region_hap_links ask): candidate fragments / units -> their mutated (position, symbol)
+// lists on the device (k_hap_*), maps + updateHapMap on the host (uvc_hap.cpp).  Needs the planes (P5's cDPM / cDPm).
+static int hap_tables(uvcgpu_region_t *r) {
+    if (r->hap_ready) return 0;
+    if (!r->accumulated) return fail(UVCGPU_ESTATE, "haplotype links before accumulate");
+    if (r->state_released) return fail(UVCGPU_ESTATE, "the planes were released by the last score (UvcScoreRequest::release_state)");
+    const RegionDev &R = r->R;
+    std::vector<int32_t> events;
+    struct Tmp { std::vector<void *> p; hipStream_t s; ~Tmp() { (void)hipStreamSynchronize(s); for (void *q : p) hipFree(q); } } tmp; tmp.s = r->stream;
+    auto get = [&](size_t bytes) -> void * { void *q = nullptr; if (hipMalloc(&q, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr; tmp.p.push_back(q); return q; };
+    for (int units = 0; units < 2; units++) {
+        if (!units && !r->P.inferred_is_vcf_generated) continue;   // P3 belongs to updateByAlns3UsingBQ (main.hpp:3691)
+        const size_t n = (size_t)(units ? R.n_fs : R.n_frags);
+        if (n == 0) continue;
+        HapWork H; memset(&H, 0, sizeof(H));
+        H.cand = (int32_t *)get(4 * n); H.cand_off = (int32_t *)get(4 * n); H.cand_cap = (int32_t *)get(4 * n);
+        char *ctr = (char *)get(16);
+        if (!H.cand || !H.cand_off || !H.cand_cap || !ctr) return fail(UVCGPU_ENOMEM, "hipMalloc(haplotype candidates)");
+        H.n_cand = (int32_t *)ctr; H.total = (unsigned long long *)(ctr + 8);
+        HIP_OK(hipMemsetAsync(ctr, 0, 16, r->stream));
+        uvc_launch_hap_cand(&R, &H, units, r->stream);
+        struct { int32_t n_cand, pad; unsigned long long total; } c;
+        HIP_OK(hipMemcpyAsync(&c, ctr, 16, hipMemcpyDeviceToHost, r->stream));
+        HIP_OK(hipStreamSynchronize(r->stream));
+        if (c.n_cand == 0) continue;
+        if (c.total >= ((unsigned long long)1 << 31)) return fail(UVCGPU_EUNSUPPORTED, "more than 2^31 haplotype event slots in one region");
+        H.events = (int32_t *)get(4 * (size_t)c.total);
+        if (!H.events) return fail(UVCGPU_ENOMEM, "hipMalloc(haplotype events)");
+        HIP_OK(hipMemsetAsync(H.events, 0xFF, 4 * (size_t)c.total, r->stream));
+        uvc_launch_hap_events(&R, &r->P, &H, units, c.n_cand, r->stream);
+        HIP_OK(hipGetLastError());
+        const size_t at = events.size();
+        events.resize(at + (size_t)c.total);
+        HIP_OK(hipMemcpyAsync(events.data() + at, H.events, 4 * (size_t)c.total, hipMemcpyDeviceToHost, r->stream));
+        HIP_OK(hipStreamSynchronize(r->stream));
+    }
+    { const int rc = uvcgpu_region_sync(r); if (rc) return rc; }
+    uvc_hap_build(events.data(), (int64_t)events.size(), r->beg, r->npos, r->P.phasing_haplotype_max_count, r->P.phasing_haplotype_min_ad, r->P.phasing_haplotype_max_detail_cnt, r->hap);
+    r->hap_ready = true;
+    return 0;
+}
+const std::vector<UvcHapLinkHost> *uvcgpu_region_hap_(uvcgpu_region_t *r) { return hap_tables(r) ? nullptr : r->hap; }   // for uvc_vcf.cpp
+
+int uvcgpu_region_hap_links(uvcgpu_region_t *r, UvcHapLink *links, int64_t link_capacity, int64_t *n_links, int32_t *muts, int64_t mut_capacity, int64_t *n_mut_ints) {
+    if (!r) return fail(UVCGPU_EINVAL, "null region");
+    int rc = hap_tables(r);
+    if (rc) return rc;
+    int64_t nl = 0, nm = 0;
+    for (int w = 0; w < 3; w++) for (const UvcHapLinkHost &h : r->hap[w]) { nl++; nm += 2 * (int64_t)h.form.size(); }
+    if (n_links) *n_links = nl;
+    if (n_mut_ints) *n_mut_ints = nm;
+    if (nl > link_capacity || nm > mut_capacity || (nl && !links) || (nm && !muts)) return fail(UVCGPU_ENOMEM, "haplotype link capacity too small");
+    int64_t li = 0, mi = 0;
+    for (int w = 0; w < 3; w++) for (const UvcHapLinkHost &h : r->hap[w]) {
+        UvcHapLink &o = links[li++];
+        o.which = w; o.n_muts = (int32_t)h.form.size(); o.mut_off = mi; o.fr_cnt[0] = h.fr[0]; o.fr_cnt[1] = h.fr[1]; o.other_cnt[0] = h.other[0]; o.other_cnt[1] = h.other[1];
+        for (const auto &ps : h.form) { muts[mi++] = ps.first; muts[mi++] = ps.second; }
+    }
     return 0;
 }
 

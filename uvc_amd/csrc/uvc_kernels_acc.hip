@@ -480,6 +480,8 @@ DEV int aln_prelude_one(const RegionDev &R, const RawReads &W, const UvcParams &
     R.alns[id] = a;
     const int rk = W.fast_rank[id];
     int n_mis = 0;
+    a.n_mutc = bm[0] + bm[1] + bm[2] + bm[3] + bm[4] + ngo;
+    R.alns[id].n_mutc = a.n_mutc;
     if (rk >= 0 || W.kind[id] == 2) n_mis = bm[0] + bm[1] + bm[2] + bm[3] + bm[4];   // every alignment that can be on the P2 work list: its mismatching bases go through the mismatch queue
     if (rk >= 0) {
         R.fast[rk] = a;
@@ -2843,6 +2845,130 @@ __global__ void __launch_bounds__(256) k_gap_rows(RegionDev R) {
         R.gap.rows[atomicAdd(R.gap.n_rows, 1)] = row;
         if (!hashed) break;   // exact codes: the whole run is one row
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Haplotype links.  The reference strings together, per fragment (P3) and per family-strand unit (P5), the positions whose
+// consensus symbol is a high-quality mutation (main.hpp:2720-2737, 3490-3521) and counts equal strings per strand
+// (mutform2count4map_bq / _fq / _f2q); updateHapMap (main.hpp:3596-3663) turns the maps into the links FORMAT/bHap, cHap, c2Hap print.
+// Only objects with at least two such positions matter, and an object cannot have more of them than its alignments have mismatching
+// bases + InDel ops (AlnRec::n_mutc).  So: pick the candidates, reserve their slots, then one wave per candidate re-derives its consensus
+// along its span (the generic per-position forms: this is O(candidates), off the accumulate path, run when the links are asked for).
+// The maps, the sort and the link arithmetic are host work on a few thousand short lists (uvc_hap.cpp).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_hap_cand(RegionDev R, HapWork H, int units) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = units ? R.n_fs : R.n_frags;
+    if (i >= n) return;
+    int a0, a1;
+    if (units) { const FsRec &u = R.fss[i]; a0 = R.frags[u.frag_beg].aln_beg; a1 = R.frags[u.frag_end - 1].aln_end; }
+    else { a0 = R.frags[i].aln_beg; a1 = R.frags[i].aln_end; }
+    int bound = 0;
+    for (int k = a0; k < a1; k++) bound += R.alns[k].n_mutc;
+    if (bound < 2) return;
+    const int span = units ? (R.fss[i].end - R.fss[i].beg) : (R.frags[i].end - R.frags[i].beg);
+    bound = imin(bound, 2 * span);
+    const int slot = atomicAdd(H.n_cand, 1);
+    H.cand[slot] = i; H.cand_cap[slot] = bound;
+    H.cand_off[slot] = (int)atomicAdd(H.total, (unsigned long long)((units ? 2 : 1) * (bound + 2)));
+}
+// appends this lane's (up to two) events in lane order behind `count` events already written; LINK before BASE at one position
+DEV int hap_append(int32_t *dst, int cap, int count, bool evL, int vL, bool evB, int vB, int lane, int32_t *err) {
+    const unsigned long long mL = __ballot(evL), mB = __ballot(evB), below = (lane == 0 ? 0ull : (~0ull >> (64 - lane)));
+    const int at = count + __popcll(mL & below) + __popcll(mB & below);
+    if (evL) { if (at < cap) dst[2 + at] = vL; else atomicExch(err, UVCGPU_EDEVICE); }
+    if (evB) { const int a2 = at + (evL ? 1 : 0); if (a2 < cap) dst[2 + a2] = vB; else atomicExch(err, UVCGPU_EDEVICE); }
+    return count + __popcll(mL) + __popcll(mB);
+}
+__global__ void __launch_bounds__(64) k_hap_frags(RegionDev R, UvcParams P, HapWork H, int n_cand) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= n_cand) return;
+    const int fi = H.cand[t];
+    const FragRec &f = R.frags[fi];
+    int32_t *dst = H.events + H.cand_off[t];
+    const int cap = H.cand_cap[t];
+    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    int count = 0;
+    int cnt[NSYM];
+    for (int i0 = 0; i0 < f.end - f.beg; i0 += 64) {
+        const int p = f.beg + i0 + lane;
+        bool ev[2] = { false, false }; int val[2] = { 0, 0 };
+        if (p < f.end) {
+            frag_counts(R, P, f, p, proton, cnt);
+            const int refsymbol = R.refsym[p - R.beg];
+            for (int vi = 0; vi < 2; vi++) {   // SYMBOL_TYPES_IN_VCF_ORDER: LINK, then BASE
+                const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
+                int cs, cc, ct;
+                fill_consensus(cnt, cs, cc, ct, st, st == UVC_LINK_SYMBOL, false);
+                if (0 == ct) continue;
+                const int con_qual = cc * 2 - ct;
+                const bool highBQ = (proton ? (UVC_BASE_SYMBOL == st || con_qual + 3 >= P.bias_thres_highBQ) : (UVC_LINK_SYMBOL == st || con_qual >= P.bias_thres_highBQ));
+                if (symbols_mutated(refsymbol, cs) && highBQ) { ev[vi] = true; val[vi] = ((p - R.beg) << 4) | cs; }
+            }
+        }
+        count = hap_append(dst, cap, count, ev[0], val[0], ev[1], val[1], lane, R.err);
+    }
+    if (lane == 0) { dst[0] = f.strand | (cap << 8); dst[1] = imin(count, cap); }   // kind 0 (bq); the slot length lets the host walk the buffer
+}
+__global__ void __launch_bounds__(64) k_hap_units(RegionDev R, UvcParams P, HapWork H, int n_cand) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= n_cand) return;
+    const FsRec u = R.fss[H.cand[t]];
+    const int cap = H.cand_cap[t];
+    int32_t *dst1 = H.events + H.cand_off[t], *dst2 = dst1 + cap + 2;   // fq, f2q
+    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    const int strand = u.strand;
+    __shared__ int con_s[NSYM][64], mmm_s[NSYM][64];
+    const LdsCounts<64> con = { &con_s[0][lane] }, mmm = { &mmm_s[0][lane] };
+    int count1 = 0, count2 = 0;
+    for (int i0 = 0; i0 < u.end - u.beg; i0 += 64) {
+        const int p = u.beg + i0 + lane;
+        bool ev1[2] = { false, false }, ev2[2] = { false, false }; int val[2] = { 0, 0 };
+        if (p < u.end) {
+            const int64_t x = p - R.beg;
+            unit_counts<true>(R, P, u, p, proton, con, mmm);
+            for (int vi = 0; vi < 2; vi++) {
+                const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
+                int cs, con_sumBQs, tot_sumBQs;
+                fill_consensus(mmm, cs, con_sumBQs, tot_sumBQs, st, false, false);
+                if (0 == tot_sumBQs) continue;
+                const int con_nfrags = con[cs];
+                int tot_nfrags = 0;
+                const int sb = (st == 0 ? UVC_BASE_A : UVC_LINK_M), se = (st == 0 ? UVC_BASE_NN : UVC_LINK_NN);
+                for (int s2 = sb; s2 <= se; s2++) tot_nfrags += con[s2];
+                // the empirical family quality of P5 (main.hpp:3472-3488), as in k_fam_p5
+                const int avgBQ = ((0 == tot_nfrags) ? 1 : (con_sumBQs / tot_nfrags));
+                const int majorcount = FAP(R, strand, UVC_FAM_cDPM, cs, x), minorcount = FAP(R, strand, UVC_FAM_cDPm, cs, x);
+                const double prior_weight = 1.0 / (minorcount + 1.0);
+                const double p2p = pow(10.0, (double)(-((float)avgBQ) / 10));
+                const double prob = (minorcount + prior_weight) / (majorcount + minorcount + prior_weight / p2p);
+                const double realphred = -10 * log(prob) / log(10.0);
+                const int indep_frag_phred = (int)round(((con_nfrags * 2) - tot_nfrags) * realphred);
+                int confam_qual;
+                if (UVC_LINK_SYMBOL == st) confam_qual = imax(1, imin(indep_frag_phred, P.fam_phred_indel_inc_before_barcode_labeling + (int)round(realphred)));
+                else confam_qual = imax(1, imin(indep_frag_phred, (con_sumBQs * 2) - tot_sumBQs));
+                const bool highBQ = (proton ? (UVC_BASE_SYMBOL == st || imax(confam_qual + 3, avgBQ) >= P.bias_thres_highBQ) : (UVC_LINK_SYMBOL == st || confam_qual >= P.bias_thres_highBQ));
+                if (symbols_mutated(R.refsym[x], cs) && highBQ) {
+                    ev1[vi] = true; val[vi] = ((int)x << 4) | cs;
+                    int cs1, cc1, ct1;
+                    fill_consensus(con, cs1, cc1, ct1, st, false, false);
+                    if (cs == cs1 && P.fam_thres_dup1add <= ct1 && (cc1 * 100 >= ct1 * P.fam_thres_dup1perc)) ev2[vi] = true;
+                }
+            }
+        }
+        count1 = hap_append(dst1, cap, count1, ev1[0], val[0], ev1[1], val[1], lane, R.err);
+        count2 = hap_append(dst2, cap, count2, ev2[0], val[0], ev2[1], val[1], lane, R.err);
+    }
+    if (lane == 0) { dst1[0] = strand | (1 << 1) | (cap << 8); dst1[1] = imin(count1, cap); dst2[0] = strand | (2 << 1) | (cap << 8); dst2[1] = imin(count2, cap); }
+}
+extern "C" void uvc_launch_hap_cand(const RegionDev *R, const HapWork *H, int units, hipStream_t s) {
+    const int n = units ? R->n_fs : R->n_frags;
+    if (n > 0) hipLaunchKernelGGL(k_hap_cand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, *R, *H, units);
+}
+extern "C" void uvc_launch_hap_events(const RegionDev *R, const UvcParams *P, const HapWork *H, int units, int n_cand, hipStream_t s) {
+    if (n_cand <= 0) return;
+    if (units) hipLaunchKernelGGL(k_hap_units, dim3((unsigned)n_cand), dim3(64), 0, s, *R, *P, *H, n_cand);
+    else hipLaunchKernelGGL(k_hap_frags, dim3((unsigned)n_cand), dim3(64), 0, s, *R, *P, *H, n_cand);
 }
 
 extern "C" int uvc_gap_sort(void *tmp, size_t tmp_bytes, const unsigned long long *kin, unsigned long long *kout, const unsigned long long *vin, unsigned long long *vout,

@@ -3,6 +3,7 @@
 // the score records (uvcgpu_region_score), the plane columns of the positions that are written (uvcgpu_region_fetch_columns, one small
 // gather kernel) and the InDel allele rows (uvcgpu_region_indel_alleles).  O(emitted records); nothing here is on the hot path.
 #include "uvcgpu.h"
+#include "uvc_hap.h"
 
 #include <algorithm>
 #include <cmath>
@@ -14,6 +15,7 @@
 extern "C" const char *uvcgpu_region_refseq(const uvcgpu_region_t *r, int32_t *beg, int32_t *end);   // uvc_host.cpp
 extern "C" const int32_t *uvcgpu_region_repeat_tracks(const uvcgpu_region_t *r, int64_t *npos);    // host copy, [UVC_NRTR][npos]
 extern "C" const UvcParams *uvcgpu_region_params(const uvcgpu_region_t *r);
+extern "C" const std::vector<UvcHapLinkHost> *uvcgpu_region_hap_(uvcgpu_region_t *r);   // the three link vectors (uvc_host.cpp), NULL on error
 extern "C" int uvcgpu_fail_(int code, const char *msg);
 extern "C" int uvcgpu_region_block_stats_(uvcgpu_region_t *r, int32_t refpos_beg, int32_t refpos_end, int32_t *dst);   // 10 ints per position, k_block_stats
 
@@ -461,6 +463,8 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
         kept.push_back(i); refrec.push_back(found);
     }
     std::vector<std::pair<int32_t, std::string>> rec_lines;   // (zerobased_pos of the iteration that writes it, line)
+    const std::vector<UvcHapLinkHost> *hap = nullptr;
+    if (!kept.empty()) { hap = uvcgpu_region_hap_(r); if (!hap) return UVCGPU_EDEVICE; }
     if (!kept.empty()) {
         const int32_t ncol = uvcgpu_region_n_columns();
         std::vector<int32_t> where(kept.size());
@@ -588,7 +592,11 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
                     if (nm == "GT") out += "./1";
                     else if (nm == "GQ") out += "0";
                     else if (nm == "HQ") out += "0,0";
-                    else if (nm == "FT" || nm == "bHap" || nm == "cHap" || nm == "c2Hap" || nm == "note") out += ".";
+                    else if (nm == "bHap" || nm == "cHap" || nm == "c2Hap") {   // main.hpp:4242-4244
+                        const std::string ph = uvc_hap_phase_string(hap[nm == "bHap" ? 0 : nm == "cHap" ? 1 : 2], refpos, symbol);
+                        out += (ph.empty() ? std::string(".") : ph);
+                    }
+                    else if (nm == "FT" || nm == "note") out += ".";
                     else if (nm == "FTS") {
                         // fmt_bias_push appends "<name>-<round(100 * biasFA / refFA)>" for each bias that fired
                         const uint32_t bits = (uint32_t)F(ia, UVC_O_FTS);

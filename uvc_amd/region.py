@@ -261,6 +261,26 @@ class Region:
             req.tumor_ref_alt = C.cast(ras, C.c_void_p)
         return req, (arr, tk, cols, ras)
 
+    def hap_links(self):
+        """hap_bq / hap_fq / hap_f2q of updateByRegion3Aln (uvcgpu_region_hap_links): three lists of (mutations, (fwd, rev), (other fwd, other rev))
+        with mutations = ((refpos, symbol), ...)."""
+        fn = getattr(self.lib.dll, self.lib.prefix + "region_hap_links")
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        n, m = C.c_int64(0), C.c_int64(0)
+        rc = fn(self.h, None, 0, C.byref(n), None, 0, C.byref(m))
+        if rc not in (0, -6):
+            self._check(rc)
+        links = (_ffi.UvcHapLink * max(1, n.value))()
+        muts = np.zeros(max(1, m.value), dtype=np.int32)
+        self._check(fn(self.h, links, n.value, C.byref(n), muts.ctypes.data, m.value, C.byref(m)))
+        out = [[], [], []]
+        for i in range(n.value):
+            l = links[i]
+            pairs = tuple((int(muts[l.mut_off + 2 * k]), int(muts[l.mut_off + 2 * k + 1])) for k in range(l.n_muts))
+            out[l.which].append((pairs, (l.fr_cnt[0], l.fr_cnt[1]), (l.other_cnt[0], l.other_cnt[1])))
+        return out
+
     def score(self, all_out=False, pos_beg=-1, pos_end=-1, is_amplicon=False, indel_alleles=None, capacity=None, copy=True, tumor_keys=None, release_state=False, base_at_pos_beg=False, region_beg=0):
         req, _keep = self.make_request(all_out, pos_beg, pos_end, is_amplicon, indel_alleles, tumor_keys, release_state, base_at_pos_beg, region_beg)
         if capacity is None:
