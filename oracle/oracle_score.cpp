@@ -1330,6 +1330,55 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
             i64 rec0 = (i64)records.size();
             for (int t = 0; t < st; t++) if (!(zpos == pos_beg && UVC_BASE_SYMBOL == t && !base_at_beg)) rec0 += (i64)fmts[t].size();
             call_germline(P, st_refsymbol[st], fmts[st], rec0);
+            if (S.vcf_sink && fmts[st][0].germ_emit) {   // the GERMLINE line of output_germline (main.hpp:5612-5775)
+                static const char *const DESC[] = { "A", "C", "G", "T", "N", "*", "<LR>", "<LD3P>", "<LD2>", "<LD1>", "<LI3P>", "<LI2>", "<LI1>", "*", "<NONE>" };
+                static const char *const GT4[4] = { "0/0", "0/1", "1/1", "1/2" };
+                const Fmt &f0 = fmts[st][0];
+                const bool subst = (UVC_BASE_SYMBOL == st);
+                const int rel[3] = { f0.g_ref_rel, f0.g_alt1_rel, f0.g_alt2_rel };
+                auto sym_of = [&](int q) { return rel[q] >= 0 ? fmts[st][(size_t)rel[q]].symbol : (int)SYM_END; };
+                auto cdp0a = [&](int q) { return rel[q] >= 0 ? fmts[st][(size_t)rel[q]].cDP0a : 0; };
+                auto allele_text = [&](int symbol, int q) -> std::string {
+                    int seen = 0;
+                    for (size_t j = 0; j < fmts[st].size(); j++) if (fmts[st][j].symbol == symbol) { if (seen++ == q) return texts[st][j].empty() ? std::string(DESC[symbol]) : texts[st][j]; }
+                    return std::string();
+                };
+                const i32 regionpos = refpos - ext_beg;
+                const int s0 = sym_of(0), s1 = sym_of(1), s2 = sym_of(2), GLidx = f0.germ_GT;
+                std::string vref, valt;
+                if (subst) { vref = DESC[s0]; valt = DESC[s1]; if (3 == GLidx) valt += std::string(",") + DESC[s2]; }
+                else {
+                    const std::string vref1 = (regionpos > 0 ? S.refstring.substr((size_t)regionpos - 1, 1) : std::string("n"));
+                    const std::string str1 = (s1 < (int)SYM_END ? allele_text(s1, 0) : std::string());
+                    vref = vref1;
+                    if (3 != GLidx) {
+                        if (str1.empty() || str1[0] == '<') valt = DESC[s1];
+                        else { valt = vref; if (is_ins(s1)) valt += str1; else if (is_del(s1)) vref += str1; else valt = DESC[s1]; }
+                    } else {
+                        const std::string str2 = (s2 < (int)SYM_END ? allele_text(s2, s2 == s1 ? 1 : 0) : std::string());
+                        valt = vref1;
+                        if (str1.empty() || str1[0] == '<' || str2.empty() || str2[0] == '<') valt = std::string(DESC[s1]) + "," + DESC[s2];
+                        else if (is_ins(s1) && is_ins(s2)) valt = vref1 + str1 + "," + vref1 + str2;
+                        else if (is_del(s1) && is_del(s2)) {
+                            if (str1.size() > str2.size()) { vref = vref1 + str1; valt = vref1 + "," + vref1 + str1.substr(str2.size()); }
+                            else { vref = vref1 + str2; valt = vref1 + str2.substr(str1.size()) + "," + vref1; }
+                        }
+                        else if (is_ins(s1) && is_del(s2)) { valt = vref1 + str1 + str2 + "," + vref1; vref = vref1 + str2; }
+                        else if (is_del(s1) && is_ins(s2)) { valt = vref1 + "," + vref1 + str2 + str1; vref = vref1 + str1; }
+                        else valt = std::string(DESC[s1]) + "," + DESC[s2];
+                    }
+                }
+                const int nn = (subst ? UVC_BASE_NN : UVC_LINK_NN);
+                const i64 x = refpos - S.beg;
+                std::string l = S.vcf_sink->tname + "\t" + std::to_string(refpos + (subst ? 1 : 0)) + "\t.\t" + vref + "\t" + valt + "\t" + std::to_string(f0.germ_GQ) + "\tPASS\tGERMLINE\tGT:GQ:HQ:FT:CDP1:cDP1:GL4:GST:note\t"
+                    + GT4[GLidx] + ":" + std::to_string(f0.germ_GQ) + ":0,0:PASS:" + std::to_string(f0.DP) + "," + std::to_string(2 * S.FA(0, UVC_FAM_cDP1, nn, x)) + ":"
+                    + std::to_string(cdp0a(0)) + "," + std::to_string(cdp0a(1)) + (3 == GLidx ? "," + std::to_string(cdp0a(2)) : std::string()) + ":";
+                for (int q = 0; q < 4; q++) l += (q ? "," : "") + std::to_string(f0.GL4[q]);
+                l += ":";
+                for (int q = 0; q < 8; q++) l += (q ? "," : "") + std::to_string(f0.GST[q]);
+                l += ":";
+                S.vcf_sink->fixed.push_back(l); S.vcf_sink->spec.push_back(std::string()); S.vcf_sink->tier2.push_back(-1);
+            }
         }
         const bool is_germline_var_generated = ((!fmts[0].empty() && fmts[0][0].germ_emit) || (!fmts[1].empty() && fmts[1][0].germ_emit));
         for (int st = 0; st < 2; st++) {   // main.cpp:1073-1168

@@ -90,7 +90,7 @@ def test_header_lines_match_reference_ids_numbers_types(ref_vcf, product_dll):
 
 # ---- GPU: record lines ----
 PHRED_TAGS = {"aBQ", "a2BQf", "a2BQr", "aBQQ", "bMQ", "aAaMQ", "bNMQ", "bNMa", "bNMb", "bMQQ", "bIAQ", "cIAQ", "bTINQ", "cTINQ", "cPCQ1", "cPLQ1", "cVQ1", "gVQ1",
-              "cPCQ2", "cPLQ2", "cVQ2", "cMmQ", "dVQinc", "CONTQ", "nPF", "nNFA", "nAFA", "nBCFA", "cVQ1M", "cVQ2M", "vHGQ", "vNLODQ"}
+              "cPCQ2", "cPLQ2", "cVQ2", "cMmQ", "dVQinc", "CONTQ", "nPF", "nNFA", "nAFA", "nBCFA", "cVQ1M", "cVQ2M", "vHGQ", "vNLODQ", "GQ", "GL4", "GST"}
 PCT_TAGS = {"cDP1v", "CDP1v", "cDP1w", "CDP1w", "cDP1x", "CDP1x", "cDP2v", "CDP2v", "cDP2w", "CDP2w", "cDP2x", "CDP2x"}
 PHRED_INFO = {"SomaticQ", "TLODQ", "NLODQ", "TNBQF", "TNCQF"}
 
@@ -377,4 +377,29 @@ def test_haplotype_links_match_the_oracle(name, oracle_lib, gpu_lib, ref_vcf):
         f = dict(zip(c[8].split(":"), c[9].split(":")))
         n_linked += f["bHap"] != "."
     assert n_linked >= 5
+    Ro.close(); Rg.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["config1_10kb_30x", "dense_indels_120x"])
+def test_germline_lines(name, oracle_lib, gpu_lib, ref_vcf):
+    """OUTVAR_GERMLINE (--outvar-flag bit 1): the GERMLINE lines of output_germline (main.hpp:5612-5775) -- genotype, GQ, the REF / ALT text
+    of one or two alternative alleles (two InDel alleles share the longer REF), CDP1, the allele depths, GL4 and GST -- in front of the
+    records of their position."""
+    kw = dict(CASES, **HAP_CASES)[name]
+    reads = synth.generate_region(**kw)
+    out = []
+    for lib in (oracle_lib, gpu_lib):
+        p = region.default_params(lib)
+        p.outvar_flag = 63
+        out.append(run_region(lib, reads, params=p))
+    Ro, Rg = out
+    rg = Rg.score()
+    mine = Rg.vcf_records("chr20", rg).splitlines()
+    want = _oracle_lines(oracle_lib, ref_vcf, Ro, "chr20")
+    germ = [l.split("\t") for l in want if l.split("\t")[7] == "GERMLINE"]
+    assert len(germ) >= 5 and {c[9].split(":")[0] for c in germ} >= {"0/1"} and all(c[8] == "GT:GQ:HQ:FT:CDP1:cDP1:GL4:GST:note" for c in germ)
+    if name == "dense_indels_120x":
+        assert any(len(c[3]) != len(c[4].split(",")[0]) for c in germ)       # an InDel genotype with its REF / ALT text
+    compare_lines(mine, want)
     Ro.close(); Rg.close()

@@ -638,6 +638,92 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
             rec_lines.emplace_back(F(ia, UVC_O_refpos) + (is_base(F(ia, UVC_O_symbol)) ? 1 : 0), std::move(out));
         }
     }
+    // ---- GERMLINE lines (OUTVAR_GERMLINE, output_germline: main.hpp:5612-5775): one per (zerobased_pos, symbol type) whose genotype call is
+    // written, in front of the records of the position (main.cpp:1049-1066 runs before the record loop :1073-1168), BASE before LINK ----
+    std::vector<std::pair<int32_t, std::string>> germ_lines;
+    if (P.outvar_flag & 0x1) {
+        std::vector<int64_t> heads;   // first record of every group with a written genotype
+        for (int64_t i = 0; i < n; i++) {
+            const bool bs = is_base(F(i, UVC_O_symbol));
+            const bool head = (i == 0 || F(i - 1, UVC_O_refpos) != F(i, UVC_O_refpos) || is_base(F(i - 1, UVC_O_symbol)) != bs);
+            if (head && F(i, UVC_O_germ_emit)) heads.push_back(i);
+        }
+        if (!heads.empty()) {
+            const int32_t ncol = uvcgpu_region_n_columns();
+            std::vector<int32_t> where(heads.size());
+            for (size_t k = 0; k < heads.size(); k++) where[k] = F(heads[k], UVC_O_refpos);
+            std::vector<int64_t> cols((size_t)ncol * heads.size());
+            int rc = uvcgpu_region_fetch_columns(r, where.data(), (int64_t)where.size(), cols.data());
+            if (rc) return rc;
+            Rows G; int64_t nr = 0, nb = 0;
+            rc = uvcgpu_region_indel_alleles(r, nullptr, 0, &nr, nullptr, 0, &nb);
+            if (rc && rc != UVCGPU_ENOMEM) return rc;
+            G.rows.resize((size_t)nr); G.seq.resize((size_t)nb + 1);
+            if (nr) { rc = uvcgpu_region_indel_alleles(r, G.rows.data(), nr, &nr, G.seq.data(), nb + 1, &nb); if (rc) return rc; }
+            Cols C; for (int g = 0; g < UVC_NUM_FIELD_GROUPS; g++) C.base[g] = uvcgpu_region_column_base(g);
+            static const char *const GT4[4] = { "0/0", "0/1", "1/1", "1/2" };
+            for (size_t k = 0; k < heads.size(); k++) {
+                const int64_t i0 = heads[k];
+                C.v = cols.data() + (size_t)ncol * k;
+                const int32_t refpos = F(i0, UVC_O_refpos), refsymbol = F(i0, UVC_O_refsymbol);
+                const bool subst = is_base(refsymbol);
+                int64_t i1 = i0; while (i1 < n && F(i1, UVC_O_refpos) == refpos && is_base(F(i1, UVC_O_symbol)) == subst) i1++;
+                const int64_t regionpos = (int64_t)refpos - beg;
+                const int GLidx = F(i0, UVC_O_germ_GT);
+                const int32_t sel[3] = { F(i0, UVC_O_germ_ref), F(i0, UVC_O_germ_alt1), F(i0, UVC_O_germ_alt2) };
+                auto sym_of = [&](int32_t rec) { return rec >= 0 ? F(rec, UVC_O_symbol) : NSYM; };   // the padding allele: END_ALIGNMENT_SYMBOLS, "<NONE>"
+                auto cdp0a = [&](int32_t rec) { return rec >= 0 ? F(rec, UVC_O_cDP0a) : 0; };
+                // the q-th allele string of (refpos, symbol) in indel_get_majority order = the order of its records
+                auto allele_text = [&](int symbol, int q) -> std::string {
+                    int seen = 0;
+                    for (int64_t j = i0; j < i1; j++) if (F(j, UVC_O_symbol) == symbol) {
+                        if (seen++ == q) { const int32_t row = F(j, UVC_O_gapSa); return (row >= 0 && row < (int32_t)G.rows.size()) ? G.text(G.rows[(size_t)row], ref, beg) : std::string(SYMBOL_DESC[symbol]); }
+                    }
+                    return std::string();
+                };
+                auto ref_at = [&](int64_t q) { return (q >= 0 && q < (int64_t)ref.size()) ? std::string(1, ref[(size_t)q]) : std::string("n"); };
+                const int s0 = sym_of(sel[0]), s1 = sym_of(sel[1]), s2 = sym_of(sel[2]);
+                std::string vref, valt;
+                if (subst) {
+                    vref = SYMBOL_DESC[std::min(s0, NSYM)]; valt = SYMBOL_DESC[std::min(s1, NSYM)];
+                    if (3 == GLidx) { valt += ","; valt += SYMBOL_DESC[std::min(s2, NSYM)]; }
+                } else {
+                    const std::string vref1 = (regionpos > 0 ? ref_at(regionpos - 1) : std::string("n"));
+                    const std::string str1 = (s1 < NSYM ? allele_text(s1, 0) : std::string());
+                    vref = vref1;
+                    if (3 != GLidx) {
+                        if (str1.empty() || str1[0] == '<') valt = SYMBOL_DESC[std::min(s1, NSYM)];
+                        else { valt = vref; if (is_ins(s1)) valt += str1; else if (is_del(s1)) vref += str1; else valt = SYMBOL_DESC[std::min(s1, NSYM)]; }
+                    } else {
+                        const std::string str2 = (s2 < NSYM ? allele_text(s2, s2 == s1 ? 1 : 0) : std::string());
+                        valt = vref1;
+                        if (str1.empty() || str1[0] == '<' || str2.empty() || str2[0] == '<') valt = std::string(SYMBOL_DESC[std::min(s1, NSYM)]) + "," + SYMBOL_DESC[std::min(s2, NSYM)];
+                        else if (is_ins(s1) && is_ins(s2)) valt = vref1 + str1 + "," + vref1 + str2;
+                        else if (is_del(s1) && is_del(s2)) {
+                            if (str1.size() > str2.size()) { vref = vref1 + str1; valt = vref1 + "," + vref1 + str1.substr(str2.size()); }
+                            else { vref = vref1 + str2; valt = vref1 + str2.substr(str1.size()) + "," + vref1; }
+                        }
+                        else if (is_ins(s1) && is_del(s2)) { valt = vref1 + str1 + str2 + "," + vref1; vref = vref1 + str2; }
+                        else if (is_del(s1) && is_ins(s2)) { valt = vref1 + "," + vref1 + str2 + str1; vref = vref1 + str1; }
+                        else valt = std::string(SYMBOL_DESC[std::min(s1, NSYM)]) + "," + SYMBOL_DESC[std::min(s2, NSYM)];
+                    }
+                }
+                const int nn = (subst ? UVC_BASE_NN : UVC_LINK_NN);
+                const int64_t cdp1d = 2 * C.fr(UVC_F_FAM, UVC_NFAM, 0, UVC_FAM_cDP1, nn);   // SUMPAIR(CDP1d): fill_symboltype_nn_fmt pushes the forward value twice (main.hpp:3774-3786)
+                std::string line = tname; line += '\t'; put(line, (int64_t)refpos + (subst ? 1 : 0)); line += "\t.\t"; line += vref; line += '\t'; line += valt; line += '\t';
+                put(line, F(i0, UVC_O_germ_GQ)); line += "\tPASS\tGERMLINE\tGT:GQ:HQ:FT:CDP1:cDP1:GL4:GST:note\t";
+                line += GT4[std::min(std::max(GLidx, 0), 3)]; line += ':'; put(line, F(i0, UVC_O_germ_GQ)); line += ":0,0:PASS:";
+                put2(line, F(i0, UVC_O_DP), cdp1d); line += ':';
+                put2(line, cdp0a(sel[0]), cdp0a(sel[1])); if (3 == GLidx) { line += ','; put(line, cdp0a(sel[2])); }
+                line += ':';
+                for (int q = 0; q < 4; q++) { if (q) line += ','; put(line, F(i0, UVC_O_GL4_0 + q)); }
+                line += ':';
+                for (int q = 0; q < 8; q++) { if (q) line += ','; put(line, F(i0, UVC_O_GST0 + q)); }
+                line += ":\n";   // FORMAT/note of the reference allele: empty unless should_add_note
+                germ_lines.emplace_back(refpos + (subst ? 1 : 0), std::move(line));
+            }
+        }
+    }
     std::string out;
 // ---- the position-level lines, in front of the records of their zerobased_pos (main.cpp:607-799) ----
     {
@@ -708,9 +794,11 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
                 prev_track = curr_track;
             }
         }
-        size_t a = 0, b = 0;
-        while (a < pos_lines.size() || b < rec_lines.size()) {
-            if (b >= rec_lines.size() || (a < pos_lines.size() && pos_lines[a].first <= rec_lines[b].first)) out += pos_lines[a++].second;
+        size_t a = 0, b = 0, g = 0;   // at one zerobased_pos: block / candidate lines, GERMLINE lines, records
+        while (a < pos_lines.size() || b < rec_lines.size() || g < germ_lines.size()) {
+            const int32_t za = (a < pos_lines.size() ? pos_lines[a].first : INT32_MAX), zg = (g < germ_lines.size() ? germ_lines[g].first : INT32_MAX), zb = (b < rec_lines.size() ? rec_lines[b].first : INT32_MAX);
+            if (za <= zg && za <= zb) out += pos_lines[a++].second;
+            else if (zg <= zb) out += germ_lines[g++].second;
             else out += rec_lines[b++].second;
         }
     }
