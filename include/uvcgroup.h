@@ -78,6 +78,14 @@ int uvcgpu_qname_digest(const char *qname, int molecule_tag, int disable_duplex,
 /* the same for n NUL-terminated names stored back to back (names + off[i]), e.g. UvcBamBatch::qnames / qname_off of uvcio.h */
 int uvcgpu_qname_digest_batch(const char *names, const int64_t *off, int64_t n, int molecule_tag, int disable_duplex,
                               uint64_t *qname_hash31, uint64_t *qname_hash17, uint64_t *umi_hash31, uint64_t *umi_hash17, uint8_t *umi_kind);
+/* bam2umihash (grouping.cpp:569-606, 787-792): the in-read UMI pattern of single-end (IonTorrent) reads.  `umi_struct` is the pattern the
+ * reference takes from the environment variable ONE_STEP_UMI_STRUCT (main.cpp:1224-1225), e.g. "NNNACTNNNTGA": N = a UMI letter, anything
+ * else must match; it is looked for at the first five offsets of the read and, failing that, reverse-complemented from its end.  For
+ * every unpaired alignment whose umi_kind has no UMI from the name, a hit sets bit 0 of umi_kind[i] (MolecularBarcode::duplexflag 0x1 and
+ * the UMI arm of the dedup_idflag choice follow from it); umi_hash (optional) receives the base-16 hash of the UMI letters, which the
+ * reference computes and never reads.  The UMI hash pair of such a read stays 0, 0: its key carries an empty umistring (grouping.cpp:929). */
+int uvcgpu_umi_in_read_batch(const char *umi_struct, const uint8_t *bases, const int64_t *seq_off, const int32_t *l_qseq, const uint16_t *flag, int64_t n,
+                             uint8_t *umi_kind, uint64_t *umi_hash);
 /* 0 or a negative UVCGPU_E* code (uvcgpu_last_error() has the text) */
 int uvcgpu_group_families(const UvcGroupParams *params, const UvcGroupInput *in, UvcGroupOut *out);
 

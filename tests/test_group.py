@@ -232,3 +232,69 @@ def test_gpu_against_oracle(oracle_lib, gpu_lib, case):
     assert (np.diff(rg["fam_id"]) >= 0).all() and (np.diff(rg["frag_id"]) >= 0).all()
     for s in ["q#ACGT+TTGA", "plain"]:
         assert group.qname_digest(gpu_lib, s) == group.qname_digest(oracle_lib, s)
+
+
+def py_bam2umihash(pattern, bases, flag, kind0):
+    """grouping.cpp:569-606, 787-792, restated independently on base codes 0..4."""
+    nt16 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    pat = [nt16.get(c.upper(), 15) for c in pattern]
+    code16 = [1, 2, 4, 8, 15]
+    rc = {1: 8, 2: 4, 4: 2, 8: 1}
+    if (kind0 & 1) or (flag & 1) or not pat:
+        return kind0, 0
+    for is_rc in (False, True):
+        for i in range(5):
+            patpos, h = 0, 0
+            for j in range(i, len(bases)):
+                if patpos >= len(pat):
+                    break
+                b = code16[bases[len(bases) - 1 - j]] if is_rc else code16[bases[j]]
+                if is_rc:
+                    b = rc.get(b, b)
+                if pat[patpos] == b or pat[patpos] == 15:
+                    if pat[patpos] == 15:
+                        h = (h * 16 + b) & M64
+                    patpos += 1
+                else:
+                    break
+            if patpos == len(pat):
+                return kind0 | 1, h
+    return kind0, 0
+
+
+def test_in_read_umi_pattern(oracle_lib):
+    """a11: bam2umihash.  Product (a host function of libuvcgpu: no GPU needed) and oracle against the restatement above."""
+    import ctypes as C
+    from uvc_amd import _ffi
+    product = _ffi.Lib.__new__(_ffi.Lib); product.dll = C.CDLL(_ffi.gpu_library_path()); product.prefix = "uvcgpu_"
+    rng = np.random.default_rng(3)
+    pattern = "NNNACTNNNTGA"
+    reads, flags, kinds = [], [], []
+    def planted(offset, revcomp):
+        umi = rng.integers(0, 4, 12)
+        for k, ch in enumerate(pattern):
+            if ch != "N":
+                umi[k] = "ACGT".index(ch)
+        body = rng.integers(0, 4, 60)
+        seq = np.concatenate([rng.integers(0, 4, offset), umi, body])
+        if revcomp:
+            seq = (3 - seq)[::-1]
+        return seq.astype(np.uint8)
+    for off in range(0, 7):
+        for revcomp in (False, True):
+            reads.append(planted(off, revcomp)); flags.append(0); kinds.append(0)
+    reads.append(planted(0, False)); flags.append(0x1); kinds.append(0)      # paired: not searched
+    reads.append(planted(0, False)); flags.append(0); kinds.append(3)        # a UMI in the name wins
+    for _ in range(40):
+        reads.append(rng.integers(0, 5, int(rng.integers(8, 90))).astype(np.uint8)); flags.append(0); kinds.append(0)
+    reads.append(np.array([0, 1, 2], np.uint8)); flags.append(0); kinds.append(0)   # shorter than the pattern
+    cols = dict(bases=np.concatenate(reads), seq_off=np.cumsum([0] + [len(r) for r in reads[:-1]]), l_qseq=np.array([len(r) for r in reads]), flag=np.array(flags))
+    want = [py_bam2umihash(pattern, [int(x) for x in r], f, k) for r, f, k in zip(reads, flags, kinds)]
+    assert sum(k & 1 for k, _ in want) >= 11 and want[10][0] == 0 and want[11][0] == 0 and want[12][0] == 0 and want[13][0] == 0   # offsets 5 and 6 are out of reach
+    for lib in (oracle_lib, product):
+        kind = np.array(kinds, np.uint8)
+        h = group.umi_in_read_batch(lib, pattern, cols, kind)
+        assert [(int(k), int(x)) for k, x in zip(kind, h)] == want
+        kind2 = np.array(kinds, np.uint8)
+        group.umi_in_read_batch(lib, "", cols, kind2)
+        assert kind2.tolist() == kinds

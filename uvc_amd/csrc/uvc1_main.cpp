@@ -34,7 +34,7 @@ namespace {
 const int32_t MAX_INSERT_SIZE = 2000, MAX_STR_N_BASES = 100;   // common.hpp:63-64
 
 struct Opts {
-    std::string bam, fasta, out, sample = "-", targets, bed, tumor_vcf, bed_out, bed_in;
+    std::string bam, fasta, out, sample = "-", targets, bed, tumor_vcf, bed_out, bed_in, umi_struct;
     std::vector<int> devices;
     int threads = 0, outvar_flag = -1, repeat = 1, shard = 0, n_shards = 1, tn_is_paired = 0, tumor_format = 1;
     int64_t tile = 1000000;
@@ -84,6 +84,7 @@ Opts parse(int argc, char **argv) {
         else die("more than one inputBAM");
     }
     if (o.bam.empty() || o.fasta.empty() || o.out.empty()) { usage(); exit(2); }
+    if (const char *us = getenv("ONE_STEP_UMI_STRUCT")) o.umi_struct = us;   // the reference takes the in-read UMI pattern from the environment (main.cpp:1224-1225)
     return o;
 }
 
@@ -116,6 +117,7 @@ bool call_tile(Worker &w, const Opts &o, const UvcParams &P, const Tile &t, int6
     if (n == 0) return false;
     w.h31.resize(n); w.h17.resize(n); w.u31.resize(n); w.u17.resize(n); w.kind.resize(n);
     uvcgpu_qname_digest_batch(b.qnames, b.qname_off, n, 0, 0, w.h31.data(), w.h17.data(), w.u31.data(), w.u17.data(), w.kind.data());
+    if (!o.umi_struct.empty() && uvcgpu_umi_in_read_batch(o.umi_struct.c_str(), b.bases, b.seq_off, b.l_qseq, b.flag, n, w.kind.data(), nullptr)) die(uvcgpu_last_error());   // grouping.cpp:787-792
     UvcGroupParams gp; uvcgpu_group_params_default(&gp);
     gp.fetch_tbeg = (int32_t)t.beg; gp.fetch_tend = (int32_t)t.end; gp.inferred_sequencing_platform = P.inferred_sequencing_platform;
     UvcGroupInput gi; memset(&gi, 0, sizeof(gi));

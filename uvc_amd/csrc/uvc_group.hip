@@ -278,6 +278,46 @@ int uvcgpu_qname_digest_batch(const char *names, const int64_t *off, int64_t n, 
     return 0;
 }
 
+
+// bam2umihash (grouping.cpp:569-606, called :787-792): single-end reads without a UMI in their name are searched for an in-read UMI
+// pattern (environment ONE_STEP_UMI_STRUCT of the reference, main.cpp:1224-1225; letters as seq_nt16_table codes, N = any base = a UMI
+// letter), forward at the first five offsets, then reverse-complemented from the read's end.  A hit sets the "UMI found" bit of umi_kind;
+// the hash of the UMI letters is returned too, although the reference's family key never reads it (its umistring stays empty there:
+// umi_beg / umi_len come from the read name, grouping.cpp:929).  Bases arrive as the codes of UvcBamBatch (0..3 = ACGT, 4 = anything
+// else, which the reference holds as its 4-bit code: an ambiguity letter in the READ therefore only matches an N of the pattern).
+static int uvc_nt16_of_char(char c) {   // seq_nt16_table of htslib (SAM specification, section 4.2.3: "=ACMGRSVTWYHKDBN")
+    switch (c) { case '=': return 0; case 'A': case 'a': return 1; case 'C': case 'c': return 2; case 'M': case 'm': return 3; case 'G': case 'g': return 4;
+                 case 'R': case 'r': return 5; case 'S': case 's': return 6; case 'V': case 'v': return 7; case 'T': case 't': return 8; case 'W': case 'w': return 9;
+                 case 'Y': case 'y': return 10; case 'H': case 'h': return 11; case 'K': case 'k': return 12; case 'D': case 'd': return 13; case 'B': case 'b': return 14; default: return 15; }
+}
+int uvcgpu_umi_in_read_batch(const char *umi_struct, const uint8_t *bases, const int64_t *seq_off, const int32_t *l_qseq, const uint16_t *flag, int64_t n,
+                           uint8_t *umi_kind, uint64_t *umi_hash) {
+    if (n < 0 || (n > 0 && (!bases || !seq_off || !l_qseq || !flag || !umi_kind))) return uvcgpu_set_error(UVCGPU_EINVAL, "bad argument");
+    if (!umi_struct || !*umi_struct) return 0;
+    int pat[256]; int np = 0;
+    for (const char *c = umi_struct; *c && np < 256; c++) pat[np++] = uvc_nt16_of_char(*c);
+    static const int code16[5] = { 1, 2, 4, 8, 15 };
+    static const int rc16[16] = { 0, 8, 4, 3, 2, 5, 6, 7, 1, 9, 10, 11, 12, 13, 14, 15 };   // STATIC_REV_COMPLEMENT.table16, common.hpp:177-183
+    for (int64_t r = 0; r < n; r++) {
+        if (umi_hash) umi_hash[r] = 0;
+        if ((umi_kind[r] & 1) || (flag[r] & 0x1)) continue;   // a UMI in the name wins; paired reads are not searched ("should be proton")
+        const uint8_t *b = bases + seq_off[r]; const int lq = l_qseq[r];
+        bool found = false; uint64_t h = 0;
+        for (int is_rc = 0; is_rc < 2 && !found; is_rc++) for (int i = 0; i < 5 && !found; i++) {
+            int patpos = 0; h = 0;
+            for (int j = i; j < lq && patpos < np; j++) {
+                const int raw = code16[b[is_rc ? (lq - 1 - j) : j] > 4 ? 4 : b[is_rc ? (lq - 1 - j) : j]];
+                const int base = (is_rc ? rc16[raw] : raw);
+                if (pat[patpos] == base || 15 == pat[patpos]) { if (15 == pat[patpos]) h = h * 16 + (uint64_t)base; patpos++; }
+                else break;
+            }
+            if (patpos == np) found = true;
+        }
+        if (found) { umi_kind[r] |= 1; if (umi_hash) umi_hash[r] = h; }
+    }
+    return 0;
+}
+
 int uvcgpu_group_families(const UvcGroupParams *Pp, const UvcGroupInput *in, UvcGroupOut *out) {
     if (!Pp || !in || !out || Pp->struct_size != (int32_t)sizeof(UvcGroupParams)) return uvcgpu_set_error(UVCGPU_EINVAL, "bad argument / UvcGroupParams::struct_size");
     if (Pp->fetch_tend <= Pp->fetch_tbeg || in->n_alns < 0 || in->n_alns >= ((int64_t)1 << 31)) return uvcgpu_set_error(UVCGPU_EINVAL, "bad region or alignment count");

@@ -111,3 +111,17 @@ def group_families(lib, params, cols):
                n_kept=k, n_fams=f, n_frags=out.n_frags, ext_beg=out.extended_inclu_beg_pos, ext_end=out.extended_exclu_end_pos,
                n_amplicon=out.n_amplicon, n_visited_qnames=out.n_visited_qnames)
     return res
+
+
+def umi_in_read_batch(lib, umi_struct, cols, umi_kind):
+    """bam2umihash (grouping.cpp:569-606): marks in `umi_kind` (uint8 array, edited in place) the unpaired reads of a fetched batch (`cols` =
+    uvc_amd.io.Bam.fetch columns) that carry the in-read UMI pattern `umi_struct` (ONE_STEP_UMI_STRUCT); returns the hashes of their UMI letters."""
+    n = len(umi_kind)
+    h = np.zeros(max(n, 1), np.uint64)
+    keep = [np.ascontiguousarray(cols["bases"], np.uint8), np.ascontiguousarray(cols["seq_off"], np.int64), np.ascontiguousarray(cols["l_qseq"], np.int32), np.ascontiguousarray(cols["flag"], np.uint16)]
+    assert umi_kind.dtype == np.uint8 and umi_kind.flags["C_CONTIGUOUS"]
+    f = _fn(lib, "umi_in_read_batch", C.c_int, [C.c_char_p] + [C.c_void_p] * 4 + [C.c_int64, C.c_void_p, C.c_void_p])
+    rc = f(umi_struct.encode(), keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data, keep[3].ctypes.data, n, umi_kind.ctypes.data, h.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("umi_in_read_batch failed: %d" % rc)
+    return h[:n]

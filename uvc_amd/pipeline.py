@@ -24,7 +24,7 @@ FILTERS = ["Q10", "Q20", "Q30", "Q40", "Q50", "Q60", "PASS"]
 
 
 def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None, molecule_tag=0, disable_duplex=0, correct_bq=True, all_out=False, keep_handle=False, reuse=None, vcf=False,
-                continues=False, has_next=False, region_beg=None, tumor_vcf=None):
+                continues=False, has_next=False, region_beg=None, tumor_vcf=None, umi_struct=None):
     """Scores [beg, end) of `chrom`.  Returns None when no read passes the filters (process_batch returns -1, main.cpp:520-523), else a
     dict: records (field -> int32 array), alleles (InDel allele rows), score range, region handle (if keep_handle).
     Tiles of one stretch: the reference scores zerobased_pos rpos_beg .. rpos_end inclusive and skips the BASE sub-position of the first
@@ -33,7 +33,8 @@ def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None
     [.., beg) is in front) makes this one score `beg` completely, BASE sub-position included (UvcScoreRequest::base_at_pos_beg) -- a run of
     tiles writes the records of one uncut region.  `region_beg`: begin of the BED line / contig range the run belongs to (incluBegPosition
     of main.cpp:655-656, default `beg`).  `tumor_vcf`: normal sample of a T/N pair -- the tumor pass's VCF as `uvc_amd.io.TumorVcf` (its records
-    of this region become UvcScoreRequest::tumor_keys; `params.tumor_vcf_is_provided` must be set).
+    of this region become UvcScoreRequest::tumor_keys; `params.tumor_vcf_is_provided` must be set).  `umi_struct`: the in-read UMI pattern
+    (the reference's environment variable ONE_STEP_UMI_STRUCT).
     `reuse`: a dict the caller keeps between calls; the region handle lives in it and is reset for every new region instead of being
     created and destroyed (its device buffers survive while the regions do not grow)."""
     import os, time
@@ -48,6 +49,9 @@ def call_region(lib, bam, fasta, chrom, beg, end, params=None, group_params=None
     if n == 0:
         return None
     kind, h = group._digest_batch(lib, cols["qnames"], molecule_tag, disable_duplex)
+    if umi_struct:                                                                     # ONE_STEP_UMI_STRUCT: the in-read UMI of single-end reads (bam2umihash, grouping.cpp:787-792)
+        kind = np.ascontiguousarray(kind)
+        group.umi_in_read_batch(lib, umi_struct, cols, kind)
     gp = group_params if group_params is not None else group.default_params(lib, beg, end, platform=(params.inferred_sequencing_platform if params is not None else 1))
     gp.fetch_tbeg, gp.fetch_tend = beg, end
     g = group.group_families(lib, gp, dict(tid=cols["tid"], pos=cols["pos"], endpos=cols["endpos"], mtid=cols["mtid"], mpos=cols["mpos"], isize=cols["isize"], flag=cols["flag"], mapq=cols["mapq"],
