@@ -95,7 +95,7 @@ def run_cpu_baseline(depth, n_regions=64, region_len=20000):
     """Times the oracle (test infrastructure) on `n_regions` independent regions, one thread each: accumulate + default-gate scoring."""
     from concurrent.futures import ThreadPoolExecutor
     from uvc_amd import _ffi, region
-    lib = _ffi.Lib(_ffi.oracle_library_path(), "uvc_oracle_")
+    lib = _ffi.Lib(__import__("oracle").library_path(), "uvc_oracle_")
     params = region.default_params(lib)
     cores = min(16, os.cpu_count() or 1)
     regs = []

@@ -3,7 +3,7 @@ import sys; sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tes
 import importlib.util
 from uvc_amd import _ffi, region
 spec = importlib.util.spec_from_file_location("ta", "/root/repo/tests/test_gpu_indel_alleles.py"); ta = importlib.util.module_from_spec(spec); spec.loader.exec_module(ta)
-ol = _ffi.Lib(_ffi.oracle_library_path(), "uvc_oracle_"); gl = region.gpu_lib()
+ol = _ffi.Lib(__import__("oracle").library_path(), "uvc_oracle_"); gl = region.gpu_lib()
 seed, umi, n = int(sys.argv[1]), int(sys.argv[2]) != 0, int(sys.argv[3])
 reads = ta.indel_sites_region(seed, n_fam=n, umi=umi)
 o, g = ta.run(ol, reads), ta.run(gl, reads)

@@ -4,7 +4,7 @@ import importlib.util, numpy as np
 from uvc_amd import _ffi, region
 from util import diff_groups
 spec = importlib.util.spec_from_file_location("fz", "/root/repo/tests/test_gpu_fuzz.py"); fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
-ol = _ffi.Lib(_ffi.oracle_library_path(), "uvc_oracle_"); gl = region.gpu_lib()
+ol = _ffi.Lib(__import__("oracle").library_path(), "uvc_oracle_"); gl = region.gpu_lib()
 seed = int(sys.argv[1])
 reads = fz.weird_region(seed, umi=(seed % 3 == 2))
 OPS = "MIDNSH"

@@ -5,7 +5,7 @@ from uvc_amd import _ffi, region
 from util import diff_groups
 spec = importlib.util.spec_from_file_location("fz", "/root/repo/tests/test_gpu_fuzz.py"); fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
 from test_gpu_parity import compare_records
-ol = _ffi.Lib(_ffi.oracle_library_path(), "uvc_oracle_"); gl = region.gpu_lib()
+ol = _ffi.Lib(__import__("oracle").library_path(), "uvc_oracle_"); gl = region.gpu_lib()
 nbad = nref = 0
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     reads = fz.weird_region(seed, n_frag=120 + (seed * 37) % 400, ref_len=300 + (seed * 91) % 900, umi=(seed % 3 == 2))

@@ -4,7 +4,7 @@ sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 from uvc_amd import _ffi, region
 import test_vcf_text as T
 from test_gpu_fuzz import run, weird_region
-ol = _ffi.Lib(_ffi.oracle_library_path(), "uvc_oracle_"); gl = region.gpu_lib()
+ol = _ffi.Lib(__import__("oracle").library_path(), "uvc_oracle_"); gl = region.gpu_lib()
 L = C.CDLL(T.REF_SO)
 for n in ("uvc_ref_format_string", "uvc_ref_format_id", "uvc_ref_format_line", "uvc_ref_filter_id", "uvc_ref_filter_line"): getattr(L, n).restype = C.c_char_p
 L.uvc_ref_stream_format.restype = C.c_int64; L.uvc_ref_stream_format.argtypes = [C.c_char_p, C.c_char_p, C.c_int64]

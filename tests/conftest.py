@@ -17,7 +17,7 @@ def pytest_configure(config):
 def oracle_lib():
     """The CPU oracle (test infrastructure only)."""
     from uvc_amd import _ffi
-    path = _ffi.oracle_library_path()
+    path = __import__("oracle").library_path()
     if not os.path.exists(path):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "liboracle.so")])
     return _ffi.Lib(path, "uvc_oracle_")

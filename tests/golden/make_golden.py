@@ -22,7 +22,7 @@ CASES = {
 }
 
 if __name__ == "__main__":
-    lib = _ffi.Lib(_ffi.oracle_library_path(), "uvc_oracle_")
+    lib = _ffi.Lib(__import__("oracle").library_path(), "uvc_oracle_")
     for name, kw in CASES.items():
         reads = synth.generate_region(**kw)
         R = run_region(lib, reads)

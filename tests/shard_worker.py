@@ -28,7 +28,7 @@ def main():
     bam_path, fa_path, chrom, tile = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
     clock = shard.Clock(backend="gloo")
     rank, world = clock.rank, clock.world
-    lib = _ffi.Lib(_ffi.oracle_library_path(), "uvc_oracle_")
+    lib = _ffi.Lib(__import__("oracle").library_path(), "uvc_oracle_")
     bam, fa = uio.Bam(bam_path), uio.Fasta(fa_path)
     tid = bam.tid(chrom)
     tiles = pipeline.contig_tiles(0, bam.refs[tid][1], tile)

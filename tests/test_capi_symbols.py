@@ -65,6 +65,7 @@ def test_no_cpu_fallback(dll):
 def test_product_does_not_reference_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "uvc_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".cpp", ".h")) and f != "_ffi.py":
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
-                assert "liboracle" not in src and "uvc_oracle_" not in src and "oracle/" not in src, os.path.join(dirpath, f)
+                # no path, symbol prefix, import or attribute access of the checker (prose may mention it)
+                assert "liboracle" not in src and "uvc_oracle_" not in src and "import oracle" not in src and "oracle/" not in src and "oracle.library_path" not in src, os.path.join(dirpath, f)

@@ -1,8 +1,8 @@
 """ctypes mirror of include/uvcgpu.h (struct layouts are generated from include/uvc_params.def).
 
-The same declarations serve the product library (uvc_amd/csrc/libuvcgpu.so, prefix `uvcgpu_`)
-and, in tests / smoke / bench cpu_baseline only, the oracle (oracle/liboracle.so, prefix
-`uvc_oracle_`).
+`Lib` binds any shared library that exports the uvcgpu.h entry points under a prefix: the product library
+(uvc_amd/csrc/libuvcgpu.so, prefix `uvcgpu_`) and, in tests / smoke / bench cpu_baseline only, the checker of the
+same ABI (whose path lives with it, outside this package -- nothing here knows where it is).
 """
 import ctypes as C
 import os
@@ -159,7 +159,3 @@ class Lib:
 
 def gpu_library_path():
     return os.path.join(ROOT, "uvc_amd", "csrc", "libuvcgpu.so")
-
-
-def oracle_library_path():
-    return os.path.join(ROOT, "oracle", "liboracle.so")
