@@ -46,6 +46,13 @@ extern "C" void uvc_launch_rank_from_sorted(const uint32_t *perm, int64_t n, int
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+// C++ exceptions must not cross the C boundary (std::terminate would take the caller's process down): every entry point that allocates
+// host memory reports them as an error code instead
+template <class F> static int guarded(const char *what, F &&f) {
+    try { return f(); }
+    catch (const std::bad_alloc &) { return fail(UVCGPU_ENOMEM, std::string(what) + ": out of host memory"); }
+    catch (const std::exception &e) { return fail(UVCGPU_EDEVICE, std::string(what) + ": " + e.what()); }
+}
 extern "C" int uvcgpu_set_error(int code, const char *msg) { return fail(code, msg ? msg : ""); }   // for the other translation units of the library
 #define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(UVCGPU_EDEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
@@ -316,7 +323,7 @@ static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t 
     return 0;
 }
 
-int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params, int32_t tid, int32_t beg, int32_t end, const char *refseq) {
+static int uvcgpu_region_create_impl(uvcgpu_region_t **out, const UvcParams *params, int32_t tid, int32_t beg, int32_t end, const char *refseq) {
     if (!out || !params || !refseq || end <= beg) return fail(UVCGPU_EINVAL, "bad argument");
     if (params->struct_size != (int32_t)sizeof(UvcParams)) return fail(UVCGPU_EINVAL, "UvcParams::struct_size mismatch");
     if (params->indel_str_repeatsize_max < 1 || params->indel_vntr_repeatsize_max < params->indel_str_repeatsize_max) return fail(UVCGPU_EINVAL, "bad repeat-size parameters");
@@ -337,7 +344,7 @@ int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params, int32_t
 
 // The same handle for another region (the next tile): reads, results and the plane contents of the previous region are dropped, streams,
 // events and -- when the new region is not longer than the longest one the handle has seen -- the device buffers are kept.
-int uvcgpu_region_reset(uvcgpu_region_t *r, int32_t tid, int32_t beg, int32_t end, const char *refseq) {
+static int uvcgpu_region_reset_impl(uvcgpu_region_t *r, int32_t tid, int32_t beg, int32_t end, const char *refseq) {
     if (!r || !refseq || end <= beg) return fail(UVCGPU_EINVAL, "bad argument");
     HIP_OK(hipStreamSynchronize(r->stream));
     if (r->side) HIP_OK(hipStreamSynchronize(r->side));
@@ -463,7 +470,7 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
 }
 
 // Host columns: they are copied to the device as they are (no host pass over the reads), then prepared there.
-int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
+static int uvcgpu_region_set_reads_impl(uvcgpu_region_t *r, const UvcReadSoA *in) {
     if (!r || !in || in->n_reads < 0 || in->n_fams < 0) return fail(UVCGPU_EINVAL, "bad reads");
     const bool timing = (getenv("UVCGPU_TIMING") != nullptr);   // stderr breakdown of the ingest, for tuning
     auto t_prev = std::chrono::steady_clock::now();
@@ -487,7 +494,7 @@ int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) {
 // The same with the columns already in HBM (every pointer of `in` is a device pointer on the handle's device): nothing is copied.  The
 // arrays must stay valid and unchanged until the handle gets other reads, is reset or destroyed -- the kernels of every accumulate
 // read bases / quals / cigars in place -- and uvcgpu_region_correct_bq edits `quals` in place, as the reference edits its bam1_t.
-int uvcgpu_region_set_reads_device(uvcgpu_region_t *r, const UvcReadSoA *in) {
+static int uvcgpu_region_set_reads_device_impl(uvcgpu_region_t *r, const UvcReadSoA *in) {
     if (!r || !in || in->n_reads < 0 || in->n_fams < 0 || in->n_bases < 0 || in->n_cigar_ops < 0) return fail(UVCGPU_EINVAL, "bad reads");
     const bool timing = (getenv("UVCGPU_TIMING") != nullptr);
     free_reads(r);
@@ -498,7 +505,7 @@ int uvcgpu_region_set_reads_device(uvcgpu_region_t *r, const UvcReadSoA *in) {
 
 // apply_bq_err_correction3 (grouping.cpp:459-543) on the resident reads, then everything derived from the base qualities again:
 // the packed base|qual array and the per-read records (the low-quality-InDel test of k_aln_prelude reads them)
-int uvcgpu_region_correct_bq(uvcgpu_region_t *r) {
+static int uvcgpu_region_correct_bq_impl(uvcgpu_region_t *r) {
     if (!r) return fail(UVCGPU_EINVAL, "null region");
     if (!r->has_reads) return fail(UVCGPU_ENOREADS, "no reads");
     uvc_launch_correct_bq(&r->R, r->P.assay_sequencing_BQ_max, r->P.assay_sequencing_BQ_inc, r->stream);
@@ -522,7 +529,7 @@ int uvcgpu_region_read_quals(uvcgpu_region_t *r, uint8_t *dst, int64_t n) {
     return 0;
 }
 
-int uvcgpu_region_accumulate(uvcgpu_region_t *r) {
+static int uvcgpu_region_accumulate_impl(uvcgpu_region_t *r) {
     if (!r) return fail(UVCGPU_EINVAL, "null region");
     if (!r->has_reads) return fail(UVCGPU_ENOREADS, "no reads");   // process_batch returns -1, main.cpp:520-523
     if (r->state_zeroed) HIP_OK(hipStreamWaitEvent(r->stream, r->e_join, 0));   // zeroed behind the last score (release_state)
@@ -577,7 +584,7 @@ int64_t uvcgpu_region_field_bytes(const uvcgpu_region_t *r, int32_t g) {
     return (int64_t)group_bytes(r, g);
 }
 
-int uvcgpu_region_fetch(uvcgpu_region_t *r, int32_t g, void *dst, int64_t dst_bytes) {
+static int uvcgpu_region_fetch_impl(uvcgpu_region_t *r, int32_t g, void *dst, int64_t dst_bytes) {
     if (!r || !dst || g < 0 || g >= UVC_NUM_FIELD_GROUPS) return fail(UVCGPU_EINVAL, "bad argument");
     if (g != UVC_F_RTR && g != UVC_F_BAQ && !r->accumulated) return fail(UVCGPU_ESTATE, "fetch before accumulate");
     if (g != UVC_F_RTR && g != UVC_F_BAQ && r->state_released) return fail(UVCGPU_ESTATE, "the planes were released by the last score (UvcScoreRequest::release_state)");
@@ -608,7 +615,7 @@ int32_t uvcgpu_region_column_base(int32_t g) {
     return at;
 }
 int32_t uvcgpu_region_n_columns(void) { int32_t at = 0; for (int q = 0; q < UVC_NUM_FIELD_GROUPS; q++) at += group_planes(q); return at; }
-int uvcgpu_region_fetch_columns(uvcgpu_region_t *r, const int32_t *refpos, int64_t n, int64_t *dst) {
+static int uvcgpu_region_fetch_columns_impl(uvcgpu_region_t *r, const int32_t *refpos, int64_t n, int64_t *dst) {
     if (!r || n < 0 || (n > 0 && (!refpos || !dst))) return fail(UVCGPU_EINVAL, "bad argument");
     if (!r->accumulated) return fail(UVCGPU_ESTATE, "fetch before accumulate");
     if (r->state_released) return fail(UVCGPU_ESTATE, "the planes were released by the last score (UvcScoreRequest::release_state)");
@@ -699,9 +706,9 @@ static int gap_tables(uvcgpu_region_t *r) {
     if (G.n_inc) { HIP_OK(hipMemcpyAsync(cnt, G.n_inc, 16, hipMemcpyDeviceToHost, cs)); HIP_OK(hipStreamSynchronize(cs)); }
     const int32_t n_rows = cnt[1];
     unsigned long long seq_len = 0; memcpy(&seq_len, &cnt[2], 8);
+    if (n_rows < 0 || n_rows > G.n_ev || seq_len > (unsigned long long)G.seq_cap) return fail(UVCGPU_EDEVICE, "allele table overflow");   // before anything is sized from them
     std::vector<GapRow> dev((size_t)n_rows);
     std::vector<uint8_t> dseq((size_t)seq_len);
-    if (n_rows > G.n_ev || (int64_t)seq_len > G.seq_cap) return fail(UVCGPU_EDEVICE, "allele table overflow");
     if (n_rows) HIP_OK(hipMemcpyAsync(dev.data(), G.rows, sizeof(GapRow) * (size_t)n_rows, hipMemcpyDeviceToHost, cs));
     if (seq_len) HIP_OK(hipMemcpyAsync(dseq.data(), G.seq, (size_t)seq_len, hipMemcpyDeviceToHost, cs));
     if (n_rows || seq_len) HIP_OK(hipStreamSynchronize(cs));
@@ -780,7 +787,7 @@ static int gap_tables(uvcgpu_region_t *r) {
     return 0;
 }
 
-int uvcgpu_region_indel_alleles(uvcgpu_region_t *r, UvcGapRow *rows, int64_t row_capacity, int64_t *n_rows, uint8_t *seq, int64_t seq_capacity, int64_t *seq_bytes) {
+static int uvcgpu_region_indel_alleles_impl(uvcgpu_region_t *r, UvcGapRow *rows, int64_t row_capacity, int64_t *n_rows, uint8_t *seq, int64_t seq_capacity, int64_t *seq_bytes) {
     if (!r) return fail(UVCGPU_EINVAL, "null region");
     if (!r->accumulated) return fail(UVCGPU_ESTATE, "indel_alleles before accumulate");
     int rc = gap_tables(r);
@@ -837,7 +844,7 @@ static int hap_tables(uvcgpu_region_t *r) {
 }
 const std::vector<UvcHapLinkHost> *uvcgpu_region_hap_(uvcgpu_region_t *r) { return hap_tables(r) ? nullptr : r->hap; }   // for uvc_vcf.cpp
 
-int uvcgpu_region_hap_links(uvcgpu_region_t *r, UvcHapLink *links, int64_t link_capacity, int64_t *n_links, int32_t *muts, int64_t mut_capacity, int64_t *n_mut_ints) {
+static int uvcgpu_region_hap_links_impl(uvcgpu_region_t *r, UvcHapLink *links, int64_t link_capacity, int64_t *n_links, int32_t *muts, int64_t mut_capacity, int64_t *n_mut_ints) {
     if (!r) return fail(UVCGPU_EINVAL, "null region");
     int rc = hap_tables(r);
     if (rc) return rc;
@@ -861,7 +868,7 @@ int64_t uvcgpu_region_score_size(const uvcgpu_region_t *r, const UvcScoreRequest
     return NSYM * (np + 1) + (req ? req->n_indel_alleles + req->n_tumor_keys : 0) + (int64_t)r->gap_alleles.size();
 }
 
-int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScoreOut *out) {
+static int uvcgpu_region_score_impl(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScoreOut *out) {
     if (!r || !out || !out->fields) return fail(UVCGPU_EINVAL, "bad argument");
     if (!r->accumulated) return fail(UVCGPU_ESTATE, "score before accumulate");
     if (r->state_released) return fail(UVCGPU_ESTATE, "the planes were released by the last score (UvcScoreRequest::release_state)");
@@ -943,6 +950,18 @@ int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScore
     }
     return rc;   // ~Temps frees the temporaries
 }
+
+int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params, int32_t tid, int32_t beg, int32_t end, const char *refseq) { return guarded("uvcgpu_region_create", [&] { return uvcgpu_region_create_impl(out, params, tid, beg, end, refseq); }); }
+int uvcgpu_region_reset(uvcgpu_region_t *r, int32_t tid, int32_t beg, int32_t end, const char *refseq) { return guarded("uvcgpu_region_reset", [&] { return uvcgpu_region_reset_impl(r, tid, beg, end, refseq); }); }
+int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *in) { return guarded("uvcgpu_region_set_reads", [&] { return uvcgpu_region_set_reads_impl(r, in); }); }
+int uvcgpu_region_set_reads_device(uvcgpu_region_t *r, const UvcReadSoA *in) { return guarded("uvcgpu_region_set_reads_device", [&] { return uvcgpu_region_set_reads_device_impl(r, in); }); }
+int uvcgpu_region_correct_bq(uvcgpu_region_t *r) { return guarded("uvcgpu_region_correct_bq", [&] { return uvcgpu_region_correct_bq_impl(r); }); }
+int uvcgpu_region_accumulate(uvcgpu_region_t *r) { return guarded("uvcgpu_region_accumulate", [&] { return uvcgpu_region_accumulate_impl(r); }); }
+int uvcgpu_region_fetch(uvcgpu_region_t *r, int32_t g, void *dst, int64_t dst_bytes) { return guarded("uvcgpu_region_fetch", [&] { return uvcgpu_region_fetch_impl(r, g, dst, dst_bytes); }); }
+int uvcgpu_region_fetch_columns(uvcgpu_region_t *r, const int32_t *refpos, int64_t n, int64_t *dst) { return guarded("uvcgpu_region_fetch_columns", [&] { return uvcgpu_region_fetch_columns_impl(r, refpos, n, dst); }); }
+int uvcgpu_region_indel_alleles(uvcgpu_region_t *r, UvcGapRow *rows, int64_t row_capacity, int64_t *n_rows, uint8_t *seq, int64_t seq_capacity, int64_t *seq_bytes) { return guarded("uvcgpu_region_indel_alleles", [&] { return uvcgpu_region_indel_alleles_impl(r, rows, row_capacity, n_rows, seq, seq_capacity, seq_bytes); }); }
+int uvcgpu_region_hap_links(uvcgpu_region_t *r, UvcHapLink *links, int64_t link_capacity, int64_t *n_links, int32_t *muts, int64_t mut_capacity, int64_t *n_mut_ints) { return guarded("uvcgpu_region_hap_links", [&] { return uvcgpu_region_hap_links_impl(r, links, link_capacity, n_links, muts, mut_capacity, n_mut_ints); }); }
+int uvcgpu_region_score(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScoreOut *out) { return guarded("uvcgpu_region_score", [&] { return uvcgpu_region_score_impl(r, req, out); }); }
 
 void uvcgpu_region_destroy(uvcgpu_region_t *r) {
     if (!r) return;
