@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--depth", type=int, default=300)
     ap.add_argument("--umi", action="store_true", help="duplex-UMI families (BASELINE config 4 shape when combined with --depth 2000 --tile-kb 200)")
     ap.add_argument("--all-out", action="store_true", help="second series of SURVEY 8(d): score every symbol of every position (-A), not only the default-gate candidates")
+    ap.add_argument("--all-records", action="store_true", help="D2H of every scored record (the round-1 form) instead of only the record groups the VCF writer reads (UvcScoreRequest::kept_only)")
     ap.add_argument("--serial", action="store_true", help="no pipelining across tiles: preparation, accumulate and score of a tile strictly one after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the pcie_inclusive and resident measurements behind the timed region (profiler runs)")
@@ -224,7 +225,7 @@ def main():
         R.accumulate()
 
     def finish(k):
-        return Rs[k % T].score(all_out=args.all_out, capacity=cap, copy=False, release_state=True)
+        return Rs[k % T].score(all_out=args.all_out, capacity=cap, copy=False, release_state=True, kept_only=not args.all_records)
 
     names_buf = C.create_string_buffer(2048)
     ms_buf = (C.c_float * 48)()
@@ -321,10 +322,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "stream of %d DISTINCT chr20-shaped tumor-only %s tiles per GPU (%d kb at %dx, 150 bp paired-end), raw UvcReadSoA columns + region side arrays resident in HBM; "
                                    "step = one tile: set_reads(device half: CIGAR facts + family/fragment nesting, radix orders, k_pack_bq, k_aln_prelude, k_build_p2list) + accumulate P1..P5b + "
-                                   "default-gate scoring / calling + D2H of the records%s" % (T, "duplex-UMI" if args.umi else "non-UMI", args.tile_kb, args.depth,
+                                   "default-gate scoring / calling + D2H of %s%s" % (T, "duplex-UMI" if args.umi else "non-UMI", args.tile_kb, args.depth,
+                                   "every scored record" if args.all_records else "the record groups the VCF writer reads (kept_only: written records + the REF / genotype records of their positions)",
                                    "; tiles strictly one after the other" if args.serial else "; tiles software-pipelined over their handles (tile k+1 is prepared and accumulating while tile k is scored)"),
                        "tile_positions": region_len, "distinct_tiles": T, "pipelined": (not args.serial) and T >= 2, "all_out": bool(args.all_out), "umi": bool(args.umi), "reads_per_tile": n_reads_tile,
-                       "read_bases_per_tile": n_reads_tile * READ_LEN, "input_bytes_per_tile": input_bytes_tile, "scored_records_last_tile": n_rec,
+                       "read_bases_per_tile": n_reads_tile * READ_LEN, "input_bytes_per_tile": input_bytes_tile, "returned_records_last_tile": n_rec, "kept_only": not args.all_records,
                        "parallelism": "region-shard x%d (no collective on the data path)" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": replayed_traffic(dom, args.tile_kb, args.depth), "traffic_source": "replayed from profiles/traffic_latest.json (two separate rocprofv3 --pmc passes), not measured in this run",

@@ -297,7 +297,11 @@ typedef struct UvcScoreRequest {
                                  * exactly once, the records of one uncut region.  Needs pos_beg > region begin */
     int32_t region_beg;         /* incluBegPosition of the BED line this region belongs to (main.cpp:655-656): besides every refpos that is a
                                  * multiple of 1000 an MGVCF block also opens at refpos == region_beg.  0 = nothing beyond the multiples */
-    int32_t reserved_;
+    int32_t kept_only;          /* 1: return only the (zerobased_pos, symbol type) groups the record writer reads -- those with a written record
+                                 * (keep && out) or a GERMLINE line (germ_emit) -- all records of such a group, in the usual order, germ_ref /
+                                 * germ_alt1 / germ_alt2 re-based to the returned array.  UvcScoreOut::capacity then only has to hold these (a
+                                 * few thousand per Mb at the default gate instead of ~54 k): the D2H shrinks by an order of magnitude.
+                                 * uvcgpu_region_vcf_records writes the same text from either form */
     const char *const *tumor_sample_columns;   /* [n_tumor_keys] or NULL: the sample column of each tumor record as text.  Only the record writer reads
                                  * it: with is_tumor_format_retrieved the normal-sample line ends with the tumor's column (bcf1_to_string,
                                  * main.hpp:5897-5910, 6269; MGVCF / ADDITIONAL_INDEL_CANDIDATE lines: main.cpp:739-757, 784-798) */

@@ -53,4 +53,4 @@ if os.path.exists(exe):
             continue
         r = subprocess.run([exe, os.path.join(d, "t.bam"), "-f", os.path.join(d, "t.fa"), "-o", os.path.join(d, "o.vcf.gz"), "--targets", "chrT:%d-%d" % (beg + 1, end),
                             "--tile", str(tile), "-t", str(threads), "--timing", "--repeat", "4"], capture_output=True, text=True)
-        print("uvc1-mi355x tile %d, -t %d: %s" % (tile, threads, " | ".join(l.strip() for l in r.stderr.splitlines()[-3:])), flush=True)
+        print("uvc1-mi355x tile %d, -t %d: %s" % (tile, threads, " | ".join(l.strip() for l in r.stderr.splitlines() if "positions/s" in l or "thread-seconds" in l)), flush=True)

@@ -403,3 +403,40 @@ def test_germline_lines(name, oracle_lib, gpu_lib, ref_vcf):
         assert any(len(c[3]) != len(c[4].split(",")[0]) for c in germ)       # an InDel genotype with its REF / ALT text
     compare_lines(mine, want)
     Ro.close(); Rg.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,outvar", [("config1_10kb_30x", None), ("config2shape_5kb_300x", None), ("dense_indels_120x", 63), ("umi_duplex_2kb_400x", 63)])
+def test_kept_only_records_are_the_groups_the_writer_reads(name, outvar, gpu_lib):
+    """UvcScoreRequest::kept_only: the (position, symbol type) groups with a written record or a GERMLINE line, whole, in order, with
+    germ_ref / germ_alt1 / germ_alt2 re-based -- and the record writer produces the same text from them as from all records."""
+    reads = synth.generate_region(**dict(CASES, **HAP_CASES)[name])
+    p = region.default_params(gpu_lib)
+    if outvar is not None:
+        p.outvar_flag = outvar
+    R = run_region(gpu_lib, reads, params=p)
+    full = R.score()
+    kept = R.score(kept_only=True, capacity=64)                  # the caller's buffer only has to hold the kept groups (the mirror grows it on ENOMEM)
+    n = len(full["refpos"])
+    is_base = full["symbol"] <= 5
+    head = np.ones(n, bool)
+    head[1:] = (full["refpos"][1:] != full["refpos"][:-1]) | (is_base[1:] != is_base[:-1])
+    gid = np.cumsum(head) - 1
+    written = ((full["keep"] == 1) & (full["out"] == 1)) | (full["germ_emit"] == 1)
+    group_kept = np.zeros(gid.max() + 1, bool)
+    group_kept[gid[written]] = True
+    sel = np.nonzero(group_kept[gid])[0]
+    assert 0 < len(sel) < n and len(kept["refpos"]) == len(sel)
+    new_index = -np.ones(n, np.int64)
+    new_index[sel] = np.arange(len(sel))
+    for f in full:
+        want = full[f][sel]
+        if f in ("germ_ref", "germ_alt1", "germ_alt2"):
+            want = np.where(want >= 0, new_index[np.maximum(want, 0)], -1)
+            assert (want[full[f][sel] >= 0] >= 0).all()          # a genotype's records belong to its own group
+        assert np.array_equal(kept[f], want), f
+    assert R.vcf_records("chr20", kept) == R.vcf_records("chr20", full)
+    # all-out: everything is written, nothing to drop but LINK_NN-only groups
+    full_a, kept_a = R.score(all_out=True), R.score(all_out=True, kept_only=True)
+    assert R.vcf_records("chr20", kept_a) == R.vcf_records("chr20", full_a) and len(kept_a["refpos"]) <= len(full_a["refpos"])
+    R.close()

@@ -65,7 +65,7 @@ class UvcHapLink(C.Structure):
 class UvcScoreRequest(C.Structure):
     _fields_ = [("pos_beg", C.c_int32), ("pos_end", C.c_int32), ("all_out", C.c_int32), ("is_amplicon", C.c_int32),
                 ("n_indel_alleles", C.c_int64), ("indel_alleles", C.c_void_p), ("n_tumor_keys", C.c_int64), ("tumor_keys", C.c_void_p),
-                ("release_state", C.c_int32), ("base_at_pos_beg", C.c_int32), ("region_beg", C.c_int32), ("reserved_", C.c_int32),
+                ("release_state", C.c_int32), ("base_at_pos_beg", C.c_int32), ("region_beg", C.c_int32), ("kept_only", C.c_int32),
                 ("tumor_sample_columns", C.c_void_p), ("tumor_ref_alt", C.c_void_p)]
 
 

@@ -102,7 +102,7 @@ struct Worker {
     std::vector<int32_t> pos, mpos, isize, nm, lq, ncig, fragp, famp; std::vector<uint16_t> flag; std::vector<uint8_t> mapq, strandp; std::vector<int64_t> soff, coff;
     std::vector<int32_t> fields; std::string ref;
     double t_fetch = 0, t_group = 0, t_region = 0, t_reads = 0, t_gpu = 0, t_text = 0;
-    int64_t n_tiles = 0;
+    int64_t n_tiles = 0, score_cap = 0, text_cap = 0;   // what the last tiles needed: the next call asks for it at once
 };
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -166,23 +166,31 @@ bool call_tile(Worker &w, const Opts &o, const UvcParams &P, const Tile &t, int6
         if (uvcio_tumor_vcf_fetch(tvcf, t.tid, (int32_t)ext_beg, (int32_t)ext_end, &keys, &cols, &ras, &nk)) die(uvcio_last_error());
         rq.tumor_keys = keys; rq.n_tumor_keys = nk; rq.tumor_sample_columns = (o.tumor_format ? cols : nullptr); rq.tumor_ref_alt = ras;
     }
-    int64_t cap = std::max<int64_t>(4096, uvcgpu_region_score_size(w.reg, &rq) / (o.all_out ? 1 : 4));
+    rq.kept_only = 1;   // only the record groups that are written travel to the host
+    int64_t cap = std::max<int64_t>(std::max<int64_t>(4096, w.score_cap), uvcgpu_region_score_size(w.reg, &rq) / (o.all_out ? 1 : 64));
     UvcScoreOut so;
     for (;;) {
         w.fields.resize((size_t)UVC_NUM_SCORE_FIELDS * (size_t)cap);
         so.capacity = cap; so.n_records = 0; so.fields = w.fields.data();
         rc = uvcgpu_region_score(w.reg, &rq, &so);
-        if (rc == UVCGPU_ENOMEM && so.n_records > cap) { cap = so.n_records; continue; }
+        if (rc == UVCGPU_ENOMEM && so.n_records > cap) { cap = so.n_records + so.n_records / 4; continue; }
         if (rc) die(uvcgpu_last_error());
         break;
     }
+    w.score_cap = cap;
     w.t_gpu += now() - t0; t0 = now();
-    int64_t len = 0;
-    rc = uvcgpu_region_vcf_records(w.reg, t.chrom.c_str(), &so, &rq, nullptr, 0, &len);
-    if (rc && rc != UVCGPU_ENOMEM) die(uvcgpu_last_error());
+    // one call with a buffer as large as the last tile needed (+ slack); a second one only when the text did not fit
     const size_t at = lines.size();
+    int64_t len = 0, room = std::max<int64_t>(1 << 16, w.text_cap);
+    for (;;) {
+        lines.resize(at + (size_t)room);
+        rc = uvcgpu_region_vcf_records(w.reg, t.chrom.c_str(), &so, &rq, &lines[at], room, &len);
+        if (rc == UVCGPU_ENOMEM && len > room) { room = len + len / 4; continue; }
+        if (rc) die(uvcgpu_last_error());
+        break;
+    }
     lines.resize(at + (size_t)len);
-    if (len && uvcgpu_region_vcf_records(w.reg, t.chrom.c_str(), &so, &rq, &lines[at], len, &len)) die(uvcgpu_last_error());
+    w.text_cap = std::max<int64_t>(w.text_cap, len + len / 4);
     w.t_text += now() - t0;
     return true;
 }

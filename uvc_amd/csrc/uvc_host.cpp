@@ -32,7 +32,7 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
                                       const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof,
                                       hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join, hipEvent_t e_fork2);
 extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles, const int32_t *d_allele_rows, int64_t n_alleles,
-                                const UvcGapRow *d_gap_rows, const uint8_t *d_gap_seq, const UvcTumorKey *d_tkeys, int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch, hipStream_t s);
+                                const UvcGapRow *d_gap_rows, const uint8_t *d_gap_seq, const UvcTumorKey *d_tkeys, int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch, int32_t *d_fields_kept, hipStream_t s);
 extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored);
 extern "C" void uvc_launch_block_stats(const RegionDev *R, const UvcParams *P, int64_t x0, int64_t n, int32_t *d_out, hipStream_t s);
 extern "C" size_t uvc_gap_sort_tmp_bytes(size_t n);
@@ -83,6 +83,7 @@ struct uvcgpu_region {
     // persistent scoring buffers (grown on demand)
     long long *d_score_scratch = nullptr; size_t score_scratch_bytes = 0;
     int32_t *d_score_fields = nullptr; int64_t score_capacity = 0; int64_t *d_score_count = nullptr;
+    int32_t *d_score_kept = nullptr; int64_t score_kept_capacity = 0;   // UvcScoreRequest::kept_only: the compacted copy, same pitch as d_score_fields
     // InDel allele tables of the last accumulate (built on first use by gap_tables)
     bool gap_ready = false;
     std::vector<UvcGapRow> gap_rows; std::vector<uint8_t> gap_seq;
@@ -913,14 +914,12 @@ static int uvcgpu_region_score_impl(uvcgpu_region_t *r, const UvcScoreRequest *r
         HIP_OK(hipMalloc((void **)&d_tk, sizeof(UvcTumorKey) * rq.n_tumor_keys));
         HIP_OK(hipMemcpyAsync(d_tk, rq.tumor_keys, sizeof(UvcTumorKey) * rq.n_tumor_keys, hipMemcpyHostToDevice, r->stream));
     }
-    const int64_t cap = std::max<int64_t>(out->capacity, 1);
-    if (cap > r->score_capacity) {
-        if (r->d_score_fields) hipFree(r->d_score_fields);
-        r->d_score_fields = nullptr; r->score_capacity = 0;
-        HIP_OK(hipMalloc((void **)&r->d_score_fields, sizeof(int32_t) * UVC_NUM_SCORE_FIELDS * cap));
-        r->score_capacity = cap;
-    }
-    if (!r->d_score_count) HIP_OK(hipMalloc((void **)&r->d_score_count, 8));
+    const bool kept_only = (rq.kept_only != 0);
+    // device capacity: the caller's in the plain form; with kept_only the caller's buffer only has to hold the kept groups, the device
+    // array every record -- start from a guess and grow once if the count says so
+    int64_t cap = std::max<int64_t>(out->capacity, 1);
+    if (kept_only) cap = std::max<int64_t>(std::max<int64_t>(cap, r->score_capacity), (int64_t)(rq.pos_end - rq.pos_beg) / 8 + 4096);
+    if (!r->d_score_count) HIP_OK(hipMalloc((void **)&r->d_score_count, 16));
     const size_t need = uvc_score_scratch_bytes(rq.pos_end - rq.pos_beg);
     if (need > r->score_scratch_bytes) {
         if (r->d_score_scratch) hipFree(r->d_score_scratch);
@@ -928,23 +927,44 @@ static int uvcgpu_region_score_impl(uvcgpu_region_t *r, const UvcScoreRequest *r
         HIP_OK(hipMalloc((void **)&r->d_score_scratch, need));
         r->score_scratch_bytes = need;
     }
-    HIP_OK(hipMemsetAsync(r->d_score_count, 0, 8, r->stream));
-    int rc = uvc_launch_score(&r->R, &r->P, &rq, use_al, use_row, n_al, r->d_gap_rows, r->d_gap_seq, d_tk, r->d_score_fields, r->score_capacity, r->d_score_count, r->d_score_scratch, r->stream);
-    if (!rc && hipGetLastError() != hipSuccess) rc = fail(UVCGPU_EDEVICE, "score kernel launch failed");
-    if (!rc) rc = uvcgpu_region_sync(r);
-    int64_t cnt = 0;
-    // copies on the handle's own stream: a null-stream hipMemcpy would also wait for every other handle's work
-    if (!rc && (hipMemcpyAsync(&cnt, r->d_score_count, 8, hipMemcpyDeviceToHost, r->stream) != hipSuccess || hipStreamSynchronize(r->stream) != hipSuccess)) rc = fail(UVCGPU_EDEVICE, "hipMemcpy(count)");
+    int rc = 0;
+    int64_t cnt[2] = { 0, 0 };
+    for (int attempt = 0; attempt < 2 && !rc; attempt++) {
+        if (cap > r->score_capacity) {
+            if (r->d_score_fields) hipFree(r->d_score_fields);
+            r->d_score_fields = nullptr; r->score_capacity = 0;
+            HIP_OK(hipMalloc((void **)&r->d_score_fields, sizeof(int32_t) * UVC_NUM_SCORE_FIELDS * cap));
+            r->score_capacity = cap;
+        }
+        if (kept_only && r->score_kept_capacity != r->score_capacity) {
+            if (r->d_score_kept) hipFree(r->d_score_kept);
+            r->d_score_kept = nullptr; r->score_kept_capacity = 0;
+            HIP_OK(hipMalloc((void **)&r->d_score_kept, sizeof(int32_t) * UVC_NUM_SCORE_FIELDS * r->score_capacity));
+            r->score_kept_capacity = r->score_capacity;
+        }
+        HIP_OK(hipMemsetAsync(r->d_score_count, 0, 16, r->stream));
+        rc = uvc_launch_score(&r->R, &r->P, &rq, use_al, use_row, n_al, r->d_gap_rows, r->d_gap_seq, d_tk, r->d_score_fields, r->score_capacity, r->d_score_count, r->d_score_scratch,
+                              kept_only ? r->d_score_kept : nullptr, r->stream);
+        if (!rc && hipGetLastError() != hipSuccess) rc = fail(UVCGPU_EDEVICE, "score kernel launch failed");
+        if (!rc) rc = uvcgpu_region_sync(r);
+        // copies on the handle's own stream: a null-stream hipMemcpy would also wait for every other handle's work
+        if (!rc && (hipMemcpyAsync(cnt, r->d_score_count, 16, hipMemcpyDeviceToHost, r->stream) != hipSuccess || hipStreamSynchronize(r->stream) != hipSuccess)) rc = fail(UVCGPU_EDEVICE, "hipMemcpy(count)");
+        if (rc || !kept_only || cnt[0] <= r->score_capacity) break;
+        cap = cnt[0] + cnt[0] / 8;   // the guess was too small: nothing was written, once more with room for every record
+    }
     if (!rc) {
-        out->n_records = cnt;
-        if (cnt > out->capacity) rc = fail(UVCGPU_ENOMEM, "score output capacity too small");   // the planes stay: the caller comes back with a larger buffer
+        const int64_t n_out = (kept_only ? cnt[1] : cnt[0]);
+        const int32_t *src = (kept_only ? r->d_score_kept : r->d_score_fields);
+        out->n_records = n_out;
+        if (kept_only && cnt[0] > r->score_capacity) rc = fail(UVCGPU_EDEVICE, "score: the record count changed between two passes");
+        else if (n_out > out->capacity) rc = fail(UVCGPU_ENOMEM, "score output capacity too small");   // the planes stay: the caller comes back with a larger buffer
         else if (rq.release_state && r->side) {   // the scoring kernels are done: zero the planes on the side stream under the D2H of the records
             if (hipEventRecord(r->e_fork, r->stream) == hipSuccess && hipStreamWaitEvent(r->side, r->e_fork, 0) == hipSuccess
                 && hipMemsetAsync(r->d_state, 0, r->buckets_clean ? r->bucket_off : r->state_bytes, r->side) == hipSuccess && hipEventRecord(r->e_join, r->side) == hipSuccess) {
                 r->state_released = true; r->state_zeroed = true;
             }
         }
-        if (!rc && cnt > 0 && (hipMemcpy2DAsync(out->fields, sizeof(int32_t) * out->capacity, r->d_score_fields, sizeof(int32_t) * r->score_capacity, sizeof(int32_t) * cnt, UVC_NUM_SCORE_FIELDS, hipMemcpyDeviceToHost, r->stream) != hipSuccess
+        if (!rc && n_out > 0 && (hipMemcpy2DAsync(out->fields, sizeof(int32_t) * out->capacity, src, sizeof(int32_t) * r->score_capacity, sizeof(int32_t) * n_out, UVC_NUM_SCORE_FIELDS, hipMemcpyDeviceToHost, r->stream) != hipSuccess
                              || hipStreamSynchronize(r->stream) != hipSuccess))
             rc = fail(UVCGPU_EDEVICE, "hipMemcpy2D(records)");
     }
@@ -980,6 +1000,7 @@ void uvcgpu_region_destroy(uvcgpu_region_t *r) {
     if (r->d_score_scratch) hipFree(r->d_score_scratch);
     if (r->d_score_fields) hipFree(r->d_score_fields);
     if (r->d_score_count) hipFree(r->d_score_count);
+    if (r->d_score_kept) hipFree(r->d_score_kept);
     if (r->d_gap_alleles) hipFree(r->d_gap_alleles);
     if (r->d_gap_allele_row) hipFree(r->d_gap_allele_row);
     if (r->d_gap_rows) hipFree(r->d_gap_rows);

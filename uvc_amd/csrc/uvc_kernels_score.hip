@@ -1137,8 +1137,43 @@ __global__ void __launch_bounds__(128) k_call(RegionDev R, UvcParams P, ScoreCtx
     }
 }
 
+// ---- UvcScoreRequest::kept_only: the groups that are written travel, nothing else ----
+// A (zerobased_pos, symbol type) group is kept iff one of its records is written (keep && out) or it has a GERMLINE line (germ_emit): the
+// record writer reads the REF record and the genotype's records of such a group and nothing of the others.  Kept groups keep their order;
+// germ_ref / germ_alt1 / germ_alt2 (record indices inside the group) move with it.
+__global__ void __launch_bounds__(256) k_keep_count(ScoreCtx C, long long ngroups, long long *counts2) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    const long long r0 = PK_COUNT(C.offsets[g]), r1 = PK_COUNT(C.offsets[g + 1]);
+    const int32_t *fields = C.fields; const long long capacity = C.capacity;
+    long long n = 0;
+    if (r1 <= capacity) for (long long r = r0; r < r1; r++) if ((FLD(UVC_O_keep, r) && FLD(UVC_O_out, r)) || FLD(UVC_O_germ_emit, r)) { n = r1 - r0; break; }
+    counts2[g] = n;
+}
+#define KEEP_LANES 8
+__global__ void __launch_bounds__(256) k_keep_copy(ScoreCtx C, long long ngroups, const long long *counts2, const long long *offsets2, int32_t *fields2) {
+    const long long n_active = PK_FLAGS(C.offsets[ngroups]);
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long ai = t / KEEP_LANES; const int sub = (int)(t % KEEP_LANES);
+    if (ai >= n_active) return;
+    const long long g = C.active[ai];
+    const long long n = counts2[g];
+    if (n == 0) return;
+    const long long r0 = PK_COUNT(C.offsets[g]), q0 = PK_COUNT(offsets2[g]);
+    const int32_t *fields = C.fields; const long long capacity = C.capacity;
+    for (int f = sub; f < UVC_NUM_SCORE_FIELDS; f += KEEP_LANES) {
+        const bool is_index = (f == UVC_O_germ_ref || f == UVC_O_germ_alt1 || f == UVC_O_germ_alt2);
+        for (long long k = 0; k < n; k++) {
+            int32_t v = fields[(size_t)f * capacity + r0 + k];
+            if (is_index && v >= 0) v = (int32_t)(v - r0 + q0);
+            fields2[(size_t)f * capacity + q0 + k] = v;
+        }
+    }
+}
+
 extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles, const int32_t *d_allele_rows, int64_t n_alleles,
-                                const UvcGapRow *d_gap_rows, const uint8_t *d_gap_seq, const UvcTumorKey *d_tkeys, int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch /* 2*ngroups + nblocks + 2 words + ngroups ints */, hipStream_t s) {
+                                const UvcGapRow *d_gap_rows, const uint8_t *d_gap_seq, const UvcTumorKey *d_tkeys, int32_t *d_fields, int64_t capacity, int64_t *d_count /* [2]: all records, kept records */,
+                                long long *scratch /* uvc_score_scratch_bytes */, int32_t *d_fields_kept /* kept_only: a second [fields][capacity] array */, hipStream_t s) {
     ScoreCtx C;
     C.pos_beg = req->pos_beg; C.pos_end = req->pos_end; C.all_out = (req->all_out || P->should_output_all) ? 1 : 0; C.is_amplicon = req->is_amplicon; C.base_at_beg = req->base_at_pos_beg ? 1 : 0;
     C.alleles = d_alleles; C.allele_rows = d_allele_rows; C.n_alleles = n_alleles; C.gap_rows = d_gap_rows; C.gap_seq = d_gap_seq; C.tkeys = d_tkeys; C.n_tkeys = (d_tkeys ? req->n_tumor_keys : 0); C.fields = d_fields; C.capacity = capacity;
@@ -1156,12 +1191,26 @@ extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const Uv
     hipLaunchKernelGGL(k_score, dim3(grid), dim3(128), 0, s, *R, *P, C);
     const long long npos_scored = C.pos_end - C.pos_beg;
     hipLaunchKernelGGL(k_call, dim3((unsigned)((npos_scored / 8 + 127) / 128 < 2048 ? (npos_scored / 8 + 127) / 128 + 1 : 2048)), dim3(128), 0, s, *R, *P, C);
+    if (req->kept_only && d_fields_kept) {
+        // second half of the scratch: counts2 [ngroups], offsets2 [ngroups + 1], block sums [nblocks + 1]
+        long long *counts2 = (long long *)((char *)scratch + (((size_t)((2 * ngroups + 1 + nblocks + 1) * 8 + ngroups * 4 + 64) + 7) & ~(size_t)7));
+        long long *offsets2 = counts2 + ngroups, *block_sums2 = offsets2 + ngroups + 1;
+        hipLaunchKernelGGL(k_keep_count, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, s, C, ngroups, counts2);
+        hipLaunchKernelGGL(k_scan_local, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, counts2, offsets2, block_sums2, ngroups);
+        hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, block_sums2, nblocks, offsets2, ngroups, (long long *)d_count + 1);
+        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, s, counts2, offsets2, block_sums2, (int *)nullptr, ngroups);   // counts2 carries no flag bits: nothing is listed
+        // one thread per (active group, field lane); the grid covers every group that could be active (the list length lives on the device)
+        const long long max_active = ngroups;
+        const long long threads = max_active * KEEP_LANES;
+        hipLaunchKernelGGL(k_keep_copy, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, C, ngroups, counts2, offsets2, d_fields_kept);
+    }
     return 0;
 }
 extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored) {
     const long long ngroups = 2LL * npos_scored;
     const long long nblocks = (ngroups + SCAN_BLOCK * SCAN_ITEMS - 1) / (SCAN_BLOCK * SCAN_ITEMS);
-    return (size_t)((2 * ngroups + 1 + nblocks + 1) * 8 + ngroups * 4 + 64);
+    const size_t first = (size_t)((2 * ngroups + 1 + nblocks + 1) * 8 + ngroups * 4 + 64);
+    return first + (size_t)((2 * ngroups + 1 + nblocks + 1) * 8 + 64);   // + the kept_only scan
 }
 
 // ---- position-level numbers of the VCF writer: the MGVCF block lines (main.cpp:655-735) and ADDITIONAL_INDEL_CANDIDATE (main.cpp:759-799) ----

@@ -235,12 +235,13 @@ class Region:
 
     @staticmethod
     def make_request(all_out=False, pos_beg=-1, pos_end=-1, is_amplicon=False, indel_alleles=None, tumor_keys=None, release_state=False, base_at_pos_beg=False, region_beg=0,
-                     tumor_sample_columns=None, tumor_ref_alt=None):
+                     tumor_sample_columns=None, tumor_ref_alt=None, kept_only=False):
         """UvcScoreRequest + the ctypes arrays it points into (keep both alive for the call)."""
         req = _ffi.UvcScoreRequest()
         req.pos_beg, req.pos_end, req.all_out, req.is_amplicon = pos_beg, pos_end, int(all_out), int(is_amplicon)
         req.release_state = int(release_state)   # the planes may be zeroed for the next accumulate as soon as the scoring kernels are done
         req.base_at_pos_beg, req.region_beg = int(base_at_pos_beg), int(region_beg)
+        req.kept_only = int(kept_only)           # only the (position, symbol type) groups the record writer reads
         arr = None
         if indel_alleles:
             arr = (_ffi.UvcIndelAllele * len(indel_alleles))(*[_ffi.UvcIndelAllele(*a) for a in indel_alleles])
@@ -281,8 +282,9 @@ class Region:
             out[l.which].append((pairs, (l.fr_cnt[0], l.fr_cnt[1]), (l.other_cnt[0], l.other_cnt[1])))
         return out
 
-    def score(self, all_out=False, pos_beg=-1, pos_end=-1, is_amplicon=False, indel_alleles=None, capacity=None, copy=True, tumor_keys=None, release_state=False, base_at_pos_beg=False, region_beg=0):
-        req, _keep = self.make_request(all_out, pos_beg, pos_end, is_amplicon, indel_alleles, tumor_keys, release_state, base_at_pos_beg, region_beg)
+    def score(self, all_out=False, pos_beg=-1, pos_end=-1, is_amplicon=False, indel_alleles=None, capacity=None, copy=True, tumor_keys=None, release_state=False, base_at_pos_beg=False, region_beg=0,
+              kept_only=False):
+        req, _keep = self.make_request(all_out, pos_beg, pos_end, is_amplicon, indel_alleles, tumor_keys, release_state, base_at_pos_beg, region_beg, kept_only=kept_only)
         if capacity is None:
             npos = (pos_end - pos_beg) if pos_beg >= 0 else self.npos
             capacity = 14 * (npos + 1) if all_out else max(4096, 4 * (npos + 1))
