@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1
+timeout -k 10 900 python -m pytest tests -m gpu -x -q --capture=sys > gpurun_out/gpu_tests.log 2>&1
 rc=$?
 tail -25 gpurun_out/gpu_tests.log
 [ $rc -ne 0 ] && exit $rc

@@ -22,7 +22,7 @@ def dll():
 
 def declared_symbols():
     names = set()
-    for hdr in ("uvcgpu.h", "uvcgroup.h"):
+    for hdr in ("uvcgpu.h", "uvcgroup.h", "uvcconsensus.h"):
         txt = open(os.path.join(ROOT, "include", hdr)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         names |= set(re.findall(r"\b(uvcgpu_[a-z_0-9]+)\s*\(", txt))

@@ -6,6 +6,9 @@
 #include "uvc_hap.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -333,6 +336,18 @@ inline void st_symbols(int st, int &first, int &count, int &nn) { if (st == UVC_
 void put(std::string &o, int64_t v) { char b[32]; snprintf(b, sizeof(b), "%lld", (long long)v); o += b; }
 void put2(std::string &o, int64_t a, int64_t b) { put(o, a); o += ','; put(o, b); }
 
+// UVCGPU_TIMING=1: where the record writer spends its time (stderr)
+struct VcfTimer {
+    bool on; std::chrono::steady_clock::time_point t;
+    VcfTimer() : on(getenv("UVCGPU_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void lap(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[uvcgpu vcf_records] %-36s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 // indelpos_to_context, main.hpp:733-755
 void repeat_context(const std::string &ref, int32_t at, int32_t smax, std::string &unit, int32_t &num) {
     num = 0; unit.clear();
@@ -464,7 +479,10 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
     }
     std::vector<std::pair<int32_t, std::string>> rec_lines;   // (zerobased_pos of the iteration that writes it, line)
     const std::vector<UvcHapLinkHost> *hap = nullptr;
+    VcfTimer timer;
+    timer.lap("written records + their REF records");
     if (!kept.empty()) { hap = uvcgpu_region_hap_(r); if (!hap) return UVCGPU_EDEVICE; }
+    timer.lap("haplotype links");
     if (!kept.empty()) {
         const int32_t ncol = uvcgpu_region_n_columns();
         std::vector<int32_t> where(kept.size());
@@ -725,6 +743,7 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
         }
     }
     std::string out;
+    timer.lap("record + GERMLINE lines");
 // ---- the position-level lines, in front of the records of their zerobased_pos (main.cpp:607-799) ----
     {
         if (pos_beg < 0) { pos_beg = beg + 1; pos_end = end; }   // the default range of uvcgpu_region_score
@@ -735,6 +754,7 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
             const int32_t s_beg = pos_beg - 1, s_end = std::min<int64_t>((int64_t)pos_end - 1 + 1001, state_end);
             std::vector<int32_t> st((size_t)10 * (size_t)std::max(0, s_end - s_beg));
             if (s_end > s_beg) { const int rc = uvcgpu_region_block_stats_(r, s_beg, s_end, st.data()); if (rc) return rc; }
+            timer.lap("block statistics (kernel + D2H)");
             auto S = [&](int32_t refpos, int q) { return st[(size_t)10 * (size_t)(refpos - s_beg) + (size_t)q]; };
             auto refchar = [&](int64_t off) { return (off >= 0 && off < (int64_t)ref.size()) ? ref[(size_t)off] : 'N'; };
             auto code_of = [](char c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; case 'I': case 'i': return 6; case '-': case '_': return 9; default: return 4; } };
@@ -794,6 +814,7 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
                 prev_track = curr_track;
             }
         }
+        timer.lap("MGVCF / indel-candidate lines");
         size_t a = 0, b = 0, g = 0;   // at one zerobased_pos: block / candidate lines, GERMLINE lines, records
         while (a < pos_lines.size() || b < rec_lines.size() || g < germ_lines.size()) {
             const int32_t za = (a < pos_lines.size() ? pos_lines[a].first : INT32_MAX), zg = (g < germ_lines.size() ? germ_lines[g].first : INT32_MAX), zb = (b < rec_lines.size() ? rec_lines[b].first : INT32_MAX);
