@@ -91,6 +91,9 @@ int uvcio_tumor_vcf_fetch(const uvcio_tumor_vcf_t *v, int32_t tid, int32_t pos_b
                           const char *const **ref_alts, int64_t *n);
 void uvcio_tumor_vcf_close(uvcio_tumor_vcf_t *v);
 
+/* CRC-32 (the zlib / BGZF footer polynomial) as the reader and the writer compute it: carry-less multiplication on CPUs that have it. */
+uint32_t uvcio_crc32(const void *p, int64_t n);
+
 /* ---- region shards ----
  * The reference balances its chunks by reads and positions (main.cpp:1380-1400).  Without reading the alignments the cost of a tile is
  * estimated from the BAI linear index: the compressed bytes between the 16 kb windows that hold its two ends (0 without an index). */

@@ -230,3 +230,17 @@ def test_tumor_vcf_reader(tmp_path):
     open(bad, "w").write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\nchrA\t5\t.\tA\tC\t1\t.\t.\tGT:VTI:BDPb\t./1:0,1:7\n")
     with pytest.raises(IOError):
         uio.TumorVcf(bad, ["chrA"])
+
+
+def test_crc32_equals_zlib():
+    """uvcio_crc32 (carry-less-multiplication folding where the CPU has it, zlib's table walk otherwise) against zlib.crc32 at every
+    length around the 16- and 64-byte steps of the folding loop and at BGZF block sizes."""
+    import ctypes
+    import zlib
+    dll = uio.dll()
+    dll.uvcio_crc32.restype = ctypes.c_uint32
+    dll.uvcio_crc32.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+    rng = np.random.default_rng(0)
+    for n in list(range(1, 200)) + [255, 256, 1000, 4095, 4096, 0xff00, 0xff01, 100003]:
+        b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert dll.uvcio_crc32(b, n) == zlib.crc32(b), n

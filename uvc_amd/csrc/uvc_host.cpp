@@ -804,12 +804,16 @@ static int uvcgpu_region_indel_alleles_impl(uvcgpu_region_t *r, UvcGapRow *rows,
 // ---- haplotype links: hap_bq / hap_fq / hap_f2q of updateByRegion3Aln (main.hpp:3665-3742) ----
 // Built on request (the record writer and uvcgpu_region_hap_links ask): candidate fragments / units -> their mutated (position, symbol)
 // lists on the device (k_hap_*), maps + updateHapMap on the host (uvc_hap.cpp).  Needs the planes (P5's cDPM / cDPm).
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static int hap_tables(uvcgpu_region_t *r) {
     if (r->hap_ready) return 0;
     if (!r->accumulated) return fail(UVCGPU_ESTATE, "haplotype links before accumulate");
     if (r->state_released) return fail(UVCGPU_ESTATE, "the planes were released by the last score (UvcScoreRequest::release_state)");
     const RegionDev &R = r->R;
     std::vector<int32_t> events;
+    const bool timing = (getenv("UVCGPU_TIMING") != nullptr);
+    double t_prev = now_s();
+    auto lap = [&](const char *what, long long n) { if (timing) { const double t = now_s(); fprintf(stderr, "[uvcgpu hap_links] %-34s %8.2f ms (%lld)\n", what, 1e3 * (t - t_prev), n); t_prev = t; } };
     struct Tmp { std::vector<void *> p; hipStream_t s; ~Tmp() { (void)hipStreamSynchronize(s); for (void *q : p) hipFree(q); } } tmp; tmp.s = r->stream;
     auto get = [&](size_t bytes) -> void * { void *q = nullptr; if (hipMalloc(&q, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr; tmp.p.push_back(q); return q; };
     for (int units = 0; units < 2; units++) {
@@ -826,6 +830,7 @@ static int hap_tables(uvcgpu_region_t *r) {
         struct { int32_t n_cand, pad; unsigned long long total; } c;
         HIP_OK(hipMemcpyAsync(&c, ctr, 16, hipMemcpyDeviceToHost, r->stream));
         HIP_OK(hipStreamSynchronize(r->stream));
+        lap(units ? "candidates of units" : "candidates of fragments", (long long)c.n_cand);
         if (c.n_cand == 0) continue;
         if (c.total >= ((unsigned long long)1 << 31)) return fail(UVCGPU_EUNSUPPORTED, "more than 2^31 haplotype event slots in one region");
         H.events = (int32_t *)get(4 * (size_t)c.total);
@@ -837,9 +842,11 @@ static int hap_tables(uvcgpu_region_t *r) {
         events.resize(at + (size_t)c.total);
         HIP_OK(hipMemcpyAsync(events.data() + at, H.events, 4 * (size_t)c.total, hipMemcpyDeviceToHost, r->stream));
         HIP_OK(hipStreamSynchronize(r->stream));
+        lap(units ? "events of units + D2H" : "events of fragments + D2H", (long long)c.total);
     }
     { const int rc = uvcgpu_region_sync(r); if (rc) return rc; }
     uvc_hap_build(events.data(), (int64_t)events.size(), r->beg, r->npos, r->P.phasing_haplotype_max_count, r->P.phasing_haplotype_min_ad, r->P.phasing_haplotype_max_detail_cnt, r->hap);
+    lap("maps + links (host)", (long long)(r->hap[0].size() + r->hap[1].size() + r->hap[2].size()));
     r->hap_ready = true;
     return 0;
 }

@@ -13,13 +13,19 @@
 #include <map>
 #include <string>
 #include <thread>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <vector>
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 extern "C" const char *uvcio_last_error(void) { return g_err.c_str(); }
+namespace { uint32_t block_crc32(const uint8_t *p, size_t n); }
+extern "C" uint32_t uvcio_crc32(const void *p, int64_t n) { return (p && n > 0) ? block_crc32((const uint8_t *)p, (size_t)n) : 0u; }
 
 namespace {
+uint32_t block_crc32(const uint8_t *p, size_t n);   // CRC-32 of a BGZF block (carry-less multiplication where the CPU has it), defined below
 
 inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -65,7 +71,7 @@ struct Bgzf {
             const int rc = inflate(&zs, Z_FINISH);
             inflateEnd(&zs);
             if (rc != Z_STREAM_END || zs.total_out != isize) return false;
-            if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), buf.data(), isize) != le32(comp.data() + cdata)) return false;
+            if (block_crc32(buf.data(), isize) != le32(comp.data() + cdata)) return false;
         }
         block_addr = addr; next_addr = addr + bsize + 1; off = 0; eof = false;
         return true;
@@ -213,6 +219,59 @@ template <class F> void parallel_for(size_t n, F f) {   // f(first, last) on con
     for (size_t t = 0; t < nt; t++) th.emplace_back([=] { f(n * t / nt, n * (t + 1) / nt); });
     for (std::thread &x : th) x.join();
 }
+// CRC-32 of a block with carry-less multiplication (the folding scheme of Intel's "Fast CRC computation using PCLMULQDQ", constants
+// for the reflected polynomial 0xEDB88320): zlib 1.2.11's table walk does 1.1 GB/s, a quarter of the time of inflating a BGZF block.
+#if defined(__x86_64__)
+__attribute__((target("pclmul,sse4.1"))) static uint32_t crc32_fold(const uint8_t *buf, size_t len, uint32_t crc) {   // len >= 64, multiple of 16; crc = ~running value
+    alignas(16) static const uint64_t k1k2[2] = { 0x0154442bd4ULL, 0x01c6e41596ULL };
+    alignas(16) static const uint64_t k3k4[2] = { 0x01751997d0ULL, 0x00ccaa009eULL };
+    alignas(16) static const uint64_t k5k0[2] = { 0x0163cd6124ULL, 0x0000000000ULL };
+    alignas(16) static const uint64_t poly[2] = { 0x01db710641ULL, 0x01f7011641ULL };
+    __m128i x0, x1, x2, x3, x4, x5, x6, x7, x8, y5, y6, y7, y8;
+    x1 = _mm_loadu_si128((const __m128i *)(buf + 0x00)); x2 = _mm_loadu_si128((const __m128i *)(buf + 0x10));
+    x3 = _mm_loadu_si128((const __m128i *)(buf + 0x20)); x4 = _mm_loadu_si128((const __m128i *)(buf + 0x30));
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)crc));
+    x0 = _mm_load_si128((const __m128i *)k1k2);
+    buf += 64; len -= 64;
+    while (len >= 64) {   // four lanes of 16 bytes folded over 64 bytes
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x6 = _mm_clmulepi64_si128(x2, x0, 0x00); x7 = _mm_clmulepi64_si128(x3, x0, 0x00); x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x2 = _mm_clmulepi64_si128(x2, x0, 0x11); x3 = _mm_clmulepi64_si128(x3, x0, 0x11); x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+        y5 = _mm_loadu_si128((const __m128i *)(buf + 0x00)); y6 = _mm_loadu_si128((const __m128i *)(buf + 0x10));
+        y7 = _mm_loadu_si128((const __m128i *)(buf + 0x20)); y8 = _mm_loadu_si128((const __m128i *)(buf + 0x30));
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5); x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), y7); x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), y8);
+        buf += 64; len -= 64;
+    }
+    x0 = _mm_load_si128((const __m128i *)k3k4);   // the four lanes into one
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+    while (len >= 16) {
+        x2 = _mm_loadu_si128((const __m128i *)buf);
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+        buf += 16; len -= 16;
+    }
+    x2 = _mm_clmulepi64_si128(x1, x0, 0x10);   // 128 -> 64 bits
+    x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+    x1 = _mm_srli_si128(x1, 8); x1 = _mm_xor_si128(x1, x2);
+    x0 = _mm_loadl_epi64((const __m128i *)k5k0);
+    x2 = _mm_srli_si128(x1, 4); x1 = _mm_and_si128(x1, x3); x1 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_xor_si128(x1, x2);
+    x0 = _mm_load_si128((const __m128i *)poly);   // Barrett reduction to 32 bits
+    x2 = _mm_and_si128(x1, x3); x2 = _mm_clmulepi64_si128(x2, x0, 0x10); x2 = _mm_and_si128(x2, x3); x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+static const bool g_have_pclmul = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+#else
+static const bool g_have_pclmul = false;
+static uint32_t crc32_fold(const uint8_t *, size_t, uint32_t c) { return c; }
+#endif
+uint32_t block_crc32(const uint8_t *p, size_t n) {
+    if (!g_have_pclmul || n < 64) return (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
+    const size_t body = n & ~(size_t)15;
+    const uint32_t c = ~crc32_fold(p, body, ~0u);
+    return (n > body) ? (uint32_t)crc32(c, p + body, (uInt)(n - body)) : c;
+}
 bool inflate_block(const uint8_t *blk, uint32_t csize, uint8_t *dst, uint32_t isize) {
     const int xlen = le16(blk + 10);
     const uint8_t *cdata = blk + 12 + xlen;
@@ -224,7 +283,7 @@ bool inflate_block(const uint8_t *blk, uint32_t csize, uint8_t *dst, uint32_t is
     zs.next_in = const_cast<uint8_t *>(cdata); zs.avail_in = (uInt)clen; zs.next_out = dst; zs.avail_out = isize;
     const int rc = inflate(&zs, Z_FINISH);
     inflateEnd(&zs);
-    return rc == Z_STREAM_END && zs.total_out == isize && (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, isize) == le32(blk + csize - 8);
+    return rc == Z_STREAM_END && zs.total_out == isize && block_crc32(dst, isize) == le32(blk + csize - 8);
 }
 const uint8_t NT16_INT[16] = { 4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4 };   // seq_nt16_int of htslib: =ACMGRSVTWYHKDBN
 
@@ -475,7 +534,7 @@ int bgzf_put_block(uvcio_bgzf_writer *w, const uint8_t *src, size_t n) {
     memcpy(out, head, 18);
     const uint32_t bsize = (uint32_t)(clen + 26 - 1);
     out[16] = (uint8_t)(bsize & 0xFF); out[17] = (uint8_t)(bsize >> 8);
-    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)n), isize = (uint32_t)n;
+    const uint32_t crc = block_crc32(src, n), isize = (uint32_t)n;
     uint8_t *t = out + 18 + clen;
     for (int i = 0; i < 4; i++) { t[i] = (uint8_t)(crc >> (8 * i)); t[4 + i] = (uint8_t)(isize >> (8 * i)); }
     if (fwrite(out, 1, clen + 26, w->fp) != clen + 26) return fail(UVCGPU_EINVAL, "short write");

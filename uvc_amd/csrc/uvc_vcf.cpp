@@ -333,7 +333,13 @@ struct Cols {
 };
 inline void st_symbols(int st, int &first, int &count, int &nn) { if (st == UVC_BASE_SYMBOL) { first = UVC_BASE_A; count = 6; nn = UVC_BASE_NN; } else { first = UVC_LINK_M; count = 8; nn = UVC_LINK_NN; } }
 
-void put(std::string &o, int64_t v) { char b[32]; snprintf(b, sizeof(b), "%lld", (long long)v); o += b; }
+void put(std::string &o, int64_t v) {   // decimal text; snprintf was most of the record writer's time (two million integers per Mb)
+    char b[24]; char *const e = b + sizeof(b); char *p = e;
+    uint64_t u = (v < 0 ? 0 - (uint64_t)v : (uint64_t)v);
+    do { *--p = (char)('0' + (int)(u % 10)); u /= 10; } while (u);
+    if (v < 0) *--p = '-';
+    o.append(p, (size_t)(e - p));
+}
 void put2(std::string &o, int64_t a, int64_t b) { put(o, a); o += ','; put(o, b); }
 
 // UVCGPU_TIMING=1: where the record writer spends its time (stderr)
@@ -490,11 +496,13 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
         std::vector<int64_t> cols((size_t)ncol * kept.size());
         int rc = uvcgpu_region_fetch_columns(r, where.data(), (int64_t)where.size(), cols.data());
         if (rc) return rc;
+        timer.lap("plane columns of the written records");
         Rows G; int64_t nr = 0, nb = 0;
         rc = uvcgpu_region_indel_alleles(r, nullptr, 0, &nr, nullptr, 0, &nb);
         if (rc && rc != UVCGPU_ENOMEM) return rc;
         G.rows.resize((size_t)nr); G.seq.resize((size_t)nb + 1);
         if (nr) { rc = uvcgpu_region_indel_alleles(r, G.rows.data(), nr, &nr, G.seq.data(), nb + 1, &nb); if (rc) return rc; }
+        timer.lap("InDel allele rows");
         Cols C; for (int g = 0; g < UVC_NUM_FIELD_GROUPS; g++) C.base[g] = uvcgpu_region_column_base(g);
         const bool tprov = (P.tumor_vcf_is_provided != 0);
         for (size_t k = 0; k < kept.size(); k++) {
@@ -768,12 +776,39 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
                 if (e - lo != 1 || !tcols[lo]) return if_many;
                 return std::string("\t") + tcols[lo];
             };
+            // indelpos_to_context at every position of the range: instead of six scans per position, one backward pass per unit size u
+            // (run = how many q' >= q in a row have ref[q'] == ref[q' + u]; the repeat count of u at q is run / u + 1) that keeps the
+            // better (unit size, count) per position as is_indel_context_more_STR ranks them (main.hpp:699-721)
+            const int32_t smax = std::max(0, std::min(P.indel_str_repeatsize_max, 64));
+            const int64_t c_lo = std::max<int64_t>((int64_t)pos_beg - 1 - beg, 0), c_hi = std::min<int64_t>((int64_t)pos_end - beg, (int64_t)ref.size());   // offsets asked for
+            std::vector<int32_t> ctx_size, ctx_num;
+            if (want_cand && c_hi > c_lo) {
+                ctx_size.assign((size_t)(c_hi - c_lo), 0); ctx_num.assign((size_t)(c_hi - c_lo), 0);
+                const int64_t n = (int64_t)ref.size();
+                const char *rs = ref.data();
+                for (int32_t u = 1; u <= smax; u++) {
+                    int32_t carry = 0; { int64_t q = c_hi; while (q + u < n && rs[q] == rs[q + u]) { q++; carry++; } }   // the run at c_hi - 1 may reach past the range
+                    for (int64_t q = c_hi - 1; q >= c_lo; q--) {
+                        carry = (q + u < n && rs[q] == rs[q + u]) ? carry + 1 : 0;
+                        const int32_t c = carry / u + 1;
+                        int32_t &bs = ctx_size[(size_t)(q - c_lo)], &num = ctx_num[(size_t)(q - c_lo)];
+                        bool better;
+                        if (bs * num == 0) better = true;
+                        else { const int r1 = (c <= 1 ? (-c * u) : ((c - 1) * u)), r2 = (num <= 1 ? (-num * u) : ((num - 1) * bs)); better = r1 > r2; }
+                        if (better) { num = c; bs = u; }
+                    }
+                }
+            }
+            auto context_at = [&](int64_t at, int32_t &best_size, int32_t &num) {
+                if (at < c_lo || at >= c_hi || ctx_size.empty()) { best_size = 0; num = 0; return; }
+                best_size = ctx_size[(size_t)(at - c_lo)]; num = ctx_num[(size_t)(at - c_lo)];
+            };
             int32_t prev_track = 0;
-            if (base_at_beg && want_cand) { std::string ru0; int32_t rcn0 = 0; repeat_context(ref, pos_beg - 1 - beg, P.indel_str_repeatsize_max, ru0, rcn0); prev_track = rcn0 * (int32_t)ru0.size(); }   // the track of the zerobased_pos in front, which the adjacent region iterated
+            if (base_at_beg && want_cand) { int32_t bs0 = 0, rcn0 = 0; context_at((int64_t)pos_beg - 1 - beg, bs0, rcn0); prev_track = rcn0 * bs0; }   // the track of the zerobased_pos in front, which the adjacent region iterated
             for (int32_t z = pos_beg; z < pos_end; z++) {
-                std::string ru; int32_t rcn = 0;
-                if (want_cand) repeat_context(ref, z - beg, P.indel_str_repeatsize_max, ru, rcn);
-                const int32_t curr_track = rcn * (int32_t)ru.size();
+                int32_t best_size = 0, rcn = 0;
+                if (want_cand) context_at((int64_t)z - beg, best_size, rcn);
+                const int32_t curr_track = rcn * best_size;
                 if (z != pos_beg || base_at_beg) {
                     const int32_t refpos = z - 1;
                     std::string line;
@@ -804,7 +839,8 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
                         if ((long_track || clip_region) && ADP >= 2 * P.microadjust_alignment_clip_min_count) {
                             const char rc1 = refchar((int64_t)refpos - beg);
                             line += tname; line += '\t'; put(line, (int64_t)refpos + 1); line += "\t.\t"; line += rc1; line += "\t<ADDITIONAL_INDEL_CANDIDATE>\t.\t.\tADDITIONAL_INDEL_CANDIDATE;RU=";
-                            line += ru; line += ";RC="; put(line, rcn); line += "\tGT:VTI:clipDP\t.:"; put(line, code_of(rc1)); line += ",16:"; put(line, ADP); line += ','; put(line, aCDP);
+                            if ((int64_t)z - beg < (int64_t)ref.size()) line += ref.substr((size_t)((int64_t)z - beg), (size_t)best_size);
+                            line += ";RC="; put(line, rcn); line += "\tGT:VTI:clipDP\t.:"; put(line, code_of(rc1)); line += ",16:"; put(line, ADP); line += ','; put(line, aCDP);
                             if (tcols_pos) line += tumor_column(refpos, UVC_ADDITIONAL_INDEL_CANDIDATE_SYMBOL, "\t.:-1,-1:-1,-1", "\t.:.,.:.,.");   // main.cpp:784-798
                             line += '\n';
                         }
