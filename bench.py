@@ -123,7 +123,10 @@ def run_cpu_baseline(depth, n_regions=64, region_len=20000):
 def _gen_tile(a):
     from uvc_amd import synth
     seed, region_len, depth, beg, umi = a
-    return synth.generate_region(seed=seed, region_len=region_len, depth=depth, beg=beg, umi=umi)
+    extra = {}
+    if os.environ.get("UVC_BENCH_INDEL_EVERY"):   # experiment knob: spacing of the synthetic InDels (0 = none); the default workload does not set it
+        extra["indel_every"] = int(os.environ["UVC_BENCH_INDEL_EVERY"])
+    return synth.generate_region(seed=seed, region_len=region_len, depth=depth, beg=beg, umi=umi, **extra)
 
 
 def spawn_ranks(n, argv):

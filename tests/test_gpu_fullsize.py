@@ -149,3 +149,47 @@ def test_no_reads_and_bad_inputs(gpu_lib):
     R.set_reads(reads)                                                       # the handle is still usable
     R.accumulate()
     assert R.fetch("PREP32")[E["UVC_P_a_dp"]].sum() == ref_consuming_coverage(reads)[0].sum()
+
+
+# ---- BASELINE config 4 at full size: a 200 kb duplex-UMI panel tile at 2000x (2.7 M reads, ~95 M (unit, position) cells) ----
+FAM_GROUPS = ("FRAG", "FAM", "FAMINFO32", "DUPLEX", "VQ", "SEG32", "PREP32")
+
+
+def _umi_tile_planes(gpu_lib, reads, fam_path, monkeypatch):
+    if fam_path:
+        monkeypatch.setenv("UVCGPU_FAM_PATH", fam_path)      # read by set_reads: generic = one thread per (unit, position), window = LDS window kernels without the digest
+    else:
+        monkeypatch.delenv("UVCGPU_FAM_PATH", raising=False)
+    R = region.Region(gpu_lib, region.default_params(gpu_lib), reads["tid"], reads["beg"], reads["end"], reads["refseq"])
+    R.set_reads(reads)
+    R.accumulate()
+    sums = checksum(R, FAM_GROUPS)
+    rec = R.score(capacity=600_000)
+    keep = {k: rec[k].copy() for k in ("refpos", "symbol", "cDP1x", "cDP2x", "cVQ1", "cVQ2", "QUAL", "keep")}
+    planes = {g: R.fetch(g) for g in ("FRAG", "FAM", "DUPLEX")} if not fam_path else None
+    R.close()
+    return sums, keep, planes
+
+
+def test_config4_tile_three_forms_of_the_family_kernels_agree(gpu_lib, monkeypatch):
+    """The digest kernels (k_fam_p4d / k_fam_win<5, true> / k_duplex_d, what a deep tile runs by default), the window kernels without the
+    digest and the one-thread-per-(unit, position) kernels are three implementations of P4 / P5 / duplex: at BASELINE config 4's full
+    tile size they must leave bit-identical planes and identical records.  Plus relations the consensus counters obey by construction."""
+    reads = synth.generate_region(seed=4242, region_len=200_000, depth=2000, umi=True)
+    assert reads["n_reads"] > 2_000_000 and reads["n_fams"] > 100_000
+    base_sums, base_rec, planes = _umi_tile_planes(gpu_lib, reads, None, monkeypatch)
+    for path in ("window", "generic"):
+        sums, rec, _ = _umi_tile_planes(gpu_lib, reads, path, monkeypatch)
+        assert sums == base_sums, path
+        assert all(np.array_equal(rec[k], base_rec[k]) for k in rec), path
+    frag, fam, dup = planes["FRAG"], planes["FAM"], planes["DUPLEX"]
+    bdp = frag[:, E["UVC_FRAG_bDP"]]                                          # [strand][symbol][position]
+    c12, c1, c2, c3 = (fam[:, E[k]] for k in ("UVC_FAM_cDP12", "UVC_FAM_cDP1", "UVC_FAM_cDP2", "UVC_FAM_cDP3"))
+    assert (c12.sum(axis=1) <= bdp.sum(axis=1)).all()                          # a family-strand unit votes once where its fragments vote at all
+    assert (c12[:, :6].sum(axis=1) * 20 >= bdp[:, :6].sum(axis=1)).all()       # ... and no unit of this data set has more than 20 fragments on one strand at a position
+    assert (c2 <= c1).all() and c3.sum() < c2.sum()                           # the stricter family-size / agreement threshold of cDP2 (main.hpp:3140-3220)
+    assert (fam[:, E["UVC_FAM_cDP21"]] <= c12).all()
+    d1, d2 = dup[E["UVC_DUPLEX_dDP1"]], dup[E["UVC_DUPLEX_dDP2"]]
+    assert (d2 <= d1).all() and d2.sum() > 10_000                              # duplex families whose two strands agree are a subset of the duplex families
+    assert (d1.sum(axis=0) <= np.minimum(c12[0].sum(axis=0), c12[1].sum(axis=0))).all()   # a duplex family needs a unit on each strand
+    assert base_rec["keep"].sum() > 50 and len(base_rec["refpos"]) > 100_000

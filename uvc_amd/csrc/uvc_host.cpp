@@ -409,7 +409,11 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
     R.generic_fs = o.generic_fs; R.n_generic_fs = o.n_generic; R.n_generic_work = o.work;
     R.generic_sorted = o.generic_sorted; R.max_unit_span = o.max_unit_span;
     R.fam_digest = nullptr;
-    if (o.work > 8 * r->npos && (size_t)o.work * 32 <= ((size_t)48 << 30) && o.max_unit_frags < 16384) {   // (the digest packs vote counts in 14 bits)
+    {   // UVCGPU_FAM_PATH=generic | window | (unset: by the data): which form of the family kernels runs -- the three give identical planes (tests/test_gpu_fullsize.py)
+        const char *fp = getenv("UVCGPU_FAM_PATH");
+        R.fam_path = (fp && !strcmp(fp, "generic")) ? 1 : ((fp && !strcmp(fp, "window")) ? 2 : 0);
+    }
+    if (R.fam_path == 0 && o.work > 8 * r->npos && (size_t)o.work * 32 <= ((size_t)48 << 30) && o.max_unit_frags < 16384) {   // (the digest packs vote counts in 14 bits)
         // deep data (the window family kernels): 32 B per (unit, position) so that P5 and the duplex pass do not walk the fragments again
         uint32_t *q = nullptr; if ((rc = dev_alloc(r, (size_t)o.work * 8, &q))) return rc; R.fam_digest = q;
     }

@@ -3131,7 +3131,7 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
         TIMED(prof, "k_fam_stat", hipLaunchKernelGGL(k_fam_stat, dim3(nblk(R->n_generic_fs, 64)), dim3(64), 0, s, *R, *P));
         // shallow data: one thread per (unit, position); deep data (many units per position, e.g. UMI panels): the window kernel, whose
         // LDS collection removes most of the atomics that bound the per-thread form
-        const bool deep = (R->n_generic_work > 8 * R->npos);
+        const bool deep = (R->fam_path == 1 ? false : (R->fam_path == 2 ? true : (R->n_generic_work > 8 * R->npos)));
         const bool digest = deep && R->fam_digest && P->inferred_is_vcf_generated;   // one walk over the fragments of a unit instead of three
         if (digest) TIMED(prof, "k_fam_p4", hipLaunchKernelGGL(k_fam_p4d, dim3(nblk(R->npos, 64)), dim3(256), 0, s, *R, *P));
         else if (deep) TIMED(prof, "k_fam_p4", hipLaunchKernelGGL((k_fam_win<4, false>), dim3(nblk(R->npos, 64)), dim3(256), 0, s, *R, *P));
