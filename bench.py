@@ -247,10 +247,12 @@ def main():
                 if ktimes is not None:
                     kernel_times(Rs[k % T], ktimes)
             return n_rec
-        prepare(k0, host)
+        ahead = max(1, min(int(os.environ.get("UVC_BENCH_AHEAD", "1")), T - 1))   # tiles prepared beyond the one being scored
+        for k in range(k0, min(k0 + ahead, k0 + n_steps)):
+            prepare(k, host)
         for k in range(k0, k0 + n_steps):
-            if k + 1 < k0 + n_steps:
-                prepare(k + 1, host)
+            if k + ahead < k0 + n_steps:
+                prepare(k + ahead, host)
             n_rec = len(finish(k)["refpos"])
             if ktimes is not None:
                 kernel_times(Rs[k % T], ktimes)

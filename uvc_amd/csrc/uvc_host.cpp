@@ -39,7 +39,7 @@ extern "C" size_t uvc_gap_sort_tmp_bytes(size_t n);
 extern "C" void uvc_launch_hap_cand(const RegionDev *R, const HapWork *H, int units, hipStream_t s);
 extern "C" void uvc_launch_hap_events(const RegionDev *R, const UvcParams *P, const HapWork *H, int units, int n_cand, hipStream_t s);
 extern "C" void uvc_launch_gather_columns(const char *const *base, const int32_t *first_col, const int32_t *elem, int64_t npos, const int32_t *d_xs, int64_t n, long long *d_out, hipStream_t s);
-extern "C" int uvc_sort_by_pos_cls(const int32_t *d_pos, const int32_t *d_cls, int32_t beg, int shift, int64_t n, uint32_t *work, void *tmp, size_t tmp_bytes, hipStream_t s);
+extern "C" int uvc_sort_by_pos_cls(const int32_t *d_pos, const int32_t *d_cls, int32_t beg, int pos_bits, int cls_bits, int64_t n, uint32_t *work, void *tmp, size_t tmp_bytes, hipStream_t s);
 extern "C" size_t uvc_sort32_tmp_bytes(size_t n);
 extern "C" void uvc_launch_gather4(const uint32_t *perm, int64_t n, const int32_t *a0, const int32_t *a1, const int32_t *a2, const int32_t *a3, int32_t *o0, int32_t *o1, int32_t *o2, int32_t *o3, hipStream_t s);
 extern "C" void uvc_launch_rank_from_sorted(const uint32_t *perm, int64_t n, int64_t n_first, int32_t *out_ids, int32_t *rank, hipStream_t s);
@@ -388,16 +388,17 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
     { FastRec *f; if ((rc = dev_alloc(r, (size_t)n_simple, &f))) return rc; R.frec = f; }
     R.complex_ids = o.complex_ids; R.n_complex = o.n_complex;
     R.frags = o.frags; R.n_frags = o.n_frags;
+    int pos_bits = 1; while (((int64_t)1 << pos_bits) < r->npos + 1) pos_bits++;   // every sorted position offset is < npos: the radix passes stop there
     {   // stable device sorts: simple alignments by begin (the others go behind them), fragments by (strand, begin) -- k_frag walks two
         // beg-sorted sub-lists, one per strand, so that the strand-specific accumulators are fixed registers
         const size_t nmax = std::max<size_t>(std::max<size_t>((size_t)n, nf), 1);
         int32_t *d_rank, *d_fsorted, *d_frank; uint32_t *work; uint8_t *tmp;
         const size_t tmp_bytes = uvc_sort32_tmp_bytes(nmax);
         if ((rc = dev_alloc(r, (size_t)n, &d_rank)) || (rc = dev_alloc(r, nf, &d_fsorted)) || (rc = dev_alloc(r, nf, &d_frank)) || (rc = dev_alloc(r, 4 * nmax, &work)) || (rc = dev_alloc(r, tmp_bytes + 16, &tmp))) return rc;
-        if (uvc_sort_by_pos_cls(W.pos, o.is_complex, r->beg, 31, n, work, tmp, tmp_bytes, r->stream) != 0) return fail(UVCGPU_EDEVICE, "device sort of the alignments failed");
+        if (uvc_sort_by_pos_cls(W.pos, o.is_complex, r->beg, pos_bits, 1, n, work, tmp, tmp_bytes, r->stream) != 0) return fail(UVCGPU_EDEVICE, "device sort of the alignments failed");
         uvc_launch_rank_from_sorted(work + 3 * n, n, n_simple, nullptr, d_rank, r->stream);
         W.fast_rank = d_rank;
-        if (uvc_sort_by_pos_cls(o.frag_beg, o.frag_strand, r->beg, 31, (int64_t)nf, work, tmp, tmp_bytes, r->stream) != 0) return fail(UVCGPU_EDEVICE, "device sort of the fragments failed");
+        if (uvc_sort_by_pos_cls(o.frag_beg, o.frag_strand, r->beg, pos_bits, 1, (int64_t)nf, work, tmp, tmp_bytes, r->stream) != 0) return fail(UVCGPU_EDEVICE, "device sort of the fragments failed");
         uvc_launch_rank_from_sorted(work + 3 * nf, (int64_t)nf, (int64_t)nf, d_fsorted, d_frank, r->stream);
         R.frag_sorted = d_fsorted; R.frag_rank = d_frank;
     }
@@ -453,7 +454,7 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
         const size_t tmp_bytes = uvc_sort32_tmp_bytes(std::max<size_t>(np2, 1));
         if ((rc = dev_alloc(r, 4 * np2, &work)) || (rc = dev_alloc(r, tmp_bytes + 16, &tmp))) return rc;
         for (int k = 0; k < 4; k++) if ((rc = dev_alloc(r, np2, &r->d_p2[k]))) return rc;
-        if (uvc_sort_by_pos_cls(o.p2_beg, o.p2_cls, r->beg, 29, (int64_t)np2, work, tmp, tmp_bytes, r->stream) != 0) return fail(UVCGPU_EDEVICE, "device sort of the P2 work list failed");
+        if (uvc_sort_by_pos_cls(o.p2_beg, o.p2_cls, r->beg, pos_bits, 2, (int64_t)np2, work, tmp, tmp_bytes, r->stream) != 0) return fail(UVCGPU_EDEVICE, "device sort of the P2 work list failed");
         uvc_launch_gather4(work + 3 * np2, (int64_t)np2, o.p2_aln, o.p2_beg, o.p2_end, o.p2_qb, r->d_p2[0], r->d_p2[1], r->d_p2[2], r->d_p2[3], r->stream);
         { FastRec *f; if ((rc = dev_alloc(r, np2, &f))) return rc; R.frec2 = f; R.n_fast2 = (int32_t)np2; R.max_p2_span = o.max_p2_span; }
         uvc_launch_build_p2list(&R, r->d_p2[0], r->d_p2[1], r->d_p2[2], r->d_p2[3], r->stream);

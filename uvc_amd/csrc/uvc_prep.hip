@@ -266,7 +266,8 @@ unsigned nblk(int64_t n, int b) { return (unsigned)std::max<int64_t>((n + b - 1)
 template <class T> size_t scan_tmp_bytes(int64_t n) { size_t b = 0; T *p = nullptr; rocprim::exclusive_scan(nullptr, b, p, p, T(0), (size_t)std::max<int64_t>(n, 1), rocprim::plus<T>(), (hipStream_t)0); return b; }
 }   // namespace
 
-extern "C" int uvc_sort_by_pos_cls(const int32_t *d_pos, const int32_t *d_cls, int32_t beg, int shift, int64_t n, uint32_t *work, void *tmp, size_t tmp_bytes, hipStream_t s);
+static inline int pos_bits_of(int64_t npos) { int b = 1; while (((int64_t)1 << b) < npos + 1) b++; return b; }
+extern "C" int uvc_sort_by_pos_cls(const int32_t *d_pos, const int32_t *d_cls, int32_t beg, int pos_bits, int cls_bits, int64_t n, uint32_t *work, void *tmp, size_t tmp_bytes, hipStream_t s);
 extern "C" size_t uvc_sort32_tmp_bytes(size_t n);
 
 #define PREP_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf(errmsg, (size_t)errcap, "%s: %s", #call, hipGetErrorString(e_)); return UVCGPU_EDEVICE; } } while (0)
@@ -366,7 +367,7 @@ extern "C" int uvc_prep_reads(const UvcPrepIn *inp, const UvcParams *P, int32_t 
         const size_t sb = uvc_sort32_tmp_bytes((size_t)ng);
         ALLOC(beg_of, int32_t, ng, 0); ALLOC(zero, int32_t, ng, 0); ALLOC(work, uint32_t, 4 * (size_t)ng, 0); ALLOC(stmp, char, sb + 16, 0);
         hipLaunchKernelGGL(k_unit_keys, dim3(nblk(ng, 256)), dim3(256), 0, s, out->fss, out->generic_fs, ng, beg_of, zero);
-        if (uvc_sort_by_pos_cls(beg_of, zero, rbeg, 31, ng, work, stmp, sb, s) != 0) { snprintf(errmsg, (size_t)errcap, "device sort of the units failed"); return UVCGPU_EDEVICE; }
+        if (uvc_sort_by_pos_cls(beg_of, zero, rbeg, pos_bits_of(npos), 0, ng, work, stmp, sb, s) != 0) { snprintf(errmsg, (size_t)errcap, "device sort of the units failed"); return UVCGPU_EDEVICE; }
         hipLaunchKernelGGL(k_take_units, dim3(nblk(ng, 256)), dim3(256), 0, s, work + 3 * (size_t)ng, out->generic_fs, ng, out->generic_sorted);
     }
     PREP_HIP(hipGetLastError());
