@@ -48,9 +48,9 @@ if tile_kb >= 200:
 import subprocess
 exe = "/root/repo/uvc_amd/csrc/uvc1-mi355x"
 if os.path.exists(exe):
-    for tile, threads in ((100_000, 1), (100_000, 4), (100_000, 8), (100_000, 16), (250_000, 4), (250_000, 8), (500_000, 2), (500_000, 4), (1_000_000, 1), (1_000_000, 2), (1_000_000, 4)):
+    for tile, threads in ((100_000, 1), (100_000, 4), (100_000, 8), (100_000, 16), (250_000, 4), (250_000, 8), (500_000, 2), (500_000, 4), (1_000_000, 1), (1_000_000, 2), (1_000_000, 4), (1_000_000, 6), (1_000_000, 8), (500_000, 8)):
         if tile > tile_kb * 1000:
             continue
         r = subprocess.run([exe, os.path.join(d, "t.bam"), "-f", os.path.join(d, "t.fa"), "-o", os.path.join(d, "o.vcf.gz"), "--targets", "chrT:%d-%d" % (beg + 1, end),
-                            "--tile", str(tile), "-t", str(threads), "--timing", "--repeat", "4"], capture_output=True, text=True)
+                            "--tile", str(tile), "-t", str(threads), "--timing", "--repeat", str(max(4, 2 * threads))], capture_output=True, text=True)
         print("uvc1-mi355x tile %d, -t %d: %s" % (tile, threads, " | ".join(l.strip() for l in r.stderr.splitlines() if "positions/s" in l or "thread-seconds" in l)), flush=True)

@@ -205,6 +205,10 @@ int main(int argc, char **argv) {
     Opts o = parse(argc, argv);
     if (o.devices.empty()) { const int nd = uvcgpu_device_count(); if (nd <= 0) die("no HIP device: uvc1-mi355x has no CPU path"); for (int d = 0; d < nd; d++) o.devices.push_back(d); }
     if (o.threads <= 0) o.threads = 4 * (int)o.devices.size();
+    if (!getenv("UVCIO_THREADS")) {   // the readers inflate BGZF blocks on their own threads: share the cores among the tiles in flight
+        const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+        setenv("UVCIO_THREADS", std::to_string(std::max(1, (hw + o.threads - 1) / o.threads)).c_str(), 1);
+    }
     if (uvcgpu_init(o.devices[0])) die(uvcgpu_last_error());
     uvcio_bam_t *bam0 = nullptr;
     if (uvcio_bam_open(&bam0, o.bam.c_str())) die(uvcio_last_error());
