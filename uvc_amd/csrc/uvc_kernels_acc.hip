@@ -1923,6 +1923,10 @@ __global__ void __launch_bounds__(64) k_fam_stat(RegionDev R, UvcParams P) {
         }
     }
     u.nsb_min = nsb_min; u.nsb_max = nsb_max;
+    // k_fam_p4d leaves the (unit, position) cells under a fragment of the general kind (InDel reads, > 2 alignments) to k_fam_p4d_rest
+    int has_general = (proton ? 1 : 0);
+    for (int f = u.frag_beg; f < u.frag_end && !has_general; f++) if (R.ffast[R.frag_rank[f]].flags & 0x101) has_general = 1;
+    u.pad_ = has_general;
     R.fss[ui] = u;
 }
 
@@ -2060,7 +2064,7 @@ __global__ void __launch_bounds__(256) k_fam_p5(RegionDev R, UvcParams P) {
 struct FamAcc {
     int (*a32)[FAMW_SLOTS][64]; unsigned long long (*a64)[UVC_NFAMINFO64][64]; int (*bk)[2][NBUCKETS][64];
     const RegionDev *R; int64_t x; int lane, my_ref;
-    DEV int dense(int cs) const { return cs == my_ref ? 0 : (cs == UVC_LINK_M ? 1 : -1); }
+    DEV int dense(int cs) const { return !a32 ? -1 : (cs == my_ref ? 0 : (cs == UVC_LINK_M ? 1 : -1)); }   // without LDS accumulators (k_fam_p4d_rest) every increment is a global atomic
     DEV void fap(int strand, int f, int cs, int v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a32[d][strand * UVC_NFAM + f][lane], v); else atomicAdd(&FAP(*R, strand, f, cs, x), v); }
     DEV void fi(int f, int cs, int v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a32[d][2 * UVC_NFAM + f][lane], v); else atomicAdd(&FIP(*R, f, cs, x), v); }
     DEV void fi64(int f, int cs, long long v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a64[d][f][lane], (unsigned long long)v); else add64(&FI64P(*R, f, cs, x), v); }
@@ -2357,7 +2361,7 @@ __global__ void __launch_bounds__(256) k_fam_win(RegionDev R, UvcParams P) {
 
 // the consensus numbers of a (unit, position) that has a fragment of the general kind: out of line, so that its registers do not count
 // against the occupancy of k_fam_p4d (the call is rare)
-__attribute__((noinline)) DEV void general_unit(const RegionDev &R, const UvcParams &P, const FsRec &u, int p, bool proton, bool padded_ignored,
+DEV void general_unit(const RegionDev &R, const UvcParams &P, const FsRec &u, int p, bool proton, bool padded_ignored,
                                                 int *vcs, int *vcc, int *vct, int *mcs, int *msum, int *mtot, int *mcon, int *dcs, int *dadj) {
     int con_l[NSYM], mmm_l[NSYM];
     unit_counts<true>(R, P, u, p, proton, con_l, mmm_l);
@@ -2517,7 +2521,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
                 const int dt = c0 + c1 + c2 + c3;
                 dcs[1] = ds; dadj[1] = imax(dc * 2, dt) - dt;
             } else { dcs[1] = bs; dadj[1] = imax(bc * 2, vct[1]) - vct[1]; }
-        } else general_unit(R, P, u, p, proton, padded_ignored, vcs, vcc, vct, mcs, msum, mtot, mcon, dcs, dadj);
+        } else continue;   // a cell under a fragment of the general kind: k_fam_p4d_rest writes its digest and its increments
         uint32_t dg6 = 0;
         uint32_t dga[2];
         for (int vi = 0; vi < 2; vi++) {
@@ -2548,6 +2552,45 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
         const int ln = i & 63, f = (i >> 6) % UVC_NFAMINFO64, d = (i >> 6) / UVC_NFAMINFO64;
         const int64_t xx = x0 + ln;
         add64(&FI64P(R, f, (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M), xx), (long long)v);
+    }
+}
+
+// The cells k_fam_p4d leaves out: positions of a unit under a fragment of the general kind (an InDel read, more than two alignments).
+// One wave per generic unit that has such a fragment (FsRec::pad_, set by k_fam_stat), lanes over its positions; the consensus comes from
+// the general walk (unit_counts<true>), the increments are global atomics.  A few per cent of the units on panel data.
+__global__ void __launch_bounds__(64) k_fam_p4d_rest(RegionDev R, UvcParams P) {
+    if ((int)blockIdx.x >= R.n_generic_fs) return;
+    const FsRec u = R.fss[R.generic_fs[blockIdx.x]];
+    if (!u.pad_) return;
+    const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    const bool padded_ignored = (P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0;
+    for (int p = u.beg + (int)threadIdx.x; p < u.end; p += 64) {
+        const int64_t x = (int64_t)p - R.beg;
+        if (x < 0 || x >= R.npos) continue;
+        bool general = false;
+        for (int f = u.frag_beg; f < u.frag_end && !general; f++) {
+            const FragFast &ff = R.ffast[R.frag_rank[f]];
+            general = (p >= ff.beg && p < ff.end && (((ff.flags & 0x101) != 0) || proton));
+        }
+        if (!general) continue;
+        int vcs[2], vcc[2], vct[2], mcs[2], msum[2], mtot[2], mcon[2], dcs[2], dadj[2];
+        general_unit(R, P, u, p, proton, padded_ignored, vcs, vcc, vct, mcs, msum, mtot, mcon, dcs, dadj);
+        uint32_t dg6 = 0;
+        uint32_t dga[2];
+        for (int vi = 0; vi < 2; vi++) {
+            dga[vi] = (uint32_t)mcs[vi] | ((uint32_t)imin(mcon[vi], 16383) << 4) | ((uint32_t)imin(vct[vi], 16383) << 18);
+            dg6 |= ((uint32_t)dcs[vi] | ((dadj[vi] >= 1) ? 16u : 0u)) << (8 * vi);
+        }
+        uint4 *dst = (uint4 *)(R.fam_digest + 8 * (u.work_off + (int64_t)(p - u.beg)));
+        dst[0] = make_uint4(dga[0], (uint32_t)msum[0], (uint32_t)mtot[0], dga[1]); dst[1] = make_uint4((uint32_t)msum[1], (uint32_t)mtot[1], dg6, 0u);
+        FamAcc A; A.a32 = nullptr; A.a64 = nullptr; A.bk = nullptr; A.R = &R; A.x = x; A.lane = 0; A.my_ref = -1;
+        P4Pos Q;
+        Q.LPxT = TH(R, UVC_T_aLPxT, x); Q.RPxT = TH(R, UVC_T_aRPxT, x); Q.LP1t = TH(R, UVC_T_aLP1t, x); Q.LP2t = TH(R, UVC_T_aLP2t, x); Q.RP1t = TH(R, UVC_T_aRP1t, x); Q.RP2t = TH(R, UVC_T_aRP2t, x);
+        Q.baq1 = BAQ1(R, p); Q.baq2 = BAQ2(R, p);
+        for (int vi = 0; vi < 2; vi++) {
+            if (0 == vct[vi]) continue;
+            p4_apply(A, R, P, u, p, x, (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL), vcs[vi], vcc[vi], vct[vi], Q);
+        }
     }
 }
 
@@ -3151,7 +3194,8 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
         // LDS collection removes most of the atomics that bound the per-thread form
         const bool deep = (R->fam_path == 1 ? false : (R->fam_path == 2 ? true : (R->n_generic_work > 8 * R->npos)));
         const bool digest = deep && R->fam_digest && P->inferred_is_vcf_generated;   // one walk over the fragments of a unit instead of three
-        if (digest) TIMED(prof, "k_fam_p4", hipLaunchKernelGGL(k_fam_p4d, dim3(nblk(R->npos, 64)), dim3(256), 0, s, *R, *P));
+        if (digest) TIMED(prof, "k_fam_p4", { hipLaunchKernelGGL(k_fam_p4d, dim3(nblk(R->npos, 64)), dim3(256), 0, s, *R, *P);
+                                               hipLaunchKernelGGL(k_fam_p4d_rest, dim3(R->n_generic_fs), dim3(64), 0, s, *R, *P); });
         else if (deep) TIMED(prof, "k_fam_p4", hipLaunchKernelGGL((k_fam_win<4, false>), dim3(nblk(R->npos, 64)), dim3(256), 0, s, *R, *P));
         else TIMED(prof, "k_fam_p4", hipLaunchKernelGGL(k_fam_p4, dim3(nblk(R->n_generic_work, 256)), dim3(256), 0, s, *R, *P));
         if (P->inferred_is_vcf_generated) {
