@@ -2074,8 +2074,13 @@ struct FamAcc {
 // The P4 increments of one (unit, position, symbol type) once the vote consensus (cs = symbol, cc = its votes, ct = all votes) is known
 // (main.hpp:2999-3355); the body of k_fam_win<4> with con[] reduced to what it uses of it.
 // what p4_apply reads of the position alone (thresholds, BAQ prefix sums): loaded once per lane, not once per unit
-struct P4Pos { int LPxT, RPxT, LP1t, LP2t, RP1t, RP2t; long long baq1, baq2; };
+struct P4Pos { int LPxT, RPxT, LP1t, LP2t, RP1t, RP2t; long long baq1, baq2;
+               const long long *lb1, *lb2; int lb_lo; };   // LB: the two BAQ prefix-sum arrays of [lb_lo, lb_lo + P4_BAQ_WIN) staged in LDS
+#define P4_BAQ_WIN (64 + 2 * MAX_STR_N_BASES + 2)   // every BAQ index of a window's cells lies within MAX_STR_N_BASES of the window
+template <bool LB = false>
 DEV void p4_apply(const FamAcc &A, const RegionDev &R, const UvcParams &P, const FsRec &u, int p, int64_t x, int st, int cs, int cc, int ct, const P4Pos &Q) {
+    auto baq1_at = [&](long long a) -> long long { if (LB) return Q.lb1[(int)a - Q.lb_lo]; return BAQ1(R, a); };
+    auto baq2_at = [&](long long a) -> long long { if (LB) return Q.lb2[(int)a - Q.lb_lo]; return BAQ2(R, a); };
     const int strand = u.strand;
     {
                 const bool is_fam_good = ((P.fam_thres_dup1add <= ct) && (cc * 100 >= ct * P.fam_thres_dup1perc) && ((u.dflag & 0x1) || (P.fam_flag & 0x2)));
@@ -2110,10 +2115,10 @@ DEV void p4_apply(const FamAcc &A, const RegionDev &R, const UvcParams &P, const
                         if ((int)nnminus(p + 1, u.nsb_min) >= P.bias_thres_strict_c2LRP0) A.fi(UVC_FI_c2LP0, cs, 1);
                         if ((int)nnminus(u.nsb_max, p) >= P.bias_thres_strict_c2LRP0) A.fi(UVC_FI_c2RP0, cs, 1);
                         const long long baq_last = R.end - 1;
-                        const int seg_l_baq = (int)(Q.baq1 - BAQ1(R, lmax((long long)rbeg, nnminus(p, MAX_STR_N_BASES))) + 1);
+                        const int seg_l_baq = (int)(Q.baq1 - baq1_at(lmax((long long)rbeg, nnminus(p, MAX_STR_N_BASES))) + 1);
                         const long long rr = lmin((long long)rend - 1, lmin((long long)p + MAX_STR_N_BASES, baq_last));
-                        const int _seg_r_baq = (int)(BAQ1(R, rr) - Q.baq1 + 1);
-                        const int seg_r_baq = (isGap ? (int)lmin((long long)_seg_r_baq, BAQ2(R, rr) - Q.baq2 + 7) : _seg_r_baq);
+                        const int _seg_r_baq = (int)(baq1_at(rr) - Q.baq1 + 1);
+                        const int seg_r_baq = (isGap ? (int)lmin((long long)_seg_r_baq, baq2_at(rr) - Q.baq2 + 7) : _seg_r_baq);
                         const int thres_highBAQ = P.bias_thres_highBAQ + (isGap ? 0 : 3);
                         if (seg_l_baq >= thres_highBAQ && seg_r_baq >= thres_highBAQ) {
                             int LB1 = 0, LB2 = 0, RB1 = 0, RB2 = 0; long long LBL = 0, RBL = 0;
@@ -2384,6 +2389,7 @@ DEV void general_unit(const RegionDev &R, const UvcParams &P, const FsRec &u, in
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_fam_p4d(RegionDev R, UvcParams P) {
     __shared__ int a32[2][FAMW_SLOTS][64];
     __shared__ unsigned long long a64[2][UVC_NFAMINFO64][64];
+    __shared__ long long baq_s[2][P4_BAQ_WIN];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t x0 = (int64_t)xcd_block() * 64;
     if (x0 >= R.npos) return;
@@ -2400,6 +2406,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     if (lo >= hi) return;   // block-uniform
     for (int i = threadIdx.x; i < 2 * FAMW_SLOTS * 64; i += 256) (&a32[0][0][0])[i] = 0;
     for (int i = threadIdx.x; i < 2 * UVC_NFAMINFO64 * 64; i += 256) (&a64[0][0][0])[i] = 0ull;
+    // the BAQ prefix sums the position-bias tests of this window can ask for (p4_apply: within MAX_STR_N_BASES of the cell), staged once:
+    // six dependent global gathers per (unit, window) otherwise
+    const int lb_lo = w0 - MAX_STR_N_BASES - 1;
+    for (int i = threadIdx.x; i < P4_BAQ_WIN; i += 256) {
+        const long long q = lmin(lmax((long long)lb_lo + i, (long long)R.beg), (long long)R.beg + R.npos - 1);
+        baq_s[0][i] = BAQ1(R, q); baq_s[1][i] = BAQ2(R, q);
+    }
     __syncthreads();
     const int p = w0 + lane;
     const int64_t x = x0 + lane;
@@ -2409,7 +2422,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     FamAcc A; A.a32 = a32; A.a64 = a64; A.bk = nullptr; A.R = &R; A.x = x; A.lane = lane; A.my_ref = (valid ? (int)R.refsym[x] : 0);
     const int noindel80 = ((valid && x > 0) ? imin(80, imin(RTRP(R, UVC_RTR_indelphred, x - 1), RTRP(R, UVC_RTR_indelphred, x))) : 80);
     const __amdgpu_buffer_rsrc_t rs = bq_rsrc(R);
-    P4Pos Q = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    P4Pos Q = { 0, 0, 0, 0, 0, 0, 0, 0, &baq_s[0][0], &baq_s[1][0], lb_lo };
     if (valid) { Q.LPxT = TH(R, UVC_T_aLPxT, x); Q.RPxT = TH(R, UVC_T_aRPxT, x); Q.LP1t = TH(R, UVC_T_aLP1t, x); Q.LP2t = TH(R, UVC_T_aLP2t, x); Q.RP1t = TH(R, UVC_T_aRP1t, x); Q.RP2t = TH(R, UVC_T_aRP2t, x);
                  Q.baq1 = BAQ1(R, p); Q.baq2 = BAQ2(R, p); }
     // the unit records of this wave, 64 at a time: one per lane, those that reach the window picked by ballot, their fields broadcast --
@@ -2532,7 +2545,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
         dst[0] = make_uint4(dga[0], (uint32_t)msum[0], (uint32_t)mtot[0], dga[1]); dst[1] = make_uint4((uint32_t)msum[1], (uint32_t)mtot[1], dg6, 0u);
         for (int vi = 0; vi < 2; vi++) {
             if (0 == vct[vi]) continue;
-            p4_apply(A, R, P, u, p, x, (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL), vcs[vi], vcc[vi], vct[vi], Q);
+            p4_apply<true>(A, R, P, u, p, x, (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL), vcs[vi], vcc[vi], vct[vi], Q);
         }
       }
     }
