@@ -92,6 +92,9 @@ struct MisItem { int32_t rank, epos, symval; };
 // compact per-fragment record for k_frag, stored in beg-sorted order (written by k_fragstat_fast).  A fragment of <= 2
 // alignments, each with at most one InDel, is described by up to two M runs per alignment (run B empty for a simple alignment)
 // plus, per alignment, the "special" positions around its InDel, which k_frag leaves to k_frag_generic.
+// The first 12 dwords of a FragFast record again, indexed by fragment number (the fragments of a family-strand unit are consecutive):
+// k_fam_p4d reaches the records of a unit without the frag_rank indirection.
+struct FragUnit { int32_t v[12]; };
 struct FragFast {
     int32_t beg, end, fi, flags;        // flags: bit0 generic path only, bit1 strand, bit2 singleton, bits 3..6 number of alignments, bit8 has runs B / special ranges
     int32_t pos0, rend0, pos1, rend1;   // run A of alignment 0 / 1: [pos, rend)
@@ -157,6 +160,7 @@ struct RegionDev {
     const int32_t *frag_rank;       // inverse permutation of frag_sorted
     int32_t frag_off[3];            // ffast = the strand-0 fragments sorted by beg, then the strand-1 fragments sorted by beg
     FragFast *ffast;                // [n_frags] in (strand, beg)-sorted order
+    FragUnit *ffast_u;              // [n_frags] by fragment number (see FragUnit)
     FsRec *fss; int32_t n_fs;
     const int32_t *generic_fs; int32_t n_generic_fs; int64_t n_generic_work;
     const int32_t *generic_sorted; int32_t max_unit_span;   // the generic units ordered by FsRec::beg (window kernels k_fam_win)

@@ -403,6 +403,7 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
         R.frag_sorted = d_fsorted; R.frag_rank = d_frank;
     }
     { FragFast *f; if ((rc = dev_alloc(r, nf, &f, true))) return rc; R.ffast = f; }
+    { FragUnit *f; if ((rc = dev_alloc(r, nf, &f, true))) return rc; R.ffast_u = f; }
     R.sweep_frags = o.sweep_frags; R.n_sweep = o.n_sweep;
     { int32_t *q; if ((rc = dev_alloc(r, nf * (size_t)(UVC_MAXEV + 2) + 1, &q, true))) return rc;
       R.frag_nmut = q; R.frag_mut = q + nf; R.overflow_frags = q + nf * (size_t)(UVC_MAXEV + 1); R.n_overflow = q + nf * (size_t)(UVC_MAXEV + 2); }

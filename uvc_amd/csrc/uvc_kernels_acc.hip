@@ -1477,7 +1477,7 @@ __global__ void __launch_bounds__(256) k_fragstat_fast(RegionDev R, UvcParams P)
             if (sb < f.beg) ok = false;
         }
         if (ok) ff.flags = (ff.flags & ~1) | 0x100;
-        R.ffast[R.frag_rank[fi]] = ff; return;
+        R.ffast[R.frag_rank[fi]] = ff; R.ffast_u[fi] = *(const FragUnit *)&ff; return;
     }
     const int nm = R.frag_nmut[fi];
     // coverage intervals [a1,b1) u [a2,b2), disjoint and ordered
@@ -1495,7 +1495,7 @@ __global__ void __launch_bounds__(256) k_fragstat_fast(RegionDev R, UvcParams P)
     int n_near = 0;
     if (nm > UVC_MAXEV) {   // too many events for the closed form: the sweep kernel (overflow pass) fills n_cov / n_near of this record
         const int k = atomicAdd(R.n_overflow, 1); R.overflow_frags[k] = fi;
-        R.ffast[R.frag_rank[fi]] = ff; return;
+        R.ffast[R.frag_rank[fi]] = ff; R.ffast_u[fi] = *(const FragUnit *)&ff; return;
     }
     if (nm > 0) {
         const int nb = P.syserr_mut_region_n_bases;
@@ -1511,7 +1511,7 @@ __global__ void __launch_bounds__(256) k_fragstat_fast(RegionDev R, UvcParams P)
     }
     R.frags[fi].n_cov = n_cov; R.frags[fi].n_near = n_near;
     ff.n_cov = n_cov; ff.n_near = n_near;
-    R.ffast[R.frag_rank[fi]] = ff;
+    R.ffast[R.frag_rank[fi]] = ff; R.ffast_u[fi] = *(const FragUnit *)&ff;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1925,7 +1925,7 @@ __global__ void __launch_bounds__(64) k_fam_stat(RegionDev R, UvcParams P) {
     u.nsb_min = nsb_min; u.nsb_max = nsb_max;
     // k_fam_p4d leaves the (unit, position) cells under a fragment of the general kind (InDel reads, > 2 alignments) to k_fam_p4d_rest
     int has_general = (proton ? 1 : 0);
-    for (int f = u.frag_beg; f < u.frag_end && !has_general; f++) if (R.ffast[R.frag_rank[f]].flags & 0x101) has_general = 1;
+    for (int f = u.frag_beg; f < u.frag_end && !has_general; f++) if (R.ffast_u[f].v[3] & 0x101) has_general = 1;
     u.pad_ = has_general;
     R.fss[ui] = u;
 }
@@ -2458,7 +2458,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
         for (int f0 = 0; f0 < nfr; f0 += 64) {
             int c[12];
             if (f0 + lane < nfr) {
-                const int4 *q4 = (const int4 *)(R.ffast + R.frag_rank[u.frag_beg + f0 + lane]);
+                const int4 *q4 = (const int4 *)(R.ffast_u + u.frag_beg + f0 + lane);
 #pragma unroll
                 for (int i = 0; i < 3; i++) { const int4 t = q4[i]; c[4 * i] = t.x; c[4 * i + 1] = t.y; c[4 * i + 2] = t.z; c[4 * i + 3] = t.w; }
             } else {
@@ -2582,8 +2582,8 @@ __global__ void __launch_bounds__(64) k_fam_p4d_rest(RegionDev R, UvcParams P) {
         if (x < 0 || x >= R.npos) continue;
         bool general = false;
         for (int f = u.frag_beg; f < u.frag_end && !general; f++) {
-            const FragFast &ff = R.ffast[R.frag_rank[f]];
-            general = (p >= ff.beg && p < ff.end && (((ff.flags & 0x101) != 0) || proton));
+            const FragUnit &ff = R.ffast_u[f];
+            general = (p >= ff.v[0] && p < ff.v[1] && (((ff.v[3] & 0x101) != 0) || proton));
         }
         if (!general) continue;
         int vcs[2], vcc[2], vct[2], mcs[2], msum[2], mtot[2], mcon[2], dcs[2], dadj[2];
