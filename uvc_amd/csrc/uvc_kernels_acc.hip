@@ -2153,6 +2153,7 @@ __global__ void __launch_bounds__(256) k_fam_win(RegionDev R, UvcParams P) {
     __shared__ int a32[2][FAMW_SLOTS][64];
     __shared__ unsigned long long a64[2][UVC_NFAMINFO64][64];
     __shared__ int bk[PASS == 5 ? 2 : 1][2][NBUCKETS][PASS == 5 ? 64 : 1];
+    __shared__ double p2p_s[PASS == 5 ? 128 : 1];   // phred2prob of every average quality a cell can have: one pow() per value and block, not one per cell
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t x0 = (int64_t)xcd_block() * 64;
     if (x0 >= R.npos) return;
@@ -2171,6 +2172,7 @@ __global__ void __launch_bounds__(256) k_fam_win(RegionDev R, UvcParams P) {
     for (int i = threadIdx.x; i < 2 * FAMW_SLOTS * 64; i += 256) (&a32[0][0][0])[i] = 0;
     for (int i = threadIdx.x; i < 2 * UVC_NFAMINFO64 * 64; i += 256) (&a64[0][0][0])[i] = 0ull;
     if (PASS == 5) for (int i = threadIdx.x; i < 2 * 2 * NBUCKETS * 64; i += 256) (&bk[0][0][0][0])[i] = 0;
+    if (PASS == 5) for (int i = threadIdx.x; i < 128; i += 256) p2p_s[i] = pow(10.0, (double)(-((float)i) / 10));   // the expression of the cell, see below
     __syncthreads();
     const int p = w0 + lane;
     const int64_t x = x0 + lane;
@@ -2320,7 +2322,7 @@ __global__ void __launch_bounds__(256) k_fam_win(RegionDev R, UvcParams P) {
                 const int avgBQ = ((0 == tot_nfrags) ? 1 : (con_sumBQs / tot_nfrags));
                 const int majorcount = FAP(R, strand, UVC_FAM_cDPM, cs, x), minorcount = FAP(R, strand, UVC_FAM_cDPm, cs, x);   // complete: P4 ran before
                 const double prior_weight = 1.0 / (minorcount + 1.0);
-                const double p2p = pow(10.0, (double)(-((float)avgBQ) / 10));   // phred2prob's float cast, main_conversion.hpp:885-888
+                const double p2p = ((unsigned)avgBQ < 128u) ? p2p_s[avgBQ] : pow(10.0, (double)(-((float)avgBQ) / 10));   // phred2prob's float cast, main_conversion.hpp:885-888
                 const double prob = (minorcount + prior_weight) / (majorcount + minorcount + prior_weight / p2p);
                 const double realphred = -10 * log(prob) / log(10.0);
                 const int indep_frag_phred = (int)round(((con_nfrags * 2) - tot_nfrags) * realphred);
