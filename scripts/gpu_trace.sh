@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out/trace
 export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/trace/run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --tiles 4 > gpurun_out/trace/bench.json 2> gpurun_out/trace/err.txt
+timeout -k 10 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/trace/run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --tiles 4 $TRACE_ARGS > gpurun_out/trace/bench.json 2> gpurun_out/trace/err.txt
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/trace/run/**/*kernel_trace.csv", recursive=True)[0]

@@ -12,6 +12,39 @@ pytestmark = pytest.mark.gpu
 GROUPS = ("PREP32", "SEG32", "SEG64", "VQ", "BQSUM", "FRAG", "FAM", "FAMINFO32", "DUPLEX")
 
 
+class DeviceColumns:
+    """The UvcReadSoA columns of `reads` in device memory, allocated through the HIP runtime the library itself links (torch brings its own
+    copy of the runtime, which does not find the GPU once another copy has initialised it)."""
+    def __init__(self, reads, misalign=0):
+        import ctypes as C
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]; self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]; self.hip.hipFree.argtypes = [C.c_void_p]
+        self.ptrs = []
+        soa = _ffi.UvcReadSoA()
+        soa.n_reads = int(reads["n_reads"])
+
+        def put(a, dt, shift=0):
+            a = np.ascontiguousarray(a, dtype=dt)
+            p = C.c_void_p()
+            assert self.hip.hipMalloc(C.byref(p), a.nbytes + 64) == 0
+            self.ptrs.append(p)
+            if a.nbytes:
+                assert self.hip.hipMemcpy(p.value + shift, a.ctypes.data, a.nbytes, 1) == 0
+            return p.value + shift
+        for name, dt in region._READ_FIELDS:
+            setattr(soa, name, put(reads[name], dt))
+        for name, dt, cnt in (("bases", np.uint8, "n_bases"), ("quals", np.uint8, "n_bases"), ("cigars", np.uint32, "n_cigar_ops")):
+            setattr(soa, name, put(reads[name], dt, misalign if name != "cigars" else 0))
+            setattr(soa, cnt, int(np.asarray(reads[name]).size))
+        soa.n_fams = int(reads["n_fams"])
+        soa.fam_dflag = put(reads["fam_dflag"], np.uint8)
+        self.soa = soa
+
+    def free(self):
+        for p in self.ptrs:
+            self.hip.hipFree(p)
+
+
 def planes_and_records(R):
     R.accumulate()
     sums = {g: zlib.crc32(R.fetch(g).tobytes()) for g in GROUPS}
@@ -21,26 +54,18 @@ def planes_and_records(R):
 
 @pytest.mark.parametrize("kw", [dict(seed=21, region_len=6000, depth=120), dict(seed=22, region_len=2500, depth=300, umi=True)])
 def test_device_columns_equal_host_columns(kw, gpu_lib):
-    import torch
     reads = synth.generate_region(**kw)
     p = region.default_params(gpu_lib)
     Rh = region.Region(gpu_lib, p, reads["tid"], reads["beg"], reads["end"], reads["refseq"])
     Rh.set_reads(reads)
     want_sums, want_rec = planes_and_records(Rh)
-    dev = torch.device("cuda", 0)
-    Rd = region.Region(gpu_lib, p, reads["tid"], reads["beg"], reads["end"], reads["refseq"])
-    Rd.set_reads_device(region.device_reads(reads, dev))
-    sums, rec = planes_and_records(Rd)
-    assert sums == want_sums and all(np.array_equal(rec[k], want_rec[k]) for k in rec)
-    # the same columns again, bases and qualities as sub-arrays that start one byte into their allocations
-    soa, keep = region.device_reads(reads, dev)
-    b = np.ascontiguousarray(reads["bases"], np.uint8); q = np.ascontiguousarray(reads["quals"], np.uint8)
-    tb = torch.from_numpy(np.concatenate([[255], b]).astype(np.uint8)).to(dev); tq = torch.from_numpy(np.concatenate([[255], q]).astype(np.uint8)).to(dev)
-    soa.bases = tb.data_ptr() + 1; soa.quals = tq.data_ptr() + 1
-    assert soa.bases % 8 != 0
-    Ro = region.Region(gpu_lib, p, reads["tid"], reads["beg"], reads["end"], reads["refseq"])
-    Ro.set_reads_device((soa, keep + [tb, tq]))
-    sums, rec = planes_and_records(Ro)
-    assert sums == want_sums and all(np.array_equal(rec[k], want_rec[k]) for k in rec)
-    for R in (Rh, Rd, Ro):
-        R.close()
+    # aligned device columns, then bases and qualities as sub-arrays that start one byte into their allocations
+    for misalign in (0, 1):
+        cols = DeviceColumns(reads, misalign)
+        assert (cols.soa.bases % 8 != 0) == (misalign == 1)
+        Rd = region.Region(gpu_lib, p, reads["tid"], reads["beg"], reads["end"], reads["refseq"])
+        Rd.set_reads_device((cols.soa, cols))
+        sums, rec = planes_and_records(Rd)
+        assert sums == want_sums and all(np.array_equal(rec[k], want_rec[k]) for k in rec), misalign
+        Rd.close(); cols.free()
+    Rh.close()

@@ -95,7 +95,9 @@ def pack_reads(reads):
 
 def device_reads(reads, device):
     """The UvcReadSoA columns of `reads` as torch tensors on `device` (torch is only the owner of the HBM here) -> (UvcReadSoA of device
-    pointers, keepalive) for Region.set_reads_device: what a caller has whose decoder writes straight to the GPU."""
+    pointers, keepalive) for Region.set_reads_device: what a caller has whose decoder writes straight to the GPU.
+    torch ships its own copy of the HIP runtime: initialise torch.cuda BEFORE libuvcgpu.so touches the device (bench.py does), the other
+    order leaves torch without a GPU.  Without torch, allocate through the runtime the library links (tests/test_gpu_device_reads.py)."""
     import torch
     keep = []
     soa = _ffi.UvcReadSoA()
