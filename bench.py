@@ -279,6 +279,8 @@ def main():
                     pinned.append(a)
         n_extra = max(4, min(args.steps, 2 * T))
         n_thr = max(1, min(3, T))
+        import threading
+        handle_locks = [threading.Lock() for _ in range(T)]
 
         def run_threads(k0, n_steps):
             """Tiles in flight on host threads, as uvc1-mi355x runs them: thread w takes tiles k0 + w, k0 + w + n_thr, ...; the copy of one tile
@@ -287,7 +289,8 @@ def main():
             def work(w):
                 lib.dll.uvcgpu_init(local_rank)                 # hipSetDevice is per host thread
                 for k in range(k0 + w, k0 + n_steps, n_thr):
-                    prepare(k, True); finish(k)
+                    with handle_locks[k % T]:                    # a handle serves one tile at a time: a thread that runs ahead waits for it
+                        prepare(k, True); finish(k)
             th = [threading.Thread(target=work, args=(w,)) for w in range(n_thr)]
             for t in th: t.start()
             for t in th: t.join()

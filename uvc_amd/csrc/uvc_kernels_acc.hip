@@ -3187,6 +3187,9 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
             hipLaunchKernelGGL(k_gap_rows, dim3(nblk(G.inc_cap, 256)), dim3(256), 0, s, *R);
         });
     }
+    // per-unit statistics of the generic family units (medians, first / last consensus position, general-kind flag): they need the contribution
+    // table and the fragment records only, so they run behind the allele tables on the side stream, underneath k_frag
+    if (R->n_generic_fs) TIMED2(prof, "k_fam_stat", hipLaunchKernelGGL(k_fam_stat, dim3(nblk(R->n_generic_fs, 64)), dim3(64), 0, s, *R, *P));
     if (side) hipEventRecord(e_fork2, s2);
     if (P->inferred_is_vcf_generated && R->n_complex) TIMED(prof, "k_p2_items", hipLaunchKernelGGL(k_p2_items, dim3(R->n_complex), dim3(64), 0, s, *R, *P));
     {
@@ -3203,8 +3206,7 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
         else TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag<false>, dim3(nwin), dim3(256), 0, s, *R, *P));
     }
     if (R->n_generic_fs) {
-        if (side && G.n_ev > 0) hipStreamWaitEvent(s, e_fork2, 0);   // fam2_ins_len reads what k_gap_alleles left (done long before: it ran under k_frag)
-        TIMED(prof, "k_fam_stat", hipLaunchKernelGGL(k_fam_stat, dim3(nblk(R->n_generic_fs, 64)), dim3(64), 0, s, *R, *P));
+        if (side) hipStreamWaitEvent(s, e_fork2, 0);   // k_fam_stat's unit records; fam2_ins_len reads what k_gap_alleles left (both ran under k_frag)
         // shallow data: one thread per (unit, position); deep data (many units per position, e.g. UMI panels): the window kernel, whose
         // LDS collection removes most of the atomics that bound the per-thread form
         const bool deep = (R->fam_path == 1 ? false : (R->fam_path == 2 ? true : (R->n_generic_work > 8 * R->npos)));
