@@ -85,6 +85,32 @@ def replayed_traffic(kernel, tile_kb, depth):
         return None
 
 
+def valu_issue(kernel, kernel_ms, args):
+    """What actually bounds the kernel: the share of the chip's VALU issue slots it uses (1024 SIMDs, one wave64 VALU instruction per 4
+    cycles, 2.4 GHz max clock), from the replayed SQ_INSTS_VALU count and this run's duration."""
+    n = replayed_valu(kernel, args.tile_kb, args.depth)
+    if not n or not kernel_ms:
+        return None
+    slots = 1024 * (kernel_ms * 1e-3) * 2.4e9 / 4.0
+    return {"valu_wave_instructions_per_launch": n, "frac_of_issue_slots": n / slots, "clock_assumed_ghz": 2.4,
+            "source": "SQ_INSTS_VALU replayed from profiles/traffic_latest.json; the kernel is bound by instruction issue, not by HBM bytes (DESIGN.md section 6a)"}
+
+
+def replayed_valu(kernel, tile_kb, depth):
+    """VALU wave-instructions per launch of `kernel`, REPLAYED from the committed PMC pass (SQ_INSTS_VALU in profiles/traffic_latest.json)."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        t = json.load(open(path))
+        if t.get("_workload") != {"tile_kb": tile_kb, "depth": depth}:
+            return None
+        for name in PROFILE_NAMES.get(kernel, (kernel,)):
+            if name in t and "SQ_INSTS_VALU_per_launch" in t[name]:
+                return t[name]["SQ_INSTS_VALU_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def _cpu_region(args):
     from uvc_amd import synth
     seed, region_len, depth = args
@@ -339,6 +365,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": replayed_traffic(dom, args.tile_kb, args.depth), "traffic_source": "replayed from profiles/traffic_latest.json (two separate rocprofv3 --pmc passes), not measured in this run",
                          "algorithmic_bytes_per_launch": abytes, "kernel_ms": avg[dom],
+                         "valu_issue": valu_issue(dom, avg[dom], args),
                          "note": "HIP events on the library's stream over the timed steps; with pipelining another tile's preparation kernels may run beside the kernel (see resident.kernel_ms for the undisturbed durations)"},
             "kernel_ms": {k: round(v, 4) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])},
             "read_bases_per_s": n_reads_tile * READ_LEN * world * args.steps / dt,
