@@ -2645,27 +2645,30 @@ __global__ void __launch_bounds__(256) k_duplex(RegionDev R, UvcParams P, const 
 }
 
 // the duplex pass from the digests P4 left (k_fam_win<4, true>): the votes of the two strand units of a duplex family at a position
-__global__ void __launch_bounds__(256) k_duplex_d(RegionDev R, const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_work) {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_work) return;
-    int lo = 0, hi = n_dup;
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (dup_off[mid] <= w) lo = mid; else hi = mid; }
-    const FsRec u0 = R.fss[dup_units[lo]];
+__global__ void __launch_bounds__(64) k_duplex_d(RegionDev R, const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_work) {
+    // one wave per duplex family (its strand-0 unit), lanes over the positions of the two units' common span: no search for the family of a
+    // (family, position) cell, the two unit records are read once
+    if ((int)blockIdx.x >= n_dup) return;
+    const FsRec u0 = R.fss[dup_units[blockIdx.x]];
     const FsRec u1 = R.fss[u0.other_fs];
-    const int p = imin(u0.beg, u1.beg) + (int)(w - dup_off[lo]);
-    const int64_t x = p - R.beg;
-    uint32_t v[2] = { 0, 0 };
-    if (p >= u0.beg && p < u0.end) v[0] = R.fam_digest[8 * (u0.work_off + (int64_t)(p - u0.beg)) + 6];
-    if (p >= u1.beg && p < u1.end) v[1] = R.fam_digest[8 * (u1.work_off + (int64_t)(p - u1.beg)) + 6];
-    for (int vi = 0; vi < 2; vi++) {   // fill_consensus over at most two votes: the larger count wins, the smaller symbol on a tie
-        const uint32_t a = (v[0] >> (8 * vi)) & 31u, b = (v[1] >> (8 * vi)) & 31u;
-        const bool va = (a & 16u) != 0, vb = (b & 16u) != 0;
-        if (!va && !vb) continue;
-        const int sa = (int)(a & 15u), sb = (int)(b & 15u);
-        const int ct = (va ? 1 : 0) + (vb ? 1 : 0);
-        const int cs = (va && vb) ? ((sa == sb) ? sa : imin(sa, sb)) : (va ? sa : sb);
-        atomicAdd(&DUP(R, UVC_DUPLEX_dDP1, cs, x), 1);
-        if (1 < ct) atomicAdd(&DUP(R, UVC_DUPLEX_dDP2, cs, x), 1);   // tot_count of the two votes, as fill_consensus sums it (main.hpp:3540-3546)
+    const int pbeg = imin(u0.beg, u1.beg);
+    const int span = (int)(((int)blockIdx.x + 1 < n_dup ? dup_off[blockIdx.x + 1] : n_work) - dup_off[blockIdx.x]);   // the family's cells in the old (family, position) numbering
+    for (int i = (int)threadIdx.x; i < span; i += 64) {
+        const int p = pbeg + i;
+        const int64_t x = p - R.beg;
+        uint32_t v[2] = { 0, 0 };
+        if (p >= u0.beg && p < u0.end) v[0] = R.fam_digest[8 * (u0.work_off + (int64_t)(p - u0.beg)) + 6];
+        if (p >= u1.beg && p < u1.end) v[1] = R.fam_digest[8 * (u1.work_off + (int64_t)(p - u1.beg)) + 6];
+        for (int vi = 0; vi < 2; vi++) {   // fill_consensus over at most two votes: the larger count wins, the smaller symbol on a tie
+            const uint32_t a = (v[0] >> (8 * vi)) & 31u, b = (v[1] >> (8 * vi)) & 31u;
+            const bool va = (a & 16u) != 0, vb = (b & 16u) != 0;
+            if (!va && !vb) continue;
+            const int sa = (int)(a & 15u), sb = (int)(b & 15u);
+            const int ct = (va ? 1 : 0) + (vb ? 1 : 0);
+            const int cs = (va && vb) ? ((sa == sb) ? sa : imin(sa, sb)) : (va ? sa : sb);
+            atomicAdd(&DUP(R, UVC_DUPLEX_dDP1, cs, x), 1);
+            if (1 < ct) atomicAdd(&DUP(R, UVC_DUPLEX_dDP2, cs, x), 1);   // tot_count of the two votes, as fill_consensus sums it (main.hpp:3540-3546)
+        }
     }
 }
 
@@ -3218,7 +3221,7 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
         if (P->inferred_is_vcf_generated) {
             if (digest) TIMED(prof, "k_fam_p5", hipLaunchKernelGGL((k_fam_win<5, true>), dim3(nblk(R->npos, 64)), dim3(256), 0, s, *R, *P));
             else TIMED(prof, "k_fam_p5", hipLaunchKernelGGL(k_fam_p5, dim3(nblk(R->n_generic_work, 256)), dim3(256), 0, s, *R, *P));
-            if (n_dup && digest) TIMED(prof, "k_duplex", hipLaunchKernelGGL(k_duplex_d, dim3(nblk(n_dup_work, 256)), dim3(256), 0, s, *R, dup_units, n_dup, dup_off, n_dup_work));
+            if (n_dup && digest) TIMED(prof, "k_duplex", hipLaunchKernelGGL(k_duplex_d, dim3(n_dup), dim3(64), 0, s, *R, dup_units, n_dup, dup_off, n_dup_work));
             else if (n_dup) TIMED(prof, "k_duplex", hipLaunchKernelGGL(k_duplex, dim3(nblk(n_dup_work, 256)), dim3(256), 0, s, *R, *P, dup_units, n_dup, dup_off, n_dup_work));
         }
     }
