@@ -412,6 +412,11 @@ int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *contig_name, const
  * arrays of uvcgpu_region_set_reads): copies then run at PCIe speed.  Unpin before freeing the buffer. */
 int uvcgpu_pin_host_buffer(void *p, int64_t bytes);
 int uvcgpu_unpin_host_buffer(void *p);
+/* Page-locked host memory owned by the library (hipHostMalloc): the safe home of a records buffer that lives as long as a handle.  Pinning
+ * a heap buffer in place works, but heap pages change roles -- memory that once was the (read-only mapped) source of a pageable upload and
+ * was freed can come back as the buffer the records are written to, and the copy then faults ("write access to a read-only page"). */
+int uvcgpu_host_alloc(void **p, int64_t bytes);
+int uvcgpu_host_free(void *p);
 int uvcgpu_region_sync(uvcgpu_region_t *r);
 /* Measurement hooks (bench.py): HIP-event timing of every kernel of the LAST accumulate, recorded on the handle's stream.
  * kernel_times returns the number of kernels; `names` receives their names separated by ';'. */

@@ -49,7 +49,14 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // C++ exceptions must not cross the C boundary (std::terminate would take the caller's process down): every entry point that allocates
 // host memory reports them as an error code instead
 template <class F> static int guarded(const char *what, F &&f) {
-    try { return f(); }
+    try {
+        const int rc = f();
+        // a HIP call whose failure was handled (or did not matter) still leaves its code in the thread's "last error", where the launch checks of
+        // rocPRIM in a later call would find it and refuse: it ends here (UVCGPU_DEBUG names the entry point that left one)
+        const hipError_t stale = hipGetLastError();
+        if (stale != hipSuccess && getenv("UVCGPU_DEBUG")) fprintf(stderr, "[uvcgpu] %s (rc %d) left HIP error: %s\n", what, rc, hipGetErrorString(stale));
+        return rc;
+    }
     catch (const std::bad_alloc &) { return fail(UVCGPU_ENOMEM, std::string(what) + ": out of host memory"); }
     catch (const std::exception &e) { return fail(UVCGPU_EDEVICE, std::string(what) + ": " + e.what()); }
 }
@@ -83,6 +90,7 @@ struct uvcgpu_region {
     // persistent scoring buffers (grown on demand)
     long long *d_score_scratch = nullptr; size_t score_scratch_bytes = 0;
     int32_t *d_score_fields = nullptr; int64_t score_capacity = 0; int64_t *d_score_count = nullptr;
+    uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;   // page-locked staging for the small per-call uploads of score (tumor keys, caller's alleles): never the caller's own pages
     int32_t *d_score_kept = nullptr; int64_t score_kept_capacity = 0;   // UvcScoreRequest::kept_only: the compacted copy, same pitch as d_score_fields
     // InDel allele tables of the last accumulate (built on first use by gap_tables)
     bool gap_ready = false;
@@ -675,6 +683,19 @@ int uvcgpu_pin_host_buffer(void *p, int64_t bytes) {
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(UVCGPU_EDEVICE, std::string("hipHostRegister: ") + hipGetErrorString(e)); }
     return 0;
 }
+int uvcgpu_host_alloc(void **p, int64_t bytes) {
+    if (!p || bytes <= 0) return fail(UVCGPU_EINVAL, "bad argument");
+    *p = nullptr;
+    hipError_t e = hipHostMalloc(p, (size_t)bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return fail(UVCGPU_ENOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+    return 0;
+}
+int uvcgpu_host_free(void *p) {
+    if (!p) return 0;
+    hipError_t e = hipHostFree(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); if (getenv("UVCGPU_DEBUG")) fprintf(stderr, "[uvcgpu] hipHostFree: %s\n", hipGetErrorString(e)); return fail(UVCGPU_EDEVICE, std::string("hipHostFree: ") + hipGetErrorString(e)); }
+    return 0;
+}
 int uvcgpu_unpin_host_buffer(void *p) {
     if (!p) return 0;
     hipError_t e = hipHostUnregister(p);
@@ -882,6 +903,23 @@ int64_t uvcgpu_region_score_size(const uvcgpu_region_t *r, const UvcScoreRequest
     return NSYM * (np + 1) + (req ? req->n_indel_alleles + req->n_tumor_keys : 0) + (int64_t)r->gap_alleles.size();
 }
 
+// Small host arrays of a score call go to the device through the handle's own page-locked staging buffer: an asynchronous copy straight from
+// the caller's pageable memory lets the runtime map those heap pages for the GPU (read-only, as a copy source), and heap pages come back to the
+// caller in other roles -- as a records buffer the next copy writes to.  `at` advances through the staging buffer within one call.
+static int stage_upload(uvcgpu_region_t *r, void *dst, const void *src, size_t bytes, size_t &at, size_t total) {
+    if (total > r->h_stage_cap) {
+        if (r->h_stage) { (void)hipStreamSynchronize(r->stream); (void)hipHostFree(r->h_stage); }
+        r->h_stage = nullptr; r->h_stage_cap = 0;
+        const size_t want = total + total / 2 + 4096;
+        if (hipHostMalloc((void **)&r->h_stage, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail(UVCGPU_ENOMEM, "hipHostMalloc(staging)"); }
+        r->h_stage_cap = want;
+    }
+    memcpy(r->h_stage + at, src, bytes);
+    if (hipMemcpyAsync(dst, r->h_stage + at, bytes, hipMemcpyHostToDevice, r->stream) != hipSuccess) return fail(UVCGPU_EDEVICE, "hipMemcpyAsync(staging)");
+    at += (bytes + 63) & ~(size_t)63;
+    return 0;
+}
+
 static int uvcgpu_region_score_impl(uvcgpu_region_t *r, const UvcScoreRequest *req, UvcScoreOut *out) {
     if (!r || !out || !out->fields) return fail(UVCGPU_EINVAL, "bad argument");
     if (!r->accumulated) return fail(UVCGPU_ESTATE, "score before accumulate");
@@ -901,6 +939,9 @@ static int uvcgpu_region_score_impl(uvcgpu_region_t *r, const UvcScoreRequest *r
     struct Temps { uvcgpu_region *r; UvcIndelAllele *&a; int32_t *&b; UvcTumorKey *&c;
                    ~Temps() { if (a || b || c) (void)hipStreamSynchronize(r->stream); if (a) hipFree(a); if (b) hipFree(b); if (c) hipFree(c); } } temps = { r, d_al, d_al_row, d_tk };
     const UvcIndelAllele *use_al = r->d_gap_alleles; const int32_t *use_row = r->d_gap_allele_row; int64_t n_al = (int64_t)r->gap_alleles.size();
+    // one staging layout per call (an earlier call's copies are complete: score synchronises before it returns)
+    size_t stage_at = 0;
+    const size_t stage_total = (sizeof(UvcIndelAllele) + sizeof(int32_t)) * (size_t)(r->gap_alleles.size() + (size_t)std::max<int64_t>(rq.n_indel_alleles, 0)) + sizeof(UvcTumorKey) * (size_t)std::max<int64_t>(rq.n_tumor_keys, 0) + 256;
     if (rq.n_indel_alleles > 0) {
         auto less = [](const UvcIndelAllele &a, const UvcIndelAllele &b) { return a.refpos < b.refpos || (a.refpos == b.refpos && a.symbol < b.symbol); };
         for (int64_t q = 1; q < rq.n_indel_alleles; q++) if (less(rq.indel_alleles[q], rq.indel_alleles[q - 1])) return fail(UVCGPU_EINVAL, "indel_alleles must be sorted by (refpos, symbol)");
@@ -915,8 +956,8 @@ static int uvcgpu_region_score_impl(uvcgpu_region_t *r, const UvcScoreRequest *r
         n_al = (int64_t)merged.size();
         HIP_OK(hipMalloc((void **)&d_al, sizeof(UvcIndelAllele) * (size_t)n_al));
         HIP_OK(hipMalloc((void **)&d_al_row, sizeof(int32_t) * (size_t)n_al));
-        HIP_OK(hipMemcpyAsync(d_al, merged.data(), sizeof(UvcIndelAllele) * (size_t)n_al, hipMemcpyHostToDevice, r->stream));
-        HIP_OK(hipMemcpyAsync(d_al_row, merged_row.data(), sizeof(int32_t) * (size_t)n_al, hipMemcpyHostToDevice, r->stream));
+        { int rc1 = stage_upload(r, d_al, merged.data(), sizeof(UvcIndelAllele) * (size_t)n_al, stage_at, stage_total); if (rc1) return rc1; }
+        { int rc1 = stage_upload(r, d_al_row, merged_row.data(), sizeof(int32_t) * (size_t)n_al, stage_at, stage_total); if (rc1) return rc1; }
         use_al = d_al; use_row = d_al_row;
     }
     if (r->P.tumor_vcf_is_provided && rq.n_tumor_keys > 0) {   // normal sample of a T/N pair: the tumor records, sorted by (refpos, symbol)
@@ -925,7 +966,7 @@ static int uvcgpu_region_score_impl(uvcgpu_region_t *r, const UvcScoreRequest *r
             if (a.refpos > b.refpos || (a.refpos == b.refpos && a.symbol > b.symbol)) return fail(UVCGPU_EINVAL, "tumor_keys must be sorted by (refpos, symbol)");
         }
         HIP_OK(hipMalloc((void **)&d_tk, sizeof(UvcTumorKey) * rq.n_tumor_keys));
-        HIP_OK(hipMemcpyAsync(d_tk, rq.tumor_keys, sizeof(UvcTumorKey) * rq.n_tumor_keys, hipMemcpyHostToDevice, r->stream));
+        { int rc1 = stage_upload(r, d_tk, rq.tumor_keys, sizeof(UvcTumorKey) * (size_t)rq.n_tumor_keys, stage_at, stage_total); if (rc1) return rc1; }
     }
     const bool kept_only = (rq.kept_only != 0);
     // device capacity: the caller's in the plain form; with kept_only the caller's buffer only has to hold the kept groups, the device
@@ -1014,12 +1055,14 @@ void uvcgpu_region_destroy(uvcgpu_region_t *r) {
     if (r->d_score_fields) hipFree(r->d_score_fields);
     if (r->d_score_count) hipFree(r->d_score_count);
     if (r->d_score_kept) hipFree(r->d_score_kept);
+    if (r->h_stage) (void)hipHostFree(r->h_stage);
     if (r->d_gap_alleles) hipFree(r->d_gap_alleles);
     if (r->d_gap_allele_row) hipFree(r->d_gap_allele_row);
     if (r->d_gap_rows) hipFree(r->d_gap_rows);
     if (r->d_gap_seq) hipFree(r->d_gap_seq);
     if (r->stream) hipStreamDestroy(r->stream);
     delete r;
+    { const hipError_t stale = hipGetLastError(); if (stale != hipSuccess && getenv("UVCGPU_DEBUG")) fprintf(stderr, "[uvcgpu] uvcgpu_region_destroy left HIP error: %s\n", hipGetErrorString(stale)); }
 }
 
 }  // extern "C"

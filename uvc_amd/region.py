@@ -173,8 +173,7 @@ class Region:
             fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p]
             self._check(fn(self.h, tid, beg, end, ref))
         self.tid, self.beg, self.end, self.npos = tid, beg, end, end - beg + 1
-        self._unpin_score_buf()
-        self._score_buf = None
+        self._free_score_buf()
 
     def set_reads(self, reads):
         soa, keep = pack_reads(reads)
@@ -294,12 +293,8 @@ class Region:
         while True:
             buf = getattr(self, "_score_buf", None)   # reused across calls: the library fills n_records columns of every row
             if buf is None or buf.shape[1] != capacity:
-                self._unpin_score_buf()
-                buf = self._score_buf = np.empty((_ffi.NUM_SCORE_FIELDS, capacity), dtype=np.int32)
-                pin = getattr(self.lib.dll, self.lib.prefix + "pin_host_buffer", None)   # page-locked: the D2H of the records runs at PCIe speed
-                if pin is not None and not os.environ.get("UVC_NO_PIN"):
-                    pin.restype, pin.argtypes = C.c_int, [C.c_void_p, C.c_int64]
-                    self._score_buf_pinned = (pin(buf.ctypes.data, buf.nbytes) == 0)
+                self._free_score_buf()
+                buf = self._score_buf = self._alloc_score_buf(capacity)
             out = _ffi.UvcScoreOut(capacity, 0, buf.ctypes.data)
             rc = self.lib.call("score", self.h, C.byref(req), C.byref(out))
             if rc == -6 and out.n_records > capacity:
@@ -344,16 +339,32 @@ class Region:
         self._check(fn(self.h, contig_name.encode(), C.byref(so), C.byref(req), dst, ln.value, C.byref(ln)))
         return dst.raw[:ln.value].decode()
 
-    def _unpin_score_buf(self):
-        if getattr(self, "_score_buf_pinned", False) and getattr(self, "_score_buf", None) is not None:
-            fn = getattr(self.lib.dll, self.lib.prefix + "unpin_host_buffer")
+    def _alloc_score_buf(self, capacity):
+        """[NUM_SCORE_FIELDS][capacity] int32 in page-locked memory of the library's own (uvcgpu_host_alloc), so that the D2H of the records runs
+        at PCIe speed.  Not a pinned numpy buffer: heap pages that once were the source of a pageable upload can be mapped read-only for the
+        GPU and come back from the allocator as such a buffer.  Libraries without the call (the oracle) get a plain array."""
+        n = _ffi.NUM_SCORE_FIELDS * capacity
+        alloc = getattr(self.lib.dll, self.lib.prefix + "host_alloc", None)
+        if alloc is not None and not os.environ.get("UVC_NO_PIN"):
+            alloc.restype, alloc.argtypes = C.c_int, [C.POINTER(C.c_void_p), C.c_int64]
+            p = C.c_void_p()
+            if alloc(C.byref(p), n * 4) == 0 and p.value:
+                self._score_buf_host = p
+                return np.ctypeslib.as_array((C.c_int32 * n).from_address(p.value)).reshape(_ffi.NUM_SCORE_FIELDS, capacity)
+        self._score_buf_host = None
+        return np.empty((_ffi.NUM_SCORE_FIELDS, capacity), dtype=np.int32)
+
+    def _free_score_buf(self):
+        p = getattr(self, "_score_buf_host", None)
+        self._score_buf = None
+        if p is not None and p.value:
+            fn = getattr(self.lib.dll, self.lib.prefix + "host_free")
             fn.restype, fn.argtypes = C.c_int, [C.c_void_p]
-            fn(self._score_buf.ctypes.data)
-        self._score_buf_pinned = False
+            fn(p)
+        self._score_buf_host = None
 
     def close(self):
-        self._unpin_score_buf()
-        self._score_buf = None
+        self._free_score_buf()
         if self.h:
             self.lib.call("destroy", self.h)
             self.h = C.c_void_p()
