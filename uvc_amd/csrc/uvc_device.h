@@ -95,8 +95,12 @@ struct MisItem { int32_t rank, epos, symval; };
 // The first 12 dwords of a FragFast record again, indexed by fragment number (the fragments of a family-strand unit are consecutive):
 // k_fam_p4d reaches the records of a unit without the frag_rank indirection.
 struct FragUnit { int32_t v[12]; };
+// What a plain fragment (<= 2 simple alignments, flags & 0x301 == 0) adds to LINK_M and to "some base" at a position does not depend on the
+// position's bases: a count by micro_nogap_penal class (1..5) for the bucket histogram and sums of per-fragment constants.  k_frag_sums builds
+// them as interval sums (O(1) per fragment and plane), k_frag reads them back per position instead of adding them per (fragment, position).
+enum { UVC_FSUM_LCNT = 0 /* .. 4: LINK_M by class */, UVC_FSUM_LTA = 5, UVC_FSUM_LTB, UVC_FSUM_LSING, UVC_FSUM_LMQ, UVC_FSUM_BDP, UVC_FSUM_BTA, UVC_FSUM_BTB, UVC_FSUM_BMQ, UVC_FSUM_N };
 struct FragFast {
-    int32_t beg, end, fi, flags;        // flags: bit0 generic path only, bit1 strand, bit2 singleton, bits 3..6 number of alignments, bit8 has runs B / special ranges
+    int32_t beg, end, fi, flags;        // flags: bit0 generic path only, bit1 strand, bit2 singleton, bits 3..6 number of alignments, bit8 has runs B / special ranges, bit9 a micro_nogap_penal outside 1..5 (k_frag adds its LINK_M per position)
     int32_t pos0, rend0, pos1, rend1;   // run A of alignment 0 / 1: [pos, rend)
     int32_t qb0, qb1, nogap0, nogap1;   // low word of the query offset of run A; micro_nogap_penal of the alignment
     int32_t sq, n_cov, n_near, pad_;    // sq = normMQ^2 / SQR_QUAL_DIV
@@ -161,6 +165,8 @@ struct RegionDev {
     int32_t frag_off[3];            // ffast = the strand-0 fragments sorted by beg, then the strand-1 fragments sorted by beg
     FragFast *ffast;                // [n_frags] in (strand, beg)-sorted order
     FragUnit *ffast_u;              // [n_frags] by fragment number (see FragUnit)
+    int32_t *win; int32_t nwin;     // window index [7 lists][lo, hi][nwin = ceil(npos / 64)] (k_win_index)
+    int32_t *fsum;                  // [2 strands][UVC_FSUM_N][npos]: interval sums of the plain fragments (k_frag_sums), read by k_frag
     FsRec *fss; int32_t n_fs;
     const int32_t *generic_fs; int32_t n_generic_fs; int64_t n_generic_work;
     const int32_t *generic_sorted; int32_t max_unit_span;   // the generic units ordered by FsRec::beg (window kernels k_fam_win)
@@ -269,6 +275,22 @@ DEV void infer_max_qual(int &maxvqual, int &argmaxAD, int &argmaxBQ, int max_qua
         const double expBQ = 10.0 / log(10.0) * log(((double)totDP / (double)currAD) + 2.220446049250313e-16);
         const int currvqual = (int)(currAD * (currBQ - expBQ));
         if (currvqual > maxvqual) { argmaxAD = currAD; argmaxBQ = currBQ; maxvqual = currvqual; }
+    }
+}
+
+// the same with the bucket counts in registers (fully unrolled: static indices), dec_qual == 1
+DEV void infer_max_qual_regs(int &maxvqual, int &argmaxAD, int &argmaxBQ, int max_qual, int totDP, const int (&h)[NBUCKETS]) {
+    int currAD = 0;
+    maxvqual = 0; argmaxAD = 0; argmaxBQ = 0;
+#pragma unroll
+    for (int idx = 0; idx < NBUCKETS; idx++) {
+        if (idx < max_qual && h[idx] != 0) {
+            currAD += h[idx];
+            const int currBQ = max_qual - idx;
+            const double expBQ = 10.0 / log(10.0) * log(((double)totDP / (double)currAD) + 2.220446049250313e-16);
+            const int currvqual = (int)(currAD * (currBQ - expBQ));
+            if (currvqual > maxvqual) { argmaxAD = currAD; argmaxBQ = currBQ; maxvqual = currvqual; }
+        }
     }
 }
 

@@ -72,7 +72,7 @@ struct uvcgpu_region {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr; hipEvent_t e_fork = nullptr, e_join = nullptr, e_fork2 = nullptr;   // fork/join inside accumulate (see uvc_launch_accumulate)
     // device buffers
-    uint8_t *d_refsym = nullptr; int32_t *d_rtr = nullptr, *d_rtr0 = nullptr; int64_t *d_baq = nullptr;
+    uint8_t *d_refsym = nullptr; int32_t *d_rtr = nullptr, *d_rtr0 = nullptr, *d_fsum = nullptr, *d_win = nullptr; int64_t *d_baq = nullptr;
     char *d_state = nullptr; size_t state_bytes = 0;
     int64_t npos_cap = 0;         // positions the side arrays and the slab were allocated for (uvcgpu_region_reset reuses them)
     size_t bucket_off = 0; bool buckets_clean = false;   // the transient bucket planes (tail of the slab) are left zero by P3b / P5b
@@ -305,10 +305,10 @@ static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t 
     r->state_bytes = o;
     if (r->npos > r->npos_cap) {
         quiesce(r);
-        for (void *p : { (void *)r->d_refsym, (void *)r->d_rtr, (void *)r->d_rtr0, (void *)r->d_baq, (void *)r->d_state }) if (p) hipFree(p);
-        r->d_refsym = nullptr; r->d_rtr = r->d_rtr0 = nullptr; r->d_baq = nullptr; r->d_state = nullptr; r->npos_cap = 0;
+        for (void *p : { (void *)r->d_refsym, (void *)r->d_rtr, (void *)r->d_rtr0, (void *)r->d_fsum, (void *)r->d_win, (void *)r->d_baq, (void *)r->d_state }) if (p) hipFree(p);
+        r->d_refsym = nullptr; r->d_rtr = r->d_rtr0 = r->d_fsum = r->d_win = nullptr; r->d_baq = nullptr; r->d_state = nullptr; r->npos_cap = 0;
         if (hipMalloc((void **)&r->d_refsym, (size_t)r->npos + 1) != hipSuccess || hipMalloc((void **)&r->d_rtr, sizeof(int32_t) * rtr.size()) != hipSuccess
-            || hipMalloc((void **)&r->d_rtr0, sizeof(int32_t) * rtr.size()) != hipSuccess || hipMalloc((void **)&r->d_baq, sizeof(int64_t) * baq.size()) != hipSuccess
+            || hipMalloc((void **)&r->d_rtr0, sizeof(int32_t) * rtr.size()) != hipSuccess || hipMalloc((void **)&r->d_fsum, sizeof(int32_t) * 2 * UVC_FSUM_N * (size_t)r->npos) != hipSuccess || hipMalloc((void **)&r->d_win, sizeof(int32_t) * 14 * (size_t)((r->npos + 63) / 64)) != hipSuccess || hipMalloc((void **)&r->d_baq, sizeof(int64_t) * baq.size()) != hipSuccess
             || hipMalloc((void **)&r->d_state, r->state_bytes) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(region planes) failed");
         r->npos_cap = r->npos;
     }
@@ -319,7 +319,7 @@ static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t 
     int32_t *d_err = r->R.err;
     RegionDev &R = r->R;
     memset(&R, 0, sizeof(R));
-    R.beg = r->beg; R.end = r->end; R.npos = r->npos; R.refsym = r->d_refsym; R.rtr = r->d_rtr; R.baq = r->d_baq;
+    R.beg = r->beg; R.end = r->end; R.npos = r->npos; R.refsym = r->d_refsym; R.rtr = r->d_rtr; R.baq = r->d_baq; R.fsum = r->d_fsum; R.win = r->d_win; R.nwin = (int32_t)((r->npos + 63) / 64);
     char *b = r->d_state;
     R.prep64 = (int64_t *)(b + r->off[UVC_F_PREP64]); R.seg64 = (int64_t *)(b + r->off[UVC_F_SEG64]); R.faminfo64 = (int64_t *)(b + r->off[UVC_F_FAMINFO64]);
     R.prep32 = (int32_t *)(b + r->off[UVC_F_PREP32]); R.thres = (int32_t *)(b + r->off[UVC_F_THRES]); R.seg32 = (int32_t *)(b + r->off[UVC_F_SEG32]);
@@ -1045,6 +1045,8 @@ void uvcgpu_region_destroy(uvcgpu_region_t *r) {
     if (r->d_rtr) hipFree(r->d_rtr);
     if (r->d_rtr0) hipFree(r->d_rtr0);
     if (r->d_baq) hipFree(r->d_baq);
+    if (r->d_fsum) hipFree(r->d_fsum);
+    if (r->d_win) hipFree(r->d_win);
     if (r->side) hipStreamDestroy(r->side);
     if (r->e_fork) hipEventDestroy(r->e_fork);
     if (r->e_join) hipEventDestroy(r->e_join);

@@ -68,6 +68,26 @@ DEV int lower_bound_frec(const FastRec *a, int n, int key) {   // first index wi
     while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid].pos < key) lo = mid + 1; else hi = mid; }
     return lo;
 }
+// Window index: for every 64-position window w and every begin-sorted work list, the records a wave of window w walks:
+// [first record with begin >= window begin - longest span + 1, first record with begin >= window end).  A binary search per wave and list is
+// ~20 dependent memory round trips (8 lists' bounds in k_p2_fast: an eighth of a wave's life); the table costs one load each.
+// Lists: 0 = frec (k_prep_fast), 1..4 = the four sub-lists of frec2 (k_p2_fast), 5..6 = the two strands of ffast (k_frag).
+#define WIN_LISTS 7
+DEV int win_lo(const RegionDev &R, int list, int w) { return R.win[((size_t)list * 2) * R.nwin + w]; }
+DEV int win_hi(const RegionDev &R, int list, int w) { return R.win[((size_t)list * 2 + 1) * R.nwin + w]; }
+__global__ void __launch_bounds__(256) k_win_index(RegionDev R, int list_beg, int list_end) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per_list = 2 * (int64_t)R.nwin;
+    if (t >= per_list * (list_end - list_beg)) return;
+    const int list = list_beg + (int)(t / per_list), which = (int)((t % per_list) / R.nwin), w = (int)(t % R.nwin);
+    const char *base; int stride, lo, hi, span;
+    if (list == 0) { base = (const char *)&R.frec[0].pos; stride = sizeof(FastRec); lo = 0; hi = R.n_fast; span = R.max_aln_span; }
+    else if (list <= 4) { base = (const char *)&R.frec2[0].pos; stride = sizeof(FastRec); lo = R.p2_off[list - 1]; hi = R.p2_off[list]; span = R.max_p2_span; }
+    else { base = (const char *)&R.ffast[0].beg; stride = sizeof(FragFast); lo = R.frag_off[list - 5]; hi = R.frag_off[list - 4]; span = R.max_frag_span; }
+    const int w0 = R.beg + 64 * w, key = (which == 0 ? w0 - span + 1 : w0 + 64);
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (*(const int32_t *)(base + (size_t)mid * stride) < key) lo = mid + 1; else hi = mid; }
+    R.win[((size_t)list * 2 + which) * R.nwin + w] = lo;
+}
 DEV int lower_bound_pos(const AlnRec *a, int n, int key) {   // first index with a[i].pos >= key
     int lo = 0, hi = n;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid].pos < key) lo = mid + 1; else hi = mid; }
@@ -572,8 +592,7 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
     const int my_baq = valid ? (int)R.baq[x] : 0;
     int dp = 0, pcr = 0, umi = 0, qlen_s = 0, xm_s = 0, lidp = 0, ridp = 0, ldist = 0, rdist = 0, hbq = 0;
     long long li = 0, ri = 0, lbaq = 0, rbaq = 0;
-    const int lo = wave_uniform(lower_bound_frec(R.frec, R.n_fast, w0 - R.max_aln_span + 1));
-    const int hi = wave_uniform(lower_bound_frec(R.frec, R.n_fast, w0 + 64));
+    const int lo = wave_uniform(win_lo(R, 0, (int)(x0 >> 6))), hi = wave_uniform(win_hi(R, 0, (int)(x0 >> 6)));
     const __amdgpu_buffer_rsrc_t rs = bq_rsrc(R);
     // Mismatching bases are rare per lane but present in a large share of the iterations of a wave, and their handling (SNV / DNV
     // run detection, fragment mutation events) is a chain of dependent loads.  They are queued per wave and handled 64 at a time,
@@ -927,10 +946,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k
     };
     const __amdgpu_buffer_rsrc_t rs = bq_rsrc(R);
     // the work list is stored as four pos-sorted sub-lists, one per (is-reverse, bam_get_strand) class
-    auto run_list = [&](auto IS, auto ST, int seg_beg, int seg_end) {
+    auto run_list = [&](auto IS, auto ST, int cls) {
     constexpr bool ISRC = decltype(IS)::value, STRAND = decltype(ST)::value;
-    const int lo = wave_uniform(seg_beg + lower_bound_frec(R.frec2 + seg_beg, seg_end - seg_beg, w0 - R.max_p2_span + 1));
-    const int hi = wave_uniform(seg_beg + lower_bound_frec(R.frec2 + seg_beg, seg_end - seg_beg, w0 + 64));
+    const int lo = wave_uniform(win_lo(R, 1 + cls, (int)(x0 >> 6))), hi = wave_uniform(win_hi(R, 1 + cls, (int)(x0 >> 6)));
     for (int k0 = lo; k0 < hi; k0 += 64) {
         Chunk16 c;
         load_chunk16(R.frec2, k0 + lane, hi, c);
@@ -990,10 +1008,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k
         }
     }
     };
-    run_list(std::false_type{}, std::false_type{}, R.p2_off[0], R.p2_off[1]);
-    run_list(std::true_type{}, std::false_type{}, R.p2_off[1], R.p2_off[2]);
-    run_list(std::false_type{}, std::true_type{}, R.p2_off[2], R.p2_off[3]);
-    run_list(std::true_type{}, std::true_type{}, R.p2_off[3], R.p2_off[4]);
+    run_list(std::false_type{}, std::false_type{}, 0);
+    run_list(std::true_type{}, std::false_type{}, 1);
+    run_list(std::false_type{}, std::true_type{}, 2);
+    run_list(std::true_type{}, std::true_type{}, 3);
     if (DO_B && nq > 0) flush_queue();
     if (!valid) return;
     // k_p2_fast runs before every other writer of these planes (k_p2_mism, k_p2_items), and the two instantiations own
@@ -1491,6 +1509,9 @@ __global__ void __launch_bounds__(256) k_fragstat_fast(RegionDev R, UvcParams P)
         if (c < a1) { int t = a1; a1 = c; c = t; t = b1; b1 = d; d = t; }
         if (c <= b1) { b1 = imax(b1, d); } else { a2 = c; b2 = d; }
     }
+    // k_frag_sums counts LINK_M by micro_nogap_penal class 1..5 (main.hpp:1882-1885 gives min(4, ..) + 1; below 1 only when NM is smaller than
+    // the InDel lengths it should contain): anything else keeps the per-position form
+    if (ff.nogap0 < 1 || ff.nogap0 > 5 || (f.aln_end - f.aln_beg == 2 && (ff.nogap1 < 1 || ff.nogap1 > 5))) ff.flags |= 0x200;
     const int n_cov = (b1 - a1) + (b2 - a2);
     int n_near = 0;
     if (nm > UVC_MAXEV) {   // too many events for the closed form: the sweep kernel (overflow pass) fills n_cov / n_near of this record
@@ -1512,6 +1533,88 @@ __global__ void __launch_bounds__(256) k_fragstat_fast(RegionDev R, UvcParams P)
     R.frags[fi].n_cov = n_cov; R.frags[fi].n_near = n_near;
     ff.n_cov = n_cov; ff.n_near = n_near;
     R.ffast[R.frag_rank[fi]] = ff; R.ffast_u[fi] = *(const FragUnit *)&ff;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_frag_sums: what the plain fragments add to LINK_M and to "a base is here" at every position, as interval sums.
+// For a fragment of <= 2 simple alignments the LINK_M consensus at p is max(noindel80(p) - micro_nogap_penal, 0) + 1 of the better mate that
+// has a link at p (main.hpp:1919-1923, 339-349): given the position it depends on the fragment through the penalty class only, and bDP / bTA /
+// bTB / bMQ / the singleton votes are per-fragment constants.  One block per (tile of FSUM_TILE positions, strand): a lane per fragment adds
+// +v at the begin and -v at the end of each of its <= 3 class pieces in LDS, a block-wide prefix sum turns the differences into sums.
+// k_frag then spends nothing per (fragment, position) on LINK_M, and on the base side only what depends on the base and its quality.
+// ------------------------------------------------------------------------------------------------
+#define FSUM_TILE 1024
+__global__ void __launch_bounds__(256) k_frag_sums(RegionDev R, UvcParams P) {
+    __shared__ int d[UVC_FSUM_N][FSUM_TILE + 1];
+    __shared__ int wtot[4];
+    const int strand = blockIdx.y;
+    const int t0 = R.beg + (int)blockIdx.x * FSUM_TILE, t1 = imin(t0 + FSUM_TILE, R.beg + (int)R.npos);
+    for (int i = threadIdx.x; i < UVC_FSUM_N * (FSUM_TILE + 1); i += 256) (&d[0][0])[i] = 0;
+    __syncthreads();
+    const int seg_beg = R.frag_off[strand], seg_end = R.frag_off[strand + 1];
+    int lo, hi;
+    {
+        int l = seg_beg, h = seg_end;
+        const int key = t0 - R.max_frag_span + 1;
+        while (l < h) { const int m = (l + h) >> 1; if (R.ffast[m].beg < key) l = m + 1; else h = m; }
+        lo = l; h = seg_end;
+        while (l < h) { const int m = (l + h) >> 1; if (R.ffast[m].beg < t1) l = m + 1; else h = m; }
+        hi = l;
+    }
+    auto put = [&](int f, int a, int b, int v) {   // += v on [a, b) of plane f, clipped to the tile
+        a = imax(a, t0); b = imin(b, t1);
+        if (a < b) { atomicAdd(&d[f][a - t0], v); atomicAdd(&d[f][b - t0], -v); }
+    };
+    for (int k = lo + (int)threadIdx.x; k < hi; k += 256) {
+        const int4 *q4 = (const int4 *)(R.ffast + k);
+        const int4 h0 = q4[0];   // beg, end, fi, flags
+        if ((h0.w & 0x301) || h0.y <= t0) continue;
+        const int4 h1 = q4[1], h2 = q4[2], h3 = q4[3];   // pos0 rend0 pos1 rend1 | qb0 qb1 nogap0 nogap1 | sq n_cov n_near
+        const bool has2 = (((h0.w >> 3) & 0xF) == 2);
+        const int sing = (h0.w >> 2) & 1, sq = h3.x, n_cov = h3.y, n_near = h3.z;
+        // k_frag only looks at positions of [beg, end)
+        const int a0 = imax(h1.x, h0.x), a1 = imin(h1.y, h0.y), b0 = (has2 ? imax(h1.z, h0.x) : 0), b1 = (has2 ? imin(h1.w, h0.y) : 0);
+        {   // base side: the union of [a0, a1) and [b0, b1)
+            auto base = [&](int a, int b) { put(UVC_FSUM_BDP, a, b, 1); put(UVC_FSUM_BTA, a, b, n_cov); put(UVC_FSUM_BTB, a, b, n_near); put(UVC_FSUM_BMQ, a, b, sq); };
+            if (a0 < a1 && b0 < b1 && imax(a0, b0) <= imin(a1, b1)) base(imin(a0, b0), imax(a1, b1));
+            else { if (a0 < a1) base(a0, a1); if (b0 < b1) base(b0, b1); }
+        }
+        {   // LINK_M exists from the second base of a run on: (pos, rend); the better (smaller) penalty wins where the mates overlap
+            const int la0 = imax(h1.x + 1, h0.x), lb0 = (has2 ? imax(h1.z + 1, h0.x) : 0);
+            const int ea = h2.z, eb = h2.w;
+            auto link = [&](int a, int b, int e) {
+                if (a >= b) return;
+                put(UVC_FSUM_LCNT + e - 1, a, b, 1); put(UVC_FSUM_LTA, a, b, n_cov); put(UVC_FSUM_LTB, a, b, n_near); put(UVC_FSUM_LMQ, a, b, sq);
+                if (sing) put(UVC_FSUM_LSING, a, b, 1);
+            };
+            const int o0 = imax(la0, lb0), o1 = imin(a1, b1);
+            if (la0 < a1 && lb0 < b1 && o0 < o1) {
+                link(imin(la0, lb0), o0, la0 < lb0 ? ea : eb);
+                link(o0, o1, imin(ea, eb));
+                link(o1, imax(a1, b1), a1 > b1 ? ea : eb);
+            } else { link(la0, a1, ea); link(lb0, b1, eb); }
+        }
+    }
+    __syncthreads();
+    // prefix sums: four consecutive positions per thread, the block's 256 partial sums by wave scan + the waves' totals
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int32_t *out = R.fsum + (size_t)strand * UVC_FSUM_N * R.npos + (size_t)blockIdx.x * FSUM_TILE;
+    const int n_here = t1 - t0;
+    for (int f = 0; f < UVC_FSUM_N; f++) {
+        int v[4], run = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { run += d[f][threadIdx.x * 4 + i]; v[i] = run; }
+        int inc = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();
+        int before = inc - run;
+        for (int i = 0; i < w; i++) before += wtot[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int x = threadIdx.x * 4 + i; if (x < n_here) out[(size_t)f * R.npos + x] = before + v[i]; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1588,14 +1691,21 @@ __global__ void __launch_bounds__(64) k_frag_generic(RegionDev R, UvcParams P, c
 // PLAIN: VCF run, Illumina-like values, no SSCS table cap (fam_flag & 1), padded deletions counted: the common case without those arms
 // H16: no position is covered by 65 536 fragments or more (host bound, RegionDev::max_frag_depth), so two buckets share one LDS word:
 // 16 KiB per block instead of 32, six waves per SIMD instead of five.
+#define RQ_CAP 128   // events per wave between two flushes (one record adds at most 64)
+#ifdef UVC_FRAG_COARSE   // debug build (make XFLAGS=-DUVC_FRAG_COARSE): s_memtime at the three stages of k_frag, printed for a few waves
+#define COARSE_T(v) unsigned long long v; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory");
+#else
+#define COARSE_T(v)
+#endif
 template <bool PLAIN, bool H16>
-DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUCKETS / (H16 ? 2 : 1)][256]) {
+DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUCKETS / (H16 ? 2 : 1)][256], unsigned long long (*rq)[RQ_CAP], int (*lacc)[256]) {
     auto hist_add = [&](int dense, int b) {   // ds_add_u32 without return
         if (H16) atomicAdd(&hist[dense][b >> 1][threadIdx.x], 1u << (16 * (b & 1))); else atomicAdd(&hist[dense][b][threadIdx.x], 1u);
     };
     auto hist_get = [&](int dense, int b) -> int {
         return H16 ? (int)((hist[dense][b >> 1][threadIdx.x] >> (16 * (b & 1))) & 0xFFFFu) : (int)hist[dense][b][threadIdx.x];
     };
+    COARSE_T(ct0)
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform((int)((xcd_block() * blockDim.x + threadIdx.x) >> 6));
     const int64_t x0 = (int64_t)wave * 64;
@@ -1609,6 +1719,7 @@ DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUC
     const bool vcfgen = (PLAIN ? true : (P.inferred_is_vcf_generated != 0));   // P3 belongs to updateByAlns3UsingBQ, skipped on FASTQ-only runs (main.hpp:3691)
     const int my_ref = valid ? R.refsym[x] : 0;
     for (int b = 0; b < NBUCKETS / (H16 ? 2 : 1); b++) { hist[0][b][threadIdx.x] = 0; hist[1][b][threadIdx.x] = 0; }
+    for (int i = 0; i < 5; i++) lacc[i][threadIdx.x] = 0;
     // avgBQ + 8 (get_avgBQ, main_conversion.hpp:791-796) of the five read symbols and of LINK_M; LINK_M value of a simple read here
     auto maxq_at = [&](int sym) {
         const int ad = S32(R, UVC_S_aDPff, sym, x) + S32(R, UVC_S_aDPfr, sym, x) + S32(R, UVC_S_aDPrf, sym, x) + S32(R, UVC_S_aDPrr, sym, x);
@@ -1627,63 +1738,93 @@ DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUC
     }
     auto maxq_base = [&](int cs) { return cs >= UVC_BASE_N ? mqN : (int)((mq_acgt >> (16 * cs)) & 0xFFFFull); };   // cs in A..N
     const int maxq_ref = maxq_base(my_ref);
-    // dense accumulators: [strand][ref, link] x {bDP, bTA, bTB, cDP12 (== cDP21), cDP1}, bMQ x {ref, link}.  Named structs, selected by
+    // dense accumulators of the reference symbol: [strand] x {bDP, bTA, bTB, cDP12 (== cDP21), cDP1}, bMQ.  Named structs, selected by
     // a wave-uniform branch on the strand: runtime-indexed local arrays would live in scratch memory (one VMEM round trip per update).
     struct DAcc { int bDP, bTA, bTB, c12, c1; };
-    DAcc a_fr = {0,0,0,0,0}, a_fl = {0,0,0,0,0}, a_rr = {0,0,0,0,0}, a_rl = {0,0,0,0,0};   // {fwd,rev} x {ref,link}
-    int bMQ_r = 0, bMQ_l = 0;
+    DAcc a_fr = {0,0,0,0,0}, a_rr = {0,0,0,0,0};   // {fwd,rev} of the reference symbol (LINK_M: interval sums + lacc, see the end)
+    int bMQ_r = 0;
     // One (fragment, position, symbol type) consensus (cs = symbol, cc = its value, ct = total) -> P3 outputs and, for singleton units,
     // the P4/P5 identities:
     //   con = 1 vote for the fragment consensus when 2*max - tot passes the threshold (main.hpp:466-495) => cDP12, cDP21 (tot_count == 1)
     //   mmm = 2*max - tot when positive (main.hpp:497-520)                                              => cDP1
-    // The reference symbol and LINK_M accumulate in registers / LDS; every other symbol is rare and goes to the planes with
-    // fire-and-forget atomics (no returned value, so the wave never waits for them; the fence before P3b orders them).
-    auto apply = [&](DAcc &ar, DAcc &al, int st, int cs, int cc, int ct, int cs4, int cc4, int ct4, int max_qual, int strand, int sq, int n_cov, int n_near, bool singleton) {
-        const int dense = (cs == UVC_LINK_M ? 1 : (cs == my_ref ? 0 : -1));
+    // The reference symbol accumulates in registers / LDS.  Every other symbol is rare and becomes an EVENT in the wave's LDS queue:
+    // the loop itself issues no store or atomic to memory, so the s_waitcnt vmcnt(0) in front of the next record's prefetched bytes
+    // waits for those bytes only (with the atomics in the loop it waited for every one of them to reach the L2: two thirds of
+    // the kernel's wave-cycles, SQ_WAIT_ANY).  flush_events turns the queue into fire-and-forget atomics, a lane per event.
+    //   event: bit 63 valid | fragment index k << 24 | p3 << 23 | c12 << 22 | c1 << 21 | strand << 20 | bucket (31 = none) << 14 | cs4 << 10 | cs << 6 | lane
+    unsigned long long *myq = rq[threadIdx.x >> 6];
+    int nq = 0;   // wave-uniform: only updated in uniform control flow
+    auto flush_events = [&]() {
+#ifdef UVC_ABLATE_RARE
+        nq = 0; return;
+#endif
+        for (int i = lane; i < nq; i += 64) {
+            const unsigned long long e = myq[i];
+            const int le = (int)(e & 63), cs = (int)((e >> 6) & 15), cs4 = (int)((e >> 10) & 15), pb = (int)((e >> 14) & 31), st = (int)((e >> 20) & 1);
+            const int64_t xe = x0 + le;
+            const FragFast *ff = R.ffast + (int)((e >> 24) & 0x7FFFFFFFull);
+            if ((e >> 23) & 1) {
+                if (pb < NBUCKETS) atomicAdd(&BKP(R, 0, cs, pb, xe), 1);
+                atomicAdd(&FRP(R, st, UVC_FRAG_bDP, cs, xe), 1); atomicAdd(&FRP(R, st, UVC_FRAG_bTA, cs, xe), ff->n_cov); atomicAdd(&FRP(R, st, UVC_FRAG_bTB, cs, xe), ff->n_near);
+                atomicAdd(&VQP(R, UVC_VQ_bMQ, cs, xe), ff->sq);
+            }
+            if ((e >> 22) & 1) { atomicAdd(&FAP(R, st, UVC_FAM_cDP12, cs4, xe), 1); atomicAdd(&FAP(R, st, UVC_FAM_cDP21, cs4, xe), 1); }
+            if ((e >> 21) & 1) atomicAdd(&FAP(R, st, UVC_FAM_cDP1, cs, xe), 1);
+        }
+        nq = 0;
+    };
+    // FULL: the fragment is not in k_frag_sums' interval sums, its per-fragment constants are added here.  Otherwise the sums hold them for
+    // every position with a base, as if the base were the reference: a rare symbol takes its share back out of the reference's accumulators.
+    // K(i): dword i of the fragment's record.  Returns the event of a rare symbol, or 0.
+    auto apply = [&](bool full, DAcc &ar, int cs, int cc, int ct, int cs4, int cc4, int ct4, int max_qual, int strand, auto K, bool singleton, int k) -> unsigned long long {
+        const bool is_ref = (cs == my_ref);
+        int pb = 31;
         if (vcfgen) {
             const int con_qual = cc * 2 - ct;
             int phredlike = imin(con_qual, max_qual);
             if (!PLAIN && (0x1 & P.fam_flag)) phredlike = imin(phredlike, sscs_phred(P, my_ref, cs));
             const int pbucket = imax(0, max_qual - phredlike);
-            if (dense >= 0) {
-                if (pbucket < NBUCKETS) hist_add(dense, pbucket);
-                if (dense == 0) { ar.bDP += 1; ar.bTA += n_cov; ar.bTB += n_near; bMQ_r += sq; }
-                else { al.bDP += 1; al.bTA += n_cov; al.bTB += n_near; bMQ_l += sq; }
+            if (is_ref) {
+                if (pbucket < NBUCKETS) hist_add(0, pbucket);
+                if (full) { ar.bDP += 1; ar.bTA += K(13); ar.bTB += K(14); bMQ_r += K(12); }
             } else {
-                if (pbucket < NBUCKETS) atomicAdd(&BKP(R, 0, cs, pbucket, x), 1);
-                atomicAdd(&FRP(R, strand, UVC_FRAG_bDP, cs, x), 1); atomicAdd(&FRP(R, strand, UVC_FRAG_bTA, cs, x), n_cov); atomicAdd(&FRP(R, strand, UVC_FRAG_bTB, cs, x), n_near);
-                atomicAdd(&VQP(R, UVC_VQ_bMQ, cs, x), sq);
+                pb = imin(pbucket, 31);
+                if (!full) { ar.bDP -= 1; ar.bTA -= K(13); ar.bTB -= K(14); bMQ_r -= K(12); }
             }
         }
+        bool e12 = false, e1 = false;
         if (singleton) {
             const int adj = imax(cc4 * 2, ct4) - ct4;
-            const int thr = (st == UVC_BASE_SYMBOL ? P.fam_thres_highBQ_snv : 0);
-            if (adj >= thr && adj > 0) {   // cDP12 == cDP21 for a singleton unit
-                if (cs4 == UVC_LINK_M) al.c12 += 1; else if (cs4 == my_ref) ar.c12 += 1;
-                else { atomicAdd(&FAP(R, strand, UVC_FAM_cDP12, cs4, x), 1); atomicAdd(&FAP(R, strand, UVC_FAM_cDP21, cs4, x), 1); }
+            if (adj >= P.fam_thres_highBQ_snv && adj > 0) {   // cDP12 == cDP21 for a singleton unit
+                if (cs4 == my_ref) ar.c12 += 1; else e12 = true;
             }
             const int adj5 = imax(cc * 2, ct) - ct;
-            if (adj5 > 0 && vcfgen) {
-                if (dense == 0) ar.c1 += 1; else if (dense == 1) al.c1 += 1; else atomicAdd(&FAP(R, strand, UVC_FAM_cDP1, cs, x), 1);
-            }
+            if (adj5 > 0 && vcfgen) { if (is_ref) ar.c1 += 1; else e1 = true; }
         }
+        const bool e3 = (vcfgen && !is_ref);
+        if (!(e3 || e12 || e1)) return 0ull;
+        return (1ull << 63) | ((unsigned long long)(unsigned)k << 24) | ((unsigned long long)e3 << 23) | ((unsigned long long)e12 << 22) | ((unsigned long long)e1 << 21)
+             | ((unsigned long long)strand << 20) | ((unsigned long long)pb << 14) | ((unsigned long long)(cs4 & 15) << 10) | ((unsigned long long)(cs & 15) << 6) | (unsigned long long)lane;
+    };
+    // LINK_M of a fragment outside the interval sums (few): value lv > 0 at this position, its consensus is a vote (threshold 0) and an mmm > 0.
+    // Bucket and sums in LDS (lacc: bDP, bTA, bTB, bMQ, singleton votes of the strand being walked; moved to the planes after each list).
+    auto link_full = [&](int lv, int strand, auto K, bool singleton) {
+        if (vcfgen) {
+            int phredlike = imin(lv, maxq_link);
+            if (!PLAIN && (0x1 & P.fam_flag)) phredlike = imin(phredlike, sscs_phred(P, my_ref, UVC_LINK_M));
+            const int pbucket = imax(0, maxq_link - phredlike);
+            if (pbucket < NBUCKETS) hist_add(1, pbucket);
+            atomicAdd(&lacc[0][threadIdx.x], 1); atomicAdd(&lacc[1][threadIdx.x], K(13)); atomicAdd(&lacc[2][threadIdx.x], K(14)); atomicAdd(&lacc[3][threadIdx.x], K(12));
+        }
+        if (singleton) atomicAdd(&lacc[4][threadIdx.x], 1);
     };
     auto maxq_generic = [&](int cs) { return cs == UVC_LINK_M ? maxq_link : (cs <= UVC_BASE_N ? maxq_base(cs) : maxq_at(cs)); };
     const __amdgpu_buffer_rsrc_t rs = bq_rsrc(R);
-    auto run_list = [&](auto ST, DAcc &ar, DAcc &al, int seg_beg, int seg_end) {
+    auto run_list = [&](auto ST, DAcc &ar) {
     constexpr int strand = decltype(ST)::value ? 1 : 0;
-    int lo, hi;
-    {
-        int l = seg_beg, h = seg_end;
-        const int key = w0 - R.max_frag_span + 1;
-        while (l < h) { int m = (l + h) >> 1; if (R.ffast[m].beg < key) l = m + 1; else h = m; }
-        lo = wave_uniform(l);
-        l = lo; h = seg_end;
-        while (l < h) { int m = (l + h) >> 1; if (R.ffast[m].beg < w0 + 64) l = m + 1; else h = m; }
-        hi = wave_uniform(l);
-    }
+    const int lo = wave_uniform(win_lo(R, 5 + strand, (int)(x0 >> 6))), hi = wave_uniform(win_hi(R, 5 + strand, (int)(x0 >> 6)));
     for (int k0 = lo; k0 < hi; k0 += 64) {
-        // one FragFast (24 dwords) per lane, fields of record j broadcast with v_readlane; base/qual bytes of record j+1 are
+            // one FragFast (24 dwords) per lane, fields of record j broadcast with v_readlane; base/qual bytes of record j+1 are
         // requested before record j is processed
         int c[24];
         if (k0 + lane < hi) {
@@ -1714,14 +1855,17 @@ DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUC
             const int fbeg = bcast(c[0], j), fend = bcast(c[1], j), flags = bcast(c[3], j);
             if (fend <= w0) continue;
             if (flags & 1) continue;   // done by k_frag_generic
-            if (!(valid && p >= fbeg && p < fend)) continue;
+            // from here on the control flow stays wave-uniform down to the queue bookkeeping (nq is a scalar): per-lane conditions are predicates
+            bool cover = (valid && p >= fbeg && p < fend);
             const bool singleton = (flags >> 2) & 1;
-            {
-                // consensus of <= 2 alignments in registers, written with selects (BASE_QUALITY_MAX merge, main.hpp:339-349)
-                const int pos0 = bcast(c[4], j), rend0 = bcast(c[5], j), pos1 = bcast(c[6], j), rend1 = bcast(c[7], j);
-                const int nogap0 = bcast(c[10], j), nogap1 = bcast(c[11], j), sq = bcast(c[12], j), n_cov = bcast(c[13], j), n_near = bcast(c[14], j);
-                const bool has2 = (((flags >> 3) & 0xF) == 2);
-                bool in0 = (p >= pos0 && p < rend0), in1 = (has2 && p >= pos1 && p < rend1);
+            auto K = [&](int i) { return bcast(c[i], j); };
+            // consensus of <= 2 alignments in registers, written with selects (BASE_QUALITY_MAX merge, main.hpp:339-349)
+            const int pos0 = bcast(c[4], j), rend0 = bcast(c[5], j), pos1 = bcast(c[6], j), rend1 = bcast(c[7], j);
+            const bool has2 = (((flags >> 3) & 0xF) == 2);
+            bool in0 = (p >= pos0 && p < rend0), in1 = (has2 && p >= pos1 && p < rend1);
+            const bool full = (flags & 0x300) != 0;   // wave-uniform: not in k_frag_sums
+            if (full) {
+                const int nogap0 = bcast(c[10], j), nogap1 = bcast(c[11], j);
                 bool lk0 = (in0 && p > pos0), lk1 = (in1 && p > pos1);   // LINK_M exists from the second base of a run on
                 if (flags & 0x100) {
                     const int bpos0 = bcast(c[16], j), brend0 = bcast(c[17], j), bpos1 = bcast(c[20], j), brend1 = bcast(c[21], j);
@@ -1731,78 +1875,190 @@ DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUC
                     lk0 = lk0 || (inb0 && p > bpos0); lk1 = lk1 || (inb1 && p > bpos1);
                     // positions next to an InDel carry InDel symbols / padded-deletion symbols: k_frag_generic does them for this fragment
                     const unsigned off = (unsigned)(p - fbeg);
-                    if (off - (unsigned)(sp0 & 0xFFFF) < (unsigned)(sp0 >> 16) || off - (unsigned)(sp1 & 0xFFFF) < (unsigned)(sp1 >> 16)) continue;
+                    if (off - (unsigned)(sp0 & 0xFFFF) < (unsigned)(sp0 >> 16) || off - (unsigned)(sp1 & 0xFFFF) < (unsigned)(sp1 >> 16)) cover = false;
                 }
                 // LINK_M: value of the better mate
                 const int lv0 = (lk0 ? imax(noindel80 - nogap0, 0) + 1 : 0), lv1 = (lk1 ? imax(noindel80 - nogap1, 0) + 1 : 0);
                 const int lv = imax(lv0, lv1);
-                if (lv > 0) apply(ar, al, UVC_LINK_SYMBOL, UVC_LINK_M, lv, lv, UVC_LINK_M, lv, lv, maxq_link, strand, sq, n_cov, n_near, singleton);
-                if (in0 || in1) {
-                    const int v0 = q0 + P.bq_phred_added_misma, v1 = q1 + P.bq_phred_added_misma;
-                    const int A = (in0 ? v0 : 0), B = (in1 ? v1 : 0);
-                    const bool diff = (in0 && in1 && b0 != b1);
-                    const bool first = (v0 > v1) || (v0 == v1 && b0 < b1);
-                    const int cc = imax(A, B), ct = (diff ? A + B : cc);
-                    const int cs = ((in0 && (!diff || first)) ? b0 : b1);
-                    int cs4 = cs, cc4 = cc, ct4 = ct;
-                    if (padded_ignored) {   // fillConsensusCounts<false, true>: only A..T take part (main.hpp:410)
-                        const int A4 = ((in0 && b0 <= UVC_BASE_T) ? v0 : 0), B4 = ((in1 && b1 <= UVC_BASE_T) ? v1 : 0);
-                        const bool first4 = (A4 > B4) || (A4 == B4 && b0 < b1);
-                        cc4 = imax(A4, B4); ct4 = (diff ? A4 + B4 : cc4);
-                        cs4 = ((A4 == 0 && B4 == 0) ? UVC_BASE_T : (diff ? (first4 ? b0 : b1) : cs));
-                    }
-                    const int mq = maxq_base(cs);
-                    apply(ar, al, UVC_BASE_SYMBOL, cs, cc, ct, cs4, cc4, ct4, mq, strand, sq, n_cov, n_near, singleton);
+                if (cover && lv > 0) link_full(lv, strand, K, singleton);
+            }
+            unsigned long long ev = 0ull;
+            if (cover && (in0 || in1)) {
+                const int v0 = q0 + P.bq_phred_added_misma, v1 = q1 + P.bq_phred_added_misma;
+                const int A = (in0 ? v0 : 0), B = (in1 ? v1 : 0);
+                const bool diff = (in0 && in1 && b0 != b1);
+                const bool first = (v0 > v1) || (v0 == v1 && b0 < b1);
+                const int cc = imax(A, B), ct = (diff ? A + B : cc);
+                const int cs = ((in0 && (!diff || first)) ? b0 : b1);
+                int cs4 = cs, cc4 = cc, ct4 = ct;
+                if (padded_ignored) {   // fillConsensusCounts<false, true>: only A..T take part (main.hpp:410)
+                    const int A4 = ((in0 && b0 <= UVC_BASE_T) ? v0 : 0), B4 = ((in1 && b1 <= UVC_BASE_T) ? v1 : 0);
+                    const bool first4 = (A4 > B4) || (A4 == B4 && b0 < b1);
+                    cc4 = imax(A4, B4); ct4 = (diff ? A4 + B4 : cc4);
+                    cs4 = ((A4 == 0 && B4 == 0) ? UVC_BASE_T : (diff ? (first4 ? b0 : b1) : cs));
                 }
+                const int mq = maxq_base(cs);
+                ev = apply(full, ar, cs, cc, ct, cs4, cc4, ct4, mq, strand, K, singleton, k0 + j);
+            }
+            const wmask mm = BAL(ev != 0ull);
+            if (mm) {
+                if (nq > RQ_CAP - 64) flush_events();
+                if (ev != 0ull) myq[nq + (int)__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = ev;
+                nq += (int)__builtin_popcountll(mm);
             }
         }
     }
     };
-    run_list(std::false_type{}, a_fr, a_fl, R.frag_off[0], R.frag_off[1]);
-    run_list(std::true_type{}, a_rr, a_rl, R.frag_off[1], R.frag_off[2]);
+    COARSE_T(ct1)
+    // LINK_M sums of the fragments outside the interval sums, strand by strand: plain read-modify-write (these cells are this lane's)
+    auto lacc_out = [&](int strand) {
+        const int n = lacc[0][threadIdx.x], ta = lacc[1][threadIdx.x], tb = lacc[2][threadIdx.x], mq = lacc[3][threadIdx.x], sg = lacc[4][threadIdx.x];
+        if (valid && (n | sg)) {
+            const int v0 = FRP(R, strand, UVC_FRAG_bDP, UVC_LINK_M, x), v1 = FRP(R, strand, UVC_FRAG_bTA, UVC_LINK_M, x), v2 = FRP(R, strand, UVC_FRAG_bTB, UVC_LINK_M, x);
+            const int v3 = VQP(R, UVC_VQ_bMQ, UVC_LINK_M, x), v4 = FAP(R, strand, UVC_FAM_cDP12, UVC_LINK_M, x), v5 = FAP(R, strand, UVC_FAM_cDP21, UVC_LINK_M, x), v6 = FAP(R, strand, UVC_FAM_cDP1, UVC_LINK_M, x);
+            if (n) { FRP(R, strand, UVC_FRAG_bDP, UVC_LINK_M, x) = v0 + n; FRP(R, strand, UVC_FRAG_bTA, UVC_LINK_M, x) = v1 + ta; FRP(R, strand, UVC_FRAG_bTB, UVC_LINK_M, x) = v2 + tb; VQP(R, UVC_VQ_bMQ, UVC_LINK_M, x) = v3 + mq; }
+            if (sg) { FAP(R, strand, UVC_FAM_cDP12, UVC_LINK_M, x) = v4 + sg; FAP(R, strand, UVC_FAM_cDP21, UVC_LINK_M, x) = v5 + sg; if (vcfgen) FAP(R, strand, UVC_FAM_cDP1, UVC_LINK_M, x) = v6 + sg; }
+        }
+#pragma unroll
+        for (int i = 0; i < 5; i++) lacc[i][threadIdx.x] = 0;
+    };
+    run_list(std::false_type{}, a_fr);
+    lacc_out(0);
+    run_list(std::true_type{}, a_rr);
+    lacc_out(1);
+    if (nq > 0) flush_events();
+    COARSE_T(ct2)
     if (!valid) return;
     // the atomics above must have landed (and this CU's L1 must not hold older copies) before the planes are read back
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-    // flush the dense accumulators (plain read-modify-write: nobody else touches these symbols at this position in this kernel)
-    auto flush = [&](const DAcc &a, int s, int sym) {
-        if (a.bDP) { FRP(R, s, UVC_FRAG_bDP, sym, x) += a.bDP; FRP(R, s, UVC_FRAG_bTA, sym, x) += a.bTA; FRP(R, s, UVC_FRAG_bTB, sym, x) += a.bTB; }
-        if (a.c12) { FAP(R, s, UVC_FAM_cDP12, sym, x) += a.c12; FAP(R, s, UVC_FAM_cDP21, sym, x) += a.c12; }
-        if (a.c1) FAP(R, s, UVC_FAM_cDP1, sym, x) += a.c1;
-    };
-    flush(a_fr, 0, my_ref); flush(a_rr, 1, my_ref); flush(a_fl, 0, UVC_LINK_M); flush(a_rl, 1, UVC_LINK_M);
-    if (bMQ_r) VQP(R, UVC_VQ_bMQ, my_ref, x) += bMQ_r;
-    if (bMQ_l) VQP(R, UVC_VQ_bMQ, UVC_LINK_M, x) += bMQ_l;
-    // P3b (main.hpp:2801-2828)
-    const bool has_generic = (R.n_sweep > 0 || proton);
-    for (int st = 0; st < 2 && vcfgen; st++) {
-        const int sb = (st == 0 ? UVC_BASE_A : UVC_LINK_M), se = (st == 0 ? UVC_BASE_NN : UVC_LINK_NN);
-        int totDP = 0;
-        for (int s = sb; s <= se; s++) totDP += FRP(R, 0, UVC_FRAG_bDP, s, x) + FRP(R, 1, UVC_FRAG_bDP, s, x);
-        for (int s = sb; s <= se; s++) {
-            const int nfr = FRP(R, 0, UVC_FRAG_bDP, s, x) + FRP(R, 1, UVC_FRAG_bDP, s, x);
-            if (nfr == 0) continue;   // empty histogram -> all three outputs are 0
-            const int dense = (s == my_ref ? 0 : (s == UVC_LINK_M ? 1 : -1));
-            const int max_qual = maxq_generic(s);
-            int mv, ad2, bq2;
-            if (dense >= 0 && !has_generic) infer_max_qual(mv, ad2, bq2, max_qual, 1, totDP, [&](int b) { return hist_get(dense, b); });
-            else {   // the global buckets hold the rare symbols and everything k_frag_generic added
-                infer_max_qual(mv, ad2, bq2, max_qual, 1, totDP, [&](int b) { return BKP(R, 0, s, b, x) + (dense >= 0 ? hist_get(dense, b) : 0); });
-                for (int b = 0; b < NBUCKETS; b++) BKP(R, 0, s, b, x) = 0;   // clearSymbolBucketCount, main.hpp:2827
+    // the interval sums of the plain fragments (k_frag_sums): LINK_M by penalty class into the bucket histogram, the rest into the accumulators
+    DAcc a_fl = {0,0,0,0,0}, a_rl = {0,0,0,0,0};
+    int bMQ_l = 0;
+    if (!proton) {
+        int lcnt[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int32_t *S = R.fsum + (size_t)s * UVC_FSUM_N * R.npos + x;
+            DAcc &ar = (s ? a_rr : a_fr), &al = (s ? a_rl : a_fl);
+            const int sing = S[(size_t)UVC_FSUM_LSING * R.npos];
+            al.c12 += sing;   // a LINK_M consensus is a vote of its own value > 0: cDP12 / cDP21, and cDP1 with P3
+            if (vcfgen) {
+                int n = 0;
+#pragma unroll
+                for (int e = 0; e < 5; e++) { const int c = S[(size_t)(UVC_FSUM_LCNT + e) * R.npos]; lcnt[e] += c; n += c; }
+                al.bDP += n; al.bTA += S[(size_t)UVC_FSUM_LTA * R.npos]; al.bTB += S[(size_t)UVC_FSUM_LTB * R.npos]; bMQ_l += S[(size_t)UVC_FSUM_LMQ * R.npos];
+                al.c1 += sing;
+                ar.bDP += S[(size_t)UVC_FSUM_BDP * R.npos]; ar.bTA += S[(size_t)UVC_FSUM_BTA * R.npos]; ar.bTB += S[(size_t)UVC_FSUM_BTB * R.npos]; bMQ_r += S[(size_t)UVC_FSUM_BMQ * R.npos];
             }
-            VQP(R, UVC_VQ_bIAQb, s, x) += mv; VQP(R, UVC_VQ_bIADb, s, x) += ad2; VQP(R, UVC_VQ_bIDQb, s, x) += bq2;
+        }
+#pragma unroll
+        for (int e = 0; e < 5; e++) {
+            if (lcnt[e] == 0) continue;
+            const int lv = imax(noindel80 - (e + 1), 0) + 1;
+            int phredlike = imin(lv, maxq_link);
+            if (!PLAIN && (0x1 & P.fam_flag)) phredlike = imin(phredlike, sscs_phred(P, my_ref, UVC_LINK_M));
+            const int b = imax(0, maxq_link - phredlike);
+            if (b < NBUCKETS) { if (H16) hist[1][b >> 1][threadIdx.x] += (unsigned)lcnt[e] << (16 * (b & 1)); else hist[1][b][threadIdx.x] += (unsigned)lcnt[e]; }
         }
     }
+    // ---- the rest reads and writes this position's planes.  A read-modify-write per counter, one after the other, costs a memory round
+    // trip each (measured with s_memtime: a quarter of a wave's life went here): every stage below issues all of its loads, then computes,
+    // then stores.  Nobody else touches these cells in this kernel and the atomics above have landed.
+    const bool has_generic = (R.n_sweep > 0 || proton);
+    // (1) fragment depth of every symbol with the dense accumulators folded in; which symbols are present
+    int totDP_b = 0, totDP_l = 0; unsigned present = 0;
+    {
+        int f0[NSYM], f1[NSYM];
+#pragma unroll
+        for (int s = 0; s < NSYM; s++) { f0[s] = FRP(R, 0, UVC_FRAG_bDP, s, x); f1[s] = FRP(R, 1, UVC_FRAG_bDP, s, x); }
+#pragma unroll
+        for (int s = 0; s < NSYM; s++) {
+            int d0 = 0, d1 = 0;
+            if (s <= UVC_BASE_NN && s == my_ref) { d0 = a_fr.bDP; d1 = a_rr.bDP; }
+            if (s == UVC_LINK_M) { d0 = a_fl.bDP; d1 = a_rl.bDP; }
+            if (d0) FRP(R, 0, UVC_FRAG_bDP, s, x) = f0[s] + d0;
+            if (d1) FRP(R, 1, UVC_FRAG_bDP, s, x) = f1[s] + d1;
+            const int nfr = f0[s] + f1[s] + d0 + d1;
+            if (s <= UVC_BASE_NN) totDP_b += nfr; else totDP_l += nfr;
+            if (nfr) present |= 1u << s;
+        }
+    }
+    // (2) the other dense accumulators
+    {
+        const int sy[2] = { my_ref, UVC_LINK_M };
+        int v[2][2][5], q[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                v[k][t][0] = FRP(R, t, UVC_FRAG_bTA, sy[k], x); v[k][t][1] = FRP(R, t, UVC_FRAG_bTB, sy[k], x);
+                v[k][t][2] = FAP(R, t, UVC_FAM_cDP12, sy[k], x); v[k][t][3] = FAP(R, t, UVC_FAM_cDP21, sy[k], x); v[k][t][4] = FAP(R, t, UVC_FAM_cDP1, sy[k], x);
+            }
+            q[k] = VQP(R, UVC_VQ_bMQ, sy[k], x);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const DAcc &a = (k == 0 ? (t ? a_rr : a_fr) : (t ? a_rl : a_fl));
+                if (a.bTA) FRP(R, t, UVC_FRAG_bTA, sy[k], x) = v[k][t][0] + a.bTA;
+                if (a.bTB) FRP(R, t, UVC_FRAG_bTB, sy[k], x) = v[k][t][1] + a.bTB;
+                if (a.c12) { FAP(R, t, UVC_FAM_cDP12, sy[k], x) = v[k][t][2] + a.c12; FAP(R, t, UVC_FAM_cDP21, sy[k], x) = v[k][t][3] + a.c12; }
+                if (a.c1) FAP(R, t, UVC_FAM_cDP1, sy[k], x) = v[k][t][4] + a.c1;
+            }
+            const int mq = (k == 0 ? bMQ_r : bMQ_l);
+            if (mq) VQP(R, UVC_VQ_bMQ, sy[k], x) = q[k] + mq;
+        }
+    }
+    // (3) P3b (main.hpp:2801-2828): one pass per symbol that some lane of the wave has; its 16 buckets and three outputs in one batch of loads
+    if (vcfgen) {
+        unsigned long long todo = 0;   // wave-uniform set of symbols
+#pragma unroll
+        for (int s = 0; s < NSYM; s++) if (BAL((present >> s) & 1u)) todo |= 1ull << s;
+        while (todo) {
+            const int s = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            if (!((present >> s) & 1u)) continue;   // empty histogram -> all three outputs are 0
+            const int dense = (s == my_ref ? 0 : (s == UVC_LINK_M ? 1 : -1));
+            const bool global_b = (dense < 0 || has_generic);   // the global buckets hold the rare symbols and everything k_frag_generic added
+            int h[NBUCKETS];
+#pragma unroll
+            for (int b = 0; b < NBUCKETS; b++) h[b] = (global_b ? BKP(R, 0, s, b, x) : 0);
+            const int o0 = VQP(R, UVC_VQ_bIAQb, s, x), o1 = VQP(R, UVC_VQ_bIADb, s, x), o2 = VQP(R, UVC_VQ_bIDQb, s, x);
+            const int max_qual = maxq_generic(s);
+            if (global_b) {
+#pragma unroll
+                for (int b = 0; b < NBUCKETS; b++) if (h[b]) BKP(R, 0, s, b, x) = 0;   // clearSymbolBucketCount, main.hpp:2827
+            }
+            if (dense >= 0) {
+#pragma unroll
+                for (int b = 0; b < NBUCKETS; b++) h[b] += hist_get(dense, b);
+            }
+            int mv, ad2, bq2;
+            infer_max_qual_regs(mv, ad2, bq2, max_qual, (s <= UVC_BASE_NN ? totDP_b : totDP_l), h);
+            if (mv | ad2 | bq2) { VQP(R, UVC_VQ_bIAQb, s, x) = o0 + mv; VQP(R, UVC_VQ_bIADb, s, x) = o1 + ad2; VQP(R, UVC_VQ_bIDQb, s, x) = o2 + bq2; }
+        }
+    }
+#ifdef UVC_FRAG_COARSE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    COARSE_T(ct3)
+    if (lane == 0 && (wave % 1499) == 7) printf("coarse wave %d prologue %llu lists %llu epilogue %llu\n", wave, ct1 - ct0, ct2 - ct1, ct3 - ct2);
+#endif
 }
 
 template <bool PLAIN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,5))) k_frag(RegionDev R, UvcParams P) {
-    __shared__ unsigned hist[2][NBUCKETS][256];   // [dense symbol][bucket][thread]: conflict-free, 32 KiB so that five blocks share a CU
-    frag_body<PLAIN, false>(R, P, hist);
+    __shared__ unsigned hist[2][NBUCKETS][256];   // [dense symbol][bucket][thread]: conflict-free
+    __shared__ unsigned long long rq[4][RQ_CAP];
+    __shared__ int lacc[5][256];
+    frag_body<PLAIN, false>(R, P, hist, rq, lacc);
 }
 template <bool PLAIN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6,6))) k_frag16(RegionDev R, UvcParams P) {
-    __shared__ unsigned hist[2][NBUCKETS / 2][256];
-    frag_body<PLAIN, true>(R, P, hist);
+    __shared__ unsigned hist[2][NBUCKETS / 2][256];   // 16 + 4 + 5 KiB: six blocks share a CU
+    __shared__ unsigned long long rq[4][RQ_CAP];
+    __shared__ int lacc[5][256];
+    frag_body<PLAIN, true>(R, P, hist, rq, lacc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3145,6 +3401,10 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
     const unsigned nwin = nblk(R->npos, 256);   // 4 waves x 64 positions per block
     if (prof) prof->n = 0;
     hipStream_t s2 = (side ? side : s);
+    {   // the window index of the alignment lists (the fragment list's follows k_fragstat_fast, which writes it)
+        const int64_t n = 2 * (int64_t)R->nwin * 5;
+        TIMED(prof, "k_win_index", hipLaunchKernelGGL(k_win_index, dim3(nblk(n, 256)), dim3(256), 0, s, *R, 0, 5));
+    }
     if (P->inferred_is_vcf_generated) {
         // P1: the InDel reads (one wave per read) underneath the position-centric pass
         if (side && R->n_complex) { hipEventRecord(e_fork, s); hipStreamWaitEvent(s2, e_fork, 0); }
@@ -3160,9 +3420,12 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
     if (P->inferred_is_vcf_generated && R->n_complex) TIMED2(prof, "k_p2_slow_walk", hipLaunchKernelGGL(k_p2_slow<true>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
     if (R->n_complex) TIMED2(prof, "k_p2_slow_table", hipLaunchKernelGGL(k_p2_slow<false>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
     TIMED2(prof, "k_fragstat_fast", hipLaunchKernelGGL(k_fragstat_fast, dim3(nblk(R->n_frags, 256)), dim3(256), 0, s, *R, *P));
+    TIMED2(prof, "k_win_index_frag", hipLaunchKernelGGL(k_win_index, dim3(nblk(2 * (int64_t)R->nwin * 2, 256)), dim3(256), 0, s, *R, 5, 7));
     if (R->n_sweep) TIMED2(prof, "k_fragstat_sweep", hipLaunchKernelGGL(k_fragstat_sweep, dim3(R->n_sweep), dim3(64), 0, s, *R, *P, R->sweep_frags, (const int32_t *)nullptr, R->n_sweep));
     // fragments whose event list overflowed (device-side list; the grid covers the worst case, surplus threads exit)
     TIMED2(prof, "k_fragstat_overflow", hipLaunchKernelGGL(k_fragstat_sweep, dim3(imin_h(R->n_frags, 65535)), dim3(64), 0, s, *R, *P, (const int32_t *)R->overflow_frags, (const int32_t *)R->n_overflow, 0));
+    if (UVC_PLATFORM_IONTORRENT != P->inferred_sequencing_platform)   // (there every fragment takes k_frag_generic)
+        TIMED2(prof, "k_frag_sums", hipLaunchKernelGGL(k_frag_sums, dim3(nblk(R->npos, FSUM_TILE), 2), dim3(256), 0, s, *R, *P));
     // ---- main stream: the base symbols first, so that the queued mismatches (rare symbols, atomics: disjoint from the planes the
     // LINK_M pass stores to) are applied on the side stream while the LINK_M pass runs
     if (P->inferred_is_vcf_generated) {
