@@ -278,14 +278,38 @@ DEV void infer_max_qual(int &maxvqual, int &argmaxAD, int &argmaxBQ, int max_qua
     }
 }
 
-// the same with the bucket counts in registers (fully unrolled: static indices), dec_qual == 1
+// The same with the bucket counts in registers (fully unrolled: static indices), dec_qual == 1, and the fp64 logarithm only where it can
+// matter.  The scan keeps the first bucket that attains the largest (int)(currAD * (currBQ - expBQ)) > 0.  A single-precision pass (v_rcp,
+// v_log: |error of the product| < 3 while currAD < 65 536) finds the largest approximate value; a bucket more than 2 * 8 + 1 below it is
+// more than 1 below the true maximum and can neither win nor tie after truncation, so only the others are evaluated exactly, in order.
+// (A wave evaluates a bucket index if any of its lanes needs it: 3-4 of 16 instead of all -- the logarithms were 12 % of k_frag's instructions.)
 DEV void infer_max_qual_regs(int &maxvqual, int &argmaxAD, int &argmaxBQ, int max_qual, int totDP, const int (&h)[NBUCKETS]) {
+    unsigned cand = 0;
+    {
+        const bool small = (totDP < 65536);
+        const float ft = (float)totDP;
+        auto approx = [&](int idx, int ad) {   // (two passes instead of sixteen live values)
+            const float e = 3.0102999566f * __builtin_amdgcn_logf(ft * __builtin_amdgcn_rcpf((float)ad));   // 10 log10(totDP / currAD)
+            return (float)ad * ((float)(max_qual - idx) - e);
+        };
+        float amax = -3.0e38f;
+        int ad = 0;
+#pragma unroll
+        for (int idx = 0; idx < NBUCKETS; idx++) if (idx < max_qual && h[idx] != 0) { ad += h[idx]; amax = fmaxf(amax, approx(idx, ad)); }
+        ad = 0;
+#pragma unroll
+        for (int idx = 0; idx < NBUCKETS; idx++) if (idx < max_qual && h[idx] != 0) {
+            ad += h[idx];
+            const float a = approx(idx, ad);
+            if (!small || (a >= amax - 17.0f && a > -16.0f)) cand |= 1u << idx;   // (values <= 0 never win: maxvqual starts at 0)
+        }
+    }
     int currAD = 0;
     maxvqual = 0; argmaxAD = 0; argmaxBQ = 0;
 #pragma unroll
     for (int idx = 0; idx < NBUCKETS; idx++) {
-        if (idx < max_qual && h[idx] != 0) {
-            currAD += h[idx];
+        if (idx < max_qual) currAD += h[idx];
+        if ((cand >> idx) & 1u) {
             const int currBQ = max_qual - idx;
             const double expBQ = 10.0 / log(10.0) * log(((double)totDP / (double)currAD) + 2.220446049250313e-16);
             const int currvqual = (int)(currAD * (currBQ - expBQ));

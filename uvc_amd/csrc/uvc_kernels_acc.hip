@@ -48,6 +48,11 @@ DEV int xcd_block() {
 }
 
 DEV int bcast(int v, int j) { return __builtin_amdgcn_readlane(v, j); }   // j must be wave-uniform
+#ifdef UVC_FRAG_COARSE   // debug build (make XFLAGS=-DUVC_FRAG_COARSE): s_memtime at the three stages of k_frag, printed for a few waves
+#define COARSE_T(v) unsigned long long v; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory");
+#else
+#define COARSE_T(v)
+#endif
 // base | qual << 8 of read byte `idx` through a raw buffer descriptor: out-of-range indices (lanes outside the read) return 0
 DEV __amdgpu_buffer_rsrc_t bq_rsrc(const RegionDev &R) { return __builtin_amdgcn_make_buffer_rsrc((void *)R.bq, 0, (int)R.bq_bytes, 0x00020000); }
 DEV int bq_load(__amdgpu_buffer_rsrc_t rs, int idx) { return (int)__builtin_amdgcn_raw_buffer_load_b16(rs, idx << 1, 0, 0); }
@@ -906,6 +911,7 @@ template <bool DO_L, bool DO_B, bool PLAIN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k_p2_fast(RegionDev R, UvcParams P) {
     __shared__ int amp1[256], amp2[256];
     __shared__ MisItem misq[DO_B ? 4 : 1][DO_B ? MISQ_CAP : 1];
+    COARSE_T(ct0)
     {
         const int v = threadIdx.x;
         amp1[v] = (v < P.bias_thres_PFBQ1 ? 100 * (v * v) / (P.bias_thres_PFBQ1 * P.bias_thres_PFBQ1) : 100);
@@ -1008,16 +1014,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k
         }
     }
     };
+    COARSE_T(ct1)
     run_list(std::false_type{}, std::false_type{}, 0);
     run_list(std::true_type{}, std::false_type{}, 1);
     run_list(std::false_type{}, std::true_type{}, 2);
     run_list(std::true_type{}, std::true_type{}, 3);
     if (DO_B && nq > 0) flush_queue();
+    COARSE_T(ct2)
     if (!valid) return;
     // k_p2_fast runs before every other writer of these planes (k_p2_mism, k_p2_items), and the two instantiations own
     // different symbols: plain stores
     if (DO_B) seg_store(R, Aref, my_ref, x);
     if (DO_L) seg_store(R, Alink, UVC_LINK_M, x);
+#ifdef UVC_FRAG_COARSE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    COARSE_T(ct3)
+    if (lane == 0 && (wave % 2999) == 7) printf("coarse p2<%d,%d> wave %d prologue %llu lists %llu epilogue %llu\n", (int)DO_L, (int)DO_B, wave, ct1 - ct0, ct2 - ct1, ct3 - ct2);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1692,11 +1705,6 @@ __global__ void __launch_bounds__(64) k_frag_generic(RegionDev R, UvcParams P, c
 // H16: no position is covered by 65 536 fragments or more (host bound, RegionDev::max_frag_depth), so two buckets share one LDS word:
 // 16 KiB per block instead of 32, six waves per SIMD instead of five.
 #define RQ_CAP 128   // events per wave between two flushes (one record adds at most 64)
-#ifdef UVC_FRAG_COARSE   // debug build (make XFLAGS=-DUVC_FRAG_COARSE): s_memtime at the three stages of k_frag, printed for a few waves
-#define COARSE_T(v) unsigned long long v; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory");
-#else
-#define COARSE_T(v)
-#endif
 template <bool PLAIN, bool H16>
 DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUCKETS / (H16 ? 2 : 1)][256], unsigned long long (*rq)[RQ_CAP], int (*lacc)[256]) {
     auto hist_add = [&](int dense, int b) {   // ds_add_u32 without return
@@ -1763,13 +1771,18 @@ DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUC
             const int le = (int)(e & 63), cs = (int)((e >> 6) & 15), cs4 = (int)((e >> 10) & 15), pb = (int)((e >> 14) & 31), st = (int)((e >> 20) & 1);
             const int64_t xe = x0 + le;
             const FragFast *ff = R.ffast + (int)((e >> 24) & 0x7FFFFFFFull);
+            // The cells of a position belong to its wave in this kernel: the adds need to be atomic among the lanes of this flush only, so
+            // they are L2 atomics of workgroup scope.  (Agent scope sends each one to the memory side and makes the fence below a write-back +
+            // invalidate of the XCD's whole L2 -- per wave, 15 000 times per launch: it was what kept every load of the kernel slow.)
+            auto add_own = [](int32_t *cell, int v) { __hip_atomic_fetch_add(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+            const int sq = ff->sq, n_cov = ff->n_cov, n_near = ff->n_near;
             if ((e >> 23) & 1) {
-                if (pb < NBUCKETS) atomicAdd(&BKP(R, 0, cs, pb, xe), 1);
-                atomicAdd(&FRP(R, st, UVC_FRAG_bDP, cs, xe), 1); atomicAdd(&FRP(R, st, UVC_FRAG_bTA, cs, xe), ff->n_cov); atomicAdd(&FRP(R, st, UVC_FRAG_bTB, cs, xe), ff->n_near);
-                atomicAdd(&VQP(R, UVC_VQ_bMQ, cs, xe), ff->sq);
+                if (pb < NBUCKETS) add_own(&BKP(R, 0, cs, pb, xe), 1);
+                add_own(&FRP(R, st, UVC_FRAG_bDP, cs, xe), 1); add_own(&FRP(R, st, UVC_FRAG_bTA, cs, xe), n_cov); add_own(&FRP(R, st, UVC_FRAG_bTB, cs, xe), n_near);
+                add_own(&VQP(R, UVC_VQ_bMQ, cs, xe), sq);
             }
-            if ((e >> 22) & 1) { atomicAdd(&FAP(R, st, UVC_FAM_cDP12, cs4, xe), 1); atomicAdd(&FAP(R, st, UVC_FAM_cDP21, cs4, xe), 1); }
-            if ((e >> 21) & 1) atomicAdd(&FAP(R, st, UVC_FAM_cDP1, cs, xe), 1);
+            if ((e >> 22) & 1) { add_own(&FAP(R, st, UVC_FAM_cDP12, cs4, xe), 1); add_own(&FAP(R, st, UVC_FAM_cDP21, cs4, xe), 1); }
+            if ((e >> 21) & 1) add_own(&FAP(R, st, UVC_FAM_cDP1, cs, xe), 1);
         }
         nq = 0;
     };
@@ -1929,11 +1942,13 @@ DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUC
     if (nq > 0) flush_events();
     COARSE_T(ct2)
     if (!valid) return;
-    // the atomics above must have landed (and this CU's L1 must not hold older copies) before the planes are read back
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    // the adds above must have reached the L2 before the planes are read back (they pass through this CU's L1, which drops its copy of the line)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    COARSE_T(ce0)
     // the interval sums of the plain fragments (k_frag_sums): LINK_M by penalty class into the bucket histogram, the rest into the accumulators
     DAcc a_fl = {0,0,0,0,0}, a_rl = {0,0,0,0,0};
     int bMQ_l = 0;
+    asm volatile("" ::: "memory");
     if (!proton) {
         int lcnt[5] = {0, 0, 0, 0, 0};
 #pragma unroll
@@ -1950,6 +1965,7 @@ DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUC
                 al.c1 += sing;
                 ar.bDP += S[(size_t)UVC_FSUM_BDP * R.npos]; ar.bTA += S[(size_t)UVC_FSUM_BTA * R.npos]; ar.bTB += S[(size_t)UVC_FSUM_BTB * R.npos]; bMQ_r += S[(size_t)UVC_FSUM_BMQ * R.npos];
             }
+            asm volatile("" ::: "memory");
         }
 #pragma unroll
         for (int e = 0; e < 5; e++) {
@@ -1967,49 +1983,51 @@ DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUC
     const bool has_generic = (R.n_sweep > 0 || proton);
     // (1) fragment depth of every symbol with the dense accumulators folded in; which symbols are present
     int totDP_b = 0, totDP_l = 0; unsigned present = 0;
-    {
-        int f0[NSYM], f1[NSYM];
+#define STAGE_FENCE asm volatile("" ::: "memory");   // keeps the compiler from hoisting the next stage's loads into this one (registers: no scratch here)
+    auto depth_stage = [&](auto LINKS) {
+        constexpr int sb = decltype(LINKS)::value ? UVC_LINK_M : UVC_BASE_A, se = decltype(LINKS)::value ? UVC_LINK_NN : UVC_BASE_NN;
+        int f0[se - sb + 1], f1[se - sb + 1];
 #pragma unroll
-        for (int s = 0; s < NSYM; s++) { f0[s] = FRP(R, 0, UVC_FRAG_bDP, s, x); f1[s] = FRP(R, 1, UVC_FRAG_bDP, s, x); }
+        for (int s = sb; s <= se; s++) { f0[s - sb] = FRP(R, 0, UVC_FRAG_bDP, s, x); f1[s - sb] = FRP(R, 1, UVC_FRAG_bDP, s, x); }
 #pragma unroll
-        for (int s = 0; s < NSYM; s++) {
+        for (int s = sb; s <= se; s++) {
             int d0 = 0, d1 = 0;
             if (s <= UVC_BASE_NN && s == my_ref) { d0 = a_fr.bDP; d1 = a_rr.bDP; }
             if (s == UVC_LINK_M) { d0 = a_fl.bDP; d1 = a_rl.bDP; }
-            if (d0) FRP(R, 0, UVC_FRAG_bDP, s, x) = f0[s] + d0;
-            if (d1) FRP(R, 1, UVC_FRAG_bDP, s, x) = f1[s] + d1;
-            const int nfr = f0[s] + f1[s] + d0 + d1;
+            if (d0) FRP(R, 0, UVC_FRAG_bDP, s, x) = f0[s - sb] + d0;
+            if (d1) FRP(R, 1, UVC_FRAG_bDP, s, x) = f1[s - sb] + d1;
+            const int nfr = f0[s - sb] + f1[s - sb] + d0 + d1;
             if (s <= UVC_BASE_NN) totDP_b += nfr; else totDP_l += nfr;
             if (nfr) present |= 1u << s;
         }
+    };
+    STAGE_FENCE
+    depth_stage(std::false_type{});
+    STAGE_FENCE
+    depth_stage(std::true_type{});
+    STAGE_FENCE
+    COARSE_T(ce1)
+    // (2) the other dense accumulators, one (symbol, strand) at a time: five loads, five stores
+    auto flush5 = [&](const DAcc &a, int t, int sym) {
+        if (!(a.bTA | a.bTB | a.c12 | a.c1)) return;
+        const int v0 = FRP(R, t, UVC_FRAG_bTA, sym, x), v1 = FRP(R, t, UVC_FRAG_bTB, sym, x);
+        const int v2 = FAP(R, t, UVC_FAM_cDP12, sym, x), v3 = FAP(R, t, UVC_FAM_cDP21, sym, x), v4 = FAP(R, t, UVC_FAM_cDP1, sym, x);
+        if (a.bTA) FRP(R, t, UVC_FRAG_bTA, sym, x) = v0 + a.bTA;
+        if (a.bTB) FRP(R, t, UVC_FRAG_bTB, sym, x) = v1 + a.bTB;
+        if (a.c12) { FAP(R, t, UVC_FAM_cDP12, sym, x) = v2 + a.c12; FAP(R, t, UVC_FAM_cDP21, sym, x) = v3 + a.c12; }
+        if (a.c1) FAP(R, t, UVC_FAM_cDP1, sym, x) = v4 + a.c1;
+    };
+    flush5(a_fr, 0, my_ref); STAGE_FENCE
+    flush5(a_rr, 1, my_ref); STAGE_FENCE
+    flush5(a_fl, 0, UVC_LINK_M); STAGE_FENCE
+    flush5(a_rl, 1, UVC_LINK_M); STAGE_FENCE
+    if (bMQ_r | bMQ_l) {
+        const int q0 = VQP(R, UVC_VQ_bMQ, my_ref, x), q1 = VQP(R, UVC_VQ_bMQ, UVC_LINK_M, x);
+        if (bMQ_r) VQP(R, UVC_VQ_bMQ, my_ref, x) = q0 + bMQ_r;
+        if (bMQ_l) VQP(R, UVC_VQ_bMQ, UVC_LINK_M, x) = q1 + bMQ_l;
     }
-    // (2) the other dense accumulators
-    {
-        const int sy[2] = { my_ref, UVC_LINK_M };
-        int v[2][2][5], q[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                v[k][t][0] = FRP(R, t, UVC_FRAG_bTA, sy[k], x); v[k][t][1] = FRP(R, t, UVC_FRAG_bTB, sy[k], x);
-                v[k][t][2] = FAP(R, t, UVC_FAM_cDP12, sy[k], x); v[k][t][3] = FAP(R, t, UVC_FAM_cDP21, sy[k], x); v[k][t][4] = FAP(R, t, UVC_FAM_cDP1, sy[k], x);
-            }
-            q[k] = VQP(R, UVC_VQ_bMQ, sy[k], x);
-        }
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const DAcc &a = (k == 0 ? (t ? a_rr : a_fr) : (t ? a_rl : a_fl));
-                if (a.bTA) FRP(R, t, UVC_FRAG_bTA, sy[k], x) = v[k][t][0] + a.bTA;
-                if (a.bTB) FRP(R, t, UVC_FRAG_bTB, sy[k], x) = v[k][t][1] + a.bTB;
-                if (a.c12) { FAP(R, t, UVC_FAM_cDP12, sy[k], x) = v[k][t][2] + a.c12; FAP(R, t, UVC_FAM_cDP21, sy[k], x) = v[k][t][3] + a.c12; }
-                if (a.c1) FAP(R, t, UVC_FAM_cDP1, sy[k], x) = v[k][t][4] + a.c1;
-            }
-            const int mq = (k == 0 ? bMQ_r : bMQ_l);
-            if (mq) VQP(R, UVC_VQ_bMQ, sy[k], x) = q[k] + mq;
-        }
-    }
+    STAGE_FENCE
+    COARSE_T(ce2)
     // (3) P3b (main.hpp:2801-2828): one pass per symbol that some lane of the wave has; its 16 buckets and three outputs in one batch of loads
     if (vcfgen) {
         unsigned long long todo = 0;   // wave-uniform set of symbols
@@ -2037,12 +2055,13 @@ DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUC
             int mv, ad2, bq2;
             infer_max_qual_regs(mv, ad2, bq2, max_qual, (s <= UVC_BASE_NN ? totDP_b : totDP_l), h);
             if (mv | ad2 | bq2) { VQP(R, UVC_VQ_bIAQb, s, x) = o0 + mv; VQP(R, UVC_VQ_bIADb, s, x) = o1 + ad2; VQP(R, UVC_VQ_bIDQb, s, x) = o2 + bq2; }
+            STAGE_FENCE
         }
     }
 #ifdef UVC_FRAG_COARSE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     COARSE_T(ct3)
-    if (lane == 0 && (wave % 1499) == 7) printf("coarse wave %d prologue %llu lists %llu epilogue %llu\n", wave, ct1 - ct0, ct2 - ct1, ct3 - ct2);
+    if (lane == 0 && (wave % 1499) == 7) printf("coarse wave %d prologue %llu lists %llu epilogue %llu = fence %llu sums+depth %llu flush %llu p3b %llu\n", wave, ct1 - ct0, ct2 - ct1, ct3 - ct2, ce0 - ct2, ce1 - ce0, ce2 - ce1, ct3 - ce2);
 #endif
 }
 
