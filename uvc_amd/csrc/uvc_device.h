@@ -221,6 +221,11 @@ DEV int cig_len(uint32_t c) { return (int)(c >> 4); }
 #define BAQ2(R, p) ((R).baq[(R).npos + (p) - (R).beg])
 
 DEV void add64(int64_t *p, int64_t v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
+// Adds to a cell that only one workgroup touches during the kernel (a window kernel owns its 64 positions): an L2 atomic of workgroup
+// scope.  atomicAdd() has agent scope, which on this part is carried out at the memory side (the L2s of the eight XCDs are not coherent
+// with each other) and costs a memory round trip per add.
+DEV void add_own(int32_t *p, int v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DEV void add64_own(int64_t *p, int64_t v) { __hip_atomic_fetch_add((unsigned long long *)p, (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // per-thread symbol-count array kept in LDS ([symbol][thread], conflict-free): dynamic indexing by symbol without scratch memory
 template <int STRIDE> struct LdsCounts {

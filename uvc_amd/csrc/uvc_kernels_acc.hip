@@ -583,6 +583,104 @@ DEV void mut_event(const RegionDev &R, const UvcParams &P, const AlnRec &a, int 
 }
 
 #define PREPQ_CAP 192   // per-wave LDS queue of (alignment, position) pairs whose base differs from the reference
+// ------------------------------------------------------------------------------------------------
+// k_prep_sums: the P1 counters of the simple alignments that do not depend on the bases, as interval sums (the scheme of k_frag_sums).
+// a_dp, a_pcr_dp, a_umi_dp, a_qlen, a_XM1500, a_LIDP, a_RIDP are sums of per-read constants over the reads that cover a position;
+// a_LI / a_RI add min(distance to the insert end, MAX_INSERT_SIZE) (main.hpp:1006-1017), which is p * A(p) + B(p) with A the number of
+// covering reads on the linear piece and B the sum of their offsets plus MAX_INSERT_SIZE per read on the clamped piece.  One block per
+// tile: a lane per read adds +v / -v at the ends of its pieces in LDS, prefix sums, plain stores (the planes are zero; k_prep_fast and
+// k_prep_slow add theirs with atomics afterwards).  k_prep_fast keeps the queue of mismatching bases and the counters behind base quality.
+// ------------------------------------------------------------------------------------------------
+#define PSUM_TILE 1024
+enum { PS_DP = 0, PS_PCR, PS_UMI, PS_QLEN, PS_XM, PS_LIDP, PS_RIDP, PS_LIA, PS_RIA, PS_N32 };
+__global__ void __launch_bounds__(256) k_prep_sums(RegionDev R, UvcParams P) {
+    __shared__ int d[PS_N32][PSUM_TILE + 1];
+    __shared__ unsigned long long d64[2][PSUM_TILE + 1];   // B of a_LI, a_RI
+    __shared__ int wtot[4];
+    __shared__ unsigned long long wtot64[4];
+    const int t0 = R.beg + (int)blockIdx.x * PSUM_TILE, t1 = imin(t0 + PSUM_TILE, R.beg + (int)R.npos);
+    for (int i = threadIdx.x; i < PS_N32 * (PSUM_TILE + 1); i += 256) (&d[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < 2 * (PSUM_TILE + 1); i += 256) (&d64[0][0])[i] = 0ull;
+    __syncthreads();
+    const int w_first = (int)blockIdx.x * (PSUM_TILE / 64), w_last = imin(w_first + PSUM_TILE / 64, R.nwin) - 1;
+    const int lo = win_lo(R, 0, w_first), hi = win_hi(R, 0, w_last);
+    auto put = [&](int f, int a, int b, int v) {   // += v on [a, b) of plane f, clipped to the tile
+        a = imax(a, t0); b = imin(b, t1);
+        if (a < b && v != 0) { atomicAdd(&d[f][a - t0], v); atomicAdd(&d[f][b - t0], -v); }
+    };
+    auto put64 = [&](int f, int a, int b, long long v) {
+        a = imax(a, t0); b = imin(b, t1);
+        if (a < b && v != 0) { atomicAdd(&d64[f][a - t0], (unsigned long long)v); atomicAdd(&d64[f][b - t0], (unsigned long long)(-v)); }
+    };
+    for (int k = lo + (int)threadIdx.x; k < hi; k += 256) {
+        const int4 *q4 = (const int4 *)(R.frec + k);
+        const int4 h0 = q4[0], h1 = q4[1];   // pos rend qb_lo aln | fmd isize mpos xm1500
+        const int apos = h0.x, rend = h0.y;
+        if (rend <= t0 || apos >= t1) continue;
+        const int dflag = (h1.x >> 24) & 0xFF;
+        put(PS_DP, apos, rend, 1); put(PS_PCR, apos, rend, (dflag & 0x4) ? 1 : 0); put(PS_UMI, apos, rend, (dflag & 0x1) ? 1 : 0);
+        put(PS_QLEN, apos, rend, rend - apos); put(PS_XM, apos, rend, h1.w);
+        if (h1.y != 0) {
+            const int fl = imin(apos, h1.z);
+            if (h1.x & 0x10) {   // a_LI: min(p - fl + 1, MAX) = p + (1 - fl) while p < fl + MAX
+                const int brk = imax(apos, imin(rend, (int)lmin((long long)fl + MAX_INSERT_SIZE, (long long)INT32_MAX)));
+                put(PS_LIDP, apos, rend, 1);
+                put(PS_LIA, apos, brk, 1); put64(0, apos, brk, 1LL - fl); put64(0, brk, rend, MAX_INSERT_SIZE);
+            } else {             // a_RI: min(fr - p, MAX) = fr - p once p > fr - MAX
+                const long long fr = (long long)fl + (long long)abs(h1.y);
+                const int brk = imax(apos, imin(rend, (int)lmax(lmin(fr - MAX_INSERT_SIZE + 1, (long long)INT32_MAX), (long long)INT32_MIN)));
+                put(PS_RIDP, apos, rend, 1);
+                put64(1, apos, brk, MAX_INSERT_SIZE); put(PS_RIA, brk, rend, 1); put64(1, brk, rend, fr);
+            }
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n_here = t1 - t0;
+    const int64_t xb = (int64_t)blockIdx.x * PSUM_TILE;
+    int liA[4] = {0, 0, 0, 0}, riA[4] = {0, 0, 0, 0};
+    const int plane_of[PS_N32] = { UVC_P_a_dp, UVC_P_a_pcr_dp, UVC_P_a_umi_dp, UVC_P_a_qlen, UVC_P_a_XM1500, UVC_P_a_LIDP, UVC_P_a_RIDP, -1, -1 };
+    for (int f = 0; f < PS_N32; f++) {
+        int v[4], run = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { run += d[f][threadIdx.x * 4 + i]; v[i] = run; }
+        int inc = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();
+        int before = inc - run;
+        for (int i = 0; i < w; i++) before += wtot[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int x = threadIdx.x * 4 + i, val = before + v[i];
+            if (f == PS_LIA) liA[i] = val; else if (f == PS_RIA) riA[i] = val;
+            else if (x < n_here && val != 0) P32(R, plane_of[f], xb + x) = val;
+        }
+    }
+    for (int f = 0; f < 2; f++) {
+        unsigned long long v[4], run = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { run += d64[f][threadIdx.x * 4 + i]; v[i] = run; }
+        unsigned long long inc = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) wtot64[w] = inc;
+        __syncthreads();
+        unsigned long long before = inc - run;
+        for (int i = 0; i < w; i++) before += wtot64[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int x = threadIdx.x * 4 + i;
+            const long long pp = (long long)t0 + x;
+            const long long val = (long long)(before + v[i]) + (f == 0 ? pp * liA[i] : -pp * riA[i]);
+            if (x < n_here && val != 0) P64(R, f == 0 ? UVC_P_a_LI : UVC_P_a_RI, xb + x) = val;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
     __shared__ int2 prepq[4][PREPQ_CAP];
     const int lane = threadIdx.x & 63;
@@ -595,9 +693,10 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
     const bool valid = x < R.npos;
     const int my_ref = valid ? R.refsym[x] : 0;
     const int my_baq = valid ? (int)R.baq[x] : 0;
-    int dp = 0, pcr = 0, umi = 0, qlen_s = 0, xm_s = 0, lidp = 0, ridp = 0, ldist = 0, rdist = 0, hbq = 0;
-    long long li = 0, ri = 0, lbaq = 0, rbaq = 0;
+    int ldist = 0, rdist = 0, hbq = 0;
+    long long lbaq = 0, rbaq = 0;
     const int lo = wave_uniform(win_lo(R, 0, (int)(x0 >> 6))), hi = wave_uniform(win_hi(R, 0, (int)(x0 >> 6)));
+    COARSE_T(ct1)
     const __amdgpu_buffer_rsrc_t rs = bq_rsrc(R);
     // Mismatching bases are rare per lane but present in a large share of the iterations of a wave, and their handling (SNV / DNV
     // run detection, fragment mutation events) is a chain of dependent loads.  They are queued per wave and handled 64 at a time,
@@ -634,17 +733,7 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
                 if (cover && b != my_ref) myq[nq + (int)__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = make_int2(k0 + j, p);
                 nq += (int)__builtin_popcountll(mm);
             }
-            if (cover) {
-                const int fmd = bcast(c.v[4], j), isize = bcast(c.v[5], j), mpos = bcast(c.v[6], j), xm1500 = bcast(c.v[7], j);
-                const int dflag = (fmd >> 24) & 0xFF;
-                const int pcr_inc = ((dflag & 0x4) ? 1 : 0);
-                dp += 1; pcr += pcr_inc; umi += ((dflag & 0x1) ? 1 : 0);
-                qlen_s += rend - apos; xm_s += xm1500;
-                if (isize != 0) {
-                    const int fl = imin(apos, mpos);
-                    if (fmd & 0x10) { li += imin(p - fl + 1, MAX_INSERT_SIZE); lidp += 1; }
-                    else { ri += imin(fl + abs(isize) - p, MAX_INSERT_SIZE); ridp += 1; }
-                }
+            if (cover) {   // (the counters that do not look at the base: k_prep_sums)
                 if (q >= P.bias_thres_highBQ) {
                     ldist += p - apos + 1; rdist += rend - p;
                     lbaq += (my_baq - bcast(c.v[12], j) + 1);
@@ -654,6 +743,7 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
                 const int clips = bcast(c.v[11], j);
                 if (clips != 0) {
                     const int lclip = clips & 0xFFFF, rclip = (clips >> 16) & 0xFFFF;
+                    const int pcr_inc = (((bcast(c.v[4], j) >> 24) & 0x4) ? 1 : 0);
                     if (p == apos && lclip > 0) clip_event(R, P, apos, 0, lclip, pcr_inc);
                     if (p == rend - 1 && rclip > 0) clip_event(R, P, rend, 1, rclip, pcr_inc);   // any index > 0 gives rpos_delta = -1
                 }
@@ -661,20 +751,19 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
         }
     }
     if (nq > 0) drain();
+    COARSE_T(ct2)
     if (!valid) return;
     // k_prep_slow runs concurrently on the side stream and adds to the same fields: atomics
-    if (dp) atomicAdd(&P32(R, UVC_P_a_dp, x), dp);
-    if (pcr) atomicAdd(&P32(R, UVC_P_a_pcr_dp, x), pcr);
-    if (umi) atomicAdd(&P32(R, UVC_P_a_umi_dp, x), umi);
-    if (qlen_s) atomicAdd(&P32(R, UVC_P_a_qlen, x), qlen_s);
-    if (xm_s) atomicAdd(&P32(R, UVC_P_a_XM1500, x), xm_s);
-    if (lidp) { atomicAdd(&P32(R, UVC_P_a_LIDP, x), lidp); add64(&P64(R, UVC_P_a_LI, x), li); }
-    if (ridp) { atomicAdd(&P32(R, UVC_P_a_RIDP, x), ridp); add64(&P64(R, UVC_P_a_RI, x), ri); }
     if (hbq) {
         atomicAdd(&P32(R, UVC_P_a_highBQ_dp, x), hbq);
         atomicAdd(&P32(R, UVC_P_a_l_dist_sum, x), ldist); atomicAdd(&P32(R, UVC_P_a_r_dist_sum, x), rdist);
         add64(&P64(R, UVC_P_a_l_BAQ_sum, x), lbaq); add64(&P64(R, UVC_P_a_r_BAQ_sum, x), rbaq);
     }
+#ifdef UVC_FRAG_COARSE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    COARSE_T(ct3)
+    if (lane == 0 && ((int)(x0 >> 6) % 2999) == 7) printf("coarse prep wave %d lists %llu epilogue %llu\n", (int)(x0 >> 6), ct2 - ct1, ct3 - ct2);
+#endif
 }
 
 // P1 for one alignment whose CIGAR has InDels / unusual clip layouts: one wave per read, lanes stride over the bases of
@@ -908,9 +997,7 @@ DEV void mis_apply(const RegionDev &R, const UvcParams &P, const MisItem &it) {
 // Two instantiations, <true,false> for LINK_M and <false,true> for the read bases: each keeps one SegAcc in registers,
 // which halves the accumulator footprint and doubles the waves per SIMD.
 template <bool DO_L, bool DO_B, bool PLAIN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k_p2_fast(RegionDev R, UvcParams P) {
-    __shared__ int amp1[256], amp2[256];
-    __shared__ MisItem misq[DO_B ? 4 : 1][DO_B ? MISQ_CAP : 1];
+DEV void p2_fast_body(const RegionDev &R, const UvcParams &P, int *amp1, int *amp2, MisItem (*misq)[DO_B ? MISQ_CAP : 1]) {
     COARSE_T(ct0)
     {
         const int v = threadIdx.x;
@@ -1031,6 +1118,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k
     COARSE_T(ct3)
     if (lane == 0 && (wave % 2999) == 7) printf("coarse p2<%d,%d> wave %d prologue %llu lists %llu epilogue %llu\n", (int)DO_L, (int)DO_B, wave, ct1 - ct0, ct2 - ct1, ct3 - ct2);
 #endif
+}
+template <bool DO_L, bool DO_B, bool PLAIN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k_p2_fast(RegionDev R, UvcParams P) {
+    __shared__ int amp1[256], amp2[256];
+    __shared__ MisItem misq[DO_B ? 4 : 1][DO_B ? MISQ_CAP : 1];
+    p2_fast_body<DO_L, DO_B, PLAIN>(R, P, amp1, amp2, misq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2340,10 +2433,12 @@ struct FamAcc {
     int (*a32)[FAMW_SLOTS][64]; unsigned long long (*a64)[UVC_NFAMINFO64][64]; int (*bk)[2][NBUCKETS][64];
     const RegionDev *R; int64_t x; int lane, my_ref;
     DEV int dense(int cs) const { return !a32 ? -1 : (cs == my_ref ? 0 : (cs == UVC_LINK_M ? 1 : -1)); }   // without LDS accumulators (k_fam_p4d_rest) every increment is a global atomic
-    DEV void fap(int strand, int f, int cs, int v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a32[d][strand * UVC_NFAM + f][lane], v); else atomicAdd(&FAP(*R, strand, f, cs, x), v); }
-    DEV void fi(int f, int cs, int v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a32[d][2 * UVC_NFAM + f][lane], v); else atomicAdd(&FIP(*R, f, cs, x), v); }
-    DEV void fi64(int f, int cs, long long v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a64[d][f][lane], (unsigned long long)v); else add64(&FI64P(*R, f, cs, x), v); }
-    DEV void bucket(int strand, int cs, int b) const { const int d = dense(cs); if (d >= 0) atomicAdd(&bk[d][strand][b][lane], 1); else atomicAdd(&BKP(*R, strand, cs, b, x), 1); R->p5flag[(size_t)strand * R->npos + x] = 1; }
+    // a window kernel (a32 set) owns its positions: its adds to the planes are L2 atomics of workgroup scope (add_own)
+    DEV void gadd(int32_t *p, int v) const { if (a32) add_own(p, v); else atomicAdd(p, v); }
+    DEV void fap(int strand, int f, int cs, int v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a32[d][strand * UVC_NFAM + f][lane], v); else gadd(&FAP(*R, strand, f, cs, x), v); }
+    DEV void fi(int f, int cs, int v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a32[d][2 * UVC_NFAM + f][lane], v); else gadd(&FIP(*R, f, cs, x), v); }
+    DEV void fi64(int f, int cs, long long v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a64[d][f][lane], (unsigned long long)v); else if (a32) add64_own(&FI64P(*R, f, cs, x), v); else add64(&FI64P(*R, f, cs, x), v); }
+    DEV void bucket(int strand, int cs, int b) const { const int d = dense(cs); if (d >= 0) atomicAdd(&bk[d][strand][b][lane], 1); else gadd(&BKP(*R, strand, cs, b, x), 1); R->p5flag[(size_t)strand * R->npos + x] = 1; }
 };
 
 // The P4 increments of one (unit, position, symbol type) once the vote consensus (cs = symbol, cc = its votes, ct = all votes) is known
@@ -2622,22 +2717,22 @@ __global__ void __launch_bounds__(256) k_fam_win(RegionDev R, UvcParams P) {
         const int ln = i & 63, slot = (i >> 6) % FAMW_SLOTS, d = (i >> 6) / FAMW_SLOTS;
         const int64_t xx = x0 + ln;
         const int sym = (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M);
-        if (slot < 2 * UVC_NFAM) atomicAdd(&FAP(R, slot / UVC_NFAM, slot % UVC_NFAM, sym, xx), v);
-        else atomicAdd(&FIP(R, slot - 2 * UVC_NFAM, sym, xx), v);
+        if (slot < 2 * UVC_NFAM) add_own(&FAP(R, slot / UVC_NFAM, slot % UVC_NFAM, sym, xx), v);
+        else add_own(&FIP(R, slot - 2 * UVC_NFAM, sym, xx), v);
     }
     for (int i = threadIdx.x; i < 2 * UVC_NFAMINFO64 * 64; i += 256) {
         const unsigned long long v = (&a64[0][0][0])[i];
         if (!v) continue;
         const int ln = i & 63, f = (i >> 6) % UVC_NFAMINFO64, d = (i >> 6) / UVC_NFAMINFO64;
         const int64_t xx = x0 + ln;
-        add64(&FI64P(R, f, (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M), xx), (long long)v);
+        add64_own(&FI64P(R, f, (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M), xx), (long long)v);
     }
     if (PASS == 5) for (int i = threadIdx.x; i < 2 * 2 * NBUCKETS * 64; i += 256) {
         const int v = (&bk[0][0][0][0])[i];
         if (!v) continue;
         const int ln = i & 63, b = (i >> 6) % NBUCKETS, strand = ((i >> 6) / NBUCKETS) % 2, d = (i >> 6) / (2 * NBUCKETS);
         const int64_t xx = x0 + ln;
-        atomicAdd(&BKP(R, strand, (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M), b, xx), v);
+        add_own(&BKP(R, strand, (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M), b, xx), v);
     }
 }
 
@@ -2833,15 +2928,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
         const int ln = i & 63, slot = (i >> 6) % FAMW_SLOTS, d = (i >> 6) / FAMW_SLOTS;
         const int64_t xx = x0 + ln;
         const int sym = (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M);
-        if (slot < 2 * UVC_NFAM) atomicAdd(&FAP(R, slot / UVC_NFAM, slot % UVC_NFAM, sym, xx), v);
-        else atomicAdd(&FIP(R, slot - 2 * UVC_NFAM, sym, xx), v);
+        if (slot < 2 * UVC_NFAM) add_own(&FAP(R, slot / UVC_NFAM, slot % UVC_NFAM, sym, xx), v);
+        else add_own(&FIP(R, slot - 2 * UVC_NFAM, sym, xx), v);
     }
     for (int i = threadIdx.x; i < 2 * UVC_NFAMINFO64 * 64; i += 256) {
         const unsigned long long v = (&a64[0][0][0])[i];
         if (!v) continue;
         const int ln = i & 63, f = (i >> 6) % UVC_NFAMINFO64, d = (i >> 6) / UVC_NFAMINFO64;
         const int64_t xx = x0 + ln;
-        add64(&FI64P(R, f, (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M), xx), (long long)v);
+        add64_own(&FI64P(R, f, (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M), xx), (long long)v);
     }
 }
 
@@ -3414,16 +3509,19 @@ extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const 
 // The sequential, low-occupancy kernels of the InDel reads and the per-fragment statistics need P1 / P1b only, not P2: they run on
 // a side stream underneath the two issue-bound P2 kernels and join before anything reads their outputs.
 #define TIMED2(prof, kname, ...) do { hipStream_t s = s2; TIMED(prof, kname, __VA_ARGS__); } while (0)
+#define TIMED3(prof, kname, ...) do { hipStream_t s = s3; TIMED(prof, kname, __VA_ARGS__); } while (0)
 extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, int half_ratio_phred,
                                       const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof,
-                                      hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join, hipEvent_t e_fork2) {
+                                      hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join, hipEvent_t e_fork2, hipStream_t side3, hipEvent_t e_join3) {
     const unsigned nwin = nblk(R->npos, 256);   // 4 waves x 64 positions per block
     if (prof) prof->n = 0;
     hipStream_t s2 = (side ? side : s);
+    hipStream_t s3 = ((side && side3) ? side3 : s2);   // the two CIGAR walks of the InDel reads are independent, one wave per 64 reads and long: a stream each
     {   // the window index of the alignment lists (the fragment list's follows k_fragstat_fast, which writes it)
         const int64_t n = 2 * (int64_t)R->nwin * 5;
         TIMED(prof, "k_win_index", hipLaunchKernelGGL(k_win_index, dim3(nblk(n, 256)), dim3(256), 0, s, *R, 0, 5));
     }
+    if (P->inferred_is_vcf_generated && R->n_fast) TIMED(prof, "k_prep_sums", hipLaunchKernelGGL(k_prep_sums, dim3(nblk(R->npos, PSUM_TILE)), dim3(256), 0, s, *R, *P));
     if (P->inferred_is_vcf_generated) {
         // P1: the InDel reads (one wave per read) underneath the position-centric pass
         if (side && R->n_complex) { hipEventRecord(e_fork, s); hipStreamWaitEvent(s2, e_fork, 0); }
@@ -3434,30 +3532,34 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
     }
     // P1b is part of updateByAlns3UsingBQ too (main.hpp:3691-3702): on a FASTQ-only run the thresholds stay zero and rtr.indelphred unedited
     if (P->inferred_is_vcf_generated) TIMED(prof, "k_thres", hipLaunchKernelGGL(k_thres, dim3(nblk(R->npos, 256)), dim3(256), 0, s, *R, *P, half_ratio_phred));
-    if (side) { hipEventRecord(e_fork, s); hipStreamWaitEvent(s2, e_fork, 0); }
-    // ---- side stream
+    if (side) { hipEventRecord(e_fork, s); hipStreamWaitEvent(s2, e_fork, 0); if (s3 != s2) hipStreamWaitEvent(s3, e_fork, 0); }
+    // ---- side streams.  s2: the walk that produces the P2 items.  s3: the walk that fills the contribution table, then the per-fragment
+    // statistics, the fragment window index and the interval sums (they need P1 / P1b only), then the queued mismatches of the base pass.
     if (P->inferred_is_vcf_generated && R->n_complex) TIMED2(prof, "k_p2_slow_walk", hipLaunchKernelGGL(k_p2_slow<true>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
-    if (R->n_complex) TIMED2(prof, "k_p2_slow_table", hipLaunchKernelGGL(k_p2_slow<false>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
-    TIMED2(prof, "k_fragstat_fast", hipLaunchKernelGGL(k_fragstat_fast, dim3(nblk(R->n_frags, 256)), dim3(256), 0, s, *R, *P));
-    TIMED2(prof, "k_win_index_frag", hipLaunchKernelGGL(k_win_index, dim3(nblk(2 * (int64_t)R->nwin * 2, 256)), dim3(256), 0, s, *R, 5, 7));
-    if (R->n_sweep) TIMED2(prof, "k_fragstat_sweep", hipLaunchKernelGGL(k_fragstat_sweep, dim3(R->n_sweep), dim3(64), 0, s, *R, *P, R->sweep_frags, (const int32_t *)nullptr, R->n_sweep));
+    if (R->n_complex) TIMED3(prof, "k_p2_slow_table", hipLaunchKernelGGL(k_p2_slow<false>, dim3(nblk(R->n_complex, 64)), dim3(64), 0, s, *R, *P));
+    TIMED3(prof, "k_fragstat_fast", hipLaunchKernelGGL(k_fragstat_fast, dim3(nblk(R->n_frags, 256)), dim3(256), 0, s, *R, *P));
+    TIMED3(prof, "k_win_index_frag", hipLaunchKernelGGL(k_win_index, dim3(nblk(2 * (int64_t)R->nwin * 2, 256)), dim3(256), 0, s, *R, 5, 7));
+    if (R->n_sweep) TIMED3(prof, "k_fragstat_sweep", hipLaunchKernelGGL(k_fragstat_sweep, dim3(R->n_sweep), dim3(64), 0, s, *R, *P, R->sweep_frags, (const int32_t *)nullptr, R->n_sweep));
     // fragments whose event list overflowed (device-side list; the grid covers the worst case, surplus threads exit)
-    TIMED2(prof, "k_fragstat_overflow", hipLaunchKernelGGL(k_fragstat_sweep, dim3(imin_h(R->n_frags, 65535)), dim3(64), 0, s, *R, *P, (const int32_t *)R->overflow_frags, (const int32_t *)R->n_overflow, 0));
+    TIMED3(prof, "k_fragstat_overflow", hipLaunchKernelGGL(k_fragstat_sweep, dim3(imin_h(R->n_frags, 65535)), dim3(64), 0, s, *R, *P, (const int32_t *)R->overflow_frags, (const int32_t *)R->n_overflow, 0));
     if (UVC_PLATFORM_IONTORRENT != P->inferred_sequencing_platform)   // (there every fragment takes k_frag_generic)
-        TIMED2(prof, "k_frag_sums", hipLaunchKernelGGL(k_frag_sums, dim3(nblk(R->npos, FSUM_TILE), 2), dim3(256), 0, s, *R, *P));
+        TIMED3(prof, "k_frag_sums", hipLaunchKernelGGL(k_frag_sums, dim3(nblk(R->npos, FSUM_TILE), 2), dim3(256), 0, s, *R, *P));
     // ---- main stream: the base symbols first, so that the queued mismatches (rare symbols, atomics: disjoint from the planes the
-    // LINK_M pass stores to) are applied on the side stream while the LINK_M pass runs
+    // LINK_M pass stores to) are applied on a side stream while the LINK_M pass runs
     if (P->inferred_is_vcf_generated) {
         // no IonTorrent values, no amplicon-flagged family, no primer length: the specialisation without those arms
         const bool plain = (UVC_PLATFORM_IONTORRENT != P->inferred_sequencing_platform) && !R->any_amplicon && !(P->primerlen > 0 && !(0x2 & P->primer_flag));
         if (plain) TIMED(prof, "k_p2_fast_base", hipLaunchKernelGGL((k_p2_fast<false, true, true>), dim3(nwin), dim3(256), 0, s, *R, *P));
         else TIMED(prof, "k_p2_fast_base", hipLaunchKernelGGL((k_p2_fast<false, true, false>), dim3(nwin), dim3(256), 0, s, *R, *P));
-        if (side) { hipEventRecord(e_fork2, s); hipStreamWaitEvent(s2, e_fork2, 0); }
-        TIMED2(prof, "k_p2_mism", hipLaunchKernelGGL(k_p2_mism, dim3(2048), dim3(256), 0, s, *R, *P));
+        if (side) { hipEventRecord(e_fork2, s); hipStreamWaitEvent(s3, e_fork2, 0); }
+        TIMED3(prof, "k_p2_mism", hipLaunchKernelGGL(k_p2_mism, dim3(2048), dim3(256), 0, s, *R, *P));
         if (plain) TIMED(prof, "k_p2_fast_link", hipLaunchKernelGGL((k_p2_fast<true, false, true>), dim3(nwin), dim3(256), 0, s, *R, *P));
         else TIMED(prof, "k_p2_fast_link", hipLaunchKernelGGL((k_p2_fast<true, false, false>), dim3(nwin), dim3(256), 0, s, *R, *P));
     }
-    if (side) { hipEventRecord(e_join, s2); hipStreamWaitEvent(s, e_join, 0); }
+    if (side) {
+        hipEventRecord(e_join, s2); hipStreamWaitEvent(s, e_join, 0);
+        if (s3 != s2) { hipEventRecord(e_join3, s3); hipStreamWaitEvent(s, e_join3, 0); hipStreamWaitEvent(s2, e_join3, 0); }   // (the allele tables below read the contribution table)
+    }
     // InDel allele tables: they read the contribution table (side stream) and the reads only, so the pipeline stays on the side stream
     // underneath the fragment / family kernels; the main stream picks it up at the end
     const GapWork &G = R->gap;
