@@ -54,7 +54,7 @@ def algorithmic_bytes_per_position(kernel, depth):
         "k_prep_fast": reads + 1 + 8 + 208,                         # + ref, baq ; writes SegFormatPrepSet
         "k_thres": 208 + 28 + 72 + 4,                                # prep + rtr -> thres + indelphred
         "k_p2_fast_link": 48.0 * d / READ_LEN + 72 + 16 + 8 + (152 + 16 + 4),        # read records, thres, 2 baq, 2 indelphred ; writes LINK_M seg info + a1/a2 BQ + bqsum
-        "k_p2_fast_base": reads + 1 + 72 + 16 + 13 * (152 + 16 + 4),                 # + ref, thres, 2 baq ; writes the base symbols' seg info
+        "k_p2_fast_base": reads + 1 + 72 + 16 + (152 + 16 + 4),                      # + ref, thres, 2 baq ; writes the reference base's seg info (the other symbols' cells: k_p2_mism)
         "k_frag": reads + 48.0 * d / (2 * READ_LEN) + 1 + 8 + 14 * 20 + 14 * 4 * (6 + 6 + 4),   # + fragment records, avgBQ inputs ; writes frag, fam(3), VQ(4)
         "k_p5b": 2 * 14 * 4 + 14 * 4 * 6,
     }
