@@ -193,3 +193,26 @@ def test_config4_tile_three_forms_of_the_family_kernels_agree(gpu_lib, monkeypat
     assert (d2 <= d1).all() and d2.sum() > 10_000                              # duplex families whose two strands agree are a subset of the duplex families
     assert (d1.sum(axis=0) <= np.minimum(c12[0].sum(axis=0), c12[1].sum(axis=0))).all()   # a duplex family needs a unit on each strand
     assert base_rec["keep"].sum() > 50 and len(base_rec["refpos"]) > 100_000
+
+
+def test_k_frag_with_32_bit_buckets_equals_the_packed_form(gpu_lib, monkeypatch):
+    """k_frag keeps its LDS bucket histogram packed two per word while fewer than 65 536 fragments cover a position (k_frag16) and in 32-bit
+    words otherwise (k_frag: a depth no test tile has).  UVCGPU_FRAG32 forces the second form: same planes, same records, on a tile with
+    InDel fragments (the LINK_M arm outside the interval sums) and rare symbols (the event queue)."""
+    reads = synth.generate_region(seed=777, region_len=120_000, depth=300)
+    out = []
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("UVCGPU_FRAG32", "1")     # read by set_reads
+        else:
+            monkeypatch.delenv("UVCGPU_FRAG32", raising=False)
+        R = region.Region(gpu_lib, region.default_params(gpu_lib), reads["tid"], reads["beg"], reads["end"], reads["refseq"])
+        R.set_reads(reads)
+        R.accumulate()
+        sums = checksum(R)
+        rec = R.score(capacity=200_000)
+        out.append((sums, {k: rec[k].copy() for k in ("refpos", "symbol", "QUAL", "keep")}))
+        R.close()
+    assert out[0][0] == out[1][0]
+    assert all(np.array_equal(out[0][1][k], out[1][1][k]) for k in out[0][1])
+    assert len(out[0][1]["refpos"]) > 1_000

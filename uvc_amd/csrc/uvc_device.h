@@ -178,6 +178,7 @@ struct RegionDev {
     unsigned long long *mis_total;  // number of read bases of simple alignments that differ from the reference (k_aln_prelude)
     int32_t max_aln_span, max_frag_span;
     int32_t any_amplicon;           // some family carries the amplicon flag (fam_dflag & 0x4)
+    int32_t frag32;                 // UVCGPU_FRAG32=1: k_frag with 32-bit buckets although the depth would allow the packed form (tests compare the two)
     int32_t fam_path;               // 0: the family kernels are chosen from the data; 1 / 2: UVCGPU_FAM_PATH=generic / window (tests compare the three forms)
     int32_t max_frag_depth;         // upper bound of the number of fragments that cover one position
     int32_t *err;                   // device error flag (unsupported CIGAR shapes etc.)

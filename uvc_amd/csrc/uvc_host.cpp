@@ -425,6 +425,7 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
     {   // UVCGPU_FAM_PATH=generic | window | (unset: by the data): which form of the family kernels runs -- the three give identical planes (tests/test_gpu_fullsize.py)
         const char *fp = getenv("UVCGPU_FAM_PATH");
         R.fam_path = (fp && !strcmp(fp, "generic")) ? 1 : ((fp && !strcmp(fp, "window")) ? 2 : 0);
+        R.frag32 = (getenv("UVCGPU_FRAG32") != nullptr);
     }
     if (R.fam_path == 0 && o.work > 8 * r->npos && (size_t)o.work * 32 <= ((size_t)48 << 30) && o.max_unit_frags < 16384) {   // (the digest packs vote counts in 14 bits)
         // deep data (the window family kernels): 32 B per (unit, position) so that P5 and the duplex pass do not walk the fragments again

@@ -3586,7 +3586,7 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
     }
     {
         const bool plain = P->inferred_is_vcf_generated && (UVC_PLATFORM_IONTORRENT != P->inferred_sequencing_platform) && !(0x1 & P->fam_flag) && !(P->microadjust_padded_deletion_flag & 0x1);
-        const bool h16 = (R->max_frag_depth < 65536);
+        const bool h16 = (R->max_frag_depth < 65536) && !R->frag32;
         if (plain && h16) TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag16<true>, dim3(nwin), dim3(256), 0, s, *R, *P));
         else if (plain) TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag<true>, dim3(nwin), dim3(256), 0, s, *R, *P));
         else if (h16) TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag16<false>, dim3(nwin), dim3(256), 0, s, *R, *P));
