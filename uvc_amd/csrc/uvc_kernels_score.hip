@@ -123,7 +123,10 @@ struct Al {   // one allele (index a = 0 everywhere in the reference)
     int cDP1v, cDP1w, cDP1x, cDP2v, cDP2w, cDP2x;
 };
 
-#define SUMSYM(expr) ({ long long r_ = 0; for (int k_ = 0; k_ < nsym; k_++) { const int s = st_symbol(st, k_); r_ += (long long)(expr); } r_; })
+// sum of a plane value over the symbols of the type (integer: any order).  Unrolled over the eight possible symbols with a guard, so that the
+// loads of one sum -- and of the neighbouring sums -- are issued together: as a loop over nsym every load waited for the one before it, and
+// k_score is a chain of dependent loads at less than one wave per SIMD (420 memory round trips per group in group_totals alone).
+#define SUMSYM(expr) ({ long long r_ = 0; const int sb_ = (st == UVC_BASE_SYMBOL ? UVC_BASE_A : UVC_LINK_M); _Pragma("unroll") for (int k_ = 0; k_ < 8; k_++) { if (k_ < nsym) { const int s = sb_ + k_; r_ += (long long)(expr); } } r_; })
 
 DEV void group_totals(const RegionDev &R, int64_t x, int st, Tot &f) {
     const int nsym = st_count(st);
