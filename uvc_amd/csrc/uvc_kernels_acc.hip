@@ -1943,8 +1943,13 @@ DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUC
         }
         const int n = imin(64, hi - k0);
         int bq0n = 0, bq1n = 0;
+        int n_fl = 0, n_fend = 0;   // of the record whose bytes are on their way: read once, used by its iteration too
         auto issue = [&](int j) {
-            const int fl = bcast(c[3], j);
+            const int fl = n_fl = bcast(c[3], j);
+            n_fend = bcast(c[1], j);
+            // the list holds every fragment that could reach the window (begin within the longest span): four in ten end in front of it,
+            // and a fragment of the generic kind is not read here at all -- no bytes for those
+            if (n_fend <= w0 || (fl & 1)) return;
             int i0 = bcast(c[8], j), i1 = bcast(c[9], j);
             if (fl & 0x100) {   // the lane's position may lie in run B of either alignment
                 if (p >= bcast(c[16], j) && p < bcast(c[17], j)) i0 = bcast(c[18], j);
@@ -1957,9 +1962,10 @@ DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUC
         issue(0);
         for (int j = 0; j < n; j++) {
             const int b0 = bq0n & 0xFF, q0 = (bq0n >> 8) & 0xFF, b1 = bq1n & 0xFF, q1 = (bq1n >> 8) & 0xFF;
+            const int flags = n_fl, fend = n_fend;
             if (j + 1 < n) issue(j + 1);
-            const int fbeg = bcast(c[0], j), fend = bcast(c[1], j), flags = bcast(c[3], j);
             if (fend <= w0) continue;
+            const int fbeg = bcast(c[0], j);
             if (flags & 1) continue;   // done by k_frag_generic
             // from here on the control flow stays wave-uniform down to the queue bookkeeping (nq is a scalar): per-lane conditions are predicates
             bool cover = (valid && p >= fbeg && p < fend);
