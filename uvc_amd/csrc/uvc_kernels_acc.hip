@@ -2697,13 +2697,32 @@ __global__ void __launch_bounds__(256) k_fam_win(RegionDev R, UvcParams P) {
                     A.fap(strand, UVC_FAM_cDPD, cs, 1);
                 const int avgBQ = ((0 == tot_nfrags) ? 1 : (con_sumBQs / tot_nfrags));
                 const int majorcount = FAP(R, strand, UVC_FAM_cDPM, cs, x), minorcount = FAP(R, strand, UVC_FAM_cDPm, cs, x);   // complete: P4 ran before
-                const double prior_weight = 1.0 / (minorcount + 1.0);
-                const double p2p = ((unsigned)avgBQ < 128u) ? p2p_s[avgBQ] : pow(10.0, (double)(-((float)avgBQ) / 10));   // phred2prob's float cast, main_conversion.hpp:885-888
-                const double prob = (minorcount + prior_weight) / (majorcount + minorcount + prior_weight / p2p);
-                const double realphred = -10 * log(prob) / log(10.0);
-                const int indep_frag_phred = (int)round(((con_nfrags * 2) - tot_nfrags) * realphred);
+                // realphred = -10 log10(prob) enters through round(k * realphred) and round(realphred) only.  A single-precision evaluation
+                // (error of realphred < 1e-5) decides both roundings unless a product lies within its error bound of a half: only then (one
+                // wave iteration in ten) the fp64 expression of the reference is evaluated.  Two fp64 divisions and a log per cell and symbol
+                // type were most of this kernel.
+                const int kfr = (con_nfrags * 2) - tot_nfrags;
+                int indep_frag_phred, round_realphred;
+                {
+                    const float wf = __builtin_amdgcn_rcpf((float)minorcount + 1.0f);
+                    const float p2pf = ((unsigned)avgBQ < 128u) ? (float)p2p_s[avgBQ] : 0.0f;
+                    const float probf = ((float)minorcount + wf) * __builtin_amdgcn_rcpf((float)majorcount + (float)minorcount + wf * __builtin_amdgcn_rcpf(p2pf));
+                    const float rf = -3.0102999566f * __builtin_amdgcn_logf(probf);   // v_log_f32 is log2
+                    const float v1 = (float)kfr * rf;
+                    const float tol1 = 5.0e-4f + 4.0e-5f * fabsf((float)kfr) + 1.0e-6f * fabsf(v1), tol0 = 5.0e-4f;
+                    const bool safe = ((unsigned)avgBQ < 128u) && (majorcount + minorcount < (1 << 22)) && rf > 0.0f && rf < 1000.0f
+                                      && fabsf(v1 - floorf(v1) - 0.5f) > tol1 && fabsf(rf - floorf(rf) - 0.5f) > tol0;
+                    if (safe) { indep_frag_phred = (int)roundf(v1); round_realphred = (int)roundf(rf); }
+                    else {
+                        const double prior_weight = 1.0 / (minorcount + 1.0);
+                        const double p2p = ((unsigned)avgBQ < 128u) ? p2p_s[avgBQ] : pow(10.0, (double)(-((float)avgBQ) / 10));   // phred2prob's float cast, main_conversion.hpp:885-888
+                        const double prob = (minorcount + prior_weight) / (majorcount + minorcount + prior_weight / p2p);
+                        const double realphred = -10 * log(prob) / log(10.0);
+                        indep_frag_phred = (int)round(kfr * realphred); round_realphred = (int)round(realphred);
+                    }
+                }
                 int confam_qual;
-                if (UVC_LINK_SYMBOL == st) confam_qual = imax(1, imin(indep_frag_phred, P.fam_phred_indel_inc_before_barcode_labeling + (int)round(realphred)));
+                if (UVC_LINK_SYMBOL == st) confam_qual = imax(1, imin(indep_frag_phred, P.fam_phred_indel_inc_before_barcode_labeling + round_realphred));
                 else confam_qual = imax(1, imin(indep_frag_phred, (con_sumBQs * 2) - tot_sumBQs));
                 const int max_qual = sscs_phred(P, R.refsym[x], cs) + (!P.tumor_vcf_is_provided ? 0 : 4);
                 const int confam_qual2 = imin(confam_qual, max_qual);
