@@ -165,7 +165,7 @@ struct RegionDev {
     int32_t frag_off[3];            // ffast = the strand-0 fragments sorted by beg, then the strand-1 fragments sorted by beg
     FragFast *ffast;                // [n_frags] in (strand, beg)-sorted order
     FragUnit *ffast_u;              // [n_frags] by fragment number (see FragUnit)
-    int32_t *win; int32_t nwin;     // window index [7 lists][lo, hi][nwin = ceil(npos / 64)] (k_win_index)
+    int32_t *win; int32_t nwin;     // window index [8 lists][lo, hi][nwin = ceil(npos / 64)] (k_win_index)
     int32_t *fsum;                  // [2 strands][UVC_FSUM_N][npos]: interval sums of the plain fragments (k_frag_sums), read by k_frag
     FsRec *fss; int32_t n_fs;
     const int32_t *generic_fs; int32_t n_generic_fs; int64_t n_generic_work;

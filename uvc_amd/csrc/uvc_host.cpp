@@ -308,7 +308,7 @@ static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t 
         for (void *p : { (void *)r->d_refsym, (void *)r->d_rtr, (void *)r->d_rtr0, (void *)r->d_fsum, (void *)r->d_win, (void *)r->d_baq, (void *)r->d_state }) if (p) hipFree(p);
         r->d_refsym = nullptr; r->d_rtr = r->d_rtr0 = r->d_fsum = r->d_win = nullptr; r->d_baq = nullptr; r->d_state = nullptr; r->npos_cap = 0;
         if (hipMalloc((void **)&r->d_refsym, (size_t)r->npos + 1) != hipSuccess || hipMalloc((void **)&r->d_rtr, sizeof(int32_t) * rtr.size()) != hipSuccess
-            || hipMalloc((void **)&r->d_rtr0, sizeof(int32_t) * rtr.size()) != hipSuccess || hipMalloc((void **)&r->d_fsum, sizeof(int32_t) * 2 * UVC_FSUM_N * (size_t)r->npos) != hipSuccess || hipMalloc((void **)&r->d_win, sizeof(int32_t) * 14 * (size_t)((r->npos + 63) / 64)) != hipSuccess || hipMalloc((void **)&r->d_baq, sizeof(int64_t) * baq.size()) != hipSuccess
+            || hipMalloc((void **)&r->d_rtr0, sizeof(int32_t) * rtr.size()) != hipSuccess || hipMalloc((void **)&r->d_fsum, sizeof(int32_t) * 2 * UVC_FSUM_N * (size_t)r->npos) != hipSuccess || hipMalloc((void **)&r->d_win, sizeof(int32_t) * 16 * (size_t)((r->npos + 63) / 64)) != hipSuccess || hipMalloc((void **)&r->d_baq, sizeof(int64_t) * baq.size()) != hipSuccess
             || hipMalloc((void **)&r->d_state, r->state_bytes) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(region planes) failed");
         r->npos_cap = r->npos;
     }

@@ -76,8 +76,9 @@ DEV int lower_bound_frec(const FastRec *a, int n, int key) {   // first index wi
 // Window index: for every 64-position window w and every begin-sorted work list, the records a wave of window w walks:
 // [first record with begin >= window begin - longest span + 1, first record with begin >= window end).  A binary search per wave and list is
 // ~20 dependent memory round trips (8 lists' bounds in k_p2_fast: an eighth of a wave's life); the table costs one load each.
-// Lists: 0 = frec (k_prep_fast), 1..4 = the four sub-lists of frec2 (k_p2_fast), 5..6 = the two strands of ffast (k_frag).
-#define WIN_LISTS 7
+// Lists: 0 = frec (k_prep_fast), 1..4 = the four sub-lists of frec2 (k_p2_fast), 5..6 = the two strands of ffast (k_frag),
+// 7 = the generic family-strand units by begin (the window kernels of the family passes: two loads per search step there).
+#define WIN_LISTS 8
 DEV int win_lo(const RegionDev &R, int list, int w) { return R.win[((size_t)list * 2) * R.nwin + w]; }
 DEV int win_hi(const RegionDev &R, int list, int w) { return R.win[((size_t)list * 2 + 1) * R.nwin + w]; }
 __global__ void __launch_bounds__(256) k_win_index(RegionDev R, int list_beg, int list_end) {
@@ -88,9 +89,11 @@ __global__ void __launch_bounds__(256) k_win_index(RegionDev R, int list_beg, in
     const char *base; int stride, lo, hi, span;
     if (list == 0) { base = (const char *)&R.frec[0].pos; stride = sizeof(FastRec); lo = 0; hi = R.n_fast; span = R.max_aln_span; }
     else if (list <= 4) { base = (const char *)&R.frec2[0].pos; stride = sizeof(FastRec); lo = R.p2_off[list - 1]; hi = R.p2_off[list]; span = R.max_p2_span; }
-    else { base = (const char *)&R.ffast[0].beg; stride = sizeof(FragFast); lo = R.frag_off[list - 5]; hi = R.frag_off[list - 4]; span = R.max_frag_span; }
+    else if (list <= 6) { base = (const char *)&R.ffast[0].beg; stride = sizeof(FragFast); lo = R.frag_off[list - 5]; hi = R.frag_off[list - 4]; span = R.max_frag_span; }
+    else { base = nullptr; stride = 0; lo = 0; hi = R.n_generic_fs; span = R.max_unit_span; }
     const int w0 = R.beg + 64 * w, key = (which == 0 ? w0 - span + 1 : w0 + 64);
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (*(const int32_t *)(base + (size_t)mid * stride) < key) lo = mid + 1; else hi = mid; }
+    if (list <= 6) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (*(const int32_t *)(base + (size_t)mid * stride) < key) lo = mid + 1; else hi = mid; } }
+    else { while (lo < hi) { const int mid = (lo + hi) >> 1; if (R.fss[R.generic_sorted[mid]].beg < key) lo = mid + 1; else hi = mid; } }
     R.win[((size_t)list * 2 + which) * R.nwin + w] = lo;
 }
 DEV int lower_bound_pos(const AlnRec *a, int n, int key) {   // first index with a[i].pos >= key
@@ -2535,15 +2538,7 @@ __global__ void __launch_bounds__(256) k_fam_win(RegionDev R, UvcParams P) {
     if (x0 >= R.npos) return;
     const int w0 = R.beg + (int)x0;
     // the units whose span can reach this window (sorted by begin)
-    int lo, hi;
-    {
-        int l = 0, h = R.n_generic_fs;
-        const int key = w0 - R.max_unit_span + 1;
-        while (l < h) { int m = (l + h) >> 1; if (R.fss[R.generic_sorted[m]].beg < key) l = m + 1; else h = m; }
-        lo = l; h = R.n_generic_fs;
-        while (l < h) { int m = (l + h) >> 1; if (R.fss[R.generic_sorted[m]].beg < w0 + 64) l = m + 1; else h = m; }
-        hi = l;
-    }
+    const int lo = win_lo(R, 7, (int)(x0 >> 6)), hi = win_hi(R, 7, (int)(x0 >> 6));
     if (lo >= hi) return;   // block-uniform
     for (int i = threadIdx.x; i < 2 * FAMW_SLOTS * 64; i += 256) (&a32[0][0][0])[i] = 0;
     for (int i = threadIdx.x; i < 2 * UVC_NFAMINFO64 * 64; i += 256) (&a64[0][0][0])[i] = 0ull;
@@ -2791,15 +2786,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     const int64_t x0 = (int64_t)xcd_block() * 64;
     if (x0 >= R.npos) return;
     const int w0 = R.beg + (int)x0;
-    int lo, hi;
-    {
-        int l = 0, h = R.n_generic_fs;
-        const int key = w0 - R.max_unit_span + 1;
-        while (l < h) { int m = (l + h) >> 1; if (R.fss[R.generic_sorted[m]].beg < key) l = m + 1; else h = m; }
-        lo = l; h = R.n_generic_fs;
-        while (l < h) { int m = (l + h) >> 1; if (R.fss[R.generic_sorted[m]].beg < w0 + 64) l = m + 1; else h = m; }
-        hi = l;
-    }
+    const int lo = win_lo(R, 7, (int)(x0 >> 6)), hi = win_hi(R, 7, (int)(x0 >> 6));
     if (lo >= hi) return;   // block-uniform
     for (int i = threadIdx.x; i < 2 * FAMW_SLOTS * 64; i += 256) (&a32[0][0][0])[i] = 0;
     for (int i = threadIdx.x; i < 2 * UVC_NFAMINFO64 * 64; i += 256) (&a64[0][0][0])[i] = 0ull;
@@ -3545,6 +3532,7 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
     {   // the window index of the alignment lists (the fragment list's follows k_fragstat_fast, which writes it)
         const int64_t n = 2 * (int64_t)R->nwin * 5;
         TIMED(prof, "k_win_index", hipLaunchKernelGGL(k_win_index, dim3(nblk(n, 256)), dim3(256), 0, s, *R, 0, 5));
+        if (R->n_generic_fs) hipLaunchKernelGGL(k_win_index, dim3(nblk(2 * (int64_t)R->nwin, 256)), dim3(256), 0, s, *R, 7, 8);
     }
     if (P->inferred_is_vcf_generated && R->n_fast) TIMED(prof, "k_prep_sums", hipLaunchKernelGGL(k_prep_sums, dim3(nblk(R->npos, PSUM_TILE)), dim3(256), 0, s, *R, *P));
     if (P->inferred_is_vcf_generated) {
