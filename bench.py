@@ -297,10 +297,23 @@ def main():
     pcie = resident = None
     if not args.no_extras:
         # (1) the same stream with the columns in pinned host memory: H2D of every column inside the step
-        pinned = []
+        # the columns move into page-locked memory of the library's own (uvcgpu_host_alloc = hipHostMalloc): a numpy array page-locked in place
+        # (uvcgpu_pin_host_buffer = hipHostRegister over 4 KiB heap pages) is copied at 29 GB/s on this box, library-owned memory at 57 GB/s
+        # (gpurun_out/trace_pcie, scripts/gpu_trace_pcie.sh) -- a binding that fills the UvcReadSoA columns anyway fills them there
+        pinned, host_bufs = [], []
+        lib.dll.uvcgpu_host_alloc.restype, lib.dll.uvcgpu_host_alloc.argtypes = C.c_int, [C.POINTER(C.c_void_p), C.c_int64]
+        lib.dll.uvcgpu_host_free.restype, lib.dll.uvcgpu_host_free.argtypes = C.c_int, [C.c_void_p]
         for t in tiles:
             for k in ("pos", "mpos", "isize", "flag", "mapq", "nm", "l_qseq", "seq_off", "cigar_off", "n_cigar", "frag_id", "fam_id", "fam_strand", "bases", "quals", "cigars"):
-                a = t[k] = np.ascontiguousarray(t[k])
+                a = np.ascontiguousarray(t[k])
+                hp = C.c_void_p()
+                if a.nbytes and not os.environ.get("UVC_BENCH_REGISTER") and lib.dll.uvcgpu_host_alloc(C.byref(hp), C.c_int64(a.nbytes)) == 0 and hp.value:
+                    host_bufs.append(hp)
+                    b = np.ctypeslib.as_array((C.c_uint8 * a.nbytes).from_address(hp.value)).view(a.dtype).reshape(a.shape)
+                    b[...] = a
+                    t[k] = b
+                    continue
+                t[k] = a
                 if a.nbytes and lib.dll.uvcgpu_pin_host_buffer(C.c_void_p(a.ctypes.data), C.c_int64(a.nbytes)) == 0:
                     pinned.append(a)
         n_extra = max(4, min(args.steps, 2 * T))
@@ -326,10 +339,16 @@ def main():
         torch.cuda.synchronize(); clock.barrier(); sdt = clock.max_over_ranks(time.perf_counter() - ts)
         pcie = {"value": clock.sum_over_ranks(float(region_len)) * n_extra / sdt, "unit": "positions/s", "ms_per_step": 1e3 * sdt / n_extra, "steps": n_extra,
                 "h2d_bytes_per_tile": input_bytes_tile, "tiles_in_flight": n_thr,
-                "note": "as `value`, but every tile's columns start in pinned host memory and uvcgpu_region_set_reads copies them first (H2D + set_reads + kernels + D2H per tile, "
+                "note": "as `value`, but every tile's columns start in page-locked host memory (uvcgpu_host_alloc) and uvcgpu_region_set_reads copies them first (H2D + set_reads + kernels + D2H per tile, "
                         "the unit of SURVEY 8d); %d tiles in flight on host threads so that one tile's copy runs under another's kernels; measured behind the timed region" % n_thr}
         for a in pinned:
             lib.dll.uvcgpu_unpin_host_buffer(C.c_void_p(a.ctypes.data))
+        torch.cuda.synchronize()
+        for t in tiles:   # the views die with their memory
+            for k in ("pos", "mpos", "isize", "flag", "mapq", "nm", "l_qseq", "seq_off", "cigar_off", "n_cigar", "frag_id", "fam_id", "fam_strand", "bases", "quals", "cigars"):
+                t[k] = None
+        for hp in host_bufs:
+            lib.dll.uvcgpu_host_free(hp)
         # (2) one prepared tile, accumulate + score again and again, nothing overlapped
         R = Rs[0]
         R.set_reads_device(dreads[0])
