@@ -317,7 +317,7 @@ def main():
                 if a.nbytes and lib.dll.uvcgpu_pin_host_buffer(C.c_void_p(a.ctypes.data), C.c_int64(a.nbytes)) == 0:
                     pinned.append(a)
         n_extra = max(4, min(args.steps, 2 * T))
-        n_thr = max(1, min(3, T))
+        n_thr = max(1, min(int(os.environ.get("UVC_BENCH_THREADS", "3")), T))
         import threading
         handle_locks = [threading.Lock() for _ in range(T)]
 
