@@ -93,6 +93,9 @@ void uvcio_tumor_vcf_close(uvcio_tumor_vcf_t *v);
 
 /* CRC-32 (the zlib / BGZF footer polynomial) as the reader and the writer compute it: carry-less multiplication on CPUs that have it. */
 uint32_t uvcio_crc32(const void *p, int64_t n);
+/* Test hook: one raw DEFLATE stream of known output size through the library's own decoder (uvc_inflate_fast.h), which the BGZF reader tries
+ * before zlib: 1 = decoded (out holds out_len bytes), 0 = declined (the reader would hand the block to zlib). */
+int uvcio_inflate_raw_fast(const void *in, int64_t in_len, void *out, int64_t out_len);
 
 /* ---- region shards ----
  * The reference balances its chunks by reads and positions (main.cpp:1380-1400).  Without reading the alignments the cost of a tile is

@@ -244,3 +244,48 @@ def test_crc32_equals_zlib():
     for n in list(range(1, 200)) + [255, 256, 1000, 4095, 4096, 0xff00, 0xff01, 100003]:
         b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
         assert dll.uvcio_crc32(b, n) == zlib.crc32(b), n
+
+
+def test_fast_inflate_equals_zlib_on_every_block_type():
+    """The library's own DEFLATE decoder (uvc_inflate_fast.h: what the BGZF reader tries before zlib) against zlib: stored, fixed and dynamic
+    blocks, every strategy and level, literal-heavy and match-heavy data, empty and one-byte streams, BGZF-sized blocks.  A stream it
+    declines is fine (the reader falls back); a stream it decodes must be byte-identical.  Corrupted streams must be declined or decoded
+    without touching memory outside the output."""
+    import ctypes
+    import zlib
+    dll = uio.dll()
+    f = dll.uvcio_inflate_raw_fast
+    f.restype, f.argtypes = ctypes.c_int, [ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64]
+    rng = np.random.default_rng(5)
+
+    def make(kind, n):
+        if kind == 0: return rng.integers(0, 256, n, dtype=np.uint8).tobytes()                       # incompressible
+        if kind == 1: return rng.choice(np.frombuffer(b"ACGT", np.uint8), n).tobytes()               # 2 bits per byte
+        if kind == 2: return (b"read_name_0123456789:" * (n // 21 + 1))[:n]                          # long matches
+        if kind == 3: return (rng.integers(0, 41, n, dtype=np.uint8) + 33).tobytes()                 # quality strings: literals
+        return b"\x00" * n                                                                           # one run
+    decoded = total = 0
+    for trial in range(120):
+        n = int(rng.choice([0, 1, 2, 7, 100, 1000, 5000, 20000, 65280]))
+        data = make(trial % 5, n)
+        for level in (0, 1, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED):
+                co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+                comp = co.compress(data) + co.flush()
+                out = ctypes.create_string_buffer(max(n, 1) + 16)
+                out.raw = b"\xAA" * (max(n, 1) + 16)
+                total += 1
+                if f(comp, len(comp), out, n):
+                    decoded += 1
+                    assert out.raw[:n] == data, (trial, n, level, strategy)
+                    assert out.raw[n:] == b"\xAA" * (len(out.raw) - n)                               # nothing behind the block
+    assert decoded == total                                                                          # zlib's own output: nothing to decline
+    for trial in range(400):                                                                         # bit flips: no crash, no overrun
+        data = make(trial % 5, int(rng.choice([100, 5000])))
+        comp = bytearray(zlib.compress(data, 6)[2:-4])
+        for _ in range(int(rng.integers(1, 5))):
+            comp[int(rng.integers(0, len(comp)))] ^= 1 << int(rng.integers(0, 8))
+        out = ctypes.create_string_buffer(len(data) + 16)
+        out.raw = b"\xAA" * (len(data) + 16)
+        f(bytes(comp), len(comp), out, len(data))
+        assert out.raw[len(data):] == b"\xAA" * 16

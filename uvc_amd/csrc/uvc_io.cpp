@@ -3,6 +3,7 @@
 // Host code only: it feeds the family assignment (include/uvcgroup.h) and uvcgpu_region_set_reads.
 #include "uvcio.h"
 #include "uvcgpu.h"
+#include "uvc_inflate_fast.h"
 
 #include <zlib.h>
 
@@ -22,6 +23,10 @@ static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 extern "C" const char *uvcio_last_error(void) { return g_err.c_str(); }
 namespace { uint32_t block_crc32(const uint8_t *p, size_t n); }
+// test entry: one raw DEFLATE stream of known output size through the fast decoder (1 = decoded, 0 = declined)
+extern "C" int uvcio_inflate_raw_fast(const void *in, int64_t in_len, void *out, int64_t out_len) {
+    return (in && out && in_len >= 0 && out_len >= 0 && uvc_fast_inflate::inflate((const uint8_t *)in, (size_t)in_len, (uint8_t *)out, (size_t)out_len)) ? 1 : 0;
+}
 extern "C" uint32_t uvcio_crc32(const void *p, int64_t n) { return (p && n > 0) ? block_crc32((const uint8_t *)p, (size_t)n) : 0u; }
 
 namespace {
@@ -272,12 +277,15 @@ uint32_t block_crc32(const uint8_t *p, size_t n) {
     const uint32_t c = ~crc32_fold(p, body, ~0u);
     return (n > body) ? (uint32_t)crc32(c, p + body, (uInt)(n - body)) : c;
 }
+const bool g_fast_inflate = (getenv("UVCIO_ZLIB") == nullptr);   // UVCIO_ZLIB=1: every block through zlib (A/B)
 bool inflate_block(const uint8_t *blk, uint32_t csize, uint8_t *dst, uint32_t isize) {
     const int xlen = le16(blk + 10);
     const uint8_t *cdata = blk + 12 + xlen;
     const int clen = (int)csize - xlen - 20;
     if (clen < 0) return false;
     if (isize == 0) return true;
+    // the decoder of uvc_inflate_fast.h first; zlib looks at whatever it declines or gets wrong (the CRC-32 of the block decides)
+    if (g_fast_inflate && uvc_fast_inflate::inflate(cdata, (size_t)clen, dst, isize) && block_crc32(dst, isize) == le32(blk + csize - 8)) return true;
     z_stream zs; memset(&zs, 0, sizeof(zs));
     if (inflateInit2(&zs, -15) != Z_OK) return false;
     zs.next_in = const_cast<uint8_t *>(cdata); zs.avail_in = (uInt)clen; zs.next_out = dst; zs.avail_out = isize;
