@@ -92,6 +92,10 @@ int uvcio_tumor_vcf_fetch(const uvcio_tumor_vcf_t *v, int32_t tid, int32_t pos_b
 void uvcio_tumor_vcf_close(uvcio_tumor_vcf_t *v);
 
 /* CRC-32 (the zlib / BGZF footer polynomial) as the reader and the writer compute it: carry-less multiplication on CPUs that have it. */
+/* Where the two large columns of a batch (UvcBamBatch::bases, ::quals) live: NULL, NULL = the C heap.  A caller that hands the batch to
+ * uvcgpu_region_set_reads passes page-locked memory of the GPU library here (wrappers of uvcgpu_host_alloc / uvcgpu_host_free), so that the
+ * 2 x 300 MB of a 1 Mb x 300x tile travel by DMA.  Set it before the first uvcio_bam_fetch; buffers are kept and grown per BAM handle. */
+void uvcio_set_column_allocator(void *(*alloc_fn)(size_t), void (*free_fn)(void *));
 uint32_t uvcio_crc32(const void *p, int64_t n);
 /* Test hook: one raw DEFLATE stream of known output size through the library's own decoder (uvc_inflate_fast.h), which the BGZF reader tries
  * before zlib: 1 = decoded (out holds out_len bytes), 0 = declined (the reader would hand the block to zlib). */

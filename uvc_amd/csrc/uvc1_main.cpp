@@ -291,6 +291,11 @@ int main(int argc, char **argv) {
         uvcgpu_params_apply_platform(&P, platform, readlen, maxmq);
     }
     uvcio_bam_close(bam0);
+    // UVC1_PINNED=1: the workers' base / quality columns live in page-locked memory of the GPU library from here on, so that set_reads copies
+    // them by DMA.  Off by default: on the boxes measured the files -> VCF rate did not move with it (scripts/bench_cli.py; the chain is not
+    // bound by that copy) and it locks ~ 800 MB of host memory per worker.
+    if (getenv("UVC1_PINNED"))
+        uvcio_set_column_allocator([](size_t n) -> void * { void *q = nullptr; return uvcgpu_host_alloc(&q, (int64_t)n) == 0 ? q : nullptr; }, [](void *q) { (void)uvcgpu_host_free(q); });
     // T/N: the tumor pass's records (rescue_variants_from_vcf, main.cpp:183-398)
     uvcio_tumor_vcf_t *tvcf = nullptr;
     if (!o.tumor_vcf.empty()) {

@@ -170,6 +170,46 @@ static bool inflate(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_l
             }
             if (!build(T.ll, (int)(sizeof(T.ll) / 4), LL_BITS, lens, 288, 0)) return false;
             { uint8_t dl[30] = { 0 }; memcpy(dl, lens + 288, (size_t)hdist); if (!build(T.d, (int)(sizeof(T.d) / 4), D_BITS, dl, 30, 1, type == 1)) return false; }
+            const uint32_t *const ll = T.ll, *const dt = T.d;
+            // Fast loop: while 16 input bytes and 3 literals + the longest match + the copy's overrun fit, nothing is bounds-checked per
+            // symbol, the refill has no branch, and the next table entry is fetched before the current literal is stored.
+            while (in_end - ip >= 16 && out_end - op >= 3 + 258 + 8) {
+                bb |= load64(ip) << bc; ip += (63 - bc) >> 3; bc |= 56;
+                uint32_t e = ll[bb & ((1 << LL_BITS) - 1)];
+                if ((e & 0x300) == 0 && (e & 0xFF)) {            // literal
+                    TAKE((int)(e & 0xFF)); const uint32_t e2 = ll[bb & ((1 << LL_BITS) - 1)]; *op++ = (uint8_t)(e >> 16);
+                    if ((e2 & 0x300) == 0 && (e2 & 0xFF)) {
+                        TAKE((int)(e2 & 0xFF)); const uint32_t e3 = ll[bb & ((1 << LL_BITS) - 1)]; *op++ = (uint8_t)(e2 >> 16);
+                        if ((e3 & 0x300) == 0 && (e3 & 0xFF)) { TAKE((int)(e3 & 0xFF)); *op++ = (uint8_t)(e3 >> 16); continue; }
+                        e = e3;
+                    } else e = e2;
+                    // >= 56 - 30 = 26 bits left: enough for a length code with its extra bits (20) or a sub-table walk (15)
+                }
+                if (((e >> 8) & 3) == K_SUB) { TAKE(LL_BITS); e = ll[(e >> 16) + (bb & ((1u << ((e >> 10) & 63)) - 1))]; }
+                const int l = (int)(e & 0xFF), kind = (int)((e >> 8) & 3);
+                if (!l) return false;
+                TAKE(l);
+                if (kind == K_LIT) { *op++ = (uint8_t)(e >> 16); continue; }   // (a literal with a code longer than the primary table)
+                if (kind == K_EOB) goto block_done;
+                const int xl = (int)((e >> 10) & 63);
+                const uint32_t len = (e >> 16) + (uint32_t)(bb & ((1u << xl) - 1));
+                TAKE(xl);
+                bb |= load64(ip) << bc; ip += (63 - bc) >> 3; bc |= 56;
+                uint32_t de = dt[bb & ((1 << D_BITS) - 1)];
+                if (((de >> 8) & 3) == K_SUB) { TAKE(D_BITS); de = dt[(de >> 16) + (bb & ((1u << ((de >> 10) & 63)) - 1))]; }
+                const int dl = (int)(de & 0xFF);
+                if (!dl) return false;
+                TAKE(dl);
+                const int dx = (int)((de >> 10) & 63);
+                const uint32_t dist = (de >> 16) + (uint32_t)(bb & ((1u << dx) - 1));
+                TAKE(dx);
+                if (dist > (size_t)(op - out)) return false;
+                const uint8_t *src = op - dist;
+                if (dist >= 8) { uint8_t *dst = op; uint8_t *const e8 = op + len; do { memcpy(dst, src, 8); dst += 8; src += 8; } while (dst < e8); }
+                else if (dist == 1) memset(op, *src, len);
+                else for (uint32_t i = 0; i < len; i++) op[i] = src[i];
+                op += len;
+            }
             for (;;) {
                 REFILL();
                 uint32_t e = T.ll[bb & ((1 << LL_BITS) - 1)];
@@ -212,6 +252,7 @@ static bool inflate(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_l
                 else for (uint32_t i = 0; i < len; i++) op[i] = src[i];
                 op += len;
             }
+            block_done:;
         } else return false;
         if (final) break;
     }

@@ -27,6 +27,8 @@ namespace { uint32_t block_crc32(const uint8_t *p, size_t n); }
 extern "C" int uvcio_inflate_raw_fast(const void *in, int64_t in_len, void *out, int64_t out_len) {
     return (in && out && in_len >= 0 && out_len >= 0 && uvc_fast_inflate::inflate((const uint8_t *)in, (size_t)in_len, (uint8_t *)out, (size_t)out_len)) ? 1 : 0;
 }
+namespace { extern void *(*g_col_alloc)(size_t); extern void (*g_col_free)(void *); }
+extern "C" void uvcio_set_column_allocator(void *(*alloc_fn)(size_t), void (*free_fn)(void *)) { g_col_alloc = alloc_fn; g_col_free = free_fn; }
 extern "C" uint32_t uvcio_crc32(const void *p, int64_t n) { return (p && n > 0) ? block_crc32((const uint8_t *)p, (size_t)n) : 0u; }
 
 namespace {
@@ -112,6 +114,30 @@ struct RawBuf {
     uint8_t *need(size_t n) { if (n > cap) { cap = n + n / 4 + 4096; p = (uint8_t *)realloc(p, cap); } return p; }
     ~RawBuf() { free(p); }
 };
+// The two large columns of a batch (one byte per base each) live in memory from the caller's allocator when one is set
+// (uvcio_set_column_allocator: uvc1-mi355x hands in uvcgpu_host_alloc, so that uvcgpu_region_set_reads copies them at DMA speed instead of
+// through the runtime's pageable staging path, which serialises the worker threads).  Grow-only, no value initialisation, contents kept.
+void *(*g_col_alloc)(size_t) = nullptr; void (*g_col_free)(void *) = nullptr;
+struct ColBuf {
+    uint8_t *p = nullptr; size_t n = 0, cap = 0; bool hooked = false;
+    uint8_t *data() { return p; }
+    size_t size() const { return n; }
+    void clear() { n = 0; }
+    void resize(size_t m) {
+        if (m > cap) {
+            const size_t ncap = m + m / 4 + 65536;
+            const bool use_hook = (g_col_alloc && g_col_free);
+            uint8_t *q = (uint8_t *)(use_hook ? g_col_alloc(ncap) : malloc(ncap));
+            if (!q) throw std::bad_alloc();
+            if (n) memcpy(q, p, n);
+            release();
+            p = q; cap = ncap; hooked = use_hook;
+        }
+        n = m;
+    }
+    void release() { if (p) { if (hooked) g_col_free(p); else free(p); } p = nullptr; cap = 0; }
+    ~ColBuf() { release(); }
+};
 struct Chunk { uint64_t beg, end; };
 struct RefIndex { std::map<uint32_t, std::vector<Chunk>> bins; std::vector<uint64_t> linear; };
 
@@ -138,7 +164,7 @@ struct uvcio_bam {
     std::vector<int32_t> tid, pos, endpos, mtid, mpos, isize, nm, l_qseq, n_cigar;
     std::vector<uint16_t> flag; std::vector<uint8_t> mapq;
     std::vector<int64_t> seq_off, cigar_off, qname_off;
-    std::vector<uint8_t> bases, quals; std::vector<uint32_t> cigars; std::vector<char> qnames;
+    ColBuf bases, quals; std::vector<uint32_t> cigars; std::vector<char> qnames;
     RawBuf comp, infl;             // compressed / inflated bytes of the current batch (kept between queries)
 };
 
