@@ -41,7 +41,7 @@ def record_bytes(tid, pos, qname, flag, mapq, cigar, bases, quals, mtid, mpos, t
     return struct.pack("<i", len(body)) + body, end
 
 
-def write_bam(path, refs, records, block_bytes=30000, with_index=True):
+def write_bam(path, refs, records, block_bytes=30000, with_index=True, packed=False):
     """refs: [(name, length)]; records: dicts with tid, pos, qname, flag, mapq, cigar, bases, quals, mtid, mpos, tlen, nm -- sorted by (tid, pos)"""
     text = ("@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)).encode()
     hdr = b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs)) + b"".join(struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", ln) for n, ln in refs)
@@ -56,9 +56,11 @@ def write_bam(path, refs, records, block_bytes=30000, with_index=True):
             out.extend(bgzf_block(bytes(cur))); cur = bytearray(); block_addr = len(out)
     for r in records:
         b, end = record_bytes(r["tid"], r["pos"], r["qname"], r["flag"], r["mapq"], r["cigar"], r["bases"], r["quals"], r.get("mtid", -1), r.get("mpos", -1), r.get("tlen", 0), r.get("nm"), r.get("aux", b""))
-        if len(cur) + len(b) > block_bytes: flush()
+        if not packed and len(cur) + len(b) > block_bytes: flush()   # htslib: a record never straddles two blocks (bgzf_flush_try)
         v0 = (block_addr << 16) | len(cur)
         cur.extend(b)
+        while packed and len(cur) >= block_bytes:                        # packed: blocks of exactly block_bytes, records straddle them
+            rest = cur[block_bytes:]; cur = cur[:block_bytes]; flush(); cur = rest
         v1 = (block_addr << 16) | len(cur)
         if r["tid"] >= 0:
             ix = index[r["tid"]]

@@ -22,6 +22,7 @@ def files(tmp_path_factory):
     refs = [("chrA", 5000), ("chr20", 200000)]
     bamwriter.write_bam(str(d / "t.bam"), refs, recs, block_bytes=20000)
     bamwriter.write_bam(str(d / "noidx.bam"), refs, recs, block_bytes=50000, with_index=False)
+    bamwriter.write_bam(str(d / "packed.bam"), refs, recs, block_bytes=3000, packed=True)   # records straddle the BGZF blocks (not what htslib writes)
     rng = np.random.default_rng(1)
     seqs = [("chrA", "".join("acgtN"[i] for i in rng.integers(0, 5, 5000))), ("chr20", "".join("ACGT"[i] for i in rng.integers(0, 4, 200000)))]
     bamwriter.write_fasta(str(d / "ref.fa"), seqs, width=70)
@@ -38,13 +39,19 @@ def expected(recs, tid, beg, end):
 
 
 @pytest.mark.parametrize("batch", [None, "65536", "70001"])
-@pytest.mark.parametrize("name", ["t.bam", "noidx.bam"])
-def test_fetch_equals_the_overlap_definition(files, name, batch, monkeypatch):
+@pytest.mark.parametrize("walk", ["blocks", "serial"])
+@pytest.mark.parametrize("name", ["t.bam", "noidx.bam", "packed.bam"])
+def test_fetch_equals_the_overlap_definition(files, name, batch, walk, monkeypatch):
+    """t.bam / noidx.bam: every BGZF block begins with a record (htslib's layout): the reader walks the blocks in parallel; packed.bam: records
+    straddle the blocks, the parallel walk notices and the sequential one takes over; UVCIO_SERIAL_WALK forces the sequential one."""
     d, refs, recs, _ = files
     if batch: monkeypatch.setenv("UVCIO_BATCH_BYTES", batch)     # several batches per query: records and blocks straddle them
     else: monkeypatch.delenv("UVCIO_BATCH_BYTES", raising=False)
+    if walk == "serial": monkeypatch.setenv("UVCIO_SERIAL_WALK", "1")
+    else: monkeypatch.delenv("UVCIO_SERIAL_WALK", raising=False)
+    monkeypatch.setenv("UVCIO_THREADS", "4")
     b = uio.Bam(str(d / name))
-    assert b.refs == refs and b.has_index == (name == "t.bam")
+    assert b.refs == refs and b.has_index == (name != "noidx.bam")
     for tid, beg, end in [(1, 100000, 140000), (1, 118000, 121000), (1, 0, 100001), (1, 139990, 200000), (0, 0, 5000), (0, 100, 101), (1, 16384 * 7, 16384 * 7 + 1), (1, 150000, 160000)]:
         got = b.fetch(tid, beg, end)
         want = expected(recs, tid, beg, end)

@@ -442,29 +442,90 @@ extern "C" int uvcio_bam_fetch(uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t
                 skip = 0;
                 if (hit_last) { const BlockRef &L = blocks.back(); if (L.addr == last_addr) hi = carry.size() + L.out_off + std::min<size_t>(last_u, L.isize); chunk_done = true; }
                 if (at_eof && o >= got - std::min<size_t>(got, 17)) chunk_done = true;   // end of file
-                // 3. sequential walk over the record sizes: which records overlap, where their outputs go
+                // 3. Which records overlap, where their outputs go.  The chain of record sizes is one dependent load per record through
+                // memory that other cores have just written (~100 ns each: as long as the parallel inflate when walked by one thread).
+                // htslib starts a new BGZF block rather than let a record straddle two (bgzf_flush_try in bam_write1), so in the files it
+                // wrote every block begins with a record: the blocks are walked in parallel, twice (sizes, then offsets).  A block whose
+                // walk does not end on its last byte disproves that for this file, and the batch is walked the sequential way.
                 recs.clear();
                 size_t p = lo;
                 int64_t nb = (int64_t)b->bases.size(), nc = (int64_t)b->cigars.size(), nq = (int64_t)b->qnames.size();
-                while (p + 4 <= hi) {
+                // one record at ibuf + q: 0 = behind the query (stop), 1 = skip, 2 = keep; sizes of a kept record in *e .. *ln
+                auto classify = [&](size_t q, uint32_t bs, int32_t *e_out, int32_t *lseq, int32_t *ncig, int32_t *ln, bool *bad) -> int {
+                    const uint8_t *r = ibuf + q + 4;
+                    const int32_t rt = (int32_t)le32(r), rp = (int32_t)le32(r + 4);
+                    const int l_name = r[8], n_cig = le16(r + 12); const int32_t l_seq = (int32_t)le32(r + 16);
+                    if (rt > tid || rt < 0 || (rt == tid && rp >= end)) return 0;
+                    if (rt != tid) return 1;
+                    const size_t o_cig = 32 + (size_t)l_name;
+                    if (l_seq < 0 || o_cig + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq > bs) { *bad = true; return 0; }
+                    int64_t e = rp;
+                    for (int k = 0; k < n_cig; k++) { const uint32_t cg = le32(r + o_cig + 4 * (size_t)k); const int op = (int)(cg & 0xF); if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) e += (int64_t)(cg >> 4); }
+                    if (e == rp) e = rp + 1;
+                    if (!(rp < end && e > beg)) return 1;
+                    *e_out = (int32_t)e; *lseq = l_seq; *ncig = n_cig; *ln = l_name + ((l_name == 0 || r[32 + l_name - 1] != 0) ? 1 : 0);
+                    return 2;
+                };
+                bool walked = false;
+                if (carry.empty() && blocks.size() >= 4 && n_threads() > 1 && !getenv("UVCIO_SERIAL_WALK")) {
+                    struct BlockWalk { size_t stop; int64_t n, sb, sc, sq; bool aligned, past, bad, size_bad; };
+                    const int32_t n_refs = (int32_t)b->ref_names.size();
+                    std::vector<BlockWalk> bw(blocks.size());
+                    auto walk_block = [&](size_t k, RecRef *dst, int64_t ob, int64_t oc, int64_t oq) {   // dst == nullptr: count only
+                        const size_t s0 = std::max(blocks[k].out_off, lo), e0 = std::min(blocks[k].out_off + (size_t)blocks[k].isize, hi);
+                        BlockWalk w = { s0, 0, 0, 0, 0, true, false, false, false };
+                        size_t q = s0;
+                        while (q + 4 <= e0) {
+                            const uint32_t bs = le32(ibuf + q);
+                            if (bs < 32 || bs > (1u << 28)) { w.size_bad = true; break; }
+                            if (q + 4 + bs > e0) break;
+                            {   // bytes that only look like a record (a block that does begin inside one) must not pass: what every record has
+                                const uint8_t *r = ibuf + q + 4;
+                                const int32_t rt = (int32_t)le32(r), rp = (int32_t)le32(r + 4); const int l_name = r[8];
+                                if (rt < -1 || rt >= n_refs || rp < -1 || l_name < 1 || 32 + (uint32_t)l_name > bs || r[32 + l_name - 1] != 0) { w.size_bad = true; break; }
+                            }
+                            int32_t e = 0, ls = 0, ncg = 0, ln = 0;
+                            const int c = classify(q, bs, &e, &ls, &ncg, &ln, &w.bad);
+                            if (c == 0) { w.past = !w.bad; break; }
+                            if (c == 2) {
+                                if (dst) dst[w.n] = RecRef{ ibuf + q + 4, bs, e, ob + w.sb, oc + w.sc, oq + w.sq };
+                                w.n++; w.sb += ls; w.sc += ncg; w.sq += ln;
+                            }
+                            q += 4 + bs;
+                        }
+                        w.stop = q;
+                        // the walk must end on the block's last byte (the last block of the query may end at the chunk's end instead)
+                        w.aligned = (w.past || w.bad || w.size_bad || q == e0 || s0 >= e0);
+                        if (!dst) bw[k] = w;
+                    };
+                    parallel_for(blocks.size(), [&](size_t k0, size_t k1) { for (size_t k = k0; k < k1; k++) walk_block(k, nullptr, 0, 0, 0); });
+                    bool all_aligned = true;
+                    for (size_t k = 0; k + 1 < blocks.size(); k++) if (!bw[k].aligned) { all_aligned = false; break; }   // (the last block may hold the first part of a record)
+                    for (const BlockWalk &w : bw) if (w.size_bad || w.bad) all_aligned = false;   // not records there: the sequential walk decides what the file is
+                    if (all_aligned) {
+                        // up to the first block that reaches the end of the query
+                        size_t k_end = blocks.size();
+                        for (size_t k = 0; k < blocks.size(); k++) {
+                            if (bw[k].past) { k_end = k + 1; past = true; break; }
+                        }
+                        std::vector<int64_t> off_n(k_end + 1, 0), off_b(k_end + 1, nb), off_c(k_end + 1, nc), off_q(k_end + 1, nq);
+                        for (size_t k = 0; k < k_end; k++) { off_n[k + 1] = off_n[k] + bw[k].n; off_b[k + 1] = off_b[k] + bw[k].sb; off_c[k + 1] = off_c[k] + bw[k].sc; off_q[k + 1] = off_q[k] + bw[k].sq; }
+                        recs.resize((size_t)off_n[k_end]);
+                        parallel_for(k_end, [&](size_t k0, size_t k1) { for (size_t k = k0; k < k1; k++) walk_block(k, recs.data() + off_n[k], off_b[k], off_c[k], off_q[k]); });
+                        nb = off_b[k_end]; nc = off_c[k_end]; nq = off_q[k_end];
+                        p = bw[k_end - 1].stop;
+                        walked = true;
+                    }
+                }
+                if (!walked) while (p + 4 <= hi) {
                     const uint32_t bs = le32(ibuf + p);
                     if (bs < 32 || bs > (1u << 28)) return fail(UVCGPU_EINVAL, "implausible BAM record size");
                     if (p + 4 + bs > hi) break;
-                    const uint8_t *r = ibuf + p + 4;
-                    const int32_t rt = (int32_t)le32(r), rp = (int32_t)le32(r + 4);
-                    const int l_name = r[8], n_cig = le16(r + 12); const int32_t l_seq = (int32_t)le32(r + 16);
-                    if (rt > tid || rt < 0 || (rt == tid && rp >= end)) { past = true; break; }
-                    if (rt == tid) {
-                        const size_t o_cig = 32 + (size_t)l_name;
-                        if (l_seq < 0 || o_cig + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq > bs) return fail(UVCGPU_EINVAL, "corrupt BAM record");
-                        int64_t e = rp;
-                        for (int k = 0; k < n_cig; k++) { const uint32_t cg = le32(r + o_cig + 4 * (size_t)k); const int op = (int)(cg & 0xF); if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) e += (int64_t)(cg >> 4); }
-                        if (e == rp) e = rp + 1;
-                        if (rp < end && e > beg) {
-                            recs.push_back(RecRef{ r, bs, (int32_t)e, nb, nc, nq });
-                            nb += l_seq; nc += n_cig; nq += l_name + ((l_name == 0 || r[32 + l_name - 1] != 0) ? 1 : 0);
-                        }
-                    }
+                    int32_t e = 0, ls = 0, ncg = 0, ln = 0; bool bad = false;
+                    const int c = classify(p, bs, &e, &ls, &ncg, &ln, &bad);
+                    if (bad) return fail(UVCGPU_EINVAL, "corrupt BAM record");
+                    if (c == 0) { past = true; break; }
+                    if (c == 2) { recs.push_back(RecRef{ ibuf + p + 4, bs, e, nb, nc, nq }); nb += ls; nc += ncg; nq += ln; }
                     p += 4 + bs;
                 }
                 t_walk += now() - t0; t0 = now();
