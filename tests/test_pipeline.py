@@ -140,6 +140,13 @@ def test_native_command_line_equals_the_python_chain(tmp_path, gpu_lib):
     r = subprocess.run([exe, bam, "-f", fa, "-o", out_b, "-s", "T1", "-R", bed, "-t", "2"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert gzip.open(out_b, "rt").read() == gzip.open(out_c, "rt").read()
+    # the reader's switches leave the output alone: zlib instead of the own DEFLATE decoder, the sequential record walk, base / quality columns
+    # in page-locked memory of the GPU library
+    for env in ({"UVCIO_ZLIB": "1", "UVCIO_SERIAL_WALK": "1"}, {"UVC1_PINNED": "1"}):
+        out_e = str(tmp_path / "e.vcf.gz")
+        r = subprocess.run([exe, bam, "-f", fa, "-o", out_e, "-s", "T1", "-R", bed, "-t", "2"], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
+        assert r.returncode == 0, r.stderr
+        assert gzip.open(out_e, "rt").read() == gzip.open(out_c, "rt").read(), env
     r = subprocess.run([exe, bam, "-f", fa, "-o", out_c, "--no-such-option"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "unknown option" in r.stderr
 
