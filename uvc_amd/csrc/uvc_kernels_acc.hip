@@ -684,10 +684,14 @@ __global__ void __launch_bounds__(256) k_prep_sums(RegionDev R, UvcParams P) {
     }
 }
 
+// SPLIT: a region with fewer windows than the chip has wave slots (a deep, short panel region: 200 kb are three waves per SIMD, each walking
+// thousands of reads) gives every window to a BLOCK: its four waves take every fourth chunk of the window's reads.  The kernel ends in
+// atomics anyway, so the partial sums need no reduction.
+template <bool SPLIT>
 __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
     __shared__ int2 prepq[4][PREPQ_CAP];
     const int lane = threadIdx.x & 63;
-    const int wave = wave_uniform((int)((xcd_block() * blockDim.x + threadIdx.x) >> 6));
+    const int wave = SPLIT ? wave_uniform((int)xcd_block()) : wave_uniform((int)((xcd_block() * blockDim.x + threadIdx.x) >> 6));
     const int64_t x0 = (int64_t)wave * 64;
     if (x0 >= R.npos) return;
     const int w0 = R.beg + (int)x0;
@@ -715,7 +719,7 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
         }
         nq = 0;
     };
-    for (int k0 = lo; k0 < hi; k0 += 64) {
+    for (int k0 = lo + (SPLIT ? 64 * (int)(threadIdx.x >> 6) : 0); k0 < hi; k0 += (SPLIT ? 256 : 64)) {
         Chunk16 c;
         load_chunk16(R.frec, k0 + lane, hi, c);
         const int n = imin(64, hi - k0);
@@ -999,8 +1003,13 @@ DEV void mis_apply(const RegionDev &R, const UvcParams &P, const MisItem &it) {
 // ------------------------------------------------------------------------------------------------
 // Two instantiations, <true,false> for LINK_M and <false,true> for the read bases: each keeps one SegAcc in registers,
 // which halves the accumulator footprint and doubles the waves per SIMD.
-template <bool DO_L, bool DO_B, bool PLAIN>
-DEV void p2_fast_body(const RegionDev &R, const UvcParams &P, int *amp1, int *amp2, MisItem (*misq)[DO_B ? MISQ_CAP : 1]) {
+// SPLIT (see k_prep_fast): a block per window, its four waves take every fourth chunk of the window's entries; their counters are added up
+// in LDS (red: one slot per counter and lane) and stored by the four waves together.
+#define P2_RED_SLOTS (UVC_NSEG32 + 2 * UVC_NSEG64 + 5)
+// the 64-bit counter f of the LDS reduction area: two int rows of 64 = one row of 64 unsigned long long
+DEV unsigned long long *red64(int (*red)[64], int f) { return (unsigned long long *)&red[UVC_NSEG32 + 2 * f][0]; }
+template <bool DO_L, bool DO_B, bool PLAIN, bool SPLIT = false>
+DEV void p2_fast_body(const RegionDev &R, const UvcParams &P, int *amp1, int *amp2, MisItem (*misq)[DO_B ? MISQ_CAP : 1], int (*red)[64] = nullptr) {
     COARSE_T(ct0)
     {
         const int v = threadIdx.x;
@@ -1009,9 +1018,10 @@ DEV void p2_fast_body(const RegionDev &R, const UvcParams &P, int *amp1, int *am
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int wave = wave_uniform((int)((xcd_block() * blockDim.x + threadIdx.x) >> 6));
+    const int wave = SPLIT ? wave_uniform((int)xcd_block()) : wave_uniform((int)((xcd_block() * blockDim.x + threadIdx.x) >> 6));
     const int64_t x0 = (int64_t)wave * 64;
-    if (x0 >= R.npos) return;
+    if (x0 >= R.npos) return;   // (block-uniform in the split form)
+    if (SPLIT) { for (int i2 = threadIdx.x; i2 < P2_RED_SLOTS * 64; i2 += 256) (&red[0][0])[i2] = 0; __syncthreads(); }
     const int w0 = R.beg + (int)x0;
     const int p = w0 + lane;
     const int64_t x = x0 + lane;
@@ -1045,7 +1055,7 @@ DEV void p2_fast_body(const RegionDev &R, const UvcParams &P, int *amp1, int *am
     auto run_list = [&](auto IS, auto ST, int cls) {
     constexpr bool ISRC = decltype(IS)::value, STRAND = decltype(ST)::value;
     const int lo = wave_uniform(win_lo(R, 1 + cls, (int)(x0 >> 6))), hi = wave_uniform(win_hi(R, 1 + cls, (int)(x0 >> 6)));
-    for (int k0 = lo; k0 < hi; k0 += 64) {
+    for (int k0 = lo + (SPLIT ? 64 * (int)(threadIdx.x >> 6) : 0); k0 < hi; k0 += (SPLIT ? 256 : 64)) {
         Chunk16 c;
         load_chunk16(R.frec2, k0 + lane, hi, c);
         const int n = imin(64, hi - k0);
@@ -1111,6 +1121,32 @@ DEV void p2_fast_body(const RegionDev &R, const UvcParams &P, int *amp1, int *am
     run_list(std::true_type{}, std::true_type{}, 3);
     if (DO_B && nq > 0) flush_queue();
     COARSE_T(ct2)
+    if (SPLIT) {   // the four partial sets -> LDS -> one set (the two passes own different symbols: one symbol per kernel)
+        const SegAcc &A = (DO_B ? Aref : Alink);
+#pragma unroll
+        for (int f = 0; f < UVC_NSEG32; f++) if (A.s[f]) atomicAdd(&red[f][lane], A.s[f]);
+#pragma unroll
+        for (int f = 0; f < UVC_NSEG64; f++) if (A.l[f]) atomicAdd(&red64(red, f)[lane], (unsigned long long)A.l[f]);
+        if (A.a1BQf) atomicAdd(&red[UVC_NSEG32 + 2 * UVC_NSEG64 + 0][lane], A.a1BQf);
+        if (A.a1BQr) atomicAdd(&red[UVC_NSEG32 + 2 * UVC_NSEG64 + 1][lane], A.a1BQr);
+        if (A.a2BQf) atomicAdd(&red[UVC_NSEG32 + 2 * UVC_NSEG64 + 2][lane], A.a2BQf);
+        if (A.a2BQr) atomicAdd(&red[UVC_NSEG32 + 2 * UVC_NSEG64 + 3][lane], A.a2BQr);
+        if (A.bq) atomicAdd(&red[UVC_NSEG32 + 2 * UVC_NSEG64 + 4][lane], A.bq);
+        __syncthreads();
+        if (!valid) return;
+        const int sym = (DO_B ? my_ref : UVC_LINK_M), wv = (int)(threadIdx.x >> 6);
+        for (int f = wv; f < UVC_NSEG32; f += 4) { const int v = red[f][lane]; if (v) S32(R, f, sym, x) = v; }
+        for (int f = wv; f < UVC_NSEG64; f += 4) { const long long v = (long long)red64(red, f)[lane]; if (v) S64(R, f, sym, x) = v; }
+        if (wv == 0) {
+            const int b0 = UVC_NSEG32 + 2 * UVC_NSEG64;
+            if (red[b0][lane]) VQP(R, UVC_VQ_a1BQf, sym, x) = red[b0][lane];
+            if (red[b0 + 1][lane]) VQP(R, UVC_VQ_a1BQr, sym, x) = red[b0 + 1][lane];
+            if (red[b0 + 2][lane]) VQP(R, UVC_VQ_a2BQf, sym, x) = red[b0 + 2][lane];
+            if (red[b0 + 3][lane]) VQP(R, UVC_VQ_a2BQr, sym, x) = red[b0 + 3][lane];
+            if (red[b0 + 4][lane]) BQS(R, sym, x) = red[b0 + 4][lane];
+        }
+        return;
+    }
     if (!valid) return;
     // k_p2_fast runs before every other writer of these planes (k_p2_mism, k_p2_items), and the two instantiations own
     // different symbols: plain stores
@@ -1127,6 +1163,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) k
     __shared__ int amp1[256], amp2[256];
     __shared__ MisItem misq[DO_B ? 4 : 1][DO_B ? MISQ_CAP : 1];
     p2_fast_body<DO_L, DO_B, PLAIN>(R, P, amp1, amp2, misq);
+}
+template <bool DO_L, bool DO_B, bool PLAIN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_p2_fast_split(RegionDev R, UvcParams P) {
+    __shared__ int amp1[256], amp2[256];
+    __shared__ MisItem misq[DO_B ? 4 : 1][DO_B ? MISQ_CAP : 1];
+    __shared__ __attribute__((aligned(8))) int red[P2_RED_SLOTS][64];
+    p2_fast_body<DO_L, DO_B, PLAIN, true>(R, P, amp1, amp2, misq, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3526,6 +3569,9 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
                                       const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof,
                                       hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join, hipEvent_t e_fork2, hipStream_t side3, hipEvent_t e_join3) {
     const unsigned nwin = nblk(R->npos, 256);   // 4 waves x 64 positions per block
+    // fewer windows than four per SIMD: a block per window in the kernels that can share a window's reads among its waves (UVCGPU_SPLIT=0 / 1 forces)
+    const char *sp_env = getenv("UVCGPU_SPLIT");
+    const bool split_windows = sp_env ? (atoi(sp_env) != 0) : (R->nwin < 4 * 1024);
     if (prof) prof->n = 0;
     hipStream_t s2 = (side ? side : s);
     hipStream_t s3 = ((side && side3) ? side3 : s2);   // the two CIGAR walks of the InDel reads are independent, one wave per 64 reads and long: a stream each
@@ -3540,7 +3586,8 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
         if (side && R->n_complex) { hipEventRecord(e_fork, s); hipStreamWaitEvent(s2, e_fork, 0); }
         if (R->n_complex) TIMED2(prof, "k_prep_slow", hipLaunchKernelGGL(k_prep_slow, dim3(R->n_complex), dim3(64), 0, s, *R, *P));
         if (side && R->n_complex) hipEventRecord(e_join, s2);
-        TIMED(prof, "k_prep_fast", hipLaunchKernelGGL(k_prep_fast, dim3(nwin), dim3(256), 0, s, *R, *P));
+        if (split_windows) TIMED(prof, "k_prep_fast", hipLaunchKernelGGL(k_prep_fast<true>, dim3(R->nwin), dim3(256), 0, s, *R, *P));
+        else TIMED(prof, "k_prep_fast", hipLaunchKernelGGL(k_prep_fast<false>, dim3(nwin), dim3(256), 0, s, *R, *P));
         if (side && R->n_complex) hipStreamWaitEvent(s, e_join, 0);
     }
     // P1b is part of updateByAlns3UsingBQ too (main.hpp:3691-3702): on a FASTQ-only run the thresholds stay zero and rtr.indelphred unedited
@@ -3562,11 +3609,15 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
     if (P->inferred_is_vcf_generated) {
         // no IonTorrent values, no amplicon-flagged family, no primer length: the specialisation without those arms
         const bool plain = (UVC_PLATFORM_IONTORRENT != P->inferred_sequencing_platform) && !R->any_amplicon && !(P->primerlen > 0 && !(0x2 & P->primer_flag));
-        if (plain) TIMED(prof, "k_p2_fast_base", hipLaunchKernelGGL((k_p2_fast<false, true, true>), dim3(nwin), dim3(256), 0, s, *R, *P));
+        if (split_windows && plain) TIMED(prof, "k_p2_fast_base", hipLaunchKernelGGL((k_p2_fast_split<false, true, true>), dim3(R->nwin), dim3(256), 0, s, *R, *P));
+        else if (split_windows) TIMED(prof, "k_p2_fast_base", hipLaunchKernelGGL((k_p2_fast_split<false, true, false>), dim3(R->nwin), dim3(256), 0, s, *R, *P));
+        else if (plain) TIMED(prof, "k_p2_fast_base", hipLaunchKernelGGL((k_p2_fast<false, true, true>), dim3(nwin), dim3(256), 0, s, *R, *P));
         else TIMED(prof, "k_p2_fast_base", hipLaunchKernelGGL((k_p2_fast<false, true, false>), dim3(nwin), dim3(256), 0, s, *R, *P));
         if (side) { hipEventRecord(e_fork2, s); hipStreamWaitEvent(s3, e_fork2, 0); }
         TIMED3(prof, "k_p2_mism", hipLaunchKernelGGL(k_p2_mism, dim3(2048), dim3(256), 0, s, *R, *P));
-        if (plain) TIMED(prof, "k_p2_fast_link", hipLaunchKernelGGL((k_p2_fast<true, false, true>), dim3(nwin), dim3(256), 0, s, *R, *P));
+        if (split_windows && plain) TIMED(prof, "k_p2_fast_link", hipLaunchKernelGGL((k_p2_fast_split<true, false, true>), dim3(R->nwin), dim3(256), 0, s, *R, *P));
+        else if (split_windows) TIMED(prof, "k_p2_fast_link", hipLaunchKernelGGL((k_p2_fast_split<true, false, false>), dim3(R->nwin), dim3(256), 0, s, *R, *P));
+        else if (plain) TIMED(prof, "k_p2_fast_link", hipLaunchKernelGGL((k_p2_fast<true, false, true>), dim3(nwin), dim3(256), 0, s, *R, *P));
         else TIMED(prof, "k_p2_fast_link", hipLaunchKernelGGL((k_p2_fast<true, false, false>), dim3(nwin), dim3(256), 0, s, *R, *P));
     }
     if (side) {
