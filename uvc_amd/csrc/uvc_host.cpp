@@ -30,7 +30,7 @@ extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const 
 struct UvcProf { int on; int n; const char *name[24]; hipEvent_t ev[24][2]; };
 extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, int half_ratio_phred,
                                       const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof,
-                                      hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join, hipEvent_t e_fork2, hipStream_t side3, hipEvent_t e_join3);
+                                      hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join, hipEvent_t e_fork2, hipStream_t side3, hipEvent_t e_join3, hipEvent_t e_stat, hipEvent_t e_alleles);
 extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles, const int32_t *d_allele_rows, int64_t n_alleles,
                                 const UvcGapRow *d_gap_rows, const uint8_t *d_gap_seq, const UvcTumorKey *d_tkeys, int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch, int32_t *d_fields_kept, hipStream_t s);
 extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored);
@@ -70,7 +70,7 @@ struct uvcgpu_region {
     std::string refstring;
     std::vector<int32_t> h_rtr;   // host copy of the repeat tracks as built (the record writer reads begpos / tracklen / unitlen)
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr, side3 = nullptr; hipEvent_t e_fork = nullptr, e_join = nullptr, e_fork2 = nullptr, e_join3 = nullptr;   // fork/join inside accumulate (see uvc_launch_accumulate)
+    hipStream_t side = nullptr, side3 = nullptr; hipEvent_t e_fork = nullptr, e_join = nullptr, e_fork2 = nullptr, e_join3 = nullptr, e_stat = nullptr, e_alleles = nullptr;   // fork/join inside accumulate (see uvc_launch_accumulate)
     // device buffers
     uint8_t *d_refsym = nullptr; int32_t *d_rtr = nullptr, *d_rtr0 = nullptr, *d_fsum = nullptr, *d_win = nullptr; int64_t *d_baq = nullptr;
     char *d_state = nullptr; size_t state_bytes = 0;
@@ -343,7 +343,7 @@ static int uvcgpu_region_create_impl(uvcgpu_region_t **out, const UvcParams *par
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess) { delete r; return fail(UVCGPU_EDEVICE, "hipStreamCreate failed (no GPU?)"); }
     // UVCGPU_ONE_STREAM=1 (diagnosis): no side streams, every kernel of a handle runs alone, so that UVCGPU_TIMING shows undisturbed durations
     if (getenv("UVCGPU_ONE_STREAM")) { /* side stays null: uvc_launch_accumulate and score run everything on the main stream */ }
-    else if (hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&r->side3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&r->e_join3, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_fork2, hipEventDisableTiming) != hipSuccess) {
+    else if (hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&r->side3, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&r->e_join3, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_stat, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_alleles, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&r->e_fork2, hipEventDisableTiming) != hipSuccess) {
         uvcgpu_region_destroy(r); return fail(UVCGPU_EDEVICE, "hipStreamCreate / hipEventCreate failed");
     }
     if (hipMalloc((void **)&r->R.err, 4) != hipSuccess) { uvcgpu_region_destroy(r); return fail(UVCGPU_ENOMEM, "hipMalloc failed"); }
@@ -564,7 +564,7 @@ static int uvcgpu_region_accumulate_impl(uvcgpu_region_t *r) {
         // rows were set to 0xFF in set_reads and k_p2_slow<false> is idempotent under MAX, so no reset is needed
     }
     const int half = (int)std::round((10.0 / std::log(10.0)) * std::log(r->P.indel_del_to_ins_err_ratio)) / 2;   // main.hpp:1244
-    uvc_launch_accumulate(&r->R, &r->P, half, r->d_dup_units, r->n_dup, r->d_dup_off, r->n_dup_work, r->stream, &r->prof, r->side, r->e_fork, r->e_join, r->e_fork2, r->side3, r->e_join3);
+    uvc_launch_accumulate(&r->R, &r->P, half, r->d_dup_units, r->n_dup, r->d_dup_off, r->n_dup_work, r->stream, &r->prof, r->side, r->e_fork, r->e_join, r->e_fork2, r->side3, r->e_join3, r->e_stat, r->e_alleles);
     HIP_OK(hipGetLastError());
     r->buckets_clean = (r->P.inferred_is_vcf_generated != 0);   // k_frag (P3b) and k_p5b cleared every bucket they consumed
     r->accumulated = true; r->gap_ready = false; r->hap_ready = false;
@@ -1054,6 +1054,8 @@ void uvcgpu_region_destroy(uvcgpu_region_t *r) {
     if (r->side) hipStreamDestroy(r->side);
     if (r->side3) hipStreamDestroy(r->side3);
     if (r->e_join3) hipEventDestroy(r->e_join3);
+    if (r->e_stat) hipEventDestroy(r->e_stat);
+    if (r->e_alleles) hipEventDestroy(r->e_alleles);
     if (r->e_fork) hipEventDestroy(r->e_fork);
     if (r->e_join) hipEventDestroy(r->e_join);
     if (r->e_fork2) hipEventDestroy(r->e_fork2);

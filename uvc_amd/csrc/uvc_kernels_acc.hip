@@ -1844,17 +1844,21 @@ __global__ void __launch_bounds__(64) k_frag_generic(RegionDev R, UvcParams P, c
 // H16: no position is covered by 65 536 fragments or more (host bound, RegionDev::max_frag_depth), so two buckets share one LDS word:
 // 16 KiB per block instead of 32, six waves per SIMD instead of five.
 #define RQ_CAP 128   // events per wave between two flushes (one record adds at most 64)
-template <bool PLAIN, bool H16>
-DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUCKETS / (H16 ? 2 : 1)][256], unsigned long long (*rq)[RQ_CAP], int (*lacc)[256]) {
+// SPLIT (see k_prep_fast): a block per window.  The four waves take every fourth chunk of the window's fragments and add into ONE set of LDS
+// columns (bucket histogram, lacc, racc: a column per position, LDS atomics); behind the lists wave 0 alone holds the sums and runs the rest.
+template <bool PLAIN, bool H16, bool SPLIT = false>
+DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUCKETS / (H16 ? 2 : 1)][SPLIT ? 64 : 256], unsigned long long (*rq)[RQ_CAP], int (*lacc)[SPLIT ? 64 : 256], int (*racc)[64] = nullptr) {
+    const int col = (SPLIT ? (int)(threadIdx.x & 63) : (int)threadIdx.x);   // this thread's column of the LDS arrays
     auto hist_add = [&](int dense, int b) {   // ds_add_u32 without return
-        if (H16) atomicAdd(&hist[dense][b >> 1][threadIdx.x], 1u << (16 * (b & 1))); else atomicAdd(&hist[dense][b][threadIdx.x], 1u);
+        if (H16) atomicAdd(&hist[dense][b >> 1][col], 1u << (16 * (b & 1))); else atomicAdd(&hist[dense][b][col], 1u);
     };
     auto hist_get = [&](int dense, int b) -> int {
-        return H16 ? (int)((hist[dense][b >> 1][threadIdx.x] >> (16 * (b & 1))) & 0xFFFFu) : (int)hist[dense][b][threadIdx.x];
+        return H16 ? (int)((hist[dense][b >> 1][col] >> (16 * (b & 1))) & 0xFFFFu) : (int)hist[dense][b][col];
     };
     COARSE_T(ct0)
     const int lane = threadIdx.x & 63;
-    const int wave = wave_uniform((int)((xcd_block() * blockDim.x + threadIdx.x) >> 6));
+    const int wave = SPLIT ? wave_uniform((int)xcd_block()) : wave_uniform((int)((xcd_block() * blockDim.x + threadIdx.x) >> 6));
+    const int wv = (int)(threadIdx.x >> 6);
     const int64_t x0 = (int64_t)wave * 64;
     if (x0 >= R.npos) return;
     const int w0 = R.beg + (int)x0;
@@ -1865,8 +1869,12 @@ DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUC
     const bool padded_ignored = (PLAIN ? false : ((P.microadjust_padded_deletion_flag & (proton ? 0x2 : 0x1)) != 0));
     const bool vcfgen = (PLAIN ? true : (P.inferred_is_vcf_generated != 0));   // P3 belongs to updateByAlns3UsingBQ, skipped on FASTQ-only runs (main.hpp:3691)
     const int my_ref = valid ? R.refsym[x] : 0;
-    for (int b = 0; b < NBUCKETS / (H16 ? 2 : 1); b++) { hist[0][b][threadIdx.x] = 0; hist[1][b][threadIdx.x] = 0; }
-    for (int i = 0; i < 5; i++) lacc[i][threadIdx.x] = 0;
+    if (!SPLIT || wv == 0) {
+        for (int b = 0; b < NBUCKETS / (H16 ? 2 : 1); b++) { hist[0][b][col] = 0; hist[1][b][col] = 0; }
+        for (int i = 0; i < (SPLIT ? 10 : 5); i++) lacc[i][col] = 0;
+        if (SPLIT) for (int i = 0; i < 11; i++) racc[i][col] = 0;
+    }
+    if (SPLIT) __syncthreads();   // (block-uniform: the four waves share the window)
     // avgBQ + 8 (get_avgBQ, main_conversion.hpp:791-796) of the five read symbols and of LINK_M; LINK_M value of a simple read here
     auto maxq_at = [&](int sym) {
         const int ad = S32(R, UVC_S_aDPff, sym, x) + S32(R, UVC_S_aDPfr, sym, x) + S32(R, UVC_S_aDPrf, sym, x) + S32(R, UVC_S_aDPrr, sym, x);
@@ -1966,17 +1974,18 @@ DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUC
             if (!PLAIN && (0x1 & P.fam_flag)) phredlike = imin(phredlike, sscs_phred(P, my_ref, UVC_LINK_M));
             const int pbucket = imax(0, maxq_link - phredlike);
             if (pbucket < NBUCKETS) hist_add(1, pbucket);
-            atomicAdd(&lacc[0][threadIdx.x], 1); atomicAdd(&lacc[1][threadIdx.x], K(13)); atomicAdd(&lacc[2][threadIdx.x], K(14)); atomicAdd(&lacc[3][threadIdx.x], K(12));
+            const int lr = (SPLIT ? 5 * strand : 0);
+            atomicAdd(&lacc[lr + 0][col], 1); atomicAdd(&lacc[lr + 1][col], K(13)); atomicAdd(&lacc[lr + 2][col], K(14)); atomicAdd(&lacc[lr + 3][col], K(12));
         }
-        if (singleton) atomicAdd(&lacc[4][threadIdx.x], 1);
+        if (singleton) atomicAdd(&lacc[(SPLIT ? 5 * strand : 0) + 4][col], 1);
     };
     auto maxq_generic = [&](int cs) { return cs == UVC_LINK_M ? maxq_link : (cs <= UVC_BASE_N ? maxq_base(cs) : maxq_at(cs)); };
     const __amdgpu_buffer_rsrc_t rs = bq_rsrc(R);
     auto run_list = [&](auto ST, DAcc &ar) {
     constexpr int strand = decltype(ST)::value ? 1 : 0;
     const int lo = wave_uniform(win_lo(R, 5 + strand, (int)(x0 >> 6))), hi = wave_uniform(win_hi(R, 5 + strand, (int)(x0 >> 6)));
-    for (int k0 = lo; k0 < hi; k0 += 64) {
-            // one FragFast (24 dwords) per lane, fields of record j broadcast with v_readlane; base/qual bytes of record j+1 are
+    for (int k0 = lo + (SPLIT ? 64 * wv : 0); k0 < hi; k0 += (SPLIT ? 256 : 64)) {
+        // one FragFast (24 dwords) per lane, fields of record j broadcast with v_readlane; base/qual bytes of record j+1 are
         // requested before record j is processed
         int c[24];
         if (k0 + lane < hi) {
@@ -2070,21 +2079,33 @@ DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUC
     COARSE_T(ct1)
     // LINK_M sums of the fragments outside the interval sums, strand by strand: plain read-modify-write (these cells are this lane's)
     auto lacc_out = [&](int strand) {
-        const int n = lacc[0][threadIdx.x], ta = lacc[1][threadIdx.x], tb = lacc[2][threadIdx.x], mq = lacc[3][threadIdx.x], sg = lacc[4][threadIdx.x];
+        const int lr = (SPLIT ? 5 * strand : 0);
+        const int n = lacc[lr + 0][col], ta = lacc[lr + 1][col], tb = lacc[lr + 2][col], mq = lacc[lr + 3][col], sg = lacc[lr + 4][col];
         if (valid && (n | sg)) {
             const int v0 = FRP(R, strand, UVC_FRAG_bDP, UVC_LINK_M, x), v1 = FRP(R, strand, UVC_FRAG_bTA, UVC_LINK_M, x), v2 = FRP(R, strand, UVC_FRAG_bTB, UVC_LINK_M, x);
             const int v3 = VQP(R, UVC_VQ_bMQ, UVC_LINK_M, x), v4 = FAP(R, strand, UVC_FAM_cDP12, UVC_LINK_M, x), v5 = FAP(R, strand, UVC_FAM_cDP21, UVC_LINK_M, x), v6 = FAP(R, strand, UVC_FAM_cDP1, UVC_LINK_M, x);
             if (n) { FRP(R, strand, UVC_FRAG_bDP, UVC_LINK_M, x) = v0 + n; FRP(R, strand, UVC_FRAG_bTA, UVC_LINK_M, x) = v1 + ta; FRP(R, strand, UVC_FRAG_bTB, UVC_LINK_M, x) = v2 + tb; VQP(R, UVC_VQ_bMQ, UVC_LINK_M, x) = v3 + mq; }
             if (sg) { FAP(R, strand, UVC_FAM_cDP12, UVC_LINK_M, x) = v4 + sg; FAP(R, strand, UVC_FAM_cDP21, UVC_LINK_M, x) = v5 + sg; if (vcfgen) FAP(R, strand, UVC_FAM_cDP1, UVC_LINK_M, x) = v6 + sg; }
         }
-#pragma unroll
-        for (int i = 0; i < 5; i++) lacc[i][threadIdx.x] = 0;
+        if (!SPLIT) { for (int i = 0; i < 5; i++) lacc[i][col] = 0; }
     };
     run_list(std::false_type{}, a_fr);
-    lacc_out(0);
+    if (!SPLIT) lacc_out(0);
     run_list(std::true_type{}, a_rr);
-    lacc_out(1);
+    if (!SPLIT) lacc_out(1);
     if (nq > 0) flush_events();
+    if (SPLIT) {
+        // the partial sums of the four waves -> racc; every wave's adds to the planes must have reached the L2 before wave 0 reads them back
+        const int part[11] = { a_fr.bDP, a_fr.bTA, a_fr.bTB, a_fr.c12, a_fr.c1, a_rr.bDP, a_rr.bTA, a_rr.bTB, a_rr.c12, a_rr.c1, bMQ_r };
+#pragma unroll
+        for (int i = 0; i < 11; i++) if (part[i]) atomicAdd(&racc[i][col], part[i]);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __syncthreads();
+        if (wv != 0) return;
+        a_fr.bDP = racc[0][col]; a_fr.bTA = racc[1][col]; a_fr.bTB = racc[2][col]; a_fr.c12 = racc[3][col]; a_fr.c1 = racc[4][col];
+        a_rr.bDP = racc[5][col]; a_rr.bTA = racc[6][col]; a_rr.bTB = racc[7][col]; a_rr.c12 = racc[8][col]; a_rr.c1 = racc[9][col]; bMQ_r = racc[10][col];
+        lacc_out(0); lacc_out(1);
+    }
     COARSE_T(ct2)
     if (!valid) return;
     // the adds above must have reached the L2 before the planes are read back (they pass through this CU's L1, which drops its copy of the line)
@@ -2119,7 +2140,7 @@ DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUC
             int phredlike = imin(lv, maxq_link);
             if (!PLAIN && (0x1 & P.fam_flag)) phredlike = imin(phredlike, sscs_phred(P, my_ref, UVC_LINK_M));
             const int b = imax(0, maxq_link - phredlike);
-            if (b < NBUCKETS) { if (H16) hist[1][b >> 1][threadIdx.x] += (unsigned)lcnt[e] << (16 * (b & 1)); else hist[1][b][threadIdx.x] += (unsigned)lcnt[e]; }
+            if (b < NBUCKETS) { if (H16) hist[1][b >> 1][col] += (unsigned)lcnt[e] << (16 * (b & 1)); else hist[1][b][col] += (unsigned)lcnt[e]; }
         }
     }
     // ---- the rest reads and writes this position's planes.  A read-modify-write per counter, one after the other, costs a memory round
@@ -2216,6 +2237,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,5)))
     __shared__ unsigned long long rq[4][RQ_CAP];
     __shared__ int lacc[5][256];
     frag_body<PLAIN, false>(R, P, hist, rq, lacc);
+}
+template <bool PLAIN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5,6))) k_frag16_split(RegionDev R, UvcParams P) {
+    __shared__ unsigned hist[2][NBUCKETS / 2][64];
+    __shared__ unsigned long long rq[4][RQ_CAP];
+    __shared__ int lacc[10][64];
+    __shared__ int racc[11][64];
+    frag_body<PLAIN, true, true>(R, P, hist, rq, lacc, racc);
 }
 template <bool PLAIN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6,6))) k_frag16(RegionDev R, UvcParams P) {
@@ -3567,7 +3596,7 @@ extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const 
 #define TIMED3(prof, kname, ...) do { hipStream_t s = s3; TIMED(prof, kname, __VA_ARGS__); } while (0)
 extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, int half_ratio_phred,
                                       const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof,
-                                      hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join, hipEvent_t e_fork2, hipStream_t side3, hipEvent_t e_join3) {
+                                      hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join, hipEvent_t e_fork2, hipStream_t side3, hipEvent_t e_join3, hipEvent_t e_stat, hipEvent_t e_alleles) {
     const unsigned nwin = nblk(R->npos, 256);   // 4 waves x 64 positions per block
     // fewer windows than four per SIMD: a block per window in the kernels that can share a window's reads among its waves (UVCGPU_SPLIT=0 / 1 forces)
     const char *sp_env = getenv("UVCGPU_SPLIT");
@@ -3634,14 +3663,16 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
             uvc_gap_sort(G.sort_tmp, G.sort_tmp_bytes, G.ckey, G.ckey_s, G.cval, G.cval_s, (size_t)G.n_ev, 58, s);
             hipMemsetAsync(G.ikey, 0xFF, sizeof(unsigned long long) * (size_t)G.inc_cap, s);
             hipLaunchKernelGGL(k_gap_alleles, dim3(nblk(G.n_ev, 64)), dim3(64), 0, s, *R, *P);
+            if (side) hipEventRecord(e_alleles, s);   // what the family kernels read of this chain (fam2_ins_len) is complete here
             uvc_gap_sort(G.sort_tmp, G.sort_tmp_bytes, G.ikey, G.ikey_s, G.ival, G.ival_s, (size_t)G.inc_cap, 64, s);
             hipLaunchKernelGGL(k_gap_rows, dim3(nblk(G.inc_cap, 256)), dim3(256), 0, s, *R);
         });
     }
+    if (side && !(P->inferred_is_vcf_generated && G.n_ev > 0)) hipEventRecord(e_alleles, s2);
     // per-unit statistics of the generic family units (medians, first / last consensus position, general-kind flag): they need the contribution
-    // table and the fragment records only, so they run behind the allele tables on the side stream, underneath k_frag
-    if (R->n_generic_fs) TIMED2(prof, "k_fam_stat", hipLaunchKernelGGL(k_fam_stat, dim3(nblk(R->n_generic_fs, 64)), dim3(64), 0, s, *R, *P));
-    if (side) hipEventRecord(e_fork2, s2);
+    // table and the fragment records only: on s3 behind the queued mismatches, beside the allele tables on s2, underneath k_frag
+    if (R->n_generic_fs) TIMED3(prof, "k_fam_stat", hipLaunchKernelGGL(k_fam_stat, dim3(nblk(R->n_generic_fs, 64)), dim3(64), 0, s, *R, *P));
+    if (side) { hipEventRecord(e_stat, s3); hipEventRecord(e_fork2, s2); }
     if (P->inferred_is_vcf_generated && R->n_complex) TIMED(prof, "k_p2_items", hipLaunchKernelGGL(k_p2_items, dim3(R->n_complex), dim3(64), 0, s, *R, *P));
     {
         const bool proton = (UVC_PLATFORM_IONTORRENT == P->inferred_sequencing_platform);
@@ -3651,13 +3682,15 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
     {
         const bool plain = P->inferred_is_vcf_generated && (UVC_PLATFORM_IONTORRENT != P->inferred_sequencing_platform) && !(0x1 & P->fam_flag) && !(P->microadjust_padded_deletion_flag & 0x1);
         const bool h16 = (R->max_frag_depth < 65536) && !R->frag32;
-        if (plain && h16) TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag16<true>, dim3(nwin), dim3(256), 0, s, *R, *P));
+        if (split_windows && h16 && plain) TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag16_split<true>, dim3(R->nwin), dim3(256), 0, s, *R, *P));
+        else if (split_windows && h16) TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag16_split<false>, dim3(R->nwin), dim3(256), 0, s, *R, *P));
+        else if (plain && h16) TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag16<true>, dim3(nwin), dim3(256), 0, s, *R, *P));
         else if (plain) TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag<true>, dim3(nwin), dim3(256), 0, s, *R, *P));
         else if (h16) TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag16<false>, dim3(nwin), dim3(256), 0, s, *R, *P));
         else TIMED(prof, "k_frag", hipLaunchKernelGGL(k_frag<false>, dim3(nwin), dim3(256), 0, s, *R, *P));
     }
     if (R->n_generic_fs) {
-        if (side) hipStreamWaitEvent(s, e_fork2, 0);   // k_fam_stat's unit records; fam2_ins_len reads what k_gap_alleles left (both ran under k_frag)
+        if (side) { hipStreamWaitEvent(s, e_stat, 0); hipStreamWaitEvent(s, e_alleles, 0); }   // k_fam_stat's unit records; fam2_ins_len reads what k_gap_alleles left (both ran under k_frag)
         // shallow data: one thread per (unit, position); deep data (many units per position, e.g. UMI panels): the window kernel, whose
         // LDS collection removes most of the atomics that bound the per-thread form
         const bool deep = (R->fam_path == 1 ? false : (R->fam_path == 2 ? true : (R->n_generic_work > 8 * R->npos)));
