@@ -216,3 +216,22 @@ def test_k_frag_with_32_bit_buckets_equals_the_packed_form(gpu_lib, monkeypatch)
     assert out[0][0] == out[1][0]
     assert all(np.array_equal(out[0][1][k], out[1][1][k]) for k in out[0][1])
     assert len(out[0][1]["refpos"]) > 1_000
+
+
+def test_split_window_kernels_equal_the_one_wave_per_window_kernels(gpu_lib, monkeypatch):
+    """Deep, short regions run k_prep_fast / k_p2_fast / k_frag16 with a block per window (four waves share the window's reads, LDS reduction);
+    everything else one wave per window.  UVCGPU_SPLIT forces either form: same planes, same records, on a UMI tile with InDel fragments."""
+    reads = synth.generate_region(seed=99, region_len=30_000, depth=600, umi=True)
+    out = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("UVCGPU_SPLIT", force)     # read by every accumulate
+        R = region.Region(gpu_lib, region.default_params(gpu_lib), reads["tid"], reads["beg"], reads["end"], reads["refseq"])
+        R.set_reads(reads)
+        R.accumulate()
+        sums = checksum(R)
+        rec = R.score(capacity=200_000)
+        out.append((sums, {k: rec[k].copy() for k in ("refpos", "symbol", "QUAL", "keep")}))
+        R.close()
+    assert out[0][0] == out[1][0]
+    assert all(np.array_equal(out[0][1][k], out[1][1][k]) for k in out[0][1])
+    assert len(out[0][1]["refpos"]) > 1_000

@@ -3598,9 +3598,12 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
                                       const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof,
                                       hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join, hipEvent_t e_fork2, hipStream_t side3, hipEvent_t e_join3, hipEvent_t e_stat, hipEvent_t e_alleles) {
     const unsigned nwin = nblk(R->npos, 256);   // 4 waves x 64 positions per block
-    // fewer windows than four per SIMD: a block per window in the kernels that can share a window's reads among its waves (UVCGPU_SPLIT=0 / 1 forces)
+    // fewer windows than four per SIMD, and many reads on each (at least sixteen chunks of 64: at 300x a wave of the split form would get fewer
+    // than two and pay its prologue for them -- twice as slow on the 1 Mb tile): a block per window in the kernels that can share a window's
+    // reads among its waves (UVCGPU_SPLIT=0 / 1 forces)
     const char *sp_env = getenv("UVCGPU_SPLIT");
-    const bool split_windows = sp_env ? (atoi(sp_env) != 0) : (R->nwin < 4 * 1024);
+    const long long per_window = (long long)R->n_fast2 * (R->max_p2_span + 64) / (R->npos > 0 ? R->npos : 1);
+    const bool split_windows = sp_env ? (atoi(sp_env) != 0) : (R->nwin < 4 * 1024 && per_window >= 1024);
     if (prof) prof->n = 0;
     hipStream_t s2 = (side ? side : s);
     hipStream_t s3 = ((side && side3) ? side3 : s2);   // the two CIGAR walks of the InDel reads are independent, one wave per 64 reads and long: a stream each
