@@ -68,6 +68,32 @@ def test_fetch_equals_the_overlap_definition(files, name, batch, walk, monkeypat
     b.close()
 
 
+def test_readers_on_several_threads_share_the_pool(files, monkeypatch):
+    """uvc1-mi355x keeps several tiles in flight, one reader each; their inflate / walk / decode slices go through one process-wide pool
+    and every caller works on the queue (its own slices or another reader's) while it waits.  Same columns as a reader that is alone."""
+    import threading
+    d, refs, recs, _ = files
+    monkeypatch.setenv("UVCIO_BATCH_BYTES", "65536")
+    queries = [(1, 100000, 140000), (1, 118000, 121000), (0, 0, 5000), (1, 139990, 200000)]
+    keys = ("pos", "endpos", "flag", "mapq", "isize", "seq_off", "l_qseq", "bases", "quals", "cigars")
+    solo = uio.Bam(str(d / "t.bam"))
+    want = [{k: np.array(g[k]).copy() for k in keys} for g in (solo.fetch(*q) for q in queries)]
+    solo.close()
+    bad = []
+    def work(seed):
+        b = uio.Bam(str(d / ("t.bam" if seed % 2 else "packed.bam")))
+        for rep in range(6):
+            qi = (seed + rep) % len(queries)
+            g = b.fetch(*queries[qi])
+            for k in keys:
+                if not np.array_equal(np.array(g[k]), want[qi][k]): bad.append((seed, rep, k))
+        b.close()
+    th = [threading.Thread(target=work, args=(s,)) for s in range(6)]
+    for x in th: x.start()
+    for x in th: x.join()
+    assert not bad, bad[:5]
+
+
 def test_fasta_fetch(files):
     d, _, _, seqs = files
     f = uio.Fasta(str(d / "ref.fa"))

@@ -16,6 +16,7 @@
 #include "uvcgpu.h"
 #include "uvcgroup.h"
 #include "uvcio.h"
+#include "uvc_cpus.h"
 
 #include <algorithm>
 #include <atomic>
@@ -205,10 +206,8 @@ int main(int argc, char **argv) {
     Opts o = parse(argc, argv);
     if (o.devices.empty()) { const int nd = uvcgpu_device_count(); if (nd <= 0) die("no HIP device: uvc1-mi355x has no CPU path"); for (int d = 0; d < nd; d++) o.devices.push_back(d); }
     if (o.threads <= 0) o.threads = 4 * (int)o.devices.size();
-    if (!getenv("UVCIO_THREADS")) {   // the readers inflate BGZF blocks on their own threads: share the cores among the tiles in flight
-        const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
-        setenv("UVCIO_THREADS", std::to_string(std::max(1, (hw + o.threads - 1) / o.threads)).c_str(), 1);
-    }
+    // the readers of all tiles in flight share one pool of inflate / decode threads inside libuvcio (as many as this process has cores:
+    // quota- and affinity-aware, uvc_cpus.h); UVCIO_THREADS overrides
     if (uvcgpu_init(o.devices[0])) die(uvcgpu_last_error());
     uvcio_bam_t *bam0 = nullptr;
     if (uvcio_bam_open(&bam0, o.bam.c_str())) die(uvcio_last_error());

@@ -5,6 +5,7 @@
 #include "uvc_alloc.h"
 #include "uvc_prep.h"
 #include "uvc_hap.h"
+#include "uvc_cpus.h"
 
 #include <algorithm>
 #include <chrono>
@@ -168,7 +169,7 @@ void build_tracks(const std::string &ref, const UvcParams &P, std::vector<Track>
         }
     };
     {
-        const int nt = (int)std::min<int64_t>(std::max(1u, std::min(std::thread::hardware_concurrency(), 16u)), std::max<int64_t>(n / 8192, 1));
+        const int nt = (int)std::min<int64_t>((unsigned)std::max(1, std::min(uvc_effective_cpus(), 16)), std::max<int64_t>(n / 8192, 1));
         if (nt <= 1) fill_cands(0, n);
         else {
             std::vector<std::thread> th;

@@ -4,6 +4,9 @@
 // what bounds files -> VCF: zlib's inflate decodes a symbol per table probe with a byte-wise bit buffer.  This
 // decoder keeps 56+ bits in a 64-bit buffer (one unaligned 8-byte load per refill), resolves a literal / length code in one probe of an
 // 11-bit table (longer codes through sub-tables), takes up to three literals per refill and copies matches eight bytes at a time.
+// A length / distance entry carries code bits + extra bits as one count: the bit buffer is shifted once per symbol and the extra bits are
+// read from the value it had before, off the dependency chain from one table probe to the next (BAM records inflate as mostly short
+// matches, ~7 bytes each, so that chain is the decoder's speed).
 // It decodes ONE complete stream of known output size (a BGZF block: <= 64 KiB) and returns false on anything it does not like -- the
 // caller then lets zlib look at the block, and checks the CRC-32 of the result in either case (uvc_io.cpp: inflate_block).
 #ifndef UVC_INFLATE_FAST_H
@@ -15,7 +18,7 @@ namespace uvc_fast_inflate {
 
 enum { LL_BITS = 11, D_BITS = 8, PRE_BITS = 7 };
 enum { K_LIT = 0, K_LEN = 1, K_EOB = 2, K_SUB = 3 };
-// entry: bits 0..7 code length to consume (for K_SUB: the primary bits), 8..9 kind, 10..15 number of extra bits (K_SUB: log2 of the sub-table),
+// entry: bits 0..7 bits to consume (K_LEN: code + extra bits; K_SUB: the primary bits), 8..9 kind, 10..15 number of extra bits (K_SUB: log2 of the sub-table),
 //        16..31 literal / base value / first index of the sub-table
 static inline uint32_t mk(int len, int kind, int extra, int val) { return (uint32_t)len | ((uint32_t)kind << 8) | ((uint32_t)extra << 10) | ((uint32_t)val << 16); }
 
@@ -80,9 +83,9 @@ static bool build(uint32_t *tab, int tab_cap, int primary_bits, const uint8_t *l
         if (which == 0) {
             if (s < 256) e = mk(l, K_LIT, 0, s);
             else if (s == 256) e = mk(l, K_EOB, 0, 0);
-            else if (s <= 285) e = mk(l, K_LEN, LEN_EXTRA[s - 257], LEN_BASE[s - 257]);
+            else if (s <= 285) e = mk(l + LEN_EXTRA[s - 257], K_LEN, LEN_EXTRA[s - 257], LEN_BASE[s - 257]);
             else e = 0;   // 286, 287: never valid in a stream
-        } else if (which == 1) e = (s < 30 ? mk(l, K_LEN, DIST_EXTRA[s], DIST_BASE[s]) : 0);
+        } else if (which == 1) e = (s < 30 ? mk(l + DIST_EXTRA[s], K_LEN, DIST_EXTRA[s], DIST_BASE[s]) : 0);
         else e = mk(l, K_LIT, 0, s);
         if (l <= primary_bits) {
             if (tab[r] != 0 && ((tab[r] >> 8) & 3) == K_SUB) return false;   // cannot happen in a prefix code
@@ -90,7 +93,7 @@ static bool build(uint32_t *tab, int tab_cap, int primary_bits, const uint8_t *l
         } else {
             const uint32_t pfx = r & (uint32_t)(psize - 1), head = tab[pfx];
             const int sb = (int)((head >> 10) & 63), base = (int)(head >> 16), sl = l - primary_bits;
-            e = (e & ~0xFFu) | (uint32_t)sl;   // bits to consume after the primary ones
+            e = (e & ~0xFFu) | (uint32_t)(sl + (((e >> 8) & 3) == K_LEN ? (int)((e >> 10) & 63) : 0));   // bits to consume after the primary ones
             for (uint32_t i = r >> primary_bits; i < (1u << sb); i += 1u << sl) tab[base + i] = e;
         }
     }
@@ -173,7 +176,7 @@ static bool inflate(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_l
             const uint32_t *const ll = T.ll, *const dt = T.d;
             // Fast loop: while 16 input bytes and 3 literals + the longest match + the copy's overrun fit, nothing is bounds-checked per
             // symbol, the refill has no branch, and the next table entry is fetched before the current literal is stored.
-            while (in_end - ip >= 16 && out_end - op >= 3 + 258 + 8) {
+            while (in_end - ip >= 16 && out_end - op >= 3 + 258 + 16) {
                 bb |= load64(ip) << bc; ip += (63 - bc) >> 3; bc |= 56;
                 uint32_t e = ll[bb & ((1 << LL_BITS) - 1)];
                 if ((e & 0x300) == 0 && (e & 0xFF)) {            // literal
@@ -188,24 +191,27 @@ static bool inflate(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_l
                 if (((e >> 8) & 3) == K_SUB) { TAKE(LL_BITS); e = ll[(e >> 16) + (bb & ((1u << ((e >> 10) & 63)) - 1))]; }
                 const int l = (int)(e & 0xFF), kind = (int)((e >> 8) & 3);
                 if (!l) return false;
+                const uint64_t sv = bb;
                 TAKE(l);
                 if (kind == K_LIT) { *op++ = (uint8_t)(e >> 16); continue; }   // (a literal with a code longer than the primary table)
                 if (kind == K_EOB) goto block_done;
                 const int xl = (int)((e >> 10) & 63);
-                const uint32_t len = (e >> 16) + (uint32_t)(bb & ((1u << xl) - 1));
-                TAKE(xl);
+                const uint32_t len = (e >> 16) + (uint32_t)((sv >> (l - xl)) & ((1u << xl) - 1));
                 bb |= load64(ip) << bc; ip += (63 - bc) >> 3; bc |= 56;
                 uint32_t de = dt[bb & ((1 << D_BITS) - 1)];
                 if (((de >> 8) & 3) == K_SUB) { TAKE(D_BITS); de = dt[(de >> 16) + (bb & ((1u << ((de >> 10) & 63)) - 1))]; }
                 const int dl = (int)(de & 0xFF);
                 if (!dl) return false;
+                const uint64_t sd = bb;
                 TAKE(dl);
                 const int dx = (int)((de >> 10) & 63);
-                const uint32_t dist = (de >> 16) + (uint32_t)(bb & ((1u << dx) - 1));
-                TAKE(dx);
+                const uint32_t dist = (de >> 16) + (uint32_t)((sd >> (dl - dx)) & ((1u << dx) - 1));
                 if (dist > (size_t)(op - out)) return false;
                 const uint8_t *src = op - dist;
-                if (dist >= 8) { uint8_t *dst = op; uint8_t *const e8 = op + len; do { memcpy(dst, src, 8); dst += 8; src += 8; } while (dst < e8); }
+                if (dist >= 8) {
+                    memcpy(op, src, 8); memcpy(op + 8, src + 8, 8);
+                    if (len > 16) { uint8_t *dst = op + 16; src += 16; uint8_t *const e8 = op + len; do { memcpy(dst, src, 8); dst += 8; src += 8; } while (dst < e8); }
+                }
                 else if (dist == 1) memset(op, *src, len);
                 else for (uint32_t i = 0; i < len; i++) op[i] = src[i];
                 op += len;
@@ -229,20 +235,20 @@ static bool inflate(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_l
                     TAKE((int)(e & 0xFF)); *op++ = (uint8_t)(e >> 16);
                     continue;
                 }
+                const uint64_t sv = bb;
                 TAKE(l);
                 if (kind == K_EOB) break;
                 const int xl = (int)((e >> 10) & 63);
-                const uint32_t len = (e >> 16) + (uint32_t)(bb & ((1u << xl) - 1));
-                TAKE(xl);
+                const uint32_t len = (e >> 16) + (uint32_t)((sv >> (l - xl)) & ((1u << xl) - 1));
                 if (bc < 32) REFILL();
                 uint32_t de = T.d[bb & ((1 << D_BITS) - 1)];
                 if (((de >> 8) & 3) == K_SUB) { TAKE(D_BITS); de = T.d[(de >> 16) + (bb & ((1u << ((de >> 10) & 63)) - 1))]; }
                 const int dl = (int)(de & 0xFF);
                 if (!dl) return false;
+                const uint64_t sd = bb;
                 TAKE(dl);
                 const int dx = (int)((de >> 10) & 63);
-                const uint32_t dist = (de >> 16) + (uint32_t)(bb & ((1u << dx) - 1));
-                TAKE(dx);
+                const uint32_t dist = (de >> 16) + (uint32_t)((sd >> (dl - dx)) & ((1u << dx) - 1));
                 if (dist > (size_t)(op - out) || len > (size_t)(out_end - op)) return false;
                 const uint8_t *src = op - dist;
                 if (dist >= 8 && (size_t)(out_end - op) >= len + 8) {   // eight bytes at a time; the overrun stays inside this block's output

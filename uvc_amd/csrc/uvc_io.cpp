@@ -3,6 +3,7 @@
 // Host code only: it feeds the family assignment (include/uvcgroup.h) and uvcgpu_region_set_reads.
 #include "uvcio.h"
 #include "uvcgpu.h"
+#include "uvc_cpus.h"
 #include "uvc_inflate_fast.h"
 
 #include <zlib.h>
@@ -11,7 +12,11 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #if defined(__x86_64__)
@@ -240,15 +245,38 @@ struct BlockRef { int64_t addr; uint32_t csize /* whole block */, isize; size_t 
 struct RecRef { const uint8_t *r; uint32_t size; int32_t endpos; int64_t base_off, cig_off, name_off; };
 
 int n_threads() {
-    static const int n = [] { const char *e = getenv("UVCIO_THREADS"); int v = e ? atoi(e) : (int)std::thread::hardware_concurrency(); return std::max(1, std::min(v, 32)); }();
+    static const int n = [] { const char *e = getenv("UVCIO_THREADS"); int v = e ? atoi(e) : uvc_effective_cpus(); return std::max(1, std::min(v, 64)); }();
     return n;
 }
+// One pool of helper threads for the whole process (UVCIO_THREADS of them, default: the cores the process may use, uvc_cpus.h).
+// The command line keeps several tiles in flight, one reader each: with a pool per call every reader owned cores/readers threads and
+// those cores idled while its worker was in a single-threaded stage; with one queue the slices of every reader go to whichever core is
+// free.  The calling thread works on the queue too until its own slices are done, so a call never waits for a busy pool (and a
+// process that forked after the pool was made still finishes, on its own thread).
+struct SliceGroup { std::mutex m; std::condition_variable cv; size_t left = 0; };
+struct Slice { const std::function<void(size_t, size_t)> *f; size_t a, b; SliceGroup *g; };
+struct Pool {
+    std::mutex m; std::condition_variable cv; std::deque<Slice> q;
+    explicit Pool(int n) { for (int i = 0; i < n; i++) std::thread([this] { for (;;) { Slice s; { std::unique_lock<std::mutex> l(m); cv.wait(l, [this] { return !q.empty(); }); s = q.front(); q.pop_front(); } run(s); } }).detach(); }
+    static void run(const Slice &s) { (*s.f)(s.a, s.b); std::lock_guard<std::mutex> l(s.g->m); if (--s.g->left == 0) s.g->cv.notify_all(); }
+    bool try_pop(Slice &s) { std::lock_guard<std::mutex> l(m); if (q.empty()) return false; s = q.front(); q.pop_front(); return true; }
+};
+Pool *pool() { static Pool *p = new Pool(std::max(0, n_threads() - 1)); return p; }   // never destroyed: its threads sleep on it until the process ends
 template <class F> void parallel_for(size_t n, F f) {   // f(first, last) on contiguous slices
-    const size_t nt = std::min<size_t>((size_t)n_threads(), std::max<size_t>(n / 64, 1));
-    if (nt <= 1) { f((size_t)0, n); return; }
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < nt; t++) th.emplace_back([=] { f(n * t / nt, n * (t + 1) / nt); });
-    for (std::thread &x : th) x.join();
+    const size_t nt = std::min<size_t>((size_t)n_threads() * 2, std::max<size_t>(n / 64, 1));
+    if (nt <= 1 || n_threads() <= 1) { f((size_t)0, n); return; }
+    const std::function<void(size_t, size_t)> fn = f;
+    SliceGroup g; g.left = nt;
+    Pool *P = pool();
+    { std::lock_guard<std::mutex> l(P->m); for (size_t t = 1; t < nt; t++) P->q.push_back(Slice{ &fn, n * t / nt, n * (t + 1) / nt, &g }); }
+    P->cv.notify_all();
+    Pool::run(Slice{ &fn, 0, n / nt, &g });
+    for (;;) {
+        { std::lock_guard<std::mutex> l(g.m); if (g.left == 0) break; }
+        Slice s;
+        if (P->try_pop(s)) { Pool::run(s); continue; }   // ours or another reader's: either way a core does useful work
+        std::unique_lock<std::mutex> l(g.m); g.cv.wait(l, [&] { return g.left == 0; }); break;
+    }
 }
 // CRC-32 of a block with carry-less multiplication (the folding scheme of Intel's "Fast CRC computation using PCLMULQDQ", constants
 // for the reflected polynomial 0xEDB88320): zlib 1.2.11's table walk does 1.1 GB/s, a quarter of the time of inflating a BGZF block.
