@@ -4,9 +4,6 @@
 // what bounds files -> VCF: zlib's inflate decodes a symbol per table probe with a byte-wise bit buffer.  This
 // decoder keeps 56+ bits in a 64-bit buffer (one unaligned 8-byte load per refill), resolves a literal / length code in one probe of an
 // 11-bit table (longer codes through sub-tables), takes up to three literals per refill and copies matches eight bytes at a time.
-// A length / distance entry carries code bits + extra bits as one count: the bit buffer is shifted once per symbol and the extra bits are
-// read from the value it had before, off the dependency chain from one table probe to the next (BAM records inflate as mostly short
-// matches, ~7 bytes each, so that chain is the decoder's speed).
 // It decodes ONE complete stream of known output size (a BGZF block: <= 64 KiB) and returns false on anything it does not like -- the
 // caller then lets zlib look at the block, and checks the CRC-32 of the result in either case (uvc_io.cpp: inflate_block).
 #ifndef UVC_INFLATE_FAST_H
@@ -18,7 +15,7 @@ namespace uvc_fast_inflate {
 
 enum { LL_BITS = 11, D_BITS = 8, PRE_BITS = 7 };
 enum { K_LIT = 0, K_LEN = 1, K_EOB = 2, K_SUB = 3 };
-// entry: bits 0..7 bits to consume (K_LEN: code + extra bits; K_SUB: the primary bits), 8..9 kind, 10..15 number of extra bits (K_SUB: log2 of the sub-table),
+// entry: bits 0..7 code length to consume (for K_SUB: the primary bits), 8..9 kind, 10..15 number of extra bits (K_SUB: log2 of the sub-table),
 //        16..31 literal / base value / first index of the sub-table
 static inline uint32_t mk(int len, int kind, int extra, int val) { return (uint32_t)len | ((uint32_t)kind << 8) | ((uint32_t)extra << 10) | ((uint32_t)val << 16); }
 
@@ -33,10 +30,10 @@ static const uint8_t LEN_EXTRA[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2,
 static const uint16_t DIST_BASE[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
 static const uint8_t DIST_EXTRA[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
 
-struct Rev8 { uint8_t r[256]; Rev8() { for (int i = 0; i < 256; i++) { int v = 0; for (int b = 0; b < 8; b++) if (i & (1 << b)) v |= 0x80 >> b; r[i] = (uint8_t)v; } } };
-static inline uint32_t bitrev(uint32_t code, int len) {   // len <= 15
-    static const Rev8 R;
-    return (((uint32_t)R.r[code & 0xFF] << 8) | R.r[(code >> 8) & 0xFF]) >> (16 - len);
+static inline uint32_t bitrev(uint32_t code, int len) {
+    uint32_t r = 0;
+    for (int i = 0; i < len; i++) { r = (r << 1) | (code & 1); code >>= 1; }
+    return r;
 }
 
 // which: 0 literal/length alphabet, 1 distance alphabet, 2 code-length alphabet.  A canonical code from the lengths, entries indexed by the
@@ -53,14 +50,11 @@ static bool build(uint32_t *tab, int tab_cap, int primary_bits, const uint8_t *l
     if (left > 0 && !(which == 1 && (used == 1 || fixed))) return false;   // (the fixed distance code has 30 of its 32 codes)
     int next[16]; next[1] = 0;
     for (int l = 1; l < 15; l++) next[l + 1] = (next[l] + count[l]) << 1;
-    const bool complete = (left == 0);   // every slot of the table and of its sub-tables is written below: nothing to clear
-    if (!complete) for (int i = 0; i < psize; i++) tab[i] = 0;
+    for (int i = 0; i < psize; i++) tab[i] = 0;
     // sub-tables: for every primary prefix the longest code that starts with it
     uint8_t sub_bits[1 << LL_BITS];
-    int n_long = 0;
-    for (int l = primary_bits + 1; l <= 15; l++) n_long += count[l];
-    if (n_long) {
-        memset(sub_bits, 0, (size_t)psize);
+    memset(sub_bits, 0, (size_t)psize);
+    {
         int nx[16]; memcpy(nx, next, sizeof(nx));
         for (int s = 0; s < n; s++) {
             const int l = lens[s];
@@ -71,11 +65,11 @@ static bool build(uint32_t *tab, int tab_cap, int primary_bits, const uint8_t *l
         }
     }
     int free_at = psize;
-    if (n_long) for (int pfx = 0; pfx < psize; pfx++) if (sub_bits[pfx]) {
+    for (int pfx = 0; pfx < psize; pfx++) if (sub_bits[pfx]) {
         const int sz = 1 << sub_bits[pfx];
         if (free_at + sz > tab_cap) return false;
         tab[pfx] = mk(primary_bits, K_SUB, sub_bits[pfx], free_at);
-        if (!complete) for (int i = 0; i < sz; i++) tab[free_at + i] = 0;
+        for (int i = 0; i < sz; i++) tab[free_at + i] = 0;
         free_at += sz;
     }
     for (int s = 0; s < n; s++) {
@@ -86,17 +80,17 @@ static bool build(uint32_t *tab, int tab_cap, int primary_bits, const uint8_t *l
         if (which == 0) {
             if (s < 256) e = mk(l, K_LIT, 0, s);
             else if (s == 256) e = mk(l, K_EOB, 0, 0);
-            else if (s <= 285) e = mk(l + LEN_EXTRA[s - 257], K_LEN, LEN_EXTRA[s - 257], LEN_BASE[s - 257]);
+            else if (s <= 285) e = mk(l, K_LEN, LEN_EXTRA[s - 257], LEN_BASE[s - 257]);
             else e = 0;   // 286, 287: never valid in a stream
-        } else if (which == 1) e = (s < 30 ? mk(l + DIST_EXTRA[s], K_LEN, DIST_EXTRA[s], DIST_BASE[s]) : 0);
+        } else if (which == 1) e = (s < 30 ? mk(l, K_LEN, DIST_EXTRA[s], DIST_BASE[s]) : 0);
         else e = mk(l, K_LIT, 0, s);
         if (l <= primary_bits) {
-
+            if (tab[r] != 0 && ((tab[r] >> 8) & 3) == K_SUB) return false;   // cannot happen in a prefix code
             for (uint32_t i = r; i < (uint32_t)psize; i += 1u << l) tab[i] = e;
         } else {
             const uint32_t pfx = r & (uint32_t)(psize - 1), head = tab[pfx];
             const int sb = (int)((head >> 10) & 63), base = (int)(head >> 16), sl = l - primary_bits;
-            e = (e & ~0xFFu) | (uint32_t)(sl + (((e >> 8) & 3) == K_LEN ? (int)((e >> 10) & 63) : 0));   // bits to consume after the primary ones
+            e = (e & ~0xFFu) | (uint32_t)sl;   // bits to consume after the primary ones
             for (uint32_t i = r >> primary_bits; i < (1u << sb); i += 1u << sl) tab[base + i] = e;
         }
     }
@@ -179,7 +173,7 @@ static bool inflate(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_l
             const uint32_t *const ll = T.ll, *const dt = T.d;
             // Fast loop: while 16 input bytes and 3 literals + the longest match + the copy's overrun fit, nothing is bounds-checked per
             // symbol, the refill has no branch, and the next table entry is fetched before the current literal is stored.
-            while (in_end - ip >= 16 && out_end - op >= 3 + 258 + 16) {
+            while (in_end - ip >= 16 && out_end - op >= 3 + 258 + 8) {
                 bb |= load64(ip) << bc; ip += (63 - bc) >> 3; bc |= 56;
                 uint32_t e = ll[bb & ((1 << LL_BITS) - 1)];
                 if ((e & 0x300) == 0 && (e & 0xFF)) {            // literal
@@ -194,27 +188,24 @@ static bool inflate(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_l
                 if (((e >> 8) & 3) == K_SUB) { TAKE(LL_BITS); e = ll[(e >> 16) + (bb & ((1u << ((e >> 10) & 63)) - 1))]; }
                 const int l = (int)(e & 0xFF), kind = (int)((e >> 8) & 3);
                 if (!l) return false;
-                const uint64_t sv = bb;
                 TAKE(l);
                 if (kind == K_LIT) { *op++ = (uint8_t)(e >> 16); continue; }   // (a literal with a code longer than the primary table)
                 if (kind == K_EOB) goto block_done;
                 const int xl = (int)((e >> 10) & 63);
-                const uint32_t len = (e >> 16) + (uint32_t)((sv >> (l - xl)) & ((1u << xl) - 1));
+                const uint32_t len = (e >> 16) + (uint32_t)(bb & ((1u << xl) - 1));
+                TAKE(xl);
                 bb |= load64(ip) << bc; ip += (63 - bc) >> 3; bc |= 56;
                 uint32_t de = dt[bb & ((1 << D_BITS) - 1)];
                 if (((de >> 8) & 3) == K_SUB) { TAKE(D_BITS); de = dt[(de >> 16) + (bb & ((1u << ((de >> 10) & 63)) - 1))]; }
                 const int dl = (int)(de & 0xFF);
                 if (!dl) return false;
-                const uint64_t sd = bb;
                 TAKE(dl);
                 const int dx = (int)((de >> 10) & 63);
-                const uint32_t dist = (de >> 16) + (uint32_t)((sd >> (dl - dx)) & ((1u << dx) - 1));
+                const uint32_t dist = (de >> 16) + (uint32_t)(bb & ((1u << dx) - 1));
+                TAKE(dx);
                 if (dist > (size_t)(op - out)) return false;
                 const uint8_t *src = op - dist;
-                if (dist >= 8) {
-                    memcpy(op, src, 8); memcpy(op + 8, src + 8, 8);
-                    if (len > 16) { uint8_t *dst = op + 16; src += 16; uint8_t *const e8 = op + len; do { memcpy(dst, src, 8); dst += 8; src += 8; } while (dst < e8); }
-                }
+                if (dist >= 8) { uint8_t *dst = op; uint8_t *const e8 = op + len; do { memcpy(dst, src, 8); dst += 8; src += 8; } while (dst < e8); }
                 else if (dist == 1) memset(op, *src, len);
                 else for (uint32_t i = 0; i < len; i++) op[i] = src[i];
                 op += len;
@@ -238,20 +229,20 @@ static bool inflate(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_l
                     TAKE((int)(e & 0xFF)); *op++ = (uint8_t)(e >> 16);
                     continue;
                 }
-                const uint64_t sv = bb;
                 TAKE(l);
                 if (kind == K_EOB) break;
                 const int xl = (int)((e >> 10) & 63);
-                const uint32_t len = (e >> 16) + (uint32_t)((sv >> (l - xl)) & ((1u << xl) - 1));
+                const uint32_t len = (e >> 16) + (uint32_t)(bb & ((1u << xl) - 1));
+                TAKE(xl);
                 if (bc < 32) REFILL();
                 uint32_t de = T.d[bb & ((1 << D_BITS) - 1)];
                 if (((de >> 8) & 3) == K_SUB) { TAKE(D_BITS); de = T.d[(de >> 16) + (bb & ((1u << ((de >> 10) & 63)) - 1))]; }
                 const int dl = (int)(de & 0xFF);
                 if (!dl) return false;
-                const uint64_t sd = bb;
                 TAKE(dl);
                 const int dx = (int)((de >> 10) & 63);
-                const uint32_t dist = (de >> 16) + (uint32_t)((sd >> (dl - dx)) & ((1u << dx) - 1));
+                const uint32_t dist = (de >> 16) + (uint32_t)(bb & ((1u << dx) - 1));
+                TAKE(dx);
                 if (dist > (size_t)(op - out) || len > (size_t)(out_end - op)) return false;
                 const uint8_t *src = op - dist;
                 if (dist >= 8 && (size_t)(out_end - op) >= len + 8) {   // eight bytes at a time; the overrun stays inside this block's output

@@ -33,10 +33,10 @@ static const uint8_t LEN_EXTRA[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2,
 static const uint16_t DIST_BASE[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
 static const uint8_t DIST_EXTRA[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
 
-struct Rev8 { uint8_t r[256]; Rev8() { for (int i = 0; i < 256; i++) { int v = 0; for (int b = 0; b < 8; b++) if (i & (1 << b)) v |= 0x80 >> b; r[i] = (uint8_t)v; } } };
-static inline uint32_t bitrev(uint32_t code, int len) {   // len <= 15
-    static const Rev8 R;
-    return (((uint32_t)R.r[code & 0xFF] << 8) | R.r[(code >> 8) & 0xFF]) >> (16 - len);
+static inline uint32_t bitrev(uint32_t code, int len) {
+    uint32_t r = 0;
+    for (int i = 0; i < len; i++) { r = (r << 1) | (code & 1); code >>= 1; }
+    return r;
 }
 
 // which: 0 literal/length alphabet, 1 distance alphabet, 2 code-length alphabet.  A canonical code from the lengths, entries indexed by the
@@ -53,14 +53,11 @@ static bool build(uint32_t *tab, int tab_cap, int primary_bits, const uint8_t *l
     if (left > 0 && !(which == 1 && (used == 1 || fixed))) return false;   // (the fixed distance code has 30 of its 32 codes)
     int next[16]; next[1] = 0;
     for (int l = 1; l < 15; l++) next[l + 1] = (next[l] + count[l]) << 1;
-    const bool complete = (left == 0);   // every slot of the table and of its sub-tables is written below: nothing to clear
-    if (!complete) for (int i = 0; i < psize; i++) tab[i] = 0;
+    for (int i = 0; i < psize; i++) tab[i] = 0;
     // sub-tables: for every primary prefix the longest code that starts with it
     uint8_t sub_bits[1 << LL_BITS];
-    int n_long = 0;
-    for (int l = primary_bits + 1; l <= 15; l++) n_long += count[l];
-    if (n_long) {
-        memset(sub_bits, 0, (size_t)psize);
+    memset(sub_bits, 0, (size_t)psize);
+    {
         int nx[16]; memcpy(nx, next, sizeof(nx));
         for (int s = 0; s < n; s++) {
             const int l = lens[s];
@@ -71,11 +68,11 @@ static bool build(uint32_t *tab, int tab_cap, int primary_bits, const uint8_t *l
         }
     }
     int free_at = psize;
-    if (n_long) for (int pfx = 0; pfx < psize; pfx++) if (sub_bits[pfx]) {
+    for (int pfx = 0; pfx < psize; pfx++) if (sub_bits[pfx]) {
         const int sz = 1 << sub_bits[pfx];
         if (free_at + sz > tab_cap) return false;
         tab[pfx] = mk(primary_bits, K_SUB, sub_bits[pfx], free_at);
-        if (!complete) for (int i = 0; i < sz; i++) tab[free_at + i] = 0;
+        for (int i = 0; i < sz; i++) tab[free_at + i] = 0;
         free_at += sz;
     }
     for (int s = 0; s < n; s++) {
@@ -91,7 +88,7 @@ static bool build(uint32_t *tab, int tab_cap, int primary_bits, const uint8_t *l
         } else if (which == 1) e = (s < 30 ? mk(l + DIST_EXTRA[s], K_LEN, DIST_EXTRA[s], DIST_BASE[s]) : 0);
         else e = mk(l, K_LIT, 0, s);
         if (l <= primary_bits) {
-
+            if (tab[r] != 0 && ((tab[r] >> 8) & 3) == K_SUB) return false;   // cannot happen in a prefix code
             for (uint32_t i = r; i < (uint32_t)psize; i += 1u << l) tab[i] = e;
         } else {
             const uint32_t pfx = r & (uint32_t)(psize - 1), head = tab[pfx];
