@@ -205,7 +205,10 @@ int main(int argc, char **argv) {
     }
     Opts o = parse(argc, argv);
     if (o.devices.empty()) { const int nd = uvcgpu_device_count(); if (nd <= 0) die("no HIP device: uvc1-mi355x has no CPU path"); for (int d = 0; d < nd; d++) o.devices.push_back(d); }
-    if (o.threads <= 0) o.threads = 4 * (int)o.devices.size();
+    // tiles in flight: the host stages of a tile (inflate above all) cost ~1.3 core-seconds per 1 Mb x 300x, the device ~10 ms: as many workers
+    // as half the cores this process may use keep the cores busy (measured on a 16-core quota: 4 -> 6.7, 8 -> 8-11, 12-16 -> 8-9.6 M positions/s),
+    // never more than 8 per device (a region handle holds ~7 GB of planes) and at least one per device
+    if (o.threads <= 0) { const int nd = (int)o.devices.size(); o.threads = std::max(nd, std::min(8 * nd, uvc_effective_cpus() / 2)); }
     // the readers of all tiles in flight share one pool of inflate / decode threads inside libuvcio (as many as this process has cores:
     // quota- and affinity-aware, uvc_cpus.h); UVCIO_THREADS overrides
     if (uvcgpu_init(o.devices[0])) die(uvcgpu_last_error());
