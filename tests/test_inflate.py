@@ -70,8 +70,16 @@ def _gpu_inflate(lib, comps, sizes):
     return rc, out, out_off
 
 
+@pytest.fixture(params=["lane per block", "wave per block"])
+def kernel_form(request, monkeypatch):
+    """uvc_inflate.hip has two kernels: k_bgzf_inflate (default) and k_bgzf_inflate_wave (UVCGPU_INFLATE_WAVE, read at every call)"""
+    if request.param == "wave per block": monkeypatch.setenv("UVCGPU_INFLATE_WAVE", "1")
+    else: monkeypatch.delenv("UVCGPU_INFLATE_WAVE", raising=False)
+    return request.param
+
+
 @pytest.mark.gpu
-def test_device_inflate_equals_zlib(gpu_lib):
+def test_device_inflate_equals_zlib(gpu_lib, kernel_form):
     cases = payloads()
     rc, out, off = _gpu_inflate(gpu_lib, [c for _, _, c in cases], [len(d) for _, d, _ in cases])
     assert rc == 0, gpu_lib.last_error()
@@ -82,7 +90,7 @@ def test_device_inflate_equals_zlib(gpu_lib):
 
 
 @pytest.mark.gpu
-def test_device_inflate_of_a_bam_and_a_corrupt_block(gpu_lib, tmp_path):
+def test_device_inflate_of_a_bam_and_a_corrupt_block(gpu_lib, tmp_path, kernel_form):
     import bamwriter
     from uvc_amd import synth
     reads = synth.generate_region(seed=77, region_len=20000, depth=200)

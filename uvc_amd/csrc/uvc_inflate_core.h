@@ -62,8 +62,11 @@ UVC_HD int uvc_infl_build(PL lens, int n, PC count, PS sym, PF fast, int fast_bi
 }
 
 // Inflates in[0, in_len) into out[0, out_len); returns UVC_INFL_OK only if the stream ends with its final block exactly at out_len bytes.
-template <class ST>
-UVC_HD int uvc_inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, ST &S) {
+// COOP (device only): the 64 lanes of a wave run this function together on ONE block, every value below identical in all of them (one table
+// set per wave, input words read by broadcast); lane 0 stores literals, and a match is copied by the lanes side by side -- one step per
+// match whatever its length, behind a wavefront-scope fence that orders the wave's earlier stores before the loads of the copy.
+template <bool COOP, class ST>
+UVC_HD int uvc_inflate_block_t(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, ST &S, const uint32_t lane) {
     uint64_t bitbuf = 0; int bitcnt = 0; uint32_t ip = 0, op = 0;
     // phases of the one loop
     enum { PH_HEADER, PH_STORED, PH_LENS, PH_SYMBOL, PH_COPY, PH_DONE };
@@ -125,7 +128,7 @@ UVC_HD int uvc_inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             if (e) { used = e >> 9; sym = e & 511; } else sym = slow(&S.lit_count[0], &S.lit_sym[0], used);
             if (sym < 0 || used > bitcnt) { err = (sym < 0 ? UVC_INFL_ECODE : UVC_INFL_EINPUT); break; }
             UVC_INFL_TAKE(used);
-            if (sym < 256) { if (op >= out_len) { err = UVC_INFL_EOUTPUT; break; } out[op++] = (uint8_t)sym; continue; }
+            if (sym < 256) { if (op >= out_len) { err = UVC_INFL_EOUTPUT; break; } if (!COOP || lane == 0) out[op] = (uint8_t)sym; op++; continue; }
             if (sym == 256) { phase = last ? PH_DONE : PH_HEADER; continue; }
             sym -= 257;
             if (sym >= 29) { err = UVC_INFL_ECODE; break; }
@@ -144,6 +147,16 @@ UVC_HD int uvc_inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             if (bitcnt < 0) { err = UVC_INFL_EINPUT; break; }
             if (dist > op) { err = UVC_INFL_EDIST; break; }
             if (len > out_len - op) { err = UVC_INFL_EOUTPUT; break; }
+            if (COOP) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+                const uint8_t *const src = out + op - dist;   // everything in [op - dist, op) was written by earlier steps
+                if (dist >= len) { for (uint32_t k = lane; k < len; k += 64) out[op + k] = src[k]; }
+                else { for (uint32_t k = lane; k < len; k += 64) out[op + k] = src[k % dist]; }
+                op += len;
+                continue;
+            }
             copy_len = len; copy_dist = dist; phase = PH_COPY;
             continue;
         }
@@ -187,7 +200,7 @@ UVC_HD int uvc_inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             uint32_t n = stored_left < 4 ? stored_left : 4;
             if (n > out_len - op) { err = UVC_INFL_EOUTPUT; break; }
             if ((int)(n * 8) > bitcnt) { err = UVC_INFL_EINPUT; break; }
-            for (uint32_t k = 0; k < n; k++) { out[op++] = (uint8_t)(bitbuf & 0xFF); UVC_INFL_TAKE(8); }
+            for (uint32_t k = 0; k < n; k++) { if (!COOP || lane == 0) out[op] = (uint8_t)(bitbuf & 0xFF); op++; UVC_INFL_TAKE(8); }
             stored_left -= n;
             if (stored_left == 0) phase = last ? PH_DONE : PH_HEADER;
             continue;
@@ -221,5 +234,7 @@ UVC_HD int uvc_inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, u
     if (phase != PH_DONE) return UVC_INFL_EINPUT;     // (the iteration bound: cannot be reached by a well-formed stream)
     return op == out_len ? UVC_INFL_OK : UVC_INFL_ESHORT;
 }
+template <class ST>
+UVC_HD int uvc_inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, ST &S) { return uvc_inflate_block_t<false>(in, in_len, out, out_len, S, 0u); }
 
 #endif
