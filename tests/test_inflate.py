@@ -70,10 +70,10 @@ def _gpu_inflate(lib, comps, sizes):
     return rc, out, out_off
 
 
-@pytest.fixture(params=["lane per block", "wave per block"])
+@pytest.fixture(params=["lane per block", "wave per block", "wave per block, 8 waves per SIMD"])
 def kernel_form(request, monkeypatch):
     """uvc_inflate.hip has two kernels: k_bgzf_inflate (default) and k_bgzf_inflate_wave (UVCGPU_INFLATE_WAVE, read at every call)"""
-    if request.param == "wave per block": monkeypatch.setenv("UVCGPU_INFLATE_WAVE", "1")
+    if request.param.startswith("wave per block"): monkeypatch.setenv("UVCGPU_INFLATE_WAVE", "8" if "8" in request.param else "1")
     else: monkeypatch.delenv("UVCGPU_INFLATE_WAVE", raising=False)
     return request.param
 

@@ -24,6 +24,7 @@
 
 extern "C" int uvcgpu_set_error(int code, const char *msg);   // uvc_host.cpp
 
+#define DEV_INLINE __device__ __forceinline__
 struct BgzfBlockDev { unsigned long long in_off, out_off; uint32_t in_len, out_len; };
 
 __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *comp, const BgzfBlockDev *blocks, int n, uint8_t *out, int32_t *status) {
@@ -39,8 +40,7 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *comp, const 
 // One WAVE per BGZF block (UVCGPU_INFLATE_WAVE=1): the lane-per-block form above waits for its slowest lane and copies a match 8 bytes per step
 // through global memory; here the 64 lanes decode one block together (uvc_inflate_block_t<true>), four blocks per workgroup, one table set
 // (2.3 KB of LDS) per wave, a tile's ~8 500 blocks resident at once.
-__global__ void __launch_bounds__(256) k_bgzf_inflate_wave(const uint8_t *comp, const BgzfBlockDev *blocks, int n, uint8_t *out, int32_t *status) {
-    __shared__ __attribute__((aligned(16))) InflState lds_state[4];
+DEV_INLINE void bgzf_inflate_wave_body(const uint8_t *comp, const BgzfBlockDev *blocks, int n, uint8_t *out, int32_t *status, InflState *lds_state) {
     typedef __attribute__((address_space(3))) InflState LdsState;
     LdsState *S = (LdsState *)lds_state + (threadIdx.x >> 6);
     const int i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -48,6 +48,15 @@ __global__ void __launch_bounds__(256) k_bgzf_inflate_wave(const uint8_t *comp, 
     const BgzfBlockDev b = blocks[i];
     const int rc = uvc_inflate_block_t<true>(comp + b.in_off, b.in_len, out + b.out_off, b.out_len, *S, (uint32_t)(threadIdx.x & 63));
     if ((threadIdx.x & 63) == 0) status[i] = rc;
+}
+__global__ void __launch_bounds__(256) k_bgzf_inflate_wave(const uint8_t *comp, const BgzfBlockDev *blocks, int n, uint8_t *out, int32_t *status) {
+    __shared__ __attribute__((aligned(16))) InflState lds_state[4];
+    bgzf_inflate_wave_body(comp, blocks, n, out, status, lds_state);
+}
+// the same with the register budget of eight waves per SIMD (every block of a 1 Mb tile resident at once; UVCGPU_INFLATE_WAVE=8)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_bgzf_inflate_wave8(const uint8_t *comp, const BgzfBlockDev *blocks, int n, uint8_t *out, int32_t *status) {
+    __shared__ __attribute__((aligned(16))) InflState lds_state[4];
+    bgzf_inflate_wave_body(comp, blocks, n, out, status, lds_state);
 }
 
 namespace {
@@ -105,8 +114,10 @@ extern "C" int uvcgpu_bgzf_inflate(void *, const uint8_t *comp, int64_t comp_byt
         const bool timing = (getenv("UVCGPU_TIMING") != nullptr);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, C.stream); }
-        const bool wave_per_block = (getenv("UVCGPU_INFLATE_WAVE") != nullptr);   // read per call: the tests run both forms in one process
-        if (wave_per_block) hipLaunchKernelGGL(k_bgzf_inflate_wave, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, C.stream, (const uint8_t *)C.comp.p, (const BgzfBlockDev *)C.blocks.p, (int)n, (uint8_t *)C.out.p, (int32_t *)C.status.p);
+        const char *wenv = getenv("UVCGPU_INFLATE_WAVE");   // read per call: the tests run every form in one process
+        const int wave_per_block = wenv ? atoi(wenv) : 0;
+        if (wave_per_block == 8) hipLaunchKernelGGL(k_bgzf_inflate_wave8, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, C.stream, (const uint8_t *)C.comp.p, (const BgzfBlockDev *)C.blocks.p, (int)n, (uint8_t *)C.out.p, (int32_t *)C.status.p);
+        else if (wave_per_block) hipLaunchKernelGGL(k_bgzf_inflate_wave, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, C.stream, (const uint8_t *)C.comp.p, (const BgzfBlockDev *)C.blocks.p, (int)n, (uint8_t *)C.out.p, (int32_t *)C.status.p);
         else hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, C.stream, (const uint8_t *)C.comp.p, (const BgzfBlockDev *)C.blocks.p, (int)n, (uint8_t *)C.out.p, (int32_t *)C.status.p);
         if (hipGetLastError() != hipSuccess) return uvcgpu_set_error(UVCGPU_EDEVICE, "bgzf_inflate: kernel launch failed");
         if (timing) hipEventRecord(e1, C.stream);

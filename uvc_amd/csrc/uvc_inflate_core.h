@@ -113,6 +113,88 @@ UVC_HD int uvc_inflate_block_t(const uint8_t *in, uint32_t in_len, uint8_t *out,
     };
     const uint64_t max_iter = (uint64_t)in_len * 8 + (uint64_t)out_len + 1024;   // every iteration consumes a bit, produces a byte, or ends a block
     for (uint64_t it = 0; phase != PH_DONE && it < max_iter; it++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (COOP) {   // tell the compiler what the launch guarantees: the decoder's state is the same in every lane -> scalar registers, scalar branches
+            auto u32 = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+            auto u64 = [&](uint64_t v) -> uint64_t { return (uint64_t)u32((uint32_t)v) | ((uint64_t)u32((uint32_t)(v >> 32)) << 32); };
+            bitbuf = u64(bitbuf); ahead = u64(ahead); bitcnt = (int)u32((uint32_t)bitcnt); ahead_bits = (int)u32((uint32_t)ahead_bits);
+            ip = u32(ip); op = u32(op); phase = (int)u32((uint32_t)phase); last = (int)u32((uint32_t)last); stored_left = u32(stored_left);
+            lens_at = (int)u32((uint32_t)lens_at); nlen = (int)u32((uint32_t)nlen); ndist = (int)u32((uint32_t)ndist);
+        }
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (COOP && phase == PH_SYMBOL) {
+            // The symbols of one Huffman block in a loop of their own.  The state machine around it costs ~300 instructions per symbol, and with
+            // every block of a tile resident (8 waves per SIMD) the kernel is bound by instruction issue, not by latency.  Here the bit reader is
+            // a 64-bit scalar buffer topped up 32 bits at a time from a word loaded one step ahead; table entries and input words come back
+            // through v_readfirstlane, everything else is scalar.  Bits behind the end of the input read as zeros and are caught at the end.
+            auto u32 = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+            auto word = [&](uint32_t at) -> uint32_t { uint32_t w = 0; if (at < in_len) { __builtin_memcpy(&w, in + at, 4); w = u32(w); } return w; };   // (in has 8 bytes of padding behind the last block)
+            const uint32_t bitpos = ip * 8 - (uint32_t)ahead_bits - (uint32_t)bitcnt;   // bits consumed so far
+            uint32_t wp = bitpos >> 3;
+            uint64_t bb = ((uint64_t)word(wp) | ((uint64_t)word(wp + 4) << 32)) >> (bitpos & 7);
+            int bc = 64 - (int)(bitpos & 7);
+            wp += 8;
+            uint32_t nextw = word(wp);
+            for (;;) {
+                if (bc <= 32) { bb |= (uint64_t)nextw << bc; bc += 32; wp += 4; nextw = word(wp); }
+                int sym, used;
+                const uint32_t e = u32(S.lit_fast[bb & ((1u << UVC_INFL_LBITS) - 1)]);
+                if (e) { used = (int)(e >> 9); sym = (int)(e & 511); }
+                else {   // longer than the fast table: bit by bit (puff's decode)
+                    int code = 0, first = 0, index = 0; sym = -1; used = 0;
+                    for (int l = 1; l < 16; l++) {
+                        code |= (int)((bb >> (l - 1)) & 1);
+                        const int c = (int)u32(S.lit_count[l]);
+                        if (code - c < first) { used = l; sym = (int)u32(S.lit_sym[index + (code - first)]); break; }
+                        index += c; first += c; first <<= 1; code <<= 1;
+                    }
+                }
+                if (sym < 0) { err = UVC_INFL_ECODE; break; }
+                bb >>= used; bc -= used;
+                if (sym < 256) { if (op >= out_len) { err = UVC_INFL_EOUTPUT; break; } if (lane == 0) out[op] = (uint8_t)sym; op++; continue; }
+                if (sym == 256) { phase = last ? PH_DONE : PH_HEADER; break; }
+                sym -= 257;
+                if (sym >= 29) { err = UVC_INFL_ECODE; break; }
+                const int lext = len_ext(sym);
+                const uint32_t len = len_base(sym) + (uint32_t)(bb & ((1u << lext) - 1));
+                bb >>= lext; bc -= lext;
+                if (bc <= 32) { bb |= (uint64_t)nextw << bc; bc += 32; wp += 4; nextw = word(wp); }
+                int dsym, dused;
+                const uint32_t de = u32(S.dist_fast[bb & ((1u << UVC_INFL_DBITS) - 1)]);
+                if (de) { dused = (int)(de >> 5); dsym = (int)(de & 31); }
+                else {
+                    int code = 0, first = 0, index = 0; dsym = -1; dused = 0;
+                    for (int l = 1; l < 16; l++) {
+                        code |= (int)((bb >> (l - 1)) & 1);
+                        const int c = (int)u32(S.dist_count[l]);
+                        if (code - c < first) { dused = l; dsym = (int)u32(S.dist_sym[index + (code - first)]); break; }
+                        index += c; first += c; first <<= 1; code <<= 1;
+                    }
+                }
+                if (dsym < 0 || dsym >= 30) { err = UVC_INFL_ECODE; break; }
+                bb >>= dused; bc -= dused;
+                const int dext = dist_ext(dsym);
+                const uint32_t dist = dist_base(dsym) + (uint32_t)(bb & ((1u << dext) - 1));
+                bb >>= dext; bc -= dext;
+                if (dist > op) { err = UVC_INFL_EDIST; break; }
+                if (len > out_len - op) { err = UVC_INFL_EOUTPUT; break; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint8_t *const src = out + op - dist;
+                if (dist >= len) { for (uint32_t k = lane; k < len; k += 64) out[op + k] = src[k]; }
+                else { for (uint32_t k = lane; k < len; k += 64) out[op + k] = src[k % dist]; }
+                op += len;
+            }
+            if (err) break;
+            const uint32_t endpos = wp * 8 - (uint32_t)bc;   // first unread bit
+            if (endpos > in_len * 8) { err = UVC_INFL_EINPUT; break; }
+            // hand the position back to the reader of the state machine (headers, stored blocks)
+            ip = endpos >> 3; ahead = 0; ahead_bits = 0; bitbuf = 0; bitcnt = 0;
+            UVC_INFL_REFILL();
+            UVC_INFL_TAKE((int)(endpos & 7));   // (endpos <= in_len * 8: the byte that holds these bits was there to load)
+            continue;
+        }
+#endif
         if (phase == PH_COPY) {   // at most 8 bytes of the pending match
             uint32_t n = copy_len < 8 ? copy_len : 8;
             if (n == 8 && copy_dist >= 8) { uint64_t w_; __builtin_memcpy(&w_, out + op - copy_dist, 8); __builtin_memcpy(out + op, &w_, 8); op += 8; }   // source and destination do not overlap
