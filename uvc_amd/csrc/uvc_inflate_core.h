@@ -129,15 +129,21 @@ UVC_HD int uvc_inflate_block_t(const uint8_t *in, uint32_t in_len, uint8_t *out,
             // a 64-bit scalar buffer topped up 32 bits at a time from a word loaded one step ahead; table entries and input words come back
             // through v_readfirstlane, everything else is scalar.  Bits behind the end of the input read as zeros and are caught at the end.
             auto u32 = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-            auto word = [&](uint32_t at) -> uint32_t { uint32_t w = 0; if (at < in_len) { __builtin_memcpy(&w, in + at, 4); w = u32(w); } return w; };   // (in has 8 bytes of padding behind the last block)
+            // (in has 8 bytes of padding behind the last block.)  wordv leaves the loaded word in a vector register: it is read (u32) at the NEXT
+            // top-up, two or three symbols later, so the memory round trip of the look-ahead word is never waited for
+            auto wordv = [&](uint32_t at) -> uint32_t { uint32_t w = 0; if (at < in_len) __builtin_memcpy(&w, in + at, 4); return w; };
+            auto word = [&](uint32_t at) -> uint32_t { return u32(wordv(at)); };
             const uint32_t bitpos = ip * 8 - (uint32_t)ahead_bits - (uint32_t)bitcnt;   // bits consumed so far
             uint32_t wp = bitpos >> 3;
             uint64_t bb = ((uint64_t)word(wp) | ((uint64_t)word(wp + 4) << 32)) >> (bitpos & 7);
             int bc = 64 - (int)(bitpos & 7);
             wp += 8;
-            uint32_t nextw = word(wp);
+            uint32_t nextw = wordv(wp);
+            // a match of <= 64 bytes is loaded at once and stored when the next match (or the end of the block) comes: its round trip runs beside
+            // the decoding of the symbols in between
+            uint32_t pend_len = 0, pend_op = 0; uint8_t pend_byte = 0;
             for (;;) {
-                if (bc <= 32) { bb |= (uint64_t)nextw << bc; bc += 32; wp += 4; nextw = word(wp); }
+                if (bc <= 32) { bb |= (uint64_t)u32(nextw) << bc; bc += 32; wp += 4; nextw = wordv(wp); }
                 int sym, used;
                 const uint32_t e = u32(S.lit_fast[bb & ((1u << UVC_INFL_LBITS) - 1)]);
                 if (e) { used = (int)(e >> 9); sym = (int)(e & 511); }
@@ -159,7 +165,7 @@ UVC_HD int uvc_inflate_block_t(const uint8_t *in, uint32_t in_len, uint8_t *out,
                 const int lext = len_ext(sym);
                 const uint32_t len = len_base(sym) + (uint32_t)(bb & ((1u << lext) - 1));
                 bb >>= lext; bc -= lext;
-                if (bc <= 32) { bb |= (uint64_t)nextw << bc; bc += 32; wp += 4; nextw = word(wp); }
+                if (bc <= 32) { bb |= (uint64_t)u32(nextw) << bc; bc += 32; wp += 4; nextw = wordv(wp); }
                 int dsym, dused;
                 const uint32_t de = u32(S.dist_fast[bb & ((1u << UVC_INFL_DBITS) - 1)]);
                 if (de) { dused = (int)(de >> 5); dsym = (int)(de & 31); }
@@ -179,12 +185,15 @@ UVC_HD int uvc_inflate_block_t(const uint8_t *in, uint32_t in_len, uint8_t *out,
                 bb >>= dext; bc -= dext;
                 if (dist > op) { err = UVC_INFL_EDIST; break; }
                 if (len > out_len - op) { err = UVC_INFL_EOUTPUT; break; }
+                if (pend_len) { if (lane < pend_len) out[pend_op + lane] = pend_byte; pend_len = 0; }   // (this match may read those bytes)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const uint8_t *const src = out + op - dist;
-                if (dist >= len) { for (uint32_t k = lane; k < len; k += 64) out[op + k] = src[k]; }
+                if (len <= 64) { if (lane < len) pend_byte = src[dist >= len ? lane : lane % dist]; pend_op = op; pend_len = len; }
+                else if (dist >= len) { for (uint32_t k = lane; k < len; k += 64) out[op + k] = src[k]; }
                 else { for (uint32_t k = lane; k < len; k += 64) out[op + k] = src[k % dist]; }
                 op += len;
             }
+            if (pend_len && lane < pend_len) out[pend_op + lane] = pend_byte;
             if (err) break;
             const uint32_t endpos = wp * 8 - (uint32_t)bc;   // first unread bit
             if (endpos > in_len * 8) { err = UVC_INFL_EINPUT; break; }
