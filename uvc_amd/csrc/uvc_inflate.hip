@@ -40,22 +40,23 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const uint8_t *comp, const 
 // One WAVE per BGZF block (UVCGPU_INFLATE_WAVE=1): the lane-per-block form above waits for its slowest lane and copies a match 8 bytes per step
 // through global memory; here the 64 lanes decode one block together (uvc_inflate_block_t<true>), four blocks per workgroup, one table set
 // (2.3 KB of LDS) per wave, a tile's ~8 500 blocks resident at once.
-DEV_INLINE void bgzf_inflate_wave_body(const uint8_t *comp, const BgzfBlockDev *blocks, int n, uint8_t *out, int32_t *status, InflState *lds_state) {
-    typedef __attribute__((address_space(3))) InflState LdsState;
+typedef InflStateT<10, 9> InflStateWave;   // one table set per wave: 3.9 KB, 32 waves of a CU = 125 KB of its 160 KB LDS
+DEV_INLINE void bgzf_inflate_wave_body(const uint8_t *comp, const BgzfBlockDev *blocks, int n, uint8_t *out, int32_t *status, InflStateWave *lds_state) {
+    typedef __attribute__((address_space(3))) InflStateWave LdsState;
     LdsState *S = (LdsState *)lds_state + (threadIdx.x >> 6);
     const int i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (i >= n) return;
     const BgzfBlockDev b = blocks[i];
-    const int rc = uvc_inflate_block_t<true>(comp + b.in_off, b.in_len, out + b.out_off, b.out_len, *S, (uint32_t)(threadIdx.x & 63));
+    const int rc = uvc_inflate_block_t<true, 10, 9>(comp + b.in_off, b.in_len, out + b.out_off, b.out_len, *S, (uint32_t)(threadIdx.x & 63));
     if ((threadIdx.x & 63) == 0) status[i] = rc;
 }
 __global__ void __launch_bounds__(256) k_bgzf_inflate_wave(const uint8_t *comp, const BgzfBlockDev *blocks, int n, uint8_t *out, int32_t *status) {
-    __shared__ __attribute__((aligned(16))) InflState lds_state[4];
+    __shared__ __attribute__((aligned(16))) InflStateWave lds_state[4];
     bgzf_inflate_wave_body(comp, blocks, n, out, status, lds_state);
 }
 // the same with the register budget of eight waves per SIMD (every block of a 1 Mb tile resident at once; UVCGPU_INFLATE_WAVE=8)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_bgzf_inflate_wave8(const uint8_t *comp, const BgzfBlockDev *blocks, int n, uint8_t *out, int32_t *status) {
-    __shared__ __attribute__((aligned(16))) InflState lds_state[4];
+    __shared__ __attribute__((aligned(16))) InflStateWave lds_state[4];
     bgzf_inflate_wave_body(comp, blocks, n, out, status, lds_state);
 }
 

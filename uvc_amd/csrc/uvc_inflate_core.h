@@ -20,13 +20,17 @@
 #define UVC_INFL_LBITS 9    // literal / length codes up to this long resolve with one table read
 #define UVC_INFL_DBITS 7    // (2.3 KB of tables per block: 64 decoders fit the 160 KB of LDS of one CU)
 
-struct InflState {
-    uint16_t lit_fast[1 << UVC_INFL_LBITS];    // len << 9 | symbol, 0 = longer code
-    uint16_t dist_fast[1 << UVC_INFL_DBITS];   // len << 5 | symbol, 0 = longer code
+// LB / DB: index bits of the two fast tables.  The lane-per-block kernel and the host build use 9 / 7; the wave-per-block kernels have one
+// table set per wave and can afford 10 / 9 (3.9 KB), which takes most distance codes of BAM data off the bit-by-bit path.
+template <int LB, int DB>
+struct InflStateT {
+    uint16_t lit_fast[1 << LB];                // len << 9 | symbol, 0 = longer code
+    uint16_t dist_fast[1 << DB];               // len << 5 | symbol, 0 = longer code
     uint16_t lit_count[16], dist_count[16];    // canonical form for the longer codes: codes per length, symbols in code order
     uint16_t lit_sym[288], dist_sym[32];
     uint8_t lens[320];                         // code lengths of a dynamic header while they are read
 };
+typedef InflStateT<UVC_INFL_LBITS, UVC_INFL_DBITS> InflState;
 
 enum { UVC_INFL_OK = 0, UVC_INFL_EINPUT = -1 /* ran out of input */, UVC_INFL_EOUTPUT = -2 /* more output than ISIZE */, UVC_INFL_ECODE = -3 /* invalid code / header */,
        UVC_INFL_ESHORT = -4 /* stream ended before ISIZE bytes */, UVC_INFL_EDIST = -5 /* distance before the start of the block */ };
@@ -65,7 +69,7 @@ UVC_HD int uvc_infl_build(PL lens, int n, PC count, PS sym, PF fast, int fast_bi
 // COOP (device only): the 64 lanes of a wave run this function together on ONE block, every value below identical in all of them (one table
 // set per wave, input words read by broadcast); lane 0 stores literals, and a match is copied by the lanes side by side -- one step per
 // match whatever its length, behind a wavefront-scope fence that orders the wave's earlier stores before the loads of the copy.
-template <bool COOP, class ST>
+template <bool COOP, int LB, int DB, class ST>
 UVC_HD int uvc_inflate_block_t(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, ST &S, const uint32_t lane) {
     uint64_t bitbuf = 0; int bitcnt = 0; uint32_t ip = 0, op = 0;
     // phases of the one loop
@@ -145,7 +149,7 @@ UVC_HD int uvc_inflate_block_t(const uint8_t *in, uint32_t in_len, uint8_t *out,
             for (;;) {
                 if (bc <= 32) { bb |= (uint64_t)u32(nextw) << bc; bc += 32; wp += 4; nextw = wordv(wp); }
                 int sym, used;
-                const uint32_t e = u32(S.lit_fast[bb & ((1u << UVC_INFL_LBITS) - 1)]);
+                const uint32_t e = u32(S.lit_fast[bb & ((1u << LB) - 1)]);
                 if (e) { used = (int)(e >> 9); sym = (int)(e & 511); }
                 else {   // longer than the fast table: bit by bit (puff's decode)
                     int code = 0, first = 0, index = 0; sym = -1; used = 0;
@@ -167,7 +171,7 @@ UVC_HD int uvc_inflate_block_t(const uint8_t *in, uint32_t in_len, uint8_t *out,
                 bb >>= lext; bc -= lext;
                 if (bc <= 32) { bb |= (uint64_t)u32(nextw) << bc; bc += 32; wp += 4; nextw = wordv(wp); }
                 int dsym, dused;
-                const uint32_t de = u32(S.dist_fast[bb & ((1u << UVC_INFL_DBITS) - 1)]);
+                const uint32_t de = u32(S.dist_fast[bb & ((1u << DB) - 1)]);
                 if (de) { dused = (int)(de >> 5); dsym = (int)(de & 31); }
                 else {
                     int code = 0, first = 0, index = 0; dsym = -1; dused = 0;
@@ -215,7 +219,7 @@ UVC_HD int uvc_inflate_block_t(const uint8_t *in, uint32_t in_len, uint8_t *out,
         UVC_INFL_REFILL();
         if (phase == PH_SYMBOL) {
             int sym, used;
-            const uint16_t e = S.lit_fast[bitbuf & ((1u << UVC_INFL_LBITS) - 1)];
+            const uint16_t e = S.lit_fast[bitbuf & ((1u << LB) - 1)];
             if (e) { used = e >> 9; sym = e & 511; } else sym = slow(&S.lit_count[0], &S.lit_sym[0], used);
             if (sym < 0 || used > bitcnt) { err = (sym < 0 ? UVC_INFL_ECODE : UVC_INFL_EINPUT); break; }
             UVC_INFL_TAKE(used);
@@ -228,7 +232,7 @@ UVC_HD int uvc_inflate_block_t(const uint8_t *in, uint32_t in_len, uint8_t *out,
             UVC_INFL_TAKE(lext);
             UVC_INFL_REFILL();
             int dsym, dused;
-            const uint16_t de = S.dist_fast[bitbuf & ((1u << UVC_INFL_DBITS) - 1)];
+            const uint16_t de = S.dist_fast[bitbuf & ((1u << DB) - 1)];
             if (de) { dused = de >> 5; dsym = de & 31; } else dsym = slow(&S.dist_count[0], &S.dist_sym[0], dused);
             if (dsym < 0 || dsym >= 30) { err = UVC_INFL_ECODE; break; }
             UVC_INFL_TAKE(dused);
@@ -268,9 +272,9 @@ UVC_HD int uvc_inflate_block_t(const uint8_t *in, uint32_t in_len, uint8_t *out,
                 for (int i = 144; i < 256; i++) S.lens[i] = 9;
                 for (int i = 256; i < 280; i++) S.lens[i] = 7;
                 for (int i = 280; i < 288; i++) S.lens[i] = 8;
-                uvc_infl_build(&S.lens[0], 288, &S.lit_count[0], &S.lit_sym[0], &S.lit_fast[0], UVC_INFL_LBITS, 9);
+                uvc_infl_build(&S.lens[0], 288, &S.lit_count[0], &S.lit_sym[0], &S.lit_fast[0], LB, 9);
                 for (int i = 0; i < 30; i++) S.lens[i] = 5;
-                uvc_infl_build(&S.lens[0], 30, &S.dist_count[0], &S.dist_sym[0], &S.dist_fast[0], UVC_INFL_DBITS, 5);
+                uvc_infl_build(&S.lens[0], 30, &S.dist_count[0], &S.dist_sym[0], &S.dist_fast[0], DB, 5);
                 phase = PH_SYMBOL;
             } else if (type == 2) {   // dynamic codes: HLIT, HDIST, HCLEN and the code-length code
                 if (bitcnt < 14) { err = UVC_INFL_EINPUT; break; }
@@ -312,7 +316,7 @@ UVC_HD int uvc_inflate_block_t(const uint8_t *in, uint32_t in_len, uint8_t *out,
             }
             if (lens_at == nlen + ndist) {
                 if (S.lens[256] == 0) { err = UVC_INFL_ECODE; break; }   // no end-of-block code
-                if (uvc_infl_build(&S.lens[0], nlen, &S.lit_count[0], &S.lit_sym[0], &S.lit_fast[0], UVC_INFL_LBITS, 9) || uvc_infl_build(&S.lens[0] + nlen, ndist, &S.dist_count[0], &S.dist_sym[0], &S.dist_fast[0], UVC_INFL_DBITS, 5)) { err = UVC_INFL_ECODE; break; }
+                if (uvc_infl_build(&S.lens[0], nlen, &S.lit_count[0], &S.lit_sym[0], &S.lit_fast[0], LB, 9) || uvc_infl_build(&S.lens[0] + nlen, ndist, &S.dist_count[0], &S.dist_sym[0], &S.dist_fast[0], DB, 5)) { err = UVC_INFL_ECODE; break; }
                 phase = PH_SYMBOL;
             }
             continue;
@@ -326,6 +330,6 @@ UVC_HD int uvc_inflate_block_t(const uint8_t *in, uint32_t in_len, uint8_t *out,
     return op == out_len ? UVC_INFL_OK : UVC_INFL_ESHORT;
 }
 template <class ST>
-UVC_HD int uvc_inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, ST &S) { return uvc_inflate_block_t<false>(in, in_len, out, out_len, S, 0u); }
+UVC_HD int uvc_inflate_block(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, ST &S) { return uvc_inflate_block_t<false, UVC_INFL_LBITS, UVC_INFL_DBITS>(in, in_len, out, out_len, S, 0u); }
 
 #endif
