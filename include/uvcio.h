@@ -96,6 +96,16 @@ void uvcio_tumor_vcf_close(uvcio_tumor_vcf_t *v);
  * uvcgpu_region_set_reads passes page-locked memory of the GPU library here (wrappers of uvcgpu_host_alloc / uvcgpu_host_free), so that the
  * 2 x 300 MB of a 1 Mb x 300x tile travel by DMA.  Set it before the first uvcio_bam_fetch; buffers are kept and grown per BAM handle. */
 void uvcio_set_column_allocator(void *(*alloc_fn)(size_t), void (*free_fn)(void *));
+
+/* The BGZF blocks of a batch inflated somewhere else than on the host's cores.  fn gets the raw DEFLATE payloads of n blocks (in_off / in_len
+ * inside comp) and the place of each block's output (out_off / out_len = the block's ISIZE) and returns 0 when every byte of every block is
+ * in place; the reader then checks each block's CRC-32 itself.  Anything else (non-zero return, a CRC mismatch) and the reader inflates the
+ * batch on the host as if no function had been set.  uvcgpu_bgzf_inflate (uvcgpu.h) has this signature: uvc1-mi355x --device-inflate sets
+ * it (the calling thread must have selected its device, uvcgpu_init).  Batches with fewer than min_blocks blocks stay on the host.
+ * Replaces bgzf_read's inflate of the reference's reader (htslib behind grouping.cpp:617-731).  Process-wide; set it before the first fetch. */
+typedef int (*uvcio_inflate_fn)(void *ctx, const uint8_t *comp, int64_t comp_bytes, const int64_t *in_off, const int32_t *in_len,
+                                const int64_t *out_off, const int32_t *out_len, int64_t n, uint8_t *out, int64_t out_bytes);
+void uvcio_set_inflate(uvcio_inflate_fn fn, void *ctx, int32_t min_blocks);
 uint32_t uvcio_crc32(const void *p, int64_t n);
 /* Test hook: one raw DEFLATE stream of known output size through the library's own decoder (uvc_inflate_fast.h), which the BGZF reader tries
  * before zlib: 1 = decoded (out holds out_len bytes), 0 = declined (the reader would hand the block to zlib). */

@@ -27,8 +27,8 @@ print("files written in %.1f s" % (time.perf_counter() - t0), flush=True)
 exe = "/root/repo/uvc_amd/csrc/uvc1-mi355x"
 beg, end = reads["beg"], reads["end"]
 outs = []
-for label, env in (("shared pool, quota-aware size", {}), ("shared pool of 8", {"UVCIO_THREADS": "8"}), ("shared pool of 32", {"UVCIO_THREADS": "32"}), ("shared pool, zlib", {"UVCIO_ZLIB": "1"})):
-    for threads in (4, 8, 12, 16):
+for label, env in (("host inflate", {}), ("device inflate", {"UVC1_DEVICE_INFLATE": "1"}), ("device inflate, page-locked columns", {"UVC1_DEVICE_INFLATE": "1", "UVC1_PINNED": "1"})):
+    for threads in (4, 8, 12):
         e = dict(os.environ); e.update(env)
         out = os.path.join(d, "o_%d_%d.vcf.gz" % (len(outs), threads)); outs.append((threads, out))
         r0 = resource.getrusage(resource.RUSAGE_CHILDREN); w0 = time.perf_counter()

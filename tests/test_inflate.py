@@ -72,9 +72,9 @@ def _gpu_inflate(lib, comps, sizes):
 
 @pytest.fixture(params=["lane per block", "wave per block", "wave per block, 8 waves per SIMD"])
 def kernel_form(request, monkeypatch):
-    """uvc_inflate.hip has two kernels: k_bgzf_inflate (default) and k_bgzf_inflate_wave (UVCGPU_INFLATE_WAVE, read at every call)"""
+    """uvc_inflate.hip has three kernels, chosen by UVCGPU_INFLATE_WAVE at every call: 0 k_bgzf_inflate, 1 k_bgzf_inflate_wave, 8 (default) k_bgzf_inflate_wave8"""
     if request.param.startswith("wave per block"): monkeypatch.setenv("UVCGPU_INFLATE_WAVE", "8" if "8" in request.param else "1")
-    else: monkeypatch.delenv("UVCGPU_INFLATE_WAVE", raising=False)
+    else: monkeypatch.setenv("UVCGPU_INFLATE_WAVE", "0")
     return request.param
 
 

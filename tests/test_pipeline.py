@@ -142,7 +142,8 @@ def test_native_command_line_equals_the_python_chain(tmp_path, gpu_lib):
     assert gzip.open(out_b, "rt").read() == gzip.open(out_c, "rt").read()
     # the reader's switches leave the output alone: zlib instead of the own DEFLATE decoder, the sequential record walk, base / quality columns
     # in page-locked memory of the GPU library
-    for env in ({"UVCIO_ZLIB": "1", "UVCIO_SERIAL_WALK": "1"}, {"UVC1_PINNED": "1"}):
+    # ... the BGZF blocks inflated by the device (every batch, however small)
+    for env in ({"UVCIO_ZLIB": "1", "UVCIO_SERIAL_WALK": "1"}, {"UVC1_PINNED": "1"}, {"UVC1_DEVICE_INFLATE": "1", "UVC1_DEVICE_INFLATE_MIN": "1"}):
         out_e = str(tmp_path / "e.vcf.gz")
         r = subprocess.run([exe, bam, "-f", fa, "-o", out_e, "-s", "T1", "-R", bed, "-t", "2"], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
         assert r.returncode == 0, r.stderr

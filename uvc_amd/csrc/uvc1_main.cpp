@@ -39,13 +39,13 @@ struct Opts {
     std::vector<int> devices;
     int threads = 0, outvar_flag = -1, repeat = 1, shard = 0, n_shards = 1, tn_is_paired = 0, tumor_format = 1;
     int64_t tile = 1000000;
-    bool all_out = false, timing = false, no_header = false;
+    bool all_out = false, timing = false, no_header = false, device_inflate = false;
     double vqual = -1e9;
 };
 [[noreturn]] void die(const std::string &m) { fprintf(stderr, "uvc1-mi355x: %s\n", m.c_str()); exit(2); }
 void usage() {
     fprintf(stderr, "usage: uvc1-mi355x inputBAM -f ref.fa -o out.vcf.gz [-s sample] [--targets chr[:beg-end] | -R regions.bed] [-t threads] [-A] [-q vqual]\n"
-                    "                   [--outvar-flag bits] [--tile bp] [--devices 0,1,..] [--shard i/n] [--no-header] [--timing]\n"
+                    "                   [--outvar-flag bits] [--tile bp] [--devices 0,1,..] [--shard i/n] [--no-header] [--timing] [--device-inflate]\n"
                     "                   [--tn-is-paired 0|1] [--tumor-vcf tumor.vcf.gz] [--is-tumor-format-retrieved 0|1] [--bed-out-fname f] [--bed-in-fname f]\n"
                     "       uvc1-mi355x --concat out.vcf.gz shard0.vcf.gz shard1.vcf.gz ...\n");
 }
@@ -73,6 +73,7 @@ Opts parse(int argc, char **argv) {
         else if (a == "--shard") { const std::string v = val(); if (sscanf(v.c_str(), "%d/%d", &o.shard, &o.n_shards) != 2 || o.n_shards < 1 || o.shard < 0 || o.shard >= o.n_shards) die("--shard takes i/n with 0 <= i < n"); }
         else if (a == "--no-header") o.no_header = true;
         else if (a == "--timing") o.timing = true;
+        else if (a == "--device-inflate") o.device_inflate = true;   // the BGZF blocks of the BAM inflated by the GPU (uvcgpu_bgzf_inflate) instead of the host cores
         else if (a == "--tumor-vcf") o.tumor_vcf = val();
         else if (a == "--tn-is-paired") o.tn_is_paired = atoi(val().c_str());
         else if (a == "--is-tumor-format-retrieved") o.tumor_format = atoi(val().c_str());
@@ -296,6 +297,14 @@ int main(int argc, char **argv) {
     // UVC1_PINNED=1: the workers' base / quality columns live in page-locked memory of the GPU library from here on, so that set_reads copies
     // them by DMA.  Off by default: on the boxes measured the files -> VCF rate did not move with it (scripts/bench_cli.py; the chain is not
     // bound by that copy) and it locks ~ 800 MB of host memory per worker.
+    // --device-inflate (or UVC1_DEVICE_INFLATE=1): the inflate is ~half of the host's work per tile and the host's cores bound files -> VCF
+    // (DESIGN.md 6b).  One device call per batch of blocks costs about as much for 500 blocks as for 8 000 (every block is a wave of its own):
+    // the reader takes the compressed bytes of a whole tile as one batch.
+    if (o.device_inflate || getenv("UVC1_DEVICE_INFLATE")) {
+        const char *mb = getenv("UVC1_DEVICE_INFLATE_MIN");   // batches with fewer blocks stay on the host (tests: 1)
+        uvcio_set_inflate(uvcgpu_bgzf_inflate, nullptr, mb ? atoi(mb) : 256);
+        setenv("UVCIO_BATCH_BYTES", "402653184", 0);
+    }
     if (getenv("UVC1_PINNED"))
         uvcio_set_column_allocator([](size_t n) -> void * { void *q = nullptr; return uvcgpu_host_alloc(&q, (int64_t)n) == 0 ? q : nullptr; }, [](void *q) { (void)uvcgpu_host_free(q); });
     // T/N: the tumor pass's records (rescue_variants_from_vcf, main.cpp:183-398)

@@ -116,7 +116,7 @@ extern "C" int uvcgpu_bgzf_inflate(void *, const uint8_t *comp, int64_t comp_byt
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, C.stream); }
         const char *wenv = getenv("UVCGPU_INFLATE_WAVE");   // read per call: the tests run every form in one process
-        const int wave_per_block = wenv ? atoi(wenv) : 0;
+        const int wave_per_block = wenv ? atoi(wenv) : 8;   // default: a wave per block at 8 waves per SIMD; 1: the compiler's register budget; 0: a lane per block
         if (wave_per_block == 8) hipLaunchKernelGGL(k_bgzf_inflate_wave8, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, C.stream, (const uint8_t *)C.comp.p, (const BgzfBlockDev *)C.blocks.p, (int)n, (uint8_t *)C.out.p, (int32_t *)C.status.p);
         else if (wave_per_block) hipLaunchKernelGGL(k_bgzf_inflate_wave, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, C.stream, (const uint8_t *)C.comp.p, (const BgzfBlockDev *)C.blocks.p, (int)n, (uint8_t *)C.out.p, (int32_t *)C.status.p);
         else hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, C.stream, (const uint8_t *)C.comp.p, (const BgzfBlockDev *)C.blocks.p, (int)n, (uint8_t *)C.out.p, (int32_t *)C.status.p);

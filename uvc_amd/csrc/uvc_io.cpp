@@ -33,6 +33,8 @@ extern "C" int uvcio_inflate_raw_fast(const void *in, int64_t in_len, void *out,
     return (in && out && in_len >= 0 && out_len >= 0 && uvc_fast_inflate::inflate((const uint8_t *)in, (size_t)in_len, (uint8_t *)out, (size_t)out_len)) ? 1 : 0;
 }
 namespace { extern void *(*g_col_alloc)(size_t); extern void (*g_col_free)(void *); }
+namespace { uvcio_inflate_fn g_inflate_fn = nullptr; void *g_inflate_ctx = nullptr; int32_t g_inflate_min = 0; }
+extern "C" void uvcio_set_inflate(uvcio_inflate_fn fn, void *ctx, int32_t min_blocks) { g_inflate_fn = fn; g_inflate_ctx = ctx; g_inflate_min = min_blocks; }
 extern "C" void uvcio_set_column_allocator(void *(*alloc_fn)(size_t), void (*free_fn)(void *)) { g_col_alloc = alloc_fn; g_col_free = free_fn; }
 extern "C" uint32_t uvcio_crc32(const void *p, int64_t n) { return (p && n > 0) ? block_crc32((const uint8_t *)p, (size_t)n) : 0u; }
 
@@ -461,8 +463,24 @@ extern "C" int uvcio_bam_fetch(uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t
                 const size_t infl_size = carry.size() + out_bytes;
                 uint8_t *const ibuf = b->infl.need(std::max<size_t>(infl_size, 1));
                 if (!carry.empty()) memcpy(ibuf, carry.data(), carry.size());
-                bool ok = true;
-                parallel_for(blocks.size(), [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; i++) if (!inflate_block(cbuf + blocks[i].in_off, blocks[i].csize, ibuf + carry.size() + blocks[i].out_off, blocks[i].isize)) ok = false; });
+                bool ok = true, done = false;
+                if (g_inflate_fn && (int64_t)blocks.size() >= (int64_t)g_inflate_min) {   // somewhere else (the device); the CRC-32 of every block is checked here
+                    const size_t nb2 = blocks.size();
+                    std::vector<int64_t> in_off(nb2), out_off(nb2); std::vector<int32_t> in_len(nb2), out_len(nb2);
+                    bool sane = true;
+                    for (size_t i = 0; i < nb2; i++) {
+                        const uint8_t *blk = cbuf + blocks[i].in_off;
+                        const int xlen = le16(blk + 10), clen = (int)blocks[i].csize - xlen - 20;
+                        if (clen < 0) { sane = false; break; }
+                        in_off[i] = (int64_t)blocks[i].in_off + 12 + xlen; in_len[i] = clen; out_off[i] = (int64_t)(carry.size() + blocks[i].out_off); out_len[i] = (int32_t)blocks[i].isize;
+                    }
+                    if (sane && g_inflate_fn(g_inflate_ctx, cbuf, (int64_t)o, in_off.data(), in_len.data(), out_off.data(), out_len.data(), (int64_t)nb2, ibuf, (int64_t)infl_size) == 0) {
+                        bool crc_ok = true;
+                        parallel_for(nb2, [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; i++) if (blocks[i].isize && block_crc32(ibuf + out_off[i], blocks[i].isize) != le32(cbuf + blocks[i].in_off + blocks[i].csize - 8)) crc_ok = false; });
+                        done = crc_ok;
+                    }
+                }
+                if (!done) parallel_for(blocks.size(), [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; i++) if (!inflate_block(cbuf + blocks[i].in_off, blocks[i].csize, ibuf + carry.size() + blocks[i].out_off, blocks[i].isize)) ok = false; });
                 if (!ok) return fail(UVCGPU_EINVAL, "corrupt BGZF block (inflate / CRC)");
                 t_inf += now() - t0; t0 = now();
                 // the usable byte range of this batch
