@@ -4,6 +4,7 @@
 #include "uvc_device.h"
 #include "uvc_alloc.h"
 #include "uvc_prep.h"
+#include "uvc_rtr.h"
 #include "uvc_hap.h"
 #include "uvc_cpus.h"
 
@@ -69,7 +70,9 @@ struct uvcgpu_region {
     int32_t tid, beg, end;     // state covers [beg, end): end = caller's end + 1 (main.cpp:569)
     int64_t npos;
     std::string refstring;
-    std::vector<int32_t> h_rtr;   // host copy of the repeat tracks as built (the record writer reads begpos / tracklen / unitlen)
+    std::vector<int32_t> h_rtr; bool h_rtr_valid = false;   // host copy of the repeat tracks as built (begpos / tracklen / unitlen planes), fetched when the record writer first asks
+    UvcRtrWork rw; char *d_rtrwork = nullptr; bool thr_ready = false;   // scratch of the side-array kernels (uvc_rtr.hip)
+    char *h_ref = nullptr; size_t h_ref_cap = 0;                        // page-locked staging of the reference characters
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr, side3 = nullptr; hipEvent_t e_fork = nullptr, e_join = nullptr, e_fork2 = nullptr, e_join3 = nullptr, e_stat = nullptr, e_alleles = nullptr;   // fork/join inside accumulate (see uvc_launch_accumulate)
     // device buffers
@@ -126,89 +129,9 @@ static size_t group_bytes(const uvcgpu_region *r, int g) {
 }
 
 // ---------------------------------------------------------------- region side arrays (a3) ---
-// refstring2repeatvec (main.hpp:803-874) + region_repeatvec_to_baq_offsetarr (main.cpp:400-429), host side
-// (O(region x 35); SURVEY C10: "cheap; do on host first").
+// refstring2repeatvec (main.hpp:803-874) + region_repeatvec_to_baq_offsetarr (main.cpp:400-429) run on the device (uvc_rtr.hip); the host
+// only stages the reference characters and, once per handle, turns indel_phred (main.hpp:794-801) into its threshold table.
 namespace {
-struct Track { int32_t begpos = 0, tracklen = 0, unitlen = 0, indelphred = 0, a_begpos = 0, a_tracklen = 0, a_unitlen = 0; };
-
-bool str_better(int32_t ulen1, int32_t cnt1, int32_t ulen2, int32_t cnt2, int32_t umax) {   // is_indel_context_more_STR, main.hpp:699-721
-    if (ulen2 * cnt2 == 0) return true;
-    if (ulen1 > umax || ulen2 > umax) return (ulen1 < ulen2 || (ulen1 == ulen2 && cnt1 > cnt2));
-    int r1 = (cnt1 <= 1 ? (-(int)cnt1 * ulen1) : ((int)(cnt1 - 1) * ulen1));
-    int r2 = (cnt2 <= 1 ? (-(int)cnt2 * ulen1) : ((int)(cnt2 - 1) * ulen2));
-    if (0 == cnt1 || 0 == ulen1) r1 = -100;
-    if (0 == cnt2 || 0 == ulen2) r2 = -100;
-    return r1 > r2;
-}
-int32_t slip_phred(double ampfact, int32_t ulen, int32_t cnt) {   // indel_phred, main.hpp:794-801
-    const int32_t span = ulen * cnt;
-    const double slips = (span > 64 ? (double)(span - 8) : std::log1p(std::exp((double)span - 8.0))) * ampfact / ((double)(ulen * ulen));
-    return (int32_t)std::floor(-10 * std::log((1.0 - 2.220446049250313e-16) / (slips + 1.0)) / std::log(10.0));
-}
-void build_tracks(const std::string &ref, const UvcParams &P, std::vector<Track> &tr, std::vector<int64_t> &baq /*[2][npos]*/) {
-    const int32_t n = (int32_t)ref.size();
-    tr.assign(n, Track());
-    for (auto &t : tr) t.indelphred = P.indel_BQ_max;
-    const int32_t smax = P.indel_str_repeatsize_max, vmax = P.indel_vntr_repeatsize_max;
-    // The walk below visits start positions one after the other (the step depends on the repeat found), but what it finds at a start
-    // depends on the reference alone: the candidates of all positions are computed on the host cores first, the walk then only follows them.
-    struct Cand { int32_t best_u, best_c, best_end, any_u, any_end, dec; };
-    std::vector<Cand> cand((size_t)n);
-    auto fill_cands = [&](int32_t a0, int32_t a1) {
-        for (int32_t at = a0; at < a1; at++) {
-            int32_t best_u = 0, best_c = 0, best_end = at, any_u = 0, any_c = 0, any_end = at;
-            for (int32_t u = 1; u <= vmax; u++) {
-                int32_t q = at;
-                while (q + u < n && ref[q] == ref[q + u]) q++;
-                const int32_t c = (q - at) / u + 1;
-                if (u <= smax && str_better(u, c, best_u, best_c, smax)) { best_u = u; best_c = c; best_end = q + u; }
-                if (str_better(u, c, any_u, any_c, vmax)) { any_u = u; any_c = c; any_end = q + u; }
-            }
-            const int32_t len = std::min(best_end, n) - at;
-            cand[(size_t)at] = Cand{ best_u, best_c, best_end, any_u, any_end, slip_phred(P.indel_polymerase_slip_rate * P.indel_del_to_ins_err_ratio, best_u, len / best_u) };
-        }
-    };
-    {
-        const int nt = (int)std::min<int64_t>((unsigned)std::max(1, std::min(uvc_effective_cpus(), 16)), std::max<int64_t>(n / 8192, 1));
-        if (nt <= 1) fill_cands(0, n);
-        else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nt; t++) th.emplace_back(fill_cands, (int32_t)((int64_t)n * t / nt), (int32_t)((int64_t)n * (t + 1) / nt));
-            for (std::thread &x : th) x.join();
-        }
-    }
-    int32_t at = 0;
-    while (at < n) {
-        const Cand &c = cand[(size_t)at];
-        const int32_t best_u = c.best_u, best_c = c.best_c, best_end = c.best_end, any_u = c.any_u, any_end = c.any_end, dec = c.dec;
-        const int32_t stop = std::min(best_end, n), len = stop - at;
-        for (int32_t i = at; i != stop; i++) if (len > tr[i].tracklen) {
-            tr[i].begpos = at; tr[i].tracklen = len; tr[i].unitlen = best_u; tr[i].indelphred = P.indel_BQ_max - std::min(P.indel_BQ_max - 1, dec);
-        }
-        const int32_t astop = std::min(any_end, n), alen = astop - at;
-        for (int32_t i = at; i != astop; i++) if (alen > tr[i].a_tracklen) { tr[i].a_begpos = at; tr[i].a_tracklen = alen; tr[i].a_unitlen = any_u; }
-        const int32_t skip = smax + best_u;
-        at += std::max(best_u * best_c, skip + 1) - skip;
-    }
-    tr.push_back(tr.back());
-    const size_t npos = tr.size();
-    baq.assign(2 * npos, 0);
-    for (int any = 0; any < 2; any++) {
-        int64_t run = 0;
-        for (size_t i = 0; i < npos; i++) {
-            const int32_t tl = any ? tr[i].a_tracklen : tr[i].tracklen;
-            const int32_t reps = tl / tr[i].unitlen;
-            if (reps >= 3 || (reps >= 2 && tl >= (int32_t)std::round(P.indel_polymerase_size))) run += (P.indel_str_phred_per_region * 10) / tl + 1;
-            else run += P.indel_nonSTR_phred_per_base * 10;
-            baq[any * npos + i] = run;
-        }
-        for (size_t i = 0; i < npos; i++) baq[any * npos + i] /= 10;
-    }
-}
-uint8_t base_code(char c) {   // CHAR_TO_SYMBOL, main_conversion.hpp:473-488
-    switch (c) { case 'A': case 'a': return UVC_BASE_A; case 'C': case 'c': return UVC_BASE_C; case 'G': case 'g': return UVC_BASE_G; case 'T': case 't': return UVC_BASE_T;
-                 case 'I': case 'i': return UVC_LINK_M; case '-': case '_': return UVC_LINK_D1; default: return UVC_BASE_N; }
-}
 template <class T> int upload(uvcgpu_region *r, const std::vector<T> &v, T **out, bool owned = true) {
     *out = nullptr;
     const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
@@ -286,17 +209,7 @@ static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t 
     r->tid = tid; r->beg = beg; r->end = end + 1; r->npos = (int64_t)end - beg + 1;
     r->refstring.assign(refseq, (size_t)(end - beg));
     r->accumulated = false; r->gap_ready = false; r->hap_ready = false; r->buckets_clean = false; r->state_released = false; r->state_zeroed = false;
-    std::vector<Track> tr; std::vector<int64_t> baq;
-    build_tracks(r->refstring, r->P, tr, baq);
-    std::vector<uint8_t> refsym((size_t)r->npos + 1, 0);
-    for (size_t i = 0; i < r->refstring.size(); i++) refsym[i] = base_code(r->refstring[i]);
-    std::vector<int32_t> rtr((size_t)UVC_NRTR * r->npos);
-    for (int64_t i = 0; i < r->npos; i++) {
-        const Track &t = tr[i];
-        const int32_t v[UVC_NRTR] = { t.begpos, t.tracklen, t.unitlen, t.indelphred, t.a_begpos, t.a_tracklen, t.a_unitlen };
-        for (int f = 0; f < UVC_NRTR; f++) rtr[(size_t)f * r->npos + i] = v[f];
-    }
-    r->h_rtr = rtr;
+    r->h_rtr_valid = false;
     // one slab for all per-position planes (+ the transient bucket planes), 8-byte groups first
     const int order[] = { UVC_F_PREP64, UVC_F_SEG64, UVC_F_FAMINFO64, UVC_F_PREP32, UVC_F_THRES, UVC_F_SEG32, UVC_F_VQ, UVC_F_BQSUM, UVC_F_FRAG, UVC_F_FAM, UVC_F_FAMINFO32, UVC_F_DUPLEX };
     size_t o = 0;
@@ -304,19 +217,40 @@ static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t 
     r->p5flag_off = o; o += ((size_t)2 * r->npos + 255) & ~(size_t)255;   // one byte per (strand, position): a P5 bucket was filled (k_p5b skips the others); zeroed with the planes
     r->bucket_off = o; o += (size_t)4 * r->npos * 2 * NSYM * NBUCKETS;
     r->state_bytes = o;
+    const int vmax = r->P.indel_vntr_repeatsize_max, smax = r->P.indel_str_repeatsize_max, bqm = r->P.indel_BQ_max;
+    const size_t n_rtr = (size_t)UVC_NRTR * r->npos;
     if (r->npos > r->npos_cap) {
         quiesce(r);
-        for (void *p : { (void *)r->d_refsym, (void *)r->d_rtr, (void *)r->d_rtr0, (void *)r->d_fsum, (void *)r->d_win, (void *)r->d_baq, (void *)r->d_state }) if (p) hipFree(p);
-        r->d_refsym = nullptr; r->d_rtr = r->d_rtr0 = r->d_fsum = r->d_win = nullptr; r->d_baq = nullptr; r->d_state = nullptr; r->npos_cap = 0;
-        if (hipMalloc((void **)&r->d_refsym, (size_t)r->npos + 1) != hipSuccess || hipMalloc((void **)&r->d_rtr, sizeof(int32_t) * rtr.size()) != hipSuccess
-            || hipMalloc((void **)&r->d_rtr0, sizeof(int32_t) * rtr.size()) != hipSuccess || hipMalloc((void **)&r->d_fsum, sizeof(int32_t) * 2 * UVC_FSUM_N * (size_t)r->npos) != hipSuccess || hipMalloc((void **)&r->d_win, sizeof(int32_t) * 16 * (size_t)((r->npos + 63) / 64)) != hipSuccess || hipMalloc((void **)&r->d_baq, sizeof(int64_t) * baq.size()) != hipSuccess
-            || hipMalloc((void **)&r->d_state, r->state_bytes) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(region planes) failed");
+        for (void *p : { (void *)r->d_refsym, (void *)r->d_rtr, (void *)r->d_rtr0, (void *)r->d_fsum, (void *)r->d_win, (void *)r->d_baq, (void *)r->d_state, (void *)r->d_rtrwork }) if (p) hipFree(p);
+        r->d_refsym = nullptr; r->d_rtr = r->d_rtr0 = r->d_fsum = r->d_win = nullptr; r->d_baq = nullptr; r->d_state = nullptr; r->d_rtrwork = nullptr; r->npos_cap = 0; r->thr_ready = false;
+        size_t scan_tmp = 0;
+        const size_t work_bytes = uvc_rtr_work_bytes(r->npos, vmax, smax, bqm, &scan_tmp);
+        if (hipMalloc((void **)&r->d_refsym, (size_t)r->npos + 1) != hipSuccess || hipMalloc((void **)&r->d_rtr, sizeof(int32_t) * n_rtr) != hipSuccess
+            || hipMalloc((void **)&r->d_rtr0, sizeof(int32_t) * n_rtr) != hipSuccess || hipMalloc((void **)&r->d_fsum, sizeof(int32_t) * 2 * UVC_FSUM_N * (size_t)r->npos) != hipSuccess || hipMalloc((void **)&r->d_win, sizeof(int32_t) * 16 * (size_t)((r->npos + 63) / 64)) != hipSuccess || hipMalloc((void **)&r->d_baq, sizeof(int64_t) * 2 * (size_t)r->npos) != hipSuccess
+            || hipMalloc((void **)&r->d_state, r->state_bytes) != hipSuccess || hipMalloc((void **)&r->d_rtrwork, work_bytes) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(region planes) failed");
+        uvc_rtr_bind(&r->rw, r->d_rtrwork, r->npos, vmax, smax, bqm, scan_tmp);
         r->npos_cap = r->npos;
     }
-    HIP_OK(hipMemcpyAsync(r->d_refsym, refsym.data(), refsym.size(), hipMemcpyHostToDevice, r->stream));
-    HIP_OK(hipMemcpyAsync(r->d_rtr0, rtr.data(), sizeof(int32_t) * rtr.size(), hipMemcpyHostToDevice, r->stream));
-    HIP_OK(hipMemcpyAsync(r->d_rtr, rtr.data(), sizeof(int32_t) * rtr.size(), hipMemcpyHostToDevice, r->stream));
-    HIP_OK(hipMemcpyAsync(r->d_baq, baq.data(), sizeof(int64_t) * baq.size(), hipMemcpyHostToDevice, r->stream));
+    if (!r->thr_ready) {   // parameters only: once per handle (and again when the scratch moved)
+        std::vector<int32_t> thr((size_t)smax * bqm);
+        uvc_rtr_thresholds(&r->P, thr.data());
+        HIP_OK(hipMemcpy(r->rw.thr, thr.data(), sizeof(int32_t) * thr.size(), hipMemcpyHostToDevice));
+        r->thr_ready = true;
+    }
+    // the reference characters travel from page-locked memory of the handle, so that the copy is a stream operation like the kernels behind it
+    const size_t n_ref = (size_t)(end - beg);
+    if (n_ref > r->h_ref_cap) {
+        if (r->h_ref) (void)hipHostFree(r->h_ref);
+        r->h_ref = nullptr; r->h_ref_cap = 0;
+        if (hipHostMalloc((void **)&r->h_ref, n_ref, hipHostMallocDefault) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipHostMalloc(reference staging) failed");
+        r->h_ref_cap = n_ref;
+    }
+    memcpy(r->h_ref, refseq, n_ref);
+    HIP_OK(hipMemcpyAsync(r->rw.refchar, r->h_ref, n_ref, hipMemcpyHostToDevice, r->stream));
+    {
+        const int e = uvc_launch_region_tracks(&r->rw, &r->P, r->npos, r->d_refsym, r->d_rtr0, r->d_baq, r->stream);
+        if (e) return fail(UVCGPU_EDEVICE, std::string("side-array kernels: ") + hipGetErrorString((hipError_t)e));
+    }
     int32_t *d_err = r->R.err;
     RegionDev &R = r->R;
     memset(&R, 0, sizeof(R));
@@ -329,14 +263,14 @@ static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t 
     R.bucket = (int32_t *)(b + r->bucket_off); R.p5flag = (uint8_t *)(b + r->p5flag_off);
     R.err = d_err;
     HIP_OK(hipMemsetAsync(d_err, 0, 4, r->stream));
-    HIP_OK(hipStreamSynchronize(r->stream));   // the staging vectors above die here
-    return 0;
+    return 0;   // nothing to wait for: the staging memory belongs to the handle and a handle is rebound only when its streams are idle
 }
 
 static int uvcgpu_region_create_impl(uvcgpu_region_t **out, const UvcParams *params, int32_t tid, int32_t beg, int32_t end, const char *refseq) {
     if (!out || !params || !refseq || end <= beg) return fail(UVCGPU_EINVAL, "bad argument");
     if (params->struct_size != (int32_t)sizeof(UvcParams)) return fail(UVCGPU_EINVAL, "UvcParams::struct_size mismatch");
     if (params->indel_str_repeatsize_max < 1 || params->indel_vntr_repeatsize_max < params->indel_str_repeatsize_max) return fail(UVCGPU_EINVAL, "bad repeat-size parameters");
+    if (params->indel_vntr_repeatsize_max > 255 || params->indel_BQ_max < 1 || params->indel_BQ_max > 32767) return fail(UVCGPU_EUNSUPPORTED, "indel_vntr_repeatsize_max > 255 or indel_BQ_max outside 1..32767");
     uvcgpu_region *r = new uvcgpu_region();
     memset(&r->prof, 0, sizeof(r->prof));
     memset(&r->R, 0, sizeof(r->R));
@@ -611,7 +545,7 @@ static int uvcgpu_region_fetch_impl(uvcgpu_region_t *r, int32_t g, void *dst, in
     if ((int64_t)group_bytes(r, g) != dst_bytes) return fail(UVCGPU_EINVAL, "bad destination size");
     int rc = uvcgpu_region_sync(r);
     if (rc) return rc;
-    const void *src = (g == UVC_F_RTR) ? (const void *)r->d_rtr : (g == UVC_F_BAQ) ? (const void *)r->d_baq : (const void *)(r->d_state + r->off[g]);
+    const void *src = (g == UVC_F_RTR) ? (const void *)(r->accumulated ? r->d_rtr : r->d_rtr0) /* P1b's edit of indelphred exists after accumulate only */ : (g == UVC_F_BAQ) ? (const void *)r->d_baq : (const void *)(r->d_state + r->off[g]);
     HIP_OK(hipMemcpy(dst, src, (size_t)dst_bytes, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -710,7 +644,18 @@ int uvcgpu_unpin_host_buffer(void *p) {
 
 // what uvc_vcf.cpp reads of a handle besides the public calls
 const char *uvcgpu_region_refseq(const uvcgpu_region_t *r, int32_t *beg, int32_t *end) { if (beg) *beg = r->beg; if (end) *end = r->end - 1; return r->refstring.c_str(); }
-const int32_t *uvcgpu_region_repeat_tracks(const uvcgpu_region_t *r, int64_t *npos) { if (npos) *npos = r->npos; return r->h_rtr.data(); }
+// begpos / tracklen / unitlen of every position as refstring2repeatvec built them (the first three planes of UVC_F_RTR before P1b): the
+// record writer's INFO/R3X2.  Fetched from the device on first use after a (re)bind; NULL when the copy fails.
+const int32_t *uvcgpu_region_repeat_tracks(const uvcgpu_region_t *cr, int64_t *npos) {
+    uvcgpu_region_t *r = const_cast<uvcgpu_region_t *>(cr);
+    if (npos) *npos = r->npos;
+    if (!r->h_rtr_valid) {
+        r->h_rtr.resize((size_t)3 * r->npos);
+        if (hipStreamSynchronize(r->stream) != hipSuccess || hipMemcpy(r->h_rtr.data(), r->d_rtr0, sizeof(int32_t) * r->h_rtr.size(), hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+        r->h_rtr_valid = true;
+    }
+    return r->h_rtr.data();
+}
 const UvcParams *uvcgpu_region_params(const uvcgpu_region_t *r) { return &r->P; }
 int uvcgpu_fail_(int code, const char *msg) { return fail(code, msg); }
 
@@ -1050,6 +995,8 @@ void uvcgpu_region_destroy(uvcgpu_region_t *r) {
     if (r->d_rtr) hipFree(r->d_rtr);
     if (r->d_rtr0) hipFree(r->d_rtr0);
     if (r->d_baq) hipFree(r->d_baq);
+    if (r->d_rtrwork) hipFree(r->d_rtrwork);
+    if (r->h_ref) (void)hipHostFree(r->h_ref);
     if (r->d_fsum) hipFree(r->d_fsum);
     if (r->d_win) hipFree(r->d_win);
     if (r->side) hipStreamDestroy(r->side);

@@ -42,7 +42,8 @@ __global__ void __launch_bounds__(256) k_read_facts(UvcPrepIn in, int32_t rbeg, 
     int32_t o_end = pos + 1, o_kind = 1, o_np2 = 0; int64_t o_gaps = 0, o_trows = 0, o_items = 0, o_ins = 0;
     int err = 0;
     const int fam = in.fam_id[i], strand = in.fam_strand[i];
-    if (fam < 0 || fam >= in.n_fams || strand > 1) err = 5;
+    const bool bad_fam = (fam < 0 || fam >= in.n_fams || strand < 0 || strand > 1);   // kept apart from err: a later check must not hide it (fam indexes fam_dflag below)
+    if (bad_fam) err = 5;
     if (in.seq_off[i] < 0 || in.seq_off[i] + lq > in.n_bases || in.cigar_off[i] < 0 || in.cigar_off[i] + nc > in.n_cigar_ops || nc < 1) err = 1;
     if (!err) {
         const uint32_t *cg = in.cigars + in.cigar_off[i];
@@ -92,7 +93,7 @@ __global__ void __launch_bounds__(256) k_read_facts(UvcPrepIn in, int32_t rbeg, 
     }
     if (err) { w_err = pmax(w_err, err); o_kind = 1; o_gaps = 0; o_ins = 0; o_np2 = 0; }
     endpos[i] = o_end; kind[i] = o_kind; n_p2[i] = o_np2; gaps[i] = o_gaps; trows[i] = o_trows; items[i] = o_items; ins[i] = o_ins; is_complex[i] = (o_kind != 0);
-    const bool ok_fam = (err != 5);
+    const bool ok_fam = !bad_fam;
     const int df = ok_fam ? (int)in.fam_dflag[fam] : 0;
     dflag_of[i] = df;
     if (df & 0x4) w_amp = 1;
@@ -289,7 +290,8 @@ extern "C" int uvc_prep_reads(const UvcPrepIn *inp, const UvcParams *P, int32_t 
     ALLOC(trows, int64_t, n, 0); ALLOC(items, int64_t, n, 0); ALLOC(ins, int64_t, n, 0); ALLOC(ins_off, int64_t, n, 0);
     Stage1 *dT1; ALLOC(dT1, Stage1, 1, 1);
     Stage2 *dT2; ALLOC(dT2, Stage2, 1, 1);
-    const size_t tmp_bytes = std::max(scan_tmp_bytes<int32_t>(n), scan_tmp_bytes<int64_t>(n)) + 64;
+    // sized for the LARGEST scan issued below: the per-read ones (n) and the fragment-depth scan over npos + 1 positions (nf >= 65536)
+    const size_t tmp_bytes = std::max(scan_tmp_bytes<int32_t>(std::max<int64_t>(n, npos + 2)), scan_tmp_bytes<int64_t>(n)) + 64;   // units and fragments never outnumber the reads
     void *tmp; ALLOC(tmp, char, tmp_bytes, 0);
     hipLaunchKernelGGL(k_read_facts, dim3(std::min(nblk(n, 256), 2048u)), dim3(256), 0, s, in, rbeg, rend, seg_eligible, out->endpos, out->kind, out->dflag_of, new_frag, new_fs, is_complex, n_p2, gaps, trows, items, ins, dT1);
     size_t tb = tmp_bytes;
