@@ -245,8 +245,14 @@ def main():
     n_reads_tile = int(np.mean([int(t["n_reads"]) for t in tiles]))
     input_bytes_tile = int(np.mean([sum(int(np.asarray(t[k]).nbytes) for k in ("pos", "mpos", "isize", "flag", "mapq", "nm", "l_qseq", "seq_off", "cigar_off", "n_cigar", "frag_id", "fam_id", "fam_strand", "bases", "quals", "cigars")) for t in tiles]))
 
+    refs = [t["refseq"].encode() if isinstance(t["refseq"], str) else bytes(t["refseq"]) for t in tiles]
+
     def prepare(k, host=False):
         R = Rs[k % T]
+        t = tiles[k % T]
+        if not os.environ.get("UVC_BENCH_NO_RESET"):
+            # the tile's own reference: CHAR_TO_SYMBOL, refstring2repeatvec and the two BAQ prefix-sum arrays on the device (uvc_rtr.hip)
+            R.reset(t["tid"], t["beg"], t["end"], refs[k % T])
         if host:
             R.set_reads(tiles[k % T])                          # PCIe-inclusive variant: the columns start in (pinned) host memory
         else:

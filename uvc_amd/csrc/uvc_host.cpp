@@ -87,6 +87,7 @@ struct uvcgpu_region {
     bool has_reads = false, accumulated = false;
     size_t p5flag_off = 0;
     bool state_released = false, state_zeroed = false;   // UvcScoreRequest::release_state: planes given up / already zeroed on the side stream (e_join marks the end)
+    size_t zeroed_bytes = 0;     // with state_zeroed: the slab is zero from its start up to here (a rebind to a region that fits keeps the benefit)
     RawReads W;                  // per-read input columns on the device (kept: uvcgpu_region_correct_bq re-derives the per-read records)
     int32_t *d_p2[4] = { nullptr, nullptr, nullptr, nullptr };   // P2 work list: alignment, begin, end, query offset
     int64_t n_bases = 0;
@@ -208,7 +209,7 @@ void uvcgpu_params_apply_platform(UvcParams *p, int32_t platform, int32_t centra
 static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t end, const char *refseq) {
     r->tid = tid; r->beg = beg; r->end = end + 1; r->npos = (int64_t)end - beg + 1;
     r->refstring.assign(refseq, (size_t)(end - beg));
-    r->accumulated = false; r->gap_ready = false; r->hap_ready = false; r->buckets_clean = false; r->state_released = false; r->state_zeroed = false;
+    r->accumulated = false; r->gap_ready = false; r->hap_ready = false; r->state_released = false;
     r->h_rtr_valid = false;
     // one slab for all per-position planes (+ the transient bucket planes), 8-byte groups first
     const int order[] = { UVC_F_PREP64, UVC_F_SEG64, UVC_F_FAMINFO64, UVC_F_PREP32, UVC_F_THRES, UVC_F_SEG32, UVC_F_VQ, UVC_F_BQSUM, UVC_F_FRAG, UVC_F_FAM, UVC_F_FAMINFO32, UVC_F_DUPLEX };
@@ -217,6 +218,9 @@ static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t 
     r->p5flag_off = o; o += ((size_t)2 * r->npos + 255) & ~(size_t)255;   // one byte per (strand, position): a P5 bucket was filled (k_p5b skips the others); zeroed with the planes
     r->bucket_off = o; o += (size_t)4 * r->npos * 2 * NSYM * NBUCKETS;
     r->state_bytes = o;
+    // planes that the last score zeroed on the side stream (release_state) stay zero under the new layout when it fits into what was zeroed
+    r->state_zeroed = r->state_zeroed && r->npos <= r->npos_cap && r->state_bytes <= r->zeroed_bytes;
+    r->buckets_clean = r->state_zeroed;
     const int vmax = r->P.indel_vntr_repeatsize_max, smax = r->P.indel_str_repeatsize_max, bqm = r->P.indel_BQ_max;
     const size_t n_rtr = (size_t)UVC_NRTR * r->npos;
     if (r->npos > r->npos_cap) {
@@ -965,7 +969,7 @@ static int uvcgpu_region_score_impl(uvcgpu_region_t *r, const UvcScoreRequest *r
         else if (rq.release_state && r->side) {   // the scoring kernels are done: zero the planes on the side stream under the D2H of the records
             if (hipEventRecord(r->e_fork, r->stream) == hipSuccess && hipStreamWaitEvent(r->side, r->e_fork, 0) == hipSuccess
                 && hipMemsetAsync(r->d_state, 0, r->buckets_clean ? r->bucket_off : r->state_bytes, r->side) == hipSuccess && hipEventRecord(r->e_join, r->side) == hipSuccess) {
-                r->state_released = true; r->state_zeroed = true;
+                r->state_released = true; r->state_zeroed = true; r->zeroed_bytes = r->state_bytes;
             }
         }
         if (!rc && n_out > 0 && (hipMemcpy2DAsync(out->fields, sizeof(int32_t) * out->capacity, src, sizeof(int32_t) * r->score_capacity, sizeof(int32_t) * n_out, UVC_NUM_SCORE_FIELDS, hipMemcpyDeviceToHost, r->stream) != hipSuccess

@@ -172,8 +172,7 @@ class Region:
         else:
             fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p]
             self._check(fn(self.h, tid, beg, end, ref))
-        self.tid, self.beg, self.end, self.npos = tid, beg, end, end - beg + 1
-        self._free_score_buf()
+        self.tid, self.beg, self.end, self.npos = tid, beg, end, end - beg + 1   # (the records buffer stays: score() replaces it when the capacity asked for changes)
 
     def set_reads(self, reads):
         soa, keep = pack_reads(reads)
