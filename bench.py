@@ -220,6 +220,12 @@ def main():
         tiles = [_gen_tile(sp) for sp in specs]
     t_gen = time.perf_counter() - t_gen
 
+    # the form the columns are handed over in: BAM's own 4-bit bases and no offset columns (UvcReadSoA::bases4, seq_off = cigar_off = NULL:
+    # 530 instead of 712 MB per tile; the library unpacks and scans on the device) unless UVC_BENCH_PLAIN asks for one byte per base + offsets
+    COLS = ("pos", "mpos", "isize", "flag", "mapq", "nm", "l_qseq", "seq_off", "cigar_off", "n_cigar", "frag_id", "fam_id", "fam_strand", "bases", "bases4", "quals", "cigars")
+    if not os.environ.get("UVC_BENCH_PLAIN"):
+        from uvc_amd import region as _region
+        tiles = [_region.compact_form(t) for t in tiles]
     import torch
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -243,7 +249,7 @@ def main():
     T = len(tiles)
     cap = 15 * (region_len + 2) if args.all_out else max(65536, region_len // 4)
     n_reads_tile = int(np.mean([int(t["n_reads"]) for t in tiles]))
-    input_bytes_tile = int(np.mean([sum(int(np.asarray(t[k]).nbytes) for k in ("pos", "mpos", "isize", "flag", "mapq", "nm", "l_qseq", "seq_off", "cigar_off", "n_cigar", "frag_id", "fam_id", "fam_strand", "bases", "quals", "cigars")) for t in tiles]))
+    input_bytes_tile = int(np.mean([sum(int(np.asarray(t[k]).nbytes) for k in COLS if t.get(k) is not None) for t in tiles]))
 
     refs = [t["refseq"].encode() if isinstance(t["refseq"], str) else bytes(t["refseq"]) for t in tiles]
 
@@ -310,7 +316,9 @@ def main():
         lib.dll.uvcgpu_host_alloc.restype, lib.dll.uvcgpu_host_alloc.argtypes = C.c_int, [C.POINTER(C.c_void_p), C.c_int64]
         lib.dll.uvcgpu_host_free.restype, lib.dll.uvcgpu_host_free.argtypes = C.c_int, [C.c_void_p]
         for t in tiles:
-            for k in ("pos", "mpos", "isize", "flag", "mapq", "nm", "l_qseq", "seq_off", "cigar_off", "n_cigar", "frag_id", "fam_id", "fam_strand", "bases", "quals", "cigars"):
+            for k in COLS:
+                if t.get(k) is None:
+                    continue
                 a = np.ascontiguousarray(t[k])
                 hp = C.c_void_p()
                 if a.nbytes and not os.environ.get("UVC_BENCH_REGISTER") and lib.dll.uvcgpu_host_alloc(C.byref(hp), C.c_int64(a.nbytes)) == 0 and hp.value:
@@ -351,7 +359,7 @@ def main():
             lib.dll.uvcgpu_unpin_host_buffer(C.c_void_p(a.ctypes.data))
         torch.cuda.synchronize()
         for t in tiles:   # the views die with their memory
-            for k in ("pos", "mpos", "isize", "flag", "mapq", "nm", "l_qseq", "seq_off", "cigar_off", "n_cigar", "frag_id", "fam_id", "fam_strand", "bases", "quals", "cigars"):
+            for k in COLS:
                 t[k] = None
         for hp in host_bufs:
             lib.dll.uvcgpu_host_free(hp)

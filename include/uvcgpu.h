@@ -94,8 +94,9 @@ typedef struct UvcReadSoA {
     const uint8_t  *mapq;       /* core.qual                                                    */
     const int32_t  *nm;         /* NM aux tag, -1 when absent (main.hpp:980-981)                */
     const int32_t  *l_qseq;     /* core.l_qseq                                                  */
-    const int64_t  *seq_off;    /* offset of the read's first base in bases[] / quals[]         */
-    const int64_t  *cigar_off;  /* offset of the read's first op in cigars[]                    */
+    const int64_t  *seq_off;    /* offset of the read's first base in bases[] / quals[]; NULL = the reads lie back to back in read
+                                   order (seq_off[i] = sum of l_qseq[0..i)): the library derives the offsets on the device            */
+    const int64_t  *cigar_off;  /* offset of the read's first op in cigars[]; NULL = back to back in read order                     */
     const int32_t  *n_cigar;    /* core.n_cigar                                                 */
     const int32_t  *frag_id;    /* fragment (qname group) id, unique within (fam_id, strand)    */
     const int32_t  *fam_id;     /* family index, 0..n_fams-1                                    */
@@ -108,6 +109,12 @@ typedef struct UvcReadSoA {
     int32_t n_fams;
     const uint8_t  *fam_dflag;  /* MolecularBarcode::duplexflag per family (grouping.cpp:931):
                                    0x1 UMI found, 0x2 duplex found, 0x4 amplicon, 0x8 borders preserved */
+    /* Alternative to `bases` (then bases == NULL): the bases as the BAM record holds them (bam_get_seq: 4-bit codes "=ACMGRSVTWYHKDBN",
+     * two per byte, high nibble first, every read starting on a byte boundary), the reads back to back in read order -- read i's bytes
+     * start at sum of (l_qseq[j] + 1) / 2 over j < i.  The library applies seq_nt16_int[] on the device.  A quarter less to copy than
+     * one byte per base + qual. */
+    const uint8_t  *bases4;
+    int64_t n_bases4_bytes;
 } UvcReadSoA;
 
 /* ---------------------------------------------------------------- per-position state (a2) -- */

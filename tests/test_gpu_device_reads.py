@@ -32,10 +32,16 @@ class DeviceColumns:
                 assert self.hip.hipMemcpy(p.value + shift, a.ctypes.data, a.nbytes, 1) == 0
             return p.value + shift
         for name, dt in region._READ_FIELDS:
-            setattr(soa, name, put(reads[name], dt))
+            if reads.get(name) is not None:   # the compact form has no seq_off / cigar_off
+                setattr(soa, name, put(reads[name], dt))
         for name, dt, cnt in (("bases", np.uint8, "n_bases"), ("quals", np.uint8, "n_bases"), ("cigars", np.uint32, "n_cigar_ops")):
+            if reads.get(name) is None:
+                continue
             setattr(soa, name, put(reads[name], dt, misalign if name != "cigars" else 0))
             setattr(soa, cnt, int(np.asarray(reads[name]).size))
+        if reads.get("bases") is None:
+            soa.bases4 = put(reads["bases4"], np.uint8, misalign)
+            soa.n_bases4_bytes = int(reads["bases4"].size)
         soa.n_fams = int(reads["n_fams"])
         soa.fam_dflag = put(reads["fam_dflag"], np.uint8)
         self.soa = soa
@@ -69,3 +75,38 @@ def test_device_columns_equal_host_columns(kw, gpu_lib):
         assert sums == want_sums and all(np.array_equal(rec[k], want_rec[k]) for k in rec), misalign
         Rd.close(); cols.free()
     Rh.close()
+
+
+@pytest.mark.parametrize("kw", [dict(seed=31, region_len=5000, depth=100), dict(seed=32, region_len=2000, depth=300, umi=True), dict(weird=7)])
+def test_compact_columns_equal_plain_columns(kw, gpu_lib):
+    """UvcReadSoA::bases4 (BAM's 4-bit codes, reads back to back) with seq_off / cigar_off left NULL: the offsets are prefix sums on the
+    device, the bases go through seq_nt16_int there -- same planes, same records, from host columns and from device columns."""
+    if "weird" in kw:   # the fuzz generator: read lengths of every parity (each read starts on a byte boundary of bases4), InDels, clips
+        from test_gpu_fuzz import weird_region
+        reads = weird_region(kw["weird"])
+        assert (np.asarray(reads["l_qseq"]) % 2 == 1).any()
+    else:
+        reads = synth.generate_region(**kw)
+    p = region.default_params(gpu_lib)
+    Rh = region.Region(gpu_lib, p, reads["tid"], reads["beg"], reads["end"], reads["refseq"])
+    Rh.set_reads(reads)
+    want_sums, want_rec = planes_and_records(Rh)
+    comp = region.compact_form(reads)
+    assert "bases" not in comp and comp["bases4"].size < reads["bases"].size * 0.51
+    Rc = region.Region(gpu_lib, p, reads["tid"], reads["beg"], reads["end"], reads["refseq"])
+    Rc.set_reads(comp)
+    sums, rec = planes_and_records(Rc)
+    assert sums == want_sums and all(np.array_equal(rec[k], want_rec[k]) for k in rec)
+    for misalign in (0, 1):
+        cols = DeviceColumns(comp, misalign)
+        Rc.reset(reads["tid"], reads["beg"], reads["end"], reads["refseq"])
+        Rc.set_reads_device((cols.soa, cols))
+        sums, rec = planes_and_records(Rc)
+        assert sums == want_sums and all(np.array_equal(rec[k], want_rec[k]) for k in rec), misalign
+        cols.free()
+    # a packed column that is too short for the read lengths is refused, not read past its end
+    bad = dict(comp); bad["bases4"] = comp["bases4"][: comp["bases4"].size // 2]
+    with pytest.raises(region.UvcError) as e:
+        Rc.reset(reads["tid"], reads["beg"], reads["end"], reads["refseq"]); Rc.set_reads(bad)
+    assert e.value.code == -2
+    Rc.close(); Rh.close()

@@ -40,6 +40,7 @@ class UvcReadSoA(C.Structure):
         ("n_bases", C.c_int64), ("bases", C.c_void_p), ("quals", C.c_void_p),
         ("n_cigar_ops", C.c_int64), ("cigars", C.c_void_p),
         ("n_fams", C.c_int32), ("fam_dflag", C.c_void_p),
+        ("bases4", C.c_void_p), ("n_bases4_bytes", C.c_int64),
     ]
 
 

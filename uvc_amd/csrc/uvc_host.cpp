@@ -43,6 +43,9 @@ extern "C" void uvc_launch_hap_events(const RegionDev *R, const UvcParams *P, co
 extern "C" void uvc_launch_gather_columns(const char *const *base, const int32_t *first_col, const int32_t *elem, int64_t npos, const int32_t *d_xs, int64_t n, long long *d_out, hipStream_t s);
 extern "C" int uvc_sort_by_pos_cls(const int32_t *d_pos, const int32_t *d_cls, int32_t beg, int pos_bits, int cls_bits, int64_t n, uint32_t *work, void *tmp, size_t tmp_bytes, hipStream_t s);
 extern "C" size_t uvc_sort32_tmp_bytes(size_t n);
+extern "C" size_t uvc_prep_compact_tmp_bytes(int64_t n);
+extern "C" int uvc_prep_compact(const int32_t *l_qseq, const int32_t *n_cigar, int64_t n, int64_t n_bases, const uint8_t *bases4, int64_t n_b4, int64_t *seq_off_out, const int64_t *seq_off_in,
+                                int64_t *cigar_off_out, int64_t *b4_off, uint8_t *bases_out, int32_t *bad, void *tmp, size_t tmp_bytes, hipStream_t s);
 extern "C" void uvc_launch_gather4(const uint32_t *perm, int64_t n, const int32_t *a0, const int32_t *a1, const int32_t *a2, const int32_t *a3, int32_t *o0, int32_t *o1, int32_t *o2, int32_t *o3, hipStream_t s);
 extern "C" void uvc_launch_rank_from_sorted(const uint32_t *perm, int64_t n, int64_t n_first, int32_t *out_ids, int32_t *rank, hipStream_t s);
 
@@ -316,6 +319,25 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
     const int64_t n = d->n_reads;
     if (r->npos >= ((int64_t)1 << 29)) return fail(UVCGPU_EUNSUPPORTED, "region longer than 2^29");
     if (d->n_bases >= ((int64_t)1 << 31)) return fail(UVCGPU_EUNSUPPORTED, "more than 2^31 read bases in one region: split the region");
+    if (!d->bases && !d->bases4 && d->n_bases > 0) return fail(UVCGPU_EINVAL, "neither bases nor bases4");
+    // compact input forms: offsets as prefix sums of l_qseq / n_cigar, BAM's 4-bit base codes unpacked on the device
+    UvcReadSoA dd = *d;
+    int32_t *d_bad = nullptr;
+    if (!d->seq_off || !d->cigar_off || !d->bases) {
+        int rc0;
+        int64_t *so = nullptr, *co = nullptr, *b4o = nullptr; uint8_t *ub = nullptr; char *tmp = nullptr;
+        const size_t tb = uvc_prep_compact_tmp_bytes(n);
+        if ((rc0 = dev_alloc(r, tb, &tmp)) || (rc0 = dev_alloc(r, 1, &d_bad, true))) return rc0;
+        if (!d->seq_off && (rc0 = dev_alloc(r, (size_t)n, &so))) return rc0;
+        if (!d->cigar_off && (rc0 = dev_alloc(r, (size_t)n, &co))) return rc0;
+        if (!d->bases && ((rc0 = dev_alloc(r, (size_t)n, &b4o)) || (rc0 = dev_alloc(r, (size_t)std::max<int64_t>(d->n_bases, 1), &ub)))) return rc0;
+        const int e = uvc_prep_compact(d->l_qseq, d->n_cigar, n, d->n_bases, d->bases ? nullptr : d->bases4, d->n_bases4_bytes, so, d->seq_off, co, b4o, ub, d_bad, tmp, tb, r->stream);
+        if (e) return fail(UVCGPU_EDEVICE, std::string("offset scans: ") + hipGetErrorString((hipError_t)e));
+        if (so) dd.seq_off = so;
+        if (co) dd.cigar_off = co;
+        if (ub) dd.bases = ub;
+        d = &dd;
+    }
     UvcPrepIn in; memset(&in, 0, sizeof(in));
     in.n_reads = n; in.n_bases = d->n_bases; in.n_cigar_ops = d->n_cigar_ops; in.n_fams = d->n_fams;
     in.pos = d->pos; in.mpos = d->mpos; in.isize = d->isize; in.nm = d->nm; in.l_qseq = d->l_qseq; in.n_cigar = d->n_cigar; in.frag_id = d->frag_id; in.fam_id = d->fam_id;
@@ -413,9 +435,11 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
     }
     HIP_OK(hipGetLastError());
     {   // the queue of mismatching bases (k_p2_fast -> k_p2_mism) is sized from the count the prelude made
-        unsigned long long total = 0;
+        unsigned long long total = 0; int32_t bad4 = 0;
         HIP_OK(hipMemcpyAsync(&total, R.mis_total, sizeof(total), hipMemcpyDeviceToHost, r->stream));
+        if (d_bad) HIP_OK(hipMemcpyAsync(&bad4, d_bad, sizeof(bad4), hipMemcpyDeviceToHost, r->stream));
         HIP_OK(hipStreamSynchronize(r->stream));
+        if (bad4) return fail(UVCGPU_EINVAL, "bases4 / l_qseq / n_bases do not fit together");
         if (total > ((unsigned long long)1 << 30)) return fail(UVCGPU_EUNSUPPORTED, "more than 2^30 mismatching bases in one region");
         MisItem *q = nullptr;
         if ((rc = dev_alloc(r, (size_t)(total + 64), &q))) return rc;
@@ -442,8 +466,12 @@ static int uvcgpu_region_set_reads_impl(uvcgpu_region_t *r, const UvcReadSoA *in
     int rc;
 #define UP(field, T, count) { T *q; if ((rc = upload_raw(r, in->field, (size_t)(count), &q))) return rc; d.field = q; }
     UP(pos, int32_t, n) UP(mpos, int32_t, n) UP(isize, int32_t, n) UP(flag, uint16_t, n) UP(mapq, uint8_t, n) UP(nm, int32_t, n) UP(l_qseq, int32_t, n)
-    UP(seq_off, int64_t, n) UP(cigar_off, int64_t, n) UP(n_cigar, int32_t, n) UP(frag_id, int32_t, n) UP(fam_id, int32_t, n) UP(fam_strand, uint8_t, n)
-    UP(bases, uint8_t, in->n_bases) UP(quals, uint8_t, in->n_bases) UP(cigars, uint32_t, in->n_cigar_ops) UP(fam_dflag, uint8_t, in->n_fams)
+    UP(n_cigar, int32_t, n) UP(frag_id, int32_t, n) UP(fam_id, int32_t, n) UP(fam_strand, uint8_t, n)
+    if (in->seq_off) UP(seq_off, int64_t, n)
+    if (in->cigar_off) UP(cigar_off, int64_t, n)
+    if (in->bases) UP(bases, uint8_t, in->n_bases)
+    else if (in->bases4) { if (in->n_bases4_bytes < 0) return fail(UVCGPU_EINVAL, "bad reads"); UP(bases4, uint8_t, in->n_bases4_bytes) }
+    UP(quals, uint8_t, in->n_bases) UP(cigars, uint32_t, in->n_cigar_ops) UP(fam_dflag, uint8_t, in->n_fams)
 #undef UP
     if (timing) { hipStreamSynchronize(r->stream); const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[uvcgpu set_reads] %-28s %8.2f ms\n", "H2D of the columns", std::chrono::duration<double, std::milli>(t - t_prev).count()); t_prev = t; }
     return set_reads_on_device(r, &d, timing, t_prev);

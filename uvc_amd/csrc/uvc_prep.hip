@@ -9,6 +9,7 @@
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 #include <stdint.h>
 #include "uvc_prep.h"
 
@@ -266,6 +267,43 @@ __global__ void __launch_bounds__(256) k_take_units(const uint32_t *perm, const 
 unsigned nblk(int64_t n, int b) { return (unsigned)std::max<int64_t>((n + b - 1) / b, 1); }
 template <class T> size_t scan_tmp_bytes(int64_t n) { size_t b = 0; T *p = nullptr; rocprim::exclusive_scan(nullptr, b, p, p, T(0), (size_t)std::max<int64_t>(n, 1), rocprim::plus<T>(), (hipStream_t)0); return b; }
 }   // namespace
+
+// ---- compact input forms (UvcReadSoA::seq_off / cigar_off == NULL, UvcReadSoA::bases4): offsets by prefix sums, BAM's 4-bit base codes
+// through seq_nt16_int[] (htslib: A C G T -> 0..3, everything else 4) into the one-byte-per-base array the kernels read
+namespace {
+struct Widen { __device__ int64_t operator()(int32_t v) const { return (int64_t)v; } };
+struct HalfUp { __device__ int64_t operator()(int32_t v) const { return (int64_t)((v + 1) >> 1); } };
+__global__ void __launch_bounds__(256) k_unpack_bases4(const uint8_t *b4, int64_t n_b4, const int64_t *b4_off, const int64_t *seq_off, const int32_t *l_qseq, int64_t n, int64_t n_bases,
+                                                       uint8_t *bases, int32_t *bad) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n; i += nwaves) {
+        const int32_t lq = l_qseq[i];
+        const int64_t so = seq_off[i], bo = b4_off[i];
+        if (lq < 0 || so < 0 || so + lq > n_bases || bo + ((lq + 1) >> 1) > n_b4) { if (lane == 0) *bad = 1; continue; }
+        const uint8_t *src = b4 + bo; uint8_t *dst = bases + so;
+        for (int k = lane; k < lq; k += 64) {
+            const int byte = src[k >> 1], code = (k & 1) ? (byte & 15) : (byte >> 4);
+            dst[k] = (uint8_t)(code == 1 ? 0 : code == 2 ? 1 : code == 4 ? 2 : code == 8 ? 3 : 4);
+        }
+    }
+}
+}   // namespace
+extern "C" size_t uvc_prep_compact_tmp_bytes(int64_t n) { return scan_tmp_bytes<int64_t>(n) + 64; }
+// seq_off / cigar_off / b4_off: outputs (device, n entries each) or NULL when the caller supplied that column; bases_out: n_bases bytes, with bases4
+extern "C" int uvc_prep_compact(const int32_t *l_qseq, const int32_t *n_cigar, int64_t n, int64_t n_bases, const uint8_t *bases4, int64_t n_b4,
+                                int64_t *seq_off_out, const int64_t *seq_off_in, int64_t *cigar_off_out, int64_t *b4_off, uint8_t *bases_out, int32_t *bad,
+                                void *tmp, size_t tmp_bytes, hipStream_t s) {
+    size_t tb = tmp_bytes;
+    hipError_t e = hipSuccess;
+    if (seq_off_out) { e = rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(l_qseq, Widen()), seq_off_out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s); tb = tmp_bytes; }
+    if (e == hipSuccess && cigar_off_out) { e = rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(n_cigar, Widen()), cigar_off_out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s); tb = tmp_bytes; }
+    if (e == hipSuccess && bases4) {
+        e = rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(l_qseq, HalfUp()), b4_off, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s);
+        if (e == hipSuccess) hipLaunchKernelGGL(k_unpack_bases4, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 65536)), dim3(256), 0, s, bases4, n_b4, b4_off, seq_off_out ? seq_off_out : seq_off_in, l_qseq, n, n_bases, bases_out, bad);
+    }
+    return (int)e;
+}
 
 static inline int pos_bits_of(int64_t npos) { int b = 1; while (((int64_t)1 << b) < npos + 1) b++; return b; }
 extern "C" int uvc_sort_by_pos_cls(const int32_t *d_pos, const int32_t *d_cls, int32_t beg, int pos_bits, int cls_bits, int64_t n, uint32_t *work, void *tmp, size_t tmp_bytes, hipStream_t s);

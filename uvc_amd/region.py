@@ -71,26 +71,72 @@ _READ_FIELDS = [("pos", np.int32), ("mpos", np.int32), ("isize", np.int32), ("fl
                 ("frag_id", np.int32), ("fam_id", np.int32), ("fam_strand", np.uint8)]
 
 
-def pack_reads(reads):
-    """dict of numpy arrays -> (UvcReadSoA, keepalive list)."""
-    keep = []
+_NT16 = np.array([1, 2, 4, 8, 15], dtype=np.uint8)   # A C G T N as BAM's 4-bit codes (seq_nt16_str "=ACMGRSVTWYHKDBN")
+
+
+def compact_form(reads):
+    """The same reads in the compact input form of UvcReadSoA: `bases4` = the bases as a BAM record holds them (two 4-bit codes per byte, high
+    nibble first, every read on a byte boundary, reads back to back) instead of one byte per base, and no seq_off / cigar_off columns (the
+    library derives them on the device).  Needs the reads back to back in read order, which is how every packer here lays them out."""
+    n = int(reads["n_reads"])
+    lq = np.asarray(reads["l_qseq"], dtype=np.int64)
+    nc = np.asarray(reads["n_cigar"], dtype=np.int64)
+    so = np.concatenate(([0], np.cumsum(lq)))[:n]
+    co = np.concatenate(([0], np.cumsum(nc)))[:n]
+    if not (np.array_equal(so, np.asarray(reads["seq_off"])) and np.array_equal(co, np.asarray(reads["cigar_off"]))):
+        raise ValueError("compact_form needs reads that lie back to back in read order")
+    codes = _NT16[np.minimum(np.asarray(reads["bases"], dtype=np.uint8), 4)]
+    nb = (lq + 1) // 2
+    bo = np.concatenate(([0], np.cumsum(nb)))
+    if n and not (lq % 2).any():                                     # every read starts on an even base index: two neighbours per byte
+        out4 = (codes[0::2] << 4) | codes[1::2]
+    else:
+        out4 = np.zeros(int(bo[-1]), dtype=np.uint8)
+        if n:
+            k = np.arange(int(lq.sum())) - np.repeat(so, lq)            # index of every base inside its read
+            byte = np.repeat(bo[:n], lq) + k // 2
+            hi = (k % 2 == 0)
+            out4[byte[hi]] = codes[hi] << 4                              # each byte has one high and at most one low nibble
+            out4[byte[~hi]] |= codes[~hi]
+    c = {k_: v for k_, v in reads.items() if k_ not in ("bases", "seq_off", "cigar_off")}
+    c["bases4"] = out4
+    return c
+
+
+def _fill_soa(reads, put):
+    """UvcReadSoA from a dict of columns; `put(array, dtype) -> address` places a column (host or device).  Columns a compact dict leaves
+    out (seq_off, cigar_off, bases) stay NULL."""
     soa = _ffi.UvcReadSoA()
     soa.n_reads = int(reads["n_reads"])
     for name, dt in _READ_FIELDS:
+        if name in ("seq_off", "cigar_off") and reads.get(name) is None:
+            continue
         a = np.ascontiguousarray(reads[name], dtype=dt)
         assert a.shape == (soa.n_reads,), name
-        keep.append(a)
-        setattr(soa, name, a.ctypes.data)
-    for name, dt, cnt in (("bases", np.uint8, "n_bases"), ("quals", np.uint8, "n_bases"), ("cigars", np.uint32, "n_cigar_ops")):
-        a = np.ascontiguousarray(reads[name], dtype=dt)
-        keep.append(a)
-        setattr(soa, name, a.ctypes.data)
-        setattr(soa, cnt, a.size)
-    d = np.ascontiguousarray(reads["fam_dflag"], dtype=np.uint8)
-    keep.append(d)
+        setattr(soa, name, put(a, dt))
+    soa.n_bases = int(np.asarray(reads["quals"]).size)
+    soa.n_cigar_ops = int(np.asarray(reads["cigars"]).size)
+    soa.quals = put(reads["quals"], np.uint8)
+    soa.cigars = put(reads["cigars"], np.uint32)
+    if reads.get("bases") is not None:
+        soa.bases = put(reads["bases"], np.uint8)
+    else:
+        soa.bases4 = put(reads["bases4"], np.uint8)
+        soa.n_bases4_bytes = int(np.asarray(reads["bases4"]).size)
     soa.n_fams = int(reads["n_fams"])
-    soa.fam_dflag = d.ctypes.data
-    return soa, keep
+    soa.fam_dflag = put(reads["fam_dflag"], np.uint8)
+    return soa
+
+
+def pack_reads(reads):
+    """dict of numpy arrays -> (UvcReadSoA, keepalive list)."""
+    keep = []
+
+    def put(a, dt):
+        a = np.ascontiguousarray(a, dtype=dt)
+        keep.append(a)
+        return a.ctypes.data
+    return _fill_soa(reads, put), keep
 
 
 def device_reads(reads, device):
@@ -100,8 +146,6 @@ def device_reads(reads, device):
     order leaves torch without a GPU.  Without torch, allocate through the runtime the library links (tests/test_gpu_device_reads.py)."""
     import torch
     keep = []
-    soa = _ffi.UvcReadSoA()
-    soa.n_reads = int(reads["n_reads"])
 
     def put(a, dt):
         a = np.ascontiguousarray(a, dtype=dt)
@@ -109,13 +153,7 @@ def device_reads(reads, device):
         t = torch.from_numpy(a.view(np.uint8).reshape(-1)).to(device)
         keep.append(t)
         return t.data_ptr() if t.numel() else 0
-    for name, dt in _READ_FIELDS:
-        setattr(soa, name, put(reads[name], dt))
-    for name, dt, cnt in (("bases", np.uint8, "n_bases"), ("quals", np.uint8, "n_bases"), ("cigars", np.uint32, "n_cigar_ops")):
-        setattr(soa, name, put(reads[name], dt))
-        setattr(soa, cnt, int(np.asarray(reads[name]).size))
-    soa.n_fams = int(reads["n_fams"])
-    soa.fam_dflag = put(reads["fam_dflag"], np.uint8)
+    soa = _fill_soa(reads, put)
     torch.cuda.synchronize(device)
     return soa, keep
 
