@@ -6,7 +6,10 @@ from uvc_amd import region
 from rtr_cases import fuzz_reference
 lib = region.gpu_lib(); assert lib.dll.uvcgpu_init(0) == 0
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
-refs = [fuzz_reference(s, n, kinds="plain").encode() for s in range(3)]
+import numpy as np
+from uvc_amd import synth
+# the bench's own kind of reference (synth.make_reference: random + planted STRs every few kb), then a repeat-dense fuzz reference
+refs = [np.frombuffer(b"ACGT", dtype=np.uint8)[synth.make_reference(np.random.default_rng(s), n)].tobytes() for s in range(2)] + [fuzz_reference(7, n, kinds="plain").encode()]
 R = region.Region(lib, region.default_params(lib), 0, 1000000, 1000000 + n, refs[0])
 lib.dll.uvcgpu_region_sync.argtypes = [C.c_void_p]
 for rep in range(3):

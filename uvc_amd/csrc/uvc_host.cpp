@@ -44,8 +44,8 @@ extern "C" void uvc_launch_gather_columns(const char *const *base, const int32_t
 extern "C" int uvc_sort_by_pos_cls(const int32_t *d_pos, const int32_t *d_cls, int32_t beg, int pos_bits, int cls_bits, int64_t n, uint32_t *work, void *tmp, size_t tmp_bytes, hipStream_t s);
 extern "C" size_t uvc_sort32_tmp_bytes(size_t n);
 extern "C" size_t uvc_prep_compact_tmp_bytes(int64_t n);
-extern "C" int uvc_prep_compact(const int32_t *l_qseq, const int32_t *n_cigar, int64_t n, int64_t n_bases, const uint8_t *bases4, int64_t n_b4, int64_t *seq_off_out, const int64_t *seq_off_in,
-                                int64_t *cigar_off_out, int64_t *b4_off, uint8_t *bases_out, int32_t *bad, void *tmp, size_t tmp_bytes, hipStream_t s);
+extern "C" int uvc_prep_compact(const int32_t *l_qseq, const int32_t *n_cigar, int64_t n, int64_t n_bases, const uint8_t *bases4, int64_t n_b4, const uint8_t *quals, int64_t *seq_off_out, const int64_t *seq_off_in,
+                                int64_t *cigar_off_out, int64_t *b4_off, uint8_t *bases_out, uint16_t *bq_out, int32_t *bad, void *tmp, size_t tmp_bytes, hipStream_t s);
 extern "C" void uvc_launch_gather4(const uint32_t *perm, int64_t n, const int32_t *a0, const int32_t *a1, const int32_t *a2, const int32_t *a3, int32_t *o0, int32_t *o1, int32_t *o2, int32_t *o3, hipStream_t s);
 extern "C" void uvc_launch_rank_from_sorted(const uint32_t *perm, int64_t n, int64_t n_first, int32_t *out_ids, int32_t *rank, hipStream_t s);
 
@@ -322,7 +322,7 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
     if (!d->bases && !d->bases4 && d->n_bases > 0) return fail(UVCGPU_EINVAL, "neither bases nor bases4");
     // compact input forms: offsets as prefix sums of l_qseq / n_cigar, BAM's 4-bit base codes unpacked on the device
     UvcReadSoA dd = *d;
-    int32_t *d_bad = nullptr;
+    int32_t *d_bad = nullptr; uint16_t *bq_done = nullptr;
     if (!d->seq_off || !d->cigar_off || !d->bases) {
         int rc0;
         int64_t *so = nullptr, *co = nullptr, *b4o = nullptr; uint8_t *ub = nullptr; char *tmp = nullptr;
@@ -330,8 +330,8 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
         if ((rc0 = dev_alloc(r, tb, &tmp)) || (rc0 = dev_alloc(r, 1, &d_bad, true))) return rc0;
         if (!d->seq_off && (rc0 = dev_alloc(r, (size_t)n, &so))) return rc0;
         if (!d->cigar_off && (rc0 = dev_alloc(r, (size_t)n, &co))) return rc0;
-        if (!d->bases && ((rc0 = dev_alloc(r, (size_t)n, &b4o)) || (rc0 = dev_alloc(r, (size_t)std::max<int64_t>(d->n_bases, 1), &ub)))) return rc0;
-        const int e = uvc_prep_compact(d->l_qseq, d->n_cigar, n, d->n_bases, d->bases ? nullptr : d->bases4, d->n_bases4_bytes, so, d->seq_off, co, b4o, ub, d_bad, tmp, tb, r->stream);
+        if (!d->bases && ((rc0 = dev_alloc(r, (size_t)n, &b4o)) || (rc0 = dev_alloc(r, (size_t)std::max<int64_t>(d->n_bases, 1), &ub)) || (rc0 = dev_alloc(r, (size_t)std::max<int64_t>(d->n_bases, 1), &bq_done)))) return rc0;
+        const int e = uvc_prep_compact(d->l_qseq, d->n_cigar, n, d->n_bases, d->bases ? nullptr : d->bases4, d->n_bases4_bytes, d->quals, so, d->seq_off, co, b4o, ub, bq_done, d_bad, tmp, tb, r->stream);
         if (e) return fail(UVCGPU_EDEVICE, std::string("offset scans: ") + hipGetErrorString((hipError_t)e));
         if (so) dd.seq_off = so;
         if (co) dd.cigar_off = co;
@@ -353,7 +353,8 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
     R.bases = d->bases; R.quals = d->quals; R.cigars = d->cigars;
     R.frag_off[0] = 0; R.frag_off[1] = o.n_frag_strand0; R.frag_off[2] = o.n_frags;
     const int64_t n_simple = o.n_simple; const size_t nf = (size_t)o.n_frags;
-    { uint16_t *b = nullptr; if ((rc = dev_alloc(r, (size_t)std::max<int64_t>(d->n_bases, 1), &b))) return rc; R.bq = b; R.bq_bytes = (uint32_t)(d->n_bases * 2);
+    if (bq_done) { R.bq = bq_done; R.bq_bytes = (uint32_t)(d->n_bases * 2); }   // packed while the 4-bit bases were unpacked
+    else { uint16_t *b = nullptr; if ((rc = dev_alloc(r, (size_t)std::max<int64_t>(d->n_bases, 1), &b))) return rc; R.bq = b; R.bq_bytes = (uint32_t)(d->n_bases * 2);
       uvc_launch_pack_bq(R.bases, R.quals, b, d->n_bases, r->stream); }
     { AlnRec *a; if ((rc = dev_alloc(r, (size_t)n, &a))) return rc; R.alns = a; R.n_alns = (int32_t)n; }
     { AlnRec *a; if ((rc = dev_alloc(r, (size_t)n_simple, &a))) return rc; R.fast = a; R.n_fast = (int32_t)n_simple; }

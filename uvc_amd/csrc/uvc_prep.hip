@@ -273,34 +273,73 @@ template <class T> size_t scan_tmp_bytes(int64_t n) { size_t b = 0; T *p = nullp
 namespace {
 struct Widen { __device__ int64_t operator()(int32_t v) const { return (int64_t)v; } };
 struct HalfUp { __device__ int64_t operator()(int32_t v) const { return (int64_t)((v + 1) >> 1); } };
-__global__ void __launch_bounds__(256) k_unpack_bases4(const uint8_t *b4, int64_t n_b4, const int64_t *b4_off, const int64_t *seq_off, const int32_t *l_qseq, int64_t n, int64_t n_bases,
-                                                       uint8_t *bases, int32_t *bad) {
+// seq_nt16_int[] as a nibble table: codes 1 2 4 8 (A C G T) -> 0 1 2 3, everything else 4
+#define NT16_INT_LUT 0x4444444344424104ULL
+PDEV unsigned nt16_int(unsigned code) { return (unsigned)(NT16_INT_LUT >> (4 * code)) & 0xF; }
+// General form, one wave per read, a lane per packed byte (two bases): the one-byte-per-base array and base | qual << 8 in one pass
+__global__ void __launch_bounds__(256) k_pack_bq4_reads(const uint8_t *b4, int64_t n_b4, const int64_t *b4_off, const int64_t *seq_off, const int32_t *l_qseq, const uint8_t *quals, int64_t n, int64_t n_bases,
+                                                        uint8_t *bases, uint16_t *bq, int32_t *bad) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t i = wave; i < n; i += nwaves) {
         const int32_t lq = l_qseq[i];
         const int64_t so = seq_off[i], bo = b4_off[i];
         if (lq < 0 || so < 0 || so + lq > n_bases || bo + ((lq + 1) >> 1) > n_b4) { if (lane == 0) *bad = 1; continue; }
-        const uint8_t *src = b4 + bo; uint8_t *dst = bases + so;
-        for (int k = lane; k < lq; k += 64) {
-            const int byte = src[k >> 1], code = (k & 1) ? (byte & 15) : (byte >> 4);
-            dst[k] = (uint8_t)(code == 1 ? 0 : code == 2 ? 1 : code == 4 ? 2 : code == 8 ? 3 : 4);
+        for (int k = 2 * lane; k < lq; k += 128) {
+            const unsigned byte = b4[bo + (k >> 1)];
+            const unsigned b0 = nt16_int(byte >> 4), b1 = nt16_int(byte & 15);
+            bases[so + k] = (uint8_t)b0; bq[so + k] = (uint16_t)(b0 | (quals[so + k] << 8));
+            if (k + 1 < lq) { bases[so + k + 1] = (uint8_t)b1; bq[so + k + 1] = (uint16_t)(b1 | (quals[so + k + 1] << 8)); }
         }
     }
 }
+// Dense form (every read has an even length, so base g is nibble g of the packed column): eight bases per thread, wide loads and stores
+__global__ void __launch_bounds__(256) k_pack_bq4_dense(const uint32_t *b4, const unsigned long long *quals, int64_t n8, unsigned long long *bases, uint4 *bq) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t w = b4[i]; const unsigned long long q = quals[i];
+        unsigned long long bb = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const unsigned byte = (w >> (8 * (j >> 1))) & 0xFF;
+            bb |= (unsigned long long)nt16_int((j & 1) ? (byte & 15) : (byte >> 4)) << (8 * j);
+        }
+        bases[i] = bb;
+        uint4 o;
+        o.x = (uint32_t)((bb & 0xFF) | ((q & 0xFF) << 8) | (((bb >> 8) & 0xFF) << 16) | (((q >> 8) & 0xFF) << 24));
+        o.y = (uint32_t)(((bb >> 16) & 0xFF) | (((q >> 16) & 0xFF) << 8) | (((bb >> 24) & 0xFF) << 16) | (((q >> 24) & 0xFF) << 24));
+        o.z = (uint32_t)(((bb >> 32) & 0xFF) | (((q >> 32) & 0xFF) << 8) | (((bb >> 40) & 0xFF) << 16) | (((q >> 40) & 0xFF) << 24));
+        o.w = (uint32_t)(((bb >> 48) & 0xFF) | (((q >> 48) & 0xFF) << 8) | (((bb >> 56) & 0xFF) << 16) | (((q >> 56) & 0xFF) << 24));
+        bq[i] = o;
+    }
+}
+// the dense form is only right when no read has an odd length: checked where the lengths are
+__global__ void __launch_bounds__(256) k_any_odd(const int32_t *l_qseq, int64_t n, int32_t *bad) {
+    int odd = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) odd |= (l_qseq[i] & 1) | (l_qseq[i] < 0);
+    if (__any(odd) && (threadIdx.x & 63) == 0) *bad = 1;
+}
 }   // namespace
 extern "C" size_t uvc_prep_compact_tmp_bytes(int64_t n) { return scan_tmp_bytes<int64_t>(n) + 64; }
-// seq_off / cigar_off / b4_off: outputs (device, n entries each) or NULL when the caller supplied that column; bases_out: n_bases bytes, with bases4
-extern "C" int uvc_prep_compact(const int32_t *l_qseq, const int32_t *n_cigar, int64_t n, int64_t n_bases, const uint8_t *bases4, int64_t n_b4,
-                                int64_t *seq_off_out, const int64_t *seq_off_in, int64_t *cigar_off_out, int64_t *b4_off, uint8_t *bases_out, int32_t *bad,
+// seq_off / cigar_off / b4_off: outputs (device, n entries each) or NULL when the caller supplied that column; with bases4: bases_out (n_bases
+// bytes) and bq_out (n_bases x base | qual << 8) are written here, so that no separate packing pass runs behind it
+extern "C" int uvc_prep_compact(const int32_t *l_qseq, const int32_t *n_cigar, int64_t n, int64_t n_bases, const uint8_t *bases4, int64_t n_b4, const uint8_t *quals,
+                                int64_t *seq_off_out, const int64_t *seq_off_in, int64_t *cigar_off_out, int64_t *b4_off, uint8_t *bases_out, uint16_t *bq_out, int32_t *bad,
                                 void *tmp, size_t tmp_bytes, hipStream_t s) {
     size_t tb = tmp_bytes;
     hipError_t e = hipSuccess;
     if (seq_off_out) { e = rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(l_qseq, Widen()), seq_off_out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s); tb = tmp_bytes; }
     if (e == hipSuccess && cigar_off_out) { e = rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(n_cigar, Widen()), cigar_off_out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s); tb = tmp_bytes; }
     if (e == hipSuccess && bases4) {
-        e = rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(l_qseq, HalfUp()), b4_off, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s);
-        if (e == hipSuccess) hipLaunchKernelGGL(k_unpack_bases4, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 65536)), dim3(256), 0, s, bases4, n_b4, b4_off, seq_off_out ? seq_off_out : seq_off_in, l_qseq, n, n_bases, bases_out, bad);
+        // reads back to back (offsets derived here) with 2 x bytes == bases can only be all-even lengths: nibble g is base g
+        const bool dense = seq_off_out && 2 * n_b4 == n_bases && (n_bases & 7) == 0 && !(((uintptr_t)bases4) & 3) && !(((uintptr_t)quals | (uintptr_t)bases_out) & 7) && !(((uintptr_t)bq_out) & 15);
+        if (dense) {
+            hipLaunchKernelGGL(k_any_odd, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, l_qseq, n, bad);
+            hipLaunchKernelGGL(k_pack_bq4_dense, dim3((unsigned)std::min<int64_t>((n_bases / 8 + 255) / 256 + 1, 16384)), dim3(256), 0, s, (const uint32_t *)bases4, (const unsigned long long *)quals, n_bases / 8,
+                               (unsigned long long *)bases_out, (uint4 *)bq_out);
+        } else {
+            e = rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(l_qseq, HalfUp()), b4_off, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s);
+            if (e == hipSuccess) hipLaunchKernelGGL(k_pack_bq4_reads, dim3((unsigned)std::min<int64_t>((n + 3) / 4, 65536)), dim3(256), 0, s, bases4, n_b4, b4_off, seq_off_out ? seq_off_out : seq_off_in, l_qseq, quals, n, n_bases, bases_out, bq_out, bad);
+        }
     }
     return (int)e;
 }

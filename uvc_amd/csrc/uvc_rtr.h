@@ -15,6 +15,8 @@ struct UvcRtrWork {
     int32_t *long_n;            // [1] number of entries of long_list
     int32_t *long_list;         // [3 * cap] (start, track length, any-TR track length) of visited starts with a track longer than 1024
     int32_t *thr;               // [smax][bq_max] indel_phred as thresholds: thr[(u - 1) * bq_max + d] = smallest repeat count whose decphred is >= d
+    int32_t *incs;              // [2][cap + 1] BAQ increments per position
+    long long *btot;            // [2][ceil(cap / 1024)] their sums per k_rtr_tracks block
     void *scan_tmp; size_t scan_tmp_bytes;
 };
 size_t uvc_rtr_work_bytes(int64_t cap, int vmax, int smax, int bq_max, size_t *scan_tmp_bytes);

@@ -23,7 +23,6 @@
 #include <algorithm>
 #include <cmath>
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_scan.hpp>
 #include <stdint.h>
 #include "uvc_rtr.h"
 
@@ -62,18 +61,16 @@ RDEV int wave_suffix_min(int v, int lane) {
     return v;
 }
 
-__global__ void __launch_bounds__(256) k_rtr_refsym(const uint8_t *ref, int64_t n, int64_t npos, uint8_t *refsym) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < npos) refsym[i] = (i < n ? base_code(ref[i]) : 0);
-}
-
-// first[u - 1][chunk] = smallest q of the chunk with !(q + u < n && ref[q] == ref[q + u]), INF when the chunk has none
-__global__ void __launch_bounds__(256) k_rtr_first(const uint8_t *ref, int n, int vmax, int nchunk, int32_t *first) {
+// first[u - 1][chunk] = smallest q of the chunk with !(q + u < n && ref[q] == ref[q + u]), INF when the chunk has none; also the symbol codes
+__global__ void __launch_bounds__(256) k_rtr_first(const uint8_t *ref, int n, int64_t npos, int vmax, int nchunk, int32_t *first, uint8_t *refsym) {
     __shared__ uint8_t sref[TC + 256];
-    __shared__ int wmin[4];
+    __shared__ int wmin[256][4];
     const int t = threadIdx.x, base = blockIdx.x * TC;
     for (int w = t; w < TC + vmax; w += 256) sref[w] = (base + w < n ? ref[base + w] : 0);
     __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int64_t i = (int64_t)base + t + 256 * j; if (i < npos) refsym[i] = (i < n ? base_code(sref[t + 256 * j]) : 0); }
+    if (blockIdx.x == gridDim.x - 1) for (int64_t i = (int64_t)gridDim.x * TC + t; i < npos; i += 256) refsym[i] = 0;   // npos = n + 1 may start a chunk of its own
     for (int u = 1; u <= vmax; u++) {
         int v = INF;
 #pragma unroll
@@ -82,11 +79,10 @@ __global__ void __launch_bounds__(256) k_rtr_first(const uint8_t *ref, int n, in
             if (q < n && !(q + u < n && sref[w] == sref[w + u])) v = q;   // descending j: the smallest q survives
         }
         for (int d = 32; d > 0; d >>= 1) v = rmin(v, __shfl_xor(v, d));
-        if ((t & 63) == 0) wmin[t >> 6] = v;
-        __syncthreads();
-        if (t == 0) first[(size_t)(u - 1) * nchunk + blockIdx.x] = rmin(rmin(wmin[0], wmin[1]), rmin(wmin[2], wmin[3]));
-        __syncthreads();
+        if ((t & 63) == 0) wmin[u][t >> 6] = v;
     }
+    __syncthreads();
+    if (t >= 1 && t <= vmax) first[(size_t)(t - 1) * nchunk + blockIdx.x] = rmin(rmin(wmin[t][0], wmin[t][1]), rmin(wmin[t][2], wmin[t][3]));
 }
 // in place: first[u - 1][k] = min over k' >= k
 __global__ void __launch_bounds__(256) k_rtr_suffix(int nchunk, int32_t *first) {
@@ -116,11 +112,12 @@ struct Best { int u, c, end; };
 __global__ void __launch_bounds__(NT) k_rtr_cand(const uint8_t *ref, int n, int smax, int vmax, int bq_max, const int32_t *thr, const int32_t *suf, int nchunk,
                                                  int32_t *c_len, int32_t *c_alen, int32_t *c_info, int32_t *c_next, int32_t *exit1) {
     extern __shared__ uint8_t dyn[];            // WIN + vmax reference characters
-    __shared__ int nm[WIN];                     // window-relative index of the first failing comparison at or behind each window element
-    __shared__ int wtot[NT / 64];
+    __shared__ int nm[2][WIN];                  // window-relative index of the first failing comparison at or behind each window element, as far as
+                                                // the element's own wave (192 elements) sees; INF = look at the waves behind.  Two buffers: one barrier per unit
+    __shared__ int wtot[2][NT / 64];
     __shared__ int nx[SC];
     uint8_t *sref = dyn;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
     const int cs = blockIdx.x * SC, ce = rmin(cs + SC, n);
     for (int w = t; w < WIN + vmax; w += NT) sref[w] = (cs + w < n ? ref[cs + w] : 0);
     Best b[2], a[2];
@@ -129,7 +126,8 @@ __global__ void __launch_bounds__(NT) k_rtr_cand(const uint8_t *ref, int n, int 
     const int open_chunk = (cs + WIN) / TC;   // a run that is still open at the end of the window fails first at or behind this chunk
     __syncthreads();
     for (int u = 1; u <= vmax; u++) {
-        // window elements 3t .. 3t + 2 of this thread: suffix minimum of the failing positions
+        const int buf = u & 1;
+        // window elements 3t .. 3t + 2 of this thread: suffix minimum of the failing positions inside the wave
         const int w0 = 3 * t;
         int v[3];
         int run = INF;
@@ -141,17 +139,16 @@ __global__ void __launch_bounds__(NT) k_rtr_cand(const uint8_t *ref, int n, int 
         }
         const int incl = wave_suffix_min(run, lane);
         int excl = __shfl_down(incl, 1); if (lane == 63) excl = INF;
-        if (lane == 0) wtot[wave] = incl;
-        __syncthreads();
-        for (int w = wave + 1; w < NT / 64; w++) excl = rmin(excl, wtot[w]);
+        if (lane == 0) wtot[buf][t >> 6] = incl;
 #pragma unroll
-        for (int j = 0; j < 3; j++) nm[w0 + j] = rmin(v[j], excl);
+        for (int j = 0; j < 3; j++) nm[buf][w0 + j] = rmin(v[j], excl);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const int s = t + NT * k, at = cs + s;
             if (at >= n) continue;
-            const int e = nm[s];
+            int e = nm[buf][s];
+            for (int w = s / 192 + 1; e == INF && w < NT / 64; w++) e = wtot[buf][w];   // the waves lie in window order: the first one that has a failure has the nearest
             const int q = (e == INF ? suf[(size_t)(u - 1) * nchunk + open_chunk] : cs + e);
             const int c = (q - at) / u + 1;
             if (u <= smax && str_better(u, c, b[k].u, b[k].c, smax)) { b[k].u = u; b[k].c = c; b[k].end = q + u; }
@@ -191,20 +188,28 @@ __global__ void __launch_bounds__(NT) k_rtr_cand(const uint8_t *ref, int n, int 
     for (int k = 0; k < 2; k++) { const int at = cs + t + NT * k; if (at < n) exit1[at] = nx[t + NT * k]; }
 }
 
-// entry[k] = the start at which the walk enters chunk k, -1 when it jumps over the chunk
+// entry[k] = the start at which the walk enters chunk k, -1 when it jumps over the chunk.  One wave: 64 chunks per step while the walk
+// enters each chunk at its first base (what it does wherever no long repeat straddles a chunk boundary), one dependent load per chunk otherwise.
 __global__ void __launch_bounds__(256) k_rtr_chain(int n, int nsc, const int32_t *exit1, int32_t *entry, int32_t *long_n) {
-    constexpr int CAP = 8192;
-    __shared__ int x[CAP];
     const int t = threadIdx.x;
-    for (int k = t; k < nsc; k += 256) { entry[k] = -1; if (k < CAP) x[k] = exit1[(size_t)k * SC]; }
+    for (int k = t; k < nsc; k += 256) entry[k] = -1;
     if (t == 0) *long_n = 0;
     __syncthreads();
-    if (t == 0) {
-        int e = 0;
-        while (e < n) {
-            const int k = e / SC;
-            entry[k] = e;
-            e = (e == k * SC && k < CAP) ? x[k] : exit1[e];
+    if (t >= 64) return;
+    int e = 0;
+    while (e < n) {
+        const int k = e / SC;
+        if (e == k * SC) {
+            const int kk = k + t;
+            const int xv = (kk < nsc ? exit1[(size_t)kk * SC] : INF);             // exit of chunk kk when it is entered at its first base
+            const unsigned long long ok = __ballot(kk < nsc && xv == (kk + 1) * SC);
+            const int run = (~ok == 0 ? 64 : __builtin_ctzll(~ok));              // chunks k .. k + run - 1 hand over to the next chunk's first base
+            const int last = (run < 64 ? run : 63);                               // lane whose exit the walk continues from
+            if (t <= last && kk < nsc) entry[kk] = kk * SC;
+            e = __shfl(xv, last);
+        } else {
+            if (t == 0) entry[k] = e;
+            e = exit1[e];
         }
     }
 }
@@ -257,7 +262,7 @@ RDEV void lds_max(unsigned long long *p, unsigned long long v) { __hip_atomic_fe
 
 __global__ void __launch_bounds__(NT) k_rtr_tracks(int n, int64_t npos, int bq_max, int polymerase_size, int str_phred_per_region, int nonstr_phred_per_base,
                                                    const uint8_t *visited, const int32_t *c_len, const int32_t *c_alen, const int32_t *c_info,
-                                                   const int32_t *long_n, const int32_t *long_list, int32_t *rtr, int64_t *baq) {
+                                                   const int32_t *long_n, const int32_t *long_list, int32_t *rtr, int32_t *incs /* [2][npos] */, long long *btot /* [2][blocks] */) {
     __shared__ unsigned long long keyS[TB], keyA[TB];
     __shared__ int ov[NT * 3];
     __shared__ int n_ov;
@@ -300,42 +305,86 @@ __global__ void __launch_bounds__(NT) k_rtr_tracks(int n, int64_t npos, int bq_m
     }
     __syncthreads();
     const int p = cs + t;
-    if (p >= ce) return;
-    // every position lies in [a, next(a)) of the start a the walk stopped at in front of it, and next(a) <= a + track length: a key is never 0
-    // (the guard only keeps a broken invariant from becoming a wild read)
-    const unsigned long long ks = keyS[t] ? keyS[t] : track_key(0, p), ka = keyA[t] ? keyA[t] : track_key(0, p);
-    const int tl = (int)(ks >> 32), at_s = INF - (int)(unsigned)ks, atl = (int)(ka >> 32), at_a = INF - (int)(unsigned)ka;
-    const int info_s = c_info[at_s], info_a = c_info[at_a];
-    const int ul = info_s & 0xFF, phred = info_s >> 16, aul = (info_a >> 8) & 0xFF;
-    // region_repeatvec_to_baq_offsetarr, main.cpp:400-429: the increments (both arrays divide by the STR unit length, as the reference does)
-    int64_t inc[2];
+    int inc[2] = { 0, 0 };
+    if (p < ce) {
+        // every position lies in [a, next(a)) of the start a the walk stopped at in front of it, and next(a) <= a + track length: a key is never 0
+        // (the guard only keeps a broken invariant from becoming a wild read)
+        const unsigned long long ks = keyS[t] ? keyS[t] : track_key(0, p), ka = keyA[t] ? keyA[t] : track_key(0, p);
+        const int tl = (int)(ks >> 32), at_s = INF - (int)(unsigned)ks, atl = (int)(ka >> 32), at_a = INF - (int)(unsigned)ka;
+        const int info_s = c_info[at_s], info_a = c_info[at_a];
+        const int ul = info_s & 0xFF, phred = info_s >> 16, aul = (info_a >> 8) & 0xFF;
+        // region_repeatvec_to_baq_offsetarr, main.cpp:400-429: the increments (both arrays divide by the STR unit length, as the reference does)
 #pragma unroll
-    for (int any = 0; any < 2; any++) {
-        const int l2 = any ? atl : tl, reps = l2 / ul;
-        inc[any] = (reps >= 3 || (reps >= 2 && l2 >= polymerase_size)) ? (int64_t)((str_phred_per_region * 10) / l2 + 1) : (int64_t)(nonstr_phred_per_base * 10);
+        for (int any = 0; any < 2; any++) {
+            const int l2 = any ? atl : tl, reps = l2 / ul;
+            inc[any] = (reps >= 3 || (reps >= 2 && l2 >= polymerase_size)) ? ((str_phred_per_region * 10) / l2 + 1) : (nonstr_phred_per_base * 10);
+        }
+        const int vals[UVC_NRTR] = { at_s, tl, ul, phred, at_a, atl, aul };
+#pragma unroll
+        for (int f = 0; f < UVC_NRTR; f++) rtr[(size_t)f * npos + p] = vals[f];
+        incs[p] = inc[0]; incs[npos + p] = inc[1];
+        if (p == n - 1) {   // region_repeatvec.push_back(LAST(region_repeatvec)), main.hpp:872
+#pragma unroll
+            for (int f = 0; f < UVC_NRTR; f++) rtr[(size_t)f * npos + n] = vals[f];
+            incs[n] = inc[0]; incs[npos + n] = inc[1];
+        }
     }
-    const int vals[UVC_NRTR] = { at_s, tl, ul, phred, at_a, atl, aul };
+    // what this block's positions add to the prefix sums (the repeated last entry is not part of any total: k_rtr_baq reads it itself)
+    __shared__ long long wtot2[2][NT / 64];
 #pragma unroll
-    for (int f = 0; f < UVC_NRTR; f++) rtr[(size_t)f * npos + p] = vals[f];
-    baq[p] = inc[0]; baq[npos + p] = inc[1];
-    if (p == n - 1) {   // region_repeatvec.push_back(LAST(region_repeatvec)), main.hpp:872
+    for (int a = 0; a < 2; a++) {
+        long long v = inc[a];
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+        if ((t & 63) == 0) wtot2[a][t >> 6] = v;
+    }
+    __syncthreads();
+    if (t < 2) { long long v = 0; for (int w = 0; w < NT / 64; w++) v += wtot2[t][w]; btot[(size_t)t * gridDim.x + blockIdx.x] = v; }
+}
+// region_repeatvec_to_baq_offsetarr, main.cpp:400-429: prefix sums of the increments from the region start, then / 10.  Every block sums the
+// totals of the blocks in front of it itself (k_rtr_tracks left one per block), then scans its own 1024 positions.
+__global__ void __launch_bounds__(NT) k_rtr_baq(int nb_tracks, int64_t npos, const int32_t *incs /* [2][npos] */, const long long *btot /* [2][nb_tracks] */, int64_t *baq) {
+    __shared__ long long wsum[2][NT / 64];
+    __shared__ long long base_s[2];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, cs = blockIdx.x * TB;
+    const int np = (int)npos;
+    // the blocks in front of this one
+    long long pre[2] = { 0, 0 };
+    for (int i = t; i < (int)blockIdx.x && i < nb_tracks; i += NT) { pre[0] += btot[i]; pre[1] += btot[(size_t)nb_tracks + i]; }
+    long long own[2] = { 0, 0 };
+    const int p = cs + t;
+    if (p < np) { own[0] = incs[p]; own[1] = incs[npos + p]; }
 #pragma unroll
-        for (int f = 0; f < UVC_NRTR; f++) rtr[(size_t)f * npos + n] = vals[f];
-        baq[n] = inc[0]; baq[npos + n] = inc[1];
+    for (int a = 0; a < 2; a++) {
+        long long v = pre[a];
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+        if (lane == 0) wsum[a][wave] = v;
+    }
+    __syncthreads();
+    if (t < 2) { long long v = 0; for (int w = 0; w < NT / 64; w++) v += wsum[t][w]; base_s[t] = v; }
+    __syncthreads();
+    long long incl[2];
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        long long v = own[a];
+        for (int d = 1; d < 64; d <<= 1) { const long long o = __shfl_up(v, d); if (lane >= d) v += o; }
+        incl[a] = v;
+        if (lane == 63) wsum[a][wave] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        long long v = incl[a] + base_s[a];
+        for (int w = 0; w < wave; w++) v += wsum[a][w];
+        if (p < np) baq[(size_t)a * npos + p] = v / 10;
     }
 }
-__global__ void __launch_bounds__(256) k_rtr_div10(int64_t *baq, int64_t n2) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n2) baq[i] /= 10;
-}
-size_t scan_bytes(int64_t npos) { size_t b = 0; int64_t *p = nullptr; rocprim::inclusive_scan(nullptr, b, p, p, (size_t)std::max<int64_t>(npos, 1), rocprim::plus<int64_t>(), (hipStream_t)0); return b; }
 size_t a256(size_t b) { return (b + 255) & ~(size_t)255; }
 }   // namespace
 
 size_t uvc_rtr_work_bytes(int64_t cap, int vmax, int smax, int bq_max, size_t *scan_tmp_bytes) {
     const size_t n = (size_t)cap, ntc = (n + TC - 1) / TC + 1, nsc = (n + SC - 1) / SC + 1;
-    *scan_tmp_bytes = scan_bytes(cap + 1);
-    return a256(n + 1) + a256(4 * (size_t)vmax * ntc) + 5 * a256(4 * n) + a256(4 * nsc) + a256(n) + a256(4) + a256(12 * n) + a256(4 * (size_t)smax * bq_max) + a256(*scan_tmp_bytes) + 256;
+    *scan_tmp_bytes = 0;
+    return a256(n + 1) + a256(4 * (size_t)vmax * ntc) + 5 * a256(4 * n) + a256(4 * nsc) + a256(n) + a256(4) + a256(12 * n) + a256(4 * (size_t)smax * bq_max) + a256(8 * (n + 2)) + a256(16 * ntc) + 256;
 }
 void uvc_rtr_bind(UvcRtrWork *W, char *b, int64_t cap, int vmax, int smax, int bq_max, size_t scan_tmp_bytes) {
     const size_t n = (size_t)cap, ntc = (n + TC - 1) / TC + 1, nsc = (n + SC - 1) / SC + 1;
@@ -349,7 +398,9 @@ void uvc_rtr_bind(UvcRtrWork *W, char *b, int64_t cap, int vmax, int smax, int b
     W->long_n = (int32_t *)b; b += a256(4);
     W->long_list = (int32_t *)b; b += a256(12 * n);
     W->thr = (int32_t *)b; b += a256(4 * (size_t)smax * bq_max);
-    W->scan_tmp = b; W->scan_tmp_bytes = scan_tmp_bytes;
+    W->incs = (int32_t *)b; b += a256(8 * (n + 2));
+    W->btot = (long long *)b; b += a256(16 * ntc);
+    W->scan_tmp = nullptr; W->scan_tmp_bytes = scan_tmp_bytes;
 }
 
 // indel_phred (main.hpp:794-801) is evaluated on the host, with the host's libm, into thresholds: for a unit length the value is a
@@ -374,19 +425,14 @@ void uvc_rtr_thresholds(const UvcParams *P, int32_t *thr) {
 int uvc_launch_region_tracks(const UvcRtrWork *W, const UvcParams *P, int64_t npos, uint8_t *refsym, int32_t *rtr0, int64_t *baq, hipStream_t s) {
     const int n = (int)(npos - 1), smax = P->indel_str_repeatsize_max, vmax = P->indel_vntr_repeatsize_max, bq = P->indel_BQ_max;
     const int ntc = (n + TC - 1) / TC, nsc = (n + SC - 1) / SC;
-    hipLaunchKernelGGL(k_rtr_refsym, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, s, W->refchar, (int64_t)n, npos, refsym);
-    hipLaunchKernelGGL(k_rtr_first, dim3(ntc), dim3(256), 0, s, W->refchar, n, vmax, ntc, W->first);
+    const int nbt = (n + TB - 1) / TB;
+    hipLaunchKernelGGL(k_rtr_first, dim3(ntc), dim3(256), 0, s, W->refchar, n, npos, vmax, ntc, W->first, refsym);
     hipLaunchKernelGGL(k_rtr_suffix, dim3(vmax), dim3(256), 0, s, ntc, W->first);
     hipLaunchKernelGGL(k_rtr_cand, dim3(nsc), dim3(NT), (size_t)(WIN + vmax), s, W->refchar, n, smax, vmax, bq, W->thr, W->first, ntc, W->c_len, W->c_alen, W->c_info, W->c_next, W->exit1);
     hipLaunchKernelGGL(k_rtr_chain, dim3(1), dim3(256), 0, s, n, nsc, W->exit1, W->entry, W->long_n);
     hipLaunchKernelGGL(k_rtr_mark, dim3(nsc), dim3(NT), 0, s, n, W->entry, W->c_next, W->c_len, W->c_alen, W->visited, W->long_n, W->long_list);
-    hipLaunchKernelGGL(k_rtr_tracks, dim3((n + TB - 1) / TB), dim3(NT), 0, s, n, npos, bq, (int)std::round(P->indel_polymerase_size), P->indel_str_phred_per_region, P->indel_nonSTR_phred_per_base,
-                       W->visited, W->c_len, W->c_alen, W->c_info, W->long_n, W->long_list, rtr0, baq);
-    for (int any = 0; any < 2; any++) {
-        size_t tb = W->scan_tmp_bytes;
-        const hipError_t e = rocprim::inclusive_scan(W->scan_tmp, tb, baq + (size_t)any * npos, baq + (size_t)any * npos, (size_t)npos, rocprim::plus<int64_t>(), s);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(k_rtr_div10, dim3((unsigned)((2 * npos + 255) / 256)), dim3(256), 0, s, baq, 2 * npos);
+    hipLaunchKernelGGL(k_rtr_tracks, dim3(nbt), dim3(NT), 0, s, n, npos, bq, (int)std::round(P->indel_polymerase_size), P->indel_str_phred_per_region, P->indel_nonSTR_phred_per_base,
+                       W->visited, W->c_len, W->c_alen, W->c_info, W->long_n, W->long_list, rtr0, W->incs, W->btot);
+    hipLaunchKernelGGL(k_rtr_baq, dim3((unsigned)((npos + TB - 1) / TB)), dim3(NT), 0, s, nbt, npos, W->incs, W->btot, baq);
     return (int)hipGetLastError();
 }
