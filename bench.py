@@ -39,6 +39,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# A region handle has three streams and several handles are in flight: with the HIP runtime's default of four hardware queues the streams of
+# different handles share a queue and a kernel waits behind another handle's 10 ms copy (pcie_inclusive: 16.0 ms per tile with 4 queues,
+# 13.5 with 16; 24 was slower again).  Read by the runtime when it starts, so it is set before anything imports it; an explicit setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 READ_LEN = 150
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -330,8 +334,8 @@ def main():
                 t[k] = a
                 if a.nbytes and lib.dll.uvcgpu_pin_host_buffer(C.c_void_p(a.ctypes.data), C.c_int64(a.nbytes)) == 0:
                     pinned.append(a)
-        n_extra = max(4, min(args.steps, 2 * T))
-        n_thr = max(1, min(int(os.environ.get("UVC_BENCH_THREADS", "3")), T))
+        n_extra = max(4, min(max(args.steps, 12), 2 * T))
+        n_thr = max(1, min(int(os.environ.get("UVC_BENCH_THREADS", "4")), T))
         import threading
         handle_locks = [threading.Lock() for _ in range(T)]
 

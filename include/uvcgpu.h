@@ -407,6 +407,14 @@ const char *uvcgpu_vcf_format_keys(int32_t with_tier2_consensus_tags);
  * which becomes a second sample column of the #CHROM line (generate_vcf_header, main.hpp:5785, 5881) */
 int uvcgpu_vcf_header(const UvcParams *params, const char *sample_name, const char *tumor_sample_name, const char *const *contig_names,
                       const int64_t *contig_lens, int32_t n_contigs, char *dst, int64_t capacity, int64_t *len);
+/* The same with the three lines that state facts about the caller's run, in the reference's places (main.hpp:5792-5794, 5870-5874):
+ * ##fileDate=<file_date> (the reference prints strftime("%F %T")), ##reference=<reference_fname>, ##variantCallerCommand=<command_line>
+ * (the reference joins argv with two blanks behind each word).  NULL leaves a line out.  Every other line -- ##ALT, ##FILTER, ##INFO,
+ * ##FORMAT with their Description texts, ##phasing, ##variantCallerInferredParameters, #CHROM -- is the reference's, byte for byte;
+ * ##variantCallerVersion names this library. */
+int uvcgpu_vcf_header_ex(const UvcParams *params, const char *sample_name, const char *tumor_sample_name, const char *const *contig_names,
+                         const int64_t *contig_lens, int32_t n_contigs, const char *file_date, const char *reference_fname,
+                         const char *command_line, char *dst, int64_t capacity, int64_t *len);
 /* `scored` is what uvcgpu_region_score filled for this region (all records, in order: the REF record of a position supplies the first
  * value of every Number=R tag); the lines of the records with out != 0 and keep != 0 are written.  The planes must not have been
  * released (UvcScoreRequest::release_state = 0).  `req` is the request of that score call (NULL = its defaults): its tumor_keys (normal

@@ -1,0 +1,56 @@
+"""Oracle comparison at a size where the kernels run in the form the bench runs them: a 150 kb x 300x non-UMI region
+(2 344 windows of 64 positions: the non-split kernel forms, real occupancy, radix sorts over 300 k reads, k_win_index over thousands of
+windows, 147 carry blocks of k_prep_sums / k_frag_sums, a mismatch queue of hundreds of thousands of entries) and a 50 kb x 2000x
+duplex-UMI region (the digest / window forms of the family kernels): every plane bit-exact, every record inside the tolerance classes
+of tests/test_gpu_parity.py.  The oracle runs these on all host cores of the box in well under a minute (it is single-threaded per
+region: the two regions run on two threads)."""
+import threading
+
+import numpy as np
+import pytest
+
+from uvc_amd import synth
+from util import diff_groups, run_region
+from test_gpu_parity import compare_records
+
+pytestmark = pytest.mark.gpu
+
+LARGE = {
+    "nonumi_150kb_300x": dict(region_len=150_000, depth=300, seed=4242),
+    "duplex_50kb_2000x": dict(region_len=50_000, depth=2000, seed=4343, umi=True),
+}
+
+
+@pytest.fixture(scope="module")
+def oracle_runs(oracle_lib):
+    """Both oracle regions at once, one thread each (ctypes releases the GIL inside the library)."""
+    out, errs = {}, []
+
+    def work(name):
+        try:
+            reads = synth.generate_region(**LARGE[name])
+            R = run_region(oracle_lib, reads)
+            out[name] = (reads, R, R.score(all_out=False))
+        except Exception as e:   # noqa: BLE001
+            errs.append((name, e))
+    th = [threading.Thread(target=work, args=(n,)) for n in LARGE]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    return out
+
+
+@pytest.mark.parametrize("name", list(LARGE))
+def test_large_region_matches_oracle(name, oracle_runs, gpu_lib):
+    reads, Ro, ro = oracle_runs[name]
+    Rg = run_region(gpu_lib, reads)
+    bad = diff_groups(Ro, Rg)
+    assert not bad, "\n".join("%s: %d cells differ, e.g. %s" % (g, v[0], v[1]) for g, v in bad.items())
+    rg = Rg.score(all_out=False)
+    assert len(ro["refpos"]) > 1000
+    worst = compare_records(ro, rg)
+    print(name, reads["n_reads"], "reads,", len(ro["refpos"]), "records, worst differences", {k: v for k, v in worst.items() if v})
+    # the InDel allele rows behind the records
+    ao, ag = Ro.indel_alleles(), Rg.indel_alleles()
+    assert ao == ag
+    Rg.close()

@@ -62,30 +62,71 @@ def _parse_meta(line):
     return m.groups()
 
 
-def test_header_lines_match_reference_ids_numbers_types(ref_vcf, product_dll):
+def _reference_header_literals(params):
+    """The static text of generate_vcf_header (main.hpp:5778-5883) read from the reference source as TEXT: every string literal of the
+    function body in order, with the three compile-time / parameter expressions the body splices in replaced by their values.  Loop bodies
+    appear once.  Returns the text split into lines."""
+    import os, re
+    path = "/root/reference/main.hpp"
+    if not os.path.exists(path):
+        pytest.skip("reference source not present on this box")
+    src = open(path).read()
+    body = src[src.index("generate_vcf_header("):]
+    body = body[body.index('std::string ret = "";'):body.index("return ret;")]
+    body = body.replace("std::to_string(MGVCF_REGION_MAX_SIZE)", '"1000"')
+    body = body.replace("std::to_string(paramset.germ_phred_hetero_indel - paramset.germ_phred_hetero_snp)", '"%d"' % (params.germ_phred_hetero_indel - params.germ_phred_hetero_snp))
+    body = body.replace("SYMBOL_TO_DESC_ARR[ADDITIONAL_INDEL_CANDIDATE_SYMBOL]", '"<ADDITIONAL_INDEL_CANDIDATE>"')
+    lits = re.findall(r'"((?:[^"\\]|\\.)*)"', body)
+    text = "".join(lits).replace('\\"', '"').replace("\\n", "\n").replace("\\t", "\t")
+    return text.split("\n")
+
+
+def test_header_is_the_references_text(ref_vcf, product_dll):
+    """VERDICT r2 missing #4: the ##ALT / ##FILTER / ##INFO / ##FORMAT lines of uvcgpu_vcf_header byte for byte -- Description texts included --
+    against (a) FILTER_LINES / FORMAT_LINES of the reference's own generated header (libref_vcf.so = bcf_formats_generator1.cpp compiled as it
+    lies), all 258 FORMAT lines incl. the eight tags the reference declares and never writes, and (b) the string literals of
+    generate_vcf_header read from the reference source, in the reference's order."""
     lib = _HostLib(product_dll)
     p = _ffi.UvcParams()
     product_dll.uvcgpu_params_default.argtypes = [C.POINTER(_ffi.UvcParams)]
     product_dll.uvcgpu_params_default(C.byref(p))
+    p.inferred_sequencing_platform = 1; p.central_readlen = 150
     hdr = region.vcf_header(lib, p, "S1", [("chr20", 64444167), ("chrM", 16569)]).splitlines()
     assert hdr[0] == "##fileformat=VCFv4.2" and hdr[1] == "##contig=<ID=chr20,length=64444167>" and hdr[2] == "##contig=<ID=chrM,length=16569>"
     assert hdr[-1] == "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1"
-    mine_fmt = [_parse_meta(l) for l in hdr if l.startswith("##FORMAT=")]
-    ref_fmt = [_parse_meta(ref_vcf.uvc_ref_format_line(i).decode()) for i in range(ref_vcf.uvc_ref_n_format())]
-    skipped = {"C2LP2", "C2RP2", "C2LPL", "C2RPL", "C2LB2", "C2RB2", "C2LBL", "C2RBL"}   # not_put_in_vcf(): declared by the reference, never written
-    ref_fmt = [r for r in ref_fmt if r[1] not in skipped]
-    extra = mine_fmt[len(ref_fmt):]     # the six FORMAT lines generate_vcf_header writes by hand behind the generated ones (main.hpp:5847-5875)
-    mine_fmt = mine_fmt[:len(ref_fmt)]
-    assert [e[1:4] for e in extra] == [("GL4", "4", "Integer"), ("GST", ".", "Integer"), ("CDP1", "2", "Integer"), ("cDP1", "2", "Integer"),
-                                       ("POS_VT_BDP_CDP_HomRefQ", ".", "Integer"), ("clipDP", "2", "Integer")]
-    assert [m[1:4] for m in mine_fmt] == [r[1:4] for r in ref_fmt]
-    for m, r in zip(mine_fmt, ref_fmt):
-        assert m[4].startswith("SUB-HEADER: ") == r[4].startswith("SUB-HEADER: "), m[1]
-    mine_flt = [_parse_meta(l)[1] for l in hdr if l.startswith("##FILTER=")]
-    assert mine_flt == [ref_vcf.uvc_ref_filter_id(i).decode() for i in range(ref_vcf.uvc_ref_n_filter())]
-    info_ids = [_parse_meta(l)[1] for l in hdr if l.startswith("##INFO=")]
-    for k in ("ANY_VAR", "SOMATIC", "MGVCF_BLOCK", "ADDITIONAL_INDEL_CANDIDATE", "SomaticQ", "TLODQ", "NLODQ", "NLODV", "TNBQF", "TNCQF", "tbDP", "tDP", "tAD", "t2DP", "t2AD", "nDP", "nAD", "n2AD", "RU", "RC", "R3X2"):
-        assert k in info_ids
+    assert hdr[-2] == "##variantCallerInferredParameters=(inferred_sequencing_platform=Illumina/BGI,central_readlen=150)"
+    ref_filter = [ref_vcf.uvc_ref_filter_line(i).decode() for i in range(ref_vcf.uvc_ref_n_filter())]
+    ref_format = [ref_vcf.uvc_ref_format_line(i).decode() for i in range(ref_vcf.uvc_ref_n_format())]
+    i_alt = hdr.index([l for l in hdr if l.startswith("##ALT=")][0])
+    assert hdr[i_alt + 1: i_alt + 1 + len(ref_filter)] == ref_filter                       # right behind ##ALT, main.hpp:5796-5801
+    i_fmt = hdr.index(ref_format[0])
+    assert hdr[i_fmt: i_fmt + len(ref_format)] == ref_format and len(ref_format) == 258
+    assert hdr[i_fmt - 1].startswith("##INFO=<ID=R3X2,")                                    # the generated lines follow the last ##INFO, main.hpp:5841-5845
+    assert [l.split(",")[0] for l in hdr[i_fmt + len(ref_format): i_fmt + len(ref_format) + 6]] == ["##FORMAT=<ID=" + k for k in ("GL4", "GST", "CDP1", "cDP1", "POS_VT_BDP_CDP_HomRefQ", "clipDP")]
+    # every hand-written line of the reference's function, same bytes, same order
+    ref_static = [l for l in _reference_header_literals(p) if l.startswith(("##ALT=", "##INFO=", "##FORMAT=", "##phasing", "##fileformat"))]
+    mine_static = [l for l in hdr if l.startswith(("##ALT=", "##INFO=", "##phasing", "##fileformat")) or (l.startswith("##FORMAT=") and l not in ref_format)]
+    assert len(ref_static) == 1 + 1 + 22 + 6 + 1   # fileformat, ALT, 22 INFO, 6 FORMAT, phasing
+    assert mine_static == ref_static
+
+
+def test_header_ex_adds_the_run_lines(product_dll):
+    """##fileDate, ##reference and ##variantCallerCommand sit where generate_vcf_header writes them (main.hpp:5792-5794, 5870-5874)."""
+    p = _ffi.UvcParams()
+    product_dll.uvcgpu_params_default.argtypes = [C.POINTER(_ffi.UvcParams)]
+    product_dll.uvcgpu_params_default(C.byref(p))
+    fn = product_dll.uvcgpu_vcf_header_ex
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(_ffi.UvcParams), C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    names = (C.c_char_p * 1)(b"chr1"); lens = (C.c_int64 * 1)(1000)
+    n = C.c_int64()
+    fn(C.byref(p), b"S", None, names, lens, 1, b"2026-01-02 03:04:05", b"ref.fa", b"uvc1  a.bam  ", None, 0, C.byref(n))
+    buf = C.create_string_buffer(n.value)
+    assert fn(C.byref(p), b"S", None, names, lens, 1, b"2026-01-02 03:04:05", b"ref.fa", b"uvc1  a.bam  ", buf, n.value, C.byref(n)) == 0
+    hdr = buf.raw[:n.value].decode().splitlines()
+    assert hdr[:4] == ["##fileformat=VCFv4.2", "##fileDate=2026-01-02 03:04:05", "##reference=ref.fa", "##contig=<ID=chr1,length=1000>"]
+    i = [k for k, l in enumerate(hdr) if l.startswith("##variantCallerVersion=")][0]
+    assert hdr[i - 1] == "##phasing=partial" and hdr[i + 1] == "##variantCallerCommand=uvc1  a.bam  " and hdr[i + 2].startswith("##variantCallerInferredParameters=")
 
 
 # ---- GPU: record lines ----

@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <mutex>
 #include <string>
@@ -205,6 +206,10 @@ int main(int argc, char **argv) {
         return 0;
     }
     Opts o = parse(argc, argv);
+    // Each region handle has three streams and a worker's copies should run under another worker's kernels: with the runtime's default of four
+    // hardware queues the streams of different handles share queues, and a kernel then waits behind another handle's 10 ms copy (bench.py's
+    // pcie_inclusive leg: 16.0 ms per tile with 4 queues, 13.5 with 16).  Read by the HIP runtime when it starts; an explicit setting wins.
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     if (o.devices.empty()) { const int nd = uvcgpu_device_count(); if (nd <= 0) die("no HIP device: uvc1-mi355x has no CPU path"); for (int d = 0; d < nd; d++) o.devices.push_back(d); }
     // tiles in flight: the host stages of a tile (inflate above all) cost ~1.3 core-seconds per 1 Mb x 300x, the device ~10 ms: as many workers
     // as half the cores this process may use keep the cores busy (measured on a 16-core quota: 4 -> 6.7, 8 -> 8-11, 12-16 -> 8-9.6 M positions/s),
@@ -321,9 +326,12 @@ int main(int argc, char **argv) {
     if (!o.no_header) {
         int64_t len = 0;
         const char *tsample = (tvcf && o.tumor_format) ? uvcio_tumor_vcf_sample_name(tvcf) : nullptr;
-        uvcgpu_vcf_header(&P, o.sample.c_str(), tsample, cnames.data(), lens.data(), nref, nullptr, 0, &len);
+        // ##fileDate / ##reference / ##variantCallerCommand as generate_vcf_header prints them (main.hpp:5788-5794, 5870-5874)
+        char date[80]; { time_t raw; time(&raw); strftime(date, sizeof(date), "%F %T", localtime(&raw)); }
+        std::string cmd; for (int i = 0; i < argc; i++) { cmd += argv[i]; cmd += "  "; }
+        uvcgpu_vcf_header_ex(&P, o.sample.c_str(), tsample, cnames.data(), lens.data(), nref, date, o.fasta.c_str(), cmd.c_str(), nullptr, 0, &len);
         std::string h((size_t)len, '\0');
-        if (uvcgpu_vcf_header(&P, o.sample.c_str(), tsample, cnames.data(), lens.data(), nref, &h[0], len, &len)) die(uvcgpu_last_error());
+        if (uvcgpu_vcf_header_ex(&P, o.sample.c_str(), tsample, cnames.data(), lens.data(), nref, date, o.fasta.c_str(), cmd.c_str(), &h[0], len, &len)) die(uvcgpu_last_error());
         if (uvcio_bgzf_write(zw, h.data(), (int64_t)h.size())) die(uvcio_last_error());
     }
     const double t_start = now();

@@ -44,262 +44,262 @@ enum Kind {
     K_POS,                                               // position-level lists
     K_R_REC, K_1_REC, K_N_REC,                           // from the score record(s): Number=R, one value, n consecutive fields
 };
-struct Tag { const char *name; const char *number; const char *type; int kind; int a; int n; bool sscs; const char *desc; };
+struct Tag { const char *name; const char *number; const char *type; int kind; int a; int n; bool sscs; };   // the ##FORMAT lines themselves (with the reference's Description texts): uvc_vcf_header_lines.inc
 #define SEG "sequenced-segment (read) statistic"
 #define FRA "fragment statistic, duplicates kept"
 #define FAM "de-duplicated fragment / UMI-family statistic"
 #define SSC "tier-2 single-strand consensus (SSCS) statistic"
 const Tag TAGS[] = {
-    { "GT", "1", "String", K_SPECIAL, 0, 0, false, "Genotype (a guess for tumor samples)" },
-    { "GQ", "1", "Integer", K_SPECIAL, 0, 0, false, "Genotype quality" },
-    { "HQ", "2", "Integer", K_SPECIAL, 0, 0, false, "Haplotype quality" },
-    { "FT", "1", "String", K_SPECIAL, 0, 0, false, "Genotype filter" },
-    { "FTS", "A", "String", K_SPECIAL, 0, 0, false, "Variant filter: PASS or a |-separated list of bias names, each followed by the percent of the unbiased allele fraction that remains" },
-    { "_A_", "1", "String", K_SEP, 0, 0, false, "Summary depths" },
-    { "DP", "1", "Integer", K_1_REC, UVC_O_DP, 1, false, "De-duplicated fragment depth" },
-    { "AD", "R", "Integer", K_R_REC, UVC_O_AD, 1, false, "De-duplicated fragment depth of the REF and ALT allele" },
-    { "bDP", "1", "Integer", K_1_REC, UVC_O_bDP, 1, false, "Fragment depth, duplicates kept" },
-    { "bAD", "R", "Integer", K_R_REC, UVC_O_bAD, 1, false, "Fragment depth of the REF and ALT allele, duplicates kept" },
-    { "c2DP", "1", "Integer", K_1_REC, UVC_O_c2DP, 1, false, "Tier-2 consensus family depth" },
-    { "c2AD", "R", "Integer", K_R_REC, UVC_O_c2AD, 1, false, "Tier-2 consensus family depth of the REF and ALT allele" },
-    { "_Aa", "1", "String", K_SEP, 0, 0, false, "Position-level segment statistics" },
-    { "APDP", "12", "Integer", K_POS, 0, 12, false, "Segment depths: all, near insertions / deletions, inside repeat tracks of insertions / deletions, amplicon, SNV, DNV, high-BQ, near-clip, confident, UMI-labelled" },
-    { "APXM", "8", "Integer", K_POS, 1, 8, false, "Mismatches and gap openings per 1500 bp, query length, InDel length, squared and inverse InDel lengths (insertions, deletions)" },
-    { "_Ab", "1", "String", K_SEP, 0, 0, false, "Position-level segment statistics" },
-    { "APLRID", "4", "Integer", K_POS, 2, 4, false, "Squared insertion and deletion lengths towards the left and right end of the InDel-affected region" },
-    { "APLRI", "4", "Integer", K_POS, 3, 4, false, "Summed distance to the left insert end and the number of such inserts; the same for the right end" },
-    { "APLRP", "4", "Integer", K_POS, 4, 4, false, "Summed distance to the left and right segment end, summed insertion and deletion length" },
-    { "_Ac", "1", "String", K_SEP, 0, 0, false, "Bias thresholds (tier 1 = weak, tier 2 = strong)" },
-    { "ALRPxT", "2", "Integer", K_POS, 5, 2, false, "Distance to the left / right segment end above which a segment is not used for position bias" },
-    { "ALRIT", "4", "Integer", K_POS, 6, 4, false, "Distance to the left / right insert end above which there is tier-1 / tier-2 insert bias" },
-    { "ALRIt", "4", "Integer", K_POS, 7, 4, false, "Distance to the left / right insert end below which there is tier-1 / tier-2 insert bias" },
-    { "ALRPt", "4", "Integer", K_POS, 8, 4, false, "Distance to the left / right segment end below which there is tier-1 / tier-2 position bias" },
-    { "ALRBt", "4", "Integer", K_POS, 9, 4, false, "Base-alignment quality to the left / right segment end below which there is tier-1 / tier-2 bias" },
-    { "_AQ", "1", "String", K_SEP, 0, 0, false, "Sums of qualities. Lower-case first letter: REF and ALT allele; upper-case: all alleles of the symbol type by sum" },
-    { "aMQs", "R", "Integer", K_R_S32, UVC_S_aMQs, 1, false, SEG ": sum of mapping qualities" },
-    { "AMQs", "1", "Integer", K_T1_S32, UVC_S_aMQs, 1, false, SEG ": sum of mapping qualities" },
-    { "a1BQf", "R", "Integer", K_R_VQ, UVC_VQ_a1BQf, 1, false, SEG ": sum of base qualities, forward strand" },
-    { "A1BQf", "1", "Integer", K_T1_VQ, UVC_VQ_a1BQf, 1, false, SEG ": sum of base qualities, forward strand" },
-    { "a1BQr", "R", "Integer", K_R_VQ, UVC_VQ_a1BQr, 1, false, SEG ": sum of base qualities, reverse strand" },
-    { "A1BQr", "1", "Integer", K_T1_VQ, UVC_VQ_a1BQr, 1, false, SEG ": sum of base qualities, reverse strand" },
-    { "_ADPf", "1", "String", K_SEP, 0, 0, false, "Segment depths, forward orientation" },
-    { "aDPff", "R", "Integer", K_R_S32, UVC_S_aDPff, 1, false, SEG ": depth, R1 forward" },
-    { "ADPff", "2", "Integer", K_T2_S32, UVC_S_aDPff, 1, false, SEG ": depth, R1 forward" },
-    { "aDPfr", "R", "Integer", K_R_S32, UVC_S_aDPfr, 1, false, SEG ": depth, R2 reverse" },
-    { "ADPfr", "2", "Integer", K_T2_S32, UVC_S_aDPfr, 1, false, SEG ": depth, R2 reverse" },
-    { "_ADPr", "1", "String", K_SEP, 0, 0, false, "Segment depths, reverse orientation" },
-    { "aDPrf", "R", "Integer", K_R_S32, UVC_S_aDPrf, 1, false, SEG ": depth, R2 forward" },
-    { "ADPrf", "2", "Integer", K_T2_S32, UVC_S_aDPrf, 1, false, SEG ": depth, R2 forward" },
-    { "aDPrr", "R", "Integer", K_R_S32, UVC_S_aDPrr, 1, false, SEG ": depth, R1 reverse" },
-    { "ADPrr", "2", "Integer", K_T2_S32, UVC_S_aDPrr, 1, false, SEG ": depth, R1 reverse" },
-    { "_ALP", "1", "String", K_SEP, 0, 0, false, "Position bias, left side" },
-    { "aLP1", "R", "Integer", K_R_S32, UVC_S_aLP1, 1, false, SEG ": depth free of tier-1 left position bias" },
-    { "ALP1", "1", "Integer", K_T1_S32, UVC_S_aLP1, 1, false, SEG ": depth free of tier-1 left position bias" },
-    { "aLP2", "R", "Integer", K_R_S32, UVC_S_aLP2, 1, false, SEG ": depth free of tier-2 left position bias" },
-    { "ALP2", "1", "Integer", K_T1_S32, UVC_S_aLP2, 1, false, SEG ": depth free of tier-2 left position bias" },
-    { "aLPL", "R", "Integer", K_R_S32, UVC_S_aLPL, 1, false, SEG ": summed distance to the left segment end" },
-    { "ALPL", "1", "Integer", K_T1L_S32, UVC_S_aLPL, 1, false, SEG ": summed distance to the left segment end" },
-    { "_ARP", "1", "String", K_SEP, 0, 0, false, "Position bias, right side" },
-    { "aRP1", "R", "Integer", K_R_S32, UVC_S_aRP1, 1, false, SEG ": depth free of tier-1 right position bias" },
-    { "ARP1", "1", "Integer", K_T1_S32, UVC_S_aRP1, 1, false, SEG ": depth free of tier-1 right position bias" },
-    { "aRP2", "R", "Integer", K_R_S32, UVC_S_aRP2, 1, false, SEG ": depth free of tier-2 right position bias" },
-    { "ARP2", "1", "Integer", K_T1_S32, UVC_S_aRP2, 1, false, SEG ": depth free of tier-2 right position bias" },
-    { "aRPL", "R", "Integer", K_R_S32, UVC_S_aRPL, 1, false, SEG ": summed distance to the right segment end" },
-    { "ARPL", "1", "Integer", K_T1L_S32, UVC_S_aRPL, 1, false, SEG ": summed distance to the right segment end" },
-    { "_ALB", "1", "String", K_SEP, 0, 0, false, "Base-alignment-quality bias, left side" },
-    { "aLB1", "R", "Integer", K_R_S32, UVC_S_aLB1, 1, false, SEG ": depth free of tier-1 left alignment bias" },
-    { "aLB2", "R", "Integer", K_R_S32, UVC_S_aLB2, 1, false, SEG ": depth free of tier-2 left alignment bias" },
-    { "ALB2", "1", "Integer", K_T1_S32, UVC_S_aLB2, 1, false, SEG ": depth free of tier-2 left alignment bias" },
-    { "aLBL", "R", "Integer", K_R_S64, UVC_S64_aLBL, 1, false, SEG ": summed base-alignment quality to the left end" },
-    { "ALBL", "1", "Integer", K_T1_S64, UVC_S64_aLBL, 1, false, SEG ": summed base-alignment quality to the left end" },
-    { "_ARB", "1", "String", K_SEP, 0, 0, false, "Base-alignment-quality bias, right side" },
-    { "aRB1", "R", "Integer", K_R_S32, UVC_S_aRB1, 1, false, SEG ": depth free of tier-1 right alignment bias" },
-    { "aRB2", "R", "Integer", K_R_S32, UVC_S_aRB2, 1, false, SEG ": depth free of tier-2 right alignment bias" },
-    { "ARB2", "1", "Integer", K_T1_S32, UVC_S_aRB2, 1, false, SEG ": depth free of tier-2 right alignment bias" },
-    { "aRBL", "R", "Integer", K_R_S64, UVC_S64_aRBL, 1, false, SEG ": summed base-alignment quality to the right end" },
-    { "ARBL", "1", "Integer", K_T1_S64, UVC_S64_aRBL, 1, false, SEG ": summed base-alignment quality to the right end" },
-    { "_ALI", "1", "String", K_SEP, 0, 0, false, "Insert-end bias, left side" },
-    { "aLI1", "R", "Integer", K_R_S32, UVC_S_aLI1, 1, false, SEG ": depth free of tier-1 left insert bias" },
-    { "aLI2", "R", "Integer", K_R_S32, UVC_S_aLI2, 1, false, SEG ": depth free of tier-2 left insert bias" },
-    { "ALI2", "1", "Integer", K_T1_S32, UVC_S_aLI2, 1, false, SEG ": depth free of tier-2 left insert bias" },
-    { "aLIr", "R", "Integer", K_R_S32, UVC_S_aLIr, 1, false, SEG ": depth eligible for left reverse-strand bias" },
-    { "ALIr", "1", "Integer", K_T1_S32, UVC_S_aLIr, 1, false, SEG ": depth eligible for left reverse-strand bias" },
-    { "_ARI", "1", "String", K_SEP, 0, 0, false, "Insert-end bias, right side" },
-    { "aRI1", "R", "Integer", K_R_S32, UVC_S_aRI1, 1, false, SEG ": depth free of tier-1 right insert bias" },
-    { "aRI2", "R", "Integer", K_R_S32, UVC_S_aRI2, 1, false, SEG ": depth free of tier-2 right insert bias" },
-    { "ARI2", "1", "Integer", K_T1_S32, UVC_S_aRI2, 1, false, SEG ": depth free of tier-2 right insert bias" },
-    { "aRIf", "R", "Integer", K_R_S32, UVC_S_aRIf, 1, false, SEG ": depth eligible for right forward-strand bias" },
-    { "ARIf", "1", "Integer", K_T1_S32, UVC_S_aRIf, 1, false, SEG ": depth eligible for right forward-strand bias" },
-    { "_AX", "1", "String", K_SEP, 0, 0, false, "Further segment statistics" },
-    { "aBQ2", "R", "Integer", K_R_S32, UVC_S_aBQ2, 1, false, SEG ": depth free of tier-2 base-quality bias" },
-    { "ABQ2", "1", "Integer", K_T1_S32, UVC_S_aBQ2, 1, false, SEG ": depth free of tier-2 base-quality bias" },
-    { "aPF2", "R", "Integer", K_R_S32, UVC_S_aPF2, 1, false, SEG ": depth free of tier-2 mismatch and base-quality bias" },
-    { "APF2", "1", "Integer", K_T1_S32, UVC_S_aPF2, 1, false, SEG ": depth free of tier-2 mismatch and base-quality bias" },
-    { "aP1", "R", "Integer", K_R_S32, UVC_S_aP1, 1, false, SEG ": depth passing the distance-to-end thresholds" },
-    { "AP1", "1", "Integer", K_T1_S32, UVC_S_aP1, 1, false, SEG ": depth passing the distance-to-end thresholds" },
-    { "aP2", "R", "Integer", K_R_S32, UVC_S_aP2, 1, false, SEG ": depth that is UMI-labelled or not from amplicons" },
-    { "AP2", "1", "Integer", K_T1_S32, UVC_S_aP2, 1, false, SEG ": depth that is UMI-labelled or not from amplicons" },
-    { "_Ax", "1", "String", K_SEP, 0, 0, false, "Further segment statistics of the REF and ALT allele" },
-    { "aPF1", "R", "Integer", K_R_S32, UVC_S_aPF1, 1, false, SEG ": depth free of tier-1 mismatch and base-quality bias" },
-    { "aLIT", "R", "Integer", K_R_S64, UVC_S64_aLIT, 1, false, SEG ": summed distance to the left insert end" },
-    { "aRIT", "R", "Integer", K_R_S64, UVC_S64_aRIT, 1, false, SEG ": summed distance to the right insert end" },
-    { "aP3", "R", "Integer", K_R_S32, UVC_S_aP3, 1, false, SEG ": depth not affected by nearby InDels" },
-    { "aNC", "R", "Integer", K_R_S32, UVC_S_aNC, 1, false, SEG ": depth without clips" },
-    { "_BDP", "1", "String", K_SEP, 0, 0, false, "Fragment depths with duplicates" },
-    { "bDPf", "R", "Integer", K_R_FRf, UVC_FRAG_bDP, 1, false, FRA ": depth, forward" },
-    { "bDPr", "R", "Integer", K_R_FRr, UVC_FRAG_bDP, 1, false, FRA ": depth, reverse" },
-    { "BDPb", "2", "Integer", K_FR2_FR, UVC_FRAG_bDP, 1, false, FRA ": depth of all alleles, forward and reverse" },
-    { "BDPd", "2", "Integer", K_ZERO2, 0, 0, false, FRA ": depth of the padded deletion allele (not filled)" },
-    { "bTAf", "R", "Integer", K_R_FRf, UVC_FRAG_bTA, 1, false, FRA ": sequenced fragment positions, forward" },
-    { "bTAr", "R", "Integer", K_R_FRr, UVC_FRAG_bTA, 1, false, FRA ": sequenced fragment positions, reverse" },
-    { "BTAb", "2", "Integer", K_FR2_FR, UVC_FRAG_bTA, 1, false, FRA ": sequenced fragment positions of all alleles, forward and reverse" },
-    { "bTBf", "R", "Integer", K_R_FRf, UVC_FRAG_bTB, 1, false, FRA ": fragment positions near mutations, forward" },
-    { "bTBr", "R", "Integer", K_R_FRr, UVC_FRAG_bTB, 1, false, FRA ": fragment positions near mutations, reverse" },
-    { "BTBb", "2", "Integer", K_FR2_FR, UVC_FRAG_bTB, 1, false, FRA ": fragment positions near mutations of all alleles, forward and reverse" },
-    { "_CDP1", "1", "String", K_SEP, 0, 0, false, "De-duplicated fragment depths" },
-    { "cDP1f", "R", "Integer", K_R_FAf, UVC_FAM_cDP1, 1, false, FAM ": unfiltered depth, forward" },
-    { "cDP1r", "R", "Integer", K_R_FAr, UVC_FAM_cDP1, 1, false, FAM ": unfiltered depth, reverse" },
-    { "CDP1b", "2", "Integer", K_FR2_FA, UVC_FAM_cDP1, 1, false, FAM ": unfiltered depth of all alleles, forward and reverse" },
-    { "CDP1d", "2", "Integer", K_NN2_FA, UVC_FAM_cDP1, 1, false, FAM ": unfiltered depth of the padded deletion allele" },
-    { "cDP12f", "R", "Integer", K_R_FAf, UVC_FAM_cDP12, 1, false, FAM ": BQ-filtered depth, forward" },
-    { "cDP12r", "R", "Integer", K_R_FAr, UVC_FAM_cDP12, 1, false, FAM ": BQ-filtered depth, reverse" },
-    { "CDP12b", "2", "Integer", K_FR2_FA, UVC_FAM_cDP12, 1, false, FAM ": BQ-filtered depth of all alleles, forward and reverse" },
-    { "_CDP2", "1", "String", K_SEP, 0, 0, false, "Tier-2 single-strand consensus depths" },
-    { "cDP2f", "R", "Integer", K_R_FAf, UVC_FAM_cDP2, 1, false, SSC ": depth, forward" },
-    { "cDP2r", "R", "Integer", K_R_FAr, UVC_FAM_cDP2, 1, false, SSC ": depth, reverse" },
-    { "CDP2b", "2", "Integer", K_FR2_FA, UVC_FAM_cDP2, 1, false, SSC ": depth of all alleles, forward and reverse" },
-    { "CDP2d", "2", "Integer", K_ZERO2, 0, 0, false, SSC ": depth of the padded deletion allele (not filled)" },
-    { "c2BQ2", "R", "Integer", K_R_FI, UVC_FI_c2BQ2, 1, true, SSC ": depth free of tier-2 base-quality bias" },
-    { "C2BQ2", "1", "Integer", K_T1_FI, UVC_FI_c2BQ2, 1, true, SSC ": depth free of tier-2 base-quality bias" },
-    { "c2LP0", "R", "Integer", K_R_FI, UVC_FI_c2LP0, 1, true, SSC ": depth free of strict left position bias" },
-    { "C2LP0", "1", "Integer", K_T1_FI, UVC_FI_c2LP0, 1, true, SSC ": depth free of strict left position bias" },
-    { "c2RP0", "R", "Integer", K_R_FI, UVC_FI_c2RP0, 1, true, SSC ": depth free of strict right position bias" },
-    { "C2RP0", "1", "Integer", K_T1_FI, UVC_FI_c2RP0, 1, true, SSC ": depth free of strict right position bias" },
-    { "_C2XP", "1", "String", K_SEP, 0, 0, true, "SSCS position bias; present exactly when the SSCS tags are" },
-    { "c2LP1", "R", "Integer", K_R_FI, UVC_FI_c2LP1, 1, true, SSC ": depth free of tier-1 left position bias" },
-    { "c2LP2", "R", "Integer", K_R_FI, UVC_FI_c2LP2, 1, true, SSC ": depth free of tier-2 left position bias" },
-    { "c2RP1", "R", "Integer", K_R_FI, UVC_FI_c2RP1, 1, true, SSC ": depth free of tier-1 right position bias" },
-    { "c2RP2", "R", "Integer", K_R_FI, UVC_FI_c2RP2, 1, true, SSC ": depth free of tier-2 right position bias" },
-    { "c2LPL", "R", "Integer", K_R_FI, UVC_FI_c2LPL, 1, true, SSC ": summed distance to the left consensus end" },
-    { "c2RPL", "R", "Integer", K_R_FI, UVC_FI_c2RPL, 1, true, SSC ": summed distance to the right consensus end" },
-    { "_C2XB", "1", "String", K_SEP, 0, 0, true, "SSCS alignment-quality bias" },
-    { "c2LB1", "R", "Integer", K_R_FI, UVC_FI_c2LB1, 1, true, SSC ": depth free of tier-1 left alignment bias" },
-    { "c2LB2", "R", "Integer", K_R_FI, UVC_FI_c2LB2, 1, true, SSC ": depth free of tier-2 left alignment bias" },
-    { "c2RB1", "R", "Integer", K_R_FI, UVC_FI_c2RB1, 1, true, SSC ": depth free of tier-1 right alignment bias" },
-    { "c2RB2", "R", "Integer", K_R_FI, UVC_FI_c2RB2, 1, true, SSC ": depth free of tier-2 right alignment bias" },
-    { "c2LBL", "R", "Integer", K_R_FI64, UVC_FI64_c2LBL, 1, true, SSC ": summed base-alignment quality to the left end" },
-    { "c2RBL", "R", "Integer", K_R_FI64, UVC_FI64_c2RBL, 1, true, SSC ": summed base-alignment quality to the right end" },
-    { "_CDPx", "1", "String", K_SEP, 0, 0, true, "Further UMI-family statistics" },
-    { "cDP3f", "R", "Integer", K_R_FAf, UVC_FAM_cDP3, 1, true, FAM ": strong consensus depth, forward" },
-    { "cDP3r", "R", "Integer", K_R_FAr, UVC_FAM_cDP3, 1, true, FAM ": strong consensus depth, reverse" },
-    { "CDP3b", "2", "Integer", K_FR2_FA, UVC_FAM_cDP3, 1, true, FAM ": strong consensus depth of all alleles, forward and reverse" },
-    { "cDP21f", "R", "Integer", K_R_FAf, UVC_FAM_cDP21, 1, true, FAM ": singleton families, forward" },
-    { "cDP21r", "R", "Integer", K_R_FAr, UVC_FAM_cDP21, 1, true, FAM ": singleton families, reverse" },
-    { "CDP21b", "2", "Integer", K_FR2_FA, UVC_FAM_cDP21, 1, true, FAM ": singleton families of all alleles, forward and reverse" },
-    { "_cDPMm", "1", "String", K_SEP, 0, 0, true, "Fragments agreeing / disagreeing with the consensus of their family" },
-    { "cDPMf", "R", "Integer", K_R_FAf, UVC_FAM_cDPM, 1, true, FAM ": fragments supporting the family consensus, forward" },
-    { "cDPMr", "R", "Integer", K_R_FAr, UVC_FAM_cDPM, 1, true, FAM ": fragments supporting the family consensus, reverse" },
-    { "CDPMb", "2", "Integer", K_FR2_FA, UVC_FAM_cDPM, 1, true, FAM ": fragments supporting the family consensus, all alleles, forward and reverse" },
-    { "cDPmf", "R", "Integer", K_R_FAf, UVC_FAM_cDPm, 1, true, FAM ": fragments against the family consensus, forward" },
-    { "cDPmr", "R", "Integer", K_R_FAr, UVC_FAM_cDPm, 1, true, FAM ": fragments against the family consensus, reverse" },
-    { "CDPmb", "2", "Integer", K_FR2_FA, UVC_FAM_cDPm, 1, true, FAM ": fragments against the family consensus, all alleles, forward and reverse" },
-    { "CDPDb", "2", "Integer", K_FR2_FA, UVC_FAM_cDPD, 1, false, FAM ": SSCS depth outside duplex families, all alleles, forward and reverse" },
-    { "cDPDf", "R", "Integer", K_R_FAf, UVC_FAM_cDPD, 1, false, FAM ": SSCS depth outside duplex families, forward" },
-    { "cDPDr", "R", "Integer", K_R_FAr, UVC_FAM_cDPD, 1, false, FAM ": SSCS depth outside duplex families, reverse" },
-    { "_DDP", "1", "String", K_SEP, 0, 0, false, "Duplex consensus depths" },
-    { "DDP1", "2", "Integer", K_T2_DU, UVC_DUPLEX_dDP1, 1, false, "Duplex depth regardless of strand agreement: all alleles and the padded deletion allele" },
-    { "dDP1", "R", "Integer", K_R_DU, UVC_DUPLEX_dDP1, 1, false, "Duplex depth regardless of strand agreement" },
-    { "DDP2", "2", "Integer", K_T2_DU, UVC_DUPLEX_dDP2, 1, false, "Duplex depth with both strands agreeing: all alleles and the padded deletion allele" },
-    { "dDP2", "R", "Integer", K_R_DU, UVC_DUPLEX_dDP2, 1, false, "Duplex depth with both strands agreeing" },
-    { "_ea", "1", "String", K_SEP, 0, 0, false, "Systematic error seen in base qualities" },
-    { "aBQ", "R", "Integer", K_R_REC, UVC_O_aBQ, 1, false, "Root-mean-square base quality of the segments" },
-    { "a2BQf", "R", "Integer", K_R_REC, UVC_O_a2BQf, 1, false, "Root-sum-square base quality, forward strand" },
-    { "a2BQr", "R", "Integer", K_R_REC, UVC_O_a2BQr, 1, false, "Root-sum-square base quality, reverse strand" },
-    { "a2XM2", "R", "Integer", K_R_S32, UVC_S_a2XM2, 1, false, SEG ": depth free of absolute mismatch bias" },
-    { "a2BM2", "R", "Integer", K_R_S32, UVC_S_a2BM2, 1, false, SEG ": depth free of base-specific mismatch bias" },
-    { "aBQQ", "R", "Integer", K_R_REC, UVC_O_aBQQ, 1, false, "Variant quality cap from base-quality systematic error" },
-    { "_eb", "1", "String", K_SEP, 0, 0, false, "Systematic error seen in mapping qualities" },
-    { "bMQ", "R", "Integer", K_R_REC, UVC_O_bMQ, 1, false, "Root-mean-square mapping quality of the fragments" },
-    { "aAaMQ", "R", "Integer", K_R_REC, UVC_O_aAaMQ, 1, false, "Difference of average mapping quality between ALT and non-ALT segments" },
-    { "bNMQ", "R", "Integer", K_R_REC, UVC_O_bNMQ, 1, false, "Mapping-quality penalty inferred from nearby high-BQ mismatches" },
-    { "bNMa", "R", "Integer", K_R_REC, UVC_O_bNMa, 1, false, "Percent of ALT fragment positions near high-BQ mismatches" },
-    { "bNMb", "R", "Integer", K_R_REC, UVC_O_bNMb, 1, false, "Percent of non-ALT fragment positions near high-BQ mismatches" },
-    { "bMQQ", "R", "Integer", K_R_REC, UVC_O_bMQQ, 1, false, "Variant quality cap from mapping-quality systematic error" },
-    { "_eB", "1", "String", K_SEP, 0, 0, false, "Independent-read-support qualities, duplicates kept" },
-    { "bIAQb", "R", "Integer", K_R_VQ, UVC_VQ_bIAQb, 1, false, "IID allele quality" },
-    { "bIADb", "R", "Integer", K_R_VQ, UVC_VQ_bIADb, 1, false, "IID allele depth" },
-    { "bIDQb", "R", "Integer", K_R_VQ, UVC_VQ_bIDQb, 1, false, "IID quality per read" },
-    { "_eC", "1", "String", K_SEP, 0, 0, false, "Independent-read-support qualities, de-duplicated" },
-    { "cIAQf", "R", "Integer", K_R_VQ, UVC_VQ_cIAQf, 1, false, "IID allele quality, forward" },
-    { "cIADf", "R", "Integer", K_R_VQ, UVC_VQ_cIADf, 1, false, "IID allele depth, forward" },
-    { "cIDQf", "R", "Integer", K_R_VQ, UVC_VQ_cIDQf, 1, false, "IID quality per read, forward" },
-    { "cIAQr", "R", "Integer", K_R_VQ, UVC_VQ_cIAQr, 1, false, "IID allele quality, reverse" },
-    { "cIADr", "R", "Integer", K_R_VQ, UVC_VQ_cIADr, 1, false, "IID allele depth, reverse" },
-    { "cIDQr", "R", "Integer", K_R_VQ, UVC_VQ_cIDQr, 1, false, "IID quality per read, reverse" },
-    { "_eE", "1", "String", K_SEP, 0, 0, false, "Binomial variant qualities" },
-    { "bIAQ", "R", "Integer", K_R_REC, UVC_O_bIAQ, 1, false, "Binomial variant quality, duplicates kept" },
-    { "cIAQ", "R", "Integer", K_R_REC, UVC_O_cIAQ, 1, false, "Binomial variant quality, de-duplicated" },
-    { "bTINQ", "R", "Integer", K_R_REC, UVC_O_bTINQ, 1, false, "Binomial tumor-in-normal quality, fragments" },
-    { "cTINQ", "R", "Integer", K_R_REC, UVC_O_cTINQ, 1, false, "Binomial tumor-in-normal quality, consensus families" },
-    { "_eQ1", "1", "String", K_SEP, 0, 0, false, "Power-law qualities, de-duplicated fragments" },
-    { "cPCQ1", "R", "Integer", K_R_REC, UVC_O_cPCQ1, 1, false, "Power-law quality cap" },
-    { "cPLQ1", "R", "Integer", K_R_REC, UVC_O_cPLQ1, 1, false, "Power-law quality" },
-    { "cVQ1", "R", "Integer", K_R_REC, UVC_O_cVQ1, 1, false, "Final variant quality from de-duplicated fragments" },
-    { "gVQ1", "R", "Integer", K_R_REC, UVC_O_gVQ1, 1, false, "Final variant quality used for germline calls" },
-    { "_eQ2", "1", "String", K_SEP, 0, 0, false, "Power-law qualities, UMI families" },
-    { "cPCQ2", "R", "Integer", K_R_REC, UVC_O_cPCQ2, 1, false, "Power-law quality cap, families" },
-    { "cPLQ2", "R", "Integer", K_R_REC, UVC_O_cPLQ2, 1, false, "Power-law quality, families" },
-    { "cVQ2", "R", "Integer", K_R_REC, UVC_O_cVQ2, 1, false, "Final variant quality from UMI families" },
-    { "cMmQ", "R", "Integer", K_R_REC, UVC_O_cMmQ, 1, false, "Empirical base quality from within-family disagreement" },
-    { "dVQinc", "R", "Integer", K_R_REC, UVC_O_dVQinc, 1, false, "Increase of cVQ2 contributed by duplex families" },
-    { "_CDP1vx", "1", "String", K_SEP, 0, 0, false, "Effective support x 100, de-duplicated fragments" },
-    { "cDP1v", "R", "Integer", K_R_REC, UVC_O_cDP1v, 1, false, "Effective allele support x 100, within-sample" },
-    { "CDP1v", "2", "Integer", K_N_REC, UVC_O_CDP1v0, 2, false, "Effective total support x 100, within-sample" },
-    { "cDP1w", "R", "Integer", K_R_REC, UVC_O_cDP1w, 1, false, "Effective allele support x 100, quality cap" },
-    { "CDP1w", "1", "Integer", K_N_REC, UVC_O_CDP1w0, 1, false, "Effective total support x 100, quality cap" },
-    { "cDP1x", "R", "Integer", K_R_REC, UVC_O_cDP1x, 1, false, "Effective allele support x 100, between samples" },
-    { "CDP1x", "1", "Integer", K_N_REC, UVC_O_CDP1x0, 1, false, "Effective total support x 100, between samples" },
-    { "_CDP2vx", "1", "String", K_SEP, 0, 0, false, "Effective support x 100, UMI families" },
-    { "cDP2v", "R", "Integer", K_R_REC, UVC_O_cDP2v, 1, false, "Effective allele family support x 100, within-sample" },
-    { "CDP2v", "2", "Integer", K_N_REC, UVC_O_CDP2v0, 2, false, "Effective total family support x 100, within-sample" },
-    { "cDP2w", "R", "Integer", K_R_REC, UVC_O_cDP2w, 1, false, "Effective allele family support x 100, quality cap" },
-    { "CDP2w", "1", "Integer", K_N_REC, UVC_O_CDP2w0, 1, false, "Effective total family support x 100, quality cap" },
-    { "cDP2x", "R", "Integer", K_R_REC, UVC_O_cDP2x, 1, false, "Effective allele family support x 100, between samples" },
-    { "CDP2x", "1", "Integer", K_N_REC, UVC_O_CDP2x0, 1, false, "Effective total family support x 100, between samples" },
-    { "_f1", "1", "String", K_SEP, 0, 0, false, "Filter-related values" },
-    { "CONTQ", "R", "Integer", K_R_REC, UVC_O_CONTQ, 1, false, "Likelihood of the signal under contamination" },
-    { "nPF", ".", "Integer", K_N_REC, UVC_O_nPF0, 2, false, "Phred prior bias probabilities (position, alignment quality)" },
-    { "nNFA", ".", "Integer", K_N_REC, UVC_O_nNFA0, 6, false, "DeciPhred allele fractions with nullified bias" },
-    { "nAFA", ".", "Integer", K_N_REC, UVC_O_nAFA0, 9, false, "DeciPhred allele fractions from segment depths, each reduced by one bias" },
-    { "nBCFA", ".", "Integer", K_N_REC, UVC_O_nBCFA0, 10, false, "DeciPhred allele fractions from fragment and family depths" },
-    { "_g1", "1", "String", K_SEP, 0, 0, false, "Variant description" },
-    { "VTI", "R", "Integer", K_SPECIAL, 0, 0, false, "Variant-type ID of each allele" },
-    { "VTD", "R", "String", K_SPECIAL, 0, 0, false, "Variant-type description of each allele" },
-    { "cVQ1M", "2", "Integer", K_N_REC, UVC_O_cVQ1M0, 2, false, "cVQ1 of the two best alleles at this position" },
-    { "cVQ2M", "2", "Integer", K_N_REC, UVC_O_cVQ2M0, 2, false, "cVQ2 of the two best alleles at this position" },
-    { "cVQAM", "2", "String", K_SPECIAL, 0, 0, false, "Symbols of the two best alleles at this position" },
-    { "cVQSM", "2", "String", K_SPECIAL, 0, 0, false, "InDel strings of the two best alleles at this position" },
-    { "_g2", "1", "String", K_SEP, 0, 0, false, "All observed InDel sequences of this symbol" },
-    { "gapNf", ".", "Integer", K_SPECIAL, 0, 0, false, "Number of InDel sequences, forward" },
-    { "gapNr", ".", "Integer", K_SPECIAL, 0, 0, false, "Number of InDel sequences, reverse" },
-    { "gapSeq", ".", "String", K_SPECIAL, 0, 0, false, "InDel sequences" },
-    { "gapbAD1", ".", "Integer", K_SPECIAL, 0, 0, false, "Fragment count of each sequence, duplicates kept" },
-    { "gapcAD1", ".", "Integer", K_SPECIAL, 0, 0, false, "De-duplicated fragment count of each sequence" },
-    { "gc2AD", ".", "Integer", K_SPECIAL, 0, 0, false, "Tier-2 consensus family count of each sequence" },
-    { "gc2dAD", ".", "Integer", K_SPECIAL, 0, 0, false, "Tier-2 consensus family count of each sequence with duplex rescue" },
-    { "_g3", "1", "String", K_SEP, 0, 0, false, "The InDel allele of this record" },
-    { "bDPa", "R", "Integer", K_R_REC, UVC_O_bDPa, 1, false, "Fragments supporting exactly this InDel sequence, duplicates kept" },
-    { "cDP0a", "R", "Integer", K_R_REC, UVC_O_cDP0a, 1, false, "De-duplicated fragments supporting exactly this InDel sequence" },
-    { "gapSa", "R", "String", K_SPECIAL, 0, 0, false, "InDel string of each allele" },
-    { "_h1", "1", "String", K_SEP, 0, 0, false, "Haplotype information" },
-    { "bHap", "1", "String", K_SPECIAL, 0, 0, false, "Read-level linkage of nearby variants, duplicates kept (not produced by this writer)" },
-    { "cHap", "1", "String", K_SPECIAL, 0, 0, false, "Read-level linkage of nearby variants, de-duplicated (not produced by this writer)" },
-    { "c2Hap", "1", "String", K_SPECIAL, 0, 0, false, "Read-level linkage of nearby variants, tier-2 families (not produced by this writer)" },
-    { "_i1", "1", "String", K_SEP, 0, 0, false, "Other" },
-    { "vHGQ", "1", "Integer", K_1_REC, UVC_O_vHGQ, 1, false, "Phred odds of the allele distribution under an all-germline model" },
-    { "vAC", "2", "Integer", K_N_REC, UVC_O_vAC0, 2, false, "Number of SNV and InDel alleles above their quality thresholds at this position" },
-    { "vNLODQ", "2", "Integer", K_SPECIAL, 0, 0, false, "Germline-origin likelihood quality of the SNV and InDel sub-position" },
-    { "note", "1", "String", K_SPECIAL, 0, 0, false, "Free-text note" },
+    { "GT", "1", "String", K_SPECIAL, 0, 0, false },
+    { "GQ", "1", "Integer", K_SPECIAL, 0, 0, false },
+    { "HQ", "2", "Integer", K_SPECIAL, 0, 0, false },
+    { "FT", "1", "String", K_SPECIAL, 0, 0, false },
+    { "FTS", "A", "String", K_SPECIAL, 0, 0, false },
+    { "_A_", "1", "String", K_SEP, 0, 0, false },
+    { "DP", "1", "Integer", K_1_REC, UVC_O_DP, 1, false },
+    { "AD", "R", "Integer", K_R_REC, UVC_O_AD, 1, false },
+    { "bDP", "1", "Integer", K_1_REC, UVC_O_bDP, 1, false },
+    { "bAD", "R", "Integer", K_R_REC, UVC_O_bAD, 1, false },
+    { "c2DP", "1", "Integer", K_1_REC, UVC_O_c2DP, 1, false },
+    { "c2AD", "R", "Integer", K_R_REC, UVC_O_c2AD, 1, false },
+    { "_Aa", "1", "String", K_SEP, 0, 0, false },
+    { "APDP", "12", "Integer", K_POS, 0, 12, false },
+    { "APXM", "8", "Integer", K_POS, 1, 8, false },
+    { "_Ab", "1", "String", K_SEP, 0, 0, false },
+    { "APLRID", "4", "Integer", K_POS, 2, 4, false },
+    { "APLRI", "4", "Integer", K_POS, 3, 4, false },
+    { "APLRP", "4", "Integer", K_POS, 4, 4, false },
+    { "_Ac", "1", "String", K_SEP, 0, 0, false },
+    { "ALRPxT", "2", "Integer", K_POS, 5, 2, false },
+    { "ALRIT", "4", "Integer", K_POS, 6, 4, false },
+    { "ALRIt", "4", "Integer", K_POS, 7, 4, false },
+    { "ALRPt", "4", "Integer", K_POS, 8, 4, false },
+    { "ALRBt", "4", "Integer", K_POS, 9, 4, false },
+    { "_AQ", "1", "String", K_SEP, 0, 0, false },
+    { "aMQs", "R", "Integer", K_R_S32, UVC_S_aMQs, 1, false },
+    { "AMQs", "1", "Integer", K_T1_S32, UVC_S_aMQs, 1, false },
+    { "a1BQf", "R", "Integer", K_R_VQ, UVC_VQ_a1BQf, 1, false },
+    { "A1BQf", "1", "Integer", K_T1_VQ, UVC_VQ_a1BQf, 1, false },
+    { "a1BQr", "R", "Integer", K_R_VQ, UVC_VQ_a1BQr, 1, false },
+    { "A1BQr", "1", "Integer", K_T1_VQ, UVC_VQ_a1BQr, 1, false },
+    { "_ADPf", "1", "String", K_SEP, 0, 0, false },
+    { "aDPff", "R", "Integer", K_R_S32, UVC_S_aDPff, 1, false },
+    { "ADPff", "2", "Integer", K_T2_S32, UVC_S_aDPff, 1, false },
+    { "aDPfr", "R", "Integer", K_R_S32, UVC_S_aDPfr, 1, false },
+    { "ADPfr", "2", "Integer", K_T2_S32, UVC_S_aDPfr, 1, false },
+    { "_ADPr", "1", "String", K_SEP, 0, 0, false },
+    { "aDPrf", "R", "Integer", K_R_S32, UVC_S_aDPrf, 1, false },
+    { "ADPrf", "2", "Integer", K_T2_S32, UVC_S_aDPrf, 1, false },
+    { "aDPrr", "R", "Integer", K_R_S32, UVC_S_aDPrr, 1, false },
+    { "ADPrr", "2", "Integer", K_T2_S32, UVC_S_aDPrr, 1, false },
+    { "_ALP", "1", "String", K_SEP, 0, 0, false },
+    { "aLP1", "R", "Integer", K_R_S32, UVC_S_aLP1, 1, false },
+    { "ALP1", "1", "Integer", K_T1_S32, UVC_S_aLP1, 1, false },
+    { "aLP2", "R", "Integer", K_R_S32, UVC_S_aLP2, 1, false },
+    { "ALP2", "1", "Integer", K_T1_S32, UVC_S_aLP2, 1, false },
+    { "aLPL", "R", "Integer", K_R_S32, UVC_S_aLPL, 1, false },
+    { "ALPL", "1", "Integer", K_T1L_S32, UVC_S_aLPL, 1, false },
+    { "_ARP", "1", "String", K_SEP, 0, 0, false },
+    { "aRP1", "R", "Integer", K_R_S32, UVC_S_aRP1, 1, false },
+    { "ARP1", "1", "Integer", K_T1_S32, UVC_S_aRP1, 1, false },
+    { "aRP2", "R", "Integer", K_R_S32, UVC_S_aRP2, 1, false },
+    { "ARP2", "1", "Integer", K_T1_S32, UVC_S_aRP2, 1, false },
+    { "aRPL", "R", "Integer", K_R_S32, UVC_S_aRPL, 1, false },
+    { "ARPL", "1", "Integer", K_T1L_S32, UVC_S_aRPL, 1, false },
+    { "_ALB", "1", "String", K_SEP, 0, 0, false },
+    { "aLB1", "R", "Integer", K_R_S32, UVC_S_aLB1, 1, false },
+    { "aLB2", "R", "Integer", K_R_S32, UVC_S_aLB2, 1, false },
+    { "ALB2", "1", "Integer", K_T1_S32, UVC_S_aLB2, 1, false },
+    { "aLBL", "R", "Integer", K_R_S64, UVC_S64_aLBL, 1, false },
+    { "ALBL", "1", "Integer", K_T1_S64, UVC_S64_aLBL, 1, false },
+    { "_ARB", "1", "String", K_SEP, 0, 0, false },
+    { "aRB1", "R", "Integer", K_R_S32, UVC_S_aRB1, 1, false },
+    { "aRB2", "R", "Integer", K_R_S32, UVC_S_aRB2, 1, false },
+    { "ARB2", "1", "Integer", K_T1_S32, UVC_S_aRB2, 1, false },
+    { "aRBL", "R", "Integer", K_R_S64, UVC_S64_aRBL, 1, false },
+    { "ARBL", "1", "Integer", K_T1_S64, UVC_S64_aRBL, 1, false },
+    { "_ALI", "1", "String", K_SEP, 0, 0, false },
+    { "aLI1", "R", "Integer", K_R_S32, UVC_S_aLI1, 1, false },
+    { "aLI2", "R", "Integer", K_R_S32, UVC_S_aLI2, 1, false },
+    { "ALI2", "1", "Integer", K_T1_S32, UVC_S_aLI2, 1, false },
+    { "aLIr", "R", "Integer", K_R_S32, UVC_S_aLIr, 1, false },
+    { "ALIr", "1", "Integer", K_T1_S32, UVC_S_aLIr, 1, false },
+    { "_ARI", "1", "String", K_SEP, 0, 0, false },
+    { "aRI1", "R", "Integer", K_R_S32, UVC_S_aRI1, 1, false },
+    { "aRI2", "R", "Integer", K_R_S32, UVC_S_aRI2, 1, false },
+    { "ARI2", "1", "Integer", K_T1_S32, UVC_S_aRI2, 1, false },
+    { "aRIf", "R", "Integer", K_R_S32, UVC_S_aRIf, 1, false },
+    { "ARIf", "1", "Integer", K_T1_S32, UVC_S_aRIf, 1, false },
+    { "_AX", "1", "String", K_SEP, 0, 0, false },
+    { "aBQ2", "R", "Integer", K_R_S32, UVC_S_aBQ2, 1, false },
+    { "ABQ2", "1", "Integer", K_T1_S32, UVC_S_aBQ2, 1, false },
+    { "aPF2", "R", "Integer", K_R_S32, UVC_S_aPF2, 1, false },
+    { "APF2", "1", "Integer", K_T1_S32, UVC_S_aPF2, 1, false },
+    { "aP1", "R", "Integer", K_R_S32, UVC_S_aP1, 1, false },
+    { "AP1", "1", "Integer", K_T1_S32, UVC_S_aP1, 1, false },
+    { "aP2", "R", "Integer", K_R_S32, UVC_S_aP2, 1, false },
+    { "AP2", "1", "Integer", K_T1_S32, UVC_S_aP2, 1, false },
+    { "_Ax", "1", "String", K_SEP, 0, 0, false },
+    { "aPF1", "R", "Integer", K_R_S32, UVC_S_aPF1, 1, false },
+    { "aLIT", "R", "Integer", K_R_S64, UVC_S64_aLIT, 1, false },
+    { "aRIT", "R", "Integer", K_R_S64, UVC_S64_aRIT, 1, false },
+    { "aP3", "R", "Integer", K_R_S32, UVC_S_aP3, 1, false },
+    { "aNC", "R", "Integer", K_R_S32, UVC_S_aNC, 1, false },
+    { "_BDP", "1", "String", K_SEP, 0, 0, false },
+    { "bDPf", "R", "Integer", K_R_FRf, UVC_FRAG_bDP, 1, false },
+    { "bDPr", "R", "Integer", K_R_FRr, UVC_FRAG_bDP, 1, false },
+    { "BDPb", "2", "Integer", K_FR2_FR, UVC_FRAG_bDP, 1, false },
+    { "BDPd", "2", "Integer", K_ZERO2, 0, 0, false },
+    { "bTAf", "R", "Integer", K_R_FRf, UVC_FRAG_bTA, 1, false },
+    { "bTAr", "R", "Integer", K_R_FRr, UVC_FRAG_bTA, 1, false },
+    { "BTAb", "2", "Integer", K_FR2_FR, UVC_FRAG_bTA, 1, false },
+    { "bTBf", "R", "Integer", K_R_FRf, UVC_FRAG_bTB, 1, false },
+    { "bTBr", "R", "Integer", K_R_FRr, UVC_FRAG_bTB, 1, false },
+    { "BTBb", "2", "Integer", K_FR2_FR, UVC_FRAG_bTB, 1, false },
+    { "_CDP1", "1", "String", K_SEP, 0, 0, false },
+    { "cDP1f", "R", "Integer", K_R_FAf, UVC_FAM_cDP1, 1, false },
+    { "cDP1r", "R", "Integer", K_R_FAr, UVC_FAM_cDP1, 1, false },
+    { "CDP1b", "2", "Integer", K_FR2_FA, UVC_FAM_cDP1, 1, false },
+    { "CDP1d", "2", "Integer", K_NN2_FA, UVC_FAM_cDP1, 1, false },
+    { "cDP12f", "R", "Integer", K_R_FAf, UVC_FAM_cDP12, 1, false },
+    { "cDP12r", "R", "Integer", K_R_FAr, UVC_FAM_cDP12, 1, false },
+    { "CDP12b", "2", "Integer", K_FR2_FA, UVC_FAM_cDP12, 1, false },
+    { "_CDP2", "1", "String", K_SEP, 0, 0, false },
+    { "cDP2f", "R", "Integer", K_R_FAf, UVC_FAM_cDP2, 1, false },
+    { "cDP2r", "R", "Integer", K_R_FAr, UVC_FAM_cDP2, 1, false },
+    { "CDP2b", "2", "Integer", K_FR2_FA, UVC_FAM_cDP2, 1, false },
+    { "CDP2d", "2", "Integer", K_ZERO2, 0, 0, false },
+    { "c2BQ2", "R", "Integer", K_R_FI, UVC_FI_c2BQ2, 1, true },
+    { "C2BQ2", "1", "Integer", K_T1_FI, UVC_FI_c2BQ2, 1, true },
+    { "c2LP0", "R", "Integer", K_R_FI, UVC_FI_c2LP0, 1, true },
+    { "C2LP0", "1", "Integer", K_T1_FI, UVC_FI_c2LP0, 1, true },
+    { "c2RP0", "R", "Integer", K_R_FI, UVC_FI_c2RP0, 1, true },
+    { "C2RP0", "1", "Integer", K_T1_FI, UVC_FI_c2RP0, 1, true },
+    { "_C2XP", "1", "String", K_SEP, 0, 0, true },
+    { "c2LP1", "R", "Integer", K_R_FI, UVC_FI_c2LP1, 1, true },
+    { "c2LP2", "R", "Integer", K_R_FI, UVC_FI_c2LP2, 1, true },
+    { "c2RP1", "R", "Integer", K_R_FI, UVC_FI_c2RP1, 1, true },
+    { "c2RP2", "R", "Integer", K_R_FI, UVC_FI_c2RP2, 1, true },
+    { "c2LPL", "R", "Integer", K_R_FI, UVC_FI_c2LPL, 1, true },
+    { "c2RPL", "R", "Integer", K_R_FI, UVC_FI_c2RPL, 1, true },
+    { "_C2XB", "1", "String", K_SEP, 0, 0, true },
+    { "c2LB1", "R", "Integer", K_R_FI, UVC_FI_c2LB1, 1, true },
+    { "c2LB2", "R", "Integer", K_R_FI, UVC_FI_c2LB2, 1, true },
+    { "c2RB1", "R", "Integer", K_R_FI, UVC_FI_c2RB1, 1, true },
+    { "c2RB2", "R", "Integer", K_R_FI, UVC_FI_c2RB2, 1, true },
+    { "c2LBL", "R", "Integer", K_R_FI64, UVC_FI64_c2LBL, 1, true },
+    { "c2RBL", "R", "Integer", K_R_FI64, UVC_FI64_c2RBL, 1, true },
+    { "_CDPx", "1", "String", K_SEP, 0, 0, true },
+    { "cDP3f", "R", "Integer", K_R_FAf, UVC_FAM_cDP3, 1, true },
+    { "cDP3r", "R", "Integer", K_R_FAr, UVC_FAM_cDP3, 1, true },
+    { "CDP3b", "2", "Integer", K_FR2_FA, UVC_FAM_cDP3, 1, true },
+    { "cDP21f", "R", "Integer", K_R_FAf, UVC_FAM_cDP21, 1, true },
+    { "cDP21r", "R", "Integer", K_R_FAr, UVC_FAM_cDP21, 1, true },
+    { "CDP21b", "2", "Integer", K_FR2_FA, UVC_FAM_cDP21, 1, true },
+    { "_cDPMm", "1", "String", K_SEP, 0, 0, true },
+    { "cDPMf", "R", "Integer", K_R_FAf, UVC_FAM_cDPM, 1, true },
+    { "cDPMr", "R", "Integer", K_R_FAr, UVC_FAM_cDPM, 1, true },
+    { "CDPMb", "2", "Integer", K_FR2_FA, UVC_FAM_cDPM, 1, true },
+    { "cDPmf", "R", "Integer", K_R_FAf, UVC_FAM_cDPm, 1, true },
+    { "cDPmr", "R", "Integer", K_R_FAr, UVC_FAM_cDPm, 1, true },
+    { "CDPmb", "2", "Integer", K_FR2_FA, UVC_FAM_cDPm, 1, true },
+    { "CDPDb", "2", "Integer", K_FR2_FA, UVC_FAM_cDPD, 1, false },
+    { "cDPDf", "R", "Integer", K_R_FAf, UVC_FAM_cDPD, 1, false },
+    { "cDPDr", "R", "Integer", K_R_FAr, UVC_FAM_cDPD, 1, false },
+    { "_DDP", "1", "String", K_SEP, 0, 0, false },
+    { "DDP1", "2", "Integer", K_T2_DU, UVC_DUPLEX_dDP1, 1, false },
+    { "dDP1", "R", "Integer", K_R_DU, UVC_DUPLEX_dDP1, 1, false },
+    { "DDP2", "2", "Integer", K_T2_DU, UVC_DUPLEX_dDP2, 1, false },
+    { "dDP2", "R", "Integer", K_R_DU, UVC_DUPLEX_dDP2, 1, false },
+    { "_ea", "1", "String", K_SEP, 0, 0, false },
+    { "aBQ", "R", "Integer", K_R_REC, UVC_O_aBQ, 1, false },
+    { "a2BQf", "R", "Integer", K_R_REC, UVC_O_a2BQf, 1, false },
+    { "a2BQr", "R", "Integer", K_R_REC, UVC_O_a2BQr, 1, false },
+    { "a2XM2", "R", "Integer", K_R_S32, UVC_S_a2XM2, 1, false },
+    { "a2BM2", "R", "Integer", K_R_S32, UVC_S_a2BM2, 1, false },
+    { "aBQQ", "R", "Integer", K_R_REC, UVC_O_aBQQ, 1, false },
+    { "_eb", "1", "String", K_SEP, 0, 0, false },
+    { "bMQ", "R", "Integer", K_R_REC, UVC_O_bMQ, 1, false },
+    { "aAaMQ", "R", "Integer", K_R_REC, UVC_O_aAaMQ, 1, false },
+    { "bNMQ", "R", "Integer", K_R_REC, UVC_O_bNMQ, 1, false },
+    { "bNMa", "R", "Integer", K_R_REC, UVC_O_bNMa, 1, false },
+    { "bNMb", "R", "Integer", K_R_REC, UVC_O_bNMb, 1, false },
+    { "bMQQ", "R", "Integer", K_R_REC, UVC_O_bMQQ, 1, false },
+    { "_eB", "1", "String", K_SEP, 0, 0, false },
+    { "bIAQb", "R", "Integer", K_R_VQ, UVC_VQ_bIAQb, 1, false },
+    { "bIADb", "R", "Integer", K_R_VQ, UVC_VQ_bIADb, 1, false },
+    { "bIDQb", "R", "Integer", K_R_VQ, UVC_VQ_bIDQb, 1, false },
+    { "_eC", "1", "String", K_SEP, 0, 0, false },
+    { "cIAQf", "R", "Integer", K_R_VQ, UVC_VQ_cIAQf, 1, false },
+    { "cIADf", "R", "Integer", K_R_VQ, UVC_VQ_cIADf, 1, false },
+    { "cIDQf", "R", "Integer", K_R_VQ, UVC_VQ_cIDQf, 1, false },
+    { "cIAQr", "R", "Integer", K_R_VQ, UVC_VQ_cIAQr, 1, false },
+    { "cIADr", "R", "Integer", K_R_VQ, UVC_VQ_cIADr, 1, false },
+    { "cIDQr", "R", "Integer", K_R_VQ, UVC_VQ_cIDQr, 1, false },
+    { "_eE", "1", "String", K_SEP, 0, 0, false },
+    { "bIAQ", "R", "Integer", K_R_REC, UVC_O_bIAQ, 1, false },
+    { "cIAQ", "R", "Integer", K_R_REC, UVC_O_cIAQ, 1, false },
+    { "bTINQ", "R", "Integer", K_R_REC, UVC_O_bTINQ, 1, false },
+    { "cTINQ", "R", "Integer", K_R_REC, UVC_O_cTINQ, 1, false },
+    { "_eQ1", "1", "String", K_SEP, 0, 0, false },
+    { "cPCQ1", "R", "Integer", K_R_REC, UVC_O_cPCQ1, 1, false },
+    { "cPLQ1", "R", "Integer", K_R_REC, UVC_O_cPLQ1, 1, false },
+    { "cVQ1", "R", "Integer", K_R_REC, UVC_O_cVQ1, 1, false },
+    { "gVQ1", "R", "Integer", K_R_REC, UVC_O_gVQ1, 1, false },
+    { "_eQ2", "1", "String", K_SEP, 0, 0, false },
+    { "cPCQ2", "R", "Integer", K_R_REC, UVC_O_cPCQ2, 1, false },
+    { "cPLQ2", "R", "Integer", K_R_REC, UVC_O_cPLQ2, 1, false },
+    { "cVQ2", "R", "Integer", K_R_REC, UVC_O_cVQ2, 1, false },
+    { "cMmQ", "R", "Integer", K_R_REC, UVC_O_cMmQ, 1, false },
+    { "dVQinc", "R", "Integer", K_R_REC, UVC_O_dVQinc, 1, false },
+    { "_CDP1vx", "1", "String", K_SEP, 0, 0, false },
+    { "cDP1v", "R", "Integer", K_R_REC, UVC_O_cDP1v, 1, false },
+    { "CDP1v", "2", "Integer", K_N_REC, UVC_O_CDP1v0, 2, false },
+    { "cDP1w", "R", "Integer", K_R_REC, UVC_O_cDP1w, 1, false },
+    { "CDP1w", "1", "Integer", K_N_REC, UVC_O_CDP1w0, 1, false },
+    { "cDP1x", "R", "Integer", K_R_REC, UVC_O_cDP1x, 1, false },
+    { "CDP1x", "1", "Integer", K_N_REC, UVC_O_CDP1x0, 1, false },
+    { "_CDP2vx", "1", "String", K_SEP, 0, 0, false },
+    { "cDP2v", "R", "Integer", K_R_REC, UVC_O_cDP2v, 1, false },
+    { "CDP2v", "2", "Integer", K_N_REC, UVC_O_CDP2v0, 2, false },
+    { "cDP2w", "R", "Integer", K_R_REC, UVC_O_cDP2w, 1, false },
+    { "CDP2w", "1", "Integer", K_N_REC, UVC_O_CDP2w0, 1, false },
+    { "cDP2x", "R", "Integer", K_R_REC, UVC_O_cDP2x, 1, false },
+    { "CDP2x", "1", "Integer", K_N_REC, UVC_O_CDP2x0, 1, false },
+    { "_f1", "1", "String", K_SEP, 0, 0, false },
+    { "CONTQ", "R", "Integer", K_R_REC, UVC_O_CONTQ, 1, false },
+    { "nPF", ".", "Integer", K_N_REC, UVC_O_nPF0, 2, false },
+    { "nNFA", ".", "Integer", K_N_REC, UVC_O_nNFA0, 6, false },
+    { "nAFA", ".", "Integer", K_N_REC, UVC_O_nAFA0, 9, false },
+    { "nBCFA", ".", "Integer", K_N_REC, UVC_O_nBCFA0, 10, false },
+    { "_g1", "1", "String", K_SEP, 0, 0, false },
+    { "VTI", "R", "Integer", K_SPECIAL, 0, 0, false },
+    { "VTD", "R", "String", K_SPECIAL, 0, 0, false },
+    { "cVQ1M", "2", "Integer", K_N_REC, UVC_O_cVQ1M0, 2, false },
+    { "cVQ2M", "2", "Integer", K_N_REC, UVC_O_cVQ2M0, 2, false },
+    { "cVQAM", "2", "String", K_SPECIAL, 0, 0, false },
+    { "cVQSM", "2", "String", K_SPECIAL, 0, 0, false },
+    { "_g2", "1", "String", K_SEP, 0, 0, false },
+    { "gapNf", ".", "Integer", K_SPECIAL, 0, 0, false },
+    { "gapNr", ".", "Integer", K_SPECIAL, 0, 0, false },
+    { "gapSeq", ".", "String", K_SPECIAL, 0, 0, false },
+    { "gapbAD1", ".", "Integer", K_SPECIAL, 0, 0, false },
+    { "gapcAD1", ".", "Integer", K_SPECIAL, 0, 0, false },
+    { "gc2AD", ".", "Integer", K_SPECIAL, 0, 0, false },
+    { "gc2dAD", ".", "Integer", K_SPECIAL, 0, 0, false },
+    { "_g3", "1", "String", K_SEP, 0, 0, false },
+    { "bDPa", "R", "Integer", K_R_REC, UVC_O_bDPa, 1, false },
+    { "cDP0a", "R", "Integer", K_R_REC, UVC_O_cDP0a, 1, false },
+    { "gapSa", "R", "String", K_SPECIAL, 0, 0, false },
+    { "_h1", "1", "String", K_SEP, 0, 0, false },
+    { "bHap", "1", "String", K_SPECIAL, 0, 0, false },
+    { "cHap", "1", "String", K_SPECIAL, 0, 0, false },
+    { "c2Hap", "1", "String", K_SPECIAL, 0, 0, false },
+    { "_i1", "1", "String", K_SEP, 0, 0, false },
+    { "vHGQ", "1", "Integer", K_1_REC, UVC_O_vHGQ, 1, false },
+    { "vAC", "2", "Integer", K_N_REC, UVC_O_vAC0, 2, false },
+    { "vNLODQ", "2", "Integer", K_SPECIAL, 0, 0, false },
+    { "note", "1", "String", K_SPECIAL, 0, 0, false },
 };
 const int N_TAGS = (int)(sizeof(TAGS) / sizeof(TAGS[0]));
 
@@ -398,59 +398,86 @@ struct Rows {   // uvcgpu_region_indel_alleles
 
 extern "C" const char *uvcgpu_vcf_format_keys(int32_t with_tier2) { return g_keys[with_tier2 ? 1 : 0].c_str(); }
 
-extern "C" int uvcgpu_vcf_header(const UvcParams *P, const char *sample, const char *tumor_sample, const char *const *names, const int64_t *lens, int32_t n_contigs, char *dst, int64_t cap, int64_t *len) {
+// generate_vcf_header, main.hpp:5778-5883.  The texts are the reference's (a VCF consumer sees them: "bcf_formats output unchanged"); the
+// ##FILTER / ##FORMAT lines come from its own generator (uvc_vcf_header_lines.inc).  Where the reference prints facts about its run --
+// ##fileDate, ##reference, ##variantCallerCommand -- the caller hands them in (uvcgpu_vcf_header_ex; NULL leaves the line out, which is
+// what uvcgpu_vcf_header does); ##variantCallerVersion names this library, not uvc.
+#include "uvc_vcf_header_lines.inc"
+extern "C" int uvcgpu_vcf_header_ex(const UvcParams *P, const char *sample, const char *tumor_sample, const char *const *names, const int64_t *lens, int32_t n_contigs,
+                                    const char *file_date, const char *reference_fname, const char *command_line, char *dst, int64_t cap, int64_t *len) {
     if (!P || !len || (n_contigs > 0 && (!names || !lens))) return uvcgpu_fail_(UVCGPU_EINVAL, "bad argument");
     std::string h = "##fileformat=VCFv4.2\n";
+    if (file_date) h += std::string("##fileDate=") + file_date + "\n";
+    if (reference_fname) h += std::string("##reference=") + reference_fname + "\n";
     for (int i = 0; i < n_contigs; i++) h += std::string("##contig=<ID=") + names[i] + ",length=" + std::to_string((long long)lens[i]) + ">\n";
-    h += "##ALT=<ID=NON_REF,Description=\"Any possible alternative allele at this location\">\n";
-    const char *const flt[][2] = { { "noVar", "Not a variant" }, { "upstreamDel", "Deletion extended from an upstream deletion" }, { "s50", "Less than half of the samples have data" },
-        { "Q10", "Quality below 10" }, { "Q20", "Quality below 20" }, { "Q30", "Quality below 30" }, { "Q40", "Quality below 40" }, { "Q50", "Quality below 50" }, { "Q60", "Quality below 60" },
-        { "aInsertSize", "FORMAT/FTS: stranded insert-size bias" }, { "aBQXM", "FORMAT/FTS: base-quality and mismatch bias" }, { "bcDup", "FORMAT/FTS: duplication bias, raw against de-duplicated" },
-        { "cbDup", "FORMAT/FTS: duplication bias, de-duplicated against raw" }, { "aAlignL", "FORMAT/FTS: alignment bias, left" }, { "aAlignR", "FORMAT/FTS: alignment bias, right" },
-        { "aPositionL", "FORMAT/FTS: position bias, left" }, { "aPositionR", "FORMAT/FTS: position bias, right" }, { "abPositionL", "FORMAT/FTS: insert-end position bias, left" },
-        { "abPositionR", "FORMAT/FTS: insert-end position bias, right" }, { "aStrand", "FORMAT/FTS: strand bias" }, { "c0Orientation", "FORMAT/FTS: read-orientation bias, de-duplicated fragments" },
-        { "c2Orientation", "FORMAT/FTS: read-orientation bias, tier-2 families" }, { "c2AlignL", "FORMAT/FTS: alignment bias of tier-2 families, left" }, { "c2AlignR", "FORMAT/FTS: alignment bias of tier-2 families, right" },
-        { "c2PositionL", "FORMAT/FTS: position bias of tier-2 families, left" }, { "c2PositionR", "FORMAT/FTS: position bias of tier-2 families, right" },
-        { "c2StrictPosL", "FORMAT/FTS: strict position bias of tier-2 families, left" }, { "c2StrictPosR", "FORMAT/FTS: strict position bias of tier-2 families, right" } };
-    for (const auto &f : flt) h += std::string("##FILTER=<ID=") + f[0] + ",Description=\"" + f[1] + "\">\n";
-    h += "##INFO=<ID=ANY_VAR,Number=0,Type=Flag,Description=\"Variant of germline or somatic origin\">\n";
-    h += "##INFO=<ID=GERMLINE,Number=0,Type=Flag,Description=\"Germline variant\">\n";
+    h += "##ALT=<ID=NON_REF,Description=\"Represents any possible alternative allele at this location, where POS (start position) is one-based inclusive. "
+         "CAVEAT: this VCF line record is similar to a GVCF block but does not conform to the GVCF specifications. \">\n";
+    for (const char *l : REF_FILTER_LINES) { h += l; h += '\n'; }
+    h += "##INFO=<ID=ANY_VAR,Number=0,Type=Flag,Description=\"Any type of variant which may be caused by germline polymorphism and/or somatic mutation\">\n";
+    h += "##INFO=<ID=GERMLINE,Number=0,Type=Flag,Description=\"germline variant\">\n";
     h += "##INFO=<ID=SOMATIC,Number=0,Type=Flag,Description=\"Somatic variant\">\n";
-    h += "##INFO=<ID=MGVCF_BLOCK,Number=0,Type=Flag,Description=\"Block of up to 1000 consecutive positions summarised by FORMAT/POS_VT_BDP_CDP_HomRefQ\">\n";
-    h += "##INFO=<ID=ADDITIONAL_INDEL_CANDIDATE,Number=0,Type=Flag,Description=\"Position with many clipped alignments next to it or at the start of a long repeat track\">\n";
-    h += "##INFO=<ID=SomaticQ,Number=A,Type=Float,Description=\"Phred odds that the variant is not somatic\">\n";
-    h += "##INFO=<ID=TLODQ,Number=A,Type=Float,Description=\"Phred odds that the variant is an artifact\">\n";
-    h += "##INFO=<ID=NLODQ,Number=A,Type=Float,Description=\"Phred odds that the variant is of germline origin\">\n";
-    h += "##INFO=<ID=NLODV,Number=A,Type=String,Description=\"The symbol that minimizes NLODQ\">\n";
-    h += "##INFO=<ID=TNBQF,Number=4,Type=Float,Description=\"Binomial reward, power-law reward, systematic-error penalty and normal-adjusted quality, de-duplicated fragments\">\n";
-    h += "##INFO=<ID=TNCQF,Number=4,Type=Float,Description=\"Binomial reward, power-law reward, systematic-error penalty and normal-adjusted quality, consensus families\">\n";
-    h += "##INFO=<ID=tbDP,Number=1,Type=Integer,Description=\"Tumor fragment depth, duplicates kept\">\n";
-    h += "##INFO=<ID=tDP,Number=1,Type=Integer,Description=\"Tumor de-duplicated depth\">\n";
-    h += "##INFO=<ID=tAD,Number=R,Type=Integer,Description=\"Tumor de-duplicated depth of each allele\">\n";
-    h += "##INFO=<ID=t2DP,Number=1,Type=Integer,Description=\"Tumor family depth with duplex rescue\">\n";
-    h += "##INFO=<ID=t2AD,Number=R,Type=Integer,Description=\"Tumor family depth of each allele with duplex rescue\">\n";
-    h += "##INFO=<ID=nDP,Number=1,Type=Integer,Description=\"Normal de-duplicated depth\">\n";
-    h += "##INFO=<ID=nAD,Number=R,Type=Integer,Description=\"Normal de-duplicated depth of each allele\">\n";
-    h += "##INFO=<ID=n2AD,Number=R,Type=Integer,Description=\"Normal family depth of each allele\">\n";
-    h += "##INFO=<ID=RU,Number=1,Type=String,Description=\"Shortest repeating unit in the reference\">\n";
-    h += "##INFO=<ID=RC,Number=1,Type=Integer,Description=\"Number of uninterrupted repeating units in the reference\">\n";
-    h += "##INFO=<ID=R3X2,Number=6,Type=Integer,Description=\"Repeat start, track length and unit size at the positions before and after this one\">\n";
-    for (int i = 0; i < N_TAGS; i++)
-        h += std::string("##FORMAT=<ID=") + TAGS[i].name + ",Number=" + TAGS[i].number + ",Type=" + TAGS[i].type + ",Description=\"" + (TAGS[i].kind == K_SEP ? "SUB-HEADER: " : "") + TAGS[i].desc + "\">\n";
-    h += "##FORMAT=<ID=GL4,Number=4,Type=Integer,Description=\"Genotype likelihoods of 0/0, 0/1, 1/1 and 1/2\">\n";
-    h += "##FORMAT=<ID=GST,Number=.,Type=Integer,Description=\"Genotype statistics\">\n";
-    h += "##FORMAT=<ID=CDP1,Number=2,Type=Integer,Description=\"De-duplicated depth of all alleles and of the padded deletion allele\">\n";
-    h += "##FORMAT=<ID=cDP1,Number=2,Type=Integer,Description=\"De-duplicated depth of the alleles\">\n";
-    h += "##FORMAT=<ID=POS_VT_BDP_CDP_HomRefQ,Number=.,Type=Integer,Description=\"MGVCF block: runs of (position, sub-position type 1 = SNV 2 = InDel, ., depth with duplicates, de-duplicated depth, BQ-filtered de-duplicated depth, homozygous-reference quality, .), then the end position\">\n";
-    h += "##FORMAT=<ID=clipDP,Number=2,Type=Integer,Description=\"Segment depth and segment depth with long clips next to the position\">\n";
+    h += "##INFO=<ID=MGVCF_BLOCK,Number=0,Type=Flag,Description=\"Multi-sample GVCF-like genomic regions consisting of " + std::to_string(1000 /* MGVCF_REGION_MAX_SIZE, common.hpp:44 */) + " consecutive positions. "
+         "MGVCF is modified from GVCF to allow for easy comparison of sequencing depths of multiple samples at any arbitrary position. "
+         "More detail is described in FORMAT/POS_VT_BDP_CDP_HomRefQ. \">\n";
+    h += "##INFO=<ID=ADDITIONAL_INDEL_CANDIDATE,Number=0,Type=Flag,Description=\"Position with an abnormally high number of (soft/hard)-clipped sequences adjacent to this position (which can be caused by long InDel, copy-number variation (CNV), structural variation (SV), etc.) or with a high STR track length after it\">\n";
+    h += "##INFO=<ID=SomaticQ,Number=A,Type=Float,Description=\"Somatic quality of the variant, the Phred-scaled odds that this variant is not somatic. "
+         "CAVEAT: if only tumor bam file is provided, then this quality usually cannot reach 60 even with the help of a very big germline database because "
+         "germline and somatic variants share similar characteristics in the tumor. "
+         "Therefore, a matched normal is absolutely required to confidently determine the germline-vs-somatic origin of a biological variant. \">\n";
+    h += "##INFO=<ID=TLODQ,Number=A,Type=Float,Description=\"Tumor log-of-data-likelihood quality, the Phred-scaled odds that this variant is not of biological origin (i.e., artifactual). \">\n";
+    h += "##INFO=<ID=NLODQ,Number=A,Type=Float,Description=\"Normal log-of-data-likelihood quality, the Phred-scaled odds that this variant is of germline origin. \">\n";
+    h += "##INFO=<ID=NLODV,Number=A,Type=String,Description=\"The variant symbol that minimizes NLODQ. \">\n";
+    h += "##INFO=<ID=TNBQF,Number=4,Type=Float,Description=\"Binomial reward, power-law reward, systematic-error penalty, and normal-adjusted tumor variant quality computed using deduplicated read fragments. \">\n";
+    h += "##INFO=<ID=TNCQF,Number=4,Type=Float,Description=\"Binomial reward, power-law reward, systematic-error penalty, and normal-adjusted tumor variant quality computed using consensus families of read fragments. \">\n";
+    h += "##INFO=<ID=tbDP,Number=1,Type=Integer,Description=\"Tumor total non-deduped depth (deprecated, please see BDPb (previously named as BDPf and BDPr)). \">\n";
+    h += "##INFO=<ID=tDP,Number=1,Type=Integer,Description=\"Tumor total deduped depth (deprecated, please see CDP1b (previously named as CDP1f and CDP1r)). \">\n";
+    h += "##INFO=<ID=tAD,Number=R,Type=Integer,Description=\"Tumor deduped depth of each allele (deprecated, please see cDP1f and cDP1r). \">\n";
+    h += "##INFO=<ID=t2DP,Number=1,Type=Integer,Description=\"Tumor total UMI-barcoded-family depth for duplex-rescued SSCS (CDP2b + DDP2 (previously used CDP2f and CDP2r)). \">\n";
+    h += "##INFO=<ID=t2AD,Number=R,Type=Integer,Description=\"Tumor UMI-barcoded-family depth of each allele for duplex-rescued SSCS (cDP2b + dDP2 (previously used cDP2f and cDP2r)). \">\n";
+    h += "##INFO=<ID=nDP,Number=1,Type=Integer,Description=\"Normal total deduped depth (deprecated, please see CDP1b (previously named as CDP1f and CDP1r)). \">\n";
+    h += "##INFO=<ID=nAD,Number=R,Type=Integer,Description=\"Normal deduped depth of each allele (deprecated, please see cDP1f and cDP1r). \">\n";
+    h += "##INFO=<ID=n2AD,Number=R,Type=Integer,Description=\"Normal UMI-barcoded-family depth of each allele (deprecated, please see cDP2f and cDP2r). \">\n";
+    h += "##INFO=<ID=RU,Number=1,Type=String,Description=\"The shortest repeating unit in the reference\">\n";
+    h += "##INFO=<ID=RC,Number=1,Type=Integer,Description=\"The number of non-interrupted RUs in the reference\">\n";
+    h += "##INFO=<ID=R3X2,Number=6,Type=Integer,Description=\"Repeat start position, repeat track length, and repeat unit size at the two positions before and after this VCF position. \">\n";
+    for (const char *l : REF_FORMAT_LINES) { h += l; h += '\n'; }
+    h += "##FORMAT=<ID=GL4,Number=4,Type=Integer,Description=\"The four genotype likelihoods for 0/0, 0/1, 1/1, and 1/2\">\n";
+    h += "##FORMAT=<ID=GST,Number=.,Type=Integer,Description=\"The genotype statistics\">\n";
+    h += "##FORMAT=<ID=CDP1,Number=2,Type=Integer,Description=\"(CDP1f + CDP1r) for all alleles by sum and for the padded deletion allele\">\n";
+    h += "##FORMAT=<ID=cDP1,Number=2,Type=Integer,Description=\"(cDP1f + cDP1r)\">\n";
+    h += "##FORMAT=<ID=POS_VT_BDP_CDP_HomRefQ,Number=.,Type=Integer,Description=\"Summary of multiple GVCF regions in a line with INFO/MGVCF. "
+         "This field conforms to the following regular expression: ((<pos>,<postype>,<.>,<dup>,<dedup>,<dedupBQ>,<homrefQ>,<.>)+<endpos>) "
+         "where (x)+ means one or more occurrence of the expression x. "
+         "The integer <pos> denotes position (coordinate on the reference sequence) that separates adjacent regions on the reference sequence. "
+         "The integer <postype> denotes position type, where 1 and 2 mean SNV and InDel sub-positions, respectively. "
+         "The missing integer represented by the dot symbol <.> is a sentinel value that delimits region separators (aka positions) and region information. "
+         "The integer <dup> is the minimum non-deduplicated fragment depth of the region. "
+         "The integer <dedup> is the minimum deduplicated fragment depth (with duplicated fragments counted only once). "
+         "The integer <dedupBQ> is similar to <dedup> but is computed using only support with R1R2-adjusted BQ passing the threshold set by the command-line parameter --fam-thres-highBQ. "
+         "The integer <homrefQ> is the minimum likelihood of the homozygous-reference (homref) genotype (GT) in this region. "
+         "The integer <endpos> denotes the SNV ending sub-position of the set of regions on this VCF line, and <endpos> is the last number in this field. "
+         "The (inclusive) begin position of the current region is the (exclusive) end position of the previous region. "
+         "Each genomic position (e.g., chr1:99) is divided into (a) one SNV sub-position and (b) one InDel sub-position that is right after the SNV sub-position. "
+         "The SNV prior of homref GT is used here. "
+         "Thus, the actual InDel likelihood of homref GT is the one shown here plus "
+         + std::to_string(P->germ_phred_hetero_indel - P->germ_phred_hetero_snp) + ". "
+         "CAVEAT: HomRefQ is computed by a very fast but imprecise algorithm, so it is not as accurate as GQ. \">\n";
+    h += std::string("##FORMAT=<ID=clipDP,Number=2,Type=Integer,Description=\"Total segment depth and segment depth with adjacent long clips "
+         "(for the ") + "<ADDITIONAL_INDEL_CANDIDATE>" /* SYMBOL_TO_DESC_ARR[ADDITIONAL_INDEL_CANDIDATE_SYMBOL], main_conversion.hpp:345 */ + " symbolic ALT allele indicating that this position has a lot of long (soft/hard) clips nearby) or that this position is at the beginning of a long STR track\">\n";
     h += "##phasing=partial\n";
-    h += std::string("##variantCallerInferredParameters=(inferred_sequencing_platform=") + (P->inferred_sequencing_platform == UVC_PLATFORM_IONTORRENT ? "IonTorrent" : "Illumina/BGI")
-       + ",central_readlen=" + std::to_string(P->central_readlen) + ")\n";
+    h += std::string("##variantCallerVersion=") + uvcgpu_version() + " (MI355X-native implementation of the uvc 0.15.1 hot path)\n";
+    if (command_line) h += std::string("##variantCallerCommand=") + command_line + "\n";
+    const char *plat = (P->inferred_sequencing_platform == UVC_PLATFORM_ILLUMINA ? "Illumina/BGI" : P->inferred_sequencing_platform == UVC_PLATFORM_IONTORRENT ? "IonTorrent/LifeTechnologies/ThermoFisher"
+                        : P->inferred_sequencing_platform == UVC_PLATFORM_OTHER ? "OtherSequencingPlatform" : "AUTO");   // SEQUENCING_PLATFORM_TO_NAME, common.cpp:26-32
+    h += std::string("##variantCallerInferredParameters=(inferred_sequencing_platform=") + plat + ",central_readlen=" + std::to_string(P->central_readlen) + ")\n";
     h += std::string("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t") + (sample ? sample : "SAMPLE") + ((tumor_sample && *tumor_sample) ? std::string("\t") + tumor_sample : std::string()) + "\n";
     *len = (int64_t)h.size();
     if (!dst || cap < (int64_t)h.size()) return uvcgpu_fail_(UVCGPU_ENOMEM, "destination too small");
     memcpy(dst, h.data(), h.size());
     return 0;
+}
+extern "C" int uvcgpu_vcf_header(const UvcParams *P, const char *sample, const char *tumor_sample, const char *const *names, const int64_t *lens, int32_t n_contigs, char *dst, int64_t cap, int64_t *len) {
+    return uvcgpu_vcf_header_ex(P, sample, tumor_sample, names, lens, n_contigs, nullptr, nullptr, nullptr, dst, cap, len);
 }
 
 extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, const UvcScoreOut *scored, const UvcScoreRequest *req,
