@@ -492,6 +492,28 @@ static void segbias(State &S, bool isGap, i32 bq, i32 rpos, int sym, const Aln &
     }
 }
 
+// Test hook (tests/test_segbias_cpu.py): ONE call of dealwith_segbias on a zeroed cell of the handle's planes, with the position's
+// SegFormatThresSet given by the caller; out = the cell's SegFormatInfoSet i32 fields, its four i64 fields, then a1BQf a1BQr a2BQf a2BQr.
+void test_segbias(State &S, bool isGap, i32 bq, i32 rpos, int sym, i32 a_pos, i32 a_endpos, i32 a_mpos, i32 a_isize, i32 a_flag, i32 a_mapq,
+                  i32 xm1500, i32 bm1500, int cigar_op, i32 indel_len, i32 dist, int dflag, i32 clip_cnt, const i32 *thres, i64 *out) {
+    const i64 x = rpos - S.beg;
+    if (S.seg32.empty()) {   // the planes are allocated by accumulate(): a handle without reads gets them here
+        S.thres.assign((size_t)S.npos * UVC_NTHRES, 0); S.seg32.assign((size_t)S.npos * NSYM * UVC_NSEG32, 0); S.seg64.assign((size_t)S.npos * NSYM * UVC_NSEG64, 0);
+        S.vq.assign((size_t)S.npos * NSYM * UVC_NVQ, 0);
+    }
+    for (int f = 0; f < UVC_NTHRES; f++) S.th(f, x) = thres[f];
+    for (int f = 0; f < UVC_NSEG32; f++) S.s32(f, sym, x) = 0;
+    for (int f = 0; f < UVC_NSEG64; f++) S.s64(f, sym, x) = 0;
+    for (int f = 0; f < UVC_NVQ; f++) S.VQ(f, sym, x) = 0;
+    Aln a; memset(&a, 0, sizeof(a));
+    a.pos = a_pos; a.endpos = a_endpos; a.mpos = a_mpos; a.isize = a_isize; a.flag = a_flag; a.mapq = a_mapq;
+    segbias(S, isGap, bq, rpos, sym, a, xm1500, bm1500, cigar_op, indel_len, dist, dflag, clip_cnt);
+    int k = 0;
+    for (int f = 0; f < UVC_NSEG32; f++) out[k++] = S.s32(f, sym, x);
+    for (int f = 0; f < UVC_NSEG64; f++) out[k++] = S.s64(f, sym, x);
+    out[k++] = S.VQ(UVC_VQ_a1BQf, sym, x); out[k++] = S.VQ(UVC_VQ_a1BQr, sym, x); out[k++] = S.VQ(UVC_VQ_a2BQf, sym, x); out[k++] = S.VQ(UVC_VQ_a2BQr, sym, x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // ref_to_phredvalue, main.hpp:876-922.  NOTE: n_units is an OUT parameter bound to inslen/dellen
 // at the call sites (main.hpp:2025-2026, 2134-2135), so it overwrites the indel length there.

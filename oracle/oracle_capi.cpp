@@ -5,7 +5,9 @@
 
 using namespace uvco;
 
-namespace uvco { i32 oracle_sscs_phred(const UvcParams &P, int con_symbol, int alt_symbol); }
+namespace uvco { i32 oracle_sscs_phred(const UvcParams &P, int con_symbol, int alt_symbol);
+void test_segbias(State &S, bool isGap, i32 bq, i32 rpos, int sym, i32 a_pos, i32 a_endpos, i32 a_mpos, i32 a_isize, i32 a_flag, i32 a_mapq,
+                  i32 xm1500, i32 bm1500, int cigar_op, i32 indel_len, i32 dist, int dflag, i32 clip_cnt, const i32 *thres, i64 *out); }
 
 static thread_local std::string g_err;
 
@@ -140,6 +142,13 @@ int uvc_oracle_region_read_quals(void *h, uint8_t *dst, int64_t n) {
     return 0;
 }
 
+// test hook: one dealwith_segbias call (args[17] = isGap bq rpos sym pos endpos mpos isize flag mapq xm1500 bm1500 cigar_op indel_len dist dflag clip_cnt)
+int uvc_oracle_test_segbias(void *h, const int32_t *args, const int32_t *thres, int64_t *out) {
+    State &S = *(State *)h;
+    if (args[2] < S.beg || args[2] >= S.end || args[4] < S.beg || args[5] > S.end || args[5] <= args[4]) { g_err = "segbias hook: positions outside the region"; return UVCGPU_EINVAL; }
+    test_segbias(S, args[0] != 0, args[1], args[2], args[3], args[4], args[5], args[6], args[7], args[8], args[9], args[10], args[11], args[12], args[13], args[14], args[15], args[16], thres, out);
+    return 0;
+}
 int uvc_oracle_accumulate(void *h) { State &S = *(State *)h; return accumulate(S, g_err); }
 
 // transposes the position-major internal storage into the plane layout [field][symbol][pos] of uvcgpu.h
