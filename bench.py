@@ -174,6 +174,105 @@ def spawn_ranks(n, argv):
     return rc
 
 
+class Leg:
+    """One stream of tiles through region handles: reset (side arrays of the tile's own reference) + set_reads + accumulate, then score."""
+    def __init__(self, lib, region, params, tiles, dev, all_out=False, all_records=False):
+        self.lib, self.region, self.tiles, self.all_out, self.all_records = lib, region, tiles, all_out, all_records
+        self.T = len(tiles)
+        self.dreads = [region.device_reads(t, dev) for t in tiles]
+        self.Rs = [region.Region(lib, params, t["tid"], t["beg"], t["end"], t["refseq"]) for t in tiles]
+        for R in self.Rs:
+            lib.dll.uvcgpu_region_set_profiling(R.h, 1)          # HIP events around the kernels of every accumulate / score (the roofline legs read them)
+        self.refs = [t["refseq"].encode() if isinstance(t["refseq"], str) else bytes(t["refseq"]) for t in tiles]
+        rl = tiles[0]["end"] - tiles[0]["beg"]
+        self.cap = 15 * (rl + 2) if all_out else max(65536, rl // 4)
+        self.names_buf = C.create_string_buffer(4096)
+        self.ms_buf = (C.c_float * 64)()
+
+    def prepare(self, k, host=False):
+        R, t = self.Rs[k % self.T], self.tiles[k % self.T]
+        if not os.environ.get("UVC_BENCH_NO_RESET"):
+            # the tile's own reference: CHAR_TO_SYMBOL, refstring2repeatvec and the two BAQ prefix-sum arrays on the device (uvc_rtr.hip, SURVEY row a3)
+            R.reset(t["tid"], t["beg"], t["end"], self.refs[k % self.T])
+        if host:
+            R.set_reads(t)                                     # PCIe-inclusive variant: the columns start in (pinned) host memory
+        else:
+            R.set_reads_device(self.dreads[k % self.T])
+        R.accumulate()
+
+    def finish(self, k):
+        R = self.Rs[k % self.T]
+        rec = R.score(all_out=self.all_out, capacity=self.cap, copy=False, release_state=True, kept_only=not self.all_records)
+        sc = C.c_int64()
+        self.lib.dll.uvcgpu_region_last_score_counts(R.h, C.byref(sc), None)
+        self.scored = sc.value                                 # records scored (the kept-only form returns fewer)
+        return rec
+
+    def kernel_times(self, R, into):
+        n = self.lib.dll.uvcgpu_region_kernel_times(R.h, self.names_buf, 4096, self.ms_buf, 64)   # the handle's stream is idle here: its score() was synchronous
+        for nm, ms in zip(self.names_buf.value.decode().split(";")[:n], list(self.ms_buf)[:n]):
+            into.setdefault(nm, []).append(ms)
+
+    def run_stream(self, k0, n_steps, host=False, ktimes=None, serial=False):
+        """n_steps tiles, software-pipelined: tile k + 1 is prepared and its accumulate enqueued before tile k is scored."""
+        n_rec, T = 0, self.T
+        if serial or T < 2:   # one handle cannot hold the next tile's reads while the current one is still being scored
+            for k in range(k0, k0 + n_steps):
+                self.prepare(k, host); n_rec = len(self.finish(k)["refpos"])
+                if ktimes is not None:
+                    self.kernel_times(self.Rs[k % T], ktimes)
+            return n_rec
+        ahead = max(1, min(int(os.environ.get("UVC_BENCH_AHEAD", "1")), T - 1))   # tiles prepared beyond the one being scored
+        for k in range(k0, min(k0 + ahead, k0 + n_steps)):
+            self.prepare(k, host)
+        for k in range(k0, k0 + n_steps):
+            if k + ahead < k0 + n_steps:
+                self.prepare(k + ahead, host)
+            n_rec = len(self.finish(k)["refpos"])
+            if ktimes is not None:
+                self.kernel_times(self.Rs[k % T], ktimes)
+        return n_rec
+
+    def close(self):
+        for R in self.Rs:
+            R.close()
+        self.Rs, self.dreads = [], []
+
+
+def side_leg(lib, region, params, tiles, dev, torch, steps, all_out, depth, what):
+    """A short timed stream of other tiles behind the main legs (config 4 shape, all-out scoring): ms per tile, per-kernel times, the
+    scoring kernels' own roofline.  Inputs resident in HBM, same step as `value`."""
+    leg = Leg(lib, region, params, tiles, dev, all_out=all_out, all_records=all_out)
+    rl = tiles[0]["end"] - tiles[0]["beg"]
+    leg.run_stream(0, leg.T); leg.run_stream(0, leg.T)                 # priming: every handle twice (buffers sized, records buffer page-locked)
+    kt = {}
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    n_rec = leg.run_stream(0, steps, ktimes=kt)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    avg = {k: sum(v) / len(v) for k, v in kt.items()}
+    out = {"workload": what, "tile_positions": rl, "tiles": leg.T, "steps": steps, "ms_per_step": 1e3 * dt / steps, "value": rl * steps / dt, "unit": "positions/s",
+           "records_last_tile": n_rec, "reads_per_tile": int(tiles[0]["n_reads"]),
+           "kernel_ms": {k: round(v, 4) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])}}
+    if "k_score_all" in avg:
+        out["roofline_score"] = score_roofline(avg["k_score_all"], rl + 1, leg.scored, all_out)
+    b_d = 2.0 * depth + 48.0 * depth / READ_LEN + 48 + 5544                  # SURVEY 8(d): B(D), whole path
+    out["path_roofline_frac"] = b_d * rl / (1e-3 * out["ms_per_step"]) / 1e9 / HBM_PEAK_GBS
+    leg.close()
+    return out
+
+
+def score_roofline(ms, npos, n_records, all_out):
+    """The scoring kernels (candidate gate + scan + k_score + k_call + kept-groups copy; HIP events around uvc_launch_score) against HBM.
+    `nominal`: SURVEY 8(d)'s per-position figure for the scoring kernel (5.6 KB default gate: the whole accumulator record read once;
+    8.3 KB all-out).  `needed`: what the kernels have to move at the default gate -- the gate reads the 2 x 14 fragment-depth cells of every
+    position (112 B), and only a scored record reads its ~5.5 KB of state and writes its fields."""
+    nominal = (8300.0 if all_out else 5600.0) * npos
+    needed = nominal if all_out else 112.0 * npos + n_records * (5544.0 + 4.0 * 160)
+    return {"bound": "hbm", "kernels": "k_score_count + scans + k_score + k_call (+ kept-groups copy)", "kernel_ms": ms, "records": n_records,
+            "algorithmic_bytes_nominal": nominal, "achieved_nominal": nominal / (ms * 1e-3) / 1e9, "frac_nominal": nominal / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes": needed, "achieved": needed / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": needed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,6 +287,7 @@ def main():
     ap.add_argument("--serial", action="store_true", help="no pipelining across tiles: preparation, accumulate and score of a tile strictly one after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the pcie_inclusive and resident measurements behind the timed region (profiler runs)")
+    ap.add_argument("--no-side", action="store_true", help="skip the config-4 and all-out side objects (they need ~1 min of synthetic data generation)")
     ap.add_argument("--dry-run", action="store_true", help="CPU-only rehearsal of the launch protocol (no kernels): ranks, barrier, max-over-ranks clock")
     args = ap.parse_args()
 
@@ -204,18 +304,26 @@ def main():
         clock.barrier(); t0 = time.perf_counter()
         for _ in range(args.steps):
             time.sleep(0.01 * (1 + rank))
-        clock.barrier(); dt = clock.max_over_ranks(time.perf_counter() - t0)
+        clock.barrier(); own = time.perf_counter() - t0; dt = clock.max_over_ranks(own)
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": world * region_len * args.steps / dt, "unit": "positions/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-                              "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic", "config": {"workload": "dry-run"}, "dry_run": True}))
+                              "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic", "config": {"workload": "dry-run"}, "dry_run": True,
+                              "per_rank_ms_per_step": {"min": 1e3 * clock.min_over_ranks(own) / args.steps, "max": 1e3 * dt / args.steps}}))
+        else:
+            clock.min_over_ranks(own)
         clock.close()
         return
 
     # ---- synthetic tiles (host, before any GPU call so that the generator may fork) ----
+    side = (world == 1) and not (args.no_side or args.no_extras or args.umi or args.all_out or args.tile_kb != 1000 or args.depth != 300)
     t_gen = time.perf_counter()
     specs = [(12345 + rank + 1000 * i, region_len, args.depth, 1000000 + i * (region_len + 1000), args.umi) for i in range(args.tiles)]
-    workers = min(len(specs), 4 if world == 1 else 2, max(1, (os.cpu_count() or 2) // max(1, world)))
+    n_main = len(specs)
+    if side:
+        specs += [(4000 + i, 200000, 2000, 1000000 + i * 201000, True) for i in range(2)]      # BASELINE config 4 shape: 200 kb duplex-UMI panel tiles at 2000x
+        specs += [(5000, 200000, args.depth, 1000000, False)]                                   # all-out scoring (-A) tile
+    workers = min(len(specs), 6 if world == 1 else 2, max(1, (os.cpu_count() or 2) // max(1, world)))
     if workers > 1:
         from concurrent.futures import ProcessPoolExecutor
         with ProcessPoolExecutor(max_workers=workers) as ex:
@@ -230,6 +338,8 @@ def main():
     if not os.environ.get("UVC_BENCH_PLAIN"):
         from uvc_amd import region as _region
         tiles = [_region.compact_form(t) for t in tiles]
+    side_tiles = tiles[n_main:]
+    tiles = tiles[:n_main]
     import torch
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -239,66 +349,23 @@ def main():
     rc = lib.dll.uvcgpu_init(local_rank)
     if rc != 0:
         raise RuntimeError(lib.last_error())
+    lib.dll.uvcgpu_region_last_score_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.dll.uvcgpu_region_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.dll.uvcgpu_region_kernel_times.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_float), C.c_int]
     params = region.default_params(lib)
 
-    # inputs resident in HBM: the raw columns of every tile + one handle per tile bound to its region (reference side arrays, planes)
+    # inputs resident in HBM: the columns of every tile + one handle per tile (planes, scratch); the region side arrays are rebuilt from the
+    # tile's own reference inside every step (uvcgpu_region_reset)
     t_h2d = time.perf_counter()
-    dreads = [region.device_reads(t, dev) for t in tiles]
+    leg = Leg(lib, region, params, tiles, dev, all_out=args.all_out, all_records=args.all_records)
     t_h2d = time.perf_counter() - t_h2d
-    Rs = [region.Region(lib, params, t["tid"], t["beg"], t["end"], t["refseq"]) for t in tiles]
-    for R in Rs:
-        lib.dll.uvcgpu_region_set_profiling(R.h, 1)          # HIP events around the kernels of every accumulate (the roofline leg reads them)
-    T = len(tiles)
-    cap = 15 * (region_len + 2) if args.all_out else max(65536, region_len // 4)
+    Rs, T = leg.Rs, leg.T
     n_reads_tile = int(np.mean([int(t["n_reads"]) for t in tiles]))
     input_bytes_tile = int(np.mean([sum(int(np.asarray(t[k]).nbytes) for k in COLS if t.get(k) is not None) for t in tiles]))
-
-    refs = [t["refseq"].encode() if isinstance(t["refseq"], str) else bytes(t["refseq"]) for t in tiles]
-
-    def prepare(k, host=False):
-        R = Rs[k % T]
-        t = tiles[k % T]
-        if not os.environ.get("UVC_BENCH_NO_RESET"):
-            # the tile's own reference: CHAR_TO_SYMBOL, refstring2repeatvec and the two BAQ prefix-sum arrays on the device (uvc_rtr.hip)
-            R.reset(t["tid"], t["beg"], t["end"], refs[k % T])
-        if host:
-            R.set_reads(tiles[k % T])                          # PCIe-inclusive variant: the columns start in (pinned) host memory
-        else:
-            R.set_reads_device(dreads[k % T])
-        R.accumulate()
-
-    def finish(k):
-        return Rs[k % T].score(all_out=args.all_out, capacity=cap, copy=False, release_state=True, kept_only=not args.all_records)
-
-    names_buf = C.create_string_buffer(2048)
-    ms_buf = (C.c_float * 48)()
-
-    def kernel_times(R, into):
-        n = lib.dll.uvcgpu_region_kernel_times(R.h, names_buf, 2048, ms_buf, 48)   # the handle's stream is idle here: its score() was synchronous
-        for nm, ms in zip(names_buf.value.decode().split(";")[:n], list(ms_buf)[:n]):
-            into.setdefault(nm, []).append(ms)
+    prepare, finish, kernel_times = leg.prepare, leg.finish, leg.kernel_times
 
     def run_stream(k0, n_steps, host=False, ktimes=None):
-        """n_steps tiles, software-pipelined: tile k + 1 is prepared and its accumulate enqueued before tile k is scored."""
-        n_rec = 0
-        if args.serial or T < 2:   # one handle cannot hold the next tile's reads while the current one is still being scored
-            for k in range(k0, k0 + n_steps):
-                prepare(k, host); n_rec = len(finish(k)["refpos"])
-                if ktimes is not None:
-                    kernel_times(Rs[k % T], ktimes)
-            return n_rec
-        ahead = max(1, min(int(os.environ.get("UVC_BENCH_AHEAD", "1")), T - 1))   # tiles prepared beyond the one being scored
-        for k in range(k0, min(k0 + ahead, k0 + n_steps)):
-            prepare(k, host)
-        for k in range(k0, k0 + n_steps):
-            if k + ahead < k0 + n_steps:
-                prepare(k + ahead, host)
-            n_rec = len(finish(k)["refpos"])
-            if ktimes is not None:
-                kernel_times(Rs[k % T], ktimes)
-        return n_rec
+        return leg.run_stream(k0, n_steps, host=host, ktimes=ktimes, serial=args.serial)
 
     run_stream(0, T)              # untimed priming: every handle once (its first set_reads sizes the cached device blocks, its first score page-locks its records buffer)
     run_stream(0, args.warmup)    # the W warmup steps of the contract
@@ -307,7 +374,10 @@ def main():
     t0 = time.perf_counter()
     n_rec = run_stream(args.warmup, args.steps, ktimes=ktimes)
     torch.cuda.synchronize(); clock.barrier()
-    dt = clock.max_over_ranks(time.perf_counter() - t0)
+    own_dt = time.perf_counter() - t0
+    scored_main = leg.scored
+    dt = clock.max_over_ranks(own_dt)
+    dt_min = clock.min_over_ranks(own_dt)
     total_positions = clock.sum_over_ranks(float(region_len)) * args.steps
 
     pcie = resident = None
@@ -354,11 +424,12 @@ def main():
         run_threads(0, n_thr)
         torch.cuda.synchronize(); clock.barrier(); ts = time.perf_counter()
         run_threads(n_thr, n_extra)
-        torch.cuda.synchronize(); clock.barrier(); sdt = clock.max_over_ranks(time.perf_counter() - ts)
+        torch.cuda.synchronize(); clock.barrier(); own_sdt = time.perf_counter() - ts; sdt = clock.max_over_ranks(own_sdt); sdt_min = clock.min_over_ranks(own_sdt)
         pcie = {"value": clock.sum_over_ranks(float(region_len)) * n_extra / sdt, "unit": "positions/s", "ms_per_step": 1e3 * sdt / n_extra, "steps": n_extra,
-                "h2d_bytes_per_tile": input_bytes_tile, "tiles_in_flight": n_thr,
-                "note": "as `value`, but every tile's columns start in page-locked host memory (uvcgpu_host_alloc) and uvcgpu_region_set_reads copies them first (H2D + set_reads + kernels + D2H per tile, "
-                        "the unit of SURVEY 8d); %d tiles in flight on host threads so that one tile's copy runs under another's kernels; measured behind the timed region" % n_thr}
+                "h2d_bytes_per_tile": input_bytes_tile, "tiles_in_flight": n_thr, "per_rank_ms_per_step": {"min": 1e3 * sdt_min / n_extra, "max": 1e3 * sdt / n_extra},
+                "note": "THE UNIT OF SURVEY 8(d): every tile's columns start in page-locked host memory (uvcgpu_host_alloc) and the step is region reset (side arrays on the device) + H2D of the "
+                        "columns + set_reads + accumulate + scoring + D2H of the records; %d tiles in flight on host threads so that one tile's copy runs under another's kernels; whole-job aggregate "
+                        "over all ranks, measured behind the timed region.  `value` keeps the harness contract (inputs resident in HBM when the clock starts)" % n_thr}
         for a in pinned:
             lib.dll.uvcgpu_unpin_host_buffer(C.c_void_p(a.ctypes.data))
         torch.cuda.synchronize()
@@ -369,7 +440,7 @@ def main():
             lib.dll.uvcgpu_host_free(hp)
         # (2) one prepared tile, accumulate + score again and again, nothing overlapped
         R = Rs[0]
-        R.set_reads_device(dreads[0])
+        R.set_reads_device(leg.dreads[0])
         sk = {}
         R.accumulate(); finish(0)
         torch.cuda.synchronize(); ts = time.perf_counter()
@@ -382,17 +453,30 @@ def main():
                     "kernel_ms": {k: round(sum(v) / len(v), 4) for k, v in sorted(sk.items(), key=lambda kv: -sum(kv[1]))},
                     "note": "one tile whose reads are already prepared (set_reads done once): accumulate P1..P5b + scoring + D2H per step, one handle, nothing overlapped; measured behind the timed region"}
 
+    # side objects (rank 0 of a one-GPU run): BASELINE config 4 shape and the all-out series of SURVEY 8(d); the main handles give their HBM back first
+    side_out = {}
+    if side and side_tiles:
+        leg.close()
+        side_out["config4"] = side_leg(lib, region, params, side_tiles[:2], dev, torch, 4, False, 2000,
+                                       "BASELINE config 4 shape: 2 distinct 200 kb duplex-UMI panel tiles at 2000x, pipelined over two handles, inputs resident in HBM, same step as `value`")
+        side_out["all_out"] = side_leg(lib, region, params, side_tiles[2:3], dev, torch, 3, True, args.depth,
+                                       "second series of SURVEY 8(d): one 200 kb non-UMI tile at %dx with -A (every symbol of every position scored, 14 records per position, every record returned)" % args.depth)
+
     if rank == 0:
         avg = {k: sum(v) / len(v) for k, v in ktimes.items()}
+        score_ms = avg.pop("k_score_all", None)
         dom = max(avg, key=avg.get)
-        abytes = algorithmic_bytes_per_position(dom, args.depth) * Rs[0].npos   # per launch: one region
+        npos_tile = region_len + 1
+        abytes = algorithmic_bytes_per_position(dom, args.depth) * npos_tile   # per launch: one region
         achieved = abytes / (avg[dom] * 1e-3) / 1e9
         out = {
             "metric": METRIC, "value": total_positions / dt, "unit": "positions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "stream of %d DISTINCT chr20-shaped tumor-only %s tiles per GPU (%d kb at %dx, 150 bp paired-end), raw UvcReadSoA columns + region side arrays resident in HBM; "
-                                   "step = one tile: set_reads(device half: CIGAR facts + family/fragment nesting, radix orders, k_pack_bq, k_aln_prelude, k_build_p2list) + accumulate P1..P5b + "
+            "per_rank_ms_per_step": {"min": 1e3 * dt_min / args.steps, "max": 1e3 * dt / args.steps},
+            "config": {"workload": "stream of %d DISTINCT chr20-shaped tumor-only %s tiles per GPU (%d kb at %dx, 150 bp paired-end), UvcReadSoA columns (BAM 4-bit bases, qualities, per-read fields) resident in HBM; "
+                                   "step = one tile: region reset (CHAR_TO_SYMBOL, refstring2repeatvec, BAQ prefix sums of the tile's own reference on the device) + set_reads(offset scans, base unpack, CIGAR facts + "
+                                   "family/fragment nesting, radix orders, k_aln_prelude, k_build_p2list) + accumulate P1..P5b + "
                                    "default-gate scoring / calling + D2H of %s%s" % (T, "duplex-UMI" if args.umi else "non-UMI", args.tile_kb, args.depth,
                                    "every scored record" if args.all_records else "the record groups the VCF writer reads (kept_only: written records + the REF / genotype records of their positions)",
                                    "; tiles strictly one after the other" if args.serial else "; tiles software-pipelined over their handles (tile k+1 is prepared and accumulating while tile k is scored)"),
@@ -408,6 +492,9 @@ def main():
             "read_bases_per_s": n_reads_tile * READ_LEN * world * args.steps / dt,
             "host_prep_s": {"generate": round(t_gen, 2), "columns_to_hbm": round(t_h2d, 3)},
         }
+        if score_ms:
+            out["roofline_score"] = score_roofline(score_ms, npos_tile, scored_main, args.all_out)
+        out.update(side_out)
         if pcie:
             out["pcie_inclusive"] = pcie
         if resident:
@@ -418,8 +505,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline(args.depth)
         print(json.dumps(out))
-    for R in Rs:
-        R.close()
+    if leg.Rs:
+        leg.close()
     clock.close()
 
 

@@ -433,6 +433,8 @@ int uvcgpu_unpin_host_buffer(void *p);
 int uvcgpu_host_alloc(void **p, int64_t bytes);
 int uvcgpu_host_free(void *p);
 int uvcgpu_region_sync(uvcgpu_region_t *r);
+/* Record counts of the last uvcgpu_region_score on this handle: scored in all, and returned (fewer with UvcScoreRequest::kept_only). */
+int uvcgpu_region_last_score_counts(const uvcgpu_region_t *r, int64_t *scored, int64_t *returned);
 /* Measurement hooks (bench.py): HIP-event timing of every kernel of the LAST accumulate, recorded on the handle's stream.
  * kernel_times returns the number of kernels; `names` receives their names separated by ';'. */
 int uvcgpu_region_set_profiling(uvcgpu_region_t *r, int on);

@@ -29,7 +29,7 @@ extern "C" void uvc_launch_correct_bq(const RegionDev *R, int bq_max, int bq_inc
 extern "C" void uvc_launch_pack_bq(const uint8_t *bases, const uint8_t *quals, uint16_t *bq, int64_t n, hipStream_t s);
 extern "C" void uvc_launch_build_p2list(const RegionDev *R, const int32_t *aln, const int32_t *cbeg, const int32_t *cend, const int32_t *qb, hipStream_t s);
 extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const UvcParams *P, hipStream_t s);
-struct UvcProf { int on; int n; const char *name[24]; hipEvent_t ev[24][2]; };
+struct UvcProf { int on; int n; const char *name[32]; hipEvent_t ev[32][2]; };
 extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, int half_ratio_phred,
                                       const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof,
                                       hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join, hipEvent_t e_fork2, hipStream_t side3, hipEvent_t e_join3, hipEvent_t e_stat, hipEvent_t e_alleles);
@@ -90,6 +90,7 @@ struct uvcgpu_region {
     bool has_reads = false, accumulated = false;
     size_t p5flag_off = 0;
     bool state_released = false, state_zeroed = false;   // UvcScoreRequest::release_state: planes given up / already zeroed on the side stream (e_join marks the end)
+    int64_t last_scored = 0, last_returned = 0;   // record counts of the last score call (uvcgpu_region_last_score_counts)
     size_t zeroed_bytes = 0;     // with state_zeroed: the slab is zero from its start up to here (a rebind to a region that fits keeps the benefit)
     RawReads W;                  // per-read input columns on the device (kept: uvcgpu_region_correct_bq re-derives the per-read records)
     int32_t *d_p2[4] = { nullptr, nullptr, nullptr, nullptr };   // P2 work list: alignment, begin, end, query offset
@@ -556,6 +557,14 @@ int uvcgpu_region_kernel_times(uvcgpu_region_t *r, char *names, int names_bytes,
     return n;
 }
 
+// how many records the last uvcgpu_region_score scored, and how many it returned (fewer with UvcScoreRequest::kept_only)
+int uvcgpu_region_last_score_counts(const uvcgpu_region_t *r, int64_t *scored, int64_t *returned) {
+    if (!r) return fail(UVCGPU_EINVAL, "null region");
+    if (scored) *scored = r->last_scored;
+    if (returned) *returned = r->last_returned;
+    return 0;
+}
+
 int uvcgpu_region_sync(uvcgpu_region_t *r) {
     if (!r) return fail(UVCGPU_EINVAL, "null region");
     HIP_OK(hipStreamSynchronize(r->stream));
@@ -980,8 +989,11 @@ static int uvcgpu_region_score_impl(uvcgpu_region_t *r, const UvcScoreRequest *r
             r->score_kept_capacity = r->score_capacity;
         }
         HIP_OK(hipMemsetAsync(r->d_score_count, 0, 16, r->stream));
+        int pi = -1;   // with profiling on, the scoring kernels (gate + scan + k_score + k_call + the kept-groups copy) as one more entry of uvcgpu_region_kernel_times
+        if (r->prof.on && r->prof.n < 32) { pi = r->prof.n++; r->prof.name[pi] = "k_score_all"; if (!r->prof.ev[pi][0]) { hipEventCreate(&r->prof.ev[pi][0]); hipEventCreate(&r->prof.ev[pi][1]); } hipEventRecord(r->prof.ev[pi][0], r->stream); }
         rc = uvc_launch_score(&r->R, &r->P, &rq, use_al, use_row, n_al, r->d_gap_rows, r->d_gap_seq, d_tk, r->d_score_fields, r->score_capacity, r->d_score_count, r->d_score_scratch,
                               kept_only ? r->d_score_kept : nullptr, r->stream);
+        if (pi >= 0) hipEventRecord(r->prof.ev[pi][1], r->stream);
         if (!rc && hipGetLastError() != hipSuccess) rc = fail(UVCGPU_EDEVICE, "score kernel launch failed");
         if (!rc) rc = uvcgpu_region_sync(r);
         // copies on the handle's own stream: a null-stream hipMemcpy would also wait for every other handle's work
@@ -991,6 +1003,7 @@ static int uvcgpu_region_score_impl(uvcgpu_region_t *r, const UvcScoreRequest *r
     }
     if (!rc) {
         const int64_t n_out = (kept_only ? cnt[1] : cnt[0]);
+        r->last_scored = cnt[0]; r->last_returned = n_out;
         const int32_t *src = (kept_only ? r->d_score_kept : r->d_score_fields);
         out->n_records = n_out;
         if (kept_only && cnt[0] > r->score_capacity) rc = fail(UVCGPU_EDEVICE, "score: the record count changed between two passes");

@@ -3492,10 +3492,10 @@ static inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / 
 static inline int imin_h(int a, int b) { return a < b ? a : b; }
 
 // optional per-kernel HIP-event timing on the handle's own stream (bench.py roofline leg)
-struct UvcProf { int on; int n; const char *name[24]; hipEvent_t ev[24][2]; };
+struct UvcProf { int on; int n; const char *name[32]; hipEvent_t ev[32][2]; };
 #define TIMED(prof, kname, ...) do { \
         UvcProf *p_ = (prof); int i_ = -1; \
-        if (p_ && p_->on && p_->n < 24) { i_ = p_->n++; p_->name[i_] = kname; if (!p_->ev[i_][0]) { hipEventCreate(&p_->ev[i_][0]); hipEventCreate(&p_->ev[i_][1]); } hipEventRecord(p_->ev[i_][0], s); } \
+        if (p_ && p_->on && p_->n < 32) { i_ = p_->n++; p_->name[i_] = kname; if (!p_->ev[i_][0]) { hipEventCreate(&p_->ev[i_][0]); hipEventCreate(&p_->ev[i_][1]); } hipEventRecord(p_->ev[i_][0], s); } \
         __VA_ARGS__; \
         if (i_ >= 0) hipEventRecord(p_->ev[i_][1], s); \
     } while (0)

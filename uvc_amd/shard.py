@@ -69,6 +69,15 @@ class Clock:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def min_over_ranks(self, value):
+        if self.dist is None:
+            return value
+        import torch
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = torch.tensor([value], dtype=torch.float64, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return float(t.item())
+
     def sum_over_ranks(self, value):
         if self.dist is None:
             return value
