@@ -122,9 +122,7 @@ def test_weird_reads(seed, oracle_lib, gpu_lib):
             outcome.append(e.code)
     o, g = outcome
     if isinstance(o, int) or isinstance(g, int):
-        # the HIP path may refuse shapes the reference handles (documented limits: > 3 LINK symbols of one read at one position,
-        # > 16 low-quality InDels in one read) -- with UVCGPU_EUNSUPPORTED, never silently; anything else must be refused by both
-        assert (g == -3 and not isinstance(o, int)) or o == g, (o, g)
+        assert o == g, (o, g)   # refused by both with the same code: since round 3 the HIP path has no read shape of its own to refuse
         return
     bad = diff_groups(o, g)
     assert not bad, "\n".join("%s: %d cells differ, e.g. %s" % (k, v[0], v[1]) for k, v in bad.items())
@@ -157,3 +155,53 @@ def test_fragment_longer_than_the_sweep_window(oracle_lib, gpu_lib):
     o, g = run(oracle_lib, reads), run(gpu_lib, reads)
     bad = diff_groups(o, g)
     assert not bad, "\n".join("%s: %d cells differ, e.g. %s" % (k, v[0], v[1]) for k, v in bad.items())
+
+
+def add_read(reads, pos, ops, quals_value, nm, rng, frag, fam, strand=0, flag=0x0):
+    """Appends one alignment (ops = [(op, len)], bases drawn from the reference with a few mismatches) to a weird_region dict, as a fragment
+    and family of its own."""
+    ref = np.frombuffer(reads["refseq"].encode(), dtype=np.uint8)
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+    q = []; rp = pos - reads["beg"]
+    for o, l in ops:
+        if o == M: q += [code[int(c)] for c in ref[rp:rp + l]]; rp += l
+        elif o in (I, S): q += list(rng.integers(0, 4, l))
+        elif o in (D, N): rp += l
+    qlen = len(q)
+    app = dict(pos=pos, mpos=-1, isize=0, flag=flag, mapq=60, nm=nm, l_qseq=qlen, seq_off=len(reads["bases"]), cigar_off=len(reads["cigars"]), n_cigar=len(ops), frag_id=frag, fam_id=fam, fam_strand=strand)
+    for k, v in app.items():
+        reads[k] = np.append(reads[k], np.array([v], reads[k].dtype))
+    reads["bases"] = np.append(reads["bases"], np.array(q, np.uint8)); reads["quals"] = np.append(reads["quals"], np.full(qlen, quals_value, np.uint8))
+    reads["cigars"] = np.append(reads["cigars"], np.array([(l << 4) | o for o, l in ops], np.uint32))
+    reads["fam_dflag"] = np.append(reads["fam_dflag"], np.array([0], np.uint8))
+    reads["n_reads"] += 1; reads["n_fams"] += 1
+
+
+@pytest.mark.parametrize("platform", [1, 2])
+def test_reads_beyond_the_former_capacity_limits(platform, oracle_lib, gpu_lib):
+    """shapes the library used to refuse (UVCGPU_EUNSUPPORTED) and the reference processes -- a read with 25 and one with
+    60 low-quality InDels (the list of k_p2_slow held 16), piles of insertion + deletion + padded-deletion symbols at one position over and
+    over (three LINK slots per table row), NM tags hundreds below the InDel lengths (penalties below -150: values beyond 8 bits), and a
+    fragment span beyond the LDS window of k_fragstat_sweep with InDel reads at both ends.  Planes, allele rows and records as the oracle's."""
+    rng = np.random.default_rng(77)
+    ref_len, beg = 9000, 3_000_000
+    reads = weird_region(11, n_frag=120, ref_len=ref_len, beg=beg)
+    frag, fam = int(reads["frag_id"].max()) + 1, int(reads["n_fams"])
+    many = lambda k, m: [(M, 4)] + [x for _ in range(k) for x in ((I, 1), (M, m), (D, 1), (M, m))] + [(M, 3)]
+    add_read(reads, beg + 300, many(13, 2), 2, 30, rng, frag, fam); frag += 1; fam += 1                  # 26 low-quality InDels
+    add_read(reads, beg + 320, many(30, 1), 8, 0, rng, frag, fam, strand=1, flag=0x10); frag += 1; fam += 1   # 60 of them, reverse strand, NM = 0
+    pile = [(M, 5)] + [x for k in range(8) for x in ((I, 1 + k % 3), (D, 1 + (k + 1) % 3))] + [(M, 5)]   # I then D at every position: I*, D*, LINK_NN / BASE_NN together
+    add_read(reads, beg + 700, pile, 30, 3, rng, frag, fam); frag += 1; fam += 1
+    add_read(reads, beg + 702, pile[:-1] + [(I, 2), (M, 4)], 12, -1, rng, frag, fam, strand=1, flag=0x10); frag += 1; fam += 1
+    add_read(reads, beg + 1000, [(M, 12), (D, 400), (M, 12)], 35, 0, rng, frag, fam); frag += 1; fam += 1       # NM 0 against a 400-base deletion: penalty -(400 * 1500 / 24) / 30
+    add_read(reads, beg + 1010, [(M, 6), (D, 900), (M, 6), (I, 2), (M, 6)], 20, 1, rng, frag, fam); frag += 1; fam += 1
+    # one read name with InDel reads 6.5 kb apart: the fragment sweep runs in chunks
+    add_read(reads, beg + 1500, [(M, 30), (I, 2), (M, 30)], 30, 2, rng, frag, fam, flag=0x1 | 0x40)
+    add_read(reads, beg + 8000, [(M, 20), (D, 3), (M, 40)], 30, 3, rng, frag, fam, flag=0x1 | 0x80 | 0x10); frag += 1; fam += 1
+    reads["n_fams"] -= 1; reads["fam_dflag"] = reads["fam_dflag"][:-1]     # the two mates share one family
+    o, g = run(oracle_lib, reads, platform=platform), run(gpu_lib, reads, platform=platform)
+    bad = diff_groups(o, g)
+    assert not bad, "\n".join("%s: %d cells differ, e.g. %s" % (k, v[0], v[1]) for k, v in bad.items())
+    assert o.indel_alleles() == g.indel_alleles()
+    from test_gpu_parity import compare_records
+    compare_records(o.score(all_out=True), g.score(all_out=True))

@@ -39,14 +39,15 @@ struct Opts {
     std::string bam, fasta, out, sample = "-", targets, bed, tumor_vcf, bed_out, bed_in, umi_struct;
     std::vector<int> devices;
     int threads = 0, outvar_flag = -1, repeat = 1, shard = 0, n_shards = 1, tn_is_paired = 0, tumor_format = 1;
-    int64_t tile = 1000000;
+    int64_t tile = 0;            // 0 = no fixed tiles: the regions are the reference's own cuts (uvcio_plan_regions = SamIter::iternext); --tile N overrides
+    int64_t mem_per_thread = 1536;   // --mem-per-thread (MB), CmdLineArgs.hpp:33: enters the reference's region cuts
     bool all_out = false, timing = false, no_header = false, device_inflate = false;
     double vqual = -1e9;
 };
 [[noreturn]] void die(const std::string &m) { fprintf(stderr, "uvc1-mi355x: %s\n", m.c_str()); exit(2); }
 void usage() {
     fprintf(stderr, "usage: uvc1-mi355x inputBAM -f ref.fa -o out.vcf.gz [-s sample] [--targets chr[:beg-end] | -R regions.bed] [-t threads] [-A] [-q vqual]\n"
-                    "                   [--outvar-flag bits] [--tile bp] [--devices 0,1,..] [--shard i/n] [--no-header] [--timing] [--device-inflate]\n"
+                    "                   [--outvar-flag bits] [--tile bp (default: the reference's region cuts)] [--mem-per-thread MB] [--devices 0,1,..] [--shard i/n] [--no-header] [--timing] [--device-inflate]\n"
                     "                   [--tn-is-paired 0|1] [--tumor-vcf tumor.vcf.gz] [--is-tumor-format-retrieved 0|1] [--bed-out-fname f] [--bed-in-fname f]\n"
                     "       uvc1-mi355x --concat out.vcf.gz shard0.vcf.gz shard1.vcf.gz ...\n");
 }
@@ -65,6 +66,7 @@ Opts parse(int argc, char **argv) {
         else if (a == "-q" || a == "--vqual") o.vqual = atof(val().c_str());
         else if (a == "--outvar-flag") o.outvar_flag = atoi(val().c_str());
         else if (a == "--tile") o.tile = std::max<int64_t>(100, atoll(val().c_str()));
+        else if (a == "--mem-per-thread") o.mem_per_thread = std::max<int64_t>(1, atoll(val().c_str()));
         else if (a == "--device" || a == "--devices") {   // comma-separated HIP device ids; an id may repeat (two workers sets on one GPU)
             o.devices.clear();
             const std::string v = val(); size_t at = 0;
@@ -227,8 +229,25 @@ int main(int argc, char **argv) {
     for (auto &s : names) cnames.push_back(s.c_str());
     // the tiles: --bed-in-fname / -R regions, --targets "chr" or "chr:beg-end" (1-based inclusive as in samtools), else every contig
     std::vector<Tile> tiles;
-    auto add = [&](int32_t tid, int64_t beg, int64_t end) { for (int64_t b = beg; b < end; b += o.tile) tiles.push_back(Tile{ tid, names[(size_t)tid], b, std::min(b + o.tile, end), false, false, b }); };
     const std::string bed_path = (!o.bed_in.empty() ? o.bed_in : o.bed);
+    // Without --tile and without a BED file the regions are the ones the reference itself would hand to process_batch: one pass over the
+    // alignments of the targets (as SamIter::iternext makes it, grouping.cpp:225-312) through uvcio_plan_regions -- cuts at contig changes, at
+    // gaps of more than 200 bp and where the per-thread memory model says so (grouping.cpp:28-67: ~20-40 kb at 300x).  Every such region is
+    // then processed exactly like a process_batch call (its own reference window, repeat tracks and BAQ sums from its own start, zerobased_pos
+    // beg .. end inclusive), so the records equal the reference's also next to a cut.  --tile N trades that for long regions (faster on the
+    // device; qualities within one unit next to a cut).
+    const bool ref_cuts = (o.tile <= 0 && bed_path.empty());
+    if (o.tile <= 0) o.tile = 1000000;
+    std::vector<int32_t> pl_tid, pl_pos, pl_end; std::vector<uint16_t> pl_flag;
+    auto add = [&](int32_t tid, int64_t beg, int64_t end) {
+        if (!ref_cuts) { for (int64_t b = beg; b < end; b += o.tile) tiles.push_back(Tile{ tid, names[(size_t)tid], b, std::min(b + o.tile, end), false, false, b }); return; }
+        const int64_t W = 4000000;   // the planning pass reads the span window by window; an alignment is taken by the window it starts in (the first window also takes those that reach into it)
+        for (int64_t wb = beg; wb < end; wb += W) {
+            UvcBamBatch b;
+            if (uvcio_bam_fetch(bam0, tid, wb, std::min(wb + W, end), &b)) die(uvcio_last_error());
+            for (int64_t i = 0; i < b.n_alns; i++) if (b.pos[i] >= wb || wb == beg) { pl_tid.push_back(b.tid[i]); pl_pos.push_back(b.pos[i]); pl_end.push_back(b.endpos[i]); pl_flag.push_back(b.flag[i]); }
+        }
+    };
     if (!bed_path.empty()) {   // one region per BED line (0-based, half-open), cut into tiles; overrides --targets as in the reference
         FILE *fb = fopen(bed_path.c_str(), "r");
         if (!fb) die("cannot open " + bed_path);
@@ -255,7 +274,20 @@ int main(int argc, char **argv) {
         if (tid < 0) die("--targets names a contig that is not in the BAM header: " + chrom);
         add(tid, beg, end < 0 ? lens[(size_t)tid] : std::min(end, lens[(size_t)tid]));
     } else for (int32_t i = 0; i < nref; i++) add(i, 0, lens[(size_t)i]);
-    // ownership of the shared end points: a tile whose predecessor ends where it begins continues that one's run
+    if (ref_cuts) {
+        const double tp = now();
+        const int plan_threads = (o.threads > 0 ? o.threads : 8);   // the reference's -t default (CmdLineArgs.hpp:34): enters only where a batch of regions ends
+        int64_t n_cuts = 0;
+        if (uvcio_plan_regions(pl_tid.data(), pl_pos.data(), pl_end.data(), pl_flag.data(), (int64_t)pl_tid.size(), lens.data(), nref, plan_threads, o.mem_per_thread, nullptr, 0, &n_cuts) && n_cuts == 0 && !pl_tid.empty()) die(uvcio_last_error());
+        std::vector<UvcRegionCut> cuts((size_t)std::max<int64_t>(n_cuts, 1));
+        if (n_cuts > 0 && uvcio_plan_regions(pl_tid.data(), pl_pos.data(), pl_end.data(), pl_flag.data(), (int64_t)pl_tid.size(), lens.data(), nref, plan_threads, o.mem_per_thread, cuts.data(), n_cuts, &n_cuts)) die(uvcio_last_error());
+        for (int64_t q = 0; q < n_cuts; q++) tiles.push_back(Tile{ cuts[(size_t)q].tid, names[(size_t)cuts[(size_t)q].tid], cuts[(size_t)q].beg, cuts[(size_t)q].end, false, false, cuts[(size_t)q].beg });
+        fprintf(stderr, "uvc1-mi355x: %lld regions from the reference's cuts over %zu alignments (planning pass %.2f s)\n", (long long)n_cuts, pl_tid.size(), now() - tp);
+        std::vector<int32_t>().swap(pl_tid); std::vector<int32_t>().swap(pl_pos); std::vector<int32_t>().swap(pl_end); std::vector<uint16_t>().swap(pl_flag);
+    }
+    // ownership of the shared end points: a tile whose predecessor ends where it begins continues that one's run (fixed tiles only: the
+    // reference's own regions each write both end points, main.cpp:608, 643)
+    if (!ref_cuts)
     for (size_t q = 1; q < tiles.size(); q++) if (tiles[q].tid == tiles[q - 1].tid && tiles[q].beg == tiles[q - 1].end) { tiles[q].continues = true; tiles[q - 1].has_next = true; tiles[q].run_beg = tiles[q - 1].run_beg; }
     // --shard i/n: the i-th of n contiguous runs of the list, balanced by index bytes + positions
     if (o.n_shards > 1) {

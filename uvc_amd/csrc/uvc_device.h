@@ -83,7 +83,8 @@ static_assert(sizeof(FsRec) == 64, "k_fam_p4d fetches a unit record as four 16-b
 
 // One P2 update of an InDel read: "add value `val` of symbol `sym` at position `epos` and run dealwith_segbias with these
 // arguments".  The sequential CIGAR walk (k_p2_slow<true>) only produces items; k_p2_items applies them in parallel.
-struct Item { int32_t epos; uint8_t sym, flags /* bit0 isGap, bits 1..4 cigar op */, val, pad; uint16_t dist, indel_len; int32_t pad2; };
+struct Item { int32_t epos; uint8_t sym, flags /* bit0 isGap, bits 1..4 cigar op */; uint16_t val; uint16_t dist, indel_len; int32_t pad2; };
+static_assert(sizeof(Item) == 16, "Item");
 
 // A base of a simple alignment that differs from the reference: its P2 update goes to a non-dense symbol, so k_p2_fast
 // queues it here and k_p2_mism applies it (one lane per item).  symval = sym | value << 8.
@@ -130,7 +131,11 @@ struct GapWork {
 };
 
 // contribution of one alignment at one reference position under BASE_QUALITY_MAX (main.hpp:1980, 1924, 2077, 2192, 2223)
-struct Contrib { uint8_t bsym, bval, l1sym, l1val, l2sym, l2val, l3sym, l3val; };   // sym == 0xFF: empty slot
+// BASE_QUALITY_MAX contributions of an InDel read at one reference position: its base symbol (if any) and one slot per LINK symbol, so that
+// any pile of LINK symbols at one position of one read fits (an insertion in front of a deletion behind a padded deletion ...); 16-bit
+// values: reads whose NM tag is far below their InDel lengths get negative penalties, i.e. values beyond 255 (main.hpp:1882-1885)
+struct Contrib { uint8_t bsym_p1 /* base symbol + 1, 0 = none */, lmask /* bit s - LINK_M: LINK symbol s present */; uint16_t bval; uint16_t lval[8]; uint16_t pad_[2]; };
+static_assert(sizeof(Contrib) == 24, "Contrib rows are zero-filled as bytes and indexed as 24-byte records");
 
 // haplotype links: the candidates (fragments / family-strand units with at least two possible mutations), where each one's
 // events go in the event buffer, and the buffer.  An event list: [strand | kind << 1, count, (x << 4 | symbol) ...], kind 0 bq, 1 fq, 2 f2q.
@@ -173,6 +178,7 @@ struct RegionDev {
     uint8_t *p5flag;                // [2][npos]: a P5 bucket of this (strand, position) was filled
     uint32_t *fam_digest;           // [n_generic_work][8] or NULL: what P4 leaves per (unit, position) for P5 and the duplex pass (k_fam_win<4> / k_fam_win5d / k_duplex_d)
     Contrib *table;
+    int32_t *ir_list;               // per InDel read: the positions of its low-quality InDels (k_p2_slow's cursor, main.hpp:1817-1859), [gap_off + 2 * rank .. ) with sentinels
     Item *items; int32_t *item_cnt;     // per complex alignment (indexed like complex_ids)
     MisItem *mis; int32_t *mis_cnt; int32_t mis_cap;   // mismatch queue of k_p2_fast, sized from the exact count below
     unsigned long long *mis_total;  // number of read bases of simple alignments that differ from the reference (k_aln_prelude)

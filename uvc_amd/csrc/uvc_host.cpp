@@ -396,6 +396,7 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
     }
     if (timing) fprintf(stderr, "[uvcgpu set_reads] %d fragments, %d units, %d generic units, %lld (unit, position) cells, longest unit %d, %lld positions\n", o.n_frags, o.n_fs, o.n_generic, (long long)o.work, o.max_unit_span, (long long)r->npos);
     { Contrib *t; if ((rc = dev_alloc(r, (size_t)std::max<int64_t>(o.table_rows, 1), &t))) return rc; R.table = t; }
+    { int32_t *t; if ((rc = dev_alloc(r, (size_t)(o.gap_slots + 2 * (int64_t)o.n_complex + 4), &t))) return rc; R.ir_list = t; }
     { Item *t; if ((rc = dev_alloc(r, (size_t)std::max<int64_t>(o.item_slots, 1), &t))) return rc; R.items = t;
       int32_t *c; if ((rc = dev_alloc(r, (size_t)o.n_complex + 1, &c, true))) return rc; R.item_cnt = c; }
     {   // InDel allele pipeline (k_gap_*): events, two sort stages, rows
@@ -419,7 +420,7 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
     R.any_amplicon = o.any_amplicon;
     R.max_frag_depth = o.max_frag_depth;   // k_frag packs two 16-bit bucket counters per LDS word when it is below 65 536
     // table rows are written by k_p2_slow<false>; mark all slots empty (0xFF)
-    HIP_OK(hipMemsetAsync(R.table, 0xFF, (size_t)std::max<int64_t>(o.table_rows, 1) * sizeof(Contrib), r->stream));
+    HIP_OK(hipMemsetAsync(R.table, 0, (size_t)std::max<int64_t>(o.table_rows, 1) * sizeof(Contrib), r->stream));   // no base, no LINK symbol
     lap("allocations + orders");
     uvc_launch_prelude(&R, &W, &r->P, r->stream);
     lap("prelude kernel");
@@ -570,7 +571,7 @@ int uvcgpu_region_sync(uvcgpu_region_t *r) {
     HIP_OK(hipStreamSynchronize(r->stream));
     int32_t e = 0;
     HIP_OK(hipMemcpy(&e, r->R.err, 4, hipMemcpyDeviceToHost));
-    if (e) return fail(e, "a kernel flagged an unsupported read shape (CIGAR with >3 LINK symbols at one position, >16 low-quality InDels, or an op the reference throws on)");
+    if (e) return fail(e, "a kernel flagged an unsupported read shape (a CIGAR op the reference itself throws on, process_cigar main_conversion.hpp:902-916)");
     return 0;
 }
 

@@ -332,7 +332,7 @@ DEV void segbias_simple(SegAcc &AL, SegAcc &AB, const UvcParams &P, const SegRea
     }
     if (hasL) {
         common(AL, bqL);
-        AL.s[UVC_S_aPF1] += imin(100, amp1[bqL]); AL.s[UVC_S_aPF2] += imin(100, amp2[bqL]);
+        AL.s[UVC_S_aPF1] += imin(100, amp1[imin(bqL, 255)]); AL.s[UVC_S_aPF2] += imin(100, amp2[imin(bqL, 255)]);
         // the gap side enters when dist_to_interfering_indel (10000) >= bias_thres_interfering_indel
         if (10000 >= P.bias_thres_interfering_indel) bias(AL, true, 0, m_farL, m_unaffL, BAL(r_baqL >= P.bias_thres_BAQ1), BAL(r_baqL >= P.bias_thres_BAQ2), r_baqL);
         else addm(AL.s[UVC_S_aP1], m_farL & m_unaffL & m_iend);
@@ -493,9 +493,9 @@ DEV int aln_prelude_one(const RegionDev &R, const RawReads &W, const UvcParams &
     const int by_nm = (a.xm1500 + a.go1500) / 30;
     a.indel_penal = imin(1, by_nm + by_clip);
     a.nogap_penal = imin(4, by_nm + by_clip) + 1;
-    // NM below the InDel lengths (malformed, but the reference computes with it) makes the penalties negative; the 8-bit value
-    // fields of Item / Contrib hold the results only down to here
-    if (by_nm + by_clip < -150) atomicExch(R.err, UVCGPU_EUNSUPPORTED);
+    // NM below the InDel lengths (malformed, but the reference computes with it) makes the penalties negative; the 16-bit value
+    // fields of Item / Contrib hold the results down to here
+    if (by_nm + by_clip < -30000) atomicExch(R.err, UVCGPU_EUNSUPPORTED);   // (an NM tag tens of thousands below the InDel lengths of the read)
     a.lclip_q = lclip_q; a.m_index = m_index;
     a.lclip_oplen = 0; a.rclip_oplen = 0;
     if (a.kind == 0) {
@@ -1223,19 +1223,15 @@ DEV int ref_to_phredvalue_dev(int &n_units, int &max_rn, int &rs_at_max, const R
 DEV int proton_cigarlen2phred(int cigarlen) { const int t[13] = { 0, 0, 9, 14, 18, 21, 23, 25, 27, 29, 30, 31, 32 }; return t[imin(cigarlen, 12)]; }
 
 DEV void table_put(const RegionDev &R, Contrib *row, int sym, int v) {
-    const uint8_t vv = (uint8_t)imin(v, 255);
+    const uint16_t vv = (uint16_t)imin(imax(v, 0), 65535);
     if (sym <= UVC_BASE_NN) {
-        if (row->bsym == 0xFF || row->bsym == sym) { row->bval = (row->bsym == sym) ? (uint8_t)imax(row->bval, vv) : vv; row->bsym = (uint8_t)sym; }
-        else atomicExch(R.err, UVCGPU_EUNSUPPORTED);
+        if (row->bsym_p1 == 0 || row->bsym_p1 == sym + 1) { row->bval = (row->bsym_p1 == sym + 1) ? (uint16_t)imax((int)row->bval, (int)vv) : vv; row->bsym_p1 = (uint8_t)(sym + 1); }
+        else atomicExch(R.err, UVCGPU_EDEVICE);   // two different bases of one read at one reference position: no CIGAR does that
         return;
     }
-    uint8_t *s[3] = { &row->l1sym, &row->l2sym, &row->l3sym };
-    uint8_t *q[3] = { &row->l1val, &row->l2val, &row->l3val };
-    for (int k = 0; k < 3; k++) {
-        if (*s[k] == sym) { *q[k] = (uint8_t)imax(*q[k], vv); return; }
-        if (*s[k] == 0xFF) { *s[k] = (uint8_t)sym; *q[k] = vv; return; }
-    }
-    atomicExch(R.err, UVCGPU_EUNSUPPORTED);   // more than three LINK symbols at one position of one read
+    const int k = sym - UVC_LINK_M;   // one slot per LINK symbol: any pile fits
+    if (row->lmask & (1 << k)) row->lval[k] = (uint16_t)imax((int)row->lval[k], (int)vv);
+    else { row->lmask = (uint8_t)(row->lmask | (1 << k)); row->lval[k] = vv; }
 }
 
 template <bool BIAS>
@@ -1256,14 +1252,16 @@ __global__ void __launch_bounds__(64) k_p2_slow(RegionDev R, UvcParams P) {
     int n_items = 0;
     auto emit = [&](bool gap, int epos, int sym, int v, int bm, int op, int indel_len, int dist) {
         if (BIAS) {   // the bias update itself is applied by k_p2_items, in parallel over the items
-            Item it; it.epos = epos; it.sym = (uint8_t)sym; it.flags = (uint8_t)((gap ? 1 : 0) | (op << 1)); it.val = (uint8_t)imin(v, 255); it.pad = 0;
+            Item it; it.epos = epos; it.sym = (uint8_t)sym; it.flags = (uint8_t)((gap ? 1 : 0) | (op << 1)); it.val = (uint16_t)imin(imax(v, 0), 65535);
             it.dist = (uint16_t)imin(imax(dist, 0), 65535); it.indel_len = (uint16_t)imin(indel_len, 65535); it.pad2 = 0;
             items[n_items++] = it;
         } else if (epos >= a.pos && epos <= a.rend) table_put(R, table + (epos - a.pos), sym, v);
         else atomicExch(R.err, UVCGPU_EDEVICE);   // would leave the read's rows
     };
-    // low-BQ InDel positions (main.hpp:1817-1859); at most 16 tracked, more => unsupported
-    int indel_rposs[18]; int n_ir = 0; indel_rposs[n_ir++] = 0;
+    // low-BQ InDel positions (main.hpp:1817-1859): a list of the read's own in global memory (one slot per I / D op + two sentinels), so
+    // that a read with any number of them is walked like every other read
+    int32_t *indel_rposs = R.ir_list + a.gap_off + 2 * (int64_t)t; int n_ir = 0;
+    if (BIAS) indel_rposs[n_ir++] = 0;
     int nge = 0;
     {
         int qpos = 0, rpos = a.pos;
@@ -1274,17 +1272,17 @@ __global__ void __launch_bounds__(64) k_p2_slow(RegionDev R, UvcParams P) {
                 nge += len;
                 bool low = false;
                 for (int q2 = qpos - imin(qpos, 1); q2 < imin(qpos + len + 1, rend); q2++) if (Q(q2) < P.bias_thres_interfering_indel_BQ) low = true;
-                if (low) { if (n_ir < 17) indel_rposs[n_ir++] = rpos; else atomicExch(R.err, UVCGPU_EUNSUPPORTED); }
+                if (low && BIAS) indel_rposs[n_ir++] = rpos;
                 qpos += len;
             } else if (op == C_DEL) {
                 nge += len;
                 const bool low = (imin(Q(imax(1, qpos) - 1), Q(qpos)) <= P.bias_thres_interfering_indel_BQ);
-                if (low) { if (n_ir < 17) indel_rposs[n_ir++] = rpos; else atomicExch(R.err, UVCGPU_EUNSUPPORTED); }
+                if (low && BIAS) indel_rposs[n_ir++] = rpos;
                 rpos += len;
             } else if (op == C_REF_SKIP) rpos += len;
             else if (op == C_SOFT_CLIP) qpos += len;
         }
-        indel_rposs[n_ir++] = INT32_MAX;
+        if (BIAS) indel_rposs[n_ir++] = INT32_MAX;
     }
     int ir_idx = 0;
     int ibeg, iend;
@@ -1497,10 +1495,11 @@ DEV void aln_contrib_max(const RegionDev &R, const UvcParams &P, const AlnRec &a
         cnt[sym] = imax(cnt[sym], v);
     } else {
         const Contrib c = R.table[a.table_off + (p - a.pos)];
-        if (c.bsym != 0xFF) cnt[c.bsym] = imax(cnt[c.bsym], (int)c.bval);
-        if (c.l1sym != 0xFF) cnt[c.l1sym] = imax(cnt[c.l1sym], (int)c.l1val);
-        if (c.l2sym != 0xFF) cnt[c.l2sym] = imax(cnt[c.l2sym], (int)c.l2val);
-        if (c.l3sym != 0xFF) cnt[c.l3sym] = imax(cnt[c.l3sym], (int)c.l3val);
+        if (c.bsym_p1) cnt[c.bsym_p1 - 1] = imax(cnt[c.bsym_p1 - 1], (int)c.bval);
+        if (c.lmask) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (c.lmask & (1 << k)) cnt[UVC_LINK_M + k] = imax(cnt[UVC_LINK_M + k], (int)c.lval[k]);
+        }
     }
 }
 
@@ -1560,35 +1559,41 @@ __global__ void __launch_bounds__(64) k_fragstat_sweep(RegionDev R, UvcParams P,
     const int fi = list[t];
     const FragRec &f = R.frags[fi];
     const int span = f.end - f.beg, nb = P.syserr_mut_region_n_bases;
-    if (span > SWEEP_MAXSPAN) { if (lane == 0) { if (nb > 31) atomicExch(R.err, UVCGPU_EUNSUPPORTED); else fragstat_sweep(R, P, fi); } return; }
+    // spans beyond the LDS window are taken in chunks with a halo of nb positions either side (a mutation reaches nb positions far)
+    const int step = SWEEP_MAXSPAN - 2 * nb;
+    if (step < 64) { if (lane == 0) atomicExch(R.err, UVCGPU_EUNSUPPORTED); return; }   // syserr_mut_region_n_bases beyond 2 000
     const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
     if (lane < 2) tot[lane] = 0;
     int cnt[NSYM];
-    for (int i = lane; i < span; i += 64) {
-        const int p = f.beg + i;
-        frag_counts(R, P, f, p, proton, cnt);
-        int fl = 0;
-        const int refsymbol = R.refsym[p - R.beg];
-        for (int vi = 0; vi < 2; vi++) {
-            const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
-            int cs, cc, ct;
-            fill_consensus(cnt, cs, cc, ct, st, st == UVC_LINK_SYMBOL, false);
-            if (0 == ct) continue;
-            fl |= 1;
-            const int con_qual = cc * 2 - ct;
-            const bool highBQ = (proton ? (UVC_BASE_SYMBOL == st || con_qual + 3 >= P.bias_thres_highBQ) : (UVC_LINK_SYMBOL == st || con_qual >= P.bias_thres_highBQ));
-            if (symbols_mutated(refsymbol, cs) && highBQ) fl |= 2;
-        }
-        flag[i] = (uint8_t)fl;
-    }
-    __syncthreads();
     int n_cov = 0, n_near = 0;
-    for (int i = lane; i < span; i += 64) {
-        if (!(flag[i] & 1)) continue;
-        n_cov++;
-        bool near = false;
-        for (int j = imax(0, i - nb); j <= imin(span - 1, i + nb) && !near; j++) near = (flag[j] & 2) != 0;
-        if (near) n_near++;
+    for (int c0 = 0; c0 < span; c0 += step) {
+        const int w0 = imax(0, c0 - nb), w1 = imin(span, c0 + step + nb);
+        __syncthreads();   // the previous chunk's flags have been read
+        for (int i = w0 + lane; i < w1; i += 64) {
+            const int p = f.beg + i;
+            frag_counts(R, P, f, p, proton, cnt);
+            int fl = 0;
+            const int refsymbol = R.refsym[p - R.beg];
+            for (int vi = 0; vi < 2; vi++) {
+                const int st = (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL);
+                int cs, cc, ct;
+                fill_consensus(cnt, cs, cc, ct, st, st == UVC_LINK_SYMBOL, false);
+                if (0 == ct) continue;
+                fl |= 1;
+                const int con_qual = cc * 2 - ct;
+                const bool highBQ = (proton ? (UVC_BASE_SYMBOL == st || con_qual + 3 >= P.bias_thres_highBQ) : (UVC_LINK_SYMBOL == st || con_qual >= P.bias_thres_highBQ));
+                if (symbols_mutated(refsymbol, cs) && highBQ) fl |= 2;
+            }
+            flag[i - w0] = (uint8_t)fl;
+        }
+        __syncthreads();
+        for (int i = c0 + lane; i < imin(span, c0 + step); i += 64) {
+            if (!(flag[i - w0] & 1)) continue;
+            n_cov++;
+            bool near = false;
+            for (int j = imax(0, i - nb); j <= imin(span - 1, i + nb) && !near; j++) near = (flag[j - w0] & 2) != 0;
+            if (near) n_near++;
+        }
     }
     atomicAdd(&tot[0], n_cov); atomicAdd(&tot[1], n_near);
     __syncthreads();
