@@ -317,3 +317,43 @@ def test_default_regions_are_the_references_cuts(tmp_path, gpu_lib):
         assert r1.returncode == 0, r1.stderr
         want += [l for l in gzip.open(o1, "rt").read().splitlines() if not l.startswith("#")]
     assert body == want
+
+
+@pytest.mark.gpu
+def test_sharded_normal_pass_of_a_tn_pair(tmp_path, gpu_lib):
+    """BASELINE config 5 sharded (bin/uvcTN.sh:92-127 per chromosome; here per shard of the region table): the normal pass with --bed-in-fname
+    + --tumor-vcf run as two --shard i/2 processes and joined by --concat writes the lines of the one-process normal pass; the tumor pass
+    sharded the same way writes the one-process tumor VCF and region table."""
+    import gzip
+    rd = make_tn_files(tmp_path)
+    tb, nb, fa = str(tmp_path / "tumor.bam"), str(tmp_path / "normal.bam"), str(tmp_path / "tn.fa")
+    b0 = rd["tumor"]["beg"]
+    target = "chrT:%d-%d" % (b0 + 1, b0 + 5000)
+
+    def text(path):
+        return [l for l in gzip.open(path, "rt").read().splitlines() if not l.startswith(("##fileDate=", "##variantCallerCommand="))]
+    tv, bed = str(tmp_path / "T.vcf.gz"), str(tmp_path / "T.bed")
+    t_args = [tb, "-f", fa, "-s", "TUM", "--targets", target, "--tile", "1000", "--tn-is-paired", "1", "-t", "2"]
+    _run_cli(t_args + ["-o", tv, "--bed-out-fname", bed])
+    parts = []
+    for i in range(2):
+        part = str(tmp_path / ("T%d.vcf.gz" % i))
+        _run_cli(t_args + ["-o", part, "--shard", "%d/2" % i])
+        parts.append(part)
+    tj = str(tmp_path / "Tj.vcf.gz")
+    _run_cli(["--concat", tj] + parts)
+    assert text(tj) == text(tv)
+    n_args = [nb, "-f", fa, "-s", "NOR", "--tn-is-paired", "1", "--bed-in-fname", bed, "--tumor-vcf", tv, "--tile", "1000", "-t", "2"]
+    nv = str(tmp_path / "N.vcf.gz")
+    _run_cli(n_args + ["-o", nv])
+    parts = []
+    for i in range(2):
+        part = str(tmp_path / ("N%d.vcf.gz" % i))
+        err = _run_cli(n_args + ["-o", part, "--shard", "%d/2" % i])
+        assert "shard %d of 2 takes" % i in err and "tumor records from" in err
+        parts.append(part)
+        assert len([l for l in gzip.open(part, "rt").read().splitlines() if not l.startswith("#")]) >= 1
+    nj = str(tmp_path / "Nj.vcf.gz")
+    _run_cli(["--concat", nj] + parts)
+    assert text(nj) == text(nv)
+    assert sum(1 for l in text(nv) if "\tSOMATIC" in l) >= 3
