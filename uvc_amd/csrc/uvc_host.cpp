@@ -522,7 +522,7 @@ static int uvcgpu_region_accumulate_impl(uvcgpu_region_t *r) {
     if (!r) return fail(UVCGPU_EINVAL, "null region");
     if (!r->has_reads) return fail(UVCGPU_ENOREADS, "no reads");   // process_batch returns -1, main.cpp:520-523
     if (r->state_zeroed) HIP_OK(hipStreamWaitEvent(r->stream, r->e_join, 0));   // zeroed behind the last score (release_state)
-    else if (!getenv("UVCGPU_EXPERIMENT_SKIP_ZERO")) HIP_OK(hipMemsetAsync(r->d_state, 0, r->buckets_clean ? r->bucket_off : r->state_bytes, r->stream));
+    else HIP_OK(hipMemsetAsync(r->d_state, 0, r->buckets_clean ? r->bucket_off : r->state_bytes, r->stream));
     r->state_zeroed = false; r->state_released = false;
     r->buckets_clean = false;
     HIP_OK(hipMemcpyAsync(r->d_rtr, r->d_rtr0, (size_t)4 * UVC_NRTR * r->npos, hipMemcpyDeviceToDevice, r->stream));   // P1b edits indelphred in place
@@ -1011,7 +1011,7 @@ static int uvcgpu_region_score_impl(uvcgpu_region_t *r, const UvcScoreRequest *r
         else if (n_out > out->capacity) rc = fail(UVCGPU_ENOMEM, "score output capacity too small");   // the planes stay: the caller comes back with a larger buffer
         else if (rq.release_state && r->side) {   // the scoring kernels are done: zero the planes on the side stream under the D2H of the records
             if (hipEventRecord(r->e_fork, r->stream) == hipSuccess && hipStreamWaitEvent(r->side, r->e_fork, 0) == hipSuccess
-                && (getenv("UVCGPU_EXPERIMENT_SKIP_ZERO") || hipMemsetAsync(r->d_state, 0, r->buckets_clean ? r->bucket_off : r->state_bytes, r->side) == hipSuccess) && hipEventRecord(r->e_join, r->side) == hipSuccess) {
+                && hipMemsetAsync(r->d_state, 0, r->buckets_clean ? r->bucket_off : r->state_bytes, r->side) == hipSuccess && hipEventRecord(r->e_join, r->side) == hipSuccess) {
                 r->state_released = true; r->state_zeroed = true; r->zeroed_bytes = r->state_bytes;
             }
         }

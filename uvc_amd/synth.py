@@ -1,8 +1,8 @@
 """Synthetic pileup regions (SURVEY.md section 8d "Synthetic inputs").
 
-There is no htslib / BAM reader in either environment, so the benchmark and the parity tests
-run on in-memory regions laid out as the `alns3`-equivalent SoA of include/uvcgpu.h
-(`UvcReadSoA`).  The generator follows the SURVEY recipe: uniform random reference with planted
+The benchmark and the parity tests run on in-memory regions laid out as the `alns3`-equivalent SoA of
+include/uvcgpu.h (`UvcReadSoA`); the same dicts become BAM files through tests/bamwriter.py for the
+file-level tests (libuvcio reads BAM / BAI / FASTA itself, htslib is not available here).  The generator follows the SURVEY recipe: uniform random reference with planted
 homopolymer and (AC)n tracks, 150-bp paired-end reads, insert ~N(350, 50) clipped to [200, 600],
 both orientations 50/50, MAPQ 60 (5 % at 20-40), base quality 30+U{0..7} with the last 15
 sequenced bases degraded, 1e-3 sequencing errors, germline-like SNVs every 1 kb (AF 0.5),
