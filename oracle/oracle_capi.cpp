@@ -6,6 +6,7 @@
 using namespace uvco;
 
 namespace uvco { i32 oracle_sscs_phred(const UvcParams &P, int con_symbol, int alt_symbol);
+const char *score_trace_names();
 void test_segbias(State &S, bool isGap, i32 bq, i32 rpos, int sym, i32 a_pos, i32 a_endpos, i32 a_mpos, i32 a_isize, i32 a_flag, i32 a_mapq,
                   i32 xm1500, i32 bm1500, int cigar_op, i32 indel_len, i32 dist, int dflag, i32 clip_cnt, const i32 *thres, i64 *out); }
 
@@ -201,6 +202,22 @@ int uvc_oracle_score(void *h, const UvcScoreRequest *req, UvcScoreOut *out) {
     out->n_records = (i64)recs.size();
     if (out->n_records > out->capacity) { g_err = "score output capacity too small"; return UVCGPU_ENOMEM; }
     for (i64 i = 0; i < out->n_records; i++) for (int f = 0; f < UVC_NUM_SCORE_FIELDS; f++) out->fields[(size_t)f * out->capacity + i] = recs[i][f];
+    return 0;
+}
+
+// test hook: the inputs of calc_DPv / calc_qual of every record the request scores, in record order (names: uvc_oracle_score_trace_names,
+// ';'-separated); *n_values = records x names.  UVCGPU_ENOMEM with *n_values set when `cap` is too small.
+const char *uvc_oracle_score_trace_names(void) { return score_trace_names(); }
+int uvc_oracle_score_trace(void *h, const UvcScoreRequest *req, double *buf, int64_t cap, int64_t *n_values) {
+    State &S = *(State *)h;
+    std::vector<double> t; std::vector<std::vector<i32>> recs;
+    S.trace = &t;
+    const int rc = score(S, req, recs, g_err);
+    S.trace = nullptr;
+    if (rc) return rc;
+    *n_values = (i64)t.size();
+    if ((i64)t.size() > cap) { g_err = "trace capacity too small"; return UVCGPU_ENOMEM; }
+    if (!t.empty()) memcpy(buf, t.data(), t.size() * sizeof(double));
     return 0;
 }
 

@@ -197,6 +197,42 @@ static void symbol_init(Fmt &f, State &S, i32 refpos, int sym, i32 bDPa, i32 cDP
 static inline bool implies_short_frag(const Fmt &f, i32 wgs_min_avg_fragsize) { return (f.APLRI[0] + f.APLRI[2]) < (f.APLRI[1] + f.APLRI[3]) * (i64)wgs_min_avg_fragsize; }
 static inline double norm_fa(double FA, double refbias) { return (FA + FA * refbias) / (FA + (1.0 - FA) / (1.0 + refbias) + FA * refbias); }   // main.hpp:4253-4256
 
+// ---- test hook: what BcfFormat_symboltype_init / BcfFormat_symbol_init gathered for one record, as named numbers, so that an independent
+// restatement of calc_DPv / calc_qual (tests/score_restatement.py) starts from the same inputs
+#define TRACE_ARR(X) X(APDP, 12) X(APXM, 8) X(APLRI, 4) X(A1BQf, 2) X(A1BQr, 2) X(AMQs, 2) X(AP1, 2) X(AP2, 2) X(ADPff, 2) X(ADPfr, 2) X(ADPrf, 2) X(ADPrr, 2) \
+    X(ALP1, 2) X(ALP2, 2) X(ALPL, 2) X(ARP1, 2) X(ARP2, 2) X(ARPL, 2) X(ALB2, 2) X(ALBL, 2) X(ARB2, 2) X(ARBL, 2) X(ABQ2, 2) X(APF2, 2) X(ALI2, 2) X(ARIf, 2) X(ARI2, 2) X(ALIr, 2) \
+    X(BDPb, 2) X(BTAb, 2) X(BTBb, 2) X(CDP1b, 2) X(CDP12b, 2) X(CDP2b, 2) X(CDP3b, 2) \
+    X(C2LP2, 2) X(C2LPL, 2) X(C2RP2, 2) X(C2RPL, 2) X(C2LB2, 2) X(C2LBL, 2) X(C2RB2, 2) X(C2RBL, 2) X(C2BQ2, 2) X(C2LP0, 2) X(C2RP0, 2) X(DDP1, 2) X(DDP2, 2)
+#define TRACE_SCA(X) X(symbol) X(a1BQf) X(a1BQr) X(aMQs) X(aP1) X(aP2) X(aDPff) X(aDPfr) X(aDPrf) X(aDPrr) X(aLP1) X(aLP2) X(aRP1) X(aRP2) X(aLB1) X(aLB2) X(aRB1) X(aRB2) \
+    X(aLPL) X(aRPL) X(aLBL) X(aRBL) X(aLIT) X(aRIT) X(a2XM2) X(a2BM2) X(aBQ2) X(aPF1) X(aPF2) X(aLI1) X(aLI2) X(aLIr) X(aRI1) X(aRI2) X(aRIf) X(aP3) X(aNC) \
+    X(bDPf) X(bTAf) X(bTBf) X(bDPr) X(bTAr) X(bTBr) X(cDP1f) X(cDP12f) X(cDP2f) X(cDP3f) X(cDP21f) X(cDPMf) X(cDPmf) X(cDPDf) X(cDP1r) X(cDP12r) X(cDP2r) X(cDP3r) X(cDP21r) X(cDPMr) X(cDPmr) X(cDPDr) \
+    X(c2LP1) X(c2LP2) X(c2RP1) X(c2RP2) X(c2LP0) X(c2RP0) X(c2LB1) X(c2LB2) X(c2RB1) X(c2RB2) X(c2BQ2) X(c2LPL) X(c2RPL) X(c2LBL) X(c2RBL) X(dDP1) X(dDP2) \
+    X(DP) X(AD) X(bDP) X(bAD) X(c2DP) X(c2AD) X(bMQ) X(a2BQf) X(a2BQr) X(aBQ) X(aBQQ) X(bIAQb) X(bIADb) X(bIDQb) X(cIAQf) X(cIADf) X(cIDQf) X(cIAQr) X(cIADr) X(cIDQr) \
+    X(bDPa) X(cDP0a) X(gapSa_len) X(refpos) X(refsymbol) X(tki_tier2) X(tpfa_dpv) X(tpfa_qual)
+static const char *trace_names() {
+    static std::string s;
+    if (s.empty()) {
+#define X(n, k) for (int i = 0; i < k; i++) { s += #n; s += "["; s += std::to_string(i); s += "];"; }
+        TRACE_ARR(X)
+#undef X
+#define X(n) s += #n ";";
+        TRACE_SCA(X)
+#undef X
+        s += "rtr1_tracklen;rtr1_unitlen;rtr1_anyTR_tracklen;rtr2_tracklen;rtr2_unitlen;rtr2_anyTR_tracklen;";
+    }
+    return s.c_str();
+}
+static void trace_record(std::vector<double> &t, const Fmt &f, const Rtr &rtr1, const Rtr &rtr2) {
+#define X(n, k) for (int i = 0; i < k; i++) t.push_back((double)f.n[i]);
+    TRACE_ARR(X)
+#undef X
+#define X(n) t.push_back((double)f.n);
+    TRACE_SCA(X)
+#undef X
+    t.push_back(rtr1.tracklen); t.push_back(rtr1.unitlen); t.push_back(rtr1.anyTR_tracklen); t.push_back(rtr2.tracklen); t.push_back(rtr2.unitlen); t.push_back(rtr2.anyTR_tracklen);
+}
+const char *score_trace_names() { return trace_names(); }
+
 // BcfFormat_symbol_calc_DPv, main.hpp:4274-4844
 static void calc_DPv(Fmt &fmt, const Rtr &rtr1, const Rtr &rtr2, int refsymbol, State &S, i32 refpos) {
     const UvcParams &P = S.P;
@@ -1289,6 +1325,7 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
                     const i32 minABQ = (is_subst(symbol) ? (i32)nnminus(minABQ_snv, (homopol_1bp ? (homopol_2bp ? 20 : 10) : 0)) : minABQ_indel);
                     symbol_init(f, S, refpos, symbol, al.bDPa, al.cDP0a, al.indel_len, minABQ);
                     f.gapSa_row = (ai < allele_rows.size() ? allele_rows[ai] : -1);
+                    if (S.trace) trace_record(*S.trace, f, S.rtr[max_(refpos - ext_beg, 3) - 3], S.rtr[min_(refpos - ext_beg + 3, nrtr - 1)]);
                     calc_DPv(f, S.rtr[max_(refpos - ext_beg, 3) - 3], S.rtr[min_(refpos - ext_beg + 3, nrtr - 1)], refsymbol, S, refpos);
                     fmts[st].push_back(f); texts[st].push_back(ai < allele_texts.size() ? allele_texts[ai] : std::string());   // InDel string as text, for the order of cVQSM
                 }
