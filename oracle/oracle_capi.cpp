@@ -208,16 +208,17 @@ int uvc_oracle_score(void *h, const UvcScoreRequest *req, UvcScoreOut *out) {
 // test hook: the inputs of calc_DPv / calc_qual of every record the request scores, in record order (names: uvc_oracle_score_trace_names,
 // ';'-separated); *n_values = records x names.  UVCGPU_ENOMEM with *n_values set when `cap` is too small.
 const char *uvc_oracle_score_trace_names(void) { return score_trace_names(); }
-int uvc_oracle_score_trace(void *h, const UvcScoreRequest *req, double *buf, int64_t cap, int64_t *n_values) {
+int uvc_oracle_score_trace(void *h, const UvcScoreRequest *req, double *buf, int64_t cap, int64_t *n_values, double *buf2 /* [records][6] or NULL */) {
     State &S = *(State *)h;
-    std::vector<double> t; std::vector<std::vector<i32>> recs;
-    S.trace = &t;
+    std::vector<double> t, t2; std::vector<std::vector<i32>> recs;
+    S.trace = &t; S.trace2 = &t2;
     const int rc = score(S, req, recs, g_err);
-    S.trace = nullptr;
+    S.trace = nullptr; S.trace2 = nullptr;
     if (rc) return rc;
     *n_values = (i64)t.size();
     if ((i64)t.size() > cap) { g_err = "trace capacity too small"; return UVCGPU_ENOMEM; }
     if (!t.empty()) memcpy(buf, t.data(), t.size() * sizeof(double));
+    if (buf2 && !t2.empty()) memcpy(buf2, t2.data(), t2.size() * sizeof(double));   // 6 per record, same record order
     return 0;
 }
 

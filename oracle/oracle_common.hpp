@@ -100,6 +100,7 @@ struct VcfSink { std::string tname; std::vector<std::string> fixed, spec; std::v
 
 struct State {
     VcfSink *vcf_sink = nullptr;
+    std::vector<double> *trace2 = nullptr;  // ... and the six position-level arguments of calc_qual (ins / del depths, repeat unit size and count), per record
     std::vector<double> *trace = nullptr;   // test hook (uvc_oracle_score_trace): the BcfFormat inputs of every record in front of calc_DPv / calc_qual
     i32 tid, beg, end;      // state covers [beg, end): end = caller's `end` + 1 (main.cpp:569)
     i64 npos;

@@ -1347,6 +1347,7 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
             std::vector<Top> tops;
             for (size_t fi = 0; fi < fmts[st].size(); fi++) {
                 Fmt &f = fmts[st][fi];
+                if (S.trace2) { const double v6[6] = { (double)ins_cdepth, (double)del_cdepth, (double)ins1_cdepth, (double)del1_cdepth, (double)repeatunit_size, (double)repeatnum }; S.trace2->insert(S.trace2->end(), v6, v6 + 6); }
                 calc_qual(f, ins_cdepth, del_cdepth, ins1_cdepth, del1_cdepth, repeatunit_size, repeatnum,
                           S.rtr[max_(refpos - ext_beg, 3) - 3], S.rtr[min_(refpos - ext_beg + 3, nrtr - 1)], refpos, st_refsymbol[st], S);
                 if (st_refsymbol[st] != f.symbol) {   // main.cpp:990-998

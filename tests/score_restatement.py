@@ -407,3 +407,297 @@ def sum_DPv(outs, symbols):
             for i, k in enumerate(keys):
                 s2[i] = o[k]
     return s1, s2
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# BcfFormat_symbol_calc_qual, main.hpp:4908-5343 (+ PhredMutationTable :213-262, calc_binom_10log10_likeratio main_conversion.hpp:222-237,
+# logit2 :211-219, indel_phred main.hpp:794-801, indel_len_rusize_phred :757-790).  C++ types are followed where they change a result:
+# `auto` and ternaries that mix int and double are double, a double assigned to an integer variable or pushed into a FORMAT vector is
+# truncated, int64mul() truncates its operands first.
+# ------------------------------------------------------------------------------------------------------------------------------------
+BASE_A, BASE_C, BASE_G, BASE_T = 0, 1, 2, 3
+INS_N_ANCHOR_BASES = 1              # main.hpp:155
+TIN_CONTAM_MICRO_VQ_DELTA = 0       # main.hpp:157
+
+
+def calc_binom_10log10_likeratio(prob, a, b, bidirectional=False, set_max_prob_to_one=False):
+    if set_max_prob_to_one:
+        prob = min(1.0, prob)
+    prob = (prob + DBL_EPSILON) / (1.0 + (2.0 * DBL_EPSILON))
+    a += DBL_EPSILON
+    b += DBL_EPSILON
+    A = prob * (a + b)
+    B = (1.0 - prob) * (a + b)
+    if bidirectional or a > A:
+        return 10.0 / math.log(10.0) * (a * math.log(a / A) + b * math.log(b / B))
+    return 0.0
+
+
+def logit2(a, b):
+    return math.log(prob2odds((a + DBL_EPSILON) / (a + b + 2.0 * DBL_EPSILON)))
+
+
+def indel_phred(ampfact, repeatsize_at_max_repeatnum, max_repeatnum):
+    region_size = repeatsize_at_max_repeatnum * max_repeatnum
+    num_slips = ((float(region_size - 8)) if region_size > 64 else math.log1p(math.exp(float(region_size) - 8.0))) * ampfact / float(repeatsize_at_max_repeatnum * repeatsize_at_max_repeatnum)
+    return int(math.floor(-10 * math.log((1.0 - DBL_EPSILON) / (num_slips + 1.0)) / math.log(10)))
+
+
+N_UNITS_TO_PHRED = [0, 0, 3, 5, 6, 7, 8, 8, 9, 10, 10, 10, 11, 11, 11, 12, 12, 12, 13]
+
+
+def indel_len_rusize_phred(indel_len, repeatunit_size):
+    if 0 == (indel_len % repeatunit_size):
+        return N_UNITS_TO_PHRED[min(indel_len // repeatunit_size, len(N_UNITS_TO_PHRED) - 1)]
+    return N_UNITS_TO_PHRED[min(indel_len, len(N_UNITS_TO_PHRED) - 1)]
+
+
+def sscs_phred_err_rate(P, con_symbol, alt_symbol):
+    """PhredMutationTable::toPhredErrRate with the table calc_qual builds (main.hpp:4935-4942)."""
+    if is_ins(con_symbol) or is_del(con_symbol):
+        raw = P.fam_phred_sscs_indel_open
+    elif con_symbol == LINK_M:
+        if alt_symbol in (LINK_D1, LINK_I1): raw = P.fam_phred_sscs_indel_open
+        elif alt_symbol in (LINK_D2, LINK_I2): raw = P.fam_phred_sscs_indel_open + P.fam_phred_sscs_indel_ext * 1
+        else: raw = P.fam_phred_sscs_indel_open + P.fam_phred_sscs_indel_ext * 2
+    elif (con_symbol == BASE_C and alt_symbol == BASE_T) or (con_symbol == BASE_G and alt_symbol == BASE_A): raw = P.fam_phred_sscs_transition_CG_TA
+    elif (con_symbol == BASE_A and alt_symbol == BASE_G) or (con_symbol == BASE_T and alt_symbol == BASE_C): raw = P.fam_phred_sscs_transition_AT_GC
+    elif (con_symbol == BASE_C and alt_symbol == BASE_A) or (con_symbol == BASE_G and alt_symbol == BASE_T): raw = P.fam_phred_sscs_transversion_CG_AT
+    else: raw = P.fam_phred_sscs_transversion_other
+    return raw + (3 if P.tumor_vcf_fname_nonempty else 0)
+
+
+def calc_qual(d, dpv, cdpv, extra, P):
+    """d: traced inputs of the record; dpv: calc_DPv's outputs for it; cdpv = (sums [6], NN [6]) of its group from sum_DPv;
+    extra = (ins_cdepth, del_cdepth, ins1_cdepth, del1_cdepth, repeatunit.size(), repeatnum).  Returns the FORMAT values the function pushes."""
+    f = _F(d)
+    out = {}
+    tprov = bool(P.tumor_vcf_is_provided)
+    is_rescued = tprov                                        # main.cpp:979
+    ins_cdepth, del_cdepth, ins1_cdepth, del1_cdepth, ru_size, repeatnum = [int(v) for v in extra]
+    rtr1_tracklen, rtr1_unitlen, rtr2_tracklen, rtr2_unitlen = int(d["rtr1_tracklen"]), int(d["rtr1_unitlen"]), int(d["rtr2_tracklen"]), int(d["rtr2_unitlen"])
+    tpfa = float(d["tpfa_qual"])
+    refsymbol, symbol = int(d["refsymbol"]), f.a("symbol")
+    indel_size = f.a("gapSa_len")
+    cDP1v, cDP1w, cDP1x, cDP2v, cDP2w = dpv["cDP1v"], dpv["cDP1w"], dpv["cDP1x"], dpv["cDP2v"], dpv["cDP2w"]
+    CDP1v0, CDP1x0 = cdpv[0][0], cdpv[0][2]
+    tier2 = bool(dpv["tier2"])
+    bNMQ = dpv["bNMQ"]
+    sCDP1, sCDP2, sCDP12, sBDP = f.sumpair("CDP1b"), f.sumpair("CDP2b"), f.sumpair("CDP12b"), f.sumpair("BDPb")
+    a_pcr_dp, a_snv_dp = f.X("APDP", 5), f.X("APDP", 6)
+
+    cFA2 = (f.a("cDP2f") + f.a("cDP2r") + 0.5) / (sCDP2 + 1.0)
+    powlaw_sscs_phrederr = sscs_phred_err_rate(P, refsymbol, symbol) + (0 if not tprov else 4)
+    umi_cFA = (float(cDP2v) + 0.5) / float(sCDP2 * 100 + 1.0)
+    umi_cFA_w = (float(cDP2w) + 0.5) / float(sCDP2 * 100 + 1.0)
+    powlaw_sscs_inc1 = trunc(powlaw_sscs_phrederr - ((float(P.fam_phred_pow_sscs_transversion_AT_TA_origin) if ((BASE_A == refsymbol and BASE_T == symbol) or (BASE_T == refsymbol and BASE_A == symbol))
+                                                       else P.fam_phred_pow_sscs_snv_origin) if is_subst(symbol) else P.fam_phred_pow_sscs_indel_origin))
+    powlaw_sscs_inc4tn = trunc((max(P.fam_phred_sscs_transition_CG_TA, P.fam_phred_sscs_transition_AT_GC, P.fam_phred_sscs_transversion_CG_AT, P.fam_phred_sscs_transversion_other)
+                                - P.fam_phred_pow_sscs_snv_origin) if is_subst(symbol) else float(powlaw_sscs_inc1))
+    is_substitution_oxidation = (BASE_C == refsymbol and BASE_A == symbol) or (BASE_G == refsymbol and BASE_T == symbol)
+    powlaw_sscs_inc4tn += P.tn_q_inc_max_sscs_CG_AT if is_substitution_oxidation else P.tn_q_inc_max_sscs_other
+    t2n_contam_frac = (tpfa if tpfa > 0 else 0) * P.contam_t2n_mul_frac
+    contamfrac = P.contam_any_mul_frac + (1.0 - P.contam_any_mul_frac) * t2n_contam_frac
+
+    aDP = f.a("aDPff") + f.a("aDPfr") + f.a("aDPrf") + f.a("aDPrr")
+    ADP = f.X("ADPff") + f.X("ADPrf") + f.X("ADPfr") + f.X("ADPrr")
+    cDP0, CDP0 = f.a("cDP1f") + f.a("cDP1r"), sCDP1
+    cDP2, CDP2 = f.a("cDP2f") + f.a("cDP2r"), sCDP2
+    aavgMQ = cdiv(f.a("aMQs"), max(1, aDP))
+    diffAaMQs = cdiv(f.X("AMQs") - f.a("aMQs"), max(1, ADP - aDP)) - aavgMQ
+    tn_q_inc_max = P.tn_q_inc_max
+    noUMI_bias_inc = min(P.bias_FA_powerlaw_noUMI_phred_inc_snv, cdiv(aDP, 2))
+    pl_noUMI_phred_inc = P.powlaw_anyvar_base + (noUMI_bias_inc if is_subst(symbol) else P.bias_FA_powerlaw_noUMI_phred_inc_indel)          # double
+    withUMI_bias_inc = min(P.bias_FA_powerlaw_withUMI_phred_inc_snv - P.bias_FA_powerlaw_noUMI_phred_inc_snv, cdiv(cDP2, 2)) + noUMI_bias_inc
+    pl_withUMI_phred_inc = P.powlaw_anyvar_base + (withUMI_bias_inc if is_subst(symbol) else P.bias_FA_powerlaw_withUMI_phred_inc_indel)    # double
+    prior_weight = 1.0 / (f.a("cDPmf") + f.a("cDPmr") + 1.0)
+    fam_thres_highBQ = P.fam_thres_highBQ_snv if is_subst(symbol) else P.fam_thres_highBQ_indel
+    cMmQ = cround(numstates2phred((f.a("cDPMf") + f.a("cDPmf") + f.a("cDPMr") + f.a("cDPmr") + math.pow(10, fam_thres_highBQ / 10.0) * prior_weight)
+                                  / (f.a("cDPmf") + f.a("cDPmr") + prior_weight)))
+    nbases_x100_1 = f.a("bIADb") * 100 + 1
+    nbases_x100_2 = min(nbases_x100_1, cDP1v + 1)
+    perbase_likeratio_q_x10_1 = cdiv(10 * f.a("bIAQb"), max(1, f.a("bIADb")))
+    perbase_likeratio_q_x10_2 = perbase_likeratio_q_x10_1 + cround(10 * numstates2phred(float(nbases_x100_2) / float(nbases_x100_1)))
+    duped_frag_binom_qual = cdiv((perbase_likeratio_q_x10_1 if (is_ins(symbol) or is_del(symbol)) else perbase_likeratio_q_x10_2) * nbases_x100_2, 10 * 100)
+    contam_frag_withmin_qual = cround(calc_binom_10log10_likeratio(t2n_contam_frac, cDP0, CDP0 - cDP0)) + 9 - 3
+    phred_het3al_chance_inc_snp = max(0, 2 * P.germ_phred_hetero_snp - P.germ_phred_het3al_snp - TIN_CONTAM_MICRO_VQ_DELTA)
+    phred_het3al_chance_inc_indel = max(0, 2 * P.germ_phred_hetero_indel - P.germ_phred_het3al_indel - TIN_CONTAM_MICRO_VQ_DELTA)
+    phred_het3al_chance_inc = phred_het3al_chance_inc_snp if is_subst(symbol) else phred_het3al_chance_inc_indel
+    if is_ins(symbol) or is_del(symbol):
+        phred_het3al_chance_inc = non_neg_minus(phred_het3al_chance_inc_indel + 1, indel_size)
+    contam_syserr_phred_bypassed = phred_het3al_chance_inc
+    normcDP1 = f.a("cDP12f") + f.a("cDP12r") + 1
+    normCDP1 = sCDP12 + 1
+    normBDP = sBDP + 1
+    sscs_dec1_div = 2 if is_rescued else 1
+    sscs_dec1a = 0 if ((cdiv(P.fam_min_n_copies, sscs_dec1_div) <= normCDP1) or (cdiv(P.fam_min_n_copies_DPxAD, sscs_dec1_div) <= normCDP1 * normcDP1)) else (powlaw_sscs_inc1 + 3)
+    sscs_dec1b = 0 if ((cdiv(P.fam_min_overseq_perc - 100, sscs_dec1_div) + 100) * normCDP1 <= 100 * normBDP) else (powlaw_sscs_inc1 + 3)
+    sscs_dec1 = max(sscs_dec1a, sscs_dec1b)
+    sscs_dec2 = non_neg_minus(fam_thres_highBQ, cMmQ)
+    cIADnormcnt = (f.a("cIADf") + f.a("cIADr")) * 100 + 1
+    cIADmincnt = min(cIADnormcnt, cDP2v + 1)
+    sscs_binom_qual_fw = f.a("cIAQf") + cdiv(f.a("cIAQr") * min(P.fam_phred_dscs_all - f.a("cIDQf"), f.a("cIDQr")), max(f.a("cIDQr"), 1))
+    sscs_binom_qual_rv = f.a("cIAQr") + cdiv(f.a("cIAQf") * min(P.fam_phred_dscs_all - f.a("cIDQr"), f.a("cIDQf")), max(f.a("cIDQf"), 1))
+    contam_sscs_withmin_qual = cround(calc_binom_10log10_likeratio(t2n_contam_frac, cDP2, CDP2 - cDP2)) + 9 - 3
+    mx = max(sscs_binom_qual_fw, sscs_binom_qual_rv)
+    sub = numstates2phred(cIADnormcnt / float(cIADmincnt)) * cIADnormcnt / 100.0
+    nnm = (mx - sub) if mx > sub else 0                       # non_neg_minus(int64, double): a double (or the int 0)
+    sscs_binom_qual = cdiv(trunc(nnm) * cIADmincnt, cIADnormcnt)
+    if mx > P.microadjust_fam_binom_qual_halving_thres and is_subst(symbol):
+        sscs_binom_qual = min(sscs_binom_qual, P.microadjust_fam_binom_qual_halving_thres + cdiv(mx - P.microadjust_fam_binom_qual_halving_thres, 2))
+    sscs_binom_qual -= sscs_dec1 + sscs_dec2
+    min_bcFA_v = (float(cDP1v) + 0.5) / float(sCDP1 * 100 + 1.0)
+    dedup_frag_powlaw_qual_v = cround(P.powlaw_exponent * numstates2phred(min_bcFA_v) + pl_noUMI_phred_inc)
+    min_bcFA_w = (float(cDP1w) + 0.5) / float(sCDP1 * 100 + 1.0)
+    dedup_frag_powlaw_qual_w = cround(P.powlaw_exponent * numstates2phred(min_bcFA_w) + pl_noUMI_phred_inc + tn_q_inc_max)
+    ds_vq_inc_powlaw = trunc(cround(10 / math.log(10) * min(math.log((f.a("cDP12f") + 0.5) / (f.X("CDP12b", 0) + 1.0)), math.log((f.a("cDP12r") + 0.5) / (f.X("CDP12b", 1) + 1.0)))) + powlaw_sscs_phrederr)
+    ds_vq_inc_binom = 3 * min(f.a("cDP2f"), f.a("cDP2r"))
+    powlaw_sscs_inc2 = max(0, min(sscs_binom_qual_fw, sscs_binom_qual_rv, ds_vq_inc_powlaw, ds_vq_inc_binom, 3)) * (1 if cFA2 > 0.002 else 0)
+    sscs_dec3 = -3 if is_rescued else (0 if cFA2 >= 0.003 else 5)
+    sscs_base_2 = trunc(pl_withUMI_phred_inc + powlaw_sscs_inc1 + powlaw_sscs_inc2 - sscs_dec1 - sscs_dec2 - sscs_dec3)
+    sscs_base_2tn = trunc(pl_withUMI_phred_inc + powlaw_sscs_inc4tn + powlaw_sscs_inc2 - sscs_dec1 - sscs_dec2 - sscs_dec3)
+    sscs_powlaw_qual_v = cround(P.powlaw_exponent * numstates2phred(umi_cFA) + sscs_base_2)
+    sscs_powlaw_qual_w = cround(P.powlaw_exponent * numstates2phred(umi_cFA_w) + sscs_base_2tn)
+    dFA = float(f.a("dDP2") + 0.5) / float(f.X("DDP1") + 1.0)
+    dSNR = float(f.a("dDP2") + 0.5) / float(f.a("dDP1") + 1.0)
+    dnormFA = dFA * math.pow(dSNR, 1.0 / P.powlaw_exponent)
+    fam_phred_dscs_estimated = cround((P.fam_phred_dscs_max + powlaw_sscs_phrederr) / 2.0)
+    dFA_vq_binom = cdiv((fam_phred_dscs_estimated - cround(numstates2phred(1.0 / dnormFA))) * f.a("dDP2") * cIADmincnt, cIADnormcnt)
+    dFA_vq_powlaw = trunc(P.powlaw_anyvar_base + (fam_phred_dscs_estimated - P.fam_phred_pow_dscs_all_origin)
+                          + cround(numstates2phred(dnormFA * min(1.0, float(cDP1v + 0.5) / float(sCDP1 * 100 + 1.0)))))
+    out["cMmQ"] = cMmQ
+
+    eps = FLT_EPSILON
+    is_indel_penal_applied = (SEQUENCING_PLATFORM_IONTORRENT == P.inferred_sequencing_platform) and (not tprov)
+    indel_penal_base = (cround(P.indel_multiallele_samepos_penal / math.log(2) * math.log(float(max(aDP + eps, f.X("APDP", 1), f.X("APDP", 2))) / float(aDP + eps)))
+                        if is_indel_penal_applied else 0)
+    indel_penal4multialleles = 0
+    indel_penal4multialleles_g = 0
+    indel_penal4multialleles_soma = 0
+    indel_UMI_penal = 0
+    if indel_size > 0 and f.a("cDP0a") > 0:
+        indel_pq = float(min(indel_phred(P.indel_polymerase_slip_rate, ru_size, repeatnum), 24)) + 2 - 10.0
+        eff_tracklen1 = ru_size * max(1, repeatnum) - ru_size
+        eff_tracklen2 = cdiv(max(rtr1_tracklen - rtr1_unitlen, rtr2_tracklen - rtr2_unitlen), 3)
+        indel_ic = (numstates2phred(float(max(indel_size + (INS_N_ANCHOR_BASES if is_ins(symbol) else 0), 1)) / float(max(eff_tracklen1, eff_tracklen2) + 1))
+                    + ((numstates2phred(P.indel_del_to_ins_err_ratio) * min(200, f.a("cDP0a")) / 200) if is_ins(symbol) else 0))
+        indelcdepth = ins_cdepth if is_ins(symbol) else del_cdepth
+        if LINK_D1 == symbol:
+            indelcdepth += ins1_cdepth
+        if LINK_I1 == symbol:
+            indelcdepth = trunc(indelcdepth + del1_cdepth / P.indel_del_to_ins_err_ratio)     # int += double
+        nearInDelDP = f.X("APDP", 1) if is_ins(symbol) else f.X("APDP", 2)
+        indel_penal4multialleles1 = cround(P.indel_multiallele_samepos_penal / math.log(2.0) * math.log(float(indelcdepth + eps) / float(f.a("cDP0a") + eps)))
+        if SEQUENCING_PLATFORM_IONTORRENT == P.inferred_sequencing_platform:
+            indel_penal4multialleles1 = trunc(non_neg_minus(indel_penal4multialleles1, P.indel_multiallele_samepos_penal))
+        indel_penal4multialleles2 = cround(P.indel_multiallele_diffpos_penal / math.log(2.0) * math.log(float(nearInDelDP + eps) / float(max(aDP, nearInDelDP) + eps)))
+        indel_penal4multialleles_g = trunc(cround(P.indel_tetraallele_germline_penal_value / math.log(2.0) * math.log(float(ins_cdepth + del_cdepth + eps) / float(f.a("cDP0a") + eps)))
+                                           - P.indel_tetraallele_germline_penal_thres)
+        if is_ins(symbol):
+            indel_penal4multialleles = cdiv(indel_penal4multialleles1 * P.indel_ins_penal_pseudocount, P.indel_ins_penal_pseudocount + indel_size)
+            indel_penal4multialleles_soma = cdiv(indel_penal4multialleles1 * P.indel_ins_penal_pseudocount, P.indel_ins_penal_pseudocount + indel_size)
+        else:
+            indel_penal4multialleles = max(indel_penal4multialleles1, indel_penal4multialleles2)
+            indel_penal4multialleles_soma = indel_penal4multialleles1
+        dedup_frag_powlaw_qual_v = trunc(dedup_frag_powlaw_qual_v + cround(indel_ic))
+        dedup_frag_powlaw_qual_w = trunc(dedup_frag_powlaw_qual_w + cround(indel_ic))
+        duped_frag_binom_qual = trunc(duped_frag_binom_qual + cround(indel_pq))
+        sscs_indel_ic = numstates2phred(float(max(indel_size, 1) ** 2) / float(max(eff_tracklen1, eff_tracklen2) + 1))
+        sscs_ins_vs_del_inc = cround(P.powlaw_exponent * numstates2phred(P.indel_del_to_ins_err_ratio))
+        x = sscs_indel_ic * (0 if is_ins(symbol) else max(eff_tracklen1, eff_tracklen2)) / cround(P.indel_polymerase_size)
+        extra_reward = trunc(((sscs_ins_vs_del_inc - x) if sscs_ins_vs_del_inc > x else 0) - cdiv(sscs_ins_vs_del_inc, 2))
+        sscs_powlaw_qual_v = trunc(sscs_powlaw_qual_v + cround(sscs_indel_ic) + extra_reward)
+        sscs_powlaw_qual_w = trunc(sscs_powlaw_qual_w + cround(sscs_indel_ic) + extra_reward)
+        sscs_binom_qual = trunc(sscs_binom_qual + cround(indel_pq) + extra_reward)
+        if tier2:
+            v1 = (sBDP + 1.0) / float(sCDP1 + 1.0) * P.fam_indel_nonUMI_phred_dec_per_fold_overseq
+            v2 = (P.fam_thres_emperr_all_flat_indel + 1) * P.fam_indel_nonUMI_phred_dec_per_fold_overseq
+            indel_UMI_penal = trunc((v1 - v2) if v1 > v2 else 0)
+    if is_substitution_oxidation and tprov:
+        sscs_binom_qual = max(sscs_binom_qual, min(aDP, 3))
+    out["aAaMQ"] = diffAaMQs
+
+    readlenMQcap = cdiv(f.X("APXM", 2), max(1, f.X("APDP", 0))) - 17
+    diffMQ = max(0, diffAaMQs)
+    is_aln_extra_accurate = P.inferred_maxMQ > 60
+    _systematicMQVQadd = 0 if symbol == refsymbol else min(P.germ_phred_homalt_snp, ADP * 3)
+    _systematicMQVQadd_somatic = 0 if symbol != refsymbol else min(P.germ_phred_homalt_snp, ADP * 3)
+    is_MQ_unadjusted = is_aln_extra_accurate or (not is_subst(symbol)) or (aDP > cdiv(ADP * 3, 4))
+    _systematicMQVQminus = ((0 if is_MQ_unadjusted else cdiv(non_neg_minus(60 - 30, aavgMQ) * 2, 5))
+                            + (0 if (is_MQ_unadjusted or refsymbol != symbol) else non_neg_minus(min(15, diffMQ), aavgMQ)))
+    diffMQ2 = diffMQ
+    if f.a("bMQ") < 20 and not tprov:
+        aDPxf = f.a("aDPff") + f.a("aDPrf") + 0.5
+        aDPxr = f.a("aDPfr") + f.a("aDPrr") + 0.5
+        ADPxf = f.X("ADPff") + f.X("ADPrf") + 1.0
+        ADPxr = f.X("ADPfr") + f.X("ADPrr") + 1.0
+        if ((aDPxr / ADPxr) * 2 < (aDPxf / ADPxf) or (aDPxf / ADPxf) * 2 < (aDPxr / ADPxr)
+                or (f.a("aLI1") + 0.5) / (f.X("ALI2") + 1.0) * (2 * (1.0 + DBL_EPSILON)) < aDPxr / ADPxr
+                or (f.a("aRI1") + 0.5) / (f.X("ARI2") + 1.0) * (2 * (1.0 + DBL_EPSILON)) < aDPxf / ADPxf):
+            diffMQ2 = max(diffMQ2, 20 - min(f.a("bMQ"), 20))
+    _systematicMQ_base = (f.a("bMQ") * (P.syserr_MQ_max - P.syserr_MQ_nonref_base) / P.syserr_MQ_max + P.syserr_MQ_nonref_base) - diffMQ2 - bNMQ    # double
+    _systematicMQ = trunc(float(f.a("bMQ")) if ((refsymbol == symbol) and (ADP > aDP * 2)) else (_systematicMQ_base - trunc(numstates2phred((ADP + 1.0) / (aDP + 0.5)))))
+    is_nonWGS = does_fmt_imply_short_frag(d, P.lib_wgs_min_avg_fraglen)
+    normal_rescued_MQ = min(non_neg_minus(readlenMQcap, 60), (P.lib_nonwgs_normal_max_rescued_MQ if is_nonWGS else P.lib_wgs_normal_max_rescued_MQ))
+    systematicMQVQ1 = min(max(_systematicMQ, P.syserr_MQ_min) + _systematicMQVQadd, readlenMQcap)
+    systematicBQVQ = f.a("aBQQ") if ((SEQUENCING_PLATFORM_IONTORRENT != P.inferred_sequencing_platform) and is_subst(symbol)) else 200
+    is_strong_amplicon = (a_pcr_dp * 100) > f.X("APDP", 0) * 50
+    is_weak_amplicon = (a_pcr_dp * 100) > f.X("APDP", 0) * 30
+    is_tmore_amplicon = is_weak_amplicon if not tprov else is_strong_amplicon
+    go_per_dp = cdiv(f.X("APXM", 1), max(f.X("APDP", 0), 1))
+    if is_tmore_amplicon and (is_ins(symbol) or is_del(symbol)) and systematicMQVQ1 > 70 and go_per_dp > 20:
+        systematicMQVQ1 = 70 + cdiv((systematicMQVQ1 - 70) * 5, go_per_dp - 15)
+    indel_penal_base_add = 0
+    if not tprov:
+        delAPDP = max(f.X("APDP", 2), f.X("APDP", 4))
+        if ((f.X("APDP", 0) < 3 * delAPDP) and (f.X("APDP", 0) < 3 * a_snv_dp) and (aDP * 3 < delAPDP) and (aDP * 3 < a_snv_dp)
+                and is_subst(symbol) and (rtr2_tracklen >= 8 * rtr2_unitlen)):
+            indel_penal_base_add = P.microadjust_germline_mix_with_del_snv_penalty
+        if is_tmore_amplicon and is_del(symbol):
+            if aDP * 4 < f.X("APDP", 2):
+                indel_penal_base_add = max(indel_penal_base_add, 5)
+            elif f.a("cDP0a") * 3 < 2 * del_cdepth:
+                indel_penal_base_add = max(indel_penal_base_add, 2)
+    systematicMQVQ = max(0, systematicMQVQ1)
+    indel_penal_base2 = indel_penal_base + indel_penal_base_add
+    fmtADPfx, fmtADPrx = f.X("ADPff") + f.X("ADPfr"), f.X("ADPrf") + f.X("ADPrr")
+    fmtADPxf, fmtADPxr = f.X("ADPff") + f.X("ADPrf"), f.X("ADPfr") + f.X("ADPrr")
+    fold = P.microadjust_strand_orientation_absence_DP_fold
+    is_fmtADPfrx_imba = max(fmtADPfx, fmtADPrx) > fold * (min(fmtADPfx, fmtADPrx) + 1)
+    is_fmtADPxfr_imba = max(fmtADPxf, fmtADPxr) > fold * (min(fmtADPxf, fmtADPxr) + 1)
+    dedup_frag_powlaw_qual_v_minus = (((P.microadjust_orientation_absence_snv_penalty if is_fmtADPfrx_imba else 0) + (P.microadjust_strand_absence_snv_penalty if is_fmtADPxfr_imba else 0))
+                                      if is_subst(symbol) else (P.microadjust_dedup_absence_indel_penalty if is_tmore_amplicon else 0))
+    tn_syserr_q = systematicMQVQ + P.tn_q_inc_max + normal_rescued_MQ
+    out["bMQQ"] = systematicMQVQ
+    bIAQ = duped_frag_binom_qual - indel_penal_base2
+    cIAQ = sscs_binom_qual - indel_penal_base
+    cPCQ1 = min(dedup_frag_powlaw_qual_w - indel_penal_base2, tn_syserr_q)
+    cPLQ1 = dedup_frag_powlaw_qual_v - indel_penal_base2 - dedup_frag_powlaw_qual_v_minus
+    cPCQ2 = min(sscs_powlaw_qual_w - indel_penal_base, tn_syserr_q)
+    cPLQ2 = sscs_powlaw_qual_v - indel_penal_base
+    bTINQ = contam_frag_withmin_qual + contam_syserr_phred_bypassed
+    cTINQ = contam_sscs_withmin_qual + contam_syserr_phred_bypassed
+    out.update(bIAQ=bIAQ, cIAQ=cIAQ, cPCQ1=cPCQ1, cPLQ1=cPLQ1, cPCQ2=cPCQ2, cPLQ2=cPLQ2, bTINQ=bTINQ, cTINQ=cTINQ)
+    aDPpc = 1 if refsymbol == symbol else 0
+    penal4BQerr = (5 + cdiv(P.penal4lowdep, max(1, aDP + aDPpc) ** 2)) if is_subst(symbol) else 0
+    indel_q_inc = 0 if (((not is_ins(symbol)) and (not is_del(symbol))) or is_rescued) else indel_len_rusize_phred(indel_size, repeatnum)
+    out["gVQ1"] = trunc(max(0, indel_q_inc + min(min(systematicBQVQ, non_neg_minus(systematicMQVQ, _systematicMQVQminus)), bIAQ - penal4BQerr, cPLQ1)
+                            - 2 * max(0, indel_penal4multialleles - P.indel_multiallele_soma_penal_thres, indel_penal4multialleles_g)))
+    systematicVQsomatic_minus = 0 if is_rescued else (15 - min(cdiv(ADP * 15, 100), aDP, 15))
+    systematicVQsomatic = non_neg_minus(min(systematicBQVQ, systematicMQVQ + _systematicMQVQadd_somatic), systematicVQsomatic_minus)
+    bcVQ1 = min(systematicVQsomatic, bIAQ - (0 if is_rescued else penal4BQerr), cPLQ1) - indel_penal4multialleles_soma
+    out["cVQ1"] = max(0, min(bcVQ1, bTINQ) - indel_UMI_penal)
+    mincVQ2 = 0
+    if is_ins(symbol) or is_del(symbol):
+        sscs_floor_qual_v = trunc(min(P.germ_phred_homalt_indel + numstates2phred(umi_cFA), cdiv(cDP2v * 3, 100)) + ((INS_N_ANCHOR_BASES if is_ins(symbol) else 0) - INS_N_ANCHOR_BASES) * 3)
+        mincVQ2 = max(mincVQ2, sscs_floor_qual_v)
+    dVQinc = min(min(dFA_vq_binom, dFA_vq_powlaw) - max(0, min(cIAQ, cPLQ2)), P.fam_phred_dscs_inc_max)
+    out["dVQinc"] = dVQinc
+    cVQ2 = min(systematicVQsomatic, cIAQ + max(0, dVQinc), cPLQ2 + max(0, dVQinc)) - indel_penal4multialleles
+    out["cVQ2"] = max(mincVQ2, min(cVQ2, cTINQ))
+    cDP1y = cDP1x if is_rescued else cDP1v
+    CDP1y0 = CDP1x0 if is_rescued else CDP1v0
+    binom_contam_LODQ = calc_binom_10log10_likeratio(contamfrac, cDP1y, CDP1y0)
+    power_contam_LODQ = cround(10.0 / math.log(10.0) * P.powlaw_exponent * max(logit2((cDP1y + 1) / float(CDP1y0 + 1), contamfrac), 0.0))
+    out["CONTQ"] = trunc(min(binom_contam_LODQ, power_contam_LODQ))
+    return out

@@ -1,4 +1,4 @@
-"""BcfFormat_symbol_calc_DPv + BcfFormat_symbol_sum_DPv (main.hpp:4253-4906): the oracle's restatement against an independent Python
+"""BcfFormat_symbol_calc_DPv + BcfFormat_symbol_sum_DPv + BcfFormat_symbol_calc_qual (main.hpp:4253-5343): the oracle's restatement against an independent Python
 restatement written from the reference text (tests/score_restatement.py), record by record, on the inputs the oracle itself gathered
 (test hook uvc_oracle_score_trace) -- all-out scoring of fuzzed reads, UMI families, the IonTorrent arm and the normal sample of a T/N
 pair (is_rescued arms).  VERDICT r2 "missing" #2."""
@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from uvc_amd import _ffi, region, synth
-from score_restatement import calc_DPv, sum_DPv
+from score_restatement import calc_DPv, calc_qual, sum_DPv
 from test_gpu_fuzz import weird_region
 from util import run_region
 
@@ -21,17 +21,18 @@ def traced_score(lib, R, all_out=False, tumor_keys=None):
     n = len(rec["refpos"])
     req, _keep = R.make_request(all_out, -1, -1, False, None, tumor_keys, False, False, 0, kept_only=False)
     buf = np.zeros(n * len(names), dtype=np.float64)
+    buf2 = np.zeros(n * 6, dtype=np.float64)
     nv = C.c_int64()
     fn = lib.dll.uvc_oracle_score_trace
-    fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
-    assert fn(R.h, C.byref(req), buf.ctypes.data, buf.size, C.byref(nv)) == 0, lib.last_error()
+    fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]
+    assert fn(R.h, C.byref(req), buf.ctypes.data, buf.size, C.byref(nv), buf2.ctypes.data) == 0, lib.last_error()
     assert nv.value == buf.size, (nv.value, buf.size)
     rows = buf.reshape(n, len(names))
-    return rec, [dict(zip(names, r)) for r in rows]
+    return rec, [dict(zip(names, r)) for r in rows], buf2.reshape(n, 6)
 
 
 def check(lib, R, P, **kw):
-    rec, ins = traced_score(lib, R, **kw)
+    rec, ins, extra = traced_score(lib, R, **kw)
     n = len(ins)
     assert n > 0
     outs = [calc_DPv(d, P) for d in ins]
@@ -62,7 +63,13 @@ def check(lib, R, P, **kw):
         for q in range(i, j):
             for t, k in enumerate(("CDP1v", "CDP1w", "CDP1x", "CDP2v", "CDP2w", "CDP2x")):
                 assert (int(rec[k + "0"][q]), int(rec[k + "1"][q])) == (s1[t], s2[t]), (q, k)
+            # BcfFormat_symbol_calc_qual on top of the restated calc_DPv / sum_DPv results
+            want = calc_qual(ins[q], outs[q], (s1, s2), extra[q], P)
+            got = {k: int(rec[k][q]) for k in want}
+            if got != want:
+                bad.append((q, int(rec["refpos"][q]), int(rec["symbol"][q]), {k: (got[k], want[k]) for k in got if got[k] != want[k]}))
         i = j
+    assert not bad, ("calc_qual", len(bad), n, bad[:4])
     return n
 
 
