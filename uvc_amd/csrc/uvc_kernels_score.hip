@@ -123,16 +123,25 @@ struct Al {   // one allele (index a = 0 everywhere in the reference)
     int cDP1v, cDP1w, cDP1x, cDP2v, cDP2w, cDP2x;
 };
 
-// sum of a plane value over the symbols of the type (integer: any order).  Unrolled over the eight possible symbols with a guard, so that the
-// loads of one sum -- and of the neighbouring sums -- are issued together: as a loop over nsym every load waited for the one before it, and
-// k_score is a chain of dependent loads at less than one wave per SIMD (420 memory round trips per group in group_totals alone).
-#define SUMSYM(expr) ({ long long r_ = 0; const int sb_ = (st == UVC_BASE_SYMBOL ? UVC_BASE_A : UVC_LINK_M); _Pragma("unroll") for (int k_ = 0; k_ < 8; k_++) { if (k_ < nsym) { const int s = sb_ + k_; r_ += (long long)(expr); } } r_; })
+// sum of a plane value over the symbols of the type (integer: any order).  Unrolled over the eight possible symbols; the guard is a SELECT on the
+// loaded value, not a branch around the load (a BASE group loads its last symbol twice more and drops it): with `if (k_ < nsym)` around each
+// load the compiler emitted 332 s_cbranch_execz and a s_waitcnt vmcnt(0) behind every load.
+#define SUMSYM(expr) ({ long long r_ = 0; const int sb_ = (st == UVC_BASE_SYMBOL ? UVC_BASE_A : UVC_LINK_M); _Pragma("unroll") for (int k_ = 0; k_ < 8; k_++) { const int s = sb_ + (k_ < nsym ? k_ : nsym - 1); const long long v_ = (long long)(expr); r_ += (k_ < nsym ? v_ : 0LL); } r_; })
 
-DEV void group_totals(const RegionDev &R, int64_t x, int st, Tot &f) {
+// The plane pointers group_totals reads, by value (members named like RegionDev's so the plane macros work on it).
+struct TotSrc { const int32_t *prep32, *seg32, *vq, *frag, *fam, *faminfo32, *duplex; const int64_t *prep64, *seg64, *faminfo64; int64_t npos; };
+
+// Out of line on purpose: inlined into k_score (512 registers, spilling) the scheduler ran in its register-saving mode and put a
+// s_waitcnt vmcnt(0) behind every pair of these ~440 loads (288 waits).  As its own function -- pointers by value, totals built in
+// registers and stored once, so no store can alias a later load -- the loads go out in batches (78 waits, most of them partial).
+// Measured (1 Mb x 300x tile, 54 k records, kernel alone): 548 -> 470 us.  The kernel stays latency-bound at one wave per SIMD: PMC
+// SQ_WAIT_INST_ANY 34 %, SQ_ACTIVE_INST_ANY 15 % of SQ_WAVE_CYCLES, ~51 k VALU instructions per wave (fp64 divisions and log / exp).
+__device__ __attribute__((noinline)) void group_totals(const TotSrc R, int64_t x, int st, Tot *out) {
+    Tot f;
     const int nsym = st_count(st);
     const int pidx[12] = { UVC_P_a_dp, UVC_P_a_near_ins_dp, UVC_P_a_near_del_dp, UVC_P_a_near_RTR_ins_dp, UVC_P_a_near_RTR_del_dp, UVC_P_a_pcr_dp,
                            UVC_P_a_snv_dp, UVC_P_a_dnv_dp, UVC_P_a_highBQ_dp, UVC_P_a_near_pcr_clip_dp, UVC_P_a_near_long_clip_dp, UVC_P_a_umi_dp };
-    for (int i = 0; i < 12; i++) f.APDP[i] = P32(R, pidx[i], x);
+    _Pragma("unroll") for (int i = 0; i < 12; i++) f.APDP[i] = P32(R, pidx[i], x);
     f.APXM[0] = P32(R, UVC_P_a_XM1500, x); f.APXM[1] = P32(R, UVC_P_a_GO1500, x); f.APXM[2] = P32(R, UVC_P_a_qlen, x); f.APXM[3] = P32(R, UVC_P_a_GAPLEN, x);
     f.APXM[4] = P64(R, UVC_P_a_near_ins_pow2len, x); f.APXM[5] = P64(R, UVC_P_a_near_del_pow2len, x);
     f.APXM[6] = P32(R, UVC_P_a_near_ins_inv100len, x); f.APXM[7] = P32(R, UVC_P_a_near_del_inv100len, x);
@@ -147,7 +156,7 @@ DEV void group_totals(const RegionDev &R, int64_t x, int st, Tot &f) {
     f.ARB20 = (int)SUMSYM(S32(R, UVC_S_aRB2, s, x)); f.ARBL0 = SUMSYM(S64(R, UVC_S64_aRBL, s, x));
     f.ABQ20 = (int)SUMSYM(S32(R, UVC_S_aBQ2, s, x)); f.APF20 = (int)SUMSYM(S32(R, UVC_S_aPF2, s, x));
     f.ALI20 = (int)SUMSYM(S32(R, UVC_S_aLI2, s, x)); f.ARIf0 = (int)SUMSYM(S32(R, UVC_S_aRIf, s, x)); f.ARI20 = (int)SUMSYM(S32(R, UVC_S_aRI2, s, x)); f.ALIr0 = (int)SUMSYM(S32(R, UVC_S_aLIr, s, x));
-    for (int sd = 0; sd < 2; sd++) {
+    _Pragma("unroll") for (int sd = 0; sd < 2; sd++) {
         f.BDPb[sd] = (int)SUMSYM(FRP(R, sd, UVC_FRAG_bDP, s, x)); f.BTAb[sd] = (int)SUMSYM(FRP(R, sd, UVC_FRAG_bTA, s, x)); f.BTBb[sd] = (int)SUMSYM(FRP(R, sd, UVC_FRAG_bTB, s, x));
         f.CDP1b[sd] = (int)SUMSYM(FAP(R, sd, UVC_FAM_cDP1, s, x)); f.CDP12b[sd] = (int)SUMSYM(FAP(R, sd, UVC_FAM_cDP12, s, x));
         f.CDP2b[sd] = (int)SUMSYM(FAP(R, sd, UVC_FAM_cDP2, s, x)); f.CDP3b[sd] = (int)SUMSYM(FAP(R, sd, UVC_FAM_cDP3, s, x));
@@ -156,6 +165,7 @@ DEV void group_totals(const RegionDev &R, int64_t x, int st, Tot &f) {
     f.C2LB20 = (int)SUMSYM(FIP(R, UVC_FI_c2LB2, s, x)); f.C2LBL0 = SUMSYM(FI64P(R, UVC_FI64_c2LBL, s, x)); f.C2RB20 = (int)SUMSYM(FIP(R, UVC_FI_c2RB2, s, x)); f.C2RBL0 = SUMSYM(FI64P(R, UVC_FI64_c2RBL, s, x));
     f.C2BQ20 = (int)SUMSYM(FIP(R, UVC_FI_c2BQ2, s, x)); f.C2LP00 = (int)SUMSYM(FIP(R, UVC_FI_c2LP0, s, x)); f.C2RP00 = (int)SUMSYM(FIP(R, UVC_FI_c2RP0, s, x));
     f.DDP10 = (int)SUMSYM(DUP(R, UVC_DUPLEX_dDP1, s, x));
+    *out = f;
 }
 
 // BcfFormat_symbol_init + fill_symbol_VQ_fmts, main.hpp:4094-4251, 3820-3887
@@ -771,7 +781,8 @@ __global__ void __launch_bounds__(256) k_scan_add(const long long *in, long long
 }
 
 #define SCORE_LPG 2
-__global__ void __launch_bounds__(128) k_score(RegionDev R, UvcParams P, ScoreCtx C) {
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) k_score(RegionDev R, UvcParams P, ScoreCtx C) {
+    __shared__ Tot lds_T[128 / SCORE_LPG];
     const long long ngroups = 2LL * (C.pos_end - C.pos_beg);
     const long long n_active = PK_FLAGS(C.offsets[ngroups]);
     // SCORE_LPG adjacent lanes share one (position, symbol type) group: its records are dealt to them round-robin, the cross-allele sums
@@ -788,8 +799,12 @@ __global__ void __launch_bounds__(128) k_score(RegionDev R, UvcParams P, ScoreCt
     const int refidx = zpos - R.beg, refsize = (int)R.npos - 1;
     const int refsymbol = group_refsymbol(R, zpos, st);
     int32_t *fields = C.fields; const long long capacity = C.capacity;
-    Tot T;
-    group_totals(R, x, st, T);
+    // the symbol-type totals live in LDS, one set per group (the SCORE_LPG lanes of a group compute the same values and store them twice):
+    // as a local struct of k_score they went to scratch memory.
+    Tot &T = lds_T[threadIdx.x / SCORE_LPG];
+    { TotSrc ts; ts.prep32 = R.prep32; ts.seg32 = R.seg32; ts.vq = R.vq; ts.frag = R.frag; ts.fam = R.fam; ts.faminfo32 = R.faminfo32; ts.duplex = R.duplex;
+      ts.prep64 = R.prep64; ts.seg64 = R.seg64; ts.faminfo64 = R.faminfo64; ts.npos = R.npos;
+      group_totals(ts, x, st, &T); }
     const int totBDP = T.BDPb[0] + T.BDPb[1];
     // homopolymer context for minABQ (main.cpp:623-626, 909-928)
     const int prev1 = ((refidx >= 2) ? (int)R.refsym[refidx - 2] : UVC_BASE_NN), prev2 = ((refidx >= 3) ? (int)R.refsym[refidx - 3] : UVC_BASE_NN);
@@ -1189,8 +1204,11 @@ extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const Uv
     hipLaunchKernelGGL(k_scan_local, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, counts, offsets, block_sums, ngroups);
     hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, s, block_sums, nblocks, offsets, ngroups, (long long *)d_count);
     hipLaunchKernelGGL(k_scan_add, dim3((unsigned)((ngroups + 255) / 256)), dim3(256), 0, s, counts, offsets, block_sums, C.active, ngroups);
+    // k_score holds one wave per SIMD (512 registers): 512 blocks of two waves are one wave on every SIMD of the 256 CUs.  The list length lives on
+    // the device; with the default gate most blocks find nothing and leave, with -A (every group active) 512 blocks is the smallest grid
+    // that leaves no SIMD idle (a 200 kb tile asked for 391).
     const long long want_blocks = (ngroups / 16 * SCORE_LPG + 127) / 128;
-    const unsigned grid = (unsigned)(want_blocks < 4096 ? (want_blocks > 0 ? want_blocks : 1) : 4096);
+    const unsigned grid = (unsigned)(want_blocks < 4096 ? (want_blocks > 512 ? want_blocks : 512) : 4096);
     hipLaunchKernelGGL(k_score, dim3(grid), dim3(128), 0, s, *R, *P, C);
     const long long npos_scored = C.pos_end - C.pos_beg;
     hipLaunchKernelGGL(k_call, dim3((unsigned)((npos_scored / 8 + 127) / 128 < 2048 ? (npos_scored / 8 + 127) / 128 + 1 : 2048)), dim3(128), 0, s, *R, *P, C);
