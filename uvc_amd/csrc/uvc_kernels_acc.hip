@@ -3187,45 +3187,70 @@ __global__ void __launch_bounds__(256) k_gap_keys(RegionDev R) {
     R.gap.ckey[i] = key; R.gap.cval[i] = (unsigned long long)i;
 }
 
-__global__ void __launch_bounds__(64) k_gap_alleles(RegionDev R, UvcParams P) {
-    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = R.gap.n_ev;
-    if (i0 >= n) return;
-    const unsigned long long key = R.gap.ckey_s[i0];
-    if (key == ~0ull || (i0 > 0 && R.gap.ckey_s[i0 - 1] == key)) return;   // one thread per (family, position): the head of the run
-    int i1 = i0 + 1;
-    while (i1 < n && R.gap.ckey_s[i1] == key) i1++;
-    const unsigned long long *order = R.gap.cval_s;
-    AlnGap *ev = R.gap.ev;
+// The events of one (family, position) run as k_gap_alleles reads them.  GapEvGlobal: straight from the event array (any run).  GapEvLds: from
+// the block's LDS copy, where every lane has loaded one event and worked out its allele code -- the consensus arithmetic below is O(n^2)
+// in the events of the run and, read from global memory, a chain of thousands of dependent loads for one family of a 2000x panel (one
+// thread's chain was the kernel's whole 2.6 ms).  Runs that leave the block's 128-event window, or hold an insertion longer than 13 bases
+// (hashed code: equality needs the sequences), take the global form.
+struct GapEvL { int32_t sym, aln, weight, mark, id, pad_; unsigned long long code; };
+struct GapEvGlobal {
+    const RegionDev &R; AlnGap *ev; const unsigned long long *order; int i0;
+    DEV int id(int k) const { return (int)order[i0 + k]; }
+    DEV int sym(int k) const { return ev[id(k)].sym; }
+    DEV int aln(int k) const { return ev[id(k)].aln; }
+    DEV int weight(int k) const { return ev[id(k)].weight; }
+    DEV int mark(int k) const { return ev[id(k)].mark; }
+    DEV void set_mark(int k, int v) const { ev[id(k)].mark = v; }
+    DEV bool same(int a, int b) const { return 0 == gap_cmp(R, ev[id(a)], ev[id(b)]); }
+    DEV int cmp(int a, int b) const { return gap_cmp(R, ev[id(a)], ev[id(b)]); }
+    DEV unsigned long long code(int k) const { return gap_code(R, ev[id(k)]); }
+};
+struct GapEvLds {
+    const RegionDev &R; AlnGap *ev; GapEvL *L;
+    DEV int id(int k) const { return L[k].id; }
+    DEV int sym(int k) const { return L[k].sym; }
+    DEV int aln(int k) const { return L[k].aln; }
+    DEV int weight(int k) const { return L[k].weight; }
+    DEV int mark(int k) const { return L[k].mark; }
+    DEV void set_mark(int k, int v) const { L[k].mark = v; }
+    DEV bool same(int a, int b) const { return L[a].code == L[b].code; }   // (callers compare events of one symbol; exact codes only)
+    DEV int cmp(int a, int b) const { return gap_cmp(R, ev[L[a].id], ev[L[b].id]); }   // ties between different alleles: rare
+    DEV unsigned long long code(int k) const { return L[k].code; }
+};
+
+// one (family, position): events [0, nrun) of E, the first of them at sorted index i0
+template <class EV>
+DEV void gap_alleles_run(const RegionDev &R, const UvcParams &P, const EV &E, const int i0, const int nrun) {
     const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
-    const int epos = ev[order[i0]].epos;
+    AlnGap *ev = R.gap.ev;
+    const int epos = ev[E.id(0)].epos;
     const long long x = epos - R.beg;
-    for (int i = i0; i < i1; i++) ev[order[i]].mark = 0;
-    auto emit = [&](int strand, int level, int sym, int e) {
-        const int k = atomicAdd(R.gap.n_inc, 1);
-        if (k >= R.gap.inc_cap) { atomicExch(R.err, UVCGPU_EDEVICE); return; }   // cannot happen: the capacity is 7 per event + 8
-        R.gap.ikey[k] = ((unsigned long long)x << 38) | ((unsigned long long)(sym - UVC_LINK_D3P) << 35) | gap_code(R, ev[e]);
-        R.gap.ival[k] = ((unsigned long long)e << 8) | (unsigned long long)(strand * 4 + level);
+    for (int k = 0; k < nrun; k++) E.set_mark(k, 0);
+    auto emit = [&](int strand, int level, int sym, int k) {
+        const int q = atomicAdd(R.gap.n_inc, 1);
+        if (q >= R.gap.inc_cap) { atomicExch(R.err, UVCGPU_EDEVICE); return; }   // cannot happen: the capacity is 7 per event + 8
+        R.gap.ikey[q] = ((unsigned long long)x << 38) | ((unsigned long long)(sym - UVC_LINK_D3P) << 35) | E.code(k);
+        R.gap.ival[q] = ((unsigned long long)E.id(k) << 8) | (unsigned long long)(strand * 4 + level);
     };
-    // the event among `cand(e)` whose allele has the largest total weight; ties go to the larger allele (indelToData_getMajority, main.hpp:50-63)
+    // the event among `cand(k)` whose allele has the largest total weight; ties go to the larger allele (indelToData_getMajority, main.hpp:50-63)
     auto majority = [&](auto cand, auto weight) -> int {
         int best = -1; long long best_w = 0;
-        for (int i = i0; i < i1; i++) {
-            const int e = (int)order[i];
-            if (!cand(e)) continue;
+        for (int k = 0; k < nrun; k++) {
+            if (!cand(k)) continue;
             long long w = 0;
-            for (int j = i0; j < i1; j++) { const int e2 = (int)order[j]; if (cand(e2) && 0 == gap_cmp(R, ev[e], ev[e2])) w += weight(e2); }
+            for (int j = 0; j < nrun; j++) if (cand(j) && E.same(k, j)) w += weight(j);
             // two steps on purpose: written as one expression `best < 0 || w > best_w || (w == best_w && gap_cmp(...) > 0)` the tie arm was
             // never taken in the code hipcc 7.2 generated at -O3 (found with device printf; tests/test_gpu_indel_alleles.py covers it)
             bool take = (best < 0 || w > best_w);
-            if (!take && w == best_w) { const int c = gap_cmp(R, ev[e], ev[best]); take = (c > 0); }
-            if (take) { best = e; best_w = w; }
+            if (!take && w == best_w) { const int c = E.cmp(k, best); take = (c > 0); }
+            if (take) { best = k; best_w = w; }
         }
         return best;
     };
-    const FsRec u_first = R.fss[R.alns[ev[order[i0]].aln].fs];
+    const int fs_first = R.alns[E.aln(0)].fs;
+    const FsRec u_first = R.fss[fs_first];
     int units[2] = { -1, -1 };
-    units[u_first.strand] = R.alns[ev[order[i0]].aln].fs; units[1 - u_first.strand] = u_first.other_fs;
+    units[u_first.strand] = fs_first; units[1 - u_first.strand] = u_first.other_fs;
     const bool is_duplex_fam = (0x2 == (u_first.dflag & 0x2));
     const bool will_inc_dscs = is_duplex_fam && units[0] >= 0 && units[1] >= 0;
     const bool will_inc_sscs = is_duplex_fam && !will_inc_dscs;
@@ -3246,9 +3271,9 @@ __global__ void __launch_bounds__(64) k_gap_alleles(RegionDev R, UvcParams P) {
             const int adj = imax(cc * 2, ct) - ct;
             if (adj > 0) { con[s][cs] += 1; mmm[s][cs] += adj; }
             if (!(is_ins(cs) || is_del(cs))) continue;
-            const int e = majority([&](int q) { return ev[q].sym == cs && ev[q].aln >= f.aln_beg && ev[q].aln < f.aln_end; }, [&](int q) { return (long long)ev[q].weight; });
+            const int e = majority([&](int q) { return E.sym(q) == cs && E.aln(q) >= f.aln_beg && E.aln(q) < f.aln_end; }, [&](int q) { return (long long)E.weight(q); });
             if (e < 0) { atomicExch(R.err, UVCGPU_EDEVICE); continue; }   // an InDel consensus without an InDel event cannot happen
-            ev[e].mark = 0x10000 | (s << 8) | cs;
+            E.set_mark(e, 0x10000 | (s << 8) | cs);
             emit(s, 0, cs, e);
         }
     }
@@ -3258,16 +3283,16 @@ __global__ void __launch_bounds__(64) k_gap_alleles(RegionDev R, UvcParams P) {
     for (int s = 0; s < 2; s++) {
         if (units[s] < 0) continue;
         const FsRec u = R.fss[units[s]];
-        auto unit_allele = [&](int sym) { return majority([&](int q) { return ev[q].mark == (0x10000 | (s << 8) | sym); }, [&](int q) { return 1LL; }); };
+        auto unit_allele = [&](int sym) { return majority([&](int q) { return E.mark(q) == (0x10000 | (s << 8) | sym); }, [&](int q) { return 1LL; }); };
         {   // the count read_family_con_ampl_getMajority_ins returns: the inserted sequence most fragments of the unit agree on, over all three
             // insertion symbols (main.hpp:188-198); the FAM2 position-bias test of the family kernels reads it (main.hpp:3239-3246)
             // (the map is fed by every fragment whose consensus is an insertion symbol, main.hpp:1670-1676: the marked events of the unit)
             int m = 0;
-            for (int i = i0; i < i1; i++) {
-                const int e = (int)order[i];
-                if ((ev[e].mark >> 8) != (0x100 | s) || !is_ins(ev[e].mark & 0xFF)) continue;
+            for (int k = 0; k < nrun; k++) {
+                const int mk = E.mark(k);
+                if ((mk >> 8) != (0x100 | s) || !is_ins(mk & 0xFF)) continue;
                 int w = 0;
-                for (int j = i0; j < i1; j++) { const int e2 = (int)order[j]; if (ev[e2].mark == ev[e].mark && 0 == gap_cmp(R, ev[e], ev[e2])) w++; }
+                for (int j = 0; j < nrun; j++) if (E.mark(j) == mk && E.same(k, j)) w++;
                 m = imax(m, w);
             }
             R.gap.maj[2 * i0 + s] = m;
@@ -3306,7 +3331,7 @@ __global__ void __launch_bounds__(64) k_gap_alleles(RegionDev R, UvcParams P) {
         if (1 < ct && (is_ins(cs) || is_del(cs))) {
             int e = -1;
             const bool h0 = (dup_sym[0] == cs && dup_allele[0] >= 0), h1 = (dup_sym[1] == cs && dup_allele[1] >= 0);
-            if (h0 && h1) e = (gap_cmp(R, ev[dup_allele[0]], ev[dup_allele[1]]) >= 0 ? dup_allele[0] : dup_allele[1]);
+            if (h0 && h1) e = (E.cmp(dup_allele[0], dup_allele[1]) >= 0 ? dup_allele[0] : dup_allele[1]);
             else if (h0) e = dup_allele[0];
             else if (h1) e = dup_allele[1];
             if (e < 0) atomicExch(R.err, UVCGPU_EDEVICE);
@@ -3315,17 +3340,62 @@ __global__ void __launch_bounds__(64) k_gap_alleles(RegionDev R, UvcParams P) {
     }
 }
 
-// one thread per run of equal (position, symbol, allele) keys of the sorted increments
+#define GAP_WIN 128
+__global__ void __launch_bounds__(64) k_gap_alleles(RegionDev R, UvcParams P) {
+    __shared__ GapEvL arena[GAP_WIN];
+    const int n = R.gap.n_ev, b0 = blockIdx.x * 64, lane = threadIdx.x;
+    const unsigned long long *order = R.gap.cval_s;
+    AlnGap *ev = R.gap.ev;
+    // every lane brings two events of the block's window into LDS, with their allele codes
+    for (int h = 0; h < GAP_WIN / 64; h++) {
+        const int i = b0 + h * 64 + lane;
+        GapEvL g; g.sym = -1; g.aln = 0; g.weight = 0; g.mark = 0; g.id = 0; g.pad_ = 0; g.code = 0;
+        if (i < n && R.gap.ckey_s[i] != ~0ull) {
+            const int e = (int)order[i];
+            const AlnGap a = ev[e];
+            g.sym = a.sym; g.aln = a.aln; g.weight = a.weight; g.id = e; g.code = gap_code(R, a);
+        }
+        arena[h * 64 + lane] = g;
+    }
+    __syncthreads();
+    const int i0 = b0 + lane;
+    if (i0 >= n) return;
+    const unsigned long long key = R.gap.ckey_s[i0];
+    if (key == ~0ull || (i0 > 0 && R.gap.ckey_s[i0 - 1] == key)) return;   // one thread per (family, position): the head of the run
+    int i1 = i0 + 1;
+    while (i1 < n && R.gap.ckey_s[i1] == key) i1++;
+    bool in_lds = (i1 - b0 <= GAP_WIN);
+    for (int i = i0; in_lds && i < i1; i++) if ((arena[i - b0].code >> 34) & 1ull) in_lds = false;   // (an insertion of more than 13 bases)
+    if (in_lds) { const GapEvLds E{ R, ev, arena + lane }; gap_alleles_run(R, P, E, i0, i1 - i0); }
+    else { const GapEvGlobal E{ R, ev, order, i0 }; gap_alleles_run(R, P, E, i0, i1 - i0); }
+}
+
+// The sorted increments -> one GapRow per (position, symbol, allele).  At 2000x a site's allele has thousands of increments, so a run is
+// not summed by one thread: k_gap_rows opens a row per run (the head of the run), k_gap_rows_add lets every increment find its run's head
+// (binary search in the sorted keys) and add itself to the row's counters, k_gap_rows_fin fills in the allele of each row from its
+// representative event (the smallest event index of the run).  `run_row` (the unsorted key array, free once the sort has run) holds the
+// row of each run at the index of its head.
 __global__ void __launch_bounds__(256) k_gap_rows(RegionDev R) {
     const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = imin(*R.gap.n_inc, R.gap.inc_cap);
     if (i0 >= n) return;
     const unsigned long long key = R.gap.ikey_s[i0];
     if (i0 > 0 && R.gap.ikey_s[i0 - 1] == key) return;
+    int32_t *run_row = (int32_t *)R.gap.ikey;
+    const bool hashed = ((key >> 34) & 1ull) != 0;
+    if (!hashed) {   // exact codes: the whole run is one row
+        const int r = atomicAdd(R.gap.n_rows, 1);
+        GapRow row;
+        for (int k = 0; k < 8; k++) row.cnt[k] = 0;
+        row.x = (int)(key >> 38); row.sym = -1; row.len = 0; row.ev = INT32_MAX; row.seq_off = -1;
+        R.gap.rows[r] = row;
+        run_row[i0] = r;
+        return;
+    }
     // The allele code of an insertion longer than 13 bases is a hash: equal keys need not be equal sequences.  Such a run is split by
     // comparing the sequences themselves (one pass when they all agree, which is the case unless two long insertions of one site collide
-    // in 34 bits); bit 63 of a value marks an increment that has found its row.
-    const bool hashed = ((key >> 34) & 1ull) != 0;
+    // in 34 bits); bit 63 of a value marks an increment that has found its row.  Long insertions are rare: this thread does the run alone.
+    run_row[i0] = -1;
     int i1 = i0;
     while (i1 < n && R.gap.ikey_s[i1] == key) i1++;
     for (int ib = i0; ib < i1; ib++) {
@@ -3337,23 +3407,41 @@ __global__ void __launch_bounds__(256) k_gap_rows(RegionDev R) {
         for (int i = ib; i < i1; i++) {
             const unsigned long long v = R.gap.ival_s[i];
             if (v >> 63) continue;
-            if (hashed && i != ib && 0 != gap_cmp(R, first, R.gap.ev[(int)(v >> 8)])) continue;   // another sequence under the same hash: a later row
+            if (i != ib && 0 != gap_cmp(R, first, R.gap.ev[(int)(v >> 8)])) continue;   // another sequence under the same hash: a later row
             row.cnt[v & 0xFF] += 1;
             rep = imin(rep, (int)(v >> 8));
             R.gap.ival_s[i] = v | (1ull << 63);
         }
-        const AlnGap e = R.gap.ev[rep];
-        row.x = (int)(key >> 38); row.sym = e.sym; row.len = e.len; row.ev = rep; row.seq_off = -1;
-        if (is_ins(e.sym)) {
-            const long long off = (long long)atomicAdd(R.gap.seq_len, (unsigned long long)e.len);
-            if (off + e.len <= R.gap.seq_cap) {
-                const uint8_t *src = R.bases + R.alns[e.aln].seq_off + e.qpos;
-                for (int k = 0; k < e.len; k++) R.gap.seq[off + k] = src[k];
-                row.seq_off = off;
-            } else atomicExch(R.err, UVCGPU_EDEVICE);
-        }
+        row.x = (int)(key >> 38); row.sym = -1; row.len = 0; row.ev = rep; row.seq_off = -1;
         R.gap.rows[atomicAdd(R.gap.n_rows, 1)] = row;
-        if (!hashed) break;   // exact codes: the whole run is one row
+    }
+}
+__global__ void __launch_bounds__(256) k_gap_rows_add(RegionDev R) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = imin(*R.gap.n_inc, R.gap.inc_cap);
+    if (i >= n) return;
+    const unsigned long long key = R.gap.ikey_s[i];
+    if ((key >> 34) & 1ull) return;   // hashed alleles: done by the head of the run
+    int lo = 0, hi = i;   // first index with this key
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (R.gap.ikey_s[mid] < key) lo = mid + 1; else hi = mid; }
+    const int r = ((const int32_t *)R.gap.ikey)[lo];
+    const unsigned long long v = R.gap.ival_s[i];
+    atomicAdd(&R.gap.rows[r].cnt[v & 0xFF], 1);
+    atomicMin(&R.gap.rows[r].ev, (int)(v >> 8));
+}
+__global__ void __launch_bounds__(256) k_gap_rows_fin(RegionDev R) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= *R.gap.n_rows) return;
+    GapRow &row = R.gap.rows[r];
+    const AlnGap e = R.gap.ev[row.ev];
+    row.sym = e.sym; row.len = e.len;
+    if (is_ins(e.sym)) {
+        const long long off = (long long)atomicAdd(R.gap.seq_len, (unsigned long long)e.len);
+        if (off + e.len <= R.gap.seq_cap) {
+            const uint8_t *src = R.bases + R.alns[e.aln].seq_off + e.qpos;
+            for (int k = 0; k < e.len; k++) R.gap.seq[off + k] = src[k];
+            row.seq_off = off;
+        } else atomicExch(R.err, UVCGPU_EDEVICE);
     }
 }
 
@@ -3664,6 +3752,8 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
             if (side) hipEventRecord(e_alleles, s);   // what the family kernels read of this chain (fam2_ins_len) is complete here
             uvc_gap_sort(G.sort_tmp, G.sort_tmp_bytes, G.ikey, G.ikey_s, G.ival, G.ival_s, (size_t)G.inc_cap, 64, s);
             hipLaunchKernelGGL(k_gap_rows, dim3(nblk(G.inc_cap, 256)), dim3(256), 0, s, *R);
+            hipLaunchKernelGGL(k_gap_rows_add, dim3(nblk(G.inc_cap, 256)), dim3(256), 0, s, *R);
+            hipLaunchKernelGGL(k_gap_rows_fin, dim3(nblk(G.n_ev, 256)), dim3(256), 0, s, *R);   // (rows <= events)
         });
     }
     if (side && !(P->inferred_is_vcf_generated && G.n_ev > 0)) hipEventRecord(e_alleles, s2);
