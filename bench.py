@@ -364,7 +364,31 @@ def main():
     input_bytes_tile = int(np.mean([sum(int(np.asarray(t[k]).nbytes) for k in COLS if t.get(k) is not None) for t in tiles]))
     prepare, finish, kernel_times = leg.prepare, leg.finish, leg.kernel_times
 
+    # UVC_BENCH_VALUE_THREADS=n: the timed stream dealt to n host threads (one tile each at a time) instead of the one-thread software pipeline.
+    # One host thread issues ~400 launches per tile (reset, read preparation with three count read-backs, accumulate, scoring) and waits in the
+    # preparation's read-backs while the device runs out of work: four threads make the device the bound (10.5 -> 9.7 ms per tile).  The default
+    # stays the one-thread pipeline because `roofline` divides by the dominant kernel's own duration on its stream, and with four tiles' kernels
+    # sharing the device that duration says little about the kernel; the four-thread rate is reported beside it as `resident_in_flight4`.
+    n_thr_value = max(1, min(int(os.environ.get("UVC_BENCH_VALUE_THREADS", "1")), T))
+    def run_in_flight(k0, n_steps, n_thr, host=False, ktimes=None):
+        import threading
+        locks = [threading.Lock() for _ in range(T)]
+        out = [0]
+        def work(w):
+            lib.dll.uvcgpu_init(local_rank)                      # hipSetDevice is per host thread
+            for k in range(k0 + w, k0 + n_steps, n_thr):
+                with locks[k % T]:                               # a handle serves one tile at a time
+                    prepare(k, host); out[0] = len(finish(k)["refpos"])
+                    if ktimes is not None:
+                        kernel_times(leg.Rs[k % T], ktimes)
+        th = [threading.Thread(target=work, args=(w,)) for w in range(n_thr)]
+        for t in th: t.start()
+        for t in th: t.join()
+        return out[0]
+
     def run_stream(k0, n_steps, host=False, ktimes=None):
+        if n_thr_value > 1 and not args.serial:
+            return run_in_flight(k0, n_steps, n_thr_value, host=host, ktimes=ktimes)
         return leg.run_stream(k0, n_steps, host=host, ktimes=ktimes, serial=args.serial)
 
     run_stream(0, T)              # untimed priming: every handle once (its first set_reads sizes the cached device blocks, its first score page-locks its records buffer)
@@ -380,7 +404,17 @@ def main():
     dt_min = clock.min_over_ranks(own_dt)
     total_positions = clock.sum_over_ranks(float(region_len)) * args.steps
 
-    pcie = resident = None
+    pcie = resident = in_flight4 = None
+    if not args.no_extras and not args.serial and T >= 4:
+        # (0) the timed stream again with four tiles in flight on four host threads (inputs resident, same step)
+        nf = max(8, min(args.steps, 2 * T))
+        run_in_flight(0, 4, 4)
+        torch.cuda.synchronize(); clock.barrier(); ts = time.perf_counter()
+        run_in_flight(4, nf, 4)
+        torch.cuda.synchronize(); clock.barrier(); fdt = clock.max_over_ranks(time.perf_counter() - ts)
+        in_flight4 = {"value": clock.sum_over_ranks(float(region_len)) * nf / fdt, "unit": "positions/s", "ms_per_step": 1e3 * fdt / nf, "steps": nf, "tiles_in_flight": 4,
+                      "note": "the step of `value` (inputs resident in HBM), the tiles dealt to four host threads as uvc1-mi355x deals them to its workers: the host's launch and read-back "
+                              "time of one tile hides under the other tiles' kernels; whole-job aggregate over all ranks, measured behind the timed region"}
     if not args.no_extras:
         # (1) the same stream with the columns in pinned host memory: H2D of every column inside the step
         # the columns move into page-locked memory of the library's own (uvcgpu_host_alloc = hipHostMalloc): a numpy array page-locked in place
@@ -479,8 +513,8 @@ def main():
                                    "family/fragment nesting, radix orders, k_aln_prelude, k_build_p2list) + accumulate P1..P5b + "
                                    "default-gate scoring / calling + D2H of %s%s" % (T, "duplex-UMI" if args.umi else "non-UMI", args.tile_kb, args.depth,
                                    "every scored record" if args.all_records else "the record groups the VCF writer reads (kept_only: written records + the REF / genotype records of their positions)",
-                                   "; tiles strictly one after the other" if args.serial else "; tiles software-pipelined over their handles (tile k+1 is prepared and accumulating while tile k is scored)"),
-                       "tile_positions": region_len, "distinct_tiles": T, "pipelined": (not args.serial) and T >= 2, "all_out": bool(args.all_out), "umi": bool(args.umi), "reads_per_tile": n_reads_tile,
+                                   "; tiles strictly one after the other" if args.serial else ("; %d tiles in flight, one host thread each, every tile on its own handle" % n_thr_value if n_thr_value > 1 else "; tiles software-pipelined over their handles (tile k+1 is prepared and accumulating while tile k is scored)")),
+                       "tile_positions": region_len, "distinct_tiles": T, "pipelined": (not args.serial) and T >= 2, "tiles_in_flight": (1 if args.serial else (n_thr_value if n_thr_value > 1 else 2)), "all_out": bool(args.all_out), "umi": bool(args.umi), "reads_per_tile": n_reads_tile,
                        "read_bases_per_tile": n_reads_tile * READ_LEN, "input_bytes_per_tile": input_bytes_tile, "returned_records_last_tile": n_rec, "kept_only": not args.all_records,
                        "parallelism": "region-shard x%d (no collective on the data path)" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -495,6 +529,8 @@ def main():
         if score_ms:
             out["roofline_score"] = score_roofline(score_ms, npos_tile, scored_main, args.all_out)
         out.update(side_out)
+        if in_flight4:
+            out["resident_in_flight4"] = in_flight4
         if pcie:
             out["pcie_inclusive"] = pcie
         if resident:

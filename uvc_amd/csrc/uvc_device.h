@@ -155,8 +155,8 @@ struct RegionDev {
     const uint8_t *bases; const uint8_t *quals; const uint32_t *cigars;
     const uint16_t *bq; uint32_t bq_bytes;   // base | qual << 8 per read base: one bounds-checked buffer load per (alignment, position)
     AlnRec *alns; int32_t n_alns;
-    AlnRec *fast; int32_t n_fast;   // simple alignments, sorted by pos
-    FastRec *frec;                  // [n_fast] digest of fast[]
+    int32_t n_fast;                 // number of simple alignments
+    FastRec *frec;                  // [n_fast] their digests, sorted by pos (FastRec::aln: the index into alns[])
     int32_t p2_off[5];              // frec2 is four pos-sorted sub-lists [p2_off[c], p2_off[c + 1]), c = is-reverse | bam_get_strand << 1
     FastRec *frec2; int32_t n_fast2; int32_t max_p2_span;   // P2 work list, sorted by (class, pos): simple alignments + the M runs of InDel reads whose
                                     // InDels are all high-quality (kind 2), which behave like simple alignments in P2 (see k_p2_fast)

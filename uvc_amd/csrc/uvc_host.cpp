@@ -27,7 +27,7 @@ struct RawReads {
 };
 extern "C" void uvc_launch_correct_bq(const RegionDev *R, int bq_max, int bq_inc, hipStream_t s);
 extern "C" void uvc_launch_pack_bq(const uint8_t *bases, const uint8_t *quals, uint16_t *bq, int64_t n, hipStream_t s);
-extern "C" void uvc_launch_build_p2list(const RegionDev *R, const int32_t *aln, const int32_t *cbeg, const int32_t *cend, const int32_t *qb, hipStream_t s);
+extern "C" void uvc_launch_build_p2list(const RegionDev *R, const int32_t *fast_rank, const int32_t *aln, const int32_t *cbeg, const int32_t *cend, const int32_t *qb, hipStream_t s);
 extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const UvcParams *P, hipStream_t s);
 struct UvcProf { int on; int n; const char *name[32]; hipEvent_t ev[32][2]; };
 extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, int half_ratio_phred,
@@ -358,7 +358,7 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
     else { uint16_t *b = nullptr; if ((rc = dev_alloc(r, (size_t)std::max<int64_t>(d->n_bases, 1), &b))) return rc; R.bq = b; R.bq_bytes = (uint32_t)(d->n_bases * 2);
       uvc_launch_pack_bq(R.bases, R.quals, b, d->n_bases, r->stream); }
     { AlnRec *a; if ((rc = dev_alloc(r, (size_t)n, &a))) return rc; R.alns = a; R.n_alns = (int32_t)n; }
-    { AlnRec *a; if ((rc = dev_alloc(r, (size_t)n_simple, &a))) return rc; R.fast = a; R.n_fast = (int32_t)n_simple; }
+    R.n_fast = (int32_t)n_simple;
     { FastRec *f; if ((rc = dev_alloc(r, (size_t)n_simple, &f))) return rc; R.frec = f; }
     R.complex_ids = o.complex_ids; R.n_complex = o.n_complex;
     R.frags = o.frags; R.n_frags = o.n_frags;
@@ -434,7 +434,7 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
         if (uvc_sort_by_pos_cls(o.p2_beg, o.p2_cls, r->beg, pos_bits, 2, (int64_t)np2, work, tmp, tmp_bytes, r->stream) != 0) return fail(UVCGPU_EDEVICE, "device sort of the P2 work list failed");
         uvc_launch_gather4(work + 3 * np2, (int64_t)np2, o.p2_aln, o.p2_beg, o.p2_end, o.p2_qb, r->d_p2[0], r->d_p2[1], r->d_p2[2], r->d_p2[3], r->stream);
         { FastRec *f; if ((rc = dev_alloc(r, np2, &f))) return rc; R.frec2 = f; R.n_fast2 = (int32_t)np2; R.max_p2_span = o.max_p2_span; }
-        uvc_launch_build_p2list(&R, r->d_p2[0], r->d_p2[1], r->d_p2[2], r->d_p2[3], r->stream);
+        uvc_launch_build_p2list(&R, W.fast_rank, r->d_p2[0], r->d_p2[1], r->d_p2[2], r->d_p2[3], r->stream);
     }
     HIP_OK(hipGetLastError());
     {   // the queue of mismatching bases (k_p2_fast -> k_p2_mism) is sized from the count the prelude made
@@ -518,7 +518,7 @@ static int uvcgpu_region_correct_bq_impl(uvcgpu_region_t *r) {
     uvc_launch_pack_bq(r->R.bases, r->R.quals, (uint16_t *)r->R.bq, r->n_bases, r->stream);
     HIP_OK(hipMemsetAsync(r->R.mis_total, 0, sizeof(unsigned long long), r->stream));
     uvc_launch_prelude(&r->R, &r->W, &r->P, r->stream);
-    uvc_launch_build_p2list(&r->R, r->d_p2[0], r->d_p2[1], r->d_p2[2], r->d_p2[3], r->stream);
+    uvc_launch_build_p2list(&r->R, r->W.fast_rank, r->d_p2[0], r->d_p2[1], r->d_p2[2], r->d_p2[3], r->stream);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(r->stream));
     r->accumulated = false;

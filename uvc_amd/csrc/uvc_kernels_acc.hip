@@ -395,14 +395,23 @@ DEV void fill_fastrec(FastRec &f, const AlnRec &a, int id, int cbeg, int cend, i
     f.ext = ((cbeg - a.pos) & 0xFFFF) | ((a.rend - cend) << 16);
 }
 
-// P2 work list: entry j covers [cbeg[j], cend[j]) of alignment aln[j] (host-sorted by cbeg)
-__global__ void __launch_bounds__(256) k_build_p2list(RegionDev R, const int32_t *aln, const int32_t *cbeg, const int32_t *cend, const int32_t *qb) {
+// P2 work list: entry j covers [cbeg[j], cend[j]) of alignment aln[j] (sorted by (class, cbeg)).  The entry of a simple alignment is the
+// record k_aln_prelude already made for the P1 list (frec, the same alignment under its rank there): 64 bytes copied instead of the
+// alignment's 200-byte record read again; only the M runs of InDel reads are built from their alignment records.
+__global__ void __launch_bounds__(256) k_build_p2list(RegionDev R, const int32_t *fast_rank, const int32_t *aln, const int32_t *cbeg, const int32_t *cend, const int32_t *qb) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= R.n_fast2) return;
+    const int id = aln[j], rk = fast_rank[id];
+    if (rk >= 0) {
+        const uint4 *src = (const uint4 *)&R.frec[rk]; uint4 *dst = (uint4 *)&R.frec2[j];
+        const uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+        dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
+        return;
+    }
     FastRec f;
-    const AlnRec &a = R.alns[aln[j]];
+    const AlnRec &a = R.alns[id];
     // an InDel read that k_aln_prelude found ineligible keeps its slot (the list stays sorted) but covers nothing
-    fill_fastrec(f, a, aln[j], cbeg[j], (a.kind == 1 ? cbeg[j] : cend[j]), qb[j]);
+    fill_fastrec(f, a, id, cbeg[j], (a.kind == 1 ? cbeg[j] : cend[j]), qb[j]);
     R.frec2[j] = f;
 }
 
@@ -437,7 +446,7 @@ __global__ void __launch_bounds__(256) k_aln_bm(RegionDev R, RawReads W) {
 }
 
 // the prelude of one alignment; returns the number of its bases that go through the mismatch queue of k_p2_fast
-DEV int aln_prelude_one(const RegionDev &R, const RawReads &W, const UvcParams &P, const int id) {
+DEV int aln_prelude_one(const RegionDev &R, const RawReads &W, const UvcParams &P, const int id, AlnRec &out) {
     AlnRec a;
     a.pos = W.pos[id]; a.rend = W.endpos[id]; a.mpos = W.mpos[id]; a.isize = W.isize[id]; a.flag = W.flag[id]; a.mapq = W.mapq[id];
     a.dflag = W.dflag[id]; a.l_qseq = W.l_qseq[id]; a.seq_off = W.seq_off[id]; a.cigar_off = W.cigar_off[id]; a.table_off = W.table_off[id]; a.item_off = W.item_off[id]; a.gap_off = W.gap_off[id];
@@ -495,25 +504,36 @@ DEV int aln_prelude_one(const RegionDev &R, const RawReads &W, const UvcParams &
     a.qbase = a.seq_off + lclip_q - a.pos;
     a.baq_pos = BAQ1(R, a.pos); a.baq_last = BAQ1(R, a.rend - 1); a.baq2_last = BAQ2(R, a.rend - 1);
     if (a.kind == 2 && has_lowbq_indel(P, a, cigar, R.quals + a.seq_off)) a.kind = 1;
-    R.alns[id] = a;
     const int rk = W.fast_rank[id];
     int n_mis = 0;
     a.n_mutc = bm[0] + bm[1] + bm[2] + bm[3] + bm[4] + ngo;
-    R.alns[id].n_mutc = a.n_mutc;
+    out = a;
     if (rk >= 0 || W.kind[id] == 2) n_mis = bm[0] + bm[1] + bm[2] + bm[3] + bm[4];   // every alignment that can be on the P2 work list: its mismatching bases go through the mismatch queue
     if (rk >= 0) {
-        R.fast[rk] = a;
         FastRec f;
         fill_fastrec(f, a, id, a.pos, a.rend, (int32_t)(a.qbase & 0xFFFFFFFFLL));
         R.frec[rk] = f;
     }
     return n_mis;
 }
+// One thread per alignment.  The 200-byte records leave through LDS: written from registers, a lane's record is 25 stores that each touch 64
+// cache lines of the wave; the block's 256 records are one contiguous 51 200-byte span of alns[] and are copied out with coalesced 16-byte stores.
 __global__ void __launch_bounds__(256) k_aln_prelude(RegionDev R, RawReads W, UvcParams P) {
-    const int id = blockIdx.x * blockDim.x + threadIdx.x;
-    int n_mis = (id < R.n_alns) ? aln_prelude_one(R, W, P, id) : 0;
+    static_assert(sizeof(AlnRec) % 8 == 0 && (256 * sizeof(AlnRec)) % 16 == 0, "the staged copy moves the block's records as 16-byte words");
+    __shared__ __attribute__((aligned(16))) AlnRec stage[256];
+    const int id0 = blockIdx.x * blockDim.x, id = id0 + threadIdx.x;
+    int n_mis = (id < R.n_alns) ? aln_prelude_one(R, W, P, id, stage[threadIdx.x]) : 0;
     for (int d = 32; d > 0; d >>= 1) n_mis += __shfl_xor(n_mis, d);   // one atomic per wave: same-address atomics of every read serialise
     if ((threadIdx.x & 63) == 0 && n_mis) atomicAdd(R.mis_total, (unsigned long long)n_mis);
+    __syncthreads();
+    const int nrec = imin(256, R.n_alns - id0);
+    if (nrec == 256) {
+        const uint4 *src = (const uint4 *)&stage[0]; uint4 *dst = (uint4 *)(R.alns + id0);
+        for (int i = threadIdx.x; i < (int)(256 * sizeof(AlnRec) / 16); i += 256) dst[i] = src[i];
+    } else {
+        const unsigned long long *src = (const unsigned long long *)&stage[0]; unsigned long long *dst = (unsigned long long *)(R.alns + id0);
+        for (int i = threadIdx.x; i < nrec * (int)(sizeof(AlnRec) / 8); i += 256) dst[i] = src[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -703,7 +723,7 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
     auto drain = [&]() {
         for (int i = lane; i < nq; i += 64) {
             const int2 e = myq[i];
-            const AlnRec &a = R.fast[e.x];
+            const AlnRec &a = R.alns[e.x];
             snv_dnv_scatter(R, R.bases + a.seq_off, (int)(a.qbase + e.y - a.seq_off), a.l_qseq, a.pos, a.rend, e.y);
             mut_event(R, P, a, e.y, R.refsym[e.y - R.beg]);
         }
@@ -727,7 +747,7 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
             const wmask mm = BAL(cover && b != my_ref);
             if (mm) {
                 if (nq > PREPQ_CAP - 64) drain();
-                if (cover && b != my_ref) myq[nq + (int)__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = make_int2(k0 + j, p);
+                if (cover && b != my_ref) myq[nq + (int)__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = make_int2(bcast(c.v[3], j), p);   // (FastRec::aln, position)
                 nq += (int)__builtin_popcountll(mm);
             }
             if (cover) {   // (the counters that do not look at the base: k_prep_sums)
@@ -3666,8 +3686,8 @@ extern "C" void uvc_launch_pack_bq(const uint8_t *bases, const uint8_t *quals, u
     if (aligned) hipLaunchKernelGGL(k_pack_bq, dim3((unsigned)std::min<int64_t>(((n >> 3) + 255) / 256 + 1, 16384)), dim3(256), 0, s, bases, quals, bq, n);
     else hipLaunchKernelGGL(k_pack_bq1, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65536)), dim3(256), 0, s, bases, quals, bq, n);
 }
-extern "C" void uvc_launch_build_p2list(const RegionDev *R, const int32_t *aln, const int32_t *cbeg, const int32_t *cend, const int32_t *qb, hipStream_t s) {
-    if (R->n_fast2) hipLaunchKernelGGL(k_build_p2list, dim3(nblk(R->n_fast2, 256)), dim3(256), 0, s, *R, aln, cbeg, cend, qb);
+extern "C" void uvc_launch_build_p2list(const RegionDev *R, const int32_t *fast_rank, const int32_t *aln, const int32_t *cbeg, const int32_t *cend, const int32_t *qb, hipStream_t s) {
+    if (R->n_fast2) hipLaunchKernelGGL(k_build_p2list, dim3(nblk(R->n_fast2, 256)), dim3(256), 0, s, *R, fast_rank, aln, cbeg, cend, qb);
 }
 extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const UvcParams *P, hipStream_t s) {
     if (R->n_alns && R->n_fast) hipLaunchKernelGGL(k_aln_bm, dim3(imin_h((int)nblk(R->n_alns, 256), 16384)), dim3(256), 0, s, *R, *W);
