@@ -415,33 +415,41 @@ __global__ void __launch_bounds__(256) k_build_p2list(RegionDev R, const int32_t
     R.frec2[j] = f;
 }
 
-// Mismatching bases per base symbol (bm1500s, main.hpp:1860-1863) of the simple alignments.  A lane per alignment, eight bases per step:
-// read bases and reference codes are bytes below 0x80, so "differs" and "is symbol s" are byte-parallel tests on two 8-byte words (unaligned
-// loads: the hardware takes them) and a count is a popcount.  40 lane instructions per 8 bases against 25 wave instructions per 64 bases of
-// the wave-per-alignment form it replaces (0.59 ms per 2 M reads; one thread per alignment walking byte by byte was 2.0 ms).  The five
-// counts wait in the alignment's own FastRec slot.
+// Mismatching bases per base symbol (bm1500s, main.hpp:1860-1863) of the simple alignments.  Eight lanes per alignment, eight bases per lane
+// and step: read bases and reference codes are bytes below 0x80, so "differs" and "is symbol s" are byte-parallel tests on two 8-byte words
+// (unaligned loads: the hardware takes them) and a count is a popcount.  The eight lanes of an alignment read 64 consecutive bytes, so a
+// load of the wave touches eight cache lines; with a lane per alignment it touched 64 (8 bytes of each, 150 bytes apart) and the kernel was
+// bound by the L2 -> L1 traffic of lines read sixteen times over (0.39 ms per 2 M reads; a wave per alignment was 0.59 ms, a thread per
+// alignment walking byte by byte 2.0 ms).  The five counts wait in the alignment's own FastRec slot.
 DEV unsigned long long load8u(const uint8_t *p) { unsigned long long v; __builtin_memcpy(&v, p, 8); return v; }
 __global__ void __launch_bounds__(256) k_aln_bm(RegionDev R, RawReads W) {
     const unsigned long long K7F = 0x7F7F7F7F7F7F7F7FULL, K80 = 0x8080808080808080ULL, K01 = 0x0101010101010101ULL;
-    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < R.n_alns; id += gridDim.x * blockDim.x) {
+    const int sub = threadIdx.x & 7;
+    for (int id = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; id < R.n_alns; id += (gridDim.x * blockDim.x) >> 3) {
         const int rk = W.fast_rank[id];
-        if (rk < 0) continue;
+        if (rk < 0) continue;   // (the eight lanes of the alignment leave together)
         const int pos = W.pos[id], len = W.endpos[id] - pos;
         const uint32_t c0 = R.cigars[W.cigar_off[id]];
         const uint8_t *b = R.bases + W.seq_off[id] + (cig_op(c0) == C_SOFT_CLIP ? cig_len(c0) : 0);
         const uint8_t *rf = R.refsym + (pos - R.beg);
         int cnt[5] = { 0, 0, 0, 0, 0 };
-        int k = 0;
-        for (; k + 8 <= len; k += 8) {
+        for (int k = 8 * sub; k + 8 <= len; k += 64) {
             const unsigned long long bb = load8u(b + k), rr = load8u(rf + k);
             const unsigned long long mism = ((bb ^ rr) + K7F) & K80;          // 0x80 in every byte that differs (all bytes are < 0x80)
 #pragma unroll
             for (int s2 = 0; s2 < 5; s2++) cnt[s2] += __popcll(mism & ~((bb ^ (K01 * (unsigned)s2)) + K7F) & K80);
         }
-        for (; k < len; k++) { const int bs = b[k]; if (bs != rf[k] && bs < 5) cnt[bs] += 1; }
-        int32_t *dst = (int32_t *)&R.frec[rk];
+        { const int k = (len & ~7) + sub;   // the last len % 8 bases, one per lane
+          if (k < len) { const int bs = b[k]; const bool mm = (bs != rf[k]);
 #pragma unroll
-        for (int s2 = 0; s2 < 5; s2++) dst[s2] = cnt[s2];
+                         for (int s2 = 0; s2 < 5; s2++) cnt[s2] += (mm && bs == s2); } }
+#pragma unroll
+        for (int s2 = 0; s2 < 5; s2++) { cnt[s2] += __shfl_xor(cnt[s2], 1); cnt[s2] += __shfl_xor(cnt[s2], 2); cnt[s2] += __shfl_xor(cnt[s2], 4); }
+        if (sub == 0) {
+            int32_t *dst = (int32_t *)&R.frec[rk];
+#pragma unroll
+            for (int s2 = 0; s2 < 5; s2++) dst[s2] = cnt[s2];
+        }
     }
 }
 
@@ -522,10 +530,12 @@ __global__ void __launch_bounds__(256) k_aln_prelude(RegionDev R, RawReads W, Uv
     static_assert(sizeof(AlnRec) % 8 == 0 && (256 * sizeof(AlnRec)) % 16 == 0, "the staged copy moves the block's records as 16-byte words");
     __shared__ __attribute__((aligned(16))) AlnRec stage[256];
     const int id0 = blockIdx.x * blockDim.x, id = id0 + threadIdx.x;
+    __shared__ int mis_s[4];
     int n_mis = (id < R.n_alns) ? aln_prelude_one(R, W, P, id, stage[threadIdx.x]) : 0;
-    for (int d = 32; d > 0; d >>= 1) n_mis += __shfl_xor(n_mis, d);   // one atomic per wave: same-address atomics of every read serialise
-    if ((threadIdx.x & 63) == 0 && n_mis) atomicAdd(R.mis_total, (unsigned long long)n_mis);
+    for (int d = 32; d > 0; d >>= 1) n_mis += __shfl_xor(n_mis, d);   // one atomic per block: same-address atomics serialise
+    if ((threadIdx.x & 63) == 0) mis_s[threadIdx.x >> 6] = n_mis;
     __syncthreads();
+    if (threadIdx.x == 0) { const int t = mis_s[0] + mis_s[1] + mis_s[2] + mis_s[3]; if (t) atomicAdd(R.mis_total, (unsigned long long)t); }
     const int nrec = imin(256, R.n_alns - id0);
     if (nrec == 256) {
         const uint4 *src = (const uint4 *)&stage[0]; uint4 *dst = (uint4 *)(R.alns + id0);

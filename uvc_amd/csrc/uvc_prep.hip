@@ -153,9 +153,10 @@ __global__ void __launch_bounds__(256) k_mark_first(UvcPrepIn in, const int32_t 
 // one thread per fragment: fillTidBegEndFromAlns1 (main.hpp:658-673) with its cumulative "+1 per alignment"
 __global__ void __launch_bounds__(256) k_build_frags(UvcPrepIn in, UvcParams P, int32_t rend, const int32_t *endpos, const int32_t *kind, const int32_t *fs_of, const int32_t *dflag_of,
                                                      const int32_t *frag_first, int32_t n_frags, FragRec *frags, int32_t *sweep_flag, int32_t *frag_beg, int32_t *frag_strand, Stage2 *T) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
     int w_span = 0, w_s0 = 0;
-    if (f < n_frags) {
+    // a grid of at most 1024 blocks strides over the fragments and leaves ONE pair of atomics per block: with a wave's pair per 64 fragments the
+    // 31 000 same-line atomics of a 1 M-fragment tile were most of the kernel's time
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < n_frags; f += gridDim.x * blockDim.x) {
     FragRec r; memset(&r, 0, sizeof(r));
     const int a0 = frag_first[f], a1 = frag_first[f + 1];
     r.aln_beg = a0; r.aln_end = a1; r.beg = INT32_MAX; r.end = 0; r.fs = fs_of[a0]; r.strand = in.fam_strand[a0]; r.dflag = dflag_of[a0];
@@ -170,10 +171,17 @@ __global__ void __launch_bounds__(256) k_build_frags(UvcPrepIn in, UvcParams P, 
     r.stat_kind = (all_simple && (a1 - a0) <= 2 && !amplicon_gated) ? 0 : 1;
     sweep_flag[f] = r.stat_kind; frag_beg[f] = r.beg; frag_strand[f] = r.strand;
     frags[f] = r;
-    w_span = r.end - r.beg; w_s0 = (r.strand == 0);
+    w_span = pmax(w_span, r.end - r.beg); w_s0 += (r.strand == 0);
     }
+    __shared__ int sh[4][2];
     w_span = wave_max(w_span); w_s0 = wave_sum(w_s0);
-    if ((threadIdx.x & 63) == 0) { if (w_span) atomicMax(&T->max_frag_span, w_span); if (w_s0) atomicAdd(&T->n_frag_strand0, w_s0); }
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6][0] = w_span; sh[threadIdx.x >> 6][1] = w_s0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int sp = pmax(pmax(sh[0][0], sh[1][0]), pmax(sh[2][0], sh[3][0])), s0 = sh[0][1] + sh[1][1] + sh[2][1] + sh[3][1];
+        if (sp) atomicMax(&T->max_frag_span, sp);
+        if (s0) atomicAdd(&T->n_frag_strand0, s0);
+    }
 }
 // one thread per family-strand unit: fillTidBegEndFromAlns2 (main.hpp:675-697), the duplex partner, which kernels take it
 __global__ void __launch_bounds__(256) k_build_units(UvcPrepIn in, UvcParams P, int32_t rend, const int32_t *endpos, const int32_t *dflag_of, const int32_t *frag_first, const int32_t *fs_first_frag,
@@ -420,7 +428,7 @@ extern "C" int uvc_prep_reads(const UvcPrepIn *inp, const UvcParams *P, int32_t 
     ALLOC(gen_span, int64_t, nu, 0); ALLOC(work_off, int64_t, nu, 0); ALLOC(dup_span, int64_t, nu, 0); ALLOC(dup_off_all, int64_t, nu, 0);
     ALLOC(out->frags, FragRec, nf, 0); ALLOC(out->fss, FsRec, nu, 0); ALLOC(out->frag_beg, int32_t, nf, 0); ALLOC(out->frag_strand, int32_t, nf, 0);
     hipLaunchKernelGGL(k_mark_first, dim3(nblk(n, 256)), dim3(256), 0, s, in, new_frag, new_fs, out->frag_of, out->fs_of, frag_first, fs_first_frag, fam_fs, nf, nu, dT2);
-    hipLaunchKernelGGL(k_build_frags, dim3(nblk(nf, 256)), dim3(256), 0, s, in, *P, rend, out->endpos, out->kind, out->fs_of, out->dflag_of, frag_first, nf, out->frags, sweep_flag, out->frag_beg, out->frag_strand, dT2);
+    hipLaunchKernelGGL(k_build_frags, dim3(std::min(nblk(nf, 256), 1024u)), dim3(256), 0, s, in, *P, rend, out->endpos, out->kind, out->fs_of, out->dflag_of, frag_first, nf, out->frags, sweep_flag, out->frag_beg, out->frag_strand, dT2);
     hipLaunchKernelGGL(k_build_units, dim3(nblk(nu, 256)), dim3(256), 0, s, in, *P, rend, out->endpos, out->dflag_of, frag_first, fs_first_frag, fam_fs, nu, out->fss, generic_flag, gen_span, dT2);
     PREP_HIP(rocprim::exclusive_scan(tmp, tb, generic_flag, generic_rank, (int32_t)0, (size_t)std::max(nu, 1), rocprim::plus<int32_t>(), s)); tb = tmp_bytes;
     PREP_HIP(rocprim::exclusive_scan(tmp, tb, gen_span, work_off, (int64_t)0, (size_t)std::max(nu, 1), rocprim::plus<int64_t>(), s)); tb = tmp_bytes;
