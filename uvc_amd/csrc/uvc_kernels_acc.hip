@@ -1729,15 +1729,11 @@ __global__ void __launch_bounds__(256) k_frag_sums(RegionDev R, UvcParams P) {
     for (int i = threadIdx.x; i < UVC_FSUM_N * (FSUM_TILE + 1); i += 256) (&d[0][0])[i] = 0;
     __syncthreads();
     const int seg_beg = R.frag_off[strand], seg_end = R.frag_off[strand + 1];
-    int lo, hi;
-    {
-        int l = seg_beg, h = seg_end;
-        const int key = t0 - R.max_frag_span + 1;
-        while (l < h) { const int m = (l + h) >> 1; if (R.ffast[m].beg < key) l = m + 1; else h = m; }
-        lo = l; h = seg_end;
-        while (l < h) { const int m = (l + h) >> 1; if (R.ffast[m].beg < t1) l = m + 1; else h = m; }
-        hi = l;
-    }
+    // the fragments that can reach the tile, from the window index (k_win_index, lists 5 / 6): first with beg >= t0 - max_frag_span + 1 ..
+    // first with beg >= the end of the tile's last 64-position window; two binary searches over the list by every thread (forty dependent
+    // loads in front of the block's work) otherwise
+    (void)seg_beg; (void)seg_end;
+    const int lo = win_lo(R, 5 + strand, (int)blockIdx.x * (FSUM_TILE / 64)), hi = win_hi(R, 5 + strand, (t1 - 1 - R.beg) >> 6);
     auto put = [&](int f, int a, int b, int v) {   // += v on [a, b) of plane f, clipped to the tile
         a = imax(a, t0); b = imin(b, t1);
         if (a < b) { atomicAdd(&d[f][a - t0], v); atomicAdd(&d[f][b - t0], -v); }
@@ -1789,8 +1785,12 @@ __global__ void __launch_bounds__(256) k_frag_sums(RegionDev R, UvcParams P) {
         int before = inc - run;
         for (int i = 0; i < w; i++) before += wtot[i];
         __syncthreads();
+        int32_t *o4 = out + (size_t)f * R.npos + threadIdx.x * 4;
+        if (threadIdx.x * 4 + 4 <= n_here && (((uintptr_t)o4) & 15) == 0) *(int4 *)o4 = make_int4(before + v[0], before + v[1], before + v[2], before + v[3]);
+        else {
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const int x = threadIdx.x * 4 + i; if (x < n_here) out[(size_t)f * R.npos + x] = before + v[i]; }
+            for (int i = 0; i < 4; i++) { const int x = threadIdx.x * 4 + i; if (x < n_here) o4[i] = before + v[i]; }
+        }
     }
 }
 
