@@ -105,8 +105,10 @@ DEV int lower_bound_pos(const AlnRec *a, int n, int key) {   // first index with
 struct SegAcc {   // SegFormatInfoSet (main_conversion.hpp:645-691) + the VQ a1/a2 sums + bqsum of ONE symbol at ONE position
     int s[UVC_NSEG32];
     long long l[UVC_NSEG64];
+    int lp[UVC_NSEG64];   // k_p2_fast: 32-bit partial sums of the 64-bit counters over one chunk of 64 reads (each term < 2^25), folded into l[] per chunk
     int a1BQf, a1BQr, a2BQf, a2BQr, bq;
-    DEV void zero() { for (int i = 0; i < UVC_NSEG32; i++) s[i] = 0; for (int i = 0; i < UVC_NSEG64; i++) l[i] = 0; a1BQf = a1BQr = a2BQf = a2BQr = bq = 0; }
+    DEV void zero() { for (int i = 0; i < UVC_NSEG32; i++) s[i] = 0; for (int i = 0; i < UVC_NSEG64; i++) { l[i] = 0; lp[i] = 0; } a1BQf = a1BQr = a2BQf = a2BQr = bq = 0; }
+    DEV void fold() { for (int i = 0; i < UVC_NSEG64; i++) { l[i] += (long long)lp[i]; lp[i] = 0; } }
 };
 
 DEV void seg_flush(const RegionDev &R, const SegAcc &A, int sym, int64_t x) {
@@ -253,7 +255,8 @@ DEV int selm(wmask m, int v) { int r; asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=
 // Everything that does not depend on the symbol is computed once for both.
 // ISRC / STRAND (bam_get_strand, common.hpp:89) are compile-time: the P2 work list is split by them, so the direction-specific
 // counters are fixed registers in each instantiation and the loop has no branch on the read's orientation.
-// PLAIN: the region holds no amplicon-flagged family and no primer length is set, so the amplicon arms are compiled out.
+// PLAIN: the region holds no amplicon-flagged family, no primer length is set and the reads are long (is_high_readlen), so the amplicon arms
+// and the microadjust arm are compiled out.
 template <bool ISRC, bool STRAND, bool PLAIN>
 DEV void segbias_simple(SegAcc &AL, SegAcc &AB, const UvcParams &P, const SegRead &r, const PosThres &T, int rpos, long long baq_p, long long baq2_p,
                         bool hasL, bool hasB, int bqL, int bqB, int xm_inc, int bm_inc, const int *amp1, const int *amp2) {
@@ -263,7 +266,8 @@ DEV void segbias_simple(SegAcc &AL, SegAcc &AB, const UvcParams &P, const SegRea
     constexpr bool isrc = ISRC, strand = STRAND;
     const bool is_normal = ((r.isize != 0) || (0 == (r.flag & 0x1)));
     const bool mate_ok = ((0 == (r.flag & 0x8)) || (0 == (r.flag & 0x1)));
-    const bool hrl = (P.central_readlen >= P.microadjust_median_readlen_thres);
+    // PLAIN also means is_high_readlen (main.hpp:1404): the microadjust arm (two full-width integer multiplies per read and wave, quarter rate) is compiled out
+    const bool hrl = (PLAIN ? true : (P.central_readlen >= P.microadjust_median_readlen_thres));
     const int l_nb = rpos - r.pos + 1, r_nb = r.rend - rpos;
     // differences of BAQ prefix sums: truncation to 32 bits commutes with the subtraction
     const int l_baq1 = (int)((unsigned)baq_p - (unsigned)r.baq_pos + 1u);
@@ -303,21 +307,22 @@ DEV void segbias_simple(SegAcc &AL, SegAcc &AB, const UvcParams &P, const SegRea
     const wmask m_okB = umask(is_normal), m_okL = m_okB | (umask(mate_ok) & m_nonb);
     const int p2 = (is_assay_UMI || !amplicon), nc = (0 == r.clip_cnt);
     auto common = [&](SegAcc &A, int bq) {
-        if (isrc) { A.a1BQr += bq; A.a2BQr += bq * bq / SQR_QUAL_DIV; } else { A.a1BQf += bq; A.a2BQf += bq * bq / SQR_QUAL_DIV; }
+        const int bq2 = (int)(__umul24((unsigned)bq, (unsigned)bq) / SQR_QUAL_DIV);   // bq < 2^12: the 24-bit multiply is exact and full rate
+        if (isrc) { A.a1BQr += bq; A.a2BQr += bq2; } else { A.a1BQf += bq; A.a2BQf += bq2; }
         A.bq += bq;
         A.s[UVC_S_aMQs] += r.mapq;
         if (strand) { if (isrc) A.s[UVC_S_aDPrr] += 1; else A.s[UVC_S_aDPrf] += 1; }
         else        { if (isrc) A.s[UVC_S_aDPfr] += 1; else A.s[UVC_S_aDPff] += 1; }
         addm(A.s[UVC_S_aP3], m_p3);
         A.s[UVC_S_aNC] += nc; A.s[UVC_S_aP2] += p2;
-        if (has_isize) { if (isrc) A.l[UVC_S64_aLIT] += (long long)fl2; else A.l[UVC_S64_aRIT] += (long long)fr2; }
+        if (has_isize) { if (isrc) A.lp[UVC_S64_aLIT] += fl2; else A.lp[UVC_S64_aRIT] += fr2; }
     };
     auto bias = [&](SegAcc &A, bool in_all, wmask in, wmask far, wmask unaff, wmask m_rb1, wmask m_rb2, int r_baq) {
         const wmask a = (in_all ? far : (in & far)), b = (in_all ? unaff : (in & unaff));
         addm(A.s[UVC_S_aLP1], a & m_lp1); addm(A.s[UVC_S_aLP2], a & m_lp2); addm(A.s[UVC_S_aRP1], a & m_rp1); addm(A.s[UVC_S_aRP2], a & m_rp2);
         A.s[UVC_S_aLPL] += selm(a, l_nb); A.s[UVC_S_aRPL] += selm(a, r_nb);
         addm(A.s[UVC_S_aLB1], b & m_lb1); addm(A.s[UVC_S_aLB2], b & m_lb2); addm(A.s[UVC_S_aRB1], b & m_rb1); addm(A.s[UVC_S_aRB2], b & m_rb2);
-        A.l[UVC_S64_aLBL] += (long long)selm(b, l_baq); A.l[UVC_S64_aRBL] += (long long)selm(b, r_baq);
+        A.lp[UVC_S64_aLBL] += selm(b, l_baq); A.lp[UVC_S64_aRBL] += selm(b, r_baq);
         if (in_all) A.s[UVC_S_aBQ2] += 1; else addm(A.s[UVC_S_aBQ2], in);
         addm(A.s[UVC_S_aP1], far & unaff & m_iend);
     };
@@ -1132,6 +1137,8 @@ DEV void p2_fast_body(const RegionDev &R, const UvcParams &P, int *amp1, int *am
                 segbias_simple<ISRC, STRAND, PLAIN>(Alink, Aref, P, sr, T, p, baq_p, baq2_p, hasL, hasB, incL, inc, xm_inc, bm_inc, amp1, amp2);
             }
         }
+        if (DO_B) Aref.fold();
+        if (DO_L) Alink.fold();
     }
     };
     COARSE_T(ct1)
@@ -3752,8 +3759,10 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
     // ---- main stream: the base symbols first, so that the queued mismatches (rare symbols, atomics: disjoint from the planes the
     // LINK_M pass stores to) are applied on a side stream while the LINK_M pass runs
     if (P->inferred_is_vcf_generated) {
-        // no IonTorrent values, no amplicon-flagged family, no primer length: the specialisation without those arms
-        const bool plain = (UVC_PLATFORM_IONTORRENT != P->inferred_sequencing_platform) && !R->any_amplicon && !(P->primerlen > 0 && !(0x2 & P->primer_flag));
+        // no IonTorrent values, no amplicon-flagged family, no primer length, median read length at or above microadjust_median_readlen_thres:
+        // the specialisation without those arms
+        const bool plain = (UVC_PLATFORM_IONTORRENT != P->inferred_sequencing_platform) && !R->any_amplicon && !(P->primerlen > 0 && !(0x2 & P->primer_flag))
+                           && (P->central_readlen >= P->microadjust_median_readlen_thres);
         if (split_windows && plain) TIMED(prof, "k_p2_fast_base", hipLaunchKernelGGL((k_p2_fast_split<false, true, true>), dim3(R->nwin), dim3(256), 0, s, *R, *P));
         else if (split_windows) TIMED(prof, "k_p2_fast_base", hipLaunchKernelGGL((k_p2_fast_split<false, true, false>), dim3(R->nwin), dim3(256), 0, s, *R, *P));
         else if (plain) TIMED(prof, "k_p2_fast_base", hipLaunchKernelGGL((k_p2_fast<false, true, true>), dim3(nwin), dim3(256), 0, s, *R, *P));
