@@ -16,7 +16,7 @@ INS_ALLELES = [[3], [2], [3, 3], [0, 1, 2], [0, 4, 2], [3] * 15 + [0, 1, 2], [3]
 DEL_ALLELES = [1, 2, 3, 5, 9]
 
 
-def indel_sites_region(seed, n_fam=90, ref_len=420, beg=3_000_000, umi=True, depth_like=1):
+def indel_sites_region(seed, n_fam=90, ref_len=420, beg=3_000_000, umi=True, depth_like=1, max_frags=7):
     rng = np.random.default_rng(seed)
     ref = rng.integers(0, 4, ref_len)
     ref[200:212] = 3                                       # a homopolymer: n_units != length for InDels inside it
@@ -33,7 +33,7 @@ def indel_sites_region(seed, n_fam=90, ref_len=420, beg=3_000_000, umi=True, dep
         fam_allele = {s: (prefer[s] if rng.random() < 0.7 else int(rng.integers(0, 9))) for s in sites}
         fam_has = {s: rng.random() < 0.6 for s in sites}
         for strand in ((0, 1) if duplex else (int(rng.integers(0, 2)),)):
-            for _ in range(int(rng.integers(1, 7)) if umi else 1):
+            for _ in range(int(rng.integers(1 if max_frags <= 7 else max_frags // 2, max_frags)) if umi else 1):
                 for mate in range(int(rng.choice([1, 2, 2]))):
                     start = fam_start + (0 if mate == 0 else int(rng.integers(0, 60)))
                     length = int(rng.integers(90, 150))
@@ -106,6 +106,21 @@ def test_allele_rows_and_records(seed, umi, n_fam, oracle_lib, gpu_lib):
         assert so["bDPa"][i] == sum(r["bAD1"] for r in same) and so["cDP0a"][i] == sum(r["cAD1"] for r in same)
     so, sg = o.score(all_out=True), g.score(all_out=True)
     compare_records(so, sg)
+
+
+@pytest.mark.parametrize("seed,n_fam,max_frags", [(11, 8, 30), (12, 5, 90), (13, 12, 45)])
+def test_deep_families(seed, n_fam, max_frags, oracle_lib, gpu_lib):
+    """Families of a panel's depth: (family, position) runs of tens to hundreds of InDel events.  k_gap_alleles reads runs inside its block's
+    128-event window from LDS and the others (longer runs, runs with an insertion of more than 13 bases) from global memory; k_gap_rows sums
+    runs of hundreds of increments with one atomic per increment.  Rows and records must equal the oracle's either way."""
+    reads = indel_sites_region(seed, n_fam=n_fam, umi=True, max_frags=max_frags)
+    o, g = run(oracle_lib, reads), run(gpu_lib, reads)
+    assert not diff_groups(o, g)
+    ro, rg = o.indel_alleles(), g.indel_alleles()
+    assert len(ro) > 10 and max(r["bAD1"] for r in ro) >= max_frags // 2
+    assert ro == rg, next((a, b) for a, b in zip(ro + [None], rg + [None]) if a != b)
+    compare_records(o.score(all_out=False), g.score(all_out=False))
+    compare_records(o.score(all_out=True), g.score(all_out=True))
 
 
 def test_caller_alleles_override_the_tables(oracle_lib, gpu_lib):
