@@ -1,9 +1,9 @@
 """Oracle comparison at a size where the kernels run in the form the bench runs them: a 150 kb x 300x non-UMI region
 (2 344 windows of 64 positions: the non-split kernel forms, real occupancy, radix sorts over 300 k reads, k_win_index over thousands of
 windows, 147 carry blocks of k_prep_sums / k_frag_sums, a mismatch queue of hundreds of thousands of entries) and a 50 kb x 2000x
-duplex-UMI region (the digest / window forms of the family kernels): every plane bit-exact, every record inside the tolerance classes
+duplex-UMI region (the digest / window forms of the family kernels), and a 1 Mb x 20x region (positions >> reads): every plane bit-exact, every record inside the tolerance classes
 of tests/test_gpu_parity.py.  The oracle runs these on all host cores of the box in well under a minute (it is single-threaded per
-region: the two regions run on two threads)."""
+region: the regions run on a thread each)."""
 import threading
 
 import numpy as np
@@ -18,6 +18,9 @@ pytestmark = pytest.mark.gpu
 LARGE = {
     "nonumi_150kb_300x": dict(region_len=150_000, depth=300, seed=4242),
     "duplex_50kb_2000x": dict(region_len=50_000, depth=2000, seed=4343, umi=True),
+    # far more positions than reads, at least 65 536 fragments: the fragment-depth scan of the read preparation runs over npos + 1 elements
+    # with the scratch sized for it (sized for the reads only it failed from ~4 positions per read on)
+    "wgs_1mb_20x": dict(region_len=1_000_000, depth=20, seed=4444),
 }
 
 
@@ -48,6 +51,7 @@ def test_large_region_matches_oracle(name, oracle_runs, gpu_lib):
     assert not bad, "\n".join("%s: %d cells differ, e.g. %s" % (g, v[0], v[1]) for g, v in bad.items())
     rg = Rg.score(all_out=False)
     assert len(ro["refpos"]) > 1000
+    if name == "wgs_1mb_20x": assert reads["n_reads"] >= 2 * 65536 and Rg.npos > 4 * reads["n_reads"]
     worst = compare_records(ro, rg)
     print(name, reads["n_reads"], "reads,", len(ro["refpos"]), "records, worst differences", {k: v for k, v in worst.items() if v})
     # the InDel allele rows behind the records
