@@ -444,8 +444,9 @@ void uvcgpu_region_destroy(uvcgpu_region_t *r);
 /* ---------------------------------------------------------------- BGZF inflate on the device -- */
 /* Replaces the zlib inflate behind htslib's bgzf_read for a batch of BGZF blocks (grouping.cpp:617-731 reads every alignment through it):
  * n raw DEFLATE payloads at comp + in_off[i] (in_len[i] bytes: the block without its 12 + XLEN header bytes and its 8 footer bytes) are
- * inflated to out + out_off[i] (out_len[i] = ISIZE bytes).  comp and out are HOST buffers of comp_bytes / out_bytes bytes; only the byte
- * range the blocks cover is written.  One lane per block, the Huffman tables of a wave's 64 decoders in LDS (uvc_inflate.hip).  The
+ * inflated to out + out_off[i] (out_len[i] = ISIZE bytes).  comp and out are HOST buffers of comp_bytes / out_bytes bytes.  The outputs
+ * must tile one span of `out` in block order (out_off[i + 1] == out_off[i] + out_len[i], as a reader's batch does; UVCGPU_EINVAL otherwise):
+ * only that span is written.  One lane per block, the Huffman tables of a wave's 64 decoders in LDS (uvc_inflate.hip).  The
  * CRC-32 of the footer is left to the caller (uvcio checks it on the returned bytes).  The signature is uvcio_inflate_fn of uvcio.h: pass
  * the function to uvcio_set_inflater.  Needs uvcgpu_init on the calling thread; UVCGPU_EINVAL names the first block whose stream is corrupt. */
 int uvcgpu_bgzf_inflate(void *ctx, const uint8_t *comp, int64_t comp_bytes, const int64_t *in_off, const int32_t *in_len,

@@ -94,13 +94,26 @@ extern "C" int uvcgpu_bgzf_inflate(void *, const uint8_t *comp, int64_t comp_byt
                 return uvcgpu_set_error(UVCGPU_EINVAL, "bgzf_inflate: a block lies outside its buffer");
             hb[(size_t)i] = BgzfBlockDev{ (unsigned long long)in_off[i], (unsigned long long)out_off[i], (uint32_t)in_len[i], (uint32_t)out_len[i] };
         }
-        int64_t lo = out_bytes, hi = 0;   // the byte range of `out` the blocks cover: nothing else is written
-        for (int64_t i = 0; i < n; i++) { lo = std::min<int64_t>(lo, out_off[i]); hi = std::max<int64_t>(hi, out_off[i] + out_len[i]); }
+        // The outputs must tile one span of `out` in block order (the reader's batches do): the span travels back as one copy, so a hole in
+        // it would be overwritten with stale device bytes, and overlapping outputs would be two waves writing the same bytes.
+        int64_t lo = out_off[0], hi = out_off[0];
+        for (int64_t i = 0; i < n; i++) {
+            if (out_off[i] != hi) return uvcgpu_set_error(UVCGPU_EINVAL, "bgzf_inflate: the outputs of the blocks must be contiguous and in order");
+            hi += out_len[i];
+        }
         if (hi <= lo) return 0;
         InflateCtx &C = g_ctx;
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return uvcgpu_set_error(UVCGPU_EDEVICE, "bgzf_inflate: no device (uvcgpu_init on this thread first)");
-        if (C.device != dev) { C = InflateCtx(); C.device = dev; }
+        if (C.device != dev) {   // another device on this thread: the staging buffers and the stream of the old one go back first
+            if (C.device >= 0) {
+                (void)hipSetDevice(C.device);
+                if (C.stream) { (void)hipStreamSynchronize(C.stream); (void)hipStreamDestroy(C.stream); }
+                for (DevBuf *b : { &C.comp, &C.out, &C.blocks, &C.status }) if (b->p) uvc_dev_free(b->p);
+                (void)hipSetDevice(dev);
+            }
+            C = InflateCtx(); C.device = dev;
+        }
         if (!C.stream && hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking) != hipSuccess) return uvcgpu_set_error(UVCGPU_EDEVICE, "bgzf_inflate: hipStreamCreate");
         const size_t lds = sizeof(InflState) * 64;
         if (!C.attr_set) {
@@ -113,7 +126,8 @@ extern "C" int uvcgpu_bgzf_inflate(void *, const uint8_t *comp, int64_t comp_byt
             || hipMemcpyAsync(C.blocks.p, hb.data(), sizeof(BgzfBlockDev) * (size_t)n, hipMemcpyHostToDevice, C.stream) != hipSuccess
             || hipMemsetAsync(C.status.p, 0x7F, sizeof(int32_t) * (size_t)n, C.stream) != hipSuccess) return uvcgpu_set_error(UVCGPU_EDEVICE, "bgzf_inflate: H2D");
         const bool timing = (getenv("UVCGPU_TIMING") != nullptr);
-        hipEvent_t e0 = nullptr, e1 = nullptr;
+        struct Events { hipEvent_t e0 = nullptr, e1 = nullptr; ~Events() { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); } } ev;   // destroyed on every return path
+        hipEvent_t &e0 = ev.e0, &e1 = ev.e1;
         if (timing) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, C.stream); }
         const char *wenv = getenv("UVCGPU_INFLATE_WAVE");   // read per call: the tests run every form in one process
         const int wave_per_block = wenv ? atoi(wenv) : 8;   // default: a wave per block at 8 waves per SIMD; 1: the compiler's register budget; 0: a lane per block
@@ -126,7 +140,7 @@ extern "C" int uvcgpu_bgzf_inflate(void *, const uint8_t *comp, int64_t comp_byt
         if (hipMemcpyAsync(st.data(), C.status.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, C.stream) != hipSuccess
             || hipMemcpyAsync(out + lo, (const uint8_t *)C.out.p + lo, (size_t)(hi - lo), hipMemcpyDeviceToHost, C.stream) != hipSuccess
             || hipStreamSynchronize(C.stream) != hipSuccess) return uvcgpu_set_error(UVCGPU_EDEVICE, "bgzf_inflate: kernel or D2H failed");
-        if (timing) { float ms = 0; hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[uvcgpu bgzf_inflate] %lld blocks, %.1f MB -> %.1f MB: kernel %.2f ms\n", (long long)n, comp_bytes / 1e6, (hi - lo) / 1e6, ms); hipEventDestroy(e0); hipEventDestroy(e1); }
+        if (timing) { float ms = 0; hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[uvcgpu bgzf_inflate] %lld blocks, %.1f MB -> %.1f MB: kernel %.2f ms\n", (long long)n, comp_bytes / 1e6, (hi - lo) / 1e6, ms); }
         for (int64_t i = 0; i < n; i++) if (st[(size_t)i] != 0)
             return uvcgpu_set_error(UVCGPU_EINVAL, (std::string("bgzf_inflate: corrupt DEFLATE stream in block ") + std::to_string(i) + " (code " + std::to_string(st[(size_t)i]) + ")").c_str());
         return 0;

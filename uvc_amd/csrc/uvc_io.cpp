@@ -9,6 +9,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -118,7 +119,8 @@ struct Bgzf {
 // grow-only byte buffer without value initialisation (a fresh std::vector of tens of MB costs its page faults on every query)
 struct RawBuf {
     uint8_t *p = nullptr; size_t cap = 0;
-    uint8_t *need(size_t n) { if (n > cap) { cap = n + n / 4 + 4096; p = (uint8_t *)realloc(p, cap); } return p; }
+    // nullptr when the memory is not there (the old block stays valid and is freed by the destructor)
+    uint8_t *need(size_t n) { if (n > cap) { const size_t c2 = n + n / 4 + 4096; uint8_t *q = (uint8_t *)realloc(p, c2); if (!q) return nullptr; p = q; cap = c2; } return p; }
     ~RawBuf() { free(p); }
 };
 // The two large columns of a batch (one byte per base each) live in memory from the caller's allocator when one is set
@@ -385,7 +387,14 @@ bool aux_nm(const uint8_t *r, size_t bs, size_t o, int32_t &nm) {
 
 }  // namespace
 
+static int bam_fetch_impl(uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t end, UvcBamBatch *out);
+// no exception crosses the C boundary: a column that cannot grow is UVCGPU_ENOMEM
 extern "C" int uvcio_bam_fetch(uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t end, UvcBamBatch *out) {
+    try { return bam_fetch_impl(b, tid, beg, end, out); }
+    catch (const std::bad_alloc &) { return fail(UVCGPU_ENOMEM, "uvcio_bam_fetch: out of host memory"); }
+    catch (const std::exception &e) { return fail(UVCGPU_EINVAL, std::string("uvcio_bam_fetch: ") + e.what()); }
+}
+static int bam_fetch_impl(uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t end, UvcBamBatch *out) {
     if (!b || !out) return fail(UVCGPU_EINVAL, "null argument");
     if (tid < 0 || tid >= (int32_t)b->ref_names.size()) return fail(UVCGPU_EINVAL, "tid out of range");
     if (beg < 0) beg = 0;
@@ -436,6 +445,7 @@ extern "C" int uvcio_bam_fetch(uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t
                 if (last_addr != INT64_MAX) want = std::min<size_t>(want, (size_t)(last_addr - addr) + (1 << 16) + 18);
                 if (file_size >= 0) want = std::min<size_t>(want, (size_t)std::max<int64_t>(file_size - addr, 0));
                 uint8_t *const cbuf = b->comp.need(std::max<size_t>(want, 1));
+                if (!cbuf) return fail(UVCGPU_ENOMEM, "uvcio_bam_fetch: no memory for the compressed batch");
                 const size_t got = fread(cbuf, 1, want, b->z.fp);
                 const bool at_eof = (file_size >= 0 ? (addr + (int64_t)got >= file_size) : (got < want));
                 blocks.clear();
@@ -462,8 +472,9 @@ extern "C" int uvcio_bam_fetch(uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t
                 // 2. inflate in parallel
                 const size_t infl_size = carry.size() + out_bytes;
                 uint8_t *const ibuf = b->infl.need(std::max<size_t>(infl_size, 1));
+                if (!ibuf) return fail(UVCGPU_ENOMEM, "uvcio_bam_fetch: no memory for the inflated batch");
                 if (!carry.empty()) memcpy(ibuf, carry.data(), carry.size());
-                bool ok = true, done = false;
+                std::atomic<bool> ok{ true }; bool done = false;   // (flags written from the pool's threads are atomics)
                 if (g_inflate_fn && (int64_t)blocks.size() >= (int64_t)g_inflate_min) {   // somewhere else (the device); the CRC-32 of every block is checked here
                     const size_t nb2 = blocks.size();
                     std::vector<int64_t> in_off(nb2), out_off(nb2); std::vector<int32_t> in_len(nb2), out_len(nb2);
@@ -475,7 +486,7 @@ extern "C" int uvcio_bam_fetch(uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t
                         in_off[i] = (int64_t)blocks[i].in_off + 12 + xlen; in_len[i] = clen; out_off[i] = (int64_t)(carry.size() + blocks[i].out_off); out_len[i] = (int32_t)blocks[i].isize;
                     }
                     if (sane && g_inflate_fn(g_inflate_ctx, cbuf, (int64_t)o, in_off.data(), in_len.data(), out_off.data(), out_len.data(), (int64_t)nb2, ibuf, (int64_t)infl_size) == 0) {
-                        bool crc_ok = true;
+                        std::atomic<bool> crc_ok{ true };
                         parallel_for(nb2, [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; i++) if (blocks[i].isize && block_crc32(ibuf + out_off[i], blocks[i].isize) != le32(cbuf + blocks[i].in_off + blocks[i].csize - 8)) crc_ok = false; });
                         done = crc_ok;
                     }
@@ -580,7 +591,7 @@ extern "C" int uvcio_bam_fetch(uvcio_bam_t *b, int32_t tid, int64_t beg, int64_t
                 b->tid.resize(r0 + nr); b->pos.resize(r0 + nr); b->endpos.resize(r0 + nr); b->mtid.resize(r0 + nr); b->mpos.resize(r0 + nr); b->isize.resize(r0 + nr); b->nm.resize(r0 + nr);
                 b->l_qseq.resize(r0 + nr); b->n_cigar.resize(r0 + nr); b->flag.resize(r0 + nr); b->mapq.resize(r0 + nr); b->seq_off.resize(r0 + nr); b->cigar_off.resize(r0 + nr); b->qname_off.resize(r0 + nr);
                 b->bases.resize((size_t)nb); b->quals.resize((size_t)nb); b->cigars.resize((size_t)nc); b->qnames.resize((size_t)nq);
-                bool aux_ok = true;
+                std::atomic<bool> aux_ok{ true };
                 parallel_for(nr, [&](size_t i0, size_t i1) {
                     for (size_t i = i0; i < i1; i++) {
                         const RecRef &q = recs[i]; const uint8_t *r = q.r; const size_t k = r0 + i;
