@@ -102,7 +102,8 @@ void uvcio_set_column_allocator(void *(*alloc_fn)(size_t), void (*free_fn)(void 
  * in place; the reader then checks each block's CRC-32 itself.  Anything else (non-zero return, a CRC mismatch) and the reader inflates the
  * batch on the host as if no function had been set.  uvcgpu_bgzf_inflate (uvcgpu.h) has this signature: uvc1-mi355x --device-inflate sets
  * it (the calling thread must have selected its device, uvcgpu_init).  Batches with fewer than min_blocks blocks stay on the host.
- * Replaces bgzf_read's inflate of the reference's reader (htslib behind grouping.cpp:617-731).  Process-wide; set it before the first fetch. */
+ * Replaces bgzf_read's inflate of the reference's reader (htslib behind grouping.cpp:617-731).  Process-wide; set it before the first fetch.
+ * The reader hands over whole batches: the outputs of the n blocks tile one span of `out` in block order (out_off[i + 1] == out_off[i] + out_len[i]). */
 typedef int (*uvcio_inflate_fn)(void *ctx, const uint8_t *comp, int64_t comp_bytes, const int64_t *in_off, const int32_t *in_len,
                                 const int64_t *out_off, const int32_t *out_len, int64_t n, uint8_t *out, int64_t out_bytes);
 void uvcio_set_inflate(uvcio_inflate_fn fn, void *ctx, int32_t min_blocks);
