@@ -11,12 +11,17 @@ import numpy as np
 from rtr_cases import _indel_phred, _more_str
 from segbias_restatement import SEG_FIELDS, cdiv, dealwith_segbias, non_neg_minus
 
+def cround(v):
+    """C round(): halves away from zero (Python's round() goes to even)."""
+    return math.floor(v + 0.5) if v >= 0 else math.ceil(v - 0.5)
+
+
 C_MATCH, C_INS, C_DEL, C_REF_SKIP, C_SOFT_CLIP, C_HARD_CLIP, C_PAD, C_EQUAL, C_DIFF = range(9)
 BASE_NN, LINK_M, LINK_D3P, LINK_D2, LINK_D1, LINK_I3P, LINK_I2, LINK_I1, LINK_NN = 5, 6, 7, 8, 9, 10, 11, 12, 13
 NSYM = 14
 INT32_MAX = 2 ** 31 - 1
 N_UNITS_TO_PHRED = [0, 0, 3, 5, 6, 7, 8, 8, 9, 10, 10, 10, 11, 11, 11, 12, 12, 12, 13]   # main.hpp:762-781
-PROTON_OPLEN2PHRED = [0] + [int(round(10.0 / math.log(10.0) * math.log(i ** 3))) for i in range(1, 13)]   # main_conversion.hpp:925-939
+PROTON_OPLEN2PHRED = [0] + [int(cround(10.0 / math.log(10.0) * math.log(i ** 3))) for i in range(1, 13)]   # main_conversion.hpp:925-939
 
 
 def u32(v):
@@ -58,7 +63,7 @@ def ref_to_phredvalue(codes, refpos, max_phred, ampfact, oplen, op, strmax, del_
 def read_events(reads, i, P, rtr, indelphred, baq, codes, prep, thres, proton, with_bias=True):
     """The updates of alignment i in the order updateByAln makes them: a list of (is_gap, value, position, symbol, cigar_op, indel_len,
     dist_to_interfering_indel) -- one inc<TUpdateType>() each, and with TIsBiasUpdated (with_bias) one dealwith_segbias<is_gap>() call with
-    these arguments.  Also returns the per-read constants those calls take: (events, aln, xm1500, bm1500s, dflag, clip_cnt)."""
+    these arguments.  Also returns the per-read constants those calls take and the allele-keyed updates: (events, aln, xm1500, bm1500s, dflag, clip_cnt, gaps)."""
     beg = int(reads["beg"])
     atd = int(P.indel_adj_tracklen_dist)
     n_rtr = rtr.shape[1]
@@ -125,6 +130,7 @@ def read_events(reads, i, P, rtr, indelphred, baq, codes, prep, thres, proton, w
     incvalue = 1
 
     ev = []
+    gaps = []   # (position, symbol, inserted text | deleted length, weight): the allele-keyed maps of incIns / incDel
 
     def bias(is_gap, bq, p, sym, op, indel_len, dist):   # one inc<>() + (with TIsBiasUpdated) one dealwith_segbias<is_gap>() of the reference
         ev.append((is_gap, bq, p, sym, op, indel_len, dist))
@@ -189,7 +195,7 @@ def read_events(reads, i, P, rtr, indelphred, baq, codes, prep, thres, proton, w
                     adp = int(prep["a_dp"][x]); at_i = int(prep["a_at_ins_dp"][x]); at_d = int(prep["a_at_del_dp"][x])
                     # a_dp == 0 (an insertion in front of a reference skip) is undefined behaviour in the reference (round(-inf) -> int): "no bonus",
                     # the convention DESIGN.md 7 documents for the library
-                    phredinc = int(round(2 * (10.0 / math.log(10.0)) * math.log(adp / (1.0 + non_neg_minus(adp, at_i + at_d))))) if adp > 0 else -1000000
+                    phredinc = int(cround(2 * (10.0 / math.log(10.0)) * math.log(adp / (1.0 + non_neg_minus(adp, at_i + at_d))))) if adp > 0 else -1000000
                     multi = int(prep["a_near_ins_pow2len"][x]) * ratiothres > i32(max(1, int(prep["a_near_ins_dp"][x])) * i32(u32(ln * 3)))
                     if inslen == 1 and not multi:
                         phredvalue += min(max(0, phredinc - 3), 4)
@@ -216,6 +222,10 @@ def read_events(reads, i, P, rtr, indelphred, baq, codes, prep, thres, proton, w
                 if nb2end >= int(P.indel_filter_edge_dist):
                     sym = LINK_I1 if inslen == 1 else (LINK_I2 if inslen == 2 else LINK_I3P)
                     bias(True, max(1, incvalue), rpos, sym, op, ln, 10000)
+                    incvalue2 = incvalue                                   # incIns, main.hpp:2101-2113: the inserted bases as text, the weakest of them caps the weight
+                    for q2 in range(qpos, qpos + ln):
+                        incvalue2 = min(incvalue2, Q[q2] + add_l)
+                    gaps.append((rpos, sym, "".join("ACGTN"[bs[q2]] for q2 in range(qpos, qpos + ln)), max(1, incvalue2)))
             qpos += ln
         elif op == C_DEL:
             if gated(rpos):
@@ -228,7 +238,7 @@ def read_events(reads, i, P, rtr, indelphred, baq, codes, prep, thres, proton, w
                     phredvalue, dellen, max_rn, rs_at = ref_to_phredvalue(codes, x, int(P.indel_BQ_max), float(P.indel_polymerase_slip_rate), ln, op,
                                                                           int(P.indel_str_repeatsize_max), float(P.indel_del_to_ins_err_ratio))
                     adp = int(prep["a_dp"][x]); at_i = int(prep["a_at_ins_dp"][x]); at_d = int(prep["a_at_del_dp"][x])
-                    phredinc = int(round(2 * (10.0 / math.log(10.0)) * math.log(adp / (1.0 + non_neg_minus(adp, at_i + at_d))))) if adp > 0 else -1000000
+                    phredinc = int(cround(2 * (10.0 / math.log(10.0)) * math.log(adp / (1.0 + non_neg_minus(adp, at_i + at_d))))) if adp > 0 else -1000000
                     if dellen == 1:
                         phredvalue += min(max(0, phredinc - 3), 4)
                     thisdp = at_d; neardp = max(int(prep["a_near_del_dp"][x]), int(prep["a_near_RTR_del_dp"][x]))
@@ -242,7 +252,7 @@ def read_events(reads, i, P, rtr, indelphred, baq, codes, prep, thres, proton, w
                     q1 = min(Q[qpos], Q[qpos - 1], minq)
                     q2v = non_neg_minus(q1, 1) if thisdp * ratiothres <= neardp else (min(q1 + PROTON_OPLEN2PHRED[min(ln, 12)], max(3, q1) * ln) if proton else 80)
                     delFA = (thisdp + 0.5) / float(adp + 1)
-                    delFAQ = max(0, int(P.microadjust_delFAQmax) + int(round(float(P.powlaw_exponent) * (10.0 / math.log(10.0)) * math.log(delFA))))
+                    delFAQ = max(0, int(P.microadjust_delFAQmax) + int(cround(float(P.powlaw_exponent) * (10.0 / math.log(10.0)) * math.log(delFA))))
                     pc, prev_rpos = ci, rpos
                     while pc != 0 and (cig[pc][0] != C_INS or cig[pc][1] != ln):
                         pc -= 1
@@ -260,6 +270,7 @@ def read_events(reads, i, P, rtr, indelphred, baq, codes, prep, thres, proton, w
                     sym = LINK_D1 if dellen == 1 else (LINK_D2 if dellen == 2 else LINK_D3P)
                     v = max(1, incvalue)
                     bias(True, v, rpos, sym, op, ln, 10000)
+                    gaps.append((rpos, sym, ln, v))                        # incDel, main.hpp:2216
                     for r2 in range(rpos, min(rpos + ln, rend)):            # the padded deletion, main.hpp:2219-2253
                         for s in (BASE_NN, LINK_NN):
                             p = r2 if s == BASE_NN else r2 + 1
@@ -277,7 +288,7 @@ def read_events(reads, i, P, rtr, indelphred, baq, codes, prep, thres, proton, w
             rpos += ln
         elif op == C_SOFT_CLIP:
             qpos += ln
-    return ev, aln, xm1500, bm1500, dflag, clip_cnt
+    return ev, aln, xm1500, bm1500, dflag, clip_cnt, gaps
 
 
 def update_by_aln(reads, P, rtr, indelphred, baq, baq2, codes, prep, thres, proton):
@@ -289,7 +300,7 @@ def update_by_aln(reads, P, rtr, indelphred, baq, baq2, codes, prep, thres, prot
     seg = {k: np.zeros((NSYM, npos), dtype=np.int64) for k in SEG_FIELDS}
     bqsum = np.zeros((NSYM, npos), dtype=np.int64)
     for i in range(int(reads["n_reads"])):
-        ev, aln, xm1500, bm1500, dflag, clip_cnt = read_events(reads, i, P, rtr, indelphred, baq, codes, prep, thres, proton, True)
+        ev, aln, xm1500, bm1500, dflag, clip_cnt, _ = read_events(reads, i, P, rtr, indelphred, baq, codes, prep, thres, proton, True)
         for is_gap, bq, p, sym, op, indel_len, dist in ev:
             bqsum[sym][p - beg] += bq
             th = {k: int(thres[k][p - beg]) for k in thres}

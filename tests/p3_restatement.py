@@ -36,7 +36,9 @@ def is_del(s): return s in (LINK_D1, LINK_D2, LINK_D3P)
 
 
 def sscs_phred(P, con, alt, is_rescued):
-    """PhredMutationTable::toPhredErrRate(con_symbol, alt_symbol) as the fragment pass calls it: (refsymbol, con_symbol)."""
+    """PhredMutationTable::toPhredErrRate(con_symbol, alt_symbol) as the fragment pass calls it: (refsymbol, con_symbol).  `is_rescued` is the
+    constructor's `vcf_tumor_fname.size() > 0` (main.hpp:2564) -- true for the default "." too (CmdLineArgs.hpp:22, 55), so all_mutation_inc is 3
+    unless the name is set to the empty string: UvcParams::tumor_vcf_fname_nonempty, not tumor_vcf_is_provided."""
     if is_ins(con) or is_del(con):
         raw = P.fam_phred_sscs_indel_open
     elif con == LINK_M:
@@ -97,7 +99,7 @@ def fragment_pass(reads, P, rtr, indelphred, baq, codes, prep, thres, seg, bqsum
         beg2, end2, normMQ = 2 ** 31 - 1, 0, 0
         evs = []
         for k in range(i, j):
-            ev, aln, _, _, _, _ = read_events(reads, k, P, rtr, indelphred, baq, codes, prep, thres, proton, with_bias=False)
+            ev, aln, _, _, _, _, _ = read_events(reads, k, P, rtr, indelphred, baq, codes, prep, thres, proton, with_bias=False)
             evs.append(ev)
             beg2 = min(beg2, aln["pos"]); end2 = max(end2, aln["endpos"]) + 1
             normMQ = max(normMQ, aln["qual"])
@@ -119,7 +121,7 @@ def fragment_pass(reads, P, rtr, indelphred, baq, codes, prep, thres, seg, bqsum
                 max_qual = 8 + avgBQ(x, con)
                 con_qual = cc * 2 - ct
                 if int(P.fam_flag) & 1:
-                    phredlike = min(con_qual, max_qual, sscs_phred(P, refsymbol, con, bool(P.tumor_vcf_is_provided)))
+                    phredlike = min(con_qual, max_qual, sscs_phred(P, refsymbol, con, bool(P.tumor_vcf_fname_nonempty)))
                 else:
                     phredlike = min(con_qual, max_qual)
                 pb = max(0, max_qual - phredlike)

@@ -33,6 +33,11 @@ def i32(v):
     return v - (1 << 32) if v & 0x80000000 else v
 
 
+def cround(v):
+    """C round(): halves away from zero (Python's round() goes to even)."""
+    return math.floor(v + 0.5) if v >= 0 else math.ceil(v - 0.5)
+
+
 def u32(v):
     return v & 0xFFFFFFFF
 
@@ -183,7 +188,7 @@ def thres_sets(prep, indelphred, P, is_normal, iontorrent):
     t = {k: np.zeros(npos, dtype=np.int64) for k in THRES}
     ip = np.array(indelphred, dtype=np.int64).copy()
     ratio = float(P.indel_del_to_ins_err_ratio)
-    half = int(cdiv(int(round((10.0 / math.log(10.0)) * math.log(ratio))), 2))   # (uvc1_qual_t)round(numstates2phred(ratio)) / 2
+    half = int(cdiv(int(cround((10.0 / math.log(10.0)) * math.log(ratio))), 2))   # (uvc1_qual_t)round(numstates2phred(ratio)) / 2
     for x in range(npos):
         p = {k: int(prep[k][x]) for k in prep}
         for k in PREP32:
