@@ -13,13 +13,13 @@ from test_gpu_fuzz import weird_region
 from util import run_region
 
 
-def traced_score(lib, R, all_out=False, tumor_keys=None):
+def traced_score(lib, R, all_out=False, tumor_keys=None, is_amplicon=False):
     """(records dict, list of per-record input dicts) of one score call."""
     lib.dll.uvc_oracle_score_trace_names.restype = C.c_char_p
     names = lib.dll.uvc_oracle_score_trace_names().decode().split(";")[:-1]
-    rec = R.score(all_out=all_out, tumor_keys=tumor_keys)
+    rec = R.score(all_out=all_out, tumor_keys=tumor_keys, is_amplicon=is_amplicon)
     n = len(rec["refpos"])
-    req, _keep = R.make_request(all_out, -1, -1, False, None, tumor_keys, False, False, 0, kept_only=False)
+    req, _keep = R.make_request(all_out, -1, -1, is_amplicon, None, tumor_keys, False, False, 0, kept_only=False)
     buf = np.zeros(n * len(names), dtype=np.float64)
     buf2 = np.zeros(n * 6, dtype=np.float64)
     nv = C.c_int64()
