@@ -90,14 +90,18 @@ def replayed_traffic(kernel, tile_kb, depth):
 
 
 def valu_issue(kernel, kernel_ms, args):
-    """What actually bounds the kernel: the share of the chip's VALU issue slots it uses (1024 SIMDs, one wave64 VALU instruction per 4
-    cycles, 2.4 GHz max clock), from the replayed SQ_INSTS_VALU count and this run's duration."""
+    """What actually bounds the kernel: the share of the chip's VALU issue rate it uses, from the replayed SQ_INSTS_VALU count and this
+    run's duration.  Two denominators: the hardware peak (1024 SIMD-32s, a wave64 VALU instruction every 2 cycles, 2.4 GHz max clock --
+    MI355X_MICROARCH.md) and what scripts/ubench/issue_model.hip sustains on this chip with >= 2 waves per SIMD (3.0 cycles per
+    instruction at the nominal clock; the scalar instructions of the same loops, ~0.6 per vector one, issue beside them at 4.35)."""
     n = replayed_valu(kernel, args.tile_kb, args.depth)
     if not n or not kernel_ms:
         return None
-    slots = 1024 * (kernel_ms * 1e-3) * 2.4e9 / 4.0
-    return {"valu_wave_instructions_per_launch": n, "frac_of_issue_slots": n / slots, "clock_assumed_ghz": 2.4,
-            "source": "SQ_INSTS_VALU replayed from profiles/traffic_latest.json; the kernel is bound by instruction issue, not by HBM bytes (DESIGN.md section 6a)"}
+    simd_cycles = 1024 * (kernel_ms * 1e-3) * 2.4e9
+    return {"valu_wave_instructions_per_launch": n, "frac_of_peak_issue_rate": n * 2.0 / simd_cycles, "frac_of_measured_issue_rate": n * 3.0 / simd_cycles,
+            "clock_assumed_ghz": 2.4,
+            "source": "SQ_INSTS_VALU replayed from profiles/traffic_latest.json; the kernel is bound by instruction issue (vector + scalar pipes), "
+                      "not by HBM bytes (DESIGN.md section 6a)"}
 
 
 def replayed_valu(kernel, tile_kb, depth):
