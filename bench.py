@@ -345,9 +345,13 @@ def main():
     side_tiles = tiles[n_main:]
     tiles = tiles[:n_main]
     import torch
+    # rehearsal of the N-rank path on a one-GPU box: UVC_BENCH_DEVICE puts every rank on one device, UVC_BENCH_CLOCK_BACKEND=gloo keeps the
+    # barrier / max-over-ranks off RCCL (which refuses two ranks on one device); a real run sets neither
+    if os.environ.get("UVC_BENCH_DEVICE"):
+        local_rank = int(os.environ["UVC_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    clock = shard.Clock(backend="nccl")
+    clock = shard.Clock(backend=os.environ.get("UVC_BENCH_CLOCK_BACKEND", "nccl"))
     from uvc_amd import region
     lib = region.gpu_lib()
     rc = lib.dll.uvcgpu_init(local_rank)
