@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/chain_*.npz: fuzzed reads + the per-position planes of the accumulate path computed by the chain of INDEPENDENT
+Python restatements (tests/rtr_cases.py -> prep_restatement.py -> p2_restatement.py / segbias_restatement.py -> p3_restatement.py ->
+p45_restatement.py), each written from the reference text.  No library is loaded here: neither the oracle nor the HIP library produces a
+number in these files, and the parameters come from tests/golden/params_default.json (the reference's own defaults, dumped by
+oracle/ref_params_dump.cpp from CmdLineArgs.hpp as it lies) with CommandLineArgs::selfUpdateByPlatform applied in Python.
+
+tests/test_chain_golden.py holds the oracle (CPU suite) and the HIP path (-m gpu) to these planes, bit for bit.
+Run from the repo root:  python tests/golden/make_chain_golden.py     (about ten seconds)
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from uvc_amd import region  # noqa: E402  (apply_platform: plain attribute arithmetic, no library)
+from rtr_cases import python_tracks  # noqa: E402
+from prep_restatement import PREP32, PREP64, THRES, prep_sets, thres_sets  # noqa: E402
+from p2_restatement import update_by_aln  # noqa: E402
+from segbias_restatement import SEG_FIELDS  # noqa: E402
+from p3_restatement import fragment_pass  # noqa: E402
+from p45_restatement import FAM, FI32, FI64, family_passes  # noqa: E402
+from gather_restatement import Planes, gather  # noqa: E402
+from score_restatement import calc_DPv, calc_qual, sum_DPv  # noqa: E402
+from test_gpu_fuzz import weird_region  # noqa: E402
+
+CASES = {
+    "chain_illumina_umi": dict(seed=61, n_frag=110, ref_len=410, umi=True, platform=1, normal=0),
+    "chain_illumina_plain": dict(seed=62, n_frag=130, ref_len=450, umi=False, platform=1, normal=0),
+    "chain_iontorrent_umi_normal": dict(seed=63, n_frag=100, ref_len=390, umi=True, platform=2, normal=1),
+    "chain_illumina_umi_deep": dict(seed=64, n_frag=600, ref_len=520, umi=True, platform=1, normal=0),
+    "chain_iontorrent_plain": dict(seed=65, n_frag=140, ref_len=430, umi=False, platform=2, normal=0),
+}
+READ_KEYS = ("pos", "mpos", "isize", "flag", "mapq", "nm", "l_qseq", "seq_off", "cigar_off", "n_cigar", "frag_id", "fam_id", "fam_strand", "fam_dflag", "bases", "quals", "cigars")
+VQ_ORDER = ("a1BQf", "a1BQr", "a2BQf", "a2BQr", "bMQ", "bIAQb", "bIADb", "bIDQb", "cIAQf", "cIADf", "cIDQf", "cIAQr", "cIADr", "cIDQr")   # enum of include/uvcgpu.h
+
+
+def params_for(platform, normal):
+    P = types.SimpleNamespace(**json.load(open(os.path.join(ROOT, "tests", "golden", "params_default.json"))))
+    region.apply_platform(P, platform, 150, 60)
+    P.tumor_vcf_is_provided = normal
+    return P
+
+
+def i32(a):
+    a = np.asarray(a).astype(np.int64)
+    return (((a + 2 ** 31) % 2 ** 32) - 2 ** 31).astype(np.int32)
+
+
+def chain_planes(reads, P, platform, normal):
+    proton = (platform == 2)
+    rtr, baq = python_tracks(reads["refseq"], smax=P.indel_str_repeatsize_max, vmax=P.indel_vntr_repeatsize_max, bq_max=P.indel_BQ_max,
+                             slip_rate=P.indel_polymerase_slip_rate, del_to_ins=P.indel_del_to_ins_err_ratio, polymerase_size=P.indel_polymerase_size,
+                             str_phred_per_region=P.indel_str_phred_per_region, nonstr_phred_per_base=P.indel_nonSTR_phred_per_base)
+    codes = np.array([{"A": 0, "C": 1, "G": 2, "T": 3}.get(c.upper(), 4) for c in reads["refseq"]], dtype=np.int32)
+    prep = prep_sets(reads, P, rtr, baq[0], np.append(codes, 4))
+    thres, ip = thres_sets(prep, rtr[3], P, is_normal=bool(normal), iontorrent=proton)
+    seg, bqsum = update_by_aln(reads, P, rtr, ip, baq[0], baq[1], codes, prep, thres, proton)
+    frag, vq3 = fragment_pass(reads, P, rtr, ip, baq[0], codes, prep, thres, seg, bqsum, proton)
+    famp, fi, dup, vq45 = family_passes(reads, P, rtr, ip, baq[0], baq[1], codes, prep, thres, proton=proton)
+    vq = dict(vq3); vq.update(vq45)
+    for name in SEG_FIELDS[34:38]:
+        vq[name] = seg[name]
+    rtr_after = np.array(rtr, dtype=np.int64); rtr_after[3] = ip       # UVC_F_RTR: the tracks AFTER P1b edited indelphred
+    return {
+        "PREP32": np.stack([i32(prep[n]) for n in PREP32]), "PREP64": np.stack([np.asarray(prep[n], dtype=np.int64) for n in PREP64]),
+        "THRES": np.stack([i32(thres[n]) for n in THRES]),
+        "SEG32": np.stack([i32(seg[n]) for n in SEG_FIELDS[:30]]), "SEG64": np.stack([np.asarray(seg[n], dtype=np.int64) for n in SEG_FIELDS[30:34]]),
+        "VQ": np.stack([i32(vq[n]) for n in VQ_ORDER]), "BQSUM": i32(bqsum),
+        "FRAG": np.stack([np.stack([i32(frag[st][f]) for f in range(3)]) for st in range(2)]),
+        "FAM": np.stack([np.stack([i32(famp[st][k]) for k in range(len(FAM))]) for st in range(2)]),
+        "FAMINFO32": np.stack([i32(fi[n]) for n in FI32]), "FAMINFO64": np.stack([np.asarray(fi[n], dtype=np.int64) for n in FI64]),
+        "DUPLEX": np.stack([i32(dup[k]) for k in range(2)]),
+        "RTR": i32(rtr_after), "BAQ": np.stack([np.asarray(baq[0], dtype=np.int64), np.asarray(baq[1], dtype=np.int64)]),
+    }
+
+
+GATHERED = ("refsymbol", "DP", "AD", "bDP", "bAD", "c2DP", "c2AD", "bDPa", "cDP0a", "a2BQf", "a2BQr", "aBQ", "aBQQ", "bMQ")
+MARGIN = 3   # positions next to the region's ends are left out: which of them a library scores is its caller's business (main.cpp:608, 643)
+
+
+def chain_records(planes, reads, P):
+    """The scored records of every base symbol (A C G T N and the padded-deletion symbol) at every inner position, all-out: gather
+    (BcfFormat_symboltype_init / _symbol_init / fill_symbol_VQ_fmts) -> calc_DPv -> sum_DPv over the six records of the position -> calc_qual,
+    all by the independent restatements, from the chain's own planes.  A base symbol's record takes bDPa / cDP0a from its own depths
+    (main.cpp:810-817, 897) and has no InDel string; the InDel arms of calc_qual are not entered."""
+    pl = Planes(lambda g: planes[g])
+    npos, beg = planes["RTR"].shape[1], int(reads["beg"])
+    codes = np.array([{"A": 0, "C": 1, "G": 2, "T": 3}.get(c.upper(), 4) for c in reads["refseq"]], dtype=np.int32)
+    rows = {}
+    def put(k, v): rows.setdefault(k, []).append(int(v))
+    for x in range(MARGIN, npos - 1 - MARGIN):
+        group = []
+        for sym in range(6):
+            d = gather(pl, x, sym, codes, P, False, npos)
+            d.update(bDPa=d["bDPf"] + d["bDPr"], cDP0a=max(d["cDP1f"], d["cDP12f"]) + max(d["cDP1r"], d["cDP12r"]), gapSa_len=0, refpos=beg + x,
+                     tki_tier2=0, tpfa_dpv=-1.0, tpfa_qual=-1.0)
+            group.append(d)
+        outs = [calc_DPv(d, P) for d in group]
+        sums = sum_DPv(outs, list(range(6)))
+        for d, o in zip(group, outs):
+            q = calc_qual(d, o, sums, (0, 0, 0, 0, 0, 0), P)
+            put("refpos", d["refpos"]); put("symbol", d["symbol"])
+            for k in GATHERED: put(k, d[k])
+            put("nPF0", o["nPF"][0]); put("nPF1", o["nPF"][1])
+            for k in ("bNMa", "bNMb", "bNMQ", "FTS", "tier2", "cDP1v", "cDP1w", "cDP1x", "cDP2v", "cDP2w", "cDP2x"): put(k, o[k])
+            for i, v in enumerate(o["nNFA"]): put("nNFA%d" % i, v)
+            for i, v in enumerate(o["nAFA"]): put("nAFA%d" % i, v)
+            for i, v in enumerate(o["nBCFA"]): put("nBCFA%d" % i, v)
+            pct = [min(max(int(v), 0), 255) for v in o["FTSpct"]] + [0]          # 19 percentages, four per record field
+            for w in range(5): put("FTSpct%d" % w, sum(pct[4 * w + b] << (8 * b) for b in range(4)))
+            for t, k in enumerate(("CDP1v", "CDP1w", "CDP1x", "CDP2v", "CDP2w", "CDP2x")):
+                put(k + "0", sums[0][t]); put(k + "1", sums[1][t])
+            for k, v in q.items(): put(k, v)
+    return {k: np.array(v, dtype=np.int64) for k, v in rows.items()}
+
+
+if __name__ == "__main__":
+    for name, kw in CASES.items():
+        reads = weird_region(kw["seed"], n_frag=kw["n_frag"], ref_len=kw["ref_len"], umi=kw["umi"])
+        P = params_for(kw["platform"], kw["normal"])
+        planes = chain_planes(reads, P, kw["platform"], kw["normal"])
+        out = {"planes__" + g: v for g, v in planes.items()}
+        recs = chain_records(planes, reads, P) if not kw["normal"] else {"refpos": np.zeros(0, dtype=np.int64)}   # a normal sample only scores what its tumor's keys name
+        out.update({"records__" + k: v for k, v in recs.items()})
+        for k in READ_KEYS:
+            out["reads__" + k] = np.asarray(reads[k])
+        out["meta"] = np.array(json.dumps(dict(tid=int(reads["tid"]), beg=int(reads["beg"]), end=int(reads["end"]), refseq=reads["refseq"], n_reads=int(reads["n_reads"]),
+                                               n_fams=int(reads["n_fams"]), platform=kw["platform"], normal=kw["normal"])))
+        path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+        np.savez_compressed(path, **out)
+        print(name, os.path.getsize(path) // 1024, "KiB", {g: (v.shape, int(np.abs(v.astype(np.float64)).sum())) for g, v in planes.items() if g in ("SEG32", "FAM", "DUPLEX")},
+              len(recs["refpos"]), "records x", len(recs), "fields")

@@ -1,0 +1,81 @@
+"""tests/golden/chain_*.npz: fuzzed reads + every per-position plane group of the accumulate path (rows a3 - a8) and the scored records of
+the base symbols (rows a13 - a17: 87 fields of gather, calc_DPv, sum_DPv, calc_qual) as computed by the chain of independent Python restatements (tests/golden/make_chain_golden.py: no library produced a number in these files; parameters from the
+reference's own defaults).  The oracle (CPU suite) and the HIP path through the C ABI (-m gpu) must both reproduce them bit for bit -- the
+one parity line of this repository whose expected values come from neither of the two."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from uvc_amd import region
+from util import INT_GROUPS, run_region
+from test_gpu_parity import EXACT_FIELDS, PCT_FIELDS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = ["chain_illumina_umi", "chain_illumina_plain", "chain_iontorrent_umi_normal", "chain_illumina_umi_deep", "chain_iontorrent_plain"]
+
+
+def load(name):
+    z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    reads = {k[len("reads__"):]: z[k] for k in z.files if k.startswith("reads__")}
+    reads.update(tid=meta["tid"], beg=meta["beg"], end=meta["end"], refseq=meta["refseq"], n_reads=meta["n_reads"], n_fams=meta["n_fams"])
+    return reads, meta, {k[len("planes__"):]: z[k] for k in z.files if k.startswith("planes__")}, {k[len("records__"):]: z[k] for k in z.files if k.startswith("records__")}
+
+
+def check(lib, name, exact_records):
+    reads, meta, planes, recs = load(name)
+    assert sorted(planes) == sorted(INT_GROUPS)
+    P = region.default_params(lib, platform=meta["platform"])
+    P.tumor_vcf_is_provided = meta["normal"]
+    R = run_region(lib, reads, params=P)
+    bad = {}
+    for g in INT_GROUPS:
+        got, want = R.fetch(g), planes[g]
+        assert got.shape == want.shape and got.dtype == want.dtype, (g, got.shape, want.shape, got.dtype, want.dtype)
+        if not np.array_equal(got, want):
+            idx = np.argwhere(got != want)
+            bad[g] = (len(idx), [(tuple(int(v) for v in i), int(got[tuple(i)]), int(want[tuple(i)])) for i in idx[:5]])
+    assert not bad, bad
+    if len(recs["refpos"]):
+        # the scored records of the base symbols, all-out: gather -> calc_DPv -> sum_DPv -> calc_qual of the restatements on the chain's planes
+        got = R.score(all_out=True)
+        at = {(int(p), int(s)): i for i, (p, s) in enumerate(zip(got["refpos"], got["symbol"])) if s <= 5}
+        assert len(at) == int((got["symbol"] <= 5).sum())                       # one record per (position, base symbol)
+        idx = np.array([at[(int(p), int(s))] for p, s in zip(recs["refpos"], recs["symbol"])])   # KeyError: a record the chain expects is missing
+        for k, want in recs.items():
+            g = got[k][idx].astype(np.int64)
+            d = np.abs(g - want)
+            if k.startswith("FTSpct") and not exact_records:
+                d = np.max([np.abs(((g >> s) & 0xFF) - ((want >> s) & 0xFF)) for s in (0, 8, 16, 24)], axis=0)
+            tol = 0 if (exact_records or k in EXACT_FIELDS) else (np.maximum(1, np.abs(want) // 100) if k in PCT_FIELDS else 1)
+            w = int(np.argmax(d - tol))
+            assert (d <= tol).all(), (k, int(recs["refpos"][w]), int(recs["symbol"][w]), int(g[w]), int(want[w]))
+    R.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_the_restatement_chain(name, oracle_lib):
+    check(oracle_lib, name, exact_records=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_gpu_reproduces_the_restatement_chain(name, gpu_lib):
+    check(gpu_lib, name, exact_records=False)      # quality fields within 1 Phred, x100 depths within 1 % (device libm), the rest exact
+
+
+def test_fixtures_are_what_the_generator_writes():
+    """The smallest fixture regenerated on the spot (pure Python, seconds): the committed file is the generator's output."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_chain_golden", os.path.join(ROOT, "tests", "golden", "make_chain_golden.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    assert sorted(mg.CASES) == sorted(CASES)
+    name = "chain_iontorrent_umi_normal"
+    kw = mg.CASES[name]
+    reads = mg.weird_region(kw["seed"], n_frag=kw["n_frag"], ref_len=kw["ref_len"], umi=kw["umi"])
+    planes = mg.chain_planes(reads, mg.params_for(kw["platform"], kw["normal"]), kw["platform"], kw["normal"])
+    _, _, gold, _ = load(name)
+    for g in INT_GROUPS:
+        assert np.array_equal(planes[g], gold[g]), g
