@@ -27,6 +27,7 @@ from p3_restatement import fragment_pass  # noqa: E402
 from p45_restatement import FAM, FI32, FI64, family_passes  # noqa: E402
 from gather_restatement import Planes, gather  # noqa: E402
 from score_restatement import calc_DPv, calc_qual, sum_DPv  # noqa: E402
+from test_call_cpu import germline, record_call  # noqa: E402  (the calling step: output_germline, NLODQ / TLODQ / QUAL / FILTER, main.cpp:990-1168)
 from test_gpu_fuzz import weird_region  # noqa: E402
 
 CASES = {
@@ -103,8 +104,18 @@ def chain_records(planes, reads, P):
             group.append(d)
         outs = [calc_DPv(d, P) for d in group]
         sums = sum_DPv(outs, list(range(6)))
-        for d, o in zip(group, outs):
-            q = calc_qual(d, o, sums, (0, 0, 0, 0, 0, 0), P)
+        quals = [calc_qual(d, o, sums, (0, 0, 0, 0, 0, 0), P) for d, o in zip(group, outs)]
+        refsym = int(group[0]["refsymbol"])
+        # the calling step on the six records of the position (tumor-only, all-out)
+        crecs = []
+        for d, o, q in zip(group, outs, quals):
+            r = dict(symbol=int(d["symbol"]), gVQ1=q["gVQ1"], CONTQ=q["CONTQ"], cDP0a=d["cDP0a"], cDP1v=o["cDP1v"], cDP1x=o["cDP1x"], cDP2x=o["cDP2x"], CDP1x0=sums[0][2], CDP2x0=sums[0][5],
+                     cVQ1=q["cVQ1"], cPCQ1=q["cPCQ1"], cVQ2=q["cVQ2"], cPCQ2=q["cPCQ2"], bNMQ=o["bNMQ"], bDP=d["bDP"], DP=d["DP"], gapSa_len=0)
+            crecs.append(r)
+        g = germline(P, refsym, crecs, False)
+        bd = lambda s_: pl.frag(0, "bDP", s_, x) + pl.frag(1, "bDP", s_, x)
+        abq2_tot = int(np.int32(sum(pl.seg("aBQ2", s_, x) for s_ in range(6))))
+        for d, o, q, r in zip(group, outs, quals, crecs):
             put("refpos", d["refpos"]); put("symbol", d["symbol"])
             for k in GATHERED: put(k, d[k])
             put("nPF0", o["nPF"][0]); put("nPF1", o["nPF"][1])
@@ -117,7 +128,15 @@ def chain_records(planes, reads, P):
             for t, k in enumerate(("CDP1v", "CDP1w", "CDP1x", "CDP2v", "CDP2w", "CDP2x")):
                 put(k + "0", sums[0][t]); put(k + "1", sums[1][t])
             for k, v in q.items(): put(k, v)
-    return {k: np.array(v, dtype=np.int64) for k, v in rows.items()}
+            put("vNLODQ", g["ret"])
+            for i, v in enumerate(g["GL4"]): put("GL4_%d" % i, v)
+            for i, v in enumerate(g["GST"]): put("GST%d" % i, v)
+            # per-record call values: meaningful where the record is written (the test compares them where the library says `out`)
+            c = record_call(P, r, g, bd(refsym), bd(r["symbol"]), pl.seg("aBQ2", r["symbol"], x), abq2_tot, None, crecs, True, False, refsym)
+            for k in ("vHGQ", "NLODQ", "NLODV", "TLODQ", "SomaticQ", "FILTER", "keep"): put("call__" + k, c[k])
+            for i in range(4): put("call__TNBQF%d" % i, c["TNBQF"][i]); put("call__TNCQF%d" % i, c["TNCQF"][i])
+            rows.setdefault("call__QUAL", []).append(float(c["QUAL"]))
+    return {k: np.array(v, dtype=(np.float64 if k == "call__QUAL" else np.int64)) for k, v in rows.items()}
 
 
 if __name__ == "__main__":
