@@ -27,6 +27,7 @@ from p3_restatement import fragment_pass  # noqa: E402
 from p45_restatement import FAM, FI32, FI64, family_passes  # noqa: E402
 from gather_restatement import Planes, gather  # noqa: E402
 from score_restatement import calc_DPv, calc_qual, sum_DPv  # noqa: E402
+from indel_alleles_restatement import DEL, INS, allele_rows, context, majority_alleles  # noqa: E402
 from test_call_cpu import germline, record_call  # noqa: E402  (the calling step: output_germline, NLODQ / TLODQ / QUAL / FILTER, main.cpp:990-1168)
 from test_gpu_fuzz import weird_region  # noqa: E402
 
@@ -62,13 +63,15 @@ def chain_planes(reads, P, platform, normal):
     prep = prep_sets(reads, P, rtr, baq[0], np.append(codes, 4))
     thres, ip = thres_sets(prep, rtr[3], P, is_normal=bool(normal), iontorrent=proton)
     seg, bqsum = update_by_aln(reads, P, rtr, ip, baq[0], baq[1], codes, prep, thres, proton)
-    frag, vq3 = fragment_pass(reads, P, rtr, ip, baq[0], codes, prep, thres, seg, bqsum, proton)
-    famp, fi, dup, vq45 = family_passes(reads, P, rtr, ip, baq[0], baq[1], codes, prep, thres, proton=proton)
+    alleles = {}
+    frag, vq3 = fragment_pass(reads, P, rtr, ip, baq[0], codes, prep, thres, seg, bqsum, proton, alleles=alleles)
+    famp, fi, dup, vq45 = family_passes(reads, P, rtr, ip, baq[0], baq[1], codes, prep, thres, proton=proton, alleles=alleles)
+    alleles.setdefault("bq", ({}, {}))
     vq = dict(vq3); vq.update(vq45)
     for name in SEG_FIELDS[34:38]:
         vq[name] = seg[name]
     rtr_after = np.array(rtr, dtype=np.int64); rtr_after[3] = ip       # UVC_F_RTR: the tracks AFTER P1b edited indelphred
-    return {
+    return alleles, {
         "PREP32": np.stack([i32(prep[n]) for n in PREP32]), "PREP64": np.stack([np.asarray(prep[n], dtype=np.int64) for n in PREP64]),
         "THRES": np.stack([i32(thres[n]) for n in THRES]),
         "SEG32": np.stack([i32(seg[n]) for n in SEG_FIELDS[:30]]), "SEG64": np.stack([np.asarray(seg[n], dtype=np.int64) for n in SEG_FIELDS[30:34]]),
@@ -81,61 +84,83 @@ def chain_planes(reads, P, platform, normal):
     }
 
 
-GATHERED = ("refsymbol", "DP", "AD", "bDP", "bAD", "c2DP", "c2AD", "bDPa", "cDP0a", "a2BQf", "a2BQr", "aBQ", "aBQQ", "bMQ")
+GATHERED = ("refsymbol", "DP", "bDP", "c2DP", "c2AD", "bDPa", "cDP0a", "gapSa_len", "a2BQf", "a2BQr", "aBQ", "aBQQ", "bMQ")
 MARGIN = 3   # positions next to the region's ends are left out: which of them a library scores is its caller's business (main.cpp:608, 643)
+LINK_SYMBOLS = (6, 12, 11, 10, 9, 8, 7, 13)   # SYMBOL_TYPE_TO_SYMBOLS[LINK_SYMBOL], main_conversion.hpp:399
 
 
-def chain_records(planes, reads, P):
-    """The scored records of every base symbol (A C G T N and the padded-deletion symbol) at every inner position, all-out: gather
-    (BcfFormat_symboltype_init / _symbol_init / fill_symbol_VQ_fmts) -> calc_DPv -> sum_DPv over the six records of the position -> calc_qual,
-    all by the independent restatements, from the chain's own planes.  A base symbol's record takes bDPa / cDP0a from its own depths
-    (main.cpp:810-817, 897) and has no InDel string; the InDel arms of calc_qual are not entered."""
-    pl = Planes(lambda g: planes[g])
-    npos, beg = planes["RTR"].shape[1], int(reads["beg"])
-    codes = np.array([{"A": 0, "C": 1, "G": 2, "T": 3}.get(c.upper(), 4) for c in reads["refseq"]], dtype=np.int32)
-    rows = {}
+def score_group(rows, pl, x, group, extra, P):
+    """calc_DPv -> sum_DPv -> calc_qual -> output_germline -> the per-record call values for the records of one (position, symbol type) group,
+    appended to `rows` (field -> list)."""
     def put(k, v): rows.setdefault(k, []).append(int(v))
+    outs = [calc_DPv(d, P) for d in group]
+    symbols = [int(d["symbol"]) for d in group]
+    sums = sum_DPv(outs, symbols)
+    quals = [calc_qual(d, o, sums, extra, P) for d, o in zip(group, outs)]
+    refsym = int(group[0]["refsymbol"])
+    crecs = [dict(symbol=int(d["symbol"]), gVQ1=q["gVQ1"], CONTQ=q["CONTQ"], cDP0a=d["cDP0a"], cDP1v=o["cDP1v"], cDP1x=o["cDP1x"], cDP2x=o["cDP2x"], CDP1x0=sums[0][2], CDP2x0=sums[0][5],
+                  cVQ1=q["cVQ1"], cPCQ1=q["cPCQ1"], cVQ2=q["cVQ2"], cPCQ2=q["cPCQ2"], bNMQ=o["bNMQ"], bDP=d["bDP"], DP=d["DP"], gapSa_len=d["gapSa_len"])
+             for d, o, q in zip(group, outs, quals)]
+    g = germline(P, refsym, crecs, False)
+    bd = lambda s_: pl.frag(0, "bDP", s_, x) + pl.frag(1, "bDP", s_, x)
+    type_syms = range(6) if refsym <= 5 else range(6, 14)
+    abq2_tot = int(np.int32(sum(pl.seg("aBQ2", s_, x) for s_ in type_syms)))
+    for d, o, q, r in zip(group, outs, quals, crecs):
+        put("refpos", d["refpos"]); put("symbol", d["symbol"])
+        for k in GATHERED: put(k, d[k])
+        put("nPF0", o["nPF"][0]); put("nPF1", o["nPF"][1])
+        for k in ("AD", "bAD", "bNMa", "bNMb", "bNMQ", "FTS", "tier2", "cDP1v", "cDP1w", "cDP1x", "cDP2v", "cDP2w", "cDP2x"): put(k, o[k])
+        for i, v in enumerate(o["nNFA"]): put("nNFA%d" % i, v)
+        for i, v in enumerate(o["nAFA"]): put("nAFA%d" % i, v)
+        for i, v in enumerate(o["nBCFA"]): put("nBCFA%d" % i, v)
+        pct = [min(max(int(v), 0), 255) for v in o["FTSpct"]] + [0]          # 19 percentages, four per record field
+        for w in range(5): put("FTSpct%d" % w, sum(pct[4 * w + b] << (8 * b) for b in range(4)))
+        for t, k in enumerate(("CDP1v", "CDP1w", "CDP1x", "CDP2v", "CDP2w", "CDP2x")):
+            put(k + "0", sums[0][t]); put(k + "1", sums[1][t])
+        for k, v in q.items(): put(k, v)
+        put("vNLODQ", g["ret"])
+        for i, v in enumerate(g["GL4"]): put("GL4_%d" % i, v)
+        for i, v in enumerate(g["GST"]): put("GST%d" % i, v)
+        # per-record call values: meaningful where the record is written (the test compares them where the library says `out`)
+        c = record_call(P, r, g, bd(refsym), bd(r["symbol"]), pl.seg("aBQ2", r["symbol"], x), abq2_tot, None, crecs, True, False, refsym)
+        for k in ("vHGQ", "NLODQ", "NLODV", "TLODQ", "SomaticQ", "FILTER", "keep"): put("call__" + k, c[k])
+        for i in range(4): put("call__TNBQF%d" % i, c["TNBQF"][i]); put("call__TNCQF%d" % i, c["TNCQF"][i])
+        rows.setdefault("call__QUAL", []).append(float(c["QUAL"]))
+
+
+def chain_records(planes, reads, P, rows_alleles):
+    """The scored records of every symbol at every inner position, all-out (tumor-only): gather (BcfFormat_symboltype_init / _symbol_init /
+    fill_symbol_VQ_fmts) -> calc_DPv -> sum_DPv over the records of the (position, symbol type) group -> calc_qual -> the calling step, all by
+    the independent restatements, from the chain's own planes and allele-keyed maps.  A base symbol's, LINK_M's or LINK_NN's record takes
+    bDPa / cDP0a from its own depths and has no InDel string (main.cpp:810-817, 897-903); an InDel symbol has one record per majority allele
+    (fill_by_indel_info + indel_get_majority, main.cpp:853-895), "<L..>" with zero depths when it has none."""
+    pl = Planes(lambda g: planes[g])
+    npos, beg, refseq = planes["RTR"].shape[1], int(reads["beg"]), reads["refseq"]
+    codes = np.array([{"A": 0, "C": 1, "G": 2, "T": 3}.get(c.upper(), 4) for c in refseq], dtype=np.int32)
+    rows = {}
     for x in range(MARGIN, npos - 1 - MARGIN):
-        group = []
-        for sym in range(6):
-            d = gather(pl, x, sym, codes, P, False, npos)
-            d.update(bDPa=d["bDPf"] + d["bDPr"], cDP0a=max(d["cDP1f"], d["cDP12f"]) + max(d["cDP1r"], d["cDP12r"]), gapSa_len=0, refpos=beg + x,
-                     tki_tier2=0, tpfa_dpv=-1.0, tpfa_qual=-1.0)
-            group.append(d)
-        outs = [calc_DPv(d, P) for d in group]
-        sums = sum_DPv(outs, list(range(6)))
-        quals = [calc_qual(d, o, sums, (0, 0, 0, 0, 0, 0), P) for d, o in zip(group, outs)]
-        refsym = int(group[0]["refsymbol"])
-        # the calling step on the six records of the position (tumor-only, all-out)
-        crecs = []
-        for d, o, q in zip(group, outs, quals):
-            r = dict(symbol=int(d["symbol"]), gVQ1=q["gVQ1"], CONTQ=q["CONTQ"], cDP0a=d["cDP0a"], cDP1v=o["cDP1v"], cDP1x=o["cDP1x"], cDP2x=o["cDP2x"], CDP1x0=sums[0][2], CDP2x0=sums[0][5],
-                     cVQ1=q["cVQ1"], cPCQ1=q["cPCQ1"], cVQ2=q["cVQ2"], cPCQ2=q["cPCQ2"], bNMQ=o["bNMQ"], bDP=d["bDP"], DP=d["DP"], gapSa_len=0)
-            crecs.append(r)
-        g = germline(P, refsym, crecs, False)
-        bd = lambda s_: pl.frag(0, "bDP", s_, x) + pl.frag(1, "bDP", s_, x)
-        abq2_tot = int(np.int32(sum(pl.seg("aBQ2", s_, x) for s_ in range(6))))
-        for d, o, q, r in zip(group, outs, quals, crecs):
-            put("refpos", d["refpos"]); put("symbol", d["symbol"])
-            for k in GATHERED: put(k, d[k])
-            put("nPF0", o["nPF"][0]); put("nPF1", o["nPF"][1])
-            for k in ("bNMa", "bNMb", "bNMQ", "FTS", "tier2", "cDP1v", "cDP1w", "cDP1x", "cDP2v", "cDP2w", "cDP2x"): put(k, o[k])
-            for i, v in enumerate(o["nNFA"]): put("nNFA%d" % i, v)
-            for i, v in enumerate(o["nAFA"]): put("nAFA%d" % i, v)
-            for i, v in enumerate(o["nBCFA"]): put("nBCFA%d" % i, v)
-            pct = [min(max(int(v), 0), 255) for v in o["FTSpct"]] + [0]          # 19 percentages, four per record field
-            for w in range(5): put("FTSpct%d" % w, sum(pct[4 * w + b] << (8 * b) for b in range(4)))
-            for t, k in enumerate(("CDP1v", "CDP1w", "CDP1x", "CDP2v", "CDP2w", "CDP2x")):
-                put(k + "0", sums[0][t]); put(k + "1", sums[1][t])
-            for k, v in q.items(): put(k, v)
-            put("vNLODQ", g["ret"])
-            for i, v in enumerate(g["GL4"]): put("GL4_%d" % i, v)
-            for i, v in enumerate(g["GST"]): put("GST%d" % i, v)
-            # per-record call values: meaningful where the record is written (the test compares them where the library says `out`)
-            c = record_call(P, r, g, bd(refsym), bd(r["symbol"]), pl.seg("aBQ2", r["symbol"], x), abq2_tot, None, crecs, True, False, refsym)
-            for k in ("vHGQ", "NLODQ", "NLODV", "TLODQ", "SomaticQ", "FILTER", "keep"): put("call__" + k, c[k])
-            for i in range(4): put("call__TNBQF%d" % i, c["TNBQF"][i]); put("call__TNCQF%d" % i, c["TNCQF"][i])
-            rows.setdefault("call__QUAL", []).append(float(c["QUAL"]))
+        for stype, symbols in ((0, range(6)), (1, LINK_SYMBOLS)):
+            group = []
+            ins_c = del_c = ins1_c = del1_c = 0
+            for sym in symbols:
+                base = gather(pl, x, sym, codes, P, False, npos)
+                bdepth = base["bDPf"] + base["bDPr"]
+                cdepth = max(base["cDP1f"], base["cDP12f"]) + max(base["cDP1r"], base["cDP12r"])
+                if sym in INS:
+                    ins_c += cdepth; ins1_c += cdepth if sym == 12 else 0
+                if sym in DEL:
+                    del_c += cdepth; del1_c += cdepth if sym == 9 else 0
+                if sym in INS or sym in DEL:
+                    alls = majority_alleles(rows_alleles, beg + x, sym, (base["bDPf"], base["bDPr"]))
+                else:
+                    alls = [(bdepth, cdepth, "")]
+                for b, c, text in alls:
+                    d = dict(base)
+                    d.update(bDPa=b, cDP0a=c, gapSa_len=len(text), refpos=beg + x, tki_tier2=0, tpfa_dpv=-1.0, tpfa_qual=-1.0)
+                    group.append(d)
+            # the InDel depths and the repeat context belong to the LINK position of the same loop iteration (main.cpp:608-640); base symbols do not read them
+            extra = (ins_c, del_c, ins1_c, del1_c) + context(refseq, x, int(P.indel_str_repeatsize_max)) if stype == 1 else (0, 0, 0, 0, 0, 0)
+            score_group(rows, pl, x, group, extra, P)
     return {k: np.array(v, dtype=(np.float64 if k == "call__QUAL" else np.int64)) for k, v in rows.items()}
 
 
@@ -143,9 +168,13 @@ if __name__ == "__main__":
     for name, kw in CASES.items():
         reads = weird_region(kw["seed"], n_frag=kw["n_frag"], ref_len=kw["ref_len"], umi=kw["umi"])
         P = params_for(kw["platform"], kw["normal"])
-        planes = chain_planes(reads, P, kw["platform"], kw["normal"])
+        alleles, planes = chain_planes(reads, P, kw["platform"], kw["normal"])
         out = {"planes__" + g: v for g, v in planes.items()}
-        recs = chain_records(planes, reads, P) if not kw["normal"] else {"refpos": np.zeros(0, dtype=np.int64)}   # a normal sample only scores what its tumor's keys name
+        arows = allele_rows(alleles, reads["refseq"], int(reads["beg"]))
+        keys = sorted(arows)
+        out["alleles__rows"] = np.array([[k[0], k[1], k[2], len(k[3])] + list(arows[k]) for k in keys], dtype=np.int64).reshape(len(keys), 8)   # refpos symbol strand len bAD1 cAD1 c2AD c2dAD
+        out["alleles__text"] = np.array(";".join(k[3] for k in keys))
+        recs = chain_records(planes, reads, P, arows) if not kw["normal"] else {"refpos": np.zeros(0, dtype=np.int64)}   # a normal sample only scores what its tumor's keys name
         out.update({"records__" + k: v for k, v in recs.items()})
         for k in READ_KEYS:
             out["reads__" + k] = np.asarray(reads[k])
@@ -154,4 +183,4 @@ if __name__ == "__main__":
         path = os.path.join(ROOT, "tests", "golden", name + ".npz")
         np.savez_compressed(path, **out)
         print(name, os.path.getsize(path) // 1024, "KiB", {g: (v.shape, int(np.abs(v.astype(np.float64)).sum())) for g, v in planes.items() if g in ("SEG32", "FAM", "DUPLEX")},
-              len(recs["refpos"]), "records x", len(recs), "fields")
+              len(recs["refpos"]), "records x", len(recs), "fields,", len(keys), "allele rows")

@@ -74,8 +74,10 @@ def infer_max_qual(max_qual, dec_qual, distr, totDP):
     return maxv, argAD, argBQ
 
 
-def fragment_pass(reads, P, rtr, indelphred, baq, codes, prep, thres, seg, bqsum, proton):
-    """-> (frag int64 [2][3][NSYM][npos] (bDP, bTA, bTB), vq {bMQ, bIAQb, bIADb, bIDQb: int64 [NSYM][npos]})."""
+def fragment_pass(reads, P, rtr, indelphred, baq, codes, prep, thres, seg, bqsum, proton, alleles=None):
+    """-> (frag int64 [2][3][NSYM][npos] (bDP, bTA, bTB), vq {bMQ, bIAQb, bIADb, bIDQb: int64 [NSYM][npos]}).
+    alleles (optional dict): gains "bq" = per strand {(symbol, position): {inserted text | deleted length: fragments}}, the allele-keyed maps of
+    symbol_to_frag_format_depth_sets (posToIndelToCount_updateByConsensus, main.hpp:2710-2717)."""
     beg = int(reads["beg"])
     npos = int(reads["end"]) - beg + 1
     frag = np.zeros((2, 3, NSYM, npos), dtype=np.int64)
@@ -98,9 +100,12 @@ def fragment_pass(reads, P, rtr, indelphred, baq, codes, prep, thres, seg, bqsum
         # fillTidBegEndFromAlns1: the end grows by one per alignment
         beg2, end2, normMQ = 2 ** 31 - 1, 0, 0
         evs = []
+        fmap = {}                                                # the fragment's own allele-keyed maps (incIns / incDel of its reads)
         for k in range(i, j):
-            ev, aln, _, _, _, _, _ = read_events(reads, k, P, rtr, indelphred, baq, codes, prep, thres, proton, with_bias=False)
+            ev, aln, _, _, _, _, gaps = read_events(reads, k, P, rtr, indelphred, baq, codes, prep, thres, proton, with_bias=False)
             evs.append(ev)
+            for gp, gs, gkey, gw in gaps:
+                d = fmap.setdefault((gs, gp), {}); d[gkey] = d.get(gkey, 0) + gw
             beg2 = min(beg2, aln["pos"]); end2 = max(end2, aln["endpos"]) + 1
             normMQ = max(normMQ, aln["qual"])
         tlen = end2 - beg2
@@ -129,6 +134,11 @@ def fragment_pass(reads, P, rtr, indelphred, baq, codes, prep, thres, seg, bqsum
                     bucket[x][con][pb] += 1
                 frag[strand][0][con][x] += 1
                 vq["bMQ"][con][x] += (normMQ * normMQ) // SQR_QUAL_DIV
+                if alleles is not None and LINK_M < con < LINK_NN:          # an InDel symbol: the fragment's majority allele gains one fragment
+                    d = fmap[(con, epos)]
+                    key = max(sorted(d), key=lambda kk: (d[kk], kk)) if len(d) > 1 else next(iter(d))   # indelToData_getMajority: ties to the larger key
+                    dst = alleles.setdefault("bq", ({}, {}))[strand].setdefault((con, epos), {})
+                    dst[key] = dst.get(key, 0) + 1
                 cov[e] |= 1
                 high = ((st == 0 or con_qual + 3 >= highBQ) if proton else (st == 1 or con_qual >= highBQ))
                 if symbols_mutated(refsymbol, con) and high:

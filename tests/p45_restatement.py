@@ -110,7 +110,7 @@ def families(reads):
     return out
 
 
-def family_passes(reads, P, rtr, ip, baq, baq2, codes, prep, thres, proton):
+def family_passes(reads, P, rtr, ip, baq, baq2, codes, prep, thres, proton, alleles=None):
     """-> (fam int64 [2][8][NSYM][npos], fi32 {name: [NSYM][npos]}, fi64 {...}, duplex [2][NSYM][npos], vq {cIAQf cIADf cIDQf cIAQr cIADr cIDQr})."""
     beg = int(reads["beg"]); npos = int(reads["end"]) - beg + 1
     famp = np.zeros((2, len(FAM), NSYM, npos), dtype=np.int64)
@@ -125,6 +125,13 @@ def family_passes(reads, P, rtr, ip, baq, baq2, codes, prep, thres, proton):
     excl_end = beg + npos
     F = {k: i for i, k in enumerate(FAM)}
     fams = families(reads)
+    # the region's allele-keyed maps per strand (optional): "fq" symbol_to_fam_format_depth_sets_2strand (main.hpp:3326-3336), "c2" pos2*2data_cDP2
+    # (main.hpp:3196-3206), "c2d" pos2*2data_c2dDP (main.hpp:3459-3469, 3535-3547)
+    amaps = None
+    if alleles is not None:
+        amaps = {k: (Cov(0, 0), Cov(0, 0)) for k in ("fq", "c2", "c2d")}
+        for k, v in amaps.items():
+            alleles[k] = (v[0].maps, v[1].maps)
 
     def B(p): return int(baq[p - beg])
     def B2(p): return int(baq2[p - beg])
@@ -190,6 +197,8 @@ def family_passes(reads, P, rtr, ip, baq, baq2, codes, prep, thres, proton):
                         continue
                     if good:
                         famp[strand][F["cDP2"]][cs][x] += 1
+                        if amaps is not None and (is_ins(cs) or is_del(cs)):
+                            amaps["c2"][strand].update_map_by_consensus(con, cs, epos, 1)
                         rbeg, rend = min(nsb_min, epos), max(nsb_max, epos)
                         if nonconf_middle and epos < r2l_med:
                             rend = max(min(l2r_med, r2l_med, rend), epos)
@@ -233,6 +242,8 @@ def family_passes(reads, P, rtr, ip, baq, baq2, codes, prep, thres, proton):
                                 fi[k2][cs][x] += v2
                     if int(P.fam_thres_dup2add) <= ct and cc * 100 >= ct * int(P.fam_thres_dup2perc):
                         famp[strand][F["cDP3"]][cs][x] += 1
+                    if amaps is not None and (is_ins(cs) or is_del(cs)):
+                        amaps["fq"][strand].update_map_by_consensus(con, cs, epos, 1)
                     subst = cs <= BASE_NN
                     flat = int(P.fam_thres_emperr_all_flat_snv if subst else P.fam_thres_emperr_all_flat_indel)
                     perc = int(P.fam_thres_emperr_con_perc_snv if subst else P.fam_thres_emperr_con_perc_indel)
@@ -278,6 +289,8 @@ def family_passes(reads, P, rtr, ip, baq, baq2, codes, prep, thres, proton):
                         famp[strand][F["cDP1"]][cs][x] += 1
                         if sscs and (not dscs) and tot_nfrags >= int(P.fam_thres_dup1add) and con_nfrags * 100 >= tot_nfrags * int(P.fam_thres_dup1perc):
                             famp[strand][F["cDPD"]][cs][x] += 1
+                            if amaps is not None and (is_ins(cs) or is_del(cs)):
+                                amaps["c2d"][strand].update_map_by_consensus(con, cs, epos, 1)
                         avgBQ = 1 if tot_nfrags == 0 else int(con_sum) // tot_nfrags
                         major = int(famp[strand][F["cDPM"]][cs][x]); minor = int(famp[strand][F["cDPm"]][cs][x])
                         pw = 1.0 / (minor + 1.0)
@@ -301,7 +314,11 @@ def family_passes(reads, P, rtr, ip, baq, baq2, codes, prep, thres, proton):
                         row = duplex.c[epos - duplex.beg]
                         cs, cc, ct = fill_consensus(row, LINK_M, LINK_NN, False) if st == 1 else fill_consensus(row, BASE_A, BASE_NN, False)
                         if ct > 0: dup[0][cs][x] += 1
-                        if ct > 1: dup[1][cs][x] += 1
+                        if ct > 1:
+                            dup[1][cs][x] += 1
+                            if amaps is not None and (is_ins(cs) or is_del(cs)):
+                                for s2 in (0, 1):
+                                    amaps["c2d"][s2].update_map_by_consensus(duplex, cs, epos, 1)
         for strand in (0, 1):
             sfx = "r" if strand else "f"
             for x in range(npos):

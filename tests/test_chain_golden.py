@@ -21,11 +21,12 @@ def load(name):
     meta = json.loads(str(z["meta"]))
     reads = {k[len("reads__"):]: z[k] for k in z.files if k.startswith("reads__")}
     reads.update(tid=meta["tid"], beg=meta["beg"], end=meta["end"], refseq=meta["refseq"], n_reads=meta["n_reads"], n_fams=meta["n_fams"])
-    return reads, meta, {k[len("planes__"):]: z[k] for k in z.files if k.startswith("planes__")}, {k[len("records__"):]: z[k] for k in z.files if k.startswith("records__")}
+    return (reads, meta, {k[len("planes__"):]: z[k] for k in z.files if k.startswith("planes__")}, {k[len("records__"):]: z[k] for k in z.files if k.startswith("records__")},
+            z["alleles__rows"], z["alleles__text"])
 
 
 def check(lib, name, exact_records):
-    reads, meta, planes, recs = load(name)
+    reads, meta, planes, recs, arows, z_text = load(name)
     assert sorted(planes) == sorted(INT_GROUPS)
     P = region.default_params(lib, platform=meta["platform"])
     P.tumor_vcf_is_provided = meta["normal"]
@@ -38,12 +39,43 @@ def check(lib, name, exact_records):
             idx = np.argwhere(got != want)
             bad[g] = (len(idx), [(tuple(int(v) for v in i), int(got[tuple(i)]), int(want[tuple(i)])) for i in idx[:5]])
     assert not bad, bad
+    # the InDel allele rows (what fill_by_indel_info reads: fragment, family, cDP2 and duplex support of every allele per strand)
+    want_rows = {}
+    texts = str(z_text).split(";") if len(arows) else []
+    for row, text in zip(arows, texts):
+        want_rows[(int(row[0]), int(row[1]), int(row[2]), text)] = tuple(int(v) for v in row[4:8])
+    got_rows = {}
+    for r in R.indel_alleles():
+        x = r["refpos"] - reads["beg"]
+        text = r["seq"] if r["seq"] is not None else reads["refseq"][x:x + r["len"]]
+        got_rows[(r["refpos"], r["symbol"], r["strand"], text)] = (r["bAD1"], r["cAD1"], r["c2AD"], r["c2dAD"])
+    assert got_rows == want_rows, sorted(set(got_rows.items()) ^ set(want_rows.items()))[:6]
     if len(recs["refpos"]):
-        # the scored records of the base symbols, all-out: gather -> calc_DPv -> sum_DPv -> calc_qual of the restatements on the chain's planes
+        # the scored records, all-out: gather -> calc_DPv -> sum_DPv -> calc_qual -> calling step of the restatements on the chain's planes.
+        # A symbol without InDel string has one record per position; the records of an InDel symbol (one per majority allele, order among equal
+        # bAD1^2 * length left open by the reference's std::sort) are matched in (length, bDPa, cDP0a) order.
         got = R.score(all_out=True)
-        at = {(int(p), int(s)): i for i, (p, s) in enumerate(zip(got["refpos"], got["symbol"])) if s <= 5}
-        assert len(at) == int((got["symbol"] <= 5).sum())                       # one record per (position, base symbol)
-        idx = np.array([at[(int(p), int(s))] for p, s in zip(recs["refpos"], recs["symbol"])])   # KeyError: a record the chain expects is missing
+        def order(rec):
+            key = np.stack([rec["refpos"].astype(np.int64), rec["symbol"].astype(np.int64), rec["gapSa_len"].astype(np.int64), rec["bDPa"].astype(np.int64), rec["cDP0a"].astype(np.int64)])
+            return np.lexsort(key[::-1])
+        og, ow = order(got), order(recs)
+        gk = {(int(got["refpos"][i]), int(got["symbol"][i])): None for i in og}
+        first = {}
+        for j, i in enumerate(og):
+            first.setdefault((int(got["refpos"][i]), int(got["symbol"][i])), j)
+        idx = []
+        seen = {}
+        for i in ow:
+            k = (int(recs["refpos"][i]), int(recs["symbol"][i]))
+            n = seen.get(k, 0); seen[k] = n + 1
+            idx.append(og[first[k] + n])                 # KeyError: a record the chain expects is missing
+        idx = np.array(idx)
+        recs = {k: v[ow] for k, v in recs.items()}
+        assert np.array_equal(got["refpos"][idx], recs["refpos"]) and np.array_equal(got["symbol"][idx], recs["symbol"])
+        cnt_g = {}
+        for i in og:
+            k = (int(got["refpos"][i]), int(got["symbol"][i])); cnt_g[k] = cnt_g.get(k, 0) + 1
+        assert all(cnt_g[k] == n for k, n in seen.items()), [(k, n, cnt_g[k]) for k, n in seen.items() if cnt_g[k] != n][:5]      # as many alleles per InDel symbol
         written = got["out"][idx] != 0
         assert written.sum() > 100
         for k, want in recs.items():
@@ -85,7 +117,7 @@ def test_fixtures_are_what_the_generator_writes():
     name = "chain_iontorrent_umi_normal"
     kw = mg.CASES[name]
     reads = mg.weird_region(kw["seed"], n_frag=kw["n_frag"], ref_len=kw["ref_len"], umi=kw["umi"])
-    planes = mg.chain_planes(reads, mg.params_for(kw["platform"], kw["normal"]), kw["platform"], kw["normal"])
-    _, _, gold, _ = load(name)
+    _, planes = mg.chain_planes(reads, mg.params_for(kw["platform"], kw["normal"]), kw["platform"], kw["normal"])
+    _, _, gold, _, _, _ = load(name)
     for g in INT_GROUPS:
         assert np.array_equal(planes[g], gold[g]), g

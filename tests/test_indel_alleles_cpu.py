@@ -53,3 +53,45 @@ def test_rows_and_alleles_of_one_insertion_site(oracle_lib):
     all_rows = R.indel_alleles()
     got = [(all_rows[i]["seq"], int(b)) for i, b in zip(rec["gapSa"][m], rec["bDPa"][m])]
     assert got == want and rec["cDP0a"][m].tolist() == [v for _, v in want] and rec["gapSa_len"][m].tolist() == [len(s) for s, _ in want]
+
+
+def test_allele_rows_against_the_independent_restatements(oracle_lib):
+    """Every row fill_by_indel_info reads (fragment, family, cDP2 and duplex support of every allele, per strand) on fuzzed reads: the oracle's
+    tables against the allele-keyed maps of the restated fragment and family passes (tests/p3_restatement.py, tests/p45_restatement.py,
+    tests/indel_alleles_restatement.py), chained behind the other restatements -- no oracle value enters."""
+    import importlib.util, os
+    from rtr_cases import python_tracks
+    from prep_restatement import prep_sets, thres_sets
+    from p2_restatement import update_by_aln
+    from p3_restatement import fragment_pass
+    from p45_restatement import family_passes
+    from indel_alleles_restatement import allele_rows
+    from util import run_region
+    spec = importlib.util.spec_from_file_location("fz_alleles", os.path.join(os.path.dirname(__file__), "test_gpu_fuzz.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    n_rows = 0
+    for seed, umi, platform in ((71, True, 1), (72, False, 1), (73, True, 2)):
+        reads = fz.weird_region(seed, n_frag=150, ref_len=420, umi=umi)
+        P = region.default_params(oracle_lib, platform=platform)
+        R = run_region(oracle_lib, reads, params=P)
+        rtr, baq = python_tracks(reads["refseq"], smax=P.indel_str_repeatsize_max, vmax=P.indel_vntr_repeatsize_max, bq_max=P.indel_BQ_max,
+                                 slip_rate=P.indel_polymerase_slip_rate, del_to_ins=P.indel_del_to_ins_err_ratio, polymerase_size=P.indel_polymerase_size,
+                                 str_phred_per_region=P.indel_str_phred_per_region, nonstr_phred_per_base=P.indel_nonSTR_phred_per_base)
+        codes = np.array([{"A": 0, "C": 1, "G": 2, "T": 3}.get(c.upper(), 4) for c in reads["refseq"]], dtype=np.int32)
+        prep = prep_sets(reads, P, rtr, baq[0], np.append(codes, 4))
+        proton = (platform == 2)
+        thres, ip = thres_sets(prep, rtr[3], P, is_normal=False, iontorrent=proton)
+        seg, bqsum = update_by_aln(reads, P, rtr, ip, baq[0], baq[1], codes, prep, thres, proton)
+        al = {}
+        fragment_pass(reads, P, rtr, ip, baq[0], codes, prep, thres, seg, bqsum, proton, alleles=al)
+        family_passes(reads, P, rtr, ip, baq[0], baq[1], codes, prep, thres, proton=proton, alleles=al)
+        want = allele_rows(al, reads["refseq"], reads["beg"])
+        got = {}
+        for r in R.indel_alleles():
+            x = r["refpos"] - reads["beg"]
+            text = r["seq"] if r["seq"] is not None else reads["refseq"][x:x + r["len"]]
+            got[(r["refpos"], r["symbol"], r["strand"], text)] = (r["bAD1"], r["cAD1"], r["c2AD"], r["c2dAD"])
+        assert got == want, sorted(set(got.items()) ^ set(want.items()))[:6]
+        n_rows += len(want)
+        R.close()
+    assert n_rows > 1000
