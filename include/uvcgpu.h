@@ -342,10 +342,10 @@ const char *uvcgpu_version(void);
  * [beg, end + 1), i.e. npos = end - beg + 1 positions, exactly like Symbol2CountCoverageSet(tid, beg, end + 1). */
 int uvcgpu_region_create(uvcgpu_region_t **out, const UvcParams *params,
                          int32_t tid, int32_t beg, int32_t end, const char *refseq);
-/* Copies the reads to the device (the caller keeps ownership of its buffers). */
 /* Re-binds the handle to another region (the next tile of a stream of tiles): as destroy + create, but the streams and, when the new
  * region is not longer than the longest one the handle has held, the device buffers are kept -- no hipMalloc / hipFree per tile. */
 int uvcgpu_region_reset(uvcgpu_region_t *r, int32_t tid, int32_t beg, int32_t end, const char *refseq);
+/* Copies the reads to the device (the caller keeps ownership of its buffers). */
 int uvcgpu_region_set_reads(uvcgpu_region_t *r, const UvcReadSoA *reads);
 /* The same for columns that are already in HBM: every pointer of `reads` is a device pointer (on the handle's device), nothing is copied.
  * The arrays must stay valid and unchanged until the handle gets other reads, is reset or destroyed; uvcgpu_region_correct_bq then edits
