@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""GPU-box helper (not a test of the suite): the fuzz comparison of tests/test_gpu_fuzz.py::test_weird_reads over many more seeds and shapes
+for a given number of seconds -- planes bit for bit, InDel allele rows, all-out records in the tolerance classes, handles reused across
+regions of different length.  Prints one line per failure and a summary; exit code 1 if anything differed.
+    python3 scripts/gpu_soak.py SECONDS [FIRST_SEED]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+from uvc_amd import _ffi, region  # noqa: E402
+from util import diff_groups  # noqa: E402
+from test_gpu_fuzz import weird_region  # noqa: E402
+from test_gpu_parity import compare_records  # noqa: E402
+
+budget, seed = float(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+glib = region.gpu_lib(); assert glib.dll.uvcgpu_init(0) == 0
+olib = _ffi.Lib(__import__("oracle").library_path(), "uvc_oracle_")
+handles = {}
+t0, n_ok, n_refused, fails = time.time(), 0, 0, []
+while time.time() - t0 < budget:
+    rng = np.random.default_rng(seed)
+    umi, platform, normal = bool(rng.integers(0, 2)), int(rng.choice([1, 1, 2])), 0
+    n_frag, ref_len = int(rng.choice([40, 150, 260, 600, 1500])), int(rng.choice([200, 450, 700, 1300, 4100]))
+    reads = weird_region(seed, n_frag=n_frag, ref_len=ref_len, umi=umi)
+    out = []
+    for name, lib in (("oracle", olib), ("gpu", glib)):
+        P = region.default_params(lib, platform=platform)
+        P.fam_flag = int(rng.integers(0, 2)) if name == "oracle" else out_fam_flag
+        out_fam_flag = P.fam_flag
+        try:
+            key = (name, platform, P.fam_flag)
+            R = handles.get(key)
+            if R is None or name == "oracle":
+                R = region.Region(lib, P, reads["tid"], reads["beg"], reads["end"], reads["refseq"])
+                if name == "gpu": handles[key] = R
+            else:
+                R.reset(reads["tid"], reads["beg"], reads["end"], reads["refseq"].encode())      # a handle that has held other regions
+            R.set_reads(reads)
+            if seed % 2: R.correct_bq()
+            R.accumulate(); R.fetch("PREP32")
+            out.append(R)
+        except region.UvcError as e:
+            out.append(e.code)
+    o, g = out
+    try:
+        if isinstance(o, int) or isinstance(g, int):
+            assert o == g, ("refusal", o, g)
+            n_refused += 1
+        else:
+            bad = diff_groups(o, g)
+            assert not bad, {k: v[0] for k, v in bad.items()}
+            assert o.indel_alleles() == g.indel_alleles(), "allele rows"
+            compare_records(o.score(all_out=True), g.score(all_out=True))
+            compare_records(o.score(all_out=False), g.score(all_out=False))
+            n_ok += 1
+    except AssertionError as e:
+        fails.append(seed); print("FAIL seed", seed, dict(umi=umi, platform=platform, n_frag=n_frag, ref_len=ref_len), str(e)[:300], flush=True)
+    if not isinstance(o, int): o.close()
+    seed += 1
+    if (n_ok + n_refused + len(fails)) % 50 == 0:
+        print("... %d regions, %.0f s" % (n_ok + n_refused + len(fails), time.time() - t0), flush=True)
+print("soak: %d regions equal, %d refused by both, %d FAILED %s in %.0f s" % (n_ok, n_refused, len(fails), fails[:20], time.time() - t0))
+sys.exit(1 if fails else 0)
