@@ -2,7 +2,8 @@
 """GPU-box helper (not a test of the suite): the fuzz comparison of tests/test_gpu_fuzz.py::test_weird_reads over many more seeds and shapes
 for a given number of seconds -- planes bit for bit, InDel allele rows, all-out records in the tolerance classes, handles reused across
 regions of different length.  Prints one line per failure and a summary; exit code 1 if anything differed.
-    python3 scripts/gpu_soak.py SECONDS [FIRST_SEED]"""
+    python3 scripts/gpu_soak.py SECONDS [FIRST_SEED] [fuzz|synth]
+synth: regions of the synthetic generator (2 .. 8 kb at 20 .. 1500x, UMI / duplex, error / InDel / clip rates up to 30 times the defaults)."""
 import os
 import sys
 import time
@@ -10,12 +11,13 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
-from uvc_amd import _ffi, region  # noqa: E402
+from uvc_amd import _ffi, region, synth  # noqa: E402
 from util import diff_groups  # noqa: E402
 from test_gpu_fuzz import weird_region  # noqa: E402
 from test_gpu_parity import compare_records  # noqa: E402
 
 budget, seed = float(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+mode = sys.argv[3] if len(sys.argv) > 3 else "fuzz"
 glib = region.gpu_lib(); assert glib.dll.uvcgpu_init(0) == 0
 olib = _ffi.Lib(__import__("oracle").library_path(), "uvc_oracle_")
 handles = {}
@@ -24,7 +26,14 @@ while time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
     umi, platform, normal = bool(rng.integers(0, 2)), int(rng.choice([1, 1, 2])), 0
     n_frag, ref_len = int(rng.choice([40, 150, 260, 600, 1500])), int(rng.choice([200, 450, 700, 1300, 4100]))
-    reads = weird_region(seed, n_frag=n_frag, ref_len=ref_len, umi=umi)
+    if mode == "synth":
+        depth = int(rng.choice([20, 60, 150, 300, 600, 1500])); ref_len = int(rng.choice([2000, 3000, 5000, 8000])) if depth <= 300 else int(rng.choice([1000, 2000]))
+        n_frag = depth
+        reads = synth.generate_region(seed=seed, region_len=ref_len, depth=depth, umi=umi, fam_mean=float(rng.choice([1.5, 4.0, 8.0])), duplex_frac=float(rng.choice([0.0, 0.6, 0.9])),
+                                      snv_every=int(rng.choice([150, 1000])), somatic_every=int(rng.choice([400, 10000])), indel_every=int(rng.choice([200, 800, 5000])),
+                                      err_rate=float(rng.choice([1e-3, 1e-2, 3e-2])), clip_frac=float(rng.choice([0.01, 0.1, 0.3])), dedup_by_position=bool(rng.integers(0, 2)))
+    else:
+        reads = weird_region(seed, n_frag=n_frag, ref_len=ref_len, umi=umi)
     out = []
     for name, lib in (("oracle", olib), ("gpu", glib)):
         P = region.default_params(lib, platform=platform)
@@ -60,7 +69,7 @@ while time.time() - t0 < budget:
         fails.append(seed); print("FAIL seed", seed, dict(umi=umi, platform=platform, n_frag=n_frag, ref_len=ref_len), str(e)[:300], flush=True)
     if not isinstance(o, int): o.close()
     seed += 1
-    if (n_ok + n_refused + len(fails)) % 50 == 0:
+    if (n_ok + n_refused + len(fails)) % (10 if mode == "synth" else 50) == 0:
         print("... %d regions, %.0f s" % (n_ok + n_refused + len(fails), time.time() - t0), flush=True)
 print("soak: %d regions equal, %d refused by both, %d FAILED %s in %.0f s" % (n_ok, n_refused, len(fails), fails[:20], time.time() - t0))
 sys.exit(1 if fails else 0)
