@@ -3,6 +3,8 @@
 for a given number of seconds -- planes bit for bit, InDel allele rows, all-out records in the tolerance classes, handles reused across
 regions of different length.  Prints one line per failure and a summary; exit code 1 if anything differed.
     python3 scripts/gpu_soak.py SECONDS [FIRST_SEED] [fuzz|synth]
+Half of the regions run under one of the parameter variants of tests/test_gpu_parity.py (primer gating, short reads, SSCS table, germline lines ...).
+tn: synth + the normal-sample pass of a T/N pair with tumor keys made from the tumor-only records.
 synth: regions of the synthetic generator (2 .. 8 kb at 20 .. 1500x, UMI / duplex, error / InDel / clip rates up to 30 times the defaults)."""
 import os
 import sys
@@ -14,7 +16,7 @@ import numpy as np  # noqa: E402
 from uvc_amd import _ffi, region, synth  # noqa: E402
 from util import diff_groups  # noqa: E402
 from test_gpu_fuzz import weird_region  # noqa: E402
-from test_gpu_parity import compare_records  # noqa: E402
+from test_gpu_parity import VARIANTS, compare_records, tumor_keys_from  # noqa: E402
 
 budget, seed = float(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 mode = sys.argv[3] if len(sys.argv) > 3 else "fuzz"
@@ -26,7 +28,9 @@ while time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
     umi, platform, normal = bool(rng.integers(0, 2)), int(rng.choice([1, 1, 2])), 0
     n_frag, ref_len = int(rng.choice([40, 150, 260, 600, 1500])), int(rng.choice([200, 450, 700, 1300, 4100]))
-    if mode == "synth":
+    variant = dict(VARIANTS[sorted(VARIANTS)[int(rng.integers(0, len(VARIANTS)))]]) if rng.random() < 0.5 else {}
+    if "platform" in variant: platform = variant["platform"]
+    if mode in ("synth", "tn"):
         depth = int(rng.choice([20, 60, 150, 300, 600, 1500])); ref_len = int(rng.choice([2000, 3000, 5000, 8000])) if depth <= 300 else int(rng.choice([1000, 2000]))
         n_frag = depth
         reads = synth.generate_region(seed=seed, region_len=ref_len, depth=depth, umi=umi, fam_mean=float(rng.choice([1.5, 4.0, 8.0])), duplex_frac=float(rng.choice([0.0, 0.6, 0.9])),
@@ -39,8 +43,10 @@ while time.time() - t0 < budget:
         P = region.default_params(lib, platform=platform)
         P.fam_flag = int(rng.integers(0, 2)) if name == "oracle" else out_fam_flag
         out_fam_flag = P.fam_flag
+        for k, v in variant.get("set", {}).items():
+            setattr(P, k, v)
         try:
-            key = (name, platform, P.fam_flag)
+            key = (name, platform, P.fam_flag, tuple(sorted(variant.get("set", {}).items())))
             R = handles.get(key)
             if R is None or name == "oracle":
                 R = region.Region(lib, P, reads["tid"], reads["beg"], reads["end"], reads["refseq"])
@@ -63,13 +69,27 @@ while time.time() - t0 < budget:
             assert not bad, {k: v[0] for k, v in bad.items()}
             assert o.indel_alleles() == g.indel_alleles(), "allele rows"
             compare_records(o.score(all_out=True), g.score(all_out=True))
-            compare_records(o.score(all_out=False), g.score(all_out=False))
+            ro = o.score(all_out=False)
+            compare_records(ro, g.score(all_out=False))
+            if mode == "tn" and len(ro["refpos"]) >= 4 and P.inferred_is_vcf_generated:
+                keys = tumor_keys_from(ro, every=int(rng.integers(1, 4)))
+                recs = []
+                for lib in (olib, glib):
+                    Pn = region.default_params(lib, platform=platform); Pn.fam_flag = out_fam_flag; Pn.tumor_vcf_is_provided = 1
+                    for k, v in variant.get("set", {}).items():
+                        setattr(Pn, k, v)
+                    Rn = region.Region(lib, Pn, reads["tid"], reads["beg"], reads["end"], reads["refseq"])
+                    Rn.set_reads(reads)
+                    if seed % 2: Rn.correct_bq()
+                    Rn.accumulate()
+                    recs.append(Rn.score(tumor_keys=keys)); Rn.close()
+                compare_records(recs[0], recs[1])
             n_ok += 1
     except AssertionError as e:
-        fails.append(seed); print("FAIL seed", seed, dict(umi=umi, platform=platform, n_frag=n_frag, ref_len=ref_len), str(e)[:300], flush=True)
+        fails.append(seed); print("FAIL seed", seed, dict(umi=umi, platform=platform, n_frag=n_frag, ref_len=ref_len, variant=variant), str(e)[:300], flush=True)
     if not isinstance(o, int): o.close()
     seed += 1
-    if (n_ok + n_refused + len(fails)) % (10 if mode == "synth" else 50) == 0:
+    if (n_ok + n_refused + len(fails)) % (50 if mode == "fuzz" else 10) == 0:
         print("... %d regions, %.0f s" % (n_ok + n_refused + len(fails), time.time() - t0), flush=True)
 print("soak: %d regions equal, %d refused by both, %d FAILED %s in %.0f s" % (n_ok, n_refused, len(fails), fails[:20], time.time() - t0))
 sys.exit(1 if fails else 0)
