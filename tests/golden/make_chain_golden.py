@@ -89,7 +89,7 @@ MARGIN = 3   # positions next to the region's ends are left out: which of them a
 LINK_SYMBOLS = (6, 12, 11, 10, 9, 8, 7, 13)   # SYMBOL_TYPE_TO_SYMBOLS[LINK_SYMBOL], main_conversion.hpp:399
 
 
-def score_group(rows, pl, x, group, extra, P):
+def score_group(rows, pl, x, group, extra, P, all_out=True):
     """calc_DPv -> sum_DPv -> calc_qual -> output_germline -> the per-record call values for the records of one (position, symbol type) group,
     appended to `rows` (field -> list)."""
     def put(k, v): rows.setdefault(k, []).append(int(v))
@@ -122,18 +122,20 @@ def score_group(rows, pl, x, group, extra, P):
         for i, v in enumerate(g["GL4"]): put("GL4_%d" % i, v)
         for i, v in enumerate(g["GST"]): put("GST%d" % i, v)
         # per-record call values: meaningful where the record is written (the test compares them where the library says `out`)
-        c = record_call(P, r, g, bd(refsym), bd(r["symbol"]), pl.seg("aBQ2", r["symbol"], x), abq2_tot, None, crecs, True, False, refsym)
+        c = record_call(P, r, g, bd(refsym), bd(r["symbol"]), pl.seg("aBQ2", r["symbol"], x), abq2_tot, None, crecs, all_out, False, refsym)
         for k in ("vHGQ", "NLODQ", "NLODV", "TLODQ", "SomaticQ", "FILTER", "keep"): put("call__" + k, c[k])
         for i in range(4): put("call__TNBQF%d" % i, c["TNBQF"][i]); put("call__TNCQF%d" % i, c["TNCQF"][i])
         rows.setdefault("call__QUAL", []).append(float(c["QUAL"]))
 
 
-def chain_records(planes, reads, P, rows_alleles):
-    """The scored records of every symbol at every inner position, all-out (tumor-only): gather (BcfFormat_symboltype_init / _symbol_init /
+def chain_records(planes, reads, P, rows_alleles, all_out=True):
+    """The scored records of every symbol at every inner position (tumor-only): gather (BcfFormat_symboltype_init / _symbol_init /
     fill_symbol_VQ_fmts) -> calc_DPv -> sum_DPv over the records of the (position, symbol type) group -> calc_qual -> the calling step, all by
     the independent restatements, from the chain's own planes and allele-keyed maps.  A base symbol's, LINK_M's or LINK_NN's record takes
     bDPa / cDP0a from its own depths and has no InDel string (main.cpp:810-817, 897-903); an InDel symbol has one record per majority allele
-    (fill_by_indel_info + indel_get_majority, main.cpp:853-895), "<L..>" with zero depths when it has none."""
+    (fill_by_indel_info + indel_get_majority, main.cpp:853-895), "<L..>" with zero depths when it has none.
+    all_out = False: the default gate of main.cpp:835-841 -- an ALT symbol needs min_altdp_thres fragments, the REF symbol as many non-REF
+    fragments of its type at the position; the sums of sum_DPv then run over the records that passed."""
     pl = Planes(lambda g: planes[g])
     npos, beg, refseq = planes["RTR"].shape[1], int(reads["beg"]), reads["refseq"]
     codes = np.array([{"A": 0, "C": 1, "G": 2, "T": 3}.get(c.upper(), 4) for c in refseq], dtype=np.int32)
@@ -142,14 +144,20 @@ def chain_records(planes, reads, P, rows_alleles):
         for stype, symbols in ((0, range(6)), (1, LINK_SYMBOLS)):
             group = []
             ins_c = del_c = ins1_c = del1_c = 0
+            type_bdp = sum(pl.frag(st, "bDP", s_, x) for st in (0, 1) for s_ in symbols)          # bDPcDP[0] of BcfFormat_symboltype_init
             for sym in symbols:
                 base = gather(pl, x, sym, codes, P, False, npos)
+                refsym = int(base["refsymbol"])
                 bdepth = base["bDPf"] + base["bDPr"]
                 cdepth = max(base["cDP1f"], base["cDP12f"]) + max(base["cDP1r"], base["cDP12r"])
                 if sym in INS:
                     ins_c += cdepth; ins1_c += cdepth if sym == 12 else 0
                 if sym in DEL:
                     del_c += cdepth; del1_c += cdepth if sym == 9 else 0
+                if not all_out:
+                    ref_bdepth = pl.frag(0, "bDP", refsym, x) + pl.frag(1, "bDP", refsym, x)
+                    if (refsym != sym and bdepth < int(P.min_altdp_thres)) or (refsym == sym and type_bdp - ref_bdepth < int(P.min_altdp_thres)):
+                        continue
                 if sym in INS or sym in DEL:
                     alls = majority_alleles(rows_alleles, beg + x, sym, (base["bDPf"], base["bDPr"]))
                 else:
@@ -158,9 +166,11 @@ def chain_records(planes, reads, P, rows_alleles):
                     d = dict(base)
                     d.update(bDPa=b, cDP0a=c, gapSa_len=len(text), refpos=beg + x, tki_tier2=0, tpfa_dpv=-1.0, tpfa_qual=-1.0)
                     group.append(d)
+            if not group:
+                continue
             # the InDel depths and the repeat context belong to the LINK position of the same loop iteration (main.cpp:608-640); base symbols do not read them
             extra = (ins_c, del_c, ins1_c, del1_c) + context(refseq, x, int(P.indel_str_repeatsize_max)) if stype == 1 else (0, 0, 0, 0, 0, 0)
-            score_group(rows, pl, x, group, extra, P)
+            score_group(rows, pl, x, group, extra, P, all_out)
     return {k: np.array(v, dtype=(np.float64 if k == "call__QUAL" else np.int64)) for k, v in rows.items()}
 
 
@@ -176,6 +186,8 @@ if __name__ == "__main__":
         out["alleles__text"] = np.array(";".join(k[3] for k in keys))
         recs = chain_records(planes, reads, P, arows) if not kw["normal"] else {"refpos": np.zeros(0, dtype=np.int64)}   # a normal sample only scores what its tumor's keys name
         out.update({"records__" + k: v for k, v in recs.items()})
+        gated = chain_records(planes, reads, P, arows, all_out=False) if not kw["normal"] else {"refpos": np.zeros(0, dtype=np.int64)}
+        out.update({"gated__" + k: v for k, v in gated.items()})
         for k in READ_KEYS:
             out["reads__" + k] = np.asarray(reads[k])
         out["meta"] = np.array(json.dumps(dict(tid=int(reads["tid"]), beg=int(reads["beg"]), end=int(reads["end"]), refseq=reads["refseq"], n_reads=int(reads["n_reads"]),
@@ -183,4 +195,4 @@ if __name__ == "__main__":
         path = os.path.join(ROOT, "tests", "golden", name + ".npz")
         np.savez_compressed(path, **out)
         print(name, os.path.getsize(path) // 1024, "KiB", {g: (v.shape, int(np.abs(v.astype(np.float64)).sum())) for g, v in planes.items() if g in ("SEG32", "FAM", "DUPLEX")},
-              len(recs["refpos"]), "records x", len(recs), "fields,", len(keys), "allele rows")
+              len(recs["refpos"]), "records x", len(recs), "fields,", len(gated["refpos"]), "under the default gate,", len(keys), "allele rows")

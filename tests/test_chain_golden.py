@@ -22,11 +22,59 @@ def load(name):
     reads = {k[len("reads__"):]: z[k] for k in z.files if k.startswith("reads__")}
     reads.update(tid=meta["tid"], beg=meta["beg"], end=meta["end"], refseq=meta["refseq"], n_reads=meta["n_reads"], n_fams=meta["n_fams"])
     return (reads, meta, {k[len("planes__"):]: z[k] for k in z.files if k.startswith("planes__")}, {k[len("records__"):]: z[k] for k in z.files if k.startswith("records__")},
-            z["alleles__rows"], z["alleles__text"])
+            z["alleles__rows"], z["alleles__text"], {k[len("gated__"):]: z[k] for k in z.files if k.startswith("gated__")})
+
+
+def compare_with_chain(got, recs, exact_records, all_out):
+    """Library records against the chain's.  A symbol without InDel string has one record per position; the records of an InDel symbol (one per
+    majority allele, order among equal bAD1^2 * length left open by the reference's std::sort) are matched in (length, bDPa, cDP0a) order."""
+    def order(rec):
+        key = np.stack([rec["refpos"].astype(np.int64), rec["symbol"].astype(np.int64), rec["gapSa_len"].astype(np.int64), rec["bDPa"].astype(np.int64), rec["cDP0a"].astype(np.int64)])
+        return np.lexsort(key[::-1])
+    inner = (got["refpos"] >= recs["refpos"].min()) & (got["refpos"] <= recs["refpos"].max())
+    og, ow = order(got), order(recs)
+    first, cnt_g = {}, {}
+    for j, i in enumerate(og):
+        k = (int(got["refpos"][i]), int(got["symbol"][i]))
+        first.setdefault(k, j); cnt_g[k] = cnt_g.get(k, 0) + 1
+    idx, seen = [], {}
+    for i in ow:
+        k = (int(recs["refpos"][i]), int(recs["symbol"][i]))
+        n = seen.get(k, 0); seen[k] = n + 1
+        assert k in first, ("a record the chain expects is missing", k)
+        idx.append(og[first[k] + n])
+    idx = np.array(idx)
+    recs = {k: v[ow] for k, v in recs.items()}
+    assert np.array_equal(got["refpos"][idx], recs["refpos"]) and np.array_equal(got["symbol"][idx], recs["symbol"])
+    assert all(cnt_g[k] == n for k, n in seen.items()), [(k, n, cnt_g[k]) for k, n in seen.items() if cnt_g[k] != n][:5]      # as many alleles per InDel symbol
+    extra_keys = [k for k in cnt_g if k not in seen and recs["refpos"].min() <= k[0] <= recs["refpos"].max()]
+    assert not extra_keys, ("records the chain does not expect", extra_keys[:5])          # the gate: exactly the chain's (position, symbol) set
+    written = got["out"][idx] != 0
+    assert written.sum() > (100 if all_out else 10)
+    is_ref = recs["symbol"] == recs["refsymbol"]
+    for k, want in recs.items():
+        sel = np.ones(len(idx), dtype=bool)
+        if k.startswith("call__"):                      # per-record values of the calling step: defined for the records that are written
+            k, sel = k[len("call__"):], written
+            if k == "keep" and not all_out:
+                sel = sel & ~is_ref                     # a REF record under the default gate is kept when a GERMLINE line is (main.cpp:1117): not restated here
+        if k == "QUAL":                                 # the record carries the bits of a float
+            q = got[k][idx].view(np.float32).astype(np.float64)
+            assert (np.abs(q - want)[sel] <= (1e-4 if exact_records else 1e-3) * np.maximum(1.0, np.abs(want[sel]))).all(), k
+            continue
+        g = got[k][idx].astype(np.int64)
+        d = np.abs(g - want)
+        if k.startswith("FTSpct") and not exact_records:
+            d = np.max([np.abs(((g >> s) & 0xFF) - ((want >> s) & 0xFF)) for s in (0, 8, 16, 24)], axis=0)
+        tol = 0 if (exact_records or k in EXACT_FIELDS) else (np.maximum(1, np.abs(want) // 100) if k in PCT_FIELDS else 1)
+        d = np.where(sel, d - tol, -1)
+        w = int(np.argmax(d))
+        assert d.max() <= 0, (k, all_out, int(recs["refpos"][w]), int(recs["symbol"][w]), int(g[w]), int(want[w]))
+    return len(idx)
 
 
 def check(lib, name, exact_records):
-    reads, meta, planes, recs, arows, z_text = load(name)
+    reads, meta, planes, recs, arows, z_text, gated = load(name)
     assert sorted(planes) == sorted(INT_GROUPS)
     P = region.default_params(lib, platform=meta["platform"])
     P.tumor_vcf_is_provided = meta["normal"]
@@ -51,49 +99,10 @@ def check(lib, name, exact_records):
         got_rows[(r["refpos"], r["symbol"], r["strand"], text)] = (r["bAD1"], r["cAD1"], r["c2AD"], r["c2dAD"])
     assert got_rows == want_rows, sorted(set(got_rows.items()) ^ set(want_rows.items()))[:6]
     if len(recs["refpos"]):
-        # the scored records, all-out: gather -> calc_DPv -> sum_DPv -> calc_qual -> calling step of the restatements on the chain's planes.
-        # A symbol without InDel string has one record per position; the records of an InDel symbol (one per majority allele, order among equal
-        # bAD1^2 * length left open by the reference's std::sort) are matched in (length, bDPa, cDP0a) order.
-        got = R.score(all_out=True)
-        def order(rec):
-            key = np.stack([rec["refpos"].astype(np.int64), rec["symbol"].astype(np.int64), rec["gapSa_len"].astype(np.int64), rec["bDPa"].astype(np.int64), rec["cDP0a"].astype(np.int64)])
-            return np.lexsort(key[::-1])
-        og, ow = order(got), order(recs)
-        gk = {(int(got["refpos"][i]), int(got["symbol"][i])): None for i in og}
-        first = {}
-        for j, i in enumerate(og):
-            first.setdefault((int(got["refpos"][i]), int(got["symbol"][i])), j)
-        idx = []
-        seen = {}
-        for i in ow:
-            k = (int(recs["refpos"][i]), int(recs["symbol"][i]))
-            n = seen.get(k, 0); seen[k] = n + 1
-            idx.append(og[first[k] + n])                 # KeyError: a record the chain expects is missing
-        idx = np.array(idx)
-        recs = {k: v[ow] for k, v in recs.items()}
-        assert np.array_equal(got["refpos"][idx], recs["refpos"]) and np.array_equal(got["symbol"][idx], recs["symbol"])
-        cnt_g = {}
-        for i in og:
-            k = (int(got["refpos"][i]), int(got["symbol"][i])); cnt_g[k] = cnt_g.get(k, 0) + 1
-        assert all(cnt_g[k] == n for k, n in seen.items()), [(k, n, cnt_g[k]) for k, n in seen.items() if cnt_g[k] != n][:5]      # as many alleles per InDel symbol
-        written = got["out"][idx] != 0
-        assert written.sum() > 100
-        for k, want in recs.items():
-            sel = np.ones(len(idx), dtype=bool)
-            if k.startswith("call__"):                      # per-record values of the calling step: defined for the records that are written
-                k, sel = k[len("call__"):], written
-            if k == "QUAL":                                 # the record carries the bits of a float
-                q = got[k][idx].view(np.float32).astype(np.float64)
-                assert (np.abs(q - want)[sel] <= (1e-4 if exact_records else 1e-3) * np.maximum(1.0, np.abs(want[sel]))).all(), k
-                continue
-            g = got[k][idx].astype(np.int64)
-            d = np.abs(g - want)
-            if k.startswith("FTSpct") and not exact_records:
-                d = np.max([np.abs(((g >> s) & 0xFF) - ((want >> s) & 0xFF)) for s in (0, 8, 16, 24)], axis=0)
-            tol = 0 if (exact_records or k in EXACT_FIELDS) else (np.maximum(1, np.abs(want) // 100) if k in PCT_FIELDS else 1)
-            d = np.where(sel, d - tol, -1)
-            w = int(np.argmax(d))
-            assert d.max() <= 0, (k, int(recs["refpos"][w]), int(recs["symbol"][w]), int(g[w]), int(want[w]))
+        # the scored records: gather -> calc_DPv -> sum_DPv -> calc_qual -> calling step of the restatements on the chain's planes, all-out and
+        # under the default gate (main.cpp:835-841)
+        assert compare_with_chain(R.score(all_out=True), recs, exact_records, True) > 2000
+        assert compare_with_chain(R.score(all_out=False), gated, exact_records, False) > 50
     R.close()
 
 
@@ -118,6 +127,6 @@ def test_fixtures_are_what_the_generator_writes():
     kw = mg.CASES[name]
     reads = mg.weird_region(kw["seed"], n_frag=kw["n_frag"], ref_len=kw["ref_len"], umi=kw["umi"])
     _, planes = mg.chain_planes(reads, mg.params_for(kw["platform"], kw["normal"]), kw["platform"], kw["normal"])
-    _, _, gold, _, _, _ = load(name)
+    _, _, gold, _, _, _, _ = load(name)
     for g in INT_GROUPS:
         assert np.array_equal(planes[g], gold[g]), g
