@@ -101,7 +101,8 @@ def score_group(rows, pl, x, group, extra, P, all_out=True):
     crecs = [dict(symbol=int(d["symbol"]), gVQ1=q["gVQ1"], CONTQ=q["CONTQ"], cDP0a=d["cDP0a"], cDP1v=o["cDP1v"], cDP1x=o["cDP1x"], cDP2x=o["cDP2x"], CDP1x0=sums[0][2], CDP2x0=sums[0][5],
                   cVQ1=q["cVQ1"], cPCQ1=q["cPCQ1"], cVQ2=q["cVQ2"], cPCQ2=q["cPCQ2"], bNMQ=o["bNMQ"], bDP=d["bDP"], DP=d["DP"], gapSa_len=d["gapSa_len"])
              for d, o, q in zip(group, outs, quals)]
-    g = germline(P, refsym, crecs, False)
+    tprov = bool(P.tumor_vcf_is_provided)
+    g = germline(P, refsym, crecs, tprov)
     bd = lambda s_: pl.frag(0, "bDP", s_, x) + pl.frag(1, "bDP", s_, x)
     type_syms = range(6) if refsym <= 5 else range(6, 14)
     abq2_tot = int(np.int32(sum(pl.seg("aBQ2", s_, x) for s_ in type_syms)))
@@ -122,7 +123,12 @@ def score_group(rows, pl, x, group, extra, P, all_out=True):
         for i, v in enumerate(g["GL4"]): put("GL4_%d" % i, v)
         for i, v in enumerate(g["GST"]): put("GST%d" % i, v)
         # per-record call values: meaningful where the record is written (the test compares them where the library says `out`)
-        c = record_call(P, r, g, bd(refsym), bd(r["symbol"]), pl.seg("aBQ2", r["symbol"], x), abq2_tot, None, crecs, all_out, False, refsym)
+        tk = d.get("tk")
+        if tprov:     # what the T/N arm of main.cpp:1081-1147 reads besides the record (does_fmt_imply_short_frag, the near-deletion depth)
+            r["short_frag"] = (pl.prep("a_LI", x) + pl.prep("a_RI", x)) < (pl.prep("a_LIDP", x) + pl.prep("a_RIDP", x)) * int(P.lib_wgs_min_avg_fraglen)
+            r["APDP0"], r["APDP2"] = pl.prep("a_dp", x), pl.prep("a_near_del_dp", x)
+        c = record_call(P, r, g, bd(refsym), bd(r["symbol"]), pl.seg("aBQ2", r["symbol"], x), abq2_tot, tk, crecs, all_out, False, refsym)
+        put("has_key", 1 if tk is not None else 0)
         for k in ("vHGQ", "NLODQ", "NLODV", "TLODQ", "SomaticQ", "FILTER", "keep"): put("call__" + k, c[k])
         for i in range(4): put("call__TNBQF%d" % i, c["TNBQF"][i]); put("call__TNCQF%d" % i, c["TNCQF"][i])
         rows.setdefault("call__QUAL", []).append(float(c["QUAL"]))
@@ -174,6 +180,69 @@ def chain_records(planes, reads, P, rows_alleles, all_out=True):
     return {k: np.array(v, dtype=(np.float64 if k == "call__QUAL" else np.int64)) for k, v in rows.items()}
 
 
+KEY_FIELDS = ("refpos", "symbol", "cDP1x", "CDP1x", "bDP", "BDP", "tier2", "indel_len", "cVQ1", "cPCQ1", "cDP2x", "CDP2x", "cVQ2", "cPCQ2", "bNMQ", "vHGQ", "tDP")   # UvcTumorKey
+
+
+def tumor_keys_from_chain(gated):
+    """A tumor-sample channel made from the chain's own tumor-only records under the default gate: every second record becomes a key
+    (one per (position, symbol); the InDel length is the record's)."""
+    keys, seen = [], set()
+    for i in range(0, len(gated["refpos"]), 2):
+        pos, sym = int(gated["refpos"][i]), int(gated["symbol"][i])
+        if (pos, sym) in seen:
+            continue
+        seen.add((pos, sym))
+        g = lambda k: int(gated[k][i])
+        keys.append((pos, sym, g("cDP1x"), g("CDP1x0"), g("bAD"), g("bDP"), g("tier2") | (i // 2 % 2), g("gapSa_len") if sym in INS or sym in DEL else 0,
+                     g("cVQ1"), g("cPCQ1"), g("cDP2x"), g("CDP2x0"), g("cVQ2"), g("cPCQ2"), g("bNMQ"), g("call__vHGQ"), g("DP") * (1 + 3 * (i % 3 == 0))))
+    return sorted(keys, key=lambda k: (k[0], k[1]))
+
+
+def chain_records_normal(planes, reads, P, rows_alleles, keys):
+    """The normal sample of a T/N pair (IS_PROVIDED(vcf_tumor_fname)): only positions that carry a tumor key are scored, every symbol of both
+    symbol types there (main.cpp:529-538, 843-845); a (position, symbol) with a key has one record per key with the key's tier-2 flag, tpfa and --
+    for an InDel -- the key's string length (main.cpp:849-903, 928-934, 985-986), the others are scored with tpfa = -1."""
+    pl = Planes(lambda g: planes[g])
+    npos, beg, refseq = planes["RTR"].shape[1], int(reads["beg"]), reads["refseq"]
+    codes = np.array([{"A": 0, "C": 1, "G": 2, "T": 3}.get(c.upper(), 4) for c in refseq], dtype=np.int32)
+    by = {}
+    for k in keys:
+        by[(k[0], k[1])] = dict(zip(KEY_FIELDS, k))
+    rows = {}
+    for pos in sorted({k[0] for k in keys}):
+        x = pos - beg
+        if not (MARGIN <= x < npos - 1 - MARGIN):
+            continue
+        for stype, symbols in ((0, range(6)), (1, LINK_SYMBOLS)):
+            group = []
+            ins_c = del_c = ins1_c = del1_c = 0
+            for sym in symbols:
+                base = gather(pl, x, sym, codes, P, False, npos)
+                bdepth = base["bDPf"] + base["bDPr"]
+                cdepth = max(base["cDP1f"], base["cDP12f"]) + max(base["cDP1r"], base["cDP12r"])
+                if sym in INS:
+                    ins_c += cdepth; ins1_c += cdepth if sym == 12 else 0
+                if sym in DEL:
+                    del_c += cdepth; del1_c += cdepth if sym == 9 else 0
+                tk = by.get((pos, sym))
+                if tk is not None:
+                    alls = [(bdepth, cdepth, "x" * tk["indel_len"] if (sym in INS or sym in DEL) else "")]
+                elif sym in INS or sym in DEL:
+                    alls = majority_alleles(rows_alleles, pos, sym, (base["bDPf"], base["bDPr"]))
+                else:
+                    alls = [(bdepth, cdepth, "")]
+                for b, c, text in alls:
+                    d = dict(base)
+                    d.update(bDPa=b, cDP0a=c, gapSa_len=len(text), refpos=pos, tki_tier2=(tk["tier2"] if tk else 0),
+                             tpfa_dpv=((tk["cDP1x"] + 1.0) / (tk["CDP1x"] + 2.0) if tk else -1.0), tpfa_qual=((tk["bDP"] + 0.5) / (tk["BDP"] + 1.0) if tk else -1.0))
+                    if tk is not None:
+                        d["tk"] = tk
+                    group.append(d)
+            extra = (ins_c, del_c, ins1_c, del1_c) + context(refseq, x, int(P.indel_str_repeatsize_max)) if stype == 1 else (0, 0, 0, 0, 0, 0)
+            score_group(rows, pl, x, group, extra, P, False)
+    return {k: np.array(v, dtype=(np.float64 if k == "call__QUAL" else np.int64)) for k, v in rows.items()}
+
+
 if __name__ == "__main__":
     for name, kw in CASES.items():
         reads = weird_region(kw["seed"], n_frag=kw["n_frag"], ref_len=kw["ref_len"], umi=kw["umi"])
@@ -181,13 +250,21 @@ if __name__ == "__main__":
         alleles, planes = chain_planes(reads, P, kw["platform"], kw["normal"])
         out = {"planes__" + g: v for g, v in planes.items()}
         arows = allele_rows(alleles, reads["refseq"], int(reads["beg"]))
-        keys = sorted(arows)
-        out["alleles__rows"] = np.array([[k[0], k[1], k[2], len(k[3])] + list(arows[k]) for k in keys], dtype=np.int64).reshape(len(keys), 8)   # refpos symbol strand len bAD1 cAD1 c2AD c2dAD
-        out["alleles__text"] = np.array(";".join(k[3] for k in keys))
+        akeys = sorted(arows)
+        out["alleles__rows"] = np.array([[k[0], k[1], k[2], len(k[3])] + list(arows[k]) for k in akeys], dtype=np.int64).reshape(len(akeys), 8)   # refpos symbol strand len bAD1 cAD1 c2AD c2dAD
+        out["alleles__text"] = np.array(";".join(k[3] for k in akeys))
         recs = chain_records(planes, reads, P, arows) if not kw["normal"] else {"refpos": np.zeros(0, dtype=np.int64)}   # a normal sample only scores what its tumor's keys name
         out.update({"records__" + k: v for k, v in recs.items()})
         gated = chain_records(planes, reads, P, arows, all_out=False) if not kw["normal"] else {"refpos": np.zeros(0, dtype=np.int64)}
         out.update({"gated__" + k: v for k, v in gated.items()})
+        if kw["normal"]:   # the tumor pass of the same reads (tumor parameters) gives the keys, the normal pass is scored on them
+            Pt = params_for(kw["platform"], 0)
+            al_t, planes_t = chain_planes(reads, Pt, kw["platform"], 0)
+            keys = tumor_keys_from_chain(chain_records(planes_t, reads, Pt, allele_rows(al_t, reads["refseq"], int(reads["beg"])), all_out=False))
+            nrecs = chain_records_normal(planes, reads, P, arows, keys)
+            out["normal__keys"] = np.array(keys, dtype=np.int64)
+            out.update({"normal__" + k: v for k, v in nrecs.items()})
+            print("   normal sample:", len(keys), "tumor keys,", len(nrecs["refpos"]), "records")
         for k in READ_KEYS:
             out["reads__" + k] = np.asarray(reads[k])
         out["meta"] = np.array(json.dumps(dict(tid=int(reads["tid"]), beg=int(reads["beg"]), end=int(reads["end"]), refseq=reads["refseq"], n_reads=int(reads["n_reads"]),
@@ -195,4 +272,4 @@ if __name__ == "__main__":
         path = os.path.join(ROOT, "tests", "golden", name + ".npz")
         np.savez_compressed(path, **out)
         print(name, os.path.getsize(path) // 1024, "KiB", {g: (v.shape, int(np.abs(v.astype(np.float64)).sum())) for g, v in planes.items() if g in ("SEG32", "FAM", "DUPLEX")},
-              len(recs["refpos"]), "records x", len(recs), "fields,", len(gated["refpos"]), "under the default gate,", len(keys), "allele rows")
+              len(recs["refpos"]), "records x", len(recs), "fields,", len(gated["refpos"]), "under the default gate,", len(akeys), "allele rows")

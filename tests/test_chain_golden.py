@@ -22,7 +22,8 @@ def load(name):
     reads = {k[len("reads__"):]: z[k] for k in z.files if k.startswith("reads__")}
     reads.update(tid=meta["tid"], beg=meta["beg"], end=meta["end"], refseq=meta["refseq"], n_reads=meta["n_reads"], n_fams=meta["n_fams"])
     return (reads, meta, {k[len("planes__"):]: z[k] for k in z.files if k.startswith("planes__")}, {k[len("records__"):]: z[k] for k in z.files if k.startswith("records__")},
-            z["alleles__rows"], z["alleles__text"], {k[len("gated__"):]: z[k] for k in z.files if k.startswith("gated__")})
+            z["alleles__rows"], z["alleles__text"], {k[len("gated__"):]: z[k] for k in z.files if k.startswith("gated__")},
+            ((z["normal__keys"], {k[len("normal__"):]: z[k] for k in z.files if k.startswith("normal__") and k != "normal__keys"}) if "normal__keys" in z.files else None))
 
 
 def compare_with_chain(got, recs, exact_records, all_out):
@@ -54,6 +55,9 @@ def compare_with_chain(got, recs, exact_records, all_out):
     is_ref = recs["symbol"] == recs["refsymbol"]
     for k, want in recs.items():
         sel = np.ones(len(idx), dtype=bool)
+        if k == "has_key":                              # (normal sample) the record was scored with its tumor key
+            assert np.array_equal(got["tkey"][idx] >= 0, want != 0), k
+            continue
         if k.startswith("call__"):                      # per-record values of the calling step: defined for the records that are written
             k, sel = k[len("call__"):], written
             if k == "keep" and not all_out:
@@ -74,7 +78,7 @@ def compare_with_chain(got, recs, exact_records, all_out):
 
 
 def check(lib, name, exact_records):
-    reads, meta, planes, recs, arows, z_text, gated = load(name)
+    reads, meta, planes, recs, arows, z_text, gated, normal = load(name)
     assert sorted(planes) == sorted(INT_GROUPS)
     P = region.default_params(lib, platform=meta["platform"])
     P.tumor_vcf_is_provided = meta["normal"]
@@ -103,6 +107,13 @@ def check(lib, name, exact_records):
         # under the default gate (main.cpp:835-841)
         assert compare_with_chain(R.score(all_out=True), recs, exact_records, True) > 2000
         assert compare_with_chain(R.score(all_out=False), gated, exact_records, False) > 50
+    if normal is not None:
+        # the normal sample of a T/N pair on tumor keys made from the chain's own tumor pass: only the keyed positions, every symbol there,
+        # the keyed records with the key's tier-2 flag / tpfa / InDel length, NLODQ and the somatic quality through the T/N arm
+        keys, nrecs = normal
+        got = R.score(tumor_keys=[tuple(int(v) for v in k) for k in keys])
+        assert set(got["refpos"].tolist()) == set(int(k[0]) for k in keys)
+        assert compare_with_chain(got, nrecs, exact_records, False) > 1000
     R.close()
 
 
@@ -127,6 +138,6 @@ def test_fixtures_are_what_the_generator_writes():
     kw = mg.CASES[name]
     reads = mg.weird_region(kw["seed"], n_frag=kw["n_frag"], ref_len=kw["ref_len"], umi=kw["umi"])
     _, planes = mg.chain_planes(reads, mg.params_for(kw["platform"], kw["normal"]), kw["platform"], kw["normal"])
-    _, _, gold, _, _, _, _ = load(name)
+    _, _, gold, _, _, _, _, _ = load(name)
     for g in INT_GROUPS:
         assert np.array_equal(planes[g], gold[g]), g
