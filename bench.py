@@ -4,16 +4,17 @@
   python bench.py --gpus N --steps K --warmup W
 
 A step = ONE TILE through the whole per-tile hot path, on a stream of DISTINCT synthetic chr20-shaped 300x non-UMI tiles (1 Mb each,
-`--tiles` of them, visited round-robin) whose raw UvcReadSoA columns and region side arrays are resident in HBM when the timed region
-starts:
+`--tiles` of them, visited round-robin) whose raw UvcReadSoA columns are resident in HBM when the timed region starts:
 
+    uvcgpu_region_reset              the region side arrays of the tile's own reference on the device (uvc_rtr.hip)
     uvcgpu_region_set_reads_device   the device half of set_reads: CIGAR facts + family / fragment nesting (uvc_prep.hip), the three
                                      radix orders, k_pack_bq, k_aln_prelude (updateByAln's per-read prelude), k_build_p2list
     uvcgpu_region_accumulate         P1 .. P5b
     uvcgpu_region_score              default-gate scoring + calling, D2H of the records
 
 Tiles are software-pipelined over their handles (the next tile's preparation and accumulate are enqueued before the synchronous score of
-the current one), which is how a caller streams chr20 through the library.  Every rank owns one GPU and its own tiles (different seeds):
+the current one; UVC_BENCH_VALUE_THREADS=n deals the tiles to n host threads instead), which is how a caller streams chr20 through the
+library.  Every rank owns one GPU and its own tiles (different seeds):
 regions shard with no data-path collective, scaling is weak.  value = ranks * tile positions * K / max-over-ranks wall time.
 `--gpus N` without a launcher starts its own N ranks (children are spawned before anything touches a GPU).
 
@@ -372,11 +373,13 @@ def main():
     input_bytes_tile = int(np.mean([sum(int(np.asarray(t[k]).nbytes) for k in COLS if t.get(k) is not None) for t in tiles]))
     prepare, finish, kernel_times = leg.prepare, leg.finish, leg.kernel_times
 
-    # UVC_BENCH_VALUE_THREADS=n: the timed stream dealt to n host threads (one tile each at a time) instead of the one-thread software pipeline.
-    # One host thread issues ~400 launches per tile (reset, read preparation with three count read-backs, accumulate, scoring) and waits in the
-    # preparation's read-backs while the device runs out of work: four threads make the device the bound (10.5 -> 9.7 ms per tile).  The default
-    # stays the one-thread pipeline because `roofline` divides by the dominant kernel's own duration on its stream, and with four tiles' kernels
-    # sharing the device that duration says little about the kernel; the four-thread rate is reported beside it as `resident_in_flight4`.
+    # UVC_BENCH_VALUE_THREADS=n: the timed stream dealt to n host threads, one tile each at a time, as uvc1-mi355x deals tiles to its workers,
+    # instead of the one-thread software pipeline.  One host thread issues ~400 launches per tile (reset, read preparation with three count
+    # read-backs, accumulate, scoring) and sits in the preparation's read-backs, so the preparations of successive tiles never overlap: on one
+    # box 9.67 ms per tile with one thread, 9.2-9.35 with two, 9.15 with three, 9.25 with four.  The default stays the one-thread pipeline:
+    # there the heavy kernels of successive tiles seldom meet on the device (k_p2_fast<base>: 1.61 ms +- 0.03 over the launches of a rocprofv3
+    # trace, the same as on an otherwise idle device), so `roofline`'s in-stream duration is the kernel's own and agrees with the committed
+    # trace; with two threads the same kernel spreads over 1.6 .. 3.3 ms.  The four-thread rate is reported beside `value` as `resident_in_flight4`.
     n_thr_value = max(1, min(int(os.environ.get("UVC_BENCH_VALUE_THREADS", "1")), T))
     def run_in_flight(k0, n_steps, n_thr, host=False, ktimes=None):
         import threading
