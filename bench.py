@@ -68,7 +68,7 @@ def algorithmic_bytes_per_position(kernel, depth):
 
 # bench kernel label -> name(s) in the rocprofv3 output (template instantiations; the default workload runs the PLAIN ones)
 PROFILE_NAMES = {"k_p2_fast_link": ("k_p2_fast<true, false, true>", "k_p2_fast<true, false, false>"), "k_p2_fast_base": ("k_p2_fast<false, true, true>", "k_p2_fast<false, true, false>"),
-                 "k_p2_slow_walk": ("k_p2_slow<true>",), "k_p2_slow_table": ("k_p2_slow<false>",), "k_frag": ("k_frag16<true>", "k_frag16<false>", "k_frag<true>", "k_frag<false>")}
+                 "k_prep_fast": ("k_prep_fast<false>", "k_prep_fast<true>"), "k_p2_slow_walk": ("k_p2_slow<true>",), "k_p2_slow_table": ("k_p2_slow<false>",), "k_frag": ("k_frag16<true>", "k_frag16<false>", "k_frag<true>", "k_frag<false>")}
 
 
 def replayed_traffic(kernel, tile_kb, depth):
@@ -548,6 +548,14 @@ def main():
             rd = resident["kernel_ms"].get(dom)
             if rd:
                 resident["roofline_frac"] = abytes / (rd * 1e-3) / 1e9 / HBM_PEAK_GBS
+            # the same figure for every kernel that has an entry in the algorithmic-bytes table, on its undisturbed duration (a small kernel whose
+            # inputs the kernel before it has just written reads them from the 256 MB Infinity Cache: k_thres' counter traffic is below its
+            # algorithmic bytes and its fraction of the HBM peak says little)
+            resident["roofline_by_kernel"] = {
+                k: {"kernel_ms": ms, "algorithmic_bytes_per_launch": algorithmic_bytes_per_position(k, args.depth) * npos_tile,
+                    "frac": round(algorithmic_bytes_per_position(k, args.depth) * npos_tile / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "traffic": replayed_traffic(k, args.tile_kb, args.depth)}
+                for k, ms in resident["kernel_ms"].items() if k in ("k_prep_fast", "k_thres", "k_p2_fast_link", "k_p2_fast_base", "k_frag", "k_p5b") and ms}
             out["resident"] = resident
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline(args.depth)
