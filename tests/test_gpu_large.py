@@ -21,6 +21,9 @@ LARGE = {
     # far more positions than reads, at least 65 536 fragments: the fragment-depth scan of the read preparation runs over npos + 1 elements
     # with the scratch sized for it (sized for the reads only it failed from ~4 positions per read on)
     "wgs_1mb_20x": dict(region_len=1_000_000, depth=20, seed=4444),
+    # 3 % base errors at 2000x: more than 65 535 fragments leave the fast fragment statistics for the sweep list whose length only the device
+    # knows (k_fragstat_overflow strides over it; found by scripts/gpu_soak.py, where a grid of 65 535 blocks left the rest with n_cov = 0)
+    "noisy_20kb_2000x": dict(region_len=20_000, depth=2000, seed=30105, err_rate=0.03, snv_every=150, somatic_every=400, indel_every=800, clip_frac=0.1, dedup_by_position=False),
 }
 
 

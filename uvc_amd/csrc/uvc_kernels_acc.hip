@@ -1580,16 +1580,19 @@ DEV void fragstat_sweep(const RegionDev &R, const UvcParams &P, int fi) {
 __global__ void __launch_bounds__(64) k_fragstat_sweep(RegionDev R, UvcParams P, const int32_t *list, const int32_t *n_dev, int n_host) {
     __shared__ uint8_t flag[SWEEP_MAXSPAN];
     __shared__ int tot[2];
-    const int t = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     const int n = (n_dev ? *n_dev : n_host);
-    if (t >= n) return;
-    const int fi = list[t];
-    const FragRec &f = R.frags[fi];
-    const int span = f.end - f.beg, nb = P.syserr_mut_region_n_bases;
+    const int nb = P.syserr_mut_region_n_bases;
     // spans beyond the LDS window are taken in chunks with a halo of nb positions either side (a mutation reaches nb positions far)
     const int step = SWEEP_MAXSPAN - 2 * nb;
-    if (step < 64) { if (lane == 0) atomicExch(R.err, UVCGPU_EUNSUPPORTED); return; }   // syserr_mut_region_n_bases beyond 2 000
+    if (step < 64) { if (lane == 0 && blockIdx.x < n) atomicExch(R.err, UVCGPU_EUNSUPPORTED); return; }   // syserr_mut_region_n_bases beyond 2 000
     const bool proton = (UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform);
+    // the list may be longer than the grid (the overflow form is launched before its length is known on the host): blocks stride over it
+    for (int t = blockIdx.x; t < n; t += gridDim.x) {
+    const int fi = list[t];
+    const FragRec &f = R.frags[fi];
+    const int span = f.end - f.beg;
+    __syncthreads();   // the previous fragment's totals have been read
     if (lane < 2) tot[lane] = 0;
     int cnt[NSYM];
     int n_cov = 0, n_near = 0;
@@ -1625,6 +1628,7 @@ __global__ void __launch_bounds__(64) k_fragstat_sweep(RegionDev R, UvcParams P,
     atomicAdd(&tot[0], n_cov); atomicAdd(&tot[1], n_near);
     __syncthreads();
     if (lane == 0) { R.frags[fi].n_cov = tot[0]; R.frags[fi].n_near = tot[1]; FragFast &ff = R.ffast[R.frag_rank[fi]]; ff.n_cov = tot[0]; ff.n_near = tot[1]; }
+    }
 }
 
 // M runs and special range of one alignment for k_frag; false when it has more than one InDel or a reference skip
