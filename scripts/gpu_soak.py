@@ -5,7 +5,7 @@ regions of different length.  Prints one line per failure and a summary; exit co
     python3 scripts/gpu_soak.py SECONDS [FIRST_SEED] [fuzz|synth]
 Half of the regions run under one of the parameter variants of tests/test_gpu_parity.py (primer gating, short reads, SSCS table, germline lines ...).
 tn: synth + the normal-sample pass of a T/N pair with tumor keys made from the tumor-only records.
-big: synth at 10 .. 90 kb and 100 .. 2000x.
+big: synth at 10 .. 90 kb and 100 .. 2000x.  deep: 1 .. 3 kb at 5 000 .. 70 000x.
 synth: regions of the synthetic generator (2 .. 8 kb at 20 .. 1500x, UMI / duplex, error / InDel / clip rates up to 30 times the defaults)."""
 import os
 import sys
@@ -31,10 +31,12 @@ while time.time() - t0 < budget:
     n_frag, ref_len = int(rng.choice([40, 150, 260, 600, 1500])), int(rng.choice([200, 450, 700, 1300, 4100]))
     variant = dict(VARIANTS[sorted(VARIANTS)[int(rng.integers(0, len(VARIANTS)))]]) if rng.random() < 0.5 else {}
     if "platform" in variant: platform = variant["platform"]
-    if mode in ("synth", "tn", "big"):
+    if mode in ("synth", "tn", "big", "deep"):
         depth = int(rng.choice([20, 60, 150, 300, 600, 1500])); ref_len = int(rng.choice([2000, 3000, 5000, 8000])) if depth <= 300 else int(rng.choice([1000, 2000]))
         if mode == "big":   # tens of kb: the non-split kernel forms, hundreds of windows, carries across the interval-sum blocks
             depth = int(rng.choice([100, 300, 1000, 2000])); ref_len = int(rng.choice([20000, 50000, 90000])) if depth <= 300 else int(rng.choice([10000, 20000]))
+        if mode == "deep":  # amplicon-like piles: up to 70 000 fragments on one position (the 16-bit bucket counters of k_frag16 end at 65 535)
+            depth = int(rng.choice([5000, 20000, 70000])); ref_len = int(rng.choice([1000, 1500])) if depth > 5000 else int(rng.choice([1000, 3000]))
         n_frag = depth
         reads = synth.generate_region(seed=seed, region_len=ref_len, depth=depth, umi=umi, fam_mean=float(rng.choice([1.5, 4.0, 8.0])), duplex_frac=float(rng.choice([0.0, 0.6, 0.9])),
                                       snv_every=int(rng.choice([150, 1000])), somatic_every=int(rng.choice([400, 10000])), indel_every=int(rng.choice([200, 800, 5000])),
