@@ -5,7 +5,7 @@ regions of different length.  Prints one line per failure and a summary; exit co
     python3 scripts/gpu_soak.py SECONDS [FIRST_SEED] [fuzz|synth]
 Half of the regions run under one of the parameter variants of tests/test_gpu_parity.py (primer gating, short reads, SSCS table, germline lines ...).
 tn: synth + the normal-sample pass of a T/N pair with tumor keys made from the tumor-only records.
-big: synth at 10 .. 90 kb and 100 .. 2000x.  deep: 1 .. 3 kb at 5 000 .. 70 000x.
+long: fuzzed reads of up to 3 000 bases.  big: synth at 10 .. 90 kb and 100 .. 2000x.  deep: 1 .. 3 kb at 5 000 .. 70 000x.
 synth: regions of the synthetic generator (2 .. 8 kb at 20 .. 1500x, UMI / duplex, error / InDel / clip rates up to 30 times the defaults)."""
 import os
 import sys
@@ -31,6 +31,17 @@ while time.time() - t0 < budget:
     n_frag, ref_len = int(rng.choice([40, 150, 260, 600, 1500])), int(rng.choice([200, 450, 700, 1300, 4100]))
     variant = dict(VARIANTS[sorted(VARIANTS)[int(rng.integers(0, len(VARIANTS)))]]) if rng.random() < 0.5 else {}
     if "platform" in variant: platform = variant["platform"]
+    # a few thresholds moved inside their plausible ranges (both libraries get the same values): arms that the defaults never take
+    TWEAK = dict(fam_thres_dup1add=(1, 4), fam_thres_dup1perc=(50, 101), fam_thres_dup2add=(2, 5), fam_thres_highBQ_snv=(0, 41), fam_thres_highBQ_indel=(0, 41),
+                 bias_thres_highBQ=(0, 41), bias_thres_highBAQ=(0, 40), bias_thres_interfering_indel=(3, 40), bias_thres_interfering_indel_BQ=(0, 41), bias_thres_BAQ1=(10, 60), bias_thres_BAQ2=(20, 80),
+                 syserr_mut_region_n_bases=(1, 60), min_altdp_thres=(1, 5), fam_flag=(0, 4), primerlen=(0, 31), primerlen2=(0, 41), indel_adj_tracklen_dist=(0, 12),
+                 indel_adj_indellen_perc=(100, 301), bq_phred_added_misma=(0, 12), bq_phred_added_indel=(0, 12), microadjust_padded_deletion_flag=(0, 4), central_readlen=(50, 300),
+                 bias_thres_PFBQ1=(10, 50), bias_thres_PFBQ2=(10, 60), fam_thres_emperr_all_flat_snv=(1, 6), fam_thres_emperr_con_perc_snv=(50, 101), bias_thres_strict_c2LRP0=(0, 20),
+                 bias_thres_aLPxT_add=(0, 12), microadjust_nobias_pos_indel_maxlen=(0, 30), fam_thres_qseqlen=(0, 120), bias_thres_aLRP1t_minus=(0, 20), syserr_minABQ_cap_snv=(0, 300))
+    tweaks = {}
+    if mode == "params" or rng.random() < 0.3:
+        for k in rng.choice(sorted(TWEAK), size=int(rng.integers(1, 6)), replace=False):
+            tweaks[str(k)] = int(rng.integers(*TWEAK[str(k)]))
     if mode in ("synth", "tn", "big", "deep"):
         depth = int(rng.choice([20, 60, 150, 300, 600, 1500])); ref_len = int(rng.choice([2000, 3000, 5000, 8000])) if depth <= 300 else int(rng.choice([1000, 2000]))
         if mode == "big":   # tens of kb: the non-split kernel forms, hundreds of windows, carries across the interval-sum blocks
@@ -41,6 +52,9 @@ while time.time() - t0 < budget:
         reads = synth.generate_region(seed=seed, region_len=ref_len, depth=depth, umi=umi, fam_mean=float(rng.choice([1.5, 4.0, 8.0])), duplex_frac=float(rng.choice([0.0, 0.6, 0.9])),
                                       snv_every=int(rng.choice([150, 1000])), somatic_every=int(rng.choice([400, 10000])), indel_every=int(rng.choice([200, 800, 5000])),
                                       err_rate=float(rng.choice([1e-3, 1e-2, 3e-2])), clip_frac=float(rng.choice([0.01, 0.1, 0.3])), dedup_by_position=bool(rng.integers(0, 2)))
+    elif mode == "long":   # reads of up to 3 000 reference bases with the fuzz generator's CIGAR shapes (M runs stay <= 40: dozens of InDels per read)
+        ref_len = int(rng.choice([1300, 4100, 9000])); n_frag = int(rng.choice([40, 150, 400]))
+        reads = weird_region(seed, n_frag=n_frag, ref_len=ref_len, umi=umi, lengths=(1, 5, 60, 150, 300, 700, 1500, 3000))
     else:
         reads = weird_region(seed, n_frag=n_frag, ref_len=ref_len, umi=umi)
     out = []
@@ -50,8 +64,11 @@ while time.time() - t0 < budget:
         out_fam_flag = P.fam_flag
         for k, v in variant.get("set", {}).items():
             setattr(P, k, v)
+        for k, v in tweaks.items():
+            setattr(P, k, v)
         try:
-            key = (name, platform, P.fam_flag, tuple(sorted(variant.get("set", {}).items())))
+            key = (name, platform, P.fam_flag, tuple(sorted(variant.get("set", {}).items())), tuple(sorted(tweaks.items())))
+            if name == "gpu" and tweaks and len(handles) > 64: handles.pop(next(iter(handles))).close()
             R = handles.get(key)
             if R is None or name == "oracle":
                 R = region.Region(lib, P, reads["tid"], reads["beg"], reads["end"], reads["refseq"])
@@ -83,6 +100,8 @@ while time.time() - t0 < budget:
                     Pn = region.default_params(lib, platform=platform); Pn.fam_flag = out_fam_flag; Pn.tumor_vcf_is_provided = 1
                     for k, v in variant.get("set", {}).items():
                         setattr(Pn, k, v)
+                    for k, v in tweaks.items():
+                        setattr(Pn, k, v)
                     Rn = region.Region(lib, Pn, reads["tid"], reads["beg"], reads["end"], reads["refseq"])
                     Rn.set_reads(reads)
                     if seed % 2: Rn.correct_bq()
@@ -91,7 +110,7 @@ while time.time() - t0 < budget:
                 compare_records(recs[0], recs[1])
             n_ok += 1
     except AssertionError as e:
-        fails.append(seed); print("FAIL seed", seed, dict(umi=umi, platform=platform, n_frag=n_frag, ref_len=ref_len, variant=variant), str(e)[:900], flush=True)
+        fails.append(seed); print("FAIL seed", seed, dict(umi=umi, platform=platform, n_frag=n_frag, ref_len=ref_len, variant=variant, tweaks=tweaks), str(e)[:900], flush=True)
     if not isinstance(o, int): o.close()
     seed += 1
     if (n_ok + n_refused + len(fails)) % (50 if mode == "fuzz" else 10) == 0:

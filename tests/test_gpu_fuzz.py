@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 M, I, D, N, S, H = 0, 1, 2, 3, 4, 5
 
 
-def weird_region(seed, n_frag=260, ref_len=700, beg=1_000_000, umi=False):
+def weird_region(seed, n_frag=260, ref_len=700, beg=1_000_000, umi=False, lengths=(1, 2, 5, 30, 60, 90, 120, 150)):
     rng = np.random.default_rng(seed)
     ref = rng.integers(0, 4, ref_len)
     for _ in range(6):                                   # homopolymers / STRs so that the InDel context code is exercised
@@ -39,7 +39,7 @@ def weird_region(seed, n_frag=260, ref_len=700, beg=1_000_000, umi=False):
             ops = []
             style = int(rng.integers(0, 10))
             ref_room = ref_len - 2 - start
-            target = int(min(ref_room, rng.choice([1, 2, 5, 30, 60, 90, 120, 150])))
+            target = int(min(ref_room, rng.choice(list(lengths))))
             if target < 1: target = 1
             if style == 0: ops = [(M, target)]
             else:
