@@ -481,3 +481,21 @@ def test_kept_only_records_are_the_groups_the_writer_reads(name, outvar, gpu_lib
     full_a, kept_a = R.score(all_out=True), R.score(all_out=True, kept_only=True)
     assert R.vcf_records("chr20", kept_a) == R.vcf_records("chr20", full_a) and len(kept_a["refpos"]) <= len(full_a["refpos"])
     R.close()
+
+
+@pytest.mark.gpu
+def test_symbolic_indel_alleles_are_written(oracle_lib, gpu_lib, ref_vcf):
+    """-A with a low --vqual writes the records of InDel symbols nobody carries: ALT and gapSa are the symbolic allele then (the fallback of
+    indel_get_majority, main.hpp:5417-5424).  Found by scripts/gpu_soak_vcf.py: gapSa used to be empty for them."""
+    from test_gpu_fuzz import weird_region
+    reads = weird_region(118, n_frag=60, ref_len=300)
+    R = []
+    for lib in (oracle_lib, gpu_lib):
+        P = region.default_params(lib, platform=2)
+        P.should_output_all_germline, P.vqual = 1, 5.0
+        r = region.Region(lib, P, reads["tid"], reads["beg"], reads["end"], reads["refseq"]); r.set_reads(reads); r.accumulate(); R.append(r)
+    mine = R[1].vcf_records("chrS", R[1].score(all_out=True)).splitlines()
+    want = _oracle_lines(oracle_lib, ref_vcf, R[0], "chrS", all_out=True)
+    sym = [l for l in want if l.split("\t")[4] in ("<LI1>", "<LI2>", "<LI3P>", "<LD1>", "<LD2>", "<LD3P>")]
+    assert len(sym) > 50 and all(("," + l.split("\t")[4]) in l.split("\t")[9] for l in sym)
+    compare_lines(mine, want)

@@ -555,7 +555,11 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
                     }
                 }
             }
-            // (an InDel whose length came from the caller without text -- UvcIndelAllele, or UvcTumorKey without tumor_ref_alt -- is written with its symbolic allele)
+            // an InDel record without an allele row -- a symbol nobody carries, scored under -A -- has the symbol's description as its string
+            // (indel_get_majority's fallback, main.hpp:5417-5424): in ALT and in gapSa.  (An InDel whose length came from the caller without text
+            // -- UvcIndelAllele, or UvcTumorKey without tumor_ref_alt, a state the reference cannot be in -- is written with the symbolic ALT and
+            // an empty gapSa.)
+            if (indel.empty() && (is_ins(symbol) || is_del(symbol)) && F(ia, UVC_O_tkey) < 0 && !(req && req->n_indel_alleles > 0)) indel = SYMBOL_DESC[symbol];
             // CHROM POS ID REF ALT
             int64_t vcfpos; std::string vref, valt;
             auto ref_at = [&](int64_t p) { return (p >= 0 && p < (int64_t)ref.size()) ? std::string(1, ref[(size_t)p]) : std::string("n"); };
