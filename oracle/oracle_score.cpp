@@ -1287,6 +1287,18 @@ int score(State &S, const UvcScoreRequest *req, std::vector<std::vector<i32>> &r
                 if (tprov) for (i64 q = 0; q < ntk; q++) if (tk[q].refpos == refpos && tk[q].symbol == symbol) {
                     UvcIndelAllele d = { refpos, symbol, bdepth, cdepth, (is_ins(symbol) || is_del(symbol)) ? tk[q].indel_len : 0 };
                     alleles.push_back(d); akeys.push_back(&tk[q]);
+                    // the InDel string of a rescued record is the tumor record's: REF / ALT without their common head (main.cpp:867-880); without the
+                    // strings (UvcScoreRequest::tumor_ref_alt == NULL, a state the reference cannot be in) the record keeps its symbolic allele
+                    std::string text;
+                    if ((is_ins(symbol) || is_del(symbol)) && req && req->tumor_ref_alt && req->tumor_ref_alt[q]) {
+                        const std::string ra = req->tumor_ref_alt[q];
+                        const size_t tab = ra.find('\t');
+                        if (tab != std::string::npos) {
+                            const std::string vr = ra.substr(0, tab), va = ra.substr(tab + 1);
+                            if (vr.size() > va.size()) text = vr.substr(va.size()); else if (va.size() > vr.size()) text = va.substr(vr.size());
+                        }
+                    }
+                    allele_rows.push_back(-1); allele_texts.push_back(text);
                 }
                 if (!alleles.empty()) {}
                 else if (is_ins(symbol) || is_del(symbol)) {

@@ -12,12 +12,13 @@ import numpy as np  # noqa: E402
 from uvc_amd import _ffi, region, synth  # noqa: E402
 from test_gpu_fuzz import weird_region  # noqa: E402
 from test_vcf_text import _load_ref_vcf, _oracle_lines, compare_lines  # noqa: E402
+from test_gpu_parity import tumor_keys_from  # noqa: E402
 
 budget, seed = float(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 1
 glib = region.gpu_lib(); assert glib.dll.uvcgpu_init(0) == 0
 olib = _ffi.Lib(__import__("oracle").library_path(), "uvc_oracle_")
 ref_vcf = _load_ref_vcf()
-t0, n_ok, n_lines, fails = time.time(), 0, 0, []
+t0, n_ok, n_lines, n_tn, fails = time.time(), 0, 0, 0, []
 while time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
     umi, platform, all_out = bool(rng.integers(0, 2)), int(rng.choice([1, 1, 2])), bool(rng.integers(0, 2))
@@ -41,6 +42,30 @@ while time.time() - t0 < budget:
         assert len(mine) == len(want), ("line count", len(mine), len(want))
         compare_lines(mine, want)
         n_ok += 1; n_lines += len(want)
+        if rng.random() < 0.4 and not all_out:
+            # the normal-sample pass of a T/N pair on keys made from these tumor-only records; InDel keys carry "REF\tALT" strings (rescued InDel
+            # records take their string from them, main.cpp:867-880)
+            ro = R[0].score(all_out=False)
+            keys = [k + (7 + i, 3 + i % 5, 2 * i) for i, k in enumerate(tumor_keys_from(ro, every=int(rng.integers(1, 4))))]
+            if len(keys) >= 2:
+                ras = []
+                for k in keys:
+                    ln = int(k[7])
+                    if 7 <= k[1] <= 9: ras.append("A" + "C" * max(ln, 1) + "\tA")
+                    elif 10 <= k[1] <= 12: ras.append("A\tA" + "G" * max(ln, 1))
+                    else: ras.append("A\tC")
+                RN = []
+                for lib in (olib, glib):
+                    P = region.default_params(lib, platform=platform); P.tumor_vcf_is_provided = 1
+                    for kk, v in sets.items(): setattr(P, kk, v)
+                    r = region.Region(lib, P, reads["tid"], reads["beg"], reads["end"], reads["refseq"]); r.set_reads(reads); r.accumulate(); RN.append(r)
+                rgn = RN[1].score(tumor_keys=keys)
+                mine = RN[1].vcf_records("chrS", rgn, tumor_keys=keys, tumor_ref_alt=ras).splitlines()
+                want = _oracle_lines(olib, ref_vcf, RN[0], "chrS", tumor_keys=keys, tumor_ref_alt=ras)
+                assert len(mine) == len(want), ("T/N line count", len(mine), len(want))
+                compare_lines(mine, want)
+                n_tn += 1; n_lines += len(want)
+                for r in RN: r.close()
         for r in R: r.close()
     except (AssertionError, ValueError, region.UvcError) as e:
         detail = ""
@@ -54,5 +79,5 @@ while time.time() - t0 < budget:
                 if detail: break
         fails.append(seed); print("FAIL seed", seed, dict(umi=umi, platform=platform, all_out=all_out, sets=sets), repr(e)[:300] + detail, flush=True)
     seed += 1
-print("vcf soak: %d regions (%d lines) equal, %d FAILED %s in %.0f s" % (n_ok, n_lines, len(fails), fails[:20], time.time() - t0))
+print("vcf soak: %d regions + %d normal-sample passes (%d lines) equal, %d FAILED %s in %.0f s" % (n_ok, n_tn, n_lines, len(fails), fails[:20], time.time() - t0))
 sys.exit(1 if fails else 0)

@@ -499,3 +499,26 @@ def test_symbolic_indel_alleles_are_written(oracle_lib, gpu_lib, ref_vcf):
     sym = [l for l in want if l.split("\t")[4] in ("<LI1>", "<LI2>", "<LI3P>", "<LD1>", "<LD2>", "<LD3P>")]
     assert len(sym) > 50 and all(("," + l.split("\t")[4]) in l.split("\t")[9] for l in sym)
     compare_lines(mine, want)
+
+
+@pytest.mark.gpu
+def test_rescued_indel_strings_in_record_and_germline_lines(oracle_lib, gpu_lib, ref_vcf):
+    """Normal sample of a T/N pair with GERMLINE lines on and the tumor records' "REF\\tALT" strings handed over: a rescued InDel record takes its
+    string from the tumor record (main.cpp:867-880) in its own line AND in the GERMLINE line that names it (LAST(fmt.gapSa), main.hpp:5625-5700).
+    Found by scripts/gpu_soak_vcf.py: the GERMLINE line used to carry the symbolic allele."""
+    from test_gpu_fuzz import weird_region
+    from test_gpu_parity import tumor_keys_from
+    reads = weird_region(1019, n_frag=260, ref_len=700, umi=False)
+    P0 = region.default_params(oracle_lib); P0.outvar_flag = 63
+    Rt = region.Region(oracle_lib, P0, reads["tid"], reads["beg"], reads["end"], reads["refseq"]); Rt.set_reads(reads); Rt.accumulate()
+    keys = [k + (7 + i, 3 + i % 5, 2 * i) for i, k in enumerate(tumor_keys_from(Rt.score(all_out=False), every=3))]
+    ras = [("A" + "C" * max(int(k[7]), 1) + "\tA") if 7 <= k[1] <= 9 else ("A\tA" + "G" * max(int(k[7]), 1)) if 10 <= k[1] <= 12 else "A\tC" for k in keys]
+    R = []
+    for lib in (oracle_lib, gpu_lib):
+        P = region.default_params(lib); P.tumor_vcf_is_provided, P.outvar_flag = 1, 63
+        r = region.Region(lib, P, reads["tid"], reads["beg"], reads["end"], reads["refseq"]); r.set_reads(reads); r.accumulate(); R.append(r)
+    mine = R[1].vcf_records("chrS", R[1].score(tumor_keys=keys), tumor_keys=keys, tumor_ref_alt=ras).splitlines()
+    want = _oracle_lines(oracle_lib, ref_vcf, R[0], "chrS", tumor_keys=keys, tumor_ref_alt=ras)
+    germ = [l.split("\t") for l in want if "GERMLINE" in l.split("\t")[7]]
+    assert any(len(c[3]) != len(c[4]) and not c[4].startswith("<") and set(c[3][1:] + c[4][1:]) <= set("CG") for c in germ), "no GERMLINE line with a rescued InDel string in this case"
+    compare_lines(mine, want)

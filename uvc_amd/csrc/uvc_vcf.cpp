@@ -498,6 +498,16 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
     int64_t npos = 0;
     const int32_t *rtr = uvcgpu_region_repeat_tracks(r, &npos);
     auto F = [&](int64_t i, int f) { return recs[(int64_t)f * stride + i]; };
+    // the InDel string a rescued record of the normal sample takes from its tumor record: REF / ALT without their common head (main.cpp:867-880)
+    auto rescued_text = [&](int64_t i) -> std::string {
+        const int32_t tk0 = F(i, UVC_O_tkey);
+        if (!(tref_alt && tkeys && tk0 >= 0 && tk0 < n_tkeys && tref_alt[tk0])) return std::string();
+        const std::string ra = tref_alt[tk0];
+        const size_t tab = ra.find('\t');
+        if (tab == std::string::npos) return std::string();
+        const std::string vr = ra.substr(0, tab), va = ra.substr(tab + 1);
+        return vr.size() > va.size() ? vr.substr(va.size()) : (va.size() > vr.size() ? va.substr(vr.size()) : std::string());
+    };
     // the records that are written, and the ref record of each
     std::vector<int64_t> kept, refrec;
     for (int64_t i = 0; i < n; i++) {
@@ -544,17 +554,7 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
             std::string indel;
             const int32_t garow = F(ia, UVC_O_gapSa);
             if (garow >= 0 && garow < (int32_t)G.rows.size()) indel = G.text(G.rows[(size_t)garow], ref, beg);
-            {   // a rescued InDel of the normal sample takes the tumor record's string: REF / ALT without their common head (main.cpp:867-880)
-                const int32_t tk0 = F(ia, UVC_O_tkey);
-                if (indel.empty() && (is_ins(symbol) || is_del(symbol)) && tref_alt && tkeys && tk0 >= 0 && tk0 < n_tkeys && tref_alt[tk0]) {
-                    const std::string ra = tref_alt[tk0];
-                    const size_t tab = ra.find('\t');
-                    if (tab != std::string::npos) {
-                        const std::string vr = ra.substr(0, tab), va = ra.substr(tab + 1);
-                        if (vr.size() > va.size()) indel = vr.substr(va.size()); else if (va.size() > vr.size()) indel = va.substr(vr.size());
-                    }
-                }
-            }
+            if (indel.empty() && (is_ins(symbol) || is_del(symbol))) indel = rescued_text(ia);
             // an InDel record without an allele row -- a symbol nobody carries, scored under -A -- has the symbol's description as its string
             // (indel_get_majority's fallback, main.hpp:5417-5424): in ALT and in gapSa.  (An InDel whose length came from the caller without text
             // -- UvcIndelAllele, or UvcTumorKey without tumor_ref_alt, a state the reference cannot be in -- is written with the symbolic ALT and
@@ -734,7 +734,12 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
                 auto allele_text = [&](int symbol, int q) -> std::string {
                     int seen = 0;
                     for (int64_t j = i0; j < i1; j++) if (F(j, UVC_O_symbol) == symbol) {
-                        if (seen++ == q) { const int32_t row = F(j, UVC_O_gapSa); return (row >= 0 && row < (int32_t)G.rows.size()) ? G.text(G.rows[(size_t)row], ref, beg) : std::string(SYMBOL_DESC[symbol]); }
+                        if (seen++ == q) {
+                            const int32_t row = F(j, UVC_O_gapSa);
+                            if (row >= 0 && row < (int32_t)G.rows.size()) return G.text(G.rows[(size_t)row], ref, beg);
+                            const std::string rt = rescued_text(j);   // LAST(fmt.gapSa) of a rescued record is the tumor record's string
+                            return rt.empty() ? std::string(SYMBOL_DESC[symbol]) : rt;
+                        }
                     }
                     return std::string();
                 };
