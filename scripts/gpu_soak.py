@@ -21,6 +21,8 @@ from test_gpu_parity import VARIANTS, compare_records, tumor_keys_from  # noqa: 
 
 budget, seed = float(sys.argv[1]), int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 mode = sys.argv[3] if len(sys.argv) > 3 else "fuzz"
+import torch  # noqa: E402  (torch.cuda before libuvcgpu.so touches the device: uvc_amd/region.py device_reads)
+torch.cuda.init(); dev = torch.device("cuda", 0); torch.zeros(1, device=dev)
 glib = region.gpu_lib(); assert glib.dll.uvcgpu_init(0) == 0
 olib = _ffi.Lib(__import__("oracle").library_path(), "uvc_oracle_")
 handles = {}
@@ -75,7 +77,10 @@ while time.time() - t0 < budget:
                 if name == "gpu": handles[key] = R
             else:
                 R.reset(reads["tid"], reads["beg"], reads["end"], reads["refseq"].encode())      # a handle that has held other regions
-            R.set_reads(reads)
+            if name == "gpu" and seed % 3 == 0:   # the form bench.py hands the columns over in: already in HBM, 4-bit bases, no offset columns
+                R.set_reads_device(region.device_reads(region.compact_form(reads), dev))
+            else:
+                R.set_reads(reads)
             if seed % 2: R.correct_bq()
             R.accumulate(); R.fetch("PREP32")
             out.append(R)
