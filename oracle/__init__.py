@@ -6,4 +6,5 @@ import os
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "liboracle.so")
+    # UVC_ORACLE_LIBRARY: another build of the same checker (scripts/cpu_sanitize.sh: AddressSanitizer + UBSan)
+    return os.environ.get("UVC_ORACLE_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "liboracle.so")

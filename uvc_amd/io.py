@@ -22,7 +22,8 @@ _dll = None
 
 
 def library_path():
-    return os.path.join(_ffi.ROOT, "uvc_amd", "csrc", "libuvcio.so")
+    # UVCIO_LIBRARY: another build of the same library (scripts/cpu_sanitize.sh runs the reader tests on an AddressSanitizer build)
+    return os.environ.get("UVCIO_LIBRARY") or os.path.join(_ffi.ROOT, "uvc_amd", "csrc", "libuvcio.so")
 
 
 def dll():
