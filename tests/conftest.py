@@ -9,6 +9,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# every accumulate of the GPU tests is followed by uvcgpu_region_check_presence (uvc_amd/region.py): a plane cell outside the symbols the
+# scoring gather sums would change results silently
+os.environ.setdefault("UVCGPU_CHECK_PRESENCE", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -176,6 +176,7 @@ struct RegionDev {
     const int32_t *generic_fs; int32_t n_generic_fs; int64_t n_generic_work;
     const int32_t *generic_sorted; int32_t max_unit_span;   // the generic units ordered by FsRec::beg (window kernels k_fam_win)
     uint8_t *p5flag;                // [2][npos]: a P5 bucket of this (strand, position) was filled
+    uint32_t *occ;                  // [npos] bit s: a rare-symbol P2 update (seg_flush) touched (s, position); zeroed with the planes, read by k_enum
     uint32_t *fam_digest;           // [n_generic_work][8] or NULL: what P4 leaves per (unit, position) for P5 and the duplex pass (k_fam_win<4> / k_fam_win5d / k_duplex_d)
     Contrib *table;
     int32_t *ir_list;               // per InDel read: the positions of its low-quality InDels (k_p2_slow's cursor, main.hpp:1817-1859), [gap_off + 2 * rank .. ) with sentinels

@@ -34,8 +34,10 @@ extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, in
                                       const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof,
                                       hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join, hipEvent_t e_fork2, hipStream_t side3, hipEvent_t e_join3, hipEvent_t e_stat, hipEvent_t e_alleles);
 extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const UvcScoreRequest *req, const UvcIndelAllele *d_alleles, const int32_t *d_allele_rows, int64_t n_alleles,
-                                const UvcGapRow *d_gap_rows, const uint8_t *d_gap_seq, const UvcTumorKey *d_tkeys, int32_t *d_fields, int64_t capacity, int64_t *d_count, long long *scratch, int32_t *d_fields_kept, hipStream_t s);
-extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored);
+                                const UvcGapRow *d_gap_rows, const uint8_t *d_gap_seq, const UvcTumorKey *d_tkeys, int32_t *d_fields, int64_t capacity, char *scratch, int32_t *d_fields_kept, hipStream_t s);
+extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored, int64_t capacity);
+extern "C" size_t uvc_score_scratch_zero_bytes(int64_t npos_scored, int64_t capacity);
+extern "C" void uvc_launch_check_presence(const RegionDev *R, unsigned long long *d_n_bad, hipStream_t s);
 extern "C" void uvc_launch_block_stats(const RegionDev *R, const UvcParams *P, int64_t x0, int64_t n, int32_t *d_out, hipStream_t s);
 extern "C" size_t uvc_gap_sort_tmp_bytes(size_t n);
 extern "C" void uvc_launch_hap_cand(const RegionDev *R, const HapWork *H, int units, hipStream_t s);
@@ -88,7 +90,7 @@ struct uvcgpu_region {
     int32_t *d_dup_units = nullptr; int64_t *d_dup_off = nullptr; int n_dup = 0; int64_t n_dup_work = 0;
     size_t off[UVC_NUM_FIELD_GROUPS + 1];
     bool has_reads = false, accumulated = false;
-    size_t p5flag_off = 0;
+    size_t p5flag_off = 0, occ_off = 0;
     bool state_released = false, state_zeroed = false;   // UvcScoreRequest::release_state: planes given up / already zeroed on the side stream (e_join marks the end)
     int64_t last_scored = 0, last_returned = 0;   // record counts of the last score call (uvcgpu_region_last_score_counts)
     size_t zeroed_bytes = 0;     // with state_zeroed: the slab is zero from its start up to here (a rebind to a region that fits keeps the benefit)
@@ -97,7 +99,7 @@ struct uvcgpu_region {
     int64_t n_bases = 0;
     UvcProf prof;
     // persistent scoring buffers (grown on demand)
-    long long *d_score_scratch = nullptr; size_t score_scratch_bytes = 0;
+    char *d_score_scratch = nullptr; size_t score_scratch_bytes = 0;
     int32_t *d_score_fields = nullptr; int64_t score_capacity = 0; int64_t *d_score_count = nullptr;
     uint8_t *h_stage = nullptr; size_t h_stage_cap = 0;   // page-locked staging for the small per-call uploads of score (tumor keys, caller's alleles): never the caller's own pages
     int32_t *d_score_kept = nullptr; int64_t score_kept_capacity = 0;   // UvcScoreRequest::kept_only: the compacted copy, same pitch as d_score_fields
@@ -220,6 +222,7 @@ static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t 
     size_t o = 0;
     for (int g : order) { r->off[g] = o; o += group_bytes(r, g); }
     r->p5flag_off = o; o += ((size_t)2 * r->npos + 255) & ~(size_t)255;   // one byte per (strand, position): a P5 bucket was filled (k_p5b skips the others); zeroed with the planes
+    r->occ_off = o; o += ((size_t)4 * r->npos + 255) & ~(size_t)255;   // RegionDev::occ, zeroed with the planes
     r->bucket_off = o; o += (size_t)4 * r->npos * 2 * NSYM * NBUCKETS;
     r->state_bytes = o;
     // planes that the last score zeroed on the side stream (release_state) stay zero under the new layout when it fits into what was zeroed
@@ -268,7 +271,7 @@ static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t 
     R.prep32 = (int32_t *)(b + r->off[UVC_F_PREP32]); R.thres = (int32_t *)(b + r->off[UVC_F_THRES]); R.seg32 = (int32_t *)(b + r->off[UVC_F_SEG32]);
     R.vq = (int32_t *)(b + r->off[UVC_F_VQ]); R.bqsum = (int32_t *)(b + r->off[UVC_F_BQSUM]); R.frag = (int32_t *)(b + r->off[UVC_F_FRAG]);
     R.fam = (int32_t *)(b + r->off[UVC_F_FAM]); R.faminfo32 = (int32_t *)(b + r->off[UVC_F_FAMINFO32]); R.duplex = (int32_t *)(b + r->off[UVC_F_DUPLEX]);
-    R.bucket = (int32_t *)(b + r->bucket_off); R.p5flag = (uint8_t *)(b + r->p5flag_off);
+    R.bucket = (int32_t *)(b + r->bucket_off); R.p5flag = (uint8_t *)(b + r->p5flag_off); R.occ = (uint32_t *)(b + r->occ_off);
     R.err = d_err;
     HIP_OK(hipMemsetAsync(d_err, 0, 4, r->stream));
     return 0;   // nothing to wait for: the staging memory belongs to the handle and a handle is rebound only when its streams are idle
@@ -556,6 +559,19 @@ static int uvcgpu_region_accumulate_impl(uvcgpu_region_t *r) {
     r->buckets_clean = (r->P.inferred_is_vcf_generated != 0);   // k_frag (P3b) and k_p5b cleared every bucket they consumed
     r->accumulated = true; r->gap_ready = false; r->hap_ready = false;
     return 0;
+}
+
+int uvcgpu_region_check_presence(uvcgpu_region_t *r, int64_t *n_violations) {
+    if (!r || !n_violations) return fail(UVCGPU_EINVAL, "bad argument");
+    if (!r->accumulated || r->state_released) return fail(UVCGPU_ESTATE, "check_presence needs the planes of an accumulate");
+    unsigned long long *d = nullptr, h = 0;
+    HIP_OK(hipMalloc((void **)&d, 8));
+    int rc = 0;
+    if (hipMemsetAsync(d, 0, 8, r->stream) != hipSuccess) rc = fail(UVCGPU_EDEVICE, "hipMemsetAsync");
+    if (!rc) { uvc_launch_check_presence(&r->R, d, r->stream); if (hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, r->stream) != hipSuccess || hipStreamSynchronize(r->stream) != hipSuccess) rc = fail(UVCGPU_EDEVICE, "check_presence"); }
+    hipFree(d);
+    *n_violations = (int64_t)h;
+    return rc;
 }
 
 // Per-kernel timing of the LAST accumulate, measured with HIP events on the handle's own stream.
@@ -983,14 +999,6 @@ static int uvcgpu_region_score_impl(uvcgpu_region_t *r, const UvcScoreRequest *r
     // array every record -- start from a guess and grow once if the count says so
     int64_t cap = std::max<int64_t>(out->capacity, 1);
     if (kept_only) cap = std::max<int64_t>(std::max<int64_t>(cap, r->score_capacity), (int64_t)(rq.pos_end - rq.pos_beg) / 8 + 4096);
-    if (!r->d_score_count) HIP_OK(hipMalloc((void **)&r->d_score_count, 16));
-    const size_t need = uvc_score_scratch_bytes(rq.pos_end - rq.pos_beg);
-    if (need > r->score_scratch_bytes) {
-        if (r->d_score_scratch) hipFree(r->d_score_scratch);
-        r->d_score_scratch = nullptr; r->score_scratch_bytes = 0;
-        HIP_OK(hipMalloc((void **)&r->d_score_scratch, need));
-        r->score_scratch_bytes = need;
-    }
     int rc = 0;
     int64_t cnt[2] = { 0, 0 };
     for (int attempt = 0; attempt < 2 && !rc; attempt++) {
@@ -1006,10 +1014,20 @@ static int uvcgpu_region_score_impl(uvcgpu_region_t *r, const UvcScoreRequest *r
             HIP_OK(hipMalloc((void **)&r->d_score_kept, sizeof(int32_t) * UVC_NUM_SCORE_FIELDS * r->score_capacity));
             r->score_kept_capacity = r->score_capacity;
         }
-        HIP_OK(hipMemsetAsync(r->d_score_count, 0, 16, r->stream));
+        {   // the staged rows of the scoring kernels are sized by the record capacity
+            const size_t need = uvc_score_scratch_bytes(rq.pos_end - rq.pos_beg, r->score_capacity);
+            if (need > r->score_scratch_bytes) {
+                if (r->d_score_scratch) hipFree(r->d_score_scratch);
+                r->d_score_scratch = nullptr; r->score_scratch_bytes = 0;
+                HIP_OK(hipMalloc((void **)&r->d_score_scratch, need + need / 8));
+                r->score_scratch_bytes = need + need / 8;
+            }
+            r->d_score_count = (int64_t *)r->d_score_scratch;   // the record counts head the scratch (zeroed with the scan states)
+        }
+        HIP_OK(hipMemsetAsync(r->d_score_scratch, 0, uvc_score_scratch_zero_bytes(rq.pos_end - rq.pos_beg, r->score_capacity), r->stream));
         int pi = -1;   // with profiling on, the scoring kernels (gate + scan + k_score + k_call + the kept-groups copy) as one more entry of uvcgpu_region_kernel_times
         if (r->prof.on && r->prof.n < 32) { pi = r->prof.n++; r->prof.name[pi] = "k_score_all"; if (!r->prof.ev[pi][0]) { hipEventCreate(&r->prof.ev[pi][0]); hipEventCreate(&r->prof.ev[pi][1]); } hipEventRecord(r->prof.ev[pi][0], r->stream); }
-        rc = uvc_launch_score(&r->R, &r->P, &rq, use_al, use_row, n_al, r->d_gap_rows, r->d_gap_seq, d_tk, r->d_score_fields, r->score_capacity, r->d_score_count, r->d_score_scratch,
+        rc = uvc_launch_score(&r->R, &r->P, &rq, use_al, use_row, n_al, r->d_gap_rows, r->d_gap_seq, d_tk, r->d_score_fields, r->score_capacity, r->d_score_scratch,
                               kept_only ? r->d_score_kept : nullptr, r->stream);
         if (pi >= 0) hipEventRecord(r->prof.ev[pi][1], r->stream);
         if (!rc && hipGetLastError() != hipSuccess) rc = fail(UVCGPU_EDEVICE, "score kernel launch failed");
@@ -1075,7 +1093,6 @@ void uvcgpu_region_destroy(uvcgpu_region_t *r) {
     if (r->R.err) hipFree(r->R.err);
     if (r->d_score_scratch) hipFree(r->d_score_scratch);
     if (r->d_score_fields) hipFree(r->d_score_fields);
-    if (r->d_score_count) hipFree(r->d_score_count);
     if (r->d_score_kept) hipFree(r->d_score_kept);
     if (r->h_stage) (void)hipHostFree(r->h_stage);
     if (r->d_gap_alleles) hipFree(r->d_gap_alleles);

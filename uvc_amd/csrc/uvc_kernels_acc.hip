@@ -112,6 +112,7 @@ struct SegAcc {   // SegFormatInfoSet (main_conversion.hpp:645-691) + the VQ a1/
 };
 
 DEV void seg_flush(const RegionDev &R, const SegAcc &A, int sym, int64_t x) {
+    atomicOr(&R.occ[x], 1u << sym);   // the scoring gather sums these planes over the marked symbols only (k_enum)
 #pragma unroll
     for (int f = 0; f < UVC_NSEG32; f++) if (A.s[f]) atomicAdd(&S32(R, f, sym, x), A.s[f]);
 #pragma unroll

@@ -227,6 +227,14 @@ class Region:
 
     def accumulate(self):
         self._check(self.lib.call("accumulate", self.h))
+        if os.environ.get("UVCGPU_CHECK_PRESENCE") and hasattr(self.lib.dll, self.lib.prefix + "region_check_presence"):
+            # the test suite's switch: the planes of every accumulate against the presence statement the scoring gather relies on
+            n = C.c_int64(-1)
+            fn = getattr(self.lib.dll, self.lib.prefix + "region_check_presence")
+            fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]
+            self._check(fn(self.h, C.byref(n)))
+            if n.value != 0:
+                raise AssertionError("uvcgpu_region_check_presence: %d (position, symbol) cells contradict the presence statement" % n.value)
 
     def correct_bq(self):
         """apply_bq_err_correction3 (grouping.cpp:459-543) on the library's copy of the base qualities."""
