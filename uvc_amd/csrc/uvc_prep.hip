@@ -8,8 +8,6 @@
 #include <cstdio>
 #include <cstring>
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 #include <stdint.h>
 #include "uvc_prep.h"
 
@@ -22,6 +20,97 @@ PDEV bool is_m(int op) { return op == PC_MATCH || op == PC_EQUAL || op == PC_DIF
 // one atomic per wave instead of one per lane: millions of same-address atomics serialise (k_read_facts took 8.6 ms with them, 0.2 without)
 PDEV int wave_max(int v) { for (int d = 32; d > 0; d >>= 1) v = pmax(v, __shfl_xor(v, d)); return v; }
 PDEV int wave_sum(int v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d); return v; }
+
+// ---- several prefix sums over one index in three launches (tile sums inside the producing kernel, one block over the tile sums, one apply
+// pass that writes every offset column) instead of a library scan -- two launches -- per column.  Tile = 2 048 consecutive elements.
+#define SC_BLOCK 256
+#define SC_ITEMS 8
+#define SC_TILE (SC_BLOCK * SC_ITEMS)
+PDEV long long wave_sum64(long long v) { for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d); return v; }
+// block-wide sums of NC per-thread values; the result is valid in thread 0
+template <int NC> PDEV void block_sums(long long (&v)[NC], long long (*sh)[NC] /* [4][NC] */) {
+    const int wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < NC; c++) v[c] = wave_sum64(v[c]);
+    if ((threadIdx.x & 63) == 0) { for (int c = 0; c < NC; c++) sh[wv][c] = v[c]; }
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int c = 0; c < NC; c++) v[c] = sh[0][c] + sh[1][c] + sh[2][c] + sh[3][c]; }
+}
+// exclusive scan of every column of tile_sums [NC][ntiles] in place, the column totals to totals[NC]; one block of 1 024 threads
+template <int NC> __global__ void __launch_bounds__(1024) k_tile_tops(long long *tile_sums, int ntiles, long long *totals) {
+    __shared__ long long sh[1024];
+    for (int c = 0; c < NC; c++) {
+        long long carry = 0;
+        for (int b0 = 0; b0 < ntiles; b0 += 1024) {
+            const int i = b0 + (int)threadIdx.x;
+            const long long v = (i < ntiles ? tile_sums[(size_t)c * ntiles + i] : 0);
+            sh[threadIdx.x] = v;
+            __syncthreads();
+            for (int d = 1; d < 1024; d <<= 1) {
+                const long long o = (threadIdx.x >= (unsigned)d ? sh[threadIdx.x - d] : 0);
+                __syncthreads();
+                sh[threadIdx.x] += o;
+                __syncthreads();
+            }
+            if (i < ntiles) tile_sums[(size_t)c * ntiles + i] = carry + sh[threadIdx.x] - v;
+            const long long tot = sh[1023];
+            __syncthreads();
+            carry += tot;
+        }
+        if (threadIdx.x == 0) totals[c] = carry;
+    }
+}
+// exclusive prefix of this thread's NC values over the block's threads (thread order), the tile's prefix added: v[c] becomes the exclusive prefix
+template <int NC> PDEV void block_excl(long long (&v)[NC], const long long *tile_pref /* [NC][ntiles] */, int ntiles, int tile, long long (*shw)[NC] /* [4][NC] */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    long long inc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        inc[c] = v[c];
+        for (int d = 1; d < 64; d <<= 1) { const long long o = __shfl_up(inc[c], d); if (lane >= d) inc[c] += o; }
+    }
+    if (lane == 63) { for (int c = 0; c < NC; c++) shw[wv][c] = inc[c]; }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        long long base = tile_pref[(size_t)c * ntiles + tile];
+        for (int q = 0; q < 4; q++) if (q < wv) base += shw[q][c];
+        v[c] = base + inc[c] - v[c];
+    }
+}
+
+// up to three prefix sums over (possibly different) index ranges in three launches: k_cols_sums, k_tile_tops<3>, k_cols_apply
+struct ScanCols { const void *in[3]; void *out[3]; int64_t n[3]; int in64[3], out64[3], inclusive[3]; };
+PDEV long long col_load(const ScanCols &C, int c, int64_t i) { return i < C.n[c] ? (C.in64[c] ? ((const long long *)C.in[c])[i] : (long long)((const int32_t *)C.in[c])[i]) : 0LL; }
+__global__ void __launch_bounds__(SC_BLOCK) k_cols_sums(ScanCols C, long long *tile_sums, int ntiles) {
+    __shared__ long long sh[4][3];
+    long long v[3] = { 0, 0, 0 };
+    for (int k = 0; k < SC_ITEMS; k++) {
+        const int64_t i = (int64_t)blockIdx.x * SC_TILE + (int64_t)k * SC_BLOCK + threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < 3; c++) v[c] += col_load(C, c, i);
+    }
+    block_sums<3>(v, sh);
+    if (threadIdx.x == 0) { for (int c = 0; c < 3; c++) tile_sums[(size_t)c * ntiles + blockIdx.x] = v[c]; }
+}
+__global__ void __launch_bounds__(SC_BLOCK) k_cols_apply(ScanCols C, const long long *tile_pref, int ntiles) {
+    __shared__ long long shw[4][3];
+    const int64_t i0 = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_ITEMS;
+    long long e[3][SC_ITEMS], v[3] = { 0, 0, 0 };
+#pragma unroll
+    for (int c = 0; c < 3; c++) { for (int k = 0; k < SC_ITEMS; k++) { e[c][k] = col_load(C, c, i0 + k); v[c] += e[c][k]; } }
+    block_excl<3>(v, tile_pref, ntiles, (int)blockIdx.x, shw);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        for (int k = 0; k < SC_ITEMS; k++) {
+            const int64_t i = i0 + k;
+            if (i >= C.n[c]) break;
+            const long long o = (C.inclusive[c] ? v[c] + e[c][k] : v[c]);
+            if (C.out64[c]) ((long long *)C.out[c])[i] = o; else ((int32_t *)C.out[c])[i] = (int32_t)o;
+            v[c] += e[c][k];
+        }
+    }
+}
 
 struct Stage1 {   // device counters of the first stage (read back once)
     int32_t err, max_aln_span, n_frags, n_fs, n_complex, any_amplicon;
@@ -36,9 +125,13 @@ struct Stage2 {
 // ---- stage 1: what the CIGAR of each read says (nothing here depends on another read except the two "is a new ..." flags) ----
 __global__ void __launch_bounds__(256) k_read_facts(UvcPrepIn in, int32_t rbeg, int32_t rend, int seg_eligible,
                                                     int32_t *endpos, int32_t *kind, int32_t *dflag_of, int32_t *new_frag, int32_t *new_fs, int32_t *is_complex,
-                                                    int32_t *n_p2, int64_t *gaps, int64_t *trows, int64_t *items, int64_t *ins, Stage1 *T) {
+                                                    int32_t *n_p2, int64_t *gaps, int64_t *trows, int64_t *items, int64_t *ins, Stage1 *T, long long *tile_sums, int ntiles) {
     int w_err = 0, w_span = 0, w_p2span = 0, w_cls[4] = { 0, 0, 0, 0 }, w_amp = 0;   // this lane's contributions to the region-wide counters
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < in.n_reads; i += (int64_t)gridDim.x * blockDim.x) {
+    long long col[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // this lane's share of the tile's column sums (new_frag, new_fs, is_complex, n_p2, trows, items, ins, gaps)
+    // one block per tile of SC_TILE consecutive reads (the tile sums feed the offset scans of k_facts_apply)
+    for (int k8 = 0; k8 < SC_ITEMS; k8++) {
+    const int64_t i = (int64_t)blockIdx.x * SC_TILE + (int64_t)k8 * SC_BLOCK + threadIdx.x;
+    if (i >= in.n_reads) break;
     const int32_t nc = in.n_cigar[i], lq = in.l_qseq[i], pos = in.pos[i];
     int32_t o_end = pos + 1, o_kind = 1, o_np2 = 0; int64_t o_gaps = 0, o_trows = 0, o_items = 0, o_ins = 0;
     int err = 0;
@@ -99,7 +192,14 @@ __global__ void __launch_bounds__(256) k_read_facts(UvcPrepIn in, int32_t rbeg, 
     dflag_of[i] = df;
     if (df & 0x4) w_amp = 1;
     const bool nfs = (i == 0) || in.fam_id[i - 1] != fam || in.fam_strand[i - 1] != strand;
-    new_fs[i] = nfs; new_frag[i] = (nfs || in.frag_id[i - 1] != in.frag_id[i]);
+    const bool nfr = (nfs || in.frag_id[i - 1] != in.frag_id[i]);
+    new_fs[i] = nfs; new_frag[i] = nfr;
+    col[0] += nfr; col[1] += nfs; col[2] += (o_kind != 0); col[3] += o_np2; col[4] += o_trows; col[5] += o_items; col[6] += o_ins; col[7] += o_gaps;
+    }
+    {
+        __shared__ long long shc[4][8];
+        block_sums<8>(col, shc);
+        if (threadIdx.x == 0) { for (int c = 0; c < 8; c++) tile_sums[(size_t)c * ntiles + blockIdx.x] = col[c]; }
     }
     // wave, then block, then one set of atomics per block (the grid is a few thousand blocks)
     __shared__ int sh[4][8];
@@ -119,22 +219,51 @@ __global__ void __launch_bounds__(256) k_read_facts(UvcPrepIn in, int32_t rbeg, 
     }
 }
 
-// the prefix sums of stage 1 -> indices / offsets; -1 offsets for simple alignments
-__global__ void __launch_bounds__(256) k_finish_facts(int64_t n, const int32_t *kind, int32_t *frag_of /* inclusive scan of new_frag, in place */, int32_t *fs_of,
-                                                      const int32_t *complex_rank, int64_t *table_off, int64_t *item_off, int64_t *gap_off, int32_t *complex_ids) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    frag_of[i] -= 1; fs_of[i] -= 1;
-    if (kind[i] == 0) { table_off[i] = -1; item_off[i] = -1; gap_off[i] = -1; }
-    else complex_ids[complex_rank[i]] = (int32_t)i;
-}
-__global__ void k_stage1_totals(int64_t n, const int32_t *frag_incl, const int32_t *fs_incl, const int32_t *complex_rank, const int32_t *is_complex,
-                                const int32_t *p2_first, const int32_t *n_p2, const int64_t *t_off, const int64_t *trows, const int64_t *i_off, const int64_t *items,
-                                const int64_t *g_off, const int64_t *gaps, const int64_t *ins_off, const int64_t *ins, Stage1 *T) {
-    if (n <= 0) return;
-    const int64_t l = n - 1;
-    T->n_frags = frag_incl[l]; T->n_fs = fs_incl[l]; T->n_complex = complex_rank[l] + is_complex[l];
-    T->n_p2 = (int64_t)p2_first[l] + n_p2[l]; T->table_rows = t_off[l] + trows[l]; T->item_slots = i_off[l] + items[l]; T->gap_slots = g_off[l] + gaps[l]; T->ins_total = ins_off[l] + ins[l];
+// the prefix sums of stage 1 -> indices / offsets (-1 offsets for simple alignments), the list of InDel reads, the totals
+__global__ void __launch_bounds__(SC_BLOCK) k_facts_apply(int64_t n, const long long *tile_pref, int ntiles, const long long *totals, const int32_t *kind, const int32_t *new_frag, const int32_t *new_fs,
+                                                          const int32_t *n_p2, const int64_t *trows, const int64_t *items, const int64_t *gaps,
+                                                          int32_t *frag_of, int32_t *fs_of, int32_t *p2_first, int64_t *table_off, int64_t *item_off, int64_t *gap_off, int32_t *complex_ids, Stage1 *T) {
+    __shared__ long long shw[4][7];
+    const int64_t i0 = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_ITEMS;   // this thread's SC_ITEMS consecutive reads
+    long long v[7] = { 0, 0, 0, 0, 0, 0, 0 };   // new_frag, new_fs, is_complex, n_p2, trows, items, gaps (the sum of the inserted lengths is only needed as a total)
+    int e_nf[SC_ITEMS], e_ns[SC_ITEMS], e_k[SC_ITEMS], e_p2[SC_ITEMS]; long long e_tr[SC_ITEMS], e_it[SC_ITEMS], e_gp[SC_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; k++) {
+        const int64_t i = i0 + k; const bool in = (i < n);
+        e_nf[k] = in ? new_frag[i] : 0; e_ns[k] = in ? new_fs[i] : 0; e_k[k] = in ? kind[i] : 0; e_p2[k] = in ? n_p2[i] : 0;
+        e_tr[k] = in ? trows[i] : 0; e_it[k] = in ? items[i] : 0; e_gp[k] = in ? gaps[i] : 0;
+        v[0] += e_nf[k]; v[1] += e_ns[k]; v[2] += (e_k[k] != 0); v[3] += e_p2[k]; v[4] += e_tr[k]; v[5] += e_it[k]; v[6] += e_gp[k];
+    }
+    // (column 6 of the tile sums is the inserted length: skipped here)
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        long long inc[7];
+#pragma unroll
+        for (int c = 0; c < 7; c++) { inc[c] = v[c]; for (int d = 1; d < 64; d <<= 1) { const long long o = __shfl_up(inc[c], d); if (lane >= d) inc[c] += o; } }
+        if (lane == 63) { for (int c = 0; c < 7; c++) shw[wv][c] = inc[c]; }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 7; c++) {
+            long long base = tile_pref[(size_t)(c < 6 ? c : 7) * ntiles + blockIdx.x];
+            for (int q = 0; q < 4; q++) if (q < wv) base += shw[q][c];
+            v[c] = base + inc[c] - v[c];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; k++) {
+        const int64_t i = i0 + k;
+        if (i >= n) break;
+        v[0] += e_nf[k]; v[1] += e_ns[k];                 // inclusive: the index of the read's fragment / unit is the count of heads up to it, minus one
+        frag_of[i] = (int32_t)v[0] - 1; fs_of[i] = (int32_t)v[1] - 1;
+        p2_first[i] = (int32_t)v[3];
+        if (e_k[k] == 0) { table_off[i] = -1; item_off[i] = -1; gap_off[i] = -1; }
+        else { table_off[i] = v[4]; item_off[i] = v[5]; gap_off[i] = v[6]; complex_ids[v[2]] = (int32_t)i; }
+        v[2] += (e_k[k] != 0); v[3] += e_p2[k]; v[4] += e_tr[k]; v[5] += e_it[k]; v[6] += e_gp[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        T->n_frags = (int32_t)totals[0]; T->n_fs = (int32_t)totals[1]; T->n_complex = (int32_t)totals[2];
+        T->n_p2 = totals[3]; T->table_rows = totals[4]; T->item_slots = totals[5]; T->ins_total = totals[6]; T->gap_slots = totals[7];
+    }
 }
 
 // ---- stage 2: the nesting ----
@@ -273,14 +402,11 @@ __global__ void __launch_bounds__(256) k_take_units(const uint32_t *perm, const 
 }
 
 unsigned nblk(int64_t n, int b) { return (unsigned)std::max<int64_t>((n + b - 1) / b, 1); }
-template <class T> size_t scan_tmp_bytes(int64_t n) { size_t b = 0; T *p = nullptr; rocprim::exclusive_scan(nullptr, b, p, p, T(0), (size_t)std::max<int64_t>(n, 1), rocprim::plus<T>(), (hipStream_t)0); return b; }
 }   // namespace
 
 // ---- compact input forms (UvcReadSoA::seq_off / cigar_off == NULL, UvcReadSoA::bases4): offsets by prefix sums, BAM's 4-bit base codes
 // through seq_nt16_int[] (htslib: A C G T -> 0..3, everything else 4) into the one-byte-per-base array the kernels read
 namespace {
-struct Widen { __device__ int64_t operator()(int32_t v) const { return (int64_t)v; } };
-struct HalfUp { __device__ int64_t operator()(int32_t v) const { return (int64_t)((v + 1) >> 1); } };
 // seq_nt16_int[] as a nibble table: codes 1 2 4 8 (A C G T) -> 0 1 2 3, everything else 4
 #define NT16_INT_LUT 0x4444444344424104ULL
 PDEV unsigned nt16_int(unsigned code) { return (unsigned)(NT16_INT_LUT >> (4 * code)) & 0xF; }
@@ -296,6 +422,35 @@ PDEV void unpack8(uint32_t w, unsigned long long q, unsigned long long &bb, uint
     o.y = (uint32_t)(((bb >> 16) & 0xFF) | (((q >> 16) & 0xFF) << 8) | (((bb >> 24) & 0xFF) << 16) | (((q >> 24) & 0xFF) << 24));
     o.z = (uint32_t)(((bb >> 32) & 0xFF) | (((q >> 32) & 0xFF) << 8) | (((bb >> 40) & 0xFF) << 16) | (((q >> 40) & 0xFF) << 24));
     o.w = (uint32_t)(((bb >> 48) & 0xFF) | (((q >> 48) & 0xFF) << 8) | (((bb >> 56) & 0xFF) << 16) | (((q >> 56) & 0xFF) << 24));
+}
+// the offset columns of the compact input form: exclusive prefix sums of l_qseq, n_cigar and ceil(l_qseq / 2) over the reads, three at once
+__global__ void __launch_bounds__(SC_BLOCK) k_len_sums(const int32_t *l_qseq, const int32_t *n_cigar, int64_t n, long long *tile_sums, int ntiles) {
+    __shared__ long long sh[4][3];
+    long long v[3] = { 0, 0, 0 };
+    for (int k = 0; k < SC_ITEMS; k++) {
+        const int64_t i = (int64_t)blockIdx.x * SC_TILE + (int64_t)k * SC_BLOCK + threadIdx.x;
+        if (i < n) { const int32_t lq = l_qseq[i]; v[0] += lq; v[1] += n_cigar[i]; v[2] += (lq + 1) >> 1; }
+    }
+    block_sums<3>(v, sh);
+    if (threadIdx.x == 0) { for (int c = 0; c < 3; c++) tile_sums[(size_t)c * ntiles + blockIdx.x] = v[c]; }
+}
+__global__ void __launch_bounds__(SC_BLOCK) k_len_apply(const int32_t *l_qseq, const int32_t *n_cigar, int64_t n, const long long *tile_pref, int ntiles, int64_t *seq_off, int64_t *cigar_off, int64_t *b4_off) {
+    __shared__ long long shw[4][3];
+    const int64_t i0 = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_ITEMS;
+    int lq[SC_ITEMS], nc[SC_ITEMS];
+    long long v[3] = { 0, 0, 0 };
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; k++) { const int64_t i = i0 + k; lq[k] = (i < n ? l_qseq[i] : 0); nc[k] = (i < n ? n_cigar[i] : 0); v[0] += lq[k]; v[1] += nc[k]; v[2] += (lq[k] + 1) >> 1; }
+    block_excl<3>(v, tile_pref, ntiles, (int)blockIdx.x, shw);
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; k++) {
+        const int64_t i = i0 + k;
+        if (i >= n) break;
+        if (seq_off) seq_off[i] = v[0];
+        if (cigar_off) cigar_off[i] = v[1];
+        if (b4_off) b4_off[i] = v[2];
+        v[0] += lq[k]; v[1] += nc[k]; v[2] += (lq[k] + 1) >> 1;
+    }
 }
 // General form (reads of odd length: every read starts on a byte of the packed column): sixteen lanes per read, eight bases per lane and turn
 // with one 4-byte, one 8-byte load and an 8- and a 16-byte store at the read's own (unaligned) offsets; the last one to seven bases of a read
@@ -341,26 +496,30 @@ __global__ void __launch_bounds__(256) k_any_odd(const int32_t *l_qseq, int64_t 
     if (__any(odd) && (threadIdx.x & 63) == 0) *bad = 1;
 }
 }   // namespace
-extern "C" size_t uvc_prep_compact_tmp_bytes(int64_t n) { return scan_tmp_bytes<int64_t>(n) + 64; }
+extern "C" size_t uvc_prep_compact_tmp_bytes(int64_t n) { return (size_t)(3 * ((n + SC_TILE - 1) / SC_TILE) + 3) * sizeof(long long) + 64; }
 // seq_off / cigar_off / b4_off: outputs (device, n entries each) or NULL when the caller supplied that column; with bases4: bases_out (n_bases
 // bytes) and bq_out (n_bases x base | qual << 8) are written here, so that no separate packing pass runs behind it
 extern "C" int uvc_prep_compact(const int32_t *l_qseq, const int32_t *n_cigar, int64_t n, int64_t n_bases, const uint8_t *bases4, int64_t n_b4, const uint8_t *quals,
                                 int64_t *seq_off_out, const int64_t *seq_off_in, int64_t *cigar_off_out, int64_t *b4_off, uint8_t *bases_out, uint16_t *bq_out, int32_t *bad,
                                 void *tmp, size_t tmp_bytes, hipStream_t s) {
-    size_t tb = tmp_bytes;
     hipError_t e = hipSuccess;
-    if (seq_off_out) { e = rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(l_qseq, Widen()), seq_off_out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s); tb = tmp_bytes; }
-    if (e == hipSuccess && cigar_off_out) { e = rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(n_cigar, Widen()), cigar_off_out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s); tb = tmp_bytes; }
+    const int ntiles = (int)((n + SC_TILE - 1) / SC_TILE);
+    if ((size_t)(3 * ntiles + 3) * sizeof(long long) > tmp_bytes) return (int)hipErrorInvalidValue;
+    long long *tile_sums = (long long *)tmp;
+    const bool dense_form = bases4 && seq_off_out && 2 * n_b4 == n_bases && (n_bases & 7) == 0 && !(((uintptr_t)bases4) & 3) && !(((uintptr_t)quals | (uintptr_t)bases_out) & 7) && !(((uintptr_t)bq_out) & 15);
+    if ((seq_off_out || cigar_off_out || (bases4 && !dense_form)) && n > 0) {
+        hipLaunchKernelGGL(k_len_sums, dim3((unsigned)ntiles), dim3(SC_BLOCK), 0, s, l_qseq, n_cigar, n, tile_sums, ntiles);
+        hipLaunchKernelGGL(k_tile_tops<3>, dim3(1), dim3(1024), 0, s, tile_sums, ntiles, tile_sums + (size_t)3 * ntiles);
+        hipLaunchKernelGGL(k_len_apply, dim3((unsigned)ntiles), dim3(SC_BLOCK), 0, s, l_qseq, n_cigar, n, tile_sums, ntiles, seq_off_out, cigar_off_out, (bases4 && !dense_form) ? b4_off : (int64_t *)nullptr);
+    }
     if (e == hipSuccess && bases4) {
         // reads back to back (offsets derived here) with 2 x bytes == bases can only be all-even lengths: nibble g is base g
-        const bool dense = seq_off_out && 2 * n_b4 == n_bases && (n_bases & 7) == 0 && !(((uintptr_t)bases4) & 3) && !(((uintptr_t)quals | (uintptr_t)bases_out) & 7) && !(((uintptr_t)bq_out) & 15);
-        if (dense) {
+        if (dense_form) {
             hipLaunchKernelGGL(k_any_odd, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, l_qseq, n, bad);
             hipLaunchKernelGGL(k_pack_bq4_dense, dim3((unsigned)std::min<int64_t>((n_bases / 8 + 255) / 256 + 1, 16384)), dim3(256), 0, s, (const uint32_t *)bases4, (const unsigned long long *)quals, n_bases / 8,
                                (unsigned long long *)bases_out, (uint4 *)bq_out);
         } else {
-            e = rocprim::exclusive_scan(tmp, tb, rocprim::make_transform_iterator(l_qseq, HalfUp()), b4_off, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s);
-            if (e == hipSuccess) hipLaunchKernelGGL(k_pack_bq4_reads, dim3((unsigned)std::min<int64_t>((n + 15) / 16, 65536)), dim3(256), 0, s, bases4, n_b4, b4_off, seq_off_out ? seq_off_out : seq_off_in, l_qseq, quals, n, n_bases, bases_out, bq_out, bad);
+            hipLaunchKernelGGL(k_pack_bq4_reads, dim3((unsigned)std::min<int64_t>((n + 15) / 16, 65536)), dim3(256), 0, s, bases4, n_b4, b4_off, seq_off_out ? seq_off_out : seq_off_in, l_qseq, quals, n, n_bases, bases_out, bq_out, bad);
         }
     }
     return (int)e;
@@ -382,28 +541,36 @@ extern "C" int uvc_prep_reads(const UvcPrepIn *inp, const UvcParams *P, int32_t 
 #define ALLOC(ptr, T, count, zero) do { ptr = (T *)A(sizeof(T) * (size_t)(count), zero); if (!ptr) { snprintf(errmsg, (size_t)errcap, "hipMalloc(%s)", #ptr); return UVCGPU_ENOMEM; } } while (0)
     const int seg_eligible = (UVC_PLATFORM_IONTORRENT != P->inferred_sequencing_platform) && rbeg >= 65536 && P->bias_thres_interfering_indel <= 10000;
     // ---- stage 1
-    int32_t *new_frag, *new_fs, *is_complex, *complex_rank, *n_p2; int64_t *gaps, *trows, *items, *ins, *ins_off;
+    int32_t *new_frag, *new_fs, *is_complex, *n_p2; int64_t *gaps, *trows, *items, *ins;
     ALLOC(out->endpos, int32_t, n, 0); ALLOC(out->kind, int32_t, n, 0); ALLOC(out->dflag_of, int32_t, n, 0); ALLOC(out->frag_of, int32_t, n, 0); ALLOC(out->fs_of, int32_t, n, 0);
     ALLOC(out->table_off, int64_t, n, 0); ALLOC(out->item_off, int64_t, n, 0); ALLOC(out->gap_off, int64_t, n, 0); ALLOC(out->p2_first, int32_t, n, 0);
-    ALLOC(new_frag, int32_t, n, 0); ALLOC(new_fs, int32_t, n, 0); ALLOC(is_complex, int32_t, n, 0); out->is_complex = is_complex; ALLOC(complex_rank, int32_t, n, 0); ALLOC(n_p2, int32_t, n, 0); ALLOC(gaps, int64_t, n, 0);
-    ALLOC(trows, int64_t, n, 0); ALLOC(items, int64_t, n, 0); ALLOC(ins, int64_t, n, 0); ALLOC(ins_off, int64_t, n, 0);
+    ALLOC(new_frag, int32_t, n, 0); ALLOC(new_fs, int32_t, n, 0); ALLOC(is_complex, int32_t, n, 0); out->is_complex = is_complex; ALLOC(n_p2, int32_t, n, 0); ALLOC(gaps, int64_t, n, 0);
+    ALLOC(trows, int64_t, n, 0); ALLOC(items, int64_t, n, 0); ALLOC(ins, int64_t, n, 0);
     Stage1 *dT1; ALLOC(dT1, Stage1, 1, 1);
     Stage2 *dT2; ALLOC(dT2, Stage2, 1, 1);
     // sized for the LARGEST scan issued below: the per-read ones (n) and the fragment-depth scan over npos + 1 positions (nf >= 65536)
-    const size_t tmp_bytes = std::max(scan_tmp_bytes<int32_t>(std::max<int64_t>(n, npos + 2)), scan_tmp_bytes<int64_t>(n)) + 64;   // units and fragments never outnumber the reads
+    const size_t tmp_bytes = (size_t)(3 * ((std::max<int64_t>(n, npos + 2) + SC_TILE - 1) / SC_TILE) + 3) * sizeof(long long) + 64;   // tile sums of the largest three-column scan (units and fragments never outnumber the reads)
     void *tmp; ALLOC(tmp, char, tmp_bytes, 0);
-    hipLaunchKernelGGL(k_read_facts, dim3(std::min(nblk(n, 256), 2048u)), dim3(256), 0, s, in, rbeg, rend, seg_eligible, out->endpos, out->kind, out->dflag_of, new_frag, new_fs, is_complex, n_p2, gaps, trows, items, ins, dT1);
-    size_t tb = tmp_bytes;
-    int64_t *gap_off64 = out->gap_off;
-    PREP_HIP(rocprim::inclusive_scan(tmp, tb, new_frag, out->frag_of, (size_t)n, rocprim::plus<int32_t>(), s)); tb = tmp_bytes;
-    PREP_HIP(rocprim::inclusive_scan(tmp, tb, new_fs, out->fs_of, (size_t)n, rocprim::plus<int32_t>(), s)); tb = tmp_bytes;
-    PREP_HIP(rocprim::exclusive_scan(tmp, tb, is_complex, complex_rank, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), s)); tb = tmp_bytes;
-    PREP_HIP(rocprim::exclusive_scan(tmp, tb, n_p2, out->p2_first, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), s)); tb = tmp_bytes;
-    PREP_HIP(rocprim::exclusive_scan(tmp, tb, trows, out->table_off, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s)); tb = tmp_bytes;
-    PREP_HIP(rocprim::exclusive_scan(tmp, tb, items, out->item_off, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s)); tb = tmp_bytes;
-    PREP_HIP(rocprim::exclusive_scan(tmp, tb, ins, ins_off, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s)); tb = tmp_bytes;
-    PREP_HIP(rocprim::exclusive_scan(tmp, tb, gaps, gap_off64, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), s)); tb = tmp_bytes;
-    hipLaunchKernelGGL(k_stage1_totals, dim3(1), dim3(1), 0, s, n, out->frag_of, out->fs_of, complex_rank, is_complex, out->p2_first, n_p2, out->table_off, trows, out->item_off, items, gap_off64, gaps, ins_off, ins, dT1);
+    // one block per tile of SC_TILE reads; the eight offset columns come from the tile sums in two more launches (k_tile_tops, k_facts_apply)
+    const int ntiles = (int)((n + SC_TILE - 1) / SC_TILE);
+    long long *tile_sums; ALLOC(tile_sums, long long, (size_t)8 * ntiles + 8, 0);
+    long long *col_totals = tile_sums + (size_t)8 * ntiles;
+    ALLOC(out->complex_ids, int32_t, n, 0);   // (sized by the reads: the number of InDel reads is only known behind the scan that fills it)
+    hipLaunchKernelGGL(k_read_facts, dim3((unsigned)ntiles), dim3(SC_BLOCK), 0, s, in, rbeg, rend, seg_eligible, out->endpos, out->kind, out->dflag_of, new_frag, new_fs, is_complex, n_p2, gaps, trows, items, ins, dT1, tile_sums, ntiles);
+    hipLaunchKernelGGL(k_tile_tops<8>, dim3(1), dim3(1024), 0, s, tile_sums, ntiles, col_totals);
+    hipLaunchKernelGGL(k_facts_apply, dim3((unsigned)ntiles), dim3(SC_BLOCK), 0, s, n, tile_sums, ntiles, col_totals, out->kind, new_frag, new_fs, n_p2, trows, items, gaps,
+                       out->frag_of, out->fs_of, out->p2_first, out->table_off, out->item_off, out->gap_off, out->complex_ids, dT1);
+    // up to three prefix sums at once (k_cols_sums, k_tile_tops<3>, k_cols_apply); `tmp` holds the tile sums
+    auto scan3 = [&](ScanCols C) {
+        int64_t nmax = 0; for (int c = 0; c < 3; c++) nmax = std::max(nmax, C.n[c]);
+        if (nmax <= 0) return;
+        const int nt = (int)((nmax + SC_TILE - 1) / SC_TILE);
+        long long *ts = (long long *)tmp;
+        hipLaunchKernelGGL(k_cols_sums, dim3((unsigned)nt), dim3(SC_BLOCK), 0, s, C, ts, nt);
+        hipLaunchKernelGGL(k_tile_tops<3>, dim3(1), dim3(1024), 0, s, ts, nt, ts + (size_t)3 * nt);
+        hipLaunchKernelGGL(k_cols_apply, dim3((unsigned)nt), dim3(SC_BLOCK), 0, s, C, ts, nt);
+    };
+    auto col = [](ScanCols &C, int c, const void *in, void *out, int64_t n, int in64, int out64, int inclusive) { C.in[c] = in; C.out[c] = out; C.n[c] = n; C.in64[c] = in64; C.out64[c] = out64; C.inclusive[c] = inclusive; };
     Stage1 T1;
     PREP_HIP(hipMemcpyAsync(&T1, dT1, sizeof(T1), hipMemcpyDeviceToHost, s));
     PREP_HIP(hipStreamSynchronize(s));
@@ -417,8 +584,6 @@ extern "C" int uvc_prep_reads(const UvcPrepIn *inp, const UvcParams *P, int32_t 
     out->item_slots = T1.item_slots; out->gap_slots = T1.gap_slots; out->ins_total = T1.ins_total; out->max_aln_span = std::max(T1.max_aln_span, 1); out->any_amplicon = T1.any_amplicon;
     out->max_p2_span = std::max(T1.max_p2_span, 1);
     out->p2_off[0] = 0; for (int c = 0; c < 4; c++) out->p2_off[c + 1] = out->p2_off[c] + T1.p2_cls[c];
-    ALLOC(out->complex_ids, int32_t, T1.n_complex, 0);
-    hipLaunchKernelGGL(k_finish_facts, dim3(nblk(n, 256)), dim3(256), 0, s, n, out->kind, out->frag_of, out->fs_of, complex_rank, out->table_off, out->item_off, out->gap_off, out->complex_ids);
     // ---- stage 2
     const int32_t nf = T1.n_frags, nu = T1.n_fs;
     int32_t *frag_first, *fs_first_frag, *fam_fs, *sweep_flag, *sweep_rank, *generic_flag, *generic_rank, *dup_flag, *dup_rank; int64_t *gen_span, *work_off, *dup_span, *dup_off_all;
@@ -430,14 +595,11 @@ extern "C" int uvc_prep_reads(const UvcPrepIn *inp, const UvcParams *P, int32_t 
     hipLaunchKernelGGL(k_mark_first, dim3(nblk(n, 256)), dim3(256), 0, s, in, new_frag, new_fs, out->frag_of, out->fs_of, frag_first, fs_first_frag, fam_fs, nf, nu, dT2);
     hipLaunchKernelGGL(k_build_frags, dim3(std::min(nblk(nf, 256), 1024u)), dim3(256), 0, s, in, *P, rend, out->endpos, out->kind, out->fs_of, out->dflag_of, frag_first, nf, out->frags, sweep_flag, out->frag_beg, out->frag_strand, dT2);
     hipLaunchKernelGGL(k_build_units, dim3(nblk(nu, 256)), dim3(256), 0, s, in, *P, rend, out->endpos, out->dflag_of, frag_first, fs_first_frag, fam_fs, nu, out->fss, generic_flag, gen_span, dT2);
-    PREP_HIP(rocprim::exclusive_scan(tmp, tb, generic_flag, generic_rank, (int32_t)0, (size_t)std::max(nu, 1), rocprim::plus<int32_t>(), s)); tb = tmp_bytes;
-    PREP_HIP(rocprim::exclusive_scan(tmp, tb, gen_span, work_off, (int64_t)0, (size_t)std::max(nu, 1), rocprim::plus<int64_t>(), s)); tb = tmp_bytes;
-    PREP_HIP(rocprim::exclusive_scan(tmp, tb, sweep_flag, sweep_rank, (int32_t)0, (size_t)std::max(nf, 1), rocprim::plus<int32_t>(), s)); tb = tmp_bytes;
+    { ScanCols C; memset(&C, 0, sizeof(C)); col(C, 0, generic_flag, generic_rank, nu, 0, 0, 0); col(C, 1, gen_span, work_off, nu, 1, 1, 0); col(C, 2, sweep_flag, sweep_rank, nf, 0, 0, 0); scan3(C); }
     // generic_fs needs its size before k_units_post can fill it: the upper bound n_fs is small (4 B per unit)
     ALLOC(out->generic_fs, int32_t, nu, 0);
     hipLaunchKernelGGL(k_units_post, dim3(nblk(nu, 256)), dim3(256), 0, s, rend, nu, out->fss, generic_rank, work_off, out->generic_fs, dup_flag, dup_span);
-    PREP_HIP(rocprim::exclusive_scan(tmp, tb, dup_flag, dup_rank, (int32_t)0, (size_t)std::max(nu, 1), rocprim::plus<int32_t>(), s)); tb = tmp_bytes;
-    PREP_HIP(rocprim::exclusive_scan(tmp, tb, dup_span, dup_off_all, (int64_t)0, (size_t)std::max(nu, 1), rocprim::plus<int64_t>(), s)); tb = tmp_bytes;
+    { ScanCols C; memset(&C, 0, sizeof(C)); col(C, 0, dup_flag, dup_rank, nu, 0, 0, 0); col(C, 1, dup_span, dup_off_all, nu, 1, 1, 0); scan3(C); }
     ALLOC(out->dup_units, int32_t, nu, 0); ALLOC(out->dup_off, int64_t, nu, 0);
     hipLaunchKernelGGL(k_compact_dups, dim3(nblk(nu, 256)), dim3(256), 0, s, nu, dup_flag, dup_rank, dup_off_all, out->dup_units, out->dup_off);
     ALLOC(out->sweep_frags, int32_t, nf, 0);
@@ -445,7 +607,7 @@ extern "C" int uvc_prep_reads(const UvcPrepIn *inp, const UvcParams *P, int32_t 
     if (nf >= 65536) { ALLOC(depth, int32_t, npos + 2, 1); }   // fragment depth bound: below 65 536 fragments the count itself bounds it
     hipLaunchKernelGGL(k_frags_post, dim3(nblk(nf, 256)), dim3(256), 0, s, nf, out->frags, out->fss, sweep_flag, sweep_rank, out->sweep_frags, rbeg, depth);
     if (depth) {
-        PREP_HIP(rocprim::inclusive_scan(tmp, tb, depth, depth, (size_t)(npos + 1), rocprim::plus<int32_t>(), s)); tb = tmp_bytes;
+        { ScanCols C; memset(&C, 0, sizeof(C)); col(C, 0, depth, depth, npos + 1, 0, 0, 1); scan3(C); }
         hipLaunchKernelGGL(k_max_i32, dim3(256), dim3(256), 0, s, depth, npos + 1, &dT2->max_frag_depth);
     }
     hipLaunchKernelGGL(k_stage2_totals, dim3(1), dim3(1), 0, s, nu, nf, generic_rank, generic_flag, work_off, gen_span, dup_rank, dup_flag, dup_off_all, dup_span, sweep_rank, sweep_flag, dT2);
