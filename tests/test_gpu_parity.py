@@ -246,3 +246,33 @@ def test_release_state(gpu_lib):
     R.accumulate()
     rec3 = R.score(release_state=True, capacity=8)
     assert all(np.array_equal(rec[k], rec3[k]) for k in rec)
+
+
+def test_reused_handle_same_length_equals_fresh_handles(oracle_lib, gpu_lib):
+    """One handle over a run of regions of EQUAL length (what a tile stream does): the zero fill in front of an accumulate then skips the
+    (plane family, symbol, block) parts the previous accumulate did not mark (RegionDev::dirty).  Every region's planes must equal the
+    oracle's -- a stale cell of the previous region would show -- with and without release_state, and across UMI / InDel-dense / plain reads
+    so that the marked set changes from region to region."""
+    specs = [dict(region_len=9000, depth=60, seed=21, indel_every=150, snv_every=80),            # many rare symbols
+             dict(region_len=9000, depth=40, seed=22, indel_every=100000, snv_every=100000, err_rate=0.0),   # almost none: stale cells of the first would survive a wrong skip
+             dict(region_len=9000, depth=200, seed=23, umi=True),                                # FAMINFO / DUPLEX families
+             dict(region_len=9000, depth=30, seed=24, err_rate=0.0, indel_every=100000),         # none again
+             dict(region_len=9000, depth=50, seed=25, umi=True, indel_every=300)]
+    from uvc_amd import region
+    R = None
+    for k, sp in enumerate(specs):
+        reads = synth.generate_region(**sp)
+        Ro = run_region(oracle_lib, reads)
+        if R is None:
+            R = region.Region(gpu_lib, region.default_params(gpu_lib), reads["tid"], reads["beg"], reads["end"], reads["refseq"])
+        else:
+            R.reset(reads["tid"], reads["beg"], reads["end"], reads["refseq"])
+        R.set_reads(reads)
+        R.accumulate()
+        bad = diff_groups(Ro, R)
+        assert not bad, "region %d: " % k + "\n".join("%s: %d cells differ, e.g. %s" % (g, v[0], v[1]) for g, v in bad.items())
+        ro = Ro.score(all_out=True)
+        rg = R.score(all_out=True, release_state=(k % 2 == 1))   # every other region hands its planes back with the score call (zeroed on the side stream)
+        compare_records(ro, rg)
+        Ro.close()
+    R.close()

@@ -176,6 +176,9 @@ struct RegionDev {
     const int32_t *generic_fs; int32_t n_generic_fs; int64_t n_generic_work;
     const int32_t *generic_sorted; int32_t max_unit_span;   // the generic units ordered by FsRec::beg (window kernels k_fam_win)
     uint8_t *p5flag;                // [2][npos]: a P5 bucket of this (strand, position) was filled
+    uint8_t *dirty; int32_t ndblk;  // [3][NSYM][ndblk]: which (plane family, symbol, block of 4 096 positions) the accumulate wrote outside the part that is zero-filled
+                                    // anyway -- family 0: a rare symbol (BASE_NN, every LINK symbol but LINK_M) in the SEG / VQ / BQSUM / FRAG / FAM planes, 1: any symbol in
+                                    // FAMINFO32 / 64, 2: any symbol in DUPLEX.  The fill in front of the next accumulate skips what is not marked (uvc_launch_zero_state)
     uint32_t *occ;                  // [npos] bit s: a rare-symbol P2 update (seg_flush) touched (s, position); zeroed with the planes, read by k_enum
     uint32_t *fam_digest;           // [n_generic_work][8] or NULL: what P4 leaves per (unit, position) for P5 and the duplex pass (k_fam_win<4> / k_fam_win5d / k_duplex_d)
     Contrib *table;
@@ -227,6 +230,13 @@ DEV int cig_len(uint32_t c) { return (int)(c >> 4); }
 #define RTRP(R, f, x) ((R).rtr[(size_t)(f) * (R).npos + (x)])
 #define BAQ1(R, p) ((R).baq[(p) - (R).beg])
 #define BAQ2(R, p) ((R).baq[(R).npos + (p) - (R).beg])
+
+// (see RegionDev::dirty)
+#define UVC_DIRTY_SHIFT 12
+DEV bool sym_always_filled(int s) { return s < UVC_BASE_NN || s == UVC_LINK_M; }   // A C G T N (a reference base) and LINK_M: written at nearly every position
+DEV void mark_sym(const RegionDev &R, int s, int64_t x) { if (!sym_always_filled(s)) R.dirty[(size_t)s * R.ndblk + (x >> UVC_DIRTY_SHIFT)] = 1; }
+DEV void mark_fi(const RegionDev &R, int s, int64_t x) { R.dirty[((size_t)NSYM + s) * R.ndblk + (x >> UVC_DIRTY_SHIFT)] = 1; }
+DEV void mark_dup(const RegionDev &R, int s, int64_t x) { R.dirty[((size_t)2 * NSYM + s) * R.ndblk + (x >> UVC_DIRTY_SHIFT)] = 1; }
 
 DEV void add64(int64_t *p, int64_t v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
 // Adds to a cell that only one workgroup touches during the kernel (a window kernel owns its 64 positions): an L2 atomic of workgroup

@@ -37,6 +37,8 @@ extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const Uv
                                 const UvcGapRow *d_gap_rows, const uint8_t *d_gap_seq, const UvcTumorKey *d_tkeys, int32_t *d_fields, int64_t capacity, char *scratch, int32_t *d_fields_kept, hipStream_t s);
 extern "C" size_t uvc_score_scratch_bytes(int64_t npos_scored, int64_t capacity);
 extern "C" size_t uvc_score_scratch_zero_bytes(int64_t npos_scored, int64_t capacity);
+extern "C" void uvc_launch_zero_state(char *slab, const void *planes, int n_planes, uint8_t *dirty, int ndblk, int64_t npos, hipStream_t s);
+extern "C" void uvc_launch_check_dirty(const RegionDev *R, unsigned long long *d_n_bad, hipStream_t s);
 extern "C" void uvc_launch_check_presence(const RegionDev *R, unsigned long long *d_n_bad, hipStream_t s);
 extern "C" void uvc_launch_block_stats(const RegionDev *R, const UvcParams *P, int64_t x0, int64_t n, int32_t *d_out, hipStream_t s);
 extern "C" size_t uvc_gap_sort_tmp_bytes(size_t n);
@@ -91,6 +93,9 @@ struct uvcgpu_region {
     size_t off[UVC_NUM_FIELD_GROUPS + 1];
     bool has_reads = false, accumulated = false;
     size_t p5flag_off = 0, occ_off = 0;
+    // zero fill without what the last accumulate left untouched (RegionDev::dirty, uvc_launch_zero_state)
+    uint8_t *d_dirty = nullptr; void *d_zero_planes = nullptr; int n_zero_planes = 0; int64_t zero_planes_npos = 0;
+    int64_t dirty_npos = 0;      // the region length under which the slab's contents and the marks were written; 0: unknown, fill everything
     bool state_released = false, state_zeroed = false;   // UvcScoreRequest::release_state: planes given up / already zeroed on the side stream (e_join marks the end)
     int64_t last_scored = 0, last_returned = 0;   // record counts of the last score call (uvcgpu_region_last_score_counts)
     size_t zeroed_bytes = 0;     // with state_zeroed: the slab is zero from its start up to here (a rebind to a region that fits keeps the benefit)
@@ -232,13 +237,15 @@ static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t 
     const size_t n_rtr = (size_t)UVC_NRTR * r->npos;
     if (r->npos > r->npos_cap) {
         quiesce(r);
-        for (void *p : { (void *)r->d_refsym, (void *)r->d_rtr, (void *)r->d_rtr0, (void *)r->d_fsum, (void *)r->d_win, (void *)r->d_baq, (void *)r->d_state, (void *)r->d_rtrwork }) if (p) hipFree(p);
+        for (void *p : { (void *)r->d_refsym, (void *)r->d_rtr, (void *)r->d_rtr0, (void *)r->d_fsum, (void *)r->d_win, (void *)r->d_baq, (void *)r->d_state, (void *)r->d_rtrwork, (void *)r->d_dirty }) if (p) hipFree(p);
+        r->d_dirty = nullptr; r->dirty_npos = 0;
         r->d_refsym = nullptr; r->d_rtr = r->d_rtr0 = r->d_fsum = r->d_win = nullptr; r->d_baq = nullptr; r->d_state = nullptr; r->d_rtrwork = nullptr; r->npos_cap = 0; r->thr_ready = false;
         size_t scan_tmp = 0;
         const size_t work_bytes = uvc_rtr_work_bytes(r->npos, vmax, smax, bqm, &scan_tmp);
         if (hipMalloc((void **)&r->d_refsym, (size_t)r->npos + 1) != hipSuccess || hipMalloc((void **)&r->d_rtr, sizeof(int32_t) * n_rtr) != hipSuccess
             || hipMalloc((void **)&r->d_rtr0, sizeof(int32_t) * n_rtr) != hipSuccess || hipMalloc((void **)&r->d_fsum, sizeof(int32_t) * 2 * UVC_FSUM_N * (size_t)r->npos) != hipSuccess || hipMalloc((void **)&r->d_win, sizeof(int32_t) * 16 * (size_t)((r->npos + 63) / 64)) != hipSuccess || hipMalloc((void **)&r->d_baq, sizeof(int64_t) * 2 * (size_t)r->npos) != hipSuccess
-            || hipMalloc((void **)&r->d_state, r->state_bytes) != hipSuccess || hipMalloc((void **)&r->d_rtrwork, work_bytes) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(region planes) failed");
+            || hipMalloc((void **)&r->d_state, r->state_bytes) != hipSuccess || hipMalloc((void **)&r->d_rtrwork, work_bytes) != hipSuccess
+            || hipMalloc((void **)&r->d_dirty, (size_t)3 * NSYM * (size_t)((r->npos >> UVC_DIRTY_SHIFT) + 2)) != hipSuccess) return fail(UVCGPU_ENOMEM, "hipMalloc(region planes) failed");
         uvc_rtr_bind(&r->rw, r->d_rtrwork, r->npos, vmax, smax, bqm, scan_tmp);
         r->npos_cap = r->npos;
     }
@@ -272,6 +279,7 @@ static int configure_region(uvcgpu_region *r, int32_t tid, int32_t beg, int32_t 
     R.vq = (int32_t *)(b + r->off[UVC_F_VQ]); R.bqsum = (int32_t *)(b + r->off[UVC_F_BQSUM]); R.frag = (int32_t *)(b + r->off[UVC_F_FRAG]);
     R.fam = (int32_t *)(b + r->off[UVC_F_FAM]); R.faminfo32 = (int32_t *)(b + r->off[UVC_F_FAMINFO32]); R.duplex = (int32_t *)(b + r->off[UVC_F_DUPLEX]);
     R.bucket = (int32_t *)(b + r->bucket_off); R.p5flag = (uint8_t *)(b + r->p5flag_off); R.occ = (uint32_t *)(b + r->occ_off);
+    R.dirty = r->d_dirty; R.ndblk = (int32_t)((r->npos + ((int64_t)1 << UVC_DIRTY_SHIFT) - 1) >> UVC_DIRTY_SHIFT);
     R.err = d_err;
     HIP_OK(hipMemsetAsync(d_err, 0, 4, r->stream));
     return 0;   // nothing to wait for: the staging memory belongs to the handle and a handle is rebound only when its streams are idle
@@ -538,11 +546,51 @@ int uvcgpu_region_read_quals(uvcgpu_region_t *r, uint8_t *dst, int64_t n) {
     return 0;
 }
 
+// Zero fill of the plane slab (everything in front of the bucket planes, and the bucket planes too unless P3b / P5b left them clean) on
+// stream `s`.  When the slab's contents were written under the present layout, only what every accumulate writes and what the last one marked
+// (RegionDev::dirty) is filled; otherwise (first use, the handle was rebound to a region of another length) the whole slab.
+struct ZeroPlaneHost { unsigned long long off; int32_t elem; int16_t fam, sym; };
+static int zero_state(uvcgpu_region *r, hipStream_t s) {
+    const size_t n_dirty = (size_t)3 * NSYM * (size_t)r->R.ndblk;
+    if (r->dirty_npos == r->npos && !getenv("UVCGPU_FILL_ALL")) {
+        if (r->zero_planes_npos != r->npos) {   // the plane table of this layout (once per region length)
+            std::vector<ZeroPlaneHost> v;
+            const size_t n = (size_t)r->npos;
+            auto sym_planes = [&](int g, int nplanes, int elem, int fam) {
+                for (int pl = 0; pl < nplanes; pl++) for (int sy = 0; sy < NSYM; sy++) {
+                    const bool always = (fam == 0 && (sy < UVC_BASE_NN || sy == UVC_LINK_M));
+                    v.push_back({ (unsigned long long)(r->off[g] + ((size_t)pl * NSYM + sy) * n * elem), elem, (int16_t)(always ? -1 : fam), (int16_t)sy });
+                }
+            };
+            for (int pl = 0; pl < UVC_NPREP32; pl++) v.push_back({ (unsigned long long)(r->off[UVC_F_PREP32] + (size_t)pl * n * 4), 4, -1, 0 });
+            for (int pl = 0; pl < UVC_NPREP64; pl++) v.push_back({ (unsigned long long)(r->off[UVC_F_PREP64] + (size_t)pl * n * 8), 8, -1, 0 });
+            // (k_thres stores every threshold of every position, but a handle that is rebound to a region of another length relies on an all-zero slab)
+            for (int pl = 0; pl < UVC_NTHRES; pl++) v.push_back({ (unsigned long long)(r->off[UVC_F_THRES] + (size_t)pl * n * 4), 4, -1, 0 });
+            sym_planes(UVC_F_SEG32, UVC_NSEG32, 4, 0); sym_planes(UVC_F_SEG64, UVC_NSEG64, 8, 0); sym_planes(UVC_F_VQ, UVC_NVQ, 4, 0); sym_planes(UVC_F_BQSUM, 1, 4, 0);
+            sym_planes(UVC_F_FRAG, 2 * UVC_NFRAG, 4, 0); sym_planes(UVC_F_FAM, 2 * UVC_NFAM, 4, 0);
+            sym_planes(UVC_F_FAMINFO32, UVC_NFAMINFO32, 4, 1); sym_planes(UVC_F_FAMINFO64, UVC_NFAMINFO64, 8, 1); sym_planes(UVC_F_DUPLEX, UVC_NDUPLEX, 4, 2);
+            v.push_back({ (unsigned long long)r->p5flag_off, 1, -1, 0 }); v.push_back({ (unsigned long long)(r->p5flag_off + n), 1, -1, 0 });
+            v.push_back({ (unsigned long long)r->occ_off, 4, -1, 0 });
+            if (r->d_zero_planes) { quiesce(r); hipFree(r->d_zero_planes); r->d_zero_planes = nullptr; }
+            HIP_OK(hipMalloc(&r->d_zero_planes, v.size() * sizeof(ZeroPlaneHost)));
+            HIP_OK(hipMemcpy(r->d_zero_planes, v.data(), v.size() * sizeof(ZeroPlaneHost), hipMemcpyHostToDevice));
+            r->n_zero_planes = (int)v.size(); r->zero_planes_npos = r->npos;
+        }
+        uvc_launch_zero_state(r->d_state, r->d_zero_planes, r->n_zero_planes, r->d_dirty, r->R.ndblk, r->npos, s);
+        if (hipGetLastError() != hipSuccess) return fail(UVCGPU_EDEVICE, "zero fill of the planes failed");
+        if (!r->buckets_clean) HIP_OK(hipMemsetAsync(r->d_state + r->bucket_off, 0, r->state_bytes - r->bucket_off, s));
+    } else {
+        HIP_OK(hipMemsetAsync(r->d_state, 0, r->buckets_clean ? r->bucket_off : r->state_bytes, s));
+    }
+    HIP_OK(hipMemsetAsync(r->d_dirty, 0, n_dirty, s));
+    return 0;
+}
+
 static int uvcgpu_region_accumulate_impl(uvcgpu_region_t *r) {
     if (!r) return fail(UVCGPU_EINVAL, "null region");
     if (!r->has_reads) return fail(UVCGPU_ENOREADS, "no reads");   // process_batch returns -1, main.cpp:520-523
     if (r->state_zeroed) HIP_OK(hipStreamWaitEvent(r->stream, r->e_join, 0));   // zeroed behind the last score (release_state)
-    else HIP_OK(hipMemsetAsync(r->d_state, 0, r->buckets_clean ? r->bucket_off : r->state_bytes, r->stream));
+    else { const int rcz = zero_state(r, r->stream); if (rcz) return rcz; }
     r->state_zeroed = false; r->state_released = false;
     r->buckets_clean = false;
     HIP_OK(hipMemcpyAsync(r->d_rtr, r->d_rtr0, (size_t)4 * UVC_NRTR * r->npos, hipMemcpyDeviceToDevice, r->stream));   // P1b edits indelphred in place
@@ -557,6 +605,7 @@ static int uvcgpu_region_accumulate_impl(uvcgpu_region_t *r) {
     uvc_launch_accumulate(&r->R, &r->P, half, r->d_dup_units, r->n_dup, r->d_dup_off, r->n_dup_work, r->stream, &r->prof, r->side, r->e_fork, r->e_join, r->e_fork2, r->side3, r->e_join3, r->e_stat, r->e_alleles);
     HIP_OK(hipGetLastError());
     r->buckets_clean = (r->P.inferred_is_vcf_generated != 0);   // k_frag (P3b) and k_p5b cleared every bucket they consumed
+    r->dirty_npos = r->npos;   // the slab and the marks now describe this layout
     r->accumulated = true; r->gap_ready = false; r->hap_ready = false;
     return 0;
 }
@@ -568,7 +617,7 @@ int uvcgpu_region_check_presence(uvcgpu_region_t *r, int64_t *n_violations) {
     HIP_OK(hipMalloc((void **)&d, 8));
     int rc = 0;
     if (hipMemsetAsync(d, 0, 8, r->stream) != hipSuccess) rc = fail(UVCGPU_EDEVICE, "hipMemsetAsync");
-    if (!rc) { uvc_launch_check_presence(&r->R, d, r->stream); if (hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, r->stream) != hipSuccess || hipStreamSynchronize(r->stream) != hipSuccess) rc = fail(UVCGPU_EDEVICE, "check_presence"); }
+    if (!rc) { uvc_launch_check_presence(&r->R, d, r->stream); uvc_launch_check_dirty(&r->R, d, r->stream); if (hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, r->stream) != hipSuccess || hipStreamSynchronize(r->stream) != hipSuccess) rc = fail(UVCGPU_EDEVICE, "check_presence"); }
     hipFree(d);
     *n_violations = (int64_t)h;
     return rc;
@@ -1046,7 +1095,7 @@ static int uvcgpu_region_score_impl(uvcgpu_region_t *r, const UvcScoreRequest *r
         else if (n_out > out->capacity) rc = fail(UVCGPU_ENOMEM, "score output capacity too small");   // the planes stay: the caller comes back with a larger buffer
         else if (rq.release_state && r->side) {   // the scoring kernels are done: zero the planes on the side stream under the D2H of the records
             if (hipEventRecord(r->e_fork, r->stream) == hipSuccess && hipStreamWaitEvent(r->side, r->e_fork, 0) == hipSuccess
-                && hipMemsetAsync(r->d_state, 0, r->buckets_clean ? r->bucket_off : r->state_bytes, r->side) == hipSuccess && hipEventRecord(r->e_join, r->side) == hipSuccess) {
+                && zero_state(r, r->side) == 0 && hipEventRecord(r->e_join, r->side) == hipSuccess) {
                 r->state_released = true; r->state_zeroed = true; r->zeroed_bytes = r->state_bytes;
             }
         }
@@ -1090,6 +1139,8 @@ void uvcgpu_region_destroy(uvcgpu_region_t *r) {
     if (r->e_join) hipEventDestroy(r->e_join);
     if (r->e_fork2) hipEventDestroy(r->e_fork2);
     if (r->d_state) hipFree(r->d_state);
+    if (r->d_dirty) hipFree(r->d_dirty);
+    if (r->d_zero_planes) hipFree(r->d_zero_planes);
     if (r->R.err) hipFree(r->R.err);
     if (r->d_score_scratch) hipFree(r->d_score_scratch);
     if (r->d_score_fields) hipFree(r->d_score_fields);

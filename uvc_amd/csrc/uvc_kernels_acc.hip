@@ -113,6 +113,7 @@ struct SegAcc {   // SegFormatInfoSet (main_conversion.hpp:645-691) + the VQ a1/
 
 DEV void seg_flush(const RegionDev &R, const SegAcc &A, int sym, int64_t x) {
     atomicOr(&R.occ[x], 1u << sym);   // the scoring gather sums these planes over the marked symbols only (k_enum)
+    mark_sym(R, sym, x);
 #pragma unroll
     for (int f = 0; f < UVC_NSEG32; f++) if (A.s[f]) atomicAdd(&S32(R, f, sym, x), A.s[f]);
 #pragma unroll
@@ -1857,15 +1858,16 @@ __global__ void __launch_bounds__(64) k_frag_generic(RegionDev R, UvcParams P, c
                     if (0x1 & P.fam_flag) phredlike = imin(phredlike, sscs_phred(P, my_ref, cs));
                     const int pbucket = imax(0, max_qual - phredlike);
                     if (pbucket < NBUCKETS) atomicAdd(&BKP(R, 0, cs, pbucket, x), 1);
+                    mark_sym(R, cs, x);
                     atomicAdd(&FRP(R, strand, UVC_FRAG_bDP, cs, x), 1); atomicAdd(&FRP(R, strand, UVC_FRAG_bTA, cs, x), f.n_cov); atomicAdd(&FRP(R, strand, UVC_FRAG_bTB, cs, x), f.n_near);
                     atomicAdd(&VQP(R, UVC_VQ_bMQ, cs, x), fsq);
                 }
                 if (singleton) {   // con / mmm identities of a one-fragment unit (main.hpp:466-520)
                     const int adj = imax(cc4 * 2, ct4) - ct4;
                     const int thr = (st == UVC_BASE_SYMBOL ? P.fam_thres_highBQ_snv : 0);
-                    if (adj >= thr && adj > 0) { atomicAdd(&FAP(R, strand, UVC_FAM_cDP12, cs4, x), 1); atomicAdd(&FAP(R, strand, UVC_FAM_cDP21, cs4, x), 1); }
+                    if (adj >= thr && adj > 0) { mark_sym(R, cs4, x); atomicAdd(&FAP(R, strand, UVC_FAM_cDP12, cs4, x), 1); atomicAdd(&FAP(R, strand, UVC_FAM_cDP21, cs4, x), 1); }
                     const int adj5 = imax(cc * 2, ct) - ct;
-                    if (adj5 > 0 && vcfgen) atomicAdd(&FAP(R, strand, UVC_FAM_cDP1, cs, x), 1);
+                    if (adj5 > 0 && vcfgen) { mark_sym(R, cs, x); atomicAdd(&FAP(R, strand, UVC_FAM_cDP1, cs, x), 1); }
                 }
             }
         }
@@ -1960,6 +1962,7 @@ DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUC
             // invalidate of the XCD's whole L2 -- per wave, 15 000 times per launch: it was what kept every load of the kernel slow.)
             auto add_own = [](int32_t *cell, int v) { __hip_atomic_fetch_add(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
             const int sq = ff->sq, n_cov = ff->n_cov, n_near = ff->n_near;
+            mark_sym(R, cs, xe); mark_sym(R, cs4, xe);
             if ((e >> 23) & 1) {
                 if (pb < NBUCKETS) add_own(&BKP(R, 0, cs, pb, xe), 1);
                 add_own(&FRP(R, st, UVC_FRAG_bDP, cs, xe), 1); add_own(&FRP(R, st, UVC_FRAG_bTA, cs, xe), n_cov); add_own(&FRP(R, st, UVC_FRAG_bTB, cs, xe), n_near);
@@ -2434,10 +2437,12 @@ __global__ void __launch_bounds__(256) k_fam_p4(RegionDev R, UvcParams P) {
         fill_consensus(con, cs, cc, ct, st, false, false);
         if (0 == ct) continue;
         const bool is_fam_good = ((P.fam_thres_dup1add <= ct) && (cc * 100 >= ct * P.fam_thres_dup1perc) && ((u.dflag & 0x1) || (P.fam_flag & 0x2)));
+        mark_sym(R, cs, x);
         atomicAdd(&FAP(R, strand, UVC_FAM_cDP12, cs, x), 1);
         if (1 == ct) atomicAdd(&FAP(R, strand, UVC_FAM_cDP21, cs, x), 1);
         if (!P.inferred_is_vcf_generated) continue;
         if (is_fam_good) {
+            mark_fi(R, cs, x);
             atomicAdd(&FAP(R, strand, UVC_FAM_cDP2, cs, x), 1);
             int rbeg = imin(u.nsb_min, p), rend = imax(u.nsb_max, p);
             const bool nonconf_middle = (u.l2r_end_median <= (u.r2l_end_median + P.indel_adj_tracklen_dist));
@@ -2490,6 +2495,7 @@ __global__ void __launch_bounds__(256) k_fam_p4(RegionDev R, UvcParams P) {
         const int sb = (st == 0 ? UVC_BASE_A : UVC_LINK_M), se = (st == 0 ? UVC_BASE_NN : UVC_LINK_NN);
         int m = 0, M = 0;
         for (int s = sb; s <= se; s++) if (s != cs) { m += con[s]; M += ct; }
+        mark_sym(R, cs, x);
         if (m) atomicAdd(&FAP(R, strand, UVC_FAM_cDPm, cs, x), m);
         atomicAdd(&FAP(R, strand, UVC_FAM_cDPM, cs, x), M);
     }
@@ -2520,6 +2526,7 @@ __global__ void __launch_bounds__(256) k_fam_p5(RegionDev R, UvcParams P) {
         int tot_nfrags = 0;
         const int sb = (st == 0 ? UVC_BASE_A : UVC_LINK_M), se = (st == 0 ? UVC_BASE_NN : UVC_LINK_NN);
         for (int s = sb; s <= se; s++) tot_nfrags += con[s];
+        mark_sym(R, cs, x);
         atomicAdd(&FAP(R, strand, UVC_FAM_cDP1, cs, x), 1);
         if (will_inc_sscs && (!will_inc_dscs) && (tot_nfrags >= P.fam_thres_dup1add) && (con_nfrags * 100 >= tot_nfrags * P.fam_thres_dup1perc))
             atomicAdd(&FAP(R, strand, UVC_FAM_cDPD, cs, x), 1);
@@ -2553,9 +2560,9 @@ struct FamAcc {
     DEV int dense(int cs) const { return !a32 ? -1 : (cs == my_ref ? 0 : (cs == UVC_LINK_M ? 1 : -1)); }   // without LDS accumulators (k_fam_p4d_rest) every increment is a global atomic
     // a window kernel (a32 set) owns its positions: its adds to the planes are L2 atomics of workgroup scope (add_own)
     DEV void gadd(int32_t *p, int v) const { if (a32) add_own(p, v); else atomicAdd(p, v); }
-    DEV void fap(int strand, int f, int cs, int v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a32[d][strand * UVC_NFAM + f][lane], v); else gadd(&FAP(*R, strand, f, cs, x), v); }
-    DEV void fi(int f, int cs, int v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a32[d][2 * UVC_NFAM + f][lane], v); else gadd(&FIP(*R, f, cs, x), v); }
-    DEV void fi64(int f, int cs, long long v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a64[d][f][lane], (unsigned long long)v); else if (a32) add64_own(&FI64P(*R, f, cs, x), v); else add64(&FI64P(*R, f, cs, x), v); }
+    DEV void fap(int strand, int f, int cs, int v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a32[d][strand * UVC_NFAM + f][lane], v); else { mark_sym(*R, cs, x); gadd(&FAP(*R, strand, f, cs, x), v); } }
+    DEV void fi(int f, int cs, int v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a32[d][2 * UVC_NFAM + f][lane], v); else { mark_fi(*R, cs, x); gadd(&FIP(*R, f, cs, x), v); } }
+    DEV void fi64(int f, int cs, long long v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a64[d][f][lane], (unsigned long long)v); else { mark_fi(*R, cs, x); if (a32) add64_own(&FI64P(*R, f, cs, x), v); else add64(&FI64P(*R, f, cs, x), v); } }
     DEV void bucket(int strand, int cs, int b) const { const int d = dense(cs); if (d >= 0) atomicAdd(&bk[d][strand][b][lane], 1); else gadd(&BKP(*R, strand, cs, b, x), 1); R->p5flag[(size_t)strand * R->npos + x] = 1; }
 };
 
@@ -2847,13 +2854,14 @@ __global__ void __launch_bounds__(256) k_fam_win(RegionDev R, UvcParams P) {
         const int64_t xx = x0 + ln;
         const int sym = (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M);
         if (slot < 2 * UVC_NFAM) add_own(&FAP(R, slot / UVC_NFAM, slot % UVC_NFAM, sym, xx), v);
-        else add_own(&FIP(R, slot - 2 * UVC_NFAM, sym, xx), v);
+        else { mark_fi(R, sym, xx); add_own(&FIP(R, slot - 2 * UVC_NFAM, sym, xx), v); }
     }
     for (int i = threadIdx.x; i < 2 * UVC_NFAMINFO64 * 64; i += 256) {
         const unsigned long long v = (&a64[0][0][0])[i];
         if (!v) continue;
         const int ln = i & 63, f = (i >> 6) % UVC_NFAMINFO64, d = (i >> 6) / UVC_NFAMINFO64;
         const int64_t xx = x0 + ln;
+        mark_fi(R, (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M), xx);
         add64_own(&FI64P(R, f, (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M), xx), (long long)v);
     }
     if (PASS == 5) for (int i = threadIdx.x; i < 2 * 2 * NBUCKETS * 64; i += 256) {
@@ -3050,13 +3058,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
         const int64_t xx = x0 + ln;
         const int sym = (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M);
         if (slot < 2 * UVC_NFAM) add_own(&FAP(R, slot / UVC_NFAM, slot % UVC_NFAM, sym, xx), v);
-        else add_own(&FIP(R, slot - 2 * UVC_NFAM, sym, xx), v);
+        else { mark_fi(R, sym, xx); add_own(&FIP(R, slot - 2 * UVC_NFAM, sym, xx), v); }
     }
     for (int i = threadIdx.x; i < 2 * UVC_NFAMINFO64 * 64; i += 256) {
         const unsigned long long v = (&a64[0][0][0])[i];
         if (!v) continue;
         const int ln = i & 63, f = (i >> 6) % UVC_NFAMINFO64, d = (i >> 6) / UVC_NFAMINFO64;
         const int64_t xx = x0 + ln;
+        mark_fi(R, (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M), xx);
         add64_own(&FI64P(R, f, (d == 0 ? (int)R.refsym[xx] : UVC_LINK_M), xx), (long long)v);
     }
 }
@@ -3130,7 +3139,7 @@ __global__ void __launch_bounds__(256) k_duplex(RegionDev R, UvcParams P, const 
     for (int st = 0; st < 2; st++) {
         int cs, cc, ct;
         fill_consensus(dup, cs, cc, ct, st, false, false);
-        if (0 < ct) atomicAdd(&DUP(R, UVC_DUPLEX_dDP1, cs, x), 1);
+        if (0 < ct) { mark_dup(R, cs, x); atomicAdd(&DUP(R, UVC_DUPLEX_dDP1, cs, x), 1); }
         if (1 < ct) atomicAdd(&DUP(R, UVC_DUPLEX_dDP2, cs, x), 1);
     }
 }
@@ -3157,6 +3166,7 @@ __global__ void __launch_bounds__(64) k_duplex_d(RegionDev R, const int32_t *dup
             const int sa = (int)(a & 15u), sb = (int)(b & 15u);
             const int ct = (va ? 1 : 0) + (vb ? 1 : 0);
             const int cs = (va && vb) ? ((sa == sb) ? sa : imin(sa, sb)) : (va ? sa : sb);
+            mark_dup(R, cs, x);
             atomicAdd(&DUP(R, UVC_DUPLEX_dDP1, cs, x), 1);
             if (1 < ct) atomicAdd(&DUP(R, UVC_DUPLEX_dDP2, cs, x), 1);   // tot_count of the two votes, as fill_consensus sums it (main.hpp:3540-3546)
         }
@@ -3719,6 +3729,52 @@ extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const 
 // a side stream underneath the two issue-bound P2 kernels and join before anything reads their outputs.
 #define TIMED2(prof, kname, ...) do { hipStream_t s = s2; TIMED(prof, kname, __VA_ARGS__); } while (0)
 #define TIMED3(prof, kname, ...) do { hipStream_t s = s3; TIMED(prof, kname, __VA_ARGS__); } while (0)
+// Zero fill of the plane slab in front of an accumulate, without the parts the last accumulate did not write (RegionDev::dirty): a block
+// per (plane, block of 4 096 positions).  A 1 Mb tile's slab is 5.6 KB per position; what every tile writes (the per-position planes, the
+// planes of A C G T N and LINK_M) is 2.5 KB of it, the rest a few per cent.
+struct ZeroPlane { unsigned long long off; int32_t elem; int16_t fam, sym; };   // fam < 0: always filled
+__global__ void __launch_bounds__(256) k_zero_state(char *slab, const ZeroPlane *planes, const uint8_t *dirty, int ndblk, int64_t npos) {
+    const ZeroPlane zp = planes[blockIdx.x];
+    const int b = (int)blockIdx.y;
+    if (zp.fam >= 0 && !dirty[((size_t)zp.fam * NSYM + zp.sym) * ndblk + b]) return;
+    const int64_t x0 = (int64_t)b << UVC_DIRTY_SHIFT, x1 = (x0 + ((int64_t)1 << UVC_DIRTY_SHIFT) < npos ? x0 + ((int64_t)1 << UVC_DIRTY_SHIFT) : npos);
+    char *p0 = slab + zp.off + x0 * zp.elem, *p1 = slab + zp.off + x1 * zp.elem;
+    char *a0 = (char *)(((uintptr_t)p0 + 15) & ~(uintptr_t)15), *a1 = (char *)((uintptr_t)p1 & ~(uintptr_t)15);
+    if (a0 >= a1) { for (char *q = p0 + threadIdx.x; q < p1; q += 256) *q = 0; return; }
+    for (char *q = p0 + threadIdx.x; q < a0; q += 256) *q = 0;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (uint4 *q = (uint4 *)a0 + threadIdx.x; q < (uint4 *)a1; q += 256) *q = z;
+    for (char *q = a1 + threadIdx.x; q < p1; q += 256) *q = 0;
+}
+extern "C" void uvc_launch_zero_state(char *slab, const void *planes, int n_planes, uint8_t *dirty, int ndblk, int64_t npos, hipStream_t s) {
+    if (n_planes <= 0 || ndblk <= 0) return;
+    hipLaunchKernelGGL(k_zero_state, dim3((unsigned)n_planes, (unsigned)ndblk), dim3(256), 0, s, slab, (const ZeroPlane *)planes, dirty, ndblk, npos);
+}
+// uvcgpu_region_check_presence, second half: a (family, symbol, block) that is not marked holds only zeros
+__global__ void __launch_bounds__(256) k_check_dirty(RegionDev R, unsigned long long *n_bad) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = (int)blockIdx.y;
+    if (x >= R.npos) return;
+    const int b = (int)(x >> UVC_DIRTY_SHIFT);
+    long long core = 0, fi = 0, du = 0;
+    for (int f = 0; f < UVC_NSEG32; f++) core |= S32(R, f, s, x);
+    for (int f = 0; f < UVC_NSEG64; f++) core |= S64(R, f, s, x);
+    for (int f = 0; f < UVC_NVQ; f++) core |= VQP(R, f, s, x);
+    core |= BQS(R, s, x);
+    for (int st = 0; st < 2; st++) { for (int f = 0; f < UVC_NFRAG; f++) core |= FRP(R, st, f, s, x); for (int f = 0; f < UVC_NFAM; f++) core |= FAP(R, st, f, s, x); }
+    for (int f = 0; f < UVC_NFAMINFO32; f++) fi |= FIP(R, f, s, x);
+    for (int f = 0; f < UVC_NFAMINFO64; f++) fi |= FI64P(R, f, s, x);
+    for (int f = 0; f < UVC_NDUPLEX; f++) du |= DUP(R, f, s, x);
+    int bad = 0;
+    if (core && !sym_always_filled(s) && !R.dirty[(size_t)s * R.ndblk + b]) bad++;
+    if (fi && !R.dirty[((size_t)NSYM + s) * R.ndblk + b]) bad++;
+    if (du && !R.dirty[((size_t)2 * NSYM + s) * R.ndblk + b]) bad++;
+    if (bad) atomicAdd(n_bad, (unsigned long long)bad);
+}
+extern "C" void uvc_launch_check_dirty(const RegionDev *R, unsigned long long *d_n_bad, hipStream_t s) {
+    hipLaunchKernelGGL(k_check_dirty, dim3((unsigned)((R->npos + 255) / 256), NSYM), dim3(256), 0, s, *R, d_n_bad);
+}
+
 extern "C" void uvc_launch_accumulate(const RegionDev *R, const UvcParams *P, int half_ratio_phred,
                                       const int32_t *dup_units, int n_dup, const int64_t *dup_off, int64_t n_dup_work, hipStream_t s, UvcProf *prof,
                                       hipStream_t side, hipEvent_t e_fork, hipEvent_t e_join, hipEvent_t e_fork2, hipStream_t side3, hipEvent_t e_join3, hipEvent_t e_stat, hipEvent_t e_alleles) {
