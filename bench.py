@@ -71,17 +71,46 @@ PROFILE_NAMES = {"k_p2_fast_link": ("k_p2_fast<true, false, true>", "k_p2_fast<t
                  "k_prep_fast": ("k_prep_fast<false>", "k_prep_fast<true>"), "k_p2_slow_walk": ("k_p2_slow<true>",), "k_p2_slow_table": ("k_p2_slow<false>",), "k_frag": ("k_frag16<true>", "k_frag16<false>", "k_frag<true>", "k_frag<false>")}
 
 
+def kernel_source_hash():
+    """sha256 over the device sources the PMC passes were taken on (uvc_amd/csrc/*.hip and the headers they include): the replayed counters
+    are only quoted while the kernels are the ones that were counted."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "uvc_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "uvc_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+_TRAFFIC = {}
+
+
+def _traffic_table(tile_kb, depth):
+    """profiles/traffic_latest.json when it was counted on this workload AND on these kernel sources, else None (`_why` says which)."""
+    if "t" not in _TRAFFIC:
+        _TRAFFIC["t"], _TRAFFIC["why"] = None, "profiles/traffic_latest.json is missing"
+        path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        try:
+            t = json.load(open(path))
+            if t.get("_workload") != {"tile_kb": tile_kb, "depth": depth}:
+                _TRAFFIC["why"] = "the committed PMC passes were taken on another workload"
+            elif t.get("_source_hash") != kernel_source_hash():
+                _TRAFFIC["why"] = "stale: the kernel sources changed since the committed PMC passes (source hash %s, counted on %s); rerun scripts/gpu_round_profile.sh" % (kernel_source_hash(), t.get("_source_hash"))
+            else:
+                _TRAFFIC["t"], _TRAFFIC["why"] = t, "replayed from profiles/traffic_latest.json (separate rocprofv3 --pmc passes on these kernel sources, hash %s), not measured in this run" % t["_source_hash"]
+        except (OSError, ValueError):
+            pass
+    return _TRAFFIC["t"]
+
+
 def replayed_traffic(kernel, tile_kb, depth):
     """HBM-side bytes per launch of `kernel`, REPLAYED from the committed PMC passes (profiles/traffic_latest.json, made by
     scripts/gpu_round_profile.sh: FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes) -- not measured in this run.  None when the passes were
-    taken on another workload."""
-    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if not os.path.exists(path):
+    taken on another workload or on other kernel sources."""
+    t = _traffic_table(tile_kb, depth)
+    if t is None:
         return None
     try:
-        t = json.load(open(path))
-        if t.get("_workload") != {"tile_kb": tile_kb, "depth": depth}:
-            return None
         for name in PROFILE_NAMES.get(kernel, (kernel,)):
             if name in t:
                 return t[name]["traffic_bytes_per_launch"]
@@ -107,27 +136,23 @@ def valu_issue(kernel, kernel_ms, args):
 
 def replayed_valu(kernel, tile_kb, depth):
     """VALU wave-instructions per launch of `kernel`, REPLAYED from the committed PMC pass (SQ_INSTS_VALU in profiles/traffic_latest.json)."""
-    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    try:
-        t = json.load(open(path))
-        if t.get("_workload") != {"tile_kb": tile_kb, "depth": depth}:
-            return None
-        for name in PROFILE_NAMES.get(kernel, (kernel,)):
-            if name in t and "SQ_INSTS_VALU_per_launch" in t[name]:
-                return t[name]["SQ_INSTS_VALU_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    t = _traffic_table(tile_kb, depth)
+    if t is None:
+        return None
+    for name in PROFILE_NAMES.get(kernel, (kernel,)):
+        if name in t and "SQ_INSTS_VALU_per_launch" in t[name]:
+            return t[name]["SQ_INSTS_VALU_per_launch"]
     return None
 
 
 def _cpu_region(args):
     from uvc_amd import synth
-    seed, region_len, depth = args
-    return synth.generate_region(seed=seed, region_len=region_len, depth=depth)
+    seed, region_len, depth, umi = args
+    return synth.generate_region(seed=seed, region_len=region_len, depth=depth, umi=umi)
 
 
-def run_cpu_baseline(depth, n_regions=64, region_len=20000):
-    """Times the oracle (test infrastructure) on `n_regions` independent regions, one thread each: accumulate + default-gate scoring."""
+def run_cpu_baseline(depth, n_regions=64, region_len=20000, umi=False, all_out=False, what="accumulate + default-gate scoring"):
+    """Times the oracle (test infrastructure) on `n_regions` independent regions, one thread each: accumulate + scoring."""
     from concurrent.futures import ThreadPoolExecutor
     from uvc_amd import _ffi, region
     lib = _ffi.Lib(__import__("oracle").library_path(), "uvc_oracle_")
@@ -135,14 +160,14 @@ def run_cpu_baseline(depth, n_regions=64, region_len=20000):
     cores = min(16, os.cpu_count() or 1)
     regs = []
     for i in range(n_regions):
-        r = _cpu_region((777 + i, region_len, depth))
+        r = _cpu_region((777 + i, region_len, depth, umi))
         R = region.Region(lib, params, r["tid"], r["beg"], r["end"], r["refseq"])
         R.set_reads(r)
         regs.append(R)
 
     def work(R):
         R.accumulate()
-        return len(R.score()["refpos"])
+        return len(R.score(all_out=all_out)["refpos"])
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as ex:
@@ -151,14 +176,63 @@ def run_cpu_baseline(depth, n_regions=64, region_len=20000):
     for R in regs:
         R.close()
     return {"value": n_regions * region_len / dt, "unit": "positions/s", "cores": cores, "kind": "port",
-            "sample": "%d regions x %d bp = %.2f Mb at %dx, oracle (scalar C++ port of the reference algorithm), one region per thread, accumulate + default-gate scoring, %.1f s wall"
-                      % (n_regions, region_len, n_regions * region_len / 1e6, depth, dt)}
+            "sample": "%d regions x %d bp = %.2f Mb at %dx%s, oracle (scalar C++ port of the reference algorithm), one region per thread, %s, %.1f s wall"
+                      % (n_regions, region_len, n_regions * region_len / 1e6, depth, " duplex-UMI" if umi else "", what, dt)}
+
+
+def run_cpu_baseline_tn(depth_t, depth_n, n_regions=32, region_len=20000):
+    """The T/N flow of config 5 on the oracle: tumor pass, keys from its written records, normal pass on the keys; one region pair per thread."""
+    from concurrent.futures import ThreadPoolExecutor
+    from uvc_amd import _ffi, region, synth
+    lib = _ffi.Lib(__import__("oracle").library_path(), "uvc_oracle_")
+    pt, pn = region.default_params(lib), region.default_params(lib)
+    pn.tumor_vcf_is_provided = 1
+    cores = min(16, os.cpu_count() or 1)
+    pairs = []
+    for i in range(n_regions):
+        rt = synth.generate_region(seed=877 + i, region_len=region_len, depth=depth_t)
+        rn = synth.generate_region(seed=877 + i, region_len=region_len, depth=depth_n, somatic_every=10 ** 9)
+        Rt = region.Region(lib, pt, rt["tid"], rt["beg"], rt["end"], rt["refseq"]); Rt.set_reads(rt)
+        Rn = region.Region(lib, pn, rn["tid"], rn["beg"], rn["end"], rn["refseq"]); Rn.set_reads(rn)
+        pairs.append((Rt, Rn))
+
+    def work(pr):
+        Rt, Rn = pr
+        Rt.accumulate()
+        keys = tumor_keys_of(Rt.score())
+        Rn.accumulate()
+        return len(Rn.score(tumor_keys=keys)["refpos"])
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        list(ex.map(work, pairs))
+    dt = time.perf_counter() - t0
+    for Rt, Rn in pairs:
+        Rt.close(); Rn.close()
+    return {"value": n_regions * region_len / dt, "unit": "positions/s", "cores": cores, "kind": "port",
+            "sample": "%d region pairs x %d bp at %dx / %dx, oracle, one pair per thread: tumor pass, keys from its written records, normal pass on the keys, %.1f s wall" % (n_regions, region_len, depth_t, depth_n, dt)}
+
+
+def tumor_keys_of(rec):
+    """The tumor records that reach the VCF (keep && out) as UvcTumorKey tuples (TumorKeyInfo, main_conversion.hpp:490-529; the fields
+    rescue_variants_from_vcf reads back, main.cpp:183-398): what the normal pass of uvcTN.sh receives through --tumor-vcf."""
+    w = np.nonzero((rec["keep"] != 0) & (rec["out"] != 0))[0]
+    keys = set()
+    for i in w:
+        sym = int(rec["symbol"][i])
+        keys.add((int(rec["refpos"][i]), sym, int(rec["cDP1x"][i]), int(rec["CDP1x0"][i]), int(rec["bAD"][i]), int(rec["bDP"][i]), int(rec["tier2"][i]),
+                  int(rec["gapSa_len"][i]) if sym in (7, 8, 9, 10, 11, 12) else 0, int(rec["cVQ1"][i]), int(rec["cPCQ1"][i]), int(rec["cDP2x"][i]), int(rec["CDP2x0"][i]),
+                  int(rec["cVQ2"][i]), int(rec["cPCQ2"][i]), int(rec["bNMQ"][i]), int(rec["vHGQ"][i]), int(rec["DP"][i])))
+    first = {}
+    for k in sorted(keys):   # one record per (refpos, symbol, InDel length): the key of the tumor map
+        first.setdefault((k[0], k[1], k[7]), k)
+    return sorted(first.values(), key=lambda k: (k[0], k[1]))
 
 
 def _gen_tile(a):
     from uvc_amd import synth
-    seed, region_len, depth, beg, umi = a
-    extra = {}
+    seed, region_len, depth, beg, umi = a[:5]
+    extra = dict(a[5]) if len(a) > 5 else {}
     if os.environ.get("UVC_BENCH_INDEL_EVERY"):   # experiment knob: spacing of the synthetic InDels (0 = none); the default workload does not set it
         extra["indel_every"] = int(os.environ["UVC_BENCH_INDEL_EVERY"])
     return synth.generate_region(seed=seed, region_len=region_len, depth=depth, beg=beg, umi=umi, **extra)
@@ -266,6 +340,44 @@ def side_leg(lib, region, params, tiles, dev, torch, steps, all_out, depth, what
     return out
 
 
+def config5_leg(lib, region, params, tumor, normal, dev, torch, repeats=3):
+    """BASELINE config 5 shape on one GPU: the two passes of uvcTN.sh:120-127 on one tile pair -- tumor pass (300x: reset, set_reads, accumulate,
+    default-gate scoring, records to the host), the written records as UvcTumorKey[] (what --tumor-vcf carries, main.cpp:183-398), normal
+    pass (100x, tumor_vcf_is_provided: the keyed positions are scored, every symbol of them, NLODQ / SomaticQ through the T/N arms).
+    Positions per second of the PAIR; columns resident in HBM; strictly one pass after the other (the normal pass needs the tumor's keys)."""
+    pn = region.default_params(lib)
+    pn.tumor_vcf_is_provided = 1
+    rl = tumor["end"] - tumor["beg"]
+    dt_, dn_ = region.device_reads(tumor, dev), region.device_reads(normal, dev)
+    Rt = region.Region(lib, params, tumor["tid"], tumor["beg"], tumor["end"], tumor["refseq"])
+    Rn = region.Region(lib, pn, normal["tid"], normal["beg"], normal["end"], normal["refseq"])
+    ref_t = tumor["refseq"].encode() if isinstance(tumor["refseq"], str) else bytes(tumor["refseq"])
+    ref_n = normal["refseq"].encode() if isinstance(normal["refseq"], str) else bytes(normal["refseq"])
+    cap = max(65536, rl // 4)
+    times, n_keys, n_rec = [], 0, 0
+    for rep_ in range(repeats + 1):   # the first pair primes the handles
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        Rt.reset(tumor["tid"], tumor["beg"], tumor["end"], ref_t); Rt.set_reads_device(dt_); Rt.accumulate()
+        rec = Rt.score(capacity=cap, copy=False, release_state=True, kept_only=True)
+        t1 = time.perf_counter()
+        keys = tumor_keys_of(rec)
+        t2 = time.perf_counter()
+        Rn.reset(normal["tid"], normal["beg"], normal["end"], ref_n); Rn.set_reads_device(dn_); Rn.accumulate()
+        recn = Rn.score(capacity=cap, copy=False, release_state=True, kept_only=True, tumor_keys=keys)
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        if rep_:
+            times.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
+        n_keys, n_rec = len(keys), len(recn["refpos"])
+    Rt.close(); Rn.close()
+    times.sort()
+    med = times[len(times) // 2]
+    return {"workload": "BASELINE config 5 shape: one tumor (300x) / normal (100x) tile pair of %d kb, non-UMI, columns resident in HBM; tumor pass -> its written records as UvcTumorKey[] -> normal pass "
+                        "(uvcTN.sh:120-127, main.cpp:183-398, 1073-1169); the two passes strictly one after the other" % (rl // 1000),
+            "tile_positions": rl, "repeats": len(times), "ms_per_pair": 1e3 * med[0], "ms_tumor_pass": 1e3 * med[1], "ms_keys_host": 1e3 * med[2], "ms_normal_pass": 1e3 * med[3],
+            "ms_per_pair_min_max": [1e3 * times[0][0], 1e3 * times[-1][0]], "value": rl / med[0], "unit": "positions/s (of the pair)", "tumor_keys": n_keys, "normal_records_returned": n_rec,
+            "reads_tumor": int(tumor["n_reads"]), "reads_normal": int(normal["n_reads"])}
+
+
 def score_roofline(ms, npos, n_records, all_out):
     """The scoring kernels (candidate gate + scan + k_score + k_call + kept-groups copy; HIP events around uvc_launch_score) against HBM.
     `nominal`: SURVEY 8(d)'s per-position figure for the scoring kernel (5.6 KB default gate: the whole accumulator record read once;
@@ -273,7 +385,7 @@ def score_roofline(ms, npos, n_records, all_out):
     position (112 B), and only a scored record reads its ~5.5 KB of state and writes its fields."""
     nominal = (8300.0 if all_out else 5600.0) * npos
     needed = nominal if all_out else 112.0 * npos + n_records * (5544.0 + 4.0 * 160)
-    return {"bound": "hbm", "kernels": "k_score_count + scans + k_score + k_call (+ kept-groups copy)", "kernel_ms": ms, "records": n_records,
+    return {"bound": "hbm", "kernels": "k_gate_scan + k_enum + k_gather + k_dpv_pre + k_dp4 + k_dpv_post + k_qual + k_call (+ k_keep_scan + k_keep_copy): HIP events around uvc_launch_score", "kernel_ms": ms, "records": n_records,
             "algorithmic_bytes_nominal": nominal, "achieved_nominal": nominal / (ms * 1e-3) / 1e9, "frac_nominal": nominal / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "algorithmic_bytes": needed, "achieved": needed / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": needed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
@@ -283,8 +395,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--repeats", type=int, default=3, help="how many times the timed region of K steps is run; `value` is the median")
     ap.add_argument("--tile-kb", type=int, default=1000, help="tile length in kb (chr20 is processed as 1 Mb tiles)")
     ap.add_argument("--tiles", type=int, default=8, help="number of distinct tiles per rank in the stream")
+    ap.add_argument("--total-tiles", type=int, default=0, help="STRONG scaling: one job of this many distinct tiles (config 3's shape: a tile list cut into contiguous region shards, "
+                                                                "uvcio_plan_shards) dealt to the N ranks; each rank streams its own shard once; value = all positions / max-over-ranks time")
     ap.add_argument("--depth", type=int, default=300)
     ap.add_argument("--umi", action="store_true", help="duplex-UMI families (BASELINE config 4 shape when combined with --depth 2000 --tile-kb 200)")
     ap.add_argument("--all-out", action="store_true", help="second series of SURVEY 8(d): score every symbol of every position (-A), not only the default-gate candidates")
@@ -323,12 +438,34 @@ def main():
     # ---- synthetic tiles (host, before any GPU call so that the generator may fork) ----
     side = (world == 1) and not (args.no_side or args.no_extras or args.umi or args.all_out or args.tile_kb != 1000 or args.depth != 300)
     t_gen = time.perf_counter()
-    specs = [(12345 + rank + 1000 * i, region_len, args.depth, 1000000 + i * (region_len + 1000), args.umi) for i in range(args.tiles)]
+    # every rank keeps to its own share of the host cores (the generator's workers, the launch thread, the library's pools): N ranks of one node
+    # must not oversubscribe each other
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        mine = cores[rank * len(cores) // world:(rank + 1) * len(cores) // world]
+        if world > 1 and mine:
+            os.sched_setaffinity(0, mine)
+    except (AttributeError, OSError):
+        pass
+    strong = args.total_tiles > 0
+    if strong:
+        # the same job for every N: tile i of the list has seed 12345 + 1000 i whoever owns it; rank r owns the r-th of N contiguous runs of equal cost
+        # (equal tiles: the cut of uvcio_plan_shards / shard.plan_contiguous)
+        cut = shard.plan_contiguous([1000] * args.total_tiles, world)
+        own = [i for i in range(args.total_tiles) if int(cut[i]) == rank]
+        specs = [(12345 + 1000 * i, region_len, args.depth, 1000000 + i * (region_len + 1000), args.umi) for i in own]
+        args.tiles = len(specs)
+        args.steps = len(specs)          # the timed region of a rank: its shard, every tile once
+        args.warmup = min(args.warmup, len(specs))
+    else:
+        specs = [(12345 + rank + 1000 * i, region_len, args.depth, 1000000 + i * (region_len + 1000), args.umi) for i in range(args.tiles)]
     n_main = len(specs)
     if side:
         specs += [(4000 + i, 200000, 2000, 1000000 + i * 201000, True) for i in range(2)]      # BASELINE config 4 shape: 200 kb duplex-UMI panel tiles at 2000x
         specs += [(5000, 200000, args.depth, 1000000, False)]                                   # all-out scoring (-A) tile
-    workers = min(len(specs), 6 if world == 1 else 2, max(1, (os.cpu_count() or 2) // max(1, world)))
+        # BASELINE config 5 shape: one tumor (300x) / normal (100x) tile pair over the same reference (same seed: the reference is drawn first), no somatic variants in the normal
+        specs += [(6000, region_len, 300, 1000000, False), (6000, region_len, 100, 1000000, False, {"somatic_every": 10 ** 9})]
+    workers = max(1, min(len(specs), 6 if world == 1 else 2, max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2) // max(1, world))))
     if workers > 1:
         from concurrent.futures import ProcessPoolExecutor
         with ProcessPoolExecutor(max_workers=workers) as ex:
@@ -404,16 +541,20 @@ def main():
 
     run_stream(0, T)              # untimed priming: every handle once (its first set_reads sizes the cached device blocks, its first score page-locks its records buffer)
     run_stream(0, args.warmup)    # the W warmup steps of the contract
+    # the timed region, `--repeats` times (default 3): exactly K steps each, bracketed by barrier + synchronize on both sides, max over ranks;
+    # `value` is the MEDIAN repeat (boxes and runs differ by a few per cent: one 0.2 s region is a sample, not a measurement), all of them are on the line
     ktimes = {}
-    torch.cuda.synchronize(); clock.barrier()
-    t0 = time.perf_counter()
-    n_rec = run_stream(args.warmup, args.steps, ktimes=ktimes)
-    torch.cuda.synchronize(); clock.barrier()
-    own_dt = time.perf_counter() - t0
+    reps = []
+    for rep_ in range(max(1, args.repeats)):
+        torch.cuda.synchronize(); clock.barrier()
+        t0 = time.perf_counter()
+        n_rec = run_stream(args.warmup + rep_ * args.steps, args.steps, ktimes=ktimes)
+        torch.cuda.synchronize(); clock.barrier()
+        own_dt = time.perf_counter() - t0
+        reps.append((clock.max_over_ranks(own_dt), clock.min_over_ranks(own_dt)))
     scored_main = leg.scored
-    dt = clock.max_over_ranks(own_dt)
-    dt_min = clock.min_over_ranks(own_dt)
-    total_positions = clock.sum_over_ranks(float(region_len)) * args.steps
+    dt, dt_min = sorted(reps)[len(reps) // 2]
+    total_positions = (clock.sum_over_ranks(float(region_len) * args.steps) if strong else clock.sum_over_ranks(float(region_len)) * args.steps)
 
     pcie = resident = in_flight4 = None
     if not args.no_extras and not args.serial and T >= 4:
@@ -506,6 +647,11 @@ def main():
                                        "BASELINE config 4 shape: 2 distinct 200 kb duplex-UMI panel tiles at 2000x, pipelined over two handles, inputs resident in HBM, same step as `value`")
         side_out["all_out"] = side_leg(lib, region, params, side_tiles[2:3], dev, torch, 3, True, args.depth,
                                        "second series of SURVEY 8(d): one 200 kb non-UMI tile at %dx with -A (every symbol of every position scored, 14 records per position, every record returned)" % args.depth)
+        side_out["config5"] = config5_leg(lib, region, params, side_tiles[3], side_tiles[4], dev, torch)
+        if not args.no_cpu_baseline:   # the oracle on bounded samples of the same shapes, beside each side leg (both series, every config)
+            side_out["config4"]["cpu_baseline"] = run_cpu_baseline(2000, n_regions=16, region_len=4000, umi=True, what="accumulate + default-gate scoring")
+            side_out["all_out"]["cpu_baseline"] = run_cpu_baseline(args.depth, n_regions=32, region_len=10000, all_out=True, what="accumulate + all-out scoring (-A)")
+            side_out["config5"]["cpu_baseline"] = run_cpu_baseline_tn(300, 100, n_regions=32, region_len=10000)
 
     if rank == 0:
         avg = {k: sum(v) / len(v) for k, v in ktimes.items()}
@@ -517,8 +663,10 @@ def main():
         out = {
             "metric": METRIC, "value": total_positions / dt, "unit": "positions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "higher_is_better": True, "scaling": ("strong" if strong else "weak"), "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "per_rank_ms_per_step": {"min": 1e3 * dt_min / args.steps, "max": 1e3 * dt / args.steps},
+            "repeats": {"n": len(reps), "ms_per_step": [round(1e3 * r[0] / args.steps, 4) for r in reps], "ms_per_step_min": 1e3 * min(r[0] for r in reps) / args.steps,
+                        "ms_per_step_max": 1e3 * max(r[0] for r in reps) / args.steps, "value_is": "the median repeat (each repeat: exactly `steps` steps between barrier + synchronize, max over ranks)"},
             "config": {"workload": "stream of %d DISTINCT chr20-shaped tumor-only %s tiles per GPU (%d kb at %dx, 150 bp paired-end), UvcReadSoA columns (BAM 4-bit bases, qualities, per-read fields) resident in HBM; "
                                    "step = one tile: region reset (CHAR_TO_SYMBOL, refstring2repeatvec, BAQ prefix sums of the tile's own reference on the device) + set_reads(offset scans, base unpack, CIGAR facts + "
                                    "family/fragment nesting, radix orders, k_aln_prelude, k_build_p2list) + accumulate P1..P5b + "
@@ -527,12 +675,17 @@ def main():
                                    "; tiles strictly one after the other" if args.serial else ("; %d tiles in flight, one host thread each, every tile on its own handle" % n_thr_value if n_thr_value > 1 else "; tiles software-pipelined over their handles (tile k+1 is prepared and accumulating while tile k is scored)")),
                        "tile_positions": region_len, "distinct_tiles": T, "pipelined": (not args.serial) and T >= 2, "tiles_in_flight": (1 if args.serial else (n_thr_value if n_thr_value > 1 else 2)), "all_out": bool(args.all_out), "umi": bool(args.umi), "reads_per_tile": n_reads_tile,
                        "read_bases_per_tile": n_reads_tile * READ_LEN, "input_bytes_per_tile": input_bytes_tile, "returned_records_last_tile": n_rec, "kept_only": not args.all_records,
-                       "parallelism": "region-shard x%d (no collective on the data path)" % world},
+                       "parallelism": "region-shard x%d (no collective on the data path)" % world,
+                       "strong_scaling_job": ({"total_tiles": args.total_tiles, "tiles_of_rank0": T, "note": "--total-tiles: one tile list cut into N contiguous shards of equal cost; `steps` / `ms_per_step` are rank 0's; "
+                                               "value = positions of the whole job / the slowest rank's time"} if strong else None)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": replayed_traffic(dom, args.tile_kb, args.depth), "traffic_source": "replayed from profiles/traffic_latest.json (two separate rocprofv3 --pmc passes), not measured in this run",
+                         "traffic": replayed_traffic(dom, args.tile_kb, args.depth), "traffic_source": _TRAFFIC.get("why"),
                          "algorithmic_bytes_per_launch": abytes, "kernel_ms": avg[dom],
                          "valu_issue": valu_issue(dom, avg[dom], args),
-                         "note": "HIP events on the library's stream over the timed steps; with pipelining another tile's preparation kernels may run beside the kernel (see resident.kernel_ms for the undisturbed durations)"},
+                         "note": "HIP events on the library's stream over the timed steps; with pipelining another tile's preparation kernels may run beside the kernel (see resident.kernel_ms for the undisturbed durations)",
+                         "dominant_by": "the largest average HIP-event duration inside the pipelined stream of THIS run.  k_frag16 and k_p2_fast<base> are within a few per cent of each other (1.46 / 1.47 ms "
+                                        "undisturbed) and swap places between runs and between this figure and the committed rocprofv3 summary (profiles/): rocprofv3 sums a shorter profiled command in which "
+                                        "the two tiles in flight overlap differently.  resident.roofline_by_kernel prices both on their undisturbed durations."},
             "kernel_ms": {k: round(v, 4) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])},
             "read_bases_per_s": n_reads_tile * READ_LEN * world * args.steps / dt,
             "host_prep_s": {"generate": round(t_gen, 2), "columns_to_hbm": round(t_h2d, 3)},
@@ -557,6 +710,10 @@ def main():
                     "traffic": replayed_traffic(k, args.tile_kb, args.depth)}
                 for k, ms in resident["kernel_ms"].items() if k in ("k_prep_fast", "k_thres", "k_p2_fast_link", "k_p2_fast_base", "k_frag", "k_p5b") and ms}
             out["resident"] = resident
+            if resident["kernel_ms"].get("k_score_all") and "roofline_score" in out:
+                out["roofline_score"]["undisturbed"] = score_roofline(resident["kernel_ms"]["k_score_all"], npos_tile, scored_main, args.all_out)
+                out["roofline_score"]["note"] = ("kernel_ms = HIP events around the scoring kernels inside the pipelined stream (eleven short launches that queue behind the other tile's kernels: a span, "
+                                                 "not a cost); `undisturbed` = the same events with one tile alone on the device (the resident leg)")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline(args.depth)
         print(json.dumps(out))

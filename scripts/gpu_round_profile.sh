@@ -29,8 +29,9 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
 for k, v in res.items():
     v["traffic_bytes_per_launch"] = (2.0 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0
 res["_workload"] = {"tile_kb": 1000, "depth": 300}   # the default bench.py workload
+sys.path.insert(0, "."); import bench; res["_source_hash"] = bench.kernel_source_hash()   # bench.py quotes these counters only for the kernel sources they were counted on
 json.dump(res, open(out + "/traffic.json", "w"), indent=1, sort_keys=True)
-res.pop("_workload")
+res.pop("_workload"); res.pop("_source_hash")
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"])[:12]: print(k, {a: round(b) for a, b in v.items()})
 PY
 timeout -k 10 900 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 13; }
