@@ -243,7 +243,7 @@ constexpr GatherTab make_gather_tab() {
 }
 __constant__ GatherTab c_gather = make_gather_tab();
 // per active group
-enum { GR_x = 0, GR_zpos, GR_st, GR_refsym, GR_mask, GR_hp, GR_r1t, GR_r1u, GR_r1a, GR_r2t, GR_r2u, GR_r2a, GR_insc, GR_delc, GR_ins1c, GR_del1c, GR_rusize, GR_repnum, GR_rec0, GR_nrec, NGR };
+enum { GR_x = 0, GR_zpos, GR_st, GR_refsym, GR_mask, GR_hp, GR_r1t, GR_r1u, GR_r1a, GR_r2t, GR_r2u, GR_r2a, GR_insc, GR_delc, GR_ins1c, GR_del1c, GR_rusize, GR_repnum, GR_rec0, GR_nrec, GR_refbdp, GR_vAC, GR_gemit, NGR };
 // per record
 enum { RH_gi = 0, RH_symbol, RH_src, RH_idx, RH_bdepth, RH_cdepth, NRH };
 // what k_dpv_pre hands to k_dp4 / k_dpv_post
@@ -596,6 +596,10 @@ __global__ void __launch_bounds__(128) k_enum(RegionDev R, UvcParams P, ScoreCtx
     mask |= 1u << st_index(st, refsymbol);
     if (st == UVC_BASE_SYMBOL) mask |= 1u << (int)R.refsym[x < R.npos - 1 ? x : R.npos - 1];   // what the dense kernels call the reference base of x
     else mask |= 1u;
+    { const int kr = st_index(st, refsymbol); int rb = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) rb = (k == kr ? bd[k] : rb);
+      GR_(refbdp, gi) = rb; }   // fragment depth of the reference symbol (main.cpp:1099)
     GR_(x, gi) = (int)x; GR_(zpos, gi) = zpos; GR_(st, gi) = st; GR_(refsym, gi) = refsymbol; GR_(mask, gi) = (int)mask; GR_(rec0, gi) = (int)rec0; GR_(nrec, gi) = (int)nrec;
     // homopolymer context for minABQ (main.cpp:623-626, 909-928)
     const int prev1 = ((refidx >= 2) ? (int)R.refsym[refidx - 2] : UVC_BASE_NN), prev2 = ((refidx >= 3) ? (int)R.refsym[refidx - 3] : UVC_BASE_NN);
@@ -1229,11 +1233,12 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))
     OUT(UVC_O_CONTQ, (int)dmin(binom_contam, power_contam));
     (void)f_cDP1w; (void)f_cDP1x;
 }
-
 // ------------------------------------------------------------------------------------------------
-// k_call: the calling step behind calc_qual -- main.cpp:990-1168, output_germline (main.hpp:5483-5775) and the arithmetic of
-// append_vcf_record (main.hpp:6027-6272).  One thread per zerobased_pos: both symbol-type groups of it, because vAC and
-// "a GERMLINE line was written here" cross the two.  Works on the records k_score wrote plus a few plane reads.
+// The calling step behind calc_qual -- main.cpp:990-1168, output_germline (main.hpp:5483-5775) and the arithmetic of append_vcf_record
+// (main.hpp:6027-6272) -- on the records k_qual finished and the staged rows (no plane is read here):
+//   k_call_group  one thread per active (zerobased_pos, symbol type) group: vAC, the two best non-reference alleles, the genotype
+//   k_call_rec    one thread per record: NLODQ / TLODQ / SomaticQ / QUAL / FILTER / keep; vAC and "a GERMLINE line was written here" cross the
+//                 two symbol types of a zerobased_pos: the other type's group is the neighbour in the active list
 // ------------------------------------------------------------------------------------------------
 #define FLD(fld, rec) fields[(size_t)(fld) * capacity + (rec)]
 #define SYM_END UVC_NUM_SYMBOLS
@@ -1276,223 +1281,220 @@ DEV void normv_quals2(int out[4], double tAD, double tDP, int tVQ, int tnVQcap, 
     out[0] = binom; out[1] = powlaw; out[2] = nVQ; out[3] = (int)dbetween((double)tVQ + m - (double)nVQ, 0.0, (double)tnVQcap);
 }
 
-__global__ void __launch_bounds__(128) k_call(RegionDev R, UvcParams P, ScoreCtx C) {
-    const long long npos = C.pos_end - C.pos_beg;
+__global__ void __launch_bounds__(128) k_call_group(UvcParams P, ScoreCtx C, Stage S) {
+    const long long ngroups = 2LL * (C.pos_end - C.pos_beg);
+    const long long n_active = PK_FLAGS(C.offsets[ngroups]);
+    const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= n_active || gi >= S.cap) return;
+    const long long nrec_ = GR_(nrec, gi);
+    GR_(vAC, gi) = 0; GR_(gemit, gi) = 0;
+    if (nrec_ == 0) return;
     int32_t *fields = C.fields; const long long capacity = C.capacity;
     const bool tprov = (P.tumor_vcf_is_provided != 0);
-    // one thread per zerobased_pos that has records: the first active group of the position stands for it
-    const long long n_active = PK_FLAGS(C.offsets[2 * npos]);
-    for (long long ai_ = (long long)blockIdx.x * blockDim.x + threadIdx.x; ai_ < n_active; ai_ += (long long)gridDim.x * blockDim.x) {
-        const long long g0 = C.active[ai_];
-        if ((g0 & 1) && ai_ > 0 && C.active[ai_ - 1] == g0 - 1) continue;   // the BASE group of this position is active too and does the work
-        const long long zi = g0 >> 1;
-        const int zpos = C.pos_beg + (int)zi;
-        long long rec0[2], nrec[2];
-        for (int st = 0; st < 2; st++) { const long long g = 2 * zi + st; rec0[st] = PK_COUNT(C.offsets[g]); nrec[st] = PK_COUNT(C.offsets[g + 1]) - rec0[st]; if (rec0[st] + nrec[st] > capacity) nrec[st] = 0; }
-        if (nrec[0] + nrec[1] == 0) continue;
-        int vAC[2] = { 0, 0 };
-        bool germ_any = false;
-        for (int st = 0; st < 2; st++) {
-            if (nrec[st] == 0) continue;
-            const long long r0 = rec0[st], r1 = rec0[st] + nrec[st];
-            const int refsymbol = group_refsymbol(R, zpos, st);
-            const int het3al = ((UVC_BASE_SYMBOL == st) ? P.germ_phred_het3al_snp : P.germ_phred_het3al_indel);
-            // ---- vAC and the two best non-reference alleles (main.cpp:990-1016) ----
-            long long top[2] = { -1, -1 };
-            for (long long r = r0; r < r1; r++) {
-                if (FLD(UVC_O_symbol, r) == refsymbol) continue;
-                if (imax(FLD(UVC_O_cVQ1, r), FLD(UVC_O_cVQ2, r)) >= het3al) vAC[st] += 1;
-            }
-            for (int k = 0; k < 2; k++) {
-                long long best = -1;
-                for (long long r = r0; r < r1; r++) {
-                    if (FLD(UVC_O_symbol, r) == refsymbol || r == top[0]) continue;
-                    if (best < 0) { best = r; continue; }
-                    const int v1 = FLD(UVC_O_cVQ1, r), v2 = FLD(UVC_O_cVQ2, r), b1 = FLD(UVC_O_cVQ1, best), b2 = FLD(UVC_O_cVQ2, best);
-                    const int s = FLD(UVC_O_symbol, r), bs = FLD(UVC_O_symbol, best);
-                    bool gt;   // tuple (max, VQ1, VQ2, symbol, string) greater than the best so far
-                    if (imax(v1, v2) != imax(b1, b2)) gt = imax(v1, v2) > imax(b1, b2);
-                    else if (v1 != b1) gt = v1 > b1;
-                    else if (v2 != b2) gt = v2 > b2;
-                    else if (s != bs) gt = s > bs;
-                    else gt = (gap_row_cmp(C, FLD(UVC_O_gapSa, r), FLD(UVC_O_gapSa, best)) > 0);
-                    if (gt) best = r;
-                }
-                top[k] = best;
-            }
-            // ---- output_germline ----
-            // symbol_format_vec = the records except BASE_NN, padded with init_fmt to five entries, in descending gVQ1 (equal values keep
-            // their order); ref = the best of {refsymbol, NN}, alt1..3 = the next three others
-            int n_entries = 0;
-            for (long long r = r0; r < r1; r++) if (FLD(UVC_O_symbol, r) != UVC_BASE_NN) n_entries++;
-            const int n_pad = imax(0, 5 - n_entries);
-            long long sel[4] = { -1, -1, -1, -1 };   // record, or -2 - k for the k-th padding allele
-            bool have[4] = { false, false, false, false };
-            for (long long r = r0; r < r1; r++) {
-                const int s = FLD(UVC_O_symbol, r);
-                if (s == UVC_BASE_NN || !(s == refsymbol || s == UVC_LINK_NN)) continue;
-                if (!have[0] || FLD(UVC_O_gVQ1, r) > FLD(UVC_O_gVQ1, sel[0])) { sel[0] = r; have[0] = true; }
-            }
-            for (int k = 1; k <= 3; k++) {
-                long long best = -1; int best_q = 0; bool found = false;
-                for (long long r = r0; r < r1; r++) {
-                    const int s = FLD(UVC_O_symbol, r);
-                    if (s == UVC_BASE_NN || s == refsymbol || s == UVC_LINK_NN || r == sel[1] || r == sel[2]) continue;
-                    const int q = FLD(UVC_O_gVQ1, r);
-                    if (!found || q > best_q) { best = r; best_q = q; found = true; }
-                }
-                int pads_used = 0;
-                for (int j = 1; j < k; j++) if (sel[j] <= -2) pads_used++;
-                if (pads_used < n_pad && (!found || 0 > best_q)) { best = -2 - pads_used; found = true; }   // a padding allele (gVQ1 = 0) sorts behind the records with gVQ1 >= 0
-                sel[k] = best; have[k] = found;
-            }
-            auto gq = [&](long long r, int fld, int pad) { return r >= 0 ? FLD(fld, r) : pad; };
-            int a0 = gq(sel[0], UVC_O_gVQ1, 0), a1 = gq(sel[1], UVC_O_gVQ1, 0), a2 = gq(sel[2], UVC_O_gVQ1, 0), a3 = gq(sel[3], UVC_O_gVQ1, 0);
-            const bool isSubst = is_subst(refsymbol);
-            const int symbolNN = ((isSubst || !tprov) ? UVC_BASE_NN : UVC_LINK_NN);
-            const int symb1 = gq(sel[1], UVC_O_symbol, SYM_END), symb2 = gq(sel[2], UVC_O_symbol, SYM_END);
-            double ad0 = gq(sel[0], UVC_O_cDP1v, 50) / 100.0, ad1 = gq(sel[1], UVC_O_cDP1v, 50) / 100.0, ad2 = gq(sel[2], UVC_O_cDP1v, 50) / 100.0;
-            if (symbolNN == symb1) { ad0 += ad1; ad1 = 0; }
-            if (symbolNN == symb2) { ad0 += ad2; ad2 = 0; }
-            const int a0a1 = het_lodq(ad0, ad1, 1.0 - P.germ_hetero_FA, P.powlaw_exponent), a1a0 = het_lodq(ad1, ad0, P.germ_hetero_FA, P.powlaw_exponent);
-            const int a1a2 = het_lodq(ad1, ad2, 0.5, P.powlaw_exponent), a2a1 = het_lodq(ad2, ad1, 0.5, P.powlaw_exponent);
-            const int phred_hetero = (isSubst ? P.germ_phred_hetero_snp : P.germ_phred_hetero_indel), phred_homalt = (isSubst ? P.germ_phred_homalt_snp : P.germ_phred_homalt_indel);
-            const int phred_tri_al = (isSubst ? P.germ_phred_het3al_snp : P.germ_phred_het3al_indel);
-            if (tprov) { a0 = imin(a0, gq(sel[0], UVC_O_CONTQ, 0)); a1 = imin(a1, gq(sel[1], UVC_O_CONTQ, 0)); a2 = imin(a2, gq(sel[2], UVC_O_CONTQ, 0)); a3 = imin(a3, gq(sel[3], UVC_O_CONTQ, 0)); }
-            else a0 = imin(a0, gq(sel[0], UVC_O_CONTQ, 0));
-            const int a2penal = imax(a2 - (phred_tri_al - phred_hetero), 0), a3penal = imax(a3 - phred_hetero, 0);
-            const int a01hetp = imax(imax(a0a1, a1a0), 0), a12hetp = imax(imax(a1a2, a2a1) - 3, 0), a03trip = imax(a0, a3);
-            int tri_al_penal = 0;
-            if (is_ins(symb1) && is_ins(symb2)) { tri_al_penal += 3; if (symb1 == symb2) { tri_al_penal += 3; if (UVC_LINK_I3P == symb1) tri_al_penal += 3; } }
-            { const int n1 = indel_n_units(symb1), n2 = indel_n_units(symb2); if (n1 != 0 && n2 != 0) tri_al_penal -= ibetween(abs(n1 - n2) * 3 - 5, 0, 9); }
-            int GL4[4];
-            GL4[0] = (0 - a1 - a2penal - a3penal);
-            GL4[1] = (-phred_hetero - imax(a01hetp, a2) - imax(imin(a01hetp, a2) - phred_hetero, 0) - a3penal);
-            GL4[2] = (-phred_homalt - imax(a0, a2) - imax(imin(a0, a2) - phred_hetero, 0) - a3penal);
-            GL4[3] = (-phred_tri_al - imax(a12hetp, a03trip) - imax(imin(a12hetp, a03trip) - phred_hetero, 0) - imax(imin(a12hetp, imin(a0, a3)) - phred_hetero, 0) - tri_al_penal);
-            const int ret = GL4[0] - imax(GL4[1], imax(GL4[2], GL4[3]));
-            int i_best = 0, i_second = -1;   // descending (value, index): PairSecondLess over reverse iterators, main.hpp:5464-5469
-            for (int i = 1; i < 4; i++) if (GL4[i] >= GL4[i_best]) i_best = i;
-            for (int i = 0; i < 4; i++) if (i != i_best && (i_second < 0 || GL4[i] >= GL4[i_second])) i_second = i;
-            const int germ_GQ = GL4[i_best] - GL4[i_second];
-            int emit = ((0x1 & P.outvar_flag) ? 1 : 0);
-            if (emit && 0 == i_best && (!P.should_output_all_germline) && imax(gq(sel[1], UVC_O_cDP0a, 0), gq(sel[2], UVC_O_cDP0a, 0)) <= 2) emit = 0;
-            germ_any = germ_any || (emit != 0);
-            for (long long rec = r0; rec < r1; rec++) {
-                for (int k = 0; k < 2; k++) {
-                    OUT(UVC_O_cVQ1M0 + k, top[k] >= 0 ? FLD(UVC_O_cVQ1, top[k]) : -999); OUT(UVC_O_cVQ2M0 + k, top[k] >= 0 ? FLD(UVC_O_cVQ2, top[k]) : -999);
-                    OUT(UVC_O_cVQAM0 + k, top[k] >= 0 ? FLD(UVC_O_symbol, top[k]) : SYM_END); OUT(UVC_O_cVQSM0 + k, top[k] >= 0 ? FLD(UVC_O_gapSa, top[k]) : -1);
-                }
-                OUT(UVC_O_vNLODQ, ret);
-                for (int i = 0; i < 4; i++) OUT(UVC_O_GL4_0 + i, GL4[i]);
-                OUT(UVC_O_GST0, a0); OUT(UVC_O_GST1, a1); OUT(UVC_O_GST2, a2); OUT(UVC_O_GST3, a3); OUT(UVC_O_GST4, a0a1); OUT(UVC_O_GST5, a1a0); OUT(UVC_O_GST6, a1a2); OUT(UVC_O_GST7, a2a1);
-                OUT(UVC_O_germ_GT, i_best); OUT(UVC_O_germ_GQ, germ_GQ); OUT(UVC_O_germ_emit, emit);
-                OUT(UVC_O_germ_ref, (int)(sel[0] >= 0 ? sel[0] : -1)); OUT(UVC_O_germ_alt1, (int)(sel[1] >= 0 ? sel[1] : -1)); OUT(UVC_O_germ_alt2, (int)(sel[2] >= 0 ? sel[2] : -1));
-            }
-        }
-        // ---- per record: main.cpp:1081-1147 + append_vcf_record ----
-        for (int st = 0; st < 2; st++) {
-            if (nrec[st] == 0) continue;
-            const long long r0 = rec0[st], r1 = rec0[st] + nrec[st];
-            const int refsymbol = group_refsymbol(R, zpos, st);
-            const int refpos = (st == UVC_BASE_SYMBOL ? zpos - 1 : zpos);
-            const int64_t x = refpos - R.beg;
-            const int ref_bDP = FRP(R, 0, UVC_FRAG_bDP, refsymbol, x) + FRP(R, 1, UVC_FRAG_bDP, refsymbol, x);
-            long long ABQ2_0 = 0;
-            for (int k = 0; k < st_count(st); k++) ABQ2_0 += S32(R, UVC_S_aBQ2, st_symbol(st, k), x);
-            ABQ2_0 = (int)ABQ2_0;   // the int32 FORMAT field truncates the sum
-            const bool should_output_ref_allele = (C.all_out || germ_any);
-            for (long long rec = r0; rec < r1; rec++) {
-                const int symbol = FLD(UVC_O_symbol, rec);
-                OUT(UVC_O_vAC0, vAC[0]); OUT(UVC_O_vAC1, vAC[1]);
-                const int tki = FLD(UVC_O_tkey, rec);
-                const bool will_generate_out = (!tprov ? ((P.outvar_flag & 0x4) != 0) : (tki >= 0 && (P.outvar_flag & 0x2)));
-                const bool is_out_blocked = (((UVC_BASE_NN == symbol) && !(0x20 & P.outvar_flag)) || ((UVC_LINK_NN == symbol) && !(0x40 & P.outvar_flag)));
-                int o_out = 0, o_vHGQ = 0, o_NLODQ = 0, o_NLODV = SYM_END, o_TLODQ = 0, o_SQ = 0, o_QUAL = 0, o_FILTER = 0, o_keep = 0, bq4[4] = { 0, 0, 0, 0 }, cq4[4] = { 0, 0, 0, 0 };
-                if (will_generate_out && !is_out_blocked) {
-                    o_out = 1;
-                    const int germ_phred = (is_subst(symbol) ? P.germ_phred_hetero_snp : P.germ_phred_hetero_indel);
-                    const int nlodq_singlesite = FLD(UVC_O_vNLODQ, rec);
-                    const int nlodq_singlesample = nlodq_singlesite - 3 + germ_phred;
-                    int nlodq1;
-                    const int totBDP = FLD(UVC_O_bDP, rec);
-                    const int own_bDP = FRP(R, 0, UVC_FRAG_bDP, symbol, x) + FRP(R, 1, UVC_FRAG_bDP, symbol, x);
-                    int t_BDP, t_bDP, t_CDP1x, t_cDP1x, t_cVQ1, t_cPCQ1, t_CDP2x, t_cDP2x, t_cVQ2, t_cPCQ2, t_bNMQ, t_tDP = 0;
-                    if (tprov) {
-                        const UvcTumorKey &tk = C.tkeys[tki];
-                        int nlodq_inc = 999;
-                        const int ptr[2] = { FLD(UVC_O_germ_alt1, rec), FLD(UVC_O_germ_alt2, rec) };
-                        for (int k = 0; k < 2; k++) {
-                            const int normsymbol = (ptr[k] >= 0 ? FLD(UVC_O_symbol, ptr[k]) : SYM_END);
-                            const int bgerr_norm_max_ad = (ptr[k] >= 0 ? FLD(UVC_O_cDP1x, ptr[k]) : 50);
-                            const double tAD = (tk.cDP1x + 1 * 50) / 100.0, tDP = (tk.CDP1x + 2 * 50) / 100.0;
-                            const double nAD = (bgerr_norm_max_ad + 1 * 50) / 100.0, nDP = ((ptr[k] >= 0 ? FLD(UVC_O_CDP1x0, ptr[k]) : 0) + 2 * 50) / 100.0;
-                            const double bjpfrac = ((tAD) / (tDP)) / ((nAD) / (nDP));
-                            const int binom = (int)binom_llr((tDP - tAD) / (tDP), nDP - nAD, nAD);
-                            const int powlaw = (int)(P.powlaw_exponent * 10 / log(10.0) * log(bjpfrac));
-                            const int inc_snp = 2 * P.germ_phred_hetero_snp - P.germ_phred_het3al_snp, inc_indel = 2 * P.germ_phred_hetero_indel - P.germ_phred_het3al_indel;
-                            const int triallele_inc = ((normsymbol != symbol) ? (is_subst(symbol) ? inc_snp : inc_indel) : 0);
-                            const int new_inc = (int)dbetween((double)imin(binom, powlaw), -3.0, P.powlaw_anyvar_base) + triallele_inc;
-                            if (nlodq_inc > new_inc) { nlodq_inc = new_inc; o_NLODV = normsymbol; }
-                        }
-                        const int n_norm_alts = (totBDP - ref_bDP) + own_bDP;
-                        nlodq1 = imax(imax(nlodq_singlesite, germ_phred + nlodq_inc), tk.vHGQ + imin(3, totBDP - n_norm_alts * (int)round(0.5 / P.contam_any_mul_frac)));
-                        t_BDP = tk.BDP; t_bDP = tk.bDP; t_CDP1x = tk.CDP1x; t_cDP1x = tk.cDP1x; t_cVQ1 = tk.cVQ1; t_cPCQ1 = tk.cPCQ1;
-                        t_CDP2x = tk.CDP2x; t_cDP2x = tk.cDP2x; t_cVQ2 = tk.cVQ2; t_cPCQ2 = tk.cPCQ2; t_bNMQ = tk.bNMQ; t_tDP = tk.tDP;
-                    } else {
-                        nlodq1 = nlodq_singlesample;
-                        t_BDP = totBDP; t_bDP = own_bDP; t_CDP1x = FLD(UVC_O_CDP1x0, rec); t_cDP1x = FLD(UVC_O_cDP1x, rec); t_cVQ1 = FLD(UVC_O_cVQ1, rec); t_cPCQ1 = FLD(UVC_O_cPCQ1, rec);
-                        t_CDP2x = FLD(UVC_O_CDP2x0, rec); t_cDP2x = FLD(UVC_O_cDP2x, rec); t_cVQ2 = FLD(UVC_O_cVQ2, rec); t_cPCQ2 = FLD(UVC_O_cPCQ2, rec); t_bNMQ = FLD(UVC_O_bNMQ, rec);
-                    }
-                    o_vHGQ = nlodq_singlesample;
-                    const bool normal = tprov;
-                    const int nfm_cDP1x = (normal ? FLD(UVC_O_cDP1x, rec) : 0), nfm_CDP1x = (normal ? FLD(UVC_O_CDP1x0, rec) : 0), nfm_cDP2x = (normal ? FLD(UVC_O_cDP2x, rec) : 0), nfm_CDP2x = (normal ? FLD(UVC_O_CDP2x0, rec) : 0);
-                    const int nfm_cVQ1 = (normal ? FLD(UVC_O_cVQ1, rec) : 0), nfm_cVQ2 = (normal ? FLD(UVC_O_cVQ2, rec) : 0), nfm_BDP = (normal ? totBDP : 0), nfm_CDP1 = (normal ? FLD(UVC_O_DP, rec) : 0);
-                    const int inc_snp = imax(0, 2 * P.germ_phred_hetero_snp - P.germ_phred_het3al_snp), inc_indel = imax(0, 2 * P.germ_phred_hetero_indel - P.germ_phred_het3al_indel);
-                    int het3al_inc = (is_subst(symbol) ? inc_snp : inc_indel);
-                    if (is_ins(symbol) || is_del(symbol)) het3al_inc = (int)nnminus(inc_indel + 1, FLD(UVC_O_gapSa_len, rec));
-                    const int qmin = P.microadjust_syserr_MQ_NMR_tn_syserr_no_penal_qual_min, qmax = P.microadjust_syserr_MQ_NMR_tn_syserr_no_penal_qual_max;
-                    const int tn_dec_by_xm = ibetween(imin(FLD(UVC_O_bNMQ, rec), t_bNMQ), qmin, qmax) - qmin;
-                    double add1 = 0, add2 = 0;
-                    int tn_dec_both = 0;
-                    if (normal) {
-                        const long long LI = P64(R, UVC_P_a_LI, x) + P64(R, UVC_P_a_RI, x), LIDP = (long long)P32(R, UVC_P_a_LIDP, x) + P32(R, UVC_P_a_RIDP, x);
-                        if (LI < LIDP * (long long)P.lib_wgs_min_avg_fraglen) { add1 = P.lib_nonwgs_normal_add_mul_ad * nfm_cDP1x / 100.0; add2 = P.lib_nonwgs_normal_add_mul_ad * nfm_cDP2x / 100.0; }
-                        if (t_tDP > 500 && FLD(UVC_O_DP, rec) > 500 && is_del(symbol) && (long long)P32(R, UVC_P_a_near_del_dp, x) * 3 > (long long)P32(R, UVC_P_a_dp, x)) tn_dec_both = imin((int)nnminus(nfm_cVQ1, 31), 9);
-                    }
-                    const int prior_phred = ((UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform) ? 11 : 3);
-                    if (P.tn_syserr_norm_devqual >= 0) normv_quals(bq4, (t_cDP1x + 0.5) / 100.0 + 0.0, (t_CDP1x + 1.0) / 100.0 + 0.0, t_cVQ1, t_cPCQ1, (nfm_cDP1x + 0.5) / 100.0 + 0.0 + add1, (nfm_CDP1x + 1.0) / 100.0 + 0.0 + add1,
-                                                               (int)nnminus(nfm_cVQ1, het3al_inc), P.tn_syserr_norm_devqual, prior_phred, tn_dec_by_xm, P.powlaw_exponent);
-                    else normv_quals2(bq4, (t_cDP1x + 0.5) / 100.0 + 0.0, (t_CDP1x + 1.0) / 100.0 + 0.0, t_cVQ1, t_cPCQ1, (nfm_cDP1x + 0.5) / 100.0 + 0.0 + add1, (nfm_CDP1x + 1.0) / 100.0 + 0.0 + add1, (int)nnminus(nfm_cVQ1, het3al_inc));
-                    const int converted_nfm_cVQ2 = nfm_cVQ1 - (3 * (nfm_BDP + 1) / (nfm_CDP1 + 1));
-                    const int norm_norm_vq = (int)nnminus(nfm_cVQ2, imax(het3al_inc, 3) - 3);
-                    if (P.tn_syserr_norm_devqual >= 0) normv_quals(cq4, (t_cDP2x + 0.5) / 100.0 + 0.0, (t_CDP2x + 1.0) / 100.0 + 0.0, t_cVQ2, t_cPCQ2, (nfm_cDP2x + 0.5) / 100.0 + 0.0 + add2, (nfm_CDP2x + 1.0) / 100.0 + 0.0 + add2,
-                                                               norm_norm_vq, P.tn_syserr_norm_devqual, prior_phred, imax(tn_dec_by_xm, imin(imax(nfm_cVQ2, converted_nfm_cVQ2), 12)), P.powlaw_exponent);
-                    else normv_quals2(cq4, (t_cDP2x + 0.5) / 100.0 + 0.0, (t_CDP2x + 1.0) / 100.0 + 0.0, t_cVQ2, t_cPCQ2, (nfm_cDP2x + 0.0) / 100.0 + 0.5 + add2, (nfm_CDP2x + 0.0) / 100.0 + 1.0 + add2, norm_norm_vq);
-                    const int tlodq1 = imax(bq4[3], cq4[3]);
-                    const bool deanim = ((UVC_BASE_C == refsymbol && UVC_BASE_T == symbol) || (UVC_BASE_G == refsymbol && UVC_BASE_A == symbol));
-                    const double b_min_tlodq = 2 + 3 - (-10 * log((t_bDP + 1e-3) / (t_BDP + 1)) / log(10.0)) / 10.0;
-                    const double c2v_min_tlodq = 2 + 5 - (-10 * log((t_cDP2x * 0.01 + 1e-5) / (t_CDP2x * 0.01 + 1) / (deanim ? 5 : 1)) / log(10.0)) / 10.0;
-                    const float lowestVAQ = (float)dmax(b_min_tlodq, c2v_min_tlodq);
-                    const int tlodq = ((tlodq1 >= 10) ? tlodq1 : (tlodq1 * 3 - 20)) - tn_dec_both;
-                    const int nlodq = nlodq1 - tn_dec_both;
-                    const int somaticq = imin(tlodq, nlodq);
-                    float v = (normal ? ((float)somaticq) : fmaxf((float)tlodq, lowestVAQ));
-                    { const float base = (float)pow(10.0, 0.1); if (v < 10.0f) v = log1pf(powf(base, v)) / logf(base); }   // calc_non_negative<float>
-                    o_TLODQ = tlodq; o_NLODQ = nlodq; o_SQ = somaticq; o_QUAL = __float_as_int(v);
-                    o_FILTER = (v < 10 ? 0 : v < 20 ? 1 : v < 30 ? 2 : v < 40 ? 3 : v < 50 ? 4 : v < 60 ? 5 : 6);
-                    const int vad1 = S32(R, UVC_S_aBQ2, symbol, x); const long long vdp1 = ABQ2_0;
-                    const bool keep_var = ((((double)v >= P.vqual) || ((!tprov) && ((vad1 >= P.vad1 && vdp1 >= P.vdp1 && (vdp1 * P.vfa1) <= vad1) || (t_bDP >= P.vad2 && t_BDP >= P.vdp2 && (t_BDP * P.vfa2) <= t_bDP))))
-                                           && (symbol != refsymbol || should_output_ref_allele));
-                    o_keep = (keep_var && t_bDP >= ((symbol == refsymbol) ? P.min_r_ad : P.min_a_ad)) ? 1 : 0;
-                }
-                OUT(UVC_O_out, o_out); OUT(UVC_O_vHGQ, o_vHGQ); OUT(UVC_O_NLODQ, o_NLODQ); OUT(UVC_O_NLODV, o_NLODV); OUT(UVC_O_TLODQ, o_TLODQ); OUT(UVC_O_SomaticQ, o_SQ);
-                for (int i = 0; i < 4; i++) { OUT(UVC_O_TNBQF0 + i, bq4[i]); OUT(UVC_O_TNCQF0 + i, cq4[i]); }
-                OUT(UVC_O_QUAL, o_QUAL); OUT(UVC_O_FILTER, o_FILTER); OUT(UVC_O_keep, o_keep);
-            }
-        }
+    const int st = GR_(st, gi), refsymbol = GR_(refsym, gi);
+    const long long r0 = GR_(rec0, gi), r1 = r0 + nrec_;
+    int vAC = 0;
+    const int het3al = ((UVC_BASE_SYMBOL == st) ? P.germ_phred_het3al_snp : P.germ_phred_het3al_indel);
+    // ---- vAC and the two best non-reference alleles (main.cpp:990-1016) ----
+    long long top[2] = { -1, -1 };
+    for (long long r = r0; r < r1; r++) {
+        if (FLD(UVC_O_symbol, r) == refsymbol) continue;
+        if (imax(FLD(UVC_O_cVQ1, r), FLD(UVC_O_cVQ2, r)) >= het3al) vAC += 1;
     }
+    for (int k = 0; k < 2; k++) {
+        long long best = -1;
+        for (long long r = r0; r < r1; r++) {
+            if (FLD(UVC_O_symbol, r) == refsymbol || r == top[0]) continue;
+            if (best < 0) { best = r; continue; }
+            const int v1 = FLD(UVC_O_cVQ1, r), v2 = FLD(UVC_O_cVQ2, r), b1 = FLD(UVC_O_cVQ1, best), b2 = FLD(UVC_O_cVQ2, best);
+            const int s = FLD(UVC_O_symbol, r), bs = FLD(UVC_O_symbol, best);
+            bool gt;   // tuple (max, VQ1, VQ2, symbol, string) greater than the best so far
+            if (imax(v1, v2) != imax(b1, b2)) gt = imax(v1, v2) > imax(b1, b2);
+            else if (v1 != b1) gt = v1 > b1;
+            else if (v2 != b2) gt = v2 > b2;
+            else if (s != bs) gt = s > bs;
+            else gt = (gap_row_cmp(C, FLD(UVC_O_gapSa, r), FLD(UVC_O_gapSa, best)) > 0);
+            if (gt) best = r;
+        }
+        top[k] = best;
+    }
+    // ---- output_germline ----
+    // symbol_format_vec = the records except BASE_NN, padded with init_fmt to five entries, in descending gVQ1 (equal values keep
+    // their order); ref = the best of {refsymbol, NN}, alt1..3 = the next three others
+    int n_entries = 0;
+    for (long long r = r0; r < r1; r++) if (FLD(UVC_O_symbol, r) != UVC_BASE_NN) n_entries++;
+    const int n_pad = imax(0, 5 - n_entries);
+    long long sel[4] = { -1, -1, -1, -1 };   // record, or -2 - k for the k-th padding allele
+    bool have[4] = { false, false, false, false };
+    for (long long r = r0; r < r1; r++) {
+        const int s = FLD(UVC_O_symbol, r);
+        if (s == UVC_BASE_NN || !(s == refsymbol || s == UVC_LINK_NN)) continue;
+        if (!have[0] || FLD(UVC_O_gVQ1, r) > FLD(UVC_O_gVQ1, sel[0])) { sel[0] = r; have[0] = true; }
+    }
+    for (int k = 1; k <= 3; k++) {
+        long long best = -1; int best_q = 0; bool found = false;
+        for (long long r = r0; r < r1; r++) {
+            const int s = FLD(UVC_O_symbol, r);
+            if (s == UVC_BASE_NN || s == refsymbol || s == UVC_LINK_NN || r == sel[1] || r == sel[2]) continue;
+            const int q = FLD(UVC_O_gVQ1, r);
+            if (!found || q > best_q) { best = r; best_q = q; found = true; }
+        }
+        int pads_used = 0;
+        for (int j = 1; j < k; j++) if (sel[j] <= -2) pads_used++;
+        if (pads_used < n_pad && (!found || 0 > best_q)) { best = -2 - pads_used; found = true; }   // a padding allele (gVQ1 = 0) sorts behind the records with gVQ1 >= 0
+        sel[k] = best; have[k] = found;
+    }
+    auto gq = [&](long long r, int fld, int pad) { return r >= 0 ? FLD(fld, r) : pad; };
+    int a0 = gq(sel[0], UVC_O_gVQ1, 0), a1 = gq(sel[1], UVC_O_gVQ1, 0), a2 = gq(sel[2], UVC_O_gVQ1, 0), a3 = gq(sel[3], UVC_O_gVQ1, 0);
+    const bool isSubst = is_subst(refsymbol);
+    const int symbolNN = ((isSubst || !tprov) ? UVC_BASE_NN : UVC_LINK_NN);
+    const int symb1 = gq(sel[1], UVC_O_symbol, SYM_END), symb2 = gq(sel[2], UVC_O_symbol, SYM_END);
+    double ad0 = gq(sel[0], UVC_O_cDP1v, 50) / 100.0, ad1 = gq(sel[1], UVC_O_cDP1v, 50) / 100.0, ad2 = gq(sel[2], UVC_O_cDP1v, 50) / 100.0;
+    if (symbolNN == symb1) { ad0 += ad1; ad1 = 0; }
+    if (symbolNN == symb2) { ad0 += ad2; ad2 = 0; }
+    const int a0a1 = het_lodq(ad0, ad1, 1.0 - P.germ_hetero_FA, P.powlaw_exponent), a1a0 = het_lodq(ad1, ad0, P.germ_hetero_FA, P.powlaw_exponent);
+    const int a1a2 = het_lodq(ad1, ad2, 0.5, P.powlaw_exponent), a2a1 = het_lodq(ad2, ad1, 0.5, P.powlaw_exponent);
+    const int phred_hetero = (isSubst ? P.germ_phred_hetero_snp : P.germ_phred_hetero_indel), phred_homalt = (isSubst ? P.germ_phred_homalt_snp : P.germ_phred_homalt_indel);
+    const int phred_tri_al = (isSubst ? P.germ_phred_het3al_snp : P.germ_phred_het3al_indel);
+    if (tprov) { a0 = imin(a0, gq(sel[0], UVC_O_CONTQ, 0)); a1 = imin(a1, gq(sel[1], UVC_O_CONTQ, 0)); a2 = imin(a2, gq(sel[2], UVC_O_CONTQ, 0)); a3 = imin(a3, gq(sel[3], UVC_O_CONTQ, 0)); }
+    else a0 = imin(a0, gq(sel[0], UVC_O_CONTQ, 0));
+    const int a2penal = imax(a2 - (phred_tri_al - phred_hetero), 0), a3penal = imax(a3 - phred_hetero, 0);
+    const int a01hetp = imax(imax(a0a1, a1a0), 0), a12hetp = imax(imax(a1a2, a2a1) - 3, 0), a03trip = imax(a0, a3);
+    int tri_al_penal = 0;
+    if (is_ins(symb1) && is_ins(symb2)) { tri_al_penal += 3; if (symb1 == symb2) { tri_al_penal += 3; if (UVC_LINK_I3P == symb1) tri_al_penal += 3; } }
+    { const int n1 = indel_n_units(symb1), n2 = indel_n_units(symb2); if (n1 != 0 && n2 != 0) tri_al_penal -= ibetween(abs(n1 - n2) * 3 - 5, 0, 9); }
+    int GL4[4];
+    GL4[0] = (0 - a1 - a2penal - a3penal);
+    GL4[1] = (-phred_hetero - imax(a01hetp, a2) - imax(imin(a01hetp, a2) - phred_hetero, 0) - a3penal);
+    GL4[2] = (-phred_homalt - imax(a0, a2) - imax(imin(a0, a2) - phred_hetero, 0) - a3penal);
+    GL4[3] = (-phred_tri_al - imax(a12hetp, a03trip) - imax(imin(a12hetp, a03trip) - phred_hetero, 0) - imax(imin(a12hetp, imin(a0, a3)) - phred_hetero, 0) - tri_al_penal);
+    const int ret = GL4[0] - imax(GL4[1], imax(GL4[2], GL4[3]));
+    int i_best = 0, i_second = -1;   // descending (value, index): PairSecondLess over reverse iterators, main.hpp:5464-5469
+    for (int i = 1; i < 4; i++) if (GL4[i] >= GL4[i_best]) i_best = i;
+    for (int i = 0; i < 4; i++) if (i != i_best && (i_second < 0 || GL4[i] >= GL4[i_second])) i_second = i;
+    const int germ_GQ = GL4[i_best] - GL4[i_second];
+    int emit = ((0x1 & P.outvar_flag) ? 1 : 0);
+    if (emit && 0 == i_best && (!P.should_output_all_germline) && imax(gq(sel[1], UVC_O_cDP0a, 0), gq(sel[2], UVC_O_cDP0a, 0)) <= 2) emit = 0;
+    
+    for (long long rec = r0; rec < r1; rec++) {
+        for (int k = 0; k < 2; k++) {
+            OUT(UVC_O_cVQ1M0 + k, top[k] >= 0 ? FLD(UVC_O_cVQ1, top[k]) : -999); OUT(UVC_O_cVQ2M0 + k, top[k] >= 0 ? FLD(UVC_O_cVQ2, top[k]) : -999);
+            OUT(UVC_O_cVQAM0 + k, top[k] >= 0 ? FLD(UVC_O_symbol, top[k]) : SYM_END); OUT(UVC_O_cVQSM0 + k, top[k] >= 0 ? FLD(UVC_O_gapSa, top[k]) : -1);
+        }
+        OUT(UVC_O_vNLODQ, ret);
+        for (int i = 0; i < 4; i++) OUT(UVC_O_GL4_0 + i, GL4[i]);
+        OUT(UVC_O_GST0, a0); OUT(UVC_O_GST1, a1); OUT(UVC_O_GST2, a2); OUT(UVC_O_GST3, a3); OUT(UVC_O_GST4, a0a1); OUT(UVC_O_GST5, a1a0); OUT(UVC_O_GST6, a1a2); OUT(UVC_O_GST7, a2a1);
+        OUT(UVC_O_germ_GT, i_best); OUT(UVC_O_germ_GQ, germ_GQ); OUT(UVC_O_germ_emit, emit);
+        OUT(UVC_O_germ_ref, (int)(sel[0] >= 0 ? sel[0] : -1)); OUT(UVC_O_germ_alt1, (int)(sel[1] >= 0 ? sel[1] : -1)); OUT(UVC_O_germ_alt2, (int)(sel[2] >= 0 ? sel[2] : -1));
+    }
+    GR_(vAC, gi) = vAC; GR_(gemit, gi) = emit;
 }
+
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) k_call_rec(UvcParams P, ScoreCtx C, Stage S) {
+    REC_PROLOGUE
+    const bool tprov = (P.tumor_vcf_is_provided != 0);
+    const int st = GR_(st, gi);
+    // the other symbol type's group of this zerobased_pos, if it is active: BASE (even group index) sits right in front of LINK in the list
+    const long long g = C.active[gi];
+    long long gj = -1;
+    {
+        const long long ngroups = 2LL * (C.pos_end - C.pos_beg);
+        const long long n_active = PK_FLAGS(C.offsets[ngroups]);
+        if (st == UVC_BASE_SYMBOL) { if (gi + 1 < n_active && gi + 1 < S.cap && C.active[gi + 1] == g + 1) gj = gi + 1; }
+        else if (gi > 0 && C.active[gi - 1] == g - 1) gj = gi - 1;
+    }
+    const int vA_own = GR_(vAC, gi), vA_oth = (gj >= 0 ? GR_(vAC, gj) : 0);
+    const int vAC0 = (st == UVC_BASE_SYMBOL ? vA_own : vA_oth), vAC1 = (st == UVC_BASE_SYMBOL ? vA_oth : vA_own);
+    const bool germ_any = (GR_(gemit, gi) != 0) || (gj >= 0 && GR_(gemit, gj) != 0);
+    const int ref_bDP = GR_(refbdp, gi);
+    const bool should_output_ref_allele = (C.all_out || germ_any);
+    OUT(UVC_O_vAC0, vAC0); OUT(UVC_O_vAC1, vAC1);
+    const int tki = FLD(UVC_O_tkey, rec);
+    const bool will_generate_out = (!tprov ? ((P.outvar_flag & 0x4) != 0) : (tki >= 0 && (P.outvar_flag & 0x2)));
+    const bool is_out_blocked = (((UVC_BASE_NN == symbol) && !(0x20 & P.outvar_flag)) || ((UVC_LINK_NN == symbol) && !(0x40 & P.outvar_flag)));
+    int o_out = 0, o_vHGQ = 0, o_NLODQ = 0, o_NLODV = SYM_END, o_TLODQ = 0, o_SQ = 0, o_QUAL = 0, o_FILTER = 0, o_keep = 0, bq4[4] = { 0, 0, 0, 0 }, cq4[4] = { 0, 0, 0, 0 };
+    if (will_generate_out && !is_out_blocked) {
+        o_out = 1;
+        const int germ_phred = (is_subst(symbol) ? P.germ_phred_hetero_snp : P.germ_phred_hetero_indel);
+        const int nlodq_singlesite = FLD(UVC_O_vNLODQ, rec);
+        const int nlodq_singlesample = nlodq_singlesite - 3 + germ_phred;
+        int nlodq1;
+        const int totBDP = FLD(UVC_O_bDP, rec);
+        const int own_bDP = RH_(bdepth, rec);
+        int t_BDP, t_bDP, t_CDP1x, t_cDP1x, t_cVQ1, t_cPCQ1, t_CDP2x, t_cDP2x, t_cVQ2, t_cPCQ2, t_bNMQ, t_tDP = 0;
+        if (tprov) {
+            const UvcTumorKey &tk = C.tkeys[tki];
+            int nlodq_inc = 999;
+            const int ptr[2] = { FLD(UVC_O_germ_alt1, rec), FLD(UVC_O_germ_alt2, rec) };
+            for (int k = 0; k < 2; k++) {
+                const int normsymbol = (ptr[k] >= 0 ? FLD(UVC_O_symbol, ptr[k]) : SYM_END);
+                const int bgerr_norm_max_ad = (ptr[k] >= 0 ? FLD(UVC_O_cDP1x, ptr[k]) : 50);
+                const double tAD = (tk.cDP1x + 1 * 50) / 100.0, tDP = (tk.CDP1x + 2 * 50) / 100.0;
+                const double nAD = (bgerr_norm_max_ad + 1 * 50) / 100.0, nDP = ((ptr[k] >= 0 ? FLD(UVC_O_CDP1x0, ptr[k]) : 0) + 2 * 50) / 100.0;
+                const double bjpfrac = ((tAD) / (tDP)) / ((nAD) / (nDP));
+                const int binom = (int)binom_llr((tDP - tAD) / (tDP), nDP - nAD, nAD);
+                const int powlaw = (int)(P.powlaw_exponent * 10 / log(10.0) * log(bjpfrac));
+                const int inc_snp = 2 * P.germ_phred_hetero_snp - P.germ_phred_het3al_snp, inc_indel = 2 * P.germ_phred_hetero_indel - P.germ_phred_het3al_indel;
+                const int triallele_inc = ((normsymbol != symbol) ? (is_subst(symbol) ? inc_snp : inc_indel) : 0);
+                const int new_inc = (int)dbetween((double)imin(binom, powlaw), -3.0, P.powlaw_anyvar_base) + triallele_inc;
+                if (nlodq_inc > new_inc) { nlodq_inc = new_inc; o_NLODV = normsymbol; }
+            }
+            const int n_norm_alts = (totBDP - ref_bDP) + own_bDP;
+            nlodq1 = imax(imax(nlodq_singlesite, germ_phred + nlodq_inc), tk.vHGQ + imin(3, totBDP - n_norm_alts * (int)round(0.5 / P.contam_any_mul_frac)));
+            t_BDP = tk.BDP; t_bDP = tk.bDP; t_CDP1x = tk.CDP1x; t_cDP1x = tk.cDP1x; t_cVQ1 = tk.cVQ1; t_cPCQ1 = tk.cPCQ1;
+            t_CDP2x = tk.CDP2x; t_cDP2x = tk.cDP2x; t_cVQ2 = tk.cVQ2; t_cPCQ2 = tk.cPCQ2; t_bNMQ = tk.bNMQ; t_tDP = tk.tDP;
+        } else {
+            nlodq1 = nlodq_singlesample;
+            t_BDP = totBDP; t_bDP = own_bDP; t_CDP1x = FLD(UVC_O_CDP1x0, rec); t_cDP1x = FLD(UVC_O_cDP1x, rec); t_cVQ1 = FLD(UVC_O_cVQ1, rec); t_cPCQ1 = FLD(UVC_O_cPCQ1, rec);
+            t_CDP2x = FLD(UVC_O_CDP2x0, rec); t_cDP2x = FLD(UVC_O_cDP2x, rec); t_cVQ2 = FLD(UVC_O_cVQ2, rec); t_cPCQ2 = FLD(UVC_O_cPCQ2, rec); t_bNMQ = FLD(UVC_O_bNMQ, rec);
+        }
+        o_vHGQ = nlodq_singlesample;
+        const bool normal = tprov;
+        const int nfm_cDP1x = (normal ? FLD(UVC_O_cDP1x, rec) : 0), nfm_CDP1x = (normal ? FLD(UVC_O_CDP1x0, rec) : 0), nfm_cDP2x = (normal ? FLD(UVC_O_cDP2x, rec) : 0), nfm_CDP2x = (normal ? FLD(UVC_O_CDP2x0, rec) : 0);
+        const int nfm_cVQ1 = (normal ? FLD(UVC_O_cVQ1, rec) : 0), nfm_cVQ2 = (normal ? FLD(UVC_O_cVQ2, rec) : 0), nfm_BDP = (normal ? totBDP : 0), nfm_CDP1 = (normal ? FLD(UVC_O_DP, rec) : 0);
+        const int inc_snp = imax(0, 2 * P.germ_phred_hetero_snp - P.germ_phred_het3al_snp), inc_indel = imax(0, 2 * P.germ_phred_hetero_indel - P.germ_phred_het3al_indel);
+        int het3al_inc = (is_subst(symbol) ? inc_snp : inc_indel);
+        if (is_ins(symbol) || is_del(symbol)) het3al_inc = (int)nnminus(inc_indel + 1, FLD(UVC_O_gapSa_len, rec));
+        const int qmin = P.microadjust_syserr_MQ_NMR_tn_syserr_no_penal_qual_min, qmax = P.microadjust_syserr_MQ_NMR_tn_syserr_no_penal_qual_max;
+        const int tn_dec_by_xm = ibetween(imin(FLD(UVC_O_bNMQ, rec), t_bNMQ), qmin, qmax) - qmin;
+        double add1 = 0, add2 = 0;
+        int tn_dec_both = 0;
+        if (normal) {
+            const long long LI = T_APLRI0 + T_APLRI2, LIDP = T_APLRI1 + T_APLRI3;
+            if (LI < LIDP * (long long)P.lib_wgs_min_avg_fraglen) { add1 = P.lib_nonwgs_normal_add_mul_ad * nfm_cDP1x / 100.0; add2 = P.lib_nonwgs_normal_add_mul_ad * nfm_cDP2x / 100.0; }
+            if (t_tDP > 500 && FLD(UVC_O_DP, rec) > 500 && is_del(symbol) && T_APDP2 * 3 > T_APDP0) tn_dec_both = imin((int)nnminus(nfm_cVQ1, 31), 9);
+        }
+        const int prior_phred = ((UVC_PLATFORM_IONTORRENT == P.inferred_sequencing_platform) ? 11 : 3);
+        if (P.tn_syserr_norm_devqual >= 0) normv_quals(bq4, (t_cDP1x + 0.5) / 100.0 + 0.0, (t_CDP1x + 1.0) / 100.0 + 0.0, t_cVQ1, t_cPCQ1, (nfm_cDP1x + 0.5) / 100.0 + 0.0 + add1, (nfm_CDP1x + 1.0) / 100.0 + 0.0 + add1,
+                                                   (int)nnminus(nfm_cVQ1, het3al_inc), P.tn_syserr_norm_devqual, prior_phred, tn_dec_by_xm, P.powlaw_exponent);
+        else normv_quals2(bq4, (t_cDP1x + 0.5) / 100.0 + 0.0, (t_CDP1x + 1.0) / 100.0 + 0.0, t_cVQ1, t_cPCQ1, (nfm_cDP1x + 0.5) / 100.0 + 0.0 + add1, (nfm_CDP1x + 1.0) / 100.0 + 0.0 + add1, (int)nnminus(nfm_cVQ1, het3al_inc));
+        const int converted_nfm_cVQ2 = nfm_cVQ1 - (3 * (nfm_BDP + 1) / (nfm_CDP1 + 1));
+        const int norm_norm_vq = (int)nnminus(nfm_cVQ2, imax(het3al_inc, 3) - 3);
+        if (P.tn_syserr_norm_devqual >= 0) normv_quals(cq4, (t_cDP2x + 0.5) / 100.0 + 0.0, (t_CDP2x + 1.0) / 100.0 + 0.0, t_cVQ2, t_cPCQ2, (nfm_cDP2x + 0.5) / 100.0 + 0.0 + add2, (nfm_CDP2x + 1.0) / 100.0 + 0.0 + add2,
+                                                   norm_norm_vq, P.tn_syserr_norm_devqual, prior_phred, imax(tn_dec_by_xm, imin(imax(nfm_cVQ2, converted_nfm_cVQ2), 12)), P.powlaw_exponent);
+        else normv_quals2(cq4, (t_cDP2x + 0.5) / 100.0 + 0.0, (t_CDP2x + 1.0) / 100.0 + 0.0, t_cVQ2, t_cPCQ2, (nfm_cDP2x + 0.0) / 100.0 + 0.5 + add2, (nfm_CDP2x + 0.0) / 100.0 + 1.0 + add2, norm_norm_vq);
+        const int tlodq1 = imax(bq4[3], cq4[3]);
+        const bool deanim = ((UVC_BASE_C == refsymbol && UVC_BASE_T == symbol) || (UVC_BASE_G == refsymbol && UVC_BASE_A == symbol));
+        const double b_min_tlodq = 2 + 3 - (-10 * log((t_bDP + 1e-3) / (t_BDP + 1)) / log(10.0)) / 10.0;
+        const double c2v_min_tlodq = 2 + 5 - (-10 * log((t_cDP2x * 0.01 + 1e-5) / (t_CDP2x * 0.01 + 1) / (deanim ? 5 : 1)) / log(10.0)) / 10.0;
+        const float lowestVAQ = (float)dmax(b_min_tlodq, c2v_min_tlodq);
+        const int tlodq = ((tlodq1 >= 10) ? tlodq1 : (tlodq1 * 3 - 20)) - tn_dec_both;
+        const int nlodq = nlodq1 - tn_dec_both;
+        const int somaticq = imin(tlodq, nlodq);
+        float v = (normal ? ((float)somaticq) : fmaxf((float)tlodq, lowestVAQ));
+        { const float base = (float)pow(10.0, 0.1); if (v < 10.0f) v = log1pf(powf(base, v)) / logf(base); }   // calc_non_negative<float>
+        o_TLODQ = tlodq; o_NLODQ = nlodq; o_SQ = somaticq; o_QUAL = __float_as_int(v);
+        o_FILTER = (v < 10 ? 0 : v < 20 ? 1 : v < 30 ? 2 : v < 40 ? 3 : v < 50 ? 4 : v < 60 ? 5 : 6);
+        const int vad1 = f_aBQ2; const long long vdp1 = T_ABQ20;
+        const bool keep_var = ((((double)v >= P.vqual) || ((!tprov) && ((vad1 >= P.vad1 && vdp1 >= P.vdp1 && (vdp1 * P.vfa1) <= vad1) || (t_bDP >= P.vad2 && t_BDP >= P.vdp2 && (t_BDP * P.vfa2) <= t_bDP))))
+                               && (symbol != refsymbol || should_output_ref_allele));
+        o_keep = (keep_var && t_bDP >= ((symbol == refsymbol) ? P.min_r_ad : P.min_a_ad)) ? 1 : 0;
+    }
+    OUT(UVC_O_out, o_out); OUT(UVC_O_vHGQ, o_vHGQ); OUT(UVC_O_NLODQ, o_NLODQ); OUT(UVC_O_NLODV, o_NLODV); OUT(UVC_O_TLODQ, o_TLODQ); OUT(UVC_O_SomaticQ, o_SQ);
+    for (int i = 0; i < 4; i++) { OUT(UVC_O_TNBQF0 + i, bq4[i]); OUT(UVC_O_TNCQF0 + i, cq4[i]); }
+    OUT(UVC_O_QUAL, o_QUAL); OUT(UVC_O_FILTER, o_FILTER); OUT(UVC_O_keep, o_keep);
+}
+
 
 // ---- UvcScoreRequest::kept_only: the groups that are written travel, nothing else ----
 // A (zerobased_pos, symbol type) group is kept iff one of its records is written (keep && out) or it has a GERMLINE line (germ_emit): the
@@ -1609,7 +1611,8 @@ extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const Uv
     hipLaunchKernelGGL(k_dp4, dim3((unsigned)((max_recs + 63) / 64), NDP4 / DP4_WAVES), dim3(64 * DP4_WAVES), 0, s, *P, C, S);
     hipLaunchKernelGGL(k_dpv_post, dim3((unsigned)((max_recs + 127) / 128)), dim3(128), 0, s, *P, C, S);
     hipLaunchKernelGGL(k_qual, dim3((unsigned)((max_recs + 127) / 128)), dim3(128), 0, s, *P, C, S);
-    hipLaunchKernelGGL(k_call, dim3((unsigned)((npos_scored / 8 + 127) / 128 < 2048 ? (npos_scored / 8 + 127) / 128 + 1 : 2048)), dim3(128), 0, s, *R, *P, C);
+    hipLaunchKernelGGL(k_call_group, dim3((unsigned)((max_groups + 127) / 128)), dim3(128), 0, s, *P, C, S);
+    hipLaunchKernelGGL(k_call_rec, dim3((unsigned)((max_recs + 127) / 128)), dim3(128), 0, s, *P, C, S);
     if (req->kept_only && d_fields_kept) {
         const long long tiles2 = (max_groups + GS_TILE - 1) / GS_TILE;
         hipLaunchKernelGGL(k_keep_scan, dim3((unsigned)(tiles2 < 1024 ? (tiles2 > 0 ? tiles2 : 1) : 1024)), dim3(GS_BLOCK), 0, s, C, S, ngroups, d_count + 1, R->err);
