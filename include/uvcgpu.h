@@ -86,6 +86,9 @@ void uvcgpu_params_apply_platform(UvcParams *p, int32_t platform, int32_t centra
  * of one (fam_id, fam_strand) contiguous, both strands of one family contiguous.
  * Per read (htslib bam1_core_t fields, BAM spec):                                              */
 typedef struct UvcReadSoA {
+    int32_t struct_size;        /* sizeof(UvcReadSoA) of the header the caller was built with: the library refuses any other (fields were
+                                   added to the end of this struct before, and will be again)                                         */
+    int32_t reserved_;
     int64_t n_reads;
     const int32_t  *pos;        /* core.pos  (0-based leftmost)                                  */
     const int32_t  *mpos;       /* core.mpos                                                    */

@@ -68,6 +68,15 @@ int uvcio_bgzf_write_close(uvcio_bgzf_writer_t *w);
  * alignment columns of a file or query in file order.  One cut per block the reference would hand to process_batch: `flag` = 16 contig
  * changed | 8 gap of more than 200 bp | 4 per-thread memory budget | 2 end of file, `batch` = the iternext() call that returns it. */
 typedef struct UvcRegionCut { int32_t tid, beg, end, flag, batch; int64_t n_reads; } UvcRegionCut;
+/* The same walk as a stream (it keeps a handful of scalars between alignments): feed the alignment columns piece by piece in file order, take the
+ * finished cuts as they appear, finish at the end of the file.  Memory is bounded by the piece, not by the file. */
+typedef struct uvcio_planner uvcio_planner_t;
+int uvcio_planner_open(uvcio_planner_t **out, const int64_t *target_len, int32_t n_targets, int32_t nthreads, int64_t mem_per_thread_mb);
+int uvcio_planner_feed(uvcio_planner_t *p, const int32_t *tid, const int32_t *pos, const int32_t *endpos, const uint16_t *flag, int64_t n);
+int uvcio_planner_finish(uvcio_planner_t *p);
+int64_t uvcio_planner_take(uvcio_planner_t *p, UvcRegionCut *out, int64_t capacity);
+int64_t uvcio_planner_pending(const uvcio_planner_t *p);
+void uvcio_planner_close(uvcio_planner_t *p);
 int uvcio_plan_regions(const int32_t *tid, const int32_t *pos, const int32_t *endpos, const uint16_t *flag, int64_t n,
                        const int64_t *target_len, int32_t n_targets, int32_t nthreads, int64_t mem_per_thread_mb,
                        UvcRegionCut *out, int64_t capacity, int64_t *n_out);

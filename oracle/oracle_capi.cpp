@@ -40,6 +40,7 @@ int uvc_oracle_create(void **out, const UvcParams *params, int32_t tid, int32_t 
 int uvc_oracle_set_reads(void *h, const UvcReadSoA *r) {
     State &S = *(State *)h;
     if (!r || r->n_reads < 0) { g_err = "bad reads"; return UVCGPU_EINVAL; }
+    if (r->struct_size != (int32_t)sizeof(UvcReadSoA)) { g_err = "UvcReadSoA::struct_size mismatch"; return UVCGPU_EINVAL; }
     S.bases.assign(r->bases, r->bases + r->n_bases);
     S.quals.assign(r->quals, r->quals + r->n_bases);
     S.cigars.assign(r->cigars, r->cigars + r->n_cigar_ops);

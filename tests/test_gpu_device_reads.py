@@ -21,6 +21,7 @@ class DeviceColumns:
         self.hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]; self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]; self.hip.hipFree.argtypes = [C.c_void_p]
         self.ptrs = []
         soa = _ffi.UvcReadSoA()
+        soa.struct_size = C.sizeof(_ffi.UvcReadSoA)
         soa.n_reads = int(reads["n_reads"])
 
         def put(a, dt, shift=0):

@@ -216,6 +216,13 @@ def test_region_planner_follows_samiter(seed, mem, nthreads):
     got = uio.plan_regions(tid, pos, endpos, flag, tlen, nthreads=nthreads, mem_per_thread_mb=mem)
     want = _plan_py(tid, pos, endpos, flag, tlen, nthreads, mem)
     assert got == want
+    # the streaming form (what uvc1-mi355x feeds window by window): the same cuts whatever the piece size, also when a piece ends on the record that
+    # closes a batch or on an unmapped one
+    for piece in (1, 7, 1000, len(tid) + 5):
+        assert uio.plan_regions_stream(tid, pos, endpos, flag, tlen, nthreads=nthreads, mem_per_thread_mb=mem, piece=piece) == want, piece
+    for cutoff in (len(tid) - 1, len(tid) // 2, 3):   # files that end elsewhere (the end-of-file step runs on the record the last call holds)
+        w2 = _plan_py(tid[:cutoff], pos[:cutoff], endpos[:cutoff], flag[:cutoff], tlen, nthreads, mem)
+        assert uio.plan_regions_stream(tid[:cutoff], pos[:cutoff], endpos[:cutoff], flag[:cutoff], tlen, nthreads=nthreads, mem_per_thread_mb=mem, piece=11) == w2, cutoff
     assert len(got) >= 3 and {16, 8} <= {c["flag"] & 24 for c in got} | {c["flag"] & 16 for c in got} | {c["flag"] & 8 for c in got}
     if mem == 1:
         assert any(c["flag"] & 4 for c in got) and max(c["batch"] for c in got) > 0   # the memory model cuts blocks and closes batches

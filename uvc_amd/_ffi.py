@@ -33,6 +33,7 @@ class UvcParams(C.Structure):
 
 class UvcReadSoA(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_int32), ("reserved_", C.c_int32),
         ("n_reads", C.c_int64),
         ("pos", C.c_void_p), ("mpos", C.c_void_p), ("isize", C.c_void_p), ("flag", C.c_void_p), ("mapq", C.c_void_p),
         ("nm", C.c_void_p), ("l_qseq", C.c_void_p), ("seq_off", C.c_void_p), ("cigar_off", C.c_void_p), ("n_cigar", C.c_void_p),

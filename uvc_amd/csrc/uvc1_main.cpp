@@ -154,7 +154,7 @@ bool call_tile(Worker &w, const Opts &o, const UvcParams &P, const Tile &t, int6
     auto gather = [&](auto &dst, const auto *src) { dst.resize((size_t)k); for (int64_t i = 0; i < k; i++) dst[(size_t)i] = src[w.order[(size_t)i]]; };
     gather(w.pos, b.pos); gather(w.mpos, b.mpos); gather(w.isize, w.isz.data()); gather(w.flag, b.flag); gather(w.mapq, b.mapq); gather(w.nm, b.nm);
     gather(w.lq, b.l_qseq); gather(w.soff, b.seq_off); gather(w.coff, b.cigar_off); gather(w.ncig, b.n_cigar);
-    UvcReadSoA rs; memset(&rs, 0, sizeof(rs));
+    UvcReadSoA rs; memset(&rs, 0, sizeof(rs)); rs.struct_size = (int32_t)sizeof(rs);
     rs.n_reads = k; rs.pos = w.pos.data(); rs.mpos = w.mpos.data(); rs.isize = w.isize.data(); rs.flag = w.flag.data(); rs.mapq = w.mapq.data(); rs.nm = w.nm.data();
     rs.l_qseq = w.lq.data(); rs.seq_off = w.soff.data(); rs.cigar_off = w.coff.data(); rs.n_cigar = w.ncig.data();
     rs.frag_id = w.frag.data(); rs.fam_id = w.fam.data(); rs.fam_strand = w.fstrand.data();
@@ -238,14 +238,22 @@ int main(int argc, char **argv) {
     // device; qualities within one unit next to a cut).
     const bool ref_cuts = (o.tile <= 0 && bed_path.empty());
     if (o.tile <= 0) o.tile = 1000000;
-    std::vector<int32_t> pl_tid, pl_pos, pl_end; std::vector<uint16_t> pl_flag;
+    // the planning pass is a stream: every 4 Mb window of alignments goes straight into the planner, nothing per alignment is kept
+    uvcio_planner_t *planner = nullptr; int64_t n_planned = 0; const double tp = now();
+    if (ref_cuts && uvcio_planner_open(&planner, lens.data(), nref, (o.threads > 0 ? o.threads : 8) /* the reference's -t default (CmdLineArgs.hpp:34): enters only where a batch of regions ends */, o.mem_per_thread)) die(uvcio_last_error());
+    std::vector<int32_t> pl_tid, pl_pos, pl_end; std::vector<uint16_t> pl_flag;   // one window's columns
+    auto take_cuts = [&]() { UvcRegionCut c[256]; int64_t k; while ((k = uvcio_planner_take(planner, c, 256)) > 0) for (int64_t q = 0; q < k; q++) tiles.push_back(Tile{ c[q].tid, names[(size_t)c[q].tid], c[q].beg, c[q].end, false, false, c[q].beg }); };
     auto add = [&](int32_t tid, int64_t beg, int64_t end) {
         if (!ref_cuts) { for (int64_t b = beg; b < end; b += o.tile) tiles.push_back(Tile{ tid, names[(size_t)tid], b, std::min(b + o.tile, end), false, false, b }); return; }
         const int64_t W = 4000000;   // the planning pass reads the span window by window; an alignment is taken by the window it starts in (the first window also takes those that reach into it)
         for (int64_t wb = beg; wb < end; wb += W) {
             UvcBamBatch b;
             if (uvcio_bam_fetch(bam0, tid, wb, std::min(wb + W, end), &b)) die(uvcio_last_error());
+            pl_tid.clear(); pl_pos.clear(); pl_end.clear(); pl_flag.clear();
             for (int64_t i = 0; i < b.n_alns; i++) if (b.pos[i] >= wb || wb == beg) { pl_tid.push_back(b.tid[i]); pl_pos.push_back(b.pos[i]); pl_end.push_back(b.endpos[i]); pl_flag.push_back(b.flag[i]); }
+            if (uvcio_planner_feed(planner, pl_tid.data(), pl_pos.data(), pl_end.data(), pl_flag.data(), (int64_t)pl_tid.size())) die(uvcio_last_error());
+            n_planned += (int64_t)pl_tid.size();
+            take_cuts();
         }
     };
     if (!bed_path.empty()) {   // one region per BED line (0-based, half-open), cut into tiles; overrides --targets as in the reference
@@ -275,14 +283,10 @@ int main(int argc, char **argv) {
         add(tid, beg, end < 0 ? lens[(size_t)tid] : std::min(end, lens[(size_t)tid]));
     } else for (int32_t i = 0; i < nref; i++) add(i, 0, lens[(size_t)i]);
     if (ref_cuts) {
-        const double tp = now();
-        const int plan_threads = (o.threads > 0 ? o.threads : 8);   // the reference's -t default (CmdLineArgs.hpp:34): enters only where a batch of regions ends
-        int64_t n_cuts = 0;
-        if (uvcio_plan_regions(pl_tid.data(), pl_pos.data(), pl_end.data(), pl_flag.data(), (int64_t)pl_tid.size(), lens.data(), nref, plan_threads, o.mem_per_thread, nullptr, 0, &n_cuts) && n_cuts == 0 && !pl_tid.empty()) die(uvcio_last_error());
-        std::vector<UvcRegionCut> cuts((size_t)std::max<int64_t>(n_cuts, 1));
-        if (n_cuts > 0 && uvcio_plan_regions(pl_tid.data(), pl_pos.data(), pl_end.data(), pl_flag.data(), (int64_t)pl_tid.size(), lens.data(), nref, plan_threads, o.mem_per_thread, cuts.data(), n_cuts, &n_cuts)) die(uvcio_last_error());
-        for (int64_t q = 0; q < n_cuts; q++) tiles.push_back(Tile{ cuts[(size_t)q].tid, names[(size_t)cuts[(size_t)q].tid], cuts[(size_t)q].beg, cuts[(size_t)q].end, false, false, cuts[(size_t)q].beg });
-        fprintf(stderr, "uvc1-mi355x: %lld regions from the reference's cuts over %zu alignments (planning pass %.2f s)\n", (long long)n_cuts, pl_tid.size(), now() - tp);
+        if (uvcio_planner_finish(planner)) die(uvcio_last_error());
+        take_cuts();
+        uvcio_planner_close(planner); planner = nullptr;
+        fprintf(stderr, "uvc1-mi355x: %zu regions from the reference's cuts over %lld alignments (planning pass %.2f s)\n", tiles.size(), (long long)n_planned, now() - tp);
         std::vector<int32_t>().swap(pl_tid); std::vector<int32_t>().swap(pl_pos); std::vector<int32_t>().swap(pl_end); std::vector<uint16_t>().swap(pl_flag);
     }
     // ownership of the shared end points: a tile whose predecessor ends where it begins continues that one's run (fixed tiles only: the

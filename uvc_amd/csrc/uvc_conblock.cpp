@@ -102,6 +102,7 @@ int finish(std::vector<UvcConBlock> &B, std::vector<int32_t> &rows, UvcConBlock 
 }
 int check_reads(const UvcReadSoA *R) {
     if (!R || R->n_reads < 0) return uvcgpu_set_error(UVCGPU_EINVAL, "consensus blocks: bad argument");
+    if (R->struct_size != (int32_t)sizeof(UvcReadSoA)) return uvcgpu_set_error(UVCGPU_EINVAL, "UvcReadSoA::struct_size mismatch");
     if (R->n_reads > 0 && (!R->pos || !R->mpos || !R->isize || !R->flag || !R->seq_off || !R->cigar_off || !R->n_cigar || !R->frag_id || !R->fam_id || !R->fam_strand || !R->bases || !R->quals || !R->cigars))
         return uvcgpu_set_error(UVCGPU_EINVAL, "consensus blocks: a read column is NULL");
     return 0;

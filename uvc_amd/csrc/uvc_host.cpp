@@ -26,7 +26,7 @@ struct RawReads {
     const int64_t *seq_off, *cigar_off, *table_off, *item_off, *gap_off;
 };
 extern "C" void uvc_launch_correct_bq(const RegionDev *R, int bq_max, int bq_inc, hipStream_t s);
-extern "C" void uvc_launch_pack_bq(const uint8_t *bases, const uint8_t *quals, uint16_t *bq, int64_t n, hipStream_t s);
+extern "C" void uvc_launch_pack_bq(const uint8_t *bases, const uint8_t *quals, uint16_t *bq, int64_t n, int32_t *bad, hipStream_t s);
 extern "C" void uvc_launch_build_p2list(const RegionDev *R, const int32_t *fast_rank, const int32_t *aln, const int32_t *cbeg, const int32_t *cend, const int32_t *qb, hipStream_t s);
 extern "C" void uvc_launch_prelude(const RegionDev *R, const RawReads *W, const UvcParams *P, hipStream_t s);
 struct UvcProf { int on; int n; const char *name[32]; hipEvent_t ev[32][2]; };
@@ -367,7 +367,8 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
     const int64_t n_simple = o.n_simple; const size_t nf = (size_t)o.n_frags;
     if (bq_done) { R.bq = bq_done; R.bq_bytes = (uint32_t)(d->n_bases * 2); }   // packed while the 4-bit bases were unpacked
     else { uint16_t *b = nullptr; if ((rc = dev_alloc(r, (size_t)std::max<int64_t>(d->n_bases, 1), &b))) return rc; R.bq = b; R.bq_bytes = (uint32_t)(d->n_bases * 2);
-      uvc_launch_pack_bq(R.bases, R.quals, b, d->n_bases, r->stream); }
+      if (!d_bad && (rc = dev_alloc(r, 1, &d_bad, true))) return rc;
+      uvc_launch_pack_bq(R.bases, R.quals, b, d->n_bases, d_bad, r->stream); }
     { AlnRec *a; if ((rc = dev_alloc(r, (size_t)n, &a))) return rc; R.alns = a; R.n_alns = (int32_t)n; }
     R.n_fast = (int32_t)n_simple;
     { FastRec *f; if ((rc = dev_alloc(r, (size_t)n_simple, &f))) return rc; R.frec = f; }
@@ -453,6 +454,7 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
         HIP_OK(hipMemcpyAsync(&total, R.mis_total, sizeof(total), hipMemcpyDeviceToHost, r->stream));
         if (d_bad) HIP_OK(hipMemcpyAsync(&bad4, d_bad, sizeof(bad4), hipMemcpyDeviceToHost, r->stream));
         HIP_OK(hipStreamSynchronize(r->stream));
+        if (bad4 == 2) return fail(UVCGPU_EINVAL, "a base code outside 0..4 in UvcReadSoA::bases");
         if (bad4) return fail(UVCGPU_EINVAL, "bases4 / l_qseq / n_bases do not fit together");
         if (total > ((unsigned long long)1 << 30)) return fail(UVCGPU_EUNSUPPORTED, "more than 2^30 mismatching bases in one region");
         MisItem *q = nullptr;
@@ -467,7 +469,9 @@ static int set_reads_on_device(uvcgpu_region_t *r, const UvcReadSoA *d, bool tim
 
 // Host columns: they are copied to the device as they are (no host pass over the reads), then prepared there.
 static int uvcgpu_region_set_reads_impl(uvcgpu_region_t *r, const UvcReadSoA *in) {
-    if (!r || !in || in->n_reads < 0 || in->n_fams < 0) return fail(UVCGPU_EINVAL, "bad reads");
+    if (!r || !in) return fail(UVCGPU_EINVAL, "bad reads");
+    if (in->struct_size != (int32_t)sizeof(UvcReadSoA)) return fail(UVCGPU_EINVAL, "UvcReadSoA::struct_size mismatch (set it to sizeof(UvcReadSoA))");
+    if (in->n_reads < 0 || in->n_fams < 0) return fail(UVCGPU_EINVAL, "bad reads");
     const bool timing = (getenv("UVCGPU_TIMING") != nullptr);   // stderr breakdown of the ingest, for tuning
     auto t_prev = std::chrono::steady_clock::now();
     free_reads(r);
@@ -512,7 +516,9 @@ static int uvcgpu_region_set_reads_impl(uvcgpu_region_t *r, const UvcReadSoA *in
 // arrays must stay valid and unchanged until the handle gets other reads, is reset or destroyed -- the kernels of every accumulate
 // read bases / quals / cigars in place -- and uvcgpu_region_correct_bq edits `quals` in place, as the reference edits its bam1_t.
 static int uvcgpu_region_set_reads_device_impl(uvcgpu_region_t *r, const UvcReadSoA *in) {
-    if (!r || !in || in->n_reads < 0 || in->n_fams < 0 || in->n_bases < 0 || in->n_cigar_ops < 0) return fail(UVCGPU_EINVAL, "bad reads");
+    if (!r || !in) return fail(UVCGPU_EINVAL, "bad reads");
+    if (in->struct_size != (int32_t)sizeof(UvcReadSoA)) return fail(UVCGPU_EINVAL, "UvcReadSoA::struct_size mismatch (set it to sizeof(UvcReadSoA))");
+    if (in->n_reads < 0 || in->n_fams < 0 || in->n_bases < 0 || in->n_cigar_ops < 0) return fail(UVCGPU_EINVAL, "bad reads");
     const bool timing = (getenv("UVCGPU_TIMING") != nullptr);
     free_reads(r);
     if (in->n_reads == 0) return 0;
@@ -526,7 +532,7 @@ static int uvcgpu_region_correct_bq_impl(uvcgpu_region_t *r) {
     if (!r) return fail(UVCGPU_EINVAL, "null region");
     if (!r->has_reads) return fail(UVCGPU_ENOREADS, "no reads");
     uvc_launch_correct_bq(&r->R, r->P.assay_sequencing_BQ_max, r->P.assay_sequencing_BQ_inc, r->stream);
-    uvc_launch_pack_bq(r->R.bases, r->R.quals, (uint16_t *)r->R.bq, r->n_bases, r->stream);
+    uvc_launch_pack_bq(r->R.bases, r->R.quals, (uint16_t *)r->R.bq, r->n_bases, nullptr, r->stream);
     HIP_OK(hipMemsetAsync(r->R.mis_total, 0, sizeof(unsigned long long), r->stream));
     uvc_launch_prelude(&r->R, &r->W, &r->P, r->stream);
     uvc_launch_build_p2list(&r->R, r->W.fast_rank, r->d_p2[0], r->d_p2[1], r->d_p2[2], r->d_p2[3], r->stream);
@@ -776,7 +782,8 @@ const int32_t *uvcgpu_region_repeat_tracks(const uvcgpu_region_t *cr, int64_t *n
     if (npos) *npos = r->npos;
     if (!r->h_rtr_valid) {
         r->h_rtr.resize((size_t)3 * r->npos);
-        if (hipStreamSynchronize(r->stream) != hipSuccess || hipMemcpy(r->h_rtr.data(), r->d_rtr0, sizeof(int32_t) * r->h_rtr.size(), hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+        // on the handle's own stream: a null-stream copy would also wait for every other handle's work
+        if (hipMemcpyAsync(r->h_rtr.data(), r->d_rtr0, sizeof(int32_t) * r->h_rtr.size(), hipMemcpyDeviceToHost, r->stream) != hipSuccess || hipStreamSynchronize(r->stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         r->h_rtr_valid = true;
     }
     return r->h_rtr.data();

@@ -742,62 +742,98 @@ bool plan_block_over(int64_t n_reads, int64_t n_rposs, int64_t mem_mb, int64_t c
     return used > memfree + memfree * ovl / 150;
 }
 }
+// The planner as a stream: the walk keeps a handful of scalars between alignments, so a caller that reads a whole genome feeds it window by
+// window and holds no per-alignment column (uvc1-mi355x; uvcio_plan_regions below is the one-call form of the same code).
+struct uvcio_planner {
+    int64_t nthreads, mem_mb; std::vector<int64_t> target_len;
+    int64_t block_tid = -1, block_beg = -1, block_running_end = -1;   // last_it_* (grouping.hpp)
+    int64_t total_reads = 0, total_rposs = 0, total_reads_sq = 0, total_rposs_sq = 0;   // of the current iternext() call
+    int64_t region_reads = 0, region_rposs = 0, region_rposs_add = 0;
+    int32_t batch = 0;
+    bool any = false, last_unmapped = false, done = false;
+    bool cur_valid = false;   // this iternext() call has read a record (the end of the file is only processed on a record the call itself holds)
+    int64_t last_tid = 0, last_pos = 0, last_end = 0;
+    std::vector<UvcRegionCut> cuts;   // cuts that have not been taken yet
+    void new_call() { cur_valid = false; total_reads = total_rposs = total_reads_sq = total_rposs_sq = 0; region_reads = region_rposs = region_rposs_add = 0; batch++; }
+    // the body of iternext's read loop for one record (ret = 0) or for the end of the file (ret = -1, on the last record read)
+    void step(int64_t curr_tid, int64_t curr_beg, int64_t curr_end, int ret) {
+        const bool sub_over = plan_block_over(region_reads, region_rposs + region_rposs_add, mem_mb, curr_beg, block_running_end < 0 ? 0 : block_running_end);
+        const bool tmpl_changed = (curr_tid != block_tid);
+        const bool far_jumped = ((curr_tid == block_tid) && (block_running_end + (PLAN_MAX_STR_N_BASES * 2) < curr_beg));
+        const int32_t rflag = (tmpl_changed ? 16 : 0) + (far_jumped ? 8 : 0) + (sub_over ? 4 : 0) + ((-1 == ret) ? 2 : 0);
+        if (rflag) {
+            const bool first = (-1 == block_tid);
+            const int64_t tlen = first ? (int64_t)INT32_MAX : ((block_tid < (int64_t)target_len.size()) ? target_len[(size_t)block_tid] : (int64_t)INT32_MAX);
+            const int64_t norm_end = std::min(block_running_end, tlen);
+            const bool zero = (block_beg >= norm_end);
+            if (!first && !zero) {
+                cuts.push_back(UvcRegionCut{ (int32_t)block_tid, (int32_t)block_beg, (int32_t)norm_end, rflag, batch, region_reads });
+                const int64_t s_rposs = region_rposs + region_rposs_add;
+                total_reads += region_reads; total_rposs += s_rposs; total_reads_sq += region_reads * region_reads; total_rposs_sq += s_rposs * s_rposs;
+                region_rposs = 0; region_rposs_add = 0; region_reads = 0;
+            }
+            block_tid = curr_tid;
+            const int64_t new_beg = std::max(block_beg, curr_beg);
+            block_beg = (tmpl_changed ? curr_beg : std::max(new_beg, norm_end));
+            if (plan_batch_over(total_reads, total_reads_sq, total_rposs, total_rposs_sq, nthreads, mem_mb)) {
+                block_running_end = std::max(block_beg, norm_end);
+                new_call();   // iternext returns here: the record that closed the batch is not counted (the reference drops it the same way)
+                return;
+            }
+        }
+        if (tmpl_changed) { block_beg = curr_beg; block_running_end = curr_end; region_rposs_add += region_rposs; }
+        else block_running_end = std::max(block_running_end, curr_end);
+        region_reads++;
+        region_rposs = block_running_end - block_beg;
+    }
+};
+extern "C" int uvcio_planner_open(uvcio_planner_t **out, const int64_t *target_len, int32_t n_targets, int32_t nthreads, int64_t mem_per_thread_mb) {
+    if (!out || nthreads < 1 || mem_per_thread_mb < 1 || n_targets < 0) return fail(UVCGPU_EINVAL, "bad argument");
+    uvcio_planner *p = new uvcio_planner();
+    p->nthreads = nthreads; p->mem_mb = mem_per_thread_mb;
+    if (target_len) p->target_len.assign(target_len, target_len + n_targets);
+    *out = p;
+    return 0;
+}
+extern "C" int uvcio_planner_feed(uvcio_planner_t *p, const int32_t *tid, const int32_t *pos, const int32_t *endpos, const uint16_t *flag, int64_t n) {
+    if (!p || n < 0 || (n > 0 && (!tid || !pos || !endpos || !flag)) || p->done) return fail(UVCGPU_EINVAL, "bad argument");
+    for (int64_t i = 0; i < n; i++) {
+        p->any = true; p->cur_valid = true; p->last_unmapped = (flag[i] & 0x4) != 0; p->last_tid = tid[i]; p->last_pos = pos[i]; p->last_end = endpos[i];
+        if (flag[i] & 0x4) continue;   // BAM_FUNMAP
+        p->step(tid[i], pos[i], endpos[i], 0);
+    }
+    return 0;
+}
+extern "C" int uvcio_planner_finish(uvcio_planner_t *p) {   // the end of the file: the read call fails and the loop body runs once more on the record it still holds
+    if (!p) return fail(UVCGPU_EINVAL, "bad argument");
+    if (!p->done && p->any && p->cur_valid && !p->last_unmapped) p->step(p->last_tid, p->last_pos, p->last_end, -1);
+    p->done = true;
+    return 0;
+}
+extern "C" int64_t uvcio_planner_take(uvcio_planner_t *p, UvcRegionCut *out, int64_t capacity) {   // moves up to `capacity` finished cuts out, in order
+    if (!p || capacity < 0 || (capacity > 0 && !out)) return 0;
+    const int64_t n = std::min<int64_t>(capacity, (int64_t)p->cuts.size());
+    for (int64_t k = 0; k < n; k++) out[k] = p->cuts[(size_t)k];
+    p->cuts.erase(p->cuts.begin(), p->cuts.begin() + n);
+    return n;
+}
+extern "C" int64_t uvcio_planner_pending(const uvcio_planner_t *p) { return p ? (int64_t)p->cuts.size() : 0; }
+extern "C" void uvcio_planner_close(uvcio_planner_t *p) { delete p; }
+
 extern "C" int uvcio_plan_regions(const int32_t *tid, const int32_t *pos, const int32_t *endpos, const uint16_t *flag, int64_t n,
                                   const int64_t *target_len, int32_t n_targets, int32_t nthreads, int64_t mem_per_thread_mb,
                                   UvcRegionCut *out, int64_t capacity, int64_t *n_out) {
     if (!n_out || n < 0 || (n > 0 && (!tid || !pos || !endpos || !flag)) || nthreads < 1 || mem_per_thread_mb < 1) return fail(UVCGPU_EINVAL, "bad argument");
-    std::vector<UvcRegionCut> cuts;
-    int64_t block_tid = -1, block_beg = -1, block_running_end = -1;   // last_it_* (grouping.hpp)
-    int64_t i = 0; bool file_done = (n == 0);
-    int32_t batch = 0;
-    while (!file_done) {   // one iternext() call per turn
-        int64_t total_reads = 0, total_rposs = 0, total_reads_sq = 0, total_rposs_sq = 0;
-        int64_t region_reads = 0, region_rposs = 0, region_rposs_add = 0;
-        bool returned_early = false;
-        int64_t cur = -1;   // the record alnrecord holds (stays the last one when the read call reports the end of the file)
-        int ret;
-        do {
-            ret = (i < n) ? 0 : -1;
-            if (ret >= 0) { cur = i; i++; }
-            if (cur < 0) break;
-            if (flag[cur] & 0x4) continue;   // BAM_FUNMAP
-            const int64_t curr_tid = tid[cur], curr_beg = pos[cur], curr_end = endpos[cur];
-            const bool sub_over = plan_block_over(region_reads, region_rposs + region_rposs_add, mem_per_thread_mb, curr_beg, block_running_end < 0 ? 0 : block_running_end);
-            const bool tmpl_changed = (curr_tid != block_tid);
-            const bool far_jumped = ((curr_tid == block_tid) && (block_running_end + (PLAN_MAX_STR_N_BASES * 2) < curr_beg));
-            const int32_t rflag = (tmpl_changed ? 16 : 0) + (far_jumped ? 8 : 0) + (sub_over ? 4 : 0) + ((-1 == ret) ? 2 : 0);
-            if (rflag) {
-                const bool first = (-1 == block_tid);
-                const int64_t tlen = first ? (int64_t)INT32_MAX : ((block_tid < n_targets && target_len) ? target_len[block_tid] : (int64_t)INT32_MAX);
-                const int64_t norm_end = std::min(block_running_end, tlen);
-                const bool zero = (block_beg >= norm_end);
-                if (!first && !zero) {
-                    cuts.push_back(UvcRegionCut{ (int32_t)block_tid, (int32_t)block_beg, (int32_t)norm_end, rflag, batch, region_reads });
-                    const int64_t s_rposs = region_rposs + region_rposs_add;
-                    total_reads += region_reads; total_rposs += s_rposs; total_reads_sq += region_reads * region_reads; total_rposs_sq += s_rposs * s_rposs;
-                    region_rposs = 0; region_rposs_add = 0; region_reads = 0;
-                }
-                block_tid = curr_tid;
-                const int64_t new_beg = std::max(block_beg, curr_beg);
-                block_beg = (tmpl_changed ? curr_beg : std::max(new_beg, norm_end));
-                if (plan_batch_over(total_reads, total_reads_sq, total_rposs, total_rposs_sq, nthreads, mem_per_thread_mb)) {
-                    block_running_end = std::max(block_beg, norm_end);
-                    returned_early = true;
-                    break;
-                }
-            }
-            if (tmpl_changed) { block_beg = curr_beg; block_running_end = curr_end; region_rposs_add += region_rposs; }
-            else block_running_end = std::max(block_running_end, curr_end);
-            region_reads++;
-            region_rposs = block_running_end - block_beg;
-        } while (ret >= 0);
-        if (!returned_early) file_done = true;
-        batch++;
-    }
-    *n_out = (int64_t)cuts.size();
-    if ((int64_t)cuts.size() > capacity || (!out && !cuts.empty())) return fail(UVCGPU_ENOMEM, "destination too small");
-    for (size_t k = 0; k < cuts.size(); k++) out[k] = cuts[k];
-    return 0;
+    uvcio_planner_t *p = nullptr;
+    if (uvcio_planner_open(&p, target_len, target_len ? n_targets : 0, nthreads, mem_per_thread_mb)) return UVCGPU_EINVAL;
+    uvcio_planner_feed(p, tid, pos, endpos, flag, n);
+    uvcio_planner_finish(p);
+    *n_out = uvcio_planner_pending(p);
+    int rc = 0;
+    if (*n_out > capacity || (!out && *n_out > 0)) rc = fail(UVCGPU_ENOMEM, "destination too small");
+    else uvcio_planner_take(p, out, *n_out);
+    uvcio_planner_close(p);
+    return rc;
 }
 
 // ---- region shards: cost estimate, contiguous balanced partition, concatenation of the shard outputs ----

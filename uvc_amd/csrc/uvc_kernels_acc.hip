@@ -3693,15 +3693,23 @@ extern "C" void uvc_launch_correct_bq(const RegionDev *R, int bq_max, int bq_inc
     if (R->n_alns) hipLaunchKernelGGL(k_correct_bq, dim3((unsigned)((R->n_alns + 255) / 256)), dim3(256), 0, s, *R, bq_max, bq_inc);
 }
 
-__global__ void __launch_bounds__(256) k_pack_bq1(const uint8_t *bases, const uint8_t *quals, uint16_t *bq, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+// (a base code above 4 is refused here, where the one-byte-per-base column enters: k_aln_bm compares eight bases per load and relies on every
+// byte being below 0x80, the per-symbol tables index with the code)
+__global__ void __launch_bounds__(256) k_pack_bq1(const uint8_t *bases, const uint8_t *quals, uint16_t *bq, int64_t n, int32_t *bad) {
+    int any = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         bq[i] = (uint16_t)(bases[i] | (quals[i] << 8));
+        any |= (bases[i] > 4);
+    }
+    if (bad && __any(any) && (threadIdx.x & 63) == 0) *bad = 2;
 }
 // eight read bases per thread: two 8-byte loads, one 16-byte store (a byte per thread ran at 1.7 TB/s of the 1.2 GB it moves)
-__global__ void __launch_bounds__(256) k_pack_bq(const uint8_t *bases, const uint8_t *quals, uint16_t *bq, int64_t n) {
+__global__ void __launch_bounds__(256) k_pack_bq(const uint8_t *bases, const uint8_t *quals, uint16_t *bq, int64_t n, int32_t *bad) {
     const int64_t n8 = n >> 3;
+    unsigned long long over = 0;   // bits 3..7 of any byte set <=> a code above 7; codes 5..7: bit 2 with bit 0 or 1
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const unsigned long long b = ((const unsigned long long *)bases)[i], q = ((const unsigned long long *)quals)[i];
+        over |= (b & 0xF8F8F8F8F8F8F8F8ull) | (b & 0x0404040404040404ull & (((b | (b >> 1)) & 0x0101010101010101ull) << 2));
         uint4 o;
         o.x = (uint32_t)((b & 0xFF) | ((q & 0xFF) << 8) | (((b >> 8) & 0xFF) << 16) | (((q >> 8) & 0xFF) << 24));
         o.y = (uint32_t)(((b >> 16) & 0xFF) | (((q >> 16) & 0xFF) << 8) | (((b >> 24) & 0xFF) << 16) | (((q >> 24) & 0xFF) << 24));
@@ -3709,14 +3717,15 @@ __global__ void __launch_bounds__(256) k_pack_bq(const uint8_t *bases, const uin
         o.w = (uint32_t)(((b >> 48) & 0xFF) | (((q >> 48) & 0xFF) << 8) | (((b >> 56) & 0xFF) << 16) | (((q >> 56) & 0xFF) << 24));
         ((uint4 *)bq)[i] = o;
     }
-    if (blockIdx.x == 0) for (int64_t i = (n8 << 3) + threadIdx.x; i < n; i += blockDim.x) bq[i] = (uint16_t)(bases[i] | (quals[i] << 8));   // the last n % 8
+    if (blockIdx.x == 0) for (int64_t i = (n8 << 3) + threadIdx.x; i < n; i += blockDim.x) { bq[i] = (uint16_t)(bases[i] | (quals[i] << 8)); over |= (bases[i] > 4); }   // the last n % 8
+    if (bad && __any(over != 0) && (threadIdx.x & 63) == 0) *bad = 2;
 }
-extern "C" void uvc_launch_pack_bq(const uint8_t *bases, const uint8_t *quals, uint16_t *bq, int64_t n, hipStream_t s) {
+extern "C" void uvc_launch_pack_bq(const uint8_t *bases, const uint8_t *quals, uint16_t *bq, int64_t n, int32_t *bad, hipStream_t s) {
     if (n <= 0) return;
     // the wide form needs 8- / 16-byte aligned columns (device allocations are; a caller's sub-array of set_reads_device may not be)
     const bool aligned = !(((uintptr_t)bases | (uintptr_t)quals) & 7) && !((uintptr_t)bq & 15);
-    if (aligned) hipLaunchKernelGGL(k_pack_bq, dim3((unsigned)std::min<int64_t>(((n >> 3) + 255) / 256 + 1, 16384)), dim3(256), 0, s, bases, quals, bq, n);
-    else hipLaunchKernelGGL(k_pack_bq1, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65536)), dim3(256), 0, s, bases, quals, bq, n);
+    if (aligned) hipLaunchKernelGGL(k_pack_bq, dim3((unsigned)std::min<int64_t>(((n >> 3) + 255) / 256 + 1, 16384)), dim3(256), 0, s, bases, quals, bq, n, bad);
+    else hipLaunchKernelGGL(k_pack_bq1, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65536)), dim3(256), 0, s, bases, quals, bq, n, bad);
 }
 extern "C" void uvc_launch_build_p2list(const RegionDev *R, const int32_t *fast_rank, const int32_t *aln, const int32_t *cbeg, const int32_t *cend, const int32_t *qb, hipStream_t s) {
     if (R->n_fast2) hipLaunchKernelGGL(k_build_p2list, dim3(nblk(R->n_fast2, 256)), dim3(256), 0, s, *R, fast_rank, aln, cbeg, cend, qb);

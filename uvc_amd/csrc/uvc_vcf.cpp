@@ -497,6 +497,7 @@ extern "C" int uvcgpu_region_vcf_records(uvcgpu_region_t *r, const char *tname, 
     const std::string ref(refp, (size_t)(end - beg));
     int64_t npos = 0;
     const int32_t *rtr = uvcgpu_region_repeat_tracks(r, &npos);
+    if (!rtr) return uvcgpu_fail_(UVCGPU_EDEVICE, "vcf_records: the repeat tracks could not be fetched from the device");
     auto F = [&](int64_t i, int f) { return recs[(int64_t)f * stride + i]; };
     // the InDel string a rescued record of the normal sample takes from its tumor record: REF / ALT without their common head (main.cpp:867-880)
     auto rescued_text = [&](int64_t i) -> std::string {

@@ -186,6 +186,38 @@ def plan_regions(tid, pos, endpos, flag, target_lens, nthreads=1, mem_per_thread
     return [dict(tid=c.tid, beg=c.beg, end=c.end, flag=c.flag, batch=c.batch, n_reads=c.n_reads) for c in out[:n.value]]
 
 
+def plan_regions_stream(tid, pos, endpos, flag, target_lens, nthreads=1, mem_per_thread_mb=1536, piece=1000):
+    """The same cuts through the streaming form (uvcio_planner_*): the columns are fed `piece` alignments at a time, cuts are taken as they appear."""
+    d = dll()
+    d.uvcio_planner_open.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int32, C.c_int32, C.c_int64]
+    d.uvcio_planner_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    d.uvcio_planner_finish.argtypes = [C.c_void_p]
+    d.uvcio_planner_take.restype, d.uvcio_planner_take.argtypes = C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64]
+    d.uvcio_planner_close.restype, d.uvcio_planner_close.argtypes = None, [C.c_void_p]
+    a = [np.ascontiguousarray(tid, dtype=np.int32), np.ascontiguousarray(pos, dtype=np.int32), np.ascontiguousarray(endpos, dtype=np.int32), np.ascontiguousarray(flag, dtype=np.uint16)]
+    tl = np.ascontiguousarray(target_lens, dtype=np.int64)
+    h = C.c_void_p()
+    _check(d.uvcio_planner_open(C.byref(h), tl.ctypes.data, len(tl), nthreads, mem_per_thread_mb))
+    cuts, buf = [], (UvcRegionCut * 64)()
+
+    def take():
+        while True:
+            k = d.uvcio_planner_take(h, buf, 64)
+            cuts.extend(dict(tid=c.tid, beg=c.beg, end=c.end, flag=c.flag, batch=c.batch, n_reads=c.n_reads) for c in buf[:k])
+            if k < 64:
+                break
+    try:
+        for i in range(0, len(a[0]), max(1, piece)):
+            s = [x[i:i + piece] for x in a]
+            _check(d.uvcio_planner_feed(h, s[0].ctypes.data, s[1].ctypes.data, s[2].ctypes.data, s[3].ctypes.data, len(s[0])))
+            take()
+        _check(d.uvcio_planner_finish(h))
+        take()
+    finally:
+        d.uvcio_planner_close(h)
+    return cuts
+
+
 class TumorVcf:
     """The tumor VCF of a T/N pair as the normal pass reads it (uvcio_tumor_vcf_*: rescue_variants_from_vcf, main.cpp:183-398)."""
 

@@ -107,6 +107,7 @@ def _fill_soa(reads, put):
     """UvcReadSoA from a dict of columns; `put(array, dtype) -> address` places a column (host or device).  Columns a compact dict leaves
     out (seq_off, cigar_off, bases) stay NULL."""
     soa = _ffi.UvcReadSoA()
+    soa.struct_size = C.sizeof(_ffi.UvcReadSoA)
     soa.n_reads = int(reads["n_reads"])
     for name, dt in _READ_FIELDS:
         if name in ("seq_off", "cigar_off") and reads.get(name) is None:
