@@ -4,6 +4,7 @@ reference's own defaults).  The oracle (CPU suite) and the HIP path through the 
 one parity line of this repository whose expected values come from neither of the two."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -128,16 +129,21 @@ def test_gpu_reproduces_the_restatement_chain(name, gpu_lib):
     check(gpu_lib, name, exact_records=False)      # quality fields within 1 Phred, x100 depths within 1 % (device libm), the rest exact
 
 
-def test_fixtures_are_what_the_generator_writes():
-    """The smallest fixture regenerated on the spot (pure Python, seconds): the committed file is the generator's output."""
+def _regenerate(name):
     import importlib.util
     spec = importlib.util.spec_from_file_location("make_chain_golden", os.path.join(ROOT, "tests", "golden", "make_chain_golden.py"))
     mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
-    assert sorted(mg.CASES) == sorted(CASES)
-    name = "chain_iontorrent_umi_normal"
     kw = mg.CASES[name]
     reads = mg.weird_region(kw["seed"], n_frag=kw["n_frag"], ref_len=kw["ref_len"], umi=kw["umi"])
     _, planes = mg.chain_planes(reads, mg.params_for(kw["platform"], kw["normal"]), kw["platform"], kw["normal"])
+    return planes
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_every_fixture_is_what_the_generator_writes(name):
+    """All committed fixtures regenerated on the spot (pure Python, a few seconds each): a fixture that drifted from
+    tests/golden/make_chain_golden.py would go unnoticed otherwise."""
+    planes = _regenerate(name)
     _, _, gold, _, _, _, _, _ = load(name)
     for g in INT_GROUPS:
         assert np.array_equal(planes[g], gold[g]), g

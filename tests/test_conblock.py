@@ -203,3 +203,11 @@ def test_bad_arguments(product_lib):
     assert consensus.block_to_seq(product_lib, np.zeros((0, 8), np.int32)) == []
     # an all-zero row (a base of quality 0) votes for BASE_NN: '*' with family size 0
     assert consensus.block_to_seq(product_lib, [[0, 0, 0, 0, 0, 1, 0, 1]]) == [("*", 0, 0, 0)]
+
+
+@pytest.mark.gpu
+def test_on_the_gpu_box_too(product_lib, oracle_lib):
+    """Row a9 is host code inside libuvcgpu.so: the same comparison once more under `-m gpu`, so that the driver's GPU run loads the library
+    that hosts it and exercises it there as well (the CPU suite above runs everywhere)."""
+    test_a_family_written_down_by_hand(product_lib)
+    test_product_equals_the_oracle_and_an_independent_restatement(dict(seed=33, region_len=3000, depth=150, umi=True, indel_every=120, clip_frac=0.25), product_lib, oracle_lib)

@@ -61,3 +61,21 @@ def test_large_region_matches_oracle(name, oracle_runs, gpu_lib):
     ao, ag = Ro.indel_alleles(), Rg.indel_alleles()
     assert ao == ag
     Rg.close()
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("UVC_FULL_ORACLE"), reason="minutes of oracle time and ~16 GB of host memory: UVC_FULL_ORACLE=1 (the soak runs set it)")
+def test_the_bench_tile_itself_matches_oracle(oracle_lib, gpu_lib):
+    """The 1 Mb x 300x tile bench.py times (its first tile: seed 12345, the generator's defaults) through the oracle: every plane bit-exact, the
+    default-gate records inside the tolerance classes.  The largest comparison of the default suite is 150 kb; this one is behind a switch
+    because the single-threaded oracle takes a few minutes on it."""
+    reads = synth.generate_region(seed=12345, region_len=1_000_000, depth=300, beg=1000000)
+    Ro = run_region(oracle_lib, reads)
+    ro = Ro.score(all_out=False)
+    Rg = run_region(gpu_lib, reads)
+    bad = diff_groups(Ro, Rg)
+    assert not bad, "\n".join("%s: %d cells differ, e.g. %s" % (g, v[0], v[1]) for g, v in bad.items())
+    rg = Rg.score(all_out=False)
+    assert len(ro["refpos"]) > 40000
+    worst = compare_records(ro, rg)
+    print("bench tile:", reads["n_reads"], "reads,", len(ro["refpos"]), "records, worst differences", {k: v for k, v in worst.items() if v})
+    Ro.close(); Rg.close()
