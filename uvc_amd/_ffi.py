@@ -160,4 +160,5 @@ class Lib:
 
 
 def gpu_library_path():
-    return os.path.join(ROOT, "uvc_amd", "csrc", "libuvcgpu.so")
+    # UVCGPU_LIBRARY: another build of the same ABI (A/B measurements of a kernel variant on one GPU box: scripts/gpu_ab_*.sh)
+    return os.environ.get("UVCGPU_LIBRARY") or os.path.join(ROOT, "uvc_amd", "csrc", "libuvcgpu.so")

@@ -750,16 +750,13 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
         Chunk16 c;
         load_chunk16(R.frec, k0 + lane, hi, c);
         const int n = imin(64, hi - k0);
-        int bqn = 0;
-        auto issue = [&](int j) {
-            bqn = bq_load(rs, bcast(c.v[2], j) + p);   // low word of qbase + p: exact for lanes inside the read, harmless elsewhere
-        };
-        issue(0);
-        for (int j = 0; j < n; j++) {
+        // the base | quality bytes of the chunk's reads are requested four reads ahead (one load per read and lane, HBM / L2 latency each:
+        // with one read of look-ahead the wave waited for most of them)
+        auto fetch = [&](int j) { return bq_load(rs, bcast(c.v[2], j) + p); };   // low word of qbase + p: exact for lanes inside the read, harmless elsewhere
+        auto one = [&](int j, int bqn) {
             const int b = bqn & 0xFF, q = (bqn >> 8) & 0xFF;
-            if (j + 1 < n) issue(j + 1);
             const int apos = bcast(c.v[0], j), rend = bcast(c.v[1], j);
-            if (rend <= w0) continue;
+            if (rend <= w0) return;
             const bool cover = (valid && p >= apos && p < rend);
             const wmask mm = BAL(cover && b != my_ref);
             if (mm) {
@@ -782,6 +779,13 @@ __global__ void __launch_bounds__(256) k_prep_fast(RegionDev R, UvcParams P) {
                     if (p == rend - 1 && rclip > 0) clip_event(R, P, rend, 1, rclip, pcr_inc);   // any index > 0 gives rpos_delta = -1
                 }
             }
+        };
+        int r0 = fetch(0), r1 = (1 < n ? fetch(1) : 0), r2 = (2 < n ? fetch(2) : 0), r3 = (3 < n ? fetch(3) : 0);
+        for (int j = 0; j < n; j += 4) {
+            { const int v = r0; if (j + 4 < n) r0 = fetch(j + 4); one(j, v); }
+            if (j + 1 < n) { const int v = r1; if (j + 5 < n) r1 = fetch(j + 5); one(j + 1, v); }
+            if (j + 2 < n) { const int v = r2; if (j + 6 < n) r2 = fetch(j + 6); one(j + 2, v); }
+            if (j + 3 < n) { const int v = r3; if (j + 7 < n) r3 = fetch(j + 7); one(j + 3, v); }
         }
     }
     if (nq > 0) drain();
@@ -1024,6 +1028,9 @@ DEV void mis_apply(const RegionDev &R, const UvcParams &P, const MisItem &it) {
     seg_flush(R, A, sym, x);
 }
 
+#ifndef P2_AHEAD
+#define P2_AHEAD 2
+#endif
 #define MISQ_CAP 192   // per-wave LDS queue of mismatching bases (flushed to the global queue when fewer than 64 slots are left)
 // ------------------------------------------------------------------------------------------------
 // P2 fast: updateByAln<SYMBOL_COUNT_SUM, bias> for simple alignments, one lane per position
@@ -1086,16 +1093,12 @@ DEV void p2_fast_body(const RegionDev &R, const UvcParams &P, int *amp1, int *am
         Chunk16 c;
         load_chunk16(R.frec2, k0 + lane, hi, c);
         const int n = imin(64, hi - k0);
-        int bqn = 0;
-        auto issue = [&](int j) {
-            bqn = bq_load(rs, bcast(c.v[2], j) + p);   // low word of qbase + p: exact for lanes inside the read, harmless elsewhere
-        };
-        if (DO_B) issue(0);
-        for (int j = 0; j < n; j++) {
+        // (the base pass requests the base | quality bytes P2_AHEAD reads ahead: one load per read and lane at HBM / L2 latency)
+        auto fetch = [&](int j) { return bq_load(rs, bcast(c.v[2], j) + p); };   // low word of qbase + p: exact for lanes inside the read, harmless elsewhere
+        auto one = [&](int j, int bqn) {
             const int sym = bqn & 0xFF, q = (bqn >> 8) & 0xFF;
-            if (DO_B && j + 1 < n) issue(j + 1);
             const int apos = bcast(c.v[0], j), rend = bcast(c.v[1], j);
-            if (rend <= w0) continue;
+            if (rend <= w0) return;
             const int fmd = bcast(c.v[4], j);
             const int ext = bcast(c.v[15], j);
             SegRead sr;   // [apos, rend) is what this entry covers; the bias arithmetic uses the ends of the whole alignment
@@ -1138,7 +1141,24 @@ DEV void p2_fast_body(const RegionDev &R, const UvcParams &P, int *amp1, int *am
                 const int bm_inc = (sym < 4 ? ((bmv >> (8 * sym)) & 0xFF) : (xbv & 0xFF)), xm_inc = (xbv >> 8) & 0xFF;
                 segbias_simple<ISRC, STRAND, PLAIN>(Alink, Aref, P, sr, T, p, baq_p, baq2_p, hasL, hasB, incL, inc, xm_inc, bm_inc, amp1, amp2);
             }
-        }
+        };
+        if (DO_B) {
+            int r0 = fetch(0), r1 = (1 < n ? fetch(1) : 0);
+#if P2_AHEAD == 4
+            int r2 = (2 < n ? fetch(2) : 0), r3 = (3 < n ? fetch(3) : 0);
+            for (int j = 0; j < n; j += 4) {
+                { const int v = r0; if (j + 4 < n) r0 = fetch(j + 4); one(j, v); }
+                if (j + 1 < n) { const int v = r1; if (j + 5 < n) r1 = fetch(j + 5); one(j + 1, v); }
+                if (j + 2 < n) { const int v = r2; if (j + 6 < n) r2 = fetch(j + 6); one(j + 2, v); }
+                if (j + 3 < n) { const int v = r3; if (j + 7 < n) r3 = fetch(j + 7); one(j + 3, v); }
+            }
+#else
+            for (int j = 0; j < n; j += 2) {
+                { const int v = r0; if (j + 2 < n) r0 = fetch(j + 2); one(j, v); }
+                if (j + 1 < n) { const int v = r1; if (j + 3 < n) r1 = fetch(j + 3); one(j + 1, v); }
+            }
+#endif
+        } else for (int j = 0; j < n; j++) one(j, 0);
         if (DO_B) Aref.fold();
         if (DO_L) Alink.fold();
     }
