@@ -301,7 +301,9 @@ class Leg:
                 if ktimes is not None:
                     self.kernel_times(self.Rs[k % T], ktimes)
             return n_rec
-        ahead = max(1, min(int(os.environ.get("UVC_BENCH_AHEAD", "1")), T - 1))   # tiles prepared beyond the one being scored
+        # tiles prepared (reset + set_reads + accumulate enqueued) beyond the one being scored; two ahead = three tiles in flight measured 9.10-9.13 ms
+        # per step against 9.30-9.43 with one and 9.24-9.32 with three (round 4, one box)
+        ahead = max(1, min(int(os.environ.get("UVC_BENCH_AHEAD", "2")), T - 1))
         for k in range(k0, min(k0 + ahead, k0 + n_steps)):
             self.prepare(k, host)
         for k in range(k0, k0 + n_steps):
@@ -672,8 +674,8 @@ def main():
                                    "family/fragment nesting, radix orders, k_aln_prelude, k_build_p2list) + accumulate P1..P5b + "
                                    "default-gate scoring / calling + D2H of %s%s" % (T, "duplex-UMI" if args.umi else "non-UMI", args.tile_kb, args.depth,
                                    "every scored record" if args.all_records else "the record groups the VCF writer reads (kept_only: written records + the REF / genotype records of their positions)",
-                                   "; tiles strictly one after the other" if args.serial else ("; %d tiles in flight, one host thread each, every tile on its own handle" % n_thr_value if n_thr_value > 1 else "; tiles software-pipelined over their handles (tile k+1 is prepared and accumulating while tile k is scored)")),
-                       "tile_positions": region_len, "distinct_tiles": T, "pipelined": (not args.serial) and T >= 2, "tiles_in_flight": (1 if args.serial else (n_thr_value if n_thr_value > 1 else 2)), "all_out": bool(args.all_out), "umi": bool(args.umi), "reads_per_tile": n_reads_tile,
+                                   "; tiles strictly one after the other" if args.serial else ("; %d tiles in flight, one host thread each, every tile on its own handle" % n_thr_value if n_thr_value > 1 else "; tiles software-pipelined over their handles (tiles k+1 and k+2 are prepared and accumulating while tile k is scored)")),
+                       "tile_positions": region_len, "distinct_tiles": T, "pipelined": (not args.serial) and T >= 2, "tiles_in_flight": (1 if args.serial else (n_thr_value if n_thr_value > 1 else 1 + max(1, min(int(os.environ.get("UVC_BENCH_AHEAD", "2")), T - 1)))), "all_out": bool(args.all_out), "umi": bool(args.umi), "reads_per_tile": n_reads_tile,
                        "read_bases_per_tile": n_reads_tile * READ_LEN, "input_bytes_per_tile": input_bytes_tile, "returned_records_last_tile": n_rec, "kept_only": not args.all_records,
                        "parallelism": "region-shard x%d (no collective on the data path)" % world,
                        "strong_scaling_job": ({"total_tiles": args.total_tiles, "tiles_of_rank0": T, "note": "--total-tiles: one tile list cut into N contiguous shards of equal cost; `steps` / `ms_per_step` are rank 0's; "
