@@ -12,5 +12,5 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in csv.DictReader(open(sys.argv[1])):
     agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]] += float(r["Counter_Value"])
 for k, v in sorted(agg.items()):
-    if "fam" in k or "duplex" in k: print(k, {c: int(x) for c, x in v.items()})
+    if any(t in k for t in ("fam", "duplex", "p2_fast", "frag16", "prep_fast")): print(k, {c: int(x) for c, x in v.items()})
 PY

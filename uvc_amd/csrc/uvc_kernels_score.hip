@@ -222,6 +222,14 @@ enum { AL_LIST(X) NAL };
 // One table of the distinct planes the two lists read (every symbol plane of TOT_LIST is also an allele cell): the gather fetches a plane's
 // cells of a group once and serves the group's total and its records' own cells from them.
 struct GatherDesc { unsigned char grp, trunc; unsigned short plane; short tot, al; };
+// bits of a group's mask word above the eight symbol bits: plane groups that can hold something at this position (k_enum)
+enum { GM_FI = 1u << 8, GM_DUP = 1u << 9, GM_P5F = 1u << 10, GM_P5R = 1u << 11 };
+// the bit a plane waits for (0: always fetched)
+constexpr unsigned gather_need(int grp, int plane) {
+    return (grp == SG_FI32 || grp == SG_FI64) ? (unsigned)GM_FI : grp == SG_DUP ? (unsigned)GM_DUP
+         : (grp == SG_VQ && (plane == UVC_VQ_cIAQf || plane == UVC_VQ_cIADf || plane == UVC_VQ_cIDQf)) ? (unsigned)GM_P5F
+         : (grp == SG_VQ && (plane == UVC_VQ_cIAQr || plane == UVC_VQ_cIADr || plane == UVC_VQ_cIDQr)) ? (unsigned)GM_P5R : 0u;
+}
 #define NGATHER (24 + NAL)   // the 24 per-position planes of TOT_LIST (APDP, APXM, APLRI) + the allele cells
 struct GatherTab { GatherDesc d[NGATHER]; };
 constexpr GatherTab make_gather_tab() {
@@ -243,7 +251,7 @@ constexpr GatherTab make_gather_tab() {
 }
 __constant__ GatherTab c_gather = make_gather_tab();
 // per active group
-enum { GR_x = 0, GR_zpos, GR_st, GR_refsym, GR_mask, GR_hp, GR_r1t, GR_r1u, GR_r1a, GR_r2t, GR_r2u, GR_r2a, GR_insc, GR_delc, GR_ins1c, GR_del1c, GR_rusize, GR_repnum, GR_rec0, GR_nrec, GR_refbdp, GR_vAC, GR_gemit, NGR };
+enum { GR_x = 0, GR_zpos, GR_st, GR_refsym, GR_mask, GR_hp, GR_r1t, GR_r1u, GR_r1a, GR_r2t, GR_r2u, GR_r2a, GR_insc, GR_delc, GR_ins1c, GR_del1c, GR_rusize, GR_repnum, GR_rec0, GR_nrec, GR_refbdp, GR_vAC, GR_gemit, GR_kept, NGR };
 // per record
 enum { RH_gi = 0, RH_symbol, RH_src, RH_idx, RH_bdepth, RH_cdepth, NRH };
 // what k_dpv_pre hands to k_dp4 / k_dpv_post
@@ -600,6 +608,21 @@ __global__ void __launch_bounds__(128) k_enum(RegionDev R, UvcParams P, ScoreCtx
 #pragma unroll
       for (int k = 0; k < 8; k++) rb = (k == kr ? bd[k] : rb);
       GR_(refbdp, gi) = rb; }   // fragment depth of the reference symbol (main.cpp:1099)
+    // Plane groups the gather need not touch at all (bits 8.. of the mask word): the FAMINFO / DUPLEX cells of a symbol are zero throughout a
+    // 4 096-position block nobody marked (RegionDev::dirty -- what the zero fill relies on too), and cIAQ / cIAD / cIDQ of a strand exist only
+    // behind a P5 bucket of that (strand, position) (k_p5b).  uvcgpu_region_check_presence holds the planes against both statements.
+    { const size_t blk = (size_t)(x >> UVC_DIRTY_SHIFT);
+      unsigned fi = 0, du = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+          const int s = st_symbol(st, k < nsym ? k : nsym - 1);
+          const unsigned f1 = R.dirty[((size_t)NSYM + s) * R.ndblk + blk], f2 = R.dirty[((size_t)2 * NSYM + s) * R.ndblk + blk];
+          if ((mask >> k) & 1u) { fi |= f1; du |= f2; }
+      }
+      if (fi) mask |= GM_FI;
+      if (du) mask |= GM_DUP;
+      if (R.p5flag[x]) mask |= GM_P5F;
+      if (R.p5flag[(size_t)R.npos + x]) mask |= GM_P5R; }
     GR_(x, gi) = (int)x; GR_(zpos, gi) = zpos; GR_(st, gi) = st; GR_(refsym, gi) = refsymbol; GR_(mask, gi) = (int)mask; GR_(rec0, gi) = (int)rec0; GR_(nrec, gi) = (int)nrec;
     // homopolymer context for minABQ (main.cpp:623-626, 909-928)
     const int prev1 = ((refidx >= 2) ? (int)R.refsym[refidx - 2] : UVC_BASE_NN), prev2 = ((refidx >= 3) ? (int)R.refsym[refidx - 3] : UVC_BASE_NN);
@@ -667,6 +690,12 @@ __global__ void __launch_bounds__(256) k_gather(RegionDev R, ScoreCtx C, Stage S
         if (u >= NGATHER) break;
         const GatherDesc d = c_gather.d[u];
         if (d.grp <= SG_PREP64) { c[q][0] = stage_cell(R, d.grp, d.plane, 0, x); continue; }
+        const unsigned need = gather_need(d.grp, d.plane);
+        if (need && !(mask & need)) {   // nothing of this plane group at this position: zeros without a load
+#pragma unroll
+            for (int k = 0; k < 8; k++) c[q][k] = 0;
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < 8; k++) c[q][k] = stage_cell(R, d.grp, d.plane, st_symbol(st, ((mask >> k) & 1u) ? k : kf), x);
     }
@@ -1287,7 +1316,7 @@ __global__ void __launch_bounds__(128) k_call_group(UvcParams P, ScoreCtx C, Sta
     const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gi >= n_active || gi >= S.cap) return;
     const long long nrec_ = GR_(nrec, gi);
-    GR_(vAC, gi) = 0; GR_(gemit, gi) = 0;
+    GR_(vAC, gi) = 0; GR_(gemit, gi) = 0; GR_(kept, gi) = 0;
     if (nrec_ == 0) return;
     int32_t *fields = C.fields; const long long capacity = C.capacity;
     const bool tprov = (P.tumor_vcf_is_provided != 0);
@@ -1387,7 +1416,7 @@ __global__ void __launch_bounds__(128) k_call_group(UvcParams P, ScoreCtx C, Sta
         OUT(UVC_O_germ_GT, i_best); OUT(UVC_O_germ_GQ, germ_GQ); OUT(UVC_O_germ_emit, emit);
         OUT(UVC_O_germ_ref, (int)(sel[0] >= 0 ? sel[0] : -1)); OUT(UVC_O_germ_alt1, (int)(sel[1] >= 0 ? sel[1] : -1)); OUT(UVC_O_germ_alt2, (int)(sel[2] >= 0 ? sel[2] : -1));
     }
-    GR_(vAC, gi) = vAC; GR_(gemit, gi) = emit;
+    GR_(vAC, gi) = vAC; GR_(gemit, gi) = emit; GR_(kept, gi) = emit;   // a GERMLINE line keeps the group (k_keep_scan); k_call_rec adds the written records
 }
 
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))) k_call_rec(UvcParams P, ScoreCtx C, Stage S) {
@@ -1493,6 +1522,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 8))
     OUT(UVC_O_out, o_out); OUT(UVC_O_vHGQ, o_vHGQ); OUT(UVC_O_NLODQ, o_NLODQ); OUT(UVC_O_NLODV, o_NLODV); OUT(UVC_O_TLODQ, o_TLODQ); OUT(UVC_O_SomaticQ, o_SQ);
     for (int i = 0; i < 4; i++) { OUT(UVC_O_TNBQF0 + i, bq4[i]); OUT(UVC_O_TNCQF0 + i, cq4[i]); }
     OUT(UVC_O_QUAL, o_QUAL); OUT(UVC_O_FILTER, o_FILTER); OUT(UVC_O_keep, o_keep);
+    if (o_keep && o_out) GR_(kept, gi) = 1;   // (every writer stores the same 1; nobody reads it before k_keep_scan)
 }
 
 
@@ -1518,11 +1548,7 @@ __global__ void __launch_bounds__(GS_BLOCK) k_keep_scan(ScoreCtx C, Stage S, lon
         for (int i = 0; i < GS_ITEMS; i++) {
             const long long ai = a0 + i;
             long long n = 0;
-            if (ai < n_active) {
-                const long long g = C.active[ai];
-                const long long r0 = PK_COUNT(C.offsets[g]), r1 = PK_COUNT(C.offsets[g + 1]);
-                if (r1 <= capacity) for (long long r = r0; r < r1; r++) if ((FLD(UVC_O_keep, r) && FLD(UVC_O_out, r)) || FLD(UVC_O_germ_emit, r)) { n = r1 - r0; break; }
-            }
+            if (ai < n_active && ai < S.cap && GR_(kept, ai)) n = GR_(nrec, ai);   // (a group that did not fit has nrec 0)
             v[i] = n; s += (unsigned long long)n;
         }
         unsigned long long total = 0;
@@ -1544,8 +1570,7 @@ __global__ void __launch_bounds__(256) k_keep_copy(ScoreCtx C, Stage S, long lon
     if (ai >= n_active || ai >= S.cap) return;
     const long long q0 = S.keptoff[ai];
     if (q0 < 0) return;
-    const long long g = C.active[ai];
-    const long long r0 = PK_COUNT(C.offsets[g]), n = PK_COUNT(C.offsets[g + 1]) - r0;
+    const long long r0 = GR_(rec0, ai), n = GR_(nrec, ai);
     const int32_t *fields = C.fields; const long long capacity = C.capacity;
     for (int f = sub; f < UVC_NUM_SCORE_FIELDS; f += KEEP_LANES) {
         const bool is_index = (f == UVC_O_germ_ref || f == UVC_O_germ_alt1 || f == UVC_O_germ_alt2);
@@ -1634,6 +1659,9 @@ __global__ void __launch_bounds__(256) k_check_presence(RegionDev R, unsigned lo
     const int dd = DUP(R, UVC_DUPLEX_dDP1, s, x);
     const bool dense = (s == UVC_LINK_M || (s <= UVC_BASE_NN && s == (int)R.refsym[x]));
     if (!(dense || (b0 | b1 | c10 | c11 | c120 | c121 | dd) != 0 || ((R.occ[x] >> s) & 1u))) atomicAdd(n_bad, 1ull);
+    // cIAQ / cIAD / cIDQ of a strand only behind a P5 bucket of that (strand, position) (GM_P5F / GM_P5R of k_enum)
+    if ((VQP(R, UVC_VQ_cIAQf, s, x) | VQP(R, UVC_VQ_cIADf, s, x) | VQP(R, UVC_VQ_cIDQf, s, x)) != 0 && !R.p5flag[x]) atomicAdd(n_bad, 1ull);
+    if ((VQP(R, UVC_VQ_cIAQr, s, x) | VQP(R, UVC_VQ_cIADr, s, x) | VQP(R, UVC_VQ_cIDQr, s, x)) != 0 && !R.p5flag[(size_t)R.npos + x]) atomicAdd(n_bad, 1ull);
 }
 extern "C" void uvc_launch_check_presence(const RegionDev *R, unsigned long long *d_n_bad, hipStream_t s) {
     hipLaunchKernelGGL(k_check_presence, dim3((unsigned)((R->npos + 255) / 256), NSYM), dim3(256), 0, s, *R, d_n_bad);
