@@ -179,7 +179,7 @@ struct RegionDev {
     uint8_t *dirty; int32_t ndblk;  // [3][NSYM][ndblk]: which (plane family, symbol, block of 4 096 positions) the accumulate wrote outside the part that is zero-filled
                                     // anyway -- family 0: a rare symbol (BASE_NN, every LINK symbol but LINK_M) in the SEG / VQ / BQSUM / FRAG / FAM planes, 1: any symbol in
                                     // FAMINFO32 / 64, 2: any symbol in DUPLEX.  The fill in front of the next accumulate skips what is not marked (uvc_launch_zero_state)
-    uint32_t *occ;                  // [npos] bit s: a rare-symbol P2 update (seg_flush) touched (s, position); zeroed with the planes, read by k_enum
+    uint32_t *occ;                  // [npos] bit s: somebody wrote a cell of (s, position) outside the dense-symbol paths (occ_mark); zeroed with the planes, read by the scoring gate
     uint32_t *fam_digest;           // [n_generic_work][8] or NULL: what P4 leaves per (unit, position) for P5 and the duplex pass (k_fam_win<4> / k_fam_win5d / k_duplex_d)
     Contrib *table;
     int32_t *ir_list;               // per InDel read: the positions of its low-quality InDels (k_p2_slow's cursor, main.hpp:1817-1859), [gap_off + 2 * rank .. ) with sentinels
@@ -234,9 +234,12 @@ DEV int cig_len(uint32_t c) { return (int)(c >> 4); }
 // (see RegionDev::dirty)
 #define UVC_DIRTY_SHIFT 12
 DEV bool sym_always_filled(int s) { return s < UVC_BASE_NN || s == UVC_LINK_M; }   // A C G T N (a reference base) and LINK_M: written at nearly every position
-DEV void mark_sym(const RegionDev &R, int s, int64_t x) { if (!sym_always_filled(s)) R.dirty[(size_t)s * R.ndblk + (x >> UVC_DIRTY_SHIFT)] = 1; }
+// RegionDev::occ: every writer of a cell that does not belong to one of the position's two dense symbols says so here (agent scope: kernels
+// on the side streams mark the same words), so that scoring knows the symbols of a position without reading their planes
+DEV void occ_mark(const RegionDev &R, int s, int64_t x) { if (s != UVC_LINK_M && s != (int)R.refsym[x]) atomicOr(&R.occ[x], 1u << s); }
+DEV void mark_sym(const RegionDev &R, int s, int64_t x) { occ_mark(R, s, x); if (!sym_always_filled(s)) R.dirty[(size_t)s * R.ndblk + (x >> UVC_DIRTY_SHIFT)] = 1; }
 DEV void mark_fi(const RegionDev &R, int s, int64_t x) { R.dirty[((size_t)NSYM + s) * R.ndblk + (x >> UVC_DIRTY_SHIFT)] = 1; }
-DEV void mark_dup(const RegionDev &R, int s, int64_t x) { R.dirty[((size_t)2 * NSYM + s) * R.ndblk + (x >> UVC_DIRTY_SHIFT)] = 1; }
+DEV void mark_dup(const RegionDev &R, int s, int64_t x) { occ_mark(R, s, x); R.dirty[((size_t)2 * NSYM + s) * R.ndblk + (x >> UVC_DIRTY_SHIFT)] = 1; }
 
 DEV void add64(int64_t *p, int64_t v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
 // Adds to a cell that only one workgroup touches during the kernel (a window kernel owns its 64 positions): an L2 atomic of workgroup

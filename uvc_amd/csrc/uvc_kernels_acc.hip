@@ -112,8 +112,7 @@ struct SegAcc {   // SegFormatInfoSet (main_conversion.hpp:645-691) + the VQ a1/
 };
 
 DEV void seg_flush(const RegionDev &R, const SegAcc &A, int sym, int64_t x) {
-    atomicOr(&R.occ[x], 1u << sym);   // the scoring gather sums these planes over the marked symbols only (k_enum)
-    mark_sym(R, sym, x);
+    mark_sym(R, sym, x);   // (with RegionDev::occ: scoring looks at the marked symbols of a position only)
 #pragma unroll
     for (int f = 0; f < UVC_NSEG32; f++) if (A.s[f]) atomicAdd(&S32(R, f, sym, x), A.s[f]);
 #pragma unroll
@@ -2581,8 +2580,8 @@ struct FamAcc {
     // a window kernel (a32 set) owns its positions: its adds to the planes are L2 atomics of workgroup scope (add_own)
     DEV void gadd(int32_t *p, int v) const { if (a32) add_own(p, v); else atomicAdd(p, v); }
     DEV void fap(int strand, int f, int cs, int v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a32[d][strand * UVC_NFAM + f][lane], v); else { mark_sym(*R, cs, x); gadd(&FAP(*R, strand, f, cs, x), v); } }
-    DEV void fi(int f, int cs, int v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a32[d][2 * UVC_NFAM + f][lane], v); else { mark_fi(*R, cs, x); gadd(&FIP(*R, f, cs, x), v); } }
-    DEV void fi64(int f, int cs, long long v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a64[d][f][lane], (unsigned long long)v); else { mark_fi(*R, cs, x); if (a32) add64_own(&FI64P(*R, f, cs, x), v); else add64(&FI64P(*R, f, cs, x), v); } }
+    DEV void fi(int f, int cs, int v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a32[d][2 * UVC_NFAM + f][lane], v); else { occ_mark(*R, cs, x); mark_fi(*R, cs, x); gadd(&FIP(*R, f, cs, x), v); } }
+    DEV void fi64(int f, int cs, long long v) const { const int d = dense(cs); if (d >= 0) atomicAdd(&a64[d][f][lane], (unsigned long long)v); else { occ_mark(*R, cs, x); mark_fi(*R, cs, x); if (a32) add64_own(&FI64P(*R, f, cs, x), v); else add64(&FI64P(*R, f, cs, x), v); } }
     DEV void bucket(int strand, int cs, int b) const { const int d = dense(cs); if (d >= 0) atomicAdd(&bk[d][strand][b][lane], 1); else gadd(&BKP(*R, strand, cs, b, x), 1); R->p5flag[(size_t)strand * R->npos + x] = 1; }
 };
 

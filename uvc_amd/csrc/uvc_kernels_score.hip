@@ -93,6 +93,12 @@ DEV int st_symbol(int st, int k) {
     return link[k];
 }
 DEV int st_count(int st) { return st == UVC_BASE_SYMBOL ? 6 : 8; }
+// index of symbol s in the iteration order of its type (inverse of st_symbol)
+DEV int st_index(int st, int s) {
+    if (st == UVC_BASE_SYMBOL) return s;
+    return s == UVC_LINK_M ? 0 : s == UVC_LINK_I1 ? 1 : s == UVC_LINK_I2 ? 2 : s == UVC_LINK_I3P ? 3 : s == UVC_LINK_D1 ? 4 : s == UVC_LINK_D2 ? 5 : s == UVC_LINK_D3P ? 6 : 7;
+}
+DEV int st_symbol_at(int st, int k) { return st == UVC_BASE_SYMBOL ? k : (k == 0 ? UVC_LINK_M : (k == 7 ? UVC_LINK_NN : UVC_LINK_NN - k)); }   // st_symbol for an index that is not a constant (I1 I2 I3P D1 D2 D3P = 12 .. 7)
 DEV double norm_fa(double FA, double refbias) { return (FA + FA * refbias) / (FA + (1.0 - FA) / (1.0 + refbias) + FA * refbias); }           // main.hpp:4253-4256
 
 struct RtrLite { int tracklen, unitlen, anyTR_tracklen; };
@@ -504,6 +510,30 @@ DEV bool gate_b(const UvcParams &P, int symbol, int refsymbol, int bdepth, int t
     if (refsymbol != symbol) return !(bdepth < P.min_altdp_thres);
     return !(totBDP - bdepth < P.min_altdp_thres);
 }
+// The symbols of a type that can have a non-zero cell at position x, as bits in the type's iteration order (st_symbol): the position's dense
+// symbol of the type (reference base / LINK_M: P2 and the fragment kernel store them without saying so) and what RegionDev::occ names --
+// every other writer of a cell marks its symbol there (occ_mark).  uvcgpu_region_check_presence holds all planes against this statement.
+DEV unsigned type_mask(const RegionDev &R, int st, int64_t x, int refsymbol) {
+    const unsigned occ = R.occ[x];
+    unsigned m;
+    if (st == UVC_BASE_SYMBOL) m = (occ & 0x3Fu) | (1u << (int)R.refsym[x < R.npos - 1 ? x : R.npos - 1]);   // what the dense kernels call the reference base of x
+    else { const unsigned o = (occ >> UVC_LINK_M) & 0xFFu; m = (o & 0x81u) | (__brev(o & 0x7Eu) >> 24) | 1u; }   // M D3P D2 D1 I3P I2 I1 NN -> M I1 I2 I3P D1 D2 D3P NN
+    return m | (1u << st_index(st, refsymbol));
+}
+// fragment depth of the marked symbols (the others have none), by iteration index
+DEV int masked_bdepths(const RegionDev &R, int st, int64_t x, unsigned mask, int bd[8]) {
+    int tot = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) bd[k] = 0;
+    for (unsigned m = mask & 0xFFu; m; m &= m - 1u) {
+        const int k = __builtin_ctz(m), s = st_symbol_at(st, k);
+        const int v = FRP(R, 0, UVC_FRAG_bDP, s, x) + FRP(R, 1, UVC_FRAG_bDP, s, x);
+        tot += v;
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) bd[kk] = (kk == k ? v : bd[kk]);
+    }
+    return tot;
+}
 DEV int gate_count(const RegionDev &R, const UvcParams &P, const ScoreCtx &C, long long g) {
     const int zpos = C.pos_beg + (int)(g >> 1), st = (int)(g & 1);
     if (zpos == C.pos_beg && st == UVC_BASE_SYMBOL && !C.base_at_beg) return 0;   // main.cpp:643
@@ -511,8 +541,10 @@ DEV int gate_count(const RegionDev &R, const UvcParams &P, const ScoreCtx &C, lo
     const int64_t x = refpos - R.beg;
     const int refsymbol = group_refsymbol(R, zpos, st), nsym = st_count(st);
     int bd[8], totBDP = 0;
+    if (C.all_out || P.tumor_vcf_is_provided) {   // the gate does not look at the depths
 #pragma unroll
-    for (int k = 0; k < 8; k++) { const int s = st_symbol(st, k < nsym ? k : nsym - 1); const int v = FRP(R, 0, UVC_FRAG_bDP, s, x) + FRP(R, 1, UVC_FRAG_bDP, s, x); bd[k] = (k < nsym ? v : 0); totBDP += bd[k]; }
+        for (int k = 0; k < 8; k++) bd[k] = 0;
+    } else totBDP = masked_bdepths(R, st, x, type_mask(R, st, x, refsymbol), bd);
     bool pos_rescued = false;
     if (P.tumor_vcf_is_provided && C.n_tkeys) { const long long q = tkey_lower_bound(C, refpos, 0); pos_rescued = (q < C.n_tkeys && C.tkeys[q].refpos == refpos); }
     int n = 0;
@@ -565,17 +597,8 @@ __global__ void __launch_bounds__(GS_BLOCK) k_gate_scan(RegionDev R, UvcParams P
     }
     if (g0 <= ngroups - 1 && ngroups - 1 < g0 + GS_ITEMS) { C.offsets[ngroups] = (long long)(sh_prefix + total); *total_records = PK_COUNT((long long)(sh_prefix + total)); }   // the thread that owns the last group
 }
-// index of symbol s in the iteration order of its type (inverse of st_symbol)
-DEV int st_index(int st, int s) {
-    if (st == UVC_BASE_SYMBOL) return s;
-    return s == UVC_LINK_M ? 0 : s == UVC_LINK_I1 ? 1 : s == UVC_LINK_I2 ? 2 : s == UVC_LINK_I3P ? 3 : s == UVC_LINK_D1 ? 4 : s == UVC_LINK_D2 ? 5 : s == UVC_LINK_D3P ? 6 : 7;
-}
 
-// One thread per active group: the group's scalars, the symbols that have anything at this position, one header per record.
-// Which symbols can have a non-zero cell in the planes the totals sum: the two dense symbols (reference base / LINK_M; P2 and the fragment
-// kernel store them), a symbol a rare-symbol P2 update touched (RegionDev::occ, set in seg_flush), and a symbol with fragment, family or
-// duplex depth -- bTA / bTB are added where bDP is, cDP2 / cDP3 / c2* where cDP12 is (main.hpp:3196-3355).  uvc_check_masks (tests) holds
-// the planes against exactly this statement.
+// One thread per active group: the group's scalars, the symbols that have anything at this position (type_mask), one header per record.
 __global__ void __launch_bounds__(128) k_enum(RegionDev R, UvcParams P, ScoreCtx C, Stage S) {
     const long long ngroups = 2LL * (C.pos_end - C.pos_beg);
     const long long n_active = PK_FLAGS(C.offsets[ngroups]);
@@ -589,21 +612,18 @@ __global__ void __launch_bounds__(128) k_enum(RegionDev R, UvcParams P, ScoreCtx
     const int64_t x = refpos - R.beg;
     const int refidx = zpos - R.beg, refsize = (int)R.npos - 1;
     const int refsymbol = group_refsymbol(R, zpos, st), nsym = st_count(st);
-    int bd[8], cd[8], totBDP = 0; unsigned mask = 0;
-    const unsigned occ = R.occ[x];
+    unsigned mask = type_mask(R, st, x, refsymbol);
+    int bd[8], cd[8];
+    const int totBDP = masked_bdepths(R, st, x, mask, bd);
+    // deduplicated depth of the marked symbols (main.cpp:806-812)
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int s = st_symbol(st, k < nsym ? k : nsym - 1);
-        const int b0 = FRP(R, 0, UVC_FRAG_bDP, s, x), b1 = FRP(R, 1, UVC_FRAG_bDP, s, x);
-        const int c10 = FAP(R, 0, UVC_FAM_cDP1, s, x), c11 = FAP(R, 1, UVC_FAM_cDP1, s, x), c120 = FAP(R, 0, UVC_FAM_cDP12, s, x), c121 = FAP(R, 1, UVC_FAM_cDP12, s, x);
-        const int dd = DUP(R, UVC_DUPLEX_dDP1, s, x);
-        const bool in = (k < nsym);
-        bd[k] = (in ? b0 + b1 : 0); cd[k] = (in ? imax(c10, c120) + imax(c11, c121) : 0); totBDP += bd[k];
-        if (in && ((b0 | b1 | c10 | c11 | c120 | c121 | dd) != 0 || ((occ >> s) & 1u))) mask |= 1u << k;
+    for (int k = 0; k < 8; k++) cd[k] = 0;
+    for (unsigned m = mask & 0xFFu; m; m &= m - 1u) {
+        const int k = __builtin_ctz(m), s = st_symbol_at(st, k);
+        const int v = imax(FAP(R, 0, UVC_FAM_cDP1, s, x), FAP(R, 0, UVC_FAM_cDP12, s, x)) + imax(FAP(R, 1, UVC_FAM_cDP1, s, x), FAP(R, 1, UVC_FAM_cDP12, s, x));
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) cd[kk] = (kk == k ? v : cd[kk]);
     }
-    mask |= 1u << st_index(st, refsymbol);
-    if (st == UVC_BASE_SYMBOL) mask |= 1u << (int)R.refsym[x < R.npos - 1 ? x : R.npos - 1];   // what the dense kernels call the reference base of x
-    else mask |= 1u;
     { const int kr = st_index(st, refsymbol); int rb = 0;
 #pragma unroll
       for (int k = 0; k < 8; k++) rb = (k == kr ? bd[k] : rb);
@@ -1536,7 +1556,6 @@ __global__ void __launch_bounds__(GS_BLOCK) k_keep_scan(ScoreCtx C, Stage S, lon
     __shared__ int sh_tile;
     const long long n_active = PK_FLAGS(C.offsets[ngroups]);
     const int ntiles = (int)((n_active + GS_TILE - 1) / GS_TILE);
-    const int32_t *fields = C.fields; const long long capacity = C.capacity;
     for (;;) {
         if (threadIdx.x == 0) sh_tile = (int)atomicAdd(&S.cnt[CNT_ticket2], 1u);
         __syncthreads();
@@ -1654,11 +1673,8 @@ __global__ void __launch_bounds__(256) k_check_presence(RegionDev R, unsigned lo
     long long any = 0;
     for (int a = 0; a < NAL; a++) { const GatherDesc d = c_gather.d[24 + a]; any |= stage_cell(R, d.grp, d.plane, s, x); }
     if (!any) return;
-    const int b0 = FRP(R, 0, UVC_FRAG_bDP, s, x), b1 = FRP(R, 1, UVC_FRAG_bDP, s, x);
-    const int c10 = FAP(R, 0, UVC_FAM_cDP1, s, x), c11 = FAP(R, 1, UVC_FAM_cDP1, s, x), c120 = FAP(R, 0, UVC_FAM_cDP12, s, x), c121 = FAP(R, 1, UVC_FAM_cDP12, s, x);
-    const int dd = DUP(R, UVC_DUPLEX_dDP1, s, x);
     const bool dense = (s == UVC_LINK_M || (s <= UVC_BASE_NN && s == (int)R.refsym[x]));
-    if (!(dense || (b0 | b1 | c10 | c11 | c120 | c121 | dd) != 0 || ((R.occ[x] >> s) & 1u))) atomicAdd(n_bad, 1ull);
+    if (!(dense || ((R.occ[x] >> s) & 1u))) atomicAdd(n_bad, 1ull);   // type_mask
     // cIAQ / cIAD / cIDQ of a strand only behind a P5 bucket of that (strand, position) (GM_P5F / GM_P5R of k_enum)
     if ((VQP(R, UVC_VQ_cIAQf, s, x) | VQP(R, UVC_VQ_cIADf, s, x) | VQP(R, UVC_VQ_cIDQf, s, x)) != 0 && !R.p5flag[x]) atomicAdd(n_bad, 1ull);
     if ((VQP(R, UVC_VQ_cIAQr, s, x) | VQP(R, UVC_VQ_cIADr, s, x) | VQP(R, UVC_VQ_cIDQr, s, x)) != 0 && !R.p5flag[(size_t)R.npos + x]) atomicAdd(n_bad, 1ull);
