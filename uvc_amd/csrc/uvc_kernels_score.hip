@@ -544,7 +544,12 @@ DEV int gate_count(const RegionDev &R, const UvcParams &P, const ScoreCtx &C, lo
     if (C.all_out || P.tumor_vcf_is_provided) {   // the gate does not look at the depths
 #pragma unroll
         for (int k = 0; k < 8; k++) bd[k] = 0;
-    } else totBDP = masked_bdepths(R, st, x, type_mask(R, st, x, refsymbol), bd);
+    } else {
+        const unsigned mask = type_mask(R, st, x, refsymbol);
+        // nothing but the reference symbol at this position: an ALT needs min_altdp_thres fragments, the REF as many beside it (main.cpp:832-837)
+        if (P.min_altdp_thres > 0 && !(mask & (mask - 1u))) return 0;
+        totBDP = masked_bdepths(R, st, x, mask, bd);
+    }
     bool pos_rescued = false;
     if (P.tumor_vcf_is_provided && C.n_tkeys) { const long long q = tkey_lower_bound(C, refpos, 0); pos_rescued = (q < C.n_tkeys && C.tkeys[q].refpos == refpos); }
     int n = 0;
@@ -560,42 +565,48 @@ DEV int gate_count(const RegionDev &R, const UvcParams &P, const ScoreCtx &C, lo
 #define GS_BLOCK 256
 #define GS_ITEMS 8
 #define GS_TILE (GS_BLOCK * GS_ITEMS)
+// groups per thread of the gate (measured on the 1 Mb tile: 8 -> 58 us, 4 -> 69 us, 2 -> 84 us: more tiles cost more in tickets and look-back
+// than the shorter chains of dependent loads per thread give back)
+#ifndef GATE_ITEMS
+#define GATE_ITEMS 8
+#endif
+#define GATE_TILE (GS_BLOCK * GATE_ITEMS)
 // gate + record slots + active list in one launch.  offsets[g] = packed (number of active groups << 32 | number of records) in front of g.
 __global__ void __launch_bounds__(GS_BLOCK) k_gate_scan(RegionDev R, UvcParams P, ScoreCtx C, Stage S, long long *total_records) {
-    __shared__ long long sh_cnt[GS_TILE + GS_TILE / 8];   // one pad word per 8: thread t reads 8 consecutive words, 9 apart from its neighbour's
+    __shared__ long long sh_cnt[GATE_TILE + GATE_TILE / 8];   // one pad word per 8: thread t reads 8 consecutive words, 9 apart from its neighbour's
     __shared__ unsigned long long sh_wave[4], sh_prefix;
     __shared__ int sh_tile;
     if (threadIdx.x == 0) sh_tile = (int)atomicAdd(&S.cnt[CNT_ticket1], 1u);
     __syncthreads();
     const int tile = sh_tile;
     const long long ngroups = 2LL * (C.pos_end - C.pos_beg);
-    const long long base = (long long)tile * GS_TILE;
+    const long long base = (long long)tile * GATE_TILE;
     // counted striped (consecutive lanes = consecutive groups = consecutive positions of the depth planes), scanned blocked
 #pragma unroll 1
-    for (int i = 0; i < GS_ITEMS; i++) {
+    for (int i = 0; i < GATE_ITEMS; i++) {
         const int j = i * GS_BLOCK + (int)threadIdx.x;
         const long long g = base + j;
         const long long n = (g < ngroups ? (long long)gate_count(R, P, C, g) : 0LL);
         sh_cnt[j + (j >> 3)] = n | (n > 0 ? (1LL << 32) : 0LL);
     }
     __syncthreads();
-    long long v[GS_ITEMS]; unsigned long long s = 0;
-    { const int j0 = (int)threadIdx.x * GS_ITEMS;
+    long long v[GATE_ITEMS]; unsigned long long s = 0;
+    { const int j0 = (int)threadIdx.x * GATE_ITEMS;
 #pragma unroll
-      for (int i = 0; i < GS_ITEMS; i++) { v[i] = sh_cnt[j0 + i + (j0 >> 3)]; s += (unsigned long long)v[i]; } }
+      for (int i = 0; i < GATE_ITEMS; i++) { v[i] = sh_cnt[j0 + i + (j0 >> 3)]; s += (unsigned long long)v[i]; } }
     unsigned long long total = 0;
     const unsigned long long excl = block_excl_scan256(s, sh_wave, total);
     if (threadIdx.x < 64) { const unsigned long long p = cs_lookback(S.status1, tile, total, (int)threadIdx.x, R.err); if (threadIdx.x == 0) sh_prefix = p; }
     __syncthreads();
     long long run = (long long)(sh_prefix + excl);
-    const long long g0 = base + (long long)threadIdx.x * GS_ITEMS;
+    const long long g0 = base + (long long)threadIdx.x * GATE_ITEMS;
 #pragma unroll
-    for (int i = 0; i < GS_ITEMS; i++) {
+    for (int i = 0; i < GATE_ITEMS; i++) {
         const long long g = g0 + i;
         if (g < ngroups) { C.offsets[g] = run; if (PK_FLAGS(v[i])) C.active[PK_FLAGS(run)] = (int)g; }
         run += v[i];
     }
-    if (g0 <= ngroups - 1 && ngroups - 1 < g0 + GS_ITEMS) { C.offsets[ngroups] = (long long)(sh_prefix + total); *total_records = PK_COUNT((long long)(sh_prefix + total)); }   // the thread that owns the last group
+    if (g0 <= ngroups - 1 && ngroups - 1 < g0 + GATE_ITEMS) { C.offsets[ngroups] = (long long)(sh_prefix + total); *total_records = PK_COUNT((long long)(sh_prefix + total)); }   // the thread that owns the last group
 }
 
 // One thread per active group: the group's scalars, the symbols that have anything at this position (type_mask), one header per record.
@@ -1606,7 +1617,7 @@ static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 struct ScratchLayout { size_t zero_bytes, cnt, status1, status2, offsets, active, grp, tot, rh, al, al64, mid, d4, keptoff, total; };
 static ScratchLayout scratch_layout(int64_t npos_scored, int64_t cap) {
     const size_t ngroups = (size_t)(2 * npos_scored), c = (size_t)(cap > 0 ? cap : 1);
-    const size_t ntiles1 = (ngroups + GS_TILE - 1) / GS_TILE + 1, ntiles2 = (std::min(ngroups, c) + GS_TILE - 1) / GS_TILE + 1;
+    const size_t ntiles1 = (ngroups + GATE_TILE - 1) / GATE_TILE + 1, ntiles2 = (std::min(ngroups, c) + GS_TILE - 1) / GS_TILE + 1;
     ScratchLayout L; size_t o = 16;
     L.cnt = o; o += NCNT * 4;
     L.status1 = o; o += ntiles1 * 8;
@@ -1645,7 +1656,7 @@ extern "C" int uvc_launch_score(const RegionDev *R, const UvcParams *P, const Uv
     C.offsets = (long long *)(scratch + L.offsets); C.active = (int *)(scratch + L.active);
     S.grp = (int32_t *)(scratch + L.grp); S.tot = (long long *)(scratch + L.tot); S.rh = (int32_t *)(scratch + L.rh); S.al = (int32_t *)(scratch + L.al); S.al64 = (long long *)(scratch + L.al64);
     S.mid = (double *)(scratch + L.mid); S.d4 = (double *)(scratch + L.d4); S.keptoff = (int32_t *)(scratch + L.keptoff); S.cap = capacity;
-    const unsigned ntiles = (unsigned)((ngroups + GS_TILE - 1) / GS_TILE);
+    const unsigned ntiles = (unsigned)((ngroups + GATE_TILE - 1) / GATE_TILE);
     hipLaunchKernelGGL(k_gate_scan, dim3(ntiles), dim3(GS_BLOCK), 0, s, *R, *P, C, S, d_count);
     // every kernel below works on a list whose length lives on the device: grids cover what the rows can hold, the threads beyond the length leave
     const long long max_groups = (ngroups < capacity ? ngroups : capacity), max_recs = capacity;
