@@ -236,7 +236,8 @@ DEV int cig_len(uint32_t c) { return (int)(c >> 4); }
 DEV bool sym_always_filled(int s) { return s < UVC_BASE_NN || s == UVC_LINK_M; }   // A C G T N (a reference base) and LINK_M: written at nearly every position
 // RegionDev::occ: every writer of a cell that does not belong to one of the position's two dense symbols says so here (agent scope: kernels
 // on the side streams mark the same words), so that scoring knows the symbols of a position without reading their planes
-DEV void occ_mark(const RegionDev &R, int s, int64_t x) { if (s != UVC_LINK_M && s != (int)R.refsym[x]) atomicOr(&R.occ[x], 1u << s); }
+// (a plain look first: the P2 kernels have usually marked the symbol long before the fragment and family kernels come by; a stale look costs an OR)
+DEV void occ_mark(const RegionDev &R, int s, int64_t x) { if (s != UVC_LINK_M && s != (int)R.refsym[x] && !((R.occ[x] >> s) & 1u)) atomicOr(&R.occ[x], 1u << s); }
 DEV void mark_sym(const RegionDev &R, int s, int64_t x) { occ_mark(R, s, x); if (!sym_always_filled(s)) R.dirty[(size_t)s * R.ndblk + (x >> UVC_DIRTY_SHIFT)] = 1; }
 DEV void mark_fi(const RegionDev &R, int s, int64_t x) { R.dirty[((size_t)NSYM + s) * R.ndblk + (x >> UVC_DIRTY_SHIFT)] = 1; }
 DEV void mark_dup(const RegionDev &R, int s, int64_t x) { occ_mark(R, s, x); R.dirty[((size_t)2 * NSYM + s) * R.ndblk + (x >> UVC_DIRTY_SHIFT)] = 1; }
