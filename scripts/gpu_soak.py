@@ -36,7 +36,7 @@ while time.time() - t0 < budget:
     # a few thresholds moved inside their plausible ranges (both libraries get the same values): arms that the defaults never take
     TWEAK = dict(fam_thres_dup1add=(1, 4), fam_thres_dup1perc=(50, 101), fam_thres_dup2add=(2, 5), fam_thres_highBQ_snv=(0, 41), fam_thres_highBQ_indel=(0, 41),
                  bias_thres_highBQ=(0, 41), bias_thres_highBAQ=(0, 40), bias_thres_interfering_indel=(3, 40), bias_thres_interfering_indel_BQ=(0, 41), bias_thres_BAQ1=(10, 60), bias_thres_BAQ2=(20, 80),
-                 syserr_mut_region_n_bases=(1, 60), min_altdp_thres=(1, 5), fam_flag=(0, 4), primerlen=(0, 31), primerlen2=(0, 41), indel_adj_tracklen_dist=(0, 12),
+                 syserr_mut_region_n_bases=(1, 60), min_altdp_thres=(0, 5), fam_flag=(0, 4), primerlen=(0, 31), primerlen2=(0, 41), indel_adj_tracklen_dist=(0, 12),
                  indel_adj_indellen_perc=(100, 301), bq_phred_added_misma=(0, 12), bq_phred_added_indel=(0, 12), microadjust_padded_deletion_flag=(0, 4), central_readlen=(50, 300),
                  bias_thres_PFBQ1=(10, 50), bias_thres_PFBQ2=(10, 60), fam_thres_emperr_all_flat_snv=(1, 6), fam_thres_emperr_con_perc_snv=(50, 101), bias_thres_strict_c2LRP0=(0, 20),
                  bias_thres_aLPxT_add=(0, 12), microadjust_nobias_pos_indel_maxlen=(0, 30), fam_thres_qseqlen=(0, 120), bias_thres_aLRP1t_minus=(0, 20), syserr_minABQ_cap_snv=(0, 300))

@@ -3,7 +3,8 @@
 // Input: the caller's UvcReadSoA columns, already in HBM.  Output: per-read facts (bam_endpos, simple / InDel kind, table / item /
 // InDel-event offsets), FragRec / FsRec records with the reference's span rules (fillTidBegEndFromAlns1 / 2, main.hpp:658-697), the
 // unit lists of the family kernels, the fragment lists of the statistics kernels and the P2 work-list entries.
-// Everything is a per-read map, a prefix sum (rocPRIM) or a per-fragment / per-unit fold; two small read-backs size the allocations.
+// Everything is a per-read map, a prefix sum (own multi-column scans: tile sums in the producer, k_tile_tops, an apply pass) or a per-fragment / per-unit fold;
+// two small read-backs size the allocations.
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
