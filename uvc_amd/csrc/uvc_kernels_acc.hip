@@ -2658,6 +2658,66 @@ DEV void p4_apply(const FamAcc &A, const RegionDev &R, const UvcParams &P, const
     }
 }
 
+// ---- p4_apply for the cells whose consensus symbol is one of the window kernel's two dense symbols (nearly all of them) ----
+// p4_apply spends its time in the control flow around its ~20 conditional increments (exec-mask bookkeeping, the dense / rare select of every
+// FamAcc call): 2.35 of k_fam_p4d's 5.4 ms on a 200 kb x 2000x tile.  Here every condition is a 0 / 1 value and every increment an
+// unconditional LDS add of a value that may be 0, and what depends on (unit, position) only -- the two distances, the BAQ differences, the
+// position-bias flags -- is computed once for the cell's LINK and BASE consensus (P4Cell) instead of once per symbol type.  Same sums.
+struct P4Cell { int good_unit, l_nb, r_nb, lp1, lp2, rp1, rp2, lp0, rp0, seg_l_baq, seg_r_base, seg_r_gap; };
+DEV void p4_cell(P4Cell &W, const RegionDev &R, const UvcParams &P, const FsRec &u, int p, const P4Pos &Q) {
+    W.good_unit = (((u.dflag & 0x1) || (P.fam_flag & 0x2)) ? 1 : 0);
+    int rbeg = imin(u.nsb_min, p), rend = imax(u.nsb_max, p);
+    const bool nonconf_middle = (u.l2r_end_median <= (u.r2l_end_median + P.indel_adj_tracklen_dist));
+    if (nonconf_middle && p < u.r2l_end_median) rend = imax(imin(u.l2r_end_median, imin(u.r2l_end_median, rend)), p);
+    if (nonconf_middle && u.l2r_end_median < p) rbeg = imin(imax(u.l2r_end_median, imax(u.r2l_end_median, rbeg)), p);
+    W.l_nb = (int)nnminus(p + 1, rbeg); W.r_nb = (int)nnminus(rend, p);
+    // update_bidirectional_bias with tier2 = true, n_indel = 0 (bidir above)
+    W.lp1 = (W.l_nb >= Q.LP1t); W.lp2 = (W.l_nb >= Q.LP2t); W.rp1 = (W.r_nb >= Q.RP1t); W.rp2 = (W.r_nb >= Q.RP2t);
+    W.lp0 = ((int)nnminus(p + 1, u.nsb_min) >= P.bias_thres_strict_c2LRP0); W.rp0 = ((int)nnminus(u.nsb_max, p) >= P.bias_thres_strict_c2LRP0);
+    const long long baq_last = R.end - 1;
+    W.seg_l_baq = (int)(Q.baq1 - Q.lb1[(int)lmax((long long)rbeg, nnminus(p, MAX_STR_N_BASES)) - Q.lb_lo] + 1);
+    const int rr = (int)lmin((long long)rend - 1, lmin((long long)p + MAX_STR_N_BASES, baq_last)) - Q.lb_lo;
+    W.seg_r_base = (int)(Q.lb1[rr] - Q.baq1 + 1);
+    W.seg_r_gap = (int)lmin((long long)W.seg_r_base, Q.lb2[rr] - Q.baq2 + 7);
+}
+// d = FamAcc::dense(cs) >= 0; GAP = the LINK symbol type (cs == LINK_M, never an insertion: indel_len = 0)
+template <bool GAP>
+DEV void p4_apply_dense(const FamAcc &A, int d, const UvcParams &P, const FsRec &u, int cc, int ct, const P4Pos &Q, const P4Cell &W) {
+    int *b32 = &A.a32[d][0][A.lane];
+    unsigned long long *b64 = &A.a64[d][0][A.lane];
+#define P4ADD_FAP(f, v) atomicAdd(b32 + (u.strand * UVC_NFAM + (f)) * 64, (v))
+#define P4ADD_FI(f, v) atomicAdd(b32 + (2 * UVC_NFAM + (f)) * 64, (v))
+    P4ADD_FAP(UVC_FAM_cDP12, 1);
+    P4ADD_FAP(UVC_FAM_cDP21, (1 == ct) ? 1 : 0);
+    if (!P.inferred_is_vcf_generated) return;   // (uniform)
+    const int good = ((P.fam_thres_dup1add <= ct) && (cc * 100 >= ct * P.fam_thres_dup1perc) && W.good_unit) ? 1 : 0;
+    P4ADD_FAP(UVC_FAM_cDP2, good);
+    const int bq = 90, dist = 1024 * 1024;
+    if (GAP ? (dist >= P.bias_thres_highBQ) : (bq >= P.bias_thres_highBQ)) {   // (uniform; then tier2 is true for both types)
+        const int LPxT = (GAP ? Q.LPxT : imin(Q.LPxT, Q.RPxT));
+        const int gf = (good && (W.l_nb >= LPxT) && (W.r_nb >= Q.RPxT)) ? 1 : 0;
+        P4ADD_FI(UVC_FI_c2LP1, gf & W.lp1); P4ADD_FI(UVC_FI_c2LP2, gf & W.lp2); P4ADD_FI(UVC_FI_c2RP1, gf & W.rp1); P4ADD_FI(UVC_FI_c2RP2, gf & W.rp2);
+        P4ADD_FI(UVC_FI_c2LPL, gf ? W.l_nb : 0); P4ADD_FI(UVC_FI_c2RPL, gf ? W.r_nb : 0);
+        P4ADD_FI(UVC_FI_c2LP0, good & W.lp0); P4ADD_FI(UVC_FI_c2RP0, good & W.rp0);
+        const int seg_r_baq = (GAP ? W.seg_r_gap : W.seg_r_base);
+        const int thres_highBAQ = P.bias_thres_highBAQ + (GAP ? 0 : 3);
+        const int gb = (good && W.seg_l_baq >= thres_highBAQ && seg_r_baq >= thres_highBAQ) ? 1 : 0;
+        P4ADD_FI(UVC_FI_c2LB1, gb & (W.seg_l_baq >= P.bias_thres_BAQ1 ? 1 : 0)); P4ADD_FI(UVC_FI_c2LB2, gb & (W.seg_l_baq >= P.bias_thres_BAQ2 ? 1 : 0));
+        P4ADD_FI(UVC_FI_c2RB1, gb & (seg_r_baq >= P.bias_thres_BAQ1 ? 1 : 0)); P4ADD_FI(UVC_FI_c2RB2, gb & (seg_r_baq >= P.bias_thres_BAQ2 ? 1 : 0));
+        atomicAdd(b64 + UVC_FI64_c2LBL * 64, (unsigned long long)(long long)(gb ? W.seg_l_baq : 0));
+        atomicAdd(b64 + UVC_FI64_c2RBL * 64, (unsigned long long)(long long)(gb ? seg_r_baq : 0));
+        P4ADD_FI(UVC_FI_c2BQ2, good);
+    }
+    P4ADD_FAP(UVC_FAM_cDP3, ((P.fam_thres_dup2add <= ct) && (cc * 100 >= ct * P.fam_thres_dup2perc)) ? 1 : 0);
+    const int flat = (GAP ? P.fam_thres_emperr_all_flat_indel : P.fam_thres_emperr_all_flat_snv);
+    const int perc = (GAP ? P.fam_thres_emperr_con_perc_indel : P.fam_thres_emperr_con_perc_snv);
+    const bool e = (ct >= flat) && (cc * 100 >= ct * perc);
+    P4ADD_FAP(UVC_FAM_cDPm, e ? ct - cc : 0);
+    P4ADD_FAP(UVC_FAM_cDPM, e ? ct * (GAP ? (UVC_LINK_NN - UVC_LINK_M) : (UVC_BASE_NN - UVC_BASE_A)) : 0);
+#undef P4ADD_FAP
+#undef P4ADD_FI
+}
+
 // DG: P4 leaves a digest per (unit, position) -- the BQ-sum consensus P5 needs and the {1, 1}-threshold vote consensus of the duplex pass --
 // so that the unit's fragments are walked once instead of three times (R.fam_digest, 32 B per cell); P5 then only reads it.
 template <int PASS, bool DG>
@@ -3063,10 +3123,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
         }
         uint4 *dst = (uint4 *)(R.fam_digest + 8 * (u.work_off + (int64_t)(p - u.beg)));
         dst[0] = make_uint4(dga[0], (uint32_t)msum[0], (uint32_t)mtot[0], dga[1]); dst[1] = make_uint4((uint32_t)msum[1], (uint32_t)mtot[1], dg6, 0u);
-        for (int vi = 0; vi < 2; vi++) {
-            if (0 == vct[vi]) continue;
-            p4_apply<true>(A, R, P, u, p, x, (vi == 0 ? UVC_LINK_SYMBOL : UVC_BASE_SYMBOL), vcs[vi], vcc[vi], vct[vi], Q);
-        }
+#ifndef UVC_ABLATE_P4APPLY
+        P4Cell W;
+        p4_cell(W, R, P, u, p, Q);
+        if (vct[0]) { const int d = A.dense(vcs[0]); if (d >= 0) p4_apply_dense<true>(A, d, P, u, vcc[0], vct[0], Q, W); else p4_apply<true>(A, R, P, u, p, x, UVC_LINK_SYMBOL, vcs[0], vcc[0], vct[0], Q); }
+        if (vct[1]) { const int d = A.dense(vcs[1]); if (d >= 0) p4_apply_dense<false>(A, d, P, u, vcc[1], vct[1], Q, W); else p4_apply<true>(A, R, P, u, p, x, UVC_BASE_SYMBOL, vcs[1], vcc[1], vct[1], Q); }
+#endif
       }
     }
     __syncthreads();
