@@ -685,7 +685,7 @@ def main():
                          "algorithmic_bytes_per_launch": abytes, "kernel_ms": avg[dom],
                          "valu_issue": valu_issue(dom, avg[dom], args),
                          "note": "HIP events on the library's stream over the timed steps; with pipelining another tile's preparation kernels may run beside the kernel (see resident.kernel_ms for the undisturbed durations)",
-                         "dominant_by": "the largest average HIP-event duration inside the pipelined stream of THIS run.  k_frag16 and k_p2_fast<base> are within a few per cent of each other (1.46 / 1.47 ms "
+                         "dominant_by": "the largest average HIP-event duration inside the pipelined stream of THIS run.  k_frag16 and k_p2_fast<base> are within a few per cent of each other (1.52 / 1.54 ms "
                                         "undisturbed) and swap places between runs and between this figure and the committed rocprofv3 summary (profiles/): rocprofv3 sums a shorter profiled command in which "
                                         "the two tiles in flight overlap differently.  resident.roofline_by_kernel prices both on their undisturbed durations."},
             "kernel_ms": {k: round(v, 4) for k, v in sorted(avg.items(), key=lambda kv: -kv[1])},
