@@ -421,19 +421,30 @@ def main():
     args.gpus = world
     region_len = args.tile_kb * 1000
 
+    if args.total_tiles > 0 and args.total_tiles < world:
+        sys.exit("--total-tiles %d: fewer tiles than ranks (%d): a rank would have nothing to time" % (args.total_tiles, world))
     if args.dry_run:
         clock = shard.Clock(backend="gloo")
+        strong_job = None
+        if args.total_tiles > 0:   # the strong-scaling cut, as the real run makes it: every tile owned once, every rank owns some
+            cut = shard.plan_contiguous([1000] * args.total_tiles, world)
+            mine = [i for i in range(args.total_tiles) if int(cut[i]) == rank]
+            assert mine == list(range(mine[0], mine[-1] + 1)), "a shard is a contiguous run of the tile list"
+            args.steps = len(mine)
+            strong_job = {"total_tiles": args.total_tiles, "tiles_owned_sum": int(clock.sum_over_ranks(float(len(mine)))), "tiles_of_a_rank_min": int(clock.min_over_ranks(float(len(mine)))),
+                          "tiles_of_a_rank_max": int(clock.max_over_ranks(float(len(mine))))}
         clock.barrier(); t0 = time.perf_counter()
         for _ in range(args.steps):
             time.sleep(0.01 * (1 + rank))
         clock.barrier(); own = time.perf_counter() - t0; dt = clock.max_over_ranks(own)
+        total_positions = (clock.sum_over_ranks(float(region_len) * args.steps) if strong_job else float(world * region_len * args.steps))
+        own_min = clock.min_over_ranks(own)
         if rank == 0:
-            print(json.dumps({"metric": METRIC, "value": world * region_len * args.steps / dt, "unit": "positions/s",
-                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-                              "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic", "config": {"workload": "dry-run"}, "dry_run": True,
-                              "per_rank_ms_per_step": {"min": 1e3 * clock.min_over_ranks(own) / args.steps, "max": 1e3 * dt / args.steps}}))
-        else:
-            clock.min_over_ranks(own)
+            print(json.dumps({"metric": METRIC, "value": total_positions / dt, "unit": "positions/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(1, args.steps), "higher_is_better": True,
+                              "scaling": ("strong" if strong_job else "weak"), "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+                              "config": {"workload": "dry-run", "strong_scaling_job": strong_job}, "dry_run": True,
+                              "per_rank_ms_per_step": {"min": 1e3 * own_min / max(1, args.steps), "max": 1e3 * dt / max(1, args.steps)}}))
         clock.close()
         return
 

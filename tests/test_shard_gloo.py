@@ -52,3 +52,22 @@ def test_bench_starts_its_own_ranks():
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 3
     assert j["ms_per_step"] >= 19.0              # max over ranks: rank 1 sleeps 20 ms per step, rank 0 only 10 ms
     assert abs(j["value"] - 2 * 10000 * 3 / (j["ms_per_step"] * 3 / 1e3)) / j["value"] < 1e-6
+
+
+def test_bench_strong_scaling_cut_over_three_ranks():
+    """`--total-tiles M` (config 3's shape: one job, N shards): three ranks cut seven tiles into contiguous shards that cover the list once,
+    `steps` of a rank = its shard, the line says `scaling: strong` and prices the whole job against the slowest rank; fewer tiles than ranks
+    is refused before anything is timed.  --dry-run: the cut and the clock protocol on the CPU, no kernels."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--total-tiles", "7", "--warmup", "0", "--tile-kb", "10", "--dry-run"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    job = j["config"]["strong_scaling_job"]
+    assert j["n_gpus"] == 3 and j["scaling"] == "strong"
+    assert job["total_tiles"] == 7 and job["tiles_owned_sum"] == 7 and job["tiles_of_a_rank_min"] >= 2 and job["tiles_of_a_rank_max"] <= 3
+    assert abs(j["value"] - 7 * 10000 / (j["ms_per_step"] * j["steps"] / 1e3)) / j["value"] < 1e-6      # whole job / slowest rank (rank 0 prints its own `steps`)
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--total-tiles", "2", "--dry-run"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "fewer tiles than ranks" in (bad.stderr + bad.stdout)
