@@ -103,6 +103,9 @@ def _traffic_table(tile_kb, depth):
     return _TRAFFIC["t"]
 
 
+SCORE_KERNELS = ("k_gate_scan", "k_enum", "k_gather", "k_dpv_pre", "k_dp4", "k_dpv_post", "k_qual", "k_call_group", "k_call_rec", "k_keep_scan", "k_keep_copy")
+
+
 def replayed_traffic(kernel, tile_kb, depth):
     """HBM-side bytes per launch of `kernel`, REPLAYED from the committed PMC passes (profiles/traffic_latest.json, made by
     scripts/gpu_round_profile.sh: FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes) -- not measured in this run.  None when the passes were
@@ -705,6 +708,17 @@ def main():
         }
         if score_ms:
             out["roofline_score"] = score_roofline(score_ms, npos_tile, scored_main, args.all_out)
+            # counter traffic of the scoring launches (replayed like roofline.traffic: only for the workload and the kernel sources the PMC passes saw)
+            parts = {k: replayed_traffic(k, args.tile_kb, args.depth) for k in SCORE_KERNELS}
+            if not args.all_out and all(v is not None for v in parts.values()):
+                tot = float(sum(parts.values()))
+                out["roofline_score"]["traffic"] = tot
+                out["roofline_score"]["traffic_over_algorithmic"] = round(tot / out["roofline_score"]["algorithmic_bytes"], 3)
+                out["roofline_score"]["traffic_by_kernel"] = {k: v for k, v in sorted(parts.items(), key=lambda kv: -kv[1])}
+                out["roofline_score"]["traffic_note"] = ("FETCH_SIZE x 2 + WRITE_SIZE per launch, summed over the scoring kernels; k_gather's share is 128-byte lines fetched for 4-byte cells "
+                                                         "(profiles/r04_fetch_calibration.txt: every fabric read is a 128-byte request)")
+            else:
+                out["roofline_score"]["traffic"] = None
         out.update(side_out)
         if in_flight4:
             out["resident_in_flight4"] = in_flight4
