@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """CPU helper (not a test of the suite): uvcio_plan_regions (SamIter::iternext, grouping.cpp:225-312, with its memory model) against the Python
-restatement of tests/test_io.py over many seeds, thread counts and memory budgets.   python3 scripts/cpu_soak_planner.py SECONDS [FIRST_SEED]"""
+restatement of tests/test_io.py over many seeds, thread counts and memory budgets; one-shot and streamed (uvcio_planner_*, random piece sizes).   python3 scripts/cpu_soak_planner.py SECONDS [FIRST_SEED]"""
 import os
 import sys
 import time
@@ -32,6 +32,10 @@ while time.time() - t0 < budget:
         got = uio.plan_regions(tid, pos, endpos, flag, tlen, nthreads=nthreads, mem_per_thread_mb=mem)
         want = _plan_py(tid, pos, endpos, flag, tlen, nthreads, mem)
         assert got == want, (len(got), len(want), [(a, b) for a, b in zip(got, want) if a != b][:2])
+        # the streaming form (what uvc1-mi355x plans with): the same columns fed in pieces, cuts taken as they become final
+        piece = int(rng.choice([1, 7, 100, 1000, 100000]))
+        got2 = uio.plan_regions_stream(tid, pos, endpos, flag, tlen, nthreads=nthreads, mem_per_thread_mb=mem, piece=piece)
+        assert got2 == want, ("streamed, piece %d" % piece, len(got2), len(want), [(a, b) for a, b in zip(got2, want) if a != b][:2])
         n_ok += 1
     except AssertionError as e:
         fails.append(seed); print("FAIL seed", seed, dict(tlen=tlen, n=len(pos), nthreads=nthreads, mem=mem), repr(e)[:400], flush=True)
