@@ -47,7 +47,8 @@ enum {
     UVCGPU_OK = 0,
     UVCGPU_ENOREADS = -1,      /* region has no reads: process_batch returns -1 (main.cpp:520-523) */
     UVCGPU_EINVAL = -2,        /* malformed argument (bad offsets, read outside region, ...) */
-    UVCGPU_EUNSUPPORTED = -3,  /* CIGAR op the reference itself throws on (process_cigar, main_conversion.hpp:902-916) or a shape beyond the documented limits */
+    UVCGPU_EUNSUPPORTED = -3,  /* CIGAR op the reference itself throws on (process_cigar, main_conversion.hpp:902-916) or a shape beyond the documented limits
+                                  (2^29 positions, 2^31 read bases, 2^27 InDel ops per region; bias_thres_interfering_indel above 10000) */
     UVCGPU_EDEVICE = -4,       /* HIP runtime failure / no gfx950 device */
     UVCGPU_ESTATE = -5,        /* call order violated (e.g. score before accumulate) */
     UVCGPU_ENOMEM = -6

@@ -153,7 +153,21 @@ VARIANTS = {
     "germline_lines": dict(set=dict(outvar_flag=63, should_output_all_germline=1, vqual=5.0)),   # OUTVAR_GERMLINE: GERMLINE lines are written, so REF alleles are kept too
     "germline_default_gate": dict(set=dict(outvar_flag=63)),
     "normv_quals2": dict(set=dict(tn_syserr_norm_devqual=-1.0, min_a_ad=3, vad1=2, vdp1=50)),   # calc_binom_powlaw_syserr_normv_quals2 arm + the AD / DP keep rules
+    "interfering_indel_at_the_limit": dict(set=dict(bias_thres_interfering_indel=10000)),   # the largest threshold the kernels take (dist_to_interfering_indel is 10000 on a simple read, main.hpp:1897): aP3 needs both ends 10000 away, the gap side still enters its bias block
 }
+
+
+@pytest.mark.gpu
+def test_interfering_indel_threshold_beyond_the_distance_code_is_refused(gpu_lib):
+    """Above 10000 the reference compares the threshold with differences of genome coordinates (the sentinels of a read's InDel list); the
+    kernels carry the distance in 16 bits with '10000 or more' as one value: such a threshold is refused when the handle is made, not approximated."""
+    from uvc_amd import region
+    reads = synth.generate_region(seed=5, region_len=600, depth=10)
+    p = region.default_params(gpu_lib)
+    p.bias_thres_interfering_indel = 10001
+    with pytest.raises(region.UvcError) as e:
+        region.Region(gpu_lib, p, reads["tid"], reads["beg"], reads["end"], reads["refseq"])
+    assert e.value.code == -3 and "above 10000" in str(e.value)   # UVCGPU_EUNSUPPORTED
 
 
 @pytest.mark.parametrize("variant", list(VARIANTS))

@@ -290,6 +290,10 @@ static int uvcgpu_region_create_impl(uvcgpu_region_t **out, const UvcParams *par
     if (params->struct_size != (int32_t)sizeof(UvcParams)) return fail(UVCGPU_EINVAL, "UvcParams::struct_size mismatch");
     if (params->indel_str_repeatsize_max < 1 || params->indel_vntr_repeatsize_max < params->indel_str_repeatsize_max) return fail(UVCGPU_EINVAL, "bad repeat-size parameters");
     if (params->indel_vntr_repeatsize_max > 255 || params->indel_BQ_max < 1 || params->indel_BQ_max > 32767) return fail(UVCGPU_EUNSUPPORTED, "indel_vntr_repeatsize_max > 255 or indel_BQ_max outside 1..32767");
+    // dist_to_interfering_indel is 10000 where a read has no low-quality InDel (main.hpp:1897) and a difference of GENOME coordinates next to
+    // the sentinels of its InDel list otherwise: a threshold above 10000 compares with those.  The kernels carry the distance in 16 bits with
+    // "10000 or more" as one value, which is exact for every threshold up to 10000 (the default is 5) and wrong beyond: refused, not approximated.
+    if (params->bias_thres_interfering_indel > 10000) return fail(UVCGPU_EUNSUPPORTED, "bias_thres_interfering_indel above 10000");
     uvcgpu_region *r = new uvcgpu_region();
     memset(&r->prof, 0, sizeof(r->prof));
     memset(&r->R, 0, sizeof(r->R));

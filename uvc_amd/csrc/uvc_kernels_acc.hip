@@ -318,13 +318,14 @@ DEV void segbias_simple(SegAcc &AL, SegAcc &AB, const UvcParams &P, const SegRea
         A.s[UVC_S_aNC] += nc; A.s[UVC_S_aP2] += p2;
         if (has_isize) { if (isrc) A.lp[UVC_S64_aLIT] += fl2; else A.lp[UVC_S64_aRIT] += fr2; }
     };
+    // (in_all: `in` is one wave-uniform mask, all lanes or none -- a mask, not a branch around the block: the loop has no branch per read for it)
     auto bias = [&](SegAcc &A, bool in_all, wmask in, wmask far, wmask unaff, wmask m_rb1, wmask m_rb2, int r_baq) {
-        const wmask a = (in_all ? far : (in & far)), b = (in_all ? unaff : (in & unaff));
+        const wmask a = (in & far), b = (in & unaff);
         addm(A.s[UVC_S_aLP1], a & m_lp1); addm(A.s[UVC_S_aLP2], a & m_lp2); addm(A.s[UVC_S_aRP1], a & m_rp1); addm(A.s[UVC_S_aRP2], a & m_rp2);
         A.s[UVC_S_aLPL] += selm(a, l_nb); A.s[UVC_S_aRPL] += selm(a, r_nb);
         addm(A.s[UVC_S_aLB1], b & m_lb1); addm(A.s[UVC_S_aLB2], b & m_lb2); addm(A.s[UVC_S_aRB1], b & m_rb1); addm(A.s[UVC_S_aRB2], b & m_rb2);
         A.lp[UVC_S64_aLBL] += selm(b, l_baq); A.lp[UVC_S64_aRBL] += selm(b, r_baq);
-        if (in_all) A.s[UVC_S_aBQ2] += 1; else addm(A.s[UVC_S_aBQ2], in);
+        if (in_all) A.s[UVC_S_aBQ2] += (in ? 1 : 0); else addm(A.s[UVC_S_aBQ2], in);
         addm(A.s[UVC_S_aP1], far & unaff & m_iend);
     };
     if (hasB) {
@@ -340,8 +341,7 @@ DEV void segbias_simple(SegAcc &AL, SegAcc &AB, const UvcParams &P, const SegRea
         common(AL, bqL);
         AL.s[UVC_S_aPF1] += imin(100, amp1[imin(bqL, 255)]); AL.s[UVC_S_aPF2] += imin(100, amp2[imin(bqL, 255)]);
         // the gap side enters when dist_to_interfering_indel (10000) >= bias_thres_interfering_indel
-        if (10000 >= P.bias_thres_interfering_indel) bias(AL, true, 0, m_farL, m_unaffL, BAL(r_baqL >= P.bias_thres_BAQ1), BAL(r_baqL >= P.bias_thres_BAQ2), r_baqL);
-        else addm(AL.s[UVC_S_aP1], m_farL & m_unaffL & m_iend);
+        bias(AL, true, umask(10000 >= P.bias_thres_interfering_indel), m_farL, m_unaffL, BAL(r_baqL >= P.bias_thres_BAQ1), BAL(r_baqL >= P.bias_thres_BAQ2), r_baqL);   // (aP1 inside does not look at `in`)
         if (isrc) { addm(AL.s[UVC_S_aLI1], m_i1lo & m_okL); addm(AL.s[UVC_S_aLI2], m_i2lo & m_okL & m_goodL); addm(AL.s[UVC_S_aLIr], m_goodL); }
         else      { addm(AL.s[UVC_S_aRI1], m_i1lo & m_okL); addm(AL.s[UVC_S_aRI2], m_i2lo & m_okL & m_goodL); addm(AL.s[UVC_S_aRIf], m_goodL); }
     }
@@ -1119,7 +1119,8 @@ DEV void p2_fast_body(const RegionDev &R, const UvcParams &P, int *amp1, int *am
                 gate = (ibeg <= p && p < iend);
             }
             // the queue bookkeeping below must run in wave-uniform control flow (nq is a scalar): no divergent `continue` before it
-            const bool cover = (valid && p >= apos && p < rend && gate);
+            // (one mask, not a chain of short-circuit tests: every `&&` of per-lane conditions is an exec-mask level of its own -- save, branch, restore)
+            const bool cover = (valid & (p >= apos) & (p < rend) & gate);
             const bool hasL = DO_L && (p > apos), hasB = DO_B && (sym == my_ref);
             int inc = 0, incL = 0;
             if (proton) {   // IonTorrent values need neighbouring qualities and clip lengths: take them from the full record
@@ -1135,10 +1136,11 @@ DEV void p2_fast_body(const RegionDev &R, const UvcParams &P, int *amp1, int *am
                 if (cover && !hasB) { MisItem it; it.rank = bcast(c.v[3], j); it.epos = p; it.symval = sym | (inc << 8); myq[nq + (int)__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = it; }
                 nq += (int)__builtin_popcountll(mm);
             }
-            if (cover) {
+            // a pass that only has the LINK side acts on a lane iff hasL; the base pass on every covered lane (hasB inside)
+            if (DO_B ? cover : (cover & hasL)) {
                 const int bmv = bcast(c.v[8], j), xbv = bcast(c.v[9], j);
                 const int bm_inc = (sym < 4 ? ((bmv >> (8 * sym)) & 0xFF) : (xbv & 0xFF)), xm_inc = (xbv >> 8) & 0xFF;
-                segbias_simple<ISRC, STRAND, PLAIN>(Alink, Aref, P, sr, T, p, baq_p, baq2_p, hasL, hasB, incL, inc, xm_inc, bm_inc, amp1, amp2);
+                segbias_simple<ISRC, STRAND, PLAIN>(Alink, Aref, P, sr, T, p, baq_p, baq2_p, DO_B ? hasL : true, hasB, incL, inc, xm_inc, bm_inc, amp1, amp2);
             }
         };
         if (DO_B) {
