@@ -72,13 +72,19 @@ PROFILE_NAMES = {"k_p2_fast_link": ("k_p2_fast<true, false, true>", "k_p2_fast<t
 
 
 def kernel_source_hash():
-    """sha256 over the device sources the PMC passes were taken on (uvc_amd/csrc/*.hip and the headers they include): the replayed counters
-    are only quoted while the kernels are the ones that were counted."""
+    """sha256 over the device sources the PMC passes were taken on (uvc_amd/csrc/*.hip and the headers they include, comments and white space
+    removed): the replayed counters are only quoted while the kernels are the ones that were counted."""
     import glob
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "uvc_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "uvc_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
-        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+        text = open(f, "r", errors="replace").read()
+        # comments and white space do not make another kernel: a reworded comment must not declare the counters stale
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        text = re.sub(r"\s+", " ", text)
+        h.update(os.path.basename(f).encode()); h.update(text.encode())
     return h.hexdigest()[:16]
 
 

@@ -439,10 +439,13 @@ int uvcgpu_host_free(void *p);
 int uvcgpu_region_sync(uvcgpu_region_t *r);
 /* Record counts of the last uvcgpu_region_score on this handle: scored in all, and returned (fewer with UvcScoreRequest::kept_only). */
 int uvcgpu_region_last_score_counts(const uvcgpu_region_t *r, int64_t *scored, int64_t *returned);
-/* Self-check of the statement the scoring gather relies on (uvc_kernels_score.hip, k_enum): a cell of a symbol's planes at a position can
- * be non-zero only if the symbol is the position's reference base / LINK_M, was touched by a rare-symbol P2 update, or has fragment,
- * family or duplex depth there.  Sweeps every plane of the last accumulate; *n_violations = cells that contradict it (0 expected).
- * The test suite runs it behind every accumulate (UVCGPU_CHECK_PRESENCE=1 in uvc_amd/region.py). */
+/* Self-check (a TEST entry point) of the three statements about ALL planes that scoring and the zero fill of a reused handle rely on:
+ * (1) a cell of a symbol's planes at a position can be non-zero only if the symbol is the position's reference base / LINK_M or is marked
+ * in the position's occupancy word (every writer of any other cell marks it: uvc_device.h occ_mark; uvc_kernels_score.hip type_mask);
+ * (2) a (plane family, symbol, 4 096-position block) nobody marked holds only zeros (the fill skips it, the gather skips its FAMINFO /
+ * DUPLEX planes); (3) cIAQ / cIAD / cIDQ of a strand are non-zero only behind a P5 bucket of that (strand, position).
+ * Sweeps every plane of the last accumulate; *n_violations = cells that contradict one of them (0 expected).
+ * The test suite and the soak scripts run it behind every accumulate (UVCGPU_CHECK_PRESENCE=1 in uvc_amd/region.py). */
 int uvcgpu_region_check_presence(uvcgpu_region_t *r, int64_t *n_violations);
 /* Measurement hooks (bench.py): HIP-event timing of every kernel of the LAST accumulate, recorded on the handle's stream.
  * kernel_times returns the number of kernels; `names` receives their names separated by ';'. */
