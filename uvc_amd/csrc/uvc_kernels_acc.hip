@@ -2013,15 +2013,16 @@ DEV void frag_body(const RegionDev &R, const UvcParams &P, unsigned (*hist)[NBUC
                 if (!full) { ar.bDP -= 1; ar.bTA -= K(13); ar.bTB -= K(14); bMQ_r -= K(12); }
             }
         }
-        bool e12 = false, e1 = false;
-        if (singleton) {
-            const int adj = imax(cc4 * 2, ct4) - ct4;
-            if (adj >= P.fam_thres_highBQ_snv && adj > 0) {   // cDP12 == cDP21 for a singleton unit
-                if (cs4 == my_ref) ar.c12 += 1; else e12 = true;
-            }
-            const int adj5 = imax(cc * 2, ct) - ct;
-            if (adj5 > 0 && vcfgen) { if (is_ref) ar.c1 += 1; else e1 = true; }
-        }
+        // (conditions as values, increments as adds of 0 / 1: a nest of per-lane ifs is an exec-mask level each -- save, branch, restore -- per record)
+        const int adj = imax(cc4 * 2, ct4) - ct4;
+        const bool v12 = singleton & (adj >= P.fam_thres_highBQ_snv) & (adj > 0);   // cDP12 == cDP21 for a singleton unit
+        const bool r4 = (cs4 == my_ref);
+        ar.c12 += ((v12 & r4) ? 1 : 0);
+        const bool e12 = v12 & !r4;
+        const int adj5 = imax(cc * 2, ct) - ct;
+        const bool v1 = singleton & (adj5 > 0) & vcfgen;
+        ar.c1 += ((v1 & is_ref) ? 1 : 0);
+        const bool e1 = v1 & !is_ref;
         const bool e3 = (vcfgen && !is_ref);
         if (!(e3 || e12 || e1)) return 0ull;
         return (1ull << 63) | ((unsigned long long)(unsigned)k << 24) | ((unsigned long long)e3 << 23) | ((unsigned long long)e12 << 22) | ((unsigned long long)e1 << 21)
