@@ -8,6 +8,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+unset UVCGPU_CHECK_PRESENCE   # (a test switch: the validator sweeps every plane behind each accumulate)
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 8 --warmup 2 --tiles 4 --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || exit 11
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats.csv
 for ctr in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do

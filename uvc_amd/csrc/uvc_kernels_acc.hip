@@ -1136,11 +1136,12 @@ DEV void p2_fast_body(const RegionDev &R, const UvcParams &P, int *amp1, int *am
                 if (cover && !hasB) { MisItem it; it.rank = bcast(c.v[3], j); it.epos = p; it.symval = sym | (inc << 8); myq[nq + (int)__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = it; }
                 nq += (int)__builtin_popcountll(mm);
             }
-            // a pass that only has the LINK side acts on a lane iff hasL; the base pass on every covered lane (hasB inside)
-            if (DO_B ? cover : (cover & hasL)) {
+            // a pass with one side acts on a lane iff that side has something there (one exec-mask level instead of cover, then hasL / hasB inside)
+            constexpr bool ONE_SIDE = (DO_B != DO_L);
+            if (!ONE_SIDE ? cover : (DO_B ? (cover & hasB) : (cover & hasL))) {
                 const int bmv = bcast(c.v[8], j), xbv = bcast(c.v[9], j);
                 const int bm_inc = (sym < 4 ? ((bmv >> (8 * sym)) & 0xFF) : (xbv & 0xFF)), xm_inc = (xbv >> 8) & 0xFF;
-                segbias_simple<ISRC, STRAND, PLAIN>(Alink, Aref, P, sr, T, p, baq_p, baq2_p, DO_B ? hasL : true, hasB, incL, inc, xm_inc, bm_inc, amp1, amp2);
+                segbias_simple<ISRC, STRAND, PLAIN>(Alink, Aref, P, sr, T, p, baq_p, baq2_p, ONE_SIDE ? DO_L : hasL, ONE_SIDE ? DO_B : hasB, incL, inc, xm_inc, bm_inc, amp1, amp2);
             }
         };
         if (DO_B) {
