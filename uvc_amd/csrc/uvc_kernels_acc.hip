@@ -1090,26 +1090,26 @@ DEV void p2_fast_body(const RegionDev &R, const UvcParams &P, int *amp1, int *am
     const int lo = wave_uniform(win_lo(R, 1 + cls, (int)(x0 >> 6))), hi = wave_uniform(win_hi(R, 1 + cls, (int)(x0 >> 6)));
     for (int k0 = lo + (SPLIT ? 64 * (int)(threadIdx.x >> 6) : 0); k0 < hi; k0 += (SPLIT ? 256 : 64)) {
         Chunk16 c;
-        load_chunk16(R.frec2, k0 + lane, hi, c);
+        if (DO_B) load_chunk16(R.frec2, k0 + lane, hi, c);   // (the LINK-only pass reads its records through the scalar cache, below)
         const int n = imin(64, hi - k0);
         // (the base pass requests the base | quality bytes P2_AHEAD reads ahead: one load per read and lane at HBM / L2 latency)
         auto fetch = [&](int j) { return bq_load(rs, bcast(c.v[2], j) + p); };   // low word of qbase + p: exact for lanes inside the read, harmless elsewhere
-        auto one = [&](int j, int bqn) {
+        auto one = [&](auto K, int bqn) {   // K(i): dword i of the work-list record
             const int sym = bqn & 0xFF, q = (bqn >> 8) & 0xFF;
-            const int apos = bcast(c.v[0], j), rend = bcast(c.v[1], j);
+            const int apos = K(0), rend = K(1);
             if (rend <= w0) return;
-            const int fmd = bcast(c.v[4], j);
-            const int ext = bcast(c.v[15], j);
+            const int fmd = K(4);
+            const int ext = K(15);
             SegRead sr;   // [apos, rend) is what this entry covers; the bias arithmetic uses the ends of the whole alignment
             sr.pos = apos - (ext & 0xFFFF); sr.rend = rend + (int)((unsigned)ext >> 16); sr.flag = fmd & 0xFFFF; sr.mapq = (fmd >> 16) & 0xFF; sr.dflag = (fmd >> 24) & 0xFF;
-            sr.isize = bcast(c.v[5], j);
-            const int mpos = bcast(c.v[6], j);
+            sr.isize = K(5);
+            const int mpos = K(6);
             sr.frag_pos_L = imin(sr.pos, mpos); sr.frag_pos_R = sr.frag_pos_L + abs(sr.isize);
-            sr.xm1500 = bcast(c.v[7], j);
-            const int bm4c = bcast(c.v[10], j);
+            sr.xm1500 = K(7);
+            const int bm4c = K(10);
             sr.clip_cnt = (bm4c >> 16) & 0xF;
             const int nogap = (int)(short)(bm4c & 0xFFFF);
-            sr.baq_pos = bcast(c.v[12], j); sr.baq_last = bcast(c.v[13], j); sr.baq2_last = bcast(c.v[14], j);
+            sr.baq_pos = K(12); sr.baq_last = K(13); sr.baq2_last = K(14);
             const bool is_assay_amplicon = (PLAIN ? false : ((sr.dflag & 0x4) || ((P.primerlen > 0) && !(0x2 & P.primer_flag))));
             bool gate = true;
             if (is_assay_amplicon && !normal_filter_primers) {   // primer gating, main.hpp:1872-1875, 1895
@@ -1125,7 +1125,7 @@ DEV void p2_fast_body(const RegionDev &R, const UvcParams &P, int *amp1, int *am
             int inc = 0, incL = 0;
             if (proton) {   // IonTorrent values need neighbouring qualities and clip lengths: take them from the full record
                 if (cover) {
-                    const AlnRec &a = R.alns[bcast(c.v[3], j)];
+                    const AlnRec &a = R.alns[K(3)];
                     if (DO_B) inc = simple_base_value(P, a, p, R.quals + a.qbase, true);
                     if (DO_L) incL = (p > apos ? simple_link_value(R, P, a, p, R.quals + a.qbase, true) : 0);
                 }
@@ -1133,13 +1133,13 @@ DEV void p2_fast_body(const RegionDev &R, const UvcParams &P, int *amp1, int *am
             const wmask mm = DO_B ? BAL(cover && !hasB) : 0ull;
             if (DO_B && mm) {   // bases that differ from the reference go to the wave's queue; k_p2_mism applies them
                 if (nq > MISQ_CAP - 64) flush_queue();
-                if (cover && !hasB) { MisItem it; it.rank = bcast(c.v[3], j); it.epos = p; it.symval = sym | (inc << 8); myq[nq + (int)__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = it; }
+                if (cover && !hasB) { MisItem it; it.rank = K(3); it.epos = p; it.symval = sym | (inc << 8); myq[nq + (int)__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = it; }
                 nq += (int)__builtin_popcountll(mm);
             }
             // a pass with one side acts on a lane iff that side has something there (one exec-mask level instead of cover, then hasL / hasB inside)
             constexpr bool ONE_SIDE = (DO_B != DO_L);
             if (!ONE_SIDE ? cover : (DO_B ? (cover & hasB) : (cover & hasL))) {
-                const int bmv = bcast(c.v[8], j), xbv = bcast(c.v[9], j);
+                const int bmv = K(8), xbv = K(9);
                 const int bm_inc = (sym < 4 ? ((bmv >> (8 * sym)) & 0xFF) : (xbv & 0xFF)), xm_inc = (xbv >> 8) & 0xFF;
                 segbias_simple<ISRC, STRAND, PLAIN>(Alink, Aref, P, sr, T, p, baq_p, baq2_p, ONE_SIDE ? DO_L : hasL, ONE_SIDE ? DO_B : hasB, incL, inc, xm_inc, bm_inc, amp1, amp2);
             }
@@ -1149,18 +1149,52 @@ DEV void p2_fast_body(const RegionDev &R, const UvcParams &P, int *amp1, int *am
 #if P2_AHEAD == 4
             int r2 = (2 < n ? fetch(2) : 0), r3 = (3 < n ? fetch(3) : 0);
             for (int j = 0; j < n; j += 4) {
-                { const int v = r0; if (j + 4 < n) r0 = fetch(j + 4); one(j, v); }
-                if (j + 1 < n) { const int v = r1; if (j + 5 < n) r1 = fetch(j + 5); one(j + 1, v); }
-                if (j + 2 < n) { const int v = r2; if (j + 6 < n) r2 = fetch(j + 6); one(j + 2, v); }
-                if (j + 3 < n) { const int v = r3; if (j + 7 < n) r3 = fetch(j + 7); one(j + 3, v); }
+                { const int v = r0; if (j + 4 < n) r0 = fetch(j + 4); one([&](int i) { return bcast(c.v[i], j); }, v); }
+                if (j + 1 < n) { const int v = r1; if (j + 5 < n) r1 = fetch(j + 5); one([&](int i) { return bcast(c.v[i], j + 1); }, v); }
+                if (j + 2 < n) { const int v = r2; if (j + 6 < n) r2 = fetch(j + 6); one([&](int i) { return bcast(c.v[i], j + 2); }, v); }
+                if (j + 3 < n) { const int v = r3; if (j + 7 < n) r3 = fetch(j + 7); one([&](int i) { return bcast(c.v[i], j + 3); }, v); }
             }
 #else
+#ifdef UVC_P2_BASE_VECREC
             for (int j = 0; j < n; j += 2) {
-                { const int v = r0; if (j + 2 < n) r0 = fetch(j + 2); one(j, v); }
-                if (j + 1 < n) { const int v = r1; if (j + 3 < n) r1 = fetch(j + 3); one(j + 1, v); }
+                { const int v = r0; if (j + 2 < n) r0 = fetch(j + 2); one([&](int i) { return bcast(c.v[i], j); }, v); }
+                if (j + 1 < n) { const int v = r1; if (j + 3 < n) r1 = fetch(j + 3); one([&](int i) { return bcast(c.v[i], j + 1); }, v); }
+            }
+#else
+            // the record's fields through the scalar cache as in the LINK pass; the per-lane copy of the chunk stays for the one field the byte
+            // requests need two reads ahead (fetch)
+            typedef int v4i_ __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(4))) const v4i_ *crec4;
+            v4i_ a0, a1, a2, a3;
+            const int kb = wave_uniform(k0), nb = wave_uniform(n);
+            { crec4 q = (crec4)(R.frec2 + kb); a0 = q[0]; a1 = q[1]; a2 = q[2]; a3 = q[3]; }
+            for (int j = 0; j < nb; j += 2) {
+                { const int v = r0; if (j + 2 < nb) r0 = fetch(j + 2);
+                  const v4i_ c0 = a0, c1 = a1, c2 = a2, c3 = a3;
+                  if (j + 1 < nb) { crec4 q = (crec4)(R.frec2 + (kb + j + 1)); a0 = q[0]; a1 = q[1]; a2 = q[2]; a3 = q[3]; }
+                  one([&](int i) { const v4i_ w = (i < 4 ? c0 : i < 8 ? c1 : i < 12 ? c2 : c3); return (int)w[i & 3]; }, v); }
+                if (j + 1 < nb) { const int v = r1; if (j + 3 < nb) r1 = fetch(j + 3);
+                  const v4i_ c0 = a0, c1 = a1, c2 = a2, c3 = a3;
+                  if (j + 2 < nb) { crec4 q = (crec4)(R.frec2 + (kb + j + 2)); a0 = q[0]; a1 = q[1]; a2 = q[2]; a3 = q[3]; }
+                  one([&](int i) { const v4i_ w = (i < 4 ? c0 : i < 8 ? c1 : i < 12 ? c2 : c3); return (int)w[i & 3]; }, v); }
             }
 #endif
-        } else for (int j = 0; j < n; j++) one(j, 0);
+#endif
+        } else {
+            // The LINK pass reads no read bytes: its only per-read data is the 64-byte work-list record.  Straight into scalar registers (s_load through
+            // the constant address space, the next record requested while this one is worked on) instead of a per-lane vector load of 64 records and
+            // eleven v_readlane per read.
+            typedef int v4i_ __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(4))) const v4i_ *crec4;
+            v4i_ a0, a1, a2, a3;
+            const int kb = wave_uniform(k0), nb = wave_uniform(n);   // (the split form's k0 depends on the wave's number in the block: uniform, but not to the compiler)
+            { crec4 q = (crec4)(R.frec2 + kb); a0 = q[0]; a1 = q[1]; a2 = q[2]; a3 = q[3]; }
+            for (int j = 0; j < nb; j++) {
+                const v4i_ c0 = a0, c1 = a1, c2 = a2, c3 = a3;   // (sixteen s_mov; two register sets and a loop unrolled by two measured slower: 1.27 against 1.24 ms)
+                if (j + 1 < nb) { crec4 q = (crec4)(R.frec2 + (kb + j + 1)); a0 = q[0]; a1 = q[1]; a2 = q[2]; a3 = q[3]; }
+                one([&](int i) { const v4i_ w = (i < 4 ? c0 : i < 8 ? c1 : i < 12 ? c2 : c3); return (int)w[i & 3]; }, 0);
+            }
+        }
         if (DO_B) Aref.fold();
         if (DO_L) Alink.fold();
     }
